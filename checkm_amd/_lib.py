@@ -1,0 +1,289 @@
+"""ctypes binding of libcheckm_hip.so (include/checkm_hip.h).
+
+The library is the only compute path: if it is missing or no gfx950 device is usable this
+module raises -- there is no CPU fallback anywhere in checkm_amd.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcheckm_hip.so")
+
+ABI_VERSION = 1
+
+
+class CkmError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "libcheckm_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class ModelHeader(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("acc", C.c_char_p), ("desc", C.c_char_p), ("leng", C.c_int32),
+                ("has_ga", C.c_int32), ("has_tc", C.c_int32), ("has_nc", C.c_int32),
+                ("ga", C.c_float * 2), ("tc", C.c_float * 2), ("nc", C.c_float * 2), ("evparam", C.c_float * 6)]
+
+
+class HitColumns(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("nbins", C.c_uint32), ("bin_row_off", C.POINTER(C.c_uint64)),
+                ("seq", C.POINTER(C.c_uint32)), ("model", C.POINTER(C.c_uint32)),
+                ("tlen", C.POINTER(C.c_int32)), ("qlen", C.POINTER(C.c_int32)),
+                ("full_evalue", C.POINTER(C.c_double)), ("full_score", C.POINTER(C.c_float)), ("full_bias", C.POINTER(C.c_float)),
+                ("dom_idx", C.POINTER(C.c_int32)), ("ndom", C.POINTER(C.c_int32)),
+                ("c_evalue", C.POINTER(C.c_double)), ("i_evalue", C.POINTER(C.c_double)),
+                ("dom_score", C.POINTER(C.c_float)), ("dom_bias", C.POINTER(C.c_float)),
+                ("hmm_from", C.POINTER(C.c_int32)), ("hmm_to", C.POINTER(C.c_int32)),
+                ("ali_from", C.POINTER(C.c_int32)), ("ali_to", C.POINTER(C.c_int32)),
+                ("env_from", C.POINTER(C.c_int32)), ("env_to", C.POINTER(C.c_int32)), ("acc", C.POINTER(C.c_float))]
+
+
+HIT_FIELDS = ["seq", "model", "tlen", "qlen", "full_evalue", "full_score", "full_bias", "dom_idx", "ndom", "c_evalue",
+              "i_evalue", "dom_score", "dom_bias", "hmm_from", "hmm_to", "ali_from", "ali_to", "env_from", "env_to", "acc"]
+
+
+class SearchStats(C.Structure):
+    _fields_ = [("pairs_ssv", C.c_uint64), ("pairs_msv_full", C.c_uint64), ("pairs_bias", C.c_uint64), ("pairs_vit", C.c_uint64),
+                ("pairs_fwd", C.c_uint64), ("pairs_dom", C.c_uint64), ("envelopes", C.c_uint64), ("cells_ssv", C.c_uint64),
+                ("residue_hmm", C.c_uint64), ("ms_ssv", C.c_double), ("ms_filters", C.c_double), ("ms_fwdbwd", C.c_double),
+                ("ms_domains", C.c_double), ("ms_host", C.c_double), ("ms_total", C.c_double), ("ssv_launches", C.c_uint32)]
+
+
+class StageScores(C.Structure):
+    _fields_ = [("msv_xJ", C.c_int32), ("msv_sc", C.c_float), ("null_sc", C.c_float), ("bias_sc", C.c_float),
+                ("vit_xC", C.c_int32), ("vit_sc", C.c_float), ("fwd_sc", C.c_float), ("fwd_xC", C.c_float),
+                ("fwd_nscale", C.c_int32), ("ssv_maxv", C.c_int32)]
+
+
+class EnvelopeResult(C.Structure):
+    _fields_ = [("envsc", C.c_float), ("oasc", C.c_float), ("fwd_xC", C.c_float), ("nscale", C.c_int32), ("null2", C.c_float * 20),
+                ("hmm_from", C.c_int32), ("hmm_to", C.c_int32), ("ali_from", C.c_int32), ("ali_to", C.c_int32), ("ok", C.c_int32)]
+
+
+class ModelInfo(C.Structure):
+    _fields_ = [("nmodels", C.c_uint32), ("qlen", C.c_void_p), ("thr_kind", C.c_void_p), ("thr_full", C.c_void_p),
+                ("thr_dom", C.c_void_p), ("is_pf", C.c_void_p), ("clan", C.c_void_p), ("nest_off", C.c_void_p),
+                ("nest_idx", C.c_void_p), ("key", C.c_void_p)]
+
+
+class ReduceFlags(C.Structure):
+    _fields_ = [("ignore_thresholds", C.c_int32), ("skip_pseudogene_correction", C.c_int32), ("skip_adj_correction", C.c_int32),
+                ("individual_markers", C.c_int32), ("evalue_threshold", C.c_double), ("length_threshold", C.c_double)]
+
+
+class MarkerSetsCSR(C.Structure):
+    _fields_ = [("nbins", C.c_uint32), ("set_off", C.c_void_p), ("marker_off", C.c_void_p), ("marker_key", C.c_void_p)]
+
+
+class QAColumns(C.Structure):
+    _fields_ = [("nbins", C.c_uint32), ("hist", C.POINTER(C.c_int32)), ("completeness", C.POINTER(C.c_double)),
+                ("contamination", C.POINTER(C.c_double)), ("set_off", C.POINTER(C.c_uint32)),
+                ("set_present", C.POINTER(C.c_int32)), ("set_multi", C.POINTER(C.c_int32)),
+                ("nkept", C.c_uint64), ("kept_bin_off", C.POINTER(C.c_uint64)), ("kept_key", C.POINTER(C.c_uint32)),
+                ("kept_row", C.POINTER(C.c_uint64)), ("kept_row2", C.POINTER(C.c_uint64)),
+                ("kept_tlen", C.POINTER(C.c_int32)), ("kept_hmm_from", C.POINTER(C.c_int32)), ("kept_hmm_to", C.POINTER(C.c_int32)),
+                ("kept_ali_from", C.POINTER(C.c_int32)), ("kept_ali_to", C.POINTER(C.c_int32)),
+                ("kept_env_from", C.POINTER(C.c_int32)), ("kept_env_to", C.POINTER(C.c_int32))]
+
+
+# every symbol include/checkm_hip.h declares
+EXPORTS = ["ckm_last_error", "ckm_abi_version", "ckm_device_count", "ckm_ctx_create", "ckm_ctx_destroy",
+           "ckm_profiles_load", "ckm_profiles_count", "ckm_profiles_header", "ckm_profiles_free",
+           "ckm_seqs_pack", "ckm_seqs_residues", "ckm_seqs_free", "ckm_search", "ckm_hits_columns", "ckm_hits_free",
+           "ckm_hits_write_domtblout", "ckm_last_search_stats", "ckm_reduce", "ckm_qa_columns_get", "ckm_qa_free",
+           "ckm_debug_stages", "ckm_debug_envelopes"]
+
+_lib = None
+
+
+def load():
+    """Load the shared library (no device needed for this); raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.ckm_last_error.restype = C.c_char_p
+    L.ckm_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.ckm_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.ckm_ctx_destroy.argtypes = [C.c_void_p]
+    L.ckm_ctx_destroy.restype = None
+    L.ckm_profiles_load.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
+    L.ckm_profiles_count.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    L.ckm_profiles_header.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ModelHeader)]
+    L.ckm_profiles_free.argtypes = [C.c_void_p]
+    L.ckm_profiles_free.restype = None
+    L.ckm_seqs_pack.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]
+    L.ckm_seqs_residues.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.ckm_seqs_free.argtypes = [C.c_void_p]
+    L.ckm_seqs_free.restype = None
+    L.ckm_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                             C.POINTER(C.c_void_p)]
+    L.ckm_hits_columns.argtypes = [C.c_void_p, C.POINTER(HitColumns)]
+    L.ckm_hits_free.argtypes = [C.c_void_p]
+    L.ckm_hits_free.restype = None
+    L.ckm_hits_write_domtblout.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p]
+    L.ckm_last_search_stats.argtypes = [C.c_void_p, C.POINTER(SearchStats)]
+    if hasattr(L, "ckm_reduce"):   # TEMP until the reduce half lands
+        L.ckm_reduce.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(HitColumns), C.c_void_p, C.POINTER(ModelInfo),
+                                 C.POINTER(ReduceFlags), C.POINTER(MarkerSetsCSR), C.POINTER(C.c_void_p)]
+        L.ckm_qa_columns_get.argtypes = [C.c_void_p, C.POINTER(QAColumns)]
+        L.ckm_qa_free.argtypes = [C.c_void_p]
+        L.ckm_qa_free.restype = None
+    L.ckm_debug_stages.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.ckm_debug_envelopes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_uint32, C.c_void_p]
+    if L.ckm_abi_version() != ABI_VERSION:
+        raise ImportError("libcheckm_hip ABI version mismatch")
+    _lib = L
+    return L
+
+
+def _chk(rc):
+    if rc != 0:
+        raise CkmError(rc, load().ckm_last_error().decode(errors="replace"))
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load().ckm_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+class Context(object):
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        _chk(load().ckm_ctx_create(device, C.byref(self.h)))
+        self.device = device
+
+    def close(self):
+        if self.h:
+            load().ckm_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def stats(self):
+        st = SearchStats()
+        _chk(load().ckm_last_search_stats(self.h, C.byref(st)))
+        return st
+
+
+class Profiles(object):
+    def __init__(self, ctx, path):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        _chk(load().ckm_profiles_load(ctx.h, path.encode(), C.byref(self.h)))
+        n = C.c_int32()
+        _chk(load().ckm_profiles_count(self.h, C.byref(n)))
+        self.n = n.value
+        self.headers = []
+        for i in range(self.n):
+            hd = ModelHeader()
+            _chk(load().ckm_profiles_header(self.h, i, C.byref(hd)))
+            self.headers.append({"name": hd.name.decode(), "acc": hd.acc.decode() if hd.acc else None,
+                                 "desc": hd.desc.decode() if hd.desc else None, "leng": hd.leng,
+                                 "ga": tuple(hd.ga) if hd.has_ga else None, "tc": tuple(hd.tc) if hd.has_tc else None,
+                                 "nc": tuple(hd.nc) if hd.has_nc else None, "evparam": tuple(hd.evparam)})
+
+    def close(self):
+        if self.h:
+            load().ckm_profiles_free(self.h)
+            self.h = C.c_void_p()
+
+
+class Seqs(object):
+    """All sequences of all bins, packed and resident in HBM."""
+
+    def __init__(self, ctx, bins):
+        """bins: list of lists of (name, desc, residues) records."""
+        self.ctx = ctx
+        names, descs, parts = [], [], []
+        bin_off = [0]
+        for recs in bins:
+            for name, desc, seq in recs:
+                names.append(name.encode())
+                descs.append((desc or "").encode())
+                parts.append(seq.encode() if isinstance(seq, str) else seq)
+            bin_off.append(len(names))
+        self.nseq = len(names)
+        self.nbins = len(bins)
+        self.names = [n.decode() for n in names]
+        self.descs = [d.decode() for d in descs]
+        self.lengths = np.array([len(p) for p in parts], dtype=np.int64)
+        off = np.zeros(self.nseq + 1, dtype=np.uint64)
+        np.cumsum(self.lengths, out=off[1:])
+        text = b"".join(parts)
+        self.bin_off = np.array(bin_off, dtype=np.uint32)
+        na = (C.c_char_p * max(1, self.nseq))(*names)
+        da = (C.c_char_p * max(1, self.nseq))(*descs)
+        self.h = C.c_void_p()
+        _chk(load().ckm_seqs_pack(ctx.h, text, off.ctypes.data, self.nseq, self.bin_off.ctypes.data, self.nbins, na, da,
+                                  C.byref(self.h)))
+        self.total_residues = int(self.lengths.sum())
+
+    def close(self):
+        if self.h:
+            load().ckm_seqs_free(self.h)
+            self.h = C.c_void_p()
+
+
+class Hits(object):
+    def __init__(self, h):
+        self.h = h
+        cols = HitColumns()
+        _chk(load().ckm_hits_columns(h, C.byref(cols)))
+        self.cols = cols
+        self.n = int(cols.n)
+        self.nbins = int(cols.nbins)
+        self.bin_row_off = np.ctypeslib.as_array(cols.bin_row_off, shape=(self.nbins + 1,)).copy()
+        for f in HIT_FIELDS:
+            ptr = getattr(cols, f)
+            setattr(self, f, np.ctypeslib.as_array(ptr, shape=(self.n,)).copy() if self.n else np.zeros(0))
+
+    def rows(self, b):
+        return range(int(self.bin_row_off[b]), int(self.bin_row_off[b + 1]))
+
+    def write_domtblout(self, profiles, seqs, b, path):
+        _chk(load().ckm_hits_write_domtblout(self.h, profiles.h, seqs.h, b, path.encode()))
+
+    def close(self):
+        if self.h:
+            load().ckm_hits_free(self.h)
+            self.h = None
+
+
+def search(ctx, profiles, seqs, bin_models=None, E=0.1, domE=0.1):
+    """bin_models: None (all models for every bin) or a list (per bin) of model-index lists."""
+    out = C.c_void_p()
+    if bin_models is None:
+        _chk(load().ckm_search(ctx.h, profiles.h, seqs.h, None, None, E, domE, C.byref(out)))
+    else:
+        off = np.zeros(len(bin_models) + 1, dtype=np.uint32)
+        for i, m in enumerate(bin_models):
+            off[i + 1] = off[i] + len(m)
+        flat = [x for m in bin_models for x in m]
+        idx = np.array(flat if flat else [0], dtype=np.uint32)
+        _chk(load().ckm_search(ctx.h, profiles.h, seqs.h, off.ctypes.data, idx.ctypes.data, E, domE, C.byref(out)))
+    return Hits(out)
+
+
+def debug_stages(ctx, profiles, seqs, model, seq):
+    model = np.ascontiguousarray(model, dtype=np.uint32)
+    seq = np.ascontiguousarray(seq, dtype=np.uint32)
+    out = (StageScores * len(model))()
+    _chk(load().ckm_debug_stages(ctx.h, profiles.h, seqs.h, model.ctypes.data, seq.ctypes.data, len(model), out))
+    return out
+
+
+def debug_envelopes(ctx, profiles, seqs, model, seq, ienv, jenv):
+    model = np.ascontiguousarray(model, dtype=np.uint32)
+    seq = np.ascontiguousarray(seq, dtype=np.uint32)
+    ienv = np.ascontiguousarray(ienv, dtype=np.int32)
+    jenv = np.ascontiguousarray(jenv, dtype=np.int32)
+    out = (EnvelopeResult * len(model))()
+    _chk(load().ckm_debug_envelopes(ctx.h, profiles.h, seqs.h, model.ctypes.data, seq.ctypes.data, ienv.ctypes.data,
+                                    jenv.ctypes.data, len(model), out))
+    return out

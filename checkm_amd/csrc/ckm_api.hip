@@ -1,0 +1,1002 @@
+// ckm_api.hip -- C ABI of libcheckm_hip.so: context, profile upload, sequence packing and the
+// search orchestration (host glue between the gfx950 kernels).  See include/checkm_hip.h for the
+// reference interfaces each entry point replaces.
+//
+// The host side owns every transcendental (log/exp): per-length specials, null scores, E-values.
+// The device side owns every per-cell operation.  There is no CPU implementation of any kernel in
+// this library: if HIP is unusable, ckm_ctx_create fails and nothing else can run.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <numeric>
+#include "ckm_internal.h"
+#include "dev_types.h"
+
+namespace ckm {
+
+// ---- kernel launchers (kernels_*.hip) ------------------------------------------------------------
+int launch_ssv(int Q, int nblocks, int threads, hipStream_t stream, const SsvBlockWork *work, const DevModel *models,
+               const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const uint32_t *lists, int16_t *maxv);
+void launch_msv_finish(hipStream_t stream, const FinishArgs &a, uint32_t nblocks);
+void launch_msv_full(hipStream_t stream, const PairRec *pairs, uint32_t npairs, const DevModel *models, const LenEntry *lentab,
+                     const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xJ, float *out_usc, int maxMp);
+void launch_bias(hipStream_t stream, PairRec *pairs, uint32_t npairs, const DevModel *models, const LenEntry *lentab,
+                 const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, float *raw);
+int launch_vit(int Q, hipStream_t stream, const PairRec *pairs, const uint32_t *idx, uint32_t n, const DevModel *models,
+               const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xC, float *out_sc);
+int launch_fwd(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const DevModel *models,
+               const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, FwdOut *out,
+               ScaleEvent *events, uint32_t *nevents, uint32_t cap_events);
+int launch_bwd(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const DevModel *models,
+               const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, const FwdOut *fout, int32_t *range_err);
+int launch_oa(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const DevModel *models,
+              float *ws, const int32_t *range_err, EnvOut *out);
+
+static thread_local std::string g_err;
+void set_last_error(const std::string &m) { g_err = m; }
+
+#define HIPCHK(expr)                                                                                         \
+  do {                                                                                                       \
+    hipError_t e_ = (expr);                                                                                  \
+    if (e_ != hipSuccess) throw Error(CKM_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+  } while (0)
+
+struct DevBuf {
+  void *p = nullptr; size_t cap = 0;
+  void ensure(size_t bytes) {
+    if (bytes <= cap) return;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; throw Error(CKM_ENOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed: " + hipGetErrorString(e)); }
+    cap = want;
+  }
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+}  // namespace ckm
+
+using namespace ckm;
+
+struct ckm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[8];
+  ckm_search_stats stats;
+  // reusable device scratch
+  DevBuf work, maxv, surv, nores, counters, cand, raw, idx, vitx, vits, fbwork, fbidx, ws, fout, events, rerr, envout, fullx, fullu;
+  size_t ws_budget = (size_t)8 << 30;     // float workspace budget (bytes) for Forward/Backward matrices
+};
+
+struct ckm_profiles {
+  ckm_ctx *ctx = nullptr;
+  std::vector<HostHMM> hmm;
+  std::vector<HostProfile> prof;
+  std::vector<DevModel> dm;
+  DevBuf d_models;
+  std::vector<std::unique_ptr<DevBuf>> tables;
+  int maxMp = 0;
+};
+
+struct SeqList { std::vector<uint32_t> ids; DevBuf d_ids; };
+
+struct ckm_seqs {
+  ckm_ctx *ctx = nullptr;
+  uint32_t nseq = 0, nbins = 0;
+  std::vector<uint32_t> bin_off, seq_bin;
+  std::vector<int32_t> len;
+  std::vector<uint64_t> off;          // offsets into the padded digital buffer
+  std::vector<uint8_t> dsq;           // host copy (null2 needs the residues)
+  std::vector<std::string> names, descs;
+  std::vector<LenEntry> lentab;
+  DevBuf d_res, d_off, d_len, d_lentab;
+  uint64_t total_res = 0;
+  int maxL = 0;
+  mutable std::map<std::vector<uint32_t>, std::unique_ptr<SeqList>> lists;   // bins -> length-sorted sequence ids
+};
+
+struct ckm_hits {
+  std::vector<uint64_t> bin_row_off;
+  std::vector<uint32_t> seq, model;
+  std::vector<int32_t> tlen, qlen, dom_idx, ndom, hmm_from, hmm_to, ali_from, ali_to, env_from, env_to;
+  std::vector<double> full_evalue, c_evalue, i_evalue;
+  std::vector<float> full_score, full_bias, dom_score, dom_bias, acc;
+  uint32_t nbins = 0;
+};
+
+template <class F>
+static int guarded(F &&f) {
+  try { f(); return CKM_OK; }
+  catch (const Error &e) { set_last_error(e.what()); return e.code; }
+  catch (const std::bad_alloc &) { set_last_error("out of host memory"); return CKM_ENOMEM; }
+  catch (const std::exception &e) { set_last_error(e.what()); return CKM_EINVAL; }
+}
+
+extern "C" const char *ckm_last_error(void) { return g_err.c_str(); }
+extern "C" int ckm_abi_version(void) { return CKM_ABI_VERSION; }
+
+extern "C" int ckm_device_count(int *n) {
+  return guarded([&] {
+    if (!n) throw Error(CKM_EINVAL, "n is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; throw Error(CKM_ENODEV, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *n = c;
+  });
+}
+
+extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
+  return guarded([&] {
+    if (!out) throw Error(CKM_EINVAL, "out is NULL");
+    *out = nullptr;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) throw Error(CKM_ENODEV, "no HIP device visible: libcheckm_hip has no CPU path");
+    if (device < 0 || device >= c) throw Error(CKM_ENODEV, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).compare(0, 6, "gfx950") != 0)
+      throw Error(CKM_ENODEV, std::string("device is ") + prop.gcnArchName + "; this library carries gfx950 code objects only");
+    std::unique_ptr<ckm_ctx> ctx(new ckm_ctx());
+    ctx->device = device;
+    HIPCHK(hipStreamCreate(&ctx->stream));
+    for (auto &e : ctx->ev) HIPCHK(hipEventCreate(&e));
+    memset(&ctx->stats, 0, sizeof(ctx->stats));
+    size_t fre = 0, tot = 0;
+    if (hipMemGetInfo(&fre, &tot) == hipSuccess) ctx->ws_budget = std::min<size_t>((size_t)16 << 30, fre / 4);
+    *out = ctx.release();
+  });
+}
+
+extern "C" void ckm_ctx_destroy(ckm_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &e : ctx->ev) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+// ---- profiles -----------------------------------------------------------------------------------
+template <class T>
+static const T *upload(ckm_profiles *p, const std::vector<T> &v) {
+  std::unique_ptr<DevBuf> b(new DevBuf());
+  b->ensure(std::max<size_t>(16, v.size() * sizeof(T)));
+  if (!v.empty()) HIPCHK(hipMemcpy(b->p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  const T *r = b->as<T>();
+  p->tables.push_back(std::move(b));
+  return r;
+}
+
+extern "C" int ckm_profiles_load(ckm_ctx *ctx, const char *hmm_path, ckm_profiles **out) {
+  return guarded([&] {
+    if (!ctx || !hmm_path || !out) throw Error(CKM_EINVAL, "NULL argument");
+    *out = nullptr;
+    HIPCHK(hipSetDevice(ctx->device));
+    std::unique_ptr<ckm_profiles> p(new ckm_profiles());
+    p->ctx = ctx;
+    p->hmm = read_hmm_file(hmm_path);
+    for (const auto &h : p->hmm) {
+      p->prof.push_back(configure_profile(h));
+      const HostProfile &hp = p->prof.back();
+      DevModel d;
+      memset(&d, 0, sizeof(d));
+      d.M = hp.M; d.ssvQ = hp.ssvQ; d.fbQ = hp.fbQ;
+      d.base_b = hp.base_b; d.bias_b = hp.bias_b; d.tbm_b = hp.tbm_b; d.tec_b = hp.tec_b; d.scale_b = hp.scale_b;
+      d.scale_w = hp.scale_w; d.base_w = hp.base_w; d.wE_loop = hp.wE_loop; d.wE_move = hp.wE_move;
+      d.fE_loop = hp.fE_loop; d.fE_move = hp.fE_move;
+      d.bt00 = hp.bt00; d.bt01 = hp.bt01; d.bt10 = hp.bt10; d.bt11 = hp.bt11; d.bpi0 = hp.bpi0; d.bpi1 = hp.bpi1;
+      for (int x = 0; x < NROWS; ++x) d.beo1[x] = hp.beo1[x];
+      d.thr_msv_f1 = hp.thr_msv_f1; d.thr_msv_f2 = hp.thr_msv_f2; d.thr_vit_f2 = hp.thr_vit_f2; d.thr_fwd_f3 = hp.thr_fwd_f3;
+      d.ssv_tbl = upload(p.get(), hp.ssv_tbl); d.rbv = upload(p.get(), hp.rbv); d.rwv = upload(p.get(), hp.rwv);
+      d.wtr = upload(p.get(), hp.wtr); d.wddc = upload(p.get(), hp.wddc); d.rf = upload(p.get(), hp.rf); d.ftr = upload(p.get(), hp.ftr);
+      p->dm.push_back(d);
+      p->maxMp = std::max(p->maxMp, hp.fbQ * NL);
+    }
+    p->d_models.ensure(p->dm.size() * sizeof(DevModel));
+    HIPCHK(hipMemcpy(p->d_models.p, p->dm.data(), p->dm.size() * sizeof(DevModel), hipMemcpyHostToDevice));
+    *out = p.release();
+  });
+}
+
+extern "C" int ckm_profiles_count(const ckm_profiles *p, int32_t *n) {
+  if (!p || !n) { set_last_error("NULL argument"); return CKM_EINVAL; }
+  *n = (int32_t)p->hmm.size();
+  return CKM_OK;
+}
+
+extern "C" int ckm_profiles_header(const ckm_profiles *p, int32_t i, ckm_model_header *o) {
+  if (!p || !o || i < 0 || i >= (int32_t)p->hmm.size()) { set_last_error("bad argument"); return CKM_EINVAL; }
+  const HostHMM &h = p->hmm[i];
+  o->name = h.name.c_str(); o->acc = h.has_acc ? h.acc.c_str() : nullptr; o->desc = h.has_desc ? h.desc.c_str() : nullptr;
+  o->leng = h.M; o->has_ga = h.has_ga; o->has_tc = h.has_tc; o->has_nc = h.has_nc;
+  for (int k = 0; k < 2; ++k) { o->ga[k] = h.ga[k]; o->tc[k] = h.tc[k]; o->nc[k] = h.nc[k]; }
+  for (int k = 0; k < 6; ++k) o->evparam[k] = h.evparam[k];
+  return CKM_OK;
+}
+
+extern "C" void ckm_profiles_free(ckm_profiles *p) {
+  if (!p) return;
+  if (p->ctx) (void)hipSetDevice(p->ctx->device);
+  delete p;
+}
+
+// ---- sequences ----------------------------------------------------------------------------------
+static void build_lentab(ckm_seqs *s) {
+  HostProfile dummy;    // scale_b / scale_w are model independent constants
+  dummy.scale_b = (float)(3.0 / 0.69314718055994529);
+  dummy.scale_w = (float)(500.0 / 0.69314718055994529);
+  s->lentab.resize((size_t)s->maxL + 1);
+  for (int L = 0; L <= s->maxL; ++L) {
+    const LenCfg m = len_config(dummy, L, true), u = len_config(dummy, L, false);
+    LenEntry e;
+    e.loop_m = m.loop; e.move_m = m.move; e.loop_u = u.loop; e.move_u = u.move;
+    e.nullsc = m.nullsc; e.bias_tail = m.bias_tail; e.w_move = m.w_move; e.tjb_b = m.tjb_b;
+    s->lentab[L] = e;
+  }
+}
+
+extern "C" int ckm_seqs_pack(ckm_ctx *ctx, const char *text, const uint64_t *seq_off, uint32_t nseq,
+                             const uint32_t *bin_off, uint32_t nbins, const char *const *names,
+                             const char *const *descs, ckm_seqs **out) {
+  return guarded([&] {
+    if (!ctx || !text || !seq_off || !bin_off || !out) throw Error(CKM_EINVAL, "NULL argument");
+    *out = nullptr;
+    if (nbins == 0 || bin_off[0] != 0 || bin_off[nbins] != nseq) throw Error(CKM_EINVAL, "bin_off must start at 0 and end at nseq");
+    HIPCHK(hipSetDevice(ctx->device));
+    std::unique_ptr<ckm_seqs> s(new ckm_seqs());
+    s->ctx = ctx; s->nseq = nseq; s->nbins = nbins;
+    s->bin_off.assign(bin_off, bin_off + nbins + 1);
+    s->seq_bin.resize(nseq);
+    for (uint32_t b = 0; b < nbins; ++b) {
+      if (bin_off[b + 1] < bin_off[b]) throw Error(CKM_EINVAL, "bin_off not monotone");
+      for (uint32_t i = bin_off[b]; i < bin_off[b + 1]; ++i) s->seq_bin[i] = b;
+    }
+    s->len.resize(nseq); s->off.resize(nseq);
+    uint64_t pos = 0;
+    for (uint32_t i = 0; i < nseq; ++i) {
+      if (seq_off[i + 1] < seq_off[i]) throw Error(CKM_EINVAL, "seq_off not monotone");
+      const uint64_t L = seq_off[i + 1] - seq_off[i];
+      if (L > 100000) throw Error(CKM_ERANGE, "sequence longer than 100000 residues");
+      s->len[i] = (int32_t)L; s->off[i] = pos;
+      pos += (L + 15) & ~(uint64_t)15;
+      s->total_res += L; s->maxL = std::max(s->maxL, (int)L);
+    }
+    s->dsq.assign(pos + 16, (uint8_t)PADCODE);
+    for (uint32_t i = 0; i < nseq; ++i) digitize(text + seq_off[i], (uint64_t)s->len[i], s->dsq.data() + s->off[i]);
+    s->names.resize(nseq); s->descs.resize(nseq);
+    for (uint32_t i = 0; i < nseq; ++i) {
+      if (names && names[i]) s->names[i] = names[i]; else s->names[i] = "seq" + std::to_string(i);
+      if (descs && descs[i]) s->descs[i] = descs[i];
+    }
+    build_lentab(s.get());
+    s->d_res.ensure(s->dsq.size()); HIPCHK(hipMemcpy(s->d_res.p, s->dsq.data(), s->dsq.size(), hipMemcpyHostToDevice));
+    s->d_off.ensure(std::max<size_t>(8, nseq * 8)); HIPCHK(hipMemcpy(s->d_off.p, s->off.data(), (size_t)nseq * 8, hipMemcpyHostToDevice));
+    s->d_len.ensure(std::max<size_t>(4, nseq * 4)); HIPCHK(hipMemcpy(s->d_len.p, s->len.data(), (size_t)nseq * 4, hipMemcpyHostToDevice));
+    s->d_lentab.ensure(s->lentab.size() * sizeof(LenEntry));
+    HIPCHK(hipMemcpy(s->d_lentab.p, s->lentab.data(), s->lentab.size() * sizeof(LenEntry), hipMemcpyHostToDevice));
+    *out = s.release();
+  });
+}
+
+extern "C" int ckm_seqs_residues(const ckm_seqs *s, uint64_t *total) {
+  if (!s || !total) { set_last_error("NULL argument"); return CKM_EINVAL; }
+  *total = s->total_res;
+  return CKM_OK;
+}
+
+extern "C" void ckm_seqs_free(ckm_seqs *s) {
+  if (!s) return;
+  if (s->ctx) (void)hipSetDevice(s->ctx->device);
+  delete s;
+}
+
+// ---- the search -----------------------------------------------------------------------------------
+namespace {
+
+constexpr double kLn2 = 0.69314718055994529;
+constexpr double kLog2R = 1.44269504088896341;
+constexpr float kOmega = 1.0f / 256.0f;
+constexpr float RT1 = 0.25f, RT2 = 0.10f, RT3 = 0.20f;
+
+struct Domain {
+  int ienv, jenv; float envsc, oasc, domcorrection; int hmm_from, hmm_to, ali_from, ali_to;
+  float dombias, bitscore; double lnP; bool reported;
+};
+struct Hit {
+  uint32_t model, seq; int L; float pre_score, score; double lnP; std::vector<Domain> dom; int nreported;
+};
+struct Cand {            // a pair that survived the MSV stage
+  PairRec r; float fwdsc; float fwd_xC; uint32_t slot; bool alive;
+};
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+float bits(float sc, float nullsc) { return (float)((double)(sc - nullsc) / kLn2); }
+
+const SeqList *get_list(const ckm_seqs *s, const std::vector<uint32_t> &bins) {
+  auto it = s->lists.find(bins);
+  if (it != s->lists.end()) return it->second.get();
+  std::unique_ptr<SeqList> l(new SeqList());
+  for (uint32_t b : bins) for (uint32_t i = s->bin_off[b]; i < s->bin_off[b + 1]; ++i) if (s->len[i] > 0) l->ids.push_back(i);
+  std::stable_sort(l->ids.begin(), l->ids.end(), [&](uint32_t a, uint32_t b) { return s->len[a] > s->len[b]; });
+  l->d_ids.ensure(std::max<size_t>(4, l->ids.size() * 4));
+  if (!l->ids.empty()) HIPCHK(hipMemcpy(l->d_ids.p, l->ids.data(), l->ids.size() * 4, hipMemcpyHostToDevice));
+  const SeqList *r = l.get();
+  s->lists.emplace(bins, std::move(l));
+  return r;
+}
+
+// host-side completion of a Forward score from the device's scaled xC and its rescale events
+float finish_forward(float xC, float move, const std::vector<float> &scales) {
+  float totscale = 0.f;
+  for (float sc : scales) totscale = (float)((double)totscale + log((double)sc));
+  return (float)((double)totscale + log((double)(xC * move)));
+}
+
+struct EventIndex {      // rescale events grouped by slot, rows ascending
+  std::vector<std::vector<std::pair<int, float>>> by_slot;
+  void build(const std::vector<ScaleEvent> &ev, size_t nslots) {
+    by_slot.assign(nslots, {});
+    for (const auto &e : ev) if (e.slot < nslots) by_slot[e.slot].push_back({e.row, e.scale});
+    for (auto &v : by_slot) std::sort(v.begin(), v.end());
+  }
+  std::vector<float> scales(uint32_t slot) const { std::vector<float> r; for (auto &p : by_slot[slot]) r.push_back(p.second); return r; }
+};
+
+int ssv_threads_for(int Q) {
+  const size_t lds = (size_t)NROWS * ((Q + 3) / 4) * 256;
+  if (lds <= 40 * 1024) return 256;
+  if (lds <= 80 * 1024 || Q > 40) return 512;   // kernels with Q > 40 are compiled for <= 512 threads (256 VGPRs)
+  return 1024;
+}
+
+// Runs fwd/bwd(/oa) for a list of work items, grouped by the model's canonical Q.
+struct FbBatch {
+  std::vector<FbWork> work;
+  std::vector<FwdOut> fout;
+  std::vector<ScaleEvent> events;
+  std::vector<int32_t> rerr;
+  std::vector<EnvOut> envout;
+};
+
+void run_fb(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, bool do_fwd, bool do_bwd, bool do_oa,
+            const std::vector<uint32_t> *subset /* indices into b.work, or null = all */) {
+  const size_t n = b.work.size();
+  if (!n) return;
+  ctx->fbwork.ensure(n * sizeof(FbWork));
+  HIPCHK(hipMemcpyAsync(ctx->fbwork.p, b.work.data(), n * sizeof(FbWork), hipMemcpyHostToDevice, ctx->stream));
+  std::map<int, std::vector<uint32_t>> byQ;
+  if (subset) for (uint32_t i : *subset) byQ[p->prof[b.work[i].model].fbQ].push_back(i);
+  else for (uint32_t i = 0; i < n; ++i) byQ[p->prof[b.work[i].model].fbQ].push_back(i);
+  std::vector<uint32_t> flat; std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;
+  for (auto &kv : byQ) { groups.push_back({kv.first, {flat.size(), kv.second.size()}}); flat.insert(flat.end(), kv.second.begin(), kv.second.end()); }
+  ctx->fbidx.ensure(flat.size() * 4);
+  HIPCHK(hipMemcpyAsync(ctx->fbidx.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  ctx->fout.ensure(n * sizeof(FwdOut));
+  ctx->rerr.ensure(n * 4);
+  ctx->envout.ensure(n * sizeof(EnvOut));
+  const uint32_t cap_events = (uint32_t)std::max<size_t>(1 << 20, n * 64);
+  ctx->events.ensure((size_t)cap_events * sizeof(ScaleEvent));
+  ctx->counters.ensure(64);
+  const DevModel *dm = p->d_models.as<DevModel>();
+  const LenEntry *lt = s->d_lentab.as<LenEntry>();
+  const uint8_t *res = s->d_res.as<uint8_t>();
+  const uint64_t *off = s->d_off.as<uint64_t>();
+  float *ws = ctx->ws.as<float>();
+  if (do_fwd) {
+    HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+    for (auto &g : groups)
+      if (launch_fwd(g.first, (uint32_t)g.second.second, ctx->stream, ctx->fbwork.as<FbWork>(), ctx->fbidx.as<uint32_t>() + g.second.first, dm, lt, res, off,
+                     ws, ctx->fout.as<FwdOut>(), ctx->events.as<ScaleEvent>(), ctx->counters.as<uint32_t>(), cap_events))
+        throw Error(CKM_ERANGE, "no Forward kernel instance for this model length");
+    HIPCHK(hipGetLastError());
+    b.fout.resize(n);
+    uint32_t nev = 0;
+    HIPCHK(hipMemcpyAsync(b.fout.data(), ctx->fout.p, n * sizeof(FwdOut), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&nev, ctx->counters.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (nev > cap_events) throw Error(CKM_ERANGE, "rescale event buffer overflow");
+    b.events.resize(nev);
+    if (nev) HIPCHK(hipMemcpy(b.events.data(), ctx->events.p, (size_t)nev * sizeof(ScaleEvent), hipMemcpyDeviceToHost));
+  }
+  if (do_bwd) {
+    for (auto &g : groups)
+      if (launch_bwd(g.first, (uint32_t)g.second.second, ctx->stream, ctx->fbwork.as<FbWork>(), ctx->fbidx.as<uint32_t>() + g.second.first, dm, lt, res, off,
+                     ws, ctx->fout.as<FwdOut>(), ctx->rerr.as<int32_t>()))
+        throw Error(CKM_ERANGE, "no Backward kernel instance for this model length");
+    HIPCHK(hipGetLastError());
+  }
+  if (do_oa) {
+    for (auto &g : groups)
+      if (launch_oa(g.first, (uint32_t)g.second.second, ctx->stream, ctx->fbwork.as<FbWork>(), ctx->fbidx.as<uint32_t>() + g.second.first, dm, ws,
+                    ctx->rerr.as<int32_t>(), ctx->envout.as<EnvOut>()))
+        throw Error(CKM_ERANGE, "no OA kernel instance for this model length");
+    HIPCHK(hipGetLastError());
+    b.envout.resize(n);
+    HIPCHK(hipMemcpyAsync(b.envout.data(), ctx->envout.p, n * sizeof(EnvOut), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+}
+
+size_t env_floats(int Mp, int Ld, uint64_t &xs, uint64_t &aux, uint64_t &mf, uint64_t &mb, uint64_t base) {
+  auto al = [](uint64_t v) { return (v + 31) & ~(uint64_t)31; };
+  uint64_t pos = al(base);
+  xs = pos; pos = al(pos + (uint64_t)(Ld + 1) * 6);
+  aux = pos; pos = al(al(pos + (uint64_t)(Ld + 1) * 3) + (uint64_t)(Ld + 1) * 5);
+  mf = pos; pos = al(pos + (uint64_t)(Ld + 1) * 3 * Mp);
+  mb = pos; pos = al(pos + (uint64_t)(Ld + 1) * 3 * Mp);
+  return pos;
+}
+
+// Rescore envelopes on the device; returns one Domain per envelope (ok flag via envsc NaN on range error)
+struct EnvReq { uint32_t model, seq; int ienv, jenv; };
+struct EnvRes { bool ok; float envsc, oasc, xC; int nscale; float null2[KP]; int hmm_from, hmm_to, ali_from, ali_to; };
+
+void rescore_envelopes(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<EnvReq> &req, std::vector<EnvRes> &out) {
+  out.resize(req.size());
+  size_t done = 0;
+  const uint64_t budget_floats = ctx->ws_budget / 4;
+  while (done < req.size()) {
+    FbBatch b; uint64_t pos = 0; size_t j = done;
+    for (; j < req.size(); ++j) {
+      const EnvReq &r = req[j];
+      const int Mp = p->prof[r.model].fbQ * NL, Ld = r.jenv - r.ienv + 1;
+      FbWork w; memset(&w, 0, sizeof(w));
+      uint64_t end = env_floats(Mp, Ld, w.xs_off, w.aux_off, w.mxf_off, w.mxb_off, pos);
+      if (end > budget_floats && j > done) break;
+      if (end > budget_floats) throw Error(CKM_ENOMEM, "one envelope needs more workspace than the device budget allows");
+      w.model = r.model; w.seq = r.seq; w.i0 = r.ienv - 1; w.Ld = Ld; w.Lcfg = s->len[r.seq]; w.multihit = 0; w.slot = (uint32_t)(j - done); w.full = 1;
+      b.work.push_back(w); pos = end;
+    }
+    ctx->ws.ensure(pos * 4 + 256);
+    run_fb(ctx, p, s, b, true, true, true, nullptr);
+    EventIndex ei; ei.build(b.events, b.work.size());
+    for (size_t k = 0; k < b.work.size(); ++k) {
+      const EnvReq &r = req[done + k]; EnvRes &o = out[done + k];
+      const EnvOut &eo = b.envout[k];
+      const LenEntry &le = s->lentab[s->len[r.seq]];
+      o.ok = eo.range_err == 0;
+      o.xC = b.fout[k].xC; o.nscale = b.fout[k].nscale;
+      o.envsc = finish_forward(b.fout[k].xC, le.move_u, ei.scales((uint32_t)k));
+      o.oasc = eo.oasc; o.hmm_from = eo.hmm_from; o.hmm_to = eo.hmm_to; o.ali_from = eo.ali_from; o.ali_to = eo.ali_to;
+      for (int x = 0; x < K; ++x) o.null2[x] = eo.null2[x];
+    }
+    done = j;
+  }
+}
+
+void fill_null2(float *null2) {   // degenerate symbols: plain average of the odds of their residues
+  static const char *sym = "ACDEFGHIKLMNPQRSTVWY-BJZOUX*~";
+  auto member = [&](int x, int y) {
+    switch (sym[x]) { case 'B': return sym[y] == 'D' || sym[y] == 'N'; case 'J': return sym[y] == 'I' || sym[y] == 'L';
+                      case 'Z': return sym[y] == 'E' || sym[y] == 'Q'; case 'O': return sym[y] == 'K'; case 'U': return sym[y] == 'C'; default: return true; } };
+  for (int x = 21; x <= 26; ++x) { float r = 0.f; int n = 0; for (int y = 0; y < K; ++y) if (member(x, y)) { r += null2[y]; ++n; } null2[x] = r / (float)n; }
+  null2[20] = null2[27] = null2[28] = 1.0f;
+}
+
+}  // namespace
+
+struct SearchPlan {        // which models run against which sequence lists
+  std::vector<std::vector<uint32_t>> model_bins;   // per model: bins (sorted)
+};
+
+static void do_search(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, const uint32_t *model_off, const uint32_t *model_idx,
+                      double E, double domE, ckm_hits *hits) {
+  HIPCHK(hipSetDevice(ctx->device));
+  const double t_start = now_ms();
+  ckm_search_stats &st = ctx->stats;
+  memset(&st, 0, sizeof(st));
+  const uint32_t nmodels = (uint32_t)p->hmm.size(), nbins = s->nbins;
+  // ---- plan ----
+  std::vector<std::vector<uint32_t>> bin_models(nbins);
+  for (uint32_t b = 0; b < nbins; ++b) {
+    if (model_off) { for (uint32_t k = model_off[b]; k < model_off[b + 1]; ++k) { if (model_idx[k] >= nmodels) throw Error(CKM_EINVAL, "model index out of range"); bin_models[b].push_back(model_idx[k]); } }
+    else { bin_models[b].resize(nmodels); std::iota(bin_models[b].begin(), bin_models[b].end(), 0u); }
+  }
+  std::vector<std::vector<uint32_t>> model_bins(nmodels);
+  for (uint32_t b = 0; b < nbins; ++b) {
+    std::vector<uint32_t> uniq = bin_models[b]; std::sort(uniq.begin(), uniq.end()); uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    for (uint32_t m : uniq) model_bins[m].push_back(b);
+  }
+  const DevModel *dm = p->d_models.as<DevModel>();
+  const LenEntry *lt = s->d_lentab.as<LenEntry>();
+  const uint8_t *res = s->d_res.as<uint8_t>();
+  const uint64_t *off = s->d_off.as<uint64_t>();
+  const int32_t *dlen = s->d_len.as<int32_t>();
+
+  // ---- stage 1: SSV over every pair, chunked by a pair budget ----
+  std::vector<Cand> cands;
+  {
+    const uint64_t pair_budget = (uint64_t)1 << 29;
+    uint32_t m0 = 0;
+    while (m0 < nmodels) {
+      // gather models of this chunk; every distinct sequence list gets one device array
+      struct MW { uint32_t model; const SeqList *list; uint64_t pair_base; };
+      std::vector<MW> mws; uint64_t npairs = 0; uint32_t m1 = m0;
+      for (; m1 < nmodels; ++m1) {
+        if (model_bins[m1].empty()) continue;
+        const SeqList *l = get_list(s, model_bins[m1]);
+        if (npairs + l->ids.size() > pair_budget && !mws.empty()) break;
+        mws.push_back({m1, l, npairs}); npairs += l->ids.size();
+      }
+      m0 = m1;
+      if (mws.empty() || npairs == 0) continue;
+      // the kernels index ONE lists[] array: concatenate the distinct lists of this chunk
+      std::map<const SeqList *, uint32_t> list_base; std::vector<uint32_t> all_ids;
+      for (auto &mw : mws) if (!list_base.count(mw.list)) { list_base[mw.list] = (uint32_t)all_ids.size(); all_ids.insert(all_ids.end(), mw.list->ids.begin(), mw.list->ids.end()); }
+      ctx->idx.ensure(all_ids.size() * 4);
+      HIPCHK(hipMemcpyAsync(ctx->idx.p, all_ids.data(), all_ids.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+      std::map<int, std::vector<SsvBlockWork>> byQ;
+      for (auto &mw : mws) {
+        const int Q = p->prof[mw.model].ssvQ; const int threads = ssv_threads_for(Q); const uint32_t per_block = (uint32_t)threads / 64 * 4 * 4;
+        const uint32_t n = (uint32_t)mw.list->ids.size();
+        for (uint32_t a = 0; a < n; a += per_block) {
+          SsvBlockWork w; w.model = mw.model; w.list_start = list_base[mw.list] + a; w.count = std::min(per_block, n - a); w.pair_start = (uint32_t)(mw.pair_base + a);
+          byQ[Q].push_back(w);
+        }
+        st.pairs_ssv += n;
+        for (uint32_t id : mw.list->ids) { st.residue_hmm += (uint64_t)s->len[id]; st.cells_ssv += (uint64_t)s->len[id] * (uint64_t)p->prof[mw.model].M; }
+      }
+      std::vector<SsvBlockWork> allw; std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;
+      for (auto &kv : byQ) { groups.push_back({kv.first, {allw.size(), kv.second.size()}}); allw.insert(allw.end(), kv.second.begin(), kv.second.end()); }
+      ctx->work.ensure(allw.size() * sizeof(SsvBlockWork));
+      HIPCHK(hipMemcpyAsync(ctx->work.p, allw.data(), allw.size() * sizeof(SsvBlockWork), hipMemcpyHostToDevice, ctx->stream));
+      ctx->maxv.ensure(npairs * 2 + 64);
+      uint32_t cap_surv = (uint32_t)std::max<uint64_t>(1 << 16, npairs / 8), cap_nores = (uint32_t)std::max<uint64_t>(1 << 14, npairs / 64);
+      for (int attempt = 0;; ++attempt) {
+        ctx->surv.ensure((size_t)cap_surv * sizeof(PairRec)); ctx->nores.ensure((size_t)cap_nores * sizeof(PairRec)); ctx->counters.ensure(64);
+        HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+        HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+        if (attempt == 0) {
+          for (auto &g : groups) {
+            if (launch_ssv(g.first, (int)g.second.second, ssv_threads_for(g.first), ctx->stream, ctx->work.as<SsvBlockWork>() + g.second.first, dm, res, off, dlen,
+                           ctx->idx.as<uint32_t>(), ctx->maxv.as<int16_t>()))
+              throw Error(CKM_ERANGE, "no SSV kernel instance for this model length");
+            st.ssv_launches++;
+          }
+        }
+        HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+        FinishArgs fa{dm, lt, dlen, ctx->idx.as<uint32_t>(), ctx->work.as<SsvBlockWork>(), ctx->maxv.as<int16_t>(),
+                      ctx->surv.as<PairRec>(), ctx->counters.as<uint32_t>(), cap_surv, ctx->nores.as<PairRec>(), ctx->counters.as<uint32_t>() + 1, cap_nores};
+        launch_msv_finish(ctx->stream, fa, (uint32_t)allw.size());
+        HIPCHK(hipGetLastError());
+        uint32_t cnt[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(cnt, ctx->counters.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (attempt == 0) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); st.ms_ssv += ms; }
+        if (cnt[0] > cap_surv || cnt[1] > cap_nores) { cap_surv = std::max(cap_surv, cnt[0]); cap_nores = std::max(cap_nores, cnt[1]); continue; }
+        std::vector<PairRec> sv(cnt[0]), nr(cnt[1]);
+        if (cnt[0]) HIPCHK(hipMemcpy(sv.data(), ctx->surv.p, (size_t)cnt[0] * sizeof(PairRec), hipMemcpyDeviceToHost));
+        if (cnt[1]) HIPCHK(hipMemcpy(nr.data(), ctx->nores.p, (size_t)cnt[1] * sizeof(PairRec), hipMemcpyDeviceToHost));
+        for (auto &r : sv) { Cand c; c.r = r; c.alive = true; c.fwdsc = 0; c.fwd_xC = 0; c.slot = 0; cands.push_back(c); }
+        if (!nr.empty()) {     // exact multi-hit MSV for the pairs where J could be used
+          st.pairs_msv_full += nr.size();
+          ctx->fullx.ensure(nr.size() * 4); ctx->fullu.ensure(nr.size() * 4);
+          launch_msv_full(ctx->stream, ctx->nores.as<PairRec>(), (uint32_t)nr.size(), dm, lt, res, off, dlen, ctx->fullx.as<int32_t>(), ctx->fullu.as<float>(), p->maxMp);
+          HIPCHK(hipGetLastError());
+          std::vector<float> usc(nr.size());
+          HIPCHK(hipMemcpyAsync(usc.data(), ctx->fullu.p, nr.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+          HIPCHK(hipStreamSynchronize(ctx->stream));
+          for (size_t i = 0; i < nr.size(); ++i) {
+            const float nullsc = s->lentab[s->len[nr[i].seq]].nullsc;
+            if (bits(usc[i], nullsc) >= p->prof[nr[i].model].thr_msv_f1) { Cand c; c.r = nr[i]; c.r.usc = usc[i]; c.alive = true; c.fwdsc = 0; c.fwd_xC = 0; c.slot = 0; cands.push_back(c); }
+          }
+        }
+        break;
+      }
+    }
+  }
+  // deterministic order: by model then sequence
+  std::sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.r.model != b.r.model ? a.r.model < b.r.model : a.r.seq < b.r.seq; });
+  const double t_filters0 = now_ms();
+
+  // ---- stage 2: bias filter ----
+  std::vector<PairRec> cr(cands.size());
+  for (size_t i = 0; i < cands.size(); ++i) cr[i] = cands[i].r;
+  st.pairs_bias = cands.size();
+  std::vector<uint8_t> need_vit(cands.size(), 0);
+  if (!cands.empty()) {
+    ctx->cand.ensure(cr.size() * sizeof(PairRec)); ctx->raw.ensure(cr.size() * 12);
+    HIPCHK(hipMemcpyAsync(ctx->cand.p, cr.data(), cr.size() * sizeof(PairRec), hipMemcpyHostToDevice, ctx->stream));
+    launch_bias(ctx->stream, ctx->cand.as<PairRec>(), (uint32_t)cr.size(), dm, lt, res, off, dlen, ctx->raw.as<float>());
+    HIPCHK(hipGetLastError());
+    std::vector<float> raw(cr.size() * 3);
+    HIPCHK(hipMemcpyAsync(raw.data(), ctx->raw.p, raw.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < cands.size(); ++i) {
+      Cand &c = cands[i];
+      const int L = s->len[c.r.seq];
+      const LenEntry &le = s->lentab[L];
+      const float p1 = (float)L / (float)(L + 1);
+      const float nullsc = (float)(log((double)raw[i * 3]) + (double)raw[i * 3 + 1] * kLn2);
+      c.r.filtersc = nullsc + (float)L * logf(p1) + logf(1.0f - p1);
+      (void)le;
+      const float sc = bits(c.r.usc, c.r.filtersc);
+      const HostProfile &hp = p->prof[c.r.model];
+      if (!(sc >= hp.thr_msv_f1)) { c.alive = false; continue; }
+      need_vit[i] = !(sc >= hp.thr_msv_f2);
+    }
+  }
+  // ---- stage 3: Viterbi filter ----
+  {
+    std::map<int, std::vector<uint32_t>> byQ;
+    for (size_t i = 0; i < cands.size(); ++i) if (cands[i].alive && need_vit[i]) byQ[p->prof[cands[i].r.model].vitQ].push_back((uint32_t)i);
+    std::vector<uint32_t> flat; std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;
+    for (auto &kv : byQ) { groups.push_back({kv.first, {flat.size(), kv.second.size()}}); flat.insert(flat.end(), kv.second.begin(), kv.second.end()); }
+    st.pairs_vit = flat.size();
+    if (!flat.empty()) {
+      for (size_t i = 0; i < cands.size(); ++i) cr[i] = cands[i].r;
+      HIPCHK(hipMemcpyAsync(ctx->cand.p, cr.data(), cr.size() * sizeof(PairRec), hipMemcpyHostToDevice, ctx->stream));
+      ctx->fbidx.ensure(flat.size() * 4); ctx->vitx.ensure(cands.size() * 4); ctx->vits.ensure(cands.size() * 4);
+      HIPCHK(hipMemcpyAsync(ctx->fbidx.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+      for (auto &g : groups)
+        if (launch_vit(g.first, ctx->stream, ctx->cand.as<PairRec>(), ctx->fbidx.as<uint32_t>() + g.second.first, (uint32_t)g.second.second, dm, lt, res, off, dlen,
+                       ctx->vitx.as<int32_t>(), ctx->vits.as<float>()))
+          throw Error(CKM_ERANGE, "no Viterbi kernel instance for this model length");
+      HIPCHK(hipGetLastError());
+      std::vector<float> vsc(cands.size());
+      HIPCHK(hipMemcpyAsync(vsc.data(), ctx->vits.p, cands.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      for (uint32_t i : flat) { Cand &c = cands[i]; if (!(bits(vsc[i], c.r.filtersc) >= p->prof[c.r.model].thr_vit_f2)) c.alive = false; }
+    }
+  }
+  st.ms_filters = now_ms() - t_filters0;
+  const double t_fb0 = now_ms();
+  // ---- stage 4: Forward parser (multihit, whole sequence), F3 ----
+  FbBatch fb;
+  std::vector<uint32_t> fb_cand;
+  uint64_t aux_base = 0;
+  {
+    uint64_t pos = 0, aux_total = 0;
+    for (size_t i = 0; i < cands.size(); ++i) if (cands[i].alive) {
+      const int L = s->len[cands[i].r.seq];
+      FbWork w; memset(&w, 0, sizeof(w));
+      w.model = cands[i].r.model; w.seq = cands[i].r.seq; w.i0 = 0; w.Ld = L; w.Lcfg = L; w.multihit = 1; w.full = 0; w.slot = (uint32_t)fb.work.size();
+      w.xs_off = pos; pos += ((uint64_t)(L + 1) * 6 + 31) & ~(uint64_t)31;
+      aux_total += ((uint64_t)(L + 1) * 3 + 31) & ~(uint64_t)31;
+      fb.work.push_back(w); fb_cand.push_back((uint32_t)i);
+    }
+    st.pairs_fwd = fb.work.size();
+    aux_base = pos;      // decoding terms of the F3 survivors are laid out compactly from here after the Forward pass
+    if ((pos + aux_total) * 4 > ctx->ws_budget) throw Error(CKM_ENOMEM, "Forward special-row workspace exceeds the device budget; search fewer bins per call");
+    ctx->ws.ensure((pos + aux_total) * 4 + 256);
+    run_fb(ctx, p, s, fb, true, false, false, nullptr);
+  }
+  EventIndex fev; fev.build(fb.events, fb.work.size());
+  std::vector<uint32_t> passers;
+  for (size_t k = 0; k < fb.work.size(); ++k) {
+    Cand &c = cands[fb_cand[k]];
+    const LenEntry &le = s->lentab[s->len[c.r.seq]];
+    c.fwd_xC = fb.fout[k].xC; c.slot = (uint32_t)k;
+    c.fwdsc = finish_forward(fb.fout[k].xC, le.move_m, fev.scales((uint32_t)k));
+    if (bits(c.fwdsc, c.r.filtersc) >= p->prof[c.r.model].thr_fwd_f3) passers.push_back((uint32_t)k); else c.alive = false;
+  }
+  st.pairs_dom = passers.size();
+  // ---- stage 5: Backward parser + posterior domain heuristics ----
+  std::vector<EnvReq> envreq; std::vector<std::pair<size_t, size_t>> env_of_pass(passers.size());   // [first, count)
+  std::vector<int> nregions(passers.size(), 0);
+  if (!passers.empty()) {
+    uint64_t ap = aux_base;
+    for (uint32_t k : passers) { fb.work[k].aux_off = ap; ap += ((uint64_t)(fb.work[k].Ld + 1) * 3 + 31) & ~(uint64_t)31; }
+    run_fb(ctx, p, s, fb, false, true, false, &passers);
+    // pull the decoding terms of the passers in one copy
+    std::vector<float> dec_all(ap - aux_base);
+    if (!dec_all.empty()) HIPCHK(hipMemcpy(dec_all.data(), ctx->ws.as<float>() + aux_base, dec_all.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t q = 0; q < passers.size(); ++q) {
+      const FbWork &w = fb.work[passers[q]];
+      const int L = w.Ld;
+      const float *dec = dec_all.data() + (w.aux_off - aux_base);
+      std::vector<float> btot(L + 1, 0.f), etot(L + 1, 0.f), mocc(L + 1, 0.f);
+      for (int i = 1; i <= L; ++i) { btot[i] = btot[i - 1] + dec[(size_t)i * 3]; etot[i] = etot[i - 1] + dec[(size_t)i * 3 + 1]; mocc[i] = 1.0f - dec[(size_t)i * 3 + 2]; }
+      env_of_pass[q].first = envreq.size();
+      int i = -1; bool triggered = false;
+      for (int j = 1; j <= L; ++j) {
+        if (!triggered) {
+          if (mocc[j] - (btot[j] - btot[j - 1]) < RT2) i = j; else if (i == -1) i = j;
+          if (mocc[j] >= RT1) triggered = true;
+        } else if (mocc[j] - (etot[j] - etot[j - 1]) < RT2) {
+          nregions[q]++;
+          float mx = -1.0f;
+          for (int z = i; z <= j; ++z) { const float a = etot[z] - etot[i - 1], b = btot[j] - btot[z - 1]; const float en = a < b ? a : b; if (en > mx) mx = en; }
+          if (mx >= RT3) {
+            // multi-domain region: deterministic posterior split (deviation D3)
+            int start = i; float next = 0.5f; const float total = etot[j] - etot[i - 1];
+            for (int z = i; z < j; ++z) {
+              const float a = etot[z] - etot[i - 1];
+              if (a >= next && (total - a) >= 0.5f) { envreq.push_back({w.model, w.seq, start, z}); start = z + 1; next += 1.0f; }
+            }
+            envreq.push_back({w.model, w.seq, start, j});
+          } else envreq.push_back({w.model, w.seq, i, j});
+          i = -1; triggered = false;
+        }
+      }
+      env_of_pass[q].second = envreq.size() - env_of_pass[q].first;
+    }
+  }
+  st.envelopes = envreq.size();
+  st.ms_fwdbwd = now_ms() - t_fb0;
+  const double t_dom0 = now_ms();
+  // ---- stage 6: envelope rescoring ----
+  std::vector<EnvRes> envres;
+  rescore_envelopes(ctx, p, s, envreq, envres);
+  st.ms_domains = now_ms() - t_dom0;
+  const double t_host0 = now_ms();
+  // ---- stage 7: scores, thresholds, rows ----
+  std::map<std::pair<uint32_t, uint32_t>, std::vector<Hit>> by_bin_model;     // (bin, model) -> hits
+  for (size_t q = 0; q < passers.size(); ++q) {
+    const Cand &c = cands[fb_cand[passers[q]]];
+    const HostHMM &hm = p->hmm[c.r.model];
+    const int L = s->len[c.r.seq];
+    const uint8_t *dsq = s->dsq.data() + s->off[c.r.seq];
+    const float nullsc = s->lentab[L].nullsc;
+    std::vector<float> n2sc((size_t)L + 2, 0.f);
+    Hit h; h.model = c.r.model; h.seq = c.r.seq; h.L = L; h.nreported = 0;
+    int nenv = 0;
+    for (size_t e = env_of_pass[q].first; e < env_of_pass[q].first + env_of_pass[q].second; ++e) {
+      ++nenv;
+      EnvRes &er = envres[e];
+      if (!er.ok) continue;
+      float null2[KP]; for (int x = 0; x < K; ++x) null2[x] = er.null2[x];
+      fill_null2(null2);
+      Domain d; memset(&d, 0, sizeof(d));
+      d.ienv = envreq[e].ienv; d.jenv = envreq[e].jenv; d.envsc = er.envsc; d.oasc = er.oasc;
+      d.hmm_from = er.hmm_from; d.hmm_to = er.hmm_to; d.ali_from = er.ali_from; d.ali_to = er.ali_to;
+      float dc = 0.f;
+      for (int pos = d.ienv; pos <= d.jenv; ++pos) { const float v = logf(null2[dsq[pos - 1]]); n2sc[pos] = v; dc += v; }
+      d.domcorrection = dc;
+      h.dom.push_back(d);
+    }
+    if (nregions[q] == 0 || nenv == 0 || h.dom.empty()) continue;
+    float seqbias = 0.f;
+    for (int i = 0; i <= L; ++i) seqbias += n2sc[i];
+    seqbias = flogsum(0.0f, logf(kOmega) + seqbias);
+    float pre_score = (float)((double)(c.fwdsc - nullsc) / kLn2);
+    float seq_score = (float)((double)(c.fwdsc - (nullsc + seqbias)) / kLn2);
+    float sum_score = 0.f; int Ld = 0; seqbias = 0.f;
+    for (auto &d : h.dom) if (d.envsc - d.domcorrection > 0.0f) { sum_score += d.envsc; Ld += d.jenv - d.ienv + 1; seqbias += d.domcorrection; }
+    seqbias = flogsum(0.0f, logf(kOmega) + seqbias);
+    sum_score += (float)((double)(L - Ld) * log((double)((float)L / (float)(L + 3))));
+    const float pre2 = (float)((double)(sum_score - nullsc) / kLn2);
+    sum_score = (float)((double)(sum_score - (nullsc + seqbias)) / kLn2);
+    if (Ld > 0 && sum_score > seq_score) { seq_score = sum_score; pre_score = pre2; }
+    h.pre_score = pre_score; h.score = seq_score;
+    h.lnP = exp_logsurv(seq_score, hm.evparam[4], hm.evparam[5]);
+    for (auto &d : h.dom) {
+      const int ld = d.jenv - d.ienv + 1;
+      const float bs = d.envsc + (float)((double)(L - ld) * log((double)((float)L / (float)(L + 3))));
+      d.dombias = flogsum(0.0f, logf(kOmega) + d.domcorrection);
+      d.bitscore = (float)((double)(bs - (nullsc + d.dombias)) / kLn2);
+      d.lnP = exp_logsurv(d.bitscore, hm.evparam[4], hm.evparam[5]);
+      d.reported = false;
+    }
+    by_bin_model[{s->seq_bin[c.r.seq], c.r.model}].push_back(std::move(h));
+  }
+  // rows, bin by bin, models in the bin's own order
+  hits->nbins = nbins;
+  hits->bin_row_off.assign(nbins + 1, 0);
+  for (uint32_t b = 0; b < nbins; ++b) {
+    hits->bin_row_off[b] = hits->seq.size();
+    const double Z = (double)(s->bin_off[b + 1] - s->bin_off[b]);
+    for (uint32_t m : bin_models[b]) {
+      auto it = by_bin_model.find({b, m});
+      if (it == by_bin_model.end()) continue;
+      std::vector<Hit> hs = it->second;      // copy: a model listed twice in one bin reports twice, as two records in the HMM file would
+      std::sort(hs.begin(), hs.end(), [&](const Hit &a, const Hit &c) {
+        if (a.lnP != c.lnP) return a.lnP < c.lnP;
+        const int cmp = s->names[a.seq].compare(s->names[c.seq]);
+        if (cmp) return cmp < 0;
+        return a.seq < c.seq;
+      });
+      int nrep = 0;
+      for (auto &h : hs) if (exp(h.lnP) * Z <= E) ++nrep;
+      const double domZ = (double)nrep;
+      for (auto &h : hs) {
+        if (!(exp(h.lnP) * Z <= E)) continue;
+        for (auto &d : h.dom) { d.reported = exp(d.lnP) * domZ <= domE; if (d.reported) h.nreported++; }
+        for (size_t d = 1; d < h.dom.size(); ++d) {
+          Domain &a = h.dom[d - 1], &c = h.dom[d];
+          if (a.reported && c.reported && a.ali_from == c.ali_from && a.ali_to == c.ali_to && a.hmm_from == c.hmm_from && a.hmm_to == c.hmm_to) {
+            Domain &w = (a.bitscore >= c.bitscore) ? c : a; w.reported = false; h.nreported--;
+          }
+        }
+        int nd = 0;
+        for (auto &d : h.dom) if (d.reported) {
+          ++nd;
+          hits->seq.push_back(h.seq); hits->model.push_back(h.model); hits->tlen.push_back(h.L); hits->qlen.push_back(p->hmm[h.model].M);
+          hits->full_evalue.push_back(exp(h.lnP) * Z); hits->full_score.push_back(h.score); hits->full_bias.push_back(h.pre_score - h.score);
+          hits->dom_idx.push_back(nd); hits->ndom.push_back(h.nreported);
+          hits->c_evalue.push_back(exp(d.lnP) * domZ); hits->i_evalue.push_back(exp(d.lnP) * Z);
+          hits->dom_score.push_back(d.bitscore); hits->dom_bias.push_back((float)((double)d.dombias * kLog2R));
+          hits->hmm_from.push_back(d.hmm_from); hits->hmm_to.push_back(d.hmm_to); hits->ali_from.push_back(d.ali_from); hits->ali_to.push_back(d.ali_to);
+          hits->env_from.push_back(d.ienv); hits->env_to.push_back(d.jenv);
+          hits->acc.push_back((float)((double)d.oasc / (1.0 + fabs((double)(float)(d.jenv - d.ienv)))));
+        }
+      }
+    }
+  }
+  hits->bin_row_off[nbins] = hits->seq.size();
+  st.ms_host = now_ms() - t_host0;
+  st.ms_total = now_ms() - t_start;
+}
+
+extern "C" int ckm_search(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, const uint32_t *model_off,
+                          const uint32_t *model_idx, double E, double domE, ckm_hits **out) {
+  return guarded([&] {
+    if (!ctx || !p || !s || !out) throw Error(CKM_EINVAL, "NULL argument");
+    if ((model_off == nullptr) != (model_idx == nullptr)) throw Error(CKM_EINVAL, "model_off and model_idx must both be given or both be NULL");
+    *out = nullptr;
+    std::unique_ptr<ckm_hits> h(new ckm_hits());
+    do_search(ctx, p, s, model_off, model_idx, E, domE, h.get());
+    *out = h.release();
+  });
+}
+
+extern "C" int ckm_hits_columns(const ckm_hits *h, ckm_hit_columns *o) {
+  if (!h || !o) { set_last_error("NULL argument"); return CKM_EINVAL; }
+  o->n = h->seq.size(); o->nbins = h->nbins; o->bin_row_off = h->bin_row_off.data();
+  o->seq = h->seq.data(); o->model = h->model.data(); o->tlen = h->tlen.data(); o->qlen = h->qlen.data();
+  o->full_evalue = h->full_evalue.data(); o->full_score = h->full_score.data(); o->full_bias = h->full_bias.data();
+  o->dom_idx = h->dom_idx.data(); o->ndom = h->ndom.data(); o->c_evalue = h->c_evalue.data(); o->i_evalue = h->i_evalue.data();
+  o->dom_score = h->dom_score.data(); o->dom_bias = h->dom_bias.data();
+  o->hmm_from = h->hmm_from.data(); o->hmm_to = h->hmm_to.data(); o->ali_from = h->ali_from.data(); o->ali_to = h->ali_to.data();
+  o->env_from = h->env_from.data(); o->env_to = h->env_to.data(); o->acc = h->acc.data();
+  return CKM_OK;
+}
+
+extern "C" void ckm_hits_free(ckm_hits *h) { delete h; }
+
+extern "C" int ckm_last_search_stats(const ckm_ctx *ctx, ckm_search_stats *out) {
+  if (!ctx || !out) { set_last_error("NULL argument"); return CKM_EINVAL; }
+  *out = ctx->stats;
+  return CKM_OK;
+}
+
+// ---- domtblout writer -------------------------------------------------------------------------------
+extern "C" int ckm_hits_write_domtblout(const ckm_hits *h, const ckm_profiles *p, const ckm_seqs *s, uint32_t bin, const char *path) {
+  return guarded([&] {
+    if (!h || !p || !s || !path) throw Error(CKM_EINVAL, "NULL argument");
+    if (bin >= h->nbins) throw Error(CKM_EINVAL, "bin out of range");
+    FILE *f = fopen(path, "w");
+    if (!f) throw Error(CKM_EIO, std::string("cannot write ") + path);
+    const uint64_t r0 = h->bin_row_off[bin], r1 = h->bin_row_off[bin + 1];
+    int tnamew = 20, qnamew = 20, taccw = 10, qaccw = 10;
+    for (uint64_t r = r0; r < r1; ++r) {
+      tnamew = std::max(tnamew, (int)s->names[h->seq[r]].size());
+      const HostHMM &hm = p->hmm[h->model[r]];
+      qnamew = std::max(qnamew, (int)hm.name.size());
+      if (hm.has_acc) qaccw = std::max(qaccw, (int)hm.acc.size());
+    }
+    fprintf(f, "#%*s %22s %40s %11s %11s %11s\n", tnamew + qnamew - 1 + 15 + taccw + qaccw, "", "--- full sequence ---",
+            "-------------- this domain -------------", "hmm coord", "ali coord", "env coord");
+    fprintf(f, "#%-*s %-*s %5s %-*s %-*s %5s %9s %6s %5s %3s %3s %9s %9s %6s %5s %5s %5s %5s %5s %5s %5s %4s %s\n", tnamew - 1, " target name", taccw,
+            "accession", "tlen", qnamew, "query name", qaccw, "accession", "qlen", "E-value", "score", "bias", "#", "of", "c-Evalue", "i-Evalue",
+            "score", "bias", "from", "to", "from", "to", "from", "to", "acc", "description of target");
+    auto dashes = [](int n) { return std::string((size_t)n, '-'); };
+    fprintf(f, "#%s %s %s %s %s ", dashes(tnamew - 1).c_str(), dashes(taccw).c_str(), dashes(5).c_str(), dashes(qnamew).c_str(), dashes(qaccw).c_str());
+    fprintf(f, "----- --------- ------ ----- --- --- --------- --------- ------ ----- ----- ----- ----- ----- ----- ----- ---- ---------------------\n");
+    for (uint64_t r = r0; r < r1; ++r) {
+      const HostHMM &hm = p->hmm[h->model[r]];
+      const std::string &desc = s->descs[h->seq[r]];
+      fprintf(f, "%-*s %-*s %5d %-*s %-*s %5d %9.2g %6.1f %5.1f %3d %3d %9.2g %9.2g %6.1f %5.1f %5d %5d %5ld %5ld %5ld %5ld %4.2f %s\n", tnamew,
+              s->names[h->seq[r]].c_str(), taccw, "-", h->tlen[r], qnamew, hm.name.c_str(), qaccw, (hm.has_acc && !hm.acc.empty()) ? hm.acc.c_str() : "-",
+              h->qlen[r], h->full_evalue[r], h->full_score[r], h->full_bias[r], h->dom_idx[r], h->ndom[r], h->c_evalue[r], h->i_evalue[r], h->dom_score[r],
+              h->dom_bias[r], h->hmm_from[r], h->hmm_to[r], (long)h->ali_from[r], (long)h->ali_to[r], (long)h->env_from[r], (long)h->env_to[r], h->acc[r],
+              desc.empty() ? "-" : desc.c_str());
+    }
+    fprintf(f, "#\n# Program:         hmmsearch\n# Pipeline mode:   SEARCH\n# [ok]\n");
+    if (fclose(f) != 0) throw Error(CKM_EIO, std::string("error closing ") + path);
+  });
+}
+
+// ---- diagnostics -------------------------------------------------------------------------------------
+extern "C" int ckm_debug_stages(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, const uint32_t *model, const uint32_t *seq,
+                                uint32_t npairs, ckm_stage_scores *out) {
+  return guarded([&] {
+    if (!ctx || !p || !s || !model || !seq || !out) throw Error(CKM_EINVAL, "NULL argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    const DevModel *dm = p->d_models.as<DevModel>();
+    const LenEntry *lt = s->d_lentab.as<LenEntry>();
+    const uint8_t *res = s->d_res.as<uint8_t>();
+    const uint64_t *off = s->d_off.as<uint64_t>();
+    const int32_t *dlen = s->d_len.as<int32_t>();
+    memset(out, 0, sizeof(*out) * npairs);
+    // SSV: one block per pair (count = 1)
+    std::vector<SsvBlockWork> work(npairs); std::vector<uint32_t> ids(seq, seq + npairs);
+    std::map<int, std::vector<uint32_t>> byQ;
+    for (uint32_t i = 0; i < npairs; ++i) {
+      if (model[i] >= p->hmm.size() || seq[i] >= s->nseq) throw Error(CKM_EINVAL, "pair index out of range");
+      work[i].model = model[i]; work[i].list_start = i; work[i].count = 1; work[i].pair_start = i; byQ[p->prof[model[i]].ssvQ].push_back(i);
+    }
+    std::vector<SsvBlockWork> sorted; std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;
+    for (auto &kv : byQ) { groups.push_back({kv.first, {sorted.size(), kv.second.size()}}); for (uint32_t i : kv.second) sorted.push_back(work[i]); }
+    ctx->work.ensure(npairs * sizeof(SsvBlockWork)); ctx->idx.ensure(npairs * 4); ctx->maxv.ensure(npairs * 2 + 64);
+    HIPCHK(hipMemcpy(ctx->work.p, sorted.data(), npairs * sizeof(SsvBlockWork), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->idx.p, ids.data(), npairs * 4, hipMemcpyHostToDevice));
+    for (auto &g : groups)
+      if (launch_ssv(g.first, (int)g.second.second, ssv_threads_for(g.first), ctx->stream, ctx->work.as<SsvBlockWork>() + g.second.first, dm, res, off, dlen,
+                     ctx->idx.as<uint32_t>(), ctx->maxv.as<int16_t>()))
+        throw Error(CKM_ERANGE, "no SSV kernel instance");
+    HIPCHK(hipGetLastError());
+    std::vector<int16_t> maxv(npairs);
+    HIPCHK(hipMemcpyAsync(maxv.data(), ctx->maxv.p, npairs * 2, hipMemcpyDeviceToHost, ctx->stream));
+    // full MSV on every pair
+    std::vector<PairRec> pr(npairs);
+    for (uint32_t i = 0; i < npairs; ++i) { pr[i].model = model[i]; pr[i].seq = seq[i]; pr[i].usc = 0; pr[i].filtersc = 0; }
+    ctx->cand.ensure(npairs * sizeof(PairRec)); ctx->fullx.ensure(npairs * 4); ctx->fullu.ensure(npairs * 4); ctx->raw.ensure(npairs * 12);
+    HIPCHK(hipMemcpyAsync(ctx->cand.p, pr.data(), npairs * sizeof(PairRec), hipMemcpyHostToDevice, ctx->stream));
+    launch_msv_full(ctx->stream, ctx->cand.as<PairRec>(), npairs, dm, lt, res, off, dlen, ctx->fullx.as<int32_t>(), ctx->fullu.as<float>(), p->maxMp);
+    launch_bias(ctx->stream, ctx->cand.as<PairRec>(), npairs, dm, lt, res, off, dlen, ctx->raw.as<float>());
+    HIPCHK(hipGetLastError());
+    std::vector<int32_t> xJ(npairs); std::vector<float> usc(npairs), raw(npairs * 3);
+    HIPCHK(hipMemcpyAsync(xJ.data(), ctx->fullx.p, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(usc.data(), ctx->fullu.p, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(raw.data(), ctx->raw.p, npairs * 12, hipMemcpyDeviceToHost, ctx->stream));
+    // Viterbi on every pair
+    std::map<int, std::vector<uint32_t>> vq;
+    for (uint32_t i = 0; i < npairs; ++i) vq[p->prof[model[i]].vitQ].push_back(i);
+    std::vector<uint32_t> flat; std::vector<std::pair<int, std::pair<size_t, size_t>>> vg;
+    for (auto &kv : vq) { vg.push_back({kv.first, {flat.size(), kv.second.size()}}); flat.insert(flat.end(), kv.second.begin(), kv.second.end()); }
+    ctx->fbidx.ensure(npairs * 4); ctx->vitx.ensure(npairs * 4); ctx->vits.ensure(npairs * 4);
+    HIPCHK(hipMemcpyAsync(ctx->fbidx.p, flat.data(), npairs * 4, hipMemcpyHostToDevice, ctx->stream));
+    for (auto &g : vg)
+      if (launch_vit(g.first, ctx->stream, ctx->cand.as<PairRec>(), ctx->fbidx.as<uint32_t>() + g.second.first, (uint32_t)g.second.second, dm, lt, res, off, dlen,
+                     ctx->vitx.as<int32_t>(), ctx->vits.as<float>()))
+        throw Error(CKM_ERANGE, "no Viterbi kernel instance");
+    HIPCHK(hipGetLastError());
+    std::vector<int32_t> vx(npairs); std::vector<float> vs(npairs);
+    HIPCHK(hipMemcpyAsync(vx.data(), ctx->vitx.p, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(vs.data(), ctx->vits.p, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // Forward parser on every pair
+    FbBatch fb; uint64_t pos = 0;
+    for (uint32_t i = 0; i < npairs; ++i) {
+      const int L = s->len[seq[i]];
+      FbWork w; memset(&w, 0, sizeof(w));
+      w.model = model[i]; w.seq = seq[i]; w.i0 = 0; w.Ld = L; w.Lcfg = L; w.multihit = 1; w.full = 0; w.slot = i;
+      w.xs_off = pos; pos += ((uint64_t)(L + 1) * 6 + 31) & ~(uint64_t)31;
+      w.aux_off = pos; pos += ((uint64_t)(L + 1) * 3 + 31) & ~(uint64_t)31;
+      fb.work.push_back(w);
+    }
+    ctx->ws.ensure(pos * 4 + 256);
+    run_fb(ctx, p, s, fb, true, false, false, nullptr);
+    EventIndex ei; ei.build(fb.events, npairs);
+    for (uint32_t i = 0; i < npairs; ++i) {
+      const int L = s->len[seq[i]];
+      const LenEntry &le = s->lentab[L];
+      ckm_stage_scores &o = out[i];
+      o.ssv_maxv = maxv[i]; o.msv_xJ = xJ[i]; o.msv_sc = usc[i]; o.null_sc = le.nullsc;
+      const float p1 = (float)L / (float)(L + 1);
+      const float nullsc = (float)(log((double)raw[(size_t)i * 3]) + (double)raw[(size_t)i * 3 + 1] * kLn2);
+      o.bias_sc = nullsc + (float)L * logf(p1) + logf(1.0f - p1);
+      o.vit_xC = vx[i]; o.vit_sc = vs[i];
+      o.fwd_xC = fb.fout[i].xC; o.fwd_nscale = fb.fout[i].nscale;
+      o.fwd_sc = finish_forward(fb.fout[i].xC, le.move_m, ei.scales(i));
+    }
+  });
+}
+
+extern "C" int ckm_debug_envelopes(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, const uint32_t *model, const uint32_t *seq,
+                                   const int32_t *ienv, const int32_t *jenv, uint32_t n, ckm_envelope_result *out) {
+  return guarded([&] {
+    if (!ctx || !p || !s || !model || !seq || !ienv || !jenv || !out) throw Error(CKM_EINVAL, "NULL argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<EnvReq> req(n); std::vector<EnvRes> res;
+    for (uint32_t i = 0; i < n; ++i) {
+      if (model[i] >= p->hmm.size() || seq[i] >= s->nseq || ienv[i] < 1 || jenv[i] > s->len[seq[i]] || jenv[i] < ienv[i]) throw Error(CKM_EINVAL, "bad envelope");
+      req[i] = {model[i], seq[i], ienv[i], jenv[i]};
+    }
+    rescore_envelopes(ctx, p, s, req, res);
+    for (uint32_t i = 0; i < n; ++i) {
+      out[i].envsc = res[i].envsc; out[i].oasc = res[i].oasc; out[i].fwd_xC = res[i].xC; out[i].nscale = res[i].nscale; out[i].ok = res[i].ok;
+      for (int x = 0; x < 20; ++x) out[i].null2[x] = res[i].null2[x];
+      out[i].hmm_from = res[i].hmm_from; out[i].hmm_to = res[i].hmm_to; out[i].ali_from = res[i].ali_from; out[i].ali_to = res[i].ali_to;
+    }
+  });
+}

@@ -1,0 +1,84 @@
+// ckm_internal.h -- shared declarations of libcheckm_hip.so (not part of the ABI).
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include "../../include/checkm_hip.h"
+
+namespace ckm {
+
+constexpr int K = 20;       // canonical residues
+constexpr int KP = 29;      // HMMER amino alphabet "ACDEFGHIKLMNPQRSTVWY-BJZOUX*~"
+constexpr int NROWS = 30;   // emission rows held on the device: 29 symbols + 1 all-impossible pad row
+constexpr int PADCODE = 29;
+constexpr int NL = 64;      // lanes of the canonical float order (one wavefront)
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+void set_last_error(const std::string &m);
+
+// One record of a HMMER3/f file, probabilities (not -ln p).
+struct HostHMM {
+  std::string name, acc, desc;
+  bool has_acc = false, has_desc = false;
+  int M = 0;
+  std::vector<float> t, mat, ins;    // [(M+1)*7], [(M+1)*20], [(M+1)*20]
+  float compo[K] = {0};
+  bool has_compo = false;
+  float evparam[6] = {0};
+  int stats_mask = 0;
+  float ga[2] = {0, 0}, tc[2] = {0, 0}, nc[2] = {0, 0};
+  bool has_ga = false, has_tc = false, has_nc = false;
+};
+
+std::vector<HostHMM> read_hmm_file(const std::string &path);
+
+// Search profile in the three score systems, host copy.
+struct HostProfile {
+  int M = 0;
+  // MSV / SSV (unsigned byte costs, 1/3 bit)
+  int base_b = 190, bias_b = 0, tbm_b = 0, tec_b = 0;
+  float scale_b = 0;
+  std::vector<uint8_t> rbv;       // [KP][M+1]
+  int ssvQ = 0;                   // packed i16x2 registers per lane (16 lanes per sequence): ceil(M/32) rounded to an instantiated size
+  std::vector<int16_t> ssv_tbl;   // LDS image: [NROWS][ssvQg][16 lanes][4 regs][2 halves]
+  // Viterbi filter (signed words, 1/500 bit); contiguous k, padded to vitQ*64
+  int vitQ = 0;
+  float scale_w = 0; int base_w = 12000; int wE_loop = 0, wE_move = 0;
+  std::vector<int16_t> rwv;       // [NROWS][Mp]
+  std::vector<int16_t> wtr;       // [8][Mp]: BM MM IM DM (into k) MD MI II (from k) ; [7] unused
+  std::vector<int32_t> wddc;      // [Mp+1] prefix sums of DD (C(k)), see kernels
+  // Forward/Backward odds, canonical padded layout (fbQ*64)
+  int fbQ = 0;
+  std::vector<float> rf;          // [NROWS][Mp]
+  std::vector<float> ftr;         // [8][Mp]: BM MM IM DM MI II MD DD
+  float fE_loop = 0.5f, fE_move = 0.5f;
+  // bias filter
+  float bt00, bt01, bt10, bt11, bpi0, bpi1;
+  float beo1[NROWS];
+  // score-space thresholds equivalent to P<=F1 / P<=F2 / P<=F3 (smallest passing float)
+  float thr_msv_f1, thr_msv_f2, thr_vit_f2, thr_fwd_f3;
+};
+
+HostProfile configure_profile(const HostHMM &h);
+int  canon_Q(int M);         // canonical lanes-blocked Q for the float DP
+int  ssv_Q_for(int M);       // instantiated SSV register count covering M
+
+// length-dependent specials (all host libm, shared by every stage)
+struct LenCfg { float loop, move; int w_move; int tjb_b; float nullsc; float p1; float bias_tail; };
+LenCfg len_config(const HostProfile &p, int L, bool multihit);
+
+void digitize(const char *text, uint64_t n, uint8_t *dsq);
+
+// statistics
+double gumbel_surv(double x, double mu, double lambda);
+double exp_surv(double x, double mu, double lambda);
+double exp_logsurv(double x, double mu, double lambda);
+float  flogsum(float a, float b);
+
+}  // namespace ckm

@@ -1,0 +1,95 @@
+// dev_types.h -- plain structs shared by host orchestration and the gfx950 kernels.
+#pragma once
+#include <cstdint>
+
+namespace ckm {
+
+struct DevModel {
+  int32_t M, ssvQ, fbQ, pad0;
+  // MSV
+  int32_t base_b, bias_b, tbm_b, tec_b;
+  float   scale_b;
+  // Viterbi filter
+  float   scale_w; int32_t base_w, wE_loop, wE_move;
+  // Forward
+  float   fE_loop, fE_move;
+  // bias filter
+  float   bt00, bt01, bt10, bt11, bpi0, bpi1;
+  float   beo1[30];
+  // filter thresholds (score space)
+  float   thr_msv_f1, thr_msv_f2, thr_vit_f2, thr_fwd_f3;
+  // tables in HBM
+  const int16_t *ssv_tbl;   // [30][Qg][16][8]
+  const uint8_t *rbv;       // [29][M+1]
+  const int16_t *rwv;       // [30][Mp]
+  const int16_t *wtr;       // [8][Mp]
+  const int32_t *wddc;      // [Mp+1]
+  const float   *rf;        // [30][Mp]
+  const float   *ftr;       // [8][Mp]
+};
+
+// length-dependent specials, indexed by sequence length L
+struct LenEntry {
+  float   loop_m, move_m;   // multihit N/C/J loop, move
+  float   loop_u, move_u;   // unihit
+  float   nullsc;           // null1
+  float   bias_tail;        // L*logf(p1) + logf(1-p1)
+  int32_t w_move;           // Viterbi-filter N/C/J move word (multihit)
+  int32_t tjb_b;            // MSV tjb byte cost
+};
+
+struct SsvBlockWork {        // one workgroup of the SSV kernel
+  uint32_t model;
+  uint32_t list_start;       // first entry of lists[] (sequence ids, length-sorted)
+  uint32_t count;            // sequences in this block
+  uint32_t pair_start;       // first output slot
+};
+
+struct PairRec {             // a (model, sequence) pair travelling down the cascade
+  uint32_t model, seq;
+  float    usc;              // MSV score, nats (+inf on overflow)
+  float    filtersc;         // bias-filter null score
+};
+
+struct ScaleEvent {          // one Forward rescale: pair slot, row, factor
+  uint32_t slot; int32_t row; float scale; uint32_t pad;
+};
+
+struct FwdOut {              // per pair slot
+  float xC; int32_t nscale;
+};
+
+struct FbWork {              // one Forward/Backward/OA work item (whole sequence, or one envelope)
+  uint32_t model, seq;
+  int32_t  i0, Ld, Lcfg, multihit;     // subsequence [i0, i0+Ld) of the target; length model configured for Lcfg
+  uint64_t xs_off;                     // float offset: forward special rows (Ld+1)*6  [E N J B C scale]
+  uint64_t aux_off;                    // float offset: parser mode -> decoding terms (Ld+1)*3 [bt et njcp];
+                                       // full mode -> (Ld+1)*3 [ppN ppJ ppC], then 128B-aligned (Ld+1)*5 [oN oB oE oJ oC]
+  uint64_t mxf_off, mxb_off;           // float offsets of the (Ld+1) x 3*Mp matrices (full mode only)
+  uint32_t slot, full;
+};
+
+struct FinishArgs {
+  const DevModel *models; const LenEntry *lentab; const int32_t *seq_len; const uint32_t *lists;
+  const SsvBlockWork *work;            // the table the SSV launches used (one entry per SSV block)
+  const int16_t *maxv;
+  PairRec *survivors; uint32_t *nsurv; uint32_t cap_surv;
+  PairRec *noresult;  uint32_t *nnores; uint32_t cap_nores;
+};
+
+struct EnvWork {             // one envelope to rescore
+  uint32_t model, seq;
+  int32_t  ienv, jenv;       // 1-based inclusive
+  uint64_t mx_off;           // float offset of this envelope's matrices in the workspace
+  uint64_t xs_off;           // float offset of its special rows
+};
+
+struct EnvOut {
+  float   xC; int32_t nscale;
+  float   oasc;
+  int32_t hmm_from, hmm_to, ali_from, ali_to;
+  int32_t range_err;
+  float   null2[20];
+};
+
+}  // namespace ckm

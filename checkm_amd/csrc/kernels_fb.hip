@@ -1,0 +1,504 @@
+// kernels_fb.hip -- float32 Forward / Backward / posterior decoding / null2 / optimal-accuracy
+// kernels, gfx950 only.  One wavefront per (model, sequence) pair or per envelope; lane z owns the
+// Q consecutive model nodes c = z*Q+q ("canonical 64-lane blocked order"), so
+// every order-dependent float reduction has ONE defined evaluation order:
+//   D->D chain   lane-local affine map (a,b), Kogge-Stone over lanes with __shfl_up, lane-local replay
+//   E-state sum  lane-local fold over q, then xor butterfly 32,16,8,4,2,1
+// Compiled with -ffp-contract=off: no fused multiply-add may be formed.  No transcendental is
+// evaluated on the device; rescale factors go back to the host as events and are logged there.
+// Reference stage replaced: Forward/Backward/domain definition of the hmmsearch per-target pipeline
+// (process launched at checkm/hmmer.py:70).
+#include <hip/hip_runtime.h>
+#include "dev_types.h"
+
+namespace ckm {
+
+constexpr float NEGINF_F = -__builtin_inff();
+
+template <int Q>
+struct Tr {   // transition odds of this lane's cells, LDS resident ([8][Mp]: BM MM IM DM MI II MD DD)
+  const float *t; int c0;
+  __device__ __forceinline__ float BM(int q) const { return t[0 * Q * 64 + c0 + q]; }
+  __device__ __forceinline__ float MM(int q) const { return t[1 * Q * 64 + c0 + q]; }
+  __device__ __forceinline__ float IM(int q) const { return t[2 * Q * 64 + c0 + q]; }
+  __device__ __forceinline__ float DM(int q) const { return t[3 * Q * 64 + c0 + q]; }
+  __device__ __forceinline__ float MI(int q) const { return t[4 * Q * 64 + c0 + q]; }
+  __device__ __forceinline__ float II(int q) const { return t[5 * Q * 64 + c0 + q]; }
+  __device__ __forceinline__ float MD(int q) const { return t[6 * Q * 64 + c0 + q]; }
+  __device__ __forceinline__ float DD(int q) const { return t[7 * Q * 64 + c0 + q]; }
+};
+
+template <int Q>
+__device__ __forceinline__ void load_tr(float *lds, const float *ftr, int lane) {
+  for (int i = lane; i < 8 * Q * 64; i += 64) lds[i] = ftr[i];
+  __builtin_amdgcn_wave_barrier();
+  __syncthreads();
+}
+
+__device__ __forceinline__ float wave_sum(float s) {
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) s = s + __shfl_xor(s, w);
+  return s;
+}
+
+// ---- one Forward row --------------------------------------------------------------------------
+template <int Q>
+__device__ __forceinline__ float fwd_row(float (&Mv)[Q], float (&Iv)[Q], float (&Dv)[Q], const Tr<Q> &tr,
+                                         const float *__restrict__ rfx, float xB, int lane) {
+  float mpi = __shfl_up(Mv[Q - 1], 1), ipi = __shfl_up(Iv[Q - 1], 1), dpi = __shfl_up(Dv[Q - 1], 1);
+  if (lane == 0) { mpi = 0.f; ipi = 0.f; dpi = 0.f; }
+  float Mn[Q], In[Q], Dn[Q], md[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const float mp = q ? Mv[q - 1] : mpi, ip = q ? Iv[q - 1] : ipi, dp = q ? Dv[q - 1] : dpi;
+    float sv = xB * tr.BM(q);
+    sv = sv + mp * tr.MM(q);
+    sv = sv + ip * tr.IM(q);
+    sv = sv + dp * tr.DM(q);
+    Mn[q] = sv * rfx[q];
+    const float a = Mv[q] * tr.MI(q), b = Iv[q] * tr.II(q);
+    In[q] = a + b;
+    md[q] = Mn[q] * tr.MD(q);
+  }
+  float a = 1.0f, b = 0.0f;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) { const float dd = tr.DD(q); const float t = dd * b; b = md[q] + t; a = dd * a; }
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    const float oa = __shfl_up(a, s), ob = __shfl_up(b, s);
+    if (lane >= s) { const float t = a * ob; b = b + t; a = a * oa; }
+  }
+  float d = __shfl_up(b, 1);
+  if (lane == 0) d = 0.0f;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) { Dn[q] = d; const float t = tr.DD(q) * d; d = md[q] + t; }
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) { s = s + Mn[q]; s = s + Dn[q]; }
+  s = wave_sum(s);
+#pragma unroll
+  for (int q = 0; q < Q; ++q) { Mv[q] = Mn[q]; Iv[q] = In[q]; Dv[q] = Dn[q]; }
+  return s;
+}
+
+template <int Q>
+__global__ void __launch_bounds__(64) fwd_kernel(const FbWork *__restrict__ work, const uint32_t *__restrict__ idx,
+                                                 const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
+                                                 const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
+                                                 float *__restrict__ ws, FwdOut *__restrict__ out,
+                                                 ScaleEvent *__restrict__ events, uint32_t *__restrict__ nevents, uint32_t cap_events) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int Mp = Q * 64;
+  const int lane = threadIdx.x;
+  const FbWork w = work[idx[blockIdx.x]];
+  const DevModel &md = models[w.model];
+  load_tr<Q>(lds, md.ftr, lane);
+  Tr<Q> tr{lds, lane * Q};
+  const uint8_t *rp = res + seq_off[w.seq] + w.i0;
+  const LenEntry le = lentab[w.Lcfg];
+  const float loop = w.multihit ? le.loop_m : le.loop_u, move = w.multihit ? le.move_m : le.move_u;
+  const float Eloop = w.multihit ? md.fE_loop : 0.0f, Emove = w.multihit ? md.fE_move : 1.0f;
+  float Mv[Q], Iv[Q], Dv[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) Mv[q] = Iv[q] = Dv[q] = 0.f;
+  float xN = 1.0f, xB = xN * move, xE = 0.f, xJ = 0.f, xC = 0.f;
+  int nscale = 0;
+  float *xs = ws + w.xs_off;
+  float *mx = w.full ? ws + w.mxf_off : nullptr;
+  if (lane == 0) { xs[0] = 0.f; xs[1] = xN; xs[2] = 0.f; xs[3] = xB; xs[4] = 0.f; xs[5] = 1.0f; }
+  if (mx) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { mx[lane * Q + q] = 0.f; mx[Mp + lane * Q + q] = 0.f; mx[2 * Mp + lane * Q + q] = 0.f; }
+  }
+  for (int i = 1; i <= w.Ld; ++i) {
+    const float *rfx = md.rf + (size_t)rp[i - 1] * Mp + lane * Q;
+    xE = fwd_row<Q>(Mv, Iv, Dv, tr, rfx, xB, lane);
+    xN = xN * loop;
+    { const float a = xC * loop, b = xE * Emove; xC = a + b; }
+    { const float a = xJ * loop, b = xE * Eloop; xJ = a + b; }
+    { const float a = xJ * move, b = xN * move; xB = a + b; }
+    float scale = 1.0f;
+    if (xE > 1.0e4f) {
+      const float inv = 1.0f / xE;
+      xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) { Mv[q] *= inv; Iv[q] *= inv; Dv[q] *= inv; }
+      scale = xE; xE = 1.0f; ++nscale;
+      if (lane == 0) {
+        const uint32_t e = atomicAdd(nevents, 1u);
+        if (e < cap_events) { ScaleEvent ev; ev.slot = w.slot; ev.row = i; ev.scale = scale; ev.pad = 0; events[e] = ev; }
+      }
+    }
+    if (lane == 0) { float *r = xs + (size_t)i * 6; r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; r[5] = scale; }
+    if (mx) {
+      float *r = mx + (size_t)i * 3 * Mp + lane * Q;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) { r[q] = Mv[q]; r[Mp + q] = Iv[q]; r[2 * Mp + q] = Dv[q]; }
+    }
+  }
+  if (lane == 0) { out[w.slot].xC = xC; out[w.slot].nscale = nscale; }
+}
+
+// ---- Backward -----------------------------------------------------------------------------------
+// D chain, reverse direction: D[c] = av[c] + DD[c]*D[c+1]
+template <int Q>
+__device__ __forceinline__ void bwd_dchain(float (&Dn)[Q], const float (&av)[Q], const Tr<Q> &tr, int lane) {
+  float a = 1.0f, b = 0.0f;
+#pragma unroll
+  for (int q = Q - 1; q >= 0; --q) { const float dd = tr.DD(q); const float t = dd * b; b = av[q] + t; a = dd * a; }
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    const float oa = __shfl_down(a, s), ob = __shfl_down(b, s);
+    if (lane + s < 64) { const float t = a * ob; b = b + t; a = a * oa; }
+  }
+  float d = __shfl_down(b, 1);
+  if (lane == 63) d = 0.0f;
+#pragma unroll
+  for (int q = Q - 1; q >= 0; --q) { const float t = tr.DD(q) * d; d = av[q] + t; Dn[q] = d; }
+}
+
+template <int Q>
+__global__ void __launch_bounds__(64) bwd_kernel(const FbWork *__restrict__ work, const uint32_t *__restrict__ idx,
+                                                 const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
+                                                 const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
+                                                 float *__restrict__ ws, const FwdOut *__restrict__ fout, int32_t *__restrict__ range_err) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int Mp = Q * 64;
+  const int lane = threadIdx.x;
+  const FbWork w = work[idx[blockIdx.x]];
+  const DevModel &md = models[w.model];
+  load_tr<Q>(lds, md.ftr, lane);
+  Tr<Q> tr{lds, lane * Q};
+  const uint8_t *rp = res + seq_off[w.seq] + w.i0;
+  const LenEntry le = lentab[w.Lcfg];
+  const float loop = w.multihit ? le.loop_m : le.loop_u, move = w.multihit ? le.move_m : le.move_u;
+  const float Eloop = w.multihit ? md.fE_loop : 0.0f, Emove = w.multihit ? md.fE_move : 1.0f;
+  const float *xs = ws + w.xs_off;
+  float *aux = ws + w.aux_off;
+  const float *fm = w.full ? ws + w.mxf_off : nullptr;
+  float *bm = w.full ? ws + w.mxb_off : nullptr;
+  const int L = w.Ld;
+  const float invZ = 1.0f / (fout[w.slot].xC * move);
+  // boundary transition odds of the right-hand neighbour cell (c+1)
+  float tIMn[Q], tMMn[Q], tDMn[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int c = lane * Q + q + 1;
+    tMMn[q] = (c < Mp) ? lds[1 * Mp + c] : 0.f; tIMn[q] = (c < Mp) ? lds[2 * Mp + c] : 0.f; tDMn[q] = (c < Mp) ? lds[3 * Mp + c] : 0.f;
+  }
+  float Mv[Q], Iv[Q], Dv[Q];
+  // row L
+  float xC = move, xE = xC * Emove, xJ = 0.f, xB = 0.f, xN = 0.f;
+  {
+    float av[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) av[q] = xE + 0.0f;
+    bwd_dchain<Q>(Dv, av, tr, lane);
+    float dnx = __shfl_down(Dv[0], 1); if (lane == 63) dnx = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const float dn1 = (q + 1 < Q) ? Dv[q + 1] : dnx;
+      float m = xE + 0.0f; m = m + 0.0f; m = m + tr.MD(q) * dn1;
+      Mv[q] = m; Iv[q] = 0.f;
+    }
+  }
+  bool bad = false;
+  auto emit = [&](int r) {
+    // decoding terms that become available once backward row r is final
+    if (w.full) {
+      if (r >= 1) {
+        const float *f = fm + (size_t)r * 3 * Mp + lane * Q;
+        float *b = bm + (size_t)r * 3 * Mp + lane * Q;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          float pm = f[q] * Mv[q]; pm = pm * invZ;
+          float pi = f[Mp + q] * Iv[q]; pi = pi * invZ;
+          b[q] = pm; b[Mp + q] = pi; b[2 * Mp + q] = 0.f;
+          if (!(__builtin_isfinite(pm) && __builtin_isfinite(pi))) bad = true;
+        }
+        if (lane == 0) {
+          const float wgt = invZ / xs[(size_t)r * 6 + 5];
+          float t;
+          t = xs[(size_t)(r - 1) * 6 + 1] * xN; t = t * loop; aux[(size_t)r * 3 + 0] = t * wgt;
+          t = xs[(size_t)(r - 1) * 6 + 2] * xJ; t = t * loop; aux[(size_t)r * 3 + 1] = t * wgt;
+          t = xs[(size_t)(r - 1) * 6 + 4] * xC; t = t * loop; aux[(size_t)r * 3 + 2] = t * wgt;
+        }
+      }
+    } else if (lane == 0) {
+      if (r >= 1) {
+        float et = xs[(size_t)r * 6 + 0] * xE; et = et * invZ;
+        const float wgt = invZ / xs[(size_t)r * 6 + 5];
+        float a = xs[(size_t)(r - 1) * 6 + 1] * xN; a = a * loop;
+        float b = xs[(size_t)(r - 1) * 6 + 2] * xJ; b = b * loop;
+        float c = xs[(size_t)(r - 1) * 6 + 4] * xC; c = c * loop;
+        aux[(size_t)r * 3 + 1] = et;
+        aux[(size_t)r * 3 + 2] = ((a + b) + c) * wgt;
+      }
+      if (r < L) { float bt = xs[(size_t)r * 6 + 3] * xB; bt = bt * invZ; aux[(size_t)(r + 1) * 3 + 0] = bt; }
+    }
+  };
+  emit(L);
+  for (int i = L - 1; i >= 0; --i) {
+    const float *rfx = md.rf + (size_t)rp[i] * Mp + lane * Q;    // residue i+1
+    float mn[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) mn[q] = Mv[q] * rfx[q];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { const float t = tr.BM(q) * mn[q]; s = s + t; }
+    xB = wave_sum(s);
+    { const float a = xB * move, b = xJ * loop; xJ = a + b; }
+    xC = xC * loop;
+    { const float a = xC * Emove, b = xJ * Eloop; xE = a + b; }
+    { const float a = xB * move, b = xN * loop; xN = a + b; }
+    float mnx = __shfl_down(mn[0], 1); if (lane == 63) mnx = 0.f;
+    float av[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { const float mn1 = (q + 1 < Q) ? mn[q + 1] : mnx; av[q] = xE + tDMn[q] * mn1; }
+    float Dn[Q];
+    bwd_dchain<Q>(Dn, av, tr, lane);
+    float dnx = __shfl_down(Dn[0], 1); if (lane == 63) dnx = 0.f;
+    float Mn[Q], In[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const float mn1 = (q + 1 < Q) ? mn[q + 1] : mnx;
+      const float dn1 = (q + 1 < Q) ? Dn[q + 1] : dnx;
+      { const float a = tIMn[q] * mn1, b = tr.II(q) * Iv[q]; In[q] = a + b; }
+      float m = xE + tMMn[q] * mn1;
+      m = m + tr.MI(q) * Iv[q];
+      m = m + tr.MD(q) * dn1;
+      Mn[q] = m;
+    }
+    const float sc = xs[(size_t)(i + 1) * 6 + 5];
+    if (sc != 1.0f) {
+      const float inv = 1.0f / sc;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) { Mn[q] *= inv; In[q] *= inv; Dn[q] *= inv; }
+      xE *= inv; xN *= inv; xJ *= inv; xB *= inv; xC *= inv;
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { Mv[q] = Mn[q]; Iv[q] = In[q]; Dv[q] = Dn[q]; }
+    emit(i);
+  }
+  if (w.full) {
+    const unsigned long long any = __ballot(bad);
+    if (lane == 0) range_err[w.slot] = any ? 1 : 0;
+  }
+}
+
+// ---- null2 by expectation + optimal accuracy fill + traceback -------------------------------------
+template <int Q>
+__global__ void __launch_bounds__(64) oa_kernel(const FbWork *__restrict__ work, const uint32_t *__restrict__ idx,
+                                                const DevModel *__restrict__ models, float *__restrict__ ws,
+                                                const int32_t *__restrict__ range_err, EnvOut *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int Mp = Q * 64;
+  const int lane = threadIdx.x;
+  const FbWork w = work[idx[blockIdx.x]];
+  const DevModel &md = models[w.model];
+  if (range_err[w.slot]) { if (lane == 0) out[w.slot].range_err = 1; return; }
+  load_tr<Q>(lds, md.ftr, lane);
+  Tr<Q> tr{lds, lane * Q};
+  const int M = md.M, L = w.Ld, c0 = lane * Q;
+  float *pp = ws + w.mxb_off;       // posterior rows (M, I; D = 0)
+  float *oa = ws + w.mxf_off;       // OA rows overwrite the forward matrix
+  const float *aux = ws + w.aux_off;                                   // [ppN ppJ ppC] per row (written by bwd_kernel)
+  float *oax = ws + w.aux_off + (((size_t)(w.Ld + 1) * 3 + 31) & ~(size_t)31);   // [oN oB oE oJ oC] per row, own cache lines
+  const bool Eloop_ok = false;      // envelopes are rescored unihit
+  // ---------------- null2 ----------------
+  {
+    float me[Q], ie[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) me[q] = ie[q] = 0.f;
+    float xN = 0.f, xJ = 0.f, xC = 0.f;
+    for (int i = 1; i <= L; ++i) {
+      const float *r = pp + (size_t)i * 3 * Mp + c0;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) { me[q] = me[q] + r[q]; ie[q] = ie[q] + r[Mp + q]; }
+      xN = xN + aux[(size_t)i * 3 + 0]; xJ = xJ + aux[(size_t)i * 3 + 1]; xC = xC + aux[(size_t)i * 3 + 2];
+    }
+    const float norm = 1.0f / (float)L;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { me[q] *= norm; ie[q] *= norm; }
+    const float xfactor = ((xN + xC) + xJ) * norm;
+    for (int x = 0; x < 20; ++x) {
+      const float *rfx = md.rf + (size_t)x * Mp + c0;
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) { const float t = me[q] * rfx[q]; s = s + t; s = s + ie[q]; }
+      s = wave_sum(s);
+      if (lane == 0) out[w.slot].null2[x] = s + xfactor;
+    }
+  }
+  // ---------------- OA fill ----------------
+  bool okMM[Q], okIM[Q], okDM[Q], okBM[Q], okMI[Q], okII[Q], okMDp[Q], okDDp[Q];   // *p: gate of the transition INTO cell c from c-1
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int c = c0 + q;
+    okMM[q] = c > 0 && tr.MM(q) > 0.f; okIM[q] = c > 0 && tr.IM(q) > 0.f; okDM[q] = c > 0 && tr.DM(q) > 0.f; okBM[q] = tr.BM(q) > 0.f;
+    okMI[q] = tr.MI(q) > 0.f; okII[q] = tr.II(q) > 0.f;
+    okMDp[q] = c > 0 && c < M && lds[6 * Mp + c - 1] > 0.f;
+    okDDp[q] = c > 0 && c < M && lds[7 * Mp + c - 1] > 0.f;
+  }
+  float Mv[Q], Iv[Q], Dv[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) { Mv[q] = Iv[q] = Dv[q] = NEGINF_F; oa[c0 + q] = NEGINF_F; oa[Mp + c0 + q] = NEGINF_F; oa[2 * Mp + c0 + q] = NEGINF_F; }
+  float oN = 0.f, oB = 0.f, oE = NEGINF_F, oJ = NEGINF_F, oC = NEGINF_F;
+  if (lane == 0) { oax[0] = oN; oax[1] = oB; oax[2] = oE; oax[3] = oJ; oax[4] = oC; }
+  for (int i = 1; i <= L; ++i) {
+    const float *pr = pp + (size_t)i * 3 * Mp + c0;
+    float mpi = __shfl_up(Mv[Q - 1], 1), ipi = __shfl_up(Iv[Q - 1], 1), dpi = __shfl_up(Dv[Q - 1], 1);
+    float Mn[Q], In[Q], Dn[Q];
+    float e = NEGINF_F;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int c = c0 + q;
+      const float mp = q ? Mv[q - 1] : mpi, ip = q ? Iv[q - 1] : ipi, dp = q ? Dv[q - 1] : dpi;
+      float best = NEGINF_F;
+      if (okMM[q] && mp > best) best = mp;
+      if (okIM[q] && ip > best) best = ip;
+      if (okDM[q] && dp > best) best = dp;
+      if (okBM[q] && oB > best) best = oB;
+      float bi = NEGINF_F;
+      if (okMI[q] && Mv[q] > bi) bi = Mv[q];
+      if (okII[q] && Iv[q] > bi) bi = Iv[q];
+      if (c < M) { Mn[q] = best + pr[q]; In[q] = bi + pr[Mp + q]; e = fmaxf(e, Mn[q]); }
+      else { Mn[q] = NEGINF_F; In[q] = NEGINF_F; }
+    }
+    // D chain: D(c) = max(gate_MD(c-1) ? M(c-1), gate_DD(c-1) ? D(c-1)); segmented max scan over lanes
+    float dloc[Q]; bool open[Q];
+    {
+      float d = NEGINF_F; bool op = true;   // carry-in -inf; `op`: the carry reaches this cell
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        // value entering cell q from cell q-1 of the same lane (q>0); q==0 handled by the carry
+        if (q > 0) {
+          float v = NEGINF_F;
+          if (okMDp[q] && Mn[q - 1] > v) v = Mn[q - 1];
+          if (okDDp[q] && d > v) v = d;
+          d = v; op = op && okDDp[q];
+        }
+        dloc[q] = d; open[q] = op;
+      }
+      // lane output towards the next lane's first cell: needs the gates of that cell (c0+Q)
+      const int cn = c0 + Q;
+      const bool gMD = cn < M && cn < Mp && lds[6 * Mp + cn - 1] > 0.f, gDD = cn < M && cn < Mp && lds[7 * Mp + cn - 1] > 0.f;
+      float outv = NEGINF_F;
+      if (gMD && Mn[Q - 1] > outv) outv = Mn[Q - 1];
+      if (gDD && d > outv) outv = d;
+      bool pass = op && gDD;     // a carry entering this lane's first cell survives to the next lane's first cell
+      // NOTE: the carry enters cell q=0 as D(c0) itself; it propagates to later cells only through DD gates
+#pragma unroll
+      for (int s = 1; s < 64; s <<= 1) {
+        const float ov = __shfl_up(outv, s); const int opass = __shfl_up((int)pass, s);
+        if (lane >= s) { if (pass && ov > outv) outv = ov; pass = pass && (opass != 0); }
+      }
+      float carry = __shfl_up(outv, 1);
+      if (lane == 0) carry = NEGINF_F;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        float v = dloc[q];
+        if (q == 0) v = carry; else if (open[q] && carry > v) v = carry;
+        Dn[q] = (c0 + q < M) ? v : NEGINF_F;
+      }
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) e = fmaxf(e, __shfl_xor(e, s));
+    oE = e;
+    { const float a = oJ + aux[(size_t)i * 3 + 1]; const float b = Eloop_ok ? e : NEGINF_F; oJ = a > b ? a : b; }
+    { const float a = oC + aux[(size_t)i * 3 + 2]; oC = a > e ? a : e; }
+    oN = oN + aux[(size_t)i * 3 + 0];
+    oB = oN > oJ ? oN : oJ;
+    float *r = oa + (size_t)i * 3 * Mp + c0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { Mv[q] = Mn[q]; Iv[q] = In[q]; Dv[q] = Dn[q]; r[q] = Mn[q]; r[Mp + q] = In[q]; r[2 * Mp + q] = Dn[q]; }
+    if (lane == 0) { float *a = oax + (size_t)i * 5; a[0] = oN; a[1] = oB; a[2] = oE; a[3] = oJ; a[4] = oC; }
+  }
+  __threadfence();
+  __builtin_amdgcn_wave_barrier();
+#define LD2(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)   /* L2-served: this wave's own stores are visible */
+  // ---------------- traceback (uniform control flow; select_e is lane-parallel) ----------------
+  int i = L, k = 0, st = 0;      // 0=C 1=E 2=M 3=I 4=D
+  int fi = 0, fk = 0, li = 0, lk = 0;
+  bool done = false;
+  const float *tMM = lds + 1 * Mp, *tIM = lds + 2 * Mp, *tDM = lds + 3 * Mp, *tBM = lds, *tMI = lds + 4 * Mp, *tII = lds + 5 * Mp, *tMD = lds + 6 * Mp, *tDD = lds + 7 * Mp;
+  int guard = 0;
+  while (!done && guard++ < 4 * (L + Mp) + 16) {
+    const float *cr = oa + (size_t)i * 3 * Mp;
+    const float *pr = (i > 0) ? oa + (size_t)(i - 1) * 3 * Mp : oa;
+    if (st == 0) {
+      if (i == 0) { done = true; }
+      else { const float a = LD2(&oax[(size_t)(i - 1) * 5 + 4]) + aux[(size_t)i * 3 + 2], b = LD2(&oax[(size_t)i * 5 + 2]); if (a >= b) --i; else st = 1; }
+    } else if (st == 1) {
+      const float e = LD2(&oax[(size_t)i * 5 + 2]);
+      int best = Mp;
+#pragma unroll
+      for (int q = Q - 1; q >= 0; --q) { const int c = c0 + q; if (c < M && LD2(&cr[c]) == e) best = c; }
+#pragma unroll
+      for (int s = 32; s >= 1; s >>= 1) best = min(best, __shfl_xor(best, s));
+      if (best >= Mp) done = true; else { k = best; st = 2; li = i; lk = k + 1; }
+    } else if (st == 2) {
+      fi = i; fk = k + 1;
+      float p0 = NEGINF_F, p1 = NEGINF_F, p2 = NEGINF_F, p3 = NEGINF_F;
+      if (k > 0) { if (tMM[k] > 0.f) p0 = LD2(&pr[k - 1]); if (tIM[k] > 0.f) p1 = LD2(&pr[Mp + k - 1]); if (tDM[k] > 0.f) p2 = LD2(&pr[2 * Mp + k - 1]); }
+      if (tBM[k] > 0.f) p3 = LD2(&oax[(size_t)(i - 1) * 5 + 1]);
+      int best = 0; float bv = p0;
+      if (p1 > bv) { bv = p1; best = 1; }
+      if (p2 > bv) { bv = p2; best = 2; }
+      if (p3 > bv) { bv = p3; best = 3; }
+      --i;
+      if (best == 0) { --k; st = 2; } else if (best == 1) { --k; st = 3; } else if (best == 2) { --k; st = 4; } else done = true;
+    } else if (st == 3) {
+      const float a = (tMI[k] > 0.f) ? LD2(&pr[k]) : NEGINF_F, b = (tII[k] > 0.f) ? LD2(&pr[Mp + k]) : NEGINF_F;
+      --i; st = (a >= b) ? 2 : 3;
+    } else {
+      const float a = (tMD[k - 1] > 0.f) ? LD2(&cr[k - 1]) : NEGINF_F, b = (tDD[k - 1] > 0.f) ? LD2(&cr[2 * Mp + k - 1]) : NEGINF_F;
+      --k; st = (a >= b) ? 2 : 4;
+    }
+  }
+  if (lane == 0) {
+    EnvOut &o = out[w.slot];
+    o.range_err = 0; o.oasc = oC;
+    o.hmm_from = fk; o.hmm_to = lk; o.ali_from = fi + w.i0; o.ali_to = li + w.i0;
+  }
+}
+
+// ---- launchers ----------------------------------------------------------------------------------
+#define CKM_FB_QS(X) X(1) X(2) X(3) X(4) X(6) X(8) X(12) X(16) X(24) X(32)
+
+int launch_fwd(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const DevModel *models,
+               const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, FwdOut *out,
+               ScaleEvent *events, uint32_t *nevents, uint32_t cap_events) {
+  if (!n) return 0;
+  switch (Q) {
+#define X(QV) case QV: hipLaunchKernelGGL(fwd_kernel<QV>, dim3(n), dim3(64), (size_t)8 * QV * 64 * 4, stream, work, idx, models, lentab, res, seq_off, ws, out, events, nevents, cap_events); break;
+    CKM_FB_QS(X)
+#undef X
+    default: return -1;
+  }
+  return 0;
+}
+int launch_bwd(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const DevModel *models,
+               const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, const FwdOut *fout, int32_t *range_err) {
+  if (!n) return 0;
+  switch (Q) {
+#define X(QV) case QV: hipLaunchKernelGGL(bwd_kernel<QV>, dim3(n), dim3(64), (size_t)8 * QV * 64 * 4, stream, work, idx, models, lentab, res, seq_off, ws, fout, range_err); break;
+    CKM_FB_QS(X)
+#undef X
+    default: return -1;
+  }
+  return 0;
+}
+int launch_oa(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const DevModel *models,
+              float *ws, const int32_t *range_err, EnvOut *out) {
+  if (!n) return 0;
+  switch (Q) {
+#define X(QV) case QV: hipLaunchKernelGGL(oa_kernel<QV>, dim3(n), dim3(64), (size_t)8 * QV * 64 * 4, stream, work, idx, models, ws, range_err, out); break;
+    CKM_FB_QS(X)
+#undef X
+    default: return -1;
+  }
+  return 0;
+}
+
+}  // namespace ckm

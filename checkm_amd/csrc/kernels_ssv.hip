@@ -1,0 +1,141 @@
+// kernels_ssv.hip -- the dominant kernel: single-segment ungapped Viterbi (SSV) over every
+// (model, sequence) pair, gfx950 only.
+//
+// What it replaces: HMMER's MSV/SSV filter stage of the hmmsearch process CheckM launches per bin
+// (checkm/markerGeneFinder.py:140-142 -> checkm/hmmer.py:70).  MSV in unsigned bytes is
+//     sv(i,k) = sat_sub(sat_add(max(sv(i-1,k-1), xB), bias), cost[x_i][k])
+// and while the running xJ never exceeds `base`, xB is constant, so with U = max(sv - xB, 0):
+//     V(i,k) = U(i-1,k-1) + (bias - cost[x_i][k]);   U(i,k) = max(V(i,k), 0);   maxV = max V
+// is independent of the target length; xE = max(0, xB + maxV) reproduces the byte arithmetic exactly
+// (sat_add cannot saturate before the overflow test fires).  Pairs for
+// which the J state could have been used (xJ > base) are re-run by msv_full_kernel.
+//
+// Mapping: 16 lanes per sequence (one DPP row), 4 sequences per wavefront, Q packed 2 x i16
+// registers per lane; position p = q + Q*(2*lane16 + half) so the diagonal move i-1,k-1 -> i,k is a
+// register rename plus ONE row_shr:1 DPP move per row.  Emission words for the model live in LDS
+// as [symbol][Q/4][16 lanes][16 B]: each row step is ceil(Q/4) conflict-free ds_read_b128 per lane
+// and 3 packed-i16 VALU ops per register (v_pk_add_i16 clamp, 2 x v_pk_max_i16).
+#include <hip/hip_runtime.h>
+#include "dev_types.h"
+
+namespace ckm {
+
+typedef short  s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32;
+
+__device__ __forceinline__ s16x2 as_s16x2(u32 v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ u32   as_u32(s16x2 v) { return __builtin_bit_cast(u32, v); }
+
+constexpr int SSV_NROWS = 30;
+constexpr u32 PAD4 = 0x1d1d1d1du;   // four PADCODE (29) residues
+
+template <int Q>
+__device__ __forceinline__ void ssv_row(u32 (&U)[Q], u32 &xE, const char *lds_lane, u32 x) {
+  constexpr int Qg = (Q + 3) / 4;
+  constexpr int ROWB = Qg * 256;
+  const char *rowp = lds_lane + x * ROWB;
+  u32 e[Qg * 4];
+#pragma unroll
+  for (int g = 0; g < Qg; ++g) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(rowp + g * 256);
+    e[g * 4 + 0] = v.x; e[g * 4 + 1] = v.y; e[g * 4 + 2] = v.z; e[g * 4 + 3] = v.w;
+  }
+  // cell p=0 of each lane's first register comes from the previous lane's last register (high half)
+  // and this lane's own last register (low half -> high half)
+  const u32 last = U[Q - 1];
+  const u32 prev = (u32)__builtin_amdgcn_update_dpp(0, (int)last, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
+  const u32 carry = __builtin_amdgcn_alignbit(last, prev, 16);
+  const s16x2 zero = {0, 0};
+#pragma unroll
+  for (int q = Q - 1; q >= 1; --q) {
+    const s16x2 v = __builtin_elementwise_add_sat(as_s16x2(U[q - 1]), as_s16x2(e[q]));
+    xE = as_u32(__builtin_elementwise_max(as_s16x2(xE), v));
+    U[q] = as_u32(__builtin_elementwise_max(v, zero));
+  }
+  {
+    const s16x2 v = __builtin_elementwise_add_sat(as_s16x2(carry), as_s16x2(e[0]));
+    xE = as_u32(__builtin_elementwise_max(as_s16x2(xE), v));
+    U[0] = as_u32(__builtin_elementwise_max(v, zero));
+  }
+}
+
+template <int Q>
+__global__ void __launch_bounds__(Q > 40 ? 512 : 1024) ssv_kernel(const SsvBlockWork *__restrict__ work, const DevModel *__restrict__ models,
+                           const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
+                           const int32_t *__restrict__ seq_len, const uint32_t *__restrict__ lists,
+                           int16_t *__restrict__ maxv) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int Qg = (Q + 3) / 4;
+  constexpr int ROWB = Qg * 256;
+  const SsvBlockWork w = work[blockIdx.x];
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(models[w.model].ssv_tbl);
+    uint4 *dst = reinterpret_cast<uint4 *>(smem);
+    for (int i = threadIdx.x; i < SSV_NROWS * ROWB / 16; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int seg = lane >> 4, z = lane & 15;
+  const char *lds_lane = smem + z * 16;
+  for (u32 g = wave; g * 4 < w.count; g += nwaves) {
+    const u32 li = g * 4 + seg;
+    const bool valid = li < w.count;
+    const u32 sid = valid ? lists[w.list_start + li] : 0u;
+    const int L = valid ? seq_len[sid] : 0;
+    const uint8_t *rp = res + seq_off[sid];
+    int Lmax = __builtin_amdgcn_readlane(L, 0);
+    Lmax = max(Lmax, __builtin_amdgcn_readlane(L, 16));
+    Lmax = max(Lmax, __builtin_amdgcn_readlane(L, 32));
+    Lmax = max(Lmax, __builtin_amdgcn_readlane(L, 48));
+    u32 U[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) U[q] = 0u;
+    u32 xE = 0x80008000u;
+    const int nchunk = (Lmax + 15) >> 4;
+    const uint4 padv = make_uint4(PAD4, PAD4, PAD4, PAD4);
+    uint4 cur = (0 < L) ? *reinterpret_cast<const uint4 *>(rp) : padv;
+    for (int c = 0; c < nchunk; ++c) {
+      const uint4 nxt = ((c + 1) * 16 < L) ? *reinterpret_cast<const uint4 *>(rp + (c + 1) * 16) : padv;
+#define CKM_SSV_WORD(wd)                                   \
+  ssv_row<Q>(U, xE, lds_lane, (wd) & 0xffu);               \
+  ssv_row<Q>(U, xE, lds_lane, ((wd) >> 8) & 0xffu);        \
+  ssv_row<Q>(U, xE, lds_lane, ((wd) >> 16) & 0xffu);       \
+  ssv_row<Q>(U, xE, lds_lane, (wd) >> 24);
+      CKM_SSV_WORD(cur.x) CKM_SSV_WORD(cur.y) CKM_SSV_WORD(cur.z) CKM_SSV_WORD(cur.w)
+#undef CKM_SSV_WORD
+      cur = nxt;
+    }
+    const s16x2 xv = as_s16x2(xE);
+    int m = max((int)xv.x, (int)xv.y);
+    m = max(m, __shfl_xor(m, 1, 16));
+    m = max(m, __shfl_xor(m, 2, 16));
+    m = max(m, __shfl_xor(m, 4, 16));
+    m = max(m, __shfl_xor(m, 8, 16));
+    if (valid && z == 0) maxv[w.pair_start + li] = (int16_t)m;
+  }
+}
+
+#define CKM_SSV_CASE(QV)                                                                                         \
+  case QV:                                                                                                       \
+    if ((size_t)SSV_NROWS * ((QV + 3) / 4) * 256 > 48 * 1024) {                                                  \
+      static bool attr_set = false;                                                                              \
+      if (!attr_set) { (void)hipFuncSetAttribute((const void *)ssv_kernel<QV>, hipFuncAttributeMaxDynamicSharedMemorySize, SSV_NROWS * ((QV + 3) / 4) * 256); attr_set = true; } \
+    }                                                                                                            \
+    hipLaunchKernelGGL(ssv_kernel<QV>, dim3(nblocks), dim3(threads), (size_t)SSV_NROWS * ((QV + 3) / 4) * 256, stream, \
+                       work, models, res, seq_off, seq_len, lists, maxv);                                        \
+    break;
+
+int launch_ssv(int Q, int nblocks, int threads, hipStream_t stream, const SsvBlockWork *work, const DevModel *models,
+               const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const uint32_t *lists, int16_t *maxv) {
+  switch (Q) {
+    CKM_SSV_CASE(1) CKM_SSV_CASE(2) CKM_SSV_CASE(3) CKM_SSV_CASE(4) CKM_SSV_CASE(5) CKM_SSV_CASE(6) CKM_SSV_CASE(7)
+    CKM_SSV_CASE(8) CKM_SSV_CASE(9) CKM_SSV_CASE(10) CKM_SSV_CASE(11) CKM_SSV_CASE(12) CKM_SSV_CASE(13) CKM_SSV_CASE(14)
+    CKM_SSV_CASE(15) CKM_SSV_CASE(16) CKM_SSV_CASE(18) CKM_SSV_CASE(20) CKM_SSV_CASE(22) CKM_SSV_CASE(24) CKM_SSV_CASE(26)
+    CKM_SSV_CASE(28) CKM_SSV_CASE(30) CKM_SSV_CASE(32) CKM_SSV_CASE(36) CKM_SSV_CASE(40) CKM_SSV_CASE(48) CKM_SSV_CASE(56)
+    CKM_SSV_CASE(64)
+    default: return -1;
+  }
+  return 0;
+}
+
+}  // namespace ckm

@@ -1,0 +1,200 @@
+/* checkm_hip.h -- C ABI of libcheckm_hip.so, the MI355X (gfx950) marker-gene hot path of CheckM.
+ *
+ * The reference has no FFI: its seam is a shell command plus a text file.  Each entry point below
+ * names the reference interface it replaces (paths relative to the CheckM source tree).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative CKM_E* code; ckm_last_error() returns a
+ *     thread-local message for the last failure.  No C++ exception crosses this boundary.
+ *   - the caller owns every input buffer; the library owns every output object and frees it in
+ *     the matching *_free().  Column pointers returned by ckm_hits_columns()/ckm_qa_columns() stay
+ *     valid until that object is freed.
+ *   - one ckm_ctx per (process, device).  Calls on one ctx are not re-entrant; different ctxs are
+ *     independent.  The library never falls back to a CPU implementation: without a usable HIP
+ *     device ckm_ctx_create() fails with CKM_ENODEV and nothing else can be called.
+ */
+#ifndef CHECKM_HIP_H
+#define CHECKM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CKM_ABI_VERSION 1
+
+enum {
+  CKM_OK      =  0,
+  CKM_EINVAL  = -1,   /* bad argument */
+  CKM_EIO     = -2,   /* file could not be read/written */
+  CKM_EFORMAT = -3,   /* malformed HMMER3 profile / input */
+  CKM_ENODEV  = -4,   /* no usable HIP device */
+  CKM_EHIP    = -5,   /* HIP runtime error */
+  CKM_ENOMEM  = -6,
+  CKM_ERANGE  = -7    /* size limit exceeded (see DESIGN.md limits) */
+};
+
+typedef struct ckm_ctx      ckm_ctx;
+typedef struct ckm_profiles ckm_profiles;
+typedef struct ckm_seqs     ckm_seqs;
+typedef struct ckm_hits     ckm_hits;
+typedef struct ckm_qa       ckm_qa;
+
+const char *ckm_last_error(void);
+int         ckm_abi_version(void);
+
+/* Replaces the "is hmmsearch on PATH" probe, checkm/hmmer.py:131-137 (HMMERRunner.checkForHMMER). */
+int ckm_device_count(int *n);
+int ckm_ctx_create(int device, ckm_ctx **out);
+void ckm_ctx_destroy(ckm_ctx *ctx);
+
+/* ---- profiles ------------------------------------------------------------------------------
+ * Replaces hmmsearch's reading of <hmmfile> (checkm/hmmer.py:70) and the header skim of
+ * checkm/hmmerModelParser.py:54-83.  Parses a HMMER3/f ASCII file completely (headers, COMPO,
+ * emissions, transitions, STATS LOCAL), configures the multihit-local search profiles and uploads
+ * the score tables to HBM.  The header view is the RAW per-record view; the sticky ACC/GA/TC/NC
+ * carry-over quirk of HmmModelParser.simpleParse is applied by the Python mirror, not here. */
+typedef struct {
+  const char *name;      /* NAME */
+  const char *acc;       /* ACC or NULL */
+  const char *desc;      /* DESC or NULL */
+  int32_t     leng;      /* LENG */
+  int32_t     has_ga, has_tc, has_nc;
+  float       ga[2], tc[2], nc[2];
+  float       evparam[6];   /* MSV mu,lambda; VITERBI mu,lambda; FORWARD tau,lambda */
+} ckm_model_header;
+
+int  ckm_profiles_load(ckm_ctx *ctx, const char *hmm_path, ckm_profiles **out);
+int  ckm_profiles_count(const ckm_profiles *p, int32_t *n);
+int  ckm_profiles_header(const ckm_profiles *p, int32_t i, ckm_model_header *out);
+void ckm_profiles_free(ckm_profiles *p);
+
+/* ---- target sequences ----------------------------------------------------------------------
+ * Replaces hmmsearch's reading of <seqfile> (the genes.faa written at
+ * checkm/markerGeneFinder.py:113-127).  `text` holds the residues of all sequences of all bins
+ * back to back (no separators); sequence s is text[seq_off[s] .. seq_off[s+1]).  Bin b owns
+ * sequences bin_off[b] .. bin_off[b+1]; Z of a bin = its sequence count, as one hmmsearch
+ * run per bin has it.  names/descs (nseq entries, descs may be NULL) are copied. */
+int  ckm_seqs_pack(ckm_ctx *ctx, const char *text, const uint64_t *seq_off, uint32_t nseq,
+                   const uint32_t *bin_off, uint32_t nbins,
+                   const char *const *names, const char *const *descs, ckm_seqs **out);
+int  ckm_seqs_residues(const ckm_seqs *s, uint64_t *total);
+void ckm_seqs_free(ckm_seqs *s);
+
+/* ---- the scan ------------------------------------------------------------------------------
+ * Replaces one `hmmsearch --domtblout T --notextw -E <E> --domE <domE> --noali` process per bin
+ * (checkm/markerGeneFinder.py:134-142 -> checkm/hmmer.py:61-74).
+ * Bin b is searched with models model_idx[model_off[b] .. model_off[b+1]) in that order
+ * (the order of the temporary HMM file of checkm/markerSets.py:326-343); model_off == NULL
+ * means every model of `p`, in file order, for every bin. */
+int  ckm_search(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s,
+                const uint32_t *model_off, const uint32_t *model_idx,
+                double E, double domE, ckm_hits **out);
+
+/* One entry per reported domain = one domtblout row (column contract: checkm/hmmer.py:255-285). */
+typedef struct {
+  uint64_t        n;            /* rows */
+  uint32_t        nbins;
+  const uint64_t *bin_row_off;  /* [nbins+1] rows of bin b, already in domtblout order */
+  const uint32_t *seq;          /* global sequence index (target_name / description / tlen) */
+  const uint32_t *model;        /* profile index (query_name / accession / qlen) */
+  const int32_t  *tlen, *qlen;
+  const double   *full_evalue;  const float *full_score, *full_bias;
+  const int32_t  *dom_idx, *ndom;
+  const double   *c_evalue, *i_evalue; const float *dom_score, *dom_bias;
+  const int32_t  *hmm_from, *hmm_to, *ali_from, *ali_to, *env_from, *env_to;
+  const float    *acc;
+} ckm_hit_columns;
+
+int  ckm_hits_columns(const ckm_hits *h, ckm_hit_columns *out);
+void ckm_hits_free(ckm_hits *h);
+
+/* Writes bin b's rows as hmmsearch --domtblout text, the file every later CheckM stage re-reads
+ * (checkm/resultsParser.py:191-204; written today by hmmsearch itself, checkm/hmmer.py:70). */
+int  ckm_hits_write_domtblout(const ckm_hits *h, const ckm_profiles *p, const ckm_seqs *s,
+                              uint32_t bin, const char *path);
+
+/* ---- per-stage counters of the last ckm_search on this ctx (bench.py) --- */
+typedef struct {
+  uint64_t pairs_ssv, pairs_msv_full, pairs_bias, pairs_vit, pairs_fwd, pairs_dom, envelopes;
+  uint64_t cells_ssv;           /* sum over pairs of L*M: GCUPS denominator */
+  uint64_t residue_hmm;         /* sum over pairs of L */
+  double   ms_ssv, ms_filters, ms_fwdbwd, ms_domains, ms_host, ms_total;
+  uint32_t ssv_launches;
+} ckm_search_stats;
+int ckm_last_search_stats(const ckm_ctx *ctx, ckm_search_stats *out);
+
+/* ---- the reduction --------------------------------------------------------------------------
+ * Replaces ResultsParser.parseBinHits -> ResultsManager.{vetHit,addHit} -> PFAM.filterHitsFromSameClan
+ * -> identifyAdjacentMarkerGenes -> geneCounts -> MarkerSet.genomeCheck
+ * (checkm/resultsParser.py:76-119,340-537; checkm/util/pfam.py:86-147; checkm/markerSets.py:206-238).
+ * Hits come either from ckm_search (h != NULL) or, for tables parsed from existing domtblout
+ * text, through `ext` (same columns, text-rounded values).  */
+typedef struct {
+  /* per model (index = profile index, or caller's own model numbering when ext is used) */
+  uint32_t        nmodels;
+  const int32_t  *qlen;
+  const uint8_t  *thr_kind;     /* 0 none, 1 NC(TIGR), 2 GA, 3 TC, 4 NC : the cascade of resultsParser.py:356-367, resolved by the caller from the (sticky) header view */
+  const float    *thr_full, *thr_dom;
+  const uint8_t  *is_pf;        /* marker id starts with 'PF' (pfam.py:97) */
+  const int32_t  *clan;         /* clan id or -1 (pfam.py:116: None==None counts as same clan) */
+  const uint32_t *nest_off, *nest_idx;   /* CSR: models nested with model m (pfam.py:135) */
+  const uint32_t *key;          /* models sharing one accession share a key (markerHits dict key) */
+} ckm_model_info;
+
+typedef struct {
+  int32_t ignore_thresholds, skip_pseudogene_correction, skip_adj_correction, individual_markers;
+  double  evalue_threshold, length_threshold;
+} ckm_reduce_flags;
+
+typedef struct {
+  /* CSR over bins -> collocated sets -> marker keys */
+  uint32_t        nbins;
+  const uint32_t *set_off;      /* [nbins+1] */
+  const uint32_t *marker_off;   /* [nsets+1] */
+  const uint32_t *marker_key;   /* [nmarkers] key (see ckm_model_info.key) */
+} ckm_marker_sets;
+
+int  ckm_reduce(ckm_ctx *ctx, const ckm_hits *h, const ckm_hit_columns *ext, const ckm_seqs *s,
+                const ckm_model_info *mi, const ckm_reduce_flags *fl, const ckm_marker_sets *ms, ckm_qa **out);
+
+typedef struct {
+  uint32_t        nbins;
+  const int32_t  *hist;         /* [nbins*6] markers with 0,1,2,3,4,5+ hits (resultsParser.py:513-529) */
+  const double   *completeness, *contamination;   /* markerSets.py:206-238 */
+  const uint32_t *set_off;      /* [nbins+1] */
+  const int32_t  *set_present, *set_multi;        /* per collocated set */
+  /* surviving hits (ResultsManager.markerHits after all filters), grouped by bin then marker key in
+   * the reference's dict/list order */
+  uint64_t        nkept;
+  const uint64_t *kept_bin_off; /* [nbins+1] */
+  const uint32_t *kept_key;     /* marker key */
+  const uint64_t *kept_row;     /* row index into the hit columns */
+  const uint64_t *kept_row2;    /* second row when two adjacent ORFs were merged, else UINT64_MAX */
+  const int32_t  *kept_tlen, *kept_hmm_from, *kept_hmm_to, *kept_ali_from, *kept_ali_to, *kept_env_from, *kept_env_to;
+} ckm_qa_columns;
+
+int  ckm_qa_columns_get(const ckm_qa *q, ckm_qa_columns *out);
+void ckm_qa_free(ckm_qa *q);
+
+/* ---- diagnostics used by the parity tests: every stage of one (model, sequence) pair, no filtering */
+typedef struct {
+  int32_t msv_xJ;  float msv_sc, null_sc, bias_sc;
+  int32_t vit_xC;  float vit_sc, fwd_sc, fwd_xC;  int32_t fwd_nscale;
+  int32_t ssv_maxv;
+} ckm_stage_scores;
+int ckm_debug_stages(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s,
+                     const uint32_t *model, const uint32_t *seq, uint32_t npairs, ckm_stage_scores *out);
+typedef struct {
+  float envsc, oasc, fwd_xC; int32_t nscale; float null2[20];
+  int32_t hmm_from, hmm_to, ali_from, ali_to; int32_t ok;
+} ckm_envelope_result;
+int ckm_debug_envelopes(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s,
+                        const uint32_t *model, const uint32_t *seq, const int32_t *ienv, const int32_t *jenv,
+                        uint32_t n, ckm_envelope_result *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -260,11 +260,19 @@ static void prof_free(PROF *p)
   free(p->msc); free(p->gBM); free(p->rbv); free(p->rwv); free(p->wBM); free(p->rf); free(p->fBM); free(p);
 }
 
+/* canonical slots per lane: smallest member of the fixed set covering M */
+static int canon_q(int M)
+{
+  static const int set[] = { 1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64 };
+  for (unsigned i = 0; i < sizeof(set)/sizeof(set[0]); i++) if (set[i] * P7O_NL >= M) return set[i];
+  return (M + P7O_NL - 1) / P7O_NL;
+}
+
 static PROF *prof_create(const P7O_HMM *h)
 {
   int M = h->M;
   PROF *p = calloc(1, sizeof(*p));
-  p->hmm = h; p->M = M; p->Q = (M + P7O_NL - 1) / P7O_NL; p->Mp = p->Q * P7O_NL;
+  p->hmm = h; p->M = M; p->Q = canon_q(M); p->Mp = p->Q * P7O_NL;
   /* --- generic transition scores --- */
   p->gBM = malloc(sizeof(float) * 8 * (size_t)(M+1));
   p->gMM = p->gBM + (M+1); p->gIM = p->gMM + (M+1); p->gDM = p->gIM + (M+1);

@@ -1,0 +1,157 @@
+"""GPU parity of the scan half: every kernel stage and the assembled search against the CPU oracle.
+
+Bar: bit-exact.  Integer stages (SSV/MSV bytes, Viterbi words) by construction; float stages because
+oracle and kernels evaluate in the same canonical order, so float32 results are
+compared as bit patterns, not within a tolerance.
+"""
+import numpy as np
+import pytest
+
+from checkm_amd import _lib, synth
+from oracle import p7
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+STAGE_FIELDS = ["msv_xJ", "msv_sc", "null_sc", "bias_sc", "vit_xC", "vit_sc", "fwd_sc", "fwd_xC", "fwd_nscale"]
+
+
+@pytest.fixture(scope="module")
+def world(gpu_ctx):
+    profs = common.mixed_profiles()
+    path = common.hmm_file("mixed", profs)
+    bins = [synth.make_bin(profs, 1000 + b, n_orfs=160, dup_frac=0.4) for b in range(2)]
+    # edge cases: very short, all-X, stop-only tail, a long one
+    rng = np.random.default_rng(5)
+    bins[1] += [("edge_1", "", "M*"), ("edge_2", "", "XXXXXXXXXXXXXXXXXXXXXXXXXXXXXX*"), ("edge_3", "", "ACDEFGHIKLMNPQRSTVWY"),
+                ("edge_4", "", synth.to_text(synth.random_residues(rng, 3100)) + "*"), ("edge_5", "", "BJZOUX*acdefghiklmnpqrstvwy")]
+    prof = _lib.Profiles(gpu_ctx, path)
+    seqs = _lib.Seqs(gpu_ctx, bins)
+    hs = p7.HmmSet(path)
+    recs = [r for b in bins for r in b]
+    dsq = [p7.digitize(r[2]) for r in recs]
+    yield dict(ctx=gpu_ctx, profs=profs, prof=prof, seqs=seqs, hs=hs, recs=recs, dsq=dsq, bins=bins)
+    prof.close(); seqs.close(); hs.close()
+
+
+def _cmp_stage(o, g, f):
+    a, b = getattr(o, f), getattr(g, f)
+    if isinstance(a, float):
+        return np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32) or (np.isnan(a) and np.isnan(b))
+    return a == b
+
+
+def test_stage_scores_bit_exact(world):
+    w = world
+    rng = np.random.default_rng(3)
+    nseq = len(w["recs"])
+    pairs = [(m, s) for m in range(w["hs"].n) for s in rng.choice(nseq, size=40, replace=False)]
+    pairs += [(m, nseq - k) for m in range(w["hs"].n) for k in range(1, 6)]          # edge sequences vs every model
+    model = np.array([p[0] for p in pairs]); seq = np.array([p[1] for p in pairs])
+    got = _lib.debug_stages(w["ctx"], w["prof"], w["seqs"], model, seq)
+    bad = []
+    for i, (m, s) in enumerate(pairs):
+        o = w["hs"].stages(m, w["dsq"][s])
+        for f in STAGE_FIELDS:
+            if not _cmp_stage(o, got[i], f):
+                bad.append((m, s, f, getattr(o, f), getattr(got[i], f)))
+    assert not bad, bad[:10]
+
+
+def test_planted_pairs_bit_exact(world):
+    """Every pair the oracle carries beyond the MSV filter (true hits: overflow, rescaling, J state)."""
+    w = world
+    pairs = []
+    for m in range(w["hs"].n):
+        for s in range(len(w["recs"])):
+            if len(pairs) < 4000 and w["hs"].stages(m, w["dsq"][s]).pass_msv:
+                pairs.append((m, s))
+    model = np.array([p[0] for p in pairs]); seq = np.array([p[1] for p in pairs])
+    got = _lib.debug_stages(w["ctx"], w["prof"], w["seqs"], model, seq)
+    bad = []
+    for i, (m, s) in enumerate(pairs):
+        o = w["hs"].stages(m, w["dsq"][s])
+        for f in STAGE_FIELDS:
+            if not _cmp_stage(o, got[i], f):
+                bad.append((m, s, f, getattr(o, f), getattr(got[i], f)))
+    assert len(pairs) > 20
+    assert not bad, bad[:10]
+
+
+def test_envelopes_bit_exact(world):
+    w = world
+    rows = w["hs"].search(list(range(w["hs"].n)), w["dsq"][:160], [r[0] for r in w["recs"][:160]])
+    assert len(rows) >= 10
+    model = np.array([r.model_idx for r in rows]); seq = np.array([r.seq_idx for r in rows])
+    ienv = np.array([r.env_from for r in rows]); jenv = np.array([r.env_to for r in rows])
+    got = _lib.debug_envelopes(w["ctx"], w["prof"], w["seqs"], model, seq, ienv, jenv)
+    for i, r in enumerate(rows):
+        rc, envsc, oasc, null2, coords, xC, ns = w["hs"].envelope(r.model_idx, w["dsq"][r.seq_idx], r.env_from, r.env_to)
+        g = got[i]
+        assert g.ok == 1 and rc == 0
+        assert common.float_bits(envsc) == common.float_bits(g.envsc), (i, envsc, g.envsc)
+        assert common.float_bits(xC) == common.float_bits(g.fwd_xC) and ns == g.nscale
+        assert (common.float_bits(null2) == common.float_bits(np.array(g.null2[:]))).all(), (i, null2, list(g.null2))
+        assert common.float_bits(oasc) == common.float_bits(g.oasc), (i, oasc, g.oasc)
+        assert list(coords) == [g.hmm_from, g.hmm_to, g.ali_from, g.ali_to], (i, coords, g.hmm_from, g.hmm_to, g.ali_from, g.ali_to)
+
+
+ROW_INT = ["seq", "model", "tlen", "qlen", "dom_idx", "ndom", "hmm_from", "hmm_to", "ali_from", "ali_to", "env_from", "env_to"]
+ROW_F32 = ["full_score", "full_bias", "dom_score", "dom_bias", "acc"]
+ROW_F64 = ["full_evalue", "c_evalue", "i_evalue"]
+ORACLE_NAME = {"seq": "seq_idx", "model": "model_idx"}
+
+
+def _compare_search(w, hits, bin_models):
+    off = 0
+    for b, recs in enumerate(w["bins"]):
+        names = [r[0] for r in recs]
+        dsq = w["dsq"][off:off + len(recs)]
+        models = bin_models[b] if bin_models else list(range(w["hs"].n))
+        rows = w["hs"].search(models, dsq, names)
+        got = list(hits.rows(b))
+        assert len(rows) == len(got), (b, len(rows), len(got))
+        for r, g in zip(rows, got):
+            for f in ROW_INT:
+                ov = getattr(r, ORACLE_NAME.get(f, f)) + (off if f == "seq" else 0)
+                assert ov == getattr(hits, f)[g], (b, f, ov, getattr(hits, f)[g])
+            for f in ROW_F32:
+                assert common.float_bits(getattr(r, f)) == common.float_bits(getattr(hits, f)[g]), (b, f, getattr(r, f), getattr(hits, f)[g])
+            for f in ROW_F64:
+                assert getattr(r, f) == getattr(hits, f)[g], (b, f)
+        off += len(recs)
+
+
+def test_search_rows_identical(world):
+    w = world
+    hits = _lib.search(w["ctx"], w["prof"], w["seqs"])
+    assert hits.n > 20
+    _compare_search(w, hits, None)
+    st = w["ctx"].stats()
+    assert st.pairs_ssv == sum(1 for r in w["recs"] if len(r[2]) > 0) * w["hs"].n
+    hits.close()
+
+
+def test_search_per_bin_model_subsets(world):
+    """lineage_wf shape: every bin has its own model list, in its own order (markerSets.py:337-339)."""
+    w = world
+    n = w["hs"].n
+    bin_models = [[5, 2, 9, 0, 13], list(range(n - 1, -1, -2))]
+    hits = _lib.search(w["ctx"], w["prof"], w["seqs"], bin_models)
+    _compare_search(w, hits, bin_models)
+    hits.close()
+
+
+def test_domtblout_text_identical(world, tmp_path):
+    w = world
+    hits = _lib.search(w["ctx"], w["prof"], w["seqs"])
+    off = 0
+    for b, recs in enumerate(w["bins"]):
+        names = [r[0] for r in recs]; descs = [r[1] for r in recs]
+        rows = w["hs"].search(list(range(w["hs"].n)), w["dsq"][off:off + len(recs)], names)
+        want = w["hs"].format_domtblout(rows, names, descs)
+        path = str(tmp_path / ("b%d.txt" % b))
+        hits.write_domtblout(w["prof"], w["seqs"], b, path)
+        assert open(path).read() == want
+        off += len(recs)
+    hits.close()
