@@ -36,7 +36,8 @@ class HitColumns(C.Structure):
                 ("dom_score", C.POINTER(C.c_float)), ("dom_bias", C.POINTER(C.c_float)),
                 ("hmm_from", C.POINTER(C.c_int32)), ("hmm_to", C.POINTER(C.c_int32)),
                 ("ali_from", C.POINTER(C.c_int32)), ("ali_to", C.POINTER(C.c_int32)),
-                ("env_from", C.POINTER(C.c_int32)), ("env_to", C.POINTER(C.c_int32)), ("acc", C.POINTER(C.c_float))]
+                ("env_from", C.POINTER(C.c_int32)), ("env_to", C.POINTER(C.c_int32)), ("acc", C.POINTER(C.c_float)),
+                ("target_name", C.POINTER(C.c_char_p))]
 
 
 HIT_FIELDS = ["seq", "model", "tlen", "qlen", "full_evalue", "full_score", "full_bias", "dom_idx", "ndom", "c_evalue",
@@ -69,7 +70,8 @@ class ModelInfo(C.Structure):
 
 class ReduceFlags(C.Structure):
     _fields_ = [("ignore_thresholds", C.c_int32), ("skip_pseudogene_correction", C.c_int32), ("skip_adj_correction", C.c_int32),
-                ("individual_markers", C.c_int32), ("evalue_threshold", C.c_double), ("length_threshold", C.c_double)]
+                ("individual_markers", C.c_int32), ("evalue_threshold", C.c_double), ("length_threshold", C.c_double),
+                ("bin_select", C.c_void_p)]
 
 
 class MarkerSetsCSR(C.Structure):
@@ -91,7 +93,7 @@ class QAColumns(C.Structure):
 EXPORTS = ["ckm_last_error", "ckm_abi_version", "ckm_device_count", "ckm_ctx_create", "ckm_ctx_destroy",
            "ckm_profiles_load", "ckm_profiles_count", "ckm_profiles_header", "ckm_profiles_free",
            "ckm_seqs_pack", "ckm_seqs_residues", "ckm_seqs_free", "ckm_search", "ckm_hits_columns", "ckm_hits_free",
-           "ckm_hits_write_domtblout", "ckm_last_search_stats", "ckm_reduce", "ckm_qa_columns_get", "ckm_qa_free",
+           "ckm_hits_write_domtblout", "ckm_last_search_stats", "ckm_reduce", "ckm_qa_columns_get", "ckm_qa_free", "ckm_count_sets",
            "ckm_debug_stages", "ckm_debug_envelopes"]
 
 _lib = None
@@ -128,12 +130,12 @@ def load():
     L.ckm_hits_free.restype = None
     L.ckm_hits_write_domtblout.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p]
     L.ckm_last_search_stats.argtypes = [C.c_void_p, C.POINTER(SearchStats)]
-    if hasattr(L, "ckm_reduce"):   # TEMP until the reduce half lands
-        L.ckm_reduce.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(HitColumns), C.c_void_p, C.POINTER(ModelInfo),
-                                 C.POINTER(ReduceFlags), C.POINTER(MarkerSetsCSR), C.POINTER(C.c_void_p)]
-        L.ckm_qa_columns_get.argtypes = [C.c_void_p, C.POINTER(QAColumns)]
-        L.ckm_qa_free.argtypes = [C.c_void_p]
-        L.ckm_qa_free.restype = None
+    L.ckm_reduce.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(HitColumns), C.c_void_p, C.POINTER(ModelInfo),
+                             C.POINTER(ReduceFlags), C.POINTER(MarkerSetsCSR), C.POINTER(C.c_void_p)]
+    L.ckm_qa_columns_get.argtypes = [C.c_void_p, C.POINTER(QAColumns)]
+    L.ckm_qa_free.argtypes = [C.c_void_p]
+    L.ckm_qa_free.restype = None
+    L.ckm_count_sets.argtypes = [C.c_void_p, C.POINTER(MarkerSetsCSR)] + [C.c_void_p] * 7
     L.ckm_debug_stages.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.ckm_debug_envelopes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_uint32, C.c_void_p]

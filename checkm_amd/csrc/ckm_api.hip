@@ -118,6 +118,10 @@ static int guarded(F &&f) {
   catch (const std::exception &e) { set_last_error(e.what()); return CKM_EINVAL; }
 }
 
+// accessors for ckm_reduce.hip
+const std::string &ckm_seq_name(const ckm_seqs *s, uint32_t i) { return s->names.at(i); }
+int ckm_ctx_device(const ckm_ctx *ctx) { return ctx->device; }
+
 extern "C" const char *ckm_last_error(void) { return g_err.c_str(); }
 extern "C" int ckm_abi_version(void) { return CKM_ABI_VERSION; }
 
@@ -847,6 +851,7 @@ extern "C" int ckm_hits_columns(const ckm_hits *h, ckm_hit_columns *o) {
   o->dom_score = h->dom_score.data(); o->dom_bias = h->dom_bias.data();
   o->hmm_from = h->hmm_from.data(); o->hmm_to = h->hmm_to.data(); o->ali_from = h->ali_from.data(); o->ali_to = h->ali_to.data();
   o->env_from = h->env_from.data(); o->env_to = h->env_to.data(); o->acc = h->acc.data();
+  o->target_name = nullptr;
   return CKM_OK;
 }
 

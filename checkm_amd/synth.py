@@ -102,16 +102,24 @@ def write_hmm(path, profiles, mode="w"):
             f.write("//\n")
 
 
+def _cdf(prof):
+    if not hasattr(prof, "_mat_cdf"):
+        prof._mat_cdf = np.cumsum(prof.mat / prof.mat.sum(axis=1, keepdims=True), axis=1)
+        prof._bg_cdf = np.cumsum(BGF)
+    return prof._mat_cdf, prof._bg_cdf
+
+
 def sample_domain(rng, prof, k_from=1, k_to=None):
     """Emit one pass through the core model nodes k_from..k_to (M/I/D walk)."""
     k_to = prof.M if k_to is None else k_to
+    mat_cdf, bg_cdf = _cdf(prof)
     out = []
     k, st = k_from, "M"
     while True:
         if st == "M":
-            out.append(rng.choice(20, p=prof.mat[k] / prof.mat[k].sum()))
+            out.append(min(19, int(np.searchsorted(mat_cdf[k], rng.random()))))
         elif st == "I":
-            out.append(rng.choice(20, p=BGF))
+            out.append(min(19, int(np.searchsorted(bg_cdf, rng.random()))))
         if k == k_to and st != "I":
             break
         if st == "M":
@@ -157,7 +165,9 @@ def make_bin(profiles, seed, n_orfs=2000, plant=True, dup_frac=0.05, orfs_per_co
     """
     rng = np.random.default_rng(seed)
     lens = orf_lengths(rng, n_orfs)
-    seqs = [random_residues(rng, int(L)) for L in lens]
+    flat = random_residues(rng, int(lens.sum()))
+    cuts = np.cumsum(lens)[:-1]
+    seqs = np.split(flat, cuts)
     if plant and profiles:
         slots = rng.permutation(n_orfs - 1)[: 2 * len(profiles)]
         for mi, p in enumerate(profiles):
@@ -181,6 +191,7 @@ def make_bin(profiles, seed, n_orfs=2000, plant=True, dup_frac=0.05, orfs_per_co
                     seqs[s2] = np.concatenate([fr, sample_domain(rng, p), fl])
     out = []
     pos = 1
+    lut = np.frombuffer(AMINO.encode(), dtype=np.uint8)
     for i, sq in enumerate(seqs):
         contig = i // orfs_per_contig + 1
         n = i % orfs_per_contig + 1
@@ -188,7 +199,7 @@ def make_bin(profiles, seed, n_orfs=2000, plant=True, dup_frac=0.05, orfs_per_co
         end = pos + 3 * (len(sq) + 1) - 1
         desc = "# %d # %d # 1 # ID=%d_%d;partial=00;start_type=ATG;rbs_motif=None;rbs_spacer=None" % (pos, end, contig, n)
         pos = end + 50
-        out.append((name, desc, to_text(sq) + "*"))
+        out.append((name, desc, lut[sq].tobytes().decode() + "*"))
     return out
 
 

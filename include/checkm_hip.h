@@ -105,6 +105,10 @@ typedef struct {
   const double   *c_evalue, *i_evalue; const float *dom_score, *dom_bias;
   const int32_t  *hmm_from, *hmm_to, *ali_from, *ali_to, *env_from, *env_to;
   const float    *acc;
+  /* Only when the struct is INPUT to ckm_reduce (a table parsed from existing domtblout text):
+   * target name of every row (prodigal `<contig>_<n>` form, resultsParser.py:410-422).  NULL in
+   * the struct ckm_hits_columns() fills: those rows take their names from the ckm_seqs. */
+  const char *const *target_name;
 } ckm_hit_columns;
 
 int  ckm_hits_columns(const ckm_hits *h, ckm_hit_columns *out);
@@ -136,7 +140,7 @@ typedef struct {
   uint32_t        nmodels;
   const int32_t  *qlen;
   const uint8_t  *thr_kind;     /* 0 none, 1 NC(TIGR), 2 GA, 3 TC, 4 NC : the cascade of resultsParser.py:356-367, resolved by the caller from the (sticky) header view */
-  const float    *thr_full, *thr_dom;
+  const double   *thr_full, *thr_dom; /* Python floats in the reference: compared as float64 */
   const uint8_t  *is_pf;        /* marker id starts with 'PF' (pfam.py:97) */
   const int32_t  *clan;         /* clan id or -1 (pfam.py:116: None==None counts as same clan) */
   const uint32_t *nest_off, *nest_idx;   /* CSR: models nested with model m (pfam.py:135) */
@@ -146,6 +150,7 @@ typedef struct {
 typedef struct {
   int32_t ignore_thresholds, skip_pseudogene_correction, skip_adj_correction, individual_markers;
   double  evalue_threshold, length_threshold;
+  const uint8_t *bin_select;    /* NULL = every bin; else only bins with a non-zero byte are reduced */
 } ckm_reduce_flags;
 
 typedef struct {
@@ -177,6 +182,16 @@ typedef struct {
 
 int  ckm_qa_columns_get(const ckm_qa *q, ckm_qa_columns *out);
 void ckm_qa_free(ckm_qa *q);
+
+/* The set-counting kernel alone: replaces the counting loops of MarkerSet.genomeCheck
+ * (checkm/markerSets.py:206-238) and ResultsManager.geneCounts (checkm/resultsParser.py:513-529)
+ * for caller-supplied copy numbers.  marker_count[i] = number of hits of marker i of the CSR
+ * (i indexes ms->marker_key), marker_first[i] != 0 iff this is the first occurrence of that marker
+ * within its bin.  Outputs: set_present/set_multi [nsets], hist [nbins*6], and per bin the
+ * individual-marker totals present_total/multi_total [nbins].  The float64 division is left to the
+ * caller, to be done in the reference's accumulation order. */
+int  ckm_count_sets(ckm_ctx *ctx, const ckm_marker_sets *ms, const int32_t *marker_count, const uint8_t *marker_first,
+                    int32_t *set_present, int32_t *set_multi, int32_t *hist, int32_t *present_total, int32_t *multi_total);
 
 /* ---- diagnostics used by the parity tests: every stage of one (model, sequence) pair, no filtering */
 typedef struct {
