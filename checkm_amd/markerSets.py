@@ -1,0 +1,330 @@
+"""Marker-set containers and marker-file parsing, API-compatible with checkm/markerSets.py.
+
+MarkerSet.genomeCheck (markerSets.py:206-238) is computed by the set-counting kernel
+(ckm_count_sets); the float64 division is finished here in the reference's accumulation order.
+The per-bin temporary HMM file of the reference (hmmfetch -f, markerSets.py:326-343,443-476) is
+replaced by an index list into ONE resident profile database, in database order (deterministic,
+unlike the reference's set-iteration order).
+"""
+import ast
+import ctypes as C
+import gzip
+import logging
+import os
+import pickle
+import sys
+
+import numpy as np
+
+from checkm_amd.defaultValues import DefaultValues
+from checkm_amd.hmmerModelParser import HmmModelParser, models_dict, read_headers
+from checkm_amd.pfam import PFAM
+
+
+class BinMarkerSets(object):
+    """One or more marker sets associated with a bin (markerSets.py:39-154)."""
+
+    TAXONOMIC_MARKER_SET = 1
+    TREE_MARKER_SET = 2
+    HMM_MODELS_SET = 3
+
+    def __init__(self, binId, markerSetType):
+        self.logger = logging.getLogger('timestamp')
+        self.markerSets = []
+        self.binId = binId
+        self.markerSetType = markerSetType
+        self.selectedLinageSpecificMarkerSet = None
+
+    def numMarkerSets(self):
+        return len(self.markerSets)
+
+    def addMarkerSet(self, markerSet):
+        self.markerSets.append(markerSet)
+
+    def markerSetIter(self):
+        return iter(self.markerSets)
+
+    def getMarkerGenes(self):
+        genes = set()
+        for ms in self.markerSets:
+            genes |= ms.getMarkerGenes()
+        return genes
+
+    def mostSpecificMarkerSet(self):
+        return self.markerSets[0]
+
+    def selectedMarkerSet(self):
+        if self.markerSetType == self.TAXONOMIC_MARKER_SET:
+            return self.mostSpecificMarkerSet()
+        if self.markerSetType == self.TREE_MARKER_SET:
+            return self.selectedLinageSpecificMarkerSet
+        if len(self.markerSets) == 1:
+            return self.markerSets[0]
+        self.logger.error('Expect a single marker set to be associated with each bin.')
+        sys.exit(1)
+
+    def setLineageSpecificSelectedMarkerSet(self, selectedMarkerSetMap):
+        """Follow the selected-set map until a set this bin actually carries is reached (markerSets.py:95-121)."""
+        wanted = selectedMarkerSetMap[self.mostSpecificMarkerSet().UID]
+        self.selectedLinageSpecificMarkerSet = None
+        while self.selectedLinageSpecificMarkerSet is None:
+            for ms in self.markerSets:
+                if ms.UID == wanted:
+                    self.selectedLinageSpecificMarkerSet = ms
+                    break
+            else:
+                wanted = selectedMarkerSetMap[wanted]
+        if self.selectedLinageSpecificMarkerSet is None:
+            self.logger.error('Failed to set a selected lineage-specific marker set.')
+            sys.exit(1)
+
+    def removeMarkers(self, markersToRemove):
+        for ms in self.markerSets:
+            ms.removeMarkers(markersToRemove)
+
+    def write(self, fout):
+        fout.write(self.binId + '\t' + str(len(self.markerSets)))
+        for ms in self.markerSets:
+            fout.write('\t' + str(ms))
+        fout.write('\n')
+
+    def read(self, line):
+        f = line.split('\t')
+        for i in range(int(f[1])):
+            uid, lineage, ngen, sets = f[4 * i + 2], f[4 * i + 3], int(f[4 * i + 4]), ast.literal_eval(f[4 * i + 5].strip())
+            self.markerSets.append(MarkerSet(uid, lineage, ngen, [set(s) for s in sets]))
+
+
+def count_sets(list_of_sets, hits):
+    """Device counting for ONE marker set: returns (set_present, set_multi, hist6, present_total, multi_total)."""
+    from checkm_amd import _lib, runtime
+    markers, marker_off, first = [], [0], []
+    seen = set()
+    for s in list_of_sets:
+        for m in s:
+            markers.append(m)
+            first.append(0 if m in seen else 1)
+            seen.add(m)
+        marker_off.append(len(markers))
+    counts = np.array([len(hits[m]) if m in hits else 0 for m in markers] or [0], dtype=np.int32)
+    # --individual_markers counts dict membership, even with an empty list
+    member = np.array([1 if m in hits else 0 for m in markers] or [0], dtype=np.int32)
+    nsets = len(list_of_sets)
+    set_off = np.array([0, nsets], dtype=np.uint32)
+    moff = np.array(marker_off, dtype=np.uint32)
+    mkey = np.arange(max(1, len(markers)), dtype=np.uint32)
+    firsta = np.array(first or [0], dtype=np.uint8)
+    ms = _lib.MarkerSetsCSR(1, set_off.ctypes.data, moff.ctypes.data, mkey.ctypes.data)
+    pres = np.zeros(max(1, nsets), dtype=np.int32); mult = np.zeros(max(1, nsets), dtype=np.int32)
+    hist = np.zeros(6, dtype=np.int32); pt = np.zeros(1, dtype=np.int32); mt = np.zeros(1, dtype=np.int32)
+    _lib._chk(_lib.load().ckm_count_sets(runtime.get_ctx().h, C.byref(ms), counts.ctypes.data, firsta.ctypes.data, pres.ctypes.data,
+                                         mult.ctypes.data, hist.ctypes.data, pt.ctypes.data, mt.ctypes.data))
+    n_member = int((member * firsta[:len(member)]).sum())
+    empty_members = int(((member == 1) & (counts == 0) & (firsta[:len(member)] == 1)).sum())
+    return pres[:nsets], mult[:nsets], hist, int(pt[0]), int(mt[0]), n_member, empty_members
+
+
+class MarkerSet(object):
+    """Marker genes organised into collocated sets (markerSets.py:157-238)."""
+
+    def __init__(self, UID, lineageStr, numGenomes, markerSet):
+        self.logger = logging.getLogger('timestamp')
+        self.UID = UID
+        self.lineageStr = lineageStr
+        self.numGenomes = numGenomes
+        self.markerSet = markerSet
+
+    def __repr__(self):
+        return str(self.UID) + '\t' + self.lineageStr + '\t' + str(self.numGenomes) + '\t' + str(self.markerSet)
+
+    def size(self):
+        return sum(len(m) for m in self.markerSet), len(self.markerSet)
+
+    def numMarkers(self):
+        return self.size()[0]
+
+    def numSets(self):
+        return len(self.markerSet)
+
+    def getMarkerGenes(self):
+        genes = set()
+        for m in self.markerSet:
+            genes |= set(m)
+        return genes
+
+    def removeMarkers(self, markersToRemove):
+        kept = []
+        for ms in self.markerSet:
+            rest = ms - markersToRemove
+            if rest:
+                kept.append(rest)
+        self.markerSet = kept
+
+    def genomeCheck(self, hits, bIndividualMarkers):
+        """Completeness / contamination; counting on the device, float64 division in the reference's order."""
+        pres, mult, _hist, _pt, mt, n_member, empty_members = count_sets(self.markerSet, hits)
+        if bIndividualMarkers:
+            # `marker in hits` counts a key with an empty list as present and contributes len-1 = -1
+            present = n_member
+            multi = mt - empty_members
+            return 100 * float(present) / self.numMarkers(), 100 * float(multi) / self.numMarkers()
+        comp = 0.0
+        cont = 0.0
+        for i, ms in enumerate(self.markerSet):
+            comp += float(int(pres[i])) / len(ms)
+            cont += float(int(mult[i])) / len(ms)
+        return 100 * comp / len(self.markerSet), 100 * cont / len(self.markerSet)
+
+
+class MarkerSetParser(object):
+    """Marker-file parsing (markerSets.py:241-540)."""
+
+    def __init__(self, threads=1):
+        self.logger = logging.getLogger('timestamp')
+        self.numThreads = threads
+
+    # ---- marker sets per bin ------------------------------------------------------------------
+    def getMarkerSets(self, outDir, binIds, markerFile, excludeMarkersFile=None):
+        kind = self.markerFileType(markerFile)
+        out = {}
+        if kind == BinMarkerSets.TAXONOMIC_MARKER_SET:
+            bms = self.parseTaxonomicMarkerSetFile(markerFile)
+            for binId in binIds:
+                out[binId] = bms
+        elif kind == BinMarkerSets.TREE_MARKER_SET:
+            out = self.parseLineageMarkerSetFile(markerFile)
+        else:
+            accs = set(m.acc for m in HmmModelParser(markerFile).parse())
+            ms = MarkerSet(0, "N/A", -1, [accs])
+            for binId in binIds:
+                b = BinMarkerSets(binId, BinMarkerSets.HMM_MODELS_SET)
+                b.addMarkerSet(ms)
+                out[binId] = b
+        exclude = set()
+        if excludeMarkersFile:
+            exclude = self.readExcludeMarkersFile(excludeMarkersFile)
+        exclude.update(DefaultValues.MARKERS_TO_EXCLUDE)
+        for b in out.values():
+            b.removeMarkers(exclude)
+        return out
+
+    def readExcludeMarkersFile(self, excludeMarkersFile):
+        out = set()
+        with open(excludeMarkersFile) as f:
+            for line in f:
+                if line[0] == '#':
+                    continue
+                out.add(line.strip())
+        return out
+
+    def markerFileType(self, markerFile):
+        with open(markerFile, 'r') as f:
+            header = f.readline()
+        if DefaultValues.TAXON_MARKER_FILE_HEADER in header:
+            return BinMarkerSets.TAXONOMIC_MARKER_SET
+        if DefaultValues.LINEAGE_MARKER_FILE_HEADER in header:
+            return BinMarkerSets.TREE_MARKER_SET
+        if 'HMMER3' in header:
+            return BinMarkerSets.HMM_MODELS_SET
+        self.logger.error('Unrecognized file type: ' + markerFile)
+        sys.exit(1)
+
+    def parseTaxonomicMarkerSetFile(self, markerSetFile):
+        with open(markerSetFile) as f:
+            f.readline()
+            line = f.readline()
+        bms = BinMarkerSets(line.split('\t')[0], BinMarkerSets.TAXONOMIC_MARKER_SET)
+        bms.read(line)
+        return bms
+
+    def parseLineageMarkerSetFile(self, markerSetFile):
+        out = {}
+        selected = None
+        with open(markerSetFile) as f:
+            f.readline()
+            for line in f:
+                binId = line.split('\t')[0]
+                bms = BinMarkerSets(binId, BinMarkerSets.TREE_MARKER_SET)
+                bms.read(line)
+                if selected is None:
+                    selected = self.parseSelectedMarkerSetMap()     # parsed once, not once per line (markerSets.py:506)
+                bms.setLineageSpecificSelectedMarkerSet(selected)
+                out[binId] = bms
+        return out
+
+    def parseSelectedMarkerSetMap(self):
+        m = {}
+        with open(DefaultValues.SELECTED_MARKER_SETS) as f:
+            for line in f:
+                p = line.split('\t')
+                m[p[0]] = p[1].rstrip()
+        return m
+
+    # ---- which models does a bin need ------------------------------------------------------------
+    def hmmDatabaseFor(self, markerFile):
+        """The profile database a marker file refers to: itself for raw HMM files, else checkm.hmm."""
+        return markerFile if self.markerFileType(markerFile) == BinMarkerSets.HMM_MODELS_SET else DefaultValues.HMM_MODELS
+
+    def markerAccessionsForBins(self, binIds, markerFile):
+        """{binId: set(accession)} -- marker genes plus every Pfam family of the clans they span
+        (markerSets.py:443-457); None for raw HMM files (= every model)."""
+        kind = self.markerFileType(markerFile)
+        if kind == BinMarkerSets.HMM_MODELS_SET:
+            return {b: None for b in binIds}
+        pfam = PFAM(DefaultValues.PFAM_CLAN_FILE)
+        cache = {}
+
+        def expand(bms):
+            genes = bms.getMarkerGenes()
+            key = frozenset(genes)
+            if key not in cache:
+                cache[key] = genes | pfam.genesInSameClan(genes)
+            return cache[key]
+        if kind == BinMarkerSets.TAXONOMIC_MARKER_SET:
+            accs = expand(self.parseTaxonomicMarkerSetFile(markerFile))
+            return {b: accs for b in binIds}
+        per_bin = self.parseLineageMarkerSetFile(markerFile)
+        return {b: expand(per_bin[b]) for b in binIds}
+
+    def createHmmModels(self, outDir, binIds, markerFile):
+        """{binId: {acc: HmmModel}} without launching anything (markerSets.py:299-324)."""
+        db = self.hmmDatabaseFor(markerFile)
+        headers = read_headers(db)
+        wanted = self.markerAccessionsForBins(list(binIds), markerFile)
+        out = {}
+        for b in binIds:
+            sel = [h for h in headers if wanted[b] is None or (h['acc'] or h['name']) in wanted[b]]
+            out[b] = models_dict(sel)
+        return out
+
+    def createHmmModelFile(self, binId, markerFile):
+        """Kept for API compatibility: writes the bin's model subset as a HMMER3 text file (database order)."""
+        import tempfile
+        import uuid
+        db = self.hmmDatabaseFor(markerFile)
+        wanted = self.markerAccessionsForBins([binId], markerFile)[binId]
+        out = os.path.join(tempfile.gettempdir(), str(uuid.uuid4()))
+        with open(db) as fin, open(out, 'w') as fout:
+            rec, acc, name = [], None, None
+            for line in fin:
+                rec.append(line)
+                if line.startswith('NAME'):
+                    name = line.split(None, 1)[1].strip()
+                elif line.startswith('ACC'):
+                    acc = line.split(None, 1)[1].strip()
+                elif line.startswith('//'):
+                    if wanted is None or (acc or name) in wanted:
+                        fout.writelines(rec)
+                    rec, acc, name = [], None, None
+        return out
+
+    # ---- model-info cache between `analyze` and `qa` ----------------------------------------------
+    def writeBinModels(self, binIdToModels, filename):
+        self.logger.info('Saving HMM info to file.')
+        with gzip.open(filename, 'wb') as output:
+            pickle.dump(binIdToModels, output, pickle.HIGHEST_PROTOCOL)
+
+    def loadBinModels(self, filename):
+        self.logger.info('Reading HMM info from file.')
+        with gzip.open(filename, 'rb') as f:
+            return pickle.load(f)

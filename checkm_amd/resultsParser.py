@@ -1,0 +1,393 @@
+"""ResultsParser / ResultsManager, API-compatible with checkm/resultsParser.py:41-565.
+
+All hit filtering (vetHit, addHit, clan filter, adjacent-ORF merging) runs inside libcheckm_hip
+(ckm_reduce); marker-set counting runs in its kernels (ckm_count_sets via MarkerSet.genomeCheck).
+When the scan ran in this process its packed hits are reduced directly; otherwise the domtblout
+text written earlier is parsed and handed to the same library entry (column form).
+"""
+from collections import defaultdict
+import ast
+import logging
+import os
+import sys
+
+import numpy as np
+
+from checkm_amd import qa as cqa
+from checkm_amd import runtime
+from checkm_amd.common import checkFileExists
+from checkm_amd.defaultValues import DefaultValues
+from checkm_amd.hmmer import HmmerHitDOM, read_domtblout
+from checkm_amd.markerSets import count_sets
+from checkm_amd.pfam import PFAM
+
+
+def _plan_for_models(models_list):
+    """models_list: list of HmmModel (one per model slot).  Builds the ckm_model_info part of a QAPlan."""
+    pf = PFAM(DefaultValues.PFAM_CLAN_FILE)
+    clans, nested = {}, {}
+    if os.path.exists(DefaultValues.PFAM_CLAN_FILE):
+        pf.readClansAndNesting()
+        clans, nested = pf.clan, pf.nested
+    keys = cqa.KeyTable()
+    acc = [m.acc for m in models_list]
+    qlen = [m.leng for m in models_list]
+    thr = [cqa.resolve_threshold(m.acc, m.ga, m.tc, m.nc) for m in models_list]
+    return keys, acc, qlen, thr, clans, nested
+
+
+class ResultsManager(object):
+    """Results of a single bin (resultsParser.py:322-565)."""
+
+    def __init__(self, binId, models, bIgnoreThresholds=False, evalueThreshold=DefaultValues.E_VAL,
+                 lengthThreshold=DefaultValues.LENGTH, bSkipPseudoGeneCorrection=False, binStats=None):
+        self.binId = binId
+        self.markerHits = {}
+        self.bIgnoreThresholds = bIgnoreThresholds
+        self.evalueThreshold = evalueThreshold
+        self.lengthThreshold = lengthThreshold
+        self.bSkipPseudoGeneCorrection = bSkipPseudoGeneCorrection
+        self.models = models
+        self.binStats = binStats
+        self._raw = []
+
+    # ---- hit intake: rows are collected, filtering happens in the library -------------------------
+    def addHit(self, hit):
+        self._raw.append(hit)
+
+    def _reduce_raw(self, bSkipAdjCorrection):
+        """Run vetHit/addHit/clan filter/adjacent merge for the collected rows (ext form of ckm_reduce)."""
+        accs = list(self.models.keys())
+        slot = {a: i for i, a in enumerate(accs)}
+        keys, acc, qlen, thr, clans, nested = _plan_for_models([self.models[a] for a in accs])
+        plan = cqa.QAPlan(keys, acc, qlen, thr, [[]], clans, nested)
+        rows = [h.as_dict() for h in self._raw]
+        hc = cqa.ext_columns([rows], lambda r: slot[r["query_accession"]])
+        res = plan.reduce(runtime.get_ctx(), None, None, self.bIgnoreThresholds, self.evalueThreshold, self.lengthThreshold,
+                          self.bSkipPseudoGeneCorrection, bSkipAdjCorrection, False, None, hc)
+        self.markerHits = _marker_hits_from(res, 0, keys, lambda r: self._raw[r])
+        res.close()
+
+    def identifyAdjacentMarkerGenes(self):
+        self._reduce_raw(False)
+
+    # ---- counting ----------------------------------------------------------------------------------
+    def countUniqueHits(self):
+        uniq = multi = 0
+        for hits in self.markerHits.values():
+            if len(hits) == 1:
+                uniq += 1
+            elif len(hits) > 1:
+                multi += 1
+        return uniq, multi
+
+    def hitsToMarkerGene(self, markerSet):
+        ret = {}
+        for marker in markerSet.getMarkerGenes():
+            try:
+                ret[marker] = len(self.markerHits[marker])
+            except KeyError:
+                ret[marker] = 0
+        return ret
+
+    def geneCountsForSelectedMarkerSet(self, binMarkerSets, bIndividualMarkers):
+        return self.geneCounts(binMarkerSets.selectedMarkerSet(), self.markerHits, bIndividualMarkers)
+
+    def geneCounts(self, markerSet, markerHits, bIndividualMarkers):
+        """[n0, n1, n2, n3, n4, n5+, completeness, contamination] (resultsParser.py:513-537); counted on the device."""
+        _pres, _mult, hist, _pt, _mt, _nm, empty_members = count_sets(markerSet.markerSet, markerHits)
+        counts = [int(x) for x in hist]
+        comp, cont = markerSet.genomeCheck(markerHits, bIndividualMarkers)
+        return counts + [comp, cont]
+
+    def geneCopyNumber(self, binMarkerSets):
+        out = {'GCN0': [], 'GCN1': [], 'GCN2': [], 'GCN3': [], 'GCN4': [], 'GCN5+': []}
+        genes = binMarkerSets.selectedMarkerSet().getMarkerGenes()
+        for marker in self.models:
+            if marker not in genes:
+                continue
+            mid = os.path.splitext(marker)[0]
+            if marker in self.markerHits:
+                n = len(self.markerHits[marker])
+                out['GCN5+' if n >= 5 else 'GCN' + str(n)].append(mid)
+            else:
+                out['GCN0'].append(mid)
+        return out
+
+    def getSummary(self, binMarkerSets, bIndividualMarkers, outputFormat=1):
+        summary = {}
+        if outputFormat in (1, 2):
+            sel = binMarkerSets.selectedMarkerSet()
+            data = self.geneCountsForSelectedMarkerSet(binMarkerSets, bIndividualMarkers)
+            summary['marker lineage'] = sel.lineageStr
+            summary['# genomes'] = sel.numGenomes
+            summary['# markers'] = sel.numMarkers()
+            summary['# marker sets'] = sel.numSets()
+            for i, k in enumerate(['0', '1', '2', '3', '4', '5+']):
+                summary[k] = data[i]
+            summary['Completeness'] = data[6]
+            summary['Contamination'] = data[7]
+            if outputFormat == 2 and self.binStats:
+                summary.update(self.binStats)
+        elif outputFormat == 5:
+            genes = binMarkerSets.selectedMarkerSet().getMarkerGenes()
+            for marker, hl in self.markerHits.items():
+                if marker in genes:
+                    summary[marker] = [h.target_name for h in hl]
+        elif outputFormat == 6:
+            genes = binMarkerSets.selectedMarkerSet().getMarkerGenes()
+            for marker, hl in self.markerHits.items():
+                if marker in genes and len(hl) >= 2:
+                    summary[marker] = [h.target_name for h in hl]
+        elif outputFormat == 8:
+            genes = binMarkerSets.selectedMarkerSet().getMarkerGenes()
+            per_gene = {}
+            for marker, hl in self.markerHits.items():
+                if marker not in genes:
+                    continue
+                for h in hl:
+                    per_gene.setdefault(h.target_name, []).append(h)
+            for gene, hl in per_gene.items():
+                summary[gene] = {}
+                for h in hl:
+                    summary[gene].setdefault(h.query_accession, []).append([h.ali_from, h.ali_to])
+        else:
+            print("Unknown output format: ", outputFormat)
+        return summary
+
+    def printSummary(self, outputFormat, aai, binMarkerSets, bIndividualMarkers, coverageBinProfiles=None, table=None, anaFolder=None):
+        """Formats 1 and 2 (the QA table rows, resultsParser.py:680-764)."""
+        sel = binMarkerSets.selectedMarkerSet()
+        lineage = sel.lineageStr
+        if sel.UID != '0':
+            lineage += ' (' + str(sel.UID) + ')'
+        data = self.geneCountsForSelectedMarkerSet(binMarkerSets, bIndividualMarkers)
+        het = aai.aaiMeanBinHetero.get(self.binId, 0.0) if aai is not None else 0.0
+        if outputFormat == 1:
+            if table is None:
+                print("%s\t%s\t%d\t%d\t%d\t%s\t%0.2f\t%0.2f\t%0.2f" % (self.binId, lineage, sel.numGenomes, sel.numMarkers(), sel.numSets(),
+                                                                           "\t".join(str(data[i]) for i in range(6)), data[6], data[7], het))
+            else:
+                table.add_row([self.binId, lineage, sel.numGenomes, sel.numMarkers(), sel.numSets()] + data[0:6] + [data[6], data[7], het])
+        elif outputFormat == 2:
+            bs = self.binStats or {}
+            cols = [self.binId, lineage, sel.numGenomes, sel.numMarkers(), sel.numSets(), data[6], data[7], het]
+            for k in ('Genome size', '# ambiguous bases', '# scaffolds', '# contigs', 'N50 (scaffolds)', 'N50 (contigs)',
+                      'Mean scaffold length', 'Mean contig length', 'Longest scaffold', 'Longest contig'):
+                cols.append(bs.get(k, 0))
+            cols += [bs.get('GC', 0.0) * 100, bs.get('GC std', 0.0) * 100, bs.get('Coding density', 0.0) * 100,
+                     bs.get('Translation table', 0), bs.get('# predicted genes', 0)] + data[0:6]
+            if table is None:
+                print("\t".join(("%0.2f" % c) if isinstance(c, float) else str(c) for c in cols))
+            else:
+                table.add_row(cols)
+        else:
+            self.logger = logging.getLogger('timestamp')
+            self.logger.error("Output format %d is not part of the accelerated path." % outputFormat)
+            sys.exit(1)
+        return 0
+
+
+def _marker_hits_from(res, b, keys, row_to_hit):
+    """Rebuild ResultsManager.markerHits ({acc: [HmmerHitDOM]}) of bin b from the library's kept rows.
+    A defaultdict, as PFAM.filterHitsFromSameClan returns one (pfam.py:94)."""
+    mh = defaultdict(list)
+    for i in range(int(res.kept_bin_off[b]), int(res.kept_bin_off[b + 1])):
+        base = row_to_hit(int(res.kept_row[i]))
+        h = HmmerHitDOM.from_fields(**base.as_dict())
+        if int(res.kept_row2[i]) != 0xFFFFFFFFFFFFFFFF:
+            other = row_to_hit(int(res.kept_row2[i]))
+            h.target_name = DefaultValues.SEQ_CONCAT_CHAR.join(sorted([base.target_name, other.target_name]))
+        h.target_length = int(res.kept_tlen[i])
+        h.hmm_from, h.hmm_to = int(res.kept_hmm_from[i]), int(res.kept_hmm_to[i])
+        h.ali_from, h.ali_to = int(res.kept_ali_from[i]), int(res.kept_ali_to[i])
+        h.env_from, h.env_to = int(res.kept_env_from[i]), int(res.kept_env_to[i])
+        mh[keys.names[int(res.kept_key[i])]].append(h)
+    return mh
+
+
+class _Table(object):
+    """Minimal frame-ruled table for the non-tab output mode."""
+
+    def __init__(self, header):
+        self.header = header
+        self.rows = []
+
+    def add_row(self, row):
+        self.rows.append(row)
+
+    def render(self, sort_col=None, reverse=False):
+        rows = list(self.rows)
+        if sort_col is not None:
+            i = self.header.index(sort_col)
+            rows.sort(key=lambda r: r[i], reverse=reverse)
+        txt = [[("%.2f" % c) if isinstance(c, float) else str(c) for c in r] for r in rows]
+        w = [max([len(self.header[i])] + [len(r[i]) for r in txt]) for i in range(len(self.header))]
+        rule = '-' * (sum(w) + 2 * len(w) + len(w) - 1)
+        out = [rule, '  '.join((self.header[i].ljust(w[i]) if i == 0 else self.header[i].center(w[i])) for i in range(len(w))), rule]
+        for r in txt:
+            out.append('  '.join((r[i].ljust(w[i]) if i == 0 else r[i].center(w[i])) for i in range(len(w))))
+        out.append(rule)
+        return '\n'.join(out)
+
+
+class ResultsParser(object):
+    """Parse the scan output for every bin and derive QA statistics (resultsParser.py:41-319)."""
+
+    def __init__(self, binIdToModels):
+        self.logger = logging.getLogger('timestamp')
+        self.results = {}
+        self.models = binIdToModels
+
+    def analyseResults(self, outDir, binStatsFile, hmmTableFile, bIgnoreThresholds=False, evalueThreshold=DefaultValues.E_VAL,
+                       lengthThreshold=DefaultValues.LENGTH, bSkipPseudoGeneCorrection=False, bSkipAdjCorrection=False):
+        binStats = self.parseBinStats(outDir, binStatsFile)
+        self.parseBinHits(outDir, hmmTableFile, bSkipAdjCorrection, bIgnoreThresholds, evalueThreshold, lengthThreshold,
+                          bSkipPseudoGeneCorrection, binStats)
+        return binStats
+
+    def parseBinStats(self, resultsFolder, binStatsFile):
+        path = os.path.join(resultsFolder, 'storage', binStatsFile)
+        checkFileExists(path)
+        stats = {}
+        with open(path) as f:
+            for line in f:
+                p = line.split('\t')
+                stats[p[0]] = ast.literal_eval(p[1])
+        return stats
+
+    def parseBinHits(self, outDir, hmmTableFile, bSkipAdjCorrection=False, bIgnoreThresholds=False, evalueThreshold=DefaultValues.E_VAL,
+                     lengthThreshold=DefaultValues.LENGTH, bSkipPseudoGeneCorrection=False, binStats=None):
+        if not self.models:
+            self.logger.error('Models must be parsed before identifying HMM hits.')
+            sys.exit(1)
+        self.logger.info('Parsing HMM hits to marker genes:')
+        from checkm_amd.markerGeneFinder import SCAN_CACHE
+        binIds = list(self.models.keys())
+        ent = SCAN_CACHE.get((os.path.abspath(outDir), hmmTableFile))
+        mk = lambda b: ResultsManager(b, self.models[b], bIgnoreThresholds, evalueThreshold, lengthThreshold, bSkipPseudoGeneCorrection,
+                                      binStats[b] if binStats is not None else None)
+        if ent is not None and all(b in ent["bin_index"] for b in binIds):
+            self._reduce_resident(ent, binIds, mk, bSkipAdjCorrection, bIgnoreThresholds, evalueThreshold, lengthThreshold, bSkipPseudoGeneCorrection)
+        else:
+            self._reduce_text(outDir, hmmTableFile, binIds, mk, bSkipAdjCorrection, bIgnoreThresholds, evalueThreshold, lengthThreshold,
+                              bSkipPseudoGeneCorrection)
+        self.logger.info('    Finished parsing hits for %d of %d (100.00%%) bins.' % (len(binIds), len(binIds)))
+
+    # the packed hits of a scan run in this process: no text round-trip
+    def _reduce_resident(self, ent, binIds, mk, skip_adj, ignore, evalue, length, skip_pseudo):
+        profiles, hits, seqs = ent["profiles"], ent["hits"], ent["seqs"]
+        nb = hits.nbins
+        # bins whose (possibly sticky) header view gives identical thresholds share one library call
+        groups = {}
+        for b in binIds:
+            sig = []
+            for hd in profiles.headers:
+                a = hd["acc"] if hd["acc"] else hd["name"]
+                m = self.models[b].get(a)
+                sig.append(None if m is None else (m.acc, m.leng, m.ga, m.tc, m.nc))
+            groups.setdefault(tuple(sig), []).append(b)
+        class _Blank(object):
+            def __init__(self, hd):
+                self.acc = hd["acc"] if hd["acc"] else hd["name"]; self.leng = hd["leng"]; self.ga = self.tc = self.nc = None
+        for sig, members in groups.items():
+            first = self.models[members[0]]
+            mlist = []
+            for hd in profiles.headers:
+                a = hd["acc"] if hd["acc"] else hd["name"]
+                mlist.append(first[a] if a in first else _Blank(hd))
+            keys, acc, qlen, thr, clans, nested = _plan_for_models(mlist)
+            plan = cqa.QAPlan(keys, acc, qlen, thr, [[] for _ in range(nb)], clans, nested)
+            sel = np.zeros(nb, dtype=np.uint8)
+            for b in members:
+                sel[ent["bin_index"][b]] = 1
+            res = plan.reduce(runtime.get_ctx(), hits, seqs, ignore, evalue, length, skip_pseudo, skip_adj, False, sel)
+            for b in members:
+                rm = mk(b)
+                rm.markerHits = _marker_hits_from(res, ent["bin_index"][b], keys, lambda r: _hit_from_columns(hits, seqs, profiles, r))
+                self.results[b] = rm
+            res.close()
+
+    # tables written by an earlier command: parse the text, same library entry in column form
+    def _reduce_text(self, outDir, hmmTableFile, binIds, mk, skip_adj, ignore, evalue, length, skip_pseudo):
+        for b in binIds:
+            rm = mk(b)
+            path = os.path.join(outDir, 'bins', b, hmmTableFile)
+            try:
+                for h in read_domtblout(path):
+                    rm.addHit(h)
+                rm._reduce_raw(skip_adj)
+            except IOError as detail:
+                sys.stderr.write(str(detail) + "\n")
+            self.results[b] = rm
+
+    def parseHmmerResults(self, fileName, resultsManager, bSkipAdjCorrection):
+        try:
+            for h in read_domtblout(fileName):
+                resultsManager.addHit(h)
+            resultsManager._reduce_raw(bSkipAdjCorrection)
+        except IOError as detail:
+            sys.stderr.write(str(detail) + "\n")
+
+    # ---- output ------------------------------------------------------------------------------------
+    def _getHeader(self, outputFormat, binMarkerSets=None, coverageBinProfiles=None, table=None):
+        if outputFormat == 1:
+            return ['Bin Id', 'Marker lineage', '# genomes', '# markers', '# marker sets', '0', '1', '2', '3', '4', '5+',
+                    'Completeness', 'Contamination', 'Strain heterogeneity']
+        if outputFormat == 2:
+            return ['Bin Id', 'Marker lineage', '# genomes', '# markers', '# marker sets', 'Completeness', 'Contamination',
+                    'Strain heterogeneity', 'Genome size (bp)', '# ambiguous bases', '# scaffolds', '# contigs', 'N50 (scaffolds)',
+                    'N50 (contigs)', 'Mean scaffold length (bp)', 'Mean contig length (bp)', 'Longest scaffold (bp)',
+                    'Longest contig (bp)', 'GC', 'GC std (scaffolds > 1kbp)', 'Coding density', 'Translation table',
+                    '# predicted genes', '0', '1', '2', '3', '4', '5+']
+        return None
+
+    def printSummary(self, outputFormat, aai, binIdToBinMarkerSets, bIndividualMarkers, coverageFile, bTabTable, outFile, anaFolder):
+        if outputFormat not in (1, 2):
+            self.logger.error("Output format %d is not part of the accelerated path." % outputFormat)
+            sys.exit(1)
+        old = sys.stdout
+        if outFile:
+            sys.stdout = open(outFile, 'w')
+        try:
+            header = self._getHeader(outputFormat)
+            table = None
+            if bTabTable:
+                print('\t'.join(header))
+            else:
+                table = _Table(header)
+            for binId in sorted(self.results.keys()):
+                self.results[binId].printSummary(outputFormat, aai, binIdToBinMarkerSets[binId], bIndividualMarkers, None, table, anaFolder)
+            if table is not None:
+                print(table.render('Completeness', True))
+        finally:
+            if outFile:
+                sys.stdout.close()
+            sys.stdout = old
+
+    def cacheResults(self, outDir, binIdToBinMarkerSets, bIndividualMarkers):
+        """storage/bin_stats_ext.tsv and storage/marker_gene_stats.tsv (resultsParser.py:121-143)."""
+        with open(os.path.join(outDir, 'storage', DefaultValues.BIN_STATS_EXT_OUT), 'w') as fout:
+            for binId in self.results:
+                ext = self.results[binId].getSummary(binIdToBinMarkerSets[binId], bIndividualMarkers, outputFormat=2)
+                ext.update(self.results[binId].geneCopyNumber(binIdToBinMarkerSets[binId]))
+                fout.write(binId + '\t' + str(ext) + '\n')
+        with open(os.path.join(outDir, 'storage', DefaultValues.MARKER_GENE_STATS), 'w') as fout:
+            for binId in self.results:
+                fout.write(binId + '\t' + str(self.results[binId].getSummary(binIdToBinMarkerSets[binId], bIndividualMarkers, outputFormat=8)) + '\n')
+
+
+def _hit_from_columns(hits, seqs, profiles, r):
+    """HmmerHitDOM of packed row r, with the values the domtblout TEXT carries (%9.2g / %6.1f / %5.1f / %4.2f)."""
+    hd = profiles.headers[int(hits.model[r])]
+    s = int(hits.seq[r])
+    g2 = lambda v: float("%9.2g" % v)
+    f1 = lambda v: float("%.1f" % v)
+    return HmmerHitDOM.from_fields(
+        target_name=seqs.names[s], target_accession='-', target_length=int(hits.tlen[r]), query_name=hd["name"],
+        query_accession=hd["acc"] if hd["acc"] else hd["name"], query_length=int(hits.qlen[r]),
+        full_e_value=g2(hits.full_evalue[r]), full_score=f1(hits.full_score[r]), full_bias=f1(hits.full_bias[r]),
+        dom=int(hits.dom_idx[r]), ndom=int(hits.ndom[r]), c_evalue=g2(hits.c_evalue[r]), i_evalue=g2(hits.i_evalue[r]),
+        dom_score=f1(hits.dom_score[r]), dom_bias=f1(hits.dom_bias[r]), hmm_from=int(hits.hmm_from[r]), hmm_to=int(hits.hmm_to[r]),
+        ali_from=int(hits.ali_from[r]), ali_to=int(hits.ali_to[r]), env_from=int(hits.env_from[r]), env_to=int(hits.env_to[r]),
+        acc=float("%.2f" % hits.acc[r]), target_description=seqs.descs[s] if seqs.descs[s] else '-')

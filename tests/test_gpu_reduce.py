@@ -1,0 +1,91 @@
+"""GPU parity of the reduce half: libcheckm_hip's ckm_reduce / ckm_count_sets (through the Python
+mirror classes) against the goldens produced by the reference's own classes.
+Bar: integer-identical hit lists and histograms; completeness/contamination bit-identical float64."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from checkm_amd import _lib, qa as cqa, synth
+from checkm_amd.defaultValues import DefaultValues
+from checkm_amd.hmmerModelParser import HmmModel
+from checkm_amd.markerSets import MarkerSet
+from checkm_amd.resultsParser import ResultsManager, ResultsParser
+from oracle import reduce_oracle as ro
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reduce_cases.json")
+
+
+def _view(mh):
+    return [[k, [[h.target_name, h.target_length, h.hmm_from, h.hmm_to, h.ali_from, h.ali_to, h.env_from, h.env_to, h.dom_score, h.full_e_value]
+                 for h in v]] for k, v in mh.items()]
+
+
+def test_reduce_matches_reference_goldens(gpu_ctx, tmp_path):
+    with open(GOLD) as f:
+        cases = json.load(f)["cases"]
+    root = tmp_path / "data"
+    (root / "pfam").mkdir(parents=True)
+    DefaultValues.set_data_root(str(root))
+    for ci, case in enumerate(cases):
+        (root / "pfam" / "Pfam-A.hmm.dat").write_text(case["pfam_dat"])
+        tab = tmp_path / "t.txt"
+        tab.write_text(case["domtblout"])
+        models = {}
+        for m in case["models"]:
+            hm = HmmModel({"name": m["name"], "acc": m["acc"], "leng": m["leng"]})
+            hm.ga = tuple(m["ga"]) if m["ga"] else None
+            hm.tc = tuple(m["tc"]) if m["tc"] else None
+            hm.nc = tuple(m["nc"]) if m["nc"] else None
+            models[m["acc"]] = hm
+        ms = MarkerSet(0, "k__Bacteria", 10, [set(s) for s in case["marker_sets"]])
+        for run in case["runs"]:
+            fl = run["flags"]
+            rm = ResultsManager("bin", models, fl.get("ignore_thresholds", False), fl.get("evalue", DefaultValues.E_VAL),
+                                fl.get("length", DefaultValues.LENGTH), fl.get("skip_pseudogene", False))
+            ResultsParser({"bin": models}).parseHmmerResults(str(tab), rm, fl.get("skip_adj", False))
+            assert _view(rm.markerHits) == run["expected"]["markerHits"], (ci, fl)
+            assert rm.geneCounts(ms, rm.markerHits, False) == run["expected"]["geneCounts"], (ci, fl)
+            assert rm.geneCounts(ms, rm.markerHits, True) == run["expected"]["geneCountsIndividual"], (ci, fl)
+
+
+def test_resident_hits_reduce_like_the_text_path(gpu_ctx, tmp_path):
+    """Scan -> packed hits -> ckm_reduce must equal scan -> domtblout text -> (oracle) reduce."""
+    profs = common.mixed_profiles()
+    path = common.hmm_file("mixed", profs)
+    bins = [synth.make_bin(profs, 3000 + b, n_orfs=200, dup_frac=0.9) for b in range(3)]
+    prof = _lib.Profiles(gpu_ctx, path)
+    seqs = _lib.Seqs(gpu_ctx, bins)
+    hits = _lib.search(gpu_ctx, prof, seqs)
+    plan = cqa.QAPlan.for_hmm_models(prof, [list(range(prof.n))] * len(bins))
+    models = {}
+    for hd in prof.headers:
+        a = hd["acc"] or hd["name"]
+        models[a] = {"acc": a, "ga": list(hd["ga"]) if hd["ga"] else None, "tc": list(hd["tc"]) if hd["tc"] else None,
+                     "nc": list(hd["nc"]) if hd["nc"] else None, "leng": hd["leng"]}
+    for flags in (dict(), dict(ignore_thresholds=True), dict(skip_adj=True), dict(individual_markers=True)):
+        res = plan.reduce(gpu_ctx, hits, seqs, flags.get("ignore_thresholds", False), 1e-10, 0.7, False, flags.get("skip_adj", False),
+                          flags.get("individual_markers", False))
+        nmerged = 0
+        for b in range(len(bins)):
+            t = str(tmp_path / ("b%d.txt" % b))
+            hits.write_domtblout(prof, seqs, b, t)
+            sets = [sorted(models.keys())]
+            mh, gc = ro.reduce_bin(open(t).read(), models, "", sets, flags.get("ignore_thresholds", False), 1e-10, 0.7, False,
+                                   flags.get("skip_adj", False), flags.get("individual_markers", False))
+            assert list(res.hist[b]) == gc[:6], (flags, b)
+            assert res.completeness[b] == gc[6] and res.contamination[b] == gc[7], (flags, b, res.completeness[b], gc[6])
+            want = [(k, h['target_name'].split('&&'), h['ali_from'], h['ali_to']) for k, v in mh.items() for h in v]
+            got = []
+            for i in range(int(res.kept_bin_off[b]), int(res.kept_bin_off[b + 1])):
+                names = [seqs.names[int(hits.seq[int(res.kept_row[i])])]]
+                if int(res.kept_row2[i]) != 0xFFFFFFFFFFFFFFFF:
+                    names.append(seqs.names[int(hits.seq[int(res.kept_row2[i])])]); nmerged += 1
+                got.append((plan.keys.names[int(res.kept_key[i])], sorted(names), int(res.kept_ali_from[i]), int(res.kept_ali_to[i])))
+            assert got == want, (flags, b)
+        res.close()
+    hits.close(); prof.close(); seqs.close()
