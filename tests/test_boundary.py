@@ -1,0 +1,55 @@
+"""The drop-in boundary: the shared object loads without a GPU and exports every symbol the header
+declares; the product never touches the oracle; without a device the product fails loudly."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from checkm_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "checkm_hip.h")).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(ckm_[a-z_0-9]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "libcheckm_hip.so does not export %s" % n
+    assert sorted(_lib.EXPORTS) == names
+    assert lib.ckm_abi_version() == _lib.ABI_VERSION
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for dirpath, _dirs, files in os.walk(os.path.join(ROOT, "checkm_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                if re.search(r'^\s*(from|import)\s+oracle\b', txt, flags=re.M) or 'p7oracle' in txt or 'reduce_oracle' in txt:
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+
+
+def test_no_device_is_a_loud_error():
+    """On the CPU-only build box ckm_ctx_create must fail with ENODEV (on a GPU box this test is vacuous)."""
+    if _lib.device_count() > 0:
+        pytest.skip("a device is visible")
+    with pytest.raises(_lib.CkmError) as e:
+        _lib.Context(0)
+    assert e.value.code == -4
+    assert "no CPU path" in str(e.value) or "HIP" in str(e.value)
+
+
+def test_bad_arguments_return_codes():
+    lib = _lib.load()
+    n = ctypes.c_int32()
+    assert lib.ckm_profiles_count(None, ctypes.byref(n)) == -1
+    assert b"NULL" in lib.ckm_last_error()

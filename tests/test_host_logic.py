@@ -1,0 +1,93 @@
+"""CPU tests of the host logic around the hot path, against goldens produced by the reference's own
+classes (tools/gen_host_golden.py)."""
+import json
+import os
+
+import pytest
+
+from checkm_amd.common import binIdFromFilename
+from checkm_amd.defaultValues import DefaultValues
+from checkm_amd.hmmer import HMMERParser
+from checkm_amd.hmmerModelParser import HmmModelParser
+from checkm_amd.markerSets import BinMarkerSets, MarkerSet, MarkerSetParser
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "host_cases.json")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with open(GOLD) as f:
+        return json.load(f)
+
+
+def test_sticky_header_parse(gold, tmp_path):
+    p = tmp_path / "sticky.hmm"
+    p.write_text(gold["sticky"]["hmm_text"])
+    models = HmmModelParser(str(p)).models()
+    assert set(models) == set(gold["sticky"]["models"])
+    for acc, want in gold["sticky"]["models"].items():
+        m = models[acc]
+        got = {"name": m.name, "acc": m.acc, "leng": m.leng, "ga": list(m.ga) if m.ga else None, "tc": list(m.tc) if m.tc else None,
+               "nc": list(m.nc) if m.nc else None}
+        assert got == want
+
+
+def _view(b):
+    return {bid: {"selected_uid": bm.selectedMarkerSet().UID,
+                  "sets": [[ms.UID, ms.lineageStr, ms.numGenomes, [sorted(s) for s in ms.markerSet]] for ms in bm.markerSets]} for bid, bm in b.items()}
+
+
+def test_taxon_marker_file(gold, tmp_path):
+    tf = tmp_path / "taxon.ms"
+    tf.write_text(gold["taxon"]["file"])
+    ex = tmp_path / "exclude.txt"
+    ex.write_text(gold["taxon"]["exclude_file"])
+    msp = MarkerSetParser()
+    assert msp.markerFileType(str(tf)) == BinMarkerSets.TAXONOMIC_MARKER_SET
+    assert _view(msp.getMarkerSets(str(tmp_path), ["binA", "binB"], str(tf))) == gold["taxon"]["result"]["default"]
+    assert _view(msp.getMarkerSets(str(tmp_path), ["binA", "binB"], str(tf), str(ex))) == gold["taxon"]["result"]["user_exclude"]
+
+
+def test_lineage_marker_file(gold, tmp_path):
+    DefaultValues.set_data_root(str(tmp_path))
+    (tmp_path / "selected_marker_sets.tsv").write_text(gold["lineage"]["selected_map"])
+    lf = tmp_path / "lineage.ms"
+    lf.write_text(gold["lineage"]["file"])
+    msp = MarkerSetParser()
+    assert msp.markerFileType(str(lf)) == BinMarkerSets.TREE_MARKER_SET
+    assert _view(msp.getMarkerSets(str(tmp_path), ["binA", "binB"], str(lf))) == gold["lineage"]["result"]
+
+
+def test_bin_id_from_filename(gold):
+    for name, want in gold["binIdFromFilename"].items():
+        assert binIdFromFilename(name) == want
+
+
+def test_marker_set_accessors():
+    """The accessor tests of checkm/test/test_markerSets.py:25-55, restated."""
+    ms = MarkerSet(0, 'k__Bacteria', 1, [{'a', 'b'}, {'c'}])
+    assert ms.size() == (3, 2) and ms.numMarkers() == 3 and ms.numSets() == 2
+    assert ms.getMarkerGenes() == {'a', 'b', 'c'}
+    b = BinMarkerSets('bin', BinMarkerSets.TAXONOMIC_MARKER_SET)
+    b.addMarkerSet(ms)
+    b.addMarkerSet(MarkerSet(1, 'k__Bacteria;p__X', 1, [{'d'}]))
+    assert b.numMarkerSets() == 2 and b.getMarkerGenes() == {'a', 'b', 'c', 'd'}
+    assert b.mostSpecificMarkerSet() is ms and b.selectedMarkerSet() is ms
+    ms.removeMarkers({'c'})
+    assert ms.markerSet == [{'a', 'b'}]
+
+
+def test_domtblout_reader_contract(tmp_path):
+    """Sample row of checkm/hmmer.py:188; '-' accession falls back to the name; a blank line ends the table."""
+    row = ("NODE_925902_length_6780_cov_18.428171_754_2 -            399 PGK                  PF00162.14   384  2.2e-164  543.7   0.1   1   1  "
+           "1.3e-167  2.5e-164  543.5   0.1     1   384     9   386     9   386 1.00 # 1767 # 2963 # -1 # ID=754_2;partial=00")
+    p = tmp_path / "t.txt"
+    p.write_text("# header\n" + row + "\n" + row.replace("PF00162.14", "-         ") + "\n\n" + row + "\n")
+    with open(p) as fh:
+        hp = HMMERParser(fh)
+        h1, h2, h3 = hp.next(), hp.next(), hp.next()
+    assert h1.target_name.endswith("754_2") and h1.target_length == 399 and h1.query_accession == "PF00162.14"
+    assert h1.full_e_value == 2.2e-164 and h1.dom_score == 543.5 and (h1.ali_from, h1.ali_to) == (9, 386)
+    assert h1.target_description.startswith("# 1767 # 2963")
+    assert h2.query_accession == "PGK"
+    assert h3 is None
