@@ -1,0 +1,111 @@
+"""End to end through the reference's own API surface: MarkerGeneFinder.find -> ResultsParser.analyseResults
+-> printSummary, on the GPU, against (scan oracle -> domtblout text -> reduce oracle)."""
+import os
+
+import numpy as np
+import pytest
+
+from checkm_amd import synth
+from checkm_amd.defaultValues import DefaultValues
+from checkm_amd.markerGeneFinder import MarkerGeneFinder, release_scan
+from checkm_amd.markerSets import MarkerSetParser
+from checkm_amd.resultsParser import ResultsParser
+from oracle import p7
+from oracle import reduce_oracle as ro
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(tmp_path, nbins=3):
+    profs = synth.small_profiles(11, 12, 40, 300)
+    hmm = common.hmm_file("s11", profs)
+    root = tmp_path / "data"
+    (root / "pfam").mkdir(parents=True)
+    # two Pfam families in one clan so the clan filter has work to do
+    pf = [p.acc for p in profs if p.acc.startswith("PF")]
+    dat = ""
+    for i, a in enumerate(pf):
+        dat += "# STOCKHOLM 1.0\n#=GF ID   fam%d\n#=GF AC   %s\n" % (i, a)
+        if i < 2:
+            dat += "#=GF CL   CL0001\n"
+        dat += "//\n"
+    (root / "pfam" / "Pfam-A.hmm.dat").write_text(dat)
+    DefaultValues.set_data_root(str(root))
+    binfiles, recs_all = [], []
+    for b in range(nbins):
+        recs = synth.make_bin(profs, 500 + b, n_orfs=150, dup_frac=0.6)
+        f = tmp_path / ("bin_%d.faa" % b)
+        synth.write_fasta(str(f), recs)
+        binfiles.append(str(f)); recs_all.append(recs)
+    return profs, hmm, binfiles, recs_all, dat
+
+
+def _oracle_tables(hmm, recs_all):
+    hs = p7.HmmSet(hmm)
+    texts = []
+    for recs in recs_all:
+        rows = hs.search(list(range(hs.n)), [p7.digitize(r[2]) for r in recs], [r[0] for r in recs])
+        texts.append(hs.format_domtblout(rows, [r[0] for r in recs], [r[1] for r in recs]))
+    hs.close()
+    return texts
+
+
+def test_find_then_qa_matches_oracles(gpu_ctx, tmp_path, capsys):
+    profs, hmm, binfiles, recs_all, dat = _setup(tmp_path)
+    out = tmp_path / "out"
+    (out / "storage").mkdir(parents=True)
+    models = MarkerGeneFinder(4).find(binfiles, str(out), DefaultValues.HMMER_TABLE_OUT, DefaultValues.HMMER_OUT, hmm, False, False, True)
+    assert sorted(models) == ["bin_0", "bin_1", "bin_2"]
+    texts = _oracle_tables(hmm, recs_all)
+    for b in range(3):
+        t = out / "bins" / ("bin_%d" % b) / DefaultValues.HMMER_TABLE_OUT
+        assert t.read_text() == texts[b]
+        assert (out / "bins" / ("bin_%d" % b) / DefaultValues.PRODIGAL_AA).exists()
+    # HmmModel view (sticky parse) and pickle cache round trip
+    msp = MarkerSetParser()
+    msp.writeBinModels(models, str(out / "storage" / DefaultValues.CHECKM_HMM_MODEL_INFO))
+    models2 = msp.loadBinModels(str(out / "storage" / DefaultValues.CHECKM_HMM_MODEL_INFO))
+    assert {a: (m.name, m.leng, m.ga, m.tc, m.nc) for a, m in models2["bin_1"].items()} == {a: (m.name, m.leng, m.ga, m.tc, m.nc) for a, m in models["bin_1"].items()}
+    with open(out / "storage" / DefaultValues.BIN_STATS_OUT, "w") as f:
+        for b in range(3):
+            f.write("bin_%d\t%s\n" % (b, repr({"GC": 0.5, "Genome size": 1000 + b})))
+    sets = msp.getMarkerSets(str(out), list(models), hmm)
+    want = {}
+    omodels = {a: {"acc": a, "ga": list(m.ga) if m.ga else None, "tc": list(m.tc) if m.tc else None, "nc": list(m.nc) if m.nc else None, "leng": m.leng}
+               for a, m in models["bin_0"].items()}
+    for b in range(3):
+        mh, gc = ro.reduce_bin(texts[b], omodels, dat, [sorted(s) for s in sets["bin_%d" % b].selectedMarkerSet().markerSet])
+        want["bin_%d" % b] = (ro.marker_hits_view(mh), gc)
+
+    def check(rp):
+        for b, (view, gc) in want.items():
+            rm = rp.results[b]
+            got = [[k, [[h.target_name, h.target_length, h.hmm_from, h.hmm_to, h.ali_from, h.ali_to, h.env_from, h.env_to, h.dom_score, h.full_e_value]
+                        for h in v]] for k, v in rm.markerHits.items()]
+            assert got == view, b
+            assert rm.geneCountsForSelectedMarkerSet(sets[b], False) == gc, b
+    # (1) resident packed hits, no text round trip
+    rp = ResultsParser(models)
+    stats = rp.analyseResults(str(out), DefaultValues.BIN_STATS_OUT, DefaultValues.HMMER_TABLE_OUT)
+    assert stats["bin_2"]["Genome size"] == 1002
+    check(rp)
+    rp.printSummary(1, None, sets, False, None, True, None, None)
+    lines = capsys.readouterr().out.strip().split("\n")
+    assert lines[0].split("\t")[0] == "Bin Id" and len(lines) == 4
+    for ln in lines[1:]:
+        f = ln.split("\t")
+        gc = want[f[0]][1]
+        assert [int(x) for x in f[5:11]] == gc[:6] and f[11] == "%0.2f" % gc[6] and f[12] == "%0.2f" % gc[7]
+    rp.cacheResults(str(out), sets, False)
+    assert os.path.getsize(out / "storage" / DefaultValues.BIN_STATS_EXT_OUT) > 0
+    # (2) a later `qa` command: the scan is gone, the domtblout text is re-read
+    release_scan()
+    rp2 = ResultsParser(models2)
+    rp2.analyseResults(str(out), DefaultValues.BIN_STATS_OUT, DefaultValues.HMMER_TABLE_OUT)
+    check(rp2)
+    # flags reach the library
+    rp3 = ResultsParser(models2)
+    rp3.parseBinHits(str(out), DefaultValues.HMMER_TABLE_OUT, bSkipAdjCorrection=True, bIgnoreThresholds=True)
+    mh, gc = ro.reduce_bin(texts[1], omodels, dat, [sorted(s) for s in sets["bin_1"].selectedMarkerSet().markerSet], True, 1e-10, 0.7, False, True)
+    assert rp3.results["bin_1"].geneCountsForSelectedMarkerSet(sets["bin_1"], False) == gc
