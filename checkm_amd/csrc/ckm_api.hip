@@ -28,12 +28,12 @@ void launch_bias(hipStream_t stream, PairRec *pairs, uint32_t npairs, const DevM
                  const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, float *raw);
 int launch_vit(int Q, hipStream_t stream, const PairRec *pairs, const uint32_t *idx, uint32_t n, const DevModel *models,
                const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xC, float *out_sc);
-int launch_fwd(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const DevModel *models,
+int launch_fwd(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const uint32_t *blk_model, const DevModel *models,
                const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, FwdOut *out,
                ScaleEvent *events, uint32_t *nevents, uint32_t cap_events);
-int launch_bwd(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const DevModel *models,
+int launch_bwd(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const uint32_t *blk_model, const DevModel *models,
                const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, const FwdOut *fout, int32_t *range_err);
-int launch_oa(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const DevModel *models,
+int launch_oa(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const uint32_t *blk_model, const DevModel *models,
               float *ws, const int32_t *range_err, EnvOut *out);
 
 static thread_local std::string g_err;
@@ -67,10 +67,11 @@ using namespace ckm;
 struct ckm_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t side[8];                    // per-register-class launches of the rare stages overlap on these
   hipEvent_t ev[8];
   ckm_search_stats stats;
   // reusable device scratch
-  DevBuf work, maxv, surv, nores, counters, cand, raw, idx, vitx, vits, fbwork, fbidx, ws, fout, events, rerr, envout, fullx, fullu;
+  DevBuf work, maxv, surv, nores, counters, cand, raw, idx, vitx, vits, fbwork, fbidx, fbmodel, ws, fout, events, rerr, envout, fullx, fullu;
   size_t ws_budget = (size_t)8 << 30;     // float workspace budget (bytes) for Forward/Backward matrices
 };
 
@@ -150,10 +151,11 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
     std::unique_ptr<ckm_ctx> ctx(new ckm_ctx());
     ctx->device = device;
     HIPCHK(hipStreamCreate(&ctx->stream));
+    for (auto &st : ctx->side) HIPCHK(hipStreamCreate(&st));
     for (auto &e : ctx->ev) HIPCHK(hipEventCreate(&e));
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     size_t fre = 0, tot = 0;
-    if (hipMemGetInfo(&fre, &tot) == hipSuccess) ctx->ws_budget = std::min<size_t>((size_t)16 << 30, fre / 4);
+    if (hipMemGetInfo(&fre, &tot) == hipSuccess) ctx->ws_budget = std::min<size_t>((size_t)96 << 30, fre / 2);
     *out = ctx.release();
   });
 }
@@ -163,6 +165,7 @@ extern "C" void ckm_ctx_destroy(ckm_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (auto &e : ctx->ev) (void)hipEventDestroy(e);
+  for (auto &st : ctx->side) (void)hipStreamDestroy(st);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -375,14 +378,30 @@ void run_fb(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, 
   const size_t n = b.work.size();
   if (!n) return;
   ctx->fbwork.ensure(n * sizeof(FbWork));
-  HIPCHK(hipMemcpyAsync(ctx->fbwork.p, b.work.data(), n * sizeof(FbWork), hipMemcpyHostToDevice, ctx->stream));
-  std::map<int, std::vector<uint32_t>> byQ;
-  if (subset) for (uint32_t i : *subset) byQ[p->prof[b.work[i].model].fbQ].push_back(i);
-  else for (uint32_t i = 0; i < n; ++i) byQ[p->prof[b.work[i].model].fbQ].push_back(i);
-  std::vector<uint32_t> flat; std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;
-  for (auto &kv : byQ) { groups.push_back({kv.first, {flat.size(), kv.second.size()}}); flat.insert(flat.end(), kv.second.begin(), kv.second.end()); }
-  ctx->fbidx.ensure(flat.size() * 4);
-  HIPCHK(hipMemcpyAsync(ctx->fbidx.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpy(ctx->fbwork.p, b.work.data(), n * sizeof(FbWork), hipMemcpyHostToDevice));
+  // group by canonical Q; inside a group, blocks of 4 wavefronts take 4 items of ONE model (shared LDS table)
+  std::map<int, std::map<uint32_t, std::vector<uint32_t>>> byQ;
+  auto add = [&](uint32_t i) { byQ[p->prof[b.work[i].model].fbQ][b.work[i].model].push_back(i); };
+  if (subset) for (uint32_t i : *subset) add(i); else for (uint32_t i = 0; i < n; ++i) add(i);
+  struct Group { int Q; size_t blk0, nblk; };
+  std::vector<uint32_t> items, blk_model; std::vector<Group> groups;
+  for (auto &kq : byQ) {
+    Group g{kq.first, blk_model.size(), 0};
+    // longest items first inside a model so the four wavefronts of a block finish together
+    for (auto &km : kq.second) {
+      std::vector<uint32_t> &v = km.second;
+      std::stable_sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return b.work[x].Ld > b.work[y].Ld; });
+      for (size_t i = 0; i < v.size(); i += 4) {
+        for (size_t j = 0; j < 4; ++j) items.push_back(i + j < v.size() ? v[i + j] : 0xffffffffu);
+        blk_model.push_back(km.first);
+      }
+    }
+    g.nblk = blk_model.size() - g.blk0;
+    groups.push_back(g);
+  }
+  ctx->fbidx.ensure(items.size() * 4); ctx->fbmodel.ensure(blk_model.size() * 4);
+  HIPCHK(hipMemcpy(ctx->fbidx.p, items.data(), items.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ctx->fbmodel.p, blk_model.data(), blk_model.size() * 4, hipMemcpyHostToDevice));
   ctx->fout.ensure(n * sizeof(FwdOut));
   ctx->rerr.ensure(n * 4);
   ctx->envout.ensure(n * sizeof(EnvOut));
@@ -394,39 +413,36 @@ void run_fb(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, 
   const uint8_t *res = s->d_res.as<uint8_t>();
   const uint64_t *off = s->d_off.as<uint64_t>();
   float *ws = ctx->ws.as<float>();
+  if (do_fwd) HIPCHK(hipMemset(ctx->counters.p, 0, 64));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  // every register class runs its stages in order on its own stream; classes overlap each other
+  size_t gi = 0;
+  for (auto &g : groups) {
+    hipStream_t st = ctx->side[gi++ % 8];
+    const uint32_t *ix = ctx->fbidx.as<uint32_t>() + g.blk0 * 4, *bm = ctx->fbmodel.as<uint32_t>() + g.blk0;
+    if (do_fwd && launch_fwd(g.Q, (uint32_t)g.nblk, st, ctx->fbwork.as<FbWork>(), ix, bm, dm, lt, res, off, ws, ctx->fout.as<FwdOut>(),
+                             ctx->events.as<ScaleEvent>(), ctx->counters.as<uint32_t>(), cap_events))
+      throw Error(CKM_ERANGE, "no Forward kernel instance for this model length");
+    if (do_bwd && launch_bwd(g.Q, (uint32_t)g.nblk, st, ctx->fbwork.as<FbWork>(), ix, bm, dm, lt, res, off, ws, ctx->fout.as<FwdOut>(), ctx->rerr.as<int32_t>()))
+      throw Error(CKM_ERANGE, "no Backward kernel instance for this model length");
+    if (do_oa && launch_oa(g.Q, (uint32_t)g.nblk, st, ctx->fbwork.as<FbWork>(), ix, bm, dm, ws, ctx->rerr.as<int32_t>(), ctx->envout.as<EnvOut>()))
+      throw Error(CKM_ERANGE, "no OA kernel instance for this model length");
+  }
+  HIPCHK(hipGetLastError());
+  for (auto &st : ctx->side) HIPCHK(hipStreamSynchronize(st));
   if (do_fwd) {
-    HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
-    for (auto &g : groups)
-      if (launch_fwd(g.first, (uint32_t)g.second.second, ctx->stream, ctx->fbwork.as<FbWork>(), ctx->fbidx.as<uint32_t>() + g.second.first, dm, lt, res, off,
-                     ws, ctx->fout.as<FwdOut>(), ctx->events.as<ScaleEvent>(), ctx->counters.as<uint32_t>(), cap_events))
-        throw Error(CKM_ERANGE, "no Forward kernel instance for this model length");
-    HIPCHK(hipGetLastError());
     b.fout.resize(n);
     uint32_t nev = 0;
-    HIPCHK(hipMemcpyAsync(b.fout.data(), ctx->fout.p, n * sizeof(FwdOut), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(&nev, ctx->counters.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(b.fout.data(), ctx->fout.p, n * sizeof(FwdOut), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&nev, ctx->counters.p, 4, hipMemcpyDeviceToHost));
     if (nev > cap_events) throw Error(CKM_ERANGE, "rescale event buffer overflow");
     b.events.resize(nev);
     if (nev) HIPCHK(hipMemcpy(b.events.data(), ctx->events.p, (size_t)nev * sizeof(ScaleEvent), hipMemcpyDeviceToHost));
   }
-  if (do_bwd) {
-    for (auto &g : groups)
-      if (launch_bwd(g.first, (uint32_t)g.second.second, ctx->stream, ctx->fbwork.as<FbWork>(), ctx->fbidx.as<uint32_t>() + g.second.first, dm, lt, res, off,
-                     ws, ctx->fout.as<FwdOut>(), ctx->rerr.as<int32_t>()))
-        throw Error(CKM_ERANGE, "no Backward kernel instance for this model length");
-    HIPCHK(hipGetLastError());
-  }
   if (do_oa) {
-    for (auto &g : groups)
-      if (launch_oa(g.first, (uint32_t)g.second.second, ctx->stream, ctx->fbwork.as<FbWork>(), ctx->fbidx.as<uint32_t>() + g.second.first, dm, ws,
-                    ctx->rerr.as<int32_t>(), ctx->envout.as<EnvOut>()))
-        throw Error(CKM_ERANGE, "no OA kernel instance for this model length");
-    HIPCHK(hipGetLastError());
     b.envout.resize(n);
-    HIPCHK(hipMemcpyAsync(b.envout.data(), ctx->envout.p, n * sizeof(EnvOut), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpy(b.envout.data(), ctx->envout.p, n * sizeof(EnvOut), hipMemcpyDeviceToHost));
   }
-  HIPCHK(hipStreamSynchronize(ctx->stream));
 }
 
 size_t env_floats(int Mp, int Ld, uint64_t &xs, uint64_t &aux, uint64_t &mf, uint64_t &mb, uint64_t base) {

@@ -15,23 +15,35 @@ namespace ckm {
 
 constexpr float NEGINF_F = -__builtin_inff();
 
+// Transition odds in LDS, transposed to [array][q][lane] so that the 64 lanes of a wave read 64
+// consecutive floats (conflict-free); arrays: BM MM IM DM MI II MD DD.  Cell c = lane*Q + q.
 template <int Q>
-struct Tr {   // transition odds of this lane's cells, LDS resident ([8][Mp]: BM MM IM DM MI II MD DD)
-  const float *t; int c0;
-  __device__ __forceinline__ float BM(int q) const { return t[0 * Q * 64 + c0 + q]; }
-  __device__ __forceinline__ float MM(int q) const { return t[1 * Q * 64 + c0 + q]; }
-  __device__ __forceinline__ float IM(int q) const { return t[2 * Q * 64 + c0 + q]; }
-  __device__ __forceinline__ float DM(int q) const { return t[3 * Q * 64 + c0 + q]; }
-  __device__ __forceinline__ float MI(int q) const { return t[4 * Q * 64 + c0 + q]; }
-  __device__ __forceinline__ float II(int q) const { return t[5 * Q * 64 + c0 + q]; }
-  __device__ __forceinline__ float MD(int q) const { return t[6 * Q * 64 + c0 + q]; }
-  __device__ __forceinline__ float DD(int q) const { return t[7 * Q * 64 + c0 + q]; }
-};
+__device__ __forceinline__ int lds_cell(int c) { return (c % Q) * 64 + c / Q; }
 
 template <int Q>
-__device__ __forceinline__ void load_tr(float *lds, const float *ftr, int lane) {
-  for (int i = lane; i < 8 * Q * 64; i += 64) lds[i] = ftr[i];
-  __builtin_amdgcn_wave_barrier();
+struct Tr {
+  const float *t; int lane;
+  __device__ __forceinline__ float BM(int q) const { return t[0 * Q * 64 + q * 64 + lane]; }
+  __device__ __forceinline__ float MM(int q) const { return t[1 * Q * 64 + q * 64 + lane]; }
+  __device__ __forceinline__ float IM(int q) const { return t[2 * Q * 64 + q * 64 + lane]; }
+  __device__ __forceinline__ float DM(int q) const { return t[3 * Q * 64 + q * 64 + lane]; }
+  __device__ __forceinline__ float MI(int q) const { return t[4 * Q * 64 + q * 64 + lane]; }
+  __device__ __forceinline__ float II(int q) const { return t[5 * Q * 64 + q * 64 + lane]; }
+  __device__ __forceinline__ float MD(int q) const { return t[6 * Q * 64 + q * 64 + lane]; }
+  __device__ __forceinline__ float DD(int q) const { return t[7 * Q * 64 + q * 64 + lane]; }
+  // any cell of any array (neighbour cells, traceback)
+  __device__ __forceinline__ float at(int arr, int c) const { return t[arr * Q * 64 + lds_cell<Q>(c)]; }
+};
+
+// Blocks are 4 wavefronts working on (up to) 4 items of the SAME model: one LDS copy of the transition
+// odds serves all four.  blk[4*block + wave] = work index or NO_ITEM; blk_model[block] = the model.
+constexpr uint32_t NO_ITEM = 0xffffffffu;
+constexpr int FB_WAVES = 4;
+
+template <int Q>
+__device__ __forceinline__ void load_tr(float *lds, const float *ftr) {
+  constexpr int Mp = Q * 64;
+  for (int i = threadIdx.x; i < 8 * Mp; i += blockDim.x) { const int arr = i / Mp, c = i % Mp; lds[arr * Mp + lds_cell<Q>(c)] = ftr[i]; }
   __syncthreads();
 }
 
@@ -44,7 +56,7 @@ __device__ __forceinline__ float wave_sum(float s) {
 // ---- one Forward row --------------------------------------------------------------------------
 template <int Q>
 __device__ __forceinline__ float fwd_row(float (&Mv)[Q], float (&Iv)[Q], float (&Dv)[Q], const Tr<Q> &tr,
-                                         const float *__restrict__ rfx, float xB, int lane) {
+                                         const float (&rfx)[Q], float xB, int lane) {
   float mpi = __shfl_up(Mv[Q - 1], 1), ipi = __shfl_up(Iv[Q - 1], 1), dpi = __shfl_up(Dv[Q - 1], 1);
   if (lane == 0) { mpi = 0.f; ipi = 0.f; dpi = 0.f; }
   float Mn[Q], In[Q], Dn[Q], md[Q];
@@ -82,18 +94,20 @@ __device__ __forceinline__ float fwd_row(float (&Mv)[Q], float (&Iv)[Q], float (
 }
 
 template <int Q>
-__global__ void __launch_bounds__(64) fwd_kernel(const FbWork *__restrict__ work, const uint32_t *__restrict__ idx,
+__global__ void __launch_bounds__(256) fwd_kernel(const FbWork *__restrict__ work, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ blk_model,
                                                  const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
                                                  const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
                                                  float *__restrict__ ws, FwdOut *__restrict__ out,
                                                  ScaleEvent *__restrict__ events, uint32_t *__restrict__ nevents, uint32_t cap_events) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int Mp = Q * 64;
-  const int lane = threadIdx.x;
-  const FbWork w = work[idx[blockIdx.x]];
-  const DevModel &md = models[w.model];
-  load_tr<Q>(lds, md.ftr, lane);
-  Tr<Q> tr{lds, lane * Q};
+  const int lane = threadIdx.x & 63;
+  const uint32_t item = idx[blockIdx.x * FB_WAVES + (threadIdx.x >> 6)];
+  const DevModel &md = models[blk_model[blockIdx.x]];
+  load_tr<Q>(lds, md.ftr);
+  if (item == NO_ITEM) return;
+  const FbWork w = work[item];
+  Tr<Q> tr{lds, lane};
   const uint8_t *rp = res + seq_off[w.seq] + w.i0;
   const LenEntry le = lentab[w.Lcfg];
   const float loop = w.multihit ? le.loop_m : le.loop_u, move = w.multihit ? le.move_m : le.move_u;
@@ -110,9 +124,24 @@ __global__ void __launch_bounds__(64) fwd_kernel(const FbWork *__restrict__ work
 #pragma unroll
     for (int q = 0; q < Q; ++q) { mx[lane * Q + q] = 0.f; mx[Mp + lane * Q + q] = 0.f; mx[2 * Mp + lane * Q + q] = 0.f; }
   }
+  // emission odds of the next row are fetched one row ahead (residue byte -> table row is a dependent pair of loads)
+  float rfc[Q];
+  {
+    const float *__restrict__ r0 = md.rf + (size_t)rp[0] * Mp + lane * Q;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) rfc[q] = r0[q];
+  }
   for (int i = 1; i <= w.Ld; ++i) {
-    const float *rfx = md.rf + (size_t)rp[i - 1] * Mp + lane * Q;
-    xE = fwd_row<Q>(Mv, Iv, Dv, tr, rfx, xB, lane);
+    float rfn[Q];
+    {
+      const int xn = (i < w.Ld) ? rp[i] : rp[i - 1];
+      const float *__restrict__ r1 = md.rf + (size_t)xn * Mp + lane * Q;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) rfn[q] = r1[q];
+    }
+    xE = fwd_row<Q>(Mv, Iv, Dv, tr, rfc, xB, lane);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) rfc[q] = rfn[q];
     xN = xN * loop;
     { const float a = xC * loop, b = xE * Emove; xC = a + b; }
     { const float a = xJ * loop, b = xE * Eloop; xJ = a + b; }
@@ -158,17 +187,19 @@ __device__ __forceinline__ void bwd_dchain(float (&Dn)[Q], const float (&av)[Q],
 }
 
 template <int Q>
-__global__ void __launch_bounds__(64) bwd_kernel(const FbWork *__restrict__ work, const uint32_t *__restrict__ idx,
+__global__ void __launch_bounds__(256) bwd_kernel(const FbWork *__restrict__ work, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ blk_model,
                                                  const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
                                                  const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
                                                  float *__restrict__ ws, const FwdOut *__restrict__ fout, int32_t *__restrict__ range_err) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int Mp = Q * 64;
-  const int lane = threadIdx.x;
-  const FbWork w = work[idx[blockIdx.x]];
-  const DevModel &md = models[w.model];
-  load_tr<Q>(lds, md.ftr, lane);
-  Tr<Q> tr{lds, lane * Q};
+  const int lane = threadIdx.x & 63;
+  const uint32_t item = idx[blockIdx.x * FB_WAVES + (threadIdx.x >> 6)];
+  const DevModel &md = models[blk_model[blockIdx.x]];
+  load_tr<Q>(lds, md.ftr);
+  if (item == NO_ITEM) return;
+  const FbWork w = work[item];
+  Tr<Q> tr{lds, lane};
   const uint8_t *rp = res + seq_off[w.seq] + w.i0;
   const LenEntry le = lentab[w.Lcfg];
   const float loop = w.multihit ? le.loop_m : le.loop_u, move = w.multihit ? le.move_m : le.move_u;
@@ -184,7 +215,7 @@ __global__ void __launch_bounds__(64) bwd_kernel(const FbWork *__restrict__ work
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
     const int c = lane * Q + q + 1;
-    tMMn[q] = (c < Mp) ? lds[1 * Mp + c] : 0.f; tIMn[q] = (c < Mp) ? lds[2 * Mp + c] : 0.f; tDMn[q] = (c < Mp) ? lds[3 * Mp + c] : 0.f;
+    tMMn[q] = (c < Mp) ? tr.at(1, c) : 0.f; tIMn[q] = (c < Mp) ? tr.at(2, c) : 0.f; tDMn[q] = (c < Mp) ? tr.at(3, c) : 0.f;
   }
   float Mv[Q], Iv[Q], Dv[Q];
   // row L
@@ -203,19 +234,33 @@ __global__ void __launch_bounds__(64) bwd_kernel(const FbWork *__restrict__ work
     }
   }
   bool bad = false;
+  // forward rows are pulled into registers one row ahead of their use: the loads must not sit behind the
+  // (possibly aliasing, same workspace) stores of the posterior rows
+  float fMr[Q], fIr[Q];
+  auto fetch_f = [&](int r) {
+    if (w.full && r >= 1) {
+      const float *__restrict__ f = fm + (size_t)r * 3 * Mp + lane * Q;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) { fMr[q] = f[q]; fIr[q] = f[Mp + q]; }
+    }
+  };
+  fetch_f(L);
   auto emit = [&](int r) {
     // decoding terms that become available once backward row r is final
     if (w.full) {
       if (r >= 1) {
-        const float *f = fm + (size_t)r * 3 * Mp + lane * Q;
-        float *b = bm + (size_t)r * 3 * Mp + lane * Q;
+        float *__restrict__ b = bm + (size_t)r * 3 * Mp + lane * Q;
+        float pmv[Q], piv[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-          float pm = f[q] * Mv[q]; pm = pm * invZ;
-          float pi = f[Mp + q] * Iv[q]; pi = pi * invZ;
-          b[q] = pm; b[Mp + q] = pi; b[2 * Mp + q] = 0.f;
+          float pm = fMr[q] * Mv[q]; pm = pm * invZ;
+          float pi = fIr[q] * Iv[q]; pi = pi * invZ;
+          pmv[q] = pm; piv[q] = pi;
           if (!(__builtin_isfinite(pm) && __builtin_isfinite(pi))) bad = true;
         }
+        fetch_f(r - 1);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { b[q] = pmv[q]; b[Mp + q] = piv[q]; b[2 * Mp + q] = 0.f; }
         if (lane == 0) {
           const float wgt = invZ / xs[(size_t)r * 6 + 5];
           float t;
@@ -238,11 +283,25 @@ __global__ void __launch_bounds__(64) bwd_kernel(const FbWork *__restrict__ work
     }
   };
   emit(L);
+  float rfc[Q];
+  if (L >= 1) {
+    const float *__restrict__ r0 = md.rf + (size_t)rp[L - 1] * Mp + lane * Q;    // residue L
+#pragma unroll
+    for (int q = 0; q < Q; ++q) rfc[q] = r0[q];
+  }
   for (int i = L - 1; i >= 0; --i) {
-    const float *rfx = md.rf + (size_t)rp[i] * Mp + lane * Q;    // residue i+1
+    float rfn[Q];                                                     // residue i, needed by the next iteration
+    {
+      const int xn = (i >= 1) ? rp[i - 1] : rp[0];
+      const float *__restrict__ r1 = md.rf + (size_t)xn * Mp + lane * Q;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) rfn[q] = r1[q];
+    }
     float mn[Q];
 #pragma unroll
-    for (int q = 0; q < Q; ++q) mn[q] = Mv[q] * rfx[q];
+    for (int q = 0; q < Q; ++q) mn[q] = Mv[q] * rfc[q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) rfc[q] = rfn[q];
     float s = 0.f;
 #pragma unroll
     for (int q = 0; q < Q; ++q) { const float t = tr.BM(q) * mn[q]; s = s + t; }
@@ -288,17 +347,19 @@ __global__ void __launch_bounds__(64) bwd_kernel(const FbWork *__restrict__ work
 
 // ---- null2 by expectation + optimal accuracy fill + traceback -------------------------------------
 template <int Q>
-__global__ void __launch_bounds__(64) oa_kernel(const FbWork *__restrict__ work, const uint32_t *__restrict__ idx,
+__global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ blk_model,
                                                 const DevModel *__restrict__ models, float *__restrict__ ws,
                                                 const int32_t *__restrict__ range_err, EnvOut *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int Mp = Q * 64;
-  const int lane = threadIdx.x;
-  const FbWork w = work[idx[blockIdx.x]];
-  const DevModel &md = models[w.model];
+  const int lane = threadIdx.x & 63;
+  const uint32_t item = idx[blockIdx.x * FB_WAVES + (threadIdx.x >> 6)];
+  const DevModel &md = models[blk_model[blockIdx.x]];
+  load_tr<Q>(lds, md.ftr);
+  if (item == NO_ITEM) return;
+  const FbWork w = work[item];
   if (range_err[w.slot]) { if (lane == 0) out[w.slot].range_err = 1; return; }
-  load_tr<Q>(lds, md.ftr, lane);
-  Tr<Q> tr{lds, lane * Q};
+  Tr<Q> tr{lds, lane};
   const int M = md.M, L = w.Ld, c0 = lane * Q;
   float *pp = ws + w.mxb_off;       // posterior rows (M, I; D = 0)
   float *oa = ws + w.mxf_off;       // OA rows overwrite the forward matrix
@@ -337,16 +398,28 @@ __global__ void __launch_bounds__(64) oa_kernel(const FbWork *__restrict__ work,
     const int c = c0 + q;
     okMM[q] = c > 0 && tr.MM(q) > 0.f; okIM[q] = c > 0 && tr.IM(q) > 0.f; okDM[q] = c > 0 && tr.DM(q) > 0.f; okBM[q] = tr.BM(q) > 0.f;
     okMI[q] = tr.MI(q) > 0.f; okII[q] = tr.II(q) > 0.f;
-    okMDp[q] = c > 0 && c < M && lds[6 * Mp + c - 1] > 0.f;
-    okDDp[q] = c > 0 && c < M && lds[7 * Mp + c - 1] > 0.f;
+    okMDp[q] = c > 0 && c < M && tr.at(6, c - 1) > 0.f;
+    okDDp[q] = c > 0 && c < M && tr.at(7, c - 1) > 0.f;
   }
   float Mv[Q], Iv[Q], Dv[Q];
 #pragma unroll
   for (int q = 0; q < Q; ++q) { Mv[q] = Iv[q] = Dv[q] = NEGINF_F; oa[c0 + q] = NEGINF_F; oa[Mp + c0 + q] = NEGINF_F; oa[2 * Mp + c0 + q] = NEGINF_F; }
   float oN = 0.f, oB = 0.f, oE = NEGINF_F, oJ = NEGINF_F, oC = NEGINF_F;
   if (lane == 0) { oax[0] = oN; oax[1] = oB; oax[2] = oE; oax[3] = oJ; oax[4] = oC; }
+  float ppM[Q], ppI[Q];
+  if (L >= 1) {
+    const float *__restrict__ p1 = pp + (size_t)1 * 3 * Mp + c0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { ppM[q] = p1[q]; ppI[q] = p1[Mp + q]; }
+  }
   for (int i = 1; i <= L; ++i) {
-    const float *pr = pp + (size_t)i * 3 * Mp + c0;
+    // posterior row i is in registers; row i+1 is requested now, before this row's stores
+    float ppMn[Q], ppIn[Q];
+    {
+      const float *__restrict__ pn = pp + (size_t)((i < L) ? i + 1 : i) * 3 * Mp + c0;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) { ppMn[q] = pn[q]; ppIn[q] = pn[Mp + q]; }
+    }
     float mpi = __shfl_up(Mv[Q - 1], 1), ipi = __shfl_up(Iv[Q - 1], 1), dpi = __shfl_up(Dv[Q - 1], 1);
     float Mn[Q], In[Q], Dn[Q];
     float e = NEGINF_F;
@@ -362,7 +435,7 @@ __global__ void __launch_bounds__(64) oa_kernel(const FbWork *__restrict__ work,
       float bi = NEGINF_F;
       if (okMI[q] && Mv[q] > bi) bi = Mv[q];
       if (okII[q] && Iv[q] > bi) bi = Iv[q];
-      if (c < M) { Mn[q] = best + pr[q]; In[q] = bi + pr[Mp + q]; e = fmaxf(e, Mn[q]); }
+      if (c < M) { Mn[q] = best + ppM[q]; In[q] = bi + ppI[q]; e = fmaxf(e, Mn[q]); }
       else { Mn[q] = NEGINF_F; In[q] = NEGINF_F; }
     }
     // D chain: D(c) = max(gate_MD(c-1) ? M(c-1), gate_DD(c-1) ? D(c-1)); segmented max scan over lanes
@@ -382,7 +455,7 @@ __global__ void __launch_bounds__(64) oa_kernel(const FbWork *__restrict__ work,
       }
       // lane output towards the next lane's first cell: needs the gates of that cell (c0+Q)
       const int cn = c0 + Q;
-      const bool gMD = cn < M && cn < Mp && lds[6 * Mp + cn - 1] > 0.f, gDD = cn < M && cn < Mp && lds[7 * Mp + cn - 1] > 0.f;
+      const bool gMD = cn < M && cn < Mp && tr.at(6, cn - 1) > 0.f, gDD = cn < M && cn < Mp && tr.at(7, cn - 1) > 0.f;
       float outv = NEGINF_F;
       if (gMD && Mn[Q - 1] > outv) outv = Mn[Q - 1];
       if (gDD && d > outv) outv = d;
@@ -409,9 +482,9 @@ __global__ void __launch_bounds__(64) oa_kernel(const FbWork *__restrict__ work,
     { const float a = oC + aux[(size_t)i * 3 + 2]; oC = a > e ? a : e; }
     oN = oN + aux[(size_t)i * 3 + 0];
     oB = oN > oJ ? oN : oJ;
-    float *r = oa + (size_t)i * 3 * Mp + c0;
+    float *__restrict__ r = oa + (size_t)i * 3 * Mp + c0;
 #pragma unroll
-    for (int q = 0; q < Q; ++q) { Mv[q] = Mn[q]; Iv[q] = In[q]; Dv[q] = Dn[q]; r[q] = Mn[q]; r[Mp + q] = In[q]; r[2 * Mp + q] = Dn[q]; }
+    for (int q = 0; q < Q; ++q) { Mv[q] = Mn[q]; Iv[q] = In[q]; Dv[q] = Dn[q]; r[q] = Mn[q]; r[Mp + q] = In[q]; r[2 * Mp + q] = Dn[q]; ppM[q] = ppMn[q]; ppI[q] = ppIn[q]; }
     if (lane == 0) { float *a = oax + (size_t)i * 5; a[0] = oN; a[1] = oB; a[2] = oE; a[3] = oJ; a[4] = oC; }
   }
   __threadfence();
@@ -421,7 +494,14 @@ __global__ void __launch_bounds__(64) oa_kernel(const FbWork *__restrict__ work,
   int i = L, k = 0, st = 0;      // 0=C 1=E 2=M 3=I 4=D
   int fi = 0, fk = 0, li = 0, lk = 0;
   bool done = false;
-  const float *tMM = lds + 1 * Mp, *tIM = lds + 2 * Mp, *tDM = lds + 3 * Mp, *tBM = lds, *tMI = lds + 4 * Mp, *tII = lds + 5 * Mp, *tMD = lds + 6 * Mp, *tDD = lds + 7 * Mp;
+#define tBM_(c) tr.at(0, (c))
+#define tMM_(c) tr.at(1, (c))
+#define tIM_(c) tr.at(2, (c))
+#define tDM_(c) tr.at(3, (c))
+#define tMI_(c) tr.at(4, (c))
+#define tII_(c) tr.at(5, (c))
+#define tMD_(c) tr.at(6, (c))
+#define tDD_(c) tr.at(7, (c))
   int guard = 0;
   while (!done && guard++ < 4 * (L + Mp) + 16) {
     const float *cr = oa + (size_t)i * 3 * Mp;
@@ -440,8 +520,8 @@ __global__ void __launch_bounds__(64) oa_kernel(const FbWork *__restrict__ work,
     } else if (st == 2) {
       fi = i; fk = k + 1;
       float p0 = NEGINF_F, p1 = NEGINF_F, p2 = NEGINF_F, p3 = NEGINF_F;
-      if (k > 0) { if (tMM[k] > 0.f) p0 = LD2(&pr[k - 1]); if (tIM[k] > 0.f) p1 = LD2(&pr[Mp + k - 1]); if (tDM[k] > 0.f) p2 = LD2(&pr[2 * Mp + k - 1]); }
-      if (tBM[k] > 0.f) p3 = LD2(&oax[(size_t)(i - 1) * 5 + 1]);
+      if (k > 0) { if (tMM_(k) > 0.f) p0 = LD2(&pr[k - 1]); if (tIM_(k) > 0.f) p1 = LD2(&pr[Mp + k - 1]); if (tDM_(k) > 0.f) p2 = LD2(&pr[2 * Mp + k - 1]); }
+      if (tBM_(k) > 0.f) p3 = LD2(&oax[(size_t)(i - 1) * 5 + 1]);
       int best = 0; float bv = p0;
       if (p1 > bv) { bv = p1; best = 1; }
       if (p2 > bv) { bv = p2; best = 2; }
@@ -449,10 +529,10 @@ __global__ void __launch_bounds__(64) oa_kernel(const FbWork *__restrict__ work,
       --i;
       if (best == 0) { --k; st = 2; } else if (best == 1) { --k; st = 3; } else if (best == 2) { --k; st = 4; } else done = true;
     } else if (st == 3) {
-      const float a = (tMI[k] > 0.f) ? LD2(&pr[k]) : NEGINF_F, b = (tII[k] > 0.f) ? LD2(&pr[Mp + k]) : NEGINF_F;
+      const float a = (tMI_(k) > 0.f) ? LD2(&pr[k]) : NEGINF_F, b = (tII_(k) > 0.f) ? LD2(&pr[Mp + k]) : NEGINF_F;
       --i; st = (a >= b) ? 2 : 3;
     } else {
-      const float a = (tMD[k - 1] > 0.f) ? LD2(&cr[k - 1]) : NEGINF_F, b = (tDD[k - 1] > 0.f) ? LD2(&cr[2 * Mp + k - 1]) : NEGINF_F;
+      const float a = (tMD_(k - 1) > 0.f) ? LD2(&cr[k - 1]) : NEGINF_F, b = (tDD_(k - 1) > 0.f) ? LD2(&cr[2 * Mp + k - 1]) : NEGINF_F;
       --k; st = (a >= b) ? 2 : 4;
     }
   }
@@ -466,34 +546,34 @@ __global__ void __launch_bounds__(64) oa_kernel(const FbWork *__restrict__ work,
 // ---- launchers ----------------------------------------------------------------------------------
 #define CKM_FB_QS(X) X(1) X(2) X(3) X(4) X(6) X(8) X(12) X(16) X(24) X(32)
 
-int launch_fwd(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const DevModel *models,
+int launch_fwd(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const uint32_t *blk_model, const DevModel *models,
                const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, FwdOut *out,
                ScaleEvent *events, uint32_t *nevents, uint32_t cap_events) {
   if (!n) return 0;
   switch (Q) {
-#define X(QV) case QV: hipLaunchKernelGGL(fwd_kernel<QV>, dim3(n), dim3(64), (size_t)8 * QV * 64 * 4, stream, work, idx, models, lentab, res, seq_off, ws, out, events, nevents, cap_events); break;
+#define X(QV) case QV: hipLaunchKernelGGL(fwd_kernel<QV>, dim3(n), dim3(256), (size_t)8 * QV * 64 * 4, stream, work, idx, blk_model, models, lentab, res, seq_off, ws, out, events, nevents, cap_events); break;
     CKM_FB_QS(X)
 #undef X
     default: return -1;
   }
   return 0;
 }
-int launch_bwd(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const DevModel *models,
+int launch_bwd(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const uint32_t *blk_model, const DevModel *models,
                const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, const FwdOut *fout, int32_t *range_err) {
   if (!n) return 0;
   switch (Q) {
-#define X(QV) case QV: hipLaunchKernelGGL(bwd_kernel<QV>, dim3(n), dim3(64), (size_t)8 * QV * 64 * 4, stream, work, idx, models, lentab, res, seq_off, ws, fout, range_err); break;
+#define X(QV) case QV: hipLaunchKernelGGL(bwd_kernel<QV>, dim3(n), dim3(256), (size_t)8 * QV * 64 * 4, stream, work, idx, blk_model, models, lentab, res, seq_off, ws, fout, range_err); break;
     CKM_FB_QS(X)
 #undef X
     default: return -1;
   }
   return 0;
 }
-int launch_oa(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const DevModel *models,
+int launch_oa(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const uint32_t *blk_model, const DevModel *models,
               float *ws, const int32_t *range_err, EnvOut *out) {
   if (!n) return 0;
   switch (Q) {
-#define X(QV) case QV: hipLaunchKernelGGL(oa_kernel<QV>, dim3(n), dim3(64), (size_t)8 * QV * 64 * 4, stream, work, idx, models, ws, range_err, out); break;
+#define X(QV) case QV: hipLaunchKernelGGL(oa_kernel<QV>, dim3(n), dim3(256), (size_t)8 * QV * 64 * 4, stream, work, idx, blk_model, models, ws, range_err, out); break;
     CKM_FB_QS(X)
 #undef X
     default: return -1;
