@@ -20,7 +20,7 @@ namespace ckm {
 
 // ---- kernel launchers (kernels_*.hip) ------------------------------------------------------------
 int launch_ssv(int Q, int nblocks, int threads, hipStream_t stream, const SsvBlockWork *work, const DevModel *models,
-               const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const uint32_t *lists, int16_t *maxv);
+               const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const uint32_t *lists, uint16_t *maxv);
 void launch_msv_finish(hipStream_t stream, const FinishArgs &a, uint32_t nblocks);
 void launch_msv_full(hipStream_t stream, const PairRec *pairs, uint32_t npairs, const DevModel *models, const LenEntry *lentab,
                      const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xJ, float *out_usc, int maxMp);
@@ -577,13 +577,13 @@ static void do_search(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, co
         if (attempt == 0) {
           for (auto &g : groups) {
             if (launch_ssv(g.first, (int)g.second.second, ssv_threads_for(g.first), ctx->stream, ctx->work.as<SsvBlockWork>() + g.second.first, dm, res, off, dlen,
-                           ctx->idx.as<uint32_t>(), ctx->maxv.as<int16_t>()))
+                           ctx->idx.as<uint32_t>(), ctx->maxv.as<uint16_t>()))
               throw Error(CKM_ERANGE, "no SSV kernel instance for this model length");
             st.ssv_launches++;
           }
         }
         HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
-        FinishArgs fa{dm, lt, dlen, ctx->idx.as<uint32_t>(), ctx->work.as<SsvBlockWork>(), ctx->maxv.as<int16_t>(),
+        FinishArgs fa{dm, lt, dlen, ctx->idx.as<uint32_t>(), ctx->work.as<SsvBlockWork>(), ctx->maxv.as<uint16_t>(),
                       ctx->surv.as<PairRec>(), ctx->counters.as<uint32_t>(), cap_surv, ctx->nores.as<PairRec>(), ctx->counters.as<uint32_t>() + 1, cap_nores};
         launch_msv_finish(ctx->stream, fa, (uint32_t)allw.size());
         HIPCHK(hipGetLastError());
@@ -942,10 +942,10 @@ extern "C" int ckm_debug_stages(ckm_ctx *ctx, const ckm_profiles *p, const ckm_s
     HIPCHK(hipMemcpy(ctx->idx.p, ids.data(), npairs * 4, hipMemcpyHostToDevice));
     for (auto &g : groups)
       if (launch_ssv(g.first, (int)g.second.second, ssv_threads_for(g.first), ctx->stream, ctx->work.as<SsvBlockWork>() + g.second.first, dm, res, off, dlen,
-                     ctx->idx.as<uint32_t>(), ctx->maxv.as<int16_t>()))
+                     ctx->idx.as<uint32_t>(), ctx->maxv.as<uint16_t>()))
         throw Error(CKM_ERANGE, "no SSV kernel instance");
     HIPCHK(hipGetLastError());
-    std::vector<int16_t> maxv(npairs);
+    std::vector<uint16_t> maxv(npairs);
     HIPCHK(hipMemcpyAsync(maxv.data(), ctx->maxv.p, npairs * 2, hipMemcpyDeviceToHost, ctx->stream));
     // full MSV on every pair
     std::vector<PairRec> pr(npairs);

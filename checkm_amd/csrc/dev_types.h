@@ -72,7 +72,7 @@ struct FbWork {              // one Forward/Backward/OA work item (whole sequenc
 struct FinishArgs {
   const DevModel *models; const LenEntry *lentab; const int32_t *seq_len; const uint32_t *lists;
   const SsvBlockWork *work;            // the table the SSV launches used (one entry per SSV block)
-  const int16_t *maxv;
+  const uint16_t *maxv;                // Smax per pair (0 = degenerate: recompute exactly)
   PairRec *survivors; uint32_t *nsurv; uint32_t cap_surv;
   PairRec *noresult;  uint32_t *nnores; uint32_t cap_nores;
 };

@@ -43,6 +43,12 @@ __global__ void msv_finish_kernel(FinishArgs a, uint32_t nblocks_work) {
     const int xB = max(md.base_b - tjbm, 0);
     const int xEi = xB + maxV;
     PairRec r; r.model = w.model; r.seq = sid; r.filtersc = 0.f;
+    if (maxV == 0) {                             // no cell ever rose above xB: the floored recurrence lost max V; exact kernel
+      r.usc = 0.f;
+      const uint32_t k = atomicAdd(a.nnores, 1u);
+      if (k < a.cap_nores) a.noresult[k] = r;
+      continue;
+    }
     if (xEi + md.bias_b >= 255) {               // byte overflow: score is +inf, passes every MSV test
       r.usc = __builtin_inff();
       const uint32_t k = atomicAdd(a.nsurv, 1u);
@@ -182,12 +188,22 @@ __global__ void __launch_bounds__(256) vit_kernel(const PairRec *__restrict__ pa
   int xN = md.base_w, xB = xN + le.w_move, xJ = NEG16, xC = NEG16;
   bool overflow = false;
   constexpr int NEGBIG = -(1 << 30);
-  for (int i = 0; i < L; ++i) {
-    const int x = rp[i];
-    const int16_t *er = md.rwv + (size_t)x * Mp + c0;
-    int e[Q];
+  // emission words are fetched one row ahead, the residue byte two rows ahead (dependent loads)
+  int e[Q];
+  {
+    const int16_t *__restrict__ er = md.rwv + (size_t)rp[0] * Mp + c0;
 #pragma unroll
     for (int q = 0; q < Q; ++q) e[q] = er[q];
+  }
+  int xn = (L > 1) ? rp[1] : rp[0];
+  for (int i = 0; i < L; ++i) {
+    int en[Q];
+    {
+      const int16_t *__restrict__ er = md.rwv + (size_t)xn * Mp + c0;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) en[q] = er[q];
+    }
+    xn = (i + 2 < L) ? rp[i + 2] : rp[L - 1];
     int mpi = __shfl_up(Mv[Q - 1], 1), ipi = __shfl_up(Iv[Q - 1], 1), dpi = __shfl_up(Dv[Q - 1], 1);
     if (lane == 0) { mpi = NEG16; ipi = NEG16; dpi = NEG16; }
     int xE = NEG16;
@@ -224,6 +240,8 @@ __global__ void __launch_bounds__(256) vit_kernel(const PairRec *__restrict__ pa
     xC = max(xC, xE + md.wE_move);
     xJ = max(xJ, xE + md.wE_loop);
     xB = max(xJ + le.w_move, xN + le.w_move);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) e[q] = en[q];
   }
   if (lane == 0) {
     if (overflow) { out_xC[pi] = 32767; out_sc[pi] = __builtin_inff(); }

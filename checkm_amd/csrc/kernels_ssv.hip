@@ -5,10 +5,16 @@
 // (checkm/markerGeneFinder.py:140-142 -> checkm/hmmer.py:70).  MSV in unsigned bytes is
 //     sv(i,k) = sat_sub(sat_add(max(sv(i-1,k-1), xB), bias), cost[x_i][k])
 // and while the running xJ never exceeds `base`, xB is constant, so with U = max(sv - xB, 0):
-//     V(i,k) = U(i-1,k-1) + (bias - cost[x_i][k]);   U(i,k) = max(V(i,k), 0);   maxV = max V
-// is independent of the target length; xE = max(0, xB + maxV) reproduces the byte arithmetic exactly
-// (sat_add cannot saturate before the overflow test fires).  Pairs for
-// which the J state could have been used (xJ > base) are re-run by msv_full_kernel.
+//     U(i,k) = max(U(i-1,k-1) + (bias - cost[x_i][k]), 0);   Smax = max U
+// is independent of the target length; xE = xB + Smax reproduces the byte arithmetic exactly whenever
+// Smax > 0 (sat_add cannot saturate before the overflow test fires).  Pairs
+// with Smax == 0 (no cell ever scored above xB: degenerate targets) and pairs for which the J state
+// could have been used (xJ > base) are re-run by msv_full_kernel.
+//
+// VALU budget: on gfx950 every VALU op except f32 add/mul/fma issues at 4 cycles per wave64
+// (tools/ubench/valu_rates.hip), so the kernel is bound by instruction COUNT.  U is held with a
+// -32768 offset: the saturating v_pk_add_i16 then performs the floor at 0 for free, leaving
+// 2 packed ops per register per row (add-with-clamp, running max) instead of 3.
 //
 // Mapping: 16 lanes per sequence (one DPP row), 4 sequences per wavefront, Q packed 2 x i16
 // registers per lane; position p = q + Q*(2*lane16 + half) so the diagonal move i-1,k-1 -> i,k is a
@@ -28,6 +34,7 @@ __device__ __forceinline__ u32   as_u32(s16x2 v) { return __builtin_bit_cast(u32
 
 constexpr int SSV_NROWS = 30;
 constexpr u32 PAD4 = 0x1d1d1d1du;   // four PADCODE (29) residues
+constexpr u32 U_ZERO = 0x80008000u; // two cells with U = 0 in the -32768-offset representation
 
 template <int Q>
 __device__ __forceinline__ void ssv_row(u32 (&U)[Q], u32 &xE, const char *lds_lane, u32 x) {
@@ -43,19 +50,19 @@ __device__ __forceinline__ void ssv_row(u32 (&U)[Q], u32 &xE, const char *lds_la
   // cell p=0 of each lane's first register comes from the previous lane's last register (high half)
   // and this lane's own last register (low half -> high half)
   const u32 last = U[Q - 1];
-  const u32 prev = (u32)__builtin_amdgcn_update_dpp(0, (int)last, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
+  // lane 0 of each 16-lane row has no predecessor: it keeps `old` = the offset representation of U = 0
+  const u32 prev = (u32)__builtin_amdgcn_update_dpp((int)U_ZERO, (int)last, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
   const u32 carry = __builtin_amdgcn_alignbit(last, prev, 16);
-  const s16x2 zero = {0, 0};
 #pragma unroll
   for (int q = Q - 1; q >= 1; --q) {
-    const s16x2 v = __builtin_elementwise_add_sat(as_s16x2(U[q - 1]), as_s16x2(e[q]));
+    const s16x2 v = __builtin_elementwise_add_sat(as_s16x2(U[q - 1]), as_s16x2(e[q]));   // clamps at -32768 == U 0
     xE = as_u32(__builtin_elementwise_max(as_s16x2(xE), v));
-    U[q] = as_u32(__builtin_elementwise_max(v, zero));
+    U[q] = as_u32(v);
   }
   {
     const s16x2 v = __builtin_elementwise_add_sat(as_s16x2(carry), as_s16x2(e[0]));
     xE = as_u32(__builtin_elementwise_max(as_s16x2(xE), v));
-    U[0] = as_u32(__builtin_elementwise_max(v, zero));
+    U[0] = as_u32(v);
   }
 }
 
@@ -63,7 +70,7 @@ template <int Q>
 __global__ void __launch_bounds__(Q > 40 ? 512 : 1024) ssv_kernel(const SsvBlockWork *__restrict__ work, const DevModel *__restrict__ models,
                            const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
                            const int32_t *__restrict__ seq_len, const uint32_t *__restrict__ lists,
-                           int16_t *__restrict__ maxv) {
+                           uint16_t *__restrict__ maxv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int Qg = (Q + 3) / 4;
   constexpr int ROWB = Qg * 256;
@@ -89,8 +96,8 @@ __global__ void __launch_bounds__(Q > 40 ? 512 : 1024) ssv_kernel(const SsvBlock
     Lmax = max(Lmax, __builtin_amdgcn_readlane(L, 48));
     u32 U[Q];
 #pragma unroll
-    for (int q = 0; q < Q; ++q) U[q] = 0u;
-    u32 xE = 0x80008000u;
+    for (int q = 0; q < Q; ++q) U[q] = U_ZERO;
+    u32 xE = U_ZERO;
     const int nchunk = (Lmax + 15) >> 4;
     const uint4 padv = make_uint4(PAD4, PAD4, PAD4, PAD4);
     uint4 cur = (0 < L) ? *reinterpret_cast<const uint4 *>(rp) : padv;
@@ -106,12 +113,12 @@ __global__ void __launch_bounds__(Q > 40 ? 512 : 1024) ssv_kernel(const SsvBlock
       cur = nxt;
     }
     const s16x2 xv = as_s16x2(xE);
-    int m = max((int)xv.x, (int)xv.y);
+    int m = max((int)xv.x, (int)xv.y) + 32768;   // back to Smax >= 0
     m = max(m, __shfl_xor(m, 1, 16));
     m = max(m, __shfl_xor(m, 2, 16));
     m = max(m, __shfl_xor(m, 4, 16));
     m = max(m, __shfl_xor(m, 8, 16));
-    if (valid && z == 0) maxv[w.pair_start + li] = (int16_t)m;
+    if (valid && z == 0) maxv[w.pair_start + li] = (uint16_t)m;
   }
 }
 
@@ -126,7 +133,7 @@ __global__ void __launch_bounds__(Q > 40 ? 512 : 1024) ssv_kernel(const SsvBlock
     break;
 
 int launch_ssv(int Q, int nblocks, int threads, hipStream_t stream, const SsvBlockWork *work, const DevModel *models,
-               const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const uint32_t *lists, int16_t *maxv) {
+               const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const uint32_t *lists, uint16_t *maxv) {
   switch (Q) {
     CKM_SSV_CASE(1) CKM_SSV_CASE(2) CKM_SSV_CASE(3) CKM_SSV_CASE(4) CKM_SSV_CASE(5) CKM_SSV_CASE(6) CKM_SSV_CASE(7)
     CKM_SSV_CASE(8) CKM_SSV_CASE(9) CKM_SSV_CASE(10) CKM_SSV_CASE(11) CKM_SSV_CASE(12) CKM_SSV_CASE(13) CKM_SSV_CASE(14)

@@ -129,6 +129,9 @@ def test_search_rows_identical(world):
     _compare_search(w, hits, None)
     st = w["ctx"].stats()
     assert st.pairs_ssv == sum(1 for r in w["recs"] if len(r[2]) > 0) * w["hs"].n
+    # the SSV-derived F1 decision must agree with the exact byte MSV on EVERY pair, not only on reported hits
+    want = sum(w["hs"].stages(m, d).pass_msv for m in range(w["hs"].n) for d in w["dsq"])
+    assert st.pairs_bias == want, (st.pairs_bias, want)
     hits.close()
 
 
