@@ -12,6 +12,9 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <thread>
+#include <exception>
 #include <numeric>
 #include "ckm_internal.h"
 #include "dev_types.h"
@@ -64,7 +67,10 @@ struct DevBuf {
 
 using namespace ckm;
 
-struct ckm_ctx {
+// One worker = one host thread's view of the device: its own streams, events and scratch buffers.
+// ckm_search splits the models of a call over the workers so that the latency-bound rare stages and the
+// host glue of one chunk overlap the VALU-bound SSV / Viterbi kernels of the other.
+struct Worker {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t side[8];                    // per-register-class launches of the rare stages overlap on these
@@ -73,6 +79,17 @@ struct ckm_ctx {
   // reusable device scratch
   DevBuf work, maxv, surv, nores, counters, cand, raw, idx, vitx, vits, fbwork, fbidx, fbmodel, ws, fout, events, rerr, envout, fullx, fullu;
   size_t ws_budget = (size_t)8 << 30;     // float workspace budget (bytes) for Forward/Backward matrices
+};
+
+constexpr int NWORKERS = 4;          // upper bound; CKM_WORKERS (default 1) selects how many a search uses
+
+struct ckm_ctx {
+  int device = 0;
+  int nworkers = 1;
+  DevBuf reduce_scratch;                  // grow-only device buffer of the reduce kernels
+  Worker w[NWORKERS];
+  ckm_search_stats stats;
+  std::mutex ssv_mutex;                   // SSV phases are VALU-bound: two of them side by side gain nothing
 };
 
 struct ckm_profiles {
@@ -85,7 +102,7 @@ struct ckm_profiles {
   int maxMp = 0;
 };
 
-struct SeqList { std::vector<uint32_t> ids; DevBuf d_ids; };
+struct SeqList { std::vector<uint32_t> ids; DevBuf d_ids; uint64_t total_res = 0; };
 
 struct ckm_seqs {
   ckm_ctx *ctx = nullptr;
@@ -122,6 +139,7 @@ static int guarded(F &&f) {
 // accessors for ckm_reduce.hip
 const std::string &ckm_seq_name(const ckm_seqs *s, uint32_t i) { return s->names.at(i); }
 int ckm_ctx_device(const ckm_ctx *ctx) { return ctx->device; }
+void *ckm_ctx_reduce_scratch(ckm_ctx *ctx, size_t bytes) { ctx->reduce_scratch.ensure(bytes); return ctx->reduce_scratch.p; }
 
 extern "C" const char *ckm_last_error(void) { return g_err.c_str(); }
 extern "C" int ckm_abi_version(void) { return CKM_ABI_VERSION; }
@@ -150,12 +168,19 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
       throw Error(CKM_ENODEV, std::string("device is ") + prop.gcnArchName + "; this library carries gfx950 code objects only");
     std::unique_ptr<ckm_ctx> ctx(new ckm_ctx());
     ctx->device = device;
-    HIPCHK(hipStreamCreate(&ctx->stream));
-    for (auto &st : ctx->side) HIPCHK(hipStreamCreate(&st));
-    for (auto &e : ctx->ev) HIPCHK(hipEventCreate(&e));
     memset(&ctx->stats, 0, sizeof(ctx->stats));
+    if (const char *e = getenv("CKM_WORKERS")) ctx->nworkers = std::max(1, std::min(NWORKERS, atoi(e)));
     size_t fre = 0, tot = 0;
-    if (hipMemGetInfo(&fre, &tot) == hipSuccess) ctx->ws_budget = std::min<size_t>((size_t)96 << 30, fre / 2);
+    size_t budget = (size_t)8 << 30;
+    if (hipMemGetInfo(&fre, &tot) == hipSuccess) budget = std::min<size_t>((size_t)96 << 30, fre / 2) / ctx->nworkers;
+    for (auto &w : ctx->w) {
+      w.device = device;
+      HIPCHK(hipStreamCreate(&w.stream));
+      for (auto &st : w.side) HIPCHK(hipStreamCreate(&st));
+      for (auto &e : w.ev) HIPCHK(hipEventCreate(&e));
+      memset(&w.stats, 0, sizeof(w.stats));
+      w.ws_budget = budget;
+    }
     *out = ctx.release();
   });
 }
@@ -163,10 +188,12 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
 extern "C" void ckm_ctx_destroy(ckm_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
-  for (auto &e : ctx->ev) (void)hipEventDestroy(e);
-  for (auto &st : ctx->side) (void)hipStreamDestroy(st);
-  (void)hipStreamDestroy(ctx->stream);
+  (void)hipDeviceSynchronize();
+  for (auto &w : ctx->w) {
+    for (auto &e : w.ev) (void)hipEventDestroy(e);
+    for (auto &st : w.side) (void)hipStreamDestroy(st);
+    (void)hipStreamDestroy(w.stream);
+  }
   delete ctx;
 }
 
@@ -333,6 +360,7 @@ const SeqList *get_list(const ckm_seqs *s, const std::vector<uint32_t> &bins) {
   std::unique_ptr<SeqList> l(new SeqList());
   for (uint32_t b : bins) for (uint32_t i = s->bin_off[b]; i < s->bin_off[b + 1]; ++i) if (s->len[i] > 0) l->ids.push_back(i);
   std::stable_sort(l->ids.begin(), l->ids.end(), [&](uint32_t a, uint32_t b) { return s->len[a] > s->len[b]; });
+  for (uint32_t id : l->ids) l->total_res += (uint64_t)s->len[id];
   l->d_ids.ensure(std::max<size_t>(4, l->ids.size() * 4));
   if (!l->ids.empty()) HIPCHK(hipMemcpy(l->d_ids.p, l->ids.data(), l->ids.size() * 4, hipMemcpyHostToDevice));
   const SeqList *r = l.get();
@@ -373,7 +401,7 @@ struct FbBatch {
   std::vector<EnvOut> envout;
 };
 
-void run_fb(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, bool do_fwd, bool do_bwd, bool do_oa,
+void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, bool do_fwd, bool do_bwd, bool do_oa,
             const std::vector<uint32_t> *subset /* indices into b.work, or null = all */) {
   const size_t n = b.work.size();
   if (!n) return;
@@ -459,7 +487,7 @@ size_t env_floats(int Mp, int Ld, uint64_t &xs, uint64_t &aux, uint64_t &mf, uin
 struct EnvReq { uint32_t model, seq; int ienv, jenv; };
 struct EnvRes { bool ok; float envsc, oasc, xC; int nscale; float null2[KP]; int hmm_from, hmm_to, ali_from, ali_to; };
 
-void rescore_envelopes(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<EnvReq> &req, std::vector<EnvRes> &out) {
+void rescore_envelopes(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<EnvReq> &req, std::vector<EnvRes> &out) {
   out.resize(req.size());
   size_t done = 0;
   const uint64_t budget_floats = ctx->ws_budget / 4;
@@ -507,24 +535,15 @@ struct SearchPlan {        // which models run against which sequence lists
   std::vector<std::vector<uint32_t>> model_bins;   // per model: bins (sorted)
 };
 
-static void do_search(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, const uint32_t *model_off, const uint32_t *model_idx,
-                      double E, double domE, ckm_hits *hits) {
+typedef std::map<std::pair<uint32_t, uint32_t>, std::vector<Hit>> HitMap;     // (bin, model) -> hits
+
+// The whole filter cascade + domain stage for a subset of the models, on one worker.
+static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, const ckm_seqs *s, const std::vector<uint32_t> &my_models,
+                    const std::vector<std::vector<uint32_t>> &model_bins, HitMap &by_bin_model) {
   HIPCHK(hipSetDevice(ctx->device));
   const double t_start = now_ms();
   ckm_search_stats &st = ctx->stats;
   memset(&st, 0, sizeof(st));
-  const uint32_t nmodels = (uint32_t)p->hmm.size(), nbins = s->nbins;
-  // ---- plan ----
-  std::vector<std::vector<uint32_t>> bin_models(nbins);
-  for (uint32_t b = 0; b < nbins; ++b) {
-    if (model_off) { for (uint32_t k = model_off[b]; k < model_off[b + 1]; ++k) { if (model_idx[k] >= nmodels) throw Error(CKM_EINVAL, "model index out of range"); bin_models[b].push_back(model_idx[k]); } }
-    else { bin_models[b].resize(nmodels); std::iota(bin_models[b].begin(), bin_models[b].end(), 0u); }
-  }
-  std::vector<std::vector<uint32_t>> model_bins(nmodels);
-  for (uint32_t b = 0; b < nbins; ++b) {
-    std::vector<uint32_t> uniq = bin_models[b]; std::sort(uniq.begin(), uniq.end()); uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-    for (uint32_t m : uniq) model_bins[m].push_back(b);
-  }
   const DevModel *dm = p->d_models.as<DevModel>();
   const LenEntry *lt = s->d_lentab.as<LenEntry>();
   const uint8_t *res = s->d_res.as<uint8_t>();
@@ -535,19 +554,21 @@ static void do_search(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, co
   std::vector<Cand> cands;
   {
     const uint64_t pair_budget = (uint64_t)1 << 29;
-    uint32_t m0 = 0;
-    while (m0 < nmodels) {
+    size_t i0 = 0;
+    while (i0 < my_models.size()) {
       // gather models of this chunk; every distinct sequence list gets one device array
       struct MW { uint32_t model; const SeqList *list; uint64_t pair_base; };
-      std::vector<MW> mws; uint64_t npairs = 0; uint32_t m1 = m0;
-      for (; m1 < nmodels; ++m1) {
+      std::vector<MW> mws; uint64_t npairs = 0; size_t i1 = i0;
+      for (; i1 < my_models.size(); ++i1) {
+        const uint32_t m1 = my_models[i1];
         if (model_bins[m1].empty()) continue;
-        const SeqList *l = get_list(s, model_bins[m1]);
+        const SeqList *l = get_list(s, model_bins[m1]);      // cached by do_search before the workers start
         if (npairs + l->ids.size() > pair_budget && !mws.empty()) break;
         mws.push_back({m1, l, npairs}); npairs += l->ids.size();
       }
-      m0 = m1;
+      i0 = i1;
       if (mws.empty() || npairs == 0) continue;
+      std::unique_lock<std::mutex> ssv_lock(*ssv_mutex);     // one SSV phase at a time (VALU-bound); released after the finish kernel
       // the kernels index ONE lists[] array: concatenate the distinct lists of this chunk
       std::map<const SeqList *, uint32_t> list_base; std::vector<uint32_t> all_ids;
       for (auto &mw : mws) if (!list_base.count(mw.list)) { list_base[mw.list] = (uint32_t)all_ids.size(); all_ids.insert(all_ids.end(), mw.list->ids.begin(), mw.list->ids.end()); }
@@ -562,7 +583,7 @@ static void do_search(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, co
           byQ[Q].push_back(w);
         }
         st.pairs_ssv += n;
-        for (uint32_t id : mw.list->ids) { st.residue_hmm += (uint64_t)s->len[id]; st.cells_ssv += (uint64_t)s->len[id] * (uint64_t)p->prof[mw.model].M; }
+        st.residue_hmm += mw.list->total_res; st.cells_ssv += mw.list->total_res * (uint64_t)p->prof[mw.model].M;
       }
       std::vector<SsvBlockWork> allw; std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;
       for (auto &kv : byQ) { groups.push_back({kv.first, {allw.size(), kv.second.size()}}); allw.insert(allw.end(), kv.second.begin(), kv.second.end()); }
@@ -595,6 +616,7 @@ static void do_search(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, co
         std::vector<PairRec> sv(cnt[0]), nr(cnt[1]);
         if (cnt[0]) HIPCHK(hipMemcpy(sv.data(), ctx->surv.p, (size_t)cnt[0] * sizeof(PairRec), hipMemcpyDeviceToHost));
         if (cnt[1]) HIPCHK(hipMemcpy(nr.data(), ctx->nores.p, (size_t)cnt[1] * sizeof(PairRec), hipMemcpyDeviceToHost));
+        ssv_lock.unlock();
         for (auto &r : sv) { Cand c; c.r = r; c.alive = true; c.fwdsc = 0; c.fwd_xC = 0; c.slot = 0; cands.push_back(c); }
         if (!nr.empty()) {     // exact multi-hit MSV for the pairs where J could be used
           st.pairs_msv_full += nr.size();
@@ -613,8 +635,8 @@ static void do_search(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, co
       }
     }
   }
-  // deterministic order: by model then sequence
-  std::sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.r.model != b.r.model ? a.r.model < b.r.model : a.r.seq < b.r.seq; });
+  // (the atomic append order of the survivors is arbitrary; every later stage is per pair, and the rows are
+  //  ordered at the end, so no sort is needed here)
   const double t_filters0 = now_ms();
 
   // ---- stage 2: bias filter ----
@@ -749,7 +771,6 @@ static void do_search(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, co
   st.ms_domains = now_ms() - t_dom0;
   const double t_host0 = now_ms();
   // ---- stage 7: scores, thresholds, rows ----
-  std::map<std::pair<uint32_t, uint32_t>, std::vector<Hit>> by_bin_model;     // (bin, model) -> hits
   for (size_t q = 0; q < passers.size(); ++q) {
     const Cand &c = cands[fb_cand[passers[q]]];
     const HostHMM &hm = p->hmm[c.r.model];
@@ -798,6 +819,54 @@ static void do_search(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, co
     }
     by_bin_model[{s->seq_bin[c.r.seq], c.r.model}].push_back(std::move(h));
   }
+  st.ms_host = now_ms() - t_host0;
+  st.ms_total = now_ms() - t_start;
+}
+
+static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, const uint32_t *model_off, const uint32_t *model_idx,
+                      double E, double domE, ckm_hits *hits) {
+  HIPCHK(hipSetDevice(c->device));
+  const double t_start = now_ms();
+  const uint32_t nmodels = (uint32_t)p->hmm.size(), nbins = s->nbins;
+  // ---- plan ----
+  std::vector<std::vector<uint32_t>> bin_models(nbins);
+  for (uint32_t b = 0; b < nbins; ++b) {
+    if (model_off) { for (uint32_t k = model_off[b]; k < model_off[b + 1]; ++k) { if (model_idx[k] >= nmodels) throw Error(CKM_EINVAL, "model index out of range"); bin_models[b].push_back(model_idx[k]); } }
+    else { bin_models[b].resize(nmodels); std::iota(bin_models[b].begin(), bin_models[b].end(), 0u); }
+  }
+  std::vector<std::vector<uint32_t>> model_bins(nmodels);
+  for (uint32_t b = 0; b < nbins; ++b) {
+    std::vector<uint32_t> uniq = bin_models[b]; std::sort(uniq.begin(), uniq.end()); uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    for (uint32_t m : uniq) model_bins[m].push_back(b);
+  }
+  // models -> workers: deal them out by decreasing work (pairs x M) so both chunks cost about the same
+  std::vector<uint32_t> active; std::vector<double> cost(nmodels, 0.0);
+  for (uint32_t m = 0; m < nmodels; ++m) if (!model_bins[m].empty()) { active.push_back(m); cost[m] = (double)get_list(s, model_bins[m])->ids.size() * p->prof[m].M; }
+  std::stable_sort(active.begin(), active.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
+  const int nw = (active.size() >= 2 * (size_t)c->nworkers) ? c->nworkers : 1;
+  std::vector<std::vector<uint32_t>> chunk(nw); std::vector<double> load(nw, 0.0);
+  for (uint32_t m : active) { int k = (int)(std::min_element(load.begin(), load.end()) - load.begin()); chunk[k].push_back(m); load[k] += cost[m]; }
+  for (auto &ch : chunk) std::sort(ch.begin(), ch.end());
+  std::vector<HitMap> maps(nw); std::vector<std::exception_ptr> errs(nw);
+  auto run = [&](int k) { try { cascade(&c->w[k], &c->ssv_mutex, p, s, chunk[k], model_bins, maps[k]); } catch (...) { errs[k] = std::current_exception(); } };
+  std::vector<std::thread> threads;
+  for (int k = 1; k < nw; ++k) threads.emplace_back(run, k);
+  run(0);
+  for (auto &t : threads) t.join();
+  for (auto &e : errs) if (e) std::rethrow_exception(e);
+  HitMap by_bin_model;
+  for (auto &m : maps) for (auto &kv : m) by_bin_model[kv.first] = std::move(kv.second);
+  ckm_search_stats &st = c->stats;
+  memset(&st, 0, sizeof(st));
+  for (int k = 0; k < nw; ++k) {
+    const ckm_search_stats &w = c->w[k].stats;
+    st.pairs_ssv += w.pairs_ssv; st.pairs_msv_full += w.pairs_msv_full; st.pairs_bias += w.pairs_bias; st.pairs_vit += w.pairs_vit; st.pairs_fwd += w.pairs_fwd;
+    st.pairs_dom += w.pairs_dom; st.envelopes += w.envelopes; st.cells_ssv += w.cells_ssv; st.residue_hmm += w.residue_hmm; st.ssv_launches += w.ssv_launches;
+    st.ms_ssv += w.ms_ssv;                                   // SSV phases are serialised by the mutex: the sum is the kernel time
+    st.ms_filters = std::max(st.ms_filters, w.ms_filters); st.ms_fwdbwd = std::max(st.ms_fwdbwd, w.ms_fwdbwd);
+    st.ms_domains = std::max(st.ms_domains, w.ms_domains); st.ms_host = std::max(st.ms_host, w.ms_host);
+  }
+  const double t_host0 = now_ms();
   // rows, bin by bin, models in the bin's own order
   hits->nbins = nbins;
   hits->bin_row_off.assign(nbins + 1, 0);
@@ -842,7 +911,7 @@ static void do_search(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, co
     }
   }
   hits->bin_row_off[nbins] = hits->seq.size();
-  st.ms_host = now_ms() - t_host0;
+  st.ms_host += now_ms() - t_host0;
   st.ms_total = now_ms() - t_start;
 }
 
@@ -917,10 +986,11 @@ extern "C" int ckm_hits_write_domtblout(const ckm_hits *h, const ckm_profiles *p
 }
 
 // ---- diagnostics -------------------------------------------------------------------------------------
-extern "C" int ckm_debug_stages(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, const uint32_t *model, const uint32_t *seq,
+extern "C" int ckm_debug_stages(ckm_ctx *ctx_, const ckm_profiles *p, const ckm_seqs *s, const uint32_t *model, const uint32_t *seq,
                                 uint32_t npairs, ckm_stage_scores *out) {
   return guarded([&] {
-    if (!ctx || !p || !s || !model || !seq || !out) throw Error(CKM_EINVAL, "NULL argument");
+    if (!ctx_ || !p || !s || !model || !seq || !out) throw Error(CKM_EINVAL, "NULL argument");
+    Worker *ctx = &ctx_->w[0];
     HIPCHK(hipSetDevice(ctx->device));
     const DevModel *dm = p->d_models.as<DevModel>();
     const LenEntry *lt = s->d_lentab.as<LenEntry>();
@@ -1003,10 +1073,11 @@ extern "C" int ckm_debug_stages(ckm_ctx *ctx, const ckm_profiles *p, const ckm_s
   });
 }
 
-extern "C" int ckm_debug_envelopes(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, const uint32_t *model, const uint32_t *seq,
+extern "C" int ckm_debug_envelopes(ckm_ctx *ctx_, const ckm_profiles *p, const ckm_seqs *s, const uint32_t *model, const uint32_t *seq,
                                    const int32_t *ienv, const int32_t *jenv, uint32_t n, ckm_envelope_result *out) {
   return guarded([&] {
-    if (!ctx || !p || !s || !model || !seq || !ienv || !jenv || !out) throw Error(CKM_EINVAL, "NULL argument");
+    if (!ctx_ || !p || !s || !model || !seq || !ienv || !jenv || !out) throw Error(CKM_EINVAL, "NULL argument");
+    Worker *ctx = &ctx_->w[0];
     HIPCHK(hipSetDevice(ctx->device));
     std::vector<EnvReq> req(n); std::vector<EnvRes> res;
     for (uint32_t i = 0; i < n; ++i) {

@@ -78,34 +78,38 @@ __global__ void bin_hist_kernel(uint32_t nbins, const uint32_t *__restrict__ set
   }
 }
 
-struct DevArr {
-  void *p = nullptr;
-  DevArr(size_t bytes) { if (hipMalloc(&p, std::max<size_t>(bytes, 16)) != hipSuccess) throw Error(CKM_ENOMEM, "hipMalloc failed in reduce"); }
-  ~DevArr() { if (p) (void)hipFree(p); }
-  template <class T> T *as() { return reinterpret_cast<T *>(p); }
-};
 
-static void run_count_sets(const ckm_marker_sets *ms, const int32_t *marker_count, const uint8_t *marker_first, int32_t *set_present,
+// all device arrays of one call live in ONE grow-only scratch buffer owned by the ctx (no per-call hipMalloc)
+}  // namespace ckm
+struct ckm_ctx;
+void *ckm_ctx_reduce_scratch(ckm_ctx *ctx, size_t bytes);
+namespace ckm {
+static void run_count_sets(ckm_ctx *ctx, const ckm_marker_sets *ms, const int32_t *marker_count, const uint8_t *marker_first, int32_t *set_present,
                            int32_t *set_multi, int32_t *hist, int32_t *present_total, int32_t *multi_total) {
   const uint32_t nbins = ms->nbins, nsets = ms->set_off[nbins], nmark = ms->marker_off[nsets];
-  DevArr d_setoff((size_t)(nbins + 1) * 4), d_moff((size_t)(nsets + 1) * 4), d_cnt((size_t)nmark * 4), d_first(nmark), d_pres((size_t)nsets * 4),
-      d_multi((size_t)nsets * 4), d_hist((size_t)nbins * 24), d_pt((size_t)nbins * 4), d_mt((size_t)nbins * 4);
-  HIPCHK(hipMemcpy(d_setoff.p, ms->set_off, (size_t)(nbins + 1) * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(d_moff.p, ms->marker_off, (size_t)(nsets + 1) * 4, hipMemcpyHostToDevice));
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_setoff = 0, o_moff = o_setoff + al((size_t)(nbins + 1) * 4), o_cnt = o_moff + al((size_t)(nsets + 1) * 4), o_first = o_cnt + al((size_t)nmark * 4),
+               o_pres = o_first + al(nmark), o_multi = o_pres + al((size_t)nsets * 4), o_hist = o_multi + al((size_t)nsets * 4), o_pt = o_hist + al((size_t)nbins * 24),
+               o_mt = o_pt + al((size_t)nbins * 4), total = o_mt + al((size_t)nbins * 4);
+  char *base = static_cast<char *>(::ckm_ctx_reduce_scratch(ctx, total + 256));
+  HIPCHK(hipMemcpyAsync(base + o_setoff, ms->set_off, (size_t)(nbins + 1) * 4, hipMemcpyHostToDevice, 0));
+  HIPCHK(hipMemcpyAsync(base + o_moff, ms->marker_off, (size_t)(nsets + 1) * 4, hipMemcpyHostToDevice, 0));
   if (nmark) {
-    HIPCHK(hipMemcpy(d_cnt.p, marker_count, (size_t)nmark * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_first.p, marker_first, nmark, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(base + o_cnt, marker_count, (size_t)nmark * 4, hipMemcpyHostToDevice, 0));
+    HIPCHK(hipMemcpyAsync(base + o_first, marker_first, nmark, hipMemcpyHostToDevice, 0));
   }
-  if (nsets) hipLaunchKernelGGL(count_sets_kernel, dim3((nsets + 255) / 256), dim3(256), 0, 0, nsets, d_moff.as<uint32_t>(), d_cnt.as<int32_t>(), d_pres.as<int32_t>(), d_multi.as<int32_t>());
-  if (nbins) hipLaunchKernelGGL(bin_hist_kernel, dim3((nbins + 3) / 4), dim3(256), 0, 0, nbins, d_setoff.as<uint32_t>(), d_moff.as<uint32_t>(), d_cnt.as<int32_t>(),
-                                d_first.as<uint8_t>(), d_hist.as<int32_t>(), d_pt.as<int32_t>(), d_mt.as<int32_t>());
+  if (nsets) hipLaunchKernelGGL(count_sets_kernel, dim3((nsets + 255) / 256), dim3(256), 0, 0, nsets, (const uint32_t *)(base + o_moff), (const int32_t *)(base + o_cnt),
+                                (int32_t *)(base + o_pres), (int32_t *)(base + o_multi));
+  if (nbins) hipLaunchKernelGGL(bin_hist_kernel, dim3((nbins + 3) / 4), dim3(256), 0, 0, nbins, (const uint32_t *)(base + o_setoff), (const uint32_t *)(base + o_moff),
+                                (const int32_t *)(base + o_cnt), (const uint8_t *)(base + o_first), (int32_t *)(base + o_hist), (int32_t *)(base + o_pt), (int32_t *)(base + o_mt));
   HIPCHK(hipGetLastError());
-  if (nsets) { HIPCHK(hipMemcpy(set_present, d_pres.p, (size_t)nsets * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(set_multi, d_multi.p, (size_t)nsets * 4, hipMemcpyDeviceToHost)); }
+  if (nsets) { HIPCHK(hipMemcpyAsync(set_present, base + o_pres, (size_t)nsets * 4, hipMemcpyDeviceToHost, 0)); HIPCHK(hipMemcpyAsync(set_multi, base + o_multi, (size_t)nsets * 4, hipMemcpyDeviceToHost, 0)); }
   if (nbins) {
-    HIPCHK(hipMemcpy(hist, d_hist.p, (size_t)nbins * 24, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(present_total, d_pt.p, (size_t)nbins * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(multi_total, d_mt.p, (size_t)nbins * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(hist, base + o_hist, (size_t)nbins * 24, hipMemcpyDeviceToHost, 0));
+    HIPCHK(hipMemcpyAsync(present_total, base + o_pt, (size_t)nbins * 4, hipMemcpyDeviceToHost, 0));
+    HIPCHK(hipMemcpyAsync(multi_total, base + o_mt, (size_t)nbins * 4, hipMemcpyDeviceToHost, 0));
   }
+  HIPCHK(hipStreamSynchronize(0));
 }
 
 // ---- host filters -----------------------------------------------------------------------------------
@@ -269,7 +273,7 @@ extern "C" int ckm_count_sets(ckm_ctx *ctx, const ckm_marker_sets *ms, const int
   return guarded_r([&] {
     if (!ctx || !ms || !marker_count || !marker_first || !set_present || !set_multi || !hist || !present_total || !multi_total) throw Error(CKM_EINVAL, "NULL argument");
     HIPCHK(hipSetDevice(ckm_ctx_device(ctx)));
-    run_count_sets(ms, marker_count, marker_first, set_present, set_multi, hist, present_total, multi_total);
+    run_count_sets(ctx, ms, marker_count, marker_first, set_present, set_multi, hist, present_total, multi_total);
   });
 }
 
@@ -344,7 +348,7 @@ extern "C" int ckm_reduce(ckm_ctx *ctx, const ckm_hits *h, const ckm_hit_columns
     qa->set_off.assign(ms->set_off, ms->set_off + nbins + 1);
     qa->set_present.assign(nsets, 0); qa->set_multi.assign(nsets, 0); qa->hist.assign((size_t)nbins * 6, 0);
     std::vector<int32_t> ptot(nbins, 0), mtot(nbins, 0);
-    run_count_sets(ms, marker_count.data(), marker_first.data(), qa->set_present.data(), qa->set_multi.data(), qa->hist.data(), ptot.data(), mtot.data());
+    run_count_sets(ctx, ms, marker_count.data(), marker_first.data(), qa->set_present.data(), qa->set_multi.data(), qa->hist.data(), ptot.data(), mtot.data());
     // ---- float64 division in the reference's accumulation order (markerSets.py:219-236) ----
     qa->comp.assign(nbins, 0.0); qa->cont.assign(nbins, 0.0);
     for (uint32_t b = 0; b < nbins; ++b) {
