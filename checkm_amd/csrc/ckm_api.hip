@@ -413,7 +413,8 @@ void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, b
   if (subset) for (uint32_t i : *subset) add(i); else for (uint32_t i = 0; i < n; ++i) add(i);
   struct Group { int Q; size_t blk0, nblk; };
   std::vector<uint32_t> items, blk_model; std::vector<Group> groups;
-  for (auto &kq : byQ) {
+  for (auto it = byQ.rbegin(); it != byQ.rend(); ++it) {      // heaviest register class first: its chain is the longest
+    auto &kq = *it;
     Group g{kq.first, blk_model.size(), 0};
     // longest items first inside a model so the four wavefronts of a block finish together
     for (auto &km : kq.second) {

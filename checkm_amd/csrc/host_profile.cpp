@@ -320,7 +320,9 @@ HostProfile configure_profile(const HostHMM &h) {
     p.scale_w = (float)(500.0 / kLn2);
     p.base_w = 12000;
     p.rwv.assign((size_t)NROWS * Mp, -32768);
-    for (int x = 0; x < KP; ++x) for (int k = 1; k <= M; ++k) p.rwv[(size_t)x * Mp + k - 1] = word_score(p.scale_w, msc[(size_t)x * (M + 1) + k]);
+    // device layout is q-major: cell c = lane*Q+q lives at q*64+lane, so a wave reads 64 consecutive words
+    const int VQ = p.vitQ;
+    for (int x = 0; x < KP; ++x) for (int k = 1; k <= M; ++k) { const int c = k - 1; p.rwv[(size_t)x * Mp + (c % VQ) * NL + c / VQ] = word_score(p.scale_w, msc[(size_t)x * (M + 1) + k]); }
     p.wtr.assign((size_t)8 * Mp, -32768);
     auto cap = [](int16_t v, int16_t mx) { return v <= mx ? v : mx; };
     for (int k = 1; k <= M; ++k) {
@@ -346,7 +348,8 @@ HostProfile configure_profile(const HostHMM &h) {
   {
     const int Mp = p.fbQ * NL;
     p.rf.assign((size_t)NROWS * Mp, 0.f);
-    for (int x = 0; x < KP; ++x) for (int k = 1; k <= M; ++k) p.rf[(size_t)x * Mp + k - 1] = expf(msc[(size_t)x * (M + 1) + k]);
+    const int FQ = p.fbQ;   // q-major, as above
+    for (int x = 0; x < KP; ++x) for (int k = 1; k <= M; ++k) { const int c = k - 1; p.rf[(size_t)x * Mp + (c % FQ) * NL + c / FQ] = expf(msc[(size_t)x * (M + 1) + k]); }
     p.ftr.assign((size_t)8 * Mp, 0.f);
     for (int k = 1; k <= M; ++k) {
       const int i = k - 1;

@@ -122,22 +122,22 @@ __global__ void __launch_bounds__(256) fwd_kernel(const FbWork *__restrict__ wor
   if (lane == 0) { xs[0] = 0.f; xs[1] = xN; xs[2] = 0.f; xs[3] = xB; xs[4] = 0.f; xs[5] = 1.0f; }
   if (mx) {
 #pragma unroll
-    for (int q = 0; q < Q; ++q) { mx[lane * Q + q] = 0.f; mx[Mp + lane * Q + q] = 0.f; mx[2 * Mp + lane * Q + q] = 0.f; }
+    for (int q = 0; q < Q; ++q) { mx[q * 64 + lane] = 0.f; mx[Mp + q * 64 + lane] = 0.f; mx[2 * Mp + q * 64 + lane] = 0.f; }
   }
   // emission odds of the next row are fetched one row ahead (residue byte -> table row is a dependent pair of loads)
   float rfc[Q];
   {
-    const float *__restrict__ r0 = md.rf + (size_t)rp[0] * Mp + lane * Q;
+    const float *__restrict__ r0 = md.rf + (size_t)rp[0] * Mp + lane;
 #pragma unroll
-    for (int q = 0; q < Q; ++q) rfc[q] = r0[q];
+    for (int q = 0; q < Q; ++q) rfc[q] = r0[q * 64];
   }
   for (int i = 1; i <= w.Ld; ++i) {
     float rfn[Q];
     {
       const int xn = (i < w.Ld) ? rp[i] : rp[i - 1];
-      const float *__restrict__ r1 = md.rf + (size_t)xn * Mp + lane * Q;
+      const float *__restrict__ r1 = md.rf + (size_t)xn * Mp + lane;
 #pragma unroll
-      for (int q = 0; q < Q; ++q) rfn[q] = r1[q];
+      for (int q = 0; q < Q; ++q) rfn[q] = r1[q * 64];
     }
     xE = fwd_row<Q>(Mv, Iv, Dv, tr, rfc, xB, lane);
 #pragma unroll
@@ -160,9 +160,9 @@ __global__ void __launch_bounds__(256) fwd_kernel(const FbWork *__restrict__ wor
     }
     if (lane == 0) { float *r = xs + (size_t)i * 6; r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; r[5] = scale; }
     if (mx) {
-      float *r = mx + (size_t)i * 3 * Mp + lane * Q;
+      float *r = mx + (size_t)i * 3 * Mp + lane;
 #pragma unroll
-      for (int q = 0; q < Q; ++q) { r[q] = Mv[q]; r[Mp + q] = Iv[q]; r[2 * Mp + q] = Dv[q]; }
+      for (int q = 0; q < Q; ++q) { r[q * 64] = Mv[q]; r[Mp + q * 64] = Iv[q]; r[2 * Mp + q * 64] = Dv[q]; }
     }
   }
   if (lane == 0) { out[w.slot].xC = xC; out[w.slot].nscale = nscale; }
@@ -239,9 +239,9 @@ __global__ void __launch_bounds__(256) bwd_kernel(const FbWork *__restrict__ wor
   float fMr[Q], fIr[Q];
   auto fetch_f = [&](int r) {
     if (w.full && r >= 1) {
-      const float *__restrict__ f = fm + (size_t)r * 3 * Mp + lane * Q;
+      const float *__restrict__ f = fm + (size_t)r * 3 * Mp + lane;
 #pragma unroll
-      for (int q = 0; q < Q; ++q) { fMr[q] = f[q]; fIr[q] = f[Mp + q]; }
+      for (int q = 0; q < Q; ++q) { fMr[q] = f[q * 64]; fIr[q] = f[Mp + q * 64]; }
     }
   };
   fetch_f(L);
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256) bwd_kernel(const FbWork *__restrict__ wor
     // decoding terms that become available once backward row r is final
     if (w.full) {
       if (r >= 1) {
-        float *__restrict__ b = bm + (size_t)r * 3 * Mp + lane * Q;
+        float *__restrict__ b = bm + (size_t)r * 3 * Mp + lane;
         float pmv[Q], piv[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(256) bwd_kernel(const FbWork *__restrict__ wor
         }
         fetch_f(r - 1);
 #pragma unroll
-        for (int q = 0; q < Q; ++q) { b[q] = pmv[q]; b[Mp + q] = piv[q]; b[2 * Mp + q] = 0.f; }
+        for (int q = 0; q < Q; ++q) { b[q * 64] = pmv[q]; b[Mp + q * 64] = piv[q]; b[2 * Mp + q * 64] = 0.f; }
         if (lane == 0) {
           const float wgt = invZ / xs[(size_t)r * 6 + 5];
           float t;
@@ -285,17 +285,17 @@ __global__ void __launch_bounds__(256) bwd_kernel(const FbWork *__restrict__ wor
   emit(L);
   float rfc[Q];
   if (L >= 1) {
-    const float *__restrict__ r0 = md.rf + (size_t)rp[L - 1] * Mp + lane * Q;    // residue L
+    const float *__restrict__ r0 = md.rf + (size_t)rp[L - 1] * Mp + lane;    // residue L
 #pragma unroll
-    for (int q = 0; q < Q; ++q) rfc[q] = r0[q];
+    for (int q = 0; q < Q; ++q) rfc[q] = r0[q * 64];
   }
   for (int i = L - 1; i >= 0; --i) {
     float rfn[Q];                                                     // residue i, needed by the next iteration
     {
       const int xn = (i >= 1) ? rp[i - 1] : rp[0];
-      const float *__restrict__ r1 = md.rf + (size_t)xn * Mp + lane * Q;
+      const float *__restrict__ r1 = md.rf + (size_t)xn * Mp + lane;
 #pragma unroll
-      for (int q = 0; q < Q; ++q) rfn[q] = r1[q];
+      for (int q = 0; q < Q; ++q) rfn[q] = r1[q * 64];
     }
     float mn[Q];
 #pragma unroll
@@ -373,9 +373,9 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
     for (int q = 0; q < Q; ++q) me[q] = ie[q] = 0.f;
     float xN = 0.f, xJ = 0.f, xC = 0.f;
     for (int i = 1; i <= L; ++i) {
-      const float *r = pp + (size_t)i * 3 * Mp + c0;
+      const float *r = pp + (size_t)i * 3 * Mp + lane;
 #pragma unroll
-      for (int q = 0; q < Q; ++q) { me[q] = me[q] + r[q]; ie[q] = ie[q] + r[Mp + q]; }
+      for (int q = 0; q < Q; ++q) { me[q] = me[q] + r[q * 64]; ie[q] = ie[q] + r[Mp + q * 64]; }
       xN = xN + aux[(size_t)i * 3 + 0]; xJ = xJ + aux[(size_t)i * 3 + 1]; xC = xC + aux[(size_t)i * 3 + 2];
     }
     const float norm = 1.0f / (float)L;
@@ -383,10 +383,10 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
     for (int q = 0; q < Q; ++q) { me[q] *= norm; ie[q] *= norm; }
     const float xfactor = ((xN + xC) + xJ) * norm;
     for (int x = 0; x < 20; ++x) {
-      const float *rfx = md.rf + (size_t)x * Mp + c0;
+      const float *rfx = md.rf + (size_t)x * Mp + lane;
       float s = 0.f;
 #pragma unroll
-      for (int q = 0; q < Q; ++q) { const float t = me[q] * rfx[q]; s = s + t; s = s + ie[q]; }
+      for (int q = 0; q < Q; ++q) { const float t = me[q] * rfx[q * 64]; s = s + t; s = s + ie[q]; }
       s = wave_sum(s);
       if (lane == 0) out[w.slot].null2[x] = s + xfactor;
     }
@@ -403,22 +403,22 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
   }
   float Mv[Q], Iv[Q], Dv[Q];
 #pragma unroll
-  for (int q = 0; q < Q; ++q) { Mv[q] = Iv[q] = Dv[q] = NEGINF_F; oa[c0 + q] = NEGINF_F; oa[Mp + c0 + q] = NEGINF_F; oa[2 * Mp + c0 + q] = NEGINF_F; }
+  for (int q = 0; q < Q; ++q) { Mv[q] = Iv[q] = Dv[q] = NEGINF_F; oa[q * 64 + lane] = NEGINF_F; oa[Mp + q * 64 + lane] = NEGINF_F; oa[2 * Mp + q * 64 + lane] = NEGINF_F; }
   float oN = 0.f, oB = 0.f, oE = NEGINF_F, oJ = NEGINF_F, oC = NEGINF_F;
   if (lane == 0) { oax[0] = oN; oax[1] = oB; oax[2] = oE; oax[3] = oJ; oax[4] = oC; }
   float ppM[Q], ppI[Q];
   if (L >= 1) {
-    const float *__restrict__ p1 = pp + (size_t)1 * 3 * Mp + c0;
+    const float *__restrict__ p1 = pp + (size_t)1 * 3 * Mp + lane;
 #pragma unroll
-    for (int q = 0; q < Q; ++q) { ppM[q] = p1[q]; ppI[q] = p1[Mp + q]; }
+    for (int q = 0; q < Q; ++q) { ppM[q] = p1[q * 64]; ppI[q] = p1[Mp + q * 64]; }
   }
   for (int i = 1; i <= L; ++i) {
     // posterior row i is in registers; row i+1 is requested now, before this row's stores
     float ppMn[Q], ppIn[Q];
     {
-      const float *__restrict__ pn = pp + (size_t)((i < L) ? i + 1 : i) * 3 * Mp + c0;
+      const float *__restrict__ pn = pp + (size_t)((i < L) ? i + 1 : i) * 3 * Mp + lane;
 #pragma unroll
-      for (int q = 0; q < Q; ++q) { ppMn[q] = pn[q]; ppIn[q] = pn[Mp + q]; }
+      for (int q = 0; q < Q; ++q) { ppMn[q] = pn[q * 64]; ppIn[q] = pn[Mp + q * 64]; }
     }
     float mpi = __shfl_up(Mv[Q - 1], 1), ipi = __shfl_up(Iv[Q - 1], 1), dpi = __shfl_up(Dv[Q - 1], 1);
     float Mn[Q], In[Q], Dn[Q];
@@ -482,9 +482,9 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
     { const float a = oC + aux[(size_t)i * 3 + 2]; oC = a > e ? a : e; }
     oN = oN + aux[(size_t)i * 3 + 0];
     oB = oN > oJ ? oN : oJ;
-    float *__restrict__ r = oa + (size_t)i * 3 * Mp + c0;
+    float *__restrict__ r = oa + (size_t)i * 3 * Mp + lane;
 #pragma unroll
-    for (int q = 0; q < Q; ++q) { Mv[q] = Mn[q]; Iv[q] = In[q]; Dv[q] = Dn[q]; r[q] = Mn[q]; r[Mp + q] = In[q]; r[2 * Mp + q] = Dn[q]; ppM[q] = ppMn[q]; ppI[q] = ppIn[q]; }
+    for (int q = 0; q < Q; ++q) { Mv[q] = Mn[q]; Iv[q] = In[q]; Dv[q] = Dn[q]; r[q * 64] = Mn[q]; r[Mp + q * 64] = In[q]; r[2 * Mp + q * 64] = Dn[q]; ppM[q] = ppMn[q]; ppI[q] = ppIn[q]; }
     if (lane == 0) { float *a = oax + (size_t)i * 5; a[0] = oN; a[1] = oB; a[2] = oE; a[3] = oJ; a[4] = oC; }
   }
   __threadfence();
@@ -513,14 +513,14 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
       const float e = LD2(&oax[(size_t)i * 5 + 2]);
       int best = Mp;
 #pragma unroll
-      for (int q = Q - 1; q >= 0; --q) { const int c = c0 + q; if (c < M && LD2(&cr[c]) == e) best = c; }
+      for (int q = Q - 1; q >= 0; --q) { const int c = c0 + q; if (c < M && LD2(&cr[q * 64 + lane]) == e) best = c; }
 #pragma unroll
       for (int s = 32; s >= 1; s >>= 1) best = min(best, __shfl_xor(best, s));
       if (best >= Mp) done = true; else { k = best; st = 2; li = i; lk = k + 1; }
     } else if (st == 2) {
       fi = i; fk = k + 1;
       float p0 = NEGINF_F, p1 = NEGINF_F, p2 = NEGINF_F, p3 = NEGINF_F;
-      if (k > 0) { if (tMM_(k) > 0.f) p0 = LD2(&pr[k - 1]); if (tIM_(k) > 0.f) p1 = LD2(&pr[Mp + k - 1]); if (tDM_(k) > 0.f) p2 = LD2(&pr[2 * Mp + k - 1]); }
+      if (k > 0) { if (tMM_(k) > 0.f) p0 = LD2(&pr[lds_cell<Q>(k - 1)]); if (tIM_(k) > 0.f) p1 = LD2(&pr[Mp + lds_cell<Q>(k - 1)]); if (tDM_(k) > 0.f) p2 = LD2(&pr[2 * Mp + lds_cell<Q>(k - 1)]); }
       if (tBM_(k) > 0.f) p3 = LD2(&oax[(size_t)(i - 1) * 5 + 1]);
       int best = 0; float bv = p0;
       if (p1 > bv) { bv = p1; best = 1; }
@@ -529,10 +529,10 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
       --i;
       if (best == 0) { --k; st = 2; } else if (best == 1) { --k; st = 3; } else if (best == 2) { --k; st = 4; } else done = true;
     } else if (st == 3) {
-      const float a = (tMI_(k) > 0.f) ? LD2(&pr[k]) : NEGINF_F, b = (tII_(k) > 0.f) ? LD2(&pr[Mp + k]) : NEGINF_F;
+      const float a = (tMI_(k) > 0.f) ? LD2(&pr[lds_cell<Q>(k)]) : NEGINF_F, b = (tII_(k) > 0.f) ? LD2(&pr[Mp + lds_cell<Q>(k)]) : NEGINF_F;
       --i; st = (a >= b) ? 2 : 3;
     } else {
-      const float a = (tMD_(k - 1) > 0.f) ? LD2(&cr[k - 1]) : NEGINF_F, b = (tDD_(k - 1) > 0.f) ? LD2(&cr[2 * Mp + k - 1]) : NEGINF_F;
+      const float a = (tMD_(k - 1) > 0.f) ? LD2(&cr[lds_cell<Q>(k - 1)]) : NEGINF_F, b = (tDD_(k - 1) > 0.f) ? LD2(&cr[2 * Mp + lds_cell<Q>(k - 1)]) : NEGINF_F;
       --k; st = (a >= b) ? 2 : 4;
     }
   }

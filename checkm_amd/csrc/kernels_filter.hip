@@ -191,17 +191,17 @@ __global__ void __launch_bounds__(256) vit_kernel(const PairRec *__restrict__ pa
   // emission words are fetched one row ahead, the residue byte two rows ahead (dependent loads)
   int e[Q];
   {
-    const int16_t *__restrict__ er = md.rwv + (size_t)rp[0] * Mp + c0;
+    const int16_t *__restrict__ er = md.rwv + (size_t)rp[0] * Mp + lane;
 #pragma unroll
-    for (int q = 0; q < Q; ++q) e[q] = er[q];
+    for (int q = 0; q < Q; ++q) e[q] = er[q * 64];
   }
   int xn = (L > 1) ? rp[1] : rp[0];
   for (int i = 0; i < L; ++i) {
     int en[Q];
     {
-      const int16_t *__restrict__ er = md.rwv + (size_t)xn * Mp + c0;
+      const int16_t *__restrict__ er = md.rwv + (size_t)xn * Mp + lane;
 #pragma unroll
-      for (int q = 0; q < Q; ++q) en[q] = er[q];
+      for (int q = 0; q < Q; ++q) en[q] = er[q * 64];
     }
     xn = (i + 2 < L) ? rp[i + 2] : rp[L - 1];
     int mpi = __shfl_up(Mv[Q - 1], 1), ipi = __shfl_up(Iv[Q - 1], 1), dpi = __shfl_up(Dv[Q - 1], 1);
