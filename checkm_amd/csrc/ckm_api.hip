@@ -221,15 +221,15 @@ extern "C" int ckm_profiles_load(ckm_ctx *ctx, const char *hmm_path, ckm_profile
       const HostProfile &hp = p->prof.back();
       DevModel d;
       memset(&d, 0, sizeof(d));
-      d.M = hp.M; d.ssvQ = hp.ssvQ; d.fbQ = hp.fbQ;
+      d.M = hp.M; d.ssvQ = hp.ssvQ; d.fbQ = hp.fbQ; d.vitQH = hp.vitQH;
       d.base_b = hp.base_b; d.bias_b = hp.bias_b; d.tbm_b = hp.tbm_b; d.tec_b = hp.tec_b; d.scale_b = hp.scale_b;
       d.scale_w = hp.scale_w; d.base_w = hp.base_w; d.wE_loop = hp.wE_loop; d.wE_move = hp.wE_move;
       d.fE_loop = hp.fE_loop; d.fE_move = hp.fE_move;
       d.bt00 = hp.bt00; d.bt01 = hp.bt01; d.bt10 = hp.bt10; d.bt11 = hp.bt11; d.bpi0 = hp.bpi0; d.bpi1 = hp.bpi1;
       for (int x = 0; x < NROWS; ++x) d.beo1[x] = hp.beo1[x];
       d.thr_msv_f1 = hp.thr_msv_f1; d.thr_msv_f2 = hp.thr_msv_f2; d.thr_vit_f2 = hp.thr_vit_f2; d.thr_fwd_f3 = hp.thr_fwd_f3;
-      d.ssv_tbl = upload(p.get(), hp.ssv_tbl); d.rbv = upload(p.get(), hp.rbv); d.rwv = upload(p.get(), hp.rwv);
-      d.wtr = upload(p.get(), hp.wtr); d.wddc = upload(p.get(), hp.wddc); d.rf = upload(p.get(), hp.rf); d.ftr = upload(p.get(), hp.ftr);
+      d.ssv_tbl = upload(p.get(), hp.ssv_tbl); d.rbv = upload(p.get(), hp.rbv); d.vit_e = upload(p.get(), hp.vit_e);
+      d.vit_t = upload(p.get(), hp.vit_t); d.rf = upload(p.get(), hp.rf); d.ftr = upload(p.get(), hp.ftr);
       p->dm.push_back(d);
       p->maxMp = std::max(p->maxMp, hp.fbQ * NL);
     }
@@ -670,7 +670,7 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
   // ---- stage 3: Viterbi filter ----
   {
     std::map<int, std::vector<uint32_t>> byQ;
-    for (size_t i = 0; i < cands.size(); ++i) if (cands[i].alive && need_vit[i]) byQ[p->prof[cands[i].r.model].vitQ].push_back((uint32_t)i);
+    for (size_t i = 0; i < cands.size(); ++i) if (cands[i].alive && need_vit[i]) byQ[p->prof[cands[i].r.model].vitQH].push_back((uint32_t)i);
     std::vector<uint32_t> flat; std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;
     for (auto &kv : byQ) { groups.push_back({kv.first, {flat.size(), kv.second.size()}}); flat.insert(flat.end(), kv.second.begin(), kv.second.end()); }
     st.pairs_vit = flat.size();
@@ -1032,7 +1032,7 @@ extern "C" int ckm_debug_stages(ckm_ctx *ctx_, const ckm_profiles *p, const ckm_
     HIPCHK(hipMemcpyAsync(raw.data(), ctx->raw.p, npairs * 12, hipMemcpyDeviceToHost, ctx->stream));
     // Viterbi on every pair
     std::map<int, std::vector<uint32_t>> vq;
-    for (uint32_t i = 0; i < npairs; ++i) vq[p->prof[model[i]].vitQ].push_back(i);
+    for (uint32_t i = 0; i < npairs; ++i) vq[p->prof[model[i]].vitQH].push_back(i);
     std::vector<uint32_t> flat; std::vector<std::pair<int, std::pair<size_t, size_t>>> vg;
     for (auto &kv : vq) { vg.push_back({kv.first, {flat.size(), kv.second.size()}}); flat.insert(flat.end(), kv.second.begin(), kv.second.end()); }
     ctx->fbidx.ensure(npairs * 4); ctx->vitx.ensure(npairs * 4); ctx->vits.ensure(npairs * 4);

@@ -48,11 +48,10 @@ struct HostProfile {
   int ssvQ = 0;                   // packed i16x2 registers per lane (16 lanes per sequence): ceil(M/32) rounded to an instantiated size
   std::vector<int16_t> ssv_tbl;   // LDS image: [NROWS][ssvQg][16 lanes][4 regs][2 halves]
   // Viterbi filter (signed words, 1/500 bit); contiguous k, padded to vitQ*64
-  int vitQ = 0;
+  int vitQH = 0;                  // packed registers per lane: lane z owns cells z*2QH.., register j = (cell j, cell j+QH)
   float scale_w = 0; int base_w = 12000; int wE_loop = 0, wE_move = 0;
-  std::vector<int16_t> rwv;       // [NROWS][Mp]
-  std::vector<int16_t> wtr;       // [8][Mp]: BM MM IM DM (into k) MD MI II (from k) ; [7] unused
-  std::vector<int32_t> wddc;      // [Mp+1] prefix sums of DD (C(k)), see kernels
+  std::vector<uint32_t> vit_e;    // [NROWS][vitQH][64]
+  std::vector<uint32_t> vit_t;    // [8][vitQH][64]: BM MM IM DM (into k) MD MI II DD (from k)
   // Forward/Backward odds, canonical padded layout (fbQ*64)
   int fbQ = 0;
   std::vector<float> rf;          // [NROWS][Mp]
@@ -68,6 +67,7 @@ struct HostProfile {
 HostProfile configure_profile(const HostHMM &h);
 int  canon_Q(int M);         // canonical lanes-blocked Q for the float DP
 int  ssv_Q_for(int M);       // instantiated SSV register count covering M
+int  vit_QH_for(int M);      // instantiated Viterbi packed-register count covering M
 
 // length-dependent specials (all host libm, shared by every stage)
 struct LenCfg { float loop, move; int w_move; int tjb_b; float nullsc; float p1; float bias_tail; };

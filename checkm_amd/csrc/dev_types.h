@@ -5,7 +5,7 @@
 namespace ckm {
 
 struct DevModel {
-  int32_t M, ssvQ, fbQ, pad0;
+  int32_t M, ssvQ, fbQ, vitQH;
   // MSV
   int32_t base_b, bias_b, tbm_b, tec_b;
   float   scale_b;
@@ -21,9 +21,8 @@ struct DevModel {
   // tables in HBM
   const int16_t *ssv_tbl;   // [30][Qg][16][8]
   const uint8_t *rbv;       // [29][M+1]
-  const int16_t *rwv;       // [30][Mp]
-  const int16_t *wtr;       // [8][Mp]
-  const int32_t *wddc;      // [Mp+1]
+  const uint32_t *vit_e;    // [30][vitQH][64] packed emission words (cell j | cell j+QH of each lane)
+  const uint32_t *vit_t;    // [8][vitQH][64]  packed transition words: BM MM IM DM (into) MD MI II DD (from)
   const float   *rf;        // [30][Mp]
   const float   *ftr;       // [8][Mp]
 };

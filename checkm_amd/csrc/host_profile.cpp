@@ -217,6 +217,11 @@ int canon_Q(int M) {
   for (int q : kCanonQ) if (q * NL >= M) return q;
   return -1;
 }
+static const int kVitQH[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16};
+int vit_QH_for(int M) {
+  for (int q : kVitQH) if (q * 128 >= M) return q;
+  return -1;
+}
 static const int kSsvQ[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 48, 56, 64};
 int ssv_Q_for(int M) {
   for (int q : kSsvQ) if (q * 32 >= M) return q;
@@ -256,9 +261,9 @@ HostProfile configure_profile(const HostHMM &h) {
   HostProfile p;
   p.M = M;
   p.fbQ = canon_Q(M);
-  p.vitQ = p.fbQ;
+  p.vitQH = vit_QH_for(M);
   p.ssvQ = ssv_Q_for(M);
-  if (p.fbQ < 0 || p.ssvQ < 0) throw Error(CKM_ERANGE, "model " + h.name + ": LENG " + std::to_string(M) + " exceeds the supported maximum of 2048");
+  if (p.fbQ < 0 || p.ssvQ < 0 || p.vitQH < 0) throw Error(CKM_ERANGE, "model " + h.name + ": LENG " + std::to_string(M) + " exceeds the supported maximum of 2048");
   const float NEG = -INFINITY;
   // generic log-odds: transitions indexed by source node 0..M-1; entry B->M_k stored at k-1
   std::vector<float> gBM(M + 1, NEG), gMM(M + 1, NEG), gIM(M + 1, NEG), gDM(M + 1, NEG), gMD(M + 1, NEG), gDD(M + 1, NEG), gMI(M + 1, NEG), gII(M + 1, NEG);
@@ -316,31 +321,37 @@ HostProfile configure_profile(const HostHMM &h) {
   }
   // ---- Viterbi filter ----
   {
-    const int Mp = p.vitQ * NL;
+    const int QH = p.vitQH, CELLS = 2 * QH;              // cells per lane
     p.scale_w = (float)(500.0 / kLn2);
     p.base_w = 12000;
-    p.rwv.assign((size_t)NROWS * Mp, -32768);
-    // device layout is q-major: cell c = lane*Q+q lives at q*64+lane, so a wave reads 64 consecutive words
-    const int VQ = p.vitQ;
-    for (int x = 0; x < KP; ++x) for (int k = 1; k <= M; ++k) { const int c = k - 1; p.rwv[(size_t)x * Mp + (c % VQ) * NL + c / VQ] = word_score(p.scale_w, msc[(size_t)x * (M + 1) + k]); }
-    p.wtr.assign((size_t)8 * Mp, -32768);
     auto cap = [](int16_t v, int16_t mx) { return v <= mx ? v : mx; };
-    for (int k = 1; k <= M; ++k) {
-      const int i = k - 1;
-      p.wtr[0 * Mp + i] = cap(word_score(p.scale_w, gBM[k - 1]), 0);
-      p.wtr[1 * Mp + i] = cap(word_score(p.scale_w, gMM[k - 1]), 0);
-      p.wtr[2 * Mp + i] = cap(word_score(p.scale_w, gIM[k - 1]), 0);
-      p.wtr[3 * Mp + i] = cap(word_score(p.scale_w, gDM[k - 1]), 0);
-      if (k < M) {
-        p.wtr[4 * Mp + i] = cap(word_score(p.scale_w, gMD[k]), 0);
-        p.wtr[5 * Mp + i] = cap(word_score(p.scale_w, gMI[k]), 0);
-        p.wtr[6 * Mp + i] = cap(word_score(p.scale_w, gII[k]), -1);
-        p.wtr[7 * Mp + i] = word_score(p.scale_w, gDD[k]);
+    // word of cell c (node c+1) in table `which`; out-of-model cells are -32768 (= -inf)
+    auto emis = [&](int x, int c) -> int16_t { return (c < M) ? word_score(p.scale_w, msc[(size_t)x * (M + 1) + c + 1]) : (int16_t)-32768; };
+    auto trans = [&](int which, int c) -> int16_t {
+      const int k = c + 1;
+      if (k > M) return -32768;
+      switch (which) {
+        case 0: return cap(word_score(p.scale_w, gBM[k - 1]), 0);
+        case 1: return cap(word_score(p.scale_w, gMM[k - 1]), 0);
+        case 2: return cap(word_score(p.scale_w, gIM[k - 1]), 0);
+        case 3: return cap(word_score(p.scale_w, gDM[k - 1]), 0);
+        case 4: return (k < M) ? cap(word_score(p.scale_w, gMD[k]), 0) : (int16_t)-32768;
+        case 5: return (k < M) ? cap(word_score(p.scale_w, gMI[k]), 0) : (int16_t)-32768;
+        case 6: return (k < M) ? cap(word_score(p.scale_w, gII[k]), -1) : (int16_t)-32768;
+        default: return (k < M) ? word_score(p.scale_w, gDD[k]) : (int16_t)-32768;
       }
-    }
-    // C[i] = sum of DD words of cells 0..i-1 (cell i = node i+1): D(node k) = max(floor, C[k-1] + max_{j<k}(md(j) - C[j]))
-    p.wddc.assign((size_t)Mp + 1, 0);
-    for (int i = 0; i < Mp; ++i) p.wddc[i + 1] = p.wddc[i] + (int32_t)p.wtr[7 * Mp + i];
+    };
+    auto pack = [](int16_t lo, int16_t hi) { return (uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16); };
+    p.vit_e.assign((size_t)NROWS * QH * NL, pack(-32768, -32768));
+    for (int x = 0; x < KP; ++x)
+      for (int j = 0; j < QH; ++j)
+        for (int z = 0; z < NL; ++z)
+          p.vit_e[((size_t)x * QH + j) * NL + z] = pack(emis(x, z * CELLS + j), emis(x, z * CELLS + j + QH));
+    p.vit_t.assign((size_t)8 * QH * NL, pack(-32768, -32768));
+    for (int w = 0; w < 8; ++w)
+      for (int j = 0; j < QH; ++j)
+        for (int z = 0; z < NL; ++z)
+          p.vit_t[((size_t)w * QH + j) * NL + z] = pack(trans(w, z * CELLS + j), trans(w, z * CELLS + j + QH));
     p.wE_loop = word_score(p.scale_w, (float)(-kLn2));
     p.wE_move = word_score(p.scale_w, (float)(-kLn2));
   }

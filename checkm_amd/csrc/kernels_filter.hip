@@ -2,7 +2,7 @@
 //   msv_finish_kernel  turns SSV maxV into the MSV byte score, applies F1, appends survivors
 //   msv_full_kernel    full multi-hit MSV for the rare pairs whose J state could be used
 //   bias_kernel        2-state composition filter (Forward, power-of-two rescaling), F1 again, F2 shortcut
-//   vit_kernel<Q>      16-bit Viterbi filter, one wavefront per pair, D->D by integer prefix-max scan
+//   vit_kernel<QH>     16-bit Viterbi filter, one wavefront per pair, packed words, lazy-F D->D passes
 // Reference stage being replaced: the MSV -> bias -> Viterbi part of hmmsearch's per-target pipeline
 // (process launched at checkm/hmmer.py:70 with the options of checkm/markerGeneFinder.py:141).
 // Every decision is taken on IEEE basic operations only (no device libm), so it is bit-identical
@@ -154,11 +154,27 @@ __global__ void bias_kernel(PairRec *__restrict__ pairs, uint32_t npairs, const 
 }
 
 // --------------------------------------------------------------------------------------------
-// Viterbi filter: one wavefront per pair; lane z owns cells c = z*Q+q (node k = c+1)
+// Viterbi filter: one wavefront per pair, packed 2 x i16 saturating arithmetic (v_pk_add_i16 clamp,
+// v_pk_max_i16) -- the same word arithmetic HMMER's striped filter performs, so results are
+// identical whatever the layout.  Lane z owns the 2*QH consecutive cells z*2QH .. z*2QH+2QH-1;
+// register j packs (cell j, cell j+QH) of the lane, i.e. the wave holds 128 stripes of QH cells
+// (lane z low half = stripe 2z, high half = stripe 2z+1).  The move (i-1,k-1)->(i,k) is a register
+// rename plus ONE wave_shr:1 DPP + alignbit per state array.  D->D: one in-stripe pass, then
+// "lazy-F" passes that carry stripe ends forward until no D cell improves (exact: max / saturating
+// add with non-positive addends).
 // --------------------------------------------------------------------------------------------
-__device__ __forceinline__ int sat_lo(int v) { return max(v, NEG16); }
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32;
+__device__ __forceinline__ u32 pk_adds(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ u32 pk_max(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+constexpr u32 NEG2 = 0x80008000u;     // two -32768 words
+// value of the previous stripe: low half <- previous lane's high half, high half <- own low half
+__device__ __forceinline__ u32 stripe_shift(u32 v) {
+  const u32 up = (u32)__builtin_amdgcn_update_dpp((int)NEG2, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+  return __builtin_amdgcn_alignbit(v, up, 16);
+}
 
-template <int Q>
+template <int QH>
 __global__ void __launch_bounds__(256) vit_kernel(const PairRec *__restrict__ pairs, const uint32_t *__restrict__ idx, uint32_t n,
                                                   const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
                                                   const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
@@ -169,71 +185,70 @@ __global__ void __launch_bounds__(256) vit_kernel(const PairRec *__restrict__ pa
   const uint32_t pi = idx[wi];
   const PairRec pr = pairs[pi];
   const DevModel &md = models[pr.model];
-  constexpr int Mp = Q * 64;
+  constexpr int ROW = QH * 64;                      // u32 words per table row
   const int L = seq_len[pr.seq];
   const uint8_t *rp = res + seq_off[pr.seq];
   const LenEntry le = lentab[L];
-  const int c0 = lane * Q;
-  int tBM[Q], tMM[Q], tIM[Q], tDM[Q], tMD[Q], tMI[Q], tII[Q], Cc[Q], Cn[Q];
+  u32 tBM[QH], tMM[QH], tIM[QH], tDM[QH], tMD[QH], tMI[QH], tII[QH], tDD[QH];
 #pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    const int c = c0 + q;
-    tBM[q] = md.wtr[0 * Mp + c]; tMM[q] = md.wtr[1 * Mp + c]; tIM[q] = md.wtr[2 * Mp + c]; tDM[q] = md.wtr[3 * Mp + c];
-    tMD[q] = md.wtr[4 * Mp + c]; tMI[q] = md.wtr[5 * Mp + c]; tII[q] = md.wtr[6 * Mp + c];
-    Cc[q] = md.wddc[c]; Cn[q] = md.wddc[c + 1];
+  for (int j = 0; j < QH; ++j) {
+    const u32 *t = md.vit_t + j * 64 + lane;
+    tBM[j] = t[0 * ROW]; tMM[j] = t[1 * ROW]; tIM[j] = t[2 * ROW]; tDM[j] = t[3 * ROW];
+    tMD[j] = t[4 * ROW]; tMI[j] = t[5 * ROW]; tII[j] = t[6 * ROW]; tDD[j] = t[7 * ROW];
   }
-  int Mv[Q], Iv[Q], Dv[Q];
+  u32 Mv[QH], Iv[QH], Dv[QH];
 #pragma unroll
-  for (int q = 0; q < Q; ++q) Mv[q] = Iv[q] = Dv[q] = NEG16;
+  for (int j = 0; j < QH; ++j) Mv[j] = Iv[j] = Dv[j] = NEG2;
   int xN = md.base_w, xB = xN + le.w_move, xJ = NEG16, xC = NEG16;
   bool overflow = false;
-  constexpr int NEGBIG = -(1 << 30);
-  // emission words are fetched one row ahead, the residue byte two rows ahead (dependent loads)
-  int e[Q];
+  // emission words one row ahead, residue byte two rows ahead (dependent loads)
+  u32 e[QH];
   {
-    const int16_t *__restrict__ er = md.rwv + (size_t)rp[0] * Mp + lane;
+    const u32 *__restrict__ er = md.vit_e + (size_t)rp[0] * ROW + lane;
 #pragma unroll
-    for (int q = 0; q < Q; ++q) e[q] = er[q * 64];
+    for (int j = 0; j < QH; ++j) e[j] = er[j * 64];
   }
   int xn = (L > 1) ? rp[1] : rp[0];
   for (int i = 0; i < L; ++i) {
-    int en[Q];
+    u32 en[QH];
     {
-      const int16_t *__restrict__ er = md.rwv + (size_t)xn * Mp + lane;
+      const u32 *__restrict__ er = md.vit_e + (size_t)xn * ROW + lane;
 #pragma unroll
-      for (int q = 0; q < Q; ++q) en[q] = er[q * 64];
+      for (int j = 0; j < QH; ++j) en[j] = er[j * 64];
     }
     xn = (i + 2 < L) ? rp[i + 2] : rp[L - 1];
-    int mpi = __shfl_up(Mv[Q - 1], 1), ipi = __shfl_up(Iv[Q - 1], 1), dpi = __shfl_up(Dv[Q - 1], 1);
-    if (lane == 0) { mpi = NEG16; ipi = NEG16; dpi = NEG16; }
-    int xE = NEG16;
+    const u32 ms0 = stripe_shift(Mv[QH - 1]), is0 = stripe_shift(Iv[QH - 1]), ds0 = stripe_shift(Dv[QH - 1]);
+    const u32 xBv = ((u32)(xB & 0xffff)) * 0x10001u;
+    u32 xEv = NEG2, mdv[QH];
 #pragma unroll
-    for (int q = Q - 1; q >= 0; --q) {
-      const int mp = q ? Mv[q - 1] : mpi, ip = q ? Iv[q - 1] : ipi, dp = q ? Dv[q - 1] : dpi;
-      int sv = sat_lo(xB + tBM[q]);
-      sv = max(sv, sat_lo(mp + tMM[q]));
-      sv = max(sv, sat_lo(ip + tIM[q]));
-      sv = max(sv, sat_lo(dp + tDM[q]));
-      sv = sat_lo(sv + e[q]);
-      const int ni = max(sat_lo(Mv[q] + tMI[q]), sat_lo(Iv[q] + tII[q]));
-      Iv[q] = ni; Mv[q] = sv;
-      xE = max(xE, sv);
+    for (int j = QH - 1; j >= 0; --j) {
+      const u32 mp = j ? Mv[j - 1] : ms0, ip = j ? Iv[j - 1] : is0, dp = j ? Dv[j - 1] : ds0;
+      u32 sv = pk_adds(xBv, tBM[j]);
+      sv = pk_max(sv, pk_adds(mp, tMM[j]));
+      sv = pk_max(sv, pk_adds(ip, tIM[j]));
+      sv = pk_max(sv, pk_adds(dp, tDM[j]));
+      sv = pk_adds(sv, e[j]);
+      const u32 ni = pk_max(pk_adds(Mv[j], tMI[j]), pk_adds(Iv[j], tII[j]));
+      Iv[j] = ni; Mv[j] = sv;
+      xEv = pk_max(xEv, sv);
+      mdv[j] = pk_adds(sv, tMD[j]);
     }
-    // D(c) = max(-32768, C[c] + max_{j<c}(md(j) - C[j+1])),  md(j) = sat(M(j) + tMD(j))
-    int g[Q]; int run = NEGBIG;
+    // D, pass 1: the first cell of a stripe takes the M->D word of the previous stripe's last cell
+    Dv[0] = stripe_shift(mdv[QH - 1]);
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const int mdv = sat_lo(Mv[q] + tMD[q]);
-      g[q] = (mdv <= NEG16) ? NEGBIG : mdv - Cn[q];
-      run = max(run, g[q]);
+    for (int j = 1; j < QH; ++j) Dv[j] = pk_max(mdv[j - 1], pk_adds(Dv[j - 1], tDD[j - 1]));
+    u32 carry = pk_adds(Dv[QH - 1], tDD[QH - 1]);
+    // lazy-F passes: carry stripe ends forward while some first cell still improves
+    for (int pass = 0; pass < 128; ++pass) {
+      u32 cs = stripe_shift(carry);
+      const s16x2 c2 = __builtin_bit_cast(s16x2, cs), d2 = __builtin_bit_cast(s16x2, Dv[0]);
+      if (!__any((c2.x > d2.x) || (c2.y > d2.y))) break;
+#pragma unroll
+      for (int j = 0; j < QH; ++j) { Dv[j] = pk_max(Dv[j], cs); cs = pk_adds(cs, tDD[j]); }
+      carry = cs;
     }
-    int incl = run;
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) { const int o = __shfl_up(incl, s); if (lane >= s) incl = max(incl, o); }
-    int excl = __shfl_up(incl, 1); if (lane == 0) excl = NEGBIG;
-    int pm = excl;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) { Dv[q] = (pm <= NEGBIG) ? NEG16 : sat_lo(Cc[q] + pm); pm = max(pm, g[q]); }
+    const s16x2 x2 = __builtin_bit_cast(s16x2, xEv);
+    int xE = max((int)x2.x, (int)x2.y);
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) xE = max(xE, __shfl_xor(xE, s));
     if (xE >= 32767) { overflow = true; break; }
@@ -241,7 +256,7 @@ __global__ void __launch_bounds__(256) vit_kernel(const PairRec *__restrict__ pa
     xJ = max(xJ, xE + md.wE_loop);
     xB = max(xJ + le.w_move, xN + le.w_move);
 #pragma unroll
-    for (int q = 0; q < Q; ++q) e[q] = en[q];
+    for (int j = 0; j < QH; ++j) e[j] = en[j];
   }
   if (lane == 0) {
     if (overflow) { out_xC[pi] = 32767; out_sc[pi] = __builtin_inff(); }
@@ -254,12 +269,12 @@ __global__ void __launch_bounds__(256) vit_kernel(const PairRec *__restrict__ pa
 }
 
 #define CKM_VIT_CASE(QV) case QV: hipLaunchKernelGGL(vit_kernel<QV>, dim3((n + 3) / 4), dim3(256), 0, stream, pairs, idx, n, models, lentab, res, seq_off, seq_len, out_xC, out_sc); break;
-int launch_vit(int Q, hipStream_t stream, const PairRec *pairs, const uint32_t *idx, uint32_t n, const DevModel *models,
+int launch_vit(int QH, hipStream_t stream, const PairRec *pairs, const uint32_t *idx, uint32_t n, const DevModel *models,
                const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xC, float *out_sc) {
   if (n == 0) return 0;
-  switch (Q) {
-    CKM_VIT_CASE(1) CKM_VIT_CASE(2) CKM_VIT_CASE(3) CKM_VIT_CASE(4) CKM_VIT_CASE(6) CKM_VIT_CASE(8)
-    CKM_VIT_CASE(12) CKM_VIT_CASE(16) CKM_VIT_CASE(24) CKM_VIT_CASE(32)
+  switch (QH) {
+    CKM_VIT_CASE(1) CKM_VIT_CASE(2) CKM_VIT_CASE(3) CKM_VIT_CASE(4) CKM_VIT_CASE(5) CKM_VIT_CASE(6) CKM_VIT_CASE(7) CKM_VIT_CASE(8)
+    CKM_VIT_CASE(10) CKM_VIT_CASE(12) CKM_VIT_CASE(14) CKM_VIT_CASE(16)
     default: return -1;
   }
   return 0;
