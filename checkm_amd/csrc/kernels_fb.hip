@@ -245,6 +245,16 @@ __global__ void __launch_bounds__(256) bwd_kernel(const FbWork *__restrict__ wor
     }
   };
   fetch_f(L);
+  // forward special rows r+1 (rowU), r (rowC), r-1 (rowD) ride in registers; the next one is requested a row ahead
+  float rowU[6], rowC[6], rowD[6];
+  auto load_row = [&](float (&dst)[6], int r) {
+    const float *__restrict__ x = xs + (size_t)(r < 0 ? 0 : r) * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dst[k] = x[k];
+  };
+  load_row(rowC, L); load_row(rowD, L - 1);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) rowU[k] = 1.0f;
   auto emit = [&](int r) {
     // decoding terms that become available once backward row r is final
     if (w.full) {
@@ -262,24 +272,24 @@ __global__ void __launch_bounds__(256) bwd_kernel(const FbWork *__restrict__ wor
 #pragma unroll
         for (int q = 0; q < Q; ++q) { b[q * 64] = pmv[q]; b[Mp + q * 64] = piv[q]; b[2 * Mp + q * 64] = 0.f; }
         if (lane == 0) {
-          const float wgt = invZ / xs[(size_t)r * 6 + 5];
+          const float wgt = invZ / rowC[5];
           float t;
-          t = xs[(size_t)(r - 1) * 6 + 1] * xN; t = t * loop; aux[(size_t)r * 3 + 0] = t * wgt;
-          t = xs[(size_t)(r - 1) * 6 + 2] * xJ; t = t * loop; aux[(size_t)r * 3 + 1] = t * wgt;
-          t = xs[(size_t)(r - 1) * 6 + 4] * xC; t = t * loop; aux[(size_t)r * 3 + 2] = t * wgt;
+          t = rowD[1] * xN; t = t * loop; aux[(size_t)r * 3 + 0] = t * wgt;
+          t = rowD[2] * xJ; t = t * loop; aux[(size_t)r * 3 + 1] = t * wgt;
+          t = rowD[4] * xC; t = t * loop; aux[(size_t)r * 3 + 2] = t * wgt;
         }
       }
     } else if (lane == 0) {
       if (r >= 1) {
-        float et = xs[(size_t)r * 6 + 0] * xE; et = et * invZ;
-        const float wgt = invZ / xs[(size_t)r * 6 + 5];
-        float a = xs[(size_t)(r - 1) * 6 + 1] * xN; a = a * loop;
-        float b = xs[(size_t)(r - 1) * 6 + 2] * xJ; b = b * loop;
-        float c = xs[(size_t)(r - 1) * 6 + 4] * xC; c = c * loop;
+        float et = rowC[0] * xE; et = et * invZ;
+        const float wgt = invZ / rowC[5];
+        float a = rowD[1] * xN; a = a * loop;
+        float b = rowD[2] * xJ; b = b * loop;
+        float c = rowD[4] * xC; c = c * loop;
         aux[(size_t)r * 3 + 1] = et;
         aux[(size_t)r * 3 + 2] = ((a + b) + c) * wgt;
       }
-      if (r < L) { float bt = xs[(size_t)r * 6 + 3] * xB; bt = bt * invZ; aux[(size_t)(r + 1) * 3 + 0] = bt; }
+      if (r < L) { float bt = rowC[3] * xB; bt = bt * invZ; aux[(size_t)(r + 1) * 3 + 0] = bt; }
     }
   };
   emit(L);
@@ -290,6 +300,9 @@ __global__ void __launch_bounds__(256) bwd_kernel(const FbWork *__restrict__ wor
     for (int q = 0; q < Q; ++q) rfc[q] = r0[q * 64];
   }
   for (int i = L - 1; i >= 0; --i) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { rowU[k] = rowC[k]; rowC[k] = rowD[k]; }
+    load_row(rowD, i - 1);
     float rfn[Q];                                                     // residue i, needed by the next iteration
     {
       const int xn = (i >= 1) ? rp[i - 1] : rp[0];
@@ -328,7 +341,7 @@ __global__ void __launch_bounds__(256) bwd_kernel(const FbWork *__restrict__ wor
       m = m + tr.MD(q) * dn1;
       Mn[q] = m;
     }
-    const float sc = xs[(size_t)(i + 1) * 6 + 5];
+    const float sc = rowU[5];
     if (sc != 1.0f) {
       const float inv = 1.0f / sc;
 #pragma unroll
@@ -407,6 +420,8 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
   float oN = 0.f, oB = 0.f, oE = NEGINF_F, oJ = NEGINF_F, oC = NEGINF_F;
   if (lane == 0) { oax[0] = oN; oax[1] = oB; oax[2] = oE; oax[3] = oJ; oax[4] = oC; }
   float ppM[Q], ppI[Q];
+  float ax0 = 0.f, ax1 = 0.f, ax2 = 0.f;          // ppN ppJ ppC of the current row
+  if (L >= 1) { ax0 = aux[3]; ax1 = aux[4]; ax2 = aux[5]; }
   if (L >= 1) {
     const float *__restrict__ p1 = pp + (size_t)1 * 3 * Mp + lane;
 #pragma unroll
@@ -415,6 +430,8 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
   for (int i = 1; i <= L; ++i) {
     // posterior row i is in registers; row i+1 is requested now, before this row's stores
     float ppMn[Q], ppIn[Q];
+    const float *__restrict__ axn = aux + (size_t)((i < L) ? i + 1 : i) * 3;
+    const float an0 = axn[0], an1 = axn[1], an2 = axn[2];
     {
       const float *__restrict__ pn = pp + (size_t)((i < L) ? i + 1 : i) * 3 * Mp + lane;
 #pragma unroll
@@ -478,9 +495,10 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) e = fmaxf(e, __shfl_xor(e, s));
     oE = e;
-    { const float a = oJ + aux[(size_t)i * 3 + 1]; const float b = Eloop_ok ? e : NEGINF_F; oJ = a > b ? a : b; }
-    { const float a = oC + aux[(size_t)i * 3 + 2]; oC = a > e ? a : e; }
-    oN = oN + aux[(size_t)i * 3 + 0];
+    { const float a = oJ + ax1; const float b = Eloop_ok ? e : NEGINF_F; oJ = a > b ? a : b; }
+    { const float a = oC + ax2; oC = a > e ? a : e; }
+    oN = oN + ax0;
+    ax0 = an0; ax1 = an1; ax2 = an2;
     oB = oN > oJ ? oN : oJ;
     float *__restrict__ r = oa + (size_t)i * 3 * Mp + lane;
 #pragma unroll
