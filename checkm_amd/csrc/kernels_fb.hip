@@ -47,6 +47,14 @@ __device__ __forceinline__ void load_tr(float *lds, const float *ftr) {
   __syncthreads();
 }
 
+// same image, but 0 for a possible transition and -inf for an impossible one (optimal-accuracy max-plus gates)
+template <int Q>
+__device__ __forceinline__ void load_gates(float *lds, const float *ftr) {
+  constexpr int Mp = Q * 64;
+  for (int i = threadIdx.x; i < 8 * Mp; i += blockDim.x) { const int arr = i / Mp, c = i % Mp; lds[arr * Mp + lds_cell<Q>(c)] = (ftr[i] > 0.f) ? 0.0f : -__builtin_inff(); }
+  __syncthreads();
+}
+
 __device__ __forceinline__ float wave_sum(float s) {
 #pragma unroll
   for (int w = 32; w >= 1; w >>= 1) s = s + __shfl_xor(s, w);
@@ -368,7 +376,7 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
   const int lane = threadIdx.x & 63;
   const uint32_t item = idx[blockIdx.x * FB_WAVES + (threadIdx.x >> 6)];
   const DevModel &md = models[blk_model[blockIdx.x]];
-  load_tr<Q>(lds, md.ftr);
+  load_gates<Q>(lds, md.ftr);
   if (item == NO_ITEM) return;
   const FbWork w = work[item];
   if (range_err[w.slot]) { if (lane == 0) out[w.slot].range_err = 1; return; }
@@ -405,15 +413,8 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
     }
   }
   // ---------------- OA fill ----------------
-  bool okMM[Q], okIM[Q], okDM[Q], okBM[Q], okMI[Q], okII[Q], okMDp[Q], okDDp[Q];   // *p: gate of the transition INTO cell c from c-1
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    const int c = c0 + q;
-    okMM[q] = c > 0 && tr.MM(q) > 0.f; okIM[q] = c > 0 && tr.IM(q) > 0.f; okDM[q] = c > 0 && tr.DM(q) > 0.f; okBM[q] = tr.BM(q) > 0.f;
-    okMI[q] = tr.MI(q) > 0.f; okII[q] = tr.II(q) > 0.f;
-    okMDp[q] = c > 0 && c < M && tr.at(6, c - 1) > 0.f;
-    okDDp[q] = c > 0 && c < M && tr.at(7, c - 1) > 0.f;
-  }
+  // Max-plus with additive gates: from here on the LDS image holds 0 for a possible transition and -inf for an
+  // impossible one (cells beyond M and node-0 predecessors have zero odds, so they gate themselves).
   float Mv[Q], Iv[Q], Dv[Q];
 #pragma unroll
   for (int q = 0; q < Q; ++q) { Mv[q] = Iv[q] = Dv[q] = NEGINF_F; oa[q * 64 + lane] = NEGINF_F; oa[Mp + q * 64 + lane] = NEGINF_F; oa[2 * Mp + q * 64 + lane] = NEGINF_F; }
@@ -438,59 +439,34 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
       for (int q = 0; q < Q; ++q) { ppMn[q] = pn[q * 64]; ppIn[q] = pn[Mp + q * 64]; }
     }
     float mpi = __shfl_up(Mv[Q - 1], 1), ipi = __shfl_up(Iv[Q - 1], 1), dpi = __shfl_up(Dv[Q - 1], 1);
+    if (lane == 0) { mpi = NEGINF_F; ipi = NEGINF_F; dpi = NEGINF_F; }
     float Mn[Q], In[Q], Dn[Q];
     float e = NEGINF_F;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      const int c = c0 + q;
       const float mp = q ? Mv[q - 1] : mpi, ip = q ? Iv[q - 1] : ipi, dp = q ? Dv[q - 1] : dpi;
-      float best = NEGINF_F;
-      if (okMM[q] && mp > best) best = mp;
-      if (okIM[q] && ip > best) best = ip;
-      if (okDM[q] && dp > best) best = dp;
-      if (okBM[q] && oB > best) best = oB;
-      float bi = NEGINF_F;
-      if (okMI[q] && Mv[q] > bi) bi = Mv[q];
-      if (okII[q] && Iv[q] > bi) bi = Iv[q];
-      if (c < M) { Mn[q] = best + ppM[q]; In[q] = bi + ppI[q]; e = fmaxf(e, Mn[q]); }
-      else { Mn[q] = NEGINF_F; In[q] = NEGINF_F; }
+      const float best = fmaxf(fmaxf(mp + tr.MM(q), ip + tr.IM(q)), fmaxf(dp + tr.DM(q), oB + tr.BM(q)));
+      const float bi = fmaxf(Mv[q] + tr.MI(q), Iv[q] + tr.II(q));
+      Mn[q] = best + ppM[q]; In[q] = bi + ppI[q];
+      e = fmaxf(e, Mn[q]);
     }
-    // D chain: D(c) = max(gate_MD(c-1) ? M(c-1), gate_DD(c-1) ? D(c-1)); segmented max scan over lanes
-    float dloc[Q]; bool open[Q];
+    // D chain: D(c) = max(M(c-1) + gMD(c-1), D(c-1) + gDD(c-1)): lane-local fold, max-plus Kogge-Stone over lanes
     {
-      float d = NEGINF_F; bool op = true;   // carry-in -inf; `op`: the carry reaches this cell
+      float dloc[Q], pw[Q];
+      dloc[0] = NEGINF_F; pw[0] = 0.0f;
 #pragma unroll
-      for (int q = 0; q < Q; ++q) {
-        // value entering cell q from cell q-1 of the same lane (q>0); q==0 handled by the carry
-        if (q > 0) {
-          float v = NEGINF_F;
-          if (okMDp[q] && Mn[q - 1] > v) v = Mn[q - 1];
-          if (okDDp[q] && d > v) v = d;
-          d = v; op = op && okDDp[q];
-        }
-        dloc[q] = d; open[q] = op;
-      }
-      // lane output towards the next lane's first cell: needs the gates of that cell (c0+Q)
-      const int cn = c0 + Q;
-      const bool gMD = cn < M && cn < Mp && tr.at(6, cn - 1) > 0.f, gDD = cn < M && cn < Mp && tr.at(7, cn - 1) > 0.f;
-      float outv = NEGINF_F;
-      if (gMD && Mn[Q - 1] > outv) outv = Mn[Q - 1];
-      if (gDD && d > outv) outv = d;
-      bool pass = op && gDD;     // a carry entering this lane's first cell survives to the next lane's first cell
-      // NOTE: the carry enters cell q=0 as D(c0) itself; it propagates to later cells only through DD gates
+      for (int q = 1; q < Q; ++q) { dloc[q] = fmaxf(Mn[q - 1] + tr.MD(q - 1), dloc[q - 1] + tr.DD(q - 1)); pw[q] = pw[q - 1] + tr.DD(q - 1); }
+      float outv = fmaxf(Mn[Q - 1] + tr.MD(Q - 1), dloc[Q - 1] + tr.DD(Q - 1));
+      float wgt = pw[Q - 1] + tr.DD(Q - 1);
 #pragma unroll
       for (int s = 1; s < 64; s <<= 1) {
-        const float ov = __shfl_up(outv, s); const int opass = __shfl_up((int)pass, s);
-        if (lane >= s) { if (pass && ov > outv) outv = ov; pass = pass && (opass != 0); }
+        const float ov = __shfl_up(outv, s), ow = __shfl_up(wgt, s);
+        if (lane >= s) { outv = fmaxf(outv, ov + wgt); wgt = wgt + ow; }
       }
       float carry = __shfl_up(outv, 1);
       if (lane == 0) carry = NEGINF_F;
 #pragma unroll
-      for (int q = 0; q < Q; ++q) {
-        float v = dloc[q];
-        if (q == 0) v = carry; else if (open[q] && carry > v) v = carry;
-        Dn[q] = (c0 + q < M) ? v : NEGINF_F;
-      }
+      for (int q = 0; q < Q; ++q) Dn[q] = fmaxf(dloc[q], carry + pw[q]);
     }
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) e = fmaxf(e, __shfl_xor(e, s));
@@ -538,8 +514,8 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
     } else if (st == 2) {
       fi = i; fk = k + 1;
       float p0 = NEGINF_F, p1 = NEGINF_F, p2 = NEGINF_F, p3 = NEGINF_F;
-      if (k > 0) { if (tMM_(k) > 0.f) p0 = LD2(&pr[lds_cell<Q>(k - 1)]); if (tIM_(k) > 0.f) p1 = LD2(&pr[Mp + lds_cell<Q>(k - 1)]); if (tDM_(k) > 0.f) p2 = LD2(&pr[2 * Mp + lds_cell<Q>(k - 1)]); }
-      if (tBM_(k) > 0.f) p3 = LD2(&oax[(size_t)(i - 1) * 5 + 1]);
+      if (k > 0) { if (tMM_(k) == 0.f) p0 = LD2(&pr[lds_cell<Q>(k - 1)]); if (tIM_(k) == 0.f) p1 = LD2(&pr[Mp + lds_cell<Q>(k - 1)]); if (tDM_(k) == 0.f) p2 = LD2(&pr[2 * Mp + lds_cell<Q>(k - 1)]); }
+      if (tBM_(k) == 0.f) p3 = LD2(&oax[(size_t)(i - 1) * 5 + 1]);
       int best = 0; float bv = p0;
       if (p1 > bv) { bv = p1; best = 1; }
       if (p2 > bv) { bv = p2; best = 2; }
@@ -547,10 +523,10 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
       --i;
       if (best == 0) { --k; st = 2; } else if (best == 1) { --k; st = 3; } else if (best == 2) { --k; st = 4; } else done = true;
     } else if (st == 3) {
-      const float a = (tMI_(k) > 0.f) ? LD2(&pr[lds_cell<Q>(k)]) : NEGINF_F, b = (tII_(k) > 0.f) ? LD2(&pr[Mp + lds_cell<Q>(k)]) : NEGINF_F;
+      const float a = (tMI_(k) == 0.f) ? LD2(&pr[lds_cell<Q>(k)]) : NEGINF_F, b = (tII_(k) == 0.f) ? LD2(&pr[Mp + lds_cell<Q>(k)]) : NEGINF_F;
       --i; st = (a >= b) ? 2 : 3;
     } else {
-      const float a = (tMD_(k - 1) > 0.f) ? LD2(&cr[lds_cell<Q>(k - 1)]) : NEGINF_F, b = (tDD_(k - 1) > 0.f) ? LD2(&cr[2 * Mp + lds_cell<Q>(k - 1)]) : NEGINF_F;
+      const float a = (tMD_(k - 1) == 0.f) ? LD2(&cr[lds_cell<Q>(k - 1)]) : NEGINF_F, b = (tDD_(k - 1) == 0.f) ? LD2(&cr[2 * Mp + lds_cell<Q>(k - 1)]) : NEGINF_F;
       --k; st = (a >= b) ? 2 : 4;
     }
   }
