@@ -243,7 +243,7 @@ def cpr43_profiles(seed=43, with_stats=True):
 
 
 # (seed, n, mlo, mhi) families calibrated by tools/calibrate_synth.py
-SMALL_SETS = [(7, 6, 20, 150), (11, 12, 40, 300), (13, 4, 300, 1100)]
+SMALL_SETS = [(7, 6, 20, 150), (11, 12, 40, 300), (13, 4, 300, 1100), (17, 2, 1300, 2048)]
 
 
 def small_profiles(seed, n, mlo=20, mhi=150, prefix="SYN", with_stats=True):

@@ -158,3 +158,48 @@ def test_domtblout_text_identical(world, tmp_path):
         assert open(path).read() == want
         off += len(recs)
     hits.close()
+
+
+def test_large_models_and_error_paths(gpu_ctx, tmp_path):
+    """Register classes the mixed set does not reach (M up to 2048: SSV Q 48-64, Viterbi QH 12-16, Forward Q 24-32),
+    plus the library's error codes for malformed input."""
+    profs = synth.small_profiles(17, 2, 1300, 2048)
+    path = common.hmm_file("large17", profs)
+    recs = synth.make_bin(profs, 99, n_orfs=24, dup_frac=0.0)
+    rng = np.random.default_rng(8)
+    recs += [("long_%d" % i, "", synth.to_text(synth.random_residues(rng, 2500)) + "*") for i in range(2)]
+    prof = _lib.Profiles(gpu_ctx, path)
+    seqs = _lib.Seqs(gpu_ctx, [recs])
+    hs = p7.HmmSet(path)
+    dsq = [p7.digitize(r[2]) for r in recs]
+    pairs = [(m, s) for m in range(hs.n) for s in range(len(recs))]
+    got = _lib.debug_stages(gpu_ctx, prof, seqs, np.array([p[0] for p in pairs]), np.array([p[1] for p in pairs]))
+    for i, (m, s) in enumerate(pairs):
+        o = hs.stages(m, dsq[s])
+        for f in STAGE_FIELDS:
+            assert _cmp_stage(o, got[i], f), (m, s, f, getattr(o, f), getattr(got[i], f))
+    hits = _lib.search(gpu_ctx, prof, seqs)
+    rows = hs.search(list(range(hs.n)), dsq, [r[0] for r in recs])
+    assert hits.n == len(rows) >= 2
+    for g, r in enumerate(rows):
+        assert (r.seq_idx, r.model_idx, r.hmm_from, r.hmm_to, r.ali_from, r.ali_to, r.env_from, r.env_to) == \
+            (hits.seq[g], hits.model[g], hits.hmm_from[g], hits.hmm_to[g], hits.ali_from[g], hits.ali_to[g], hits.env_from[g], hits.env_to[g])
+        for f in ROW_F32:
+            assert common.float_bits(getattr(r, f)) == common.float_bits(getattr(hits, f)[g]), f
+        assert r.full_evalue == hits.full_evalue[g] and r.c_evalue == hits.c_evalue[g]
+    hits.close(); prof.close(); seqs.close(); hs.close()
+    # error paths
+    bad = tmp_path / "bad.hmm"
+    bad.write_text("HMMER3/f [x]\nNAME  broken\nLENG  5\nALPH  amino\nHMM     A\n")
+    with pytest.raises(_lib.CkmError) as e:
+        _lib.Profiles(gpu_ctx, str(bad))
+    assert e.value.code == -3
+    with pytest.raises(_lib.CkmError) as e:
+        _lib.Profiles(gpu_ctx, str(tmp_path / "missing.hmm"))
+    assert e.value.code == -2
+    uncal = tmp_path / "uncal.hmm"
+    p = synth.random_profile(rng, 30, "nocal", "PF77777.1")
+    synth.write_hmm(str(uncal), [p])
+    with pytest.raises(_lib.CkmError) as e:
+        _lib.Profiles(gpu_ctx, str(uncal))
+    assert e.value.code == -3 and "calibrated" in str(e.value)
