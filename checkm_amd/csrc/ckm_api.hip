@@ -480,7 +480,7 @@ size_t env_floats(int Mp, int Ld, uint64_t &xs, uint64_t &aux, uint64_t &mf, uin
   xs = pos; pos = al(pos + (uint64_t)(Ld + 1) * 6);
   aux = pos; pos = al(al(pos + (uint64_t)(Ld + 1) * 3) + (uint64_t)(Ld + 1) * 5);
   mf = pos; pos = al(pos + (uint64_t)(Ld + 1) * 3 * Mp);
-  mb = pos; pos = al(pos + (uint64_t)(Ld + 1) * 3 * Mp);
+  mb = pos; pos = al(pos + (uint64_t)(Ld + 1) * 2 * Mp);     // posterior rows: M and I only
   return pos;
 }
 

@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256) fwd_kernel(const FbWork *__restrict__ wor
   if (lane == 0) { xs[0] = 0.f; xs[1] = xN; xs[2] = 0.f; xs[3] = xB; xs[4] = 0.f; xs[5] = 1.0f; }
   if (mx) {
 #pragma unroll
-    for (int q = 0; q < Q; ++q) { mx[q * 64 + lane] = 0.f; mx[Mp + q * 64 + lane] = 0.f; mx[2 * Mp + q * 64 + lane] = 0.f; }
+    for (int q = 0; q < Q; ++q) { mx[q * 64 + lane] = 0.f; mx[Mp + q * 64 + lane] = 0.f; }   // D is never read back
   }
   // emission odds of the next row are fetched one row ahead (residue byte -> table row is a dependent pair of loads)
   float rfc[Q];
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(256) fwd_kernel(const FbWork *__restrict__ wor
     if (mx) {
       float *r = mx + (size_t)i * 3 * Mp + lane;
 #pragma unroll
-      for (int q = 0; q < Q; ++q) { r[q * 64] = Mv[q]; r[Mp + q * 64] = Iv[q]; r[2 * Mp + q * 64] = Dv[q]; }
+      for (int q = 0; q < Q; ++q) { r[q * 64] = Mv[q]; r[Mp + q * 64] = Iv[q]; }
     }
   }
   if (lane == 0) { out[w.slot].xC = xC; out[w.slot].nscale = nscale; }
@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(256) bwd_kernel(const FbWork *__restrict__ wor
     // decoding terms that become available once backward row r is final
     if (w.full) {
       if (r >= 1) {
-        float *__restrict__ b = bm + (size_t)r * 3 * Mp + lane;
+        float *__restrict__ b = bm + (size_t)r * 2 * Mp + lane;     // posterior rows hold M and I only
         float pmv[Q], piv[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(256) bwd_kernel(const FbWork *__restrict__ wor
         }
         fetch_f(r - 1);
 #pragma unroll
-        for (int q = 0; q < Q; ++q) { b[q * 64] = pmv[q]; b[Mp + q * 64] = piv[q]; b[2 * Mp + q * 64] = 0.f; }
+        for (int q = 0; q < Q; ++q) { b[q * 64] = pmv[q]; b[Mp + q * 64] = piv[q]; }
         if (lane == 0) {
           const float wgt = invZ / rowC[5];
           float t;
@@ -387,31 +387,6 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
   const float *aux = ws + w.aux_off;                                   // [ppN ppJ ppC] per row (written by bwd_kernel)
   float *oax = ws + w.aux_off + (((size_t)(w.Ld + 1) * 3 + 31) & ~(size_t)31);   // [oN oB oE oJ oC] per row, own cache lines
   const bool Eloop_ok = false;      // envelopes are rescored unihit
-  // ---------------- null2 ----------------
-  {
-    float me[Q], ie[Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) me[q] = ie[q] = 0.f;
-    float xN = 0.f, xJ = 0.f, xC = 0.f;
-    for (int i = 1; i <= L; ++i) {
-      const float *r = pp + (size_t)i * 3 * Mp + lane;
-#pragma unroll
-      for (int q = 0; q < Q; ++q) { me[q] = me[q] + r[q * 64]; ie[q] = ie[q] + r[Mp + q * 64]; }
-      xN = xN + aux[(size_t)i * 3 + 0]; xJ = xJ + aux[(size_t)i * 3 + 1]; xC = xC + aux[(size_t)i * 3 + 2];
-    }
-    const float norm = 1.0f / (float)L;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) { me[q] *= norm; ie[q] *= norm; }
-    const float xfactor = ((xN + xC) + xJ) * norm;
-    for (int x = 0; x < 20; ++x) {
-      const float *rfx = md.rf + (size_t)x * Mp + lane;
-      float s = 0.f;
-#pragma unroll
-      for (int q = 0; q < Q; ++q) { const float t = me[q] * rfx[q * 64]; s = s + t; s = s + ie[q]; }
-      s = wave_sum(s);
-      if (lane == 0) out[w.slot].null2[x] = s + xfactor;
-    }
-  }
   // ---------------- OA fill ----------------
   // Max-plus with additive gates: from here on the LDS image holds 0 for a possible transition and -inf for an
   // impossible one (cells beyond M and node-0 predecessors have zero odds, so they gate themselves).
@@ -420,11 +395,16 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
   for (int q = 0; q < Q; ++q) { Mv[q] = Iv[q] = Dv[q] = NEGINF_F; oa[q * 64 + lane] = NEGINF_F; oa[Mp + q * 64 + lane] = NEGINF_F; oa[2 * Mp + q * 64 + lane] = NEGINF_F; }
   float oN = 0.f, oB = 0.f, oE = NEGINF_F, oJ = NEGINF_F, oC = NEGINF_F;
   if (lane == 0) { oax[0] = oN; oax[1] = oB; oax[2] = oE; oax[3] = oJ; oax[4] = oC; }
+  // null2 by expectation rides along: per-cell posterior sums in ascending row order (the oracle's order)
+  float me[Q], ie[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) me[q] = ie[q] = 0.f;
+  float n2N = 0.f, n2J = 0.f, n2C = 0.f;
   float ppM[Q], ppI[Q];
   float ax0 = 0.f, ax1 = 0.f, ax2 = 0.f;          // ppN ppJ ppC of the current row
   if (L >= 1) { ax0 = aux[3]; ax1 = aux[4]; ax2 = aux[5]; }
   if (L >= 1) {
-    const float *__restrict__ p1 = pp + (size_t)1 * 3 * Mp + lane;
+    const float *__restrict__ p1 = pp + (size_t)1 * 2 * Mp + lane;
 #pragma unroll
     for (int q = 0; q < Q; ++q) { ppM[q] = p1[q * 64]; ppI[q] = p1[Mp + q * 64]; }
   }
@@ -434,10 +414,13 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
     const float *__restrict__ axn = aux + (size_t)((i < L) ? i + 1 : i) * 3;
     const float an0 = axn[0], an1 = axn[1], an2 = axn[2];
     {
-      const float *__restrict__ pn = pp + (size_t)((i < L) ? i + 1 : i) * 3 * Mp + lane;
+      const float *__restrict__ pn = pp + (size_t)((i < L) ? i + 1 : i) * 2 * Mp + lane;
 #pragma unroll
       for (int q = 0; q < Q; ++q) { ppMn[q] = pn[q * 64]; ppIn[q] = pn[Mp + q * 64]; }
     }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { me[q] = me[q] + ppM[q]; ie[q] = ie[q] + ppI[q]; }
+    n2N = n2N + ax0; n2J = n2J + ax1; n2C = n2C + ax2;
     float mpi = __shfl_up(Mv[Q - 1], 1), ipi = __shfl_up(Iv[Q - 1], 1), dpi = __shfl_up(Dv[Q - 1], 1);
     if (lane == 0) { mpi = NEGINF_F; ipi = NEGINF_F; dpi = NEGINF_F; }
     float Mn[Q], In[Q], Dn[Q];
@@ -480,6 +463,20 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
 #pragma unroll
     for (int q = 0; q < Q; ++q) { Mv[q] = Mn[q]; Iv[q] = In[q]; Dv[q] = Dn[q]; r[q * 64] = Mn[q]; r[Mp + q * 64] = In[q]; r[2 * Mp + q * 64] = Dn[q]; ppM[q] = ppMn[q]; ppI[q] = ppIn[q]; }
     if (lane == 0) { float *a = oax + (size_t)i * 5; a[0] = oN; a[1] = oB; a[2] = oE; a[3] = oJ; a[4] = oC; }
+  }
+  {
+    const float norm = 1.0f / (float)L;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { me[q] *= norm; ie[q] *= norm; }
+    const float xfactor = ((n2N + n2C) + n2J) * norm;
+    for (int x = 0; x < 20; ++x) {
+      const float *rfx = md.rf + (size_t)x * Mp + lane;
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) { const float t = me[q] * rfx[q * 64]; s = s + t; s = s + ie[q]; }
+      s = wave_sum(s);
+      if (lane == 0) out[w.slot].null2[x] = s + xfactor;
+    }
   }
   __threadfence();
   __builtin_amdgcn_wave_barrier();

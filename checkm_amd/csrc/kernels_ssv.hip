@@ -100,9 +100,11 @@ __global__ void __launch_bounds__(Q > 40 ? 512 : 1024) ssv_kernel(const SsvBlock
     u32 xE = U_ZERO;
     const int nchunk = (Lmax + 15) >> 4;
     const uint4 padv = make_uint4(PAD4, PAD4, PAD4, PAD4);
-    uint4 cur = (0 < L) ? *reinterpret_cast<const uint4 *>(rp) : padv;
+    uint4 cur = padv;
+    if (0 < L) cur = *reinterpret_cast<const uint4 *>(rp);     // (not a ?: -- that selects between ADDRESSES and spills padv to scratch)
     for (int c = 0; c < nchunk; ++c) {
-      const uint4 nxt = ((c + 1) * 16 < L) ? *reinterpret_cast<const uint4 *>(rp + (c + 1) * 16) : padv;
+      uint4 nxt = padv;
+      if ((c + 1) * 16 < L) nxt = *reinterpret_cast<const uint4 *>(rp + (c + 1) * 16);
 #define CKM_SSV_WORD(wd)                                   \
   ssv_row<Q>(U, xE, lds_lane, (wd) & 0xffu);               \
   ssv_row<Q>(U, xE, lds_lane, ((wd) >> 8) & 0xffu);        \
