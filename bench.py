@@ -131,6 +131,19 @@ def main():
         alg_bytes = float(st.residue_hmm) + 12.0 * float(st.pairs_ssv)
         ssv_s = ssv_ms / args.steps / 1e3
         achieved = alg_bytes / ssv_s / 1e9
+        # HBM traffic and VALU instruction count of the same launches come from separate rocprofv3 --pmc passes
+        # (profiles/r01b_pmc_summary.txt); they are only quoted when the workload is the one that was profiled
+        traffic = None
+        valu = None
+        tf = os.path.join(ROOT, "profiles", "r01b_ssv_traffic.json")
+        if os.path.exists(tf) and args.bins == 100 and args.orfs == 2000:
+            with open(tf) as f:
+                pm = json.load(f)
+            traffic = pm["hbm_bytes_corrected"]
+            cyc = ssv_s * 2.4e9 / (pm["valu_insts"] / 1024.0)
+            valu = {"bound": "valu-issue", "wave_insts_per_step": pm["valu_insts"], "cycles_per_inst_per_simd": cyc, "ceiling_cycles_per_inst": 4.4,
+                    "frac": 4.4 / cyc, "note": "gfx950 issues every VALU op except f32 add/mul/fma at ~4.2-4.6 nominal cycles per wave64 "
+                    "(tools/ubench/valu_rates.hip -> profiles/r01_valu_rates.txt); the SSV inner loop is 2 packed-i16 ops per register per row"}
         out = {
             "metric": "residues*HMMs/s (marker-gene scan+reduce, cfg2: 43 profiles x 100 synthetic 2 Mb bins per GPU)",
             "value": value, "unit": "residue*HMM/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -143,9 +156,10 @@ def main():
             "bins_per_hour": args.bins * world / per_step * 3600.0,
             "gcups_ssv": float(st.cells_ssv) / ssv_s / 1e9,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "ssv_kernel<Q>", "ms_per_step_kernel": ssv_ms / args.steps,
+                         "traffic": traffic, "algorithmic_bytes": alg_bytes, "kernel": "ssv_kernel<Q>", "ms_per_step_kernel": ssv_ms / args.steps,
                          "launches_per_step": int(st.ssv_launches),
-                         "note": "VALU-bound by design (SURVEY H3): ~1.7 packed-i16 VALU ops per DP cell; see gcups_ssv and DESIGN.md section 6"},
+                         "note": "the kernel is VALU-issue-bound by design (SURVEY H3), not HBM-bound: see roofline_valu, gcups_ssv and DESIGN.md section 6"},
+            "roofline_valu": valu,
             "stages_ms": {"ssv": st.ms_ssv, "filters": st.ms_filters, "fwdbwd": st.ms_fwdbwd, "domains": st.ms_domains, "host": st.ms_host, "search_total": st.ms_total},
             "stage_pairs": {"ssv": int(st.pairs_ssv), "msv_full": int(st.pairs_msv_full), "bias": int(st.pairs_bias), "vit": int(st.pairs_vit),
                             "fwd": int(st.pairs_fwd), "dom": int(st.pairs_dom), "envelopes": int(st.envelopes)},
