@@ -37,10 +37,10 @@ constexpr u32 PAD4 = 0x1d1d1d1du;   // four PADCODE (29) residues
 constexpr u32 U_ZERO = 0x80008000u; // two cells with U = 0 in the -32768-offset representation
 
 template <int Q>
-__device__ __forceinline__ void ssv_row(u32 (&U)[Q], u32 &xE, const char *lds_lane, u32 x) {
+__device__ __forceinline__ void ssv_row(u32 (&U)[Q], u32 &xE, u32 &prev, const char *lds_base, u32 lane_off, u32 x) {
   constexpr int Qg = (Q + 3) / 4;
   constexpr int ROWB = Qg * 256;
-  const char *rowp = lds_lane + x * ROWB;
+  const char *rowp = lds_base + __umul24(x, (u32)ROWB) + lane_off;   // one v_mad_u32_u24
   u32 e[Qg * 4];
 #pragma unroll
   for (int g = 0; g < Qg; ++g) {
@@ -50,8 +50,9 @@ __device__ __forceinline__ void ssv_row(u32 (&U)[Q], u32 &xE, const char *lds_la
   // cell p=0 of each lane's first register comes from the previous lane's last register (high half)
   // and this lane's own last register (low half -> high half)
   const u32 last = U[Q - 1];
-  // lane 0 of each 16-lane row has no predecessor: it keeps `old` = the offset representation of U = 0
-  const u32 prev = (u32)__builtin_amdgcn_update_dpp((int)U_ZERO, (int)last, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+  // lane 0 of each 16-lane row has no predecessor: it keeps `old`.  `prev` is a persistent register that starts as the
+  // offset representation of U = 0 and is only ever overwritten in lanes 1..15, so no per-row re-initialisation is needed
+  prev = (u32)__builtin_amdgcn_update_dpp((int)prev, (int)last, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
   const u32 carry = __builtin_amdgcn_alignbit(last, prev, 16);
 #pragma unroll
   for (int q = Q - 1; q >= 1; --q) {
@@ -83,7 +84,7 @@ __global__ void __launch_bounds__(Q > 40 ? 512 : 1024) ssv_kernel(const SsvBlock
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int seg = lane >> 4, z = lane & 15;
-  const char *lds_lane = smem + z * 16;
+  const u32 lane_off = (u32)z * 16u;
   for (u32 g = wave; g * 4 < w.count; g += nwaves) {
     const u32 li = g * 4 + seg;
     const bool valid = li < w.count;
@@ -97,7 +98,7 @@ __global__ void __launch_bounds__(Q > 40 ? 512 : 1024) ssv_kernel(const SsvBlock
     u32 U[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) U[q] = U_ZERO;
-    u32 xE = U_ZERO;
+    u32 xE = U_ZERO, prev = U_ZERO;
     const int nchunk = (Lmax + 15) >> 4;
     const uint4 padv = make_uint4(PAD4, PAD4, PAD4, PAD4);
     uint4 cur = padv;
@@ -106,10 +107,10 @@ __global__ void __launch_bounds__(Q > 40 ? 512 : 1024) ssv_kernel(const SsvBlock
       uint4 nxt = padv;
       if ((c + 1) * 16 < L) nxt = *reinterpret_cast<const uint4 *>(rp + (c + 1) * 16);
 #define CKM_SSV_WORD(wd)                                   \
-  ssv_row<Q>(U, xE, lds_lane, (wd) & 0xffu);               \
-  ssv_row<Q>(U, xE, lds_lane, ((wd) >> 8) & 0xffu);        \
-  ssv_row<Q>(U, xE, lds_lane, ((wd) >> 16) & 0xffu);       \
-  ssv_row<Q>(U, xE, lds_lane, (wd) >> 24);
+  ssv_row<Q>(U, xE, prev, smem, lane_off, (wd) & 0xffu);               \
+  ssv_row<Q>(U, xE, prev, smem, lane_off, ((wd) >> 8) & 0xffu);        \
+  ssv_row<Q>(U, xE, prev, smem, lane_off, ((wd) >> 16) & 0xffu);       \
+  ssv_row<Q>(U, xE, prev, smem, lane_off, (wd) >> 24);
       CKM_SSV_WORD(cur.x) CKM_SSV_WORD(cur.y) CKM_SSV_WORD(cur.z) CKM_SSV_WORD(cur.w)
 #undef CKM_SSV_WORD
       cur = nxt;
