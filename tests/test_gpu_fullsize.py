@@ -1,0 +1,99 @@
+"""Full-shape checks (cfg2 of BASELINE.json: the 43-profile DB against 2000-ORF bins) through properties
+that do not need the oracle to finish a full-size run: determinism, bin independence (sharding and
+permutation invariance -- what the multi-GPU path relies on), recovery of every planted marker, and
+oracle spot checks on sampled pairs."""
+import numpy as np
+import pytest
+
+from checkm_amd import _lib, qa as cqa, synth
+from oracle import p7
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+NBINS = 12
+
+
+@pytest.fixture(scope="module")
+def world(gpu_ctx):
+    profs = synth.cpr43_profiles()
+    path = common.hmm_file("cpr43", profs)
+    bins = [synth.make_bin(profs, 1000 + b, n_orfs=2000) for b in range(NBINS)]
+    prof = _lib.Profiles(gpu_ctx, path)
+    yield dict(ctx=gpu_ctx, profs=profs, path=path, bins=bins, prof=prof)
+    prof.close()
+
+
+def _rows(hits, b, seq_base=0):
+    r = list(hits.rows(b))
+    return [(int(hits.seq[i]) - seq_base, int(hits.model[i]), float(hits.full_evalue[i]), np.float32(hits.full_score[i]).view(np.uint32),
+             np.float32(hits.dom_score[i]).view(np.uint32), int(hits.hmm_from[i]), int(hits.hmm_to[i]), int(hits.ali_from[i]), int(hits.ali_to[i]),
+             int(hits.env_from[i]), int(hits.env_to[i]), float(hits.c_evalue[i])) for i in r]
+
+
+def test_determinism_sharding_and_permutation(world):
+    w = world
+    ctx, prof, bins = w["ctx"], w["prof"], w["bins"]
+    seqs = _lib.Seqs(ctx, bins)
+    h1 = _lib.search(ctx, prof, seqs)
+    h2 = _lib.search(ctx, prof, seqs)
+    base = np.concatenate([[0], np.cumsum([len(b) for b in bins])])
+    ref = [_rows(h1, b, int(base[b])) for b in range(NBINS)]
+    assert ref == [_rows(h2, b, int(base[b])) for b in range(NBINS)]            # same call twice: identical, atomics notwithstanding
+    assert sum(len(r) for r in ref) >= NBINS * 40
+    h1.close(); h2.close(); seqs.close()
+    # shard the bins over two "ranks": per-bin rows must not change (Z and domZ are per bin)
+    for shard in ([0, 2, 4, 6, 8, 10], [1, 3, 5, 7, 9, 11]):
+        s2 = _lib.Seqs(ctx, [bins[b] for b in shard])
+        h = _lib.search(ctx, prof, s2)
+        b2 = np.concatenate([[0], np.cumsum([len(bins[b]) for b in shard])])
+        for k, b in enumerate(shard):
+            assert _rows(h, k, int(b2[k])) == ref[b], b
+        h.close(); s2.close()
+    # reversed bin order
+    order = list(range(NBINS))[::-1]
+    s3 = _lib.Seqs(ctx, [bins[b] for b in order])
+    h = _lib.search(ctx, prof, s3)
+    b3 = np.concatenate([[0], np.cumsum([len(bins[b]) for b in order])])
+    for k, b in enumerate(order):
+        assert _rows(h, k, int(b3[k])) == ref[b], b
+    h.close(); s3.close()
+
+
+def test_planted_markers_are_recovered_and_reduced(world):
+    w = world
+    ctx, prof, bins = w["ctx"], w["prof"], w["bins"]
+    seqs = _lib.Seqs(ctx, bins)
+    hits = _lib.search(ctx, prof, seqs)
+    plan = cqa.QAPlan.for_hmm_models(prof, [list(range(prof.n))] * NBINS)
+    res = plan.reduce(ctx, hits, seqs)
+    st = ctx.stats()
+    assert st.pairs_ssv == NBINS * 2000 * 43 and st.residue_hmm == seqs.total_residues * 43
+    for b in range(NBINS):
+        found = set(int(hits.model[i]) for i in hits.rows(b))
+        assert len(found) == 43, (b, sorted(set(range(43)) - found))                  # every model has its planted ORF reported
+        assert res.hist[b].sum() == 43
+        assert res.hist[b][0] <= 3 and res.completeness[b] >= 93.0                      # split/duplicated plants may miss a cutoff, never more
+        assert 0.0 <= res.contamination[b] <= 15.0
+        # the float64 division of the reference, redone here from the integer outputs (one set of 43 markers)
+        nm = int(res.n_markers[b])
+        s0 = int(res.set_off[b])
+        assert res.completeness[b] == 100 * (float(int(res.set_present[s0])) / nm) / 1 and res.contamination[b] == 100 * (float(int(res.set_multi[s0])) / nm) / 1
+    res.close(); hits.close(); seqs.close()
+
+
+def test_sampled_pairs_against_the_oracle(world):
+    w = world
+    ctx, prof, bins = w["ctx"], w["prof"], w["bins"]
+    seqs = _lib.Seqs(ctx, bins[:2])
+    hs = p7.HmmSet(w["path"])
+    recs = bins[0] + bins[1]
+    rng = np.random.default_rng(11)
+    pairs = [(int(m), int(s)) for m, s in zip(rng.integers(0, 43, 160), rng.integers(0, len(recs), 160))]
+    got = _lib.debug_stages(ctx, prof, seqs, np.array([p[0] for p in pairs]), np.array([p[1] for p in pairs]))
+    for i, (m, s) in enumerate(pairs):
+        o = hs.stages(m, p7.digitize(recs[s][2]))
+        assert (o.msv_xJ, o.vit_xC, o.fwd_nscale) == (got[i].msv_xJ, got[i].vit_xC, got[i].fwd_nscale), (m, s)
+        for f in ("msv_sc", "bias_sc", "vit_sc", "fwd_sc", "fwd_xC"):
+            assert np.float32(getattr(o, f)).view(np.uint32) == np.float32(getattr(got[i], f)).view(np.uint32), (m, s, f)
+    hs.close(); seqs.close()
