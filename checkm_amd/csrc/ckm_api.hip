@@ -173,6 +173,7 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
     size_t fre = 0, tot = 0;
     size_t budget = (size_t)8 << 30;
     if (hipMemGetInfo(&fre, &tot) == hipSuccess) budget = std::min<size_t>((size_t)96 << 30, fre / 2) / ctx->nworkers;
+    if (const char *e = getenv("CKM_WS_BUDGET_MB")) budget = std::max<size_t>(16, strtoull(e, nullptr, 10)) << 20;   // tests: force several envelope batches
     for (auto &w : ctx->w) {
       w.device = device;
       HIPCHK(hipStreamCreate(&w.stream));
@@ -554,7 +555,8 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
   // ---- stage 1: SSV over every pair, chunked by a pair budget ----
   std::vector<Cand> cands;
   {
-    const uint64_t pair_budget = (uint64_t)1 << 29;
+    uint64_t pair_budget = (uint64_t)1 << 29;                  // pairs per SSV chunk (2 B of maxV each); CKM_PAIR_BUDGET overrides (tests)
+    if (const char *e = getenv("CKM_PAIR_BUDGET")) pair_budget = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
     size_t i0 = 0;
     while (i0 < my_models.size()) {
       // gather models of this chunk; every distinct sequence list gets one device array

@@ -203,3 +203,40 @@ def test_large_models_and_error_paths(gpu_ctx, tmp_path):
     with pytest.raises(_lib.CkmError) as e:
         _lib.Profiles(gpu_ctx, str(uncal))
     assert e.value.code == -3 and "calibrated" in str(e.value)
+
+
+def test_chunked_execution_equals_single_pass(world):
+    """Tiny budgets force several SSV chunks and several envelope batches; rows must not change."""
+    import subprocess
+    import sys
+    import json
+    import os
+    w = world
+    hits = _lib.search(w["ctx"], w["prof"], w["seqs"])
+    ref = [[int(hits.seq[i]), int(hits.model[i]), int(hits.ali_from[i]), int(hits.ali_to[i]), int(np.float32(hits.full_score[i]).view(np.uint32)),
+            float(hits.full_evalue[i])] for i in range(hits.n)]
+    single_pass_launches = int(w["ctx"].stats().ssv_launches)
+    hits.close()
+    code = r'''
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np
+from checkm_amd import _lib, synth
+from tests import common
+profs = common.mixed_profiles(); path = common.hmm_file("mixed", profs)
+bins = [synth.make_bin(profs, 1000 + b, n_orfs=160, dup_frac=0.4) for b in range(2)]
+rng = np.random.default_rng(5)
+bins[1] += [("edge_1", "", "M*"), ("edge_2", "", "XXXXXXXXXXXXXXXXXXXXXXXXXXXXXX*"), ("edge_3", "", "ACDEFGHIKLMNPQRSTVWY"),
+            ("edge_4", "", synth.to_text(synth.random_residues(rng, 3100)) + "*"), ("edge_5", "", "BJZOUX*acdefghiklmnpqrstvwy")]
+ctx = _lib.Context(0); prof = _lib.Profiles(ctx, path); seqs = _lib.Seqs(ctx, bins)
+hits = _lib.search(ctx, prof, seqs)
+st = ctx.stats()
+print(json.dumps({"rows": [[int(hits.seq[i]), int(hits.model[i]), int(hits.ali_from[i]), int(hits.ali_to[i]), int(np.float32(hits.full_score[i]).view(np.uint32)),
+      float(hits.full_evalue[i])] for i in range(hits.n)], "launches": int(st.ssv_launches)}))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CKM_PAIR_BUDGET="700", CKM_WS_BUDGET_MB="64")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads(out.stdout.strip().split("\n")[-1])
+    assert got["rows"] == ref
+    assert got["launches"] > single_pass_launches          # several model chunks, each with its own launches
