@@ -109,7 +109,6 @@ struct ckm_profiles {
   int maxMp = 0;
 };
 
-struct SeqList { std::vector<uint32_t> ids; DevBuf d_ids; uint64_t total_res = 0; uint64_t uid = 0; };
 
 struct ckm_seqs {
   ckm_ctx *ctx = nullptr;
@@ -124,7 +123,11 @@ struct ckm_seqs {
   DevBuf d_res, d_off, d_len, d_lentab;
   uint64_t total_res = 0;
   int maxL = 0;
-  mutable std::map<std::vector<uint32_t>, std::unique_ptr<SeqList>> lists;   // bins -> length-sorted sequence ids
+  // ONE order of all non-empty sequences: grouped by bin, longest first inside a bin.  SSV blocks index ranges of it,
+  // so per-bin model subsets (lineage_wf) need no per-model lists.
+  std::vector<uint32_t> order, order_off;      // order_off[b] .. order_off[b+1]
+  std::vector<uint64_t> bin_res;               // residues of bin b
+  DevBuf d_order;
 };
 
 struct ckm_hits {
@@ -318,10 +321,20 @@ extern "C" int ckm_seqs_pack(ckm_ctx *ctx, const char *text, const uint64_t *seq
       if (names && names[i]) s->names[i] = names[i]; else s->names[i] = "seq" + std::to_string(i);
       if (descs && descs[i]) s->descs[i] = descs[i];
     }
+    s->order_off.assign(nbins + 1, 0); s->bin_res.assign(nbins, 0);
+    for (uint32_t b = 0; b < nbins; ++b) {
+      s->order_off[b] = (uint32_t)s->order.size();
+      const size_t first = s->order.size();
+      for (uint32_t i = bin_off[b]; i < bin_off[b + 1]; ++i) if (s->len[i] > 0) { s->order.push_back(i); s->bin_res[b] += (uint64_t)s->len[i]; }
+      std::stable_sort(s->order.begin() + first, s->order.end(), [&](uint32_t x, uint32_t y) { return s->len[x] > s->len[y]; });
+    }
+    s->order_off[nbins] = (uint32_t)s->order.size();
     build_lentab(s.get());
     s->d_res.ensure(s->dsq.size()); HIPCHK(hipMemcpy(s->d_res.p, s->dsq.data(), s->dsq.size(), hipMemcpyHostToDevice));
     s->d_off.ensure(std::max<size_t>(8, nseq * 8)); HIPCHK(hipMemcpy(s->d_off.p, s->off.data(), (size_t)nseq * 8, hipMemcpyHostToDevice));
     s->d_len.ensure(std::max<size_t>(4, nseq * 4)); HIPCHK(hipMemcpy(s->d_len.p, s->len.data(), (size_t)nseq * 4, hipMemcpyHostToDevice));
+    s->d_order.ensure(std::max<size_t>(4, s->order.size() * 4));
+    if (!s->order.empty()) HIPCHK(hipMemcpy(s->d_order.p, s->order.data(), s->order.size() * 4, hipMemcpyHostToDevice));
     s->d_lentab.ensure(s->lentab.size() * sizeof(LenEntry));
     HIPCHK(hipMemcpy(s->d_lentab.p, s->lentab.data(), s->lentab.size() * sizeof(LenEntry), hipMemcpyHostToDevice));
     *out = s.release();
@@ -362,21 +375,6 @@ struct Cand {            // a pair that survived the MSV stage
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 float bits(float sc, float nullsc) { return (float)((double)(sc - nullsc) / kLn2); }
-
-const SeqList *get_list(const ckm_seqs *s, const std::vector<uint32_t> &bins) {
-  auto it = s->lists.find(bins);
-  if (it != s->lists.end()) return it->second.get();
-  std::unique_ptr<SeqList> l(new SeqList());
-  l->uid = g_uid++;
-  for (uint32_t b : bins) for (uint32_t i = s->bin_off[b]; i < s->bin_off[b + 1]; ++i) if (s->len[i] > 0) l->ids.push_back(i);
-  std::stable_sort(l->ids.begin(), l->ids.end(), [&](uint32_t a, uint32_t b) { return s->len[a] > s->len[b]; });
-  for (uint32_t id : l->ids) l->total_res += (uint64_t)s->len[id];
-  l->d_ids.ensure(std::max<size_t>(4, l->ids.size() * 4));
-  if (!l->ids.empty()) HIPCHK(hipMemcpy(l->d_ids.p, l->ids.data(), l->ids.size() * 4, hipMemcpyHostToDevice));
-  const SeqList *r = l.get();
-  s->lists.emplace(bins, std::move(l));
-  return r;
-}
 
 // host-side completion of a Forward score from the device's scaled xC and its rescale events
 float finish_forward(float xC, float move, const std::vector<float> &scales) {
@@ -568,24 +566,25 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
     if (const char *e = getenv("CKM_PAIR_BUDGET")) pair_budget = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
     size_t i0 = 0;
     while (i0 < my_models.size()) {
-      // gather models of this chunk; every distinct sequence list gets one device array
-      struct MW { uint32_t model; const SeqList *list; uint64_t pair_base; };
+      // gather models of this chunk
+      struct MW { uint32_t model; uint64_t pair_base; uint64_t npairs; };
       const bool i0_was_first = (i0 == 0);
       std::vector<MW> mws; uint64_t npairs = 0; size_t i1 = i0;
       for (; i1 < my_models.size(); ++i1) {
         const uint32_t m1 = my_models[i1];
-        if (model_bins[m1].empty()) continue;
-        const SeqList *l = get_list(s, model_bins[m1]);      // cached by do_search before the workers start
-        if (npairs + l->ids.size() > pair_budget && !mws.empty()) break;
-        mws.push_back({m1, l, npairs}); npairs += l->ids.size();
+        uint64_t n = 0;
+        for (uint32_t b : model_bins[m1]) n += s->order_off[b + 1] - s->order_off[b];
+        if (n == 0) continue;
+        if (npairs + n > pair_budget && !mws.empty()) break;
+        mws.push_back({m1, npairs, n}); npairs += n;
       }
       i0 = i1;
       if (mws.empty() || npairs == 0) continue;
       std::unique_lock<std::mutex> ssv_lock(*ssv_mutex);     // one SSV phase at a time (VALU-bound); released after the finish kernel
-      // The block tables depend only on (profiles, sequences, models of this chunk): reuse the resident ones when the
+      // The block table depends only on (profiles, sequences, models and their bins): reuse the resident one when the
       // previous call on this worker had the same plan (lineage_wf scans the same bins twice; bench repeats steps).
       std::vector<uint64_t> key{p->uid, s->uid, pair_budget, (uint64_t)i0};
-      for (auto &mw : mws) { key.push_back(mw.model); key.push_back(mw.list->uid); }
+      for (auto &mw : mws) { key.push_back(0xffffffffull + mw.model); for (uint32_t b : model_bins[mw.model]) key.push_back(b); }
       std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;
       size_t nblocks_total = 0;
       const bool single_chunk = (i1 == my_models.size() && i0_was_first);
@@ -593,29 +592,34 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
         groups = ctx->plan_groups; nblocks_total = ctx->plan_nblocks;
         st.pairs_ssv += ctx->plan_pairs; st.residue_hmm += ctx->plan_residue_hmm; st.cells_ssv += ctx->plan_cells;
       } else {
-        // the kernels index ONE lists[] array: concatenate the distinct lists of this chunk
-        std::map<const SeqList *, uint32_t> list_base; std::vector<uint32_t> all_ids;
-        for (auto &mw : mws) if (!list_base.count(mw.list)) { list_base[mw.list] = (uint32_t)all_ids.size(); all_ids.insert(all_ids.end(), mw.list->ids.begin(), mw.list->ids.end()); }
-        ctx->idx.ensure(all_ids.size() * 4);
-        HIPCHK(hipMemcpyAsync(ctx->idx.p, all_ids.data(), all_ids.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         std::map<int, std::vector<SsvBlockWork>> byQ;
         uint64_t c_pairs = 0, c_res = 0, c_cells = 0;
         for (auto &mw : mws) {
           const int Q = p->prof[mw.model].ssvQ; const int threads = ssv_threads_for(Q); const uint32_t per_block = (uint32_t)threads / 64 * 4 * 4;
-          const uint32_t n = (uint32_t)mw.list->ids.size();
-          for (uint32_t a = 0; a < n; a += per_block) {
-            SsvBlockWork w; w.model = mw.model; w.list_start = list_base[mw.list] + a; w.count = std::min(per_block, n - a); w.pair_start = (uint32_t)(mw.pair_base + a);
-            byQ[Q].push_back(w);
+          uint64_t pb = mw.pair_base;
+          for (uint32_t b : model_bins[mw.model]) {
+            const uint32_t o0 = s->order_off[b], n = s->order_off[b + 1] - o0;
+            for (uint32_t a = 0; a < n; a += per_block) {
+              SsvBlockWork w; w.model = mw.model; w.list_start = o0 + a; w.count = std::min(per_block, n - a); w.pair_start = (uint32_t)(pb + a);
+              byQ[Q].push_back(w);
+            }
+            pb += n; c_res += s->bin_res[b]; c_cells += s->bin_res[b] * (uint64_t)p->prof[mw.model].M;
           }
-          c_pairs += n; c_res += mw.list->total_res; c_cells += mw.list->total_res * (uint64_t)p->prof[mw.model].M;
+          c_pairs += mw.npairs;
         }
         st.pairs_ssv += c_pairs; st.residue_hmm += c_res; st.cells_ssv += c_cells;
         std::vector<SsvBlockWork> allw;
-        for (auto &kv : byQ) { groups.push_back({kv.first, {allw.size(), kv.second.size()}}); allw.insert(allw.end(), kv.second.begin(), kv.second.end()); }
+        for (auto &kv : byQ) {
+          // longest blocks first inside a launch (a block's time is set by its first = longest sequence): without this
+          // the few very long sequences of each bin start late and leave most CUs idle at the end of every launch
+          std::stable_sort(kv.second.begin(), kv.second.end(), [&](const SsvBlockWork &x, const SsvBlockWork &y) {
+            return s->len[s->order[x.list_start]] > s->len[s->order[y.list_start]]; });
+          groups.push_back({kv.first, {allw.size(), kv.second.size()}}); allw.insert(allw.end(), kv.second.begin(), kv.second.end());
+        }
         nblocks_total = allw.size();
         ctx->work.ensure(allw.size() * sizeof(SsvBlockWork));
         HIPCHK(hipMemcpyAsync(ctx->work.p, allw.data(), allw.size() * sizeof(SsvBlockWork), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));            // allw / all_ids go out of scope
+        HIPCHK(hipStreamSynchronize(ctx->stream));            // allw goes out of scope
         if (single_chunk) { ctx->plan_key = key; ctx->plan_groups = groups; ctx->plan_nblocks = nblocks_total; ctx->plan_pairs = c_pairs; ctx->plan_residue_hmm = c_res; ctx->plan_cells = c_cells; }
         else ctx->plan_key.clear();
       }
@@ -626,15 +630,22 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
         HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
         HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
         if (attempt == 0) {
-          for (auto &g : groups) {
-            if (launch_ssv(g.first, (int)g.second.second, ssv_threads_for(g.first), ctx->stream, ctx->work.as<SsvBlockWork>() + g.second.first, dm, res, off, dlen,
-                           ctx->idx.as<uint32_t>(), ctx->maxv.as<uint16_t>()))
+          // register classes go round-robin over 4 streams (heaviest first) so the tail of one launch -- a few very long
+          // sequences -- is covered by the next launch; ev[0]..ev[1] on the main stream brackets all of them
+          constexpr int NS = 4;
+          for (int k = 0; k < NS; ++k) HIPCHK(hipStreamWaitEvent(ctx->side[k], ctx->ev[0], 0));
+          int gi = 0;
+          for (auto it = groups.rbegin(); it != groups.rend(); ++it, ++gi) {
+            auto &g = *it;
+            if (launch_ssv(g.first, (int)g.second.second, ssv_threads_for(g.first), ctx->side[gi % NS], ctx->work.as<SsvBlockWork>() + g.second.first, dm, res, off, dlen,
+                           s->d_order.as<uint32_t>(), ctx->maxv.as<uint16_t>()))
               throw Error(CKM_ERANGE, "no SSV kernel instance for this model length");
             st.ssv_launches++;
           }
+          for (int k = 0; k < NS; ++k) { HIPCHK(hipEventRecord(ctx->ev[2 + k], ctx->side[k])); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev[2 + k], 0)); }
         }
         HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
-        FinishArgs fa{dm, lt, dlen, ctx->idx.as<uint32_t>(), ctx->work.as<SsvBlockWork>(), ctx->maxv.as<uint16_t>(),
+        FinishArgs fa{dm, lt, dlen, s->d_order.as<uint32_t>(), ctx->work.as<SsvBlockWork>(), ctx->maxv.as<uint16_t>(),
                       ctx->surv.as<PairRec>(), ctx->counters.as<uint32_t>(), cap_surv, ctx->nores.as<PairRec>(), ctx->counters.as<uint32_t>() + 1, cap_nores};
         launch_msv_finish(ctx->stream, fa, (uint32_t)nblocks_total);
         HIPCHK(hipGetLastError());
@@ -874,7 +885,7 @@ static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, cons
   }
   // models -> workers: deal them out by decreasing work (pairs x M) so both chunks cost about the same
   std::vector<uint32_t> active; std::vector<double> cost(nmodels, 0.0);
-  for (uint32_t m = 0; m < nmodels; ++m) if (!model_bins[m].empty()) { active.push_back(m); cost[m] = (double)get_list(s, model_bins[m])->ids.size() * p->prof[m].M; }
+  for (uint32_t m = 0; m < nmodels; ++m) if (!model_bins[m].empty()) { active.push_back(m); double n = 0; for (uint32_t b : model_bins[m]) n += (double)s->bin_res[b]; cost[m] = n * p->prof[m].M; }
   std::stable_sort(active.begin(), active.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
   const int nw = (active.size() >= 2 * (size_t)c->nworkers) ? c->nworkers : 1;
   std::vector<std::vector<uint32_t>> chunk(nw); std::vector<double> load(nw, 0.0);
