@@ -712,21 +712,28 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
     std::map<int, std::vector<uint32_t>> byQ;
     for (size_t i = 0; i < cands.size(); ++i) if (cands[i].alive && need_vit[i]) byQ[p->prof[cands[i].r.model].vitQH].push_back((uint32_t)i);
     std::vector<uint32_t> flat; std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;
-    for (auto &kv : byQ) { groups.push_back({kv.first, {flat.size(), kv.second.size()}}); flat.insert(flat.end(), kv.second.begin(), kv.second.end()); }
+    for (auto &kv : byQ) {
+      // (survivors were appended by SSV blocks that ran longest-first, so these lists are already roughly length-ordered)
+      groups.push_back({kv.first, {flat.size(), kv.second.size()}}); flat.insert(flat.end(), kv.second.begin(), kv.second.end());
+    }
     st.pairs_vit = flat.size();
     if (!flat.empty()) {
       for (size_t i = 0; i < cands.size(); ++i) cr[i] = cands[i].r;
       HIPCHK(hipMemcpyAsync(ctx->cand.p, cr.data(), cr.size() * sizeof(PairRec), hipMemcpyHostToDevice, ctx->stream));
       ctx->fbidx.ensure(flat.size() * 4); ctx->vitx.ensure(cands.size() * 4); ctx->vits.ensure(cands.size() * 4);
       HIPCHK(hipMemcpyAsync(ctx->fbidx.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-      for (auto &g : groups)
-        if (launch_vit(g.first, ctx->stream, ctx->cand.as<PairRec>(), ctx->fbidx.as<uint32_t>() + g.second.first, (uint32_t)g.second.second, dm, lt, res, off, dlen,
-                       ctx->vitx.as<int32_t>(), ctx->vits.as<float>()))
-          throw Error(CKM_ERANGE, "no Viterbi kernel instance for this model length");
+      HIPCHK(hipStreamSynchronize(ctx->stream));            // uploads done; the launches go to the side streams
+      { int gi = 0;
+        for (auto it = groups.rbegin(); it != groups.rend(); ++it, ++gi) {
+          auto &g = *it;
+          if (launch_vit(g.first, ctx->side[gi % 4], ctx->cand.as<PairRec>(), ctx->fbidx.as<uint32_t>() + g.second.first, (uint32_t)g.second.second, dm, lt, res, off, dlen,
+                         ctx->vitx.as<int32_t>(), ctx->vits.as<float>()))
+            throw Error(CKM_ERANGE, "no Viterbi kernel instance for this model length");
+        } }
       HIPCHK(hipGetLastError());
+      for (int k = 0; k < 4; ++k) HIPCHK(hipStreamSynchronize(ctx->side[k]));
       std::vector<float> vsc(cands.size());
-      HIPCHK(hipMemcpyAsync(vsc.data(), ctx->vits.p, cands.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(hipStreamSynchronize(ctx->stream));
+      HIPCHK(hipMemcpy(vsc.data(), ctx->vits.p, cands.size() * 4, hipMemcpyDeviceToHost));
       for (uint32_t i : flat) { Cand &c = cands[i]; if (!(bits(vsc[i], c.r.filtersc) >= p->prof[c.r.model].thr_vit_f2)) c.alive = false; }
     }
   }
