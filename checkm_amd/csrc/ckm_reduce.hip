@@ -13,6 +13,7 @@
 // runs on the device: one thread per collocated set, one wave-level histogram per bin.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <charconv>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -148,10 +149,22 @@ static bool orf_number(const std::string &n, long long &out) {
   return true;
 }
 
-static double text_round(const char *fmt, double v) {
+// The value a reader of the domtblout TEXT gets back: %6.1f for scores, %9.2g for E-values (checkm/hmmer.py:270-277).
+// std::to_chars/from_chars are correctly rounded like printf/strtod and several times faster.
+static double text_round_f1(double v) {            // strtod(sprintf("%.1f", v))
   char buf[64];
-  snprintf(buf, sizeof(buf), fmt, v);
-  return strtod(buf, nullptr);
+  auto r = std::to_chars(buf, buf + sizeof(buf), v, std::chars_format::fixed, 1);
+  double out = 0.0;
+  std::from_chars(buf, r.ptr, out);
+  return out;
+}
+static double text_round_g2(double v) {            // strtod(sprintf("%.2g", v)): two significant digits in either notation
+  if (!(v == v) || v == 0.0 || std::isinf(v)) return v;
+  char buf[64];
+  auto r = std::to_chars(buf, buf + sizeof(buf), v, std::chars_format::scientific, 1);
+  double out = 0.0;
+  std::from_chars(buf, r.ptr, out);
+  return out;
 }
 
 struct OrderedHits {   // dict key -> list, Python insertion order
@@ -318,8 +331,8 @@ extern "C" int ckm_reduce(ckm_ctx *ctx, const ckm_hits *h, const ckm_hit_columns
         x.tlen = cols.tlen[r]; x.qlen = cols.qlen[r];
         x.hmm_from = cols.hmm_from[r]; x.hmm_to = cols.hmm_to[r]; x.ali_from = cols.ali_from[r]; x.ali_to = cols.ali_to[r]; x.env_from = cols.env_from[r]; x.env_to = cols.env_to[r];
         if (from_search) {   // the reference sees these through the domtblout text: %9.2g and %6.1f (checkm/hmmer.py:270-277)
-          x.full_e = text_round("%9.2g", cols.full_evalue[r]); x.i_e = text_round("%9.2g", cols.i_evalue[r]);
-          x.full_sc = text_round("%6.1f", (double)cols.full_score[r]); x.dom_sc = text_round("%6.1f", (double)cols.dom_score[r]);
+          x.full_e = text_round_g2(cols.full_evalue[r]); x.i_e = text_round_g2(cols.i_evalue[r]);
+          x.full_sc = text_round_f1((double)cols.full_score[r]); x.dom_sc = text_round_f1((double)cols.dom_score[r]);
         } else { x.full_e = cols.full_evalue[r]; x.i_e = cols.i_evalue[r]; x.full_sc = (double)cols.full_score[r]; x.dom_sc = (double)cols.dom_score[r]; }
         if (!vet_hit(x, mi, fl)) continue;
         // addHit: one domain per (marker, ORF); a strictly better one replaces and moves to the tail
