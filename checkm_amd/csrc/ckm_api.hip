@@ -64,6 +64,20 @@ struct DevBuf {
   ~DevBuf() { if (p) (void)hipFree(p); }
 };
 
+struct PinnedBuf {      // grow-only page-locked host staging buffer (pageable D2H copies run at a fraction of PCIe speed)
+  void *p = nullptr; size_t cap = 0;
+  void ensure(size_t bytes) {
+    if (bytes <= cap) return;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; throw Error(CKM_ENOMEM, "hipHostMalloc failed"); }
+    cap = want;
+  }
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+};
+
 }  // namespace ckm
 
 using namespace ckm;
@@ -81,6 +95,7 @@ struct Worker {
   std::vector<uint64_t> plan_key;         // identifies the SSV block tables currently resident in `work` / `idx`
   std::vector<std::pair<int, std::pair<size_t, size_t>>> plan_groups;
   uint64_t plan_npairs = 0, plan_nblocks = 0, plan_residue_hmm = 0, plan_cells = 0, plan_pairs = 0;
+  PinnedBuf h_a, h_b;                     // D2H staging
   DevBuf work, maxv, surv, nores, counters, cand, raw, idx, vitx, vits, fbwork, fbidx, fbmodel, ws, fout, events, rerr, envout, fullx, fullu;
   size_t ws_budget = (size_t)8 << 30;     // float workspace budget (bytes) for Forward/Backward matrices
 };
@@ -654,11 +669,14 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (attempt == 0) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); st.ms_ssv += ms; }
         if (cnt[0] > cap_surv || cnt[1] > cap_nores) { cap_surv = std::max(cap_surv, cnt[0]); cap_nores = std::max(cap_nores, cnt[1]); continue; }
-        std::vector<PairRec> sv(cnt[0]), nr(cnt[1]);
-        if (cnt[0]) HIPCHK(hipMemcpy(sv.data(), ctx->surv.p, (size_t)cnt[0] * sizeof(PairRec), hipMemcpyDeviceToHost));
+        std::vector<PairRec> nr(cnt[1]);
+        ctx->h_a.ensure((size_t)cnt[0] * sizeof(PairRec) + 16);
+        const PairRec *sv = ctx->h_a.as<PairRec>();
+        if (cnt[0]) HIPCHK(hipMemcpy(ctx->h_a.p, ctx->surv.p, (size_t)cnt[0] * sizeof(PairRec), hipMemcpyDeviceToHost));
         if (cnt[1]) HIPCHK(hipMemcpy(nr.data(), ctx->nores.p, (size_t)cnt[1] * sizeof(PairRec), hipMemcpyDeviceToHost));
         ssv_lock.unlock();
-        for (auto &r : sv) { Cand c; c.r = r; c.alive = true; c.fwdsc = 0; c.fwd_xC = 0; c.slot = 0; cands.push_back(c); }
+        cands.reserve(cands.size() + cnt[0]);
+        for (uint32_t k = 0; k < cnt[0]; ++k) { Cand c; c.r = sv[k]; c.alive = true; c.fwdsc = 0; c.fwd_xC = 0; c.slot = 0; cands.push_back(c); }
         if (!nr.empty()) {     // exact multi-hit MSV for the pairs where J could be used
           st.pairs_msv_full += nr.size();
           ctx->fullx.ensure(nr.size() * 4); ctx->fullu.ensure(nr.size() * 4);
@@ -690,8 +708,9 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
     HIPCHK(hipMemcpyAsync(ctx->cand.p, cr.data(), cr.size() * sizeof(PairRec), hipMemcpyHostToDevice, ctx->stream));
     launch_bias(ctx->stream, ctx->cand.as<PairRec>(), (uint32_t)cr.size(), dm, lt, res, off, dlen, ctx->raw.as<float>());
     HIPCHK(hipGetLastError());
-    std::vector<float> raw(cr.size() * 3);
-    HIPCHK(hipMemcpyAsync(raw.data(), ctx->raw.p, raw.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->h_a.ensure(cr.size() * 12 + 16);
+    const float *raw = ctx->h_a.as<float>();
+    HIPCHK(hipMemcpyAsync(ctx->h_a.p, ctx->raw.p, cr.size() * 12, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i < cands.size(); ++i) {
       Cand &c = cands[i];
@@ -732,8 +751,9 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
         } }
       HIPCHK(hipGetLastError());
       for (int k = 0; k < 4; ++k) HIPCHK(hipStreamSynchronize(ctx->side[k]));
-      std::vector<float> vsc(cands.size());
-      HIPCHK(hipMemcpy(vsc.data(), ctx->vits.p, cands.size() * 4, hipMemcpyDeviceToHost));
+      ctx->h_a.ensure(cands.size() * 4 + 16);
+      const float *vsc = ctx->h_a.as<float>();
+      HIPCHK(hipMemcpy(ctx->h_a.p, ctx->vits.p, cands.size() * 4, hipMemcpyDeviceToHost));
       for (uint32_t i : flat) { Cand &c = cands[i]; if (!(bits(vsc[i], c.r.filtersc) >= p->prof[c.r.model].thr_vit_f2)) c.alive = false; }
     }
   }
@@ -777,12 +797,13 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
     for (uint32_t k : passers) { fb.work[k].aux_off = ap; ap += ((uint64_t)(fb.work[k].Ld + 1) * 3 + 31) & ~(uint64_t)31; }
     run_fb(ctx, p, s, fb, false, true, false, &passers);
     // pull the decoding terms of the passers in one copy
-    std::vector<float> dec_all(ap - aux_base);
+    std::vector<float> dec_all(ap - aux_base);     // pageable on purpose: the region scan below re-reads it; pinned memory reads slowly from the CPU
+    const float *dec_all_p = dec_all.data();
     if (!dec_all.empty()) HIPCHK(hipMemcpy(dec_all.data(), ctx->ws.as<float>() + aux_base, dec_all.size() * 4, hipMemcpyDeviceToHost));
     for (size_t q = 0; q < passers.size(); ++q) {
       const FbWork &w = fb.work[passers[q]];
       const int L = w.Ld;
-      const float *dec = dec_all.data() + (w.aux_off - aux_base);
+      const float *dec = dec_all_p + (w.aux_off - aux_base);
       std::vector<float> btot(L + 1, 0.f), etot(L + 1, 0.f), mocc(L + 1, 0.f);
       for (int i = 1; i <= L; ++i) { btot[i] = btot[i - 1] + dec[(size_t)i * 3]; etot[i] = etot[i - 1] + dec[(size_t)i * 3 + 1]; mocc[i] = 1.0f - dec[(size_t)i * 3 + 2]; }
       env_of_pass[q].first = envreq.size();
