@@ -76,13 +76,6 @@ struct FinishArgs {
   PairRec *noresult;  uint32_t *nnores; uint32_t cap_nores;
 };
 
-struct EnvWork {             // one envelope to rescore
-  uint32_t model, seq;
-  int32_t  ienv, jenv;       // 1-based inclusive
-  uint64_t mx_off;           // float offset of this envelope's matrices in the workspace
-  uint64_t xs_off;           // float offset of its special rows
-};
-
 struct EnvOut {
   float   xC; int32_t nscale;
   float   oasc;

@@ -1,7 +1,7 @@
 // kernels_filter.hip -- the rest of the acceleration-filter cascade, gfx950 only:
 //   msv_finish_kernel  turns SSV maxV into the MSV byte score, applies F1, appends survivors
 //   msv_full_kernel    full multi-hit MSV for the rare pairs whose J state could be used
-//   bias_kernel        2-state composition filter (Forward, power-of-two rescaling), F1 again, F2 shortcut
+//   bias_kernel        2-state composition filter (Forward, power-of-two rescaling); F1/F2 tests follow on the host
 //   vit_kernel<QH>     16-bit Viterbi filter, one wavefront per pair, packed words, lazy-F D->D passes
 // Reference stage being replaced: the MSV -> bias -> Viterbi part of hmmsearch's per-target pipeline
 // (process launched at checkm/hmmer.py:70 with the options of checkm/markerGeneFinder.py:141).
@@ -125,11 +125,11 @@ __global__ void msv_full_kernel(const PairRec *__restrict__ pairs, uint32_t npai
 // --------------------------------------------------------------------------------------------
 // bias filter: one thread per pair
 // --------------------------------------------------------------------------------------------
-// out flags: bit0 pass F1 after bias; bit1 needs Viterbi (P > F2)
-__global__ void bias_kernel(PairRec *__restrict__ pairs, uint32_t npairs, const DevModel *__restrict__ models,
-                            const LenEntry *__restrict__ lentab, const uint8_t *__restrict__ res,
-                            const uint64_t *__restrict__ seq_off, const int32_t *__restrict__ seq_len,
-                            uint8_t *__restrict__ flags, float *__restrict__ dbg_d /* optional [npairs*3]: d0 d1 nexp */) {
+// Output per pair: [0] d0+d1 (the two states' scaled Forward mass), [1] power-of-two exponent, [2] unused.
+// The logarithm and the F1/F2 tests are taken on the host (same libm as every other score).
+__global__ void bias_kernel(const PairRec *__restrict__ pairs, uint32_t npairs, const DevModel *__restrict__ models,
+                            const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off, const int32_t *__restrict__ seq_len,
+                            float *__restrict__ dbg_d) {
   const uint32_t pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= npairs) return;
   PairRec pr = pairs[pi];
@@ -146,11 +146,9 @@ __global__ void bias_kernel(PairRec *__restrict__ pairs, uint32_t npairs, const 
     if (mx < 0x1p-40f) { d0 *= 0x1p64f; d1 *= 0x1p64f; nexp -= 64; }
     else if (mx > 0x1p40f) { d0 *= 0x1p-64f; d1 *= 0x1p-64f; nexp += 64; }
   }
-  // the log of (d0+d1) is taken on the host (same libm as every other score); here only the raw state
   dbg_d[(size_t)pi * 3 + 0] = d0 + d1;
   dbg_d[(size_t)pi * 3 + 1] = (float)nexp;
   dbg_d[(size_t)pi * 3 + 2] = 0.f;
-  (void)flags; (void)lentab;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -292,8 +290,8 @@ void launch_msv_full(hipStream_t stream, const PairRec *pairs, uint32_t npairs, 
 void launch_bias(hipStream_t stream, PairRec *pairs, uint32_t npairs, const DevModel *models, const LenEntry *lentab,
                  const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, float *raw) {
   if (!npairs) return;
-  hipLaunchKernelGGL(bias_kernel, dim3((npairs + 127) / 128), dim3(128), 0, stream, pairs, npairs, models, lentab, res, seq_off, seq_len,
-                     (uint8_t *)nullptr, raw);
+  (void)lentab;
+  hipLaunchKernelGGL(bias_kernel, dim3((npairs + 127) / 128), dim3(128), 0, stream, pairs, npairs, models, res, seq_off, seq_len, raw);
 }
 
 }  // namespace ckm
