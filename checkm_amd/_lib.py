@@ -92,7 +92,7 @@ class QAColumns(C.Structure):
 # every symbol include/checkm_hip.h declares
 EXPORTS = ["ckm_last_error", "ckm_abi_version", "ckm_device_count", "ckm_ctx_create", "ckm_ctx_destroy",
            "ckm_profiles_load", "ckm_profiles_count", "ckm_profiles_header", "ckm_profiles_free",
-           "ckm_seqs_pack", "ckm_seqs_residues", "ckm_seqs_free", "ckm_search", "ckm_hits_columns", "ckm_hits_free",
+           "ckm_seqs_pack", "ckm_seqs_from_fasta", "ckm_seqs_count", "ckm_seqs_bin_offsets", "ckm_seqs_name", "ckm_seqs_residues", "ckm_seqs_free", "ckm_search", "ckm_hits_columns", "ckm_hits_free",
            "ckm_hits_write_domtblout", "ckm_last_search_stats", "ckm_reduce", "ckm_qa_columns_get", "ckm_qa_free", "ckm_count_sets",
            "ckm_debug_stages", "ckm_debug_envelopes"]
 
@@ -120,6 +120,10 @@ def load():
     L.ckm_profiles_free.restype = None
     L.ckm_seqs_pack.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                 C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]
+    L.ckm_seqs_from_fasta.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_void_p)]
+    L.ckm_seqs_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.ckm_seqs_bin_offsets.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32))]
+    L.ckm_seqs_name.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]
     L.ckm_seqs_residues.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.ckm_seqs_free.argtypes = [C.c_void_p]
     L.ckm_seqs_free.restype = None
@@ -196,8 +200,48 @@ class Profiles(object):
             self.h = C.c_void_p()
 
 
+class _LazyStrings(object):
+    """names[i] / descs[i] fetched from the library on demand (millions of ORFs need no Python list)."""
+
+    def __init__(self, seqs, which):
+        self.seqs, self.which, self.cache = seqs, which, {}
+
+    def __len__(self):
+        return self.seqs.nseq
+
+    def __getitem__(self, i):
+        v = self.cache.get(i)
+        if v is None:
+            name, desc = C.c_char_p(), C.c_char_p()
+            _chk(load().ckm_seqs_name(self.seqs.h, int(i), C.byref(name), C.byref(desc), None))
+            v = (name.value if self.which == 0 else desc.value).decode()
+            self.cache[i] = v
+        return v
+
+
 class Seqs(object):
     """All sequences of all bins, packed and resident in HBM."""
+
+    @classmethod
+    def from_fasta(cls, ctx, paths):
+        """One protein FASTA file per bin, read, digitized and packed by the library (ckm_seqs_from_fasta)."""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+        self.h = C.c_void_p()
+        _chk(load().ckm_seqs_from_fasta(ctx.h, arr, len(paths), C.byref(self.h)))
+        n, nb = C.c_uint32(), C.c_uint32()
+        _chk(load().ckm_seqs_count(self.h, C.byref(n), C.byref(nb)))
+        self.nseq, self.nbins = n.value, nb.value
+        bo = C.POINTER(C.c_uint32)()
+        _chk(load().ckm_seqs_bin_offsets(self.h, C.byref(bo)))
+        self.bin_off = np.ctypeslib.as_array(bo, shape=(self.nbins + 1,)).copy()
+        tot = C.c_uint64()
+        _chk(load().ckm_seqs_residues(self.h, C.byref(tot)))
+        self.total_residues = int(tot.value)
+        self.names = _LazyStrings(self, 0)
+        self.descs = _LazyStrings(self, 1)
+        return self
 
     def __init__(self, ctx, bins):
         """bins: list of lists of (name, desc, residues) records."""

@@ -303,6 +303,29 @@ static void build_lentab(ckm_seqs *s) {
   }
 }
 
+// shared tail of the two constructors: s->len / s->off / s->dsq / names are filled; build the order, tables and upload
+static void finish_seqs(ckm_seqs *s) {
+  const uint32_t nbins = s->nbins, nseq = s->nseq;
+  s->seq_bin.resize(nseq);
+  for (uint32_t b = 0; b < nbins; ++b) for (uint32_t i = s->bin_off[b]; i < s->bin_off[b + 1]; ++i) s->seq_bin[i] = b;
+  s->order_off.assign(nbins + 1, 0); s->bin_res.assign(nbins, 0);
+  for (uint32_t b = 0; b < nbins; ++b) {
+    s->order_off[b] = (uint32_t)s->order.size();
+    const size_t first = s->order.size();
+    for (uint32_t i = s->bin_off[b]; i < s->bin_off[b + 1]; ++i) if (s->len[i] > 0) { s->order.push_back(i); s->bin_res[b] += (uint64_t)s->len[i]; }
+    std::stable_sort(s->order.begin() + first, s->order.end(), [&](uint32_t x, uint32_t y) { return s->len[x] > s->len[y]; });
+  }
+  s->order_off[nbins] = (uint32_t)s->order.size();
+  build_lentab(s);
+  s->d_res.ensure(s->dsq.size()); HIPCHK(hipMemcpy(s->d_res.p, s->dsq.data(), s->dsq.size(), hipMemcpyHostToDevice));
+  s->d_off.ensure(std::max<size_t>(8, (size_t)nseq * 8)); if (nseq) HIPCHK(hipMemcpy(s->d_off.p, s->off.data(), (size_t)nseq * 8, hipMemcpyHostToDevice));
+  s->d_len.ensure(std::max<size_t>(4, (size_t)nseq * 4)); if (nseq) HIPCHK(hipMemcpy(s->d_len.p, s->len.data(), (size_t)nseq * 4, hipMemcpyHostToDevice));
+  s->d_order.ensure(std::max<size_t>(4, s->order.size() * 4));
+  if (!s->order.empty()) HIPCHK(hipMemcpy(s->d_order.p, s->order.data(), s->order.size() * 4, hipMemcpyHostToDevice));
+  s->d_lentab.ensure(s->lentab.size() * sizeof(LenEntry));
+  HIPCHK(hipMemcpy(s->d_lentab.p, s->lentab.data(), s->lentab.size() * sizeof(LenEntry), hipMemcpyHostToDevice));
+}
+
 extern "C" int ckm_seqs_pack(ckm_ctx *ctx, const char *text, const uint64_t *seq_off, uint32_t nseq,
                              const uint32_t *bin_off, uint32_t nbins, const char *const *names,
                              const char *const *descs, ckm_seqs **out) {
@@ -314,11 +337,7 @@ extern "C" int ckm_seqs_pack(ckm_ctx *ctx, const char *text, const uint64_t *seq
     std::unique_ptr<ckm_seqs> s(new ckm_seqs());
     s->ctx = ctx; s->nseq = nseq; s->nbins = nbins; s->uid = g_uid++;
     s->bin_off.assign(bin_off, bin_off + nbins + 1);
-    s->seq_bin.resize(nseq);
-    for (uint32_t b = 0; b < nbins; ++b) {
-      if (bin_off[b + 1] < bin_off[b]) throw Error(CKM_EINVAL, "bin_off not monotone");
-      for (uint32_t i = bin_off[b]; i < bin_off[b + 1]; ++i) s->seq_bin[i] = b;
-    }
+    for (uint32_t b = 0; b < nbins; ++b) if (bin_off[b + 1] < bin_off[b]) throw Error(CKM_EINVAL, "bin_off not monotone");
     s->len.resize(nseq); s->off.resize(nseq);
     uint64_t pos = 0;
     for (uint32_t i = 0; i < nseq; ++i) {
@@ -336,24 +355,83 @@ extern "C" int ckm_seqs_pack(ckm_ctx *ctx, const char *text, const uint64_t *seq
       if (names && names[i]) s->names[i] = names[i]; else s->names[i] = "seq" + std::to_string(i);
       if (descs && descs[i]) s->descs[i] = descs[i];
     }
-    s->order_off.assign(nbins + 1, 0); s->bin_res.assign(nbins, 0);
-    for (uint32_t b = 0; b < nbins; ++b) {
-      s->order_off[b] = (uint32_t)s->order.size();
-      const size_t first = s->order.size();
-      for (uint32_t i = bin_off[b]; i < bin_off[b + 1]; ++i) if (s->len[i] > 0) { s->order.push_back(i); s->bin_res[b] += (uint64_t)s->len[i]; }
-      std::stable_sort(s->order.begin() + first, s->order.end(), [&](uint32_t x, uint32_t y) { return s->len[x] > s->len[y]; });
-    }
-    s->order_off[nbins] = (uint32_t)s->order.size();
-    build_lentab(s.get());
-    s->d_res.ensure(s->dsq.size()); HIPCHK(hipMemcpy(s->d_res.p, s->dsq.data(), s->dsq.size(), hipMemcpyHostToDevice));
-    s->d_off.ensure(std::max<size_t>(8, nseq * 8)); HIPCHK(hipMemcpy(s->d_off.p, s->off.data(), (size_t)nseq * 8, hipMemcpyHostToDevice));
-    s->d_len.ensure(std::max<size_t>(4, nseq * 4)); HIPCHK(hipMemcpy(s->d_len.p, s->len.data(), (size_t)nseq * 4, hipMemcpyHostToDevice));
-    s->d_order.ensure(std::max<size_t>(4, s->order.size() * 4));
-    if (!s->order.empty()) HIPCHK(hipMemcpy(s->d_order.p, s->order.data(), s->order.size() * 4, hipMemcpyHostToDevice));
-    s->d_lentab.ensure(s->lentab.size() * sizeof(LenEntry));
-    HIPCHK(hipMemcpy(s->d_lentab.p, s->lentab.data(), s->lentab.size() * sizeof(LenEntry), hipMemcpyHostToDevice));
+    finish_seqs(s.get());
     *out = s.release();
   });
+}
+
+extern "C" int ckm_seqs_from_fasta(ckm_ctx *ctx, const char *const *paths, uint32_t nbins, ckm_seqs **out) {
+  return guarded([&] {
+    if (!ctx || !paths || !out) throw Error(CKM_EINVAL, "NULL argument");
+    *out = nullptr;
+    if (nbins == 0) throw Error(CKM_EINVAL, "no bins");
+    HIPCHK(hipSetDevice(ctx->device));
+    std::unique_ptr<ckm_seqs> s(new ckm_seqs());
+    s->ctx = ctx; s->nbins = nbins; s->uid = g_uid++;
+    s->bin_off.assign(nbins + 1, 0);
+    std::vector<char> buf;
+    uint64_t pos = 0;
+    auto close_seq = [&](uint64_t start) {            // pad the record that just ended to a 16-byte boundary
+      const uint64_t L = pos - start;
+      if (L > 100000) throw Error(CKM_ERANGE, "sequence longer than 100000 residues");
+      s->len.push_back((int32_t)L); s->total_res += L; s->maxL = std::max(s->maxL, (int)L);
+      const uint64_t padded = (L + 15) & ~(uint64_t)15;
+      s->dsq.resize(start + padded, (uint8_t)PADCODE);
+      pos = start + padded;
+    };
+    for (uint32_t b = 0; b < nbins; ++b) {
+      FILE *f = fopen(paths[b], "rb");
+      if (!f) throw Error(CKM_EIO, std::string("cannot open FASTA file ") + paths[b]);
+      fseek(f, 0, SEEK_END); const long sz = ftell(f); fseek(f, 0, SEEK_SET);
+      buf.resize((size_t)std::max<long>(sz, 0));
+      const size_t got = sz > 0 ? fread(buf.data(), 1, (size_t)sz, f) : 0;
+      fclose(f);
+      if ((long)got != sz) throw Error(CKM_EIO, std::string("short read on ") + paths[b]);
+      size_t i = 0; bool open = false; uint64_t start = 0;
+      while (i < got) {
+        size_t e = i; while (e < got && buf[e] != '\n') ++e;
+        size_t le = e; if (le > i && buf[le - 1] == '\r') --le;
+        if (le > i && buf[i] == '>') {
+          if (open) close_seq(start);
+          size_t n0 = i + 1, n1 = n0; while (n1 < le && !isspace((unsigned char)buf[n1])) ++n1;
+          size_t d0 = n1; while (d0 < le && isspace((unsigned char)buf[d0])) ++d0;
+          s->names.emplace_back(buf.data() + n0, n1 - n0);
+          s->descs.emplace_back(buf.data() + d0, le - d0);
+          start = pos; s->off.push_back(start); open = true;
+        } else if (open && le > i) {
+          size_t a = i, z = le;                           // strip blanks at both ends of the line
+          while (a < z && isspace((unsigned char)buf[a])) ++a;
+          while (z > a && isspace((unsigned char)buf[z - 1])) --z;
+          if (z > a) { s->dsq.resize(pos + (z - a)); digitize(buf.data() + a, z - a, s->dsq.data() + pos); pos += z - a; }
+        }
+        i = e + 1;
+      }
+      if (open) close_seq(start);
+      s->bin_off[b + 1] = (uint32_t)s->names.size();
+    }
+    s->nseq = (uint32_t)s->names.size();
+    s->dsq.resize(pos + 16, (uint8_t)PADCODE);
+    finish_seqs(s.get());
+    *out = s.release();
+  });
+}
+
+extern "C" int ckm_seqs_count(const ckm_seqs *s, uint32_t *nseq, uint32_t *nbins) {
+  if (!s || !nseq || !nbins) { set_last_error("NULL argument"); return CKM_EINVAL; }
+  *nseq = s->nseq; *nbins = s->nbins;
+  return CKM_OK;
+}
+extern "C" int ckm_seqs_bin_offsets(const ckm_seqs *s, const uint32_t **bin_off) {
+  if (!s || !bin_off) { set_last_error("NULL argument"); return CKM_EINVAL; }
+  *bin_off = s->bin_off.data();
+  return CKM_OK;
+}
+extern "C" int ckm_seqs_name(const ckm_seqs *s, uint32_t i, const char **name, const char **desc, int32_t *len) {
+  if (!s || i >= s->nseq) { set_last_error("bad argument"); return CKM_EINVAL; }
+  if (name) *name = s->names[i].c_str();
+  if (desc) *desc = s->descs[i].c_str();
+  if (len) *len = s->len[i];
+  return CKM_OK;
 }
 
 extern "C" int ckm_seqs_residues(const ckm_seqs *s, uint64_t *total) {

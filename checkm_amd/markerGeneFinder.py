@@ -12,7 +12,7 @@ import shutil
 import sys
 
 from checkm_amd import _lib, runtime
-from checkm_amd.common import binIdFromFilename, makeSurePathExists, read_fasta
+from checkm_amd.common import binIdFromFilename, makeSurePathExists
 from checkm_amd.defaultValues import DefaultValues
 from checkm_amd.hmmerModelParser import models_dict
 from checkm_amd.markerSets import MarkerSetParser
@@ -33,8 +33,7 @@ def scan_files(hmm_file, fasta_files, table_files, E=0.1, domE=0.1, bin_models=N
     """Scan protein FASTA files (one bin each) against hmm_file; write one domtblout per bin."""
     ctx = runtime.get_ctx()
     profiles = _lib.Profiles(ctx, hmm_file)
-    bins = [read_fasta(f) for f in fasta_files]
-    seqs = _lib.Seqs(ctx, bins)
+    seqs = _lib.Seqs.from_fasta(ctx, list(fasta_files))
     hits = _lib.search(ctx, profiles, seqs, bin_models, E, domE)
     for b, path in enumerate(table_files):
         hits.write_domtblout(profiles, seqs, b, path)
@@ -87,8 +86,7 @@ class MarkerGeneFinder(object):
             bin_models = None
             if any(w is not None for w in wanted.values()):
                 bin_models = [[i for i, a in enumerate(acc_of) if wanted[b] is None or a in wanted[b]] for b in binIds]
-            bins = [read_fasta(f) for f in faa]
-            seqs = _lib.Seqs(ctx, bins)
+            seqs = _lib.Seqs.from_fasta(ctx, faa)                                # read, digitized and packed by the library
             hits = _lib.search(ctx, profiles, seqs, bin_models, 0.1, 0.1)        # -E 0.1 --domE 0.1, markerGeneFinder.py:141
             for b, binId in enumerate(binIds):
                 hits.write_domtblout(profiles, seqs, b, os.path.join(outDir, 'bins', binId, tableOut))

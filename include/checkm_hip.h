@@ -79,6 +79,13 @@ void ckm_profiles_free(ckm_profiles *p);
 int  ckm_seqs_pack(ckm_ctx *ctx, const char *text, const uint64_t *seq_off, uint32_t nseq,
                    const uint32_t *bin_off, uint32_t nbins,
                    const char *const *names, const char *const *descs, ckm_seqs **out);
+/* Same, reading the sequences itself: one protein FASTA file per bin (the bins/<binId>/genes.faa files of
+ * checkm/markerGeneFinder.py:113-127; what hmmsearch does with <seqfile>).  Name = header up to the first
+ * whitespace, description = the rest; residues are digitized on the fly.  Plain text files only. */
+int  ckm_seqs_from_fasta(ckm_ctx *ctx, const char *const *paths, uint32_t nbins, ckm_seqs **out);
+int  ckm_seqs_count(const ckm_seqs *s, uint32_t *nseq, uint32_t *nbins);
+int  ckm_seqs_bin_offsets(const ckm_seqs *s, const uint32_t **bin_off);          /* [nbins+1], owned by s */
+int  ckm_seqs_name(const ckm_seqs *s, uint32_t i, const char **name, const char **desc, int32_t *len);
 int  ckm_seqs_residues(const ckm_seqs *s, uint64_t *total);
 void ckm_seqs_free(ckm_seqs *s);
 

@@ -240,3 +240,26 @@ print(json.dumps({"rows": [[int(hits.seq[i]), int(hits.model[i]), int(hits.ali_f
     got = json.loads(out.stdout.strip().split("\n")[-1])
     assert got["rows"] == ref
     assert got["launches"] > single_pass_launches          # several model chunks, each with its own launches
+
+
+def test_fasta_ingest_equals_packed_records(world, tmp_path):
+    """ckm_seqs_from_fasta (library reads the genes.faa files) against ckm_seqs_pack (caller supplies residues)."""
+    w = world
+    paths = []
+    for b, recs in enumerate(w["bins"]):
+        p = tmp_path / ("bin%d.faa" % b)
+        synth.write_fasta(str(p), recs)
+        paths.append(str(p))
+    s2 = _lib.Seqs.from_fasta(w["ctx"], paths)
+    assert (s2.nseq, s2.nbins, s2.total_residues) == (w["seqs"].nseq, w["seqs"].nbins, w["seqs"].total_residues)
+    assert list(s2.bin_off) == list(w["seqs"].bin_off)
+    for i in (0, 7, s2.nseq - 1):
+        assert s2.names[i] == w["seqs"].names[i] and s2.descs[i] == w["seqs"].descs[i]
+    h1 = _lib.search(w["ctx"], w["prof"], w["seqs"]); h2 = _lib.search(w["ctx"], w["prof"], s2)
+    assert h1.n == h2.n
+    for f in _lib.HIT_FIELDS:
+        assert (getattr(h1, f) == getattr(h2, f)).all(), f
+    h1.close(); h2.close(); s2.close()
+    with pytest.raises(_lib.CkmError) as e:
+        _lib.Seqs.from_fasta(w["ctx"], [str(tmp_path / "nope.faa")])
+    assert e.value.code == -2
