@@ -37,7 +37,7 @@ class HitColumns(C.Structure):
                 ("hmm_from", C.POINTER(C.c_int32)), ("hmm_to", C.POINTER(C.c_int32)),
                 ("ali_from", C.POINTER(C.c_int32)), ("ali_to", C.POINTER(C.c_int32)),
                 ("env_from", C.POINTER(C.c_int32)), ("env_to", C.POINTER(C.c_int32)), ("acc", C.POINTER(C.c_float)),
-                ("target_name", C.POINTER(C.c_char_p))]
+                ("target_name", C.POINTER(C.c_char_p)), ("full_score_d", C.POINTER(C.c_double)), ("dom_score_d", C.POINTER(C.c_double))]
 
 
 HIT_FIELDS = ["seq", "model", "tlen", "qlen", "full_evalue", "full_score", "full_bias", "dom_idx", "ndom", "c_evalue",

@@ -1086,7 +1086,7 @@ extern "C" int ckm_hits_columns(const ckm_hits *h, ckm_hit_columns *o) {
   o->dom_score = h->dom_score.data(); o->dom_bias = h->dom_bias.data();
   o->hmm_from = h->hmm_from.data(); o->hmm_to = h->hmm_to.data(); o->ali_from = h->ali_from.data(); o->ali_to = h->ali_to.data();
   o->env_from = h->env_from.data(); o->env_to = h->env_to.data(); o->acc = h->acc.data();
-  o->target_name = nullptr;
+  o->target_name = nullptr; o->full_score_d = nullptr; o->dom_score_d = nullptr;
   return CKM_OK;
 }
 

@@ -333,7 +333,11 @@ extern "C" int ckm_reduce(ckm_ctx *ctx, const ckm_hits *h, const ckm_hit_columns
         if (from_search) {   // the reference sees these through the domtblout text: %9.2g and %6.1f (checkm/hmmer.py:270-277)
           x.full_e = text_round_g2(cols.full_evalue[r]); x.i_e = text_round_g2(cols.i_evalue[r]);
           x.full_sc = text_round_f1((double)cols.full_score[r]); x.dom_sc = text_round_f1((double)cols.dom_score[r]);
-        } else { x.full_e = cols.full_evalue[r]; x.i_e = cols.i_evalue[r]; x.full_sc = (double)cols.full_score[r]; x.dom_sc = (double)cols.dom_score[r]; }
+        } else {
+          x.full_e = cols.full_evalue[r]; x.i_e = cols.i_evalue[r];
+          x.full_sc = cols.full_score_d ? cols.full_score_d[r] : (double)cols.full_score[r];
+          x.dom_sc = cols.dom_score_d ? cols.dom_score_d[r] : (double)cols.dom_score[r];
+        }
         if (!vet_hit(x, mi, fl)) continue;
         // addHit: one domain per (marker, ORF); a strictly better one replaces and moves to the tail
         if (mh.has(x.key)) {

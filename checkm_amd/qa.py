@@ -182,6 +182,8 @@ def ext_columns(bins_rows, keys_model_index):
         ("c_evalue", np.float64), ("i_evalue", np.float64), ("dom_score", np.float32), ("dom_bias", np.float32),
         ("hmm_from", np.int32), ("hmm_to", np.int32), ("ali_from", np.int32), ("ali_to", np.int32),
         ("env_from", np.int32), ("env_to", np.int32), ("acc", np.float32))}
+    fs_d = np.zeros(max(n, 1), dtype=np.float64)      # scores as the float64 the text parses to
+    ds_d = np.zeros(max(n, 1), dtype=np.float64)
     names = []
     i = 0
     for b, rows in enumerate(bins_rows):
@@ -192,6 +194,7 @@ def ext_columns(bins_rows, keys_model_index):
             cols["full_evalue"][i] = r["full_e_value"]; cols["full_score"][i] = r["full_score"]; cols["full_bias"][i] = r["full_bias"]
             cols["dom_idx"][i] = r["dom"]; cols["ndom"][i] = r["ndom"]; cols["c_evalue"][i] = r["c_evalue"]; cols["i_evalue"][i] = r["i_evalue"]
             cols["dom_score"][i] = r["dom_score"]; cols["dom_bias"][i] = r["dom_bias"]
+            fs_d[i] = r["full_score"]; ds_d[i] = r["dom_score"]
             cols["hmm_from"][i] = r["hmm_from"]; cols["hmm_to"][i] = r["hmm_to"]; cols["ali_from"][i] = r["ali_from"]; cols["ali_to"][i] = r["ali_to"]
             cols["env_from"][i] = r["env_from"]; cols["env_to"][i] = r["env_to"]; cols["acc"][i] = r["acc"]
             names.append(r["target_name"].encode())
@@ -205,4 +208,6 @@ def ext_columns(bins_rows, keys_model_index):
     for f, a in cols.items():
         setattr(hc, f, a.ctypes.data_as(type(getattr(hc, f))))
     hc.target_name = name_arr
-    return hc, [off, cols, name_arr, names]
+    hc.full_score_d = fs_d.ctypes.data_as(C.POINTER(C.c_double))
+    hc.dom_score_d = ds_d.ctypes.data_as(C.POINTER(C.c_double))
+    return hc, [off, cols, name_arr, names, fs_d, ds_d]

@@ -116,6 +116,9 @@ typedef struct {
    * target name of every row (prodigal `<contig>_<n>` form, resultsParser.py:410-422).  NULL in
    * the struct ckm_hits_columns() fills: those rows take their names from the ckm_seqs. */
   const char *const *target_name;
+  /* INPUT only, optional: the two scores as float64 exactly as parsed from the text (Python floats in the
+   * reference).  float32 cannot hold "25.3" exactly, and vetHit compares scores with cutoffs such as GA 25.30. */
+  const double *full_score_d, *dom_score_d;
 } ckm_hit_columns;
 
 int  ckm_hits_columns(const ckm_hits *h, ckm_hit_columns *out);

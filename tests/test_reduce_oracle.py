@@ -32,7 +32,7 @@ def test_oracle_matches_reference_goldens(cases):
                 assert ro.marker_hits_view(mh) == run["expected"]["markerHits"], (ci, fl)
                 assert gc == run["expected"][key], (ci, fl, key, gc, run["expected"][key])
                 n += 1
-    assert n == len(cases) * 6 * 2
+    assert n == len(cases) * 6 * 2 and len(cases) >= 65
 
 
 def test_goldens_exercise_the_quirks(cases):

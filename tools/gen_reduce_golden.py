@@ -175,6 +175,18 @@ def main():
         for fl in FLAG_SETS:
             runs.append({"flags": fl, "expected": run_reference(models, pfam, table, sets, fl)})
         cases.append({"models": models, "pfam_dat": pfam, "domtblout": table, "marker_sets": sets, "runs": runs})
+    # hand-made edge cases: scores EQUAL to the cutoffs, at values float32 cannot hold exactly (25.3, 27.3, 0.7 ...)
+    for thr, sc in ((25.3, 25.3), (27.3, 27.3), (27.3, 27.2), (110.7, 110.7), (20.0, 20.0)):
+        models = [{"name": "edgeGA", "acc": "PF00001.1", "leng": 100, "ga": [thr, thr], "tc": None, "nc": None},
+                  {"name": "TIGR00001", "acc": "TIGR00001", "leng": 100, "ga": None, "tc": [thr + 5, thr + 5], "nc": [thr, thr]}]
+        rows = []
+        for m in models:
+            rows.append(["ctg_1", "-", 200, m["name"], m["acc"], 100, 1e-30, sc, 0.0, 1, 1, 1e-32, 1e-30, sc, 0.0, 1, 100, 5, 95, 1, 100, 0.99, "-"])
+            rows.append(["ctg_7", "-", 200, m["name"], m["acc"], 100, 1e-30, sc + 0.1, 0.0, 1, 1, 1e-32, 1e-30, sc - 0.1, 0.0, 1, 100, 5, 95, 1, 100, 0.99, "-"])
+        table = "# edge\n" + "\n".join(fmt_row(r) for r in rows) + "\n#\n"
+        sets = [["PF00001.1"], ["TIGR00001"]]
+        runs = [{"flags": fl, "expected": run_reference(models, "", table, sets, fl)} for fl in FLAG_SETS]
+        cases.append({"models": models, "pfam_dat": "", "domtblout": table, "marker_sets": sets, "runs": runs})
     out = os.path.join(ROOT, "tests", "golden", "reduce_cases.json")
     with open(out, "w") as f:
         json.dump({"generator": "tools/gen_reduce_golden.py", "reference": "Ecogenomics/CheckM v1.2.4 classes imported from /root/reference",
