@@ -23,7 +23,7 @@ class CkmError(RuntimeError):
 class ModelHeader(C.Structure):
     _fields_ = [("name", C.c_char_p), ("acc", C.c_char_p), ("desc", C.c_char_p), ("leng", C.c_int32),
                 ("has_ga", C.c_int32), ("has_tc", C.c_int32), ("has_nc", C.c_int32),
-                ("ga", C.c_float * 2), ("tc", C.c_float * 2), ("nc", C.c_float * 2), ("evparam", C.c_float * 6)]
+                ("ga", C.c_double * 2), ("tc", C.c_double * 2), ("nc", C.c_double * 2), ("evparam", C.c_float * 6)]
 
 
 class HitColumns(C.Structure):

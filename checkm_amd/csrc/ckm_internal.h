@@ -32,7 +32,7 @@ struct HostHMM {
   bool has_compo = false;
   float evparam[6] = {0};
   int stats_mask = 0;
-  float ga[2] = {0, 0}, tc[2] = {0, 0}, nc[2] = {0, 0};
+  double ga[2] = {0, 0}, tc[2] = {0, 0}, nc[2] = {0, 0};
   bool has_ga = false, has_tc = false, has_nc = false;
 };
 

@@ -116,9 +116,9 @@ std::vector<HostHMM> read_hmm_file(const std::string &path) {
       else if (tag == "LENG") h.M = atoi(rest.c_str());
       else if (tag == "ALPH") { std::string a = rest; std::transform(a.begin(), a.end(), a.begin(), ::tolower); if (a != "amino") throw fail("only amino-acid profiles are supported"); }
       else if (tag == "GA" || tag == "TC" || tag == "NC") {
-        float a, c;
+        double a, c;
         std::string r2 = rest; std::replace(r2.begin(), r2.end(), ';', ' ');
-        if (sscanf(r2.c_str(), "%f %f", &a, &c) != 2) throw fail("bad " + tag + " line");
+        if (sscanf(r2.c_str(), "%lf %lf", &a, &c) != 2) throw fail("bad " + tag + " line");
         if (tag == "GA") { h.ga[0] = a; h.ga[1] = c; h.has_ga = true; }
         if (tag == "TC") { h.tc[0] = a; h.tc[1] = c; h.has_tc = true; }
         if (tag == "NC") { h.nc[0] = a; h.nc[1] = c; h.has_nc = true; }

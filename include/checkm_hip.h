@@ -61,7 +61,7 @@ typedef struct {
   const char *desc;      /* DESC or NULL */
   int32_t     leng;      /* LENG */
   int32_t     has_ga, has_tc, has_nc;
-  float       ga[2], tc[2], nc[2];
+  double      ga[2], tc[2], nc[2];   /* float64: CheckM compares them as Python floats with text scores */
   float       evparam[6];   /* MSV mu,lambda; VITERBI mu,lambda; FORWARD tau,lambda */
 } ckm_model_header;
 

@@ -109,3 +109,25 @@ def test_find_then_qa_matches_oracles(gpu_ctx, tmp_path, capsys):
     rp3.parseBinHits(str(out), DefaultValues.HMMER_TABLE_OUT, bSkipAdjCorrection=True, bIgnoreThresholds=True)
     mh, gc = ro.reduce_bin(texts[1], omodels, dat, [sorted(s) for s in sets["bin_1"].selectedMarkerSet().markerSet], True, 1e-10, 0.7, False, True)
     assert rp3.results["bin_1"].geneCountsForSelectedMarkerSet(sets["bin_1"], False) == gc
+
+
+def test_cutoffs_are_float64_end_to_end(gpu_ctx, tmp_path):
+    """GA 25.10 must reach vetHit as the double 25.1 (as float32 it is 25.100000381 and would reject a 25.1 hit;
+    resultsParser.py:356-367 compares Python floats parsed from text)."""
+    from checkm_amd import _lib, qa as cqa
+    prof0 = synth.small_profiles(5, 1, 40, 41)[0]
+    prof0.acc = "PF12345.1"
+    prof0.ga, prof0.tc, prof0.nc = (25.10, 25.10), None, None
+    prof0.stats = (-8.0, 0.71, -9.0, 0.71, -3.5, 0.71)
+    path = str(tmp_path / "cut.hmm")
+    synth.write_hmm(path, [prof0])
+    prof = _lib.Profiles(gpu_ctx, path)
+    assert prof.headers[0]["ga"] == (25.1, 25.1)
+    plan = cqa.QAPlan.for_hmm_models(prof, [[0]])
+    rows = [dict(target_name="c_1", target_length=100, query_accession="PF12345.1", query_length=prof0.M, full_e_value=1e-12,
+                 full_score=25.1, full_bias=0.0, dom=1, ndom=1, c_evalue=1e-12, i_evalue=1e-12, dom_score=25.1, dom_bias=0.0,
+                 hmm_from=1, hmm_to=prof0.M, ali_from=1, ali_to=90, env_from=1, env_to=90, acc=0.9)]
+    hc = cqa.ext_columns([rows], lambda r: 0)
+    res = plan.reduce(gpu_ctx, None, None, ext=hc)
+    assert list(res.hist[0]) == [0, 1, 0, 0, 0, 0] and res.completeness[0] == 100.0
+    res.close(); prof.close()
