@@ -46,7 +46,7 @@ HIT_FIELDS = ["seq", "model", "tlen", "qlen", "full_evalue", "full_score", "full
 
 class SearchStats(C.Structure):
     _fields_ = [("pairs_ssv", C.c_uint64), ("pairs_msv_full", C.c_uint64), ("pairs_bias", C.c_uint64), ("pairs_vit", C.c_uint64),
-                ("pairs_fwd", C.c_uint64), ("pairs_dom", C.c_uint64), ("envelopes", C.c_uint64), ("cells_ssv", C.c_uint64),
+                ("pairs_fwd", C.c_uint64), ("pairs_dom", C.c_uint64), ("envelopes", C.c_uint64), ("regions_multi", C.c_uint64), ("cells_ssv", C.c_uint64),
                 ("residue_hmm", C.c_uint64), ("ms_ssv", C.c_double), ("ms_filters", C.c_double), ("ms_fwdbwd", C.c_double),
                 ("ms_domains", C.c_double), ("ms_host", C.c_double), ("ms_total", C.c_double), ("ssv_launches", C.c_uint32)]
 
@@ -94,7 +94,7 @@ EXPORTS = ["ckm_last_error", "ckm_abi_version", "ckm_device_count", "ckm_ctx_cre
            "ckm_profiles_load", "ckm_profiles_count", "ckm_profiles_header", "ckm_profiles_free",
            "ckm_seqs_pack", "ckm_seqs_from_fasta", "ckm_seqs_count", "ckm_seqs_bin_offsets", "ckm_seqs_name", "ckm_seqs_residues", "ckm_seqs_free", "ckm_search", "ckm_hits_columns", "ckm_hits_free",
            "ckm_hits_write_domtblout", "ckm_last_search_stats", "ckm_reduce", "ckm_qa_columns_get", "ckm_qa_free", "ckm_count_sets",
-           "ckm_debug_stages", "ckm_debug_envelopes"]
+           "ckm_debug_stages", "ckm_debug_envelopes", "ckm_debug_region"]
 
 _lib = None
 
@@ -143,6 +143,8 @@ def load():
     L.ckm_debug_stages.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.ckm_debug_envelopes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_uint32, C.c_void_p]
+    L.ckm_debug_region.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     if L.ckm_abi_version() != ABI_VERSION:
         raise ImportError("libcheckm_hip ABI version mismatch")
     _lib = L
@@ -333,3 +335,15 @@ def debug_envelopes(ctx, profiles, seqs, model, seq, ienv, jenv):
     _chk(load().ckm_debug_envelopes(ctx.h, profiles.h, seqs.h, model.ctypes.data, seq.ctypes.data, ienv.ctypes.data,
                                     jenv.ctypes.data, len(model), out))
     return out
+
+
+def debug_region(ctx, profiles, seqs, model, seq, ireg, jreg, cap=64):
+    """Trace ensemble of one region: (n2sum[Lr], segs[200][cap][4], nseg[200], envelopes[n][4]), region-local coordinates."""
+    n2 = np.zeros(jreg - ireg + 1, dtype=np.float32)
+    segs = np.zeros((200, cap, 4), dtype=np.int32)
+    nseg = np.zeros(200, dtype=np.int32)
+    env = np.zeros((64, 4), dtype=np.int32)
+    nenv = C.c_int32()
+    _chk(load().ckm_debug_region(ctx.h, profiles.h, seqs.h, model, seq, ireg, jreg, n2.ctypes.data, segs.ctypes.data, nseg.ctypes.data, cap,
+                                 env.ctypes.data, 64, C.byref(nenv)))
+    return n2, segs, nseg, env[:nenv.value].copy()

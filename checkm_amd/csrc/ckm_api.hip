@@ -40,6 +40,8 @@ int launch_bwd(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const 
 int launch_oa(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const uint32_t *blk_model, const DevModel *models,
               float *ws, const int32_t *range_err, EnvOut *out);
 
+void launch_ensemble(hipStream_t stream, const EnsWork *work, uint32_t nregions, int max_Ld, int max_Mp, const DevModel *models,
+                     const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, const uint32_t *seeds);
 static thread_local std::string g_err;
 void set_last_error(const std::string &m) { g_err = m; }
 
@@ -96,7 +98,7 @@ struct Worker {
   std::vector<std::pair<int, std::pair<size_t, size_t>>> plan_groups;
   uint64_t plan_npairs = 0, plan_nblocks = 0, plan_residue_hmm = 0, plan_cells = 0, plan_pairs = 0;
   PinnedBuf h_a, h_b;                     // D2H staging
-  DevBuf work, maxv, surv, nores, counters, cand, raw, idx, vitx, vits, fbwork, fbidx, fbmodel, ws, fout, events, rerr, envout, fullx, fullu;
+  DevBuf work, maxv, surv, nores, counters, cand, raw, idx, vitx, vits, fbwork, fbidx, fbmodel, ws, fout, events, rerr, envout, fullx, fullu, enswork, ensseeds;
   size_t ws_budget = (size_t)8 << 30;     // float workspace budget (bytes) for Forward/Backward matrices
 };
 
@@ -622,6 +624,148 @@ void rescore_envelopes(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, co
   }
 }
 
+
+// ---- multi-domain regions: trace ensemble on the device, clustering of the sampled segments here ----------------
+struct Seg { int32_t sqfrom, sqto, hmmfrom, hmmto; };
+struct RegionReq { uint32_t model, seq; int ireg, jreg; };
+struct RegionRes {
+  std::vector<float> n2sum;        // per region position: sum over traces of the null2 odds ratio
+  std::vector<Seg> segs;           // [200][cap], first domain first
+  std::vector<int32_t> nseg;       // [200]
+  int cap = 0;
+  std::vector<Seg> env;            // clustered envelopes, region-local coordinates, sorted by start
+};
+
+constexpr uint32_t kEnsStride = 15485863u;
+constexpr float kEnsMinOverlap = 0.8f, kEnsMinPosterior = 0.25f, kEnsMinEndpointP = 0.02f;
+constexpr int kEnsMaxDiagDiff = 4;
+
+uint32_t ens_mix3(uint32_t a, uint32_t b, uint32_t c) {
+  a -= b; a -= c; a ^= (c >> 13);  b -= c; b -= a; b ^= (a << 8);   c -= a; c -= b; c ^= (b >> 13);
+  a -= b; a -= c; a ^= (c >> 12);  b -= c; b -= a; b ^= (a << 16);  c -= a; c -= b; c ^= (b >> 5);
+  a -= b; a -= c; a ^= (c >> 3);   b -= c; b -= a; b ^= (a << 10);  c -= a; c -= b; c ^= (b >> 15);
+  return c;
+}
+// generator state of trace t: Easel's fast generator x -> 69069x+1, seeded 42 (mixed as esl_randomness_Init does), advanced t*stride steps
+uint32_t ens_seed(int t) {
+  uint32_t x = ens_mix3(42u, 87654321u, 12345678u); if (x == 0) x = 42u;
+  uint32_t A = 69069u, C = 1u, ra = 1u, rc = 0u;
+  for (uint64_t n = (uint64_t)t * kEnsStride; n; n >>= 1) { if (n & 1) { ra = A * ra; rc = A * rc + C; } C = A * C + C; A = A * A; }
+  return ra * x + rc;
+}
+
+bool seg_linked(const Seg &a, const Seg &b) {
+  int nov = std::min(a.sqto, b.sqto) - std::max(a.sqfrom, b.sqfrom) + 1;
+  int n = std::min(a.sqto - a.sqfrom + 1, b.sqto - b.sqfrom + 1);
+  if ((float)nov / (float)n < kEnsMinOverlap) return false;
+  nov = std::min(a.hmmto, b.hmmto) - std::max(a.hmmfrom, b.hmmfrom) + 1;
+  n = std::min(a.hmmto - a.hmmfrom + 1, b.hmmto - b.hmmfrom + 1);
+  if ((float)nov / (float)n < kEnsMinOverlap) return false;
+  const int d1 = (a.sqfrom - a.hmmfrom + a.sqto - a.hmmto) / 2, d2 = (b.sqfrom - b.hmmfrom + b.sqto - b.hmmto) / 2;
+  return std::abs(d1 - d2) <= kEnsMaxDiagDiff;
+}
+
+// single linkage over all sampled segments; clusters seen in >= 25% of the traces become envelopes whose ends are the
+// outermost endpoints sampled in >= 2% of those traces
+void cluster_ensemble(RegionRes &r) {
+  std::vector<Seg> sg; std::vector<int> tr;
+  for (int t = 0; t < ENS_NSAMPLES; ++t) for (int d = 0; d < r.nseg[t]; ++d) { sg.push_back(r.segs[(size_t)t * r.cap + d]); tr.push_back(t); }
+  const int n = (int)sg.size();
+  std::vector<int> asg(n, -1), stack;
+  int nc = 0;
+  for (int h = 0; h < n; ++h) if (asg[h] < 0) {
+    stack.assign(1, h); asg[h] = nc;
+    while (!stack.empty()) { const int a = stack.back(); stack.pop_back(); for (int b = 0; b < n; ++b) if (asg[b] < 0 && seg_linked(sg[a], sg[b])) { asg[b] = nc; stack.push_back(b); } }
+    ++nc;
+  }
+  for (int c = 0; c < nc; ++c) {
+    int ninc = 0, lastt = -1;
+    for (int h = 0; h < n; ++h) if (asg[h] == c && tr[h] != lastt) { ++ninc; lastt = tr[h]; }
+    if ((float)ninc / (float)ENS_NSAMPLES < kEnsMinPosterior) continue;
+    int best[4];
+    for (int f = 0; f < 4; ++f) {
+      auto val = [&](int h) { return f == 0 ? sg[h].sqfrom : f == 1 ? sg[h].sqto : f == 2 ? sg[h].hmmfrom : sg[h].hmmto; };
+      int lo = 1 << 30, hi = -1;
+      for (int h = 0; h < n; ++h) if (asg[h] == c) { lo = std::min(lo, val(h)); hi = std::max(hi, val(h)); }
+      std::vector<int> epc(hi - lo + 1, 0);
+      for (int h = 0; h < n; ++h) if (asg[h] == c) epc[val(h) - lo]++;
+      int b;
+      if (f == 0 || f == 2) { for (b = lo; b < hi; ++b) if ((float)epc[b - lo] / (float)ninc >= kEnsMinEndpointP) break; }
+      else                  { for (b = hi; b > lo; --b) if ((float)epc[b - lo] / (float)ninc >= kEnsMinEndpointP) break; }
+      best[f] = b;
+    }
+    r.env.push_back({best[0], best[1], best[2], best[3]});
+  }
+  std::stable_sort(r.env.begin(), r.env.end(), [](const Seg &a, const Seg &b) { return a.sqfrom != b.sqfrom ? a.sqfrom < b.sqfrom : a.sqto < b.sqto; });
+}
+
+void run_ensembles(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<RegionReq> &req, std::vector<RegionRes> &out) {
+  out.clear(); out.resize(req.size());
+  if (req.empty()) return;
+  if (!ctx->ensseeds.p) {
+    std::vector<uint32_t> seeds(ENS_NSAMPLES);
+    for (int t = 0; t < ENS_NSAMPLES; ++t) seeds[t] = ens_seed(t);
+    ctx->ensseeds.ensure(seeds.size() * 4);
+    HIPCHK(hipMemcpy(ctx->ensseeds.p, seeds.data(), seeds.size() * 4, hipMemcpyHostToDevice));
+  }
+  auto al = [](uint64_t v) { return (v + 31) & ~(uint64_t)31; };
+  const uint64_t budget_floats = ctx->ws_budget / 4;
+  size_t done = 0;
+  while (done < req.size()) {
+    FbBatch b; std::vector<EnsWork> ew; uint64_t pos = 0; size_t j = done; int maxLd = 0, maxMp = 0;
+    for (; j < req.size(); ++j) {
+      const RegionReq &r = req[j];
+      const int Mp = p->prof[r.model].fbQ * NL, Ld = r.jreg - r.ireg + 1, cap = std::min(Ld, 512);
+      EnsWork e; memset(&e, 0, sizeof(e));
+      uint64_t q = al(pos);
+      e.xs_off = q;    q = al(q + (uint64_t)(Ld + 1) * 6);
+      e.mx_off = q;    q = al(q + (uint64_t)(Ld + 1) * 3 * Mp);
+      e.code_off = q;  q = al(q + ((uint64_t)ENS_NSAMPLES * (Ld + 1) + 1) / 2);
+      e.ratio_off = q; q = al(q + (uint64_t)ENS_NSAMPLES * (Ld + 1));
+      e.nseg_off = q;  q = al(q + 256);
+      e.seg_off = q;   q = al(q + (uint64_t)ENS_NSAMPLES * cap * 4);
+      e.n2_off = q;    q = al(q + (uint64_t)Ld);
+      if (q > budget_floats && j > done) break;
+      if (q > budget_floats) throw Error(CKM_ENOMEM, "one multi-domain region needs more workspace than the device budget allows");
+      e.model = r.model; e.seq = r.seq; e.i0 = r.ireg - 1; e.Ld = Ld; e.Lcfg = s->len[r.seq]; e.cap = cap;
+      FbWork w; memset(&w, 0, sizeof(w));
+      w.model = r.model; w.seq = r.seq; w.i0 = e.i0; w.Ld = Ld; w.Lcfg = e.Lcfg; w.multihit = 1; w.slot = (uint32_t)(j - done); w.full = 2;
+      w.xs_off = e.xs_off; w.mxf_off = e.mx_off;
+      b.work.push_back(w); ew.push_back(e); pos = q;
+      maxLd = std::max(maxLd, Ld); maxMp = std::max(maxMp, Mp);
+    }
+    ctx->ws.ensure(pos * 4 + 256);
+    run_fb(ctx, p, s, b, true, false, false, nullptr);       // multihit Forward of every region, all three state rows kept
+    ctx->enswork.ensure(ew.size() * sizeof(EnsWork));
+    HIPCHK(hipMemcpy(ctx->enswork.p, ew.data(), ew.size() * sizeof(EnsWork), hipMemcpyHostToDevice));
+    launch_ensemble(ctx->stream, ctx->enswork.as<EnsWork>(), (uint32_t)ew.size(), maxLd, maxMp, p->d_models.as<DevModel>(), s->d_lentab.as<LenEntry>(),
+                    s->d_res.as<uint8_t>(), s->d_off.as<uint64_t>(), ctx->ws.as<float>(), ctx->ensseeds.as<uint32_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (size_t k = 0; k < ew.size(); ++k) {
+      const EnsWork &e = ew[k]; RegionRes &o = out[done + k];
+      // counts, segments and sums of one region are contiguous in the workspace: one copy
+      const uint64_t span = e.n2_off + (uint64_t)e.Ld - e.nseg_off;
+      std::vector<float> raw(span);
+      HIPCHK(hipMemcpy(raw.data(), ctx->ws.as<float>() + e.nseg_off, span * 4, hipMemcpyDeviceToHost));
+      const int32_t *ns = reinterpret_cast<const int32_t *>(raw.data());
+      const int32_t *sg = reinterpret_cast<const int32_t *>(raw.data() + (e.seg_off - e.nseg_off));
+      o.cap = e.cap; o.nseg.assign(ns, ns + ENS_NSAMPLES); o.segs.assign((size_t)ENS_NSAMPLES * e.cap, Seg{0, 0, 0, 0});
+      for (int t = 0; t < ENS_NSAMPLES; ++t) {
+        if (ns[t] < 0) throw Error(CKM_ERANGE, "a sampled trace holds more domains than the segment table allows");
+        for (int d = 0; d < ns[t]; ++d) {          // the device walks backwards: last domain first
+          const int32_t *q4 = sg + ((size_t)t * e.cap + (ns[t] - 1 - d)) * 4;
+          o.segs[(size_t)t * e.cap + d] = Seg{q4[0], q4[1], q4[2], q4[3]};
+        }
+      }
+      const float *n2 = raw.data() + (e.n2_off - e.nseg_off);
+      o.n2sum.assign(n2, n2 + e.Ld);
+      cluster_ensemble(o);
+    }
+    done = j;
+  }
+}
+
 void fill_null2(float *null2) {   // degenerate symbols: plain average of the odds of their residues
   static const char *sym = "ACDEFGHIKLMNPQRSTVWY-BJZOUX*~";
   auto member = [&](int x, int y) {
@@ -870,6 +1014,9 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
   // ---- stage 5: Backward parser + posterior domain heuristics ----
   std::vector<EnvReq> envreq; std::vector<std::pair<size_t, size_t>> env_of_pass(passers.size());   // [first, count)
   std::vector<int> nregions(passers.size(), 0);
+  struct Item { uint32_t pass; int i, j, region; };       // regions in sequence order; region >= 0: resolved by the trace ensemble
+  std::vector<Item> items; std::vector<RegionReq> regreq; std::vector<RegionRes> regres;
+  std::vector<int> env_region;                            // per envelope: index into regres or -1
   if (!passers.empty()) {
     uint64_t ap = aux_base;
     for (uint32_t k : passers) { fb.work[k].aux_off = ap; ap += ((uint64_t)(fb.work[k].Ld + 1) * 3 + 31) & ~(uint64_t)31; }
@@ -884,7 +1031,6 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
       const float *dec = dec_all_p + (w.aux_off - aux_base);
       std::vector<float> btot(L + 1, 0.f), etot(L + 1, 0.f), mocc(L + 1, 0.f);
       for (int i = 1; i <= L; ++i) { btot[i] = btot[i - 1] + dec[(size_t)i * 3]; etot[i] = etot[i - 1] + dec[(size_t)i * 3 + 1]; mocc[i] = 1.0f - dec[(size_t)i * 3 + 2]; }
-      env_of_pass[q].first = envreq.size();
       int i = -1; bool triggered = false;
       for (int j = 1; j <= L; ++j) {
         if (!triggered) {
@@ -894,16 +1040,28 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
           nregions[q]++;
           float mx = -1.0f;
           for (int z = i; z <= j; ++z) { const float a = etot[z] - etot[i - 1], b = btot[j] - btot[z - 1]; const float en = a < b ? a : b; if (en > mx) mx = en; }
-          if (mx >= RT3) {
-            // multi-domain region: deterministic posterior split (deviation D3)
-            int start = i; float next = 0.5f; const float total = etot[j] - etot[i - 1];
-            for (int z = i; z < j; ++z) {
-              const float a = etot[z] - etot[i - 1];
-              if (a >= next && (total - a) >= 0.5f) { envreq.push_back({w.model, w.seq, start, z}); start = z + 1; next += 1.0f; }
-            }
-            envreq.push_back({w.model, w.seq, start, j});
-          } else envreq.push_back({w.model, w.seq, i, j});
+          if (mx >= RT3) { items.push_back({(uint32_t)q, i, j, (int)regreq.size()}); regreq.push_back({w.model, w.seq, i, j}); }
+          else items.push_back({(uint32_t)q, i, j, -1});
           i = -1; triggered = false;
+        }
+      }
+    }
+    // multi-domain regions: 200 stochastic tracebacks each, clustered into envelopes
+    st.regions_multi = regreq.size();
+    run_ensembles(ctx, p, s, regreq, regres);
+    size_t it = 0;
+    for (size_t q = 0; q < passers.size(); ++q) {
+      const FbWork &w = fb.work[passers[q]];
+      env_of_pass[q].first = envreq.size();
+      for (; it < items.size() && items[it].pass == q; ++it) {
+        const Item &im = items[it];
+        if (im.region < 0) { envreq.push_back({w.model, w.seq, im.i, im.j}); env_region.push_back(-1); continue; }
+        int last_j2 = 0;
+        for (const Seg &e : regres[im.region].env) {
+          const int i2 = e.sqfrom + im.i - 1, j2 = e.sqto + im.i - 1;
+          if (i2 <= last_j2) continue;        // overlapping envelopes: the later one is skipped, as HMMER does
+          envreq.push_back({w.model, w.seq, i2, j2}); env_region.push_back(im.region);
+          last_j2 = j2;
         }
       }
       env_of_pass[q].second = envreq.size() - env_of_pass[q].first;
@@ -918,6 +1076,7 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
   st.ms_domains = now_ms() - t_dom0;
   const double t_host0 = now_ms();
   // ---- stage 7: scores, thresholds, rows ----
+  size_t item_at = 0;
   for (size_t q = 0; q < passers.size(); ++q) {
     const Cand &c = cands[fb_cand[passers[q]]];
     const HostHMM &hm = p->hmm[c.r.model];
@@ -927,6 +1086,11 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
     std::vector<float> n2sc((size_t)L + 2, 0.f);
     Hit h; h.model = c.r.model; h.seq = c.r.seq; h.L = L; h.nreported = 0;
     int nenv = 0;
+    for (; item_at < items.size() && items[item_at].pass == q; ++item_at) if (items[item_at].region >= 0) {
+      // null2 of an ensemble region: log of the mean odds ratio over the traces, for every residue of the region
+      const Item &im = items[item_at]; const RegionRes &rr = regres[im.region];
+      for (int pos = im.i; pos <= im.j; ++pos) n2sc[pos] = logf(rr.n2sum[pos - im.i] / (float)ENS_NSAMPLES);
+    }
     for (size_t e = env_of_pass[q].first; e < env_of_pass[q].first + env_of_pass[q].second; ++e) {
       ++nenv;
       EnvRes &er = envres[e];
@@ -940,7 +1104,8 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
       for (int x = 0; x < KP; ++x) ln2[x] = logf(null2[x]);          // same value the per-position logf would give
       ln2[KP] = 0.f;
       float dc = 0.f;
-      for (int pos = d.ienv; pos <= d.jenv; ++pos) { const float v = ln2[dsq[pos - 1]]; n2sc[pos] = v; dc += v; }
+      if (env_region[e] >= 0) { for (int pos = d.ienv; pos <= d.jenv; ++pos) dc += n2sc[pos]; }
+      else for (int pos = d.ienv; pos <= d.jenv; ++pos) { const float v = ln2[dsq[pos - 1]]; n2sc[pos] = v; dc += v; }
       d.domcorrection = dc;
       h.dom.push_back(d);
     }
@@ -1011,7 +1176,7 @@ static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, cons
   for (int k = 0; k < nw; ++k) {
     const ckm_search_stats &w = c->w[k].stats;
     st.pairs_ssv += w.pairs_ssv; st.pairs_msv_full += w.pairs_msv_full; st.pairs_bias += w.pairs_bias; st.pairs_vit += w.pairs_vit; st.pairs_fwd += w.pairs_fwd;
-    st.pairs_dom += w.pairs_dom; st.envelopes += w.envelopes; st.cells_ssv += w.cells_ssv; st.residue_hmm += w.residue_hmm; st.ssv_launches += w.ssv_launches;
+    st.pairs_dom += w.pairs_dom; st.envelopes += w.envelopes; st.regions_multi += w.regions_multi; st.cells_ssv += w.cells_ssv; st.residue_hmm += w.residue_hmm; st.ssv_launches += w.ssv_launches;
     st.ms_ssv += w.ms_ssv;                                   // SSV phases are serialised by the mutex: the sum is the kernel time
     st.ms_filters = std::max(st.ms_filters, w.ms_filters); st.ms_fwdbwd = std::max(st.ms_fwdbwd, w.ms_fwdbwd);
     st.ms_domains = std::max(st.ms_domains, w.ms_domains); st.ms_host = std::max(st.ms_host, w.ms_host);
@@ -1241,5 +1406,27 @@ extern "C" int ckm_debug_envelopes(ckm_ctx *ctx_, const ckm_profiles *p, const c
       for (int x = 0; x < 20; ++x) out[i].null2[x] = res[i].null2[x];
       out[i].hmm_from = res[i].hmm_from; out[i].hmm_to = res[i].hmm_to; out[i].ali_from = res[i].ali_from; out[i].ali_to = res[i].ali_to;
     }
+  });
+}
+
+extern "C" int ckm_debug_region(ckm_ctx *ctx_, const ckm_profiles *p, const ckm_seqs *s, uint32_t model, uint32_t seq, int32_t ireg, int32_t jreg,
+                                float *n2sum, int32_t *segs, int32_t *nseg, int32_t cap, int32_t *env, int32_t envcap, int32_t *nenv) {
+  return guarded([&] {
+    if (!ctx_ || !p || !s || !n2sum || !segs || !nseg || !env || !nenv) throw Error(CKM_EINVAL, "NULL argument");
+    if (model >= p->hmm.size() || seq >= s->nseq || ireg < 1 || jreg > s->len[seq] || jreg < ireg) throw Error(CKM_EINVAL, "bad region");
+    Worker *ctx = &ctx_->w[0];
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<RegionReq> req{{model, seq, ireg, jreg}}; std::vector<RegionRes> res;
+    run_ensembles(ctx, p, s, req, res);
+    const RegionRes &r = res[0];
+    for (size_t i = 0; i < r.n2sum.size(); ++i) n2sum[i] = r.n2sum[i];
+    for (int t = 0; t < ENS_NSAMPLES; ++t) {
+      if (r.nseg[t] > cap) throw Error(CKM_ERANGE, "segment table too small");
+      nseg[t] = r.nseg[t];
+      for (int d = 0; d < r.nseg[t]; ++d) { const Seg &g = r.segs[(size_t)t * r.cap + d]; int32_t *o = segs + ((size_t)t * cap + d) * 4; o[0] = g.sqfrom; o[1] = g.sqto; o[2] = g.hmmfrom; o[3] = g.hmmto; }
+    }
+    if ((int)r.env.size() > envcap) throw Error(CKM_ERANGE, "envelope table too small");
+    *nenv = (int32_t)r.env.size();
+    for (size_t e = 0; e < r.env.size(); ++e) { env[e * 4] = r.env[e].sqfrom; env[e * 4 + 1] = r.env[e].sqto; env[e * 4 + 2] = r.env[e].hmmfrom; env[e * 4 + 3] = r.env[e].hmmto; }
   });
 }

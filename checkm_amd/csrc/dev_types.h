@@ -65,7 +65,19 @@ struct FbWork {              // one Forward/Backward/OA work item (whole sequenc
   uint64_t aux_off;                    // float offset: parser mode -> decoding terms (Ld+1)*3 [bt et njcp];
                                        // full mode -> (Ld+1)*3 [ppN ppJ ppC], then 128B-aligned (Ld+1)*5 [oN oB oE oJ oC]
   uint64_t mxf_off, mxb_off;           // float offsets of the (Ld+1) x 3*Mp matrices (full mode only)
-  uint32_t slot, full;
+  uint32_t slot, full;                 // full: 0 parser (specials only), 1 matrix rows M,I, 2 matrix rows M,I,D (trace ensemble)
+};
+
+constexpr int ENS_NSAMPLES = 200;     // stochastic tracebacks per multi-domain region (HMMER's default)
+
+struct EnsWork {             // one multi-domain region handed to the trace-ensemble kernels (offsets in floats into the workspace)
+  uint32_t model, seq;
+  int32_t  i0, Ld, Lcfg, cap;          // residues [i0, i0+Ld) of the target; cap = segment slots per trace
+  uint64_t xs_off, mx_off;             // multihit Forward of the region: special rows (Ld+1)*6, matrix (Ld+1) x 3*Mp (M I D)
+  uint64_t code_off;                   // uint16 [200][Ld+1] state codes per residue
+  uint64_t ratio_off;                  // float  [200][Ld+1] null2 odds ratio per residue and trace
+  uint64_t seg_off, nseg_off;          // int32  [200][cap][4] sampled segments (last domain first), int32 [200] counts (-1 = overflow)
+  uint64_t n2_off;                     // float  [Ld] sum of the ratios over traces
 };
 
 struct FinishArgs {

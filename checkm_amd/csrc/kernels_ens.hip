@@ -1,0 +1,210 @@
+// kernels_ens.hip -- multi-domain regions: stochastic trace ensemble of a region's Forward matrix, gfx950 only.
+// Replaces, inside the hmmsearch process launched at checkm/hmmer.py:70, HMMER's "region_trace_ensemble":
+// 200 stochastic tracebacks, null2 by trace, per-position null2 odds; the sampled segments go back to the host,
+// which clusters them (integer work on a few hundred segments).
+//   ens_trace_kernel   one workgroup per region, one LANE per trace: every trace is an independent walk through
+//                      the (L2-resident) Forward matrix, driven by its own substream of HMMER's fast generator.
+//   ens_null2_kernel   one wavefront per (region, trace): state usage counts in LDS, null2 odds in the canonical
+//                      64-lane order, per-position odds ratio of this trace.
+//   ens_sum_kernel     one thread per region position: sum of the ratios over traces, trace order.
+// Float results follow the CPU restatement (trace_ensemble in the test oracle) operation by operation; -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include "dev_types.h"
+
+namespace ckm {
+
+constexpr int ENS_N = ENS_NSAMPLES;
+
+__device__ __forceinline__ double ens_roll(uint32_t &x) { x = x * 69069u + 1u; return (double)x / 4294967296.0; }
+
+// first index whose cumulative weight exceeds roll * total (weights summed in index order)
+__device__ __forceinline__ int ens_choose(double roll, const float *pth, int n) {
+  float norm = pth[0];
+  for (int i = 1; i < n; ++i) norm = norm + pth[i];
+  if (!(norm > 0.0f)) return 0;
+  const double target = roll * (double)norm;
+  double sum = 0.0;
+  for (int i = 0; i < n; ++i) { sum += (double)pth[i]; if (target < sum) return i; }
+  for (int i = n - 1; i > 0; --i) if (pth[i] > 0.0f) return i;
+  return 0;
+}
+
+__global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restrict__ work, const DevModel *__restrict__ models,
+                                                       const LenEntry *__restrict__ lentab, float *__restrict__ ws,
+                                                       const uint32_t *__restrict__ seeds) {
+  const EnsWork w = work[blockIdx.x];
+  const int t = threadIdx.x;
+  if (t >= ENS_N) return;
+  const DevModel &md = models[w.model];
+  const int Q = md.fbQ, Mp = Q * 64, M = md.M, Ld = w.Ld;
+  const size_t rowsz = (size_t)3 * Mp;
+  const float *__restrict__ mx = ws + w.mx_off;
+  const float *__restrict__ xs = ws + w.xs_off;
+  const float *__restrict__ tBM = md.ftr, *tMM = md.ftr + Mp, *tIM = md.ftr + 2 * Mp, *tDM = md.ftr + 3 * Mp,
+              *tMI = md.ftr + 4 * Mp, *tII = md.ftr + 5 * Mp, *tMD = md.ftr + 6 * Mp, *tDD = md.ftr + 7 * Mp;
+  const LenEntry le = lentab[w.Lcfg];
+  const float loop = le.loop_m, move = le.move_m, Eloop = md.fE_loop, Emove = md.fE_move;
+  uint16_t *__restrict__ code = reinterpret_cast<uint16_t *>(ws + w.code_off) + (size_t)t * (Ld + 1);
+  int32_t *__restrict__ seg = reinterpret_cast<int32_t *>(ws + w.seg_off) + (size_t)t * w.cap * 4;
+  int32_t *__restrict__ nsegp = reinterpret_cast<int32_t *>(ws + w.nseg_off);
+  uint32_t rng = seeds[t];
+#define CELL(c) (((c) % Q) * 64 + (c) / Q)
+  enum { sC, sE, sM, sI, sD, sB, sJ, sN };
+  int st = sC, i = Ld, k = 0, nseg = 0, sqto = 0, hmmto = 0;
+  bool overflow = false;
+  float pth[4];
+  for (;;) {
+    const float *cr = mx + rowsz * i, *pr = (i > 0) ? mx + rowsz * (i - 1) : mx;
+    bool stop = false;
+    switch (st) {
+    case sC:
+      pth[0] = xs[(size_t)(i - 1) * 6 + 4] * loop;
+      pth[1] = (xs[(size_t)i * 6 + 0] * Emove) * xs[(size_t)i * 6 + 5];
+      if (ens_choose(ens_roll(rng), pth, 2) == 0) { code[i] = 0; --i; } else st = sE;
+      break;
+    case sJ:
+      pth[0] = xs[(size_t)(i - 1) * 6 + 2] * loop;
+      pth[1] = (xs[(size_t)i * 6 + 0] * Eloop) * xs[(size_t)i * 6 + 5];
+      if (ens_choose(ens_roll(rng), pth, 2) == 0) { code[i] = 0; --i; } else st = sE;
+      break;
+    case sE: {
+      double total = 0.0;
+      for (int c = 0; c < M; ++c) { const int a = CELL(c); total += (double)cr[a]; total += (double)cr[2 * Mp + a]; }
+      const double target = ens_roll(rng) * total;
+      double sum = 0.0; int pick = -1, isd = 0, lastc = -1, lastd = 0;
+      for (int c = 0; c < M; ++c) {
+        const int a = CELL(c);
+        const float mv = cr[a], dv = cr[2 * Mp + a];
+        if (mv > 0.0f) { lastc = c; lastd = 0; }
+        sum += (double)mv; if (target < sum) { pick = c; isd = 0; break; }
+        if (dv > 0.0f) { lastc = c; lastd = 1; }
+        sum += (double)dv; if (target < sum) { pick = c; isd = 1; break; }
+      }
+      if (pick < 0) { pick = lastc < 0 ? 0 : lastc; isd = lastd; }
+      k = pick + 1; st = isd ? sD : sM; sqto = 0; hmmto = 0;
+    } break;
+    case sM: {
+      const int c = k - 1;
+      code[i] = (uint16_t)(0x4000 | k);
+      if (!sqto) { sqto = i; hmmto = k; }
+      pth[0] = xs[(size_t)(i - 1) * 6 + 3] * tBM[c];
+      if (c > 0) { const int a = CELL(c - 1); pth[1] = pr[a] * tMM[c]; pth[2] = pr[Mp + a] * tIM[c]; pth[3] = pr[2 * Mp + a] * tDM[c]; }
+      else pth[1] = pth[2] = pth[3] = 0.0f;
+      const int ch = ens_choose(ens_roll(rng), pth, 4);
+      if (ch == 0) {
+        if (nseg == w.cap) { overflow = true; stop = true; break; }
+        seg[nseg * 4 + 0] = i; seg[nseg * 4 + 1] = sqto; seg[nseg * 4 + 2] = k; seg[nseg * 4 + 3] = hmmto; ++nseg;
+        st = sB;
+      } else st = (ch == 1) ? sM : (ch == 2) ? sI : sD;
+      --i; --k;
+    } break;
+    case sI: {
+      const int a = CELL(k - 1);
+      code[i] = (uint16_t)(0x8000 | k);
+      pth[0] = pr[a] * tMI[k - 1]; pth[1] = pr[Mp + a] * tII[k - 1];
+      st = (ens_choose(ens_roll(rng), pth, 2) == 0) ? sM : sI;
+      --i;
+    } break;
+    case sD: {
+      const int c = k - 1;
+      if (c > 0) { const int a = CELL(c - 1); pth[0] = cr[a] * tMD[c - 1]; pth[1] = cr[2 * Mp + a] * tDD[c - 1]; } else pth[0] = pth[1] = 0.0f;
+      st = (ens_choose(ens_roll(rng), pth, 2) == 0) ? sM : sD;
+      --k;
+    } break;
+    case sB:
+      pth[0] = xs[(size_t)i * 6 + 1] * move; pth[1] = xs[(size_t)i * 6 + 2] * move;
+      st = (ens_choose(ens_roll(rng), pth, 2) == 0) ? sN : sJ;
+      break;
+    default:   // sN
+      stop = true;
+      break;
+    }
+    if (stop) break;
+    if (i < 0 || k < 0 || ((st == sM || st == sI) && (k < 1 || i < 1)) || (st == sD && k < 1) || ((st == sC || st == sJ || st == sE) && i < 1))
+      break;   // a numerically impossible move: the trace ends here
+  }
+  for (; i >= 1; --i) code[i] = 0;
+  nsegp[t] = overflow ? -1 : nseg;
+#undef CELL
+}
+
+__device__ __forceinline__ float ens_wave_sum(float s) {
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) s = s + __shfl_xor(s, w);
+  return s;
+}
+
+// grid (ENS_N, nregions), 64 threads; dynamic LDS: 2*Mp counters/floats + 32 floats
+__global__ void __launch_bounds__(64) ens_null2_kernel(const EnsWork *__restrict__ work, const DevModel *__restrict__ models,
+                                                      const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
+                                                      float *__restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const EnsWork w = work[blockIdx.y];
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const DevModel &md = models[w.model];
+  const int Q = md.fbQ, Mp = Q * 64, Ld = w.Ld;
+  uint32_t *cnt = reinterpret_cast<uint32_t *>(lds);
+  float *n2 = lds + 2 * Mp;
+  const uint16_t *__restrict__ code = reinterpret_cast<const uint16_t *>(ws + w.code_off) + (size_t)t * (Ld + 1);
+  const int32_t *__restrict__ seg = reinterpret_cast<const int32_t *>(ws + w.seg_off) + (size_t)t * w.cap * 4;
+  const int ns = reinterpret_cast<const int32_t *>(ws + w.nseg_off)[t];
+  float *__restrict__ rt = ws + w.ratio_off + (size_t)t * (Ld + 1);
+  const uint8_t *__restrict__ rd = res + seq_off[w.seq] + w.i0;
+  for (int pos = 1 + lane; pos <= Ld; pos += 64) rt[pos] = 1.0f;
+  for (int d = 0; d < ns; ++d) {
+    const int sqfrom = seg[d * 4 + 0], sqto = seg[d * 4 + 1];
+    for (int c = lane; c < 2 * Mp; c += 64) cnt[c] = 0u;
+    __syncthreads();
+    int nemit = 0;
+    for (int pos = sqfrom + lane; pos <= sqto; pos += 64) {
+      const uint16_t cd = code[pos]; const int kk = cd & 0x3fff;
+      if (cd & 0x4000) { atomicAdd(&cnt[kk - 1], 1u); ++nemit; } else if (cd & 0x8000) { atomicAdd(&cnt[Mp + kk - 1], 1u); ++nemit; }
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) nemit += __shfl_xor(nemit, s);
+    __syncthreads();
+    const float norm = 1.0f / (float)nemit;
+    for (int c = lane; c < 2 * Mp; c += 64) { const float v = (float)cnt[c] * norm; lds[c] = v; }
+    __syncthreads();
+    for (int x = 0; x < 20; ++x) {
+      const float *__restrict__ rfx = md.rf + (size_t)x * Mp + lane;
+      float s = 0.f;
+      for (int q = 0; q < Q; ++q) { const int idx = lane * Q + q; const float tt = lds[idx] * rfx[q * 64]; s = s + tt; s = s + lds[Mp + idx]; }
+      s = ens_wave_sum(s);
+      if (lane == 0) n2[x] = s + 0.0f;
+    }
+    __syncthreads();
+    if (lane == 0) {
+      // degenerate symbols: plain average over their residues (alphabet order ACDEFGHIKLMNPQRSTVWY-BJZOUX*~)
+      const float B = (n2[2] + n2[11]) / 2.0f, J = (n2[7] + n2[9]) / 2.0f, Z = (n2[3] + n2[13]) / 2.0f;
+      float r = 0.f;
+      for (int y = 0; y < 20; ++y) r += n2[y];
+      n2[20] = 1.0f; n2[21] = B; n2[22] = J; n2[23] = Z; n2[24] = n2[8] / 1.0f; n2[25] = n2[1] / 1.0f; n2[26] = r / 20.0f;
+      n2[27] = 1.0f; n2[28] = 1.0f; n2[29] = 1.0f;
+    }
+    __syncthreads();
+    for (int pos = sqfrom + 1 + lane; pos <= sqto; pos += 64) rt[pos] = n2[rd[pos - 1]];
+    __syncthreads();
+  }
+}
+
+// grid (ceil(maxLd/256), nregions)
+__global__ void __launch_bounds__(256) ens_sum_kernel(const EnsWork *__restrict__ work, float *__restrict__ ws) {
+  const EnsWork w = work[blockIdx.y];
+  const int pos = 1 + blockIdx.x * 256 + threadIdx.x;
+  if (pos > w.Ld) return;
+  const float *__restrict__ rt = ws + w.ratio_off + pos;
+  float acc = 0.0f;
+  for (int t = 0; t < ENS_N; ++t) acc = acc + rt[(size_t)t * (w.Ld + 1)];
+  (ws + w.n2_off)[pos - 1] = acc;
+}
+
+void launch_ensemble(hipStream_t stream, const EnsWork *work, uint32_t nregions, int max_Ld, int max_Mp, const DevModel *models,
+                     const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, const uint32_t *seeds) {
+  if (!nregions) return;
+  hipLaunchKernelGGL(ens_trace_kernel, dim3(nregions), dim3(256), 0, stream, work, models, lentab, ws, seeds);
+  hipLaunchKernelGGL(ens_null2_kernel, dim3(ENS_N, nregions), dim3(64), (size_t)(2 * max_Mp + 32) * 4, stream, work, models, res, seq_off, ws);
+  hipLaunchKernelGGL(ens_sum_kernel, dim3((max_Ld + 255) / 256, nregions), dim3(256), 0, stream, work, ws);
+}
+
+}  // namespace ckm

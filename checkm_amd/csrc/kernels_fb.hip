@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256) fwd_kernel(const FbWork *__restrict__ wor
   if (lane == 0) { xs[0] = 0.f; xs[1] = xN; xs[2] = 0.f; xs[3] = xB; xs[4] = 0.f; xs[5] = 1.0f; }
   if (mx) {
 #pragma unroll
-    for (int q = 0; q < Q; ++q) { mx[q * 64 + lane] = 0.f; mx[Mp + q * 64 + lane] = 0.f; }   // D is never read back
+    for (int q = 0; q < Q; ++q) { mx[q * 64 + lane] = 0.f; mx[Mp + q * 64 + lane] = 0.f; if (w.full == 2) mx[2 * Mp + q * 64 + lane] = 0.f; }
   }
   // emission odds of the next row are fetched one row ahead (residue byte -> table row is a dependent pair of loads)
   float rfc[Q];
@@ -171,6 +171,10 @@ __global__ void __launch_bounds__(256) fwd_kernel(const FbWork *__restrict__ wor
       float *r = mx + (size_t)i * 3 * Mp + lane;
 #pragma unroll
       for (int q = 0; q < Q; ++q) { r[q * 64] = Mv[q]; r[Mp + q * 64] = Iv[q]; }
+      if (w.full == 2) {      // the trace ensemble also walks delete states
+#pragma unroll
+        for (int q = 0; q < Q; ++q) r[2 * Mp + q * 64] = Dv[q];
+      }
     }
   }
   if (lane == 0) { out[w.slot].xC = xC; out[w.slot].nscale = nscale; }

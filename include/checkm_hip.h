@@ -132,6 +132,7 @@ int  ckm_hits_write_domtblout(const ckm_hits *h, const ckm_profiles *p, const ck
 /* ---- per-stage counters of the last ckm_search on this ctx (bench.py) --- */
 typedef struct {
   uint64_t pairs_ssv, pairs_msv_full, pairs_bias, pairs_vit, pairs_fwd, pairs_dom, envelopes;
+  uint64_t regions_multi;       /* regions resolved by the stochastic trace ensemble */
   uint64_t cells_ssv;           /* sum over pairs of L*M: GCUPS denominator */
   uint64_t residue_hmm;         /* sum over pairs of L */
   double   ms_ssv, ms_filters, ms_fwdbwd, ms_domains, ms_host, ms_total;
@@ -218,6 +219,14 @@ typedef struct {
 int ckm_debug_envelopes(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s,
                         const uint32_t *model, const uint32_t *seq, const int32_t *ienv, const int32_t *jenv,
                         uint32_t n, ckm_envelope_result *out);
+
+/* The trace ensemble of one multi-domain region ireg..jreg (1-based, inclusive) of sequence `seq`:
+ * n2sum[jreg-ireg+1] = per residue, sum over the 200 traces of the null2 odds ratio; segs[200*cap*4] / nseg[200] = every
+ * trace's sampled segments {sqfrom, sqto, hmmfrom, hmmto} in region-local coordinates, first domain first;
+ * env[envcap*4] / *nenv = the clustered envelopes, sorted by start. */
+int ckm_debug_region(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, uint32_t model, uint32_t seq,
+                     int32_t ireg, int32_t jreg, float *n2sum, int32_t *segs, int32_t *nseg, int32_t cap,
+                     int32_t *env, int32_t envcap, int32_t *nenv);
 
 #ifdef __cplusplus
 }

@@ -61,6 +61,10 @@ def lib():
         L.p7o_free.argtypes = [C.c_void_p]
         L.p7o_envelope.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                                    C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+        L.p7o_ensemble_seed.restype = C.c_uint32
+        L.p7o_ensemble_seed.argtypes = [C.c_int]
+        L.p7o_region_ensemble.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32)]
         _lib = L
     return _lib
 
@@ -107,6 +111,19 @@ class HmmSet(object):
         rc = lib().p7o_envelope(self.model(i), d.ctypes.data, len(d), ienv, jenv, C.byref(envsc), C.byref(oasc),
                                 null2.ctypes.data, coords.ctypes.data, C.byref(xC), C.byref(ns))
         return rc, envsc.value, oasc.value, null2, coords, xC.value, ns.value
+
+    def region_ensemble(self, i, dsq, ireg, jreg, cap=64):
+        """200-trace ensemble of region ireg..jreg: (rc, n2sum[Lr], segs[200][cap][4], nseg[200], envelopes[n][4])."""
+        d = np.ascontiguousarray(dsq, dtype=np.uint8)
+        Lr = jreg - ireg + 1
+        n2 = np.zeros(Lr, dtype=np.float32)
+        segs = np.zeros((200, cap, 4), dtype=np.int32)
+        nseg = np.zeros(200, dtype=np.int32)
+        env = np.zeros((64, 4), dtype=np.int32)
+        nenv = C.c_int32()
+        rc = lib().p7o_region_ensemble(self.model(i), d.ctypes.data, len(d), ireg, jreg, n2.ctypes.data, segs.ctypes.data,
+                                       nseg.ctypes.data, cap, env.ctypes.data, 64, C.byref(nenv))
+        return rc, n2, segs, nseg, env[:nenv.value].copy()
 
     def search(self, model_idx, seqs, names, E=0.1, domE=0.1):
         """seqs: list of digitized uint8 arrays.  Returns list of Row (copied)."""

@@ -26,8 +26,13 @@
  * per cell.  Known deviations from HMMER, all flagged "DEV" below:
  *   DEV1 bias-filter Forward rescales by exact powers of two instead of dividing by the row max;
  *   DEV2 optimal-accuracy fill gates impossible transitions with -inf instead of *FLT_MIN;
- *   DEV3 multi-domain regions (rt3 test) are resolved by the deterministic posterior split
- *        below, not by 200 seeded stochastic tracebacks + single-linkage clustering;
+ *   DEV3 multi-domain regions (rt3 test) are resolved as HMMER does -- 200 stochastic tracebacks of a
+ *        multihit Forward matrix of the region, null2 by trace, single-linkage clustering of the sampled
+ *        segments (overlap .8 of the smaller, diagonal 4, posterior .25, endpoint .02) -- with HMMER's fast
+ *        generator (x*69069+1, seed 42 mixed as Easel does), BUT trace t draws from its own substream
+ *        (start + t*15485863 steps) instead of continuing where trace t-1 stopped, so that traces are
+ *        independent work items; HMMER's own result is not reproducible across its SIMD builds either,
+ *        because one roll that lands differently shifts every later draw;
  *   DEV4 exp() for the probability-space tables uses libm expf, not HMMER's SSE polynomial.
  */
 #define _GNU_SOURCE
@@ -710,8 +715,27 @@ typedef struct {
   float dombias, bitscore; double lnP; int is_reported;
 } DOMAIN;
 
+/* null2 odds of the 20 residues from state usage (match me[], insert ie[], flanks xfactor), canonical order */
+static void null2_from_usage(const PROF *p, const float *me, const float *ie, float xfactor, float *null2)
+{
+  int Q = p->Q, Mp = p->Mp;
+  for (int x = 0; x < 20; x++) {
+    const float *rfx = p->rf + (size_t)x * Mp;
+    float S[P7O_NL], nS[P7O_NL];
+    for (int z = 0; z < P7O_NL; z++) { float s = 0.f; for (int q = 0; q < Q; q++) { int idx = z*Q+q; float t = me[idx] * rfx[idx]; s = s + t; s = s + ie[idx]; } S[z] = s; }
+    for (int w = 32; w >= 1; w >>= 1) { for (int z = 0; z < P7O_NL; z++) nS[z] = S[z] + S[z ^ w]; memcpy(S, nS, sizeof(S)); }
+    null2[x] = S[0] + xfactor;
+  }
+}
+
+static void null2_fill_degenerate(float *null2)
+{
+  for (int x = 21; x <= 26; x++) { float r = 0.f; int n = 0; for (int y = 0; y < 20; y++) if (degen(x, y)) { r += null2[y]; n++; } null2[x] = r / (float)n; }
+  null2[20] = null2[27] = null2[28] = 1.0f;
+}
+
 static int rescore_envelope(const PROF *p, const uint8_t *dsq_full, int L_full, int ienv, int jenv,
-                            float *n2sc /* per-position, 1-based, may be NULL */, DOMAIN *dom,
+                            float *n2sc /* per-position, 1-based, may be NULL */, int null2_done, DOMAIN *dom,
                             float *out_null2, float *out_xC, int *out_nscale)
 {
   int Mp = p->Mp, M = p->M, Q = p->Q, Ld = jenv - ienv + 1;
@@ -744,26 +768,20 @@ static int rescore_envelope(const PROF *p, const uint8_t *dsq_full, int L_full, 
   if (range_err) { free(fmx); free(bmx); free(fxs); free(bxs); free(ppN); free(ppJ); free(ppC); return -1; }
   /* null2 by expectation */
   float null2[P7O_KP];
-  {
+  if (!null2_done) {
     float *me = calloc((size_t)2*Mp, sizeof(float)), *ie = me + Mp; float xN = 0.f, xJ = 0.f, xC = 0.f;
     for (int i = 1; i <= Ld; i++) { float *b = bmx + rowsz * i; for (int k = 0; k < Mp; k++) { me[k] = me[k] + b[k]; ie[k] = ie[k] + b[Mp+k]; } xN = xN + ppN[i]; xJ = xJ + ppJ[i]; xC = xC + ppC[i]; }
     float norm = 1.0f / (float)Ld;
     for (int k = 0; k < Mp; k++) { me[k] *= norm; ie[k] *= norm; }
     float xfactor = ((xN + xC) + xJ) * norm;
-    for (int x = 0; x < 20; x++) {
-      const float *rfx = p->rf + (size_t)x * Mp;
-      float S[P7O_NL], nS[P7O_NL];
-      for (int z = 0; z < P7O_NL; z++) { float s = 0.f; for (int q = 0; q < Q; q++) { int idx = z*Q+q; float t = me[idx] * rfx[idx]; s = s + t; s = s + ie[idx]; } S[z] = s; }
-      for (int w = 32; w >= 1; w >>= 1) { for (int z = 0; z < P7O_NL; z++) nS[z] = S[z] + S[z ^ w]; memcpy(S, nS, sizeof(S)); }
-      null2[x] = S[0] + xfactor;
-    }
+    null2_from_usage(p, me, ie, xfactor, null2);
     free(me);
     if (out_null2) memcpy(out_null2, null2, sizeof(float)*20);
-    for (int x = 21; x <= 26; x++) { float r = 0.f; int n = 0; for (int y = 0; y < 20; y++) if (degen(x, y)) { r += null2[y]; n++; } null2[x] = r / (float)n; }
-    null2[20] = null2[27] = null2[28] = 1.0f;
+    null2_fill_degenerate(null2);
   }
   float domcorrection = 0.f;
-  for (int pos = ienv; pos <= jenv; pos++) { float v = logf(null2[dsq_full[pos-1]]); if (n2sc) n2sc[pos] = v; domcorrection += v; }
+  if (null2_done) { for (int pos = ienv; pos <= jenv; pos++) domcorrection += n2sc[pos]; }     /* set by the trace ensemble */
+  else for (int pos = ienv; pos <= jenv; pos++) { float v = logf(null2[dsq_full[pos-1]]); if (n2sc) n2sc[pos] = v; domcorrection += v; }
   dom->domcorrection = domcorrection;
   /* optimal accuracy fill (DEV2: -inf gating); matrix overwrites fmx */
   {
@@ -837,9 +855,246 @@ int p7o_envelope(const P7O_HMM *hmm, const uint8_t *dsq, int L_full, int ienv, i
                  float *envsc, float *oasc, float *null2, int32_t *coords, float *fwd_xC, int32_t *nscale)
 {
   PROF *p = prof_create(hmm); DOMAIN d; int ns;
-  int rc = rescore_envelope(p, dsq, L_full, ienv, jenv, NULL, &d, null2, fwd_xC, &ns);
+  int rc = rescore_envelope(p, dsq, L_full, ienv, jenv, NULL, 0, &d, null2, fwd_xC, &ns);
   *envsc = d.envsc; *oasc = d.oasc; coords[0] = d.hmm_from; coords[1] = d.hmm_to; coords[2] = d.ali_from; coords[3] = d.ali_to;
   if (nscale) *nscale = ns;
+  prof_free(p); return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-domain regions: stochastic trace ensemble + single-linkage clustering (see DEV3)
+ * ------------------------------------------------------------------------------------------ */
+#define ENS_NSAMPLES 200
+#define ENS_STRIDE   15485863u
+#define ENS_MIN_OVERLAP   0.8f
+#define ENS_MAX_DIAGDIFF  4
+#define ENS_MIN_POSTERIOR 0.25f
+#define ENS_MIN_ENDPOINTP 0.02f
+
+static uint32_t mix3(uint32_t a, uint32_t b, uint32_t c)
+{
+  a -= b; a -= c; a ^= (c >> 13);  b -= c; b -= a; b ^= (a << 8);   c -= a; c -= b; c ^= (b >> 13);
+  a -= b; a -= c; a ^= (c >> 12);  b -= c; b -= a; b ^= (a << 16);  c -= a; c -= b; c ^= (b >> 5);
+  a -= b; a -= c; a ^= (c >> 3);   b -= c; b -= a; b ^= (a << 10);  c -= a; c -= b; c ^= (b >> 15);
+  return c;
+}
+/* state of x -> x*69069+1 after n steps */
+static uint32_t lcg_jump(uint32_t x, uint64_t n)
+{
+  uint32_t A = 69069u, C = 1u, ra = 1u, rc = 0u;
+  while (n) { if (n & 1) { ra = A * ra; rc = A * rc + C; } C = A * C + C; A = A * A; n >>= 1; }
+  return ra * x + rc;
+}
+uint32_t p7o_ensemble_seed(int t)
+{
+  uint32_t x0 = mix3(42u, 87654321u, 12345678u); if (x0 == 0) x0 = 42u;
+  return lcg_jump(x0, (uint64_t)t * ENS_STRIDE);
+}
+static inline double roll_next(uint32_t *x) { *x = *x * 69069u + 1u; return (double)*x / 4294967296.0; }
+
+/* first index whose cumulative weight exceeds roll * total; weights summed in index order */
+static int choose(double roll, const float *pth, int n)
+{
+  float norm = pth[0]; for (int i = 1; i < n; i++) norm = norm + pth[i];
+  if (!(norm > 0.0f)) return 0;
+  double target = roll * (double)norm, sum = 0.0;
+  for (int i = 0; i < n; i++) { sum += (double)pth[i]; if (target < sum) return i; }
+  for (int i = n-1; i > 0; i--) if (pth[i] > 0.0f) return i;
+  return 0;
+}
+
+/* One stochastic traceback of the region's Forward matrix (rows 0..Ld of 3*Mp, specials xs rows of 6).
+ * code[i], i=1..Ld: 0 = residue emitted outside a domain (N/J/C); 0x4000|k match state k; 0x8000|k insert state k;
+ * bit 0x2000... not used; the first match state of each domain is additionally recorded in seg[].
+ * Segments are produced last-domain-first; returns their number (or -1 if more than cap). */
+static int stochastic_trace(const PROF *p, const XF *xf, int Ld, const float *mx, const float *xs, uint32_t *rng,
+                            uint16_t *code, P7O_SEG *seg, int cap)
+{
+  int Mp = p->Mp, M = p->M; size_t rowsz = (size_t)3 * Mp;
+  enum { sC, sE, sM, sI, sD, sB, sJ, sN } st = sC;
+  int i = Ld, k = 0, nseg = 0, sqto = 0, hmmto = 0;
+  float pth[4];
+  for (;;) {
+    const float *cr = mx + rowsz * i, *pr = (i > 0) ? mx + rowsz * (i-1) : mx;
+    switch (st) {
+    case sC:
+      pth[0] = xs[(size_t)(i-1)*6+4] * xf->loop;
+      pth[1] = (xs[(size_t)i*6+0] * xf->E_move) * xs[(size_t)i*6+5];
+      if (choose(roll_next(rng), pth, 2) == 0) { code[i] = 0; i--; } else st = sE;
+      break;
+    case sJ:
+      pth[0] = xs[(size_t)(i-1)*6+2] * xf->loop;
+      pth[1] = (xs[(size_t)i*6+0] * xf->E_loop) * xs[(size_t)i*6+5];
+      if (choose(roll_next(rng), pth, 2) == 0) { code[i] = 0; i--; } else st = sE;
+      break;
+    case sE: {
+      /* any M(i,k), D(i,k): cells in node order, match before delete */
+      double total = 0.0;
+      for (int c = 0; c < M; c++) { total += (double)cr[c]; total += (double)cr[2*Mp+c]; }
+      double target = roll_next(rng) * total, sum = 0.0; int pick = -1, isd = 0, lastc = -1, lastd = 0;
+      for (int c = 0; c < M && pick < 0; c++) {
+        if (cr[c] > 0.0f) { lastc = c; lastd = 0; }
+        sum += (double)cr[c]; if (target < sum) { pick = c; isd = 0; break; }
+        if (cr[2*Mp+c] > 0.0f) { lastc = c; lastd = 1; }
+        sum += (double)cr[2*Mp+c]; if (target < sum) { pick = c; isd = 1; break; }
+      }
+      if (pick < 0) { pick = lastc < 0 ? 0 : lastc; isd = lastd; }
+      k = pick + 1; st = isd ? sD : sM; sqto = 0; hmmto = 0;
+    } break;
+    case sM: {
+      int c = k - 1;
+      code[i] = (uint16_t)(0x4000 | k);
+      if (!sqto) { sqto = i; hmmto = k; }
+      pth[0] = xs[(size_t)(i-1)*6+3] * p->fBM[c];
+      if (c > 0) { pth[1] = pr[c-1] * p->fMM[c]; pth[2] = pr[Mp+c-1] * p->fIM[c]; pth[3] = pr[2*Mp+c-1] * p->fDM[c]; }
+      else pth[1] = pth[2] = pth[3] = 0.0f;
+      int ch = choose(roll_next(rng), pth, 4);
+      if (ch == 0) {
+        if (nseg == cap) return -1;
+        seg[nseg].sqfrom = i; seg[nseg].sqto = sqto; seg[nseg].hmmfrom = k; seg[nseg].hmmto = hmmto; nseg++;
+        st = sB;
+      } else st = (ch == 1) ? sM : (ch == 2) ? sI : sD;
+      i--; k--;
+    } break;
+    case sI: {
+      int c = k - 1;
+      code[i] = (uint16_t)(0x8000 | k);
+      pth[0] = pr[c] * p->fMI[c]; pth[1] = pr[Mp+c] * p->fII[c];
+      st = (choose(roll_next(rng), pth, 2) == 0) ? sM : sI;
+      i--;
+    } break;
+    case sD: {
+      int c = k - 1;
+      if (c > 0) { pth[0] = cr[c-1] * p->fMD[c-1]; pth[1] = cr[2*Mp+c-1] * p->fDD[c-1]; } else pth[0] = pth[1] = 0.0f;
+      st = (choose(roll_next(rng), pth, 2) == 0) ? sM : sD;
+      k--;
+    } break;
+    case sB:
+      pth[0] = xs[(size_t)i*6+1] * xf->move; pth[1] = xs[(size_t)i*6+2] * xf->move;
+      st = (choose(roll_next(rng), pth, 2) == 0) ? sN : sJ;
+      break;
+    case sN:
+      for (; i >= 1; i--) code[i] = 0;
+      return nseg;
+    }
+    if (i < 0 || k < 0 || (st == sM && (k < 1 || i < 1)) || (st == sI && (k < 1 || i < 1)) || (st == sD && k < 1) ||
+        ((st == sC || st == sJ || st == sE) && i < 1)) {
+      /* a numerically impossible move (all candidate paths zero): end the trace here */
+      for (; i >= 1; i--) code[i] = 0;
+      return nseg;
+    }
+  }
+}
+
+/* n2sum[pos-ireg] (pos = ireg..jreg) = sum over traces of the null2 odds ratio; seg_all/nseg_all: every trace's
+ * segments in region-local coordinates, first-domain-first. */
+static int trace_ensemble(const PROF *p, const uint8_t *dsq, int L, int ireg, int jreg,
+                          float *n2sum, P7O_SEG *seg_all, int *nseg_all, int cap)
+{
+  int Mp = p->Mp, Ld = jreg - ireg + 1; size_t rowsz = (size_t)3 * Mp;
+  const uint8_t *rd = dsq + (ireg - 1);
+  XF xf; xf_config(p, L, 1, &xf);
+  float *mx = malloc(sizeof(float) * rowsz * (Ld+1)), *xs = malloc(sizeof(float) * 6 * (Ld+1));
+  forward(p, &xf, rd, Ld, mx, xs, NULL, NULL);
+  uint16_t *code = malloc(sizeof(uint16_t) * (Ld+2));
+  float *ratio = malloc(sizeof(float) * (size_t)ENS_NSAMPLES * (Ld+1));
+  float *cm = malloc(sizeof(float) * 2 * Mp), *ci = cm + Mp;
+  int rc = 0;
+  for (int t = 0; t < ENS_NSAMPLES && rc == 0; t++) {
+    uint32_t rng = p7o_ensemble_seed(t);
+    P7O_SEG *seg = seg_all + (size_t)t * cap;
+    int ns = stochastic_trace(p, &xf, Ld, mx, xs, &rng, code, seg, cap);
+    if (ns < 0) { rc = -1; break; }
+    for (int a = 0, b = ns-1; a < b; a++, b--) { P7O_SEG tmp = seg[a]; seg[a] = seg[b]; seg[b] = tmp; }
+    nseg_all[t] = ns;
+    float *rt = ratio + (size_t)t * (Ld+1);
+    for (int pos = 1; pos <= Ld; pos++) rt[pos] = 1.0f;
+    for (int d = 0; d < ns; d++) {
+      float null2[P7O_KP]; int nemit = 0;
+      memset(cm, 0, sizeof(float) * 2 * Mp);
+      for (int pos = seg[d].sqfrom; pos <= seg[d].sqto; pos++) {
+        int kk = code[pos] & 0x3fff;
+        if (code[pos] & 0x4000) { cm[kk-1] += 1.0f; nemit++; } else if (code[pos] & 0x8000) { ci[kk-1] += 1.0f; nemit++; }
+      }
+      float norm = 1.0f / (float)nemit;
+      for (int c = 0; c < Mp; c++) { cm[c] *= norm; ci[c] *= norm; }
+      null2_from_usage(p, cm, ci, 0.0f, null2);
+      null2_fill_degenerate(null2);
+      /* the first residue of a domain keeps ratio 1 (HMMER's loops use pos <= sqfrom for the flank) */
+      for (int pos = seg[d].sqfrom + 1; pos <= seg[d].sqto; pos++) rt[pos] = null2[rd[pos-1]];
+    }
+  }
+  if (rc == 0) for (int pos = 1; pos <= Ld; pos++) {
+    float acc = 0.0f;
+    for (int t = 0; t < ENS_NSAMPLES; t++) acc = acc + ratio[(size_t)t * (Ld+1) + pos];
+    n2sum[pos-1] = acc;
+  }
+  free(mx); free(xs); free(code); free(ratio); free(cm);
+  return rc;
+}
+
+/* single-linkage clustering of sampled segments -> envelopes sorted by start; returns their number */
+static int seg_linked(const P7O_SEG *a, const P7O_SEG *b)
+{
+  int nov = (a->sqto < b->sqto ? a->sqto : b->sqto) - (a->sqfrom > b->sqfrom ? a->sqfrom : b->sqfrom) + 1;
+  int la = a->sqto - a->sqfrom + 1, lb = b->sqto - b->sqfrom + 1, n = la < lb ? la : lb;
+  if ((float)nov / (float)n < ENS_MIN_OVERLAP) return 0;
+  nov = (a->hmmto < b->hmmto ? a->hmmto : b->hmmto) - (a->hmmfrom > b->hmmfrom ? a->hmmfrom : b->hmmfrom) + 1;
+  la = a->hmmto - a->hmmfrom + 1; lb = b->hmmto - b->hmmfrom + 1; n = la < lb ? la : lb;
+  if ((float)nov / (float)n < ENS_MIN_OVERLAP) return 0;
+  int d1 = (a->sqfrom - a->hmmfrom + a->sqto - a->hmmto) / 2, d2 = (b->sqfrom - b->hmmfrom + b->sqto - b->hmmto) / 2;
+  if (abs(d1 - d2) > ENS_MAX_DIAGDIFF) return 0;
+  return 1;
+}
+
+static int cluster_ensemble(const P7O_SEG *seg_all, const int *nseg_all, int cap, P7O_SEG *env, int envcap)
+{
+  int n = 0;
+  for (int t = 0; t < ENS_NSAMPLES; t++) n += nseg_all[t];
+  if (!n) return 0;
+  P7O_SEG *sg = malloc(sizeof(P7O_SEG) * n); int *tr = malloc(sizeof(int) * n * 3), *asg = tr + n, *stack = asg + n;
+  { int h = 0; for (int t = 0; t < ENS_NSAMPLES; t++) for (int d = 0; d < nseg_all[t]; d++) { sg[h] = seg_all[(size_t)t * cap + d]; tr[h] = t; h++; } }
+  for (int h = 0; h < n; h++) asg[h] = -1;
+  int nc = 0;
+  for (int h = 0; h < n; h++) if (asg[h] < 0) {
+    int sp = 0; stack[sp++] = h; asg[h] = nc;
+    while (sp) { int a = stack[--sp]; for (int b = 0; b < n; b++) if (asg[b] < 0 && seg_linked(&sg[a], &sg[b])) { asg[b] = nc; stack[sp++] = b; } }
+    nc++;
+  }
+  int nenv = 0;
+  for (int c = 0; c < nc; c++) {
+    int ninc = 0, lastt = -1;
+    for (int h = 0; h < n; h++) if (asg[h] == c && tr[h] != lastt) { ninc++; lastt = tr[h]; }   /* traces are contiguous in sg[] */
+    if ((float)ninc / (float)ENS_NSAMPLES < ENS_MIN_POSTERIOR) continue;
+    int lim[4][2];   /* min,max of sqfrom, sqto, hmmfrom, hmmto */
+    for (int f = 0; f < 4; f++) { lim[f][0] = 1 << 30; lim[f][1] = -1; }
+    for (int h = 0; h < n; h++) if (asg[h] == c) {
+      int v[4] = { sg[h].sqfrom, sg[h].sqto, sg[h].hmmfrom, sg[h].hmmto };
+      for (int f = 0; f < 4; f++) { if (v[f] < lim[f][0]) lim[f][0] = v[f]; if (v[f] > lim[f][1]) lim[f][1] = v[f]; }
+    }
+    int best[4];
+    for (int f = 0; f < 4; f++) {
+      int span = lim[f][1] - lim[f][0] + 1; int *epc = calloc(span, sizeof(int));
+      for (int h = 0; h < n; h++) if (asg[h] == c) { int v = (f == 0) ? sg[h].sqfrom : (f == 1) ? sg[h].sqto : (f == 2) ? sg[h].hmmfrom : sg[h].hmmto; epc[v - lim[f][0]]++; }
+      int b;
+      if (f == 0 || f == 2) { for (b = lim[f][0]; b < lim[f][1]; b++) if ((float)epc[b - lim[f][0]] / (float)ninc >= ENS_MIN_ENDPOINTP) break; }
+      else                  { for (b = lim[f][1]; b > lim[f][0]; b--) if ((float)epc[b - lim[f][0]] / (float)ninc >= ENS_MIN_ENDPOINTP) break; }
+      best[f] = b; free(epc);
+    }
+    if (nenv < envcap) { env[nenv].sqfrom = best[0]; env[nenv].sqto = best[1]; env[nenv].hmmfrom = best[2]; env[nenv].hmmto = best[3]; nenv++; }
+  }
+  /* order by start (then end): insertion sort, clusters are few */
+  for (int a = 1; a < nenv; a++) { P7O_SEG v = env[a]; int b = a - 1; while (b >= 0 && (env[b].sqfrom > v.sqfrom || (env[b].sqfrom == v.sqfrom && env[b].sqto > v.sqto))) { env[b+1] = env[b]; b--; } env[b+1] = v; }
+  free(sg); free(tr);
+  return nenv;
+}
+
+int p7o_region_ensemble(const P7O_HMM *hmm, const uint8_t *dsq, int L, int ireg, int jreg,
+                        float *n2sum, P7O_SEG *seg_all, int32_t *nseg_all, int cap, P7O_SEG *env, int envcap, int32_t *nenv)
+{
+  PROF *p = prof_create(hmm);
+  int rc = trace_ensemble(p, dsq, L, ireg, jreg, n2sum, seg_all, nseg_all, cap);
+  if (rc == 0) *nenv = cluster_ensemble(seg_all, nseg_all, cap, env, envcap);
   prof_free(p); return rc;
 }
 
@@ -878,25 +1133,27 @@ static void domain_definition(const PROF *p, const uint8_t *dsq, int L, const fl
       float max = -1.0f;
       for (int z = i; z <= j; z++) { float a = etot[z] - etot[i-1], b = btot[j] - btot[z-1]; float en = a < b ? a : b; if (en > max) max = en; }
       if (max >= RT3) {
-        /* DEV3: deterministic posterior split.  Cut the region after every position z (i<=z<j) at which the
-         * cumulative expected number of domain ends since i-1 first reaches n-0.5 (n = 1,2,..) while at
-         * least 0.5 expected ends remain to the right -- one envelope per expected domain. */
+        /* the region holds more than one domain: resolve it by the trace ensemble (DEV3) */
         dd->nclustered++;
-        int start = i; float next = 0.5f;
-        float total = etot[j] - etot[i-1];
-        for (int z = i; z < j; z++) {
-          float a = etot[z] - etot[i-1];
-          if (a >= next && (total - a) >= 0.5f) {
+        if (getenv("P7O_TRACE_REGIONS")) fprintf(stderr, "p7o: multi-domain region %d..%d of L=%d (M=%d)\n", i, j, L, p->M);
+        int Lr = j - i + 1, cap = Lr < 512 ? Lr : 512;
+        float *n2sum = malloc(sizeof(float) * Lr);
+        P7O_SEG *seg_all = malloc(sizeof(P7O_SEG) * (size_t)ENS_NSAMPLES * cap), env[64]; int nseg_all[ENS_NSAMPLES];
+        if (trace_ensemble(p, dsq, L, i, j, n2sum, seg_all, nseg_all, cap) == 0) {
+          for (int pos = i; pos <= j; pos++) dd->n2sc[pos] = logf(n2sum[pos-i] / (float)ENS_NSAMPLES);
+          int nenv = cluster_ensemble(seg_all, nseg_all, cap, env, 64), last_j2 = 0;
+          for (int e = 0; e < nenv; e++) {
+            int i2 = env[e].sqfrom + i - 1, j2 = env[e].sqto + i - 1;
+            if (i2 <= last_j2) continue;          /* overlapping envelopes: the later one is skipped, as HMMER does */
             DOMAIN d; memset(&d, 0, sizeof(d)); dd->nenvelopes++;
-            if (rescore_envelope(p, dsq, L, start, z, dd->n2sc, &d, NULL, NULL, NULL) == 0) ddef_add(dd, &d);
-            start = z + 1; next += 1.0f;
+            if (rescore_envelope(p, dsq, L, i2, j2, dd->n2sc, 1, &d, NULL, NULL, NULL) == 0) ddef_add(dd, &d);
+            last_j2 = j2;
           }
         }
-        DOMAIN d; memset(&d, 0, sizeof(d)); dd->nenvelopes++;
-        if (rescore_envelope(p, dsq, L, start, j, dd->n2sc, &d, NULL, NULL, NULL) == 0) ddef_add(dd, &d);
+        free(n2sum); free(seg_all);
       } else {
         DOMAIN d; memset(&d, 0, sizeof(d)); dd->nenvelopes++;
-        if (rescore_envelope(p, dsq, L, i, j, dd->n2sc, &d, NULL, NULL, NULL) == 0) ddef_add(dd, &d);
+        if (rescore_envelope(p, dsq, L, i, j, dd->n2sc, 0, &d, NULL, NULL, NULL) == 0) ddef_add(dd, &d);
       }
       i = -1; triggered = 0;
     }

@@ -106,6 +106,14 @@ int p7o_envelope(const P7O_HMM *hmm, const uint8_t *dsq, int L_full, int ienv, i
                  float *envsc, float *oasc, float *null2 /*[20]*/, int32_t *coords /*[4] hmmfrom,hmmto,alifrom,alito*/,
                  float *fwd_xC, int32_t *nscale);
 
+/* multi-domain regions: 200-trace ensemble of region ireg..jreg (1-based, inclusive) of a sequence of length L.
+ * n2sum[Lr]: per position, sum over traces of the null2 odds ratio.  seg_all[200*cap] / nseg_all[200]: each trace's
+ * sampled segments in region-local coordinates.  env/nenv: clustered envelopes (region-local), sorted by start. */
+typedef struct { int32_t sqfrom, sqto, hmmfrom, hmmto; } P7O_SEG;
+uint32_t p7o_ensemble_seed(int t);
+int p7o_region_ensemble(const P7O_HMM *hmm, const uint8_t *dsq, int L, int ireg, int jreg,
+                        float *n2sum, P7O_SEG *seg_all, int32_t *nseg_all, int cap, P7O_SEG *env, int envcap, int32_t *nenv);
+
 #ifdef __cplusplus
 }
 #endif

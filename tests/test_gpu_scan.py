@@ -263,3 +263,69 @@ def test_fasta_ingest_equals_packed_records(world, tmp_path):
     with pytest.raises(_lib.CkmError) as e:
         _lib.Seqs.from_fasta(w["ctx"], [str(tmp_path / "nope.faa")])
     assert e.value.code == -2
+
+
+def _tandem_records(profs, seed, n_per_model=2):
+    """ORFs whose domain copies abut with uncertain boundaries -- a copy truncated at a random node followed at once by a
+    copy that starts mid-model, or four fragments in a row: the posterior never drops between them, so the region
+    fails the rt3 test and is resolved by the trace ensemble."""
+    rng = np.random.default_rng(seed)
+    recs = []
+    for mi, pr in enumerate(profs):
+        M = pr.M
+        for r in range(n_per_model):
+            parts = [synth.random_residues(rng, 10 + 7 * r)]
+            if r % 2 == 0:
+                a = int(rng.integers(M // 2, M)); b = int(rng.integers(1, M // 2))
+                parts += [synth.sample_domain(rng, pr, 1, a), synth.sample_domain(rng, pr, b, M)]
+            else:
+                for c in range(4):
+                    a = int(rng.integers(1, M // 2)); b = int(rng.integers(a + M // 4, M + 1))
+                    parts.append(synth.sample_domain(rng, pr, a, b))
+            parts.append(synth.random_residues(rng, 12))
+            recs.append(("tandem%d_%d" % (mi, r + 1), "", synth.to_text(np.concatenate(parts)) + "*"))
+    return recs
+
+
+@pytest.fixture(scope="module")
+def tandem(gpu_ctx):
+    profs = common.mixed_profiles()
+    path = common.hmm_file("mixed", profs)
+    recs = _tandem_records(profs, 77)
+    prof = _lib.Profiles(gpu_ctx, path)
+    seqs = _lib.Seqs(gpu_ctx, [recs])
+    hs = p7.HmmSet(path)
+    dsq = [p7.digitize(r[2]) for r in recs]
+    yield dict(ctx=gpu_ctx, profs=profs, prof=prof, seqs=seqs, hs=hs, recs=recs, dsq=dsq, bins=[recs])
+    prof.close(); seqs.close(); hs.close()
+
+
+def test_trace_ensemble_identical(tandem):
+    """Every sampled segment of every one of the 200 traces, the per-residue null2 odds sums (bit patterns) and the
+    clustered envelopes of a multi-domain region equal the oracle's."""
+    w = tandem
+    nmulti = 0
+    for s, rec in enumerate(w["recs"]):
+        m = int(rec[0][len("tandem"):].split("_")[0])
+        L = len(w["dsq"][s])
+        for (ireg, jreg) in ((1, L), (5, L - 3)):
+            rc, n2o, sego, nsego, envo = w["hs"].region_ensemble(m, w["dsq"][s], ireg, jreg)
+            assert rc == 0
+            n2g, segg, nsegg, envg = _lib.debug_region(w["ctx"], w["prof"], w["seqs"], m, s, ireg, jreg)
+            assert (nsego == nsegg).all(), (rec[0], np.nonzero(nsego != nsegg)[0][:5])
+            for t in range(200):
+                assert (sego[t, :nsego[t]] == segg[t, :nsegg[t]]).all(), (rec[0], t)
+            assert (common.float_bits(n2o) == common.float_bits(n2g)).all(), (rec[0], np.nonzero(n2o != n2g)[0][:5])
+            assert envo.tolist() == envg.tolist(), (rec[0], envo.tolist(), envg.tolist())
+            nmulti += len(envo) >= 2
+    assert nmulti >= len(w["recs"])          # the planted copies are found as separate envelopes (two regions per record)
+
+
+def test_search_multidomain_rows_identical(tandem):
+    w = tandem
+    hits = _lib.search(w["ctx"], w["prof"], w["seqs"])
+    _compare_search(w, hits, None)
+    st = w["ctx"].stats()
+    assert st.regions_multi >= len(w["recs"]) // 2, st.regions_multi
+    assert max(hits.ndom[g] for g in hits.rows(0)) >= 2
+    hits.close()
