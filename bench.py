@@ -17,6 +17,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before torch initialises HIP: see checkm_amd/__init__.py
 
 import numpy as np  # noqa: E402
 
@@ -162,7 +163,7 @@ def main():
             "roofline_valu": valu,
             "stages_ms": {"ssv": st.ms_ssv, "filters": st.ms_filters, "fwdbwd": st.ms_fwdbwd, "domains": st.ms_domains, "host": st.ms_host, "search_total": st.ms_total},
             "stage_pairs": {"ssv": int(st.pairs_ssv), "msv_full": int(st.pairs_msv_full), "bias": int(st.pairs_bias), "vit": int(st.pairs_vit),
-                            "fwd": int(st.pairs_fwd), "dom": int(st.pairs_dom), "envelopes": int(st.envelopes)},
+                            "fwd": int(st.pairs_fwd), "dom": int(st.pairs_dom), "envelopes": int(st.envelopes), "regions_multi": int(st.regions_multi)},
             "rows": int(nrows), "setup_s": {"generate": t_gen, "pack_and_upload": t_pack},
         }
         if not args.no_cpu_baseline:

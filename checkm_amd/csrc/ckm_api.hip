@@ -17,6 +17,9 @@
 #include <thread>
 #include <exception>
 #include <numeric>
+#include <array>
+#include <condition_variable>
+#include <functional>
 #include "ckm_internal.h"
 #include "dev_types.h"
 
@@ -80,6 +83,64 @@ struct PinnedBuf {      // grow-only page-locked host staging buffer (pageable D
   ~PinnedBuf() { if (p) (void)hipHostFree(p); }
 };
 
+
+// A few host threads for the per-pair / per-sequence glue between the kernel stages (logs of rescale factors, region
+// scans over the decoding terms, segment clustering, bit scores): the device idles while that glue runs.
+class HostPool {
+ public:
+  explicit HostPool(int nthreads) {
+    for (int i = 1; i < nthreads; ++i) th_.emplace_back([this] { loop(); });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+    cv_.notify_all();
+    for (auto &t : th_) t.join();
+  }
+  // f(lo, hi) over [0, n) in chunks; the caller works too; returns when every chunk is done
+  void run(size_t n, size_t chunk, const std::function<void(size_t, size_t)> &f) {
+    if (!n) return;
+    if (th_.empty() || n <= chunk) { f(0, n); return; }
+    {
+      std::lock_guard<std::mutex> g(m_);
+      job_ = &f; n_ = n; chunk_ = chunk; next_.store(0); pending_ = (n + chunk - 1) / chunk; err_ = nullptr; ++gen_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> g(m_);
+    done_.wait(g, [this] { return pending_ == 0; });
+    job_ = nullptr;
+    if (err_) std::rethrow_exception(err_);
+  }
+ private:
+  void work() {
+    for (;;) {
+      const size_t lo = next_.fetch_add(chunk_);
+      if (lo >= n_) return;
+      const size_t hi = std::min(n_, lo + chunk_);
+      try { (*job_)(lo, hi); } catch (...) { std::lock_guard<std::mutex> g(m_); if (!err_) err_ = std::current_exception(); }
+      std::lock_guard<std::mutex> g(m_);
+      if (--pending_ == 0) done_.notify_all();
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return stop_ || (gen_ != seen && job_); });
+        if (stop_) return;
+        seen = gen_;
+      }
+      work();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_; std::condition_variable cv_, done_;
+  const std::function<void(size_t, size_t)> *job_ = nullptr;
+  size_t n_ = 0, chunk_ = 1, pending_ = 0; std::atomic<size_t> next_{0};
+  uint64_t gen_ = 0; bool stop_ = false; std::exception_ptr err_;
+};
+
 }  // namespace ckm
 
 using namespace ckm;
@@ -90,6 +151,7 @@ using namespace ckm;
 struct Worker {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t ens_stream = nullptr;       // trace ensembles run beside the envelope stage
   hipStream_t side[8];                    // per-register-class launches of the rare stages overlap on these
   hipEvent_t ev[8];
   ckm_search_stats stats;
@@ -97,9 +159,10 @@ struct Worker {
   std::vector<uint64_t> plan_key;         // identifies the SSV block tables currently resident in `work` / `idx`
   std::vector<std::pair<int, std::pair<size_t, size_t>>> plan_groups;
   uint64_t plan_npairs = 0, plan_nblocks = 0, plan_residue_hmm = 0, plan_cells = 0, plan_pairs = 0;
-  PinnedBuf h_a, h_b;                     // D2H staging
-  DevBuf work, maxv, surv, nores, counters, cand, raw, idx, vitx, vits, fbwork, fbidx, fbmodel, ws, fout, events, rerr, envout, fullx, fullu, enswork, ensseeds;
+  PinnedBuf h_a, h_b, h_ens;              // D2H staging
+  DevBuf work, maxv, surv, nores, counters, cand, raw, idx, vitx, vits, fbwork, fbidx, fbmodel, ws, fout, events, rerr, envout, fullx, fullu, enswork, ensseeds, ws_ens;
   size_t ws_budget = (size_t)8 << 30;     // float workspace budget (bytes) for Forward/Backward matrices
+  std::unique_ptr<HostPool> pool;         // host threads of this worker
 };
 
 constexpr int NWORKERS = 4;          // upper bound; CKM_WORKERS (default 1) selects how many a search uses
@@ -183,6 +246,9 @@ extern "C" int ckm_device_count(int *n) {
 }
 
 extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
+  // The per-register-class launches of the rare stages overlap on up to 8 streams; the runtime's default of 4 hardware
+  // queues would serialise half of them.  Only effective if HIP has not been initialised in this process yet.
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   return guarded([&] {
     if (!out) throw Error(CKM_EINVAL, "out is NULL");
     *out = nullptr;
@@ -198,6 +264,8 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
     ctx->device = device;
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     if (const char *e = getenv("CKM_WORKERS")) ctx->nworkers = std::max(1, std::min(NWORKERS, atoi(e)));
+    int host_threads = std::max(1, std::min(8, (int)std::thread::hardware_concurrency()));
+    if (const char *e = getenv("CKM_HOST_THREADS")) host_threads = std::max(1, std::min(64, atoi(e)));
     size_t fre = 0, tot = 0;
     size_t budget = (size_t)8 << 30;
     if (hipMemGetInfo(&fre, &tot) == hipSuccess) budget = std::min<size_t>((size_t)96 << 30, fre / 2) / ctx->nworkers;
@@ -205,10 +273,12 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
     for (auto &w : ctx->w) {
       w.device = device;
       HIPCHK(hipStreamCreate(&w.stream));
+      HIPCHK(hipStreamCreate(&w.ens_stream));
       for (auto &st : w.side) HIPCHK(hipStreamCreate(&st));
       for (auto &e : w.ev) HIPCHK(hipEventCreate(&e));
       memset(&w.stats, 0, sizeof(w.stats));
       w.ws_budget = budget;
+      if (&w - ctx->w < ctx->nworkers) w.pool.reset(new HostPool(host_threads));
     }
     *out = ctx.release();
   });
@@ -222,6 +292,7 @@ extern "C" void ckm_ctx_destroy(ckm_ctx *ctx) {
     for (auto &e : w.ev) (void)hipEventDestroy(e);
     for (auto &st : w.side) (void)hipStreamDestroy(st);
     (void)hipStreamDestroy(w.stream);
+    (void)hipStreamDestroy(w.ens_stream);
   }
   delete ctx;
 }
@@ -467,6 +538,8 @@ struct Cand {            // a pair that survived the MSV stage
   PairRec r; float fwdsc; float fwd_xC; uint32_t slot; bool alive;
 };
 
+void pool_run(Worker *w, size_t n, size_t chunk, const std::function<void(size_t, size_t)> &f) { if (w->pool) w->pool->run(n, chunk, f); else if (n) f(0, n); }
+
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 float bits(float sc, float nullsc) { return (float)((double)(sc - nullsc) / kLn2); }
@@ -505,7 +578,7 @@ struct FbBatch {
 };
 
 void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, bool do_fwd, bool do_bwd, bool do_oa,
-            const std::vector<uint32_t> *subset /* indices into b.work, or null = all */) {
+            const std::vector<uint32_t> *subset /* indices into b.work, or null = all */, float *ws_other = nullptr) {
   const size_t n = b.work.size();
   if (!n) return;
   ctx->fbwork.ensure(n * sizeof(FbWork));
@@ -544,7 +617,7 @@ void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, b
   const LenEntry *lt = s->d_lentab.as<LenEntry>();
   const uint8_t *res = s->d_res.as<uint8_t>();
   const uint64_t *off = s->d_off.as<uint64_t>();
-  float *ws = ctx->ws.as<float>();
+  float *ws = ws_other ? ws_other : ctx->ws.as<float>();
   if (do_fwd) HIPCHK(hipMemset(ctx->counters.p, 0, 64));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   // every register class runs its stages in order on its own stream; classes overlap each other
@@ -666,29 +739,37 @@ bool seg_linked(const Seg &a, const Seg &b) {
 }
 
 // single linkage over all sampled segments; clusters seen in >= 25% of the traces become envelopes whose ends are the
-// outermost endpoints sampled in >= 2% of those traces
+// outermost endpoints sampled in >= 2% of those traces.  Most of the 200 traces sample the same few segments, so the
+// linkage runs over the DISTINCT segments (numbered in order of first appearance, which keeps the cluster order).
 void cluster_ensemble(RegionRes &r) {
-  std::vector<Seg> sg; std::vector<int> tr;
-  for (int t = 0; t < ENS_NSAMPLES; ++t) for (int d = 0; d < r.nseg[t]; ++d) { sg.push_back(r.segs[(size_t)t * r.cap + d]); tr.push_back(t); }
-  const int n = (int)sg.size();
+  struct Uniq { Seg g; int count; std::vector<uint8_t> in_trace; };
+  std::vector<Uniq> u;
+  std::map<std::array<int32_t, 4>, int> index;
+  for (int t = 0; t < ENS_NSAMPLES; ++t) for (int d = 0; d < r.nseg[t]; ++d) {
+    const Seg &g = r.segs[(size_t)t * r.cap + d];
+    auto ins = index.insert({{g.sqfrom, g.sqto, g.hmmfrom, g.hmmto}, (int)u.size()});
+    if (ins.second) u.push_back({g, 0, std::vector<uint8_t>(ENS_NSAMPLES, 0)});
+    Uniq &x = u[ins.first->second]; x.count++; x.in_trace[t] = 1;
+  }
+  const int n = (int)u.size();
   std::vector<int> asg(n, -1), stack;
   int nc = 0;
   for (int h = 0; h < n; ++h) if (asg[h] < 0) {
     stack.assign(1, h); asg[h] = nc;
-    while (!stack.empty()) { const int a = stack.back(); stack.pop_back(); for (int b = 0; b < n; ++b) if (asg[b] < 0 && seg_linked(sg[a], sg[b])) { asg[b] = nc; stack.push_back(b); } }
+    while (!stack.empty()) { const int a = stack.back(); stack.pop_back(); for (int b = 0; b < n; ++b) if (asg[b] < 0 && seg_linked(u[a].g, u[b].g)) { asg[b] = nc; stack.push_back(b); } }
     ++nc;
   }
   for (int c = 0; c < nc; ++c) {
-    int ninc = 0, lastt = -1;
-    for (int h = 0; h < n; ++h) if (asg[h] == c && tr[h] != lastt) { ++ninc; lastt = tr[h]; }
+    int ninc = 0;
+    for (int t = 0; t < ENS_NSAMPLES; ++t) { bool any = false; for (int h = 0; h < n && !any; ++h) any = asg[h] == c && u[h].in_trace[t]; ninc += any; }
     if ((float)ninc / (float)ENS_NSAMPLES < kEnsMinPosterior) continue;
     int best[4];
     for (int f = 0; f < 4; ++f) {
-      auto val = [&](int h) { return f == 0 ? sg[h].sqfrom : f == 1 ? sg[h].sqto : f == 2 ? sg[h].hmmfrom : sg[h].hmmto; };
+      auto val = [&](int h) { return f == 0 ? u[h].g.sqfrom : f == 1 ? u[h].g.sqto : f == 2 ? u[h].g.hmmfrom : u[h].g.hmmto; };
       int lo = 1 << 30, hi = -1;
       for (int h = 0; h < n; ++h) if (asg[h] == c) { lo = std::min(lo, val(h)); hi = std::max(hi, val(h)); }
       std::vector<int> epc(hi - lo + 1, 0);
-      for (int h = 0; h < n; ++h) if (asg[h] == c) epc[val(h) - lo]++;
+      for (int h = 0; h < n; ++h) if (asg[h] == c) epc[val(h) - lo] += u[h].count;
       int b;
       if (f == 0 || f == 2) { for (b = lo; b < hi; ++b) if ((float)epc[b - lo] / (float)ninc >= kEnsMinEndpointP) break; }
       else                  { for (b = hi; b > lo; --b) if ((float)epc[b - lo] / (float)ninc >= kEnsMinEndpointP) break; }
@@ -699,9 +780,60 @@ void cluster_ensemble(RegionRes &r) {
   std::stable_sort(r.env.begin(), r.env.end(), [](const Seg &a, const Seg &b) { return a.sqfrom != b.sqfrom ? a.sqfrom < b.sqfrom : a.sqto < b.sqto; });
 }
 
-void run_ensembles(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<RegionReq> &req, std::vector<RegionRes> &out) {
-  out.clear(); out.resize(req.size());
-  if (req.empty()) return;
+// The ensembles of a list of regions, in two halves so that the device works on them while the host drives the
+// envelope stage of the single-domain regions: ens_begin queues Forward + trace kernels + one result copy of the first
+// workspace-sized batch on the worker's ensemble stream; ens_end waits, clusters, and runs what is left.
+struct EnsJob {
+  std::vector<RegionReq> req; std::vector<int> cap;
+  std::vector<std::pair<size_t, size_t>> batches;      // [first, last) of req
+  std::vector<EnsWork> ew;                              // work of the batch in flight
+  uint64_t res_floats = 0; bool in_flight = false; size_t next_batch = 0;
+};
+
+void ens_queue_batch(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, EnsJob &job) {
+  auto al = [](uint64_t v) { return (v + 31) & ~(uint64_t)31; };
+  const auto range = job.batches[job.next_batch++];
+  job.ew.clear();
+  FbBatch b; uint64_t pos = 0; int maxLd = 0, maxMp = 0;
+  // results first (counts, segments, sums of every region: ONE copy back), then the matrices
+  for (size_t j = range.first; j < range.second; ++j) {
+    const RegionReq &r = job.req[j];
+    const int Ld = r.jreg - r.ireg + 1, cap = job.cap[j];
+    EnsWork e; memset(&e, 0, sizeof(e));
+    e.model = r.model; e.seq = r.seq; e.i0 = r.ireg - 1; e.Ld = Ld; e.Lcfg = s->len[r.seq]; e.cap = cap;
+    e.nseg_off = pos; pos += 256;
+    e.seg_off = pos;  pos += (uint64_t)ENS_NSAMPLES * cap * 4;
+    e.n2_off = pos;   pos = al(pos + (uint64_t)Ld);
+    job.ew.push_back(e);
+  }
+  job.res_floats = pos;
+  for (size_t k = 0; k < job.ew.size(); ++k) {
+    EnsWork &e = job.ew[k];
+    const int Mp = p->prof[e.model].fbQ * NL, Ld = e.Ld;
+    e.xs_off = pos;    pos = al(pos + (uint64_t)(Ld + 1) * 6);
+    e.mx_off = pos;    pos = al(pos + (uint64_t)(Ld + 1) * 3 * Mp);
+    e.code_off = pos;  pos = al(pos + ((uint64_t)ENS_NSAMPLES * (Ld + 1) + 1) / 2);
+    e.ratio_off = pos; pos = al(pos + (uint64_t)ENS_NSAMPLES * (Ld + 1));
+    FbWork w; memset(&w, 0, sizeof(w));
+    w.model = e.model; w.seq = e.seq; w.i0 = e.i0; w.Ld = Ld; w.Lcfg = e.Lcfg; w.multihit = 1; w.slot = (uint32_t)k; w.full = 2;
+    w.xs_off = e.xs_off; w.mxf_off = e.mx_off;
+    b.work.push_back(w);
+    maxLd = std::max(maxLd, Ld); maxMp = std::max(maxMp, Mp);
+  }
+  ctx->ws_ens.ensure(pos * 4 + 256);
+  run_fb(ctx, p, s, b, true, false, false, nullptr, ctx->ws_ens.as<float>());   // multihit Forward of every region, M, I and D rows kept
+  ctx->enswork.ensure(job.ew.size() * sizeof(EnsWork));
+  HIPCHK(hipMemcpyAsync(ctx->enswork.p, job.ew.data(), job.ew.size() * sizeof(EnsWork), hipMemcpyHostToDevice, ctx->ens_stream));
+  launch_ensemble(ctx->ens_stream, ctx->enswork.as<EnsWork>(), (uint32_t)job.ew.size(), maxLd, maxMp, p->d_models.as<DevModel>(), s->d_lentab.as<LenEntry>(),
+                  s->d_res.as<uint8_t>(), s->d_off.as<uint64_t>(), ctx->ws_ens.as<float>(), ctx->ensseeds.as<uint32_t>());
+  HIPCHK(hipGetLastError());
+  ctx->h_ens.ensure(job.res_floats * 4);
+  HIPCHK(hipMemcpyAsync(ctx->h_ens.p, ctx->ws_ens.p, job.res_floats * 4, hipMemcpyDeviceToHost, ctx->ens_stream));
+  job.in_flight = true;
+}
+
+void ens_begin(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, EnsJob &job) {
+  if (job.req.empty()) return;
   if (!ctx->ensseeds.p) {
     std::vector<uint32_t> seeds(ENS_NSAMPLES);
     for (int t = 0; t < ENS_NSAMPLES; ++t) seeds[t] = ens_seed(t);
@@ -710,60 +842,64 @@ void run_ensembles(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const 
   }
   auto al = [](uint64_t v) { return (v + 31) & ~(uint64_t)31; };
   const uint64_t budget_floats = ctx->ws_budget / 4;
-  size_t done = 0;
-  while (done < req.size()) {
-    FbBatch b; std::vector<EnsWork> ew; uint64_t pos = 0; size_t j = done; int maxLd = 0, maxMp = 0;
-    for (; j < req.size(); ++j) {
-      const RegionReq &r = req[j];
-      const int Mp = p->prof[r.model].fbQ * NL, Ld = r.jreg - r.ireg + 1, cap = std::min(Ld, 512);
-      EnsWork e; memset(&e, 0, sizeof(e));
-      uint64_t q = al(pos);
-      e.xs_off = q;    q = al(q + (uint64_t)(Ld + 1) * 6);
-      e.mx_off = q;    q = al(q + (uint64_t)(Ld + 1) * 3 * Mp);
-      e.code_off = q;  q = al(q + ((uint64_t)ENS_NSAMPLES * (Ld + 1) + 1) / 2);
-      e.ratio_off = q; q = al(q + (uint64_t)ENS_NSAMPLES * (Ld + 1));
-      e.nseg_off = q;  q = al(q + 256);
-      e.seg_off = q;   q = al(q + (uint64_t)ENS_NSAMPLES * cap * 4);
-      e.n2_off = q;    q = al(q + (uint64_t)Ld);
-      if (q > budget_floats && j > done) break;
-      if (q > budget_floats) throw Error(CKM_ENOMEM, "one multi-domain region needs more workspace than the device budget allows");
-      e.model = r.model; e.seq = r.seq; e.i0 = r.ireg - 1; e.Ld = Ld; e.Lcfg = s->len[r.seq]; e.cap = cap;
-      FbWork w; memset(&w, 0, sizeof(w));
-      w.model = r.model; w.seq = r.seq; w.i0 = e.i0; w.Ld = Ld; w.Lcfg = e.Lcfg; w.multihit = 1; w.slot = (uint32_t)(j - done); w.full = 2;
-      w.xs_off = e.xs_off; w.mxf_off = e.mx_off;
-      b.work.push_back(w); ew.push_back(e); pos = q;
-      maxLd = std::max(maxLd, Ld); maxMp = std::max(maxMp, Mp);
-    }
-    ctx->ws.ensure(pos * 4 + 256);
-    run_fb(ctx, p, s, b, true, false, false, nullptr);       // multihit Forward of every region, all three state rows kept
-    ctx->enswork.ensure(ew.size() * sizeof(EnsWork));
-    HIPCHK(hipMemcpy(ctx->enswork.p, ew.data(), ew.size() * sizeof(EnsWork), hipMemcpyHostToDevice));
-    launch_ensemble(ctx->stream, ctx->enswork.as<EnsWork>(), (uint32_t)ew.size(), maxLd, maxMp, p->d_models.as<DevModel>(), s->d_lentab.as<LenEntry>(),
-                    s->d_res.as<uint8_t>(), s->d_off.as<uint64_t>(), ctx->ws.as<float>(), ctx->ensseeds.as<uint32_t>());
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    for (size_t k = 0; k < ew.size(); ++k) {
-      const EnsWork &e = ew[k]; RegionRes &o = out[done + k];
-      // counts, segments and sums of one region are contiguous in the workspace: one copy
-      const uint64_t span = e.n2_off + (uint64_t)e.Ld - e.nseg_off;
-      std::vector<float> raw(span);
-      HIPCHK(hipMemcpy(raw.data(), ctx->ws.as<float>() + e.nseg_off, span * 4, hipMemcpyDeviceToHost));
-      const int32_t *ns = reinterpret_cast<const int32_t *>(raw.data());
-      const int32_t *sg = reinterpret_cast<const int32_t *>(raw.data() + (e.seg_off - e.nseg_off));
+  job.batches.clear(); job.next_batch = 0;
+  uint64_t pos = 0; size_t first = 0;
+  for (size_t j = 0; j < job.req.size(); ++j) {
+    const RegionReq &r = job.req[j];
+    const uint64_t Mp = p->prof[r.model].fbQ * NL, Ld = r.jreg - r.ireg + 1;
+    const uint64_t need = 256 + (uint64_t)ENS_NSAMPLES * job.cap[j] * 4 + al(Ld) + al((Ld + 1) * 6) + al((Ld + 1) * 3 * Mp) +
+                          al((ENS_NSAMPLES * (Ld + 1) + 1) / 2) + al(ENS_NSAMPLES * (Ld + 1)) + 64;
+    if (need > budget_floats) throw Error(CKM_ENOMEM, "one multi-domain region needs more workspace than the device budget allows");
+    if (pos + need > budget_floats) { job.batches.push_back({first, j}); first = j; pos = 0; }
+    pos += need;
+  }
+  job.batches.push_back({first, job.req.size()});
+  ens_queue_batch(ctx, p, s, job);
+}
+
+void ens_end(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, EnsJob &job, std::vector<RegionRes> &out) {
+  out.clear(); out.resize(job.req.size());
+  if (job.req.empty()) return;
+  std::vector<size_t> again;
+  size_t base = 0;
+  for (;;) {
+    HIPCHK(hipStreamSynchronize(ctx->ens_stream));
+    const float *raw = ctx->h_ens.as<float>();
+    for (size_t k = 0; k < job.ew.size(); ++k) {
+      const EnsWork &e = job.ew[k]; RegionRes &o = out[base + k];
+      const int32_t *ns = reinterpret_cast<const int32_t *>(raw + e.nseg_off);
+      const int32_t *sg = reinterpret_cast<const int32_t *>(raw + e.seg_off);
+      bool overflow = false;
+      for (int t = 0; t < ENS_NSAMPLES; ++t) overflow |= ns[t] < 0;
+      if (overflow) { again.push_back(base + k); continue; }      // more domains in one trace than slots: redo with a larger table
       o.cap = e.cap; o.nseg.assign(ns, ns + ENS_NSAMPLES); o.segs.assign((size_t)ENS_NSAMPLES * e.cap, Seg{0, 0, 0, 0});
-      for (int t = 0; t < ENS_NSAMPLES; ++t) {
-        if (ns[t] < 0) throw Error(CKM_ERANGE, "a sampled trace holds more domains than the segment table allows");
+      for (int t = 0; t < ENS_NSAMPLES; ++t)
         for (int d = 0; d < ns[t]; ++d) {          // the device walks backwards: last domain first
           const int32_t *q4 = sg + ((size_t)t * e.cap + (ns[t] - 1 - d)) * 4;
           o.segs[(size_t)t * e.cap + d] = Seg{q4[0], q4[1], q4[2], q4[3]};
         }
-      }
-      const float *n2 = raw.data() + (e.n2_off - e.nseg_off);
-      o.n2sum.assign(n2, n2 + e.Ld);
-      cluster_ensemble(o);
+      o.n2sum.assign(raw + e.n2_off, raw + e.n2_off + e.Ld);
     }
-    done = j;
+    pool_run(ctx, job.ew.size(), 1, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) if (!out[base + k].nseg.empty()) cluster_ensemble(out[base + k]); });
+    base += job.ew.size();
+    if (job.next_batch >= job.batches.size()) break;
+    ens_queue_batch(ctx, p, s, job);
   }
+  if (!again.empty()) {
+    EnsJob redo; std::vector<RegionRes> r2;
+    for (size_t j : again) { redo.req.push_back(job.req[j]); redo.cap.push_back(std::min(job.req[j].jreg - job.req[j].ireg + 1, job.cap[j] * 8)); }
+    ens_begin(ctx, p, s, redo); ens_end(ctx, p, s, redo, r2);
+    for (size_t k = 0; k < again.size(); ++k) out[again[k]] = std::move(r2[k]);
+  }
+}
+
+constexpr int kEnsCap0 = 16;      // segment slots per trace on the first attempt
+
+void run_ensembles(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<RegionReq> &req, std::vector<RegionRes> &out) {
+  EnsJob job; job.req = req;
+  for (const auto &r : req) job.cap.push_back(std::min(r.jreg - r.ireg + 1, kEnsCap0));
+  ens_begin(ctx, p, s, job);
+  ens_end(ctx, p, s, job, out);
 }
 
 void fill_null2(float *null2) {   // degenerate symbols: plain average of the odds of their residues
@@ -934,19 +1070,19 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
     const float *raw = ctx->h_a.as<float>();
     HIPCHK(hipMemcpyAsync(ctx->h_a.p, ctx->raw.p, cr.size() * 12, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    for (size_t i = 0; i < cands.size(); ++i) {
-      Cand &c = cands[i];
-      const int L = s->len[c.r.seq];
-      const LenEntry &le = s->lentab[L];
-      const float p1 = (float)L / (float)(L + 1);
-      const float nullsc = (float)(log((double)raw[i * 3]) + (double)raw[i * 3 + 1] * kLn2);
-      c.r.filtersc = nullsc + (float)L * logf(p1) + logf(1.0f - p1);
-      (void)le;
-      const float sc = bits(c.r.usc, c.r.filtersc);
-      const HostProfile &hp = p->prof[c.r.model];
-      if (!(sc >= hp.thr_msv_f1)) { c.alive = false; continue; }
-      need_vit[i] = !(sc >= hp.thr_msv_f2);
-    }
+    pool_run(ctx, cands.size(), 4096, [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; ++i) {
+        Cand &c = cands[i];
+        const int L = s->len[c.r.seq];
+        const float p1 = (float)L / (float)(L + 1);
+        const float nullsc = (float)(log((double)raw[i * 3]) + (double)raw[i * 3 + 1] * kLn2);
+        c.r.filtersc = nullsc + (float)L * logf(p1) + logf(1.0f - p1);
+        const float sc = bits(c.r.usc, c.r.filtersc);
+        const HostProfile &hp = p->prof[c.r.model];
+        if (!(sc >= hp.thr_msv_f1)) { c.alive = false; continue; }
+        need_vit[i] = !(sc >= hp.thr_msv_f2);
+      }
+    });
   }
   // ---- stage 3: Viterbi filter ----
   {
@@ -1003,13 +1139,16 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
   }
   EventIndex fev; fev.build(fb.events, fb.work.size());
   std::vector<uint32_t> passers;
-  for (size_t k = 0; k < fb.work.size(); ++k) {
-    Cand &c = cands[fb_cand[k]];
-    const LenEntry &le = s->lentab[s->len[c.r.seq]];
-    c.fwd_xC = fb.fout[k].xC; c.slot = (uint32_t)k;
-    c.fwdsc = finish_forward(fb.fout[k].xC, le.move_m, fev.scales((uint32_t)k));
-    if (bits(c.fwdsc, c.r.filtersc) >= p->prof[c.r.model].thr_fwd_f3) passers.push_back((uint32_t)k); else c.alive = false;
-  }
+  pool_run(ctx, fb.work.size(), 512, [&](size_t lo, size_t hi) {
+    for (size_t k = lo; k < hi; ++k) {
+      Cand &c = cands[fb_cand[k]];
+      const LenEntry &le = s->lentab[s->len[c.r.seq]];
+      c.fwd_xC = fb.fout[k].xC; c.slot = (uint32_t)k;
+      c.fwdsc = finish_forward(fb.fout[k].xC, le.move_m, fev.scales((uint32_t)k));
+      if (!(bits(c.fwdsc, c.r.filtersc) >= p->prof[c.r.model].thr_fwd_f3)) c.alive = false;
+    }
+  });
+  for (size_t k = 0; k < fb.work.size(); ++k) if (cands[fb_cand[k]].alive) passers.push_back((uint32_t)k);
   st.pairs_dom = passers.size();
   // ---- stage 5: Backward parser + posterior domain heuristics ----
   std::vector<EnvReq> envreq; std::vector<std::pair<size_t, size_t>> env_of_pass(passers.size());   // [first, count)
@@ -1025,30 +1164,41 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
     std::vector<float> dec_all(ap - aux_base);     // pageable on purpose: the region scan below re-reads it; pinned memory reads slowly from the CPU
     const float *dec_all_p = dec_all.data();
     if (!dec_all.empty()) HIPCHK(hipMemcpy(dec_all.data(), ctx->ws.as<float>() + aux_base, dec_all.size() * 4, hipMemcpyDeviceToHost));
-    for (size_t q = 0; q < passers.size(); ++q) {
-      const FbWork &w = fb.work[passers[q]];
-      const int L = w.Ld;
-      const float *dec = dec_all_p + (w.aux_off - aux_base);
-      std::vector<float> btot(L + 1, 0.f), etot(L + 1, 0.f), mocc(L + 1, 0.f);
-      for (int i = 1; i <= L; ++i) { btot[i] = btot[i - 1] + dec[(size_t)i * 3]; etot[i] = etot[i - 1] + dec[(size_t)i * 3 + 1]; mocc[i] = 1.0f - dec[(size_t)i * 3 + 2]; }
-      int i = -1; bool triggered = false;
-      for (int j = 1; j <= L; ++j) {
-        if (!triggered) {
-          if (mocc[j] - (btot[j] - btot[j - 1]) < RT2) i = j; else if (i == -1) i = j;
-          if (mocc[j] >= RT1) triggered = true;
-        } else if (mocc[j] - (etot[j] - etot[j - 1]) < RT2) {
-          nregions[q]++;
-          float mx = -1.0f;
-          for (int z = i; z <= j; ++z) { const float a = etot[z] - etot[i - 1], b = btot[j] - btot[z - 1]; const float en = a < b ? a : b; if (en > mx) mx = en; }
-          if (mx >= RT3) { items.push_back({(uint32_t)q, i, j, (int)regreq.size()}); regreq.push_back({w.model, w.seq, i, j}); }
-          else items.push_back({(uint32_t)q, i, j, -1});
-          i = -1; triggered = false;
+    std::vector<std::vector<Item>> found(passers.size());
+    pool_run(ctx, passers.size(), 64, [&](size_t qlo, size_t qhi) {
+      std::vector<float> btot, etot, mocc;
+      for (size_t q = qlo; q < qhi; ++q) {
+        const FbWork &w = fb.work[passers[q]];
+        const int L = w.Ld;
+        const float *dec = dec_all_p + (w.aux_off - aux_base);
+        btot.assign(L + 1, 0.f); etot.assign(L + 1, 0.f); mocc.assign(L + 1, 0.f);
+        for (int i = 1; i <= L; ++i) { btot[i] = btot[i - 1] + dec[(size_t)i * 3]; etot[i] = etot[i - 1] + dec[(size_t)i * 3 + 1]; mocc[i] = 1.0f - dec[(size_t)i * 3 + 2]; }
+        int i = -1; bool triggered = false;
+        for (int j = 1; j <= L; ++j) {
+          if (!triggered) {
+            if (mocc[j] - (btot[j] - btot[j - 1]) < RT2) i = j; else if (i == -1) i = j;
+            if (mocc[j] >= RT1) triggered = true;
+          } else if (mocc[j] - (etot[j] - etot[j - 1]) < RT2) {
+            nregions[q]++;
+            float mx = -1.0f;
+            for (int z = i; z <= j; ++z) { const float a = etot[z] - etot[i - 1], b = btot[j] - btot[z - 1]; const float en = a < b ? a : b; if (en > mx) mx = en; }
+            found[q].push_back({(uint32_t)q, i, j, (mx >= RT3) ? 0 : -1});       // region >= 0: multi-domain, numbered below
+            i = -1; triggered = false;
+          }
         }
       }
+    });
+    for (size_t q = 0; q < passers.size(); ++q) for (Item im : found[q]) {
+      const FbWork &w = fb.work[passers[q]];
+      if (im.region >= 0) { im.region = (int)regreq.size(); regreq.push_back({w.model, w.seq, im.i, im.j}); }
+      items.push_back(im);
     }
-    // multi-domain regions: 200 stochastic tracebacks each, clustered into envelopes
-    st.regions_multi = regreq.size();
-    run_ensembles(ctx, p, s, regreq, regres);
+  }
+  // multi-domain regions: 200 stochastic tracebacks each, clustered into envelopes.  (Queueing them beside the envelope
+  // stage of the single-domain regions was tried: the second envelope pass it needs costs more than it hides.)
+  st.regions_multi = regreq.size();
+  run_ensembles(ctx, p, s, regreq, regres);
+  {
     size_t it = 0;
     for (size_t q = 0; q < passers.size(); ++q) {
       const FbWork &w = fb.work[passers[q]];
@@ -1067,26 +1217,30 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
       env_of_pass[q].second = envreq.size() - env_of_pass[q].first;
     }
   }
-  st.envelopes = envreq.size();
   st.ms_fwdbwd = now_ms() - t_fb0;
   const double t_dom0 = now_ms();
   // ---- stage 6: envelope rescoring ----
   std::vector<EnvRes> envres;
   rescore_envelopes(ctx, p, s, envreq, envres);
+  st.envelopes = envreq.size();
   st.ms_domains = now_ms() - t_dom0;
   const double t_host0 = now_ms();
   // ---- stage 7: scores, thresholds, rows ----
-  size_t item_at = 0;
-  for (size_t q = 0; q < passers.size(); ++q) {
+  std::vector<std::pair<size_t, size_t>> items_of(passers.size(), {0, 0});
+  { size_t it = 0; for (size_t q = 0; q < passers.size(); ++q) { items_of[q].first = it; while (it < items.size() && items[it].pass == q) ++it; items_of[q].second = it; } }
+  std::vector<Hit> hit_of(passers.size()); std::vector<uint8_t> has_hit(passers.size(), 0);
+  pool_run(ctx, passers.size(), 32, [&](size_t qlo, size_t qhi) {
+  std::vector<float> n2sc;
+  for (size_t q = qlo; q < qhi; ++q) {
     const Cand &c = cands[fb_cand[passers[q]]];
     const HostHMM &hm = p->hmm[c.r.model];
     const int L = s->len[c.r.seq];
     const uint8_t *dsq = s->dsq.data() + s->off[c.r.seq];
     const float nullsc = s->lentab[L].nullsc;
-    std::vector<float> n2sc((size_t)L + 2, 0.f);
+    n2sc.assign((size_t)L + 2, 0.f);
     Hit h; h.model = c.r.model; h.seq = c.r.seq; h.L = L; h.nreported = 0;
     int nenv = 0;
-    for (; item_at < items.size() && items[item_at].pass == q; ++item_at) if (items[item_at].region >= 0) {
+    for (size_t item_at = items_of[q].first; item_at < items_of[q].second; ++item_at) if (items[item_at].region >= 0) {
       // null2 of an ensemble region: log of the mean odds ratio over the traces, for every residue of the region
       const Item &im = items[item_at]; const RegionRes &rr = regres[im.region];
       for (int pos = im.i; pos <= im.j; ++pos) n2sc[pos] = logf(rr.n2sum[pos - im.i] / (float)ENS_NSAMPLES);
@@ -1132,8 +1286,10 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
       d.lnP = exp_logsurv(d.bitscore, hm.evparam[4], hm.evparam[5]);
       d.reported = false;
     }
-    by_bin_model[{s->seq_bin[c.r.seq], c.r.model}].push_back(std::move(h));
+    hit_of[q] = std::move(h); has_hit[q] = 1;
   }
+  });
+  for (size_t q = 0; q < passers.size(); ++q) if (has_hit[q]) by_bin_model[{s->seq_bin[hit_of[q].seq], hit_of[q].model}].push_back(std::move(hit_of[q]));
   st.ms_host = now_ms() - t_host0;
   st.ms_total = now_ms() - t_start;
 }

@@ -10,6 +10,7 @@
 // Float results follow the CPU restatement (trace_ensemble in the test oracle) operation by operation; -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include "dev_types.h"
+#include "xlane.h"
 
 namespace ckm {
 
@@ -29,14 +30,38 @@ __device__ __forceinline__ int ens_choose(double roll, const float *pth, int n) 
   return 0;
 }
 
+// E-state choice, evaluated by the whole wavefront for one of its traces.  Canonical order: lane z owns cells
+// z*Q .. z*Q+Q-1; weights in cell order are M(c) then D(c); local[z] = sequential double sum of the lane's 2Q weights;
+// base[z] = local[0] + .. + local[z-1] accumulated in lane order; total = base[64]; the choice is the first position
+// (cell order) whose cumulative weight base[z] + running sum exceeds roll * total; none -> node 1, match.
+__device__ __forceinline__ int ens_select_e(const float *__restrict__ cr, int Q, int Mp, double roll, int lane) {
+  const float *__restrict__ mrow = cr + lane, *__restrict__ drow = cr + 2 * Mp + lane;
+  double local = 0.0;
+  for (int q = 0; q < Q; ++q) { local += (double)mrow[q * 64]; local += (double)drow[q * 64]; }
+  double base = 0.0, run = 0.0;
+#pragma unroll
+  for (int z = 0; z < 64; ++z) { const double tz = __shfl(local, z); if (lane == z) base = run; run += tz; }
+  const double target = roll * run;
+  int found = -1;
+  double acc = 0.0;
+  for (int q = 0; q < Q; ++q) {
+    acc += (double)mrow[q * 64]; if (found < 0 && target < base + acc) found = 2 * q;
+    acc += (double)drow[q * 64]; if (found < 0 && target < base + acc) found = 2 * q + 1;
+  }
+  const unsigned long long any = __ballot(found >= 0);
+  if (!any) return 0;                                   // cell 0, match
+  const int zf = __ffsll((long long)any) - 1;
+  const int f = __shfl(found, zf);
+  return ((zf * Q + (f >> 1)) << 1) | (f & 1);          // (cell << 1) | is_delete
+}
+
 __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restrict__ work, const DevModel *__restrict__ models,
                                                        const LenEntry *__restrict__ lentab, float *__restrict__ ws,
                                                        const uint32_t *__restrict__ seeds) {
   const EnsWork w = work[blockIdx.x];
-  const int t = threadIdx.x;
-  if (t >= ENS_N) return;
+  const int t = threadIdx.x, lane = threadIdx.x & 63;
   const DevModel &md = models[w.model];
-  const int Q = md.fbQ, Mp = Q * 64, M = md.M, Ld = w.Ld;
+  const int Q = md.fbQ, Mp = Q * 64, Ld = w.Ld;
   const size_t rowsz = (size_t)3 * Mp;
   const float *__restrict__ mx = ws + w.mx_off;
   const float *__restrict__ xs = ws + w.xs_off;
@@ -44,94 +69,87 @@ __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restric
               *tMI = md.ftr + 4 * Mp, *tII = md.ftr + 5 * Mp, *tMD = md.ftr + 6 * Mp, *tDD = md.ftr + 7 * Mp;
   const LenEntry le = lentab[w.Lcfg];
   const float loop = le.loop_m, move = le.move_m, Eloop = md.fE_loop, Emove = md.fE_move;
-  uint16_t *__restrict__ code = reinterpret_cast<uint16_t *>(ws + w.code_off) + (size_t)t * (Ld + 1);
-  int32_t *__restrict__ seg = reinterpret_cast<int32_t *>(ws + w.seg_off) + (size_t)t * w.cap * 4;
+  const bool live = t < ENS_N;
+  uint16_t *__restrict__ code = reinterpret_cast<uint16_t *>(ws + w.code_off) + (size_t)(live ? t : 0) * (Ld + 1);
+  int32_t *__restrict__ seg = reinterpret_cast<int32_t *>(ws + w.seg_off) + (size_t)(live ? t : 0) * w.cap * 4;
   int32_t *__restrict__ nsegp = reinterpret_cast<int32_t *>(ws + w.nseg_off);
-  uint32_t rng = seeds[t];
+  uint32_t rng = seeds[live ? t : 0];
 #define CELL(c) (((c) % Q) * 64 + (c) / Q)
   enum { sC, sE, sM, sI, sD, sB, sJ, sN };
   int st = sC, i = Ld, k = 0, nseg = 0, sqto = 0, hmmto = 0;
-  bool overflow = false;
+  bool overflow = false, done = !live;
   float pth[4];
   for (;;) {
-    const float *cr = mx + rowsz * i, *pr = (i > 0) ? mx + rowsz * (i - 1) : mx;
-    bool stop = false;
-    switch (st) {
-    case sC:
-      pth[0] = xs[(size_t)(i - 1) * 6 + 4] * loop;
-      pth[1] = (xs[(size_t)i * 6 + 0] * Emove) * xs[(size_t)i * 6 + 5];
-      if (ens_choose(ens_roll(rng), pth, 2) == 0) { code[i] = 0; --i; } else st = sE;
-      break;
-    case sJ:
-      pth[0] = xs[(size_t)(i - 1) * 6 + 2] * loop;
-      pth[1] = (xs[(size_t)i * 6 + 0] * Eloop) * xs[(size_t)i * 6 + 5];
-      if (ens_choose(ens_roll(rng), pth, 2) == 0) { code[i] = 0; --i; } else st = sE;
-      break;
-    case sE: {
-      double total = 0.0;
-      for (int c = 0; c < M; ++c) { const int a = CELL(c); total += (double)cr[a]; total += (double)cr[2 * Mp + a]; }
-      const double target = ens_roll(rng) * total;
-      double sum = 0.0; int pick = -1, isd = 0, lastc = -1, lastd = 0;
-      for (int c = 0; c < M; ++c) {
-        const int a = CELL(c);
-        const float mv = cr[a], dv = cr[2 * Mp + a];
-        if (mv > 0.0f) { lastc = c; lastd = 0; }
-        sum += (double)mv; if (target < sum) { pick = c; isd = 0; break; }
-        if (dv > 0.0f) { lastc = c; lastd = 1; }
-        sum += (double)dv; if (target < sum) { pick = c; isd = 1; break; }
-      }
-      if (pick < 0) { pick = lastc < 0 ? 0 : lastc; isd = lastd; }
-      k = pick + 1; st = isd ? sD : sM; sqto = 0; hmmto = 0;
-    } break;
-    case sM: {
-      const int c = k - 1;
-      code[i] = (uint16_t)(0x4000 | k);
-      if (!sqto) { sqto = i; hmmto = k; }
-      pth[0] = xs[(size_t)(i - 1) * 6 + 3] * tBM[c];
-      if (c > 0) { const int a = CELL(c - 1); pth[1] = pr[a] * tMM[c]; pth[2] = pr[Mp + a] * tIM[c]; pth[3] = pr[2 * Mp + a] * tDM[c]; }
-      else pth[1] = pth[2] = pth[3] = 0.0f;
-      const int ch = ens_choose(ens_roll(rng), pth, 4);
-      if (ch == 0) {
-        if (nseg == w.cap) { overflow = true; stop = true; break; }
-        seg[nseg * 4 + 0] = i; seg[nseg * 4 + 1] = sqto; seg[nseg * 4 + 2] = k; seg[nseg * 4 + 3] = hmmto; ++nseg;
-        st = sB;
-      } else st = (ch == 1) ? sM : (ch == 2) ? sI : sD;
-      --i; --k;
-    } break;
-    case sI: {
-      const int a = CELL(k - 1);
-      code[i] = (uint16_t)(0x8000 | k);
-      pth[0] = pr[a] * tMI[k - 1]; pth[1] = pr[Mp + a] * tII[k - 1];
-      st = (ens_choose(ens_roll(rng), pth, 2) == 0) ? sM : sI;
-      --i;
-    } break;
-    case sD: {
-      const int c = k - 1;
-      if (c > 0) { const int a = CELL(c - 1); pth[0] = cr[a] * tMD[c - 1]; pth[1] = cr[2 * Mp + a] * tDD[c - 1]; } else pth[0] = pth[1] = 0.0f;
-      st = (ens_choose(ens_roll(rng), pth, 2) == 0) ? sM : sD;
-      --k;
-    } break;
-    case sB:
-      pth[0] = xs[(size_t)i * 6 + 1] * move; pth[1] = xs[(size_t)i * 6 + 2] * move;
-      st = (ens_choose(ens_roll(rng), pth, 2) == 0) ? sN : sJ;
-      break;
-    default:   // sN
-      stop = true;
-      break;
+    // E-state choices are made by the whole wavefront, one requesting trace at a time (uniform control flow)
+    unsigned long long need = __ballot(!done && st == sE);
+    while (need) {
+      const int l = __ffsll((long long)need) - 1;
+      need &= need - 1;
+      uint32_t xr = rng * 69069u + 1u;
+      xr = __shfl(xr, l);
+      const int row = __shfl(i, l);
+      const int r = ens_select_e(mx + rowsz * row, Q, Mp, (double)xr / 4294967296.0, lane);
+      if (lane == l) { rng = xr; k = (r >> 1) + 1; st = (r & 1) ? sD : sM; sqto = 0; hmmto = 0; }
     }
-    if (stop) break;
-    if (i < 0 || k < 0 || ((st == sM || st == sI) && (k < 1 || i < 1)) || (st == sD && k < 1) || ((st == sC || st == sJ || st == sE) && i < 1))
-      break;   // a numerically impossible move: the trace ends here
+    if (!done) {
+      const float *cr = mx + rowsz * i, *pr = (i > 0) ? mx + rowsz * (i - 1) : mx;
+      switch (st) {
+      case sC:
+        pth[0] = xs[(size_t)(i - 1) * 6 + 4] * loop;
+        pth[1] = (xs[(size_t)i * 6 + 0] * Emove) * xs[(size_t)i * 6 + 5];
+        if (ens_choose(ens_roll(rng), pth, 2) == 0) { code[i] = 0; --i; } else st = sE;
+        break;
+      case sJ:
+        pth[0] = xs[(size_t)(i - 1) * 6 + 2] * loop;
+        pth[1] = (xs[(size_t)i * 6 + 0] * Eloop) * xs[(size_t)i * 6 + 5];
+        if (ens_choose(ens_roll(rng), pth, 2) == 0) { code[i] = 0; --i; } else st = sE;
+        break;
+      case sM: {
+        const int c = k - 1;
+        code[i] = (uint16_t)(0x4000 | k);
+        if (!sqto) { sqto = i; hmmto = k; }
+        pth[0] = xs[(size_t)(i - 1) * 6 + 3] * tBM[c];
+        if (c > 0) { const int a = CELL(c - 1); pth[1] = pr[a] * tMM[c]; pth[2] = pr[Mp + a] * tIM[c]; pth[3] = pr[2 * Mp + a] * tDM[c]; }
+        else pth[1] = pth[2] = pth[3] = 0.0f;
+        const int ch = ens_choose(ens_roll(rng), pth, 4);
+        if (ch == 0) {
+          if (nseg == w.cap) { overflow = true; done = true; break; }
+          seg[nseg * 4 + 0] = i; seg[nseg * 4 + 1] = sqto; seg[nseg * 4 + 2] = k; seg[nseg * 4 + 3] = hmmto; ++nseg;
+          st = sB;
+        } else st = (ch == 1) ? sM : (ch == 2) ? sI : sD;
+        --i; --k;
+      } break;
+      case sI: {
+        const int a = CELL(k - 1);
+        code[i] = (uint16_t)(0x8000 | k);
+        pth[0] = pr[a] * tMI[k - 1]; pth[1] = pr[Mp + a] * tII[k - 1];
+        st = (ens_choose(ens_roll(rng), pth, 2) == 0) ? sM : sI;
+        --i;
+      } break;
+      case sD: {
+        const int c = k - 1;
+        if (c > 0) { const int a = CELL(c - 1); pth[0] = cr[a] * tMD[c - 1]; pth[1] = cr[2 * Mp + a] * tDD[c - 1]; } else pth[0] = pth[1] = 0.0f;
+        st = (ens_choose(ens_roll(rng), pth, 2) == 0) ? sM : sD;
+        --k;
+      } break;
+      case sB:
+        pth[0] = xs[(size_t)i * 6 + 1] * move; pth[1] = xs[(size_t)i * 6 + 2] * move;
+        st = (ens_choose(ens_roll(rng), pth, 2) == 0) ? sN : sJ;
+        break;
+      default:   // sN: the rest of the region is flank
+        done = true;
+        break;
+      }
+      // a numerically impossible move ends the trace
+      if (i < 0 || k < 0 || ((st == sM || st == sI) && (k < 1 || i < 1)) || (st == sD && k < 1) || ((st == sC || st == sJ || st == sE) && i < 1)) done = true;
+    }
+    if (!__ballot(!done)) break;
   }
-  for (; i >= 1; --i) code[i] = 0;
-  nsegp[t] = overflow ? -1 : nseg;
+  if (live) {
+    for (; i >= 1; --i) code[i] = 0;
+    nsegp[t] = overflow ? -1 : nseg;
+  }
 #undef CELL
-}
-
-__device__ __forceinline__ float ens_wave_sum(float s) {
-#pragma unroll
-  for (int w = 32; w >= 1; w >>= 1) s = s + __shfl_xor(s, w);
-  return s;
 }
 
 // grid (ENS_N, nregions), 64 threads; dynamic LDS: 2*Mp counters/floats + 32 floats
@@ -170,7 +188,7 @@ __global__ void __launch_bounds__(64) ens_null2_kernel(const EnsWork *__restrict
       const float *__restrict__ rfx = md.rf + (size_t)x * Mp + lane;
       float s = 0.f;
       for (int q = 0; q < Q; ++q) { const int idx = lane * Q + q; const float tt = lds[idx] * rfx[q * 64]; s = s + tt; s = s + lds[Mp + idx]; }
-      s = ens_wave_sum(s);
+      s = wave_sum(s);
       if (lane == 0) n2[x] = s + 0.0f;
     }
     __syncthreads();

@@ -2,14 +2,15 @@
 // kernels, gfx950 only.  One wavefront per (model, sequence) pair or per envelope; lane z owns the
 // Q consecutive model nodes c = z*Q+q ("canonical 64-lane blocked order"), so
 // every order-dependent float reduction has ONE defined evaluation order:
-//   D->D chain   lane-local affine map (a,b), Kogge-Stone over lanes with __shfl_up, lane-local replay
-//   E-state sum  lane-local fold over q, then xor butterfly 32,16,8,4,2,1
+//   D->D chain   lane-local affine map (a,b), scan over lanes (xlane.h: rows of 16 by offsets 1,2,4,8, then row prefixes), lane-local replay
+//   E-state sum  lane-local fold over q, then xor butterfly 1,2,4,8,16,32
 // Compiled with -ffp-contract=off: no fused multiply-add may be formed.  No transcendental is
 // evaluated on the device; rescale factors go back to the host as events and are logged there.
 // Reference stage replaced: Forward/Backward/domain definition of the hmmsearch per-target pipeline
 // (process launched at checkm/hmmer.py:70).
 #include <hip/hip_runtime.h>
 #include "dev_types.h"
+#include "xlane.h"
 
 namespace ckm {
 
@@ -55,18 +56,11 @@ __device__ __forceinline__ void load_gates(float *lds, const float *ftr) {
   __syncthreads();
 }
 
-__device__ __forceinline__ float wave_sum(float s) {
-#pragma unroll
-  for (int w = 32; w >= 1; w >>= 1) s = s + __shfl_xor(s, w);
-  return s;
-}
-
 // ---- one Forward row --------------------------------------------------------------------------
 template <int Q>
 __device__ __forceinline__ float fwd_row(float (&Mv)[Q], float (&Iv)[Q], float (&Dv)[Q], const Tr<Q> &tr,
                                          const float (&rfx)[Q], float xB, int lane) {
-  float mpi = __shfl_up(Mv[Q - 1], 1), ipi = __shfl_up(Iv[Q - 1], 1), dpi = __shfl_up(Dv[Q - 1], 1);
-  if (lane == 0) { mpi = 0.f; ipi = 0.f; dpi = 0.f; }
+  const float mpi = lane_up1(Mv[Q - 1], 0.f), ipi = lane_up1(Iv[Q - 1], 0.f), dpi = lane_up1(Dv[Q - 1], 0.f);
   float Mn[Q], In[Q], Dn[Q], md[Q];
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
@@ -83,13 +77,8 @@ __device__ __forceinline__ float fwd_row(float (&Mv)[Q], float (&Iv)[Q], float (
   float a = 1.0f, b = 0.0f;
 #pragma unroll
   for (int q = 0; q < Q; ++q) { const float dd = tr.DD(q); const float t = dd * b; b = md[q] + t; a = dd * a; }
-#pragma unroll
-  for (int s = 1; s < 64; s <<= 1) {
-    const float oa = __shfl_up(a, s), ob = __shfl_up(b, s);
-    if (lane >= s) { const float t = a * ob; b = b + t; a = a * oa; }
-  }
-  float d = __shfl_up(b, 1);
-  if (lane == 0) d = 0.0f;
+  scan_up(a, b, lane);
+  float d = lane_up1(b, 0.0f);
 #pragma unroll
   for (int q = 0; q < Q; ++q) { Dn[q] = d; const float t = tr.DD(q) * d; d = md[q] + t; }
   float s = 0.f;
@@ -187,13 +176,8 @@ __device__ __forceinline__ void bwd_dchain(float (&Dn)[Q], const float (&av)[Q],
   float a = 1.0f, b = 0.0f;
 #pragma unroll
   for (int q = Q - 1; q >= 0; --q) { const float dd = tr.DD(q); const float t = dd * b; b = av[q] + t; a = dd * a; }
-#pragma unroll
-  for (int s = 1; s < 64; s <<= 1) {
-    const float oa = __shfl_down(a, s), ob = __shfl_down(b, s);
-    if (lane + s < 64) { const float t = a * ob; b = b + t; a = a * oa; }
-  }
-  float d = __shfl_down(b, 1);
-  if (lane == 63) d = 0.0f;
+  scan_down(a, b, lane);
+  float d = lane_down1(b, 0.0f);
 #pragma unroll
   for (int q = Q - 1; q >= 0; --q) { const float t = tr.DD(q) * d; d = av[q] + t; Dn[q] = d; }
 }
@@ -237,7 +221,7 @@ __global__ void __launch_bounds__(256) bwd_kernel(const FbWork *__restrict__ wor
 #pragma unroll
     for (int q = 0; q < Q; ++q) av[q] = xE + 0.0f;
     bwd_dchain<Q>(Dv, av, tr, lane);
-    float dnx = __shfl_down(Dv[0], 1); if (lane == 63) dnx = 0.f;
+    const float dnx = lane_down1(Dv[0], 0.f);
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       const float dn1 = (q + 1 < Q) ? Dv[q + 1] : dnx;
@@ -335,13 +319,13 @@ __global__ void __launch_bounds__(256) bwd_kernel(const FbWork *__restrict__ wor
     xC = xC * loop;
     { const float a = xC * Emove, b = xJ * Eloop; xE = a + b; }
     { const float a = xB * move, b = xN * loop; xN = a + b; }
-    float mnx = __shfl_down(mn[0], 1); if (lane == 63) mnx = 0.f;
+    const float mnx = lane_down1(mn[0], 0.f);
     float av[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) { const float mn1 = (q + 1 < Q) ? mn[q + 1] : mnx; av[q] = xE + tDMn[q] * mn1; }
     float Dn[Q];
     bwd_dchain<Q>(Dn, av, tr, lane);
-    float dnx = __shfl_down(Dn[0], 1); if (lane == 63) dnx = 0.f;
+    const float dnx = lane_down1(Dn[0], 0.f);
     float Mn[Q], In[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
@@ -425,8 +409,7 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
 #pragma unroll
     for (int q = 0; q < Q; ++q) { me[q] = me[q] + ppM[q]; ie[q] = ie[q] + ppI[q]; }
     n2N = n2N + ax0; n2J = n2J + ax1; n2C = n2C + ax2;
-    float mpi = __shfl_up(Mv[Q - 1], 1), ipi = __shfl_up(Iv[Q - 1], 1), dpi = __shfl_up(Dv[Q - 1], 1);
-    if (lane == 0) { mpi = NEGINF_F; ipi = NEGINF_F; dpi = NEGINF_F; }
+    const float mpi = lane_up1(Mv[Q - 1], NEGINF_F), ipi = lane_up1(Iv[Q - 1], NEGINF_F), dpi = lane_up1(Dv[Q - 1], NEGINF_F);
     float Mn[Q], In[Q], Dn[Q];
     float e = NEGINF_F;
 #pragma unroll
@@ -445,18 +428,26 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
       for (int q = 1; q < Q; ++q) { dloc[q] = fmaxf(Mn[q - 1] + tr.MD(q - 1), dloc[q - 1] + tr.DD(q - 1)); pw[q] = pw[q - 1] + tr.DD(q - 1); }
       float outv = fmaxf(Mn[Q - 1] + tr.MD(Q - 1), dloc[Q - 1] + tr.DD(Q - 1));
       float wgt = pw[Q - 1] + tr.DD(Q - 1);
-#pragma unroll
-      for (int s = 1; s < 64; s <<= 1) {
-        const float ov = __shfl_up(outv, s), ow = __shfl_up(wgt, s);
-        if (lane >= s) { outv = fmaxf(outv, ov + wgt); wgt = wgt + ow; }
+      // max-plus scan over lanes: exact whatever the association (weights are sums of 0 / -inf gates)
+#define MP(ov, ow) { outv = fmaxf(outv, (ov) + wgt); wgt = wgt + (ow); }
+#define STEP(S) { const float ov = dpp_f<DPP_ROW_SHR + S>(NEGINF_F, outv), ow = dpp_f<DPP_ROW_SHR + S>(0.0f, wgt); MP(ov, ow) }
+      STEP(1) STEP(2) STEP(4) STEP(8)
+#undef STEP
+      {
+        const float v0 = read_lane(outv, 15), w0 = read_lane(wgt, 15), v1 = read_lane(outv, 31), w1 = read_lane(wgt, 31), v2 = read_lane(outv, 47), w2 = read_lane(wgt, 47);
+        const float pv2 = fmaxf(v1, v0 + w1), pw2 = w1 + w0;
+        const float pv3 = fmaxf(v2, pv2 + w2), pw3 = w2 + pw2;
+        const int row = lane >> 4;
+        const float pv = row == 0 ? NEGINF_F : row == 1 ? v0 : row == 2 ? pv2 : pv3;
+        const float pw_ = row == 0 ? 0.0f : row == 1 ? w0 : row == 2 ? pw2 : pw3;
+        MP(pv, pw_)
       }
-      float carry = __shfl_up(outv, 1);
-      if (lane == 0) carry = NEGINF_F;
+#undef MP
+      const float carry = lane_up1(outv, NEGINF_F);
 #pragma unroll
       for (int q = 0; q < Q; ++q) Dn[q] = fmaxf(dloc[q], carry + pw[q]);
     }
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) e = fmaxf(e, __shfl_xor(e, s));
+    e = wave_max(e);
     oE = e;
     { const float a = oJ + ax1; const float b = Eloop_ok ? e : NEGINF_F; oJ = a > b ? a : b; }
     { const float a = oC + ax2; oC = a > e ? a : e; }
@@ -509,8 +500,7 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
       int best = Mp;
 #pragma unroll
       for (int q = Q - 1; q >= 0; --q) { const int c = c0 + q; if (c < M && LD2(&cr[q * 64 + lane]) == e) best = c; }
-#pragma unroll
-      for (int s = 32; s >= 1; s >>= 1) best = min(best, __shfl_xor(best, s));
+      best = wave_min(best);
       if (best >= Mp) done = true; else { k = best; st = 2; li = i; lk = k + 1; }
     } else if (st == 2) {
       fi = i; fk = k + 1;

@@ -9,6 +9,7 @@
 // to the host formulation: thresholds were converted to score space on the host (host_profile.cpp).
 #include <hip/hip_runtime.h>
 #include "dev_types.h"
+#include "xlane.h"
 
 namespace ckm {
 
@@ -106,8 +107,7 @@ __global__ void msv_full_kernel(const PairRec *__restrict__ pairs, uint32_t npai
       xE = max(xE, sv);
       nw[k] = (int16_t)sv;
     }
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) xE = max(xE, __shfl_xor(xE, s));
+    xE = wave_max(xE);
     if (min(xE + md.bias_b, 255) == 255) { overflow = true; break; }
     xE = max(xE - md.tec_b, 0);
     xJ = max(xJ, xE);
@@ -247,8 +247,7 @@ __global__ void __launch_bounds__(256) vit_kernel(const PairRec *__restrict__ pa
     }
     const s16x2 x2 = __builtin_bit_cast(s16x2, xEv);
     int xE = max((int)x2.x, (int)x2.y);
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) xE = max(xE, __shfl_xor(xE, s));
+    xE = wave_max(xE);
     if (xE >= 32767) { overflow = true; break; }
     xC = max(xC, xE + md.wE_move);
     xJ = max(xJ, xE + md.wE_loop);

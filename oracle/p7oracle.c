@@ -525,7 +525,8 @@ static int vit_filter(const PROF *p, const LENCFG *lc, const uint8_t *dsq, int L
 }
 
 /* ------------------------------------------------------------------------------------------
- * Forward / Backward in probability space, canonical 64-lane blocked evaluation order.
+ * Forward / Backward in probability space, canonical 64-lane blocked evaluation order
+ * (lane-local folds, lane scans by lane_scan_up/lane_scan_down, sums by the xor butterfly 1,2,4,8,16,32).
  * Cell idx = z*Q + q  (lane z, slot q)  <->  model node k = idx+1.
  * ------------------------------------------------------------------------------------------ */
 typedef struct { float E_loop, E_move, loop, move; } XF;
@@ -536,6 +537,54 @@ static void xf_config(const PROF *p, int L, int multihit, XF *xf)
   xf->loop = lc.loop; xf->move = lc.move;
   if (multihit) { xf->E_loop = p->fE_loop; xf->E_move = p->fE_move; }
   else          { xf->E_loop = 0.0f;       xf->E_move = 1.0f; }
+}
+
+/* (a,b) <- (a,b) after (oa,ob):  d -> a*(oa*d + ob) + b */
+#define COMPOSE(a, b, oa, ob) do { float t_ = (a) * (ob); (b) = (b) + t_; (a) = (a) * (oa); } while (0)
+
+/* Inclusive scan of the 64 lanes' affine maps towards higher lanes, canonical association: inside each row of 16 lanes
+ * Kogge-Stone with offsets 1,2,4,8 (a lane without a partner composes with the identity), then the row totals are
+ * composed one after the other and every lane applies the prefix of the rows below its own. */
+static void lane_scan_up(float *A, float *B)
+{
+  float nA[P7O_NL], nB[P7O_NL];
+  for (int s = 1; s < 16; s <<= 1) {
+    for (int z = 0; z < P7O_NL; z++) {
+      float oa = ((z & 15) >= s) ? A[z-s] : 1.0f, ob = ((z & 15) >= s) ? B[z-s] : 0.0f;
+      float a = A[z], b = B[z]; COMPOSE(a, b, oa, ob); nA[z] = a; nB[z] = b;
+    }
+    memcpy(A, nA, sizeof(nA)); memcpy(B, nB, sizeof(nB));
+  }
+  float a0 = A[15], b0 = B[15], a1 = A[31], b1 = B[31], a2 = A[47], b2 = B[47];
+  float pa2 = a1, pb2 = b1; COMPOSE(pa2, pb2, a0, b0);
+  float pa3 = a2, pb3 = b2; COMPOSE(pa3, pb3, pa2, pb2);
+  for (int z = 0; z < P7O_NL; z++) {
+    int row = z >> 4;
+    float pa = row == 0 ? 1.0f : row == 1 ? a0 : row == 2 ? pa2 : pa3;
+    float pb = row == 0 ? 0.0f : row == 1 ? b0 : row == 2 ? pb2 : pb3;
+    COMPOSE(A[z], B[z], pa, pb);
+  }
+}
+/* mirror image: lane z ends with the composition of lanes z..63 (its own map applied last) */
+static void lane_scan_down(float *A, float *B)
+{
+  float nA[P7O_NL], nB[P7O_NL];
+  for (int s = 1; s < 16; s <<= 1) {
+    for (int z = 0; z < P7O_NL; z++) {
+      float oa = ((z & 15) + s <= 15) ? A[z+s] : 1.0f, ob = ((z & 15) + s <= 15) ? B[z+s] : 0.0f;
+      float a = A[z], b = B[z]; COMPOSE(a, b, oa, ob); nA[z] = a; nB[z] = b;
+    }
+    memcpy(A, nA, sizeof(nA)); memcpy(B, nB, sizeof(nB));
+  }
+  float a3 = A[48], b3 = B[48], a2 = A[32], b2 = B[32], a1 = A[16], b1 = B[16];
+  float pa1 = a2, pb1 = b2; COMPOSE(pa1, pb1, a3, b3);
+  float pa0 = a1, pb0 = b1; COMPOSE(pa0, pb0, pa1, pb1);
+  for (int z = 0; z < P7O_NL; z++) {
+    int row = z >> 4;
+    float pa = row == 3 ? 1.0f : row == 2 ? a3 : row == 1 ? pa1 : pa0;
+    float pb = row == 3 ? 0.0f : row == 2 ? b3 : row == 1 ? pb1 : pb0;
+    COMPOSE(A[z], B[z], pa, pb);
+  }
 }
 
 /* one Forward row.  prev/cur hold M,I,D arrays of Mp floats each. returns xE */
@@ -554,19 +603,13 @@ static float fwd_row(const PROF *p, const float *rfx, float xB,
     Ic[idx] = a + b;
   }
   /* D chain: D[idx+1] = Mc[idx]*fMD[idx] + fDD[idx]*D[idx]; lane-local affine maps, Kogge-Stone across lanes */
-  float A[P7O_NL], B[P7O_NL], nA[P7O_NL], nB[P7O_NL];
+  float A[P7O_NL], B[P7O_NL];
   for (int z = 0; z < P7O_NL; z++) {
     float a = 1.0f, b = 0.0f;
     for (int q = 0; q < Q; q++) { int idx = z*Q+q; float md = Mc[idx] * p->fMD[idx]; float dd = p->fDD[idx]; float t = dd * b; b = md + t; a = dd * a; }
     A[z] = a; B[z] = b;
   }
-  for (int s = 1; s < P7O_NL; s <<= 1) {
-    for (int z = 0; z < P7O_NL; z++) {
-      if (z >= s) { float t = A[z] * B[z-s]; nB[z] = B[z] + t; nA[z] = A[z] * A[z-s]; }
-      else { nB[z] = B[z]; nA[z] = A[z]; }
-    }
-    memcpy(A, nA, sizeof(A)); memcpy(B, nB, sizeof(B));
-  }
+  lane_scan_up(A, B);
   for (int z = 0; z < P7O_NL; z++) {
     float d = z ? B[z-1] : 0.0f;
     for (int q = 0; q < Q; q++) { int idx = z*Q+q; Dc[idx] = d; float md = Mc[idx] * p->fMD[idx]; float t = p->fDD[idx] * d; d = md + t; }
@@ -574,7 +617,7 @@ static float fwd_row(const PROF *p, const float *rfx, float xB,
   /* xE = sum_k M + D: lane partials then xor butterfly */
   float S[P7O_NL], nS[P7O_NL];
   for (int z = 0; z < P7O_NL; z++) { float s = 0.f; for (int q = 0; q < Q; q++) { int idx = z*Q+q; s = s + Mc[idx]; s = s + Dc[idx]; } S[z] = s; }
-  for (int w = 32; w >= 1; w >>= 1) { for (int z = 0; z < P7O_NL; z++) nS[z] = S[z] + S[z ^ w]; memcpy(S, nS, sizeof(S)); }
+  for (int w = 1; w <= 32; w <<= 1) { for (int z = 0; z < P7O_NL; z++) nS[z] = S[z] + S[z ^ w]; memcpy(S, nS, sizeof(S)); }
   return S[0];
 }
 
@@ -621,7 +664,7 @@ static void bwd_row(const PROF *p, const XF *xf, const float *rfx /* residue i+1
   for (int idx = 0; idx < Mp; idx++) mnext[idx] = Mn[idx] * rfx[idx];
   float S[P7O_NL], nS[P7O_NL];
   for (int z = 0; z < P7O_NL; z++) { float s = 0.f; for (int q = 0; q < Q; q++) { int idx = z*Q+q; float t = p->fBM[idx] * mnext[idx]; s = s + t; } S[z] = s; }
-  for (int w = 32; w >= 1; w >>= 1) { for (int z = 0; z < P7O_NL; z++) nS[z] = S[z] + S[z ^ w]; memcpy(S, nS, sizeof(S)); }
+  for (int w = 1; w <= 32; w <<= 1) { for (int z = 0; z < P7O_NL; z++) nS[z] = S[z] + S[z ^ w]; memcpy(S, nS, sizeof(S)); }
   float xB = S[0];
   float xJn = xspec[2], xCn = xspec[4], xNn = xspec[1];
   float xJ, xC, xE, xN;
@@ -631,20 +674,14 @@ static void bwd_row(const PROF *p, const XF *xf, const float *rfx /* residue i+1
   { float a = xB * xf->move, b = xNn * xf->loop; xN = a + b; }
   xspec[0] = xE; xspec[1] = xN; xspec[2] = xJ; xspec[3] = xB; xspec[4] = xC;
   /* D chain, reverse: D[idx] = (xE + fDM[idx+1]*mnext[idx+1]) + fDD[idx]*D[idx+1] */
-  float A[P7O_NL], B[P7O_NL], nA[P7O_NL], nB[P7O_NL];
+  float A[P7O_NL], B[P7O_NL];
 #define AVAL(idx) (xE + (((idx)+1 < Mp) ? p->fDM[(idx)+1] * mnext[(idx)+1] : 0.0f))
   for (int z = 0; z < P7O_NL; z++) {
     float a = 1.0f, b = 0.0f;
     for (int q = Q-1; q >= 0; q--) { int idx = z*Q+q; float av = AVAL(idx); float dd = p->fDD[idx]; float t = dd * b; b = av + t; a = dd * a; }
     A[z] = a; B[z] = b;
   }
-  for (int s = 1; s < P7O_NL; s <<= 1) {
-    for (int z = 0; z < P7O_NL; z++) {
-      if (z + s < P7O_NL) { float t = A[z] * B[z+s]; nB[z] = B[z] + t; nA[z] = A[z] * A[z+s]; }
-      else { nB[z] = B[z]; nA[z] = A[z]; }
-    }
-    memcpy(A, nA, sizeof(A)); memcpy(B, nB, sizeof(B));
-  }
+  lane_scan_down(A, B);
   for (int z = 0; z < P7O_NL; z++) {
     float d = (z < P7O_NL-1) ? B[z+1] : 0.0f;
     for (int q = Q-1; q >= 0; q--) { int idx = z*Q+q; float av = AVAL(idx); float t = p->fDD[idx] * d; d = av + t; Dc[idx] = d; }
@@ -676,12 +713,9 @@ static void backward(const PROF *p, const XF *xf, const uint8_t *dsq, int L, con
   { /* M(L,k) = xE + fMD*D(L,k+1); D(L,k) = xE + fDD*D(L,k+1): same recurrences with mnext = 0, In = 0 */
     float zero_rf_dummy = 0.f; (void)zero_rf_dummy;
     int Q = p->Q;
-    float A[P7O_NL], B[P7O_NL], nA[P7O_NL], nB[P7O_NL];
+    float A[P7O_NL], B[P7O_NL];
     for (int z = 0; z < P7O_NL; z++) { float a = 1.f, b = 0.f; for (int q = Q-1; q >= 0; q--) { int idx = z*Q+q; float av = xE + 0.0f; float dd = p->fDD[idx]; float t = dd * b; b = av + t; a = dd * a; } A[z] = a; B[z] = b; }
-    for (int s = 1; s < P7O_NL; s <<= 1) {
-      for (int z = 0; z < P7O_NL; z++) { if (z + s < P7O_NL) { float t = A[z] * B[z+s]; nB[z] = B[z] + t; nA[z] = A[z] * A[z+s]; } else { nB[z] = B[z]; nA[z] = A[z]; } }
-      memcpy(A, nA, sizeof(A)); memcpy(B, nB, sizeof(B));
-    }
+    lane_scan_down(A, B);
     for (int z = 0; z < P7O_NL; z++) { float d = (z < P7O_NL-1) ? B[z+1] : 0.f; for (int q = Q-1; q >= 0; q--) { int idx = z*Q+q; float av = xE + 0.0f; float t = p->fDD[idx] * d; d = av + t; nd[idx] = d; } }
     for (int idx = 0; idx < Mp; idx++) { float dn1 = (idx+1 < Mp) ? nd[idx+1] : 0.f; float m = xE + 0.0f; m = m + 0.0f; m = m + p->fMD[idx] * dn1; nm[idx] = m; ni[idx] = 0.f; }
   }
@@ -723,7 +757,7 @@ static void null2_from_usage(const PROF *p, const float *me, const float *ie, fl
     const float *rfx = p->rf + (size_t)x * Mp;
     float S[P7O_NL], nS[P7O_NL];
     for (int z = 0; z < P7O_NL; z++) { float s = 0.f; for (int q = 0; q < Q; q++) { int idx = z*Q+q; float t = me[idx] * rfx[idx]; s = s + t; s = s + ie[idx]; } S[z] = s; }
-    for (int w = 32; w >= 1; w >>= 1) { for (int z = 0; z < P7O_NL; z++) nS[z] = S[z] + S[z ^ w]; memcpy(S, nS, sizeof(S)); }
+    for (int w = 1; w <= 32; w <<= 1) { for (int z = 0; z < P7O_NL; z++) nS[z] = S[z] + S[z ^ w]; memcpy(S, nS, sizeof(S)); }
     null2[x] = S[0] + xfactor;
   }
 }
@@ -738,7 +772,7 @@ static int rescore_envelope(const PROF *p, const uint8_t *dsq_full, int L_full, 
                             float *n2sc /* per-position, 1-based, may be NULL */, int null2_done, DOMAIN *dom,
                             float *out_null2, float *out_xC, int *out_nscale)
 {
-  int Mp = p->Mp, M = p->M, Q = p->Q, Ld = jenv - ienv + 1;
+  int Mp = p->Mp, M = p->M, Ld = jenv - ienv + 1;
   const uint8_t *dsq = dsq_full + (ienv - 1);
   XF xf; xf_config(p, L_full, 0, &xf);
   size_t rowsz = (size_t)3 * Mp;
@@ -910,7 +944,7 @@ static int choose(double roll, const float *pth, int n)
 static int stochastic_trace(const PROF *p, const XF *xf, int Ld, const float *mx, const float *xs, uint32_t *rng,
                             uint16_t *code, P7O_SEG *seg, int cap)
 {
-  int Mp = p->Mp, M = p->M; size_t rowsz = (size_t)3 * Mp;
+  int Mp = p->Mp; size_t rowsz = (size_t)3 * Mp;
   enum { sC, sE, sM, sI, sD, sB, sJ, sN } st = sC;
   int i = Ld, k = 0, nseg = 0, sqto = 0, hmmto = 0;
   float pth[4];
@@ -928,17 +962,21 @@ static int stochastic_trace(const PROF *p, const XF *xf, int Ld, const float *mx
       if (choose(roll_next(rng), pth, 2) == 0) { code[i] = 0; i--; } else st = sE;
       break;
     case sE: {
-      /* any M(i,k), D(i,k): cells in node order, match before delete */
-      double total = 0.0;
-      for (int c = 0; c < M; c++) { total += (double)cr[c]; total += (double)cr[2*Mp+c]; }
-      double target = roll_next(rng) * total, sum = 0.0; int pick = -1, isd = 0, lastc = -1, lastd = 0;
-      for (int c = 0; c < M && pick < 0; c++) {
-        if (cr[c] > 0.0f) { lastc = c; lastd = 0; }
-        sum += (double)cr[c]; if (target < sum) { pick = c; isd = 0; break; }
-        if (cr[2*Mp+c] > 0.0f) { lastc = c; lastd = 1; }
-        sum += (double)cr[2*Mp+c]; if (target < sum) { pick = c; isd = 1; break; }
+      /* any M(i,k), D(i,k).  Canonical order: lane z owns cells z*Q..z*Q+Q-1; weights in cell order are M(c), D(c);
+       * local[z] = sequential double sum of the lane's weights, base[z] = local[0]+..+local[z-1] in lane order,
+       * total = base[64]; first position whose cumulative weight base[z] + running sum exceeds roll*total. */
+      int Q = p->Q; double local[P7O_NL], base[P7O_NL], run = 0.0;
+      for (int z = 0; z < P7O_NL; z++) { double s = 0.0; for (int q = 0; q < Q; q++) { int c = z*Q+q; s += (double)cr[c]; s += (double)cr[2*Mp+c]; } local[z] = s; }
+      for (int z = 0; z < P7O_NL; z++) { base[z] = run; run += local[z]; }
+      double target = roll_next(rng) * run; int pick = 0, isd = 0, hit = 0;
+      for (int z = 0; z < P7O_NL && !hit; z++) {
+        double acc = 0.0;
+        for (int q = 0; q < Q && !hit; q++) {
+          int c = z*Q+q;
+          acc += (double)cr[c];      if (target < base[z] + acc) { pick = c; isd = 0; hit = 1; break; }
+          acc += (double)cr[2*Mp+c]; if (target < base[z] + acc) { pick = c; isd = 1; hit = 1; break; }
+        }
       }
-      if (pick < 0) { pick = lastc < 0 ? 0 : lastc; isd = lastd; }
       k = pick + 1; st = isd ? sD : sM; sqto = 0; hmmto = 0;
     } break;
     case sM: {
@@ -1136,10 +1174,14 @@ static void domain_definition(const PROF *p, const uint8_t *dsq, int L, const fl
         /* the region holds more than one domain: resolve it by the trace ensemble (DEV3) */
         dd->nclustered++;
         if (getenv("P7O_TRACE_REGIONS")) fprintf(stderr, "p7o: multi-domain region %d..%d of L=%d (M=%d)\n", i, j, L, p->M);
-        int Lr = j - i + 1, cap = Lr < 512 ? Lr : 512;
+        int Lr = j - i + 1, cap = Lr < 16 ? Lr : 16, ens_rc;
         float *n2sum = malloc(sizeof(float) * Lr);
         P7O_SEG *seg_all = malloc(sizeof(P7O_SEG) * (size_t)ENS_NSAMPLES * cap), env[64]; int nseg_all[ENS_NSAMPLES];
-        if (trace_ensemble(p, dsq, L, i, j, n2sum, seg_all, nseg_all, cap) == 0) {
+        /* a trace with more domains than segment slots: repeat with a larger table (a trace holds at most Lr domains) */
+        while ((ens_rc = trace_ensemble(p, dsq, L, i, j, n2sum, seg_all, nseg_all, cap)) != 0 && cap < Lr) {
+          cap = cap * 8 < Lr ? cap * 8 : Lr; seg_all = realloc(seg_all, sizeof(P7O_SEG) * (size_t)ENS_NSAMPLES * cap);
+        }
+        if (ens_rc == 0) {
           for (int pos = i; pos <= j; pos++) dd->n2sc[pos] = logf(n2sum[pos-i] / (float)ENS_NSAMPLES);
           int nenv = cluster_ensemble(seg_all, nseg_all, cap, env, 64), last_j2 = 0;
           for (int e = 0; e < nenv; e++) {
