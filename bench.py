@@ -17,7 +17,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before torch initialises HIP: see checkm_amd/__init__.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # before torch initialises HIP: see checkm_amd/__init__.py
 
 import numpy as np  # noqa: E402
 
@@ -94,11 +94,18 @@ def main():
     t_pack = time.perf_counter() - t0
     plan = cqa.QAPlan.for_hmm_models(prof, [list(range(prof.n))] * args.bins)     # one marker set of all 43 accessions per bin
 
+    part_ms = {"search": 0.0, "reduce": 0.0, "gather": 0.0}
+
     def step():
+        ta = time.perf_counter()
         hits = _lib.search(ctx, prof, seqs)
+        tb = time.perf_counter()
         qa = plan.reduce(ctx, hits, seqs)
+        tc = time.perf_counter()
         rows = cdist.pack_qa_rows(np.arange(args.bins) + rank * args.bins, qa.n_markers, qa.n_sets, qa.hist, qa.completeness, qa.contamination)
         table = cdist.gather_qa_rows(rows, args.bins, dev)
+        td = time.perf_counter()
+        part_ms["search"] += (tb - ta) * 1e3; part_ms["reduce"] += (tc - tb) * 1e3; part_ms["gather"] += (td - tc) * 1e3
         st = ctx.stats()
         n = hits.n
         hits.close(); qa.close()
@@ -112,6 +119,8 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    for k in part_ms:
+        part_ms[k] = 0.0
     t0 = time.perf_counter()
     ssv_ms = 0.0
     for _ in range(args.steps):
@@ -159,9 +168,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes": alg_bytes, "kernel": "ssv_kernel<Q>", "ms_per_step_kernel": ssv_ms / args.steps,
                          "launches_per_step": int(st.ssv_launches),
-                         "note": "the kernel is VALU-issue-bound by design (SURVEY H3), not HBM-bound: see roofline_valu, gcups_ssv and DESIGN.md section 6"},
+                         "note": "the kernel is VALU-issue-bound by design (SURVEY H3), not HBM-bound: see roofline_valu, gcups_ssv and DESIGN.md section 6; its launches share the device with the rare stages of the other length classes (3 workers), which stretches their duration by ~25% against a solo run (CKM_WORKERS=1: 42 ms, frac_valu ~1.0)"},
             "roofline_valu": valu,
             "stages_ms": {"ssv": st.ms_ssv, "filters": st.ms_filters, "fwdbwd": st.ms_fwdbwd, "domains": st.ms_domains, "host": st.ms_host, "search_total": st.ms_total},
+            "step_parts_ms": {k: v / args.steps for k, v in part_ms.items()},
             "stage_pairs": {"ssv": int(st.pairs_ssv), "msv_full": int(st.pairs_msv_full), "bias": int(st.pairs_bias), "vit": int(st.pairs_vit),
                             "fwd": int(st.pairs_fwd), "dom": int(st.pairs_dom), "envelopes": int(st.envelopes), "regions_multi": int(st.regions_multi)},
             "rows": int(nrows), "setup_s": {"generate": t_gen, "pack_and_upload": t_pack},

@@ -165,15 +165,16 @@ struct Worker {
   std::unique_ptr<HostPool> pool;         // host threads of this worker
 };
 
-constexpr int NWORKERS = 4;          // upper bound; CKM_WORKERS (default 1) selects how many a search uses
+constexpr int NWORKERS = 4;          // upper bound; CKM_WORKERS (default 3) selects how many a large search uses
 
 struct ckm_ctx {
   int device = 0;
-  int nworkers = 1;
+  int nworkers = 3;
   DevBuf reduce_scratch;                  // grow-only device buffer of the reduce kernels
   Worker w[NWORKERS];
   ckm_search_stats stats;
   std::mutex ssv_mutex;                   // SSV phases are VALU-bound: two of them side by side gain nothing
+  std::condition_variable ssv_cv; int ssv_turn = 0;    // workers take their first SSV phase in worker order (largest chunk first)
 };
 
 static std::atomic<uint64_t> g_uid{1};     // identity of every profile DB / sequence set / list ever created (pointers get reused)
@@ -248,7 +249,7 @@ extern "C" int ckm_device_count(int *n) {
 extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
   // The per-register-class launches of the rare stages overlap on up to 8 streams; the runtime's default of 4 hardware
   // queues would serialise half of them.  Only effective if HIP has not been initialised in this process yet.
-  setenv("GPU_MAX_HW_QUEUES", "8", 0);
+  setenv("GPU_MAX_HW_QUEUES", "16", 0);
   return guarded([&] {
     if (!out) throw Error(CKM_EINVAL, "out is NULL");
     *out = nullptr;
@@ -272,9 +273,10 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
     if (const char *e = getenv("CKM_WS_BUDGET_MB")) budget = std::max<size_t>(16, strtoull(e, nullptr, 10)) << 20;   // tests: force several envelope batches
     for (auto &w : ctx->w) {
       w.device = device;
-      HIPCHK(hipStreamCreate(&w.stream));
-      HIPCHK(hipStreamCreate(&w.ens_stream));
-      for (auto &st : w.side) HIPCHK(hipStreamCreate(&st));
+      // non-blocking streams: nothing here may synchronise implicitly with the null stream or with another worker's streams
+      HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+      HIPCHK(hipStreamCreateWithFlags(&w.ens_stream, hipStreamNonBlocking));
+      for (auto &st : w.side) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
       for (auto &e : w.ev) HIPCHK(hipEventCreate(&e));
       memset(&w.stats, 0, sizeof(w.stats));
       w.ws_budget = budget;
@@ -540,6 +542,12 @@ struct Cand {            // a pair that survived the MSV stage
 
 void pool_run(Worker *w, size_t n, size_t chunk, const std::function<void(size_t, size_t)> &f) { if (w->pool) w->pool->run(n, chunk, f); else if (n) f(0, n); }
 
+// blocking copy on the worker's own stream (a plain hipMemcpy would wait for every blocking stream of the device)
+void wcopy(Worker *w, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, kind, w->stream));
+  HIPCHK(hipStreamSynchronize(w->stream));
+}
+
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 float bits(float sc, float nullsc) { return (float)((double)(sc - nullsc) / kLn2); }
@@ -582,7 +590,7 @@ void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, b
   const size_t n = b.work.size();
   if (!n) return;
   ctx->fbwork.ensure(n * sizeof(FbWork));
-  HIPCHK(hipMemcpy(ctx->fbwork.p, b.work.data(), n * sizeof(FbWork), hipMemcpyHostToDevice));
+  wcopy(ctx, ctx->fbwork.p, b.work.data(), n * sizeof(FbWork), hipMemcpyHostToDevice);
   // group by canonical Q; inside a group, blocks of 4 wavefronts take 4 items of ONE model (shared LDS table)
   std::map<int, std::map<uint32_t, std::vector<uint32_t>>> byQ;
   auto add = [&](uint32_t i) { byQ[p->prof[b.work[i].model].fbQ][b.work[i].model].push_back(i); };
@@ -605,8 +613,8 @@ void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, b
     groups.push_back(g);
   }
   ctx->fbidx.ensure(items.size() * 4); ctx->fbmodel.ensure(blk_model.size() * 4);
-  HIPCHK(hipMemcpy(ctx->fbidx.p, items.data(), items.size() * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(ctx->fbmodel.p, blk_model.data(), blk_model.size() * 4, hipMemcpyHostToDevice));
+  wcopy(ctx, ctx->fbidx.p, items.data(), items.size() * 4, hipMemcpyHostToDevice);
+  wcopy(ctx, ctx->fbmodel.p, blk_model.data(), blk_model.size() * 4, hipMemcpyHostToDevice);
   ctx->fout.ensure(n * sizeof(FwdOut));
   ctx->rerr.ensure(n * 4);
   ctx->envout.ensure(n * sizeof(EnvOut));
@@ -618,7 +626,7 @@ void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, b
   const uint8_t *res = s->d_res.as<uint8_t>();
   const uint64_t *off = s->d_off.as<uint64_t>();
   float *ws = ws_other ? ws_other : ctx->ws.as<float>();
-  if (do_fwd) HIPCHK(hipMemset(ctx->counters.p, 0, 64));
+  if (do_fwd) HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   // every register class runs its stages in order on its own stream; classes overlap each other
   size_t gi = 0;
@@ -638,15 +646,15 @@ void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, b
   if (do_fwd) {
     b.fout.resize(n);
     uint32_t nev = 0;
-    HIPCHK(hipMemcpy(b.fout.data(), ctx->fout.p, n * sizeof(FwdOut), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&nev, ctx->counters.p, 4, hipMemcpyDeviceToHost));
+    wcopy(ctx, b.fout.data(), ctx->fout.p, n * sizeof(FwdOut), hipMemcpyDeviceToHost);
+    wcopy(ctx, &nev, ctx->counters.p, 4, hipMemcpyDeviceToHost);
     if (nev > cap_events) throw Error(CKM_ERANGE, "rescale event buffer overflow");
     b.events.resize(nev);
-    if (nev) HIPCHK(hipMemcpy(b.events.data(), ctx->events.p, (size_t)nev * sizeof(ScaleEvent), hipMemcpyDeviceToHost));
+    if (nev) wcopy(ctx, b.events.data(), ctx->events.p, (size_t)nev * sizeof(ScaleEvent), hipMemcpyDeviceToHost);
   }
   if (do_oa) {
     b.envout.resize(n);
-    HIPCHK(hipMemcpy(b.envout.data(), ctx->envout.p, n * sizeof(EnvOut), hipMemcpyDeviceToHost));
+    wcopy(ctx, b.envout.data(), ctx->envout.p, n * sizeof(EnvOut), hipMemcpyDeviceToHost);
   }
 }
 
@@ -838,7 +846,7 @@ void ens_begin(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, EnsJob &jo
     std::vector<uint32_t> seeds(ENS_NSAMPLES);
     for (int t = 0; t < ENS_NSAMPLES; ++t) seeds[t] = ens_seed(t);
     ctx->ensseeds.ensure(seeds.size() * 4);
-    HIPCHK(hipMemcpy(ctx->ensseeds.p, seeds.data(), seeds.size() * 4, hipMemcpyHostToDevice));
+    wcopy(ctx, ctx->ensseeds.p, seeds.data(), seeds.size() * 4, hipMemcpyHostToDevice);
   }
   auto al = [](uint64_t v) { return (v + 31) & ~(uint64_t)31; };
   const uint64_t budget_floats = ctx->ws_budget / 4;
@@ -920,7 +928,9 @@ struct SearchPlan {        // which models run against which sequence lists
 typedef std::map<std::pair<uint32_t, uint32_t>, std::vector<Hit>> HitMap;     // (bin, model) -> hits
 
 // The whole filter cascade + domain stage for a subset of the models, on one worker.
-static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, const ckm_seqs *s, const std::vector<uint32_t> &my_models,
+struct SeqRange { std::vector<uint32_t> lo, hi; std::vector<uint64_t> res; uint64_t tag = 0; };   // per bin: [lo, hi) of s->order, residues in it
+
+static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles *p, const ckm_seqs *s, const SeqRange &rng, const std::vector<uint32_t> &my_models,
                     const std::vector<std::vector<uint32_t>> &model_bins, HitMap &by_bin_model) {
   HIPCHK(hipSetDevice(ctx->device));
   const double t_start = now_ms();
@@ -934,6 +944,11 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
 
   // ---- stage 1: SSV over every pair, chunked by a pair budget ----
   std::vector<Cand> cands;
+  bool took_turn = false;
+  struct TurnGuard {      // a worker that never reaches an SSV phase (no pairs, or an error) still passes the turn on
+    ckm_ctx *o; int t; bool *took;
+    ~TurnGuard() { if (*took) return; std::unique_lock<std::mutex> l(o->ssv_mutex); o->ssv_cv.wait(l, [&] { return o->ssv_turn == t; }); o->ssv_turn++; o->ssv_cv.notify_all(); }
+  } turn_guard{owner, my_turn, &took_turn};
   {
     uint64_t pair_budget = (uint64_t)1 << 29;                  // pairs per SSV chunk (2 B of maxV each); CKM_PAIR_BUDGET overrides (tests)
     if (const char *e = getenv("CKM_PAIR_BUDGET")) pair_budget = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
@@ -946,17 +961,18 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
       for (; i1 < my_models.size(); ++i1) {
         const uint32_t m1 = my_models[i1];
         uint64_t n = 0;
-        for (uint32_t b : model_bins[m1]) n += s->order_off[b + 1] - s->order_off[b];
+        for (uint32_t b : model_bins[m1]) n += rng.hi[b] - rng.lo[b];
         if (n == 0) continue;
         if (npairs + n > pair_budget && !mws.empty()) break;
         mws.push_back({m1, npairs, n}); npairs += n;
       }
       i0 = i1;
       if (mws.empty() || npairs == 0) continue;
-      std::unique_lock<std::mutex> ssv_lock(*ssv_mutex);     // one SSV phase at a time (VALU-bound); released after the finish kernel
+      std::unique_lock<std::mutex> ssv_lock(owner->ssv_mutex);     // one SSV phase at a time (VALU-bound); released after the finish kernel
+      if (!took_turn) owner->ssv_cv.wait(ssv_lock, [&] { return owner->ssv_turn == my_turn; });
       // The block table depends only on (profiles, sequences, models and their bins): reuse the resident one when the
       // previous call on this worker had the same plan (lineage_wf scans the same bins twice; bench repeats steps).
-      std::vector<uint64_t> key{p->uid, s->uid, pair_budget, (uint64_t)i0};
+      std::vector<uint64_t> key{p->uid, s->uid, pair_budget, (uint64_t)i0, rng.tag};
       for (auto &mw : mws) { key.push_back(0xffffffffull + mw.model); for (uint32_t b : model_bins[mw.model]) key.push_back(b); }
       std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;
       size_t nblocks_total = 0;
@@ -971,12 +987,12 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
           const int Q = p->prof[mw.model].ssvQ; const int threads = ssv_threads_for(Q); const uint32_t per_block = (uint32_t)threads / 64 * 4 * 4;
           uint64_t pb = mw.pair_base;
           for (uint32_t b : model_bins[mw.model]) {
-            const uint32_t o0 = s->order_off[b], n = s->order_off[b + 1] - o0;
+            const uint32_t o0 = rng.lo[b], n = rng.hi[b] - o0;
             for (uint32_t a = 0; a < n; a += per_block) {
               SsvBlockWork w; w.model = mw.model; w.list_start = o0 + a; w.count = std::min(per_block, n - a); w.pair_start = (uint32_t)(pb + a);
               byQ[Q].push_back(w);
             }
-            pb += n; c_res += s->bin_res[b]; c_cells += s->bin_res[b] * (uint64_t)p->prof[mw.model].M;
+            pb += n; c_res += rng.res[b]; c_cells += rng.res[b] * (uint64_t)p->prof[mw.model].M;
           }
           c_pairs += mw.npairs;
         }
@@ -1030,8 +1046,9 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
         std::vector<PairRec> nr(cnt[1]);
         ctx->h_a.ensure((size_t)cnt[0] * sizeof(PairRec) + 16);
         const PairRec *sv = ctx->h_a.as<PairRec>();
-        if (cnt[0]) HIPCHK(hipMemcpy(ctx->h_a.p, ctx->surv.p, (size_t)cnt[0] * sizeof(PairRec), hipMemcpyDeviceToHost));
-        if (cnt[1]) HIPCHK(hipMemcpy(nr.data(), ctx->nores.p, (size_t)cnt[1] * sizeof(PairRec), hipMemcpyDeviceToHost));
+        if (cnt[0]) wcopy(ctx, ctx->h_a.p, ctx->surv.p, (size_t)cnt[0] * sizeof(PairRec), hipMemcpyDeviceToHost);
+        if (cnt[1]) wcopy(ctx, nr.data(), ctx->nores.p, (size_t)cnt[1] * sizeof(PairRec), hipMemcpyDeviceToHost);
+        if (!took_turn) { took_turn = true; owner->ssv_turn++; owner->ssv_cv.notify_all(); }
         ssv_lock.unlock();
         cands.reserve(cands.size() + cnt[0]);
         for (uint32_t k = 0; k < cnt[0]; ++k) { Cand c; c.r = sv[k]; c.alive = true; c.fwdsc = 0; c.fwd_xC = 0; c.slot = 0; cands.push_back(c); }
@@ -1111,7 +1128,7 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
       for (int k = 0; k < 4; ++k) HIPCHK(hipStreamSynchronize(ctx->side[k]));
       ctx->h_a.ensure(cands.size() * 4 + 16);
       const float *vsc = ctx->h_a.as<float>();
-      HIPCHK(hipMemcpy(ctx->h_a.p, ctx->vits.p, cands.size() * 4, hipMemcpyDeviceToHost));
+      wcopy(ctx, ctx->h_a.p, ctx->vits.p, cands.size() * 4, hipMemcpyDeviceToHost);
       for (uint32_t i : flat) { Cand &c = cands[i]; if (!(bits(vsc[i], c.r.filtersc) >= p->prof[c.r.model].thr_vit_f2)) c.alive = false; }
     }
   }
@@ -1163,7 +1180,7 @@ static void cascade(Worker *ctx, std::mutex *ssv_mutex, const ckm_profiles *p, c
     // pull the decoding terms of the passers in one copy
     std::vector<float> dec_all(ap - aux_base);     // pageable on purpose: the region scan below re-reads it; pinned memory reads slowly from the CPU
     const float *dec_all_p = dec_all.data();
-    if (!dec_all.empty()) HIPCHK(hipMemcpy(dec_all.data(), ctx->ws.as<float>() + aux_base, dec_all.size() * 4, hipMemcpyDeviceToHost));
+    if (!dec_all.empty()) wcopy(ctx, dec_all.data(), ctx->ws.as<float>() + aux_base, dec_all.size() * 4, hipMemcpyDeviceToHost);
     std::vector<std::vector<Item>> found(passers.size());
     pool_run(ctx, passers.size(), 64, [&](size_t qlo, size_t qhi) {
       std::vector<float> btot, etot, mocc;
@@ -1314,19 +1331,72 @@ static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, cons
   std::vector<uint32_t> active; std::vector<double> cost(nmodels, 0.0);
   for (uint32_t m = 0; m < nmodels; ++m) if (!model_bins[m].empty()) { active.push_back(m); double n = 0; for (uint32_t b : model_bins[m]) n += (double)s->bin_res[b]; cost[m] = n * p->prof[m].M; }
   std::stable_sort(active.begin(), active.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
-  const int nw = (active.size() >= 2 * (size_t)c->nworkers) ? c->nworkers : 1;
-  std::vector<std::vector<uint32_t>> chunk(nw); std::vector<double> load(nw, 0.0);
-  for (uint32_t m : active) { int k = (int)(std::min_element(load.begin(), load.end()) - load.begin()); chunk[k].push_back(m); load[k] += cost[m]; }
+  // several workers only pay off on a large search (every one of them adds its own launches and host threads)
+  uint64_t total_pairs = 0;
+  for (uint32_t m : active) for (uint32_t b : model_bins[m]) total_pairs += s->order_off[b + 1] - s->order_off[b];
+  uint64_t min_pairs = 400000;
+  if (const char *e = getenv("CKM_WORKER_MIN_PAIRS")) min_pairs = strtoull(e, nullptr, 10);      // tests: small searches on several workers
+  const int nw = (total_pairs >= min_pairs * c->nworkers) ? c->nworkers : 1;
+  // Two workers split the SEQUENCES, not the models: every stage behind SSV is bound by the row-by-row chain of the longest
+  // sequence it holds, so the few long sequences (a prefix of each bin's length-sorted order) go to worker 0, whose short SSV
+  // phase runs first and whose long chains then run underneath the SSV phase of everything else (worker 1).
+  std::vector<std::vector<uint32_t>> chunk(nw);
+  std::vector<SeqRange> ranges(nw);
+  // cut lengths, descending: class k holds the sequences with cut[k-1] >= L > cut[k].  Default: the cuts that give the
+  // classes fixed shares of the residues (measured best on cfg2: 16 / 45 / 39 % for three workers, 60 / 40 for two).
+  std::vector<int> cuts;
+  if (const char *e = getenv("CKM_LEN_SPLIT")) {
+    const std::string spec = e; size_t pos = 0;
+    while (pos < spec.size()) { size_t q = spec.find(',', pos); if (q == std::string::npos) q = spec.size(); cuts.push_back(atoi(spec.substr(pos, q - pos).c_str())); pos = q + 1; }
+    std::sort(cuts.begin(), cuts.end(), std::greater<int>());
+  } else if (nw >= 2) {
+    static const double shares2[] = {0.60}, shares3[] = {0.16, 0.61}, shares4[] = {0.10, 0.35, 0.65};
+    const double *sh = nw == 2 ? shares2 : nw == 3 ? shares3 : shares4;
+    std::vector<uint64_t> by_len((size_t)s->maxL + 2, 0);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < s->nseq; ++i) { by_len[s->len[i]] += (uint64_t)s->len[i]; total += (uint64_t)s->len[i]; }
+    uint64_t acc = 0; int k = 0;
+    for (int L = s->maxL; L >= 1 && k < nw - 1; --L) { acc += by_len[L]; if ((double)acc >= sh[k] * (double)total) { cuts.push_back(L - 1); ++k; } }
+    while ((int)cuts.size() < nw - 1) cuts.push_back(0);
+  }
+  if (nw >= 2 && (int)cuts.size() == nw - 1 && cuts.back() > 0) {
+    for (int k = 0; k < nw; ++k) { chunk[k] = active; ranges[k].lo.resize(nbins); ranges[k].hi.resize(nbins); ranges[k].res.assign(nbins, 0); ranges[k].tag = 1000 + (uint64_t)k; for (int cv : cuts) ranges[k].tag = ranges[k].tag * 4099 + (uint64_t)cv; }
+    for (uint32_t b = 0; b < nbins; ++b) {
+      uint32_t at = s->order_off[b];
+      for (int k = 0; k < nw; ++k) {
+        const int cut = (k < nw - 1) ? cuts[k] : -1;
+        uint64_t r = 0; const uint32_t lo = at;
+        while (at < s->order_off[b + 1] && s->len[s->order[at]] > cut) { r += (uint64_t)s->len[s->order[at]]; ++at; }
+        ranges[k].lo[b] = lo; ranges[k].hi[b] = at; ranges[k].res[b] = r;
+      }
+    }
+  } else {
+    // models -> workers, by decreasing work, shares ~ ratio^k
+    double ratio = 1.0;
+    if (const char *e = getenv("CKM_SPLIT_RATIO")) ratio = std::min(1.0, std::max(0.01, atof(e)));
+    std::vector<double> share(nw, 1.0), load(nw, 0.0);
+    for (int k = 1; k < nw; ++k) share[k] = share[k - 1] * ratio;
+    for (uint32_t m : active) {
+      int k = 0;
+      for (int j = 1; j < nw; ++j) if (load[j] / share[j] < load[k] / share[k]) k = j;
+      chunk[k].push_back(m); load[k] += cost[m];
+    }
+    for (int k = 0; k < nw; ++k) {
+      ranges[k].lo.assign(s->order_off.begin(), s->order_off.end() - 1); ranges[k].hi.assign(s->order_off.begin() + 1, s->order_off.end());
+      ranges[k].res = s->bin_res; ranges[k].tag = 0;
+    }
+  }
   for (auto &ch : chunk) std::sort(ch.begin(), ch.end());
   std::vector<HitMap> maps(nw); std::vector<std::exception_ptr> errs(nw);
-  auto run = [&](int k) { try { cascade(&c->w[k], &c->ssv_mutex, p, s, chunk[k], model_bins, maps[k]); } catch (...) { errs[k] = std::current_exception(); } };
+  c->ssv_turn = 0;
+  auto run = [&](int k) { try { cascade(&c->w[k], c, k, p, s, ranges[k], chunk[k], model_bins, maps[k]); } catch (...) { errs[k] = std::current_exception(); } };
   std::vector<std::thread> threads;
   for (int k = 1; k < nw; ++k) threads.emplace_back(run, k);
   run(0);
   for (auto &t : threads) t.join();
   for (auto &e : errs) if (e) std::rethrow_exception(e);
   HitMap by_bin_model;
-  for (auto &m : maps) for (auto &kv : m) by_bin_model[kv.first] = std::move(kv.second);
+  for (auto &m : maps) for (auto &kv : m) { auto &dst = by_bin_model[kv.first]; for (auto &h : kv.second) dst.push_back(std::move(h)); }
   ckm_search_stats &st = c->stats;
   memset(&st, 0, sizeof(st));
   for (int k = 0; k < nw; ++k) {
@@ -1480,8 +1550,8 @@ extern "C" int ckm_debug_stages(ckm_ctx *ctx_, const ckm_profiles *p, const ckm_
     std::vector<SsvBlockWork> sorted; std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;
     for (auto &kv : byQ) { groups.push_back({kv.first, {sorted.size(), kv.second.size()}}); for (uint32_t i : kv.second) sorted.push_back(work[i]); }
     ctx->work.ensure(npairs * sizeof(SsvBlockWork)); ctx->idx.ensure(npairs * 4); ctx->maxv.ensure(npairs * 2 + 64);
-    HIPCHK(hipMemcpy(ctx->work.p, sorted.data(), npairs * sizeof(SsvBlockWork), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ctx->idx.p, ids.data(), npairs * 4, hipMemcpyHostToDevice));
+    wcopy(ctx, ctx->work.p, sorted.data(), npairs * sizeof(SsvBlockWork), hipMemcpyHostToDevice);
+    wcopy(ctx, ctx->idx.p, ids.data(), npairs * 4, hipMemcpyHostToDevice);
     for (auto &g : groups)
       if (launch_ssv(g.first, (int)g.second.second, ssv_threads_for(g.first), ctx->stream, ctx->work.as<SsvBlockWork>() + g.second.first, dm, res, off, dlen,
                      ctx->idx.as<uint32_t>(), ctx->maxv.as<uint16_t>()))

@@ -13,6 +13,8 @@
 
 namespace ckm {
 
+constexpr int KP_SYMS = 29;    // rows of the byte cost table (one per alphabet symbol)
+
 constexpr double LN2D = 0.69314718055994529;
 constexpr int NEG16 = -32768;
 
@@ -74,47 +76,63 @@ __global__ void msv_finish_kernel(FinishArgs a, uint32_t nblocks_work) {
 }
 
 // --------------------------------------------------------------------------------------------
-// full multi-hit MSV: one wavefront per pair, cells k = lane + 64*j, row held in LDS as ints
+// full multi-hit MSV: one wavefront (= one workgroup) per pair.  The model's byte costs for all 29 symbols are copied
+// into LDS once per pair and the residues ride in registers, 64 at a time, so no global load sits on the row-to-row
+// chain (rows of the longest sequence bound the launch).  Cells k = lane + 64*j, previous/current row in LDS.
 // --------------------------------------------------------------------------------------------
-__global__ void msv_full_kernel(const PairRec *__restrict__ pairs, uint32_t npairs, const DevModel *__restrict__ models,
-                                const LenEntry *__restrict__ lentab, const uint8_t *__restrict__ res,
-                                const uint64_t *__restrict__ seq_off, const int32_t *__restrict__ seq_len,
-                                int32_t *__restrict__ out_xJ /* -1 overflow */, float *__restrict__ out_usc, int maxMp) {
+__global__ void __launch_bounds__(64) msv_full_kernel(const PairRec *__restrict__ pairs, uint32_t npairs, const DevModel *__restrict__ models,
+                                                     const LenEntry *__restrict__ lentab, const uint8_t *__restrict__ res,
+                                                     const uint64_t *__restrict__ seq_off, const int32_t *__restrict__ seq_len,
+                                                     int32_t *__restrict__ out_xJ /* -1 overflow */, float *__restrict__ out_usc, int maxMp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t pi = blockIdx.x * (blockDim.x >> 6) + wave;
+  const int lane = threadIdx.x;
+  const uint32_t pi = blockIdx.x;
   if (pi >= npairs) return;
-  int16_t *row = reinterpret_cast<int16_t *>(smem) + (size_t)wave * 2 * maxMp;   // two buffers
   const PairRec pr = pairs[pi];
   const DevModel &md = models[pr.model];
-  const int M = md.M, L = seq_len[pr.seq];
+  const int M = md.M, L = seq_len[pr.seq], W = M + 1;
+  uint8_t *tab = reinterpret_cast<uint8_t *>(smem);
+  int16_t *row = reinterpret_cast<int16_t *>(smem + (((size_t)KP_SYMS * (maxMp + 1) + 15) & ~(size_t)15));
+  {
+    const uint32_t *__restrict__ src = reinterpret_cast<const uint32_t *>(md.rbv);     // table start is 256-byte aligned
+    uint32_t *dst = reinterpret_cast<uint32_t *>(tab);
+    const int nw32 = (KP_SYMS * W + 3) >> 2;
+    for (int j = lane; j < nw32; j += 64) dst[j] = src[j];
+  }
   const uint8_t *rp = res + seq_off[pr.seq];
   const LenEntry le = lentab[L];
   const int tjbm = (le.tjb_b + md.tbm_b) & 0xff;
   int16_t *dp = row, *nw = row + maxMp;
   for (int k = lane; k < M; k += 64) dp[k] = 0;
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __syncthreads();
   int xJ = 0, xB = max(md.base_b - tjbm, 0);
   bool overflow = false;
-  for (int i = 0; i < L && !overflow; ++i) {
-    const uint8_t *cost = md.rbv + (size_t)rp[i] * (M + 1) + 1;
-    int xE = 0;
-    for (int k = lane; k < M; k += 64) {
-      const int mp = (k > 0) ? (int)dp[k - 1] : 0;
-      int sv = max(mp, xB);
-      sv = min(sv + md.bias_b, 255);
-      sv = max(sv - (int)cost[k], 0);
-      xE = max(xE, sv);
-      nw[k] = (int16_t)sv;
+  int chunk = (lane < L) ? (int)rp[lane] : 0;
+  for (int i0 = 0; i0 < L && !overflow; i0 += 64) {
+    const int nxt = (i0 + 64 + lane < L) ? (int)rp[i0 + 64 + lane] : 0;     // next 64 residues, a whole chunk ahead
+    const int n = min(64, L - i0);
+    for (int r = 0; r < n; ++r) {
+      const int x = __builtin_amdgcn_readlane(chunk, r);
+      const uint8_t *cost = tab + x * W + 1;
+      int xE = 0;
+#pragma unroll 4
+      for (int k = lane; k < M; k += 64) {
+        const int mp = (k > 0) ? (int)dp[k - 1] : 0;
+        int sv = max(mp, xB);
+        sv = min(sv + md.bias_b, 255);
+        sv = max(sv - (int)cost[k], 0);
+        xE = max(xE, sv);
+        nw[k] = (int16_t)sv;
+      }
+      xE = wave_max(xE);
+      if (min(xE + md.bias_b, 255) == 255) { overflow = true; break; }
+      xE = max(xE - md.tec_b, 0);
+      xJ = max(xJ, xE);
+      xB = max(max(md.base_b, xJ) - tjbm, 0);
+      int16_t *t = dp; dp = nw; nw = t;
+      __syncthreads();
     }
-    xE = wave_max(xE);
-    if (min(xE + md.bias_b, 255) == 255) { overflow = true; break; }
-    xE = max(xE - md.tec_b, 0);
-    xJ = max(xJ, xE);
-    xB = max(max(md.base_b, xJ) - tjbm, 0);
-    int16_t *t = dp; dp = nw; nw = t;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    chunk = nxt;
   }
   if (lane == 0) {
     if (overflow) { out_xJ[pi] = -1; out_usc[pi] = __builtin_inff(); }
@@ -283,8 +301,10 @@ void launch_msv_finish(hipStream_t stream, const FinishArgs &a, uint32_t nblocks
 void launch_msv_full(hipStream_t stream, const PairRec *pairs, uint32_t npairs, const DevModel *models, const LenEntry *lentab,
                      const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xJ, float *out_usc, int maxMp) {
   if (!npairs) return;
-  hipLaunchKernelGGL(msv_full_kernel, dim3((npairs + 3) / 4), dim3(256), (size_t)4 * 2 * maxMp * sizeof(int16_t), stream,
-                     pairs, npairs, models, lentab, res, seq_off, seq_len, out_xJ, out_usc, maxMp);
+  const size_t lds = (((size_t)KP_SYMS * (maxMp + 1) + 15) & ~(size_t)15) + (size_t)2 * maxMp * sizeof(int16_t);
+  static size_t attr_bytes = 0;
+  if (lds > 48 * 1024 && lds > attr_bytes) { (void)hipFuncSetAttribute((const void *)msv_full_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_bytes = lds; }
+  hipLaunchKernelGGL(msv_full_kernel, dim3(npairs), dim3(64), lds, stream, pairs, npairs, models, lentab, res, seq_off, seq_len, out_xJ, out_usc, maxMp);
 }
 void launch_bias(hipStream_t stream, PairRec *pairs, uint32_t npairs, const DevModel *models, const LenEntry *lentab,
                  const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, float *raw) {

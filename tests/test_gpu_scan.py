@@ -205,8 +205,9 @@ def test_large_models_and_error_paths(gpu_ctx, tmp_path):
     assert e.value.code == -3 and "calibrated" in str(e.value)
 
 
-def test_chunked_execution_equals_single_pass(world):
-    """Tiny budgets force several SSV chunks and several envelope batches; rows must not change."""
+def test_chunked_and_multi_worker_execution_equal_single_pass(world):
+    """Tiny budgets force several SSV chunks and several envelope batches; several workers split the sequences by
+    length class or the models; rows must not change."""
     import subprocess
     import sys
     import json
@@ -240,6 +241,13 @@ print(json.dumps({"rows": [[int(hits.seq[i]), int(hits.model[i]), int(hits.ali_f
     got = json.loads(out.stdout.strip().split("\n")[-1])
     assert got["rows"] == ref
     assert got["launches"] > single_pass_launches          # several model chunks, each with its own launches
+    # the same search spread over workers: by sequence-length class (2, 3, 4 workers) and by model (CKM_LEN_SPLIT=0)
+    for extra in (dict(CKM_WORKERS="2"), dict(CKM_WORKERS="3"), dict(CKM_WORKERS="4", CKM_LEN_SPLIT="900,300,120"), dict(CKM_WORKERS="3", CKM_LEN_SPLIT="0")):
+        env = dict(os.environ, CKM_WORKER_MIN_PAIRS="1", **extra)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, (extra, out.stderr[-2000:])
+        got = json.loads(out.stdout.strip().split("\n")[-1])
+        assert got["rows"] == ref, extra
 
 
 def test_fasta_ingest_equals_packed_records(world, tmp_path):
