@@ -548,7 +548,14 @@ void wcopy(Worker *w, void *dst, const void *src, size_t bytes, hipMemcpyKind ki
   HIPCHK(hipStreamSynchronize(w->stream));
 }
 
+static const bool g_trace = getenv("CKM_TRACE") != nullptr;     // per-worker stage timestamps on stderr
+static double g_trace_t0 = 0;
+#define CKM_TRACE_PT(label) do { if (g_trace) fprintf(stderr, "ckm-trace w%d %8.3f %s\n", my_turn, now_ms_() - g_trace_t0, label); } while (0)
+double now_ms_();
+
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+double now_ms_() { return now_ms(); }
 
 float bits(float sc, float nullsc) { return (float)((double)(sc - nullsc) / kLn2); }
 
@@ -631,7 +638,8 @@ void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, b
   // every register class runs its stages in order on its own stream; classes overlap each other
   size_t gi = 0;
   for (auto &g : groups) {
-    hipStream_t st = ctx->side[gi++ % 8];
+    static const int nfb = [] { const char *e = getenv("CKM_FB_STREAMS"); return e ? std::max(1, std::min(8, atoi(e))) : 8; }();
+    hipStream_t st = ctx->side[gi++ % nfb];
     const uint32_t *ix = ctx->fbidx.as<uint32_t>() + g.blk0 * 4, *bm = ctx->fbmodel.as<uint32_t>() + g.blk0;
     if (do_fwd && launch_fwd(g.Q, (uint32_t)g.nblk, st, ctx->fbwork.as<FbWork>(), ix, bm, dm, lt, res, off, ws, ctx->fout.as<FwdOut>(),
                              ctx->events.as<ScaleEvent>(), ctx->counters.as<uint32_t>(), cap_events))
@@ -970,6 +978,7 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
       if (mws.empty() || npairs == 0) continue;
       std::unique_lock<std::mutex> ssv_lock(owner->ssv_mutex);     // one SSV phase at a time (VALU-bound); released after the finish kernel
       if (!took_turn) owner->ssv_cv.wait(ssv_lock, [&] { return owner->ssv_turn == my_turn; });
+      CKM_TRACE_PT("ssv turn taken");
       // The block table depends only on (profiles, sequences, models and their bins): reuse the resident one when the
       // previous call on this worker had the same plan (lineage_wf scans the same bins twice; bench repeats steps).
       std::vector<uint64_t> key{p->uid, s->uid, pair_budget, (uint64_t)i0, rng.tag};
@@ -1042,6 +1051,7 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
         HIPCHK(hipMemcpyAsync(cnt, ctx->counters.p, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (attempt == 0) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); st.ms_ssv += ms; }
+        CKM_TRACE_PT("ssv + msv_finish done");
         if (cnt[0] > cap_surv || cnt[1] > cap_nores) { cap_surv = std::max(cap_surv, cnt[0]); cap_nores = std::max(cap_nores, cnt[1]); continue; }
         std::vector<PairRec> nr(cnt[1]);
         ctx->h_a.ensure((size_t)cnt[0] * sizeof(PairRec) + 16);
@@ -1073,6 +1083,7 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
   //  ordered at the end, so no sort is needed here)
   const double t_filters0 = now_ms();
 
+  CKM_TRACE_PT("stage1 done (ssv, msv_finish, msv_full)");
   // ---- stage 2: bias filter ----
   std::vector<PairRec> cr(cands.size());
   for (size_t i = 0; i < cands.size(); ++i) cr[i] = cands[i].r;
@@ -1102,6 +1113,7 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
     });
   }
   // ---- stage 3: Viterbi filter ----
+  CKM_TRACE_PT("bias done");
   {
     std::map<int, std::vector<uint32_t>> byQ;
     for (size_t i = 0; i < cands.size(); ++i) if (cands[i].alive && need_vit[i]) byQ[p->prof[cands[i].r.model].vitQH].push_back((uint32_t)i);
@@ -1133,6 +1145,7 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
     }
   }
   st.ms_filters = now_ms() - t_filters0;
+  CKM_TRACE_PT("viterbi done");
   const double t_fb0 = now_ms();
   // ---- stage 4: Forward parser (multihit, whole sequence), F3 ----
   FbBatch fb;
@@ -1155,6 +1168,7 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
     run_fb(ctx, p, s, fb, true, false, false, nullptr);
   }
   EventIndex fev; fev.build(fb.events, fb.work.size());
+  CKM_TRACE_PT("fwd parser kernels+copies done, event index built");
   std::vector<uint32_t> passers;
   pool_run(ctx, fb.work.size(), 512, [&](size_t lo, size_t hi) {
     for (size_t k = lo; k < hi; ++k) {
@@ -1168,6 +1182,7 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
   for (size_t k = 0; k < fb.work.size(); ++k) if (cands[fb_cand[k]].alive) passers.push_back((uint32_t)k);
   st.pairs_dom = passers.size();
   // ---- stage 5: Backward parser + posterior domain heuristics ----
+  CKM_TRACE_PT("fwd post done");
   std::vector<EnvReq> envreq; std::vector<std::pair<size_t, size_t>> env_of_pass(passers.size());   // [first, count)
   std::vector<int> nregions(passers.size(), 0);
   struct Item { uint32_t pass; int i, j, region; };       // regions in sequence order; region >= 0: resolved by the trace ensemble
@@ -1214,6 +1229,7 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
   // multi-domain regions: 200 stochastic tracebacks each, clustered into envelopes.  (Queueing them beside the envelope
   // stage of the single-domain regions was tried: the second envelope pass it needs costs more than it hides.)
   st.regions_multi = regreq.size();
+  CKM_TRACE_PT("bwd parser + region scan done");
   run_ensembles(ctx, p, s, regreq, regres);
   {
     size_t it = 0;
@@ -1235,12 +1251,14 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
     }
   }
   st.ms_fwdbwd = now_ms() - t_fb0;
+  CKM_TRACE_PT("ensembles done");
   const double t_dom0 = now_ms();
   // ---- stage 6: envelope rescoring ----
   std::vector<EnvRes> envres;
   rescore_envelopes(ctx, p, s, envreq, envres);
   st.envelopes = envreq.size();
   st.ms_domains = now_ms() - t_dom0;
+  CKM_TRACE_PT("envelopes done");
   const double t_host0 = now_ms();
   // ---- stage 7: scores, thresholds, rows ----
   std::vector<std::pair<size_t, size_t>> items_of(passers.size(), {0, 0});
@@ -1309,6 +1327,7 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
   for (size_t q = 0; q < passers.size(); ++q) if (has_hit[q]) by_bin_model[{s->seq_bin[hit_of[q].seq], hit_of[q].model}].push_back(std::move(hit_of[q]));
   st.ms_host = now_ms() - t_host0;
   st.ms_total = now_ms() - t_start;
+  CKM_TRACE_PT("cascade done");
 }
 
 static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, const uint32_t *model_off, const uint32_t *model_idx,
@@ -1389,6 +1408,7 @@ static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, cons
   for (auto &ch : chunk) std::sort(ch.begin(), ch.end());
   std::vector<HitMap> maps(nw); std::vector<std::exception_ptr> errs(nw);
   c->ssv_turn = 0;
+  g_trace_t0 = now_ms();
   auto run = [&](int k) { try { cascade(&c->w[k], c, k, p, s, ranges[k], chunk[k], model_bins, maps[k]); } catch (...) { errs[k] = std::current_exception(); } };
   std::vector<std::thread> threads;
   for (int k = 1; k < nw; ++k) threads.emplace_back(run, k);
