@@ -142,18 +142,19 @@ def main():
         ssv_s = ssv_ms / args.steps / 1e3
         achieved = alg_bytes / ssv_s / 1e9
         # HBM traffic and VALU instruction count of the same launches come from separate rocprofv3 --pmc passes
-        # (profiles/r01b_pmc_summary.txt); they are only quoted when the workload is the one that was profiled
+        # (profiles/r01c_pmc_summary.txt); they are only quoted when the workload is the one that was profiled
         traffic = None
         valu = None
-        tf = os.path.join(ROOT, "profiles", "r01b_ssv_traffic.json")
+        tf = os.path.join(ROOT, "profiles", "r01c_ssv_traffic.json")
         if os.path.exists(tf) and args.bins == 100 and args.orfs == 2000:
             with open(tf) as f:
                 pm = json.load(f)
             traffic = pm["hbm_bytes_corrected"]
             cyc = ssv_s * 2.4e9 / (pm["valu_insts"] / 1024.0)
-            valu = {"bound": "valu-issue", "wave_insts_per_step": pm["valu_insts"], "cycles_per_inst_per_simd": cyc, "ceiling_cycles_per_inst": 4.4,
-                    "frac": 4.4 / cyc, "note": "gfx950 issues every VALU op except f32 add/mul/fma at ~4.2-4.6 nominal cycles per wave64 "
-                    "(tools/ubench/valu_rates.hip -> profiles/r01_valu_rates.txt); the SSV inner loop is 2 packed-i16 ops per register per row"}
+            valu = {"bound": "valu-issue", "wave_insts_per_step": pm["valu_insts"], "cycles_per_inst_per_simd": cyc, "ceiling_cycles_per_inst": 4.0,
+                    "frac": 4.0 / cyc, "note": "issue peak = 1 wave64 instruction per 4 cycles per SIMD; isolated packed-i16 ops measure 4.2-4.6 "
+                    "(tools/ubench/valu_rates.hip -> profiles/r01_valu_rates.txt); the SSV inner loop is 2 packed-i16 ops per register per row; "
+                    "time = the workers' SSV phases (they run one after the other, sharing the device with the rare stages of the other workers)"}
         out = {
             "metric": "residues*HMMs/s (marker-gene scan+reduce, cfg2: 43 profiles x 100 synthetic 2 Mb bins per GPU)",
             "value": value, "unit": "residue*HMM/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

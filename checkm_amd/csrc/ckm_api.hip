@@ -1353,7 +1353,7 @@ static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, cons
   // several workers only pay off on a large search (every one of them adds its own launches and host threads)
   uint64_t total_pairs = 0;
   for (uint32_t m : active) for (uint32_t b : model_bins[m]) total_pairs += s->order_off[b + 1] - s->order_off[b];
-  uint64_t min_pairs = 400000;
+  uint64_t min_pairs = 300000;
   if (const char *e = getenv("CKM_WORKER_MIN_PAIRS")) min_pairs = strtoull(e, nullptr, 10);      // tests: small searches on several workers
   const int nw = (total_pairs >= min_pairs * c->nworkers) ? c->nworkers : 1;
   // Two workers split the SEQUENCES, not the models: every stage behind SSV is bound by the row-by-row chain of the longest
