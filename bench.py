@@ -173,7 +173,7 @@ def main():
             "roofline_valu": valu,
             "stages_ms": {"ssv": st.ms_ssv, "filters": st.ms_filters, "fwdbwd": st.ms_fwdbwd, "domains": st.ms_domains, "host": st.ms_host, "search_total": st.ms_total},
             "step_parts_ms": {k: v / args.steps for k, v in part_ms.items()},
-            "stage_pairs": {"ssv": int(st.pairs_ssv), "msv_full": int(st.pairs_msv_full), "bias": int(st.pairs_bias), "vit": int(st.pairs_vit),
+            "stage_pairs": {"ssv": int(st.pairs_ssv), "msv_full": int(st.pairs_msv_full), "bias": int(st.pairs_bias), "vit": int(st.pairs_vit), "vit_exact": int(st.pairs_vit_exact),
                             "fwd": int(st.pairs_fwd), "dom": int(st.pairs_dom), "envelopes": int(st.envelopes), "regions_multi": int(st.regions_multi)},
             "rows": int(nrows), "setup_s": {"generate": t_gen, "pack_and_upload": t_pack},
         }

@@ -46,7 +46,7 @@ HIT_FIELDS = ["seq", "model", "tlen", "qlen", "full_evalue", "full_score", "full
 
 class SearchStats(C.Structure):
     _fields_ = [("pairs_ssv", C.c_uint64), ("pairs_msv_full", C.c_uint64), ("pairs_bias", C.c_uint64), ("pairs_vit", C.c_uint64),
-                ("pairs_fwd", C.c_uint64), ("pairs_dom", C.c_uint64), ("envelopes", C.c_uint64), ("regions_multi", C.c_uint64), ("cells_ssv", C.c_uint64),
+                ("pairs_fwd", C.c_uint64), ("pairs_dom", C.c_uint64), ("envelopes", C.c_uint64), ("regions_multi", C.c_uint64), ("pairs_vit_exact", C.c_uint64), ("cells_ssv", C.c_uint64),
                 ("residue_hmm", C.c_uint64), ("ms_ssv", C.c_double), ("ms_filters", C.c_double), ("ms_fwdbwd", C.c_double),
                 ("ms_domains", C.c_double), ("ms_host", C.c_double), ("ms_total", C.c_double), ("ssv_launches", C.c_uint32)]
 

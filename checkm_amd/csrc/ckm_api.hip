@@ -34,7 +34,7 @@ void launch_msv_full(hipStream_t stream, const PairRec *pairs, uint32_t npairs, 
 void launch_bias(hipStream_t stream, PairRec *pairs, uint32_t npairs, const DevModel *models, const LenEntry *lentab,
                  const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, float *raw);
 int launch_vit(int Q, hipStream_t stream, const PairRec *pairs, const uint32_t *idx, uint32_t n, const DevModel *models,
-               const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xC, float *out_sc);
+               const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xC, float *out_sc, uint32_t *out_flag, bool fast);
 int launch_fwd(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const uint32_t *blk_model, const DevModel *models,
                const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, FwdOut *out,
                ScaleEvent *events, uint32_t *nevents, uint32_t cap_events);
@@ -160,7 +160,7 @@ struct Worker {
   std::vector<std::pair<int, std::pair<size_t, size_t>>> plan_groups;
   uint64_t plan_npairs = 0, plan_nblocks = 0, plan_residue_hmm = 0, plan_cells = 0, plan_pairs = 0;
   PinnedBuf h_a, h_b, h_ens;              // D2H staging
-  DevBuf work, maxv, surv, nores, counters, cand, raw, idx, vitx, vits, fbwork, fbidx, fbmodel, ws, fout, events, rerr, envout, fullx, fullu, enswork, ensseeds, ws_ens;
+  DevBuf work, maxv, surv, nores, counters, cand, raw, idx, vitx, vits, vitf, fbwork, fbidx, fbmodel, ws, fout, events, rerr, envout, fullx, fullu, enswork, ensseeds, ws_ens;
   size_t ws_budget = (size_t)8 << 30;     // float workspace budget (bytes) for Forward/Backward matrices
   std::unique_ptr<HostPool> pool;         // host threads of this worker
 };
@@ -1126,22 +1126,42 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
     if (!flat.empty()) {
       for (size_t i = 0; i < cands.size(); ++i) cr[i] = cands[i].r;
       HIPCHK(hipMemcpyAsync(ctx->cand.p, cr.data(), cr.size() * sizeof(PairRec), hipMemcpyHostToDevice, ctx->stream));
-      ctx->fbidx.ensure(flat.size() * 4); ctx->vitx.ensure(cands.size() * 4); ctx->vits.ensure(cands.size() * 4);
+      ctx->fbidx.ensure(flat.size() * 4); ctx->vitx.ensure(cands.size() * 4); ctx->vits.ensure(cands.size() * 4); ctx->vitf.ensure(cands.size() * 4);
       HIPCHK(hipMemcpyAsync(ctx->fbidx.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, ctx->stream));
       HIPCHK(hipStreamSynchronize(ctx->stream));            // uploads done; the launches go to the side streams
-      { int gi = 0;
-        for (auto it = groups.rbegin(); it != groups.rend(); ++it, ++gi) {
+      // pass 1: the J-free fast kernel (exact, or a lower bound with its flag set); pass 2: the exact kernel for the pairs
+      // whose bound fails F2 although the J state could have lifted them
+      auto run_vit = [&](const std::vector<std::pair<int, std::pair<size_t, size_t>>> &grp, bool fast) {
+        int gi = 0;
+        for (auto it = grp.rbegin(); it != grp.rend(); ++it, ++gi) {
           auto &g = *it;
           if (launch_vit(g.first, ctx->side[gi % 4], ctx->cand.as<PairRec>(), ctx->fbidx.as<uint32_t>() + g.second.first, (uint32_t)g.second.second, dm, lt, res, off, dlen,
-                         ctx->vitx.as<int32_t>(), ctx->vits.as<float>()))
+                         ctx->vitx.as<int32_t>(), ctx->vits.as<float>(), ctx->vitf.as<uint32_t>(), fast))
             throw Error(CKM_ERANGE, "no Viterbi kernel instance for this model length");
-        } }
-      HIPCHK(hipGetLastError());
-      for (int k = 0; k < 4; ++k) HIPCHK(hipStreamSynchronize(ctx->side[k]));
-      ctx->h_a.ensure(cands.size() * 4 + 16);
-      const float *vsc = ctx->h_a.as<float>();
-      wcopy(ctx, ctx->h_a.p, ctx->vits.p, cands.size() * 4, hipMemcpyDeviceToHost);
-      for (uint32_t i : flat) { Cand &c = cands[i]; if (!(bits(vsc[i], c.r.filtersc) >= p->prof[c.r.model].thr_vit_f2)) c.alive = false; }
+        }
+        HIPCHK(hipGetLastError());
+        for (int k = 0; k < 4; ++k) HIPCHK(hipStreamSynchronize(ctx->side[k]));
+      };
+      run_vit(groups, true);
+      ctx->h_a.ensure(cands.size() * 4 + 16); ctx->h_b.ensure(cands.size() * 4 + 16);
+      const float *vsc = ctx->h_a.as<float>(); const uint32_t *vfl = ctx->h_b.as<uint32_t>();
+      HIPCHK(hipMemcpyAsync(ctx->h_a.p, ctx->vits.p, cands.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+      wcopy(ctx, ctx->h_b.p, ctx->vitf.p, cands.size() * 4, hipMemcpyDeviceToHost);
+      std::map<int, std::vector<uint32_t>> redoQ;
+      for (uint32_t i : flat) {
+        Cand &c = cands[i];
+        if (bits(vsc[i], c.r.filtersc) >= p->prof[c.r.model].thr_vit_f2) continue;          // passes already on the bound
+        if (vfl[i]) redoQ[p->prof[c.r.model].vitQH].push_back(i); else c.alive = false;
+      }
+      if (!redoQ.empty()) {
+        std::vector<uint32_t> flat2; std::vector<std::pair<int, std::pair<size_t, size_t>>> groups2;
+        for (auto &kv : redoQ) { groups2.push_back({kv.first, {flat2.size(), kv.second.size()}}); flat2.insert(flat2.end(), kv.second.begin(), kv.second.end()); }
+        st.pairs_vit_exact = flat2.size();
+        wcopy(ctx, ctx->fbidx.p, flat2.data(), flat2.size() * 4, hipMemcpyHostToDevice);
+        run_vit(groups2, false);
+        wcopy(ctx, ctx->h_a.p, ctx->vits.p, cands.size() * 4, hipMemcpyDeviceToHost);
+        for (uint32_t i : flat2) { Cand &c = cands[i]; if (!(bits(vsc[i], c.r.filtersc) >= p->prof[c.r.model].thr_vit_f2)) c.alive = false; }
+      }
     }
   }
   st.ms_filters = now_ms() - t_filters0;
@@ -1421,7 +1441,7 @@ static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, cons
   memset(&st, 0, sizeof(st));
   for (int k = 0; k < nw; ++k) {
     const ckm_search_stats &w = c->w[k].stats;
-    st.pairs_ssv += w.pairs_ssv; st.pairs_msv_full += w.pairs_msv_full; st.pairs_bias += w.pairs_bias; st.pairs_vit += w.pairs_vit; st.pairs_fwd += w.pairs_fwd;
+    st.pairs_ssv += w.pairs_ssv; st.pairs_msv_full += w.pairs_msv_full; st.pairs_bias += w.pairs_bias; st.pairs_vit += w.pairs_vit; st.pairs_vit_exact += w.pairs_vit_exact; st.pairs_fwd += w.pairs_fwd;
     st.pairs_dom += w.pairs_dom; st.envelopes += w.envelopes; st.regions_multi += w.regions_multi; st.cells_ssv += w.cells_ssv; st.residue_hmm += w.residue_hmm; st.ssv_launches += w.ssv_launches;
     st.ms_ssv += w.ms_ssv;                                   // SSV phases are serialised by the mutex: the sum is the kernel time
     st.ms_filters = std::max(st.ms_filters, w.ms_filters); st.ms_fwdbwd = std::max(st.ms_fwdbwd, w.ms_fwdbwd);
@@ -1600,7 +1620,7 @@ extern "C" int ckm_debug_stages(ckm_ctx *ctx_, const ckm_profiles *p, const ckm_
     HIPCHK(hipMemcpyAsync(ctx->fbidx.p, flat.data(), npairs * 4, hipMemcpyHostToDevice, ctx->stream));
     for (auto &g : vg)
       if (launch_vit(g.first, ctx->stream, ctx->cand.as<PairRec>(), ctx->fbidx.as<uint32_t>() + g.second.first, (uint32_t)g.second.second, dm, lt, res, off, dlen,
-                     ctx->vitx.as<int32_t>(), ctx->vits.as<float>()))
+                     ctx->vitx.as<int32_t>(), ctx->vits.as<float>(), nullptr, false))
         throw Error(CKM_ERANGE, "no Viterbi kernel instance");
     HIPCHK(hipGetLastError());
     std::vector<int32_t> vx(npairs); std::vector<float> vs(npairs);

@@ -190,11 +190,16 @@ __device__ __forceinline__ u32 stripe_shift(u32 v) {
   return __builtin_amdgcn_alignbit(v, up, 16);
 }
 
-template <int QH>
+// FAST: the J state is assumed unused (xJ <= xN throughout), which makes xB a constant and removes every per-row
+// reduction: the rows only feed a running element-wise maximum.  The result is exact when max xE + E->J <= base (flag 0);
+// otherwise it is a LOWER bound of the exact score (max / saturating add are monotone in xB) and flag = 1: the caller
+// accepts the pair if the bound already passes F2 and re-runs the exact kernel if it does not.
+template <int QH, bool FAST>
 __global__ void __launch_bounds__(256) vit_kernel(const PairRec *__restrict__ pairs, const uint32_t *__restrict__ idx, uint32_t n,
                                                   const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
                                                   const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
-                                                  const int32_t *__restrict__ seq_len, int32_t *__restrict__ out_xC, float *__restrict__ out_sc) {
+                                                  const int32_t *__restrict__ seq_len, int32_t *__restrict__ out_xC, float *__restrict__ out_sc,
+                                                  uint32_t *__restrict__ out_flag) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t wi = blockIdx.x * (blockDim.x >> 6) + wave;
   if (wi >= n) return;
@@ -217,6 +222,7 @@ __global__ void __launch_bounds__(256) vit_kernel(const PairRec *__restrict__ pa
   for (int j = 0; j < QH; ++j) Mv[j] = Iv[j] = Dv[j] = NEG2;
   int xN = md.base_w, xB = xN + le.w_move, xJ = NEG16, xC = NEG16;
   bool overflow = false;
+  u32 xEv = NEG2;
   // emission words one row ahead, residue byte two rows ahead (dependent loads)
   u32 e[QH];
   {
@@ -234,8 +240,9 @@ __global__ void __launch_bounds__(256) vit_kernel(const PairRec *__restrict__ pa
     }
     xn = (i + 2 < L) ? rp[i + 2] : rp[L - 1];
     const u32 ms0 = stripe_shift(Mv[QH - 1]), is0 = stripe_shift(Iv[QH - 1]), ds0 = stripe_shift(Dv[QH - 1]);
-    const u32 xBv = ((u32)(xB & 0xffff)) * 0x10001u;
-    u32 xEv = NEG2, mdv[QH];
+    const u32 xBv = ((u32)(xB & 0xffff)) * 0x10001u;        // FAST: loop-invariant
+    u32 mdv[QH];
+    if (!FAST) xEv = NEG2;
 #pragma unroll
     for (int j = QH - 1; j >= 0; --j) {
       const u32 mp = j ? Mv[j - 1] : ms0, ip = j ? Iv[j - 1] : is0, dp = j ? Dv[j - 1] : ds0;
@@ -263,16 +270,28 @@ __global__ void __launch_bounds__(256) vit_kernel(const PairRec *__restrict__ pa
       for (int j = 0; j < QH; ++j) { Dv[j] = pk_max(Dv[j], cs); cs = pk_adds(cs, tDD[j]); }
       carry = cs;
     }
-    const s16x2 x2 = __builtin_bit_cast(s16x2, xEv);
-    int xE = max((int)x2.x, (int)x2.y);
-    xE = wave_max(xE);
-    if (xE >= 32767) { overflow = true; break; }
-    xC = max(xC, xE + md.wE_move);
-    xJ = max(xJ, xE + md.wE_loop);
-    xB = max(xJ + le.w_move, xN + le.w_move);
+    if (!FAST) {
+      const s16x2 x2 = __builtin_bit_cast(s16x2, xEv);
+      int xE = max((int)x2.x, (int)x2.y);
+      xE = wave_max(xE);
+      if (xE >= 32767) { overflow = true; break; }
+      xC = max(xC, xE + md.wE_move);
+      xJ = max(xJ, xE + md.wE_loop);
+      xB = max(xJ + le.w_move, xN + le.w_move);
+    }
 #pragma unroll
     for (int j = 0; j < QH; ++j) e[j] = en[j];
   }
+  bool jflag = false;
+  if (FAST) {
+    const s16x2 x2 = __builtin_bit_cast(s16x2, xEv);
+    int xE = max((int)x2.x, (int)x2.y);
+    xE = wave_max(xE);
+    overflow = xE >= 32767;
+    xC = max(xC, xE + md.wE_move);
+    jflag = (xE + md.wE_loop) > xN;
+  }
+  if (lane == 0 && out_flag) out_flag[pi] = (jflag && !overflow) ? 1u : 0u;
   if (lane == 0) {
     if (overflow) { out_xC[pi] = 32767; out_sc[pi] = __builtin_inff(); }
     else {
@@ -283,9 +302,13 @@ __global__ void __launch_bounds__(256) vit_kernel(const PairRec *__restrict__ pa
   }
 }
 
-#define CKM_VIT_CASE(QV) case QV: hipLaunchKernelGGL(vit_kernel<QV>, dim3((n + 3) / 4), dim3(256), 0, stream, pairs, idx, n, models, lentab, res, seq_off, seq_len, out_xC, out_sc); break;
+#define CKM_VIT_CASE(QV) case QV: \
+    if (fast) hipLaunchKernelGGL((vit_kernel<QV, true>), dim3((n + 3) / 4), dim3(256), 0, stream, pairs, idx, n, models, lentab, res, seq_off, seq_len, out_xC, out_sc, out_flag); \
+    else hipLaunchKernelGGL((vit_kernel<QV, false>), dim3((n + 3) / 4), dim3(256), 0, stream, pairs, idx, n, models, lentab, res, seq_off, seq_len, out_xC, out_sc, out_flag); \
+    break;
 int launch_vit(int QH, hipStream_t stream, const PairRec *pairs, const uint32_t *idx, uint32_t n, const DevModel *models,
-               const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xC, float *out_sc) {
+               const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xC, float *out_sc,
+               uint32_t *out_flag, bool fast) {
   if (n == 0) return 0;
   switch (QH) {
     CKM_VIT_CASE(1) CKM_VIT_CASE(2) CKM_VIT_CASE(3) CKM_VIT_CASE(4) CKM_VIT_CASE(5) CKM_VIT_CASE(6) CKM_VIT_CASE(7) CKM_VIT_CASE(8)

@@ -133,6 +133,7 @@ int  ckm_hits_write_domtblout(const ckm_hits *h, const ckm_profiles *p, const ck
 typedef struct {
   uint64_t pairs_ssv, pairs_msv_full, pairs_bias, pairs_vit, pairs_fwd, pairs_dom, envelopes;
   uint64_t regions_multi;       /* regions resolved by the stochastic trace ensemble */
+  uint64_t pairs_vit_exact;     /* Viterbi pairs re-run by the exact kernel (bound failed F2 with the J flag set) */
   uint64_t cells_ssv;           /* sum over pairs of L*M: GCUPS denominator */
   uint64_t residue_hmm;         /* sum over pairs of L */
   double   ms_ssv, ms_filters, ms_fwdbwd, ms_domains, ms_host, ms_total;

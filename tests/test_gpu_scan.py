@@ -130,8 +130,14 @@ def test_search_rows_identical(world):
     st = w["ctx"].stats()
     assert st.pairs_ssv == sum(1 for r in w["recs"] if len(r[2]) > 0) * w["hs"].n
     # the SSV-derived F1 decision must agree with the exact byte MSV on EVERY pair, not only on reported hits
-    want = sum(w["hs"].stages(m, d).pass_msv for m in range(w["hs"].n) for d in w["dsq"])
+    stages = [w["hs"].stages(m, d) for m in range(w["hs"].n) for d in w["dsq"]]
+    want = sum(s.pass_msv for s in stages)
     assert st.pairs_bias == want, (st.pairs_bias, want)
+    # ... and the two-pass Viterbi (J-free bound first, exact kernel only where the bound cannot decide) must send exactly the
+    # oracle's F2 survivors on to the Forward parser
+    want_fwd = sum(s.pass_vit for s in stages)
+    assert st.pairs_fwd == want_fwd, (st.pairs_fwd, want_fwd)
+    assert st.pairs_vit_exact < st.pairs_vit
     hits.close()
 
 
