@@ -54,7 +54,7 @@ class SearchStats(C.Structure):
 class StageScores(C.Structure):
     _fields_ = [("msv_xJ", C.c_int32), ("msv_sc", C.c_float), ("null_sc", C.c_float), ("bias_sc", C.c_float),
                 ("vit_xC", C.c_int32), ("vit_sc", C.c_float), ("fwd_sc", C.c_float), ("fwd_xC", C.c_float),
-                ("fwd_nscale", C.c_int32), ("ssv_maxv", C.c_int32)]
+                ("fwd_nscale", C.c_int32), ("ssv_maxv", C.c_int32), ("msvp_xJ", C.c_int32), ("msvp_sc", C.c_float)]
 
 
 class EnvelopeResult(C.Structure):

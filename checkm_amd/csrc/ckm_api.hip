@@ -29,6 +29,8 @@ namespace ckm {
 int launch_ssv(int Q, int nblocks, int threads, hipStream_t stream, const SsvBlockWork *work, const DevModel *models,
                const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const uint32_t *lists, uint16_t *maxv);
 void launch_msv_finish(hipStream_t stream, const FinishArgs &a, uint32_t nblocks);
+int launch_msv(int Q, int nblocks, hipStream_t stream, const SsvBlockWork *work, const DevModel *models, const LenEntry *lentab,
+               const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const uint32_t *lists, int32_t *out_xJ, float *out_usc);
 void launch_msv_full(hipStream_t stream, const PairRec *pairs, uint32_t npairs, const DevModel *models, const LenEntry *lentab,
                      const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xJ, float *out_usc, int maxMp);
 void launch_bias(hipStream_t stream, PairRec *pairs, uint32_t npairs, const DevModel *models, const LenEntry *lentab,
@@ -160,7 +162,7 @@ struct Worker {
   std::vector<std::pair<int, std::pair<size_t, size_t>>> plan_groups;
   uint64_t plan_npairs = 0, plan_nblocks = 0, plan_residue_hmm = 0, plan_cells = 0, plan_pairs = 0;
   PinnedBuf h_a, h_b, h_ens;              // D2H staging
-  DevBuf work, maxv, surv, nores, counters, cand, raw, idx, vitx, vits, vitf, fbwork, fbidx, fbmodel, ws, fout, events, rerr, envout, fullx, fullu, enswork, ensseeds, ws_ens;
+  DevBuf work, maxv, surv, nores, counters, cand, raw, idx, vitx, vits, vitf, fbwork, fbidx, fbmodel, ws, fout, events, rerr, envout, fullx, fullu, msvwork, msvlist, enswork, ensseeds, ws_ens;
   size_t ws_budget = (size_t)8 << 30;     // float workspace budget (bytes) for Forward/Backward matrices
   std::unique_ptr<HostPool> pool;         // host threads of this worker
 };
@@ -714,6 +716,54 @@ void rescore_envelopes(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, co
 }
 
 
+
+// Exact multi-hit MSV of an arbitrary list of pairs with the packed (SSV-style) kernel: pairs are grouped by model (one LDS
+// emission image per workgroup), longest sequences first, 16 sequences per workgroup (4 wavefronts x 4).  Results land in
+// usc/xJ in the order of `pairs`.
+void run_msv_exact(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<PairRec> &pairs, std::vector<float> &usc, std::vector<int32_t> *xJ) {
+  const size_t n = pairs.size();
+  usc.assign(n, 0.f); if (xJ) xJ->assign(n, 0);
+  if (!n) return;
+  std::map<int, std::map<uint32_t, std::vector<uint32_t>>> byQ;            // Q -> model -> indices into pairs
+  for (uint32_t i = 0; i < n; ++i) byQ[p->prof[pairs[i].model].ssvQ][pairs[i].model].push_back(i);
+  std::vector<SsvBlockWork> work; std::vector<uint32_t> lists, slot_of(n); std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;
+  constexpr uint32_t PER_BLOCK = 16;
+  for (auto it = byQ.rbegin(); it != byQ.rend(); ++it) {
+    const size_t first = work.size();
+    std::vector<SsvBlockWork> blocks;
+    for (auto &km : it->second) {
+      std::vector<uint32_t> &v = km.second;
+      std::stable_sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return s->len[pairs[a].seq] > s->len[pairs[b].seq]; });
+      for (size_t a = 0; a < v.size(); a += PER_BLOCK) {
+        SsvBlockWork w; w.model = km.first; w.list_start = (uint32_t)lists.size(); w.count = (uint32_t)std::min<size_t>(PER_BLOCK, v.size() - a); w.pair_start = w.list_start;
+        for (uint32_t k = 0; k < w.count; ++k) { slot_of[v[a + k]] = (uint32_t)lists.size(); lists.push_back(pairs[v[a + k]].seq); }
+        blocks.push_back(w);
+      }
+    }
+    // longest workgroups first inside a launch
+    std::stable_sort(blocks.begin(), blocks.end(), [&](const SsvBlockWork &x, const SsvBlockWork &y) { return s->len[lists[x.list_start]] > s->len[lists[y.list_start]]; });
+    work.insert(work.end(), blocks.begin(), blocks.end());
+    groups.push_back({it->first, {first, work.size() - first}});
+  }
+  ctx->msvwork.ensure(work.size() * sizeof(SsvBlockWork)); ctx->msvlist.ensure(lists.size() * 4);
+  ctx->fullx.ensure(n * 4); ctx->fullu.ensure(n * 4);
+  HIPCHK(hipMemcpyAsync(ctx->msvwork.p, work.data(), work.size() * sizeof(SsvBlockWork), hipMemcpyHostToDevice, ctx->stream));
+  wcopy(ctx, ctx->msvlist.p, lists.data(), lists.size() * 4, hipMemcpyHostToDevice);
+  int gi = 0;
+  for (auto &g : groups) {
+    if (launch_msv(g.first, (int)g.second.second, ctx->side[gi++ % 8], ctx->msvwork.as<SsvBlockWork>() + g.second.first, p->d_models.as<DevModel>(), s->d_lentab.as<LenEntry>(),
+                   s->d_res.as<uint8_t>(), s->d_off.as<uint64_t>(), s->d_len.as<int32_t>(), ctx->msvlist.as<uint32_t>(), ctx->fullx.as<int32_t>(), ctx->fullu.as<float>()))
+      throw Error(CKM_ERANGE, "no MSV kernel instance for this model length");
+  }
+  HIPCHK(hipGetLastError());
+  for (auto &st : ctx->side) HIPCHK(hipStreamSynchronize(st));
+  std::vector<float> raw(n); std::vector<int32_t> rawx(n);
+  HIPCHK(hipMemcpyAsync(raw.data(), ctx->fullu.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (xJ) HIPCHK(hipMemcpyAsync(rawx.data(), ctx->fullx.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < n; ++i) { usc[i] = raw[slot_of[i]]; if (xJ) (*xJ)[i] = rawx[slot_of[i]]; }
+}
+
 // ---- multi-domain regions: trace ensemble on the device, clustering of the sampled segments here ----------------
 struct Seg { int32_t sqfrom, sqto, hmmfrom, hmmto; };
 struct RegionReq { uint32_t model, seq; int ireg, jreg; };
@@ -1064,12 +1114,8 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
         for (uint32_t k = 0; k < cnt[0]; ++k) { Cand c; c.r = sv[k]; c.alive = true; c.fwdsc = 0; c.fwd_xC = 0; c.slot = 0; cands.push_back(c); }
         if (!nr.empty()) {     // exact multi-hit MSV for the pairs where J could be used
           st.pairs_msv_full += nr.size();
-          ctx->fullx.ensure(nr.size() * 4); ctx->fullu.ensure(nr.size() * 4);
-          launch_msv_full(ctx->stream, ctx->nores.as<PairRec>(), (uint32_t)nr.size(), dm, lt, res, off, dlen, ctx->fullx.as<int32_t>(), ctx->fullu.as<float>(), p->maxMp);
-          HIPCHK(hipGetLastError());
-          std::vector<float> usc(nr.size());
-          HIPCHK(hipMemcpyAsync(usc.data(), ctx->fullu.p, nr.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-          HIPCHK(hipStreamSynchronize(ctx->stream));
+          std::vector<float> usc;
+          run_msv_exact(ctx, p, s, nr, usc, nullptr);
           for (size_t i = 0; i < nr.size(); ++i) {
             const float nullsc = s->lentab[s->len[nr[i].seq]].nullsc;
             if (bits(usc[i], nullsc) >= p->prof[nr[i].model].thr_msv_f1) { Cand c; c.r = nr[i]; c.r.usc = usc[i]; c.alive = true; c.fwdsc = 0; c.fwd_xC = 0; c.slot = 0; cands.push_back(c); }
@@ -1599,9 +1645,12 @@ extern "C" int ckm_debug_stages(ckm_ctx *ctx_, const ckm_profiles *p, const ckm_
     HIPCHK(hipGetLastError());
     std::vector<uint16_t> maxv(npairs);
     HIPCHK(hipMemcpyAsync(maxv.data(), ctx->maxv.p, npairs * 2, hipMemcpyDeviceToHost, ctx->stream));
-    // full MSV on every pair
+    // full MSV on every pair: first with the packed kernel the search uses, then with the plain reference kernel
     std::vector<PairRec> pr(npairs);
     for (uint32_t i = 0; i < npairs; ++i) { pr[i].model = model[i]; pr[i].seq = seq[i]; pr[i].usc = 0; pr[i].filtersc = 0; }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::vector<float> uscp; std::vector<int32_t> xJp;
+    run_msv_exact(ctx, p, s, pr, uscp, &xJp);
     ctx->cand.ensure(npairs * sizeof(PairRec)); ctx->fullx.ensure(npairs * 4); ctx->fullu.ensure(npairs * 4); ctx->raw.ensure(npairs * 12);
     HIPCHK(hipMemcpyAsync(ctx->cand.p, pr.data(), npairs * sizeof(PairRec), hipMemcpyHostToDevice, ctx->stream));
     launch_msv_full(ctx->stream, ctx->cand.as<PairRec>(), npairs, dm, lt, res, off, dlen, ctx->fullx.as<int32_t>(), ctx->fullu.as<float>(), p->maxMp);
@@ -1645,6 +1694,7 @@ extern "C" int ckm_debug_stages(ckm_ctx *ctx_, const ckm_profiles *p, const ckm_
       const LenEntry &le = s->lentab[L];
       ckm_stage_scores &o = out[i];
       o.ssv_maxv = maxv[i]; o.msv_xJ = xJ[i]; o.msv_sc = usc[i]; o.null_sc = le.nullsc;
+      o.msvp_xJ = xJp[i]; o.msvp_sc = uscp[i];
       const float p1 = (float)L / (float)(L + 1);
       const float nullsc = (float)(log((double)raw[(size_t)i * 3]) + (double)raw[(size_t)i * 3 + 1] * kLn2);
       o.bias_sc = nullsc + (float)L * logf(p1) + logf(1.0f - p1);

@@ -125,6 +125,148 @@ __global__ void __launch_bounds__(Q > 40 ? 512 : 1024) ssv_kernel(const SsvBlock
   }
 }
 
+// --------------------------------------------------------------------------------------------------------------------
+// Exact multi-hit MSV for the pairs SSV cannot decide (xJ may exceed base, or Smax == 0): same lane mapping, same LDS
+// emission image, but the byte recurrence is carried in full -- sv = max(prev, xB) + (bias - cost), floored at 0 by the
+// clamped add (offset -32768 again) -- and every row ends with the 16-lane maximum that feeds xJ and xB.  sat_add(., bias)
+// cannot saturate on a row whose predecessors passed the overflow test, so adding (bias - cost) in one step is the byte
+// arithmetic exactly; the overflow flag is sticky and turns the score into +inf, as HMMER's early return does.
+// 3 packed ops per register per row + ~25 for the row maximum and the specials.
+// --------------------------------------------------------------------------------------------------------------------
+template <int Q>
+__device__ __forceinline__ void msv_row(u32 (&U)[Q], u32 &xE, u32 &prev, u32 xBv, const char *lds_base, u32 lane_off, u32 x) {
+  constexpr int Qg = (Q + 3) / 4;
+  constexpr int ROWB = Qg * 256;
+  const char *rowp = lds_base + __umul24(x, (u32)ROWB) + lane_off;
+  u32 e[Qg * 4];
+#pragma unroll
+  for (int g = 0; g < Qg; ++g) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(rowp + g * 256);
+    e[g * 4 + 0] = v.x; e[g * 4 + 1] = v.y; e[g * 4 + 2] = v.z; e[g * 4 + 3] = v.w;
+  }
+  const u32 last = U[Q - 1];
+  prev = (u32)__builtin_amdgcn_update_dpp((int)prev, (int)last, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+  const u32 carry = __builtin_amdgcn_alignbit(last, prev, 16);
+#pragma unroll
+  for (int q = Q - 1; q >= 1; --q) {
+    const s16x2 m = __builtin_elementwise_max(as_s16x2(U[q - 1]), as_s16x2(xBv));
+    const s16x2 v = __builtin_elementwise_add_sat(m, as_s16x2(e[q]));
+    xE = as_u32(__builtin_elementwise_max(as_s16x2(xE), v));
+    U[q] = as_u32(v);
+  }
+  {
+    const s16x2 m = __builtin_elementwise_max(as_s16x2(carry), as_s16x2(xBv));
+    const s16x2 v = __builtin_elementwise_add_sat(m, as_s16x2(e[0]));
+    xE = as_u32(__builtin_elementwise_max(as_s16x2(xE), v));
+    U[0] = as_u32(v);
+  }
+}
+
+__device__ __forceinline__ u32 pkmax_u(u32 a, u32 b) { return as_u32(__builtin_elementwise_max(as_s16x2(a), as_s16x2(b))); }
+
+template <int Q>
+__global__ void __launch_bounds__(256) msv_kernel(const SsvBlockWork *__restrict__ work, const DevModel *__restrict__ models,
+                                                  const LenEntry *__restrict__ lentab, const uint8_t *__restrict__ res,
+                                                  const uint64_t *__restrict__ seq_off, const int32_t *__restrict__ seq_len,
+                                                  const uint32_t *__restrict__ lists, int32_t *__restrict__ out_xJ, float *__restrict__ out_usc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int Qg = (Q + 3) / 4;
+  constexpr int ROWB = Qg * 256;
+  const SsvBlockWork w = work[blockIdx.x];
+  const DevModel &md = models[w.model];
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(md.ssv_tbl);
+    uint4 *dst = reinterpret_cast<uint4 *>(smem);
+    for (int i = threadIdx.x; i < SSV_NROWS * ROWB / 16; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int seg = lane >> 4, z = lane & 15;
+  const u32 lane_off = (u32)z * 16u;
+  const int base = md.base_b, bias = md.bias_b, tec = md.tec_b;
+  for (u32 g = wave; g * 4 < w.count; g += nwaves) {
+    const u32 li = g * 4 + seg;
+    const bool valid = li < w.count;
+    const u32 sid = valid ? lists[w.list_start + li] : 0u;
+    const int L = valid ? seq_len[sid] : 0;
+    const uint8_t *rp = res + seq_off[sid];
+    const int tjb = lentab[L].tjb_b;
+    const int tjbm = (tjb + md.tbm_b) & 0xff;
+    int Lmax = __builtin_amdgcn_readlane(L, 0);
+    Lmax = max(Lmax, __builtin_amdgcn_readlane(L, 16));
+    Lmax = max(Lmax, __builtin_amdgcn_readlane(L, 32));
+    Lmax = max(Lmax, __builtin_amdgcn_readlane(L, 48));
+    u32 U[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) U[q] = U_ZERO;
+    u32 prev = U_ZERO;
+    int xJ = 0, xB = max(base - tjbm, 0);
+    u32 xBv = (0x8000u + (u32)xB) * 0x10001u;
+    bool overflow = false;
+    const int nchunk = (Lmax + 15) >> 4;
+    const uint4 padv = make_uint4(PAD4, PAD4, PAD4, PAD4);
+    uint4 cur = padv;
+    if (0 < L) cur = *reinterpret_cast<const uint4 *>(rp);
+    for (int c = 0; c < nchunk; ++c) {
+      uint4 nxt = padv;
+      if ((c + 1) * 16 < L) nxt = *reinterpret_cast<const uint4 *>(rp + (c + 1) * 16);
+      const u32 wd[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+#pragma unroll
+        for (int b4 = 0; b4 < 4; ++b4) {
+          u32 xE = U_ZERO;
+          msv_row<Q>(U, xE, prev, xBv, smem, lane_off, (wd[k4] >> (8 * b4)) & 0xffu);
+          // maximum over the 16 lanes of the sequence, then over the two halves
+          xE = pkmax_u(xE, (u32)__builtin_amdgcn_update_dpp((int)xE, (int)xE, 0xB1, 0xf, 0xf, false));
+          xE = pkmax_u(xE, (u32)__builtin_amdgcn_update_dpp((int)xE, (int)xE, 0x4E, 0xf, 0xf, false));
+          xE = pkmax_u(xE, (u32)__builtin_amdgcn_update_dpp((int)xE, (int)xE, 0x141, 0xf, 0xf, false));
+          xE = pkmax_u(xE, (u32)__builtin_amdgcn_update_dpp((int)xE, (int)xE, 0x140, 0xf, 0xf, false));
+          xE = pkmax_u(xE, __builtin_amdgcn_alignbit(xE, xE, 16));
+          const int xe = (int)(short)(xE & 0xffffu) + 32768;
+          overflow = overflow || (xe + bias >= 255);
+          const int xe2 = max(xe - tec, 0);
+          xJ = max(xJ, xe2);
+          xB = max(max(base, xJ) - tjbm, 0);
+          xBv = (0x8000u + (u32)xB) * 0x10001u;
+        }
+      }
+      cur = nxt;
+    }
+    if (valid && z == 0) {
+      float sc = (float)(xJ - tjb) - (float)base;
+      sc = sc / md.scale_b;
+      sc = sc - 3.0f;
+      out_xJ[w.pair_start + li] = overflow ? -1 : xJ;
+      out_usc[w.pair_start + li] = overflow ? __builtin_inff() : sc;
+    }
+  }
+}
+
+#define CKM_MSV_CASE(QV)                                                                                         \
+  case QV:                                                                                                       \
+    if ((size_t)SSV_NROWS * ((QV + 3) / 4) * 256 > 48 * 1024) {                                                  \
+      static bool attr_set = false;                                                                              \
+      if (!attr_set) { (void)hipFuncSetAttribute((const void *)msv_kernel<QV>, hipFuncAttributeMaxDynamicSharedMemorySize, SSV_NROWS * ((QV + 3) / 4) * 256); attr_set = true; } \
+    }                                                                                                            \
+    hipLaunchKernelGGL(msv_kernel<QV>, dim3(nblocks), dim3(256), (size_t)SSV_NROWS * ((QV + 3) / 4) * 256, stream, \
+                       work, models, lentab, res, seq_off, seq_len, lists, out_xJ, out_usc);                     \
+    break;
+
+int launch_msv(int Q, int nblocks, hipStream_t stream, const SsvBlockWork *work, const DevModel *models, const LenEntry *lentab,
+               const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const uint32_t *lists, int32_t *out_xJ, float *out_usc) {
+  if (nblocks <= 0) return 0;
+  switch (Q) {
+    CKM_MSV_CASE(1) CKM_MSV_CASE(2) CKM_MSV_CASE(3) CKM_MSV_CASE(4) CKM_MSV_CASE(5) CKM_MSV_CASE(6) CKM_MSV_CASE(7)
+    CKM_MSV_CASE(8) CKM_MSV_CASE(9) CKM_MSV_CASE(10) CKM_MSV_CASE(11) CKM_MSV_CASE(12) CKM_MSV_CASE(13) CKM_MSV_CASE(14)
+    CKM_MSV_CASE(15) CKM_MSV_CASE(16) CKM_MSV_CASE(18) CKM_MSV_CASE(20) CKM_MSV_CASE(22) CKM_MSV_CASE(24) CKM_MSV_CASE(26)
+    CKM_MSV_CASE(28) CKM_MSV_CASE(30) CKM_MSV_CASE(32) CKM_MSV_CASE(36) CKM_MSV_CASE(40) CKM_MSV_CASE(48) CKM_MSV_CASE(56)
+    CKM_MSV_CASE(64)
+    default: return -1;
+  }
+  return 0;
+}
+
 #define CKM_SSV_CASE(QV)                                                                                         \
   case QV:                                                                                                       \
     if ((size_t)SSV_NROWS * ((QV + 3) / 4) * 256 > 48 * 1024) {                                                  \

@@ -210,6 +210,7 @@ typedef struct {
   int32_t msv_xJ;  float msv_sc, null_sc, bias_sc;
   int32_t vit_xC;  float vit_sc, fwd_sc, fwd_xC;  int32_t fwd_nscale;
   int32_t ssv_maxv;
+  int32_t msvp_xJ; float msvp_sc;      /* the packed exact-MSV kernel the search uses (must equal msv_xJ / msv_sc) */
 } ckm_stage_scores;
 int ckm_debug_stages(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s,
                      const uint32_t *model, const uint32_t *seq, uint32_t npairs, ckm_stage_scores *out);

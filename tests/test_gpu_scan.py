@@ -55,6 +55,9 @@ def test_stage_scores_bit_exact(world):
         for f in STAGE_FIELDS:
             if not _cmp_stage(o, got[i], f):
                 bad.append((m, s, f, getattr(o, f), getattr(got[i], f)))
+        # the packed exact-MSV kernel (the one the search runs on the pairs SSV cannot decide) against the same oracle bytes
+        if got[i].msvp_xJ != o.msv_xJ or common.float_bits(got[i].msvp_sc) != common.float_bits(o.msv_sc):
+            bad.append((m, s, "msv packed", o.msv_xJ, got[i].msvp_xJ, o.msv_sc, got[i].msvp_sc))
     assert not bad, bad[:10]
 
 
@@ -74,6 +77,8 @@ def test_planted_pairs_bit_exact(world):
         for f in STAGE_FIELDS:
             if not _cmp_stage(o, got[i], f):
                 bad.append((m, s, f, getattr(o, f), getattr(got[i], f)))
+        if got[i].msvp_xJ != o.msv_xJ or common.float_bits(got[i].msvp_sc) != common.float_bits(o.msv_sc):
+            bad.append((m, s, "msv packed", o.msv_xJ, got[i].msvp_xJ, o.msv_sc, got[i].msvp_sc))
     assert len(pairs) > 20
     assert not bad, bad[:10]
 
