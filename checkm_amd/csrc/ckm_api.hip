@@ -233,6 +233,9 @@ static int guarded(F &&f) {
 // accessors for ckm_reduce.hip
 const std::string &ckm_seq_name(const ckm_seqs *s, uint32_t i) { return s->names.at(i); }
 int ckm_ctx_device(const ckm_ctx *ctx) { return ctx->device; }
+void ckm_ctx_parallel_for(ckm_ctx *ctx, size_t n, size_t chunk, const std::function<void(size_t, size_t)> &f) {
+  if (ctx->w[0].pool) ctx->w[0].pool->run(n, chunk, f); else if (n) f(0, n);
+}
 void *ckm_ctx_reduce_scratch(ckm_ctx *ctx, size_t bytes) { ctx->reduce_scratch.ensure(bytes); return ctx->reduce_scratch.p; }
 
 extern "C" const char *ckm_last_error(void) { return g_err.c_str(); }

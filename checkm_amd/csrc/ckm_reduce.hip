@@ -12,6 +12,7 @@
 // order; they stay on the host as ordered containers.  The counting is the data-parallel part and
 // runs on the device: one thread per collocated set, one wave-level histogram per bin.
 #include <hip/hip_runtime.h>
+#include <functional>
 #include <algorithm>
 #include <charconv>
 #include <cmath>
@@ -272,6 +273,7 @@ struct ckm_qa {
 extern "C" int ckm_hits_columns(const ckm_hits *h, ckm_hit_columns *out);
 const std::string &ckm_seq_name(const ckm_seqs *s, uint32_t i);
 int ckm_ctx_device(const ckm_ctx *ctx);
+void ckm_ctx_parallel_for(ckm_ctx *ctx, size_t n, size_t chunk, const std::function<void(size_t, size_t)> &f);
 
 template <class F>
 static int guarded_r(F &&f) {
@@ -313,8 +315,12 @@ extern "C" int ckm_reduce(ckm_ctx *ctx, const ckm_hits *h, const ckm_hit_columns
     qa->kept_bin_off.assign(nbins + 1, 0);
     std::vector<int32_t> marker_count(nmark, 0);
     std::vector<uint8_t> marker_first(nmark, 0);
-    for (uint32_t b = 0; b < nbins; ++b) {
-      qa->kept_bin_off[b] = qa->kept_row.size();
+    // the ordered-container filters of one bin touch nothing of another bin: bins run on the context's host threads,
+    // each into its own list of kept hits, concatenated in bin order afterwards
+    struct Kept { std::vector<uint32_t> key; std::vector<RHit> hit; };
+    std::vector<Kept> kept(nbins);
+    ckm_ctx_parallel_for(ctx, nbins, 4, [&](size_t blo, size_t bhi) {
+    for (uint32_t b = (uint32_t)blo; b < (uint32_t)bhi; ++b) {
       // unique-marker flags of this bin (getMarkerGenes() is a set)
       {
         std::unordered_map<uint32_t, bool> seen;
@@ -350,14 +356,20 @@ extern "C" int ckm_reduce(ckm_ctx *ctx, const ckm_hits *h, const ckm_hit_columns
       }
       OrderedHits filt = clan_filter(mh, mi, key_is_pf);
       if (!fl->skip_adj_correction) for (uint32_t k : filt.keys) merge_adjacent(filt.lists[k]);
-      for (uint32_t k : filt.keys) for (const RHit &x : filt.lists[k]) {
-        qa->kept_key.push_back(k); qa->kept_row.push_back(x.row); qa->kept_row2.push_back(x.row2);
-        qa->kept_tlen.push_back(x.tlen); qa->kept_hmm_from.push_back(x.hmm_from); qa->kept_hmm_to.push_back(x.hmm_to);
-        qa->kept_ali_from.push_back(x.ali_from); qa->kept_ali_to.push_back(x.ali_to); qa->kept_env_from.push_back(x.env_from); qa->kept_env_to.push_back(x.env_to);
-      }
+      for (uint32_t k : filt.keys) for (const RHit &x : filt.lists[k]) { kept[b].key.push_back(k); kept[b].hit.push_back(x); }
       for (uint32_t i = ms->marker_off[ms->set_off[b]]; i < ms->marker_off[ms->set_off[b + 1]]; ++i) {
         auto it = filt.lists.find(ms->marker_key[i]);
         marker_count[i] = (it == filt.lists.end()) ? 0 : (int32_t)it->second.size();
+      }
+    }
+    });
+    for (uint32_t b = 0; b < nbins; ++b) {
+      qa->kept_bin_off[b] = qa->kept_row.size();
+      for (size_t j = 0; j < kept[b].hit.size(); ++j) {
+        const RHit &x = kept[b].hit[j];
+        qa->kept_key.push_back(kept[b].key[j]); qa->kept_row.push_back(x.row); qa->kept_row2.push_back(x.row2);
+        qa->kept_tlen.push_back(x.tlen); qa->kept_hmm_from.push_back(x.hmm_from); qa->kept_hmm_to.push_back(x.hmm_to);
+        qa->kept_ali_from.push_back(x.ali_from); qa->kept_ali_to.push_back(x.ali_to); qa->kept_env_from.push_back(x.env_from); qa->kept_env_to.push_back(x.env_to);
       }
     }
     qa->kept_bin_off[nbins] = qa->kept_row.size();
