@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define CKM_ABI_VERSION 1
+#define CKM_ABI_VERSION 2
 
 enum {
   CKM_OK      =  0,
