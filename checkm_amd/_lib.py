@@ -89,11 +89,19 @@ class QAColumns(C.Structure):
                 ("kept_env_from", C.POINTER(C.c_int32)), ("kept_env_to", C.POINTER(C.c_int32))]
 
 
+class TableColumns(C.Structure):
+    _fields_ = [("cols", HitColumns), ("target_accession", C.POINTER(C.c_char_p)), ("query_name", C.POINTER(C.c_char_p)),
+                ("query_accession", C.POINTER(C.c_char_p)), ("description", C.POINTER(C.c_char_p)),
+                ("full_bias_d", C.POINTER(C.c_double)), ("dom_bias_d", C.POINTER(C.c_double)), ("acc_d", C.POINTER(C.c_double)),
+                ("bin_missing", C.POINTER(C.c_uint8))]
+
+
 # every symbol include/checkm_hip.h declares
 EXPORTS = ["ckm_last_error", "ckm_abi_version", "ckm_device_count", "ckm_ctx_create", "ckm_ctx_destroy",
            "ckm_profiles_load", "ckm_profiles_count", "ckm_profiles_header", "ckm_profiles_free",
            "ckm_seqs_pack", "ckm_seqs_from_fasta", "ckm_seqs_count", "ckm_seqs_bin_offsets", "ckm_seqs_name", "ckm_seqs_residues", "ckm_seqs_free", "ckm_search", "ckm_hits_columns", "ckm_hits_free",
            "ckm_hits_write_domtblout", "ckm_last_search_stats", "ckm_reduce", "ckm_qa_columns_get", "ckm_qa_free", "ckm_count_sets",
+           "ckm_tables_read", "ckm_tables_assign_models", "ckm_tables_get", "ckm_tables_free",
            "ckm_debug_stages", "ckm_debug_envelopes", "ckm_debug_region"]
 
 _lib = None
@@ -140,6 +148,11 @@ def load():
     L.ckm_qa_free.argtypes = [C.c_void_p]
     L.ckm_qa_free.restype = None
     L.ckm_count_sets.argtypes = [C.c_void_p, C.POINTER(MarkerSetsCSR)] + [C.c_void_p] * 7
+    L.ckm_tables_read.argtypes = [C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_void_p)]
+    L.ckm_tables_assign_models.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_uint64)]
+    L.ckm_tables_get.argtypes = [C.c_void_p, C.POINTER(TableColumns)]
+    L.ckm_tables_free.argtypes = [C.c_void_p]
+    L.ckm_tables_free.restype = None
     L.ckm_debug_stages.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.ckm_debug_envelopes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_uint32, C.c_void_p]
@@ -300,6 +313,63 @@ class Hits(object):
     def close(self):
         if self.h:
             load().ckm_hits_free(self.h)
+            self.h = None
+
+
+class Tables(object):
+    """domtblout text of many bins, parsed by the library (ckm_tables_read); column views + the ext form ckm_reduce takes."""
+
+    def __init__(self, paths):
+        arr = (C.c_char_p * max(1, len(paths)))(*[p.encode() for p in paths])
+        h = C.c_void_p()
+        _chk(load().ckm_tables_read(arr, len(paths), C.byref(h)))
+        self.h = h
+        self._refresh()
+
+    def _refresh(self):
+        tc = TableColumns()
+        _chk(load().ckm_tables_get(self.h, C.byref(tc)))
+        self.tc = tc
+        cols = tc.cols
+        self.n = int(cols.n)
+        self.nbins = int(cols.nbins)
+        self.bin_row_off = np.ctypeslib.as_array(cols.bin_row_off, shape=(self.nbins + 1,)).copy()
+        self.missing = np.ctypeslib.as_array(tc.bin_missing, shape=(max(1, self.nbins),)).copy()[:self.nbins].astype(bool)
+
+    def assign_models(self, keys):
+        """keys: markerHits key of every model slot; returns the number of rows whose accession is not among them."""
+        arr = (C.c_char_p * max(1, len(keys)))(*[k.encode() for k in keys])
+        miss = C.c_uint64()
+        _chk(load().ckm_tables_assign_models(self.h, arr, len(keys), C.byref(miss)))
+        self._refresh()
+        return int(miss.value)
+
+    def column(self, name):
+        ptr = getattr(self.tc, name) if name in ("full_bias_d", "dom_bias_d", "acc_d") else getattr(self.tc.cols, name)
+        return np.ctypeslib.as_array(ptr, shape=(self.n,)) if self.n else np.zeros(0)
+
+    def hit(self, r):
+        """Row r as the reference's HmmerHitDOM would hold it (checkm/hmmer.py:255-285): Python ints, floats and strings."""
+        c, t = self.tc.cols, self.tc
+        return dict(target_name=c.target_name[r].decode(), target_accession=t.target_accession[r].decode(), target_length=int(c.tlen[r]),
+                    query_name=t.query_name[r].decode(), query_accession=t.query_accession[r].decode(), query_length=int(c.qlen[r]),
+                    full_e_value=float(c.full_evalue[r]), full_score=float(c.full_score_d[r]), full_bias=float(t.full_bias_d[r]),
+                    dom=int(c.dom_idx[r]), ndom=int(c.ndom[r]), c_evalue=float(c.c_evalue[r]), i_evalue=float(c.i_evalue[r]),
+                    dom_score=float(c.dom_score_d[r]), dom_bias=float(t.dom_bias_d[r]), hmm_from=int(c.hmm_from[r]), hmm_to=int(c.hmm_to[r]),
+                    ali_from=int(c.ali_from[r]), ali_to=int(c.ali_to[r]), env_from=int(c.env_from[r]), env_to=int(c.env_to[r]),
+                    acc=float(t.acc_d[r]), target_description=t.description[r].decode())
+
+    def text(self, name, r):
+        v = getattr(self.tc, name)[r] if name != "target_name" else self.tc.cols.target_name[r]
+        return v.decode()
+
+    def ext(self):
+        """(HitColumns, keepalive) for QAPlan.reduce(ext=...)."""
+        return self.tc.cols, [self]
+
+    def close(self):
+        if self.h:
+            load().ckm_tables_free(self.h)
             self.h = None
 
 

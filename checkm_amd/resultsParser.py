@@ -22,13 +22,28 @@ from checkm_amd.markerSets import count_sets
 from checkm_amd.pfam import PFAM
 
 
+_PFAM_CACHE = {}
+
+
+def _pfam_tables():
+    """Clan and nesting maps of Pfam-A.hmm.dat, parsed once per file state (the reference re-reads the file for every bin,
+    checkm/resultsParser.py:208 -> util/pfam.py:34-56)."""
+    path = DefaultValues.PFAM_CLAN_FILE
+    if not os.path.exists(path):
+        return {}, {}
+    st = os.stat(path)
+    key = (os.path.abspath(path), st.st_mtime_ns, st.st_size)
+    if key not in _PFAM_CACHE:
+        _PFAM_CACHE.clear()
+        pf = PFAM(path)
+        pf.readClansAndNesting()
+        _PFAM_CACHE[key] = (pf.clan, pf.nested)
+    return _PFAM_CACHE[key]
+
+
 def _plan_for_models(models_list):
     """models_list: list of HmmModel (one per model slot).  Builds the ckm_model_info part of a QAPlan."""
-    pf = PFAM(DefaultValues.PFAM_CLAN_FILE)
-    clans, nested = {}, {}
-    if os.path.exists(DefaultValues.PFAM_CLAN_FILE):
-        pf.readClansAndNesting()
-        clans, nested = pf.clan, pf.nested
+    clans, nested = _pfam_tables()
     keys = cqa.KeyTable()
     acc = [m.acc for m in models_list]
     qlen = [m.leng for m in models_list]
@@ -308,18 +323,37 @@ class ResultsParser(object):
                 self.results[b] = rm
             res.close()
 
-    # tables written by an earlier command: parse the text, same library entry in column form
+    # tables written by an earlier command: the library parses the text of all bins at once (ckm_tables_read) and reduces bins
+    # that share their model view in one call; rows become HmmerHitDOM objects only for the hits that are kept
     def _reduce_text(self, outDir, hmmTableFile, binIds, mk, skip_adj, ignore, evalue, length, skip_pseudo):
-        for b in binIds:
-            rm = mk(b)
-            path = os.path.join(outDir, 'bins', b, hmmTableFile)
-            try:
-                for h in read_domtblout(path):
-                    rm.addHit(h)
-                rm._reduce_raw(skip_adj)
-            except IOError as detail:
-                sys.stderr.write(str(detail) + "\n")
-            self.results[b] = rm
+        from checkm_amd import _lib
+        paths = [os.path.join(outDir, 'bins', b, hmmTableFile) for b in binIds]
+        tables = _lib.Tables(paths)
+        try:
+            for i, b in enumerate(binIds):
+                if tables.missing[i]:
+                    sys.stderr.write("[Errno 2] No such file or directory: '%s'\n" % paths[i])
+            groups = {}
+            for i, b in enumerate(binIds):
+                sig = tuple((a, m.acc, m.leng, m.ga, m.tc, m.nc) for a, m in self.models[b].items())
+                groups.setdefault(sig, []).append(i)
+            nb = len(binIds)
+            for sig, members in groups.items():
+                first = self.models[binIds[members[0]]]
+                accs = list(first.keys())
+                keys, acc, qlen, thr, clans, nested = _plan_for_models([first[a] for a in accs])
+                plan = cqa.QAPlan(keys, acc, qlen, thr, [[] for _ in range(nb)], clans, nested)
+                tables.assign_models(accs)            # a row whose accession is not a model of the bin is an error, as the reference's KeyError is
+                sel = np.zeros(nb, dtype=np.uint8)
+                sel[members] = 1
+                res = plan.reduce(runtime.get_ctx(), None, None, ignore, evalue, length, skip_pseudo, skip_adj, False, sel, tables.ext())
+                for i in members:
+                    rm = mk(binIds[i])
+                    rm.markerHits = _marker_hits_from(res, i, keys, lambda r: HmmerHitDOM.from_fields(**tables.hit(r)))
+                    self.results[binIds[i]] = rm
+                res.close()
+        finally:
+            tables.close()
 
     def parseHmmerResults(self, fileName, resultsManager, bSkipAdjCorrection):
         try:

@@ -205,6 +205,25 @@ void ckm_qa_free(ckm_qa *q);
 int  ckm_count_sets(ckm_ctx *ctx, const ckm_marker_sets *ms, const int32_t *marker_count, const uint8_t *marker_first,
                     int32_t *set_present, int32_t *set_multi, int32_t *hist, int32_t *present_total, int32_t *multi_total);
 
+/* ---- tables written by an earlier command -----------------------------------------------------
+ * Replaces HMMERParser.readHitsDOM / HmmerHitDOM (checkm/hmmer.py:184-200, 255-285) and the serial per-bin loop around them
+ * (checkm/resultsParser.py:94, 191-204): the domtblout text of all bins is parsed once, on a few threads, into the column form
+ * ckm_reduce takes as `ext`.  No device is needed.  A path that cannot be opened gives an empty bin with bin_missing = 1
+ * (the reference prints the IOError and goes on, resultsParser.py:200-204); a malformed row is CKM_EFORMAT. */
+typedef struct ckm_tables ckm_tables;
+typedef struct {
+  ckm_hit_columns    cols;               /* numeric columns, target_name, full_score_d/dom_score_d; seq = row index;
+                                            model = slot set by ckm_tables_assign_models (UINT32_MAX = not in the list) */
+  const char *const *target_accession, *const *query_name, *const *query_accession /* '-' replaced by the name */, *const *description;
+  const double      *full_bias_d, *dom_bias_d, *acc_d;      /* the remaining text floats as float64 (Python floats in HmmerHitDOM) */
+  const uint8_t     *bin_missing;        /* [nbins] */
+} ckm_table_columns;
+int  ckm_tables_read(const char *const *paths, uint32_t nbins, ckm_tables **out);
+/* model slot of every row = index of its query accession in keys[] (the markerHits keys of the caller's ckm_model_info) */
+int  ckm_tables_assign_models(ckm_tables *t, const char *const *keys, uint32_t nkeys, uint64_t *unknown_rows);
+int  ckm_tables_get(const ckm_tables *t, ckm_table_columns *out);
+void ckm_tables_free(ckm_tables *t);
+
 /* ---- diagnostics used by the parity tests: every stage of one (model, sequence) pair, no filtering */
 typedef struct {
   int32_t msv_xJ;  float msv_sc, null_sc, bias_sc;
