@@ -348,3 +348,46 @@ def test_search_multidomain_rows_identical(tandem):
     assert st.regions_multi >= len(w["recs"]) // 2, st.regions_multi
     assert max(hits.ndom[g] for g in hits.rows(0)) >= 2
     hits.close()
+
+
+def test_register_class_boundaries(gpu_ctx):
+    """Model lengths on both sides of every register-class edge (SSV: 32 cells per register, Viterbi: 128 per packed register,
+    Forward: 64 per slot) plus very short models, against planted, tandem, random and degenerate-symbol targets: every stage
+    of every pair and the assembled rows."""
+    rng = np.random.default_rng(31)
+    lengths = [5, 9, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 191, 192, 193, 255, 256, 257, 383, 384, 385, 511, 512, 513, 640, 641]
+    profs = []
+    for i, M in enumerate(lengths):
+        p = synth.random_profile(rng, M, "EDGE%03d" % M, "PF%05d.1" % (90000 + i))
+        p.stats = (-8.5 - 0.002 * M, 0.71, -9.5 - 0.002 * M, 0.71, -3.8, 0.71)
+        profs.append(p)
+    path = common.hmm_file("edges", profs)
+    recs = []
+    for i, p in enumerate(profs):
+        dom = synth.sample_domain(rng, p)
+        recs.append(("e%d_1" % i, "", synth.to_text(np.concatenate([synth.random_residues(rng, 7), dom, synth.random_residues(rng, 11)])) + "*"))
+        if p.M >= 31:
+            a = int(rng.integers(p.M // 2, p.M)); b = int(rng.integers(1, p.M // 2))
+            recs.append(("e%d_2" % i, "", synth.to_text(np.concatenate([synth.sample_domain(rng, p, 1, a), synth.sample_domain(rng, p, b, p.M)]))))
+    recs += [("r_%d" % k, "", synth.to_text(synth.random_residues(rng, int(L)))) for k, L in enumerate([1, 2, 15, 16, 17, 63, 64, 65, 300, 1023, 1024, 1025])]
+    recs += [("d_1", "", "BJZOUX" * 20), ("d_2", "", "acdefghiklmnpqrstvwy" * 9 + "*")]
+    prof = _lib.Profiles(gpu_ctx, path)
+    seqs = _lib.Seqs(gpu_ctx, [recs])
+    hs = p7.HmmSet(path)
+    dsq = [p7.digitize(r[2]) for r in recs]
+    pairs = [(m, s) for m in range(hs.n) for s in range(len(recs))]
+    got = _lib.debug_stages(gpu_ctx, prof, seqs, np.array([p[0] for p in pairs]), np.array([p[1] for p in pairs]))
+    bad = []
+    for i, (m, s) in enumerate(pairs):
+        o = hs.stages(m, dsq[s])
+        for f in STAGE_FIELDS:
+            if not _cmp_stage(o, got[i], f):
+                bad.append((lengths[m], recs[s][0], f, getattr(o, f), getattr(got[i], f)))
+        if got[i].msvp_xJ != o.msv_xJ or common.float_bits(got[i].msvp_sc) != common.float_bits(o.msv_sc):
+            bad.append((lengths[m], recs[s][0], "msv packed", o.msv_xJ, got[i].msvp_xJ))
+    assert not bad, bad[:10]
+    w = dict(bins=[recs], dsq=dsq, hs=hs)
+    hits = _lib.search(gpu_ctx, prof, seqs)
+    _compare_search(w, hits, None)
+    assert len(set(int(hits.model[g]) for g in hits.rows(0))) >= len(lengths) - 2       # (nearly) every model finds its planted target
+    hits.close(); prof.close(); seqs.close(); hs.close()
