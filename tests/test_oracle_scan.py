@@ -80,3 +80,19 @@ def test_domtblout_text_round_trips_through_the_reduce_oracle(hs):
         assert (q["hmm_from"], q["hmm_to"], q["ali_from"], q["ali_to"], q["env_from"], q["env_to"]) == (r.hmm_from, r.hmm_to, r.ali_from, r.ali_to, r.env_from, r.env_to)
         assert q["full_score"] == float("%.1f" % r.full_score) and q["full_e_value"] == float("%.2g" % r.full_evalue)
         assert q["target_description"] == recs[r.seq_idx][1]
+
+
+def test_oracle_output_is_pinned_against_its_own_record():
+    """Regression pin (NOT a reference vector, see tools/gen_oracle_selfcheck.py): the HIP path is tested against the oracle and
+    would follow an accidental change of the restatement silently; this catches it on the CPU."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import gen_oracle_selfcheck as g
+    want = json.load(open(os.path.join(root, "tests", "golden", "oracle_selfcheck.json")))
+    got = json.loads(json.dumps(g.build()))
+    for k in want:
+        assert got[k] == want[k], k
+    assert got["ensemble"]["rc"] == 0 and len(got["ensemble"]["env"]) >= 2 and got["nrows"] >= 8
