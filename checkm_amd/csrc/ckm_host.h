@@ -1,0 +1,301 @@
+// ckm_host.h -- what the host-side translation units of libcheckm_hip.so share (not part of the ABI): device and pinned buffers,
+// the host thread pool, workers and the context, the opaque handle types, and the stage drivers.
+//   ckm_api.hip     context, profiles, sequences, hit columns, domtblout writer
+//   ckm_stages.hip  drivers of the rare stages: Forward/Backward/OA batches, envelope rescoring, exact MSV, trace ensembles
+//   ckm_search.hip  the filter cascade of one worker and ckm_search
+//   ckm_debug.hip   diagnostics entries used by the parity tests
+#pragma once
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstring>
+#include <exception>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <numeric>
+#include <thread>
+#include "ckm_internal.h"
+#include "dev_types.h"
+
+namespace ckm {
+
+// ---- kernel launchers (kernels_*.hip) ------------------------------------------------------------
+
+// ---- kernel launchers (kernels_*.hip) ------------------------------------------------------------
+int launch_ssv(int Q, int nblocks, int threads, hipStream_t stream, const SsvBlockWork *work, const DevModel *models,
+               const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const uint32_t *lists, uint16_t *maxv);
+void launch_msv_finish(hipStream_t stream, const FinishArgs &a, uint32_t nblocks);
+int launch_msv(int Q, int nblocks, hipStream_t stream, const SsvBlockWork *work, const DevModel *models, const LenEntry *lentab,
+               const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const uint32_t *lists, int32_t *out_xJ, float *out_usc);
+void launch_msv_full(hipStream_t stream, const PairRec *pairs, uint32_t npairs, const DevModel *models, const LenEntry *lentab,
+                     const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xJ, float *out_usc, int maxMp);
+void launch_bias(hipStream_t stream, PairRec *pairs, uint32_t npairs, const DevModel *models, const LenEntry *lentab,
+                 const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, float *raw);
+int launch_vit(int Q, hipStream_t stream, const PairRec *pairs, const uint32_t *idx, uint32_t n, const DevModel *models,
+               const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xC, float *out_sc, uint32_t *out_flag, bool fast);
+int launch_fwd(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const uint32_t *blk_model, const DevModel *models,
+               const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, FwdOut *out,
+               ScaleEvent *events, uint32_t *nevents, uint32_t cap_events);
+int launch_bwd(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const uint32_t *blk_model, const DevModel *models,
+               const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, const FwdOut *fout, int32_t *range_err);
+int launch_oa(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const uint32_t *blk_model, const DevModel *models,
+              float *ws, const int32_t *range_err, EnvOut *out);
+
+void launch_ensemble(hipStream_t stream, const EnsWork *work, uint32_t nregions, int max_Ld, int max_Mp, const DevModel *models,
+                     const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, const uint32_t *seeds);
+#define HIPCHK(expr)                                                                                         \
+  do {                                                                                                       \
+    hipError_t e_ = (expr);                                                                                  \
+    if (e_ != hipSuccess) throw Error(CKM_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+  } while (0)
+
+struct DevBuf {
+  void *p = nullptr; size_t cap = 0;
+  void ensure(size_t bytes) {
+    if (bytes <= cap) return;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; throw Error(CKM_ENOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed: " + hipGetErrorString(e)); }
+    cap = want;
+  }
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+struct PinnedBuf {      // grow-only page-locked host staging buffer (pageable D2H copies run at a fraction of PCIe speed)
+  void *p = nullptr; size_t cap = 0;
+  void ensure(size_t bytes) {
+    if (bytes <= cap) return;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; throw Error(CKM_ENOMEM, "hipHostMalloc failed"); }
+    cap = want;
+  }
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+};
+
+
+// A few host threads for the per-pair / per-sequence glue between the kernel stages (logs of rescale factors, region
+// scans over the decoding terms, segment clustering, bit scores): the device idles while that glue runs.
+class HostPool {
+ public:
+  explicit HostPool(int nthreads) {
+    for (int i = 1; i < nthreads; ++i) th_.emplace_back([this] { loop(); });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+    cv_.notify_all();
+    for (auto &t : th_) t.join();
+  }
+  // f(lo, hi) over [0, n) in chunks; the caller works too; returns when every chunk is done and no thread is still inside
+  void run(size_t n, size_t chunk, const std::function<void(size_t, size_t)> &f) {
+    if (!n) return;
+    if (th_.empty() || n <= chunk) { f(0, n); return; }
+    {
+      std::lock_guard<std::mutex> g(m_);
+      job_ = &f; n_ = n; chunk_ = chunk; next_.store(0); err_ = nullptr; open_ = true; ++active_;
+    }
+    cv_.notify_all();
+    work(f, n, chunk);
+    std::unique_lock<std::mutex> g(m_);
+    open_ = false;                                    // late wakers must not join a job whose chunks are all handed out
+    --active_;
+    done_.wait(g, [this] { return active_ == 0; });   // every helper has left work(): the fields may change again
+    job_ = nullptr;
+    if (err_) std::rethrow_exception(err_);
+  }
+ private:
+  // the job's description travels by value: a helper never reads fields the next run() may be rewriting
+  void work(const std::function<void(size_t, size_t)> &f, size_t n, size_t chunk) {
+    for (;;) {
+      const size_t lo = next_.fetch_add(chunk);
+      if (lo >= n) return;
+      try { f(lo, std::min(n, lo + chunk)); } catch (...) { std::lock_guard<std::mutex> g(m_); if (!err_) err_ = std::current_exception(); }
+    }
+  }
+  void loop() {
+    for (;;) {
+      const std::function<void(size_t, size_t)> *f; size_t n, chunk;
+      {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return stop_ || (open_ && job_ && next_.load() < n_); });
+        if (stop_) return;
+        f = job_; n = n_; chunk = chunk_; ++active_;
+      }
+      work(*f, n, chunk);
+      std::lock_guard<std::mutex> g(m_);
+      if (--active_ == 0) done_.notify_all();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_; std::condition_variable cv_, done_;
+  const std::function<void(size_t, size_t)> *job_ = nullptr;
+  size_t n_ = 0, chunk_ = 1; std::atomic<size_t> next_{0};
+  int active_ = 0; bool open_ = false, stop_ = false; std::exception_ptr err_;
+};
+
+}  // namespace ckm
+
+using namespace ckm;      // internal header: every includer is one of the four files above
+
+extern std::atomic<uint64_t> g_uid;        // identity of every profile DB / sequence set ever created (pointers get reused)
+
+// One worker = one host thread's view of the device: its own streams, events and scratch buffers.
+// ckm_search splits the models of a call over the workers so that the latency-bound rare stages and the
+// host glue of one chunk overlap the VALU-bound SSV / Viterbi kernels of the other.
+struct Worker {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t ens_stream = nullptr;       // trace ensembles run beside the envelope stage
+  hipStream_t side[8];                    // per-register-class launches of the rare stages overlap on these
+  hipEvent_t ev[8];
+  ckm_search_stats stats;
+  // reusable device scratch
+  std::vector<uint64_t> plan_key;         // identifies the SSV block tables currently resident in `work` / `idx`
+  std::vector<std::pair<int, std::pair<size_t, size_t>>> plan_groups;
+  uint64_t plan_npairs = 0, plan_nblocks = 0, plan_residue_hmm = 0, plan_cells = 0, plan_pairs = 0;
+  PinnedBuf h_a, h_b, h_ens;              // D2H staging
+  DevBuf work, maxv, surv, nores, counters, cand, raw, idx, vitx, vits, vitf, fbwork, fbidx, fbmodel, ws, fout, events, rerr, envout, fullx, fullu, msvwork, msvlist, enswork, ensseeds, ws_ens;
+  size_t ws_budget = (size_t)8 << 30;     // float workspace budget (bytes) for Forward/Backward matrices
+  std::unique_ptr<HostPool> pool;         // host threads of this worker
+};
+
+constexpr int NWORKERS = 4;          // upper bound; CKM_WORKERS (default 3) selects how many a large search uses
+
+struct ckm_ctx {
+  int device = 0;
+  int nworkers = 3;
+  DevBuf reduce_scratch;                  // grow-only device buffer of the reduce kernels
+  Worker w[NWORKERS];
+  ckm_search_stats stats;
+  std::mutex ssv_mutex;                   // SSV phases are VALU-bound: two of them side by side gain nothing
+  std::condition_variable ssv_cv; int ssv_turn = 0;    // workers take their first SSV phase in worker order (largest chunk first)
+};
+
+struct ckm_profiles {
+  ckm_ctx *ctx = nullptr;
+  uint64_t uid = g_uid++;
+  std::vector<HostHMM> hmm;
+  std::vector<HostProfile> prof;
+  std::vector<DevModel> dm;
+  DevBuf d_models;
+  std::vector<std::unique_ptr<DevBuf>> tables;
+  int maxMp = 0;
+};
+
+
+struct ckm_seqs {
+  ckm_ctx *ctx = nullptr;
+  uint64_t uid = 0;
+  uint32_t nseq = 0, nbins = 0;
+  std::vector<uint32_t> bin_off, seq_bin;
+  std::vector<int32_t> len;
+  std::vector<uint64_t> off;          // offsets into the padded digital buffer
+  std::vector<uint8_t> dsq;           // host copy (null2 needs the residues)
+  std::vector<std::string> names, descs;
+  std::vector<LenEntry> lentab;
+  DevBuf d_res, d_off, d_len, d_lentab;
+  uint64_t total_res = 0;
+  int maxL = 0;
+  // ONE order of all non-empty sequences: grouped by bin, longest first inside a bin.  SSV blocks index ranges of it,
+  // so per-bin model subsets (lineage_wf) need no per-model lists.
+  std::vector<uint32_t> order, order_off;      // order_off[b] .. order_off[b+1]
+  std::vector<uint64_t> bin_res;               // residues of bin b
+  DevBuf d_order;
+};
+
+struct ckm_hits {
+  std::vector<uint64_t> bin_row_off;
+  std::vector<uint32_t> seq, model;
+  std::vector<int32_t> tlen, qlen, dom_idx, ndom, hmm_from, hmm_to, ali_from, ali_to, env_from, env_to;
+  std::vector<double> full_evalue, c_evalue, i_evalue;
+  std::vector<float> full_score, full_bias, dom_score, dom_bias, acc;
+  uint32_t nbins = 0;
+};
+
+template <class F>
+static inline int guarded(F &&f) {
+  try { f(); return CKM_OK; }
+  catch (const Error &e) { set_last_error(e.what()); return e.code; }
+  catch (const std::bad_alloc &) { set_last_error("out of host memory"); return CKM_ENOMEM; }
+  catch (const std::exception &e) { set_last_error(e.what()); return CKM_EINVAL; }
+}
+
+namespace ckm {
+
+constexpr double kLn2 = 0.69314718055994529;
+constexpr double kLog2R = 1.44269504088896341;
+constexpr float kOmega = 1.0f / 256.0f;
+constexpr float RT1 = 0.25f, RT2 = 0.10f, RT3 = 0.20f;
+
+struct Domain {
+  int ienv, jenv; float envsc, oasc, domcorrection; int hmm_from, hmm_to, ali_from, ali_to;
+  float dombias, bitscore; double lnP; bool reported;
+};
+struct Hit {
+  uint32_t model, seq; int L; float pre_score, score; double lnP; std::vector<Domain> dom; int nreported;
+};
+struct Cand {            // a pair that survived the MSV stage
+  PairRec r; float fwdsc; float fwd_xC; uint32_t slot; bool alive;
+};
+
+struct EventIndex {      // rescale events grouped by slot, rows ascending
+  std::vector<std::vector<std::pair<int, float>>> by_slot;
+  void build(const std::vector<ScaleEvent> &ev, size_t nslots) {
+    by_slot.assign(nslots, {});
+    for (const auto &e : ev) if (e.slot < nslots) by_slot[e.slot].push_back({e.row, e.scale});
+    for (auto &v : by_slot) std::sort(v.begin(), v.end());
+  }
+  std::vector<float> scales(uint32_t slot) const { std::vector<float> r; for (auto &p : by_slot[slot]) r.push_back(p.second); return r; }
+};
+
+// Runs fwd/bwd(/oa) for a list of work items, grouped by the model's canonical Q.
+struct FbBatch {
+  std::vector<FbWork> work;
+  std::vector<FwdOut> fout;
+  std::vector<ScaleEvent> events;
+  std::vector<int32_t> rerr;
+  std::vector<EnvOut> envout;
+};
+
+struct EnvReq { uint32_t model, seq; int ienv, jenv; };
+
+struct EnvRes { bool ok; float envsc, oasc, xC; int nscale; float null2[KP]; int hmm_from, hmm_to, ali_from, ali_to; };
+
+struct Seg { int32_t sqfrom, sqto, hmmfrom, hmmto; };
+
+struct RegionReq { uint32_t model, seq; int ireg, jreg; };
+
+struct RegionRes {
+  std::vector<float> n2sum;        // per region position: sum over traces of the null2 odds ratio
+  std::vector<Seg> segs;           // [200][cap], first domain first
+  std::vector<int32_t> nseg;       // [200]
+  int cap = 0;
+  std::vector<Seg> env;            // clustered envelopes, region-local coordinates, sorted by start
+};
+
+// ---- stage drivers (ckm_stages.hip) ----------------------------------------------------------------------------------
+void pool_run(Worker *w, size_t n, size_t chunk, const std::function<void(size_t, size_t)> &f);
+void wcopy(Worker *w, void *dst, const void *src, size_t bytes, hipMemcpyKind kind);     // blocking copy on the worker's own stream
+double now_ms();
+float bits(float sc, float nullsc);
+float finish_forward(float xC, float move, const std::vector<float> &scales);
+int ssv_threads_for(int Q);
+void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, bool do_fwd, bool do_bwd, bool do_oa,
+            const std::vector<uint32_t> *subset /* indices into b.work, or null = all */, float *ws_other = nullptr);
+void rescore_envelopes(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<EnvReq> &req, std::vector<EnvRes> &out);
+void run_msv_exact(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<PairRec> &pairs, std::vector<float> &usc, std::vector<int32_t> *xJ);
+void run_ensembles(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<RegionReq> &req, std::vector<RegionRes> &out);
+void fill_null2(float *null2);
+
+}  // namespace ckm

@@ -1,0 +1,587 @@
+// ckm_search.hip -- the filter cascade of one worker (SSV -> MSV -> bias -> Viterbi -> Forward -> Backward -> domain definition ->
+// envelope rescoring -> scores) and ckm_search, which spreads a search over the workers and assembles the rows.
+// Replaces the per-target pipeline of the hmmsearch process CheckM launches per bin (checkm/hmmer.py:70).
+#include "ckm_host.h"
+
+namespace {
+
+const bool g_trace = getenv("CKM_TRACE") != nullptr;     // per-worker stage timestamps on stderr
+double g_trace_t0 = 0;
+#define CKM_TRACE_PT(label) do { if (g_trace) fprintf(stderr, "ckm-trace w%d %8.3f %s\n", my_turn, now_ms() - g_trace_t0, label); } while (0)
+
+}  // namespace
+
+struct SearchPlan {        // which models run against which sequence lists
+  std::vector<std::vector<uint32_t>> model_bins;   // per model: bins (sorted)
+};
+
+typedef std::map<std::pair<uint32_t, uint32_t>, std::vector<Hit>> HitMap;     // (bin, model) -> hits
+
+// The whole filter cascade + domain stage for a subset of the models, on one worker.
+struct SeqRange { std::vector<uint32_t> lo, hi; std::vector<uint64_t> res; uint64_t tag = 0; };   // per bin: [lo, hi) of s->order, residues in it
+
+static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles *p, const ckm_seqs *s, const SeqRange &rng, const std::vector<uint32_t> &my_models,
+                    const std::vector<std::vector<uint32_t>> &model_bins, HitMap &by_bin_model) {
+  HIPCHK(hipSetDevice(ctx->device));
+  const double t_start = now_ms();
+  ckm_search_stats &st = ctx->stats;
+  memset(&st, 0, sizeof(st));
+  const DevModel *dm = p->d_models.as<DevModel>();
+  const LenEntry *lt = s->d_lentab.as<LenEntry>();
+  const uint8_t *res = s->d_res.as<uint8_t>();
+  const uint64_t *off = s->d_off.as<uint64_t>();
+  const int32_t *dlen = s->d_len.as<int32_t>();
+
+  // ---- stage 1: SSV over every pair, chunked by a pair budget ----
+  std::vector<Cand> cands;
+  bool took_turn = false;
+  struct TurnGuard {      // a worker that never reaches an SSV phase (no pairs, or an error) still passes the turn on
+    ckm_ctx *o; int t; bool *took;
+    ~TurnGuard() { if (*took) return; std::unique_lock<std::mutex> l(o->ssv_mutex); o->ssv_cv.wait(l, [&] { return o->ssv_turn == t; }); o->ssv_turn++; o->ssv_cv.notify_all(); }
+  } turn_guard{owner, my_turn, &took_turn};
+  {
+    uint64_t pair_budget = (uint64_t)1 << 29;                  // pairs per SSV chunk (2 B of maxV each); CKM_PAIR_BUDGET overrides (tests)
+    if (const char *e = getenv("CKM_PAIR_BUDGET")) pair_budget = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+    size_t i0 = 0;
+    while (i0 < my_models.size()) {
+      // gather models of this chunk
+      struct MW { uint32_t model; uint64_t pair_base; uint64_t npairs; };
+      const bool i0_was_first = (i0 == 0);
+      std::vector<MW> mws; uint64_t npairs = 0; size_t i1 = i0;
+      for (; i1 < my_models.size(); ++i1) {
+        const uint32_t m1 = my_models[i1];
+        uint64_t n = 0;
+        for (uint32_t b : model_bins[m1]) n += rng.hi[b] - rng.lo[b];
+        if (n == 0) continue;
+        if (npairs + n > pair_budget && !mws.empty()) break;
+        mws.push_back({m1, npairs, n}); npairs += n;
+      }
+      i0 = i1;
+      if (mws.empty() || npairs == 0) continue;
+      std::unique_lock<std::mutex> ssv_lock(owner->ssv_mutex);     // one SSV phase at a time (VALU-bound); released after the finish kernel
+      if (!took_turn) owner->ssv_cv.wait(ssv_lock, [&] { return owner->ssv_turn == my_turn; });
+      CKM_TRACE_PT("ssv turn taken");
+      // The block table depends only on (profiles, sequences, models and their bins): reuse the resident one when the
+      // previous call on this worker had the same plan (lineage_wf scans the same bins twice; bench repeats steps).
+      std::vector<uint64_t> key{p->uid, s->uid, pair_budget, (uint64_t)i0, rng.tag};
+      for (auto &mw : mws) { key.push_back(0xffffffffull + mw.model); for (uint32_t b : model_bins[mw.model]) key.push_back(b); }
+      std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;
+      size_t nblocks_total = 0;
+      const bool single_chunk = (i1 == my_models.size() && i0_was_first);
+      if (single_chunk && key == ctx->plan_key) {
+        groups = ctx->plan_groups; nblocks_total = ctx->plan_nblocks;
+        st.pairs_ssv += ctx->plan_pairs; st.residue_hmm += ctx->plan_residue_hmm; st.cells_ssv += ctx->plan_cells;
+      } else {
+        std::map<int, std::vector<SsvBlockWork>> byQ;
+        uint64_t c_pairs = 0, c_res = 0, c_cells = 0;
+        for (auto &mw : mws) {
+          const int Q = p->prof[mw.model].ssvQ; const int threads = ssv_threads_for(Q); const uint32_t per_block = (uint32_t)threads / 64 * 4 * 4;
+          uint64_t pb = mw.pair_base;
+          for (uint32_t b : model_bins[mw.model]) {
+            const uint32_t o0 = rng.lo[b], n = rng.hi[b] - o0;
+            for (uint32_t a = 0; a < n; a += per_block) {
+              SsvBlockWork w; w.model = mw.model; w.list_start = o0 + a; w.count = std::min(per_block, n - a); w.pair_start = (uint32_t)(pb + a);
+              byQ[Q].push_back(w);
+            }
+            pb += n; c_res += rng.res[b]; c_cells += rng.res[b] * (uint64_t)p->prof[mw.model].M;
+          }
+          c_pairs += mw.npairs;
+        }
+        st.pairs_ssv += c_pairs; st.residue_hmm += c_res; st.cells_ssv += c_cells;
+        std::vector<SsvBlockWork> allw;
+        for (auto &kv : byQ) {
+          // longest blocks first inside a launch (a block's time is set by its first = longest sequence): without this
+          // the few very long sequences of each bin start late and leave most CUs idle at the end of every launch
+          std::stable_sort(kv.second.begin(), kv.second.end(), [&](const SsvBlockWork &x, const SsvBlockWork &y) {
+            return s->len[s->order[x.list_start]] > s->len[s->order[y.list_start]]; });
+          groups.push_back({kv.first, {allw.size(), kv.second.size()}}); allw.insert(allw.end(), kv.second.begin(), kv.second.end());
+        }
+        nblocks_total = allw.size();
+        ctx->work.ensure(allw.size() * sizeof(SsvBlockWork));
+        HIPCHK(hipMemcpyAsync(ctx->work.p, allw.data(), allw.size() * sizeof(SsvBlockWork), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));            // allw goes out of scope
+        if (single_chunk) { ctx->plan_key = key; ctx->plan_groups = groups; ctx->plan_nblocks = nblocks_total; ctx->plan_pairs = c_pairs; ctx->plan_residue_hmm = c_res; ctx->plan_cells = c_cells; }
+        else ctx->plan_key.clear();
+      }
+      ctx->maxv.ensure(npairs * 2 + 64);
+      uint32_t cap_surv = (uint32_t)std::max<uint64_t>(1 << 16, npairs / 8), cap_nores = (uint32_t)std::max<uint64_t>(1 << 14, npairs / 64);
+      for (int attempt = 0;; ++attempt) {
+        ctx->surv.ensure((size_t)cap_surv * sizeof(PairRec)); ctx->nores.ensure((size_t)cap_nores * sizeof(PairRec)); ctx->counters.ensure(64);
+        HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+        HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+        if (attempt == 0) {
+          // register classes go round-robin over 4 streams (heaviest first) so the tail of one launch -- a few very long
+          // sequences -- is covered by the next launch; ev[0]..ev[1] on the main stream brackets all of them
+          constexpr int NS = 4;
+          for (int k = 0; k < NS; ++k) HIPCHK(hipStreamWaitEvent(ctx->side[k], ctx->ev[0], 0));
+          int gi = 0;
+          for (auto it = groups.rbegin(); it != groups.rend(); ++it, ++gi) {
+            auto &g = *it;
+            if (launch_ssv(g.first, (int)g.second.second, ssv_threads_for(g.first), ctx->side[gi % NS], ctx->work.as<SsvBlockWork>() + g.second.first, dm, res, off, dlen,
+                           s->d_order.as<uint32_t>(), ctx->maxv.as<uint16_t>()))
+              throw Error(CKM_ERANGE, "no SSV kernel instance for this model length");
+            st.ssv_launches++;
+          }
+          for (int k = 0; k < NS; ++k) { HIPCHK(hipEventRecord(ctx->ev[2 + k], ctx->side[k])); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev[2 + k], 0)); }
+        }
+        HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+        FinishArgs fa{dm, lt, dlen, s->d_order.as<uint32_t>(), ctx->work.as<SsvBlockWork>(), ctx->maxv.as<uint16_t>(),
+                      ctx->surv.as<PairRec>(), ctx->counters.as<uint32_t>(), cap_surv, ctx->nores.as<PairRec>(), ctx->counters.as<uint32_t>() + 1, cap_nores};
+        launch_msv_finish(ctx->stream, fa, (uint32_t)nblocks_total);
+        HIPCHK(hipGetLastError());
+        uint32_t cnt[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(cnt, ctx->counters.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (attempt == 0) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); st.ms_ssv += ms; }
+        CKM_TRACE_PT("ssv + msv_finish done");
+        if (cnt[0] > cap_surv || cnt[1] > cap_nores) { cap_surv = std::max(cap_surv, cnt[0]); cap_nores = std::max(cap_nores, cnt[1]); continue; }
+        std::vector<PairRec> nr(cnt[1]);
+        ctx->h_a.ensure((size_t)cnt[0] * sizeof(PairRec) + 16);
+        const PairRec *sv = ctx->h_a.as<PairRec>();
+        if (cnt[0]) wcopy(ctx, ctx->h_a.p, ctx->surv.p, (size_t)cnt[0] * sizeof(PairRec), hipMemcpyDeviceToHost);
+        if (cnt[1]) wcopy(ctx, nr.data(), ctx->nores.p, (size_t)cnt[1] * sizeof(PairRec), hipMemcpyDeviceToHost);
+        if (!took_turn) { took_turn = true; owner->ssv_turn++; owner->ssv_cv.notify_all(); }
+        ssv_lock.unlock();
+        cands.reserve(cands.size() + cnt[0]);
+        for (uint32_t k = 0; k < cnt[0]; ++k) { Cand c; c.r = sv[k]; c.alive = true; c.fwdsc = 0; c.fwd_xC = 0; c.slot = 0; cands.push_back(c); }
+        if (!nr.empty()) {     // exact multi-hit MSV for the pairs where J could be used
+          st.pairs_msv_full += nr.size();
+          std::vector<float> usc;
+          run_msv_exact(ctx, p, s, nr, usc, nullptr);
+          for (size_t i = 0; i < nr.size(); ++i) {
+            const float nullsc = s->lentab[s->len[nr[i].seq]].nullsc;
+            if (bits(usc[i], nullsc) >= p->prof[nr[i].model].thr_msv_f1) { Cand c; c.r = nr[i]; c.r.usc = usc[i]; c.alive = true; c.fwdsc = 0; c.fwd_xC = 0; c.slot = 0; cands.push_back(c); }
+          }
+        }
+        break;
+      }
+    }
+  }
+  // (the atomic append order of the survivors is arbitrary; every later stage is per pair, and the rows are
+  //  ordered at the end, so no sort is needed here)
+  const double t_filters0 = now_ms();
+
+  CKM_TRACE_PT("stage1 done (ssv, msv_finish, msv_full)");
+  // ---- stage 2: bias filter ----
+  std::vector<PairRec> cr(cands.size());
+  for (size_t i = 0; i < cands.size(); ++i) cr[i] = cands[i].r;
+  st.pairs_bias = cands.size();
+  std::vector<uint8_t> need_vit(cands.size(), 0);
+  if (!cands.empty()) {
+    ctx->cand.ensure(cr.size() * sizeof(PairRec)); ctx->raw.ensure(cr.size() * 12);
+    HIPCHK(hipMemcpyAsync(ctx->cand.p, cr.data(), cr.size() * sizeof(PairRec), hipMemcpyHostToDevice, ctx->stream));
+    launch_bias(ctx->stream, ctx->cand.as<PairRec>(), (uint32_t)cr.size(), dm, lt, res, off, dlen, ctx->raw.as<float>());
+    HIPCHK(hipGetLastError());
+    ctx->h_a.ensure(cr.size() * 12 + 16);
+    const float *raw = ctx->h_a.as<float>();
+    HIPCHK(hipMemcpyAsync(ctx->h_a.p, ctx->raw.p, cr.size() * 12, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    pool_run(ctx, cands.size(), 4096, [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; ++i) {
+        Cand &c = cands[i];
+        const int L = s->len[c.r.seq];
+        const float p1 = (float)L / (float)(L + 1);
+        const float nullsc = (float)(log((double)raw[i * 3]) + (double)raw[i * 3 + 1] * kLn2);
+        c.r.filtersc = nullsc + (float)L * logf(p1) + logf(1.0f - p1);
+        const float sc = bits(c.r.usc, c.r.filtersc);
+        const HostProfile &hp = p->prof[c.r.model];
+        if (!(sc >= hp.thr_msv_f1)) { c.alive = false; continue; }
+        need_vit[i] = !(sc >= hp.thr_msv_f2);
+      }
+    });
+  }
+  // ---- stage 3: Viterbi filter ----
+  CKM_TRACE_PT("bias done");
+  {
+    std::map<int, std::vector<uint32_t>> byQ;
+    for (size_t i = 0; i < cands.size(); ++i) if (cands[i].alive && need_vit[i]) byQ[p->prof[cands[i].r.model].vitQH].push_back((uint32_t)i);
+    std::vector<uint32_t> flat; std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;
+    for (auto &kv : byQ) {
+      // (survivors were appended by SSV blocks that ran longest-first, so these lists are already roughly length-ordered)
+      groups.push_back({kv.first, {flat.size(), kv.second.size()}}); flat.insert(flat.end(), kv.second.begin(), kv.second.end());
+    }
+    st.pairs_vit = flat.size();
+    if (!flat.empty()) {
+      for (size_t i = 0; i < cands.size(); ++i) cr[i] = cands[i].r;
+      HIPCHK(hipMemcpyAsync(ctx->cand.p, cr.data(), cr.size() * sizeof(PairRec), hipMemcpyHostToDevice, ctx->stream));
+      ctx->fbidx.ensure(flat.size() * 4); ctx->vitx.ensure(cands.size() * 4); ctx->vits.ensure(cands.size() * 4); ctx->vitf.ensure(cands.size() * 4);
+      HIPCHK(hipMemcpyAsync(ctx->fbidx.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));            // uploads done; the launches go to the side streams
+      // pass 1: the J-free fast kernel (exact, or a lower bound with its flag set); pass 2: the exact kernel for the pairs
+      // whose bound fails F2 although the J state could have lifted them
+      auto run_vit = [&](const std::vector<std::pair<int, std::pair<size_t, size_t>>> &grp, bool fast) {
+        int gi = 0;
+        for (auto it = grp.rbegin(); it != grp.rend(); ++it, ++gi) {
+          auto &g = *it;
+          if (launch_vit(g.first, ctx->side[gi % 4], ctx->cand.as<PairRec>(), ctx->fbidx.as<uint32_t>() + g.second.first, (uint32_t)g.second.second, dm, lt, res, off, dlen,
+                         ctx->vitx.as<int32_t>(), ctx->vits.as<float>(), ctx->vitf.as<uint32_t>(), fast))
+            throw Error(CKM_ERANGE, "no Viterbi kernel instance for this model length");
+        }
+        HIPCHK(hipGetLastError());
+        for (int k = 0; k < 4; ++k) HIPCHK(hipStreamSynchronize(ctx->side[k]));
+      };
+      run_vit(groups, true);
+      ctx->h_a.ensure(cands.size() * 4 + 16); ctx->h_b.ensure(cands.size() * 4 + 16);
+      const float *vsc = ctx->h_a.as<float>(); const uint32_t *vfl = ctx->h_b.as<uint32_t>();
+      HIPCHK(hipMemcpyAsync(ctx->h_a.p, ctx->vits.p, cands.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+      wcopy(ctx, ctx->h_b.p, ctx->vitf.p, cands.size() * 4, hipMemcpyDeviceToHost);
+      std::map<int, std::vector<uint32_t>> redoQ;
+      for (uint32_t i : flat) {
+        Cand &c = cands[i];
+        if (bits(vsc[i], c.r.filtersc) >= p->prof[c.r.model].thr_vit_f2) continue;          // passes already on the bound
+        if (vfl[i]) redoQ[p->prof[c.r.model].vitQH].push_back(i); else c.alive = false;
+      }
+      if (!redoQ.empty()) {
+        std::vector<uint32_t> flat2; std::vector<std::pair<int, std::pair<size_t, size_t>>> groups2;
+        for (auto &kv : redoQ) { groups2.push_back({kv.first, {flat2.size(), kv.second.size()}}); flat2.insert(flat2.end(), kv.second.begin(), kv.second.end()); }
+        st.pairs_vit_exact = flat2.size();
+        wcopy(ctx, ctx->fbidx.p, flat2.data(), flat2.size() * 4, hipMemcpyHostToDevice);
+        run_vit(groups2, false);
+        wcopy(ctx, ctx->h_a.p, ctx->vits.p, cands.size() * 4, hipMemcpyDeviceToHost);
+        for (uint32_t i : flat2) { Cand &c = cands[i]; if (!(bits(vsc[i], c.r.filtersc) >= p->prof[c.r.model].thr_vit_f2)) c.alive = false; }
+      }
+    }
+  }
+  st.ms_filters = now_ms() - t_filters0;
+  CKM_TRACE_PT("viterbi done");
+  const double t_fb0 = now_ms();
+  // ---- stage 4: Forward parser (multihit, whole sequence), F3 ----
+  FbBatch fb;
+  std::vector<uint32_t> fb_cand;
+  uint64_t aux_base = 0;
+  {
+    uint64_t pos = 0, aux_total = 0;
+    for (size_t i = 0; i < cands.size(); ++i) if (cands[i].alive) {
+      const int L = s->len[cands[i].r.seq];
+      FbWork w; memset(&w, 0, sizeof(w));
+      w.model = cands[i].r.model; w.seq = cands[i].r.seq; w.i0 = 0; w.Ld = L; w.Lcfg = L; w.multihit = 1; w.full = 0; w.slot = (uint32_t)fb.work.size();
+      w.xs_off = pos; pos += ((uint64_t)(L + 1) * 6 + 31) & ~(uint64_t)31;
+      aux_total += ((uint64_t)(L + 1) * 3 + 31) & ~(uint64_t)31;
+      fb.work.push_back(w); fb_cand.push_back((uint32_t)i);
+    }
+    st.pairs_fwd = fb.work.size();
+    aux_base = pos;      // decoding terms of the F3 survivors are laid out compactly from here after the Forward pass
+    if ((pos + aux_total) * 4 > ctx->ws_budget) throw Error(CKM_ENOMEM, "Forward special-row workspace exceeds the device budget; search fewer bins per call");
+    ctx->ws.ensure((pos + aux_total) * 4 + 256);
+    run_fb(ctx, p, s, fb, true, false, false, nullptr);
+  }
+  EventIndex fev; fev.build(fb.events, fb.work.size());
+  CKM_TRACE_PT("fwd parser kernels+copies done, event index built");
+  std::vector<uint32_t> passers;
+  pool_run(ctx, fb.work.size(), 512, [&](size_t lo, size_t hi) {
+    for (size_t k = lo; k < hi; ++k) {
+      Cand &c = cands[fb_cand[k]];
+      const LenEntry &le = s->lentab[s->len[c.r.seq]];
+      c.fwd_xC = fb.fout[k].xC; c.slot = (uint32_t)k;
+      c.fwdsc = finish_forward(fb.fout[k].xC, le.move_m, fev.scales((uint32_t)k));
+      if (!(bits(c.fwdsc, c.r.filtersc) >= p->prof[c.r.model].thr_fwd_f3)) c.alive = false;
+    }
+  });
+  for (size_t k = 0; k < fb.work.size(); ++k) if (cands[fb_cand[k]].alive) passers.push_back((uint32_t)k);
+  st.pairs_dom = passers.size();
+  // ---- stage 5: Backward parser + posterior domain heuristics ----
+  CKM_TRACE_PT("fwd post done");
+  std::vector<EnvReq> envreq; std::vector<std::pair<size_t, size_t>> env_of_pass(passers.size());   // [first, count)
+  std::vector<int> nregions(passers.size(), 0);
+  struct Item { uint32_t pass; int i, j, region; };       // regions in sequence order; region >= 0: resolved by the trace ensemble
+  std::vector<Item> items; std::vector<RegionReq> regreq; std::vector<RegionRes> regres;
+  std::vector<int> env_region;                            // per envelope: index into regres or -1
+  if (!passers.empty()) {
+    uint64_t ap = aux_base;
+    for (uint32_t k : passers) { fb.work[k].aux_off = ap; ap += ((uint64_t)(fb.work[k].Ld + 1) * 3 + 31) & ~(uint64_t)31; }
+    run_fb(ctx, p, s, fb, false, true, false, &passers);
+    // pull the decoding terms of the passers in one copy
+    std::vector<float> dec_all(ap - aux_base);     // pageable on purpose: the region scan below re-reads it; pinned memory reads slowly from the CPU
+    const float *dec_all_p = dec_all.data();
+    if (!dec_all.empty()) wcopy(ctx, dec_all.data(), ctx->ws.as<float>() + aux_base, dec_all.size() * 4, hipMemcpyDeviceToHost);
+    std::vector<std::vector<Item>> found(passers.size());
+    pool_run(ctx, passers.size(), 64, [&](size_t qlo, size_t qhi) {
+      std::vector<float> btot, etot, mocc;
+      for (size_t q = qlo; q < qhi; ++q) {
+        const FbWork &w = fb.work[passers[q]];
+        const int L = w.Ld;
+        const float *dec = dec_all_p + (w.aux_off - aux_base);
+        btot.assign(L + 1, 0.f); etot.assign(L + 1, 0.f); mocc.assign(L + 1, 0.f);
+        for (int i = 1; i <= L; ++i) { btot[i] = btot[i - 1] + dec[(size_t)i * 3]; etot[i] = etot[i - 1] + dec[(size_t)i * 3 + 1]; mocc[i] = 1.0f - dec[(size_t)i * 3 + 2]; }
+        int i = -1; bool triggered = false;
+        for (int j = 1; j <= L; ++j) {
+          if (!triggered) {
+            if (mocc[j] - (btot[j] - btot[j - 1]) < RT2) i = j; else if (i == -1) i = j;
+            if (mocc[j] >= RT1) triggered = true;
+          } else if (mocc[j] - (etot[j] - etot[j - 1]) < RT2) {
+            nregions[q]++;
+            float mx = -1.0f;
+            for (int z = i; z <= j; ++z) { const float a = etot[z] - etot[i - 1], b = btot[j] - btot[z - 1]; const float en = a < b ? a : b; if (en > mx) mx = en; }
+            found[q].push_back({(uint32_t)q, i, j, (mx >= RT3) ? 0 : -1});       // region >= 0: multi-domain, numbered below
+            i = -1; triggered = false;
+          }
+        }
+      }
+    });
+    for (size_t q = 0; q < passers.size(); ++q) for (Item im : found[q]) {
+      const FbWork &w = fb.work[passers[q]];
+      if (im.region >= 0) { im.region = (int)regreq.size(); regreq.push_back({w.model, w.seq, im.i, im.j}); }
+      items.push_back(im);
+    }
+  }
+  // multi-domain regions: 200 stochastic tracebacks each, clustered into envelopes.  (Queueing them beside the envelope
+  // stage of the single-domain regions was tried: the second envelope pass it needs costs more than it hides.)
+  st.regions_multi = regreq.size();
+  CKM_TRACE_PT("bwd parser + region scan done");
+  run_ensembles(ctx, p, s, regreq, regres);
+  {
+    size_t it = 0;
+    for (size_t q = 0; q < passers.size(); ++q) {
+      const FbWork &w = fb.work[passers[q]];
+      env_of_pass[q].first = envreq.size();
+      for (; it < items.size() && items[it].pass == q; ++it) {
+        const Item &im = items[it];
+        if (im.region < 0) { envreq.push_back({w.model, w.seq, im.i, im.j}); env_region.push_back(-1); continue; }
+        int last_j2 = 0;
+        for (const Seg &e : regres[im.region].env) {
+          const int i2 = e.sqfrom + im.i - 1, j2 = e.sqto + im.i - 1;
+          if (i2 <= last_j2) continue;        // overlapping envelopes: the later one is skipped, as HMMER does
+          envreq.push_back({w.model, w.seq, i2, j2}); env_region.push_back(im.region);
+          last_j2 = j2;
+        }
+      }
+      env_of_pass[q].second = envreq.size() - env_of_pass[q].first;
+    }
+  }
+  st.ms_fwdbwd = now_ms() - t_fb0;
+  CKM_TRACE_PT("ensembles done");
+  const double t_dom0 = now_ms();
+  // ---- stage 6: envelope rescoring ----
+  std::vector<EnvRes> envres;
+  rescore_envelopes(ctx, p, s, envreq, envres);
+  st.envelopes = envreq.size();
+  st.ms_domains = now_ms() - t_dom0;
+  CKM_TRACE_PT("envelopes done");
+  const double t_host0 = now_ms();
+  // ---- stage 7: scores, thresholds, rows ----
+  std::vector<std::pair<size_t, size_t>> items_of(passers.size(), {0, 0});
+  { size_t it = 0; for (size_t q = 0; q < passers.size(); ++q) { items_of[q].first = it; while (it < items.size() && items[it].pass == q) ++it; items_of[q].second = it; } }
+  std::vector<Hit> hit_of(passers.size()); std::vector<uint8_t> has_hit(passers.size(), 0);
+  pool_run(ctx, passers.size(), 32, [&](size_t qlo, size_t qhi) {
+  std::vector<float> n2sc;
+  for (size_t q = qlo; q < qhi; ++q) {
+    const Cand &c = cands[fb_cand[passers[q]]];
+    const HostHMM &hm = p->hmm[c.r.model];
+    const int L = s->len[c.r.seq];
+    const uint8_t *dsq = s->dsq.data() + s->off[c.r.seq];
+    const float nullsc = s->lentab[L].nullsc;
+    n2sc.assign((size_t)L + 2, 0.f);
+    Hit h; h.model = c.r.model; h.seq = c.r.seq; h.L = L; h.nreported = 0;
+    int nenv = 0;
+    for (size_t item_at = items_of[q].first; item_at < items_of[q].second; ++item_at) if (items[item_at].region >= 0) {
+      // null2 of an ensemble region: log of the mean odds ratio over the traces, for every residue of the region
+      const Item &im = items[item_at]; const RegionRes &rr = regres[im.region];
+      for (int pos = im.i; pos <= im.j; ++pos) n2sc[pos] = logf(rr.n2sum[pos - im.i] / (float)ENS_NSAMPLES);
+    }
+    for (size_t e = env_of_pass[q].first; e < env_of_pass[q].first + env_of_pass[q].second; ++e) {
+      ++nenv;
+      EnvRes &er = envres[e];
+      if (!er.ok) continue;
+      float null2[KP]; for (int x = 0; x < K; ++x) null2[x] = er.null2[x];
+      fill_null2(null2);
+      Domain d; memset(&d, 0, sizeof(d));
+      d.ienv = envreq[e].ienv; d.jenv = envreq[e].jenv; d.envsc = er.envsc; d.oasc = er.oasc;
+      d.hmm_from = er.hmm_from; d.hmm_to = er.hmm_to; d.ali_from = er.ali_from; d.ali_to = er.ali_to;
+      float ln2[KP + 1];
+      for (int x = 0; x < KP; ++x) ln2[x] = logf(null2[x]);          // same value the per-position logf would give
+      ln2[KP] = 0.f;
+      float dc = 0.f;
+      if (env_region[e] >= 0) { for (int pos = d.ienv; pos <= d.jenv; ++pos) dc += n2sc[pos]; }
+      else for (int pos = d.ienv; pos <= d.jenv; ++pos) { const float v = ln2[dsq[pos - 1]]; n2sc[pos] = v; dc += v; }
+      d.domcorrection = dc;
+      h.dom.push_back(d);
+    }
+    if (nregions[q] == 0 || nenv == 0 || h.dom.empty()) continue;
+    float seqbias = 0.f;
+    for (int i = 0; i <= L; ++i) seqbias += n2sc[i];
+    seqbias = flogsum(0.0f, logf(kOmega) + seqbias);
+    float pre_score = (float)((double)(c.fwdsc - nullsc) / kLn2);
+    float seq_score = (float)((double)(c.fwdsc - (nullsc + seqbias)) / kLn2);
+    float sum_score = 0.f; int Ld = 0; seqbias = 0.f;
+    for (auto &d : h.dom) if (d.envsc - d.domcorrection > 0.0f) { sum_score += d.envsc; Ld += d.jenv - d.ienv + 1; seqbias += d.domcorrection; }
+    seqbias = flogsum(0.0f, logf(kOmega) + seqbias);
+    sum_score += (float)((double)(L - Ld) * log((double)((float)L / (float)(L + 3))));
+    const float pre2 = (float)((double)(sum_score - nullsc) / kLn2);
+    sum_score = (float)((double)(sum_score - (nullsc + seqbias)) / kLn2);
+    if (Ld > 0 && sum_score > seq_score) { seq_score = sum_score; pre_score = pre2; }
+    h.pre_score = pre_score; h.score = seq_score;
+    h.lnP = exp_logsurv(seq_score, hm.evparam[4], hm.evparam[5]);
+    for (auto &d : h.dom) {
+      const int ld = d.jenv - d.ienv + 1;
+      const float bs = d.envsc + (float)((double)(L - ld) * log((double)((float)L / (float)(L + 3))));
+      d.dombias = flogsum(0.0f, logf(kOmega) + d.domcorrection);
+      d.bitscore = (float)((double)(bs - (nullsc + d.dombias)) / kLn2);
+      d.lnP = exp_logsurv(d.bitscore, hm.evparam[4], hm.evparam[5]);
+      d.reported = false;
+    }
+    hit_of[q] = std::move(h); has_hit[q] = 1;
+  }
+  });
+  for (size_t q = 0; q < passers.size(); ++q) if (has_hit[q]) by_bin_model[{s->seq_bin[hit_of[q].seq], hit_of[q].model}].push_back(std::move(hit_of[q]));
+  st.ms_host = now_ms() - t_host0;
+  st.ms_total = now_ms() - t_start;
+  CKM_TRACE_PT("cascade done");
+}
+
+static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, const uint32_t *model_off, const uint32_t *model_idx,
+                      double E, double domE, ckm_hits *hits) {
+  HIPCHK(hipSetDevice(c->device));
+  const double t_start = now_ms();
+  const uint32_t nmodels = (uint32_t)p->hmm.size(), nbins = s->nbins;
+  // ---- plan ----
+  std::vector<std::vector<uint32_t>> bin_models(nbins);
+  for (uint32_t b = 0; b < nbins; ++b) {
+    if (model_off) { for (uint32_t k = model_off[b]; k < model_off[b + 1]; ++k) { if (model_idx[k] >= nmodels) throw Error(CKM_EINVAL, "model index out of range"); bin_models[b].push_back(model_idx[k]); } }
+    else { bin_models[b].resize(nmodels); std::iota(bin_models[b].begin(), bin_models[b].end(), 0u); }
+  }
+  std::vector<std::vector<uint32_t>> model_bins(nmodels);
+  for (uint32_t b = 0; b < nbins; ++b) {
+    std::vector<uint32_t> uniq = bin_models[b]; std::sort(uniq.begin(), uniq.end()); uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    for (uint32_t m : uniq) model_bins[m].push_back(b);
+  }
+  // models -> workers: deal them out by decreasing work (pairs x M) so both chunks cost about the same
+  std::vector<uint32_t> active; std::vector<double> cost(nmodels, 0.0);
+  for (uint32_t m = 0; m < nmodels; ++m) if (!model_bins[m].empty()) { active.push_back(m); double n = 0; for (uint32_t b : model_bins[m]) n += (double)s->bin_res[b]; cost[m] = n * p->prof[m].M; }
+  std::stable_sort(active.begin(), active.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
+  // several workers only pay off on a large search (every one of them adds its own launches and host threads)
+  uint64_t total_pairs = 0;
+  for (uint32_t m : active) for (uint32_t b : model_bins[m]) total_pairs += s->order_off[b + 1] - s->order_off[b];
+  uint64_t min_pairs = 300000;
+  if (const char *e = getenv("CKM_WORKER_MIN_PAIRS")) min_pairs = strtoull(e, nullptr, 10);      // tests: small searches on several workers
+  const int nw = (total_pairs >= min_pairs * c->nworkers) ? c->nworkers : 1;
+  // Two workers split the SEQUENCES, not the models: every stage behind SSV is bound by the row-by-row chain of the longest
+  // sequence it holds, so the few long sequences (a prefix of each bin's length-sorted order) go to worker 0, whose short SSV
+  // phase runs first and whose long chains then run underneath the SSV phase of everything else (worker 1).
+  std::vector<std::vector<uint32_t>> chunk(nw);
+  std::vector<SeqRange> ranges(nw);
+  // cut lengths, descending: class k holds the sequences with cut[k-1] >= L > cut[k].  Default: the cuts that give the
+  // classes fixed shares of the residues (measured best on cfg2: 16 / 45 / 39 % for three workers, 60 / 40 for two).
+  std::vector<int> cuts;
+  if (const char *e = getenv("CKM_LEN_SPLIT")) {
+    const std::string spec = e; size_t pos = 0;
+    while (pos < spec.size()) { size_t q = spec.find(',', pos); if (q == std::string::npos) q = spec.size(); cuts.push_back(atoi(spec.substr(pos, q - pos).c_str())); pos = q + 1; }
+    std::sort(cuts.begin(), cuts.end(), std::greater<int>());
+  } else if (nw >= 2) {
+    static const double shares2[] = {0.60}, shares3[] = {0.16, 0.61}, shares4[] = {0.10, 0.35, 0.65};
+    const double *sh = nw == 2 ? shares2 : nw == 3 ? shares3 : shares4;
+    std::vector<uint64_t> by_len((size_t)s->maxL + 2, 0);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < s->nseq; ++i) { by_len[s->len[i]] += (uint64_t)s->len[i]; total += (uint64_t)s->len[i]; }
+    uint64_t acc = 0; int k = 0;
+    for (int L = s->maxL; L >= 1 && k < nw - 1; --L) { acc += by_len[L]; if ((double)acc >= sh[k] * (double)total) { cuts.push_back(L - 1); ++k; } }
+    while ((int)cuts.size() < nw - 1) cuts.push_back(0);
+  }
+  if (nw >= 2 && (int)cuts.size() == nw - 1 && cuts.back() > 0) {
+    for (int k = 0; k < nw; ++k) { chunk[k] = active; ranges[k].lo.resize(nbins); ranges[k].hi.resize(nbins); ranges[k].res.assign(nbins, 0); ranges[k].tag = 1000 + (uint64_t)k; for (int cv : cuts) ranges[k].tag = ranges[k].tag * 4099 + (uint64_t)cv; }
+    for (uint32_t b = 0; b < nbins; ++b) {
+      uint32_t at = s->order_off[b];
+      for (int k = 0; k < nw; ++k) {
+        const int cut = (k < nw - 1) ? cuts[k] : -1;
+        uint64_t r = 0; const uint32_t lo = at;
+        while (at < s->order_off[b + 1] && s->len[s->order[at]] > cut) { r += (uint64_t)s->len[s->order[at]]; ++at; }
+        ranges[k].lo[b] = lo; ranges[k].hi[b] = at; ranges[k].res[b] = r;
+      }
+    }
+  } else {
+    // models -> workers, by decreasing work, shares ~ ratio^k
+    double ratio = 1.0;
+    if (const char *e = getenv("CKM_SPLIT_RATIO")) ratio = std::min(1.0, std::max(0.01, atof(e)));
+    std::vector<double> share(nw, 1.0), load(nw, 0.0);
+    for (int k = 1; k < nw; ++k) share[k] = share[k - 1] * ratio;
+    for (uint32_t m : active) {
+      int k = 0;
+      for (int j = 1; j < nw; ++j) if (load[j] / share[j] < load[k] / share[k]) k = j;
+      chunk[k].push_back(m); load[k] += cost[m];
+    }
+    for (int k = 0; k < nw; ++k) {
+      ranges[k].lo.assign(s->order_off.begin(), s->order_off.end() - 1); ranges[k].hi.assign(s->order_off.begin() + 1, s->order_off.end());
+      ranges[k].res = s->bin_res; ranges[k].tag = 0;
+    }
+  }
+  for (auto &ch : chunk) std::sort(ch.begin(), ch.end());
+  std::vector<HitMap> maps(nw); std::vector<std::exception_ptr> errs(nw);
+  c->ssv_turn = 0;
+  g_trace_t0 = now_ms();
+  auto run = [&](int k) { try { cascade(&c->w[k], c, k, p, s, ranges[k], chunk[k], model_bins, maps[k]); } catch (...) { errs[k] = std::current_exception(); } };
+  std::vector<std::thread> threads;
+  for (int k = 1; k < nw; ++k) threads.emplace_back(run, k);
+  run(0);
+  for (auto &t : threads) t.join();
+  for (auto &e : errs) if (e) std::rethrow_exception(e);
+  HitMap by_bin_model;
+  for (auto &m : maps) for (auto &kv : m) { auto &dst = by_bin_model[kv.first]; for (auto &h : kv.second) dst.push_back(std::move(h)); }
+  ckm_search_stats &st = c->stats;
+  memset(&st, 0, sizeof(st));
+  for (int k = 0; k < nw; ++k) {
+    const ckm_search_stats &w = c->w[k].stats;
+    st.pairs_ssv += w.pairs_ssv; st.pairs_msv_full += w.pairs_msv_full; st.pairs_bias += w.pairs_bias; st.pairs_vit += w.pairs_vit; st.pairs_vit_exact += w.pairs_vit_exact; st.pairs_fwd += w.pairs_fwd;
+    st.pairs_dom += w.pairs_dom; st.envelopes += w.envelopes; st.regions_multi += w.regions_multi; st.cells_ssv += w.cells_ssv; st.residue_hmm += w.residue_hmm; st.ssv_launches += w.ssv_launches;
+    st.ms_ssv += w.ms_ssv;                                   // SSV phases are serialised by the mutex: the sum is the kernel time
+    st.ms_filters = std::max(st.ms_filters, w.ms_filters); st.ms_fwdbwd = std::max(st.ms_fwdbwd, w.ms_fwdbwd);
+    st.ms_domains = std::max(st.ms_domains, w.ms_domains); st.ms_host = std::max(st.ms_host, w.ms_host);
+  }
+  const double t_host0 = now_ms();
+  // rows, bin by bin, models in the bin's own order
+  hits->nbins = nbins;
+  hits->bin_row_off.assign(nbins + 1, 0);
+  for (uint32_t b = 0; b < nbins; ++b) {
+    hits->bin_row_off[b] = hits->seq.size();
+    const double Z = (double)(s->bin_off[b + 1] - s->bin_off[b]);
+    for (uint32_t m : bin_models[b]) {
+      auto it = by_bin_model.find({b, m});
+      if (it == by_bin_model.end()) continue;
+      std::vector<Hit> hs = it->second;      // copy: a model listed twice in one bin reports twice, as two records in the HMM file would
+      std::sort(hs.begin(), hs.end(), [&](const Hit &a, const Hit &c) {
+        if (a.lnP != c.lnP) return a.lnP < c.lnP;
+        const int cmp = s->names[a.seq].compare(s->names[c.seq]);
+        if (cmp) return cmp < 0;
+        return a.seq < c.seq;
+      });
+      int nrep = 0;
+      for (auto &h : hs) if (exp(h.lnP) * Z <= E) ++nrep;
+      const double domZ = (double)nrep;
+      for (auto &h : hs) {
+        if (!(exp(h.lnP) * Z <= E)) continue;
+        for (auto &d : h.dom) { d.reported = exp(d.lnP) * domZ <= domE; if (d.reported) h.nreported++; }
+        for (size_t d = 1; d < h.dom.size(); ++d) {
+          Domain &a = h.dom[d - 1], &c = h.dom[d];
+          if (a.reported && c.reported && a.ali_from == c.ali_from && a.ali_to == c.ali_to && a.hmm_from == c.hmm_from && a.hmm_to == c.hmm_to) {
+            Domain &w = (a.bitscore >= c.bitscore) ? c : a; w.reported = false; h.nreported--;
+          }
+        }
+        int nd = 0;
+        for (auto &d : h.dom) if (d.reported) {
+          ++nd;
+          hits->seq.push_back(h.seq); hits->model.push_back(h.model); hits->tlen.push_back(h.L); hits->qlen.push_back(p->hmm[h.model].M);
+          hits->full_evalue.push_back(exp(h.lnP) * Z); hits->full_score.push_back(h.score); hits->full_bias.push_back(h.pre_score - h.score);
+          hits->dom_idx.push_back(nd); hits->ndom.push_back(h.nreported);
+          hits->c_evalue.push_back(exp(d.lnP) * domZ); hits->i_evalue.push_back(exp(d.lnP) * Z);
+          hits->dom_score.push_back(d.bitscore); hits->dom_bias.push_back((float)((double)d.dombias * kLog2R));
+          hits->hmm_from.push_back(d.hmm_from); hits->hmm_to.push_back(d.hmm_to); hits->ali_from.push_back(d.ali_from); hits->ali_to.push_back(d.ali_to);
+          hits->env_from.push_back(d.ienv); hits->env_to.push_back(d.jenv);
+          hits->acc.push_back((float)((double)d.oasc / (1.0 + fabs((double)(float)(d.jenv - d.ienv)))));
+        }
+      }
+    }
+  }
+  hits->bin_row_off[nbins] = hits->seq.size();
+  st.ms_host += now_ms() - t_host0;
+  st.ms_total = now_ms() - t_start;
+}
+
+extern "C" int ckm_search(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, const uint32_t *model_off,
+                          const uint32_t *model_idx, double E, double domE, ckm_hits **out) {
+  return guarded([&] {
+    if (!ctx || !p || !s || !out) throw Error(CKM_EINVAL, "NULL argument");
+    if ((model_off == nullptr) != (model_idx == nullptr)) throw Error(CKM_EINVAL, "model_off and model_idx must both be given or both be NULL");
+    *out = nullptr;
+    std::unique_ptr<ckm_hits> h(new ckm_hits());
+    do_search(ctx, p, s, model_off, model_idx, E, domE, h.get());
+    *out = h.release();
+  });
+}

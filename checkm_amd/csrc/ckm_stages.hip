@@ -1,0 +1,404 @@
+// ckm_stages.hip -- host drivers of the stages behind the SSV filter: batches of Forward / Backward / optimal-accuracy work,
+// envelope rescoring, the exact multi-hit MSV and the trace ensembles of multi-domain regions (host glue between the gfx950
+// kernels; the per-cell work is in kernels_*.hip).
+#include "ckm_host.h"
+
+namespace ckm {
+
+void pool_run(Worker *w, size_t n, size_t chunk, const std::function<void(size_t, size_t)> &f) { if (w->pool) w->pool->run(n, chunk, f); else if (n) f(0, n); }
+
+// blocking copy on the worker's own stream (a plain hipMemcpy would wait for every blocking stream of the device)
+void wcopy(Worker *w, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, kind, w->stream));
+  HIPCHK(hipStreamSynchronize(w->stream));
+}
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+float bits(float sc, float nullsc) { return (float)((double)(sc - nullsc) / kLn2); }
+
+// host-side completion of a Forward score from the device's scaled xC and its rescale events
+float finish_forward(float xC, float move, const std::vector<float> &scales) {
+  float totscale = 0.f;
+  for (float sc : scales) totscale = (float)((double)totscale + log((double)sc));
+  return (float)((double)totscale + log((double)(xC * move)));
+}
+
+int ssv_threads_for(int Q) {
+  const size_t lds = (size_t)NROWS * ((Q + 3) / 4) * 256;
+  if (lds <= 40 * 1024) return 256;
+  if (lds <= 80 * 1024 || Q > 40) return 512;   // kernels with Q > 40 are compiled for <= 512 threads (256 VGPRs)
+  return 1024;
+}
+
+void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, bool do_fwd, bool do_bwd, bool do_oa,
+            const std::vector<uint32_t> *subset /* indices into b.work, or null = all */, float *ws_other) {
+  const size_t n = b.work.size();
+  if (!n) return;
+  ctx->fbwork.ensure(n * sizeof(FbWork));
+  wcopy(ctx, ctx->fbwork.p, b.work.data(), n * sizeof(FbWork), hipMemcpyHostToDevice);
+  // group by canonical Q; inside a group, blocks of 4 wavefronts take 4 items of ONE model (shared LDS table)
+  std::map<int, std::map<uint32_t, std::vector<uint32_t>>> byQ;
+  auto add = [&](uint32_t i) { byQ[p->prof[b.work[i].model].fbQ][b.work[i].model].push_back(i); };
+  if (subset) for (uint32_t i : *subset) add(i); else for (uint32_t i = 0; i < n; ++i) add(i);
+  struct Group { int Q; size_t blk0, nblk; };
+  std::vector<uint32_t> items, blk_model; std::vector<Group> groups;
+  for (auto it = byQ.rbegin(); it != byQ.rend(); ++it) {      // heaviest register class first: its chain is the longest
+    auto &kq = *it;
+    Group g{kq.first, blk_model.size(), 0};
+    // longest items first inside a model so the four wavefronts of a block finish together
+    for (auto &km : kq.second) {
+      std::vector<uint32_t> &v = km.second;
+      std::stable_sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return b.work[x].Ld > b.work[y].Ld; });
+      for (size_t i = 0; i < v.size(); i += 4) {
+        for (size_t j = 0; j < 4; ++j) items.push_back(i + j < v.size() ? v[i + j] : 0xffffffffu);
+        blk_model.push_back(km.first);
+      }
+    }
+    g.nblk = blk_model.size() - g.blk0;
+    groups.push_back(g);
+  }
+  ctx->fbidx.ensure(items.size() * 4); ctx->fbmodel.ensure(blk_model.size() * 4);
+  wcopy(ctx, ctx->fbidx.p, items.data(), items.size() * 4, hipMemcpyHostToDevice);
+  wcopy(ctx, ctx->fbmodel.p, blk_model.data(), blk_model.size() * 4, hipMemcpyHostToDevice);
+  ctx->fout.ensure(n * sizeof(FwdOut));
+  ctx->rerr.ensure(n * 4);
+  ctx->envout.ensure(n * sizeof(EnvOut));
+  const uint32_t cap_events = (uint32_t)std::max<size_t>(1 << 20, n * 64);
+  ctx->events.ensure((size_t)cap_events * sizeof(ScaleEvent));
+  ctx->counters.ensure(64);
+  const DevModel *dm = p->d_models.as<DevModel>();
+  const LenEntry *lt = s->d_lentab.as<LenEntry>();
+  const uint8_t *res = s->d_res.as<uint8_t>();
+  const uint64_t *off = s->d_off.as<uint64_t>();
+  float *ws = ws_other ? ws_other : ctx->ws.as<float>();
+  if (do_fwd) HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  // every register class runs its stages in order on its own stream; classes overlap each other
+  size_t gi = 0;
+  for (auto &g : groups) {
+    static const int nfb = [] { const char *e = getenv("CKM_FB_STREAMS"); return e ? std::max(1, std::min(8, atoi(e))) : 8; }();
+    hipStream_t st = ctx->side[gi++ % nfb];
+    const uint32_t *ix = ctx->fbidx.as<uint32_t>() + g.blk0 * 4, *bm = ctx->fbmodel.as<uint32_t>() + g.blk0;
+    if (do_fwd && launch_fwd(g.Q, (uint32_t)g.nblk, st, ctx->fbwork.as<FbWork>(), ix, bm, dm, lt, res, off, ws, ctx->fout.as<FwdOut>(),
+                             ctx->events.as<ScaleEvent>(), ctx->counters.as<uint32_t>(), cap_events))
+      throw Error(CKM_ERANGE, "no Forward kernel instance for this model length");
+    if (do_bwd && launch_bwd(g.Q, (uint32_t)g.nblk, st, ctx->fbwork.as<FbWork>(), ix, bm, dm, lt, res, off, ws, ctx->fout.as<FwdOut>(), ctx->rerr.as<int32_t>()))
+      throw Error(CKM_ERANGE, "no Backward kernel instance for this model length");
+    if (do_oa && launch_oa(g.Q, (uint32_t)g.nblk, st, ctx->fbwork.as<FbWork>(), ix, bm, dm, ws, ctx->rerr.as<int32_t>(), ctx->envout.as<EnvOut>()))
+      throw Error(CKM_ERANGE, "no OA kernel instance for this model length");
+  }
+  HIPCHK(hipGetLastError());
+  for (auto &st : ctx->side) HIPCHK(hipStreamSynchronize(st));
+  if (do_fwd) {
+    b.fout.resize(n);
+    uint32_t nev = 0;
+    wcopy(ctx, b.fout.data(), ctx->fout.p, n * sizeof(FwdOut), hipMemcpyDeviceToHost);
+    wcopy(ctx, &nev, ctx->counters.p, 4, hipMemcpyDeviceToHost);
+    if (nev > cap_events) throw Error(CKM_ERANGE, "rescale event buffer overflow");
+    b.events.resize(nev);
+    if (nev) wcopy(ctx, b.events.data(), ctx->events.p, (size_t)nev * sizeof(ScaleEvent), hipMemcpyDeviceToHost);
+  }
+  if (do_oa) {
+    b.envout.resize(n);
+    wcopy(ctx, b.envout.data(), ctx->envout.p, n * sizeof(EnvOut), hipMemcpyDeviceToHost);
+  }
+}
+
+size_t env_floats(int Mp, int Ld, uint64_t &xs, uint64_t &aux, uint64_t &mf, uint64_t &mb, uint64_t base) {
+  auto al = [](uint64_t v) { return (v + 31) & ~(uint64_t)31; };
+  uint64_t pos = al(base);
+  xs = pos; pos = al(pos + (uint64_t)(Ld + 1) * 6);
+  aux = pos; pos = al(al(pos + (uint64_t)(Ld + 1) * 3) + (uint64_t)(Ld + 1) * 5);
+  mf = pos; pos = al(pos + (uint64_t)(Ld + 1) * 3 * Mp);
+  mb = pos; pos = al(pos + (uint64_t)(Ld + 1) * 2 * Mp);     // posterior rows: M and I only
+  return pos;
+}
+
+// Rescore envelopes on the device; returns one Domain per envelope (ok flag via envsc NaN on range error)
+
+void rescore_envelopes(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<EnvReq> &req, std::vector<EnvRes> &out) {
+  out.resize(req.size());
+  size_t done = 0;
+  const uint64_t budget_floats = ctx->ws_budget / 4;
+  while (done < req.size()) {
+    FbBatch b; uint64_t pos = 0; size_t j = done;
+    for (; j < req.size(); ++j) {
+      const EnvReq &r = req[j];
+      const int Mp = p->prof[r.model].fbQ * NL, Ld = r.jenv - r.ienv + 1;
+      FbWork w; memset(&w, 0, sizeof(w));
+      uint64_t end = env_floats(Mp, Ld, w.xs_off, w.aux_off, w.mxf_off, w.mxb_off, pos);
+      if (end > budget_floats && j > done) break;
+      if (end > budget_floats) throw Error(CKM_ENOMEM, "one envelope needs more workspace than the device budget allows");
+      w.model = r.model; w.seq = r.seq; w.i0 = r.ienv - 1; w.Ld = Ld; w.Lcfg = s->len[r.seq]; w.multihit = 0; w.slot = (uint32_t)(j - done); w.full = 1;
+      b.work.push_back(w); pos = end;
+    }
+    ctx->ws.ensure(pos * 4 + 256);
+    run_fb(ctx, p, s, b, true, true, true, nullptr);
+    EventIndex ei; ei.build(b.events, b.work.size());
+    for (size_t k = 0; k < b.work.size(); ++k) {
+      const EnvReq &r = req[done + k]; EnvRes &o = out[done + k];
+      const EnvOut &eo = b.envout[k];
+      const LenEntry &le = s->lentab[s->len[r.seq]];
+      o.ok = eo.range_err == 0;
+      o.xC = b.fout[k].xC; o.nscale = b.fout[k].nscale;
+      o.envsc = finish_forward(b.fout[k].xC, le.move_u, ei.scales((uint32_t)k));
+      o.oasc = eo.oasc; o.hmm_from = eo.hmm_from; o.hmm_to = eo.hmm_to; o.ali_from = eo.ali_from; o.ali_to = eo.ali_to;
+      for (int x = 0; x < K; ++x) o.null2[x] = eo.null2[x];
+    }
+    done = j;
+  }
+}
+
+// Exact multi-hit MSV of an arbitrary list of pairs with the packed (SSV-style) kernel: pairs are grouped by model (one LDS
+// emission image per workgroup), longest sequences first, 16 sequences per workgroup (4 wavefronts x 4).  Results land in
+// usc/xJ in the order of `pairs`.
+void run_msv_exact(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<PairRec> &pairs, std::vector<float> &usc, std::vector<int32_t> *xJ) {
+  const size_t n = pairs.size();
+  usc.assign(n, 0.f); if (xJ) xJ->assign(n, 0);
+  if (!n) return;
+  std::map<int, std::map<uint32_t, std::vector<uint32_t>>> byQ;            // Q -> model -> indices into pairs
+  for (uint32_t i = 0; i < n; ++i) byQ[p->prof[pairs[i].model].ssvQ][pairs[i].model].push_back(i);
+  std::vector<SsvBlockWork> work; std::vector<uint32_t> lists, slot_of(n); std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;
+  constexpr uint32_t PER_BLOCK = 16;
+  for (auto it = byQ.rbegin(); it != byQ.rend(); ++it) {
+    const size_t first = work.size();
+    std::vector<SsvBlockWork> blocks;
+    for (auto &km : it->second) {
+      std::vector<uint32_t> &v = km.second;
+      std::stable_sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return s->len[pairs[a].seq] > s->len[pairs[b].seq]; });
+      for (size_t a = 0; a < v.size(); a += PER_BLOCK) {
+        SsvBlockWork w; w.model = km.first; w.list_start = (uint32_t)lists.size(); w.count = (uint32_t)std::min<size_t>(PER_BLOCK, v.size() - a); w.pair_start = w.list_start;
+        for (uint32_t k = 0; k < w.count; ++k) { slot_of[v[a + k]] = (uint32_t)lists.size(); lists.push_back(pairs[v[a + k]].seq); }
+        blocks.push_back(w);
+      }
+    }
+    // longest workgroups first inside a launch
+    std::stable_sort(blocks.begin(), blocks.end(), [&](const SsvBlockWork &x, const SsvBlockWork &y) { return s->len[lists[x.list_start]] > s->len[lists[y.list_start]]; });
+    work.insert(work.end(), blocks.begin(), blocks.end());
+    groups.push_back({it->first, {first, work.size() - first}});
+  }
+  ctx->msvwork.ensure(work.size() * sizeof(SsvBlockWork)); ctx->msvlist.ensure(lists.size() * 4);
+  ctx->fullx.ensure(n * 4); ctx->fullu.ensure(n * 4);
+  HIPCHK(hipMemcpyAsync(ctx->msvwork.p, work.data(), work.size() * sizeof(SsvBlockWork), hipMemcpyHostToDevice, ctx->stream));
+  wcopy(ctx, ctx->msvlist.p, lists.data(), lists.size() * 4, hipMemcpyHostToDevice);
+  int gi = 0;
+  for (auto &g : groups) {
+    if (launch_msv(g.first, (int)g.second.second, ctx->side[gi++ % 8], ctx->msvwork.as<SsvBlockWork>() + g.second.first, p->d_models.as<DevModel>(), s->d_lentab.as<LenEntry>(),
+                   s->d_res.as<uint8_t>(), s->d_off.as<uint64_t>(), s->d_len.as<int32_t>(), ctx->msvlist.as<uint32_t>(), ctx->fullx.as<int32_t>(), ctx->fullu.as<float>()))
+      throw Error(CKM_ERANGE, "no MSV kernel instance for this model length");
+  }
+  HIPCHK(hipGetLastError());
+  for (auto &st : ctx->side) HIPCHK(hipStreamSynchronize(st));
+  std::vector<float> raw(n); std::vector<int32_t> rawx(n);
+  HIPCHK(hipMemcpyAsync(raw.data(), ctx->fullu.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (xJ) HIPCHK(hipMemcpyAsync(rawx.data(), ctx->fullx.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < n; ++i) { usc[i] = raw[slot_of[i]]; if (xJ) (*xJ)[i] = rawx[slot_of[i]]; }
+}
+
+// ---- multi-domain regions: trace ensemble on the device, clustering of the sampled segments here ----------------
+
+constexpr uint32_t kEnsStride = 15485863u;
+constexpr float kEnsMinOverlap = 0.8f, kEnsMinPosterior = 0.25f, kEnsMinEndpointP = 0.02f;
+constexpr int kEnsMaxDiagDiff = 4;
+
+uint32_t ens_mix3(uint32_t a, uint32_t b, uint32_t c) {
+  a -= b; a -= c; a ^= (c >> 13);  b -= c; b -= a; b ^= (a << 8);   c -= a; c -= b; c ^= (b >> 13);
+  a -= b; a -= c; a ^= (c >> 12);  b -= c; b -= a; b ^= (a << 16);  c -= a; c -= b; c ^= (b >> 5);
+  a -= b; a -= c; a ^= (c >> 3);   b -= c; b -= a; b ^= (a << 10);  c -= a; c -= b; c ^= (b >> 15);
+  return c;
+}
+// generator state of trace t: Easel's fast generator x -> 69069x+1, seeded 42 (mixed as esl_randomness_Init does), advanced t*stride steps
+uint32_t ens_seed(int t) {
+  uint32_t x = ens_mix3(42u, 87654321u, 12345678u); if (x == 0) x = 42u;
+  uint32_t A = 69069u, C = 1u, ra = 1u, rc = 0u;
+  for (uint64_t n = (uint64_t)t * kEnsStride; n; n >>= 1) { if (n & 1) { ra = A * ra; rc = A * rc + C; } C = A * C + C; A = A * A; }
+  return ra * x + rc;
+}
+
+bool seg_linked(const Seg &a, const Seg &b) {
+  int nov = std::min(a.sqto, b.sqto) - std::max(a.sqfrom, b.sqfrom) + 1;
+  int n = std::min(a.sqto - a.sqfrom + 1, b.sqto - b.sqfrom + 1);
+  if ((float)nov / (float)n < kEnsMinOverlap) return false;
+  nov = std::min(a.hmmto, b.hmmto) - std::max(a.hmmfrom, b.hmmfrom) + 1;
+  n = std::min(a.hmmto - a.hmmfrom + 1, b.hmmto - b.hmmfrom + 1);
+  if ((float)nov / (float)n < kEnsMinOverlap) return false;
+  const int d1 = (a.sqfrom - a.hmmfrom + a.sqto - a.hmmto) / 2, d2 = (b.sqfrom - b.hmmfrom + b.sqto - b.hmmto) / 2;
+  return std::abs(d1 - d2) <= kEnsMaxDiagDiff;
+}
+
+// single linkage over all sampled segments; clusters seen in >= 25% of the traces become envelopes whose ends are the
+// outermost endpoints sampled in >= 2% of those traces.  Most of the 200 traces sample the same few segments, so the
+// linkage runs over the DISTINCT segments (numbered in order of first appearance, which keeps the cluster order).
+void cluster_ensemble(RegionRes &r) {
+  struct Uniq { Seg g; int count; std::vector<uint8_t> in_trace; };
+  std::vector<Uniq> u;
+  std::map<std::array<int32_t, 4>, int> index;
+  for (int t = 0; t < ENS_NSAMPLES; ++t) for (int d = 0; d < r.nseg[t]; ++d) {
+    const Seg &g = r.segs[(size_t)t * r.cap + d];
+    auto ins = index.insert({{g.sqfrom, g.sqto, g.hmmfrom, g.hmmto}, (int)u.size()});
+    if (ins.second) u.push_back({g, 0, std::vector<uint8_t>(ENS_NSAMPLES, 0)});
+    Uniq &x = u[ins.first->second]; x.count++; x.in_trace[t] = 1;
+  }
+  const int n = (int)u.size();
+  std::vector<int> asg(n, -1), stack;
+  int nc = 0;
+  for (int h = 0; h < n; ++h) if (asg[h] < 0) {
+    stack.assign(1, h); asg[h] = nc;
+    while (!stack.empty()) { const int a = stack.back(); stack.pop_back(); for (int b = 0; b < n; ++b) if (asg[b] < 0 && seg_linked(u[a].g, u[b].g)) { asg[b] = nc; stack.push_back(b); } }
+    ++nc;
+  }
+  for (int c = 0; c < nc; ++c) {
+    int ninc = 0;
+    for (int t = 0; t < ENS_NSAMPLES; ++t) { bool any = false; for (int h = 0; h < n && !any; ++h) any = asg[h] == c && u[h].in_trace[t]; ninc += any; }
+    if ((float)ninc / (float)ENS_NSAMPLES < kEnsMinPosterior) continue;
+    int best[4];
+    for (int f = 0; f < 4; ++f) {
+      auto val = [&](int h) { return f == 0 ? u[h].g.sqfrom : f == 1 ? u[h].g.sqto : f == 2 ? u[h].g.hmmfrom : u[h].g.hmmto; };
+      int lo = 1 << 30, hi = -1;
+      for (int h = 0; h < n; ++h) if (asg[h] == c) { lo = std::min(lo, val(h)); hi = std::max(hi, val(h)); }
+      std::vector<int> epc(hi - lo + 1, 0);
+      for (int h = 0; h < n; ++h) if (asg[h] == c) epc[val(h) - lo] += u[h].count;
+      int b;
+      if (f == 0 || f == 2) { for (b = lo; b < hi; ++b) if ((float)epc[b - lo] / (float)ninc >= kEnsMinEndpointP) break; }
+      else                  { for (b = hi; b > lo; --b) if ((float)epc[b - lo] / (float)ninc >= kEnsMinEndpointP) break; }
+      best[f] = b;
+    }
+    r.env.push_back({best[0], best[1], best[2], best[3]});
+  }
+  std::stable_sort(r.env.begin(), r.env.end(), [](const Seg &a, const Seg &b) { return a.sqfrom != b.sqfrom ? a.sqfrom < b.sqfrom : a.sqto < b.sqto; });
+}
+
+// The ensembles of a list of regions, in two halves so that the device works on them while the host drives the
+// envelope stage of the single-domain regions: ens_begin queues Forward + trace kernels + one result copy of the first
+// workspace-sized batch on the worker's ensemble stream; ens_end waits, clusters, and runs what is left.
+struct EnsJob {
+  std::vector<RegionReq> req; std::vector<int> cap;
+  std::vector<std::pair<size_t, size_t>> batches;      // [first, last) of req
+  std::vector<EnsWork> ew;                              // work of the batch in flight
+  uint64_t res_floats = 0; bool in_flight = false; size_t next_batch = 0;
+};
+
+void ens_queue_batch(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, EnsJob &job) {
+  auto al = [](uint64_t v) { return (v + 31) & ~(uint64_t)31; };
+  const auto range = job.batches[job.next_batch++];
+  job.ew.clear();
+  FbBatch b; uint64_t pos = 0; int maxLd = 0, maxMp = 0;
+  // results first (counts, segments, sums of every region: ONE copy back), then the matrices
+  for (size_t j = range.first; j < range.second; ++j) {
+    const RegionReq &r = job.req[j];
+    const int Ld = r.jreg - r.ireg + 1, cap = job.cap[j];
+    EnsWork e; memset(&e, 0, sizeof(e));
+    e.model = r.model; e.seq = r.seq; e.i0 = r.ireg - 1; e.Ld = Ld; e.Lcfg = s->len[r.seq]; e.cap = cap;
+    e.nseg_off = pos; pos += 256;
+    e.seg_off = pos;  pos += (uint64_t)ENS_NSAMPLES * cap * 4;
+    e.n2_off = pos;   pos = al(pos + (uint64_t)Ld);
+    job.ew.push_back(e);
+  }
+  job.res_floats = pos;
+  for (size_t k = 0; k < job.ew.size(); ++k) {
+    EnsWork &e = job.ew[k];
+    const int Mp = p->prof[e.model].fbQ * NL, Ld = e.Ld;
+    e.xs_off = pos;    pos = al(pos + (uint64_t)(Ld + 1) * 6);
+    e.mx_off = pos;    pos = al(pos + (uint64_t)(Ld + 1) * 3 * Mp);
+    e.code_off = pos;  pos = al(pos + ((uint64_t)ENS_NSAMPLES * (Ld + 1) + 1) / 2);
+    e.ratio_off = pos; pos = al(pos + (uint64_t)ENS_NSAMPLES * (Ld + 1));
+    FbWork w; memset(&w, 0, sizeof(w));
+    w.model = e.model; w.seq = e.seq; w.i0 = e.i0; w.Ld = Ld; w.Lcfg = e.Lcfg; w.multihit = 1; w.slot = (uint32_t)k; w.full = 2;
+    w.xs_off = e.xs_off; w.mxf_off = e.mx_off;
+    b.work.push_back(w);
+    maxLd = std::max(maxLd, Ld); maxMp = std::max(maxMp, Mp);
+  }
+  ctx->ws_ens.ensure(pos * 4 + 256);
+  run_fb(ctx, p, s, b, true, false, false, nullptr, ctx->ws_ens.as<float>());   // multihit Forward of every region, M, I and D rows kept
+  ctx->enswork.ensure(job.ew.size() * sizeof(EnsWork));
+  HIPCHK(hipMemcpyAsync(ctx->enswork.p, job.ew.data(), job.ew.size() * sizeof(EnsWork), hipMemcpyHostToDevice, ctx->ens_stream));
+  launch_ensemble(ctx->ens_stream, ctx->enswork.as<EnsWork>(), (uint32_t)job.ew.size(), maxLd, maxMp, p->d_models.as<DevModel>(), s->d_lentab.as<LenEntry>(),
+                  s->d_res.as<uint8_t>(), s->d_off.as<uint64_t>(), ctx->ws_ens.as<float>(), ctx->ensseeds.as<uint32_t>());
+  HIPCHK(hipGetLastError());
+  ctx->h_ens.ensure(job.res_floats * 4);
+  HIPCHK(hipMemcpyAsync(ctx->h_ens.p, ctx->ws_ens.p, job.res_floats * 4, hipMemcpyDeviceToHost, ctx->ens_stream));
+  job.in_flight = true;
+}
+
+void ens_begin(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, EnsJob &job) {
+  if (job.req.empty()) return;
+  if (!ctx->ensseeds.p) {
+    std::vector<uint32_t> seeds(ENS_NSAMPLES);
+    for (int t = 0; t < ENS_NSAMPLES; ++t) seeds[t] = ens_seed(t);
+    ctx->ensseeds.ensure(seeds.size() * 4);
+    wcopy(ctx, ctx->ensseeds.p, seeds.data(), seeds.size() * 4, hipMemcpyHostToDevice);
+  }
+  auto al = [](uint64_t v) { return (v + 31) & ~(uint64_t)31; };
+  const uint64_t budget_floats = ctx->ws_budget / 4;
+  job.batches.clear(); job.next_batch = 0;
+  uint64_t pos = 0; size_t first = 0;
+  for (size_t j = 0; j < job.req.size(); ++j) {
+    const RegionReq &r = job.req[j];
+    const uint64_t Mp = p->prof[r.model].fbQ * NL, Ld = r.jreg - r.ireg + 1;
+    const uint64_t need = 256 + (uint64_t)ENS_NSAMPLES * job.cap[j] * 4 + al(Ld) + al((Ld + 1) * 6) + al((Ld + 1) * 3 * Mp) +
+                          al((ENS_NSAMPLES * (Ld + 1) + 1) / 2) + al(ENS_NSAMPLES * (Ld + 1)) + 64;
+    if (need > budget_floats) throw Error(CKM_ENOMEM, "one multi-domain region needs more workspace than the device budget allows");
+    if (pos + need > budget_floats) { job.batches.push_back({first, j}); first = j; pos = 0; }
+    pos += need;
+  }
+  job.batches.push_back({first, job.req.size()});
+  ens_queue_batch(ctx, p, s, job);
+}
+
+void ens_end(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, EnsJob &job, std::vector<RegionRes> &out) {
+  out.clear(); out.resize(job.req.size());
+  if (job.req.empty()) return;
+  std::vector<size_t> again;
+  size_t base = 0;
+  for (;;) {
+    HIPCHK(hipStreamSynchronize(ctx->ens_stream));
+    const float *raw = ctx->h_ens.as<float>();
+    for (size_t k = 0; k < job.ew.size(); ++k) {
+      const EnsWork &e = job.ew[k]; RegionRes &o = out[base + k];
+      const int32_t *ns = reinterpret_cast<const int32_t *>(raw + e.nseg_off);
+      const int32_t *sg = reinterpret_cast<const int32_t *>(raw + e.seg_off);
+      bool overflow = false;
+      for (int t = 0; t < ENS_NSAMPLES; ++t) overflow |= ns[t] < 0;
+      if (overflow) { again.push_back(base + k); continue; }      // more domains in one trace than slots: redo with a larger table
+      o.cap = e.cap; o.nseg.assign(ns, ns + ENS_NSAMPLES); o.segs.assign((size_t)ENS_NSAMPLES * e.cap, Seg{0, 0, 0, 0});
+      for (int t = 0; t < ENS_NSAMPLES; ++t)
+        for (int d = 0; d < ns[t]; ++d) {          // the device walks backwards: last domain first
+          const int32_t *q4 = sg + ((size_t)t * e.cap + (ns[t] - 1 - d)) * 4;
+          o.segs[(size_t)t * e.cap + d] = Seg{q4[0], q4[1], q4[2], q4[3]};
+        }
+      o.n2sum.assign(raw + e.n2_off, raw + e.n2_off + e.Ld);
+    }
+    pool_run(ctx, job.ew.size(), 1, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) if (!out[base + k].nseg.empty()) cluster_ensemble(out[base + k]); });
+    base += job.ew.size();
+    if (job.next_batch >= job.batches.size()) break;
+    ens_queue_batch(ctx, p, s, job);
+  }
+  if (!again.empty()) {
+    EnsJob redo; std::vector<RegionRes> r2;
+    for (size_t j : again) { redo.req.push_back(job.req[j]); redo.cap.push_back(std::min(job.req[j].jreg - job.req[j].ireg + 1, job.cap[j] * 8)); }
+    ens_begin(ctx, p, s, redo); ens_end(ctx, p, s, redo, r2);
+    for (size_t k = 0; k < again.size(); ++k) out[again[k]] = std::move(r2[k]);
+  }
+}
+
+constexpr int kEnsCap0 = 16;      // segment slots per trace on the first attempt
+
+void run_ensembles(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<RegionReq> &req, std::vector<RegionRes> &out) {
+  EnsJob job; job.req = req;
+  for (const auto &r : req) job.cap.push_back(std::min(r.jreg - r.ireg + 1, kEnsCap0));
+  ens_begin(ctx, p, s, job);
+  ens_end(ctx, p, s, job, out);
+}
+
+void fill_null2(float *null2) {   // degenerate symbols: plain average of the odds of their residues
+  static const char *sym = "ACDEFGHIKLMNPQRSTVWY-BJZOUX*~";
+  auto member = [&](int x, int y) {
+    switch (sym[x]) { case 'B': return sym[y] == 'D' || sym[y] == 'N'; case 'J': return sym[y] == 'I' || sym[y] == 'L';
+                      case 'Z': return sym[y] == 'E' || sym[y] == 'Q'; case 'O': return sym[y] == 'K'; case 'U': return sym[y] == 'C'; default: return true; } };
+  for (int x = 21; x <= 26; ++x) { float r = 0.f; int n = 0; for (int y = 0; y < K; ++y) if (member(x, y)) { r += null2[y]; ++n; } null2[x] = r / (float)n; }
+  null2[20] = null2[27] = null2[28] = 1.0f;
+}
+
+}  // namespace ckm
