@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Turns what tools/collect_profiles.sh left under gpurun_out/<tag>/ into the files committed under profiles/<tag>_*.
+usage: python tools/make_profile_files.py <tag>"""
+import csv
+import json
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def last_json(path):
+    return json.loads(open(path).read().strip().split("\n")[-1])
+
+
+def main():
+    tag = sys.argv[1]
+    src = os.path.join(ROOT, "gpurun_out", tag)
+    dst = lambda name: os.path.join(ROOT, "profiles", "%s_%s" % (tag, name))
+    json.dump(last_json(os.path.join(src, "bench_default.json")), open(dst("bench_cfg2_line.json"), "w"), indent=1)
+    json.dump(last_json(os.path.join(src, "bench_w1.json")), open(dst("bench_cfg2_workers1_line.json"), "w"), indent=1)
+    if os.path.exists(os.path.join(src, "bench_1000bins.json")):
+        json.dump(last_json(os.path.join(src, "bench_1000bins.json")), open(dst("bench_1000bins_line.json"), "w"), indent=1)
+    ks = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), os.path.join(src, "trace", "bench_results.db"), "4"],
+                        capture_output=True, text=True).stdout
+    open(dst("bench_cfg2_kernel_stats.txt"), "w").write(
+        "# rocprofv3 --kernel-trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline   (MI355X, default = 3 workers)\n"
+        "# summarised by tools/rocprof_summary.py.  NOTE: the three workers keep up to a dozen launches in flight at once, so durations of\n"
+        "# concurrent kernels overlap in time and their SUM (ms_per_step) exceeds the wall time of a step; avg_us is the duration of one\n"
+        "# launch while it shares the device.  The solo figures are in %s_pmc_summary.txt (CKM_WORKERS=1, kernels serialised).\n" % tag + ks)
+    pm = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py")] + [os.path.join(src, d) for d in ("pmc_fetch", "pmc_write", "pmc_sq")],
+                        capture_output=True, text=True).stdout
+    hdr = ("# rocprofv3 --pmc passes, MI355X; ONE step each of: CKM_WORKERS=1 python bench.py --steps 1 --warmup 0 --no-cpu-baseline\n"
+           "# (cfg2: 43 profiles x 100 bins x 2000 ORFs; separate passes: --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_*, each with --kernel-trace only;\n"
+           "#  collected by tools/collect_profiles.sh, summarised by tools/pmc_summary.py)\n"
+           "# FETCH_SIZE / WRITE_SIZE are in KB as reported; MI355X_MICROARCH.md (HBM section): FETCH_SIZE reads 1/2 of the bytes of a wide\n"
+           "# coalesced streaming read on gfx950 -> corrected HBM read bytes = 2 * FETCH_SIZE * 1024.  WRITE_SIZE is taken as reported.\n"
+           "# SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* are in quad-cycle units.\n")
+    line = [l for l in pm.split("\n") if l.startswith("ssv_kernel ")][0]
+    valu = float(re.search(r"SQ_INSTS_VALU=(\d+)", line).group(1)); ms = float(line.split()[2])
+    tail = ("\n# ssv_kernel: VALU wave-instructions per SIMD = %.0f / 1024 = %.3e ; kernel time %.2f ms (serialised, under the counters) -> %.2f cycles per VALU\n"
+            "# instruction per SIMD at 2.4 GHz; the architectural issue peak is 1 wave64 instruction per 4 cycles per SIMD (64 lanes over a 16-lane SIMD).\n"
+            % (valu, valu / 1024, ms, ms * 1e-3 * 2.4e9 / (valu / 1024)))
+    open(dst("pmc_summary.txt"), "w").write(hdr + pm + tail)
+
+    def total(d, counter):
+        return sum(float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(src, d, "p_counter_collection.csv")))
+                   if "ssv_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter)
+    f, w = total("pmc_fetch", "FETCH_SIZE"), total("pmc_write", "WRITE_SIZE")
+    json.dump({"config": "cfg2: 43 profiles x 100 bins x 2000 ORFs, 1 GPU, CKM_WORKERS=1 (kernels serialised by counter collection)",
+               "kernel": "ssv_kernel<Q> (all launches of one step)", "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_corrected": 2 * f * 1024 + w * 1024,
+               "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads)",
+               "valu_insts": valu, "ssv_ms_under_pmc": ms}, open(dst("ssv_traffic.json"), "w"), indent=1)
+    print(open(dst("ssv_traffic.json")).read())
+
+
+if __name__ == "__main__":
+    main()
