@@ -101,7 +101,7 @@ EXPORTS = ["ckm_last_error", "ckm_abi_version", "ckm_device_count", "ckm_ctx_cre
            "ckm_profiles_load", "ckm_profiles_count", "ckm_profiles_header", "ckm_profiles_free",
            "ckm_seqs_pack", "ckm_seqs_from_fasta", "ckm_seqs_count", "ckm_seqs_bin_offsets", "ckm_seqs_name", "ckm_seqs_residues", "ckm_seqs_free", "ckm_search", "ckm_hits_columns", "ckm_hits_free",
            "ckm_hits_write_domtblout", "ckm_last_search_stats", "ckm_reduce", "ckm_qa_columns_get", "ckm_qa_free", "ckm_count_sets",
-           "ckm_tables_read", "ckm_tables_assign_models", "ckm_tables_get", "ckm_tables_free",
+           "ckm_align", "ckm_tables_read", "ckm_tables_assign_models", "ckm_tables_get", "ckm_tables_free",
            "ckm_debug_stages", "ckm_debug_envelopes", "ckm_debug_region"]
 
 _lib = None
@@ -148,6 +148,7 @@ def load():
     L.ckm_qa_free.argtypes = [C.c_void_p]
     L.ckm_qa_free.restype = None
     L.ckm_count_sets.argtypes = [C.c_void_p, C.POINTER(MarkerSetsCSR)] + [C.c_void_p] * 7
+    L.ckm_align.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.ckm_tables_read.argtypes = [C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_void_p)]
     L.ckm_tables_assign_models.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_uint64)]
     L.ckm_tables_get.argtypes = [C.c_void_p, C.POINTER(TableColumns)]
@@ -417,3 +418,16 @@ def debug_region(ctx, profiles, seqs, model, seq, ireg, jreg, cap=64):
     _chk(load().ckm_debug_region(ctx.h, profiles.h, seqs.h, model, seq, ireg, jreg, n2.ctypes.data, segs.ctypes.data, nseg.ctypes.data, cap,
                                  env.ctypes.data, 64, C.byref(nenv)))
     return n2, segs, nseg, env[:nenv.value].copy()
+
+
+def align(ctx, profiles, seqs, model, seq):
+    """Optimal-accuracy alignment of whole sequences to models (what hmmalign computes per sequence): list of int32 arrays, one per
+    pair, of length M: 1-based residue emitted by each match state, 0 = none."""
+    model = np.ascontiguousarray(model, dtype=np.uint32)
+    seq = np.ascontiguousarray(seq, dtype=np.uint32)
+    off = np.zeros(len(model) + 1, dtype=np.uint64)
+    for j, m in enumerate(model):
+        off[j + 1] = off[j] + profiles.headers[int(m)]["leng"]
+    out = np.zeros(max(1, int(off[-1])), dtype=np.int32)
+    _chk(load().ckm_align(ctx.h, profiles.h, seqs.h, model.ctypes.data, seq.ctypes.data, len(model), off.ctypes.data, out.ctypes.data))
+    return [out[int(off[j]):int(off[j + 1])].copy() for j in range(len(model))]

@@ -368,3 +368,25 @@ extern "C" int ckm_hits_write_domtblout(const ckm_hits *h, const ckm_profiles *p
     if (fclose(f) != 0) throw Error(CKM_EIO, std::string("error closing ") + path);
   });
 }
+
+// ---- alignment of marker genes to their models ---------------------------------------------------------
+extern "C" int ckm_align(ckm_ctx *ctx_, const ckm_profiles *p, const ckm_seqs *s, const uint32_t *model, const uint32_t *seq, uint32_t n,
+                         const uint64_t *out_off, int32_t *node_residue) {
+  return guarded([&] {
+    if (!ctx_ || !p || !s || (n && (!model || !seq || !out_off || !node_residue))) throw Error(CKM_EINVAL, "NULL argument");
+    Worker *ctx = &ctx_->w[0];
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<EnvReq> req; std::vector<uint32_t> which;
+    for (uint32_t j = 0; j < n; ++j) {
+      if (model[j] >= p->hmm.size() || seq[j] >= s->nseq) throw Error(CKM_EINVAL, "pair index out of range");
+      const uint64_t M = (uint64_t)p->hmm[model[j]].M;
+      if (out_off[j + 1] - out_off[j] != M) throw Error(CKM_EINVAL, "out_off does not match the model lengths");
+      std::fill(node_residue + out_off[j], node_residue + out_off[j + 1], 0);
+      if (s->len[seq[j]] < 1) continue;                 // nothing to align: every node stays unmatched
+      req.push_back({model[j], seq[j], 1, s->len[seq[j]]}); which.push_back(j);
+    }
+    std::vector<EnvRes> res; std::vector<std::vector<int32_t>> paths;
+    rescore_envelopes(ctx, p, s, req, res, &paths);
+    for (size_t k = 0; k < req.size(); ++k) if (res[k].ok) std::copy(paths[k].begin(), paths[k].end(), node_residue + out_off[which[k]]);
+  });
+}

@@ -117,8 +117,10 @@ size_t env_floats(int Mp, int Ld, uint64_t &xs, uint64_t &aux, uint64_t &mf, uin
 
 // Rescore envelopes on the device; returns one Domain per envelope (ok flag via envsc NaN on range error)
 
-void rescore_envelopes(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<EnvReq> &req, std::vector<EnvRes> &out) {
+void rescore_envelopes(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<EnvReq> &req, std::vector<EnvRes> &out,
+                       std::vector<std::vector<int32_t>> *paths) {
   out.resize(req.size());
+  if (paths) paths->assign(req.size(), {});
   size_t done = 0;
   const uint64_t budget_floats = ctx->ws_budget / 4;
   while (done < req.size()) {
@@ -128,6 +130,7 @@ void rescore_envelopes(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, co
       const int Mp = p->prof[r.model].fbQ * NL, Ld = r.jenv - r.ienv + 1;
       FbWork w; memset(&w, 0, sizeof(w));
       uint64_t end = env_floats(Mp, Ld, w.xs_off, w.aux_off, w.mxf_off, w.mxb_off, pos);
+      if (paths) { w.path_off = end + 1; end += (uint64_t)Mp; }          // match-state residues of the OA path (alignment requests)
       if (end > budget_floats && j > done) break;
       if (end > budget_floats) throw Error(CKM_ENOMEM, "one envelope needs more workspace than the device budget allows");
       w.model = r.model; w.seq = r.seq; w.i0 = r.ienv - 1; w.Ld = Ld; w.Lcfg = s->len[r.seq]; w.multihit = 0; w.slot = (uint32_t)(j - done); w.full = 1;
@@ -145,6 +148,11 @@ void rescore_envelopes(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, co
       o.envsc = finish_forward(b.fout[k].xC, le.move_u, ei.scales((uint32_t)k));
       o.oasc = eo.oasc; o.hmm_from = eo.hmm_from; o.hmm_to = eo.hmm_to; o.ali_from = eo.ali_from; o.ali_to = eo.ali_to;
       for (int x = 0; x < K; ++x) o.null2[x] = eo.null2[x];
+      if (paths) {
+        std::vector<int32_t> &pv = (*paths)[done + k];
+        pv.assign((size_t)p->hmm[r.model].M, 0);
+        if (o.ok) wcopy(ctx, pv.data(), ctx->ws.as<int32_t>() + (b.work[k].path_off - 1), pv.size() * 4, hipMemcpyDeviceToHost);
+      }
     }
     done = j;
   }

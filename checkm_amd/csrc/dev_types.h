@@ -65,6 +65,8 @@ struct FbWork {              // one Forward/Backward/OA work item (whole sequenc
   uint64_t aux_off;                    // float offset: parser mode -> decoding terms (Ld+1)*3 [bt et njcp];
                                        // full mode -> (Ld+1)*3 [ppN ppJ ppC], then 128B-aligned (Ld+1)*5 [oN oB oE oJ oC]
   uint64_t mxf_off, mxb_off;           // float offsets of the (Ld+1) x 3*Mp matrices (full mode only)
+  uint64_t path_off;                   // int32 offset + 1 of Mp entries: residue (1-based, within the envelope) emitted by each match state of the
+                                       // OA path, 0 = node not matched (alignment requests); 0 = no path wanted
   uint32_t slot, full;                 // full: 0 parser (specials only), 1 matrix rows M,I, 2 matrix rows M,I,D (trace ensemble)
 };
 

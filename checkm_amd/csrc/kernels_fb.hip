@@ -480,6 +480,8 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
   int i = L, k = 0, st = 0;      // 0=C 1=E 2=M 3=I 4=D
   int fi = 0, fk = 0, li = 0, lk = 0;
   bool done = false;
+  int32_t *path = w.path_off ? reinterpret_cast<int32_t *>(ws) + (w.path_off - 1) : nullptr;    // alignment requests: residue of every match state
+  if (path) { for (int c = lane; c < Mp; c += 64) path[c] = 0; __threadfence(); __builtin_amdgcn_wave_barrier(); }
 #define tBM_(c) tr.at(0, (c))
 #define tMM_(c) tr.at(1, (c))
 #define tIM_(c) tr.at(2, (c))
@@ -504,6 +506,7 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
       if (best >= Mp) done = true; else { k = best; st = 2; li = i; lk = k + 1; }
     } else if (st == 2) {
       fi = i; fk = k + 1;
+      if (path && lane == 0) path[k] = i;
       float p0 = NEGINF_F, p1 = NEGINF_F, p2 = NEGINF_F, p3 = NEGINF_F;
       if (k > 0) { if (tMM_(k) == 0.f) p0 = LD2(&pr[lds_cell<Q>(k - 1)]); if (tIM_(k) == 0.f) p1 = LD2(&pr[Mp + lds_cell<Q>(k - 1)]); if (tDM_(k) == 0.f) p2 = LD2(&pr[2 * Mp + lds_cell<Q>(k - 1)]); }
       if (tBM_(k) == 0.f) p3 = LD2(&oax[(size_t)(i - 1) * 5 + 1]);

@@ -18,3 +18,11 @@ def install():
     checkm.markerSets.MarkerSetParser = m.MarkerSetParser
     p.HmmModel.__module__ = 'checkm.hmmerModelParser'
     checkm.hmmerModelParser.HmmModel = p.HmmModel
+    # qa --aai_strain: only the multi-copy-marker alignment is replaced; the tree workflows keep the reference's hmmalign calls
+    import checkm.aminoAcidIdentity
+    import checkm.hmmerAligner
+    from checkm_amd import aminoAcidIdentity as a
+    from checkm_amd import hmmerAligner as h
+    for name in ('makeAlignmentsOfMultipleHits', '_align_and_mask', '_extractMarkersWithMultipleHits', '_extractSeq'):
+        setattr(checkm.hmmerAligner.HmmerAligner, name, getattr(h.HmmerAligner, name))
+    checkm.aminoAcidIdentity.AminoAcidIdentity = a.AminoAcidIdentity

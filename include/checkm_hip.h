@@ -205,6 +205,19 @@ void ckm_qa_free(ckm_qa *q);
 int  ckm_count_sets(ckm_ctx *ctx, const ckm_marker_sets *ms, const int32_t *marker_count, const uint8_t *marker_first,
                     int32_t *set_present, int32_t *set_multi, int32_t *hist, int32_t *present_total, int32_t *multi_total);
 
+/* ---- alignment of marker genes to their models ---------------------------------------------------
+ * Replaces `hmmalign --outformat Pfam <hmm> <seqs>` (checkm/hmmer.py:76-95, called from HmmerAligner._alignMarker,
+ * checkm/hmmerAligner.py:275-302) as far as CheckM consumes it: _maskAlignment (hmmerAligner.py:325-352) keeps only the
+ * match ('#=GC RF' x) columns, i.e. per model node the residue its match state emits on the optimal-accuracy path, or a gap.
+ * Pair j aligns the WHOLE sequence seq[j] to model[j] (unihit local profile, length model of that sequence, Forward / Backward /
+ * decoding / optimal accuracy -- hmmalign's own per-sequence computation).  node_residue[out_off[j] + k], k = 0..M-1, receives
+ * the 1-based residue index emitted by match state k+1, or 0 (node deleted, or outside the local alignment).
+ * out_off[j+1] - out_off[j] must equal the length of model[j].  A pair whose posterior decoding leaves the float range (the
+ * eslERANGE case of HMMER's decoding: e.g. two strong copies of the domain in one sequence under this one-domain model) reports
+ * no column at all (every entry 0). */
+int  ckm_align(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s, const uint32_t *model, const uint32_t *seq, uint32_t n,
+               const uint64_t *out_off, int32_t *node_residue);
+
 /* ---- tables written by an earlier command -----------------------------------------------------
  * Replaces HMMERParser.readHitsDOM / HmmerHitDOM (checkm/hmmer.py:184-200, 255-285) and the serial per-bin loop around them
  * (checkm/resultsParser.py:94, 191-204): the domtblout text of all bins is parsed once, on a few threads, into the column form

@@ -61,6 +61,7 @@ def lib():
         L.p7o_free.argtypes = [C.c_void_p]
         L.p7o_envelope.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                                    C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+        L.p7o_align.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.p7o_ensemble_seed.restype = C.c_uint32
         L.p7o_ensemble_seed.argtypes = [C.c_int]
         L.p7o_region_ensemble.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -111,6 +112,13 @@ class HmmSet(object):
         rc = lib().p7o_envelope(self.model(i), d.ctypes.data, len(d), ienv, jenv, C.byref(envsc), C.byref(oasc),
                                 null2.ctypes.data, coords.ctypes.data, C.byref(xC), C.byref(ns))
         return rc, envsc.value, oasc.value, null2, coords, xC.value, ns.value
+
+    def align(self, i, dsq):
+        """hmmalign restated: residue (1-based) emitted by each match state of model i on the OA path, 0 = none."""
+        d = np.ascontiguousarray(dsq, dtype=np.uint8)
+        path = np.zeros(self.M(i), dtype=np.int32)
+        rc = lib().p7o_align(self.model(i), d.ctypes.data, len(d), path.ctypes.data)
+        return rc, path
 
     def region_ensemble(self, i, dsq, ireg, jreg, cap=64):
         """200-trace ensemble of region ireg..jreg: (rc, n2sum[Lr], segs[200][cap][4], nseg[200], envelopes[n][4])."""

@@ -768,6 +768,8 @@ static void null2_fill_degenerate(float *null2)
   null2[20] = null2[27] = null2[28] = 1.0f;
 }
 
+static int32_t *g_oa_path = NULL;    /* when set: receives, per model node (0-based), the envelope-local residue its match state emits (0 = none) */
+
 static int rescore_envelope(const PROF *p, const uint8_t *dsq_full, int L_full, int ienv, int jenv,
                             float *n2sc /* per-position, 1-based, may be NULL */, int null2_done, DOMAIN *dom,
                             float *out_null2, float *out_xC, int *out_nscale)
@@ -866,6 +868,7 @@ static int rescore_envelope(const PROF *p, const uint8_t *dsq_full, int L_full, 
       case 1: { k = -1; for (int idx = 0; idx < M; idx++) if (cr[idx] == oE[i]) { k = idx; break; } if (k < 0) { done = 1; break; } st = 2; lastM_i = i; lastM_k = k+1; } break;
       case 2: {
         firstM_i = i; firstM_k = k+1;
+        if (g_oa_path) g_oa_path[k] = i;
         float path[4] = { NEGINF, NEGINF, NEGINF, NEGINF };
         if (k > 0) { if (p->fMM[k] > 0.f) path[0] = pr[k-1]; if (p->fIM[k] > 0.f) path[1] = pr[Mp+k-1]; if (p->fDM[k] > 0.f) path[2] = pr[2*Mp+k-1]; }
         if (p->fBM[k] > 0.f) path[3] = oB[i-1];
@@ -893,6 +896,23 @@ int p7o_envelope(const P7O_HMM *hmm, const uint8_t *dsq, int L_full, int ienv, i
   *envsc = d.envsc; *oasc = d.oasc; coords[0] = d.hmm_from; coords[1] = d.hmm_to; coords[2] = d.ali_from; coords[3] = d.ali_to;
   if (nscale) *nscale = ns;
   prof_free(p); return rc;
+}
+
+/* hmmalign's per-sequence computation (checkm/hmmer.py:76-95 runs `hmmalign --outformat Pfam`): unihit local profile with the
+ * length model of the sequence itself, Forward/Backward/decoding, optimal-accuracy alignment of the WHOLE sequence.  path[k]
+ * (k = 0..M-1) = 1-based residue emitted by match state k+1, 0 if the node is deleted or outside the local alignment -- all
+ * that HmmerAligner._maskAlignment keeps of the alignment (checkm/hmmerAligner.py:325-352: the '#=GC RF' x columns).
+ * Not thread-safe (uses a file-scope hook into the traceback). */
+int p7o_align(const P7O_HMM *hmm, const uint8_t *dsq, int L, int32_t *path)
+{
+  PROF *p = prof_create(hmm); DOMAIN d;
+  memset(path, 0, sizeof(int32_t) * hmm->M);
+  if (L < 1) { prof_free(p); return -1; }
+  g_oa_path = path;
+  int rc = rescore_envelope(p, dsq, L, 1, L, NULL, 0, &d, NULL, NULL, NULL);
+  g_oa_path = NULL;
+  prof_free(p);
+  return rc;
 }
 
 /* ------------------------------------------------------------------------------------------

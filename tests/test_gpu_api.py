@@ -131,3 +131,82 @@ def test_cutoffs_are_float64_end_to_end(gpu_ctx, tmp_path):
     res = plan.reduce(gpu_ctx, None, None, ext=hc)
     assert list(res.hist[0]) == [0, 1, 0, 0, 0, 0] and res.completeness[0] == 100.0
     res.close(); prof.close()
+
+
+def test_align_matches_the_oracle(gpu_ctx):
+    """ckm_align (what hmmalign computes per sequence, reduced to the match columns CheckM keeps) against the oracle's restatement:
+    whole genes with flanks, fragments, two copies in one sequence, a merged pair of adjacent ORFs, random and tiny sequences."""
+    from checkm_amd import _lib
+    profs = common.mixed_profiles()
+    path = common.hmm_file("mixed", profs)
+    rng = np.random.default_rng(41)
+    recs, model = [], []
+    for mi, p in enumerate(profs):
+        dom = synth.sample_domain(rng, p)
+        recs.append(("g%d_1" % mi, "", synth.to_text(np.concatenate([synth.random_residues(rng, 15), dom, synth.random_residues(rng, 20)])))); model.append(mi)
+        a = int(rng.integers(2, p.M // 2)); b = int(rng.integers(p.M // 2 + 1, p.M))
+        recs.append(("g%d_2" % mi, "", synth.to_text(synth.sample_domain(rng, p, a, b)))); model.append(mi)
+        recs.append(("g%d_3" % mi, "", synth.to_text(np.concatenate([dom, synth.random_residues(rng, 6), synth.sample_domain(rng, p)])))); model.append(mi)
+        recs.append(("g%d_4" % mi, "", synth.to_text(synth.random_residues(rng, int(rng.integers(1, 90)))))); model.append(mi)
+    recs.append(("tiny", "", "M")); model.append(0)
+    prof = _lib.Profiles(gpu_ctx, path)
+    seqs = _lib.Seqs(gpu_ctx, [recs])
+    hs = p7.HmmSet(path)
+    got = _lib.align(gpu_ctx, prof, seqs, model, list(range(len(recs))))
+    nmatched = 0
+    for r, (rec, m) in enumerate(zip(recs, model)):
+        rc, want = hs.align(m, p7.digitize(rec[2]))
+        assert len(got[r]) == profs[m].M
+        if rc != 0:        # posterior decoding left the float range (two strong copies under a one-domain model): no column is reported
+            assert rec[0].endswith("_3") and (got[r] == 0).all(), rec[0]
+            continue
+        assert (got[r] == want).all(), (rec[0], np.nonzero(got[r] != want)[0][:5])
+        nmatched += int((want > 0).sum())
+    assert nmatched > 0.5 * sum(profs[m].M for m in model[::4])
+    prof.close(); seqs.close(); hs.close()
+
+
+def test_multi_copy_markers_are_aligned_and_scored(gpu_ctx, tmp_path):
+    """HmmerAligner.makeAlignmentsOfMultipleHits -> <marker>.masked.faa -> AminoAcidIdentity.run, against the same steps taken with
+    the oracles (reduce oracle for which hits are kept, scan oracle for the alignment, the reference-pinned AAI arithmetic)."""
+    from checkm_amd.aminoAcidIdentity import AminoAcidIdentity
+    from checkm_amd.hmmerAligner import HmmerAligner
+    profs, hmm, binfiles, recs_all, dat = _setup(tmp_path)
+    out = tmp_path / "out"
+    (out / "storage").mkdir(parents=True)
+    models = MarkerGeneFinder(4).find(binfiles, str(out), DefaultValues.HMMER_TABLE_OUT, DefaultValues.HMMER_OUT, hmm, False, False, True)
+    sets = MarkerSetParser().getMarkerSets(str(out), list(models), hmm)
+    aai_dir = str(out / "storage" / "aai_qa")
+    HmmerAligner(2).makeAlignmentsOfMultipleHits(str(out), hmm, DefaultValues.HMMER_TABLE_OUT, models, sets, False, DefaultValues.E_VAL, DefaultValues.LENGTH, aai_dir)
+    texts = _oracle_tables(hmm, recs_all)
+    omodels = {a: {"acc": a, "ga": list(m.ga) if m.ga else None, "tc": list(m.tc) if m.tc else None, "nc": list(m.nc) if m.nc else None, "leng": m.leng}
+               for a, m in models["bin_0"].items()}
+    hs = p7.HmmSet(hmm)
+    slot = {hs.acc(i) or hs.name(i): i for i in range(hs.n)}
+    nfiles = 0
+    for b in range(3):
+        binId = "bin_%d" % b
+        mh, _gc = ro.reduce_bin(texts[b], omodels, dat, [sorted(s) for s in sets[binId].selectedMarkerSet().markerSet])
+        orfs = {r[0]: r[2] for r in recs_all[b]}
+        for marker, hits in mh.items():
+            if len(hits) < 2:
+                continue
+            hits = sorted(hits, key=lambda h: h["full_e_value"], reverse=True)
+            want = []
+            seen = {}
+            for h in hits:
+                text = "".join(orfs[s][:-1] if orfs[s].endswith("*") else orfs[s] for s in h["target_name"].split("&&"))
+                seen[h["target_name"]] = text
+            for name, text in seen.items():
+                rc, path = hs.align(slot[marker], p7.digitize(text))
+                want.append(">%s&&%s\n%s\n" % (binId, name, "".join(text.upper()[i - 1] if i > 0 else "-" for i in path)))
+            f = out / "storage" / "aai_qa" / binId / (marker + ".masked.faa")
+            assert f.read_text() == "".join(want), (binId, marker)
+            nfiles += 1
+    assert nfiles >= 3
+    a = AminoAcidIdentity()
+    a.run(0.9, str(out), str(out / "pairs.txt"))
+    assert set(a.aaiMeanBinHetero) <= {"bin_0", "bin_1", "bin_2"} and len(a.aaiMeanBinHetero) >= 1
+    for binId, v in a.aaiMeanBinHetero.items():
+        assert 0.0 <= v <= 100.0
+    hs.close(); release_scan()

@@ -91,3 +91,35 @@ def test_domtblout_reader_contract(tmp_path):
     assert h1.target_description.startswith("# 1767 # 2963")
     assert h2.query_accession == "PGK"
     assert h3 is None
+
+
+def test_amino_acid_identity_matches_the_reference(gold, tmp_path):
+    """AminoAcidIdentity.aai / strainHetero / run and HmmerAligner._extractSeq against values produced by the reference's own
+    classes (tools/gen_host_golden.py): the leading/trailing-gap quirks, the marker id cut at the first dot, the pair report."""
+    import os
+    from checkm_amd.aminoAcidIdentity import AminoAcidIdentity
+    from checkm_amd.hmmerAligner import HmmerAligner
+    a = AminoAcidIdentity()
+    for s1, s2, want in gold["aai"]:
+        assert a.aai(s1, s2) == want, (s1, s2)
+    for scores, thr, het, mean in gold["strain"]:
+        h, m = a.strainHetero(scores, thr)
+        assert {k: dict(v) for k, v in h.items()} == het and m == mean
+    g = gold["aai_run"]
+    od = tmp_path / "run"
+    for b, fs in g["files"].items():
+        (od / "bins" / b).mkdir(parents=True)
+        (od / "storage" / "aai_qa" / b).mkdir(parents=True)
+        for fn, txt in fs.items():
+            (od / "storage" / "aai_qa" / b / fn).write_text(txt)
+    (od / "bins" / "binC").mkdir()
+    r = AminoAcidIdentity()
+    rep = str(od / "pairs.txt")
+    r.run(0.9, str(od), rep)
+    assert {b: dict(d) for b, d in r.aaiRawScores.items()} == g["raw"]
+    assert {b: dict(d) for b, d in r.aaiHetero.items()} == g["hetero"] and r.aaiMeanBinHetero == g["mean"]
+    assert sorted(open(rep).read().strip().split("\n\n")) == g["report_sorted_blocks"]
+    ha = HmmerAligner(1)
+    orfs = {"c1_1": "MKV*", "c1_2": "ACD", "c9_5": "WWW*"}
+    for sid, want in gold["extract_seq"]:
+        assert ha._extractSeq(sid, orfs) == want

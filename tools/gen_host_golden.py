@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Goldens for the host logic around the hot path, produced by the REFERENCE's own classes
 (imported read-only from /root/reference): the sticky header parse (hmmerModelParser.py:54-83),
-marker-file parsing + exclusion (markerSets.py:248-297,478-522) and binIdFromFilename.
+marker-file parsing + exclusion (markerSets.py:248-297,478-522), binIdFromFilename, and AminoAcidIdentity.aai / strainHetero /
+run (aminoAcidIdentity.py:39-161) together with HmmerAligner._extractSeq (hmmerAligner.py:407-426).
 Writes tests/golden/host_cases.json (committed).  Run here only."""
 import json
 import os
@@ -72,6 +73,44 @@ def main():
     out["lineage"] = {"file": lineage, "selected_map": "10\t11\n11\t12\n12\t12\n20\t20\n",
                       "result": {bid: {"selected_uid": bm.selectedMarkerSet().UID,
                                        "sets": [[ms.UID, ms.lineageStr, ms.numGenomes, [sorted(s) for s in ms.markerSet]] for ms in bm.markerSets]} for bid, bm in b.items()}}
+    # amino-acid identity of masked alignments: hand-made edge cases + random gapped pairs, through the reference's own class
+    import random
+    from checkm.aminoAcidIdentity import AminoAcidIdentity
+    from checkm.hmmerAligner import HmmerAligner
+    aai = AminoAcidIdentity()
+    rnd = random.Random(7)
+    pairs = [("--ACDE--", "-AACDEF-"), ("ACDE", "ACDF"), ("----", "----"), ("A-", "AC"), ("-A", "CA"), ("A", "A"), ("A", "-"), ("-CDE", "ACD-"),
+             ("AC--DE", "AC--DF"), ("AC-DE", "ACWDE"), ("----A", "ACDEA"), ("A----", "A-CDE")]
+    for _ in range(60):
+        n = rnd.randint(1, 40)
+        a = "".join(rnd.choice("ACDEFGHIK-") if rnd.random() < 0.8 else "-" for _ in range(n))
+        b = "".join((c if rnd.random() < 0.7 else rnd.choice("ACDEFGHIK-")) for c in a)
+        pairs.append((a, b))
+    out["aai"] = [[a, b, aai.aai(a, b)] for a, b in pairs]
+    scores = {"bin1": {"PF1": [0.95, 0.5, 1.0], "TIGR2": [0.2]}, "bin2": {"PF1": [0.9]}, "bin3": {"M": [0.9, 0.9000001, 0.89]}}
+    out["strain"] = []
+    for thr in (0.9, 0.5, 0.0):
+        het, mean = aai.strainHetero(scores, thr)
+        out["strain"].append([scores, thr, {k: dict(v) for k, v in het.items()}, mean])
+    # run(): masked files on disk -> raw scores, heterogeneity, pair report
+    od = os.path.join(DATA, "aai_run")
+    files = {"binA": {"PF00318.15.masked.faa": ">binA&&c1_1\nACD-EF\n>binA&&c1_7&&c1_8\nACDWEF\n>binA&&c2_3\n-CDWE-\n", "notes.txt": "x"},
+             "binB": {"TIGR00001.masked.faa": ">binB&&k_1\nAAAA\n>binB&&k_2\nAAAC\n"}}
+    for b, fs in files.items():
+        os.makedirs(os.path.join(od, "bins", b), exist_ok=True)
+        os.makedirs(os.path.join(od, "storage", "aai_qa", b), exist_ok=True)
+        for fn, txt in fs.items():
+            open(os.path.join(od, "storage", "aai_qa", b, fn), "w").write(txt)
+    os.makedirs(os.path.join(od, "bins", "binC"), exist_ok=True)           # a bin without multi-copy markers
+    r = AminoAcidIdentity()
+    rep = os.path.join(od, "pairs.txt")
+    r.run(0.9, od, rep)
+    out["aai_run"] = {"files": files, "raw": {b: {m: v for m, v in d.items()} for b, d in r.aaiRawScores.items()},
+                      "hetero": {b: dict(d) for b, d in r.aaiHetero.items()}, "mean": r.aaiMeanBinHetero,
+                      "report_sorted_blocks": sorted(open(rep).read().strip().split("\n\n"))}
+    ha = HmmerAligner(1)
+    orfs = {"c1_1": "MKV*", "c1_2": "ACD", "c9_5": "WWW*"}
+    out["extract_seq"] = [[sid, ha._extractSeq(sid, orfs)] for sid in ("c1_1", "c1_2", "c1_1&&c1_2", "c1_2&&c9_5&&c1_1")]
     names = ["/a/b/bin.1.fna", "x.fa.gz", "genome.faa", "noext", "a.b.c.gz", "dir.d/file"]
     out["binIdFromFilename"] = {n: binIdFromFilename(n) for n in names}
     with open(os.path.join(ROOT, "tests", "golden", "host_cases.json"), "w") as f:
