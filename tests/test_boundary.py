@@ -53,3 +53,22 @@ def test_bad_arguments_return_codes():
     n = ctypes.c_int32()
     assert lib.ckm_profiles_count(None, ctypes.byref(n)) == -1
     assert b"NULL" in lib.ckm_last_error()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/checkm"), reason="the reference package is only present in the build container")
+def test_dropin_rebinds_the_reference_classes(tmp_path):
+    """INTEGRATION.md option A, in a subprocess so the reference package never enters this test process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import checkm_amd.dropin as d; d.install()\n"
+            "import checkm.markerGeneFinder as a, checkm.resultsParser as b, checkm.markerSets as c, checkm.hmmerAligner as e, checkm.aminoAcidIdentity as f, checkm.hmmerModelParser as g\n"
+            "mods = [a.MarkerGeneFinder.__module__, b.ResultsParser.__module__, b.ResultsManager.__module__, c.MarkerSet.__module__, c.MarkerSetParser.__module__,\n"
+            "        e.HmmerAligner.makeAlignmentsOfMultipleHits.__module__, f.AminoAcidIdentity.__module__]\n"
+            "assert all(m.startswith('checkm_amd.') for m in mods), mods\n"
+            "assert g.HmmModel.__module__ == 'checkm.hmmerModelParser'\n"
+            "assert e.HmmerAligner.makeAlignmentTopHit.__module__ == 'checkm.hmmerAligner'      # tree-side alignment untouched\n"
+            "print('ok')\n")
+    env = dict(os.environ, PYTHONPATH="/root/reference" + os.pathsep + root, CHECKM_DATA_PATH=str(tmp_path), PYTHONDONTWRITEBYTECODE="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-1500:]
