@@ -18,11 +18,10 @@ def install():
     checkm.markerSets.MarkerSetParser = m.MarkerSetParser
     p.HmmModel.__module__ = 'checkm.hmmerModelParser'
     checkm.hmmerModelParser.HmmModel = p.HmmModel
-    # qa --aai_strain: only the multi-copy-marker alignment is replaced; the tree workflows keep the reference's hmmalign calls
+    # every hmmalign call of CheckM (qa --aai_strain, qa -o 9, tree): the masked alignments come from ckm_align
     import checkm.aminoAcidIdentity
     import checkm.hmmerAligner
     from checkm_amd import aminoAcidIdentity as a
     from checkm_amd import hmmerAligner as h
-    for name in ('makeAlignmentsOfMultipleHits', '_align_and_mask', '_extractMarkersWithMultipleHits', '_extractSeq'):
-        setattr(checkm.hmmerAligner.HmmerAligner, name, getattr(h.HmmerAligner, name))
+    checkm.hmmerAligner.HmmerAligner = h.HmmerAligner
     checkm.aminoAcidIdentity.AminoAcidIdentity = a.AminoAcidIdentity

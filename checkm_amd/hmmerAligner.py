@@ -1,4 +1,4 @@
-"""HmmerAligner (the multi-copy-marker part), API-compatible with checkm/hmmerAligner.py:36-44,125-205,275-352,428-451.
+"""HmmerAligner, API-compatible with checkm/hmmerAligner.py:36-451 (the three makeAlignment* entry points).
 
 The reference writes the copies of every marker with >= 2 hits in a bin to a FASTA file, runs `hmmalign --outformat Pfam`
 against the marker's model (fetched with hmmfetch into a temporary file), and keeps of the Stockholm output only the match
@@ -22,6 +22,42 @@ class HmmerAligner(object):
         self.totalThreads = threads          # accepted for compatibility: one batched device call replaces the worker processes
         self.outputFormat = 'Pfam'
 
+    def makeAlignmentTopHit(self, outDir, hmmModelFile, hmmTableFile, binIdToModels, bIgnoreThresholds, evalueThreshold, lengthThreshold,
+                            bReportHitStats, alignOutputDir, bKeepUnmaskedAlign=False):
+        """Align the top hit of every marker in every bin (hmmerAligner.py:44-83); one <marker>.masked.faa per marker."""
+        return self._align_across_bins(self._extractMarkerSeqsTopHits, outDir, hmmModelFile, hmmTableFile, binIdToModels, bIgnoreThresholds,
+                                       evalueThreshold, lengthThreshold, bReportHitStats, alignOutputDir, bKeepUnmaskedAlign)
+
+    def makeAlignmentToPhyloMarkers(self, outDir, hmmModelFile, hmmTableFile, binIdToModels, bIgnoreThresholds, evalueThreshold, lengthThreshold,
+                                    bReportHitStats, alignOutputDir, bKeepUnmaskedAlign=False):
+        """Align the unique hits to a set of common marker genes (hmmerAligner.py:85-123)."""
+        return self._align_across_bins(self._extractMarkerSeqsUnique, outDir, hmmModelFile, hmmTableFile, binIdToModels, bIgnoreThresholds,
+                                       evalueThreshold, lengthThreshold, bReportHitStats, alignOutputDir, bKeepUnmaskedAlign)
+
+    def _align_across_bins(self, extract, outDir, hmmModelFile, hmmTableFile, binIdToModels, bIgnoreThresholds, evalueThreshold, lengthThreshold,
+                           bReportHitStats, alignOutputDir, bKeepUnmaskedAlign):
+        if bKeepUnmaskedAlign:
+            self.logger.error('The unmasked Stockholm alignment is not produced on this path (only the masked match columns are).')
+            sys.exit(1)
+        self.logger.info("Extracting marker genes to align.")
+        resultsParser = ResultsParser(binIdToModels)
+        resultsParser.parseBinHits(outDir, hmmTableFile, False, bIgnoreThresholds, evalueThreshold, lengthThreshold)
+        markerSeqs, markerStats = extract(outDir, resultsParser)
+        firstBin = list(binIdToModels.keys())[0]
+        makeSurePathExists(alignOutputDir)
+        jobs = []
+        for markerId in binIdToModels[firstBin]:          # the reference builds one temporary model file per key of the first bin
+            entries = []
+            for binId, seqs in markerSeqs.get(markerId, {}).items():
+                for seqId, seq in seqs.items():
+                    st = markerStats[markerId][binId][seqId]
+                    entries.append((binId + DefaultValues.SEQ_CONCAT_CHAR + seqId, '[e-value=%.4g,score=%.1f]' % (st[0], st[1]) if bReportHitStats else None, seq))
+            if entries:
+                jobs.append((os.path.join(alignOutputDir, markerId + '.masked.faa'), markerId, entries))
+        self.logger.info("Aligning %d marker genes:" % len(binIdToModels[firstBin]))
+        self._align_and_mask(hmmModelFile, jobs)
+        return resultsParser
+
     def makeAlignmentsOfMultipleHits(self, outDir, markerFile, hmmTableFile, binIdToModels, binIdToBinMarkerSets,
                                      bIgnoreThresholds, evalueThreshold, lengthThreshold, alignOutputDir):
         """Align markers with multiple hits within a bin (hmmerAligner.py:125-173)."""
@@ -29,17 +65,20 @@ class HmmerAligner(object):
         resultsParser = ResultsParser(binIdToModels)
         resultsParser.parseBinHits(outDir, hmmTableFile, False, bIgnoreThresholds, evalueThreshold, lengthThreshold)
         self.logger.info('Aligning marker genes with multiple hits in a single bin:')
-        jobs = []                               # (binId, markerId, [(seqId, residues)])
+        jobs = []                               # (output file, markerId, [(sequence id, header stats or None, residues)])
         for binId in binIdToModels:
             multi = self._extractMarkersWithMultipleHits(outDir, binId, resultsParser, binIdToBinMarkerSets[binId])
             for markerId, perBin in multi.items():
-                jobs.append((binId, markerId, list(perBin[binId].items())))
-        self._align_and_mask(markerFile, jobs, alignOutputDir)
+                entries = [(binId + DefaultValues.SEQ_CONCAT_CHAR + seqId, None, seq) for seqId, seq in perBin[binId].items()]
+                jobs.append((os.path.join(alignOutputDir, binId, markerId + '.masked.faa'), markerId, entries))
+        self._align_and_mask(markerFile, jobs)
         n = len(binIdToModels)
         if n and self.logger.getEffectiveLevel() <= logging.INFO:
             sys.stderr.write('    Finished processing %d of %d (%.2f%%) bins.\n' % (n, n, 100.0))
 
-    def _align_and_mask(self, hmmModelFile, jobs, alignOutputDir):
+    def _align_and_mask(self, hmmModelFile, jobs):
+        """All sequences of all jobs in ONE ckm_align call; one masked FASTA per job (what _alignMarker + _maskAlignment leave behind,
+        hmmerAligner.py:275-352): '>' id [stats], then the residue of every match column or '-'."""
         if not jobs:
             return
         ctx = runtime.get_ctx()
@@ -51,12 +90,12 @@ class HmmerAligner(object):
                 if hd["acc"]:
                     slot.setdefault(hd["acc"], i)
             recs, model, owner = [], [], []
-            for j, (binId, markerId, seqs) in enumerate(jobs):
+            for j, (_path, markerId, entries) in enumerate(jobs):
                 if markerId not in slot:
                     self.logger.error('Model %s not found in %s.' % (markerId, hmmModelFile))
                     sys.exit(1)
-                for seqId, residues in seqs:
-                    recs.append((binId + DefaultValues.SEQ_CONCAT_CHAR + seqId, '', residues))
+                for seqId, _stats, residues in entries:
+                    recs.append((seqId, '', residues))
                     model.append(slot[markerId]); owner.append(j)
             seqs = _lib.Seqs(ctx, [recs])
             try:
@@ -68,14 +107,42 @@ class HmmerAligner(object):
         masked = defaultdict(list)
         for r, path in enumerate(paths):
             text = recs[r][2].upper()
-            masked[owner[r]].append((recs[r][0], ''.join(text[i - 1] if i > 0 else '-' for i in path)))
-        for j, (binId, markerId, _seqs) in enumerate(jobs):
-            binDir = os.path.join(alignOutputDir, binId)
-            makeSurePathExists(binDir)
-            with open(os.path.join(binDir, markerId + '.masked.faa'), 'w') as fout:
-                for seqId, seq in masked[j]:
-                    fout.write('>' + seqId + '\n')
+            masked[owner[r]].append(''.join(text[i - 1] if i > 0 else '-' for i in path))
+        for j, (path, _markerId, entries) in enumerate(jobs):
+            makeSurePathExists(os.path.dirname(path))
+            with open(path, 'w') as fout:
+                for (seqId, stats, _res), seq in zip(entries, masked[j]):
+                    fout.write('>%s %s\n' % (seqId, stats) if stats else '>' + seqId + '\n')
                     fout.write(seq + '\n')
+
+    def _extractMarkerSeqsTopHits(self, outDir, resultsParser):
+        """Sequence and (e-value, score) of the top hit of every marker in every bin (hmmerAligner.py:354-376).  As in the reference the
+        hits are sorted from the HIGHEST e-value down and the first one is taken."""
+        markerSeqs, markerStats = defaultdict(dict), defaultdict(dict)
+        for binId in resultsParser.results:
+            binORFs = {name: res for name, _d, res in read_fasta(os.path.join(outDir, 'bins', binId, DefaultValues.PRODIGAL_AA))}
+            for markerId, hits in resultsParser.results[binId].markerHits.items():
+                markerSeqs[markerId][binId] = {}
+                markerStats[markerId][binId] = {}
+                hits.sort(key=lambda x: x.full_e_value, reverse=True)
+                top = hits[0]
+                markerSeqs[markerId][binId][top.target_name] = self._extractSeq(top.target_name, binORFs)
+                markerStats[markerId][binId][top.target_name] = [top.full_e_value, top.full_score]
+        return markerSeqs, markerStats
+
+    def _extractMarkerSeqsUnique(self, outDir, resultsParser):
+        """Markers with exactly one hit in a bin (hmmerAligner.py:378-405)."""
+        markerSeqs, markerStats = defaultdict(dict), defaultdict(dict)
+        for binId in resultsParser.results:
+            binORFs = {name: res for name, _d, res in read_fasta(os.path.join(outDir, 'bins', binId, DefaultValues.PRODIGAL_AA))}
+            for markerId, hits in resultsParser.results[binId].markerHits.items():
+                markerSeqs[markerId][binId] = {}
+                markerStats[markerId][binId] = {}
+                if len(hits) == 1:
+                    hit = hits[0]
+                    markerSeqs[markerId][binId][hit.target_name] = self._extractSeq(hit.target_name, binORFs)
+                    markerStats[markerId][binId][hit.target_name] = [hit.full_e_value, hit.full_score]
+        return markerSeqs, markerStats
 
     def _extractSeq(self, seqId, seqs):
         """Residues of an ORF, or of adjacent ORFs merged by the adjacency correction, without prodigal's final '*' (:407-426)."""

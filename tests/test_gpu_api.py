@@ -204,6 +204,28 @@ def test_multi_copy_markers_are_aligned_and_scored(gpu_ctx, tmp_path):
             assert f.read_text() == "".join(want), (binId, marker)
             nfiles += 1
     assert nfiles >= 3
+    # the top hit of every marker in every bin, one file per marker with the hit statistics in the header (qa -o 9 path)
+    top_dir = out / "top"
+    rp = HmmerAligner(2).makeAlignmentTopHit(str(out), hmm, DefaultValues.HMMER_TABLE_OUT, models, False, DefaultValues.E_VAL, DefaultValues.LENGTH, True, str(top_dir))
+    assert sorted(rp.results) == ["bin_0", "bin_1", "bin_2"]
+    want_files = {}
+    for b in range(3):
+        binId = "bin_%d" % b
+        mh, _gc = ro.reduce_bin(texts[b], omodels, dat, [sorted(s) for s in sets[binId].selectedMarkerSet().markerSet])
+        orfs = {r[0]: r[2] for r in recs_all[b]}
+        for marker, hits in mh.items():
+            top = sorted(hits, key=lambda h: h["full_e_value"], reverse=True)[0]
+            text = "".join(orfs[s][:-1] if orfs[s].endswith("*") else orfs[s] for s in top["target_name"].split("&&"))
+            rc, path = hs.align(slot[marker], p7.digitize(text))
+            want_files.setdefault(marker, []).append(">%s&&%s [e-value=%.4g,score=%.1f]\n%s\n" % (binId, top["target_name"], top["full_e_value"], top["full_score"],
+                                                                                                "".join(text.upper()[i - 1] if i > 0 else "-" for i in path)))
+    assert len(want_files) >= 10
+    for marker in models["bin_0"]:
+        f = top_dir / (marker + ".masked.faa")
+        if marker in want_files:
+            assert f.read_text() == "".join(want_files[marker]), marker
+        else:
+            assert not f.exists()
     a = AminoAcidIdentity()
     a.run(0.9, str(out), str(out / "pairs.txt"))
     assert set(a.aaiMeanBinHetero) <= {"bin_0", "bin_1", "bin_2"} and len(a.aaiMeanBinHetero) >= 1
