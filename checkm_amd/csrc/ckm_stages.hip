@@ -124,20 +124,25 @@ void rescore_envelopes(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, co
   size_t done = 0;
   const uint64_t budget_floats = ctx->ws_budget / 4;
   while (done < req.size()) {
-    FbBatch b; uint64_t pos = 0; size_t j = done;
+    FbBatch b; uint64_t pos = 0, path_total = 0; size_t j = done;
     for (; j < req.size(); ++j) {
       const EnvReq &r = req[j];
       const int Mp = p->prof[r.model].fbQ * NL, Ld = r.jenv - r.ienv + 1;
       FbWork w; memset(&w, 0, sizeof(w));
-      uint64_t end = env_floats(Mp, Ld, w.xs_off, w.aux_off, w.mxf_off, w.mxb_off, pos);
-      if (paths) { w.path_off = end + 1; end += (uint64_t)Mp; }          // match-state residues of the OA path (alignment requests)
-      if (end > budget_floats && j > done) break;
-      if (end > budget_floats) throw Error(CKM_ENOMEM, "one envelope needs more workspace than the device budget allows");
+      const uint64_t end = env_floats(Mp, Ld, w.xs_off, w.aux_off, w.mxf_off, w.mxb_off, pos);
+      const uint64_t need = end + path_total + (paths ? (uint64_t)Mp : 0);
+      if (need > budget_floats && j > done) break;
+      if (need > budget_floats) throw Error(CKM_ENOMEM, "one envelope needs more workspace than the device budget allows");
       w.model = r.model; w.seq = r.seq; w.i0 = r.ienv - 1; w.Ld = Ld; w.Lcfg = s->len[r.seq]; w.multihit = 0; w.slot = (uint32_t)(j - done); w.full = 1;
+      if (paths) { w.path_off = path_total + 1; path_total += (uint64_t)Mp; }      // relative for now: the zone starts behind the last item
       b.work.push_back(w); pos = end;
     }
-    ctx->ws.ensure(pos * 4 + 256);
+    const uint64_t zone = (pos + 31) & ~(uint64_t)31;          // match-state residues of the OA paths (alignment requests), one copy back
+    if (paths) for (auto &w : b.work) w.path_off += zone;
+    ctx->ws.ensure((zone + path_total) * 4 + 256);
     run_fb(ctx, p, s, b, true, true, true, nullptr);
+    std::vector<int32_t> zone_host;
+    if (paths && path_total) { zone_host.resize(path_total); wcopy(ctx, zone_host.data(), ctx->ws.as<int32_t>() + zone, path_total * 4, hipMemcpyDeviceToHost); }
     EventIndex ei; ei.build(b.events, b.work.size());
     for (size_t k = 0; k < b.work.size(); ++k) {
       const EnvReq &r = req[done + k]; EnvRes &o = out[done + k];
@@ -151,7 +156,7 @@ void rescore_envelopes(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, co
       if (paths) {
         std::vector<int32_t> &pv = (*paths)[done + k];
         pv.assign((size_t)p->hmm[r.model].M, 0);
-        if (o.ok) wcopy(ctx, pv.data(), ctx->ws.as<int32_t>() + (b.work[k].path_off - 1), pv.size() * 4, hipMemcpyDeviceToHost);
+        if (o.ok) std::copy(zone_host.begin() + (b.work[k].path_off - 1 - zone), zone_host.begin() + (b.work[k].path_off - 1 - zone) + pv.size(), pv.begin());
       }
     }
     done = j;
