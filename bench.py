@@ -218,7 +218,7 @@ def main():
                             "fwd": int(st.pairs_fwd), "dom": int(st.pairs_dom), "envelopes": int(st.envelopes), "regions_multi": int(st.regions_multi)},
             "rows": int(nrows), "setup_s": {"generate": t_gen, "pack_and_upload": t_pack},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # rank 0 at N=1 only: the other ranks would wait at the process-group teardown
             out["cpu_baseline"] = cpu_baseline(hmm_path, bins, args.cpu_baseline_seconds, args.cpu_baseline_threads)
         else:
             out["cpu_baseline"] = None
