@@ -391,3 +391,57 @@ def test_register_class_boundaries(gpu_ctx):
     _compare_search(w, hits, None)
     assert len(set(int(hits.model[g]) for g in hits.rows(0))) >= len(lengths) - 2       # (nearly) every model finds its planted target
     hits.close(); prof.close(); seqs.close(); hs.close()
+
+
+def test_ragged_model_subsets_single_and_multi_worker(gpu_ctx):
+    """lineage_wf shape at some breadth: 8 bins, each with its own random subset of the models in its own order (one bin lists a
+    model twice, one bin has no models), against the oracle bin by bin -- and the same search on 3 workers (sequence-length
+    classes) in a fresh process must return the same rows."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np
+from checkm_amd import _lib, synth
+from tests import common
+profs = common.mixed_profiles(); path = common.hmm_file("mixed", profs)
+rng = np.random.default_rng(123)
+bins = [synth.make_bin(profs, 3000 + b, n_orfs=70, dup_frac=0.3) for b in range(8)]
+bin_models = []
+for b in range(8):
+    k = int(rng.integers(3, 13))
+    bin_models.append([int(x) for x in rng.permutation(len(profs))[:k]])
+bin_models[2] = bin_models[2] + [bin_models[2][0]]
+bin_models[5] = []
+ctx = _lib.Context(0); prof = _lib.Profiles(ctx, path); seqs = _lib.Seqs(ctx, bins)
+hits = _lib.search(ctx, prof, seqs, bin_models)
+rows = [[b, int(hits.seq[i]), int(hits.model[i]), int(hits.dom_idx[i]), int(hits.ndom[i]), int(hits.env_from[i]), int(hits.env_to[i]), int(hits.ali_from[i]), int(hits.ali_to[i]),
+         int(np.float32(hits.full_score[i]).view(np.uint32)), int(np.float32(hits.dom_score[i]).view(np.uint32)), float(hits.full_evalue[i]), float(hits.i_evalue[i])]
+        for b in range(8) for i in hits.rows(b)]
+print(json.dumps({"rows": rows, "bin_models": bin_models}))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    results = []
+    for extra in (dict(CKM_WORKERS="1"), dict(CKM_WORKERS="3", CKM_WORKER_MIN_PAIRS="1")):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, (extra, out.stderr[-2000:])
+        results.append(json.loads(out.stdout.strip().split("\n")[-1]))
+    assert results[0]["rows"] == results[1]["rows"] and len(results[0]["rows"]) > 30
+    # the oracle, bin by bin, with the bin's own model list and order
+    profs = common.mixed_profiles()
+    hs = p7.HmmSet(common.hmm_file("mixed", profs))
+    bins = [synth.make_bin(profs, 3000 + b, n_orfs=70, dup_frac=0.3) for b in range(8)]
+    got = results[0]["rows"]; bin_models = results[0]["bin_models"]
+    off = 0; at = 0
+    for b, recs in enumerate(bins):
+        rows = hs.search(bin_models[b], [p7.digitize(r[2]) for r in recs], [r[0] for r in recs]) if bin_models[b] else []
+        mine = [g for g in got if g[0] == b]
+        assert len(mine) == len(rows), (b, len(mine), len(rows))
+        for g, r in zip(mine, rows):
+            assert g[1:9] == [r.seq_idx + off, r.model_idx, r.dom_idx, r.ndom, r.env_from, r.env_to, r.ali_from, r.ali_to], (b, g, r.seq_idx)
+            assert g[9] == int(common.float_bits(r.full_score)) and g[10] == int(common.float_bits(r.dom_score)) and g[11] == r.full_evalue and g[12] == r.i_evalue
+        off += len(recs)
+    assert sum(1 for g in got if g[0] == 5) == 0
+    hs.close()
