@@ -1196,14 +1196,14 @@ static void domain_definition(const PROF *p, const uint8_t *dsq, int L, const fl
         if (getenv("P7O_TRACE_REGIONS")) fprintf(stderr, "p7o: multi-domain region %d..%d of L=%d (M=%d)\n", i, j, L, p->M);
         int Lr = j - i + 1, cap = Lr < 16 ? Lr : 16, ens_rc;
         float *n2sum = malloc(sizeof(float) * Lr);
-        P7O_SEG *seg_all = malloc(sizeof(P7O_SEG) * (size_t)ENS_NSAMPLES * cap), env[64]; int nseg_all[ENS_NSAMPLES];
+        P7O_SEG *seg_all = malloc(sizeof(P7O_SEG) * (size_t)ENS_NSAMPLES * cap), *env = malloc(sizeof(P7O_SEG) * (size_t)Lr); int nseg_all[ENS_NSAMPLES];
         /* a trace with more domains than segment slots: repeat with a larger table (a trace holds at most Lr domains) */
         while ((ens_rc = trace_ensemble(p, dsq, L, i, j, n2sum, seg_all, nseg_all, cap)) != 0 && cap < Lr) {
           cap = cap * 8 < Lr ? cap * 8 : Lr; seg_all = realloc(seg_all, sizeof(P7O_SEG) * (size_t)ENS_NSAMPLES * cap);
         }
         if (ens_rc == 0) {
           for (int pos = i; pos <= j; pos++) dd->n2sc[pos] = logf(n2sum[pos-i] / (float)ENS_NSAMPLES);
-          int nenv = cluster_ensemble(seg_all, nseg_all, cap, env, 64), last_j2 = 0;
+          int nenv = cluster_ensemble(seg_all, nseg_all, cap, env, Lr), last_j2 = 0;
           for (int e = 0; e < nenv; e++) {
             int i2 = env[e].sqfrom + i - 1, j2 = env[e].sqto + i - 1;
             if (i2 <= last_j2) continue;          /* overlapping envelopes: the later one is skipped, as HMMER does */
@@ -1212,7 +1212,7 @@ static void domain_definition(const PROF *p, const uint8_t *dsq, int L, const fl
             last_j2 = j2;
           }
         }
-        free(n2sum); free(seg_all);
+        free(n2sum); free(seg_all); free(env);
       } else {
         DOMAIN d; memset(&d, 0, sizeof(d)); dd->nenvelopes++;
         if (rescore_envelope(p, dsq, L, i, j, dd->n2sc, 0, &d, NULL, NULL, NULL) == 0) ddef_add(dd, &d);

@@ -303,6 +303,16 @@ def _tandem_records(profs, seed, n_per_model=2):
                     parts.append(synth.sample_domain(rng, pr, a, b))
             parts.append(synth.random_residues(rng, 12))
             recs.append(("tandem%d_%d" % (mi, r + 1), "", synth.to_text(np.concatenate(parts)) + "*"))
+    # thirty fragments in a row: the sampled traces hold ~30 domains, more than the 16 segment slots of the first attempt,
+    # so the ensemble is repeated with a larger table (on both sides)
+    for mi in (0, 1, 4):
+        pr = profs[mi]; M = pr.M
+        parts = [synth.random_residues(rng, 8)]
+        for c in range(30):
+            a = int(rng.integers(1, M // 2)); b = int(rng.integers(a + M // 4, M + 1))
+            parts.append(synth.sample_domain(rng, pr, a, b))
+        parts.append(synth.random_residues(rng, 8))
+        recs.append(("tandem%d_%d" % (mi, n_per_model + 1), "", synth.to_text(np.concatenate(parts)) + "*"))
     return recs
 
 
@@ -346,7 +356,7 @@ def test_search_multidomain_rows_identical(tandem):
     _compare_search(w, hits, None)
     st = w["ctx"].stats()
     assert st.regions_multi >= len(w["recs"]) // 2, st.regions_multi
-    assert max(hits.ndom[g] for g in hits.rows(0)) >= 2
+    assert max(hits.ndom[g] for g in hits.rows(0)) >= 10        # the thirty-fragment targets
     hits.close()
 
 
