@@ -11,9 +11,6 @@ double g_trace_t0 = 0;
 
 }  // namespace
 
-struct SearchPlan {        // which models run against which sequence lists
-  std::vector<std::vector<uint32_t>> model_bins;   // per model: bins (sorted)
-};
 
 typedef std::map<std::pair<uint32_t, uint32_t>, std::vector<Hit>> HitMap;     // (bin, model) -> hits
 
