@@ -97,3 +97,50 @@ def test_sampled_pairs_against_the_oracle(world):
         for f in ("msv_sc", "bias_sc", "vit_sc", "fwd_sc", "fwd_xC"):
             assert np.float32(getattr(o, f)).view(np.uint32) == np.float32(getattr(got[i], f)).view(np.uint32), (m, s, f)
     hs.close(); seqs.close()
+
+
+def test_many_models_with_ragged_subsets(gpu_ctx):
+    """lineage_wf breadth: a 300-profile DB, 16 bins of 400 ORFs, every bin with its own random subset of 60-140 models in its own
+    order (~650 k pairs).  Properties: searching a bin alone gives the rows it gets in the batch (Z and domZ are per bin, the plan
+    is per bin), every planted marker of a listed model is reported, and two bins are checked against the oracle on 12 of their
+    models each."""
+    rng = np.random.default_rng(77)
+    lengths = rng.integers(40, 700, size=300)
+    profs = []
+    for i, M in enumerate(lengths):
+        p = synth.random_profile(rng, int(M), "FAM%04d" % i, ("PF%05d.1" % (10000 + i)) if i % 3 else ("TIGR%05d" % (10000 + i)))
+        p.stats = (-8.5 - 0.002 * int(M), 0.71, -9.5 - 0.002 * int(M), 0.71, -3.8, 0.71)
+        profs.append(p)
+    path = common.hmm_file("many300", profs)
+    nb = 16
+    bin_models = [[int(x) for x in rng.permutation(300)[:int(rng.integers(60, 141))]] for _ in range(nb)]
+    bins = []
+    for b in range(nb):
+        sub = [profs[m] for m in bin_models[b][:25]]                      # plant 25 of the bin's models
+        bins.append(synth.make_bin(sub, 7000 + b, n_orfs=400, dup_frac=0.1))
+    prof = _lib.Profiles(gpu_ctx, path)
+    seqs = _lib.Seqs(gpu_ctx, bins)
+    hits = _lib.search(gpu_ctx, prof, seqs, bin_models)
+    st = gpu_ctx.stats()
+    assert st.pairs_ssv == sum(len(bins[b]) * len(bin_models[b]) for b in range(nb))
+    base = np.concatenate([[0], np.cumsum([len(b) for b in bins])])
+    ref = [_rows(hits, b, int(base[b])) for b in range(nb)]
+    for b in range(nb):
+        found = set(r[1] for r in ref[b])
+        assert len(set(bin_models[b][:25]) - found) <= 2, (b, sorted(set(bin_models[b][:25]) - found))      # a planted ORF split in two halves can fall below E
+        assert found <= set(bin_models[b])
+    for b in (3, 11):                                                       # a bin searched alone
+        s1 = _lib.Seqs(gpu_ctx, [bins[b]])
+        h1 = _lib.search(gpu_ctx, prof, s1, [bin_models[b]])
+        assert _rows(h1, 0, 0) == ref[b], b
+        h1.close(); s1.close()
+    hs = p7.HmmSet(path)
+    for b in (0, 9):
+        sub = bin_models[b][:12]
+        rows = hs.search(sub, [p7.digitize(r[2]) for r in bins[b]], [r[0] for r in bins[b]])
+        mine = [r for r in ref[b] if r[1] in set(sub)]
+        assert len(rows) == len(mine) >= 12
+        for o, g in zip(rows, mine):
+            assert (o.seq_idx, o.model_idx, o.full_evalue, common.float_bits(o.full_score), common.float_bits(o.dom_score), o.hmm_from, o.hmm_to, o.ali_from, o.ali_to,
+                    o.env_from, o.env_to, o.c_evalue) == g, (b, o.seq_idx, o.model_idx)
+    hits.close(); seqs.close(); prof.close(); hs.close()
