@@ -86,10 +86,15 @@ def main():
     from checkm_amd import qa as cqa
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
-    torch.cuda.set_device(local_rank)
+    # (test hooks: CKM_BENCH_DEVICE pins every rank to one device and CKM_BENCH_DIST_BACKEND=gloo keeps the collectives on the host, so
+    #  the multi-rank control flow can be exercised on a one-GPU box; the driver's runs use neither)
+    dev_index = int(os.environ.get("CKM_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("CKM_BENCH_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        cdist.init_process_group("nccl")
-    dev = torch.device("cuda", local_rank)
+        cdist.init_process_group(backend)
+    dev = torch.device("cuda", dev_index) if backend == "nccl" else None
+    local_rank = dev_index
 
     # ---- inputs (synthetic, fixed seeds): profiles + this rank's bins, packed and resident in HBM ----
     profs = synth.cpr43_profiles()
@@ -170,7 +175,7 @@ def main():
             sync()
             dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if dev is not None else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     per_step = dt / args.steps
