@@ -171,36 +171,171 @@ class ResultsManager(object):
         return summary
 
     def printSummary(self, outputFormat, aai, binMarkerSets, bIndividualMarkers, coverageBinProfiles=None, table=None, anaFolder=None):
-        """Formats 1 and 2 (the QA table rows, resultsParser.py:680-764)."""
-        sel = binMarkerSets.selectedMarkerSet()
-        lineage = sel.lineageStr
-        if sel.UID != '0':
-            lineage += ' (' + str(sel.UID) + ')'
-        data = self.geneCountsForSelectedMarkerSet(binMarkerSets, bIndividualMarkers)
+        """One bin in output formats 1-9 (resultsParser.py:678-966); returns the number of reported rows for formats 6 and 7, else 0."""
         het = aai.aaiMeanBinHetero.get(self.binId, 0.0) if aai is not None else 0.0
+        if outputFormat in (1, 2):
+            sel = binMarkerSets.selectedMarkerSet()
+            lineage = sel.lineageStr
+            if sel.UID != '0':
+                lineage += ' (' + str(sel.UID) + ')'
+            data = self.geneCountsForSelectedMarkerSet(binMarkerSets, bIndividualMarkers)
         if outputFormat == 1:
             if table is None:
                 print("%s\t%s\t%d\t%d\t%d\t%s\t%0.2f\t%0.2f\t%0.2f" % (self.binId, lineage, sel.numGenomes, sel.numMarkers(), sel.numSets(),
                                                                            "\t".join(str(data[i]) for i in range(6)), data[6], data[7], het))
             else:
-                table.add_row([self.binId, lineage, sel.numGenomes, sel.numMarkers(), sel.numSets()] + data[0:6] + [data[6], data[7], het])
+                table.add_row([self.binId, lineage, sel.numGenomes, sel.numMarkers(), sel.numSets()] + data + [het])
         elif outputFormat == 2:
-            bs = self.binStats or {}
-            cols = [self.binId, lineage, sel.numGenomes, sel.numMarkers(), sel.numSets(), data[6], data[7], het]
-            for k in ('Genome size', '# ambiguous bases', '# scaffolds', '# contigs', 'N50 (scaffolds)', 'N50 (contigs)',
-                      'Mean scaffold length', 'Mean contig length', 'Longest scaffold', 'Longest contig'):
-                cols.append(bs.get(k, 0))
-            cols += [bs.get('GC', 0.0) * 100, bs.get('GC std', 0.0) * 100, bs.get('Coding density', 0.0) * 100,
-                     bs.get('Translation table', 0), bs.get('# predicted genes', 0)] + data[0:6]
+            bs = self.binStats
             if table is None:
-                print("\t".join(("%0.2f" % c) if isinstance(c, float) else str(c) for c in cols))
+                row = self.binId
+                row += '\t%s\t%d\t%d\t%d' % (lineage, sel.numGenomes, sel.numMarkers(), sel.numSets())
+                row += '\t%0.2f\t%0.2f\t%0.2f' % (data[6], data[7], het)
+                row += '\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d' % (bs['Genome size'], bs['# ambiguous bases'], bs['# scaffolds'], bs['# contigs'],
+                                                                     bs['N50 (scaffolds)'], bs['N50 (contigs)'], bs['Mean scaffold length'],
+                                                                     bs['Mean contig length'], bs['Longest scaffold'], bs['Longest contig'])
+                row += '\t%.1f\t%.2f' % (bs['GC'] * 100, bs['GC std'] * 100)
+                row += '\t%.2f\t%d\t%d' % (bs['Coding density'] * 100, bs['Translation table'], bs['# predicted genes'])
+                row += '\t' + '\t'.join(str(data[i]) for i in range(6))
+                if coverageBinProfiles:
+                    if self.binId in coverageBinProfiles:
+                        for _, cov in coverageBinProfiles[self.binId].items():
+                            row += '\t%.2f\t%.2f' % (cov[0], cov[1])
+                    else:
+                        for _bam in coverageBinProfiles[list(coverageBinProfiles.keys())[0]]:
+                            row += '\t%.2f\t%.2f' % (0, 0)
+                print(row)
             else:
-                table.add_row(cols)
+                row = [self.binId, lineage, sel.numGenomes, sel.numMarkers(), sel.numSets(), data[6], data[7], het]
+                row.extend([bs['Genome size'], bs['# ambiguous bases'], bs['# scaffolds'], bs['# contigs'], bs['N50 (scaffolds)'], bs['N50 (contigs)'],
+                            int(bs['Mean scaffold length']), int(bs['Mean contig length']), bs['Longest scaffold'], bs['Longest contig']])
+                row.extend([bs['GC'] * 100, bs['GC std'] * 100, bs['Coding density'] * 100, bs['Translation table'], bs['# predicted genes']])
+                row.extend(data[0:6])
+                if coverageBinProfiles:
+                    if self.binId in coverageBinProfiles:
+                        for _, cov in coverageBinProfiles[self.binId].items():
+                            row.extend(cov)
+                    else:
+                        for _bam in coverageBinProfiles[list(coverageBinProfiles.keys())[0]]:
+                            row.extend([0, 0])
+                table.add_row(row)
+        elif outputFormat == 3:
+            for ms in binMarkerSets.markerSetIter():
+                data = self.geneCounts(ms, self.markerHits, bIndividualMarkers)
+                if table is None:
+                    print("%s\t%s\t%s\t%d\t%d\t%d\t%s\t%0.2f\t%0.2f\t%0.2f" % (self.binId, ms.UID, ms.lineageStr, ms.numGenomes, ms.numMarkers(), ms.numSets(),
+                                                                                   "\t".join(str(data[i]) for i in range(6)), data[6], data[7], het))
+                else:
+                    table.add_row([self.binId, ms.UID, ms.lineageStr, ms.numGenomes, ms.numMarkers(), ms.numSets()] + data + [het])
+        elif outputFormat == 4:
+            sel = binMarkerSets.selectedMarkerSet()
+            data = self.hitsToMarkerGene(sel)
+            row = "Node Id: %s; Marker lineage: %s" % (sel.UID, sel.lineageStr)
+            for marker in data:
+                row += '\t' + marker
+            print(row)
+            row = self.binId
+            for count in data.values():
+                row += '\t' + str(count)
+            print(row)
+            print()
+        elif outputFormat == 5:
+            genes = binMarkerSets.selectedMarkerSet().getMarkerGenes()
+            for marker, hit_list in self.markerHits.items():
+                if marker not in genes:
+                    continue
+                for hit in hit_list:
+                    print(self.binId, marker, hit.target_name, sep='\t', end='\n')
+        elif outputFormat == 6:
+            genes = binMarkerSets.selectedMarkerSet().getMarkerGenes()
+            reported = 0
+            for marker, hit_list in self.markerHits.items():
+                if marker not in genes:
+                    continue
+                if len(hit_list) >= 2:
+                    print(self.binId, marker, sep='\t', end='\t')
+                    print(','.join(sorted(h.target_name for h in hit_list)), end='\n')
+                    reported += 1
+            return reported
+        elif outputFormat == 7:
+            genes = binMarkerSets.selectedMarkerSet().getMarkerGenes()
+            reported = 0
+            for marker, hit_list in self.markerHits.items():
+                if marker not in genes:
+                    continue
+                if len(hit_list) >= 2:
+                    same = set()
+                    for i in range(len(hit_list)):
+                        scaffold = hit_list[i].target_name[0:hit_list[i].target_name.rfind('_')]
+                        for j in range(i + 1, len(hit_list)):
+                            if scaffold == hit_list[j].target_name[0:hit_list[j].target_name.rfind('_')]:
+                                same.add(hit_list[i].target_name)
+                                same.add(hit_list[j].target_name)
+                    if len(same) >= 2:
+                        print(self.binId, marker, sep='\t', end='\t')
+                        print(','.join(sorted(list(same))), end='\n')
+                        reported += 1
+            return reported
+        elif outputFormat == 8:
+            genes = binMarkerSets.selectedMarkerSet().getMarkerGenes()
+            per_gene = {}
+            for marker, hit_list in self.markerHits.items():
+                if marker not in genes:
+                    continue
+                for hit in hit_list:
+                    per_gene[hit.target_name] = per_gene.get(hit.target_name, []) + [hit]
+            for gene, hits in per_gene.items():
+                row = self.binId + '\t' + gene
+                for hit in hits:
+                    row += '\t' + hit.query_accession + ',' + str(hit.ali_from) + ',' + str(hit.ali_to)
+                print(row)
+        elif outputFormat == 9:
+            if anaFolder is None:
+                raise ValueError("AnaFolder must not be None for outputFormat 9")
+            genes = binMarkerSets.selectedMarkerSet().getMarkerGenes()
+            info = {}
+            for marker, hit_list in self.markerHits.items():
+                if marker not in genes:
+                    continue
+                for hit in hit_list:
+                    info[hit.target_name] = {"marker": marker, "ali_from": str(hit.ali_from), "ali_to": str(hit.ali_to)}
+            seqs = _read_fasta_full_headers("/".join([anaFolder, "bins", self.binId, "genes.faa"]))
+            kept = [h for h in seqs.keys() if h.split(" # ")[0] in info]
+
+            def by_contig_and_gene(header):
+                ctg, num = header.split(" # ")[0].rsplit("_", 1)
+                return ctg, int(num)
+            for header in sorted(kept, key=by_contig_and_gene):
+                elems = header.split(" # ")
+                gene = elems[0]
+                contig, num = gene.rsplit("_", 1)
+                start, end, strand = elems[1], elems[2], elems[3]
+                if table is not None:       # (sic) the reference prints FASTA when a table object is given and a tab row when it is not
+                    gene_info = "geneId={};start={};end={};strand={};protlen={}".format(num, start, end, strand, str(len(seqs[header])))
+                    marker_info = "marker={};mstart={};mend={}".format(info[gene]["marker"], info[gene]["ali_from"], info[gene]["ali_to"])
+                    print(">" + " ".join([self.binId, contig, gene_info, marker_info]), seqs[header], sep="\n")
+                else:
+                    print("\t".join([self.binId, contig, num, start, end, strand, str(len(seqs[header])), info[gene]["marker"], info[gene]["ali_from"],
+                                     info[gene]["ali_to"], seqs[header]]))
         else:
-            self.logger = logging.getLogger('timestamp')
-            self.logger.error("Output format %d is not part of the accelerated path." % outputFormat)
-            sys.exit(1)
+            logging.getLogger('timestamp').error("Unknown output format: %d", outputFormat)
         return 0
+
+
+def _read_fasta_full_headers(path):
+    """header line (without '>') -> residues; every sequence line loses its last character, i.e. the newline
+    (checkm/util/seqUtils.py:180-211 with trimHeader=False)."""
+    seqs, cur = {}, None
+    with open(path) as f:
+        for line in f:
+            if not line.strip():
+                continue
+            if line[0] == '>':
+                cur = line[1:].rstrip()
+                seqs[cur] = []
+            else:
+                seqs[cur].append(line[0:-1])
+    return {k: ''.join(v) for k, v in seqs.items()}
 
 
 def _marker_hits_from(res, b, keys, row_to_hit):
@@ -365,35 +500,67 @@ class ResultsParser(object):
 
     # ---- output ------------------------------------------------------------------------------------
     def _getHeader(self, outputFormat, binMarkerSets=None, coverageBinProfiles=None, table=None):
+        """Column names of every output format (resultsParser.py:219-273)."""
         if outputFormat == 1:
             return ['Bin Id', 'Marker lineage', '# genomes', '# markers', '# marker sets', '0', '1', '2', '3', '4', '5+',
                     'Completeness', 'Contamination', 'Strain heterogeneity']
         if outputFormat == 2:
-            return ['Bin Id', 'Marker lineage', '# genomes', '# markers', '# marker sets', 'Completeness', 'Contamination',
-                    'Strain heterogeneity', 'Genome size (bp)', '# ambiguous bases', '# scaffolds', '# contigs', 'N50 (scaffolds)',
-                    'N50 (contigs)', 'Mean scaffold length (bp)', 'Mean contig length (bp)', 'Longest scaffold (bp)',
-                    'Longest contig (bp)', 'GC', 'GC std (scaffolds > 1kbp)', 'Coding density', 'Translation table',
-                    '# predicted genes', '0', '1', '2', '3', '4', '5+']
-        return None
+            header = ['Bin Id', 'Marker lineage', '# genomes', '# markers', '# marker sets', 'Completeness', 'Contamination',
+                      'Strain heterogeneity', 'Genome size (bp)', '# ambiguous bases', '# scaffolds', '# contigs', 'N50 (scaffolds)',
+                      'N50 (contigs)', 'Mean scaffold length (bp)', 'Mean contig length (bp)', 'Longest scaffold (bp)',
+                      'Longest contig (bp)', 'GC', 'GC std (scaffolds > 1kbp)', 'Coding density', 'Translation table',
+                      '# predicted genes', '0', '1', '2', '3', '4', '5+']
+            if coverageBinProfiles is not None:
+                for bamId in coverageBinProfiles[list(coverageBinProfiles.keys())[0]]:
+                    header += ['Coverage (' + bamId + ')', 'Coverage std (' + bamId + ')']
+            return header
+        if outputFormat == 3:
+            return ['Bin Id', 'Node Id', 'Marker lineage', '# genomes', '# markers', '# marker sets', '0', '1', '2', '3', '4', '5+',
+                    'Completeness', 'Contamination', 'Strain heterogeneity']
+        if outputFormat == 4:
+            return None
+        if outputFormat == 5:
+            return ['Bin Id', 'Marker Id', 'Gene Id']
+        if outputFormat in (6, 7):
+            return ['Bin Id', 'Marker Id', 'Gene Ids']
+        if outputFormat == 8:
+            return ['Bin Id', 'Gene Id', '{Marker Id, Start position, End position}']
+        if outputFormat == 9:
+            if table is not None:
+                return ['Bin Id', 'Contig', 'Gene Number', 'Gene Start', 'Gene End', 'Gene Strand', 'Prot Length', 'Marker Id', 'Align Start', 'Align End',
+                        'Sequence']
+            return " "
+        if outputFormat == 10:
+            return ['Scaffold Id', 'Bin Id', 'Length', '# contigs', 'GC', '# ORFs', 'Coding density', 'Marker Ids']
 
     def printSummary(self, outputFormat, aai, binIdToBinMarkerSets, bIndividualMarkers, coverageFile, bTabTable, outFile, anaFolder):
-        if outputFormat not in (1, 2):
-            self.logger.error("Output format %d is not part of the accelerated path." % outputFormat)
+        """The QA table in any of the output formats (resultsParser.py:275-319).  Tab mode is byte-compatible with the reference; the framed
+        table of the non-tab mode (formats 1, 2, 3, 9) is drawn by _Table (prettytable is not a dependency here)."""
+        if coverageFile:
+            self.logger.error('Coverage profiles are not part of this path.')
             sys.exit(1)
         old = sys.stdout
         if outFile:
             sys.stdout = open(outFile, 'w')
         try:
-            header = self._getHeader(outputFormat)
+            header = self._getHeader(outputFormat, binIdToBinMarkerSets[list(binIdToBinMarkerSets.keys())[0]], None, bTabTable)
             table = None
-            if bTabTable:
-                print('\t'.join(header))
+            if bTabTable or outputFormat not in (1, 2, 3, 9):
+                bTabTable = True
+                if header is not None:
+                    print('\t'.join(header))
             else:
                 table = _Table(header)
+            reported = 0
             for binId in sorted(self.results.keys()):
-                self.results[binId].printSummary(outputFormat, aai, binIdToBinMarkerSets[binId], bIndividualMarkers, None, table, anaFolder)
-            if table is not None:
-                print(table.render('Completeness', True))
+                reported += self.results[binId].printSummary(outputFormat, aai, binIdToBinMarkerSets[binId], bIndividualMarkers, None, table, anaFolder)
+            if outputFormat in (6, 7) and reported == 0:
+                print('[No marker genes satisfied the reporting criteria.]')
+            if not bTabTable:
+                if outputFormat in (1, 2):
+                    print(table.render('Completeness', True))
+                elif table.rows:
+                    print(table.render())
         finally:
             if outFile:
                 sys.stdout.close()

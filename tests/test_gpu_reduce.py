@@ -89,3 +89,72 @@ def test_resident_hits_reduce_like_the_text_path(gpu_ctx, tmp_path):
             assert got == want, (flags, b)
         res.close()
     hits.close(); prof.close(); seqs.close()
+
+
+def test_summary_formats_match_reference_text(gpu_ctx, tmp_path):
+    """ResultsParser.printSummary in tab mode, output formats 1-9, with and without --individual_markers, byte for byte against the
+    text the reference's own classes printed for the same tables (tools/gen_summary_golden.py).  Format 4 lists the markers in the
+    iteration order of a Python set of strings (not reproducible between processes): compared as marker -> count maps."""
+    from checkm_amd.markerSets import BinMarkerSets
+    with open(GOLD) as f:
+        rcases = json.load(f)["cases"]
+    with open(os.path.join(os.path.dirname(GOLD), "summary_cases.json")) as f:
+        scases = json.load(f)["cases"]
+
+    class FakeAAI(object):
+        aaiMeanBinHetero = {"binA": 12.5}
+    root = tmp_path / "data"
+    (root / "pfam").mkdir(parents=True)
+    DefaultValues.set_data_root(str(root))
+    nok = nraise = 0
+    for sc in scases:
+        case = rcases[sc["reduce_case"]]
+        (root / "pfam" / "Pfam-A.hmm.dat").write_text(case["pfam_dat"])
+        work = tmp_path / ("w%d" % sc["reduce_case"])
+        models = {}
+        for m in case["models"]:
+            hm = HmmModel({"name": m["name"], "acc": m["acc"], "leng": m["leng"]})
+            hm.ga = tuple(m["ga"]) if m["ga"] else None
+            hm.tc = tuple(m["tc"]) if m["tc"] else None
+            hm.nc = tuple(m["nc"]) if m["nc"] else None
+            models[m["acc"]] = hm
+        binIds = ["binB", "binA"]
+        rp = ResultsParser({b: models for b in binIds})
+        bms = {}
+        for k, b in enumerate(binIds):
+            rm = ResultsManager(b, models, False, DefaultValues.E_VAL, DefaultValues.LENGTH, False, sc["bin_stats"][b])
+            (work / "bins" / b).mkdir(parents=True)
+            t = work / (b + ".txt")
+            t.write_text(case["domtblout"])
+            rp.parseHmmerResults(str(t), rm, k == 1)
+            rp.results[b] = rm
+            s = BinMarkerSets(b, BinMarkerSets.TAXONOMIC_MARKER_SET)
+            s.addMarkerSet(MarkerSet(7 + k, "k__Bacteria;p__Test", 100 + k, [set(x) for x in sc["marker_sets"]]))
+            s.addMarkerSet(MarkerSet(0, "root", 5000, [set(x) for x in sc["marker_sets"][:1]]))
+            bms[b] = s
+            (work / "bins" / b / "genes.faa").write_text(sc["genes_faa"][b])
+        for key, want in sc["outputs"].items():
+            fmt, indiv = int(key.split("_")[0]), key.endswith("_1")
+            of = str(work / ("out_%s.txt" % key))
+            if isinstance(want, dict):
+                with pytest.raises(Exception) as e:
+                    rp.printSummary(fmt, FakeAAI(), bms, indiv, None, True, of, str(work))
+                assert type(e.value).__name__ == want["raises"], (sc["reduce_case"], key)
+                nraise += 1
+                continue
+            rp.printSummary(fmt, FakeAAI(), bms, indiv, None, True, of, str(work))
+            got = open(of).read()
+            if fmt == 4:
+                def as_maps(txt):
+                    blocks = [b for b in txt.split("\n\n") if b.strip()]
+                    out = []
+                    for blk in blocks:
+                        h, r = blk.strip("\n").split("\n")
+                        hp, rv = h.split("\t"), r.split("\t")
+                        out.append((hp[0], rv[0], dict(zip(hp[1:], rv[1:]))))
+                    return out
+                assert as_maps(got) == as_maps(want), (sc["reduce_case"], key)
+            else:
+                assert got == want, (sc["reduce_case"], key, got[:300], want[:300])
+            nok += 1
+    assert nok >= 80 and nraise >= 1
