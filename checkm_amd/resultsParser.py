@@ -142,7 +142,7 @@ class ResultsManager(object):
                 summary[k] = data[i]
             summary['Completeness'] = data[6]
             summary['Contamination'] = data[7]
-            if outputFormat == 2 and self.binStats:
+            if outputFormat == 2:
                 summary.update(self.binStats)
         elif outputFormat == 5:
             genes = binMarkerSets.selectedMarkerSet().getMarkerGenes()
@@ -154,6 +154,19 @@ class ResultsManager(object):
             for marker, hl in self.markerHits.items():
                 if marker in genes and len(hl) >= 2:
                     summary[marker] = [h.target_name for h in hl]
+        elif outputFormat == 7:
+            # genes that carry more than one copy of the same marker (resultsParser.py:633-653)
+            genes = binMarkerSets.selectedMarkerSet().getMarkerGenes()
+            per_gene = defaultdict(dict)
+            for marker, hl in self.markerHits.items():
+                if marker not in genes:
+                    continue
+                for h in hl:
+                    per_gene[h.target_name][marker] = per_gene[h.target_name].get(marker, 0) + 1
+            for gene, counts in per_gene.items():
+                for marker, n in counts.items():
+                    if n > 1:
+                        summary.setdefault(gene, {})[marker] = n
         elif outputFormat == 8:
             genes = binMarkerSets.selectedMarkerSet().getMarkerGenes()
             per_gene = {}

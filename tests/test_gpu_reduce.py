@@ -1,6 +1,7 @@
 """GPU parity of the reduce half: libcheckm_hip's ckm_reduce / ckm_count_sets (through the Python
 mirror classes) against the goldens produced by the reference's own classes.
 Bar: integer-identical hit lists and histograms; completeness/contamination bit-identical float64."""
+import ast
 import json
 import os
 
@@ -157,4 +158,14 @@ def test_summary_formats_match_reference_text(gpu_ctx, tmp_path):
             else:
                 assert got == want, (sc["reduce_case"], key, got[:300], want[:300])
             nok += 1
+        # the two caches `qa` leaves behind and the dictionaries they are made of (resultsParser.py:121-143, 567-676)
+        (work / "storage").mkdir()
+        rp.cacheResults(str(work), bms, False)
+        for name, want in sc["caches"].items():
+            assert (work / "storage" / name).read_text() == want, (sc["reduce_case"], name)
+        for b in binIds:
+            for f, want in sc["summaries"][b].items():
+                # compared as dictionaries: where the reference inserts markers without hits follows set hashing
+                got = rp.results[b].getSummary(bms[b], False, outputFormat=int(f))
+                assert got == ast.literal_eval(want), (sc["reduce_case"], b, f)
     assert nok >= 80 and nraise >= 1

@@ -83,7 +83,11 @@ def main():
                 except Exception as e:                      # e.g. format 9 on an ORF name without '_<n>'
                     sys.stdout = sys.__stdout__
                     outputs["%d_%d" % (fmt, int(indiv))] = {"raises": type(e).__name__}
-        out.append({"reduce_case": ci, "bin_stats": stats, "genes_faa": genes, "marker_sets": case["marker_sets"], "outputs": outputs})
+        os.makedirs(os.path.join(work, "storage"))
+        rp.cacheResults(work, bms, False)
+        caches = {n: open(os.path.join(work, "storage", n)).read() for n in (DefaultValues.BIN_STATS_EXT_OUT, DefaultValues.MARKER_GENE_STATS)}
+        summaries = {b: {str(f): repr(rp.results[b].getSummary(bms[b], False, outputFormat=f)) for f in (1, 2, 5, 6, 7, 8)} for b in binIds}
+        out.append({"caches": caches, "summaries": summaries, "reduce_case": ci, "bin_stats": stats, "genes_faa": genes, "marker_sets": case["marker_sets"], "outputs": outputs})
     json.dump({"generator": "tools/gen_summary_golden.py", "cases": out}, open(os.path.join(ROOT, "tests", "golden", "summary_cases.json"), "w"), indent=1)
     print("wrote summary_cases.json", len(out), "cases;", sum(len(v) for c in out for v in c["outputs"].values() if isinstance(v, str)), "bytes of table text")
 
