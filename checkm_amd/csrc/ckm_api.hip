@@ -53,7 +53,9 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
     std::unique_ptr<ckm_ctx> ctx(new ckm_ctx());
     ctx->device = device;
     memset(&ctx->stats, 0, sizeof(ctx->stats));
-    if (const char *e = getenv("CKM_WORKERS")) ctx->nworkers = std::max(1, std::min(NWORKERS, atoi(e)));
+    if (const char *e = getenv("CKM_WORKERS")) ctx->nclasses = std::max(1, std::min(NWORKERS, atoi(e)));
+    if (const char *e = getenv("CKM_BIN_GROUPS")) ctx->ngroups = std::max(1, std::min(NWORKERS / ctx->nclasses, atoi(e)));
+    ctx->nworkers = ctx->nclasses * ctx->ngroups;
     int host_threads = std::max(1, std::min(8, (int)std::thread::hardware_concurrency()));
     if (const char *e = getenv("CKM_HOST_THREADS")) host_threads = std::max(1, std::min(64, atoi(e)));
     size_t fre = 0, tot = 0;
@@ -62,6 +64,7 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
     if (const char *e = getenv("CKM_WS_BUDGET_MB")) budget = std::max<size_t>(16, strtoull(e, nullptr, 10)) << 20;   // tests: force several envelope batches
     for (auto &w : ctx->w) {
       w.device = device;
+      if (&w - ctx->w >= ctx->nworkers) continue;
       // non-blocking streams: nothing here may synchronise implicitly with the null stream or with another worker's streams
       HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
       HIPCHK(hipStreamCreateWithFlags(&w.ens_stream, hipStreamNonBlocking));
@@ -69,7 +72,7 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
       for (auto &e : w.ev) HIPCHK(hipEventCreate(&e));
       memset(&w.stats, 0, sizeof(w.stats));
       w.ws_budget = budget;
-      if (&w - ctx->w < ctx->nworkers) w.pool.reset(new HostPool(host_threads));
+      w.pool.reset(new HostPool(host_threads));
     }
     *out = ctx.release();
   });
@@ -80,6 +83,7 @@ extern "C" void ckm_ctx_destroy(ckm_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   for (auto &w : ctx->w) {
+    if (!w.stream) continue;
     for (auto &e : w.ev) (void)hipEventDestroy(e);
     for (auto &st : w.side) (void)hipStreamDestroy(st);
     (void)hipStreamDestroy(w.stream);

@@ -170,11 +170,12 @@ struct Worker {
   std::unique_ptr<HostPool> pool;         // host threads of this worker
 };
 
-constexpr int NWORKERS = 4;          // upper bound; CKM_WORKERS (default 3) selects how many a large search uses
+constexpr int NWORKERS = 8;          // upper bound; CKM_WORKERS (default 3) selects how many a large search uses
 
 struct ckm_ctx {
   int device = 0;
-  int nworkers = 3;
+  int nworkers = 3;                // = nclasses * ngroups
+  int nclasses = 3, ngroups = 1;   // length classes (CKM_WORKERS) x bin groups (CKM_BIN_GROUPS)
   DevBuf reduce_scratch;                  // grow-only device buffer of the reduce kernels
   Worker w[NWORKERS];
   ckm_search_stats stats;
@@ -291,6 +292,7 @@ double now_ms();
 float bits(float sc, float nullsc);
 float finish_forward(float xC, float move, const std::vector<float> &scales);
 int ssv_threads_for(int Q);
+int side_streams();
 void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, bool do_fwd, bool do_bwd, bool do_oa,
             const std::vector<uint32_t> *subset /* indices into b.work, or null = all */, float *ws_other = nullptr);
 void rescore_envelopes(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<EnvReq> &req, std::vector<EnvRes> &out,

@@ -109,7 +109,7 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
         if (attempt == 0) {
           // register classes go round-robin over 4 streams (heaviest first) so the tail of one launch -- a few very long
           // sequences -- is covered by the next launch; ev[0]..ev[1] on the main stream brackets all of them
-          constexpr int NS = 4;
+          const int NS = std::min(4, side_streams());
           for (int k = 0; k < NS; ++k) HIPCHK(hipStreamWaitEvent(ctx->side[k], ctx->ev[0], 0));
           int gi = 0;
           for (auto it = groups.rbegin(); it != groups.rend(); ++it, ++gi) {
@@ -210,7 +210,7 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
         int gi = 0;
         for (auto it = grp.rbegin(); it != grp.rend(); ++it, ++gi) {
           auto &g = *it;
-          if (launch_vit(g.first, ctx->side[gi % 4], ctx->cand.as<PairRec>(), ctx->fbidx.as<uint32_t>() + g.second.first, (uint32_t)g.second.second, dm, lt, res, off, dlen,
+          if (launch_vit(g.first, ctx->side[gi % std::min(4, side_streams())], ctx->cand.as<PairRec>(), ctx->fbidx.as<uint32_t>() + g.second.first, (uint32_t)g.second.second, dm, lt, res, off, dlen,
                          ctx->vitx.as<int32_t>(), ctx->vits.as<float>(), ctx->vitf.as<uint32_t>(), fast))
             throw Error(CKM_ERANGE, "no Viterbi kernel instance for this model length");
         }
@@ -457,31 +457,53 @@ static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, cons
   std::vector<std::vector<uint32_t>> chunk(nw);
   std::vector<SeqRange> ranges(nw);
   // cut lengths, descending: class k holds the sequences with cut[k-1] >= L > cut[k].  Default: the cuts that give the
-  // classes fixed shares of the residues (measured best on cfg2: 16 / 45 / 39 % for three workers, 60 / 40 for two).
+  // classes fixed shares of the residues (measured best on cfg2: 16 / 45 / 39 % for three classes, 60 / 40 for two);
+  // CKM_SHARES="0.16,0.61" gives the cumulative shares, CKM_LEN_SPLIT the cut lengths themselves.
+  // Worker k = group * nclasses + class: with CKM_BIN_GROUPS=G the bins are cut into G contiguous groups of about equal
+  // residue counts and every group runs its own set of classes (its post-filter stages then overlap the next group's SSV).
+  const int ncl = nw > 1 ? c->nclasses : 1, ngr = nw > 1 ? c->ngroups : 1;
   std::vector<int> cuts;
   if (const char *e = getenv("CKM_LEN_SPLIT")) {
     const std::string spec = e; size_t pos = 0;
     while (pos < spec.size()) { size_t q = spec.find(',', pos); if (q == std::string::npos) q = spec.size(); cuts.push_back(atoi(spec.substr(pos, q - pos).c_str())); pos = q + 1; }
     std::sort(cuts.begin(), cuts.end(), std::greater<int>());
-  } else if (nw >= 2) {
-    static const double shares2[] = {0.60}, shares3[] = {0.16, 0.61}, shares4[] = {0.10, 0.35, 0.65};
-    const double *sh = nw == 2 ? shares2 : nw == 3 ? shares3 : shares4;
+  } else if (ncl >= 2) {
+    std::vector<double> sh;
+    if (const char *e = getenv("CKM_SHARES")) {
+      const std::string spec = e; size_t pos = 0;
+      while (pos < spec.size()) { size_t q = spec.find(',', pos); if (q == std::string::npos) q = spec.size(); sh.push_back(atof(spec.substr(pos, q - pos).c_str())); pos = q + 1; }
+      std::sort(sh.begin(), sh.end());
+    }
+    if ((int)sh.size() != ncl - 1) {
+      if (ncl == 2) sh = {0.60}; else if (ncl == 3) sh = {0.16, 0.61}; else if (ncl == 4) sh = {0.10, 0.35, 0.65};
+      else { sh.clear(); for (int k = 1; k < ncl; ++k) sh.push_back((double)k / ncl); }
+    }
     std::vector<uint64_t> by_len((size_t)s->maxL + 2, 0);
     uint64_t total = 0;
     for (uint32_t i = 0; i < s->nseq; ++i) { by_len[s->len[i]] += (uint64_t)s->len[i]; total += (uint64_t)s->len[i]; }
     uint64_t acc = 0; int k = 0;
-    for (int L = s->maxL; L >= 1 && k < nw - 1; --L) { acc += by_len[L]; if ((double)acc >= sh[k] * (double)total) { cuts.push_back(L - 1); ++k; } }
-    while ((int)cuts.size() < nw - 1) cuts.push_back(0);
+    for (int L = s->maxL; L >= 1 && k < ncl - 1; --L) { acc += by_len[L]; if ((double)acc >= sh[k] * (double)total) { cuts.push_back(L - 1); ++k; } }
+    while ((int)cuts.size() < ncl - 1) cuts.push_back(0);
   }
-  if (nw >= 2 && (int)cuts.size() == nw - 1 && cuts.back() > 0) {
-    for (int k = 0; k < nw; ++k) { chunk[k] = active; ranges[k].lo.resize(nbins); ranges[k].hi.resize(nbins); ranges[k].res.assign(nbins, 0); ranges[k].tag = 1000 + (uint64_t)k; for (int cv : cuts) ranges[k].tag = ranges[k].tag * 4099 + (uint64_t)cv; }
+  if (nw >= 2 && (int)cuts.size() == ncl - 1 && (ncl == 1 || cuts.back() > 0)) {
+    // bin groups: contiguous, about equal residue counts
+    std::vector<int> group_of(nbins, 0);
+    {
+      uint64_t tot = 0, acc = 0; for (uint32_t b = 0; b < nbins; ++b) tot += s->bin_res[b];
+      for (uint32_t b = 0; b < nbins; ++b) { group_of[b] = std::min(ngr - 1, (int)((double)acc * ngr / std::max<double>(1.0, (double)tot))); acc += s->bin_res[b]; }
+    }
+    for (int k = 0; k < nw; ++k) { chunk[k] = active; ranges[k].lo.resize(nbins); ranges[k].hi.resize(nbins); ranges[k].res.assign(nbins, 0); ranges[k].tag = 1000 + (uint64_t)k + 64 * (uint64_t)ngr; for (int cv : cuts) ranges[k].tag = ranges[k].tag * 4099 + (uint64_t)cv; }
     for (uint32_t b = 0; b < nbins; ++b) {
       uint32_t at = s->order_off[b];
-      for (int k = 0; k < nw; ++k) {
-        const int cut = (k < nw - 1) ? cuts[k] : -1;
+      for (int cl = 0; cl < ncl; ++cl) {
+        const int cut = (cl < ncl - 1) ? cuts[cl] : -1;
         uint64_t r = 0; const uint32_t lo = at;
         while (at < s->order_off[b + 1] && s->len[s->order[at]] > cut) { r += (uint64_t)s->len[s->order[at]]; ++at; }
-        ranges[k].lo[b] = lo; ranges[k].hi[b] = at; ranges[k].res[b] = r;
+        for (int g = 0; g < ngr; ++g) {
+          const int k = g * ncl + cl;
+          if (g == group_of[b]) { ranges[k].lo[b] = lo; ranges[k].hi[b] = at; ranges[k].res[b] = r; }
+          else { ranges[k].lo[b] = lo; ranges[k].hi[b] = lo; ranges[k].res[b] = 0; }
+        }
       }
     }
   } else {

@@ -24,6 +24,14 @@ float finish_forward(float xC, float move, const std::vector<float> &scales) {
   return (float)((double)totscale + log((double)(xC * move)));
 }
 
+// Side streams a worker spreads the register classes of one stage over.  All workers together should stay within the
+// hardware queues of the device (GPU_MAX_HW_QUEUES): streams that share a queue run their kernels one behind the other,
+// and a short launch of one worker then waits behind a long one of another.
+int side_streams() {
+  static const int n = [] { const char *e = getenv("CKM_SIDE_STREAMS"); return e ? std::max(1, std::min(8, atoi(e))) : 8; }();
+  return n;
+}
+
 int ssv_threads_for(int Q) {
   const size_t lds = (size_t)NROWS * ((Q + 3) / 4) * 256;
   if (lds <= 40 * 1024) return 256;
@@ -77,8 +85,7 @@ void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, b
   // every register class runs its stages in order on its own stream; classes overlap each other
   size_t gi = 0;
   for (auto &g : groups) {
-    static const int nfb = [] { const char *e = getenv("CKM_FB_STREAMS"); return e ? std::max(1, std::min(8, atoi(e))) : 8; }();
-    hipStream_t st = ctx->side[gi++ % nfb];
+    hipStream_t st = ctx->side[gi++ % side_streams()];
     const uint32_t *ix = ctx->fbidx.as<uint32_t>() + g.blk0 * 4, *bm = ctx->fbmodel.as<uint32_t>() + g.blk0;
     if (do_fwd && launch_fwd(g.Q, (uint32_t)g.nblk, st, ctx->fbwork.as<FbWork>(), ix, bm, dm, lt, res, off, ws, ctx->fout.as<FwdOut>(),
                              ctx->events.as<ScaleEvent>(), ctx->counters.as<uint32_t>(), cap_events))
@@ -197,7 +204,7 @@ void run_msv_exact(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const 
   wcopy(ctx, ctx->msvlist.p, lists.data(), lists.size() * 4, hipMemcpyHostToDevice);
   int gi = 0;
   for (auto &g : groups) {
-    if (launch_msv(g.first, (int)g.second.second, ctx->side[gi++ % 8], ctx->msvwork.as<SsvBlockWork>() + g.second.first, p->d_models.as<DevModel>(), s->d_lentab.as<LenEntry>(),
+    if (launch_msv(g.first, (int)g.second.second, ctx->side[gi++ % side_streams()], ctx->msvwork.as<SsvBlockWork>() + g.second.first, p->d_models.as<DevModel>(), s->d_lentab.as<LenEntry>(),
                    s->d_res.as<uint8_t>(), s->d_off.as<uint64_t>(), s->d_len.as<int32_t>(), ctx->msvlist.as<uint32_t>(), ctx->fullx.as<int32_t>(), ctx->fullu.as<float>()))
       throw Error(CKM_ERANGE, "no MSV kernel instance for this model length");
   }

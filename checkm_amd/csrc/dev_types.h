@@ -19,7 +19,7 @@ struct DevModel {
   // filter thresholds (score space)
   float   thr_msv_f1, thr_msv_f2, thr_vit_f2, thr_fwd_f3;
   // tables in HBM
-  const int16_t *ssv_tbl;   // [30][Qg][16][8]
+  const int16_t *ssv_tbl;   // [Qg][30][16][8]
   const uint8_t *rbv;       // [29][M+1]
   const uint32_t *vit_e;    // [30][vitQH][64] packed emission words (cell j | cell j+QH of each lane)
   const uint32_t *vit_t;    // [8][vitQH][64]  packed transition words: BM MM IM DM (into) MD MI II DD (from)

@@ -305,7 +305,8 @@ HostProfile configure_profile(const HostHMM &h) {
     for (int x = 0; x < KP; ++x) for (int k = 1; k <= M; ++k) p.rbv[(size_t)x * (M + 1) + k] = byte_cost_biased(p.scale_b, p.bias_b, msc[(size_t)x * (M + 1) + k]);
     // LDS image for the SSV kernel.  16 lanes per sequence, Q packed registers per lane, position
     // p = q + Q*(2*z + h) (HMMER-style striping so the diagonal move is a register rename);
-    // lane z fetches registers 4g..4g+3 with one ds_read_b128 at row + g*256 + z*16.
+    // lane z fetches registers 4g..4g+3 of symbol x with one ds_read_b128 at (g*30 + x)*256 + z*16 (group-major, so
+    // that symbol*256 + lane offset is a byte permute and g rides in the instruction's offset field).
     const int Q = p.ssvQ, Qg = (Q + 3) / 4;
     p.ssv_tbl.assign((size_t)NROWS * Qg * 16 * 8, (int16_t)(p.bias_b - 255));
     for (int x = 0; x < KP; ++x)
@@ -315,7 +316,7 @@ HostProfile configure_profile(const HostHMM &h) {
             const int pos = q + Q * (2 * z + hh);
             const int k = pos + 1;
             const int cost = (k <= M) ? p.rbv[(size_t)x * (M + 1) + k] : 255;
-            const size_t idx = (((size_t)x * Qg + q / 4) * 16 + z) * 8 + (size_t)(q % 4) * 2 + hh;
+            const size_t idx = (((size_t)(q / 4) * NROWS + x) * 16 + z) * 8 + (size_t)(q % 4) * 2 + hh;
             p.ssv_tbl[idx] = (int16_t)(p.bias_b - cost);
           }
   }

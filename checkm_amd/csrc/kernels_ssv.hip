@@ -19,8 +19,10 @@
 // Mapping: 16 lanes per sequence (one DPP row), 4 sequences per wavefront, Q packed 2 x i16
 // registers per lane; position p = q + Q*(2*lane16 + half) so the diagonal move i-1,k-1 -> i,k is a
 // register rename plus ONE row_shr:1 DPP move per row.  Emission words for the model live in LDS
-// as [symbol][Q/4][16 lanes][16 B]: each row step is ceil(Q/4) conflict-free ds_read_b128 per lane
-// and 3 packed-i16 VALU ops per register (v_pk_add_i16 clamp, 2 x v_pk_max_i16).
+// as [Q/4][symbol][16 lanes][16 B]: each row step is ceil(Q/4) conflict-free ds_read_b128 per lane
+// (address = one v_perm_b32 of the residue word over the lane offset, the group index in the offset
+// field) and 2 packed-i16 VALU ops per register (v_pk_add_i16 clamp, v_pk_max_i16); per row the
+// overhead on top of 2Q is 3 VALU ops (address, DPP move, alignbit) plus a quarter op of chunk bookkeeping.
 #include <hip/hip_runtime.h>
 #include "dev_types.h"
 
@@ -36,15 +38,27 @@ constexpr int SSV_NROWS = 30;
 constexpr u32 PAD4 = 0x1d1d1d1du;   // four PADCODE (29) residues
 constexpr u32 U_ZERO = 0x80008000u; // two cells with U = 0 in the -32768-offset representation
 
+// LDS address of a residue's emission words: symbol * 256 + lane16 * 16, formed by ONE v_perm_b32 that drops byte B of the
+// residue word into byte 1 above the lane offset (symbols < 32, so the image of register group g starts at g * SSV_GSTRIDE
+// and the group index travels in the ds_read offset field).
+constexpr int SSV_GSTRIDE = SSV_NROWS * 256;
+template <int B>
+__device__ __forceinline__ u32 ssv_addr(u32 word, u32 lane_off) { return __builtin_amdgcn_perm(word, lane_off, 0x0c0c0400u + ((u32)B << 8)); }
+
+// The emission image is addressed ABSOLUTELY in LDS (it is the only LDS these kernels use, so the dynamic segment starts
+// at 0; lds_image_at_zero() traps otherwise): the permuted word IS the ds_read address, no base has to be added per row.
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const u32x4 lds_cu4;
+typedef __attribute__((address_space(3))) char lds_char;
+__device__ __forceinline__ void lds_image_at_zero(char *smem) { if ((u32)(size_t)(lds_char *)smem != 0u) __builtin_trap(); }
+
 template <int Q>
-__device__ __forceinline__ void ssv_row(u32 (&U)[Q], u32 &xE, u32 &prev, const char *lds_base, u32 lane_off, u32 x) {
+__device__ __forceinline__ void ssv_row(u32 (&U)[Q], u32 &xE, u32 &prev, u32 addr) {
   constexpr int Qg = (Q + 3) / 4;
-  constexpr int ROWB = Qg * 256;
-  const char *rowp = lds_base + __umul24(x, (u32)ROWB) + lane_off;   // one v_mad_u32_u24
   u32 e[Qg * 4];
 #pragma unroll
   for (int g = 0; g < Qg; ++g) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(rowp + g * 256);
+    const u32x4 v = *(lds_cu4 *)(size_t)(addr + (u32)(g * SSV_GSTRIDE));
     e[g * 4 + 0] = v.x; e[g * 4 + 1] = v.y; e[g * 4 + 2] = v.z; e[g * 4 + 3] = v.w;
   }
   // cell p=0 of each lane's first register comes from the previous lane's last register (high half)
@@ -75,6 +89,7 @@ __global__ void __launch_bounds__(Q > 40 ? 512 : 1024) ssv_kernel(const SsvBlock
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int Qg = (Q + 3) / 4;
   constexpr int ROWB = Qg * 256;
+  lds_image_at_zero(smem);
   const SsvBlockWork w = work[blockIdx.x];
   {
     const uint4 *src = reinterpret_cast<const uint4 *>(models[w.model].ssv_tbl);
@@ -107,10 +122,10 @@ __global__ void __launch_bounds__(Q > 40 ? 512 : 1024) ssv_kernel(const SsvBlock
       uint4 nxt = padv;
       if ((c + 1) * 16 < L) nxt = *reinterpret_cast<const uint4 *>(rp + (c + 1) * 16);
 #define CKM_SSV_WORD(wd)                                   \
-  ssv_row<Q>(U, xE, prev, smem, lane_off, (wd) & 0xffu);               \
-  ssv_row<Q>(U, xE, prev, smem, lane_off, ((wd) >> 8) & 0xffu);        \
-  ssv_row<Q>(U, xE, prev, smem, lane_off, ((wd) >> 16) & 0xffu);       \
-  ssv_row<Q>(U, xE, prev, smem, lane_off, (wd) >> 24);
+  ssv_row<Q>(U, xE, prev, ssv_addr<0>(wd, lane_off));            \
+  ssv_row<Q>(U, xE, prev, ssv_addr<1>(wd, lane_off));            \
+  ssv_row<Q>(U, xE, prev, ssv_addr<2>(wd, lane_off));            \
+  ssv_row<Q>(U, xE, prev, ssv_addr<3>(wd, lane_off));
       CKM_SSV_WORD(cur.x) CKM_SSV_WORD(cur.y) CKM_SSV_WORD(cur.z) CKM_SSV_WORD(cur.w)
 #undef CKM_SSV_WORD
       cur = nxt;
@@ -136,12 +151,11 @@ __global__ void __launch_bounds__(Q > 40 ? 512 : 1024) ssv_kernel(const SsvBlock
 template <int Q>
 __device__ __forceinline__ void msv_row(u32 (&U)[Q], u32 &xE, u32 &prev, u32 xBv, const char *lds_base, u32 lane_off, u32 x) {
   constexpr int Qg = (Q + 3) / 4;
-  constexpr int ROWB = Qg * 256;
-  const char *rowp = lds_base + __umul24(x, (u32)ROWB) + lane_off;
+  const char *rowp = lds_base + x * 256u + lane_off;
   u32 e[Qg * 4];
 #pragma unroll
   for (int g = 0; g < Qg; ++g) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(rowp + g * 256);
+    const uint4 v = *reinterpret_cast<const uint4 *>(rowp + g * SSV_GSTRIDE);
     e[g * 4 + 0] = v.x; e[g * 4 + 1] = v.y; e[g * 4 + 2] = v.z; e[g * 4 + 3] = v.w;
   }
   const u32 last = U[Q - 1];
