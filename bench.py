@@ -188,10 +188,10 @@ def main():
         ssv_s = ssv_ms / args.steps / 1e3
         achieved = alg_bytes / ssv_s / 1e9
         # HBM traffic and VALU instruction count of the same launches come from separate rocprofv3 --pmc passes
-        # (profiles/r01d_pmc_summary.txt); they are only quoted when the workload is the one that was profiled
+        # (profiles/r01e_pmc_summary.txt); they are only quoted when the workload is the one that was profiled
         traffic = None
         valu = None
-        tf = os.path.join(ROOT, "profiles", "r01d_ssv_traffic.json")
+        tf = os.path.join(ROOT, "profiles", "r01e_ssv_traffic.json")
         if os.path.exists(tf) and args.bins == 100 and args.orfs == 2000:
             with open(tf) as f:
                 pm = json.load(f)

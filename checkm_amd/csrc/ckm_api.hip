@@ -62,13 +62,15 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
     size_t budget = (size_t)8 << 30;
     if (hipMemGetInfo(&fre, &tot) == hipSuccess) budget = std::min<size_t>((size_t)96 << 30, fre / 2) / ctx->nworkers;
     if (const char *e = getenv("CKM_WS_BUDGET_MB")) budget = std::max<size_t>(16, strtoull(e, nullptr, 10)) << 20;   // tests: force several envelope batches
+    const int nside = choose_side_streams(ctx->nworkers);
     for (auto &w : ctx->w) {
-      w.device = device;
+      w.device = device; w.id = (int)(&w - ctx->w);
       if (&w - ctx->w >= ctx->nworkers) continue;
       // non-blocking streams: nothing here may synchronise implicitly with the null stream or with another worker's streams
       HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
-      HIPCHK(hipStreamCreateWithFlags(&w.ens_stream, hipStreamNonBlocking));
-      for (auto &st : w.side) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      w.nside = nside;
+      for (int k = 0; k < 8; ++k) { if (k < nside) HIPCHK(hipStreamCreateWithFlags(&w.side[k], hipStreamNonBlocking)); else w.side[k] = w.side[k % nside]; }
+      w.ens_stream = w.side[nside - 1];
       for (auto &e : w.ev) HIPCHK(hipEventCreate(&e));
       memset(&w.stats, 0, sizeof(w.stats));
       w.ws_budget = budget;
@@ -85,9 +87,8 @@ extern "C" void ckm_ctx_destroy(ckm_ctx *ctx) {
   for (auto &w : ctx->w) {
     if (!w.stream) continue;
     for (auto &e : w.ev) (void)hipEventDestroy(e);
-    for (auto &st : w.side) (void)hipStreamDestroy(st);
+    for (int k = 0; k < w.nside; ++k) (void)hipStreamDestroy(w.side[k]);
     (void)hipStreamDestroy(w.stream);
-    (void)hipStreamDestroy(w.ens_stream);
   }
   delete ctx;
 }

@@ -155,9 +155,11 @@ extern std::atomic<uint64_t> g_uid;        // identity of every profile DB / seq
 // host glue of one chunk overlap the VALU-bound SSV / Viterbi kernels of the other.
 struct Worker {
   int device = 0;
+  int id = 0;
   hipStream_t stream = nullptr;
   hipStream_t ens_stream = nullptr;       // trace ensembles run beside the envelope stage
-  hipStream_t side[8];                    // per-register-class launches of the rare stages overlap on these
+  hipStream_t side[8];                    // per-register-class launches of the rare stages overlap on these (the first side_streams() are distinct, the rest alias them)
+  int nside = 0;                          // distinct side streams owned
   hipEvent_t ev[8];
   ckm_search_stats stats;
   // reusable device scratch
@@ -293,6 +295,9 @@ float bits(float sc, float nullsc);
 float finish_forward(float xC, float move, const std::vector<float> &scales);
 int ssv_threads_for(int Q);
 int side_streams();
+int choose_side_streams(int nworkers);
+void trace_pt(const Worker *w, const char *label);      // CKM_TRACE=1: worker / ms since the search began / label on stderr
+void trace_begin();
 void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, bool do_fwd, bool do_bwd, bool do_oa,
             const std::vector<uint32_t> *subset /* indices into b.work, or null = all */, float *ws_other = nullptr);
 void rescore_envelopes(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<EnvReq> &req, std::vector<EnvRes> &out,

@@ -5,9 +5,7 @@
 
 namespace {
 
-const bool g_trace = getenv("CKM_TRACE") != nullptr;     // per-worker stage timestamps on stderr
-double g_trace_t0 = 0;
-#define CKM_TRACE_PT(label) do { if (g_trace) fprintf(stderr, "ckm-trace w%d %8.3f %s\n", my_turn, now_ms() - g_trace_t0, label); } while (0)
+#define CKM_TRACE_PT(label) trace_pt(ctx, label)     // CKM_TRACE=1: per-worker stage timestamps on stderr
 
 }  // namespace
 
@@ -525,7 +523,7 @@ static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, cons
   for (auto &ch : chunk) std::sort(ch.begin(), ch.end());
   std::vector<HitMap> maps(nw); std::vector<std::exception_ptr> errs(nw);
   c->ssv_turn = 0;
-  g_trace_t0 = now_ms();
+  trace_begin();
   auto run = [&](int k) { try { cascade(&c->w[k], c, k, p, s, ranges[k], chunk[k], model_bins, maps[k]); } catch (...) { errs[k] = std::current_exception(); } };
   std::vector<std::thread> threads;
   for (int k = 1; k < nw; ++k) threads.emplace_back(run, k);

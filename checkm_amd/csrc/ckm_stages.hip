@@ -13,6 +13,11 @@ void wcopy(Worker *w, void *dst, const void *src, size_t bytes, hipMemcpyKind ki
   HIPCHK(hipStreamSynchronize(w->stream));
 }
 
+static const bool g_trace_on = getenv("CKM_TRACE") != nullptr;
+static double g_trace_origin = 0;
+void trace_begin() { g_trace_origin = now_ms(); }
+void trace_pt(const Worker *w, const char *label) { if (g_trace_on) fprintf(stderr, "ckm-trace w%d %8.3f %s\n", w->id, now_ms() - g_trace_origin, label); }
+
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 float bits(float sc, float nullsc) { return (float)((double)(sc - nullsc) / kLn2); }
@@ -24,11 +29,17 @@ float finish_forward(float xC, float move, const std::vector<float> &scales) {
   return (float)((double)totscale + log((double)(xC * move)));
 }
 
-// Side streams a worker spreads the register classes of one stage over.  All workers together should stay within the
-// hardware queues of the device (GPU_MAX_HW_QUEUES): streams that share a queue run their kernels one behind the other,
-// and a short launch of one worker then waits behind a long one of another.
-int side_streams() {
-  static const int n = [] { const char *e = getenv("CKM_SIDE_STREAMS"); return e ? std::max(1, std::min(8, atoi(e))) : 8; }();
+// Side streams a worker spreads the register classes of one stage over.  All workers together must stay within the
+// hardware queues of the device (GPU_MAX_HW_QUEUES = 16): streams that share a queue run their kernels one behind the
+// other, and a short launch of one worker then waits behind a long one of another (measured: the Forward parser of the
+// short class, 1 ms of work, finished 12 ms late behind the envelope kernels of the long class).  So a worker creates
+// main stream + NS side streams with nworkers * (1 + NS) <= 15 and aliases the rest; CKM_SIDE_STREAMS overrides NS.
+static int g_side_streams = 8;
+int side_streams() { return g_side_streams; }
+int choose_side_streams(int nworkers) {
+  int n = std::max(1, std::min(8, 15 / std::max(1, nworkers) - 1));
+  if (const char *e = getenv("CKM_SIDE_STREAMS")) n = std::max(1, std::min(8, atoi(e)));
+  g_side_streams = n;
   return n;
 }
 
@@ -43,6 +54,7 @@ void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, b
             const std::vector<uint32_t> *subset /* indices into b.work, or null = all */, float *ws_other) {
   const size_t n = b.work.size();
   if (!n) return;
+  trace_pt(ctx, "  fb begin");
   ctx->fbwork.ensure(n * sizeof(FbWork));
   wcopy(ctx, ctx->fbwork.p, b.work.data(), n * sizeof(FbWork), hipMemcpyHostToDevice);
   // group by canonical Q; inside a group, blocks of 4 wavefronts take 4 items of ONE model (shared LDS table)
@@ -82,6 +94,7 @@ void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, b
   float *ws = ws_other ? ws_other : ctx->ws.as<float>();
   if (do_fwd) HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  trace_pt(ctx, "  fb tables uploaded");
   // every register class runs its stages in order on its own stream; classes overlap each other
   size_t gi = 0;
   for (auto &g : groups) {
@@ -96,7 +109,9 @@ void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, b
       throw Error(CKM_ERANGE, "no OA kernel instance for this model length");
   }
   HIPCHK(hipGetLastError());
+  trace_pt(ctx, "  fb launched");
   for (auto &st : ctx->side) HIPCHK(hipStreamSynchronize(st));
+  trace_pt(ctx, "  fb kernels done");
   if (do_fwd) {
     b.fout.resize(n);
     uint32_t nev = 0;
