@@ -56,9 +56,15 @@ void digitize(const char *text, uint64_t n, uint8_t *dsq) {
 // ------------------------------------------------------------------------------------------------
 // file reader
 // ------------------------------------------------------------------------------------------------
-static float as_prob(const std::string &tok) {
-  if (!tok.empty() && tok[0] == '*') return 0.0f;
-  return expf((float)(-1.0 * atof(tok.c_str())));
+// a probability field: "*" (zero) or -ln p >= 0.  hmmsearch converts with atof and takes whatever comes out; a token that is
+// not a number, or a "probability" above 1, can only come from a damaged file, so it is refused here instead of scored.
+static bool as_prob(const std::string &tok, float &p) {
+  if (tok == "*") { p = 0.0f; return true; }
+  char *end = nullptr;
+  const double v = strtod(tok.c_str(), &end);
+  if (end == tok.c_str() || *end != 0 || !(v >= 0.0) || std::isinf(v)) return false;
+  p = expf((float)(-1.0 * v));
+  return true;
 }
 
 static void parse_numbers(const std::string &line, size_t skip, float *dst, int n, int lineno, const std::string &path) {
@@ -67,7 +73,7 @@ static void parse_numbers(const std::string &line, size_t skip, float *dst, int 
   for (size_t i = 0; i < skip; ++i) is >> tok;
   for (int i = 0; i < n; ++i) {
     if (!(is >> tok)) throw Error(CKM_EFORMAT, path + ":" + std::to_string(lineno) + ": expected " + std::to_string(n) + " numeric fields");
-    dst[i] = as_prob(tok);
+    if (!as_prob(tok, dst[i])) throw Error(CKM_EFORMAT, path + ":" + std::to_string(lineno) + ": '" + tok + "' is not a probability field (-ln p >= 0 or *)");
   }
 }
 
@@ -187,9 +193,10 @@ double exp_surv(double x, double mu, double lambda) { return (x < mu) ? 1.0 : ex
 double exp_logsurv(double x, double mu, double lambda) { return (x < mu) ? 0.0 : -lambda * (x - mu); }
 
 float flogsum(float a, float b) {
-  static float tbl[16000];
-  static bool ready = false;
-  if (!ready) { for (int i = 0; i < 16000; ++i) tbl[i] = (float)log(1. + exp((double)-i / 1000.)); ready = true; }
+  // (the workers call this concurrently: the table is built by a thread-safe static initialiser)
+  struct Table { float v[16000]; Table() { for (int i = 0; i < 16000; ++i) v[i] = (float)log(1. + exp((double)-i / 1000.)); } };
+  static const Table table;
+  const float *tbl = table.v;
   const float mx = std::max(a, b), mn = std::min(a, b);
   return (mn == -INFINITY || (mx - mn) >= 15.7f) ? mx : mx + tbl[(int)((mx - mn) * 1000.f)];
 }

@@ -1,0 +1,75 @@
+"""AddressSanitizer + UBSan over the host-only parsers of the library: the HMMER3/f reader with the profile configuration
+(host_profile.cpp; the reference reads the same files at checkm/hmmerModelParser.py:54-83) and the domtblout reader
+(ckm_tables.cpp; checkm/hmmer.py:184-200).  Damaged inputs must be accepted or rejected -- never crash.  No device needed."""
+import json
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from checkm_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "checkm_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("g++ not available")
+    d = tmp_path_factory.mktemp("sanitize")
+    exe = str(d / "fuzz_host")
+    cmd = [gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-pthread",
+           "-I", CSRC, os.path.join(ROOT, "tests", "native", "fuzz_host.cpp"), os.path.join(CSRC, "host_profile.cpp"), os.path.join(CSRC, "ckm_tables.cpp"), "-o", exe]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return exe, d
+
+
+def _run(exe, mode, path, work, rounds, seed):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    out = subprocess.run([exe, mode, path, str(work), str(rounds), str(seed)], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, (out.stdout[-500:], out.stderr[-4000:])
+    return json.loads(out.stdout.strip().split("\n")[-1])
+
+
+def test_hmm_reader_survives_damaged_files(harness):
+    exe, d = harness
+    profs = synth.small_profiles(5, 3, mlo=20, mhi=70)
+    for k, pr in enumerate(profs):
+        pr.stats = (-8.0 - k, 0.71, -9.0 - k, 0.71, -4.0 - k, 0.70)      # any calibration will do: only the reader is under test
+    path = str(d / "valid.hmm")
+    synth.write_hmm(path, profs)
+    got = _run(exe, "hmm", path, d, 400, 11)
+    assert got["accepted"] >= 1 and got["rejected"] >= 100      # the undamaged file parses; most damage is noticed and refused
+
+
+def test_domtblout_reader_survives_damaged_tables(harness):
+    exe, d = harness
+    case = json.load(open(os.path.join(ROOT, "tests", "golden", "reduce_cases.json")))["cases"][0]
+    path = str(d / "valid.domtblout")
+    with open(path, "w") as f:
+        f.write(case["domtblout"])
+    got = _run(exe, "dom", path, d, 600, 12)
+    assert got["accepted"] >= 1 and got["rejected"] >= 50
+
+
+def test_hmm_reader_refuses_fields_that_are_not_probabilities(harness):
+    """hmmsearch would atof() these and score with the result; a damaged number is refused here, with file:line in the message."""
+    exe, d = harness
+    profs = synth.small_profiles(6, 1, mlo=20, mhi=30)
+    profs[0].stats = (-8.0, 0.71, -9.0, 0.71, -4.0, 0.70)
+    good = str(d / "one.hmm")
+    synth.write_hmm(good, profs)
+    lines = open(good).read().split("\n")
+    body = next(i for i, ln in enumerate(lines) if ln.split()[:1] == ["1"])       # match emissions of node 1
+    for bad_token in ("abc", "-0.25", "1.2.3", "inf"):
+        toks = lines[body].split()
+        toks[3] = bad_token
+        bad = str(d / "bad.hmm")
+        with open(bad, "w") as f:
+            f.write("\n".join(lines[:body] + ["  " + "  ".join(toks)] + lines[body + 1:]))
+        out = subprocess.run([exe, "hmm", bad, str(d), "0", "1"], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 1 and "is not a probability field" in out.stderr and ":%d:" % (body + 1) in out.stderr, (bad_token, out.stderr)
