@@ -73,3 +73,16 @@ def test_hmm_reader_refuses_fields_that_are_not_probabilities(harness):
             f.write("\n".join(lines[:body] + ["  " + "  ".join(toks)] + lines[body + 1:]))
         out = subprocess.run([exe, "hmm", bad, str(d), "0", "1"], capture_output=True, text=True, timeout=120)
         assert out.returncode == 1 and "is not a probability field" in out.stderr and ":%d:" % (body + 1) in out.stderr, (bad_token, out.stderr)
+
+
+def test_host_pool_under_thread_sanitizer(tmp_path):
+    """The per-worker thread pool (host_pool.h): thousands of back-to-back jobs on two pools, under TSan."""
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("g++ not available")
+    exe = str(tmp_path / "stress_pool")
+    out = subprocess.run([gxx, "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", "-I", CSRC, os.path.join(ROOT, "tests", "native", "stress_pool.cpp"), "-o", exe],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+    assert run.returncode == 0 and run.stdout.strip().endswith("ok"), (run.stdout[-300:], run.stderr[-4000:])
