@@ -238,45 +238,22 @@ extern "C" int ckm_seqs_from_fasta(ckm_ctx *ctx, const char *const *paths, uint3
     std::unique_ptr<ckm_seqs> s(new ckm_seqs());
     s->ctx = ctx; s->nbins = nbins; s->uid = g_uid++;
     s->bin_off.assign(nbins + 1, 0);
-    std::vector<char> buf;
-    uint64_t pos = 0;
-    auto close_seq = [&](uint64_t start) {            // pad the record that just ended to a 16-byte boundary
-      const uint64_t L = pos - start;
-      if (L > 100000) throw Error(CKM_ERANGE, "sequence longer than 100000 residues");
-      s->len.push_back((int32_t)L); s->total_res += L; s->maxL = std::max(s->maxL, (int)L);
-      const uint64_t padded = (L + 15) & ~(uint64_t)15;
-      s->dsq.resize(start + padded, (uint8_t)PADCODE);
-      pos = start + padded;
-    };
+    // the files are read and digitised on a few threads (fasta_ingest.cpp), then laid end to end
+    std::vector<FastaBin> bins = read_fasta_bins(paths, nbins, (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+    uint64_t pos = 0; size_t nrec = 0;
+    for (auto &fb : bins) { if (fb.err_code) throw Error(fb.err_code, fb.err); pos += fb.dsq.size(); nrec += fb.names.size(); }
+    s->dsq.reserve(pos + 16); s->names.reserve(nrec); s->descs.reserve(nrec); s->len.reserve(nrec); s->off.reserve(nrec);
+    pos = 0;
     for (uint32_t b = 0; b < nbins; ++b) {
-      FILE *f = fopen(paths[b], "rb");
-      if (!f) throw Error(CKM_EIO, std::string("cannot open FASTA file ") + paths[b]);
-      fseek(f, 0, SEEK_END); const long sz = ftell(f); fseek(f, 0, SEEK_SET);
-      buf.resize((size_t)std::max<long>(sz, 0));
-      const size_t got = sz > 0 ? fread(buf.data(), 1, (size_t)sz, f) : 0;
-      fclose(f);
-      if ((long)got != sz) throw Error(CKM_EIO, std::string("short read on ") + paths[b]);
-      size_t i = 0; bool open = false; uint64_t start = 0;
-      while (i < got) {
-        size_t e = i; while (e < got && buf[e] != '\n') ++e;
-        size_t le = e; if (le > i && buf[le - 1] == '\r') --le;
-        if (le > i && buf[i] == '>') {
-          if (open) close_seq(start);
-          size_t n0 = i + 1, n1 = n0; while (n1 < le && !isspace((unsigned char)buf[n1])) ++n1;
-          size_t d0 = n1; while (d0 < le && isspace((unsigned char)buf[d0])) ++d0;
-          s->names.emplace_back(buf.data() + n0, n1 - n0);
-          s->descs.emplace_back(buf.data() + d0, le - d0);
-          start = pos; s->off.push_back(start); open = true;
-        } else if (open && le > i) {
-          size_t a = i, z = le;                           // strip blanks at both ends of the line
-          while (a < z && isspace((unsigned char)buf[a])) ++a;
-          while (z > a && isspace((unsigned char)buf[z - 1])) --z;
-          if (z > a) { s->dsq.resize(pos + (z - a)); digitize(buf.data() + a, z - a, s->dsq.data() + pos); pos += z - a; }
-        }
-        i = e + 1;
+      FastaBin &fb = bins[b];
+      for (size_t r = 0; r < fb.names.size(); ++r) {
+        s->names.push_back(std::move(fb.names[r])); s->descs.push_back(std::move(fb.descs[r]));
+        s->len.push_back(fb.len[r]); s->off.push_back(pos + fb.off[r]);
       }
-      if (open) close_seq(start);
+      s->dsq.insert(s->dsq.end(), fb.dsq.begin(), fb.dsq.end());
+      pos += fb.dsq.size(); s->total_res += fb.total_res; s->maxL = std::max(s->maxL, fb.maxL);
       s->bin_off[b + 1] = (uint32_t)s->names.size();
+      FastaBin().dsq.swap(fb.dsq);                   // release the per-file copy as soon as it is merged
     }
     s->nseq = (uint32_t)s->names.size();
     s->dsq.resize(pos + 16, (uint8_t)PADCODE);

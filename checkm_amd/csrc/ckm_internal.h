@@ -75,6 +75,18 @@ LenCfg len_config(const HostProfile &p, int L, bool multihit);
 
 void digitize(const char *text, uint64_t n, uint8_t *dsq);
 
+// One FASTA file, digitised: records padded to 16 bytes with PADCODE, offsets relative to the file's own buffer.
+struct FastaBin {
+  std::vector<std::string> names, descs;
+  std::vector<int32_t> len;
+  std::vector<uint64_t> off;
+  std::vector<uint8_t> dsq;
+  uint64_t total_res = 0;
+  int maxL = 0;
+  int err_code = 0; std::string err;      // err_code != 0: the file could not be read
+};
+std::vector<FastaBin> read_fasta_bins(const char *const *paths, uint32_t nbins, int nthreads);
+
 // statistics
 double gumbel_surv(double x, double mu, double lambda);
 double exp_surv(double x, double mu, double lambda);

@@ -40,17 +40,16 @@ static bool in_degeneracy(int sym, int res) {
 }
 
 void digitize(const char *text, uint64_t n, uint8_t *dsq) {
-  static uint8_t lut[256];
-  static bool ready = false;
-  if (!ready) {
-    for (int c = 0; c < 256; ++c) lut[c] = 26;  // anything unknown scores as X
-    for (int i = 0; i < KP; ++i) {
-      lut[(unsigned char)kAlphabet[i]] = (uint8_t)i;
-      lut[(unsigned char)std::tolower((unsigned char)kAlphabet[i])] = (uint8_t)i;
+  // (called from the FASTA reader's threads: the table is built by a thread-safe static initialiser)
+  struct Lut {
+    uint8_t v[256];
+    Lut() {
+      for (int c = 0; c < 256; ++c) v[c] = 26;  // anything unknown scores as X
+      for (int i = 0; i < KP; ++i) { v[(unsigned char)kAlphabet[i]] = (uint8_t)i; v[(unsigned char)std::tolower((unsigned char)kAlphabet[i])] = (uint8_t)i; }
     }
-    ready = true;
-  }
-  for (uint64_t i = 0; i < n; ++i) dsq[i] = lut[(unsigned char)text[i]];
+  };
+  static const Lut lut;
+  for (uint64_t i = 0; i < n; ++i) dsq[i] = lut.v[(unsigned char)text[i]];
 }
 
 // ------------------------------------------------------------------------------------------------

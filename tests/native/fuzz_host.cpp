@@ -2,6 +2,7 @@
 // -fsanitize=address,undefined from checkm_amd/csrc/host_profile.cpp + ckm_tables.cpp; no device, no HIP).
 //   fuzz_host hmm  <valid.hmm>        <work_dir> <rounds> <seed>
 //   fuzz_host dom  <valid.domtblout>  <work_dir> <rounds> <seed>
+//   fuzz_host fasta <valid.faa>       <work_dir> <rounds> <seed>     (prints a digest of the undamaged file first)
 // Every round damages a copy of the valid file (truncation, byte flips, line drops, token damage) and feeds it to the reader;
 // the reader must either succeed or fail with an Error / a non-zero status -- never crash or trip a sanitizer.  Prints counts.
 #include <cstdio>
@@ -48,6 +49,24 @@ int main(int argc, char **argv) {
         for (auto &h : hs) { ckm::HostProfile p = ckm::configure_profile(h); (void)ckm::len_config(p, 300, true); }
         ++ok;
       } catch (const ckm::Error &e) { ++rejected; if (r < 0) { fprintf(stderr, "valid HMM file rejected: %s\n", e.what()); return 1; } }
+    } else if (mode == "fasta") {
+      // the same file three times over three threads: the per-file results must agree with each other
+      const char *paths[3] = {path.c_str(), path.c_str(), path.c_str()};
+      std::vector<ckm::FastaBin> bins = ckm::read_fasta_bins(paths, 3, 3);
+      for (auto &b : bins) {
+        if (b.err_code) { fprintf(stderr, "FASTA file refused: %s\n", b.err.c_str()); if (r < 0) return 1; }
+        if (b.names != bins[0].names || b.len != bins[0].len || b.dsq != bins[0].dsq || b.off != bins[0].off) { fprintf(stderr, "threads disagree\n"); return 1; }
+        if (b.names.size() != b.len.size() || b.names.size() != b.off.size() || b.names.size() != b.descs.size()) { fprintf(stderr, "ragged record columns\n"); return 1; }
+        for (size_t k = 0; k < b.len.size(); ++k) if (b.off[k] % 16 || b.off[k] + (uint64_t)b.len[k] > b.dsq.size()) { fprintf(stderr, "record outside its buffer\n"); return 1; }
+      }
+      if (bins[0].err_code) ++rejected; else ++ok;
+      if (r < 0) {
+        uint64_t h = 1469598103934665603ULL;
+        auto mix = [&](const void *p, size_t n) { const unsigned char *c = (const unsigned char *)p; for (size_t k = 0; k < n; ++k) { h ^= c[k]; h *= 1099511628211ULL; } };
+        const ckm::FastaBin &b = bins[0];
+        for (size_t k = 0; k < b.names.size(); ++k) { mix(b.names[k].data(), b.names[k].size()); mix("|", 1); mix(b.descs[k].data(), b.descs[k].size()); mix("|", 1); mix(b.dsq.data() + b.off[k], (size_t)b.len[k]); mix("\n", 1); }
+        printf("{\"nseq\": %zu, \"total_res\": %llu, \"maxL\": %d, \"bytes\": %zu, \"fnv\": \"%016llx\"}\n", b.names.size(), (unsigned long long)b.total_res, b.maxL, b.dsq.size(), (unsigned long long)h);
+      }
     } else {
       const char *paths[2] = {path.c_str(), "/nonexistent/ckm_fuzz_missing.txt"};
       ckm_tables *t = nullptr;

@@ -22,7 +22,7 @@ def harness(tmp_path_factory):
     d = tmp_path_factory.mktemp("sanitize")
     exe = str(d / "fuzz_host")
     cmd = [gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-pthread",
-           "-I", CSRC, os.path.join(ROOT, "tests", "native", "fuzz_host.cpp"), os.path.join(CSRC, "host_profile.cpp"), os.path.join(CSRC, "ckm_tables.cpp"), "-o", exe]
+           "-I", CSRC, os.path.join(ROOT, "tests", "native", "fuzz_host.cpp"), os.path.join(CSRC, "host_profile.cpp"), os.path.join(CSRC, "ckm_tables.cpp"), os.path.join(CSRC, "fasta_ingest.cpp"), "-o", exe]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     return exe, d
@@ -86,3 +86,42 @@ def test_host_pool_under_thread_sanitizer(tmp_path):
     assert out.returncode == 0, out.stderr[-3000:]
     run = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
     assert run.returncode == 0 and run.stdout.strip().endswith("ok"), (run.stdout[-300:], run.stderr[-4000:])
+
+
+def test_fasta_reader_matches_a_python_parse_and_survives_damage(harness):
+    """fasta_ingest.cpp: names / descriptions / digitised residues of a genes.faa file against a plain Python parse by the rules
+    CheckM applies to the same file (checkm/util/seqUtils.py:180-211), then damaged copies, three threads at a time."""
+    exe, d = harness
+    profs = synth.small_profiles(7, 2, mlo=20, mhi=40)
+    recs = synth.make_bin(profs, 3, n_orfs=60)
+    path = str(d / "genes.faa")
+    synth.write_fasta(path, recs)
+    with open(path, "a") as f:                       # blank lines, blanks around residues, lower case, an unknown symbol, CRLF, an empty record
+        f.write("\n>odd_1 # 5 # 40 # 1 # ID=9_1  two  blanks\r\n  mkvl AC\t\r\n\r\n?xZ*\n>empty_2\n>last_3\nMM")
+    alphabet = "ACDEFGHIKLMNPQRSTVWY-BJZOUX*~"
+    code = {c: i for i, c in enumerate(alphabet)}
+    code.update({c.lower(): i for i, c in enumerate(alphabet)})
+    names, descs, seqs = [], [], []
+    for line in open(path, "rb").read().decode("latin-1").split("\n"):
+        line = line.rstrip("\r")
+        if line.startswith(">"):
+            parts = line[1:].split(None, 1)
+            names.append(parts[0] if parts else "")
+            descs.append(parts[1].strip() if len(parts) > 1 else "")
+            seqs.append([])
+        elif names and line.strip():
+            seqs[-1].extend(code.get(c, 26) for c in line.strip())
+    h = 1469598103934665603
+    for n, ds, sq in zip(names, descs, seqs):
+        for blob in (n.encode("latin-1"), b"|", ds.encode("latin-1"), b"|", bytes(sq), b"\n"):
+            for c in blob:
+                h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    out = subprocess.run([exe, "fasta", path, str(d), "500", "13"], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert out.returncode == 0, (out.stdout[-500:], out.stderr[-4000:])
+    lines = out.stdout.strip().split("\n")
+    digest, counts = json.loads(lines[0]), json.loads(lines[-1])
+    assert digest["nseq"] == len(names) and digest["total_res"] == sum(len(x) for x in seqs) and digest["maxL"] == max(len(x) for x in seqs)
+    assert digest["bytes"] == sum((len(x) + 15) // 16 * 16 for x in seqs)
+    assert digest["fnv"] == "%016x" % h
+    assert counts["accepted"] >= 400
