@@ -43,6 +43,21 @@ def scan_files(hmm_file, fasta_files, table_files, E=0.1, domE=0.1, bin_models=N
         hits.close(); seqs.close(); profiles.close()
 
 
+GENE_CALLER = None      # a ProdigalRunner-like class (outDir) -> .areORFsCalled(bNucORFs) / .run(binFile, bNucORFs) / .aaGeneFile; None = look for CheckM's
+
+
+def gene_caller():
+    """The class that calls genes for bins given as nucleotide FASTA: GENE_CALLER if set, else the reference's ProdigalRunner when
+    CheckM is importable (the drop-in case), else None."""
+    if GENE_CALLER is not None:
+        return GENE_CALLER
+    try:
+        from checkm.prodigal import ProdigalRunner
+        return ProdigalRunner
+    except Exception:
+        return None
+
+
 class MarkerGeneFinder(object):
     """Identify marker genes within binned sequences (GPU scan of called genes)."""
 
@@ -50,14 +65,11 @@ class MarkerGeneFinder(object):
         self.logger = logging.getLogger('timestamp')
         self.totalThreads = threads
 
-    def find(self, binFiles, outDir, tableOut, hmmerOut, markerFile, bKeepAlignment, bNucORFs, bCalledGenes):
-        try:
-            runtime.get_ctx()
-        except Exception as e:
-            self.logger.error("No usable MI355X (gfx950) device for the marker-gene scan: %s" % e)
-            sys.exit(1)
-        self.logger.info("Identifying marker genes in %d bins on device %d:" % (len(binFiles), runtime.get_ctx().device))
-        binIds, faa = [], []
+    def _geneFiles(self, binFiles, outDir, bNucORFs, bCalledGenes):
+        """bins/<binId>/genes.faa for every bin (checkm/markerGeneFinder.py:108-127).  Called genes (-g) are copied in; otherwise
+        genes already present are reused and the rest are called by the reference's own ProdigalRunner (checkm/prodigal.py:54-153),
+        `threads` bins at a time -- gene calling sits BEFORE the accelerated path and is not reimplemented here."""
+        binIds, faa, todo = [], [], []
         for binFile in binFiles:
             binId = binIdFromFilename(binFile)
             binDir = os.path.join(outDir, 'bins', binId)
@@ -69,12 +81,40 @@ class MarkerGeneFinder(object):
                         shutil.copyfileobj(fin, fout)
                 else:
                     shutil.copyfile(binFile, dst)
-            elif not os.path.exists(dst):
-                # gene calling (prodigal, checkm/prodigal.py:54-153) sits BEFORE the accelerated path
-                self.logger.error("No called genes for bin %s: run with -g/--genes or provide %s (gene calling is outside this path)." % (binId, dst))
-                sys.exit(1)
+            else:
+                todo.append((binFile, binDir, binId, dst))
             binIds.append(binId)
             faa.append(dst)
+        if todo:
+            runner = gene_caller()
+            missing = [t for t in todo if runner is None and not os.path.exists(t[3])]
+            if missing:
+                self.logger.error("No called genes for bin %s and no gene caller available: run with -g/--genes, provide %s, or install prodigal "
+                                  "next to CheckM (gene calling is outside the accelerated path)." % (missing[0][2], missing[0][3]))
+                sys.exit(1)
+            if runner is not None:
+                def call(t):
+                    binFile, binDir, _binId, _dst = t
+                    prodigal = runner(binDir)
+                    if not prodigal.areORFsCalled(bNucORFs):
+                        prodigal.run(binFile, bNucORFs)
+                    return prodigal.aaGeneFile
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=max(1, int(self.totalThreads))) as pool:
+                    called = list(pool.map(call, todo))
+                for t, aa in zip(todo, called):
+                    if os.path.abspath(aa) != os.path.abspath(t[3]):
+                        shutil.copyfile(aa, t[3])
+        return binIds, faa
+
+    def find(self, binFiles, outDir, tableOut, hmmerOut, markerFile, bKeepAlignment, bNucORFs, bCalledGenes):
+        try:
+            runtime.get_ctx()
+        except Exception as e:
+            self.logger.error("No usable MI355X (gfx950) device for the marker-gene scan: %s" % e)
+            sys.exit(1)
+        self.logger.info("Identifying marker genes in %d bins on device %d:" % (len(binFiles), runtime.get_ctx().device))
+        binIds, faa = self._geneFiles(binFiles, outDir, bNucORFs, bCalledGenes)
         parser = MarkerSetParser(self.totalThreads)
         db = parser.hmmDatabaseFor(markerFile)
         wanted = parser.markerAccessionsForBins(binIds, markerFile)

@@ -68,6 +68,8 @@ def test_dropin_rebinds_the_reference_classes(tmp_path):
             "assert all(m.startswith('checkm_amd.') for m in mods), mods\n"
             "assert g.HmmModel.__module__ == 'checkm.hmmerModelParser'\n"
             "assert all(hasattr(e.HmmerAligner, n) for n in ('makeAlignmentTopHit', 'makeAlignmentToPhyloMarkers', 'makeAlignmentsOfMultipleHits'))\n"
+            "import checkm_amd.markerGeneFinder as h\n"
+            "assert h.gene_caller().__name__ == 'ProdigalRunner' and h.gene_caller().__module__ == 'checkm.prodigal'    # nucleotide bins: CheckM's own gene calling\n"
             "print('ok')\n")
     env = dict(os.environ, PYTHONPATH="/root/reference" + os.pathsep + root, CHECKM_DATA_PATH=str(tmp_path), PYTHONDONTWRITEBYTECODE="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)

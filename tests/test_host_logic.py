@@ -123,3 +123,49 @@ def test_amino_acid_identity_matches_the_reference(gold, tmp_path):
     orfs = {"c1_1": "MKV*", "c1_2": "ACD", "c9_5": "WWW*"}
     for sid, want in gold["extract_seq"]:
         assert ha._extractSeq(sid, orfs) == want
+
+
+def test_gene_files_step_of_find(tmp_path, monkeypatch):
+    """MarkerGeneFinder's first step (checkm/markerGeneFinder.py:108-127): -g copies proteins (plain or .gz) to bins/<id>/genes.faa;
+    nucleotide bins go through a ProdigalRunner-like gene caller, `threads` at a time, and bins already called are not called again."""
+    import gzip
+
+    from checkm_amd import markerGeneFinder as mgf
+    out = tmp_path / "out"
+    prot = tmp_path / "a.faa"; prot.write_text(">g_1\nMKV*\n")
+    with gzip.open(tmp_path / "b.faa.gz", "wt") as f:
+        f.write(">h_1\nMAA*\n")
+    finder = mgf.MarkerGeneFinder(3)
+    ids, faa = finder._geneFiles([str(prot), str(tmp_path / "b.faa.gz")], str(out), False, True)
+    assert ids == ["a", "b"] and [open(p).read() for p in faa] == [">g_1\nMKV*\n", ">h_1\nMAA*\n"]
+
+    calls = []
+
+    class FakeProdigal(object):
+        def __init__(self, outDir):
+            self.aaGeneFile = os.path.join(outDir, "genes.faa")
+
+        def areORFsCalled(self, bNucORFs):
+            return os.path.exists(self.aaGeneFile)
+
+        def run(self, query, bNucORFs=True):
+            calls.append((os.path.basename(query), bNucORFs))
+            with open(self.aaGeneFile, "w") as f:
+                f.write(">%s_1\nMSS*\n" % os.path.basename(query))
+
+    nuc = [tmp_path / ("n%d.fna" % i) for i in range(5)]
+    for p in nuc:
+        p.write_text(">c\nACGT\n")
+    monkeypatch.setattr(mgf, "GENE_CALLER", FakeProdigal)
+    ids, faa = finder._geneFiles([str(p) for p in nuc], str(out), True, False)
+    assert ids == ["n%d" % i for i in range(5)] and sorted(calls) == [("n%d.fna" % i, True) for i in range(5)]
+    assert open(faa[3]).read() == ">n3.fna_1\nMSS*\n"
+    del calls[:]
+    finder._geneFiles([str(p) for p in nuc[:2]], str(out), True, False)
+    assert calls == []                                   # already called: reused, as areORFsCalled decides in the reference
+    # no caller at all (CheckM not importable here) and nothing on disk: a logged error and exit code 1
+    monkeypatch.setattr(mgf, "GENE_CALLER", None)
+    monkeypatch.setattr(mgf, "gene_caller", lambda: None)
+    with pytest.raises(SystemExit) as ei:
+        finder._geneFiles([str(tmp_path / "zz.fna")], str(out), True, False)
+    assert ei.value.code == 1
