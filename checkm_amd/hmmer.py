@@ -59,6 +59,10 @@ class HMMERParser(object):
         self.handle = fileHandle
         self.mode = 'domtblout'
 
+    def readHitsDOM(self):
+        """Next hit of the table or None (checkm/hmmer.py:184-200)."""
+        return self.next()
+
     def next(self):
         while True:
             line = self.handle.readline().rstrip()

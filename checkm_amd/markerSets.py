@@ -53,6 +53,9 @@ class BinMarkerSets(object):
     def mostSpecificMarkerSet(self):
         return self.markerSets[0]
 
+    def treeMarkerSet(self):
+        pass        # a stub in the reference too (markerSets.py:78-79)
+
     def selectedMarkerSet(self):
         if self.markerSetType == self.TAXONOMIC_MARKER_SET:
             return self.mostSpecificMarkerSet()

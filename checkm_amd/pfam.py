@@ -38,6 +38,45 @@ class PFAM(object):
             self.nested[self.idToAcc[ident]] = set(self.idToAcc[x] for x in others)
         self._read = True
 
+    def filterHitsFromSameClan(self, markerHits):
+        """Per gene, drop a Pfam hit that overlaps a more significant hit of the same clan unless the two families nest
+        (checkm/util/pfam.py:86-147).  This is the row-at-a-time form; QA runs the same rule for all bins inside ckm_reduce.
+        Quirks kept: families without a clan share the clan `None`; markers whose id does not start with 'PF' pass through
+        first; the result is a defaultdict(list)."""
+        self.readClansAndNesting()
+        kept = defaultdict(list)
+        by_gene = defaultdict(list)
+        for marker, hits in markerHits.items():
+            if marker.startswith('PF'):
+                for h in hits:
+                    by_gene[h.target_name].append(h)
+            else:
+                kept[marker] = hits
+
+        def family(h):
+            a = h.query_accession
+            return a[0:a.rfind('.')]
+
+        for hits in by_gene.values():
+            hits.sort(key=lambda h: (h.full_e_value, h.i_evalue))       # stable: ties keep their order of arrival
+            fam = [family(h) for h in hits]
+            dropped = [False] * len(hits)
+            for i, hi in enumerate(hits):
+                if dropped[i]:
+                    continue
+                partners = self.nested.get(fam[i], ())
+                for j in range(i + 1, len(hits)):
+                    hj = hits[j]
+                    if dropped[j] or self.clan.get(fam[i]) != self.clan.get(fam[j]):
+                        continue
+                    overlap = (hi.ali_from <= hj.ali_from < hi.ali_to) or (hj.ali_from <= hi.ali_from < hj.ali_to)
+                    if overlap and fam[j] not in partners:
+                        dropped[j] = True
+            for h, gone in zip(hits, dropped):
+                if not gone:
+                    kept[h.query_accession].append(h)
+        return kept
+
     def pfamIdToClanId(self):
         d = {}
         acc = None

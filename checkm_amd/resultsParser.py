@@ -66,6 +66,27 @@ class ResultsManager(object):
         self.binStats = binStats
         self._raw = []
 
+    def vetHit(self, hit):
+        """One row against its model's cutoffs (resultsParser.py:340-377); the batched form of this test runs inside ckm_reduce.
+        A model that has a cutoff and fails it is rejected outright -- the E-value/length rule is only for models without cutoffs."""
+        model = self.models[hit.query_accession]
+        span = float(hit.ali_to - hit.ali_from) / float(hit.query_length)          # no +1, as in the reference
+        if not self.bSkipPseudoGeneCorrection and span < DefaultValues.PSEUDOGENE_LENGTH:
+            return False
+        cutoff = None
+        if not self.bIgnoreThresholds:
+            if model.nc is not None and 'TIGR' in model.acc:
+                cutoff = model.nc
+            elif model.ga is not None:
+                cutoff = model.ga
+            elif model.tc is not None:
+                cutoff = model.tc
+            elif model.nc is not None:
+                cutoff = model.nc
+        if cutoff is not None:
+            return bool(cutoff[0] <= hit.full_score and cutoff[1] <= hit.dom_score)
+        return bool(hit.full_e_value <= self.evalueThreshold and span >= self.lengthThreshold)
+
     # ---- hit intake: rows are collected, filtering happens in the library -------------------------
     def addHit(self, hit):
         self._raw.append(hit)
@@ -418,6 +439,24 @@ class ResultsParser(object):
                 p = line.split('\t')
                 stats[p[0]] = ast.literal_eval(p[1])
         return stats
+
+    def _parseCache(self, resultsFolder, name):
+        path = os.path.join(resultsFolder, 'storage', name)
+        checkFileExists(path)
+        table = {}
+        with open(path) as f:
+            for line in f:
+                p = line.split('\t')
+                table[p[0]] = ast.literal_eval(p[1])
+        return table
+
+    def parseBinStatsExt(self, resultsFolder):
+        """storage/bin_stats_ext.tsv back into {binId: dict} (resultsParser.py:161-174; read by the plots at main.py:685-687)."""
+        return self._parseCache(resultsFolder, DefaultValues.BIN_STATS_EXT_OUT)
+
+    def parseMarkerGeneStats(self, resultsFolder):
+        """storage/marker_gene_stats.tsv back into {binId: {gene: {marker: [[start, end], ...]}}} (resultsParser.py:176-189)."""
+        return self._parseCache(resultsFolder, DefaultValues.MARKER_GENE_STATS)
 
     def parseBinHits(self, outDir, hmmTableFile, bSkipAdjCorrection=False, bIgnoreThresholds=False, evalueThreshold=DefaultValues.E_VAL,
                      lengthThreshold=DefaultValues.LENGTH, bSkipPseudoGeneCorrection=False, binStats=None):

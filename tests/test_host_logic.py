@@ -169,3 +169,53 @@ def test_gene_files_step_of_find(tmp_path, monkeypatch):
     with pytest.raises(SystemExit) as ei:
         finder._geneFiles([str(tmp_path / "zz.fna")], str(out), True, False)
     assert ei.value.code == 1
+
+
+def test_row_at_a_time_rules_match_the_reference(gold, tmp_path):
+    """ResultsManager.vetHit and PFAM.filterHitsFromSameClan (the Python-level forms of what ckm_reduce does in bulk) against
+    verdicts recorded from the reference's classes on 260 random hits (tools/gen_host_golden.py)."""
+    from checkm_amd.hmmer import HmmerHitDOM
+    from checkm_amd.hmmerModelParser import HmmModel
+    from checkm_amd.pfam import PFAM
+    from checkm_amd.resultsParser import ResultsManager
+    r = gold["rules"]
+    models = {}
+    for acc, cut in r["models"].items():
+        m = HmmModel({"acc": acc, "name": "n_" + acc, "leng": 100})
+        m.ga, m.tc, m.nc = (tuple(cut[k]) if cut[k] is not None else None for k in ("ga", "tc", "nc"))
+        models[acc] = m
+
+    def mk(d):
+        return HmmerHitDOM([str(d[k]) for k in r["hit_field_order"]])
+    for case in r["vetHit"]:
+        rm = ResultsManager("b", models, bIgnoreThresholds=case["bIgnoreThresholds"], evalueThreshold=1e-10, lengthThreshold=0.7,
+                            bSkipPseudoGeneCorrection=case["bSkipPseudoGeneCorrection"])
+        assert [rm.vetHit(mk(d)) for d in r["hits"]] == case["verdicts"]
+    dat = tmp_path / "Pfam-A.hmm.dat"
+    dat.write_text(r["pfam_dat"])
+    for case in r["filterHitsFromSameClan"]:
+        objs, mh = {}, {}
+        for marker, idxs in case["input"].items():
+            for idx in idxs:
+                h = mk(r["hits"][idx]); objs[id(h)] = idx
+                mh.setdefault(marker, []).append(h)
+        res = PFAM(str(dat)).filterHitsFromSameClan(mh)
+        assert {k: [objs[id(h)] for h in v] for k, v in res.items()} == case["kept"]
+        assert list(res.keys()) == list(case["kept"].keys())          # non-Pfam markers first, then Pfam markers in order of survival
+        assert res["absent"] == []                                   # a defaultdict(list), as the reference returns
+
+
+def test_qa_cache_readers(tmp_path):
+    """parseBinStatsExt / parseMarkerGeneStats read back what cacheResults wrote (resultsParser.py:161-189; the reference text of both
+    caches is in tests/golden/summary_cases.json)."""
+    import ast
+
+    from checkm_amd.resultsParser import ResultsParser
+    sc = json.load(open(os.path.join(os.path.dirname(GOLD), "summary_cases.json")))["cases"][0]
+    (tmp_path / "storage").mkdir()
+    for name, text in sc["caches"].items():
+        (tmp_path / "storage" / name).write_text(text)
+    rp = ResultsParser(None)
+    for name, got in ((DefaultValues.BIN_STATS_EXT_OUT, rp.parseBinStatsExt(str(tmp_path))), (DefaultValues.MARKER_GENE_STATS, rp.parseMarkerGeneStats(str(tmp_path)))):
+        want = {ln.split("\t")[0]: ast.literal_eval(ln.split("\t")[1]) for ln in sc["caches"][name].splitlines()}
+        assert got == want and len(got) >= 2

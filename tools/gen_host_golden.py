@@ -111,6 +111,61 @@ def main():
     ha = HmmerAligner(1)
     orfs = {"c1_1": "MKV*", "c1_2": "ACD", "c9_5": "WWW*"}
     out["extract_seq"] = [[sid, ha._extractSeq(sid, orfs)] for sid in ("c1_1", "c1_2", "c1_1&&c1_2", "c1_2&&c9_5&&c1_1")]
+    # row-at-a-time rules of the reduce half: ResultsManager.vetHit (resultsParser.py:340-377) and PFAM.filterHitsFromSameClan
+    # (util/pfam.py:86-147) on random hits; hits are recorded as plain dicts, results as indices into the hit list
+    from checkm.hmmer import HmmerHitDOM
+    from checkm.hmmerModelParser import HmmModel
+    from checkm.resultsParser import ResultsManager
+    from checkm.util.pfam import PFAM
+    os.makedirs(os.path.join(DATA, "pfam"), exist_ok=True)
+    dat = ("# STOCKHOLM 1.0\n#=GF ID   famA\n#=GF AC   PF00001.3\n#=GF CL   CL0001\n#=GF NE   famC\n//\n"
+           "# STOCKHOLM 1.0\n#=GF ID   famB\n#=GF AC   PF00002.1\n#=GF CL   CL0001\n//\n"
+           "# STOCKHOLM 1.0\n#=GF ID   famC\n#=GF AC   PF00003.9\n#=GF CL   CL0001\n//\n"
+           "# STOCKHOLM 1.0\n#=GF ID   famD\n#=GF AC   PF00004.2\n//\n"
+           "# STOCKHOLM 1.0\n#=GF ID   famE\n#=GF AC   PF00005.2\n//\n")
+    dat_path = os.path.join(DATA, "pfam", "Pfam-A.hmm.dat")
+    open(dat_path, "w").write(dat)
+    model_spec = {"PF00001.3": dict(ga=(25.0, 20.0)), "PF00002.1": dict(tc=(30.0, 30.0)), "PF00003.9": dict(), "PF00004.2": dict(nc=(22.0, 21.5)),
+                  "PF00005.2": dict(ga=(10.0, 10.0), nc=(50.0, 50.0)), "TIGR00011": dict(ga=(10.0, 10.0), nc=(40.0, 35.0)), "TIGR00012": dict(tc=(33.3, 33.3))}
+    models = {}
+    for acc, cut in model_spec.items():
+        m = HmmModel({"acc": acc, "name": "n_" + acc, "leng": 100})
+        m.ga, m.tc, m.nc = cut.get("ga"), cut.get("tc"), cut.get("nc")
+        models[acc] = m
+    rnd = random.Random(21)
+    accs = sorted(model_spec)
+    hit_dicts = []
+    for k in range(260):
+        acc = rnd.choice(accs)
+        a0 = rnd.randint(1, 120); a1 = a0 + rnd.randint(0, 110)
+        fs = round(rnd.choice([9.9, 10.0, 20.0, 21.5, 22.0, 25.0, 30.0, 33.3, 35.0, 40.0, 50.0, rnd.uniform(0, 60)]), 1)
+        ds = round(rnd.choice([fs, fs - 0.1, 10.0, 20.0, 21.5, 30.0, 33.3, 35.0, rnd.uniform(0, 60)]), 1)
+        ev = rnd.choice([0.0, 1e-30, 1e-10, 1.1e-10, 9.9e-11, 1e-5])
+        hit_dicts.append({"target_name": "c%d_%d" % (rnd.randint(1, 3), rnd.randint(1, 6)), "target_accession": "-", "target_length": 300, "query_name": "n_" + acc,
+                          "query_accession": acc, "query_length": rnd.choice([100, 150, 37]), "full_e_value": ev, "full_score": fs, "full_bias": 0.0, "dom": 1, "ndom": 1,
+                          "c_evalue": ev, "i_evalue": rnd.choice([ev, ev * 10, 1e-3]), "dom_score": ds, "dom_bias": 0.0, "hmm_from": 1, "hmm_to": 90, "ali_from": a0,
+                          "ali_to": a1, "env_from": a0, "env_to": a1, "acc": 0.9, "target_description": "-"})
+    order = ["target_name", "target_accession", "target_length", "query_name", "query_accession", "query_length", "full_e_value", "full_score", "full_bias", "dom", "ndom",
+             "c_evalue", "i_evalue", "dom_score", "dom_bias", "hmm_from", "hmm_to", "ali_from", "ali_to", "env_from", "env_to", "acc", "target_description"]
+
+    def mk(d):
+        return HmmerHitDOM([str(d[k]) for k in order])
+    vet = []
+    for flags in ((False, False), (True, False), (False, True), (True, True)):
+        rm = ResultsManager("b", models, bIgnoreThresholds=flags[0], evalueThreshold=1e-10, lengthThreshold=0.7, bSkipPseudoGeneCorrection=flags[1])
+        vet.append({"bIgnoreThresholds": flags[0], "bSkipPseudoGeneCorrection": flags[1], "verdicts": [bool(rm.vetHit(mk(d))) for d in hit_dicts]})
+    clan_cases = []
+    for trial in range(12):
+        chosen = [rnd.randrange(len(hit_dicts)) for _ in range(rnd.randint(3, 40))]
+        mh = {}
+        objs = {}
+        for idx in chosen:
+            h = mk(hit_dicts[idx]); objs[id(h)] = idx
+            mh.setdefault(h.query_accession, []).append(h)
+        res = PFAM(dat_path).filterHitsFromSameClan(mh)
+        clan_cases.append({"input": {k: [objs[id(h)] for h in v] for k, v in mh.items()}, "kept": {k: [objs[id(h)] for h in v] for k, v in res.items()}})
+    out["rules"] = {"pfam_dat": dat, "models": {a: {"ga": m.ga, "tc": m.tc, "nc": m.nc} for a, m in models.items()}, "hits": hit_dicts, "hit_field_order": order,
+                    "vetHit": vet, "filterHitsFromSameClan": clan_cases}
     names = ["/a/b/bin.1.fna", "x.fa.gz", "genome.faa", "noext", "a.b.c.gz", "dir.d/file"]
     out["binIdFromFilename"] = {n: binIdFromFilename(n) for n in names}
     with open(os.path.join(ROOT, "tests", "golden", "host_cases.json"), "w") as f:
