@@ -456,3 +456,37 @@ print(json.dumps({"rows": rows, "bin_models": bin_models}))
         off += len(recs)
     assert sum(1 for g in got if g[0] == 5) == 0
     hs.close()
+
+
+def test_empty_bins_and_empty_records(gpu_ctx, tmp_path):
+    """Bins without sequences, a record without residues and a stop-only record (prodigal can emit both for a tiny contig): no rows,
+    no pairs, a domtblout that is header and trailer only -- and the neighbouring bin is scored as if it were alone."""
+    from checkm_amd import qa as cqa
+    from checkm_amd.hmmer import read_domtblout
+    profs = synth.small_profiles(7, 6, 20, 150)            # (a calibrated set: checkm_amd/synth_stats.json)
+    path = common.hmm_file("empties", profs)
+    full = synth.make_bin(profs, 77, n_orfs=40)
+    bins = [[], full, [("only_empty_1", "", ""), ("tiny_2", "", "*")], []]
+    prof = _lib.Profiles(gpu_ctx, path)
+    seqs = _lib.Seqs(gpu_ctx, bins)
+    alone = _lib.Seqs(gpu_ctx, [full])
+    hs = p7.HmmSet(path)
+    try:
+        hits = _lib.search(gpu_ctx, prof, seqs)
+        ref = _lib.search(gpu_ctx, prof, alone)
+        assert ref.n > 0 and hits.n == ref.n and list(hits.bin_row_off) == [0, 0, hits.n, hits.n, hits.n]
+        for f in ("model", "hmm_from", "hmm_to", "ali_from", "ali_to", "env_from", "env_to", "full_evalue", "i_evalue", "dom_score"):
+            assert list(getattr(hits, f)) == list(getattr(ref, f)), f
+        assert [int(x) for x in hits.seq] == [int(x) for x in ref.seq]        # bin 0 holds no sequences, so the indices coincide
+        for b in (0, 2, 3):
+            out = str(tmp_path / ("empty%d.txt" % b))
+            hits.write_domtblout(prof, seqs, b, out)
+            names = [r[0] for r in bins[b]]
+            assert open(out).read() == hs.format_domtblout([], names, [r[1] for r in bins[b]])
+            assert read_domtblout(out) == []
+        plan = cqa.QAPlan.for_hmm_models(prof, [list(range(prof.n))] * 4)
+        q = plan.reduce(gpu_ctx, hits, seqs)
+        assert [float(q.completeness[b]) for b in (0, 2, 3)] == [0.0, 0.0, 0.0] and float(q.completeness[1]) > 50.0
+        q.close(); hits.close(); ref.close()
+    finally:
+        prof.close(); seqs.close(); alone.close(); hs.close()
