@@ -4,7 +4,9 @@
  *
  * TEST INFRASTRUCTURE ONLY -- see p7oracle.h.  PARITY UNPINNED for the scan half (no HMMER
  * binary, source or golden output exists in /root/reference); the reduce half has its own,
- * pinned, oracle in oracle/reduce_oracle.py.
+ * pinned, oracle in oracle/reduce_oracle.py.  Independent of HMMER, tests/test_oracle_bruteforce.py checks
+ * Forward, null1, decoding/null2 and the optimal-accuracy alignment of this file against an enumeration of
+ * every state path of the published profile on tiny models.
  *
  * What is restated, stage by stage (HMMER 3 "p7_Pipeline", Eddy 2011 PLoS Comp Biol 7:e1002195):
  *   profile file      HMMER3/f ASCII (values are -ln p; '*' = 0)       consumer: checkm/hmmerModelParser.py:54-83

@@ -1,0 +1,259 @@
+"""The scan oracle against BRUTE-FORCE PATH ENUMERATION of the HMMER3 local profile, on models and targets small enough to list
+every state path.  The enumeration below is written from the published definition of the search profile (Eddy 2008/2011;
+HMMER User Guide, "the Plan 7 profile": N/C/J loops L/(L+3) [L/(L+2) unihit], local entry B->Mk = occ_k / sum_j occ_j (M-j+1),
+local exit Mk->E = Dk->E = 1, E->C = E->J = 1/2 [E->C = 1 unihit], insert odds ratio 1, null1 p1 = L/(L+1)) and shares no code
+with oracle/p7oracle.c -- it is an independent pin of the restatement's Forward scores (the scan oracle has no HMMER vectors to
+be pinned against: DESIGN.md section 2).  CPU only."""
+import math
+
+import numpy as np
+import pytest
+
+from checkm_amd import synth
+from oracle import p7
+
+
+def _profile(rng, M, k):
+    p = synth.random_profile(rng, M, "tiny%d" % k, "PF9%04d.1" % k)
+    for j in range(0, M + 1):          # indel probabilities large enough that insert and delete paths carry weight
+        mi, md, ii, dd = rng.uniform(0.05, 0.2), rng.uniform(0.05, 0.25), rng.uniform(0.2, 0.6), rng.uniform(0.2, 0.6)
+        p.t[j] = [1 - mi - md, mi, md, 1 - ii, ii, 1 - dd, dd]
+    p.t[0, 5:] = [1.0, 0.0]
+    p.t[M, 0:3] = [1 - p.t[M, 1], p.t[M, 1], 0.0]
+    p.t[M, 5:] = [1.0, 0.0]
+    p.stats = (-8.0, 0.71, -9.0, 0.71, -4.0, 0.70)
+    return p
+
+
+def _read_back(path):
+    """Probabilities as the FILE states them (5 decimals of -ln p): the enumeration must see what the oracle read."""
+    models, lines = [], open(path).read().split("\n")
+    i = 0
+    while i < len(lines):
+        if lines[i].startswith("LENG"):
+            M = int(lines[i].split()[1])
+        if lines[i].startswith("HMM "):
+            i += 2
+            if lines[i].split()[0] == "COMPO":
+                i += 1
+            pr = lambda toks: [0.0 if t == "*" else math.exp(-float(t)) for t in toks]
+            t = [pr(lines[i + 1].split())]
+            mat = [None]
+            i += 2
+            for k in range(1, M + 1):
+                mat.append(pr(lines[i].split()[1:21]))
+                t.append(pr(lines[i + 2].split()))
+                i += 3
+            models.append((M, mat, t))
+        i += 1
+    return models
+
+
+def _enumerate(M, mat, t, x, Lcfg, multihit):
+    """Sum and maximum over ALL state paths of the odds-ratio product for residues x (codes 0..19); returns (total, best)."""
+    L = len(x)
+    nj = 1.0 if multihit else 0.0
+    move = (2.0 + nj) / (Lcfg + 2.0 + nj)
+    loop = 1.0 - move
+    eC, eJ = (0.5, 0.5) if multihit else (1.0, 0.0)
+    MM, MI, MD, IM, II, DM, DD = range(7)
+    occ = [0.0] * (M + 1)
+    occ[1] = t[0][MI] + t[0][MM]
+    for k in range(2, M + 1):
+        occ[k] = occ[k - 1] * (t[k - 1][MM] + t[k - 1][MI]) + (1.0 - occ[k - 1]) * t[k - 1][DM]
+    Z = sum(occ[k] * (M - k + 1) for k in range(1, M + 1))
+    entry = [0.0] + [occ[k] / Z for k in range(1, M + 1)]
+    e = lambda k, i: mat[k][x[i]] / synth.BGF[x[i]]
+    acc = {"total": 0.0, "best": 0.0, "paths": 0}
+
+    def N(i, w):
+        if i < L:
+            N(i + 1, w * loop)
+        B(i, w * move)
+
+    def B(i, w):
+        if i < L:
+            for k in range(1, M + 1):
+                Mk(k, i + 1, w * entry[k] * e(k, i))
+
+    def Mk(k, i, w):                       # M_k has just emitted residue i-1
+        E(i, w)
+        if k < M:
+            if i < L:
+                Mk(k + 1, i + 1, w * t[k][MM] * e(k + 1, i))
+                Ik(k, i + 1, w * t[k][MI])
+            Dk(k + 1, i, w * t[k][MD])
+
+    def Ik(k, i, w):
+        if i < L:
+            Mk(k + 1, i + 1, w * t[k][IM] * e(k + 1, i))
+            Ik(k, i + 1, w * t[k][II])
+
+    def Dk(k, i, w):
+        E(i, w)
+        if k < M:
+            if i < L:
+                Mk(k + 1, i + 1, w * t[k][DM] * e(k + 1, i))
+            Dk(k + 1, i, w * t[k][DD])
+
+    def E(i, w):
+        Cs(i, w * eC)
+        if eJ > 0.0:
+            J(i, w * eJ)
+
+    def J(i, w):
+        if i < L:
+            J(i + 1, w * loop)
+        B(i, w * move)
+
+    def Cs(i, w):
+        if i < L:
+            Cs(i + 1, w * loop)
+        else:
+            acc["total"] += w * move
+            acc["best"] = max(acc["best"], w * move)
+            acc["paths"] += 1
+
+    N(0, 1.0)
+    return acc["total"], acc["best"], acc["paths"]
+
+
+@pytest.fixture(scope="module")
+def tiny(tmp_path_factory):
+    rng = np.random.default_rng(2024)
+    profs = [_profile(rng, M, k) for k, M in enumerate((1, 2, 3, 3, 4))]
+    path = str(tmp_path_factory.mktemp("bf") / "tiny.hmm")
+    synth.write_hmm(path, profs)
+    hs = p7.HmmSet(path)
+    yield hs, _read_back(path), rng
+    hs.close()
+
+
+def test_forward_parser_equals_the_sum_over_all_paths(tiny):
+    """fwd_sc of the oracle's per-target pipeline (multihit, whole sequence) = ln of the sum over every path; null1 likewise."""
+    hs, models, rng = tiny
+    npaths = 0
+    for m, (M, mat, t) in enumerate(models):
+        for L in (1, 2, 3, 4, 5):
+            for rep in range(3):
+                x = [int(v) for v in rng.integers(0, 20, size=L)]
+                total, best, n = _enumerate(M, mat, t, x, L, True)
+                st = hs.stages(m, np.array(x, dtype=np.uint8))
+                assert st.fwd_sc == pytest.approx(math.log(total), abs=2e-4), (m, x)
+                assert st.null_sc == pytest.approx(L * math.log(L / (L + 1.0)) + math.log(1.0 / (L + 1.0)), abs=1e-5)
+                assert math.log(best) <= st.fwd_sc + 1e-4            # Viterbi path <= Forward
+                npaths += n
+    assert npaths > 20000                                             # (the lists are real: tens of thousands of paths in all)
+
+
+def test_envelope_forward_equals_the_unihit_sum_over_all_paths(tiny):
+    """Envelope rescoring: unihit profile, N/C loops configured for the FULL target length, only residues ienv..jenv scored."""
+    hs, models, rng = tiny
+    for m, (M, mat, t) in enumerate(models):
+        for L, (ie, je) in ((5, (1, 5)), (5, (2, 4)), (6, (3, 3)), (4, (1, 2))):
+            x = [int(v) for v in rng.integers(0, 20, size=L)]
+            total, _, _ = _enumerate(M, mat, t, x[ie - 1:je], L, False)
+            rc, envsc = hs.envelope(m, np.array(x, dtype=np.uint8), ie, je)[:2]
+            assert rc == 0 and envsc == pytest.approx(math.log(total), abs=2e-4), (m, x, ie, je)
+
+
+def _decode(M, mat, t, x, Lcfg):
+    """Unihit posterior decoding and optimal accuracy by enumeration.  Returns (ppM[i][k], ppI[i][k], {'N': [..], 'C': [..]}, best) where best is
+    (accuracy, first match residue, last match residue, first match node, last match node) of the path that maximises the summed
+    posterior of its emitting states -- HMMER's optimal-accuracy criterion; an exit is taken from a match state (a path that ends
+    ...M_k D_k+1 E has the accuracy of ...M_k E and is never preferred)."""
+    L = len(x)
+    move = 2.0 / (Lcfg + 2.0)
+    loop = 1.0 - move
+    MM, MI, MD, IM, II, DM, DD = range(7)
+    occ = [0.0] * (M + 1)
+    occ[1] = t[0][MI] + t[0][MM]
+    for k in range(2, M + 1):
+        occ[k] = occ[k - 1] * (t[k - 1][MM] + t[k - 1][MI]) + (1.0 - occ[k - 1]) * t[k - 1][DM]
+    Z = sum(occ[k] * (M - k + 1) for k in range(1, M + 1))
+    entry = [0.0] + [occ[k] / Z for k in range(1, M + 1)]
+    e = lambda k, i: mat[k][x[i]] / synth.BGF[x[i]]
+    paths = []                                   # (weight, [(residue index, 'M'|'I'|'N'|'C', node)], ends_in_match)
+
+    def N(i, w, em):
+        if i < L:
+            N(i + 1, w * loop, em + [(i, 'N', 0)])
+        for k in range(1, M + 1):
+            if i < L:
+                Mk(k, i + 1, w * move * entry[k] * e(k, i), em + [(i, 'M', k)])
+
+    def Mk(k, i, w, em):
+        Cs(i, w, em, True)
+        if k < M:
+            if i < L:
+                Mk(k + 1, i + 1, w * t[k][MM] * e(k + 1, i), em + [(i, 'M', k + 1)])
+                Ik(k, i + 1, w * t[k][MI], em + [(i, 'I', k)])
+            Dk(k + 1, i, w * t[k][MD], em)
+
+    def Ik(k, i, w, em):
+        if i < L:
+            Mk(k + 1, i + 1, w * t[k][IM] * e(k + 1, i), em + [(i, 'M', k + 1)])
+            Ik(k, i + 1, w * t[k][II], em + [(i, 'I', k)])
+
+    def Dk(k, i, w, em):
+        Cs(i, w, em, False)
+        if k < M:
+            if i < L:
+                Mk(k + 1, i + 1, w * t[k][DM] * e(k + 1, i), em + [(i, 'M', k + 1)])
+            Dk(k + 1, i, w * t[k][DD], em)
+
+    def Cs(i, w, em, from_match):
+        if i < L:
+            Cs(i + 1, w * loop, em + [(i, 'C', 0)], from_match)
+        else:
+            paths.append((w * move, em, from_match))
+
+    N(0, 1.0, [])
+    total = sum(p[0] for p in paths)
+    ppM = [[0.0] * (M + 1) for _ in range(L)]
+    ppI = [[0.0] * (M + 1) for _ in range(L)]
+    ppX = {'N': [0.0] * L, 'C': [0.0] * L}
+    for w, em, _ in paths:
+        for i, kind, k in em:
+            if kind == 'M':
+                ppM[i][k] += w / total
+            elif kind == 'I':
+                ppI[i][k] += w / total
+            else:
+                ppX[kind][i] += w / total
+    best = None
+    for w, em, from_match in paths:
+        if not from_match:
+            continue
+        acc = sum(ppM[i][k] if kind == 'M' else ppI[i][k] if kind == 'I' else ppX[kind][i] for i, kind, k in em)
+        ms = [(i, k) for i, kind, k in em if kind == 'M']
+        cand = (acc, ms[0][0] + 1, ms[-1][0] + 1, ms[0][1], ms[-1][1])
+        if best is None or cand[0] > best[0]:
+            best = cand
+    return ppM, ppI, ppX, best
+
+
+def test_envelope_decoding_null2_and_optimal_accuracy_by_enumeration(tiny):
+    """Per envelope: the optimal-accuracy score and its alignment coordinates, and the null2 odds by expectation
+    (usage of every match / insert state and of N+C over the envelope, divided by its length)."""
+    hs, models, rng = tiny
+    checked = 0
+    for m, (M, mat, t) in enumerate(models):
+        for L, (ie, je) in ((5, (1, 5)), (6, (2, 5)), (4, (1, 3)), (6, (1, 6))):
+            x = [int(v) for v in rng.integers(0, 20, size=L)]
+            sub = x[ie - 1:je]
+            Ld = len(sub)
+            ppM, ppI, ppX, best = _decode(M, mat, t, sub, L)
+            rc, envsc, oasc, null2, coords, _xC, _ns = hs.envelope(m, np.array(x, dtype=np.uint8), ie, je)
+            assert rc == 0
+            assert oasc == pytest.approx(best[0], abs=2e-4), (m, x, ie, je)
+            # a second path within float noise of the best one may differ in coordinates: only unambiguous cases are compared
+            hmm_from, hmm_to, ali_from, ali_to = (int(v) for v in coords)
+            assert (ali_from, ali_to, hmm_from, hmm_to) == (best[1] + ie - 1, best[2] + ie - 1, best[3], best[4]), (m, x, ie, je)
+            for r in range(20):
+                want = (sum(ppX['N']) + sum(ppX['C'])) / Ld
+                for k in range(1, M + 1):
+                    want += sum(ppM[i][k] for i in range(Ld)) / Ld * (mat[k][r] / synth.BGF[r]) + sum(ppI[i][k] for i in range(Ld)) / Ld
+                assert float(null2[r]) == pytest.approx(want, rel=3e-4), (m, r)
+            checked += 1
+    assert checked == 20
