@@ -21,7 +21,7 @@ def _profile(rng, M, k):
     p.t[0, 5:] = [1.0, 0.0]
     p.t[M, 0:3] = [1 - p.t[M, 1], p.t[M, 1], 0.0]
     p.t[M, 5:] = [1.0, 0.0]
-    p.stats = (-8.0, 0.71, -9.0, 0.71, -4.0, 0.70)
+    p.stats = (-30.0, 0.71, -30.0, 0.71, -30.0, 0.70)      # so permissive that a five-residue target clears every filter
     return p
 
 
@@ -257,3 +257,61 @@ def test_envelope_decoding_null2_and_optimal_accuracy_by_enumeration(tiny):
                 assert float(null2[r]) == pytest.approx(want, rel=3e-4), (m, r)
             checked += 1
     assert checked == 20
+
+
+def test_reported_scores_and_evalues_follow_from_the_enumerated_quantities(tiny, capfd, monkeypatch):
+    """The score arithmetic behind a domtblout row, rebuilt from enumerated quantities only (HMMER User Guide, "how scores and
+    E-values are calculated"; p7_Pipeline): null2 bias = ln(1 + omega * prod null2(x_i)) with omega 1/256, domain bit score =
+    (envelope Forward + (L - Ld) ln(L/(L+3)) - null1 - bias) / ln 2, sequence score from the whole-sequence Forward or from the sum
+    of its domains, whichever is larger, lnP from the exponential tail (tau, lambda of the model), E = P * Z, c-E = P * domZ."""
+    hs, models, rng = tiny
+    tau, lam, omega = -30.0, 0.70, 1.0 / 256.0
+    monkeypatch.setenv("P7O_TRACE_REGIONS", "1")       # the oracle then names on stderr the regions it resolves by the stochastic ensemble
+    seen = ensemble = 0
+    for m, (M, mat, t) in enumerate(models):
+        for rep in range(50):
+            L = int(rng.integers(3, 7))
+            x = [int(v) for v in rng.integers(0, 20, size=L)]
+            if rep % 2 == 0:                       # half of the targets carry the consensus of the model: clearly positive scores
+                for k in range(1, min(M, L) + 1):
+                    x[k - 1] = int(np.argmax(mat[k]))
+            capfd.readouterr()
+            rows = hs.search([m], [np.array(x, dtype=np.uint8)], ["t"])
+            if "multi-domain region" in capfd.readouterr().err:
+                ensemble += 1                      # null2 by trace, envelopes by clustering: not a closed-form quantity
+                continue
+            if len(rows) != 1 or rows[0].ndom != 1:
+                continue
+            r = rows[0]
+            ie, je = r.env_from, r.env_to
+            sub, Ld = x[ie - 1:je], je - ie + 1
+            env_total, _, _ = _enumerate(M, mat, t, sub, L, False)
+            ppM, ppI, ppX, best = _decode(M, mat, t, sub, L)
+            null2 = []
+            for res in range(20):
+                v = (sum(ppX['N']) + sum(ppX['C'])) / Ld
+                for k in range(1, M + 1):
+                    v += sum(ppM[i][k] for i in range(Ld)) / Ld * (mat[k][res] / synth.BGF[res]) + sum(ppI[i][k] for i in range(Ld)) / Ld
+                null2.append(v)
+            domcorr = sum(math.log(null2[c]) for c in sub)
+            bias = math.log(1.0 + omega * math.exp(domcorr))
+            null1 = L * math.log(L / (L + 1.0)) + math.log(1.0 / (L + 1.0))
+            envsc = math.log(env_total)
+            dom_bits = (envsc + (L - Ld) * math.log(L / (L + 3.0)) - null1 - bias) / math.log(2.0)
+            fwd_total, _, _ = _enumerate(M, mat, t, x, L, True)
+            seq_bits = (math.log(fwd_total) - null1 - bias) / math.log(2.0)
+            pre_bits = (math.log(fwd_total) - null1) / math.log(2.0)
+            if envsc - domcorr > 0.0 and dom_bits > seq_bits:          # the domain sum replaces the whole-sequence score
+                seq_bits, pre_bits = dom_bits, (envsc + (L - Ld) * math.log(L / (L + 3.0)) - null1) / math.log(2.0)
+            tol = 3e-3                                                   # the table-driven log-sum HMMER uses is good to 1e-3 nats
+            assert r.dom_score == pytest.approx(dom_bits, abs=tol), (m, x)
+            assert r.dom_bias == pytest.approx(bias / math.log(2.0), abs=tol)
+            assert r.full_score == pytest.approx(seq_bits, abs=tol), (m, x)
+            assert r.full_bias == pytest.approx(pre_bits - seq_bits, abs=2 * tol)
+            lnP_dom = 0.0 if r.dom_score < tau else -lam * (r.dom_score - tau)
+            lnP_seq = 0.0 if r.full_score < tau else -lam * (r.full_score - tau)
+            assert r.i_evalue == pytest.approx(math.exp(lnP_dom) * 1.0, rel=1e-5) and r.c_evalue == pytest.approx(math.exp(lnP_dom) * 1.0, rel=1e-5)
+            assert r.full_evalue == pytest.approx(math.exp(lnP_seq) * 1.0, rel=1e-5)
+            assert r.acc == pytest.approx(best[0] / (1.0 + abs(je - ie)), abs=1e-4)
+            seen += 1
+    assert seen >= 30, (seen, ensemble)
