@@ -49,12 +49,14 @@ def _read_back(path):
     return models
 
 
-def _enumerate(M, mat, t, x, Lcfg, multihit):
-    """Sum and maximum over ALL state paths of the odds-ratio product for residues x (codes 0..19); returns (total, best)."""
+def _enumerate(M, mat, t, x, Lcfg, multihit, free_loops=False, ungapped_uniform=False):
+    """Sum and maximum over ALL state paths of the odds-ratio product for residues x (codes 0..19); returns (total, best, #paths).
+    free_loops: N/C/J self-loops cost nothing (the approximation both integer filters make, repaired by a flat -3 nats);
+    ungapped_uniform: the MSV model -- uniform entry 2/(M(M+1)), match-to-match for free, no inserts or deletes."""
     L = len(x)
     nj = 1.0 if multihit else 0.0
     move = (2.0 + nj) / (Lcfg + 2.0 + nj)
-    loop = 1.0 - move
+    loop = 1.0 if free_loops else 1.0 - move
     eC, eJ = (0.5, 0.5) if multihit else (1.0, 0.0)
     MM, MI, MD, IM, II, DM, DD = range(7)
     occ = [0.0] * (M + 1)
@@ -63,6 +65,9 @@ def _enumerate(M, mat, t, x, Lcfg, multihit):
         occ[k] = occ[k - 1] * (t[k - 1][MM] + t[k - 1][MI]) + (1.0 - occ[k - 1]) * t[k - 1][DM]
     Z = sum(occ[k] * (M - k + 1) for k in range(1, M + 1))
     entry = [0.0] + [occ[k] / Z for k in range(1, M + 1)]
+    if ungapped_uniform:
+        entry = [0.0] + [2.0 / (M * (M + 1.0))] * M
+        t = [[1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0] for _ in range(M + 1)]
     e = lambda k, i: mat[k][x[i]] / synth.BGF[x[i]]
     acc = {"total": 0.0, "best": 0.0, "paths": 0}
 
@@ -85,11 +90,15 @@ def _enumerate(M, mat, t, x, Lcfg, multihit):
             Dk(k + 1, i, w * t[k][MD])
 
     def Ik(k, i, w):
+        if w == 0.0:
+            return
         if i < L:
             Mk(k + 1, i + 1, w * t[k][IM] * e(k + 1, i))
             Ik(k, i + 1, w * t[k][II])
 
     def Dk(k, i, w):
+        if w == 0.0:
+            return
         E(i, w)
         if k < M:
             if i < L:
@@ -125,6 +134,7 @@ def tiny(tmp_path_factory):
     path = str(tmp_path_factory.mktemp("bf") / "tiny.hmm")
     synth.write_hmm(path, profs)
     hs = p7.HmmSet(path)
+    hs.file_path = path
     yield hs, _read_back(path), rng
     hs.close()
 
@@ -259,6 +269,82 @@ def test_envelope_decoding_null2_and_optimal_accuracy_by_enumeration(tiny):
     assert checked == 20
 
 
+def _regions(M, mat, t, x):
+    """Domain regions of the posterior heuristics (HMMER User Guide / p7_domaindef: rt1 0.25, rt2 0.10, rt3 0.20), from enumerated
+    multihit posteriors: mocc[i] = P(residue i is emitted by the model core), begin / end mass = P(a domain begins at i / ends at i).
+    Returns [(i, j, is_multidomain)]."""
+    L = len(x)
+    move = 3.0 / (L + 3.0)
+    loop = 1.0 - move
+    MM, MI, MD, IM, II, DM, DD = range(7)
+    occ = [0.0] * (M + 1)
+    occ[1] = t[0][MI] + t[0][MM]
+    for k in range(2, M + 1):
+        occ[k] = occ[k - 1] * (t[k - 1][MM] + t[k - 1][MI]) + (1.0 - occ[k - 1]) * t[k - 1][DM]
+    Z = sum(occ[k] * (M - k + 1) for k in range(1, M + 1))
+    entry = [0.0] + [occ[k] / Z for k in range(1, M + 1)]
+    e = lambda k, i: mat[k][x[i]] / synth.BGF[x[i]]
+    core = [0.0] * (L + 1)
+    beg = [0.0] * (L + 2)       # beg[i]: a domain's first residue is i (1-based)
+    end = [0.0] * (L + 1)       # end[i]: a domain's last residue is i
+    tot = [0.0]
+
+    def flank(i, w, ev):                          # N or J: i residues consumed so far
+        if i < L:
+            flank(i + 1, w * loop, ev)
+            for k in range(1, M + 1):
+                Mk(k, i + 1, w * move * entry[k] * e(k, i), ev + [('b', i + 1), ('c', i + 1)])
+
+    def Mk(k, i, w, ev):
+        E(i, w, ev)
+        if k < M:
+            if i < L:
+                Mk(k + 1, i + 1, w * t[k][MM] * e(k + 1, i), ev + [('c', i + 1)])
+                Ik(k, i + 1, w * t[k][MI], ev + [('c', i + 1)])
+            Dk(k + 1, i, w * t[k][MD], ev)
+
+    def Ik(k, i, w, ev):
+        if i < L:
+            Mk(k + 1, i + 1, w * t[k][IM] * e(k + 1, i), ev + [('c', i + 1)])
+            Ik(k, i + 1, w * t[k][II], ev + [('c', i + 1)])
+
+    def Dk(k, i, w, ev):
+        E(i, w, ev)
+        if k < M:
+            if i < L:
+                Mk(k + 1, i + 1, w * t[k][DM] * e(k + 1, i), ev + [('c', i + 1)])
+            Dk(k + 1, i, w * t[k][DD], ev)
+
+    def E(i, w, ev):
+        ev = ev + [('e', i)]
+        flank(i, w * 0.5, ev)                     # E -> J, then J behaves as N does
+        w2 = w * 0.5 * loop ** (L - i) * move     # E -> C, C emits the rest, C -> T
+        tot[0] += w2
+        for kind, pos in ev:
+            (core if kind == 'c' else beg if kind == 'b' else end)[pos] += w2
+
+    flank(0, 1.0, [])
+    mocc = [0.0] + [core[i] / tot[0] for i in range(1, L + 1)]
+    btot, etot = [0.0] * (L + 1), [0.0] * (L + 1)
+    for i in range(1, L + 1):
+        btot[i] = btot[i - 1] + beg[i] / tot[0]
+        etot[i] = etot[i - 1] + end[i] / tot[0]
+    out, i, triggered = [], -1, False
+    for j in range(1, L + 1):
+        if not triggered:
+            if mocc[j] - (btot[j] - btot[j - 1]) < 0.10:
+                i = j
+            elif i == -1:
+                i = j
+            if mocc[j] >= 0.25:
+                triggered = True
+        elif mocc[j] - (etot[j] - etot[j - 1]) < 0.10:
+            worst = max(min(etot[z] - etot[i - 1], btot[j] - btot[z - 1]) for z in range(i, j + 1))
+            out.append((i, j, worst >= 0.20))
+            i, triggered = -1, False
+    return out
+
+
 def test_reported_scores_and_evalues_follow_from_the_enumerated_quantities(tiny, capfd, monkeypatch):
     """The score arithmetic behind a domtblout row, rebuilt from enumerated quantities only (HMMER User Guide, "how scores and
     E-values are calculated"; p7_Pipeline): null2 bias = ln(1 + omega * prod null2(x_i)) with omega 1/256, domain bit score =
@@ -269,21 +355,25 @@ def test_reported_scores_and_evalues_follow_from_the_enumerated_quantities(tiny,
     monkeypatch.setenv("P7O_TRACE_REGIONS", "1")       # the oracle then names on stderr the regions it resolves by the stochastic ensemble
     seen = ensemble = 0
     for m, (M, mat, t) in enumerate(models):
-        for rep in range(50):
-            L = int(rng.integers(3, 7))
+        for rep in range(36):
+            L = int(rng.integers(3, 7 if M <= 2 else 6))          # (the multihit event enumeration grows fast with L and M)
             x = [int(v) for v in rng.integers(0, 20, size=L)]
             if rep % 2 == 0:                       # half of the targets carry the consensus of the model: clearly positive scores
                 for k in range(1, min(M, L) + 1):
                     x[k - 1] = int(np.argmax(mat[k]))
             capfd.readouterr()
             rows = hs.search([m], [np.array(x, dtype=np.uint8)], ["t"])
-            if "multi-domain region" in capfd.readouterr().err:
+            regions = _regions(M, mat, t, x)
+            used_ensemble = "multi-domain region" in capfd.readouterr().err
+            assert used_ensemble == any(multi for _, _, multi in regions), (m, x, regions)
+            if used_ensemble:
                 ensemble += 1                      # null2 by trace, envelopes by clustering: not a closed-form quantity
                 continue
             if len(rows) != 1 or rows[0].ndom != 1:
                 continue
             r = rows[0]
             ie, je = r.env_from, r.env_to
+            assert regions == [(ie, je, False)], (m, x, regions)       # a single-domain region IS the envelope
             sub, Ld = x[ie - 1:je], je - ie + 1
             env_total, _, _ = _enumerate(M, mat, t, sub, L, False)
             ppM, ppI, ppX, best = _decode(M, mat, t, sub, L)
@@ -314,4 +404,49 @@ def test_reported_scores_and_evalues_follow_from_the_enumerated_quantities(tiny,
             assert r.full_evalue == pytest.approx(math.exp(lnP_seq) * 1.0, rel=1e-5)
             assert r.acc == pytest.approx(best[0] / (1.0 + abs(je - ie)), abs=1e-4)
             seen += 1
-    assert seen >= 30, (seen, ensemble)
+    assert seen >= 20 and ensemble >= 20, (seen, ensemble)
+
+
+def test_integer_filters_approximate_the_best_path_of_their_models(tiny):
+    """ViterbiFilter (16-bit, 1/500 bit) and MSVFilter (8-bit, 1/3 bit): the best path of the full profile / of the ungapped
+    uniform-entry model with N/C/J loops for free, minus the flat 3 nats both filters charge for those loops.  The filters round
+    every term, so agreement is to the rounding they are allowed: half a unit per term of the path."""
+    hs, models, rng = tiny
+    for m, (M, mat, t) in enumerate(models):
+        for L in (2, 3, 4, 5, 6):
+            for rep in range(3):
+                x = [int(v) for v in rng.integers(0, 20, size=L)]
+                st = hs.stages(m, np.array(x, dtype=np.uint8))
+                _, best, _ = _enumerate(M, mat, t, x, L, True, free_loops=True)
+                nterms = 2 * L + 6
+                assert st.vit_sc == pytest.approx(math.log(best) - 3.0, abs=nterms * 0.5 * math.log(2.0) / 500.0 + 1e-3), (m, x)
+                _, best, _ = _enumerate(M, mat, t, x, L, True, free_loops=True, ungapped_uniform=True)
+                assert st.msv_sc == pytest.approx(math.log(best) - 3.0, abs=nterms * 0.5 * math.log(2.0) / 3.0 + 1e-3), (m, x)
+
+
+def test_bias_filter_equals_the_sum_over_all_paths_of_the_two_state_model(tiny):
+    """The composition filter: a two-state HMM (background, mean run 400; model composition, mean run M/8; start 0.999 / 0.001)
+    scored as odds against the background plus the null1 length terms -- 2^L paths, all of them listed."""
+    import itertools
+    hs, models, rng = tiny
+    compos = []
+    for ln in open(hs.file_path).read().split("\n"):
+        if ln.split()[:1] == ["COMPO"]:
+            compos.append([math.exp(-float(v)) for v in ln.split()[1:21]])
+    assert len(compos) == len(models)
+    for m, (M, mat, t) in enumerate(models):
+        L0, L1 = 400.0, M / 8.0
+        tr = [[L0 / (L0 + 1.0), 1.0 / (L0 + 1.0)], [1.0 / (L1 + 1.0), L1 / (L1 + 1.0)]]
+        pi = [0.999, 0.001]
+        for L in (1, 2, 5, 8):
+            x = [int(v) for v in rng.integers(0, 20, size=L)]
+            odds = lambda s, c: 1.0 if s == 0 else compos[m][c] / synth.BGF[c]
+            total = 0.0
+            for states in itertools.product((0, 1), repeat=L):
+                w = pi[states[0]] * odds(states[0], x[0])
+                for i in range(1, L):
+                    w *= tr[states[i - 1]][states[i]] * odds(states[i], x[i])
+                total += w
+            want = math.log(total) + L * math.log(L / (L + 1.0)) + math.log(1.0 / (L + 1.0))
+            st = hs.stages(m, np.array(x, dtype=np.uint8))
+            assert st.bias_sc == pytest.approx(want, abs=2e-5), (m, x)
