@@ -35,83 +35,65 @@ class AminoAcidIdentity(object):
     def run(self, aaiStrainThreshold, outDir, alignmentOutputFile):
         """AAI between all pairs of copies of every multi-copy marker of every bin (aminoAcidIdentity.py:39-98)."""
         self.logger.info('Calculating AAI between multi-copy marker genes.')
-        fout = open(alignmentOutputFile, 'w') if alignmentOutputFile else None
-        aaiOutputDir = os.path.join(outDir, 'storage', 'aai_qa')
+        report = open(alignmentOutputFile, 'w') if alignmentOutputFile else None
+        root = os.path.join(outDir, 'storage', 'aai_qa')
+        sep = DefaultValues.SEQ_CONCAT_CHAR
         for binId in getBinIdsFromOutDir(outDir):
-            binPath = os.path.join(aaiOutputDir, binId)
-            if not os.path.exists(binPath):
+            folder = os.path.join(root, binId)
+            if not os.path.isdir(folder):
                 continue
-            for f in os.listdir(binPath):
-                if not f.endswith('.masked.faa'):
+            for name in os.listdir(folder):
+                if not name.endswith('.masked.faa'):
                     continue
-                markerId = f[0:f.find('.')]          # cut at the FIRST dot, as the reference does (PF00318.15 -> PF00318)
-                seqs = _read_masked(os.path.join(binPath, f))
-                ids = list(seqs.keys())
-                for i in range(len(ids)):
-                    binIdI = ids[i][0:ids[i].find(DefaultValues.SEQ_CONCAT_CHAR)]
-                    for j in range(i + 1, len(ids)):
-                        binIdJ = ids[j][0:ids[j].find(DefaultValues.SEQ_CONCAT_CHAR)]
-                        if binIdI != binIdJ:
+                marker = name[:name.find('.')]                 # cut at the FIRST dot, as the reference does (PF00318.15 -> PF00318)
+                copies = list(_read_masked(os.path.join(folder, name)).items())
+                owners = [cid[:cid.find(sep)] for cid, _ in copies]
+                for a in range(len(copies)):
+                    for b in range(a + 1, len(copies)):
+                        if owners[a] != owners[b]:
                             self.logger.error('Bin ids do not match.')
                             sys.exit(1)
-                        score = self.aai(seqs[ids[i]], seqs[ids[j]])
-                        if fout:
-                            fout.write(binId + ',' + markerId + '\n')
-                            fout.write(ids[i] + '\t' + seqs[ids[i]] + '\n')
-                            fout.write(ids[j] + '\t' + seqs[ids[j]] + '\n')
-                            fout.write('AAI: %.3f\n' % score)
-                            fout.write('\n')
-                        if binIdI not in self.aaiRawScores:
-                            self.aaiRawScores[binIdI] = defaultdict(list)
-                        self.aaiRawScores[binIdI][markerId].append(score)
-        if fout:
-            fout.close()
+                        (ida, sa), (idb, sb) = copies[a], copies[b]
+                        score = self.aai(sa, sb)
+                        if report:
+                            report.write('%s,%s\n%s\t%s\n%s\t%s\nAAI: %.3f\n\n' % (binId, marker, ida, sa, idb, sb, score))
+                        if owners[a] not in self.aaiRawScores:       # (a plain defaultdict(dict) on first touch would do; kept as the reference builds it)
+                            self.aaiRawScores[owners[a]] = defaultdict(list)
+                        self.aaiRawScores[owners[a]][marker].append(score)
+        if report:
+            report.close()
         self.aaiHetero, self.aaiMeanBinHetero = self.strainHetero(self.aaiRawScores, aaiStrainThreshold)
 
     def strainHetero(self, aaiScores, aaiStrainThreshold):
         """Per marker: fraction of copy pairs above the threshold; per bin: percentage over all its pairs (:100-124)."""
-        aaiHetero = defaultdict(dict)
-        aaiMeanBinHetero = {}
+        per_marker = defaultdict(dict)
+        per_bin = {}
         for binId, markers in aaiScores.items():
-            strainCount = multiCopyPairs = 0
-            aaiHetero[binId] = {}
-            for markerId, scores in markers.items():
-                local = 0
-                for sc in scores:
-                    multiCopyPairs += 1
-                    if sc > aaiStrainThreshold:
-                        strainCount += 1
-                        local += 1
-                aaiHetero[binId][markerId] = float(local) / len(scores)
-            aaiMeanBinHetero[binId] = 100 * float(strainCount) / multiCopyPairs
-        return aaiHetero, aaiMeanBinHetero
+            above_all = pairs_all = 0
+            per_marker[binId] = {}
+            for marker, scores in markers.items():
+                above = sum(1 for sc in scores if sc > aaiStrainThreshold)
+                per_marker[binId][marker] = float(above) / len(scores)
+                above_all += above
+                pairs_all += len(scores)
+            per_bin[binId] = 100 * float(above_all) / pairs_all
+        return per_marker, per_bin
 
     def aai(self, seq1, seq2):
-        """Identity over the columns between the leading and trailing gap runs (:126-161).  The trailing scan stops at index 1 and
-        never looks at index 0, as the reference's does."""
+        """Identity over the columns between the leading and trailing gap runs (:126-161): columns where both rows are gaps do not
+        count, a gap against a residue is a mismatch.  The trailing scan never looks at column 0, as the reference's does not."""
         assert len(seq1) == len(seq2)
-        n = len(seq1)
-        start = 0
-        for i in range(n):
-            if seq1[i] == '-' or seq2[i] == '-':
-                start = i + 1
-            else:
-                break
-        end = n
-        for i in range(n - 1, 0, -1):
-            if seq1[i] == '-' or seq2[i] == '-':
-                end = i
-            else:
-                break
-        mismatches = seqLen = 0
-        for i in range(start, end):
-            if seq1[i] != seq2[i]:
-                mismatches += 1
-                seqLen += 1
-            elif seq1[i] == '-' and seq2[i] == '-':
-                pass
-            else:
-                seqLen += 1
-        if seqLen == 0:
-            return 0.0
-        return 1.0 - (float(mismatches) / seqLen)
+        gapped = [x == '-' or y == '-' for x, y in zip(seq1, seq2)]
+        first = 0
+        while first < len(gapped) and gapped[first]:
+            first += 1
+        last = len(gapped)
+        while last > 1 and gapped[last - 1]:
+            last -= 1
+        compared = differing = 0
+        for x, y in zip(seq1[first:last], seq2[first:last]):
+            if x == '-' and y == '-':
+                continue
+            compared += 1
+            differing += x != y
+        return 1.0 - float(differing) / compared if compared else 0.0
