@@ -450,3 +450,112 @@ def test_bias_filter_equals_the_sum_over_all_paths_of_the_two_state_model(tiny):
             want = math.log(total) + L * math.log(L / (L + 1.0)) + math.log(1.0 / (L + 1.0))
             st = hs.stages(m, np.array(x, dtype=np.uint8))
             assert st.bias_sc == pytest.approx(want, abs=2e-5), (m, x)
+
+
+def _segmentations(M, mat, t, x):
+    """Every multihit path of the whole target with its weight, reduced to what the trace ensemble keeps of a path: per domain
+    (first match residue, last match residue, first match node, last match node) and, for the null2-by-trace terms, the states that
+    emitted the residues from the first to the last match.  Returns (total weight, {segmentation: weight}, per-residue expectation of
+    the null2 odds ratio, its second moment)."""
+    L = len(x)
+    move = 3.0 / (L + 3.0)
+    loop = 1.0 - move
+    MM, MI, MD, IM, II, DM, DD = range(7)
+    occ = [0.0] * (M + 1)
+    occ[1] = t[0][MI] + t[0][MM]
+    for k in range(2, M + 1):
+        occ[k] = occ[k - 1] * (t[k - 1][MM] + t[k - 1][MI]) + (1.0 - occ[k - 1]) * t[k - 1][DM]
+    Z = sum(occ[k] * (M - k + 1) for k in range(1, M + 1))
+    entry = [0.0] + [occ[k] / Z for k in range(1, M + 1)]
+    e = lambda k, i: mat[k][x[i]] / synth.BGF[x[i]]
+    seg_w = {}
+    m1 = [0.0] * (L + 1)
+    m2 = [0.0] * (L + 1)
+    tot = [0.0]
+
+    def finish(w, doms):
+        tot[0] += w
+        key = []
+        ratio = [1.0] * (L + 1)
+        for em in doms:                                   # em: [(residue, 'M'|'I', node)] of one domain, in order
+            ms = [(i, k) for i, kind, k in em if kind == 'M']
+            sqfrom, sqto = ms[0][0], ms[-1][0]
+            key.append((sqfrom, sqto, ms[0][1], ms[-1][1]))
+            inside = [(i, kind, k) for i, kind, k in em if sqfrom <= i <= sqto]
+            n = float(len(inside))
+            for pos in range(sqfrom + 1, sqto + 1):       # the first residue of a domain keeps ratio 1 (HMMER's `pos <= sqfrom` loop)
+                r = x[pos - 1]
+                ratio[pos] = sum((mat[k][r] / synth.BGF[r]) if kind == 'M' else 1.0 for _, kind, k in inside) / n
+        key = tuple(key)
+        seg_w[key] = seg_w.get(key, 0.0) + w
+        for pos in range(1, L + 1):
+            m1[pos] += w * ratio[pos]
+            m2[pos] += w * ratio[pos] * ratio[pos]
+
+    def flank(i, w, doms):
+        if i < L:
+            flank(i + 1, w * loop, doms)
+            for k in range(1, M + 1):
+                Mk(k, i + 1, w * move * entry[k] * e(k, i), doms, [(i + 1, 'M', k)])
+
+    def Mk(k, i, w, doms, em):
+        E(i, w, doms + [em])
+        if k < M:
+            if i < L:
+                Mk(k + 1, i + 1, w * t[k][MM] * e(k + 1, i), doms, em + [(i + 1, 'M', k + 1)])
+                Ik(k, i + 1, w * t[k][MI], doms, em + [(i + 1, 'I', k)])
+            Dk(k + 1, i, w * t[k][MD], doms, em)
+
+    def Ik(k, i, w, doms, em):
+        if i < L:
+            Mk(k + 1, i + 1, w * t[k][IM] * e(k + 1, i), doms, em + [(i + 1, 'M', k + 1)])
+            Ik(k, i + 1, w * t[k][II], doms, em + [(i + 1, 'I', k)])
+
+    def Dk(k, i, w, doms, em):
+        E(i, w, doms + [em])
+        if k < M:
+            if i < L:
+                Mk(k + 1, i + 1, w * t[k][DM] * e(k + 1, i), doms, em + [(i + 1, 'M', k + 1)])
+            Dk(k + 1, i, w * t[k][DD], doms, em)
+
+    def E(i, w, doms):
+        flank(i, w * 0.5, doms)
+        finish(w * 0.5 * loop ** (L - i) * move, doms)
+
+    flank(0, 1.0, [])
+    return tot[0], seg_w, [v / tot[0] for v in m1], [v / tot[0] for v in m2]
+
+
+def test_trace_ensemble_samples_paths_with_their_probabilities(tiny):
+    """The 200 stochastic tracebacks of a region: the domain segmentations they produce occur with the frequencies the enumerated
+    path probabilities predict (binomial 4.5 sigma: the generator is seeded, so the outcome is fixed), no impossible segmentation
+    ever appears, and the summed per-residue null2 odds (null2 by trace) average to their exact expectation."""
+    hs, models, rng = tiny
+    N = 200
+    for m in (1, 2, 3):                                # (2, 3 and 3 nodes: the enumeration with per-domain bookkeeping grows fast)
+        M, mat, t = models[m]
+        cons = [int(np.argmax(mat[k])) for k in range(1, M + 1)]
+        for x in (cons + cons, cons + [int(rng.integers(0, 20))] + cons[:max(1, M - 1)], [int(v) for v in rng.integers(0, 20, size=5)]):
+            x = x[:6]
+            L = len(x)
+            total, seg_w, mean, second = _segmentations(M, mat, t, x)
+            rc, n2sum, segs, nseg, _env = hs.region_ensemble(m, np.array(x, dtype=np.uint8), 1, L)
+            assert rc == 0
+            seen = {}
+            for tr in range(N):
+                key = tuple(tuple(int(v) for v in segs[tr, d]) for d in range(int(nseg[tr])))
+                seen[key] = seen.get(key, 0) + 1
+            assert all(k in seg_w and seg_w[k] > 0.0 for k in seen), [k for k in seen if k not in seg_w]
+            rare_p, rare_n = 0.0, 0
+            for key, w in seg_w.items():
+                p = w / total
+                if N * p >= 3.0:
+                    sd = math.sqrt(N * p * (1.0 - p))
+                    assert abs(seen.get(key, 0) - N * p) <= 4.5 * sd + 1e-9, (m, x, key, seen.get(key, 0), N * p)
+                else:
+                    rare_p += p
+                    rare_n += seen.get(key, 0)
+            assert abs(rare_n - N * rare_p) <= 4.5 * math.sqrt(max(N * rare_p * (1.0 - rare_p), 1e-12)) + 1.0
+            for pos in range(1, L + 1):
+                sd = math.sqrt(max(second[pos] - mean[pos] ** 2, 0.0) / N)
+                assert float(n2sum[pos - 1]) / N == pytest.approx(mean[pos], abs=4.5 * sd + 1e-5), (m, x, pos)
