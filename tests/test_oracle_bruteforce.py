@@ -237,7 +237,7 @@ def _decode(M, mat, t, x, Lcfg):
             continue
         acc = sum(ppM[i][k] if kind == 'M' else ppI[i][k] if kind == 'I' else ppX[kind][i] for i, kind, k in em)
         ms = [(i, k) for i, kind, k in em if kind == 'M']
-        cand = (acc, ms[0][0] + 1, ms[-1][0] + 1, ms[0][1], ms[-1][1])
+        cand = (acc, ms[0][0] + 1, ms[-1][0] + 1, ms[0][1], ms[-1][1], ms)
         if best is None or cand[0] > best[0]:
             best = cand
     return ppM, ppI, ppX, best
@@ -559,3 +559,19 @@ def test_trace_ensemble_samples_paths_with_their_probabilities(tiny):
             for pos in range(1, L + 1):
                 sd = math.sqrt(max(second[pos] - mean[pos] ** 2, 0.0) / N)
                 assert float(n2sum[pos - 1]) / N == pytest.approx(mean[pos], abs=4.5 * sd + 1e-5), (m, x, pos)
+
+
+def test_alignment_to_the_model_is_the_optimal_accuracy_path(tiny):
+    """hmmalign restated (p7o_align: unihit, whole sequence): the residue each match state emits on the optimal-accuracy path."""
+    hs, models, rng = tiny
+    for m, (M, mat, t) in enumerate(models):
+        for L in (3, 4, 5, 6):
+            x = [int(v) for v in rng.integers(0, 20, size=L)]
+            for k in range(1, min(M, L - 1) + 1):           # consensus residues from position 2 on: the path has something to find
+                x[k] = int(np.argmax(mat[k]))
+            best = _decode(M, mat, t, x, L)[3]
+            rc, path = hs.align(m, np.array(x, dtype=np.uint8))
+            want = [0] * M
+            for i, k in best[5]:
+                want[k - 1] = i + 1
+            assert rc == 0 and [int(v) for v in path] == want, (m, x)
