@@ -575,3 +575,83 @@ def test_alignment_to_the_model_is_the_optimal_accuracy_path(tiny):
             for i, k in best[5]:
                 want[k - 1] = i + 1
             assert rc == 0 and [int(v) for v in path] == want, (m, x)
+
+
+def _cluster(segs, nseg, nsamples=200):
+    """Sampled segments -> envelopes, restated from the description of HMMER's ensemble clustering (single linkage; two segments link
+    when they overlap by >= 0.8 of the shorter one in the sequence AND in the model and their diagonals differ by <= 4; a cluster
+    counts when >= 0.25 of the traces have a segment in it; each endpoint is the outermost value reached by >= 0.02 of those traces)."""
+    items = [(tr, tuple(int(v) for v in segs[tr, d])) for tr in range(nsamples) for d in range(int(nseg[tr]))]
+
+    def linked(a, b):
+        for lo, hi in ((0, 1), (2, 3)):
+            nov = min(a[hi], b[hi]) - max(a[lo], b[lo]) + 1
+            if nov / float(min(a[hi] - a[lo] + 1, b[hi] - b[lo] + 1)) < 0.8:
+                return False
+        diag = lambda s: int((s[0] - s[2] + s[1] - s[3]) / 2)          # (C integer division: toward zero)
+        return abs(diag(a) - diag(b)) <= 4
+
+    label = [-1] * len(items)
+    ncl = 0
+    for h in range(len(items)):
+        if label[h] >= 0:
+            continue
+        label[h] = ncl
+        stack = [h]
+        while stack:
+            a = stack.pop()
+            for b in range(len(items)):
+                if label[b] < 0 and linked(items[a][1], items[b][1]):
+                    label[b] = ncl
+                    stack.append(b)
+        ncl += 1
+    envs = []
+    for c in range(ncl):
+        members = [items[h] for h in range(len(items)) if label[h] == c]
+        ninc = len(set(tr for tr, _ in members))
+        if ninc / float(nsamples) < 0.25:
+            continue
+        ends = []
+        for f in range(4):
+            vals = [sg[f] for _, sg in members]
+            order = range(min(vals), max(vals)) if f in (0, 2) else range(max(vals), min(vals), -1)
+            pick = max(vals) if f in (0, 2) else min(vals)
+            for v in order:
+                if vals.count(v) / float(ninc) >= 0.02:
+                    pick = v
+                    break
+            ends.append(pick)
+        envs.append((ends[0], ends[1], ends[2], ends[3]))
+    return sorted(envs, key=lambda s: (s[0], s[1]))
+
+
+def test_ensemble_clustering_restated(tmp_path):
+    """Envelopes of multi-domain regions (tandem fragments of one model): the oracle's clustering of its 200 traces against the
+    restatement above, on regions with 2 to ~8 sampled domains per trace."""
+    rng = np.random.default_rng(31)
+    profs = [synth.random_profile(rng, M, "cl%d" % k, "PF8%04d.1" % k) for k, M in enumerate((40, 75, 120))]
+    for p in profs:
+        p.stats = (-30.0, 0.71, -30.0, 0.71, -30.0, 0.70)
+    path = str(tmp_path / "cl.hmm")
+    synth.write_hmm(path, profs)
+    hs = p7.HmmSet(path)
+    try:
+        nenv = 0
+        for m, pr in enumerate(profs):
+            M = pr.M
+            for copies in (2, 3, 5, 8):
+                parts = [synth.random_residues(rng, 12)]
+                for c in range(copies):
+                    a = int(rng.integers(1, M // 2)); b = int(rng.integers(a + M // 4, M + 1))
+                    parts.append(synth.sample_domain(rng, pr, a, b))
+                    if c % 2:
+                        parts.append(synth.random_residues(rng, 6))
+                parts.append(synth.random_residues(rng, 12))
+                x = np.concatenate(parts).astype(np.uint8)
+                rc, _n2, segs, nseg, env = hs.region_ensemble(m, x, 1, len(x))
+                assert rc == 0
+                assert [tuple(int(v) for v in e) for e in env] == _cluster(segs, nseg), (m, copies)
+                nenv += len(env)
+        assert nenv >= 20
+    finally:
+        hs.close()
