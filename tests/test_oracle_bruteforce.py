@@ -655,3 +655,51 @@ def test_ensemble_clustering_restated(tmp_path):
         assert nenv >= 20
     finally:
         hs.close()
+
+
+def test_filter_decisions_follow_the_published_thresholds(tmp_path):
+    """F1 = 0.02 on the MSV score (Gumbel), again after the composition filter replaces null1, F2 = 1e-3 on the Viterbi filter
+    score (Gumbel), F3 = 1e-5 on the Forward score (exponential tail): the pass flags of the oracle's cascade against the formulas,
+    from its own stage scores, on targets that land on both sides of every threshold."""
+    rng = np.random.default_rng(8)
+    pr = synth.random_profile(rng, 60, "thr", "PF80000.1")
+    mu_m, lam_m, mu_v, lam_v, tau, lam_f = -7.5, 0.71, -8.3, 0.71, -3.6, 0.70
+    pr.stats = (mu_m, lam_m, mu_v, lam_v, tau, lam_f)
+    path = str(tmp_path / "thr.hmm")
+    synth.write_hmm(path, [pr])
+    hs = p7.HmmSet(path)
+    gumbel = lambda x, mu, lam: 1.0 - math.exp(-math.exp(-lam * (x - mu)))
+    tail = lambda x, mu, lam: 1.0 if x < mu else math.exp(-lam * (x - mu))
+    bits = lambda sc, null: (sc - null) / math.log(2.0)
+    counts = [0, 0, 0, 0]
+    try:
+        for rep in range(400):
+            frac = rep % 8
+            parts = [synth.random_residues(rng, int(rng.integers(20, 200)))]
+            if frac:                                  # a fragment of the model of growing length: scores from noise to clear hits
+                parts.append(synth.sample_domain(rng, pr, 1, 6 + 7 * frac))
+            parts.append(synth.random_residues(rng, int(rng.integers(5, 60))))
+            x = np.concatenate(parts).astype(np.uint8)
+            st = hs.stages(0, x)
+            p_msv = gumbel(bits(st.msv_sc, st.null_sc), mu_m, lam_m)
+            if abs(p_msv - 0.02) < 1e-4:
+                continue                               # (on the knife edge float noise decides; never happens with these seeds)
+            assert bool(st.pass_msv) == (p_msv <= 0.02)
+            counts[0] += st.pass_msv
+            if not st.pass_msv:
+                continue
+            p_bias = gumbel(bits(st.msv_sc, st.bias_sc), mu_m, lam_m)
+            assert bool(st.pass_bias) == (p_bias <= 0.02)
+            counts[1] += st.pass_bias
+            if not st.pass_bias:
+                continue
+            # the Viterbi filter is only consulted when the MSV P-value has not already cleared F2 (p7_Pipeline: `if (P > F2)`)
+            assert bool(st.pass_vit) == (p_bias <= 1e-3 or gumbel(bits(st.vit_sc, st.bias_sc), mu_v, lam_v) <= 1e-3)
+            counts[2] += st.pass_vit
+            if not st.pass_vit:
+                continue
+            assert bool(st.pass_fwd) == (tail(bits(st.fwd_sc, st.bias_sc), tau, lam_f) <= 1e-5)
+            counts[3] += st.pass_fwd
+        assert 400 > counts[0] > counts[2] > counts[3] > 20, counts
+    finally:
+        hs.close()
