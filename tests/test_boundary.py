@@ -74,3 +74,24 @@ def test_dropin_rebinds_the_reference_classes(tmp_path):
     env = dict(os.environ, PYTHONPATH="/root/reference" + os.pathsep + root, CHECKM_DATA_PATH=str(tmp_path), PYTHONDONTWRITEBYTECODE="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-1500:]
+
+
+def test_entry_points_refuse_to_run_without_a_device(tmp_path):
+    """No CPU path anywhere: bench.py stops with a message, MarkerGeneFinder.find logs an error and exits with code 1 (as the
+    reference does when hmmsearch is missing, checkm/hmmer.py:131-137).  Only meaningful where there is no GPU."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1"], capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "needs a GPU" in (out.stderr + out.stdout)
+    faa = tmp_path / "b.faa"
+    faa.write_text(">g_1\nMKV*\n")
+    code = ("import sys, logging\n"
+            "logging.basicConfig(stream=sys.stderr)\n"
+            "from checkm_amd.markerGeneFinder import MarkerGeneFinder\n"
+            "MarkerGeneFinder(1).find([%r], %r, 'hmmer.analyze.txt', 'hmmer.analyze.ali.txt', 'none.hmm', False, False, True)\n" % (str(faa), str(tmp_path / "out")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, PYTHONPATH=root))
+    assert out.returncode == 1 and "No usable MI355X" in out.stderr
