@@ -219,3 +219,27 @@ def test_qa_cache_readers(tmp_path):
     for name, got in ((DefaultValues.BIN_STATS_EXT_OUT, rp.parseBinStatsExt(str(tmp_path))), (DefaultValues.MARKER_GENE_STATS, rp.parseMarkerGeneStats(str(tmp_path)))):
         want = {ln.split("\t")[0]: ast.literal_eval(ln.split("\t")[1]) for ln in sc["caches"][name].splitlines()}
         assert got == want and len(got) >= 2
+
+
+def test_known_answers_of_the_reference_test_suite():
+    """The facts the reference's own unit tests assert on this path (checkm/test/test_aminoAcidIdentity.py:27-143 and
+    checkm/test/test_markerSets.py:26-60), restated as data."""
+    from checkm_amd.aminoAcidIdentity import AminoAcidIdentity
+    aai = AminoAcidIdentity()
+    for a, b, want in (("ACGT", "ACGT", 1.0), ("ACGT", "TGCA", 0.0), ("ACGT----", "----TGCA", 0.0), ("ACGT--", "--GTAC", 1.0),
+                       ("AAAACGTTTT", "---ACGG---", 3.0 / 4.0), ("ACGT", "ACGG", 3.0 / 4.0), ("A-C-G-T", "A-C-G-T", 1.0), ("A-C-G-T", "AACCGGT", 4.0 / 7.0)):
+        assert aai.aai(a, b) == pytest.approx(want, abs=1e-7), (a, b)
+    for scores, het, mean in (({"g1": [0.1], "g2": [0.1], "g3": [0.1]}, (0.0, 0.0, 0.0), 0.0),
+                              ({"g1": [0.95], "g2": [0.95], "g3": [0.95]}, (1.0, 1.0, 1.0), 100.0),
+                              ({"g1": [0.95], "g2": [0.1], "g3": [0.1]}, (1.0, 0.0, 0.0), 100.0 / 3.0),
+                              ({"g1": [0.95, 0.95, 0.95], "g2": [0.1, 0.1, 0.1], "g3": [0.95, 0.1, 0.1]}, (1.0, 0.0, 1.0 / 3.0), 400.0 / 9.0)):
+        h, m = aai.strainHetero({"b1": scores}, 0.9)
+        assert [h["b1"][g] for g in ("g1", "g2", "g3")] == pytest.approx(list(het), abs=1e-7)
+        assert m["b1"] == pytest.approx(mean, abs=1e-7)
+    ms = MarkerSet(0, 'k__Bacteria', 100, [{'a', 'b'}, {'c'}])
+    assert ms.size() == (3, 2) and ms.numMarkers() == 3 and ms.numSets() == 2 and ms.getMarkerGenes() == {'a', 'b', 'c'}
+    bms = BinMarkerSets(0, BinMarkerSets.TAXONOMIC_MARKER_SET)
+    ms1 = MarkerSet(1, 'k__Bacteria', 100, [{'a', 'b'}, {'c'}])
+    ms2 = MarkerSet(2, 'k__Bacteria', 100, [{'d', 'e'}, {'f'}])
+    bms.addMarkerSet(ms1); bms.addMarkerSet(ms2)
+    assert bms.getMarkerGenes() == set('abcdef') and bms.mostSpecificMarkerSet() is ms1 and bms.selectedMarkerSet() is ms1
