@@ -1,8 +1,15 @@
 #!/usr/bin/env python
-"""bench.py -- cfg2 of BASELINE.json on N MI355X: cpr_43-shaped 43-profile DB against 100 synthetic
-2 Mb bins (~2k ORFs each) PER GPU (weak scaling: bins shard over ranks, one RCCL all_gather of the QA
-rows per step).  One step = one pass of the hot path (scan + reduce + gather) over the rank's bins,
-inputs resident in HBM.  Prints ONE JSON line (rank 0).
+"""bench.py -- the marker-gene hot path of CheckM on N MI355X, one JSON line (rank 0).
+
+  --config cfg2 (default)  configs[1] of BASELINE.json: cpr_43-shaped 43-profile DB against 100 synthetic 2 Mb bins (~2k ORFs
+                           each) PER GPU.  One step = one pass of the hot path (scan + reduce + the one gather of QA rows) over the
+                           rank's bins, inputs resident in HBM.  `--scaling strong --bins-total N` shards N bins over the ranks.
+                           The same line carries `lineage_wf_equiv`: a small lineage_wf-shaped run (cfg3 inputs) from FILES through
+                           MarkerGeneFinder.find -> ResultsParser (--lineage-bins 0 skips it).
+  --config cfg3            configs[2]/[3]: 2000-profile marker DB, bins of U[1500,6000] ORFs, per-bin model subsets from a Lineage
+                           marker file (43 phylo + 300-1500 lineage models), through the product's own call sequence
+                           (find(phylo.hmm) -> find(lineage.ms) -> analyseResults -> printSummary) from genes.faa files; under
+                           torchrun the PRODUCT shards the bins over the ranks (strong scaling, cfg4).  --bins-total (default 1000).
 
   python bench.py --gpus 1 --steps 3 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -10,6 +17,8 @@ inputs resident in HBM.  Prints ONE JSON line (rank 0).
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
 import tempfile
 import time
@@ -22,7 +31,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # before torch initialises 
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-VALU_PK16_PEAK_GOPS = 256 * 4 * 32 * 2.4   # CUs x SIMDs x lanes/clk x GHz: packed-i16 VALU instructions per ns (x1e9/s)
+PROFILE_TAG = "r02"            # profiles/<tag>_ssv_traffic.json holds the PMC-pass figures of the SSV launches
 
 
 def parse():
@@ -30,29 +39,38 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--bins", type=int, default=100, help="bins per GPU (cfg2: 100)")
-    ap.add_argument("--orfs", type=int, default=2000, help="ORFs per bin (cfg2: ~2000)")
+    ap.add_argument("--config", choices=["cfg2", "cfg3"], default="cfg2")
+    ap.add_argument("--bins", type=int, default=100, help="cfg2: bins per GPU (weak scaling)")
+    ap.add_argument("--orfs", type=int, default=2000, help="cfg2: ORFs per bin")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="cfg2: strong = --bins-total bins sharded over the ranks")
+    ap.add_argument("--bins-total", type=int, default=1000, help="cfg2 strong / cfg3: bins of the whole job")
+    ap.add_argument("--lineage-bins", type=int, default=16, help="cfg2: bins of the lineage_wf-equivalent side measurement (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", type=int, default=1,
-                    help="steps in flight at once (own context, profiles and sequences each): the tail of one step then runs under the SSV phase of the next, "
-                         "as it does for a deployment that streams batches of bins; 1 = every step runs alone")
+                    help="cfg2: steps in flight at once (own context each); 1 = every step runs alone")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-baseline-threads", type=int, default=min(32, os.cpu_count() or 1))
+    ap.add_argument("--workdir", default=None, help="where the synthetic files go (default: a fresh temp dir)")
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU legs (rank 0, N=1 only).  The oracle is the CHECKER: it is timed here as the baseline, never used by the product.
+# ---------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(hmm_path, bins, budget_s, threads):
-    """The restated CPU oracle (kind 'port') on a bounded sample of the same workload: `threads` host threads, one bin each (the
-    reference's own parallelism is one hmmsearch process per bin), every thread searching all models against the first ORFs of its bin."""
+    """Scan half: the restated CPU oracle (kind 'port') on a bounded sample of the same workload: `threads` host threads, one bin each
+    (the reference runs one hmmsearch process per bin), every thread searching all models against the first ORFs of its bin.
+    Reduce half: oracle/reduce_oracle.py (the Python restatement of ResultsManager/PFAM/MarkerSet that tests pin against the
+    reference's own classes; the classes themselves are absent on the GPU box) on the domtblout text of those rows."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import p7
+    from oracle import reduce_oracle as ro
     hs = p7.HmmSet(hmm_path)
     threads = max(1, min(threads, len(bins)))
     work = []
     for recs in bins[:threads]:
-        work.append(([p7.digitize(r[2]) for r in recs], [r[0] for r in recs]))
-    # calibrate the sample: time one model on a slice, then size (models x sequences) for ~budget_s per thread
-    dsq, names = work[0]
+        work.append(([p7.digitize(r[2]) for r in recs], [r[0] for r in recs], [r[1] for r in recs]))
+    dsq, names, _d = work[0]
     nseq = min(len(dsq), 200)
     t0 = time.perf_counter()
     hs.search([0], dsq[:nseq], names[:nseq])
@@ -63,16 +81,157 @@ def cpu_baseline(hmm_path, bins, budget_s, threads):
     nseq = int(min(min(len(w[0]) for w in work), max(50, budget_s * cells_per_s / (total_M * 300.0))))
 
     def one(w):
-        return len(hs.search(models, w[0][:nseq], w[1][:nseq]))          # the C call releases the GIL
+        return hs.search(models, w[0][:nseq], w[1][:nseq])                # the C call releases the GIL
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=threads) as ex:
-        nrows = sum(ex.map(one, work))
+        rows = list(ex.map(one, work))
     dt = time.perf_counter() - t0
     residues = sum(sum(len(d) for d in w[0][:nseq]) for w in work)
+    nrows = sum(len(r) for r in rows)
+    # reduce half on the same rows
+    omodels = {}
+    for m in models:
+        omodels[hs.acc(m)] = {"acc": hs.acc(m), "ga": None, "tc": [25.0, 25.0], "nc": None, "leng": hs.M(m)}
+    texts = [hs.format_domtblout(r, w[1][:nseq], w[2][:nseq]) for r, w in zip(rows, work)]
+    t0 = time.perf_counter()
+    for t in texts:
+        ro.reduce_bin(t, omodels, "", [sorted(omodels)])
+    dt_red = time.perf_counter() - t0
+    out = {"value": residues * len(models) / dt, "unit": "residue*HMM/s", "cores": threads, "kind": "port",
+           "sample": "restated CPU oracle (NOT HMMER; HMMER is absent from the reference and this image), %d threads x (all %d models x first %d ORFs of "
+                     "one bin each), %d residues, %d rows, %.1f s" % (threads, len(models), nseq, residues, nrows, dt),
+           "reduce": {"kind": "port", "what": "oracle/reduce_oracle.py (Python restatement pinned against the reference's classes; 1 thread)",
+                      "bins": len(texts), "rows": nrows, "seconds": dt_red, "bins_per_s": len(texts) / max(dt_red, 1e-9)}}
     hs.close()
-    return {"value": residues * len(models) / dt, "unit": "residue*HMM/s", "cores": threads, "kind": "port",
-            "sample": "restated CPU oracle (NOT HMMER; HMMER is absent from the reference and this image), %d threads x (all %d models x first %d ORFs of "
-                      "one bin each), %d residues, %d rows, %.1f s" % (threads, len(models), nseq, residues, nrows, dt)}
+    return out
+
+
+def hmmer_leg(hmm_path, bins, threads, workdir):
+    """BASELINE.md leg A: if a real `hmmsearch` is on PATH, time it on the same genes (one process per bin, --cpu 1, `threads` at a
+    time, the reference's own fan-out: checkm/markerGeneFinder.py:59-83 -> checkm/hmmer.py:61-74) and diff its rows against ours
+    (tools/diff_vs_hmmsearch.py).  Returns None when HMMER is absent (as in this image)."""
+    exe = shutil.which("hmmsearch")
+    if exe is None:
+        return None
+    from concurrent.futures import ThreadPoolExecutor
+    from checkm_amd import synth
+    sample = bins[:max(1, threads)]
+    faa = []
+    for b, recs in enumerate(sample):
+        f = os.path.join(workdir, "hmmer_leg_%d.faa" % b)
+        synth.write_fasta(f, recs)
+        faa.append(f)
+
+    def run(f):
+        subprocess.check_call([exe, "--domtblout", f + ".tbl", "--noali", "--notextw", "-E", "0.1", "--domE", "0.1", "--cpu", "1", hmm_path, f],
+                              stdout=subprocess.DEVNULL)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
+        list(ex.map(run, faa))
+    dt = time.perf_counter() - t0
+    residues = sum(sum(len(r[2]) for r in recs) for recs in sample)
+    from checkm_amd import synth as _s  # noqa: F401
+    nmodels = sum(1 for line in open(hmm_path) if line.startswith("NAME"))
+    ver = subprocess.run([exe, "-h"], stdout=subprocess.PIPE).stdout.decode(errors="replace").split("\n")[1:2]
+    return {"value": residues * nmodels / dt, "unit": "residue*HMM/s", "cores": min(threads, len(sample)), "kind": "reference",
+            "sample": "hmmsearch (%s) --cpu 1, %d processes at a time, %d bins x %d models, %.1f s" % (" ".join(ver).strip("# "), min(threads, len(sample)), len(sample), nmodels, dt),
+            "tables": [f + ".tbl" for f in faa], "faa": faa}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def ssv_roofline(st_like, ssv_ms_per_step, bins, orfs, extra_note=""):
+    """roofline of the dominant kernel ssv_kernel<Q>: algorithmic bytes = sum over (model, sequence) pairs of (L + 12) over the
+    kernel's time measured with HIP events on the library's streams.  HBM traffic and the VALU instruction count come from separate
+    rocprofv3 --pmc passes recorded in profiles/ (tools/collect_profiles.sh); they are quoted -- with their source -- only for the
+    workload that was profiled."""
+    alg_bytes = float(st_like["residue_hmm"]) + 12.0 * float(st_like["pairs_ssv"])
+    ssv_s = max(ssv_ms_per_step, 1e-9) / 1e3
+    achieved = alg_bytes / ssv_s / 1e9
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes": alg_bytes, "kernel": "ssv_kernel<Q>", "ms_per_step_kernel": ssv_ms_per_step,
+            "note": "the kernel is VALU-issue-bound by design (SURVEY H3), not HBM-bound: see roofline_valu and gcups_ssv" + extra_note}
+    valu = None
+    tf = None
+    for tag in (PROFILE_TAG, "r01e"):
+        cand = os.path.join(ROOT, "profiles", "%s_ssv_traffic.json" % tag)
+        if os.path.exists(cand):
+            tf = cand
+            break
+    if tf is not None and bins == 100 and orfs == 2000:
+        with open(tf) as f:
+            pm = json.load(f)
+        src = os.path.relpath(tf, ROOT)
+        roof["traffic"] = pm["hbm_bytes_corrected"]
+        roof["traffic_source"] = src + " (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass of this workload, recorded, not measured in this run)"
+        cyc = ssv_s * 2.4e9 / (pm["valu_insts"] / 1024.0)
+        valu = {"bound": "valu-issue", "wave_insts_per_step": pm["valu_insts"], "source": src + " (rocprofv3 --pmc SQ_INSTS_VALU pass, recorded)",
+                "cycles_per_inst_per_simd": cyc, "ceiling_cycles_per_inst": 4.0, "frac": 4.0 / cyc,
+                "note": "issue peak = 1 wave64 instruction per 4 cycles per SIMD (measured for packed-i16/DPP/perm ops: tools/ubench/valu_rates.hip); "
+                        "time = the SSV launches of this run, HIP events"}
+    return roof, valu
+
+
+def stage_pairs(st):
+    g = (lambda k: int(st[k])) if isinstance(st, dict) else (lambda k: int(getattr(st, k)))
+    return {"ssv": g("pairs_ssv"), "msv_full": g("pairs_msv_full"), "bias": g("pairs_bias"), "vit": g("pairs_vit"), "vit_exact": g("pairs_vit_exact"),
+            "fwd": g("pairs_fwd"), "dom": g("pairs_dom"), "envelopes": g("envelopes"), "regions_multi": g("regions_multi")}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# lineage_wf-equivalent run from files through the product classes
+# ---------------------------------------------------------------------------------------------------------------------
+def lineage_setup(workdir, nbins, rank, world, sync):
+    """The synthetic lineage world + `nbins` genes.faa files (every rank writes a slice of them)."""
+    from checkm_amd import synth, synth_lineage as sl
+    from checkm_amd.defaultValues import DefaultValues
+    data = os.path.join(workdir, "lineage_data")
+    if rank == 0:
+        sl.World(data)
+    sync()
+    w = sl.World(data, write=False)
+    DefaultValues.set_data_root(data)
+    binIds = ["bin_%04d" % b for b in range(nbins)]
+    files = [os.path.join(workdir, "%s.faa" % b) for b in binIds]
+    for b in range(rank, nbins, world):
+        if not os.path.exists(files[b]):
+            synth.write_fasta(files[b], w.bin_records(b))
+    if rank == 0:
+        w.write_marker_files(workdir, binIds)
+    sync()
+    return w, binIds, files, os.path.join(workdir, "lineage.ms")
+
+
+def lineage_pass(w, binIds, files, lin, out, rank):
+    """One lineage_wf-equivalent pass over the marker path: tree pass (phylo.hmm), analyze pass (lineage marker file), qa table."""
+    from checkm_amd import markerGeneFinder as mgf
+    from checkm_amd.defaultValues import DefaultValues
+    from checkm_amd.markerSets import MarkerSetParser
+    from checkm_amd.resultsParser import ResultsParser
+    t0 = time.perf_counter()
+    finder = mgf.MarkerGeneFinder(8)
+    finder.find(files, out, DefaultValues.HMMER_TABLE_PHYLO_OUT, DefaultValues.HMMER_PHYLO_OUT, w.phylo_hmm, False, False, True)
+    t1 = time.perf_counter()
+    models = finder.find(files, out, DefaultValues.HMMER_TABLE_OUT, DefaultValues.HMMER_OUT, lin, False, False, True)
+    t2 = time.perf_counter()
+    tot = {}
+    for tbl in (DefaultValues.HMMER_TABLE_PHYLO_OUT, DefaultValues.HMMER_TABLE_OUT):
+        for k, v in mgf.SCAN_CACHE[(os.path.abspath(out), tbl)]["totals"].items():
+            tot[k] = tot.get(k, 0) + v
+    if rank == 0:
+        os.makedirs(os.path.join(out, "storage"), exist_ok=True)
+        with open(os.path.join(out, "storage", DefaultValues.BIN_STATS_OUT), "w") as f:
+            for b in binIds:
+                f.write("%s\t%s\n" % (b, repr({"GC": 0.5, "Genome size": 1})))
+    from checkm_amd import dist as cdist
+    cdist.barrier()
+    msp = MarkerSetParser()
+    sets = msp.getMarkerSets(out, binIds, lin)
+    rp = ResultsParser(models)
+    rp.analyseResults(out, DefaultValues.BIN_STATS_OUT, DefaultValues.HMMER_TABLE_OUT)
+    rp.printSummary(1, None, sets, False, None, True, os.path.join(out, "qa_table.tsv") if rank == 0 else None, None)
+    t3 = time.perf_counter()
+    mgf.release_scan(out)
+    return {"tree_find_s": t1 - t0, "analyze_find_s": t2 - t1, "qa_s": t3 - t2, "total_s": t3 - t0}, tot
 
 
 def main():
@@ -90,48 +249,81 @@ def main():
     #  the multi-rank control flow can be exercised on a one-GPU box; the driver's runs use neither)
     dev_index = int(os.environ.get("CKM_BENCH_DEVICE", local_rank))
     backend = os.environ.get("CKM_BENCH_DIST_BACKEND", "nccl")
+    os.environ["CHECKM_AMD_DEVICE"] = str(dev_index)
+    os.environ.setdefault("CKM_DIST_BACKEND", backend)
     torch.cuda.set_device(dev_index)
     if world > 1:
         cdist.init_process_group(backend)
     dev = torch.device("cuda", dev_index) if backend == "nccl" else None
     local_rank = dev_index
 
-    # ---- inputs (synthetic, fixed seeds): profiles + this rank's bins, packed and resident in HBM ----
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def all_sum(x):
+        if world == 1:
+            return float(x)
+        t = torch.tensor([float(x)], dtype=torch.float64, device=dev if dev is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def all_max(x):
+        if world == 1:
+            return float(x)
+        t = torch.tensor([float(x)], dtype=torch.float64, device=dev if dev is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    workdir = args.workdir
+    if workdir is None:
+        workdir = tempfile.mkdtemp(prefix="ckm_bench_") if rank == 0 else None
+        if world > 1:
+            box = [workdir]
+            dist.broadcast_object_list(box, src=0)
+            workdir = box[0]
+    os.makedirs(workdir, exist_ok=True)
+
+    if args.config == "cfg3":
+        return bench_cfg3(args, rank, world, workdir, sync, all_sum, all_max)
+
+    # ---- cfg2 inputs (synthetic, fixed seeds): profiles + this rank's bins, packed and resident in HBM ----
     profs = synth.cpr43_profiles()
-    tmp = tempfile.mkdtemp(prefix="ckm_bench_")
-    hmm_path = os.path.join(tmp, "cpr43_synth.hmm")
+    hmm_path = os.path.join(workdir, "cpr43_synth_rank%d.hmm" % rank)
     synth.write_hmm(hmm_path, profs)
+    if args.scaling == "strong":
+        # every cfg2 bin has the same shape, so the size-balanced shard (checkm_amd/dist.py:shard_bins) is a round-robin deal
+        my_bins = cdist.shard_bins([1] * args.bins_total, world)[rank]
+    else:
+        my_bins = [rank * args.bins + b for b in range(args.bins)]
+    nb = len(my_bins)
     t0 = time.perf_counter()
-    bins = [synth.make_bin(profs, 1000 + rank * args.bins + b, n_orfs=args.orfs) for b in range(args.bins)]
+    bins = [synth.make_bin(profs, 1000 + b, n_orfs=args.orfs) for b in my_bins]
     t_gen = time.perf_counter() - t0
     ctx = _lib.Context(local_rank)
     prof = _lib.Profiles(ctx, hmm_path)
     t0 = time.perf_counter()
     seqs = _lib.Seqs(ctx, bins)
     t_pack = time.perf_counter() - t0
-    plan = cqa.QAPlan.for_hmm_models(prof, [list(range(prof.n))] * args.bins)     # one marker set of all 43 accessions per bin
-
+    plan = cqa.QAPlan.for_hmm_models(prof, [list(range(prof.n))] * nb)     # one marker set of all 43 accessions per bin
+    max_rows = max(1, int(all_max(nb)))
     part_ms = {"search": 0.0, "reduce": 0.0, "gather": 0.0}
 
-    def step():
+    def step(s=seqs):
         ta = time.perf_counter()
-        hits = _lib.search(ctx, prof, seqs)
+        hits = _lib.search(ctx, prof, s)
         tb = time.perf_counter()
-        qa = plan.reduce(ctx, hits, seqs)
+        qa = plan.reduce(ctx, hits, s)
         tc = time.perf_counter()
-        rows = cdist.pack_qa_rows(np.arange(args.bins) + rank * args.bins, qa.n_markers, qa.n_sets, qa.hist, qa.completeness, qa.contamination)
-        table = cdist.gather_qa_rows(rows, args.bins, dev)
+        rows = cdist.pack_qa_rows(np.asarray(my_bins), qa.n_markers, qa.n_sets, qa.hist, qa.completeness, qa.contamination)
+        table = cdist.gather_qa_rows(rows, max_rows, dev)
         td = time.perf_counter()
         part_ms["search"] += (tb - ta) * 1e3; part_ms["reduce"] += (tc - tb) * 1e3; part_ms["gather"] += (td - tc) * 1e3
         st = ctx.stats()
         n = hits.n
         hits.close(); qa.close()
         return st, n, table
-
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -152,14 +344,14 @@ def main():
         lanes = [(ctx, prof, seqs, plan, threading.Lock())]
         for _ in range(args.pipeline - 1):
             c2 = _lib.Context(local_rank); p2 = _lib.Profiles(c2, hmm_path); s2 = _lib.Seqs(c2, bins)
-            lanes.append((c2, p2, s2, cqa.QAPlan.for_hmm_models(p2, [list(range(p2.n))] * args.bins), threading.Lock()))
+            lanes.append((c2, p2, s2, cqa.QAPlan.for_hmm_models(p2, [list(range(p2.n))] * nb), threading.Lock()))
 
         def lane_step(i):
             c, p, s, pl, lock = lanes[i % len(lanes)]
             with lock:                                   # a context runs one search at a time
                 hits = _lib.search(c, p, s)
                 qa = pl.reduce(c, hits, s)
-                rows = cdist.pack_qa_rows(np.arange(args.bins) + rank * args.bins, qa.n_markers, qa.n_sets, qa.hist, qa.completeness, qa.contamination)
+                rows = cdist.pack_qa_rows(np.asarray(my_bins), qa.n_markers, qa.n_sets, qa.hist, qa.completeness, qa.contamination)
                 stl = c.stats(); n = hits.n
                 hits.close(); qa.close()
             return rows, stl, n
@@ -170,63 +362,120 @@ def main():
             futs = [ex.submit(lane_step, i) for i in range(args.steps)]
             for f in futs:                               # gathers stay in step order on this thread (collectives must line up across ranks)
                 rows, st, nrows = f.result()
-                table = cdist.gather_qa_rows(rows, args.bins, dev)
+                table = cdist.gather_qa_rows(rows, max_rows, dev)
                 ssv_ms += st.ms_ssv
             sync()
             dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if dev is not None else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = all_max(dt)
     per_step = dt / args.steps
-    residue_hmm_rank = float(st.residue_hmm)
-    total_residue_hmm = residue_hmm_rank * world          # every rank generates the same shape
+    total_residue_hmm = all_sum(float(st.residue_hmm))        # every rank reports what IT scanned
+    total_bins = all_sum(nb)
     value = total_residue_hmm / per_step
+    # the same step when the boundary hands over HOST buffers: digitise + pack + H2D of the rank's bins, then the step (SURVEY 8d:
+    # "host<->device copies included"); measured once, outside the timed region
+    t0 = time.perf_counter()
+    seqs2 = _lib.Seqs(ctx, bins)
+    st2, _n2, _t2 = step(seqs2)
+    torch.cuda.synchronize()
+    dt_host = all_max(time.perf_counter() - t0)
+    seqs2.close()
+    # lineage_wf-equivalent side measurement (cfg3-shaped inputs, from files, product classes)
+    lineage = None
+    if args.lineage_bins > 0:
+        try:
+            w, binIds, files, lin = lineage_setup(workdir, args.lineage_bins, rank, world, sync)
+            lineage_pass(w, binIds[:2 * world], files[:2 * world], lin, os.path.join(workdir, "lw_warm"), rank)      # contexts, profile DBs, plans
+            sync()
+            parts, tot = lineage_pass(w, binIds, files, lin, os.path.join(workdir, "lw_out"), rank)
+            sync()
+            wall = all_max(parts["total_s"])
+            lineage = {"workload": "configs[2]-shaped: %d bins of U[1500,6000] ORFs, 2000-profile checkm.hmm, per-bin subsets from a Lineage marker file "
+                                   "(43 phylo + 300-1500 lineage models), from genes.faa files through MarkerGeneFinder.find x2 -> ResultsParser.analyseResults "
+                                   "-> printSummary" % args.lineage_bins,
+                       "bins": args.lineage_bins, "seconds": wall, "bins_per_hour": args.lineage_bins / wall * 3600.0, "parts_s_rank0": parts,
+                       "residue_hmm": all_sum(tot.get("residue_hmm", 0)), "residue_hmm_per_s": all_sum(tot.get("residue_hmm", 0)) / wall,
+                       "note": "includes FASTA ingest, both scans, domtblout files, reduction and the QA table; the full 1000-bin run is `bench.py --config cfg3`"}
+        except SystemExit as e:            # the product's error path is logger.error + sys.exit
+            lineage = {"error": "lineage_wf-equivalent run failed: exit %s" % (e.code,)}
     if rank == 0:
-        # roofline of the dominant kernel (ssv_kernel<Q>): algorithmic bytes = sum over pairs of (L + 12)
-        alg_bytes = float(st.residue_hmm) + 12.0 * float(st.pairs_ssv)
-        ssv_s = ssv_ms / args.steps / 1e3
-        achieved = alg_bytes / ssv_s / 1e9
-        # HBM traffic and VALU instruction count of the same launches come from separate rocprofv3 --pmc passes
-        # (profiles/r01e_pmc_summary.txt); they are only quoted when the workload is the one that was profiled
-        traffic = None
-        valu = None
-        tf = os.path.join(ROOT, "profiles", "r01e_ssv_traffic.json")
-        if os.path.exists(tf) and args.bins == 100 and args.orfs == 2000:
-            with open(tf) as f:
-                pm = json.load(f)
-            traffic = pm["hbm_bytes_corrected"]
-            cyc = ssv_s * 2.4e9 / (pm["valu_insts"] / 1024.0)
-            valu = {"bound": "valu-issue", "wave_insts_per_step": pm["valu_insts"], "cycles_per_inst_per_simd": cyc, "ceiling_cycles_per_inst": 4.0,
-                    "frac": 4.0 / cyc, "note": "issue peak = 1 wave64 instruction per 4 cycles per SIMD; isolated packed-i16 ops measure 4.2-4.6 "
-                    "(tools/ubench/valu_rates.hip -> profiles/r01_valu_rates.txt); the SSV inner loop is 2 packed-i16 ops per register per row; "
-                    "time = the workers' SSV phases (they run one after the other, sharing the device with the rare stages of the other workers)"}
+        roof, valu = ssv_roofline({"residue_hmm": st.residue_hmm, "pairs_ssv": st.pairs_ssv}, ssv_ms / args.steps, nb, args.orfs)
+        roof["launches_per_step"] = int(st.ssv_launches)
         out = {
             "metric": "residues*HMMs/s (marker-gene scan+reduce, cfg2: 43 profiles x 100 synthetic 2 Mb bins per GPU)",
             "value": value, "unit": "residue*HMM/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": per_step * 1e3, "steps_in_flight": args.pipeline, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": per_step * 1e3, "steps_in_flight": args.pipeline, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "i16 (SSV/MSV bytes, Viterbi words) + f32 (Forward/Backward)", "data": "synthetic",
-            "config": {"workload": "configs[1]: cpr_43-shaped 43 synthetic profiles (M 63..900, sum M %d) x %d bins x %d ORFs per GPU"
-                                   % (sum(p.M for p in profs), args.bins, args.orfs),
-                       "bins_per_gpu": args.bins, "orfs_per_bin": args.orfs, "residues_per_gpu": seqs.total_residues,
+            "config": {"workload": "configs[1]: cpr_43-shaped 43 synthetic profiles (M 63..900, sum M %d) x %d bins x %d ORFs %s"
+                                   % (sum(p.M for p in profs), nb if args.scaling == "weak" else args.bins_total, args.orfs,
+                                      "per GPU" if args.scaling == "weak" else "in total, sharded over the ranks"),
+                       "bins_per_gpu": nb, "bins_total": int(total_bins), "orfs_per_bin": args.orfs, "residues_rank0": seqs.total_residues,
                        "parallelism": "bins sharded over %d GPU(s); 1 all_gather of QA rows per step" % world},
-            "bins_per_hour": args.bins * world / per_step * 3600.0,
-            "gcups_ssv": float(st.cells_ssv) / ssv_s / 1e9,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes": alg_bytes, "kernel": "ssv_kernel<Q>", "ms_per_step_kernel": ssv_ms / args.steps,
-                         "launches_per_step": int(st.ssv_launches),
-                         "note": "the kernel is VALU-issue-bound by design (SURVEY H3), not HBM-bound: see roofline_valu, gcups_ssv and DESIGN.md section 6; its launches share the device with the rare stages of the other length classes (3 workers), which stretches their duration by ~25% against a solo run (CKM_WORKERS=1: 42 ms, frac_valu ~1.0)"},
-            "roofline_valu": valu,
+            "value_from_host": total_residue_hmm / dt_host,
+            "value_from_host_note": "same step with digitise + pack + H2D of the bins inside the clock (host buffers at the boundary); `value` starts from HBM-resident inputs",
+            "bins_per_hour_43models": total_bins / per_step * 3600.0,
+            "lineage_wf_equiv": lineage,
+            "gcups_ssv": float(st.cells_ssv) / max(ssv_ms / args.steps / 1e3, 1e-12) / 1e9,
+            "roofline": roof, "roofline_valu": valu,
             "stages_ms": {"ssv": st.ms_ssv, "filters": st.ms_filters, "fwdbwd": st.ms_fwdbwd, "domains": st.ms_domains, "host": st.ms_host, "search_total": st.ms_total},
             "step_parts_ms": {k: v / args.steps for k, v in part_ms.items()},
-            "stage_pairs": {"ssv": int(st.pairs_ssv), "msv_full": int(st.pairs_msv_full), "bias": int(st.pairs_bias), "vit": int(st.pairs_vit), "vit_exact": int(st.pairs_vit_exact),
-                            "fwd": int(st.pairs_fwd), "dom": int(st.pairs_dom), "envelopes": int(st.envelopes), "regions_multi": int(st.regions_multi)},
-            "rows": int(nrows), "setup_s": {"generate": t_gen, "pack_and_upload": t_pack},
+            "stage_pairs": stage_pairs(st),
+            "rows": int(nrows), "qa_rows_gathered": int(len(table)), "setup_s": {"generate": t_gen, "pack_and_upload": t_pack},
         }
         if not args.no_cpu_baseline and world == 1:          # rank 0 at N=1 only: the other ranks would wait at the process-group teardown
-            out["cpu_baseline"] = cpu_baseline(hmm_path, bins, args.cpu_baseline_seconds, args.cpu_baseline_threads)
+            real = hmmer_leg(hmm_path, bins, args.cpu_baseline_threads, workdir)
+            if real is not None:
+                from tools import diff_vs_hmmsearch as dvh
+                diffs = []
+                for b, (tbl, faa) in enumerate(zip(real.pop("tables"), real.pop("faa"))):
+                    mine = os.path.join(workdir, "hmmer_leg_%d.mine.tbl" % b)
+                    from checkm_amd.markerGeneFinder import scan_files
+                    scan_files(hmm_path, [faa], [mine])
+                    diffs.append(dvh.diff_tables(tbl, mine))
+                real["row_diff"] = dvh.merge(diffs)
+                out["cpu_baseline"] = real
+                out["cpu_baseline_port"] = cpu_baseline(hmm_path, bins, args.cpu_baseline_seconds, args.cpu_baseline_threads)
+            else:
+                out["cpu_baseline"] = cpu_baseline(hmm_path, bins, args.cpu_baseline_seconds, args.cpu_baseline_threads)
+                out["cpu_baseline"]["hmmsearch_on_path"] = False
         else:
             out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_cfg3(args, rank, world, workdir, sync, all_sum, all_max):
+    """cfg3 (N=1) / cfg4 (N>1, strong scaling): the lineage_wf marker path over --bins-total bins from files; the product shards them."""
+    import torch.distributed as dist
+    nbins = args.bins_total
+    t0 = time.perf_counter()
+    w, binIds, files, lin = lineage_setup(workdir, nbins, rank, world, sync)
+    t_setup = time.perf_counter() - t0
+    warm = min(nbins, 4 * world)
+    for k in range(max(1, args.warmup)):
+        lineage_pass(w, binIds[:warm], files[:warm], lin, os.path.join(workdir, "cfg3_warm"), rank)
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        parts, tot = lineage_pass(w, binIds, files, lin, os.path.join(workdir, "cfg3_out"), rank)
+    sync()
+    dt = all_max(time.perf_counter() - t0)
+    per_step = dt / args.steps
+    residue_hmm = all_sum(tot.get("residue_hmm", 0))
+    ssv_ms = all_max(tot.get("ms_ssv", 0.0))
+    if rank == 0:
+        roof, _valu = ssv_roofline(tot, tot.get("ms_ssv", 0.0), -1, -1, "; cfg3: summed over the %d ckm_search calls of rank 0's batches" % tot.get("searches", 0))
+        out = {"metric": "bins/hour (lineage_wf-equivalent marker path: tree pass + analyze pass + qa, from genes.faa files) and residues*HMMs/s",
+               "value": residue_hmm / per_step, "unit": "residue*HMM/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
+               "ms_per_step": per_step * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "i16 (SSV/MSV bytes, Viterbi words) + f32 (Forward/Backward)", "data": "synthetic",
+               "config": {"workload": "configs[%d]: 2000 synthetic profiles (checkm.hmm) + 43 (phylo.hmm) x %d bins of U[1500,6000] ORFs; per-bin model subsets from a "
+                                      "Lineage marker file (marker genes of the bin's lineage chain + clan expansion: 300-1500 models)" % (2 if world == 1 else 3, nbins),
+                          "bins_total": nbins, "parallelism": "bins sharded over %d GPU(s) by MarkerGeneFinder.find (file size x models); 1 all_gather of QA rows" % world},
+               "bins_per_hour_lineage_wf_equiv": nbins / per_step * 3600.0,
+               "parts_s_rank0": parts, "roofline": roof, "stage_pairs": stage_pairs(tot), "ssv_ms_max_rank": ssv_ms,
+               "setup_s": {"world_and_files": t_setup}, "cpu_baseline": None}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

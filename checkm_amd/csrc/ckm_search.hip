@@ -332,12 +332,11 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
       for (; it < items.size() && items[it].pass == q; ++it) {
         const Item &im = items[it];
         if (im.region < 0) { envreq.push_back({w.model, w.seq, im.i, im.j}); env_region.push_back(-1); continue; }
-        int last_j2 = 0;
         for (const Seg &e : regres[im.region].env) {
           const int i2 = e.sqfrom + im.i - 1, j2 = e.sqto + im.i - 1;
-          if (i2 <= last_j2) continue;        // overlapping envelopes: the later one is skipped, as HMMER does
+          // an envelope overlapping its predecessor is rescored like any other (HMMER only counts it); duplicate alignments are
+          // hidden at reporting time (its bug #h74 workaround, below)
           envreq.push_back({w.model, w.seq, i2, j2}); env_region.push_back(im.region);
-          last_j2 = j2;
         }
       }
       env_of_pass[q].second = envreq.size() - env_of_pass[q].first;
@@ -565,12 +564,14 @@ static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, cons
       for (auto &h : hs) {
         if (!(exp(h.lnP) * Z <= E)) continue;
         for (auto &d : h.dom) { d.reported = exp(d.lnP) * domZ <= domE; if (d.reported) h.nreported++; }
-        for (size_t d = 1; d < h.dom.size(); ++d) {
-          Domain &a = h.dom[d - 1], &c = h.dom[d];
-          if (a.reported && c.reported && a.ali_from == c.ali_from && a.ali_to == c.ali_to && a.hmm_from == c.hmm_from && a.hmm_to == c.hmm_to) {
-            Domain &w = (a.bitscore >= c.bitscore) ? c : a; w.reported = false; h.nreported--;
+        for (size_t d1 = 0; d1 < h.dom.size(); ++d1)          // HMMER's workaround of its bug #h74: every pair, sequence coordinates only
+          for (size_t d2 = d1 + 1; d2 < h.dom.size(); ++d2) {
+            Domain &a = h.dom[d1], &c = h.dom[d2];
+            if (a.ali_from == c.ali_from && a.ali_to == c.ali_to) {
+              Domain &w = (a.bitscore >= c.bitscore) ? c : a;
+              if (w.reported) { w.reported = false; h.nreported--; }
+            }
           }
-        }
         int nd = 0;
         for (auto &d : h.dom) if (d.reported) {
           ++nd;

@@ -24,7 +24,7 @@ def shard_bins(weights, world_size):
     return shards
 
 
-QA_WIDTH = 12   # bin index, n_markers, n_sets, hist[6], completeness, contamination, spare
+QA_WIDTH = 12   # bin index, n_markers, n_sets, hist[6], completeness, contamination, strain heterogeneity
 
 
 def pack_qa_rows(bin_ids, n_markers, n_sets, hist, comp, cont):
@@ -51,13 +51,39 @@ def init_process_group(backend=None):
         return None
     if not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("CKM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(int(os.environ.get("CHECKM_AMD_DEVICE", local_rank)))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return dist
+
+
+def collective_device():
+    """Device the gather buffers live on: the rank's GPU over RCCL, None (host) over gloo."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return None
+
+
+def shutdown():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def world_size():
+    import torch.distributed as dist
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
 def gather_qa_rows(rows, max_rows, device=None):

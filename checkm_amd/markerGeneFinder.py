@@ -15,18 +15,62 @@ from checkm_amd import _lib, runtime
 from checkm_amd.common import binIdFromFilename, makeSurePathExists
 from checkm_amd.defaultValues import DefaultValues
 from checkm_amd.hmmerModelParser import models_dict
-from checkm_amd.markerSets import MarkerSetParser
+from checkm_amd.markerSets import MarkerSetParser, wanted_model
 
-# (abs outDir, tableOut) -> dict(ctx, profiles, seqs, hits, bin_index {binId: b}, headers)
+# (abs outDir, tableOut) -> dict(ctx, profiles, parts=[dict(seqs, hits, bins=[binId...])], where={binId: (part, b)},
+#                                 owned=set(binId) scanned by THIS rank, world)
 SCAN_CACHE = {}
+
+PAIR_BUDGET = int(os.environ.get("CKM_FIND_PAIR_BUDGET", str(250 * 1000 * 1000)))   # (ORF, model) pairs per ckm_search call
+RES_BUDGET = int(os.environ.get("CKM_FIND_RES_BUDGET", str(400 * 1000 * 1000)))      # residues (~ bytes of genes.faa) per call
+
+
+# (abs path, mtime_ns, size) of an HMM file -> resident _lib.Profiles.  The reference's hmmsearch re-reads its model file for every
+# bin (checkm/hmmer.py:70); here a database (checkm.hmm is ~200 MB of text) is parsed, configured and uploaded once per process.
+PROFILE_CACHE = {}
+
+
+def profiles_for(ctx, db):
+    st = os.stat(db)
+    key = (os.path.abspath(db), st.st_mtime_ns, st.st_size)
+    p = PROFILE_CACHE.get(key)
+    if p is None or not p.h:
+        for k in [k for k in PROFILE_CACHE if k[0] == key[0]]:          # the file changed: drop the stale copy unless a scan still uses it
+            if not any(ent["profiles"] is PROFILE_CACHE[k] for ent in SCAN_CACHE.values()):
+                PROFILE_CACHE.pop(k).close()
+        p = _lib.Profiles(ctx, db)
+        PROFILE_CACHE[key] = p
+    return p
 
 
 def release_scan(outDir=None):
-    """Free cached device objects (all, or those of one output directory)."""
+    """Free cached device objects (all, or those of one output directory).  Profile databases stay resident until everything is
+    released (release_scan() without an argument)."""
     for key in list(SCAN_CACHE):
         if outDir is None or key[0] == os.path.abspath(outDir):
             ent = SCAN_CACHE.pop(key)
-            ent["hits"].close(); ent["seqs"].close(); ent["profiles"].close()
+            for part in ent["parts"]:
+                part["hits"].close(); part["seqs"].close()
+    if outDir is None:
+        for k in list(PROFILE_CACHE):
+            PROFILE_CACHE.pop(k).close()
+
+
+def plan_batches(sizes, nmodels, pair_budget=None, res_budget=None):
+    """Cut the bins (given order) into contiguous batches of one ckm_search call each: the Forward/Backward workspace of a call grows
+    with its (ORF, model) pairs, so a batch stops before PAIR_BUDGET pairs (ORFs estimated from the file size at ~320 bytes per
+    record) or RES_BUDGET residues.  Returns a list of index lists."""
+    pair_budget = PAIR_BUDGET if pair_budget is None else pair_budget
+    res_budget = RES_BUDGET if res_budget is None else res_budget
+    batches, cur, pairs, res = [], [], 0, 0
+    for i, (sz, nm) in enumerate(zip(sizes, nmodels)):
+        p = max(1, sz // 320) * max(1, nm)
+        if cur and (pairs + p > pair_budget or res + sz > res_budget):
+            batches.append(cur); cur, pairs, res = [], 0, 0
+        cur.append(i); pairs += p; res += sz
+    if cur:
+        batches.append(cur)
+    return batches
 
 
 def scan_files(hmm_file, fasta_files, table_files, E=0.1, domE=0.1, bin_models=None, keep=None):
@@ -108,40 +152,117 @@ class MarkerGeneFinder(object):
         return binIds, faa
 
     def find(self, binFiles, outDir, tableOut, hmmerOut, markerFile, bKeepAlignment, bNucORFs, bCalledGenes):
+        """checkm/markerGeneFinder.py:45-96.  One process per GPU: under torchrun (WORLD_SIZE > 1) every rank calls find() with the
+        same arguments, scans a size-balanced shard of the bins (checkm_amd/dist.py:shard_bins -- the reference's bin-level fan-out,
+        markerGeneFinder.py:59-83) and writes the files of the bins it owns; the return value covers every bin on every rank.
+        Within a rank the bins go through the device in batches: the FASTA files of batch k+1 are read, digitised and uploaded and the
+        tables of batch k-1 are written by host threads while batch k is on the GPU."""
+        from concurrent.futures import ThreadPoolExecutor
+        from checkm_amd import dist as cdist
         try:
-            runtime.get_ctx()
+            ctx = runtime.get_ctx()
         except Exception as e:
             self.logger.error("No usable MI355X (gfx950) device for the marker-gene scan: %s" % e)
             sys.exit(1)
-        self.logger.info("Identifying marker genes in %d bins on device %d:" % (len(binFiles), runtime.get_ctx().device))
-        binIds, faa = self._geneFiles(binFiles, outDir, bNucORFs, bCalledGenes)
+        rank, _local, world = cdist.env_rank()
+        if world > 1:
+            cdist.init_process_group()          # RCCL ('nccl') unless CKM_DIST_BACKEND says otherwise; no-op when the caller already did
+        self.logger.info("Identifying marker genes in %d bins on device %d:" % (len(binFiles), ctx.device))
         parser = MarkerSetParser(self.totalThreads)
         db = parser.hmmDatabaseFor(markerFile)
-        wanted = parser.markerAccessionsForBins(binIds, markerFile)
-        keep = {}
-        ctx = runtime.get_ctx()
+        allIds = [binIdFromFilename(f) for f in binFiles]
+        wanted = parser.markerAccessionsForBins(allIds, markerFile)
         try:
-            profiles = _lib.Profiles(ctx, db)
-            acc_of = [h["acc"] if h["acc"] else h["name"] for h in profiles.headers]
-            bin_models = None
-            if any(w is not None for w in wanted.values()):
-                bin_models = [[i for i, a in enumerate(acc_of) if wanted[b] is None or a in wanted[b]] for b in binIds]
-            seqs = _lib.Seqs.from_fasta(ctx, faa)                                # read, digitized and packed by the library
-            hits = _lib.search(ctx, profiles, seqs, bin_models, 0.1, 0.1)        # -E 0.1 --domE 0.1, markerGeneFinder.py:141
-            for b, binId in enumerate(binIds):
-                hits.write_domtblout(profiles, seqs, b, os.path.join(outDir, 'bins', binId, tableOut))
-                if bKeepAlignment:
-                    with open(os.path.join(outDir, 'bins', binId, hmmerOut), 'w') as f:
-                        f.write("# alignments are not produced by the MI355X scan (--noali semantics)\n")
+            profiles = profiles_for(ctx, db)
         except _lib.CkmError as e:
             self.logger.error('marker-gene scan failed: %s' % e)
             sys.exit(1)
-        release_scan(outDir) if (os.path.abspath(outDir), tableOut) in SCAN_CACHE else None
-        SCAN_CACHE[(os.path.abspath(outDir), tableOut)] = dict(ctx=ctx, profiles=profiles, seqs=seqs, hits=hits,
-                                                                bin_index={b: i for i, b in enumerate(binIds)}, bin_models=bin_models)
+        heads = profiles.headers
+        models_of = {}
+        if any(w is not None for w in wanted.values()):
+            cache = {}
+            for b in allIds:
+                w = wanted[b]
+                key = id(w)
+                if key not in cache:
+                    cache[key] = None if w is None else [i for i, h in enumerate(heads) if wanted_model(h["name"], h["acc"], w)]
+                models_of[b] = cache[key]
+        # ---- this rank's shard (weights = file size x models) ----
+        mine = list(range(len(binFiles)))
+        if world > 1:
+            wts = []
+            for f, b in zip(binFiles, allIds):
+                try:
+                    sz = os.path.getsize(f)
+                except OSError:
+                    sz = 0
+                nm = len(models_of[b]) if models_of.get(b) is not None else profiles.n
+                wts.append(sz * max(1, nm))
+            mine = cdist.shard_bins(wts, world)[rank]
+        myFiles = [binFiles[i] for i in mine]
+        binIds, faa = self._geneFiles(myFiles, outDir, bNucORFs, bCalledGenes)
+        if bKeepAlignment:
+            self.logger.warning("--ali: the MI355X scan runs with --noali semantics; %s holds a note instead of hmmsearch's alignment text "
+                                "(use `checkm_amd.hmmerAligner` for alignments of the marker genes)." % hmmerOut)
+        sizes = [os.path.getsize(f) if os.path.exists(f) else 0 for f in faa]
+        nmod = [len(models_of[b]) if models_of.get(b) is not None else profiles.n for b in binIds]
+        batches = plan_batches(sizes, nmod)
+        parts, where, totals = [], {}, {}
+
+        def load(batch):
+            return _lib.Seqs.from_fasta(ctx, [faa[i] for i in batch])             # read, digitized and packed by the library
+
+        def write(part, batch):
+            for b, i in enumerate(batch):
+                part["hits"].write_domtblout(profiles, part["seqs"], b, os.path.join(outDir, 'bins', binIds[i], tableOut))
+                if bKeepAlignment:
+                    with open(os.path.join(outDir, 'bins', binIds[i], hmmerOut), 'w') as f:
+                        f.write("# alignments are not produced by the MI355X scan (--noali semantics)\n")
+        try:
+            with ThreadPoolExecutor(max_workers=1) as loader, ThreadPoolExecutor(max_workers=2) as writer:
+                pending = []
+                nxt = loader.submit(load, batches[0]) if batches else None
+                for k, batch in enumerate(batches):
+                    seqs = nxt.result()
+                    nxt = loader.submit(load, batches[k + 1]) if k + 1 < len(batches) else None
+                    bm = None if not models_of else [models_of[binIds[i]] if models_of[binIds[i]] is not None else list(range(profiles.n)) for i in batch]
+                    hits = _lib.search(ctx, profiles, seqs, bm, 0.1, 0.1)          # -E 0.1 --domE 0.1, markerGeneFinder.py:141
+                    st = ctx.stats()
+                    for f in ("pairs_ssv", "pairs_msv_full", "pairs_bias", "pairs_vit", "pairs_vit_exact", "pairs_fwd", "pairs_dom", "envelopes", "regions_multi",
+                              "cells_ssv", "residue_hmm", "ms_ssv", "ms_total", "ssv_launches"):
+                        totals[f] = totals.get(f, 0) + getattr(st, f)
+                    totals["searches"] = totals.get("searches", 0) + 1
+                    part = dict(seqs=seqs, hits=hits, bins=[binIds[i] for i in batch])
+                    for b, i in enumerate(batch):
+                        where[binIds[i]] = (len(parts), b)
+                    parts.append(part)
+                    pending.append(writer.submit(write, part, batch))
+                for f in pending:
+                    f.result()
+        except _lib.CkmError as e:
+            self.logger.error('marker-gene scan failed: %s' % e)
+            sys.exit(1)
+        key = (os.path.abspath(outDir), tableOut)
+        if key in SCAN_CACHE:
+            old = SCAN_CACHE.pop(key)
+            for part in old["parts"]:
+                part["hits"].close(); part["seqs"].close()
+        SCAN_CACHE[key] = dict(ctx=ctx, profiles=profiles, parts=parts, where=where, owned=set(binIds), world=world,
+                               all_bins=list(allIds), totals=totals)        # totals: stage counters summed over this rank's ckm_search calls
+        if world > 1:
+            cdist.barrier()             # every rank's tables are on disk before anyone reads them
         out = {}
-        for b, binId in enumerate(binIds):
-            sel = profiles.headers if bin_models is None else [profiles.headers[i] for i in bin_models[b]]
-            out[binId] = models_dict(sel)
-        self.logger.info("    Finished processing %d of %d (100.00%%) bins." % (len(binIds), len(binIds)))
+        subset_cache = {}
+        for b in allIds:
+            m = models_of.get(b) if models_of else None
+            if m is None:
+                if None not in subset_cache:
+                    subset_cache[None] = models_dict(heads)
+                out[b] = subset_cache[None]
+            else:
+                k2 = id(m)
+                if k2 not in subset_cache:
+                    subset_cache[k2] = models_dict([heads[i] for i in m])
+                out[b] = subset_cache[k2]
+        self.logger.info("    Finished processing %d of %d (100.00%%) bins." % (len(allIds), len(allIds)))
         return out

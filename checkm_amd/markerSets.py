@@ -179,6 +179,12 @@ class MarkerSet(object):
         return 100 * comp / len(self.markerSet), 100 * cont / len(self.markerSet)
 
 
+def wanted_model(name, acc, keys):
+    """`hmmfetch -f <keyfile>` (checkm/markerSets.py:326-343 -> checkm/hmmer.py:97-110) takes a record when a key equals its NAME
+    or its ACC."""
+    return (acc is not None and acc in keys) or (name is not None and name in keys)
+
+
 class MarkerSetParser(object):
     """Marker-file parsing (markerSets.py:241-540)."""
 
@@ -296,7 +302,7 @@ class MarkerSetParser(object):
         wanted = self.markerAccessionsForBins(list(binIds), markerFile)
         out = {}
         for b in binIds:
-            sel = [h for h in headers if wanted[b] is None or (h['acc'] or h['name']) in wanted[b]]
+            sel = [h for h in headers if wanted[b] is None or wanted_model(h['name'], h['acc'], wanted[b])]
             out[b] = models_dict(sel)
         return out
 
@@ -316,7 +322,7 @@ class MarkerSetParser(object):
                 elif line.startswith('ACC'):
                     acc = line.split(None, 1)[1].strip()
                 elif line.startswith('//'):
-                    if wanted is None or (acc or name) in wanted:
+                    if wanted is None or wanted_model(name, acc, wanted):
                         fout.writelines(rec)
                     rec, acc, name = [], None, None
         return out

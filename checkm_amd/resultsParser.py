@@ -65,6 +65,9 @@ class ResultsManager(object):
         self.models = models
         self.binStats = binStats
         self._raw = []
+        self._counts = {}          # (id(markerSet), bIndividualMarkers) -> (len(markerHits), [n0..n5+, comp, cont]) from the batched count
+        self.remote = False        # True on rank 0 for a bin another rank scanned: only its gathered QA row is known here
+        self.het = None            # strain heterogeneity gathered from the owning rank
 
     def vetHit(self, hit):
         """One row against its model's cutoffs (resultsParser.py:340-377); the batched form of this test runs inside ckm_reduce.
@@ -130,7 +133,12 @@ class ResultsManager(object):
         return self.geneCounts(binMarkerSets.selectedMarkerSet(), self.markerHits, bIndividualMarkers)
 
     def geneCounts(self, markerSet, markerHits, bIndividualMarkers):
-        """[n0, n1, n2, n3, n4, n5+, completeness, contamination] (resultsParser.py:513-537); counted on the device."""
+        """[n0, n1, n2, n3, n4, n5+, completeness, contamination] (resultsParser.py:513-537); counted on the device.  When
+        ResultsParser.batchedGeneCounts has already counted this marker set for all bins in one launch, that row is returned."""
+        if markerHits is self.markerHits:
+            hit = self._counts.get((id(markerSet), bool(bIndividualMarkers)))
+            if hit is not None and hit[0] == len(markerHits):         # (out_format 4 inserts keys into the defaultdict: quirk Q11)
+                return list(hit[1])
         _pres, _mult, hist, _pt, _mt, _nm, empty_members = count_sets(markerSet.markerSet, markerHits)
         counts = [int(x) for x in hist]
         comp, cont = markerSet.genomeCheck(markerHits, bIndividualMarkers)
@@ -207,6 +215,8 @@ class ResultsManager(object):
     def printSummary(self, outputFormat, aai, binMarkerSets, bIndividualMarkers, coverageBinProfiles=None, table=None, anaFolder=None):
         """One bin in output formats 1-9 (resultsParser.py:678-966); returns the number of reported rows for formats 6 and 7, else 0."""
         het = aai.aaiMeanBinHetero.get(self.binId, 0.0) if aai is not None else 0.0
+        if self.het is not None:
+            het = self.het
         if outputFormat in (1, 2):
             sel = binMarkerSets.selectedMarkerSet()
             lineage = sel.lineageStr
@@ -468,47 +478,73 @@ class ResultsParser(object):
         binIds = list(self.models.keys())
         ent = SCAN_CACHE.get((os.path.abspath(outDir), hmmTableFile))
         mk = lambda b: ResultsManager(b, self.models[b], bIgnoreThresholds, evalueThreshold, lengthThreshold, bSkipPseudoGeneCorrection,
-                                      binStats[b] if binStats is not None else None)
-        if ent is not None and all(b in ent["bin_index"] for b in binIds):
-            self._reduce_resident(ent, binIds, mk, bSkipAdjCorrection, bIgnoreThresholds, evalueThreshold, lengthThreshold, bSkipPseudoGeneCorrection)
-        else:
-            self._reduce_text(outDir, hmmTableFile, binIds, mk, bSkipAdjCorrection, bIgnoreThresholds, evalueThreshold, lengthThreshold,
+                                      binStats[b] if (binStats is not None and b in binStats) else None)
+        self._mk, self._text_args = mk, (outDir, hmmTableFile, bSkipAdjCorrection, bIgnoreThresholds, evalueThreshold, lengthThreshold, bSkipPseudoGeneCorrection)
+        self.remote_bins = []
+        if ent is not None and ent.get("world", 1) > 1:
+            # one process per GPU: this rank reduces the bins it scanned; the QA rows of the others arrive in printSummary's gather
+            self.remote_bins = [b for b in binIds if b not in ent["owned"]]
+            binIds = [b for b in binIds if b in ent["owned"]]
+        resident = [b for b in binIds if ent is not None and b in ent["where"]]
+        rest = [b for b in binIds if ent is None or b not in ent["where"]]
+        if resident:
+            self._reduce_resident(ent, resident, mk, bSkipAdjCorrection, bIgnoreThresholds, evalueThreshold, lengthThreshold, bSkipPseudoGeneCorrection)
+        if rest:
+            self._reduce_text(outDir, hmmTableFile, rest, mk, bSkipAdjCorrection, bIgnoreThresholds, evalueThreshold, lengthThreshold,
                               bSkipPseudoGeneCorrection)
         self.logger.info('    Finished parsing hits for %d of %d (100.00%%) bins.' % (len(binIds), len(binIds)))
 
     # the packed hits of a scan run in this process: no text round-trip
     def _reduce_resident(self, ent, binIds, mk, skip_adj, ignore, evalue, length, skip_pseudo):
-        profiles, hits, seqs = ent["profiles"], ent["hits"], ent["seqs"]
-        nb = hits.nbins
-        # bins whose (possibly sticky) header view gives identical thresholds share one library call
-        groups = {}
+        profiles = ent["profiles"]
+        slot_acc = [hd["acc"] if hd["acc"] else hd["name"] for hd in profiles.headers]
+        # Bins whose (possibly sticky) header views agree on every model they share are reduced in one library call: a view is
+        # {acc: (acc, leng, ga, tc, nc)}; a bin joins the first group it does not contradict (lineage_wf: every bin has its own
+        # model subset, but the thresholds of a model rarely depend on the subset).
+        groups = []          # [merged view, members, last dict object seen]
         for b in binIds:
-            sig = []
-            for hd in profiles.headers:
-                a = hd["acc"] if hd["acc"] else hd["name"]
-                m = self.models[b].get(a)
-                sig.append(None if m is None else (m.acc, m.leng, m.ga, m.tc, m.nc))
-            groups.setdefault(tuple(sig), []).append(b)
-        class _Blank(object):
-            def __init__(self, hd):
-                self.acc = hd["acc"] if hd["acc"] else hd["name"]; self.leng = hd["leng"]; self.ga = self.tc = self.nc = None
-        for sig, members in groups.items():
-            first = self.models[members[0]]
-            mlist = []
-            for hd in profiles.headers:
-                a = hd["acc"] if hd["acc"] else hd["name"]
-                mlist.append(first[a] if a in first else _Blank(hd))
+            mb = self.models[b]
+            placed = False
+            for g in groups:
+                if g[2] is mb:
+                    g[1].append(b); placed = True
+                    break
+            if placed:
+                continue
+            view = {a: (m.acc, m.leng, m.ga, m.tc, m.nc) for a, m in mb.items()}
+            for g in groups:
+                merged = g[0]
+                if all(merged.get(a, v) == v for a, v in view.items()):
+                    merged.update(view); g[1].append(b); g[2] = mb; placed = True
+                    break
+            if not placed:
+                groups.append([view, [b], mb])
+
+        class _Slot(object):
+            def __init__(self, acc, leng, v):
+                self.acc, self.leng = (v[0], v[1]) if v else (acc, leng)
+                self.ga, self.tc, self.nc = (v[2], v[3], v[4]) if v else (None, None, None)
+        for merged, members, _last in groups:
+            mlist = [_Slot(a, hd["leng"], merged.get(a)) for a, hd in zip(slot_acc, profiles.headers)]
             keys, acc, qlen, thr, clans, nested = _plan_for_models(mlist)
-            plan = cqa.QAPlan(keys, acc, qlen, thr, [[] for _ in range(nb)], clans, nested)
-            sel = np.zeros(nb, dtype=np.uint8)
+            by_part = {}
             for b in members:
-                sel[ent["bin_index"][b]] = 1
-            res = plan.reduce(runtime.get_ctx(), hits, seqs, ignore, evalue, length, skip_pseudo, skip_adj, False, sel)
-            for b in members:
-                rm = mk(b)
-                rm.markerHits = _marker_hits_from(res, ent["bin_index"][b], keys, lambda r: _hit_from_columns(hits, seqs, profiles, r))
-                self.results[b] = rm
-            res.close()
+                pi, lb = ent["where"][b]
+                by_part.setdefault(pi, []).append((b, lb))
+            for pi, lst in by_part.items():
+                part = ent["parts"][pi]
+                hits, seqs = part["hits"], part["seqs"]
+                nb = hits.nbins
+                plan = cqa.QAPlan(keys, acc, qlen, thr, [[] for _ in range(nb)], clans, nested)
+                sel = np.zeros(nb, dtype=np.uint8)
+                for _b, lb in lst:
+                    sel[lb] = 1
+                res = plan.reduce(runtime.get_ctx(), hits, seqs, ignore, evalue, length, skip_pseudo, skip_adj, False, sel)
+                for b, lb in lst:
+                    rm = mk(b)
+                    rm.markerHits = _marker_hits_from(res, lb, keys, lambda r, h=hits, q=seqs: _hit_from_columns(h, q, profiles, r))
+                    self.results[b] = rm
+                res.close()
 
     # tables written by an earlier command: the library parses the text of all bins at once (ckm_tables_read) and reduces bins
     # that share their model view in one call; rows become HmmerHitDOM objects only for the hits that are kept
@@ -585,12 +621,105 @@ class ResultsParser(object):
         if outputFormat == 10:
             return ['Scaffold Id', 'Bin Id', 'Length', '# contigs', 'GC', '# ORFs', 'Coding density', 'Marker Ids']
 
+    def batchedGeneCounts(self, binIdToBinMarkerSets, bIndividualMarkers, binIds=None):
+        """geneCounts of the SELECTED marker set of every bin in ONE ckm_count_sets launch (the reference counts bin by bin in Python,
+        resultsParser.py:513-537 + markerSets.py:206-238); the float64 division is finished here in the reference's accumulation
+        order.  The rows are left with each ResultsManager, whose geneCounts() returns them.  Returns {binId: [n0..n5+, comp, cont]}."""
+        import ctypes as C
+        from checkm_amd import _lib
+        bins = [b for b in (binIds if binIds is not None else sorted(self.results)) if not self.results[b].remote]
+        if not bins:
+            return {}
+        set_off, marker_off, counts, first, member, sets_of = [0], [0], [], [], [], []
+        for b in bins:
+            ms = binIdToBinMarkerSets[b].selectedMarkerSet()
+            hits = self.results[b].markerHits
+            seen = set()
+            for st in ms.markerSet:
+                for m in st:
+                    present = m in hits
+                    counts.append(len(hits[m]) if present else 0)
+                    member.append(1 if present else 0)
+                    first.append(0 if m in seen else 1)
+                    seen.add(m)
+                marker_off.append(len(counts))
+            set_off.append(len(marker_off) - 1)
+            sets_of.append(ms)
+        nb, nsets = len(bins), len(marker_off) - 1
+        c = np.array(counts or [0], dtype=np.int32); fa = np.array(first or [0], dtype=np.uint8); mem = np.array(member or [0], dtype=np.int32)
+        so = np.array(set_off, dtype=np.uint32); mo = np.array(marker_off, dtype=np.uint32); mk = np.arange(max(1, len(counts)), dtype=np.uint32)
+        csr = _lib.MarkerSetsCSR(nb, so.ctypes.data, mo.ctypes.data, mk.ctypes.data)
+        pres = np.zeros(max(1, nsets), dtype=np.int32); mult = np.zeros(max(1, nsets), dtype=np.int32)
+        hist = np.zeros(nb * 6, dtype=np.int32); pt = np.zeros(nb, dtype=np.int32); mt = np.zeros(nb, dtype=np.int32)
+        _lib._chk(_lib.load().ckm_count_sets(runtime.get_ctx().h, C.byref(csr), c.ctypes.data, fa.ctypes.data, pres.ctypes.data, mult.ctypes.data,
+                                             hist.ctypes.data, pt.ctypes.data, mt.ctypes.data))
+        out = {}
+        for k, b in enumerate(bins):
+            ms = sets_of[k]
+            s0, s1 = int(so[k]), int(so[k + 1])
+            m0, m1 = int(mo[s0]), int(mo[s1])
+            if bIndividualMarkers:
+                fk = fa[m0:m1].astype(bool)
+                n_member = int(mem[m0:m1][fk].sum())
+                empty = int(((mem[m0:m1] == 1) & (c[m0:m1] == 0) & fk).sum())
+                comp, cont = 100 * float(n_member) / ms.numMarkers(), 100 * float(int(mt[k]) - empty) / ms.numMarkers()
+            else:
+                comp = cont = 0.0
+                for i, st in enumerate(ms.markerSet):
+                    comp += float(int(pres[s0 + i])) / len(st)
+                    cont += float(int(mult[s0 + i])) / len(st)
+                comp, cont = 100 * comp / len(ms.markerSet), 100 * cont / len(ms.markerSet)
+            row = [int(x) for x in hist[k * 6:k * 6 + 6]] + [comp, cont]
+            rm = self.results[b]
+            rm._counts[(id(ms), bool(bIndividualMarkers))] = (len(rm.markerHits), row)
+            out[b] = row
+        return out
+
+    def _gather_remote_rows(self, aai, binIdToBinMarkerSets, bIndividualMarkers):
+        """One process per GPU: ONE all_gather of fixed-width QA rows (checkm_amd/dist.py) brings the rows of the bins the other
+        ranks scanned; they become ResultsManagers that only know their row (remote = True)."""
+        from checkm_amd import dist as cdist
+        order = sorted(self.models.keys())
+        index = {b: i for i, b in enumerate(order)}
+        own = [b for b in sorted(self.results) if not self.results[b].remote]
+        rows = self.batchedGeneCounts(binIdToBinMarkerSets, bIndividualMarkers, own)
+        packed = cdist.pack_qa_rows([index[b] for b in own], [binIdToBinMarkerSets[b].selectedMarkerSet().numMarkers() for b in own],
+                                    [binIdToBinMarkerSets[b].selectedMarkerSet().numSets() for b in own],
+                                    [rows[b][0:6] for b in own] if own else np.zeros((0, 6)), [rows[b][6] for b in own], [rows[b][7] for b in own])
+        for k, b in enumerate(own):
+            packed[k, 11] = aai.aaiMeanBinHetero.get(b, 0.0) if aai is not None else 0.0
+        table = cdist.gather_qa_rows(packed, len(order), cdist.collective_device())
+        for r in table:
+            b = order[int(r[0])]
+            if b in self.results and not self.results[b].remote:
+                continue
+            rm = self._mk(b) if hasattr(self, "_mk") else ResultsManager(b, self.models[b])
+            rm.remote = True
+            ms = binIdToBinMarkerSets[b].selectedMarkerSet()
+            rm._counts[(id(ms), bool(bIndividualMarkers))] = (0, [int(x) for x in r[3:9]] + [float(r[9]), float(r[10])])
+            rm.het = float(r[11])
+            self.results[b] = rm
+
     def printSummary(self, outputFormat, aai, binIdToBinMarkerSets, bIndividualMarkers, coverageFile, bTabTable, outFile, anaFolder):
         """The QA table in any of the output formats (resultsParser.py:275-319).  Tab mode is byte-compatible with the reference; the framed
-        table of the non-tab mode (formats 1, 2, 3, 9) is drawn by _Table (prettytable is not a dependency here)."""
+        table of the non-tab mode (formats 1, 2, 3, 9) is drawn by _Table (prettytable is not a dependency here).
+        One process per GPU: formats 1 and 2 are completed by the single gather of QA rows and printed by rank 0; for the other
+        formats rank 0 reads the tables the other ranks wrote."""
         if coverageFile:
             self.logger.error('Coverage profiles are not part of this path.')
             sys.exit(1)
+        from checkm_amd import dist as cdist
+        if cdist.world_size() > 1:
+            if outputFormat in (1, 2):
+                self._gather_remote_rows(aai, binIdToBinMarkerSets, bIndividualMarkers)
+            elif cdist.env_rank()[0] == 0 and getattr(self, "remote_bins", None):
+                outDir, tbl, skip_adj, ignore, ev, ln, skip_ps = self._text_args
+                self._reduce_text(outDir, tbl, self.remote_bins, self._mk, skip_adj, ignore, ev, ln, skip_ps)
+                self.remote_bins = []
+            if cdist.env_rank()[0] != 0:
+                return
+        if outputFormat in (1, 2):
+            self.batchedGeneCounts(binIdToBinMarkerSets, bIndividualMarkers)
         old = sys.stdout
         if outFile:
             sys.stdout = open(outFile, 'w')

@@ -1,5 +1,5 @@
 """Process-wide device context: one ckm_ctx per (process, device), as the C ABI requires.
-The device is LOCAL_RANK when launched one-process-per-GPU, else CHECKM_AMD_DEVICE or 0."""
+The device is CHECKM_AMD_DEVICE if set, else LOCAL_RANK when launched one-process-per-GPU, else 0."""
 import atexit
 import os
 
@@ -11,7 +11,7 @@ _ctx = None
 def get_ctx():
     global _ctx
     if _ctx is None:
-        dev = int(os.environ.get("LOCAL_RANK", os.environ.get("CHECKM_AMD_DEVICE", "0")))
+        dev = int(os.environ.get("CHECKM_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         _ctx = _lib.Context(dev)          # raises CkmError(ENODEV) without a gfx950: there is no CPU path
         atexit.register(close)
     return _ctx
@@ -19,6 +19,10 @@ def get_ctx():
 
 def close():
     global _ctx
+    import sys
+    mod = sys.modules.get("checkm_amd.markerGeneFinder")
+    if mod is not None:
+        mod.release_scan()              # hits, sequences and profile databases of this context
     if _ctx is not None:
         _ctx.close()
         _ctx = None

@@ -999,12 +999,14 @@ static int stochastic_trace(const PROF *p, const XF *xf, int Ld, const float *mx
           acc += (double)cr[2*Mp+c]; if (target < base[z] + acc) { pick = c; isd = 1; hit = 1; break; }
         }
       }
-      k = pick + 1; st = isd ? sD : sM; sqto = 0; hmmto = 0;
+      /* the domain's last model node is the state E was entered from, match or delete (HMMER's trace index counts D states for
+       * the model coordinates); its last residue is set by the first match state met on the way back */
+      k = pick + 1; st = isd ? sD : sM; sqto = 0; hmmto = k;
     } break;
     case sM: {
       int c = k - 1;
       code[i] = (uint16_t)(0x4000 | k);
-      if (!sqto) { sqto = i; hmmto = k; }
+      if (!sqto) sqto = i;
       pth[0] = xs[(size_t)(i-1)*6+3] * p->fBM[c];
       if (c > 0) { pth[1] = pr[c-1] * p->fMM[c]; pth[2] = pr[Mp+c-1] * p->fIM[c]; pth[3] = pr[2*Mp+c-1] * p->fDM[c]; }
       else pth[1] = pth[2] = pth[3] = 0.0f;
@@ -1205,13 +1207,13 @@ static void domain_definition(const PROF *p, const uint8_t *dsq, int L, const fl
         }
         if (ens_rc == 0) {
           for (int pos = i; pos <= j; pos++) dd->n2sc[pos] = logf(n2sum[pos-i] / (float)ENS_NSAMPLES);
-          int nenv = cluster_ensemble(seg_all, nseg_all, cap, env, Lr), last_j2 = 0;
+          int nenv = cluster_ensemble(seg_all, nseg_all, cap, env, Lr);
           for (int e = 0; e < nenv; e++) {
             int i2 = env[e].sqfrom + i - 1, j2 = env[e].sqto + i - 1;
-            if (i2 <= last_j2) continue;          /* overlapping envelopes: the later one is skipped, as HMMER does */
+            /* an envelope that overlaps its predecessor is rescored like any other (HMMER only counts it, "noverlaps"; the
+             * duplicate alignments this can produce are hidden at reporting time: workaround of its bug #h74 below) */
             DOMAIN d; memset(&d, 0, sizeof(d)); dd->nenvelopes++;
             if (rescore_envelope(p, dsq, L, i2, j2, dd->n2sc, 1, &d, NULL, NULL, NULL) == 0) ddef_add(dd, &d);
-            last_j2 = j2;
           }
         }
         free(n2sum); free(seg_all); free(env);
@@ -1365,12 +1367,14 @@ int p7o_search(const P7O_HMMSET *set, const int32_t *model_idx, int nmodels,
       if (!(exp(h->lnP) * Z <= E)) continue;
       for (int d = 0; d < h->ndom; d++) { h->dcl[d].is_reported = (exp(h->dcl[d].lnP) * domZ <= domE); if (h->dcl[d].is_reported) h->nreported++; }
       /* bug-h74 workaround: hide the weaker of two domains with identical alignment coordinates */
-      for (int d = 1; d < h->ndom; d++) {
-        DOMAIN *a = &h->dcl[d-1], *b = &h->dcl[d];
-        if (a->is_reported && b->is_reported && a->ali_from == b->ali_from && a->ali_to == b->ali_to && a->hmm_from == b->hmm_from && a->hmm_to == b->hmm_to) {
-          DOMAIN *w = (a->bitscore >= b->bitscore) ? b : a; w->is_reported = 0; h->nreported--;
+      for (int d1 = 0; d1 < h->ndom; d1++)
+        for (int d2 = d1 + 1; d2 < h->ndom; d2++) {      /* every pair, sequence coordinates only; the lower bit score goes (the later one on a tie) */
+          DOMAIN *a = &h->dcl[d1], *b = &h->dcl[d2];
+          if (a->ali_from == b->ali_from && a->ali_to == b->ali_to) {
+            DOMAIN *w = (a->bitscore >= b->bitscore) ? b : a;
+            if (w->is_reported) { w->is_reported = 0; h->nreported--; }
+          }
         }
-      }
       int nd = 0;
       for (int d = 0; d < h->ndom; d++) if (h->dcl[d].is_reported) {
         DOMAIN *dm = &h->dcl[d]; nd++;

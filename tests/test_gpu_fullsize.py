@@ -144,3 +144,47 @@ def test_many_models_with_ragged_subsets(gpu_ctx):
             assert (o.seq_idx, o.model_idx, o.full_evalue, common.float_bits(o.full_score), common.float_bits(o.dom_score), o.hmm_from, o.hmm_to, o.ali_from, o.ali_to,
                     o.env_from, o.env_to, o.c_evalue) == g, (b, o.seq_idx, o.model_idx)
     hits.close(); seqs.close(); prof.close(); hs.close()
+
+
+def test_whole_bins_row_for_row_against_the_oracle(world):
+    """EVERY row of two complete cfg2 bins (2000 ORFs x 43 models each, 172 000 pairs) against the oracle, every column, floats as
+    bit patterns; the oracle is threaded over the models."""
+    w = world
+    ctx, prof, bins = w["ctx"], w["prof"], w["bins"]
+    seqs = _lib.Seqs(ctx, bins[:2])
+    hits = _lib.search(ctx, prof, seqs)
+    hs = p7.HmmSet(w["path"])
+    base = 0
+    for b in range(2):
+        recs = bins[b]
+        rows = common.oracle_search_threaded(hs, range(hs.n), [p7.digitize(r[2]) for r in recs], [r[0] for r in recs])
+        mine = [common.hit_key(hits, i, base) for i in hits.rows(b)]
+        assert len(rows) == len(mine) >= 43
+        for o, g in zip(rows, mine):
+            assert common.row_key(o) == g, (b, o.seq_idx, o.model_idx)
+        base += len(recs)
+    hs.close(); hits.close(); seqs.close()
+
+
+def test_biased_composition_and_paralog_family(world):
+    """A bin whose background is far from Swiss-Prot (skewed Dirichlet draw: low-complexity-like ORFs drive many more pairs past the
+    MSV and bias filters) and which carries 20 paralogous copies of one family: the rare stages (bias filter, Viterbi, Forward,
+    domain definition, null2) see the load real proteomes give them.  All rows against the oracle."""
+    from checkm_amd import synth_lineage as sl
+    w = world
+    ctx, prof, profs = w["ctx"], w["prof"], w["profs"]
+    rng = np.random.default_rng(5)
+    comp = rng.dirichlet(np.full(20, 0.35))
+    recs = sl.make_lineage_bin(profs, list(range(len(profs))), 9191, 700, composition=comp, paralogs=(profs[7], 20), dup_frac=0.1)
+    seqs = _lib.Seqs(ctx, [recs])
+    hits = _lib.search(ctx, prof, seqs)
+    st = ctx.stats()
+    hs = p7.HmmSet(w["path"])
+    rows = common.oracle_search_threaded(hs, range(hs.n), [p7.digitize(r[2]) for r in recs], [r[0] for r in recs])
+    mine = [common.hit_key(hits, i) for i in hits.rows(0)]
+    assert len(rows) == len(mine) >= 43 + 20
+    for o, g in zip(rows, mine):
+        assert common.row_key(o) == g, (o.seq_idx, o.model_idx)
+    assert sum(1 for g in mine if g[1] == 7) >= 20                                   # the paralog family is reported copy by copy
+    assert st.pairs_bias > 0.03 * st.pairs_ssv                                       # the composition really loads the filters (iid Swiss-Prot: ~2 %)
+    hs.close(); hits.close(); seqs.close()

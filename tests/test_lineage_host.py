@@ -1,0 +1,59 @@
+"""Host logic of the lineage_wf-shaped path that needs no device: the synthetic lineage world parses through the marker-file mirrors
+(checkm/markerSets.py:428-522), the model subset of a bin is its chain's marker genes plus the clan expansion (markerSets.py:443-457)
+matched by NAME or ACC as `hmmfetch -f` matches (markerSets.py:326-343), and find()'s batch plan / rank shards."""
+import os
+
+from checkm_amd import dist as cdist, markerGeneFinder as mgf, synth_lineage as sl
+from checkm_amd.defaultValues import DefaultValues
+from checkm_amd.markerSets import BinMarkerSets, MarkerSetParser, wanted_model
+
+
+def test_world_files_parse_through_the_mirrors(tmp_path):
+    w = sl.World(str(tmp_path / "data"), n_models=240, seed=77)
+    DefaultValues.set_data_root(str(tmp_path / "data"))
+    binIds = ["b%d" % i for i in range(12)]
+    lin, tax = w.write_marker_files(str(tmp_path), binIds)
+    msp = MarkerSetParser()
+    assert msp.markerFileType(lin) == BinMarkerSets.TREE_MARKER_SET and msp.markerFileType(tax) == BinMarkerSets.TAXONOMIC_MARKER_SET
+    assert msp.hmmDatabaseFor(lin) == DefaultValues.HMM_MODELS == w.checkm_hmm
+    per_bin = msp.parseLineageMarkerSetFile(lin)
+    wanted = msp.markerAccessionsForBins(binIds, lin)
+    for k, b in enumerate(binIds):
+        fid = w.family_of(k)
+        bms = per_bin[b]
+        assert [ms.UID for ms in bms.markerSets] == w.lineage.chain(fid)
+        assert bms.getMarkerGenes() == w.lineage.marker_genes(fid)
+        assert [sorted(s) for s in bms.selectedMarkerSet().markerSet] == [sorted(s) for s in w.lineage.selected_sets(fid)]
+        assert w.lineage.marker_genes(fid) <= wanted[b] <= set(w.accs)
+    # clan expansion: a marker in a clan pulls its clan-mates in
+    assert any(wanted[b] - w.lineage.marker_genes(w.family_of(k)) for k, b in enumerate(binIds))
+    t = msp.markerAccessionsForBins(binIds, tax)
+    assert all(t[b] is t[binIds[0]] for b in binIds)
+    sets = msp.getMarkerSets(str(tmp_path), binIds, tax)
+    assert sets["b3"].selectedMarkerSet().UID == "p1"
+    # records: prodigal-style names, planted markers of the selected set
+    recs = w.bin_records(0, orf_lo=200, orf_hi=260)
+    assert 200 <= len(recs) <= 260 and all(r[2].endswith("*") and "_" in r[0] for r in recs)
+    assert w.bin_records(0, orf_lo=200, orf_hi=260) == recs                      # fixed seeds
+
+
+def test_wanted_model_matches_name_or_acc():
+    keys = {"PF00001.1", "TIGR00042", "onlyname"}
+    assert wanted_model("x", "PF00001.1", keys) and wanted_model("TIGR00042", "TIGR00042", keys)
+    assert wanted_model("onlyname", "PF99999.9", keys)                            # listed by NAME although the record has an ACC
+    assert wanted_model("onlyname", None, keys) and not wanted_model("y", None, keys) and not wanted_model("y", "PF2.1", keys)
+
+
+def test_batches_and_shards():
+    sizes = [320 * 1000] * 10 + [320 * 5000] * 3          # ~1000 and ~5000 ORFs
+    nm = [500] * 13
+    b = mgf.plan_batches(sizes, nm, pair_budget=2 * 1000 * 1000, res_budget=10 ** 12)
+    assert [i for part in b for i in part] == list(range(13)) and all(part for part in b)
+    assert all(sum(sizes[i] // 320 * nm[i] for i in part) <= 2 * 1000 * 1000 or len(part) == 1 for part in b)
+    assert len(mgf.plan_batches(sizes, nm, pair_budget=10 ** 15, res_budget=10 ** 15)) == 1
+    assert mgf.plan_batches([], []) == []
+    assert len(mgf.plan_batches(sizes, nm, pair_budget=10 ** 15, res_budget=320 * 2000)) >= 8
+    sh = cdist.shard_bins([s * n for s, n in zip(sizes, nm)], 4)
+    assert sorted(i for s in sh for i in s) == list(range(13))
+    loads = [sum(sizes[i] for i in s) for s in sh]
+    assert max(loads) <= 1.6 * min(loads)

@@ -477,10 +477,10 @@ def _segmentations(M, mat, t, x):
         tot[0] += w
         key = []
         ratio = [1.0] * (L + 1)
-        for em in doms:                                   # em: [(residue, 'M'|'I', node)] of one domain, in order
+        for em, kexit in doms:                            # em: [(residue, 'M'|'I', node)] of one domain, in order; kexit: node of the state E was entered from (M or D)
             ms = [(i, k) for i, kind, k in em if kind == 'M']
             sqfrom, sqto = ms[0][0], ms[-1][0]
-            key.append((sqfrom, sqto, ms[0][1], ms[-1][1]))
+            key.append((sqfrom, sqto, ms[0][1], kexit))   # model coordinates run to the last node visited, delete states included (HMMER's trace index)
             inside = [(i, kind, k) for i, kind, k in em if sqfrom <= i <= sqto]
             n = float(len(inside))
             for pos in range(sqfrom + 1, sqto + 1):       # the first residue of a domain keeps ratio 1 (HMMER's `pos <= sqfrom` loop)
@@ -499,7 +499,7 @@ def _segmentations(M, mat, t, x):
                 Mk(k, i + 1, w * move * entry[k] * e(k, i), doms, [(i + 1, 'M', k)])
 
     def Mk(k, i, w, doms, em):
-        E(i, w, doms + [em])
+        E(i, w, doms + [(em, k)])
         if k < M:
             if i < L:
                 Mk(k + 1, i + 1, w * t[k][MM] * e(k + 1, i), doms, em + [(i + 1, 'M', k + 1)])
@@ -512,7 +512,7 @@ def _segmentations(M, mat, t, x):
             Ik(k, i + 1, w * t[k][II], doms, em + [(i + 1, 'I', k)])
 
     def Dk(k, i, w, doms, em):
-        E(i, w, doms + [em])
+        E(i, w, doms + [(em, k)])
         if k < M:
             if i < L:
                 Mk(k + 1, i + 1, w * t[k][DM] * e(k + 1, i), doms, em + [(i + 1, 'M', k + 1)])

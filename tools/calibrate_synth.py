@@ -70,7 +70,24 @@ def calibrate(profs, rng):
     return out
 
 
+def main_cfg3():
+    """STATS LOCAL lines of the 2000-profile lineage world (checkm_amd/synth_lineage.py) -> checkm_amd/synth_stats_cfg3.json."""
+    from checkm_amd import synth_lineage as sl
+    rng = np.random.default_rng(20250925)
+    profs = sl.lineage_profiles(with_stats=False)
+    stats = {}
+    for lo in range(0, len(profs), 250):
+        chunk = profs[lo:lo + 250]
+        for p, s in zip(chunk, calibrate(chunk, rng)):
+            stats[p.acc] = {"stats": s, "M": p.M}
+        print("calibrated %d / %d" % (min(lo + 250, len(profs)), len(profs)), flush=True)
+    with open(os.path.join(ROOT, "checkm_amd", "synth_stats_cfg3.json"), "w") as f:
+        json.dump(stats, f, indent=0, sort_keys=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cfg3":
+        return main_cfg3()
     rng = np.random.default_rng(20250614)
     stats = {}
     profs = synth.cpr43_profiles(with_stats=False)
