@@ -207,7 +207,7 @@ def make_lineage_bin(profs, planted, seed, n_orfs, phylo=None, dup_frac=0.04, or
     bg = synth.BGF if composition is None else np.asarray(composition, dtype=np.float64) / np.sum(composition)
     flat = rng.choice(20, size=int(lens.sum()), p=bg)
     seqs = np.split(flat, np.cumsum(lens)[:-1])
-    todo = [profs[i] for i in planted] + list(phylo or [])
+    todo = list(phylo or []) + [profs[i] for i in planted]            # (a bin too small for all its plants loses lineage markers, never the 43 phylogenetic ones)
     copies = []
     for p in todo:
         copies.append(p)
