@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcheckm_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class CkmError(RuntimeError):
@@ -48,7 +48,7 @@ class SearchStats(C.Structure):
     _fields_ = [("pairs_ssv", C.c_uint64), ("pairs_msv_full", C.c_uint64), ("pairs_bias", C.c_uint64), ("pairs_vit", C.c_uint64),
                 ("pairs_fwd", C.c_uint64), ("pairs_dom", C.c_uint64), ("envelopes", C.c_uint64), ("regions_multi", C.c_uint64), ("pairs_vit_exact", C.c_uint64), ("cells_ssv", C.c_uint64),
                 ("residue_hmm", C.c_uint64), ("ms_ssv", C.c_double), ("ms_filters", C.c_double), ("ms_fwdbwd", C.c_double),
-                ("ms_domains", C.c_double), ("ms_host", C.c_double), ("ms_total", C.c_double), ("ssv_launches", C.c_uint32)]
+                ("ms_domains", C.c_double), ("ms_host", C.c_double), ("ms_total", C.c_double), ("ssv_launches", C.c_uint32), ("cascade_fallback_lanes", C.c_uint32)]
 
 
 class StageScores(C.Structure):

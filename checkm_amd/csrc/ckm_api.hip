@@ -72,6 +72,8 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
       for (int k = 0; k < 8; ++k) { if (k < nside) HIPCHK(hipStreamCreateWithFlags(&w.side[k], hipStreamNonBlocking)); else w.side[k] = w.side[k % nside]; }
       w.ens_stream = w.side[nside - 1];
       for (auto &e : w.ev) HIPCHK(hipEventCreate(&e));
+      for (auto &e : w.cev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      for (auto &e : w.cls_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       memset(&w.stats, 0, sizeof(w.stats));
       w.ws_budget = budget;
       w.pool.reset(new HostPool(host_threads));
@@ -87,6 +89,8 @@ extern "C" void ckm_ctx_destroy(ckm_ctx *ctx) {
   for (auto &w : ctx->w) {
     if (!w.stream) continue;
     for (auto &e : w.ev) (void)hipEventDestroy(e);
+    for (auto &e : w.cev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : w.cls_ev) if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < w.nside; ++k) (void)hipStreamDestroy(w.side[k]);
     (void)hipStreamDestroy(w.stream);
   }
@@ -118,6 +122,8 @@ extern "C" int ckm_profiles_load(ckm_ctx *ctx, const char *hmm_path, ckm_profile
       DevModel d;
       memset(&d, 0, sizeof(d));
       d.M = hp.M; d.ssvQ = hp.ssvQ; d.fbQ = hp.fbQ; d.vitQH = hp.vitQH;
+      d.fb_cls = fb_class_id(hp.fbQ); d.vit_cls = vit_class_id(hp.vitQH);
+      if (d.fb_cls < 0 || d.vit_cls < 0) throw Error(CKM_ERANGE, "model " + h.name + " is longer than the instantiated kernel classes (DESIGN.md limits)");
       d.base_b = hp.base_b; d.bias_b = hp.bias_b; d.tbm_b = hp.tbm_b; d.tec_b = hp.tec_b; d.scale_b = hp.scale_b;
       d.scale_w = hp.scale_w; d.base_w = hp.base_w; d.wE_loop = hp.wE_loop; d.wE_move = hp.wE_move;
       d.fE_loop = hp.fE_loop; d.fE_move = hp.fE_move;

@@ -43,7 +43,17 @@ extern "C" int ckm_debug_stages(ckm_ctx *ctx_, const ckm_profiles *p, const ckm_
     run_msv_exact(ctx, p, s, pr, uscp, &xJp);
     ctx->cand.ensure(npairs * sizeof(PairRec)); ctx->fullx.ensure(npairs * 4); ctx->fullu.ensure(npairs * 4); ctx->raw.ensure(npairs * 12);
     HIPCHK(hipMemcpyAsync(ctx->cand.p, pr.data(), npairs * sizeof(PairRec), hipMemcpyHostToDevice, ctx->stream));
-    launch_msv_full(ctx->stream, ctx->cand.as<PairRec>(), npairs, dm, lt, res, off, dlen, ctx->fullx.as<int32_t>(), ctx->fullu.as<float>(), p->maxMp);
+    std::map<int, std::vector<uint32_t>> vq;
+    for (uint32_t i = 0; i < npairs; ++i) vq[p->prof[model[i]].vitQH].push_back(i);
+    // queue control words [count, head] for the exact-MSV launch and one pair per Viterbi register class
+    std::vector<uint32_t> qctl(2 + 2 * 64, 0u);
+    qctl[0] = npairs;
+    { size_t k = 1; for (auto &kv : vq) { qctl[2 * k] = (uint32_t)kv.second.size(); ++k; } }
+    ctx->vitq.ensure(qctl.size() * 4);
+    uint32_t *qd = ctx->vitq.as<uint32_t>();
+    HIPCHK(hipMemcpyAsync(qd, qctl.data(), qctl.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    launch_msv_full(ctx->stream, std::min<uint32_t>(npairs, 4096), WorkQueue{nullptr, qd, qd + 1, npairs}, ctx->cand.as<PairRec>(), dm, lt, res, off, dlen,
+                    ctx->fullx.as<int32_t>(), ctx->fullu.as<float>(), p->maxMp, nullptr);
     launch_bias(ctx->stream, ctx->cand.as<PairRec>(), npairs, dm, lt, res, off, dlen, ctx->raw.as<float>());
     HIPCHK(hipGetLastError());
     std::vector<int32_t> xJ(npairs); std::vector<float> usc(npairs), raw(npairs * 3);
@@ -51,16 +61,20 @@ extern "C" int ckm_debug_stages(ckm_ctx *ctx_, const ckm_profiles *p, const ckm_
     HIPCHK(hipMemcpyAsync(usc.data(), ctx->fullu.p, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(raw.data(), ctx->raw.p, npairs * 12, hipMemcpyDeviceToHost, ctx->stream));
     // Viterbi on every pair
-    std::map<int, std::vector<uint32_t>> vq;
-    for (uint32_t i = 0; i < npairs; ++i) vq[p->prof[model[i]].vitQH].push_back(i);
     std::vector<uint32_t> flat; std::vector<std::pair<int, std::pair<size_t, size_t>>> vg;
     for (auto &kv : vq) { vg.push_back({kv.first, {flat.size(), kv.second.size()}}); flat.insert(flat.end(), kv.second.begin(), kv.second.end()); }
     ctx->fbidx.ensure(npairs * 4); ctx->vitx.ensure(npairs * 4); ctx->vits.ensure(npairs * 4);
     HIPCHK(hipMemcpyAsync(ctx->fbidx.p, flat.data(), npairs * 4, hipMemcpyHostToDevice, ctx->stream));
-    for (auto &g : vg)
-      if (launch_vit(g.first, ctx->stream, ctx->cand.as<PairRec>(), ctx->fbidx.as<uint32_t>() + g.second.first, (uint32_t)g.second.second, dm, lt, res, off, dlen,
-                     ctx->vitx.as<int32_t>(), ctx->vits.as<float>(), nullptr, false))
-        throw Error(CKM_ERANGE, "no Viterbi kernel instance");
+    {
+      size_t k = 1;
+      for (auto &g : vg) {
+        const uint32_t cnt = (uint32_t)g.second.second;
+        if (launch_vit(g.first, std::min<uint32_t>((cnt + 3) / 4, 2048), ctx->stream, WorkQueue{ctx->fbidx.as<uint32_t>() + g.second.first, qd + 2 * k, qd + 2 * k + 1, cnt},
+                       ctx->cand.as<PairRec>(), dm, lt, res, off, dlen, ctx->vitx.as<int32_t>(), ctx->vits.as<float>(), nullptr, false, nullptr))
+          throw Error(CKM_ERANGE, "no Viterbi kernel instance");
+        ++k;
+      }
+    }
     HIPCHK(hipGetLastError());
     std::vector<int32_t> vx(npairs); std::vector<float> vs(npairs);
     HIPCHK(hipMemcpyAsync(vx.data(), ctx->vitx.p, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));

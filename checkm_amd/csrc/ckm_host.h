@@ -34,22 +34,29 @@ int launch_ssv(int Q, int nblocks, int threads, hipStream_t stream, const SsvBlo
 void launch_msv_finish(hipStream_t stream, const FinishArgs &a, uint32_t nblocks);
 int launch_msv(int Q, int nblocks, hipStream_t stream, const SsvBlockWork *work, const DevModel *models, const LenEntry *lentab,
                const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const uint32_t *lists, int32_t *out_xJ, float *out_usc);
-void launch_msv_full(hipStream_t stream, const PairRec *pairs, uint32_t npairs, const DevModel *models, const LenEntry *lentab,
-                     const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xJ, float *out_usc, int maxMp);
+void launch_msv_full(hipStream_t stream, uint32_t nblocks, WorkQueue queue, const PairRec *pairs, const DevModel *models, const LenEntry *lentab,
+                     const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xJ, float *out_usc, int maxMp,
+                     const CascadeDev *cd /* null: scores only */);
 void launch_bias(hipStream_t stream, PairRec *pairs, uint32_t npairs, const DevModel *models, const LenEntry *lentab,
                  const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, float *raw);
-int launch_vit(int Q, hipStream_t stream, const PairRec *pairs, const uint32_t *idx, uint32_t n, const DevModel *models,
-               const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xC, float *out_sc, uint32_t *out_flag, bool fast);
-int launch_fwd(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const uint32_t *blk_model, const DevModel *models,
+int launch_vit(int QH, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const PairRec *pairs, const DevModel *models,
+               const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xC, float *out_sc,
+               uint32_t *out_flag, bool fast, const CascadeDev *cd /* null: scores only */);
+int launch_fwd(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, FbWork *work, const DevModel *models,
                const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, FwdOut *out,
-               ScaleEvent *events, uint32_t *nevents, uint32_t cap_events);
-int launch_bwd(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const uint32_t *blk_model, const DevModel *models,
+               ScaleEvent *events, uint32_t *nevents, uint32_t cap_events, const CascadeDev *cd /* null: no F3 epilogue */);
+int launch_bwd(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const FbWork *work, const DevModel *models,
                const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, const FwdOut *fout, int32_t *range_err);
-int launch_oa(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const uint32_t *blk_model, const DevModel *models,
-              float *ws, const int32_t *range_err, EnvOut *out);
+int launch_oa(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const FbWork *work, const DevModel *models,
+              float *ws, const int32_t *range_err, const FwdOut *fout, EnvOut *out);
 
-void launch_ensemble(hipStream_t stream, const EnsWork *work, uint32_t nregions, int max_Ld, int max_Mp, const DevModel *models,
-                     const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, const uint32_t *seeds);
+void launch_ensemble(hipStream_t stream, const EnsWork *work, const uint32_t *count, uint32_t cap, uint32_t grid_regions, int max_Mp,
+                     const DevModel *models, const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, const uint32_t *seeds,
+                     float *host_res /* pinned buffer the results are exported to, or null */);
+void launch_bias_filter(hipStream_t stream, uint32_t nblocks, const CascadeDev &cd, const DevModel *models, const LenEntry *lentab,
+                        const uint8_t *res, const uint64_t *seq_off);
+void launch_regions(hipStream_t stream, uint32_t nblocks, const uint32_t *list, const uint32_t *count, uint32_t cap, const FbWork *fwork,
+                    const CascadeDev &cd, const DevModel *models, float *ws);
 #define HIPCHK(expr)                                                                                         \
   do {                                                                                                       \
     hipError_t e_ = (expr);                                                                                  \
@@ -78,7 +85,7 @@ struct PinnedBuf {      // grow-only page-locked host staging buffer (pageable D
     if (p) (void)hipHostFree(p);
     p = nullptr; cap = 0;
     const size_t want = bytes + bytes / 4 + 4096;
-    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; throw Error(CKM_ENOMEM, "hipHostMalloc failed"); }
+    if (hipHostMalloc(&p, want, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { p = nullptr; throw Error(CKM_ENOMEM, "hipHostMalloc failed"); }
     cap = want;
   }
   template <class T> T *as() const { return reinterpret_cast<T *>(p); }
@@ -109,10 +116,23 @@ struct Worker {
   std::vector<std::pair<int, std::pair<size_t, size_t>>> plan_groups;
   uint64_t plan_npairs = 0, plan_nblocks = 0, plan_residue_hmm = 0, plan_cells = 0, plan_pairs = 0;
   PinnedBuf h_a, h_b, h_ens;              // D2H staging
-  DevBuf work, maxv, surv, nores, counters, cand, raw, idx, vitx, vits, vitf, fbwork, fbidx, fbmodel, ws, fout, events, rerr, envout, fullx, fullu, msvwork, msvlist, enswork, ensseeds, ws_ens;
+  DevBuf work, maxv, surv, nores, counters, cand, raw, idx, vitx, vits, vitf, fbwork, fbidx, fbmodel, ws, fout, events, rerr, envout, fullx, fullu, msvwork, msvlist, enswork, ensseeds, ws_ens, enscount, vitq;
   size_t ws_budget = (size_t)8 << 30;     // float workspace budget (bytes) for Forward/Backward matrices
   std::unique_ptr<HostPool> pool;         // host threads of this worker
+  // ---- device-driven cascade (ckm_cascade.hip): tables, queues and result buffers of this lane; capacities only grow ----
+  struct CascadeCaps { uint32_t cand = 0, nores = 0, vq = 0, fwork = 0, ework = 0, rwork = 0, pass = 0, reg = 0, events_f = 0, events_e = 0; uint64_t hens = 0; } caps;
+  DevBuf c_cnt, c_cand, c_nores, c_bias, c_vfast, c_vexact, c_vflag, c_route, c_vq, c_vxq, c_fq, c_bq, c_eq, c_rq, c_fwork, c_ework, c_rwork, c_ens,
+         c_fout_f, c_fout_e, c_fout_r, c_rerr_e, c_rerr_r, c_tops, c_events_r;
+  PinnedBuf h_cnt, h_pass, h_reg, h_envout, h_events_f, h_events_e, h_hens;
+  hipEvent_t cev[4] = {nullptr, nullptr, nullptr, nullptr};      // fork / join points of the lane's chain
+  hipEvent_t cls_ev[16] = {};                                    // one per side stream
 };
+
+// register classes of the Viterbi-filter and Forward/Backward kernels, in queue order (DevModel::vit_cls / fb_cls index these)
+constexpr int kVitQH[ckm::NVC] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16};
+constexpr int kFbQ[ckm::NFC] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+inline int vit_class_id(int QH) { for (int i = 0; i < ckm::NVC; ++i) if (kVitQH[i] == QH) return i; return -1; }
+inline int fb_class_id(int Q) { for (int i = 0; i < ckm::NFC; ++i) if (kFbQ[i] == Q) return i; return -1; }
 
 constexpr int NWORKERS = 8;          // upper bound; CKM_WORKERS (default 3) selects how many a large search uses
 
@@ -125,6 +145,8 @@ struct ckm_ctx {
   ckm_search_stats stats;
   std::mutex ssv_mutex;                   // SSV phases are VALU-bound: two of them side by side gain nothing
   std::condition_variable ssv_cv; int ssv_turn = 0;    // workers take their first SSV phase in worker order (largest chunk first)
+  std::atomic<uint64_t> fallbacks{0};                  // lanes the device-driven cascade handed back to the host-driven one (tables / workspace too small)
+  hipEvent_t ssv_prev_done = nullptr;                  // device-driven cascade: end of the previous lane's SSV launches (the next lane's wait on it)
 };
 
 struct ckm_profiles {
@@ -247,5 +269,21 @@ void rescore_envelopes(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, co
 void run_msv_exact(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<PairRec> &pairs, std::vector<float> &usc, std::vector<int32_t> *xJ);
 void run_ensembles(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<RegionReq> &req, std::vector<RegionRes> &out);
 void fill_null2(float *null2);
+uint32_t fb_grid(size_t n);
+uint32_t ens_seed(int t);
+void cluster_ensemble(RegionRes &r);
+void ensure_ens_seeds(Worker *ctx);
+
+// what the domain stage hands to the row assembly (both cascades fill it)
+struct PassInfo { uint32_t model, seq; float fwdsc; };
+struct DomItem { uint32_t pass; int i, j, region; };       // regions in sequence order; region >= 0: resolved by the trace ensemble (index into regres)
+struct DomStage {
+  std::vector<PassInfo> pass;
+  std::vector<int> nregions;
+  std::vector<DomItem> items;
+  std::vector<RegionRes> regres;
+  std::vector<EnvReq> envreq; std::vector<int> env_region; std::vector<EnvRes> envres;
+  std::vector<std::pair<size_t, size_t>> env_of_pass;       // [first, count) into envreq
+};
 
 }  // namespace ckm

@@ -12,11 +12,83 @@ namespace {
 
 typedef std::map<std::pair<uint32_t, uint32_t>, std::vector<Hit>> HitMap;     // (bin, model) -> hits
 
+// Scores, thresholds and rows of the pairs that reached the domain stage: null2 corrections, bit scores, P-values (host libm), one Hit
+// per pair with at least one envelope.  Shared by the device-driven cascade and the host-driven one.
+void assemble_hits(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, DomStage &ds, HitMap &by_bin_model) {
+  const std::vector<DomItem> &items = ds.items; const std::vector<RegionRes> &regres = ds.regres; const std::vector<EnvReq> &envreq = ds.envreq;
+  const std::vector<int> &env_region = ds.env_region; std::vector<EnvRes> &envres = ds.envres; const std::vector<int> &nregions = ds.nregions;
+  const std::vector<std::pair<size_t, size_t>> &env_of_pass = ds.env_of_pass;
+  std::vector<std::pair<size_t, size_t>> items_of(ds.pass.size(), {0, 0});
+  { size_t it = 0; for (size_t q = 0; q < ds.pass.size(); ++q) { items_of[q].first = it; while (it < items.size() && items[it].pass == q) ++it; items_of[q].second = it; } }
+  std::vector<Hit> hit_of(ds.pass.size()); std::vector<uint8_t> has_hit(ds.pass.size(), 0);
+  pool_run(ctx, ds.pass.size(), 32, [&](size_t qlo, size_t qhi) {
+  std::vector<float> n2sc;
+  for (size_t q = qlo; q < qhi; ++q) {
+    const PassInfo &c = ds.pass[q];
+    const HostHMM &hm = p->hmm[c.model];
+    const int L = s->len[c.seq];
+    const uint8_t *dsq = s->dsq.data() + s->off[c.seq];
+    const float nullsc = s->lentab[L].nullsc;
+    n2sc.assign((size_t)L + 2, 0.f);
+    Hit h; h.model = c.model; h.seq = c.seq; h.L = L; h.nreported = 0;
+    int nenv = 0;
+    for (size_t item_at = items_of[q].first; item_at < items_of[q].second; ++item_at) if (items[item_at].region >= 0) {
+      // null2 of an ensemble region: log of the mean odds ratio over the traces, for every residue of the region
+      const DomItem &im = items[item_at]; const RegionRes &rr = regres[im.region];
+      for (int pos = im.i; pos <= im.j; ++pos) n2sc[pos] = logf(rr.n2sum[pos - im.i] / (float)ENS_NSAMPLES);
+    }
+    for (size_t e = env_of_pass[q].first; e < env_of_pass[q].first + env_of_pass[q].second; ++e) {
+      ++nenv;
+      EnvRes &er = envres[e];
+      if (!er.ok) continue;
+      float null2[KP]; for (int x = 0; x < K; ++x) null2[x] = er.null2[x];
+      fill_null2(null2);
+      Domain d; memset(&d, 0, sizeof(d));
+      d.ienv = envreq[e].ienv; d.jenv = envreq[e].jenv; d.envsc = er.envsc; d.oasc = er.oasc;
+      d.hmm_from = er.hmm_from; d.hmm_to = er.hmm_to; d.ali_from = er.ali_from; d.ali_to = er.ali_to;
+      float ln2[KP + 1];
+      for (int x = 0; x < KP; ++x) ln2[x] = logf(null2[x]);          // same value the per-position logf would give
+      ln2[KP] = 0.f;
+      float dc = 0.f;
+      if (env_region[e] >= 0) { for (int pos = d.ienv; pos <= d.jenv; ++pos) dc += n2sc[pos]; }
+      else for (int pos = d.ienv; pos <= d.jenv; ++pos) { const float v = ln2[dsq[pos - 1]]; n2sc[pos] = v; dc += v; }
+      d.domcorrection = dc;
+      h.dom.push_back(d);
+    }
+    if (nregions[q] == 0 || nenv == 0 || h.dom.empty()) continue;
+    float seqbias = 0.f;
+    for (int i = 0; i <= L; ++i) seqbias += n2sc[i];
+    seqbias = flogsum(0.0f, logf(kOmega) + seqbias);
+    float pre_score = (float)((double)(c.fwdsc - nullsc) / kLn2);
+    float seq_score = (float)((double)(c.fwdsc - (nullsc + seqbias)) / kLn2);
+    float sum_score = 0.f; int Ld = 0; seqbias = 0.f;
+    for (auto &d : h.dom) if (d.envsc - d.domcorrection > 0.0f) { sum_score += d.envsc; Ld += d.jenv - d.ienv + 1; seqbias += d.domcorrection; }
+    seqbias = flogsum(0.0f, logf(kOmega) + seqbias);
+    sum_score += (float)((double)(L - Ld) * log((double)((float)L / (float)(L + 3))));
+    const float pre2 = (float)((double)(sum_score - nullsc) / kLn2);
+    sum_score = (float)((double)(sum_score - (nullsc + seqbias)) / kLn2);
+    if (Ld > 0 && sum_score > seq_score) { seq_score = sum_score; pre_score = pre2; }
+    h.pre_score = pre_score; h.score = seq_score;
+    h.lnP = exp_logsurv(seq_score, hm.evparam[4], hm.evparam[5]);
+    for (auto &d : h.dom) {
+      const int ld = d.jenv - d.ienv + 1;
+      const float bs = d.envsc + (float)((double)(L - ld) * log((double)((float)L / (float)(L + 3))));
+      d.dombias = flogsum(0.0f, logf(kOmega) + d.domcorrection);
+      d.bitscore = (float)((double)(bs - (nullsc + d.dombias)) / kLn2);
+      d.lnP = exp_logsurv(d.bitscore, hm.evparam[4], hm.evparam[5]);
+      d.reported = false;
+    }
+    hit_of[q] = std::move(h); has_hit[q] = 1;
+  }
+  });
+  for (size_t q = 0; q < ds.pass.size(); ++q) if (has_hit[q]) by_bin_model[{s->seq_bin[hit_of[q].seq], hit_of[q].model}].push_back(std::move(hit_of[q]));
+}
+
 // The whole filter cascade + domain stage for a subset of the models, on one worker.
 struct SeqRange { std::vector<uint32_t> lo, hi; std::vector<uint64_t> res; uint64_t tag = 0; };   // per bin: [lo, hi) of s->order, residues in it
 
 static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles *p, const ckm_seqs *s, const SeqRange &rng, const std::vector<uint32_t> &my_models,
-                    const std::vector<std::vector<uint32_t>> &model_bins, HitMap &by_bin_model) {
+                    const std::vector<std::vector<uint32_t>> &model_bins, HitMap &by_bin_model, bool turn_done = false) {
   HIPCHK(hipSetDevice(ctx->device));
   const double t_start = now_ms();
   ckm_search_stats &st = ctx->stats;
@@ -29,7 +101,7 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
 
   // ---- stage 1: SSV over every pair, chunked by a pair budget ----
   std::vector<Cand> cands;
-  bool took_turn = false;
+  bool took_turn = turn_done;          // (the lane's turn was already taken and passed on by the device-driven attempt this call replaces)
   struct TurnGuard {      // a worker that never reaches an SSV phase (no pairs, or an error) still passes the turn on
     ckm_ctx *o; int t; bool *took;
     ~TurnGuard() { if (*took) return; std::unique_lock<std::mutex> l(o->ssv_mutex); o->ssv_cv.wait(l, [&] { return o->ssv_turn == t; }); o->ssv_turn++; o->ssv_cv.notify_all(); }
@@ -205,11 +277,18 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
       // pass 1: the J-free fast kernel (exact, or a lower bound with its flag set); pass 2: the exact kernel for the pairs
       // whose bound fails F2 although the J state could have lifted them
       auto run_vit = [&](const std::vector<std::pair<int, std::pair<size_t, size_t>>> &grp, bool fast) {
+        std::vector<uint32_t> qctl(2 * grp.size(), 0u);             // [count, head] per register class
+        for (size_t k = 0; k < grp.size(); ++k) qctl[2 * k] = (uint32_t)grp[k].second.second;
+        ctx->vitq.ensure(qctl.size() * 4 + 16);
+        wcopy(ctx, ctx->vitq.p, qctl.data(), qctl.size() * 4, hipMemcpyHostToDevice);
         int gi = 0;
-        for (auto it = grp.rbegin(); it != grp.rend(); ++it, ++gi) {
-          auto &g = *it;
-          if (launch_vit(g.first, ctx->side[gi % std::min(4, side_streams())], ctx->cand.as<PairRec>(), ctx->fbidx.as<uint32_t>() + g.second.first, (uint32_t)g.second.second, dm, lt, res, off, dlen,
-                         ctx->vitx.as<int32_t>(), ctx->vits.as<float>(), ctx->vitf.as<uint32_t>(), fast))
+        for (size_t k = grp.size(); k-- > 0; ++gi) {
+          auto &g = grp[k];
+          uint32_t *qd = ctx->vitq.as<uint32_t>() + 2 * k;
+          const uint32_t cnt = (uint32_t)g.second.second;
+          if (launch_vit(g.first, std::min<uint32_t>((cnt + 3) / 4, 2048), ctx->side[gi % std::min(4, side_streams())],
+                         WorkQueue{ctx->fbidx.as<uint32_t>() + g.second.first, qd, qd + 1, cnt}, ctx->cand.as<PairRec>(), dm, lt, res, off, dlen,
+                         ctx->vitx.as<int32_t>(), ctx->vits.as<float>(), ctx->vitf.as<uint32_t>(), fast, nullptr))
             throw Error(CKM_ERANGE, "no Viterbi kernel instance for this model length");
         }
         HIPCHK(hipGetLastError());
@@ -353,73 +432,423 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
   CKM_TRACE_PT("envelopes done");
   const double t_host0 = now_ms();
   // ---- stage 7: scores, thresholds, rows ----
-  std::vector<std::pair<size_t, size_t>> items_of(passers.size(), {0, 0});
-  { size_t it = 0; for (size_t q = 0; q < passers.size(); ++q) { items_of[q].first = it; while (it < items.size() && items[it].pass == q) ++it; items_of[q].second = it; } }
-  std::vector<Hit> hit_of(passers.size()); std::vector<uint8_t> has_hit(passers.size(), 0);
-  pool_run(ctx, passers.size(), 32, [&](size_t qlo, size_t qhi) {
-  std::vector<float> n2sc;
-  for (size_t q = qlo; q < qhi; ++q) {
-    const Cand &c = cands[fb_cand[passers[q]]];
-    const HostHMM &hm = p->hmm[c.r.model];
-    const int L = s->len[c.r.seq];
-    const uint8_t *dsq = s->dsq.data() + s->off[c.r.seq];
-    const float nullsc = s->lentab[L].nullsc;
-    n2sc.assign((size_t)L + 2, 0.f);
-    Hit h; h.model = c.r.model; h.seq = c.r.seq; h.L = L; h.nreported = 0;
-    int nenv = 0;
-    for (size_t item_at = items_of[q].first; item_at < items_of[q].second; ++item_at) if (items[item_at].region >= 0) {
-      // null2 of an ensemble region: log of the mean odds ratio over the traces, for every residue of the region
-      const Item &im = items[item_at]; const RegionRes &rr = regres[im.region];
-      for (int pos = im.i; pos <= im.j; ++pos) n2sc[pos] = logf(rr.n2sum[pos - im.i] / (float)ENS_NSAMPLES);
-    }
-    for (size_t e = env_of_pass[q].first; e < env_of_pass[q].first + env_of_pass[q].second; ++e) {
-      ++nenv;
-      EnvRes &er = envres[e];
-      if (!er.ok) continue;
-      float null2[KP]; for (int x = 0; x < K; ++x) null2[x] = er.null2[x];
-      fill_null2(null2);
-      Domain d; memset(&d, 0, sizeof(d));
-      d.ienv = envreq[e].ienv; d.jenv = envreq[e].jenv; d.envsc = er.envsc; d.oasc = er.oasc;
-      d.hmm_from = er.hmm_from; d.hmm_to = er.hmm_to; d.ali_from = er.ali_from; d.ali_to = er.ali_to;
-      float ln2[KP + 1];
-      for (int x = 0; x < KP; ++x) ln2[x] = logf(null2[x]);          // same value the per-position logf would give
-      ln2[KP] = 0.f;
-      float dc = 0.f;
-      if (env_region[e] >= 0) { for (int pos = d.ienv; pos <= d.jenv; ++pos) dc += n2sc[pos]; }
-      else for (int pos = d.ienv; pos <= d.jenv; ++pos) { const float v = ln2[dsq[pos - 1]]; n2sc[pos] = v; dc += v; }
-      d.domcorrection = dc;
-      h.dom.push_back(d);
-    }
-    if (nregions[q] == 0 || nenv == 0 || h.dom.empty()) continue;
-    float seqbias = 0.f;
-    for (int i = 0; i <= L; ++i) seqbias += n2sc[i];
-    seqbias = flogsum(0.0f, logf(kOmega) + seqbias);
-    float pre_score = (float)((double)(c.fwdsc - nullsc) / kLn2);
-    float seq_score = (float)((double)(c.fwdsc - (nullsc + seqbias)) / kLn2);
-    float sum_score = 0.f; int Ld = 0; seqbias = 0.f;
-    for (auto &d : h.dom) if (d.envsc - d.domcorrection > 0.0f) { sum_score += d.envsc; Ld += d.jenv - d.ienv + 1; seqbias += d.domcorrection; }
-    seqbias = flogsum(0.0f, logf(kOmega) + seqbias);
-    sum_score += (float)((double)(L - Ld) * log((double)((float)L / (float)(L + 3))));
-    const float pre2 = (float)((double)(sum_score - nullsc) / kLn2);
-    sum_score = (float)((double)(sum_score - (nullsc + seqbias)) / kLn2);
-    if (Ld > 0 && sum_score > seq_score) { seq_score = sum_score; pre_score = pre2; }
-    h.pre_score = pre_score; h.score = seq_score;
-    h.lnP = exp_logsurv(seq_score, hm.evparam[4], hm.evparam[5]);
-    for (auto &d : h.dom) {
-      const int ld = d.jenv - d.ienv + 1;
-      const float bs = d.envsc + (float)((double)(L - ld) * log((double)((float)L / (float)(L + 3))));
-      d.dombias = flogsum(0.0f, logf(kOmega) + d.domcorrection);
-      d.bitscore = (float)((double)(bs - (nullsc + d.dombias)) / kLn2);
-      d.lnP = exp_logsurv(d.bitscore, hm.evparam[4], hm.evparam[5]);
-      d.reported = false;
-    }
-    hit_of[q] = std::move(h); has_hit[q] = 1;
-  }
-  });
-  for (size_t q = 0; q < passers.size(); ++q) if (has_hit[q]) by_bin_model[{s->seq_bin[hit_of[q].seq], hit_of[q].model}].push_back(std::move(hit_of[q]));
+  DomStage ds;
+  ds.pass.resize(passers.size());
+  for (size_t q = 0; q < passers.size(); ++q) { const Cand &c = cands[fb_cand[passers[q]]]; ds.pass[q] = {c.r.model, c.r.seq, c.fwdsc}; }
+  ds.nregions = nregions;
+  for (const Item &im : items) ds.items.push_back({im.pass, im.i, im.j, im.region});
+  ds.regres = std::move(regres); ds.envreq = std::move(envreq); ds.env_region = std::move(env_region); ds.envres = std::move(envres);
+  ds.env_of_pass = std::move(env_of_pass);
+  assemble_hits(ctx, p, s, ds, by_bin_model);
   st.ms_host = now_ms() - t_host0;
   st.ms_total = now_ms() - t_start;
   CKM_TRACE_PT("cascade done");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The device-driven cascade of one lane (one worker = one length class of the sequences): every stage behind SSV is launched without
+// waiting for the one before it -- survivors travel through device-side queues (dev_types.h: CascadeDev), the kernels' epilogues take
+// the filter decisions conservatively, the region scan and the workspace allocation of the envelope stage run on the device -- and
+// the host synchronises ONCE, when the chain has drained, to take the decisions again exactly (libm) and assemble the rows.
+// A second, short round follows only for the envelopes that come out of the trace ensembles (clustered on the host).
+// Returns false when a table or the workspace was too small for this search: the caller then runs the lane through the
+// host-driven cascade (which batches by workspace) and the grown capacities serve the next call.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+template <class T> T *dev_table(DevBuf &b, size_t n) { b.ensure(std::max<size_t>(1, n) * sizeof(T)); return b.as<T>(); }
+template <class T> T *pin_table(PinnedBuf &b, size_t n) { b.ensure(std::max<size_t>(1, n) * sizeof(T)); return b.as<T>(); }
+
+constexpr int HD_MSV = 0, HD_VQ = 1, HD_VXQ = HD_VQ + NVC, HD_FQ = HD_VXQ + NVC, HD_BQ = HD_FQ + NFC, HD_EF = HD_BQ + NFC, HD_EB = HD_EF + NFC,
+              HD_EO = HD_EB + NFC, HD_RQ = HD_EO + NFC, HD_END = HD_RQ + NFC;
+static_assert(HD_END <= CC_SIZE, "head block too small");
+
+}  // namespace
+
+static bool cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles *p, const ckm_seqs *s, const SeqRange &rng,
+                        const std::vector<uint32_t> &my_models, const std::vector<std::vector<uint32_t>> &model_bins, HitMap &by_bin_model) {
+  HIPCHK(hipSetDevice(ctx->device));
+  const double t_start = now_ms();
+  ckm_search_stats &st = ctx->stats;
+  memset(&st, 0, sizeof(st));
+  const DevModel *dm = p->d_models.as<DevModel>();
+  const LenEntry *lt = s->d_lentab.as<LenEntry>();
+  const uint8_t *res = s->d_res.as<uint8_t>();
+  const uint64_t *off = s->d_off.as<uint64_t>();
+  const int32_t *dlen = s->d_len.as<int32_t>();
+  bool took_turn = false;
+  struct TurnGuard {
+    ckm_ctx *o; int t; bool *took;
+    ~TurnGuard() { if (*took) return; std::unique_lock<std::mutex> l(o->ssv_mutex); o->ssv_cv.wait(l, [&] { return o->ssv_turn == t; }); o->ssv_turn++; o->ssv_cv.notify_all(); }
+  } turn_guard{owner, my_turn, &took_turn};
+
+  // ---- the lane's pairs, SSV chunks (pair budget), register classes present ----
+  uint64_t pair_budget = (uint64_t)1 << 29;
+  if (const char *e = getenv("CKM_PAIR_BUDGET")) pair_budget = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+  struct MW { uint32_t model; uint64_t pair_base; uint64_t npairs; };
+  std::vector<std::vector<MW>> chunks; std::vector<uint64_t> chunk_pairs;
+  uint64_t total_pairs = 0;
+  bool vit_present[NVC] = {false}, fb_present[NFC] = {false};
+  {
+    std::vector<MW> cur; uint64_t np = 0;
+    for (uint32_t m1 : my_models) {
+      uint64_t n = 0;
+      for (uint32_t b : model_bins[m1]) n += rng.hi[b] - rng.lo[b];
+      if (n == 0) continue;
+      if (np + n > pair_budget && !cur.empty()) { chunks.push_back(cur); chunk_pairs.push_back(np); cur.clear(); np = 0; }
+      cur.push_back({m1, np, n}); np += n; total_pairs += n;
+      vit_present[p->dm[m1].vit_cls] = true; fb_present[p->dm[m1].fb_cls] = true;
+    }
+    if (!cur.empty()) { chunks.push_back(cur); chunk_pairs.push_back(np); }
+  }
+  if (total_pairs == 0) { st.ms_total = now_ms() - t_start; return true; }
+
+  // ---- capacities (grow-only per worker) and tables ----
+  Worker::CascadeCaps &cp = ctx->caps;
+  auto grow = [](uint32_t &v, uint64_t want) { if (v < want) v = (uint32_t)std::min<uint64_t>(want, 0xfffffff0ull); };
+  grow(cp.cand, std::max<uint64_t>(1 << 16, total_pairs / 12));
+  grow(cp.nores, std::max<uint64_t>(1 << 14, total_pairs / 48));
+  grow(cp.vq, cp.cand);
+  grow(cp.fwork, std::max<uint64_t>(1 << 14, total_pairs / 96));
+  grow(cp.pass, std::max<uint64_t>(1 << 13, total_pairs / 256));
+  grow(cp.ework, std::max<uint64_t>(1 << 13, total_pairs / 256));
+  grow(cp.rwork, std::max<uint64_t>(1 << 10, total_pairs / 4096));
+  grow(cp.reg, (uint64_t)cp.ework + cp.rwork);
+  grow(cp.events_f, std::max<uint64_t>(1 << 18, (uint64_t)cp.fwork * 16));
+  grow(cp.events_e, std::max<uint64_t>(1 << 16, (uint64_t)cp.ework * 16));
+  cp.hens = std::max<uint64_t>(cp.hens, (uint64_t)cp.rwork * (256 + ENS_NSAMPLES * 16 * 4 + 1024));
+  uint64_t maxchunk = 0; for (uint64_t c : chunk_pairs) maxchunk = std::max(maxchunk, c);
+  ctx->maxv.ensure(maxchunk * 2 + 64);
+  // the float workspace: an estimate from the pairs (special rows of ~0.3 % of them, matrices of ~0.06 %), within the lane's budget
+  {
+    const uint64_t est = (uint64_t)((double)total_pairs * 2600.0) + ((uint64_t)256 << 20);
+    const size_t want = (size_t)std::min<uint64_t>(std::max<uint64_t>(est, (uint64_t)1 << 30), (uint64_t)ctx->ws_budget);
+    if (ctx->ws.cap < want) ctx->ws.ensure(want);
+  }
+  const uint64_t ws_floats = ctx->ws.cap / 4;
+  uint32_t *d_cnt = dev_table<uint32_t>(ctx->c_cnt, 2 * CC_SIZE);
+  uint32_t *d_head = d_cnt + CC_SIZE;
+  unsigned long long *d_tops = dev_table<unsigned long long>(ctx->c_tops, 4);
+  CascadeDev cd; memset(&cd, 0, sizeof(cd));
+  cd.cand = dev_table<PairRec>(ctx->c_cand, cp.cand); cd.cap_cand = cp.cand;
+  PairRec *d_nores = dev_table<PairRec>(ctx->c_nores, cp.nores);
+  cd.bias_raw = dev_table<float>(ctx->c_bias, (size_t)cp.cand * 2);
+  cd.vit_fast = dev_table<float>(ctx->c_vfast, cp.cand); cd.vit_exact = dev_table<float>(ctx->c_vexact, cp.cand);
+  cd.vit_flag = dev_table<uint32_t>(ctx->c_vflag, cp.cand); cd.route = dev_table<uint8_t>(ctx->c_route, cp.cand);
+  cd.vq = dev_table<uint32_t>(ctx->c_vq, (size_t)NVC * cp.vq); cd.vxq = dev_table<uint32_t>(ctx->c_vxq, (size_t)NVC * cp.vq); cd.cap_vq = cp.vq;
+  cd.fq = dev_table<uint32_t>(ctx->c_fq, (size_t)NFC * cp.fwork); cd.bq = dev_table<uint32_t>(ctx->c_bq, (size_t)NFC * cp.fwork); cd.cap_fq = cp.fwork;
+  cd.eq = dev_table<uint32_t>(ctx->c_eq, (size_t)NFC * cp.ework); cd.cap_eq = cp.ework;
+  cd.rq = dev_table<uint32_t>(ctx->c_rq, (size_t)NFC * cp.rwork); cd.cap_rq = cp.rwork;
+  cd.cnt = d_cnt;
+  cd.fwork = dev_table<FbWork>(ctx->c_fwork, cp.fwork); cd.cap_fwork = cp.fwork;
+  cd.ework = dev_table<FbWork>(ctx->c_ework, cp.ework); cd.cap_ework = cp.ework;
+  cd.rwork = dev_table<FbWork>(ctx->c_rwork, cp.rwork); cd.ens = dev_table<EnsWork>(ctx->c_ens, cp.rwork); cd.cap_rwork = cp.rwork;
+  cd.ws_top = d_tops; cd.ws_cap = ws_floats;
+  cd.h_pass = pin_table<PassRec>(ctx->h_pass, cp.pass); cd.cap_pass = cp.pass;
+  cd.h_reg = pin_table<RegionRec>(ctx->h_reg, cp.reg); cd.cap_reg = cp.reg;
+  float *h_hens = pin_table<float>(ctx->h_hens, cp.hens);
+  cd.hens_top = d_tops + 1; cd.hens_cap = cp.hens;
+  cd.seq_len = dlen;
+  cd.margin_msv = 0.01f; cd.margin_vit = 0.01f; cd.margin_fwd = 0.05f;
+  FwdOut *d_fout_f = dev_table<FwdOut>(ctx->c_fout_f, cp.fwork), *d_fout_e = dev_table<FwdOut>(ctx->c_fout_e, cp.ework), *d_fout_r = dev_table<FwdOut>(ctx->c_fout_r, cp.rwork);
+  int32_t *d_rerr_e = dev_table<int32_t>(ctx->c_rerr_e, cp.ework);
+  ScaleEvent *d_events_r = dev_table<ScaleEvent>(ctx->c_events_r, 1 << 16);
+  EnvOut *h_envout = pin_table<EnvOut>(ctx->h_envout, cp.ework);
+  ScaleEvent *h_events_f = pin_table<ScaleEvent>(ctx->h_events_f, cp.events_f), *h_events_e = pin_table<ScaleEvent>(ctx->h_events_e, cp.events_e);
+  uint32_t *h_cnt = pin_table<uint32_t>(ctx->h_cnt, CC_SIZE);
+  ensure_ens_seeds(ctx);
+  float *ws = ctx->ws.as<float>();
+  hipStream_t ms = ctx->stream;
+  const int NS = side_streams();
+
+  // ---- SSV block tables (cached when the previous call on this worker had the same plan: lineage_wf scans the same bins twice, bench
+  // repeats steps).  A search of several chunks (more pairs than the budget) rebuilds the table per chunk and waits in between. ----
+  struct ChunkPlan { std::vector<std::pair<int, std::pair<size_t, size_t>>> groups; size_t nblocks = 0; };
+  auto plan_chunk = [&](size_t ci, ChunkPlan &cpn) {
+    const auto &mws = chunks[ci];
+    std::vector<uint64_t> key{p->uid, s->uid, pair_budget, (uint64_t)ci, rng.tag, 0xdeull};
+    for (auto &mw : mws) { key.push_back(0xffffffffull + mw.model); for (uint32_t b : model_bins[mw.model]) key.push_back(b); }
+    const bool single_chunk = chunks.size() == 1;
+    if (single_chunk && key == ctx->plan_key) {
+      cpn.groups = ctx->plan_groups; cpn.nblocks = ctx->plan_nblocks;
+      st.pairs_ssv += ctx->plan_pairs; st.residue_hmm += ctx->plan_residue_hmm; st.cells_ssv += ctx->plan_cells;
+      return;
+    }
+    std::map<int, std::vector<SsvBlockWork>> byQ;
+    uint64_t c_pairs = 0, c_res = 0, c_cells = 0;
+    for (auto &mw : mws) {
+      const int Q = p->prof[mw.model].ssvQ; const int threads = ssv_threads_for(Q); const uint32_t per_block = (uint32_t)threads / 64 * 4 * 4;
+      uint64_t pb = mw.pair_base;
+      for (uint32_t b : model_bins[mw.model]) {
+        const uint32_t o0 = rng.lo[b], n = rng.hi[b] - o0;
+        for (uint32_t a = 0; a < n; a += per_block) {
+          SsvBlockWork w; w.model = mw.model; w.list_start = o0 + a; w.count = std::min(per_block, n - a); w.pair_start = (uint32_t)(pb + a);
+          byQ[Q].push_back(w);
+        }
+        pb += n; c_res += rng.res[b]; c_cells += rng.res[b] * (uint64_t)p->prof[mw.model].M;
+      }
+      c_pairs += mw.npairs;
+    }
+    st.pairs_ssv += c_pairs; st.residue_hmm += c_res; st.cells_ssv += c_cells;
+    std::vector<SsvBlockWork> allw;
+    for (auto &kv : byQ) {
+      // longest blocks first inside a launch (a block's time is set by its first = longest sequence)
+      std::stable_sort(kv.second.begin(), kv.second.end(), [&](const SsvBlockWork &x, const SsvBlockWork &y) {
+        return s->len[s->order[x.list_start]] > s->len[s->order[y.list_start]]; });
+      cpn.groups.push_back({kv.first, {allw.size(), kv.second.size()}}); allw.insert(allw.end(), kv.second.begin(), kv.second.end());
+    }
+    cpn.nblocks = allw.size();
+    ctx->work.ensure(allw.size() * sizeof(SsvBlockWork));
+    HIPCHK(hipMemcpyAsync(ctx->work.p, allw.data(), allw.size() * sizeof(SsvBlockWork), hipMemcpyHostToDevice, ms));
+    HIPCHK(hipStreamSynchronize(ms));            // allw goes out of scope (pageable source); nothing of this search is queued on ms yet
+    if (single_chunk) { ctx->plan_key = key; ctx->plan_groups = cpn.groups; ctx->plan_nblocks = cpn.nblocks; ctx->plan_pairs = c_pairs; ctx->plan_residue_hmm = c_res; ctx->plan_cells = c_cells; }
+    else ctx->plan_key.clear();
+  };
+  ChunkPlan first_plan;
+  plan_chunk(0, first_plan);
+
+  // ---- SSV phase: wait for the turn (the lanes' SSV phases run one behind the other on the device: VALU-bound, nothing to gain side by
+  // side), chain the launches behind the previous lane's, pass the turn on as soon as everything is queued ----
+  {
+    std::unique_lock<std::mutex> lock(owner->ssv_mutex);
+    owner->ssv_cv.wait(lock, [&] { return owner->ssv_turn == my_turn; });
+  }
+  CKM_TRACE_PT("ssv turn taken");
+  HIPCHK(hipMemsetAsync(d_cnt, 0, 2 * CC_SIZE * sizeof(uint32_t), ms));
+  HIPCHK(hipMemsetAsync(d_tops, 0, 4 * sizeof(unsigned long long), ms));
+  if (owner->ssv_prev_done) HIPCHK(hipStreamWaitEvent(ms, owner->ssv_prev_done, 0));     // previous lane's SSV launches
+  HIPCHK(hipEventRecord(ctx->ev[0], ms));
+  const int NSS = std::min(4, NS);
+  for (size_t ci = 0; ci < chunks.size(); ++ci) {
+    ChunkPlan later;
+    if (ci > 0) { HIPCHK(hipStreamSynchronize(ms)); plan_chunk(ci, later); }      // (the previous chunk's launches read the table that is being replaced)
+    const ChunkPlan &cpn = ci == 0 ? first_plan : later;
+    // register classes round-robin over the side streams, heaviest first; the finish kernel follows on the main stream
+    HIPCHK(hipEventRecord(ctx->cev[0], ms));
+    for (int k = 0; k < NSS; ++k) HIPCHK(hipStreamWaitEvent(ctx->side[k], ctx->cev[0], 0));
+    int gi = 0;
+    for (auto it = cpn.groups.rbegin(); it != cpn.groups.rend(); ++it, ++gi) {
+      auto &g = *it;
+      if (launch_ssv(g.first, (int)g.second.second, ssv_threads_for(g.first), ctx->side[gi % NSS], ctx->work.as<SsvBlockWork>() + g.second.first, dm, res, off, dlen,
+                     s->d_order.as<uint32_t>(), ctx->maxv.as<uint16_t>()))
+        throw Error(CKM_ERANGE, "no SSV kernel instance for this model length");
+      st.ssv_launches++;
+    }
+    for (int k = 0; k < NSS; ++k) { HIPCHK(hipEventRecord(ctx->cls_ev[k], ctx->side[k])); HIPCHK(hipStreamWaitEvent(ms, ctx->cls_ev[k], 0)); }
+    FinishArgs fa{dm, lt, dlen, s->d_order.as<uint32_t>(), ctx->work.as<SsvBlockWork>(), ctx->maxv.as<uint16_t>(),
+                  cd.cand, d_cnt + CC_CAND, cp.cand, d_nores, d_cnt + CC_NORES, cp.nores};
+    launch_msv_finish(ms, fa, (uint32_t)cpn.nblocks);
+  }
+  HIPCHK(hipEventRecord(ctx->ev[1], ms));                    // ev[0]..ev[1] brackets the lane's SSV launches (+ the tiny finish kernels)
+  HIPCHK(hipEventRecord(ctx->cev[1], ms));
+  {
+    std::unique_lock<std::mutex> lock(owner->ssv_mutex);
+    owner->ssv_prev_done = ctx->cev[1];
+    took_turn = true; owner->ssv_turn++; owner->ssv_cv.notify_all();
+  }
+  HIPCHK(hipGetLastError());
+  CKM_TRACE_PT("ssv queued");
+
+  // ---- exact MSV of the pairs SSV could not decide, bias filter (+ F1/F2 decisions) ----
+  launch_msv_full(ms, 2048, WorkQueue{nullptr, d_cnt + CC_NORES, d_head + HD_MSV, cp.nores}, d_nores, dm, lt, res, off, dlen, nullptr, nullptr, p->maxMp, &cd);
+  launch_bias_filter(ms, 2048, cd, dm, lt, res, off);
+  // ---- Viterbi filter: per register class, fast kernel then exact kernel on one stream ----
+  HIPCHK(hipEventRecord(ctx->cev[2], ms));
+  for (int k = 0; k < NS; ++k) HIPCHK(hipStreamWaitEvent(ctx->side[k], ctx->cev[2], 0));
+  {
+    int gi = 0;
+    for (int c = NVC - 1; c >= 0; --c) if (vit_present[c]) {
+      hipStream_t sv = ctx->side[gi++ % NS];
+      if (launch_vit(kVitQH[c], 2048, sv, WorkQueue{cd.vq + (size_t)c * cp.vq, d_cnt + CC_VQ + c, d_head + HD_VQ + c, cp.vq}, cd.cand, dm, lt, res, off, dlen,
+                     nullptr, nullptr, nullptr, true, &cd) ||
+          launch_vit(kVitQH[c], 1024, sv, WorkQueue{cd.vxq + (size_t)c * cp.vq, d_cnt + CC_VXQ + c, d_head + HD_VXQ + c, cp.vq}, cd.cand, dm, lt, res, off, dlen,
+                     nullptr, nullptr, nullptr, false, &cd))
+        throw Error(CKM_ERANGE, "no Viterbi kernel instance for this model length");
+    }
+  }
+  for (int k = 0; k < NS; ++k) { HIPCHK(hipEventRecord(ctx->cls_ev[k], ctx->side[k])); HIPCHK(hipStreamWaitEvent(ms, ctx->cls_ev[k], 0)); }
+  // ---- per register class, one stream: Forward parser (F3) -> Backward parser -> regions -> envelope Forward / Backward / OA -> region Forward ----
+  HIPCHK(hipEventRecord(ctx->cev[3], ms));
+  for (int k = 0; k < NS; ++k) HIPCHK(hipStreamWaitEvent(ctx->side[k], ctx->cev[3], 0));
+  {
+    int gi = 0;
+    for (int c = NFC - 1; c >= 0; --c) if (fb_present[c]) {
+      hipStream_t sf = ctx->side[gi++ % NS];
+      const int Q = kFbQ[c];
+      const WorkQueue qf{cd.fq + (size_t)c * cp.fwork, d_cnt + CC_FQ + c, d_head + HD_FQ + c, cp.fwork};
+      const WorkQueue qb{cd.bq + (size_t)c * cp.fwork, d_cnt + CC_BQ + c, d_head + HD_BQ + c, cp.fwork};
+      const WorkQueue qef{cd.eq + (size_t)c * cp.ework, d_cnt + CC_EQ + c, d_head + HD_EF + c, cp.ework};
+      const WorkQueue qeb{qef.list, qef.count, d_head + HD_EB + c, cp.ework}, qeo{qef.list, qef.count, d_head + HD_EO + c, cp.ework};
+      const WorkQueue qr{cd.rq + (size_t)c * cp.rwork, d_cnt + CC_RQ + c, d_head + HD_RQ + c, cp.rwork};
+      int rc = 0;
+      rc |= launch_fwd(Q, 4096, sf, qf, cd.fwork, dm, lt, res, off, ws, d_fout_f, h_events_f, d_cnt + CC_EVENTS, cp.events_f, &cd);
+      rc |= launch_bwd(Q, 4096, sf, qb, cd.fwork, dm, lt, res, off, ws, d_fout_f, nullptr);
+      launch_regions(sf, 256, qb.list, qb.count, cp.fwork, cd.fwork, cd, dm, ws);
+      rc |= launch_fwd(Q, 4096, sf, qef, cd.ework, dm, lt, res, off, ws, d_fout_e, h_events_e, d_cnt + CC_EVENTS_E, cp.events_e, nullptr);
+      rc |= launch_bwd(Q, 4096, sf, qeb, cd.ework, dm, lt, res, off, ws, d_fout_e, d_rerr_e);
+      rc |= launch_oa(Q, 4096, sf, qeo, cd.ework, dm, ws, d_rerr_e, d_fout_e, h_envout);
+      rc |= launch_fwd(Q, 1024, sf, qr, cd.rwork, dm, lt, res, off, ws, d_fout_r, d_events_r, d_cnt + CC_EVENTS_R, 1 << 16, nullptr);
+      if (rc) throw Error(CKM_ERANGE, "no Forward/Backward kernel instance for this model length");
+    }
+  }
+  for (int k = 0; k < NS; ++k) { HIPCHK(hipEventRecord(ctx->cls_ev[k], ctx->side[k])); HIPCHK(hipStreamWaitEvent(ms, ctx->cls_ev[k], 0)); }
+  // ---- trace ensembles of the multi-domain regions, results exported to pinned memory; counters last ----
+  launch_ensemble(ms, cd.ens, d_cnt + CC_RWORK, cp.rwork, 128, p->maxMp, dm, lt, res, off, ws, ctx->ensseeds.as<uint32_t>(), h_hens);
+  HIPCHK(hipMemcpyAsync(h_cnt, d_cnt, CC_SIZE * sizeof(uint32_t), hipMemcpyDeviceToHost, ms));
+  HIPCHK(hipGetLastError());
+  CKM_TRACE_PT("chain queued");
+  HIPCHK(hipStreamSynchronize(ms));                           // ---- the one synchronisation of the lane ----
+  CKM_TRACE_PT("chain drained");
+  { float msv = 0.f; HIPCHK(hipEventElapsedTime(&msv, ctx->ev[0], ctx->ev[1])); st.ms_ssv = msv; }
+  const double t_host0 = now_ms();
+  st.ms_filters = t_host0 - t_start;          // (queueing + the whole device chain: the stages are no longer separable by host clocks)
+
+  // ---- did everything fit? ----
+  const uint32_t n_cand = h_cnt[CC_CAND], n_nores = h_cnt[CC_NORES], n_fwork = h_cnt[CC_FWORK], n_ework = h_cnt[CC_EWORK], n_rwork = h_cnt[CC_RWORK],
+                 n_pass = h_cnt[CC_PASS], n_reg = h_cnt[CC_REG], n_evf = h_cnt[CC_EVENTS], n_eve = h_cnt[CC_EVENTS_E], status = h_cnt[CC_STATUS];
+  bool fits = status == 0;
+  auto need = [&](uint32_t &cap, uint32_t n) { if (n > cap) { fits = false; cap = (uint32_t)std::min<uint64_t>((uint64_t)n + n / 4 + 1024, 0xfffffff0ull); } };
+  need(cp.cand, n_cand); need(cp.nores, n_nores); need(cp.fwork, n_fwork); need(cp.ework, n_ework); need(cp.rwork, n_rwork); need(cp.pass, n_pass);
+  need(cp.reg, n_reg); need(cp.events_f, n_evf); need(cp.events_e, n_eve);
+  for (int c = 0; c < NVC; ++c) { need(cp.vq, h_cnt[CC_VQ + c]); need(cp.vq, h_cnt[CC_VXQ + c]); }
+  if (status & CS_RWORK) cp.hens *= 2;
+  if (!fits) {
+    if (getenv("CKM_TRACE")) fprintf(stderr, "ckm-trace w%d device cascade did not fit (status 0x%x): host-driven cascade for this lane\n", ctx->id, status);
+    return false;
+  }
+  st.pairs_msv_full = n_nores; st.pairs_bias = n_cand; st.pairs_fwd = n_fwork; st.pairs_dom = n_pass; st.regions_multi = n_rwork;
+  for (int c = 0; c < NVC; ++c) { st.pairs_vit += h_cnt[CC_VQ + c]; st.pairs_vit_exact += h_cnt[CC_VXQ + c]; }
+
+  // ---- the filter decisions again, exactly (host libm), for the pairs the device let through ----
+  const PassRec *pass = cd.h_pass;
+  std::vector<ScaleEvent> evf(h_events_f, h_events_f + n_evf), eve(h_events_e, h_events_e + n_eve);
+  EventIndex fev; fev.build(evf, n_fwork);
+  EventIndex eev; eev.build(eve, n_ework);
+  std::vector<uint8_t> alive(n_pass, 0); std::vector<float> fwdsc(n_pass, 0.f);
+  std::atomic<int> inconsistent{0};
+  pool_run(ctx, n_pass, 256, [&](size_t lo, size_t hi) {
+    for (size_t k = lo; k < hi; ++k) {
+      const PassRec &r = pass[k];
+      const HostProfile &hp = p->prof[r.model];
+      const int L = s->len[r.seq];
+      const LenEntry &le = s->lentab[L];
+      const float p1 = (float)L / (float)(L + 1);
+      const float nullb = (float)(log((double)r.bias_d) + (double)r.bias_e * kLn2);
+      const float filtersc = nullb + (float)L * logf(p1) + logf(1.0f - p1);
+      const float sc = bits(r.usc, filtersc);
+      if (!(sc >= hp.thr_msv_f1)) continue;
+      if (!(sc >= hp.thr_msv_f2)) {                    // the Viterbi filter applies
+        const uint32_t route = r.route & 0x0fu;
+        if (route == 0) { inconsistent++; continue; }   // the device skipped it with a margin the exact test contradicts: cannot happen
+        if (route == 1) {
+          if (!(bits(r.vit_fast, filtersc) >= hp.thr_vit_f2)) { if (r.vit_flag) inconsistent++; continue; }   // (a bound that fails with its flag set would have been re-run)
+        } else if (!(bits(r.vit_exact, filtersc) >= hp.thr_vit_f2)) continue;
+      }
+      const float f = finish_forward(r.fwd_xC, le.move_m, fev.scales(r.fwork));
+      if (!(bits(f, filtersc) >= hp.thr_fwd_f3)) continue;
+      alive[k] = 1; fwdsc[k] = f;
+    }
+  });
+  if (inconsistent.load()) throw Error(CKM_EHIP, "device-side filter decision contradicts the exact one (margin too small): please report");
+
+  // ---- regions by pair, in sequence order; envelopes of single-domain regions are already rescored, ensembles get clustered ----
+  std::vector<uint32_t> rorder(n_reg);
+  std::iota(rorder.begin(), rorder.end(), 0u);
+  const RegionRec *reg = cd.h_reg;
+  std::sort(rorder.begin(), rorder.end(), [&](uint32_t a, uint32_t b) { return reg[a].pass != reg[b].pass ? reg[a].pass < reg[b].pass : reg[a].i < reg[b].i; });
+  DomStage ds;
+  std::vector<int32_t> dsidx(n_pass, -1);
+  for (uint32_t k = 0; k < n_pass; ++k) if (alive[k]) { dsidx[k] = (int32_t)ds.pass.size(); ds.pass.push_back({pass[k].model, pass[k].seq, fwdsc[k]}); }
+  ds.nregions.assign(ds.pass.size(), 0);
+  ds.env_of_pass.assign(ds.pass.size(), {0, 0});
+  std::vector<RegionReq> redo_req; std::vector<size_t> redo_at;          // ensembles that need more segment slots: host-driven repeat
+  std::vector<int32_t> env_src;                                         // per envelope: index into h_envout, or -1 = to be rescored (ensemble envelope)
+  std::vector<std::pair<uint32_t, uint32_t>> ens_list;                  // (region record, regres index)
+  for (uint32_t ro : rorder) {
+    const RegionRec &rr = reg[ro];
+    if (rr.pass >= n_pass || dsidx[rr.pass] < 0) continue;
+    const uint32_t q = (uint32_t)dsidx[rr.pass];
+    if (rr.target == 0xffffffffu) return false;                        // no workspace for it on the device (status would have said so)
+    ds.nregions[q]++;
+    if (!rr.multi) ds.items.push_back({q, rr.i, rr.j, -1});
+    else { ds.items.push_back({q, rr.i, rr.j, (int)ds.regres.size()}); ens_list.push_back({ro, (uint32_t)ds.regres.size()}); ds.regres.emplace_back(); }
+  }
+  // ensemble results from the pinned export; clustering on the host threads
+  for (auto &er : ens_list) {
+    const RegionRec &rr = reg[er.first]; RegionRes &o = ds.regres[er.second];
+    const int Ld = rr.j - rr.i + 1, cap = std::min(Ld, 16);
+    if (rr.pad == 0xffffffffu) return false;
+    const float *raw = h_hens + rr.pad;
+    const int32_t *ns = reinterpret_cast<const int32_t *>(raw);
+    const int32_t *sg = reinterpret_cast<const int32_t *>(raw + 256);
+    bool overflow = false;
+    for (int t = 0; t < ENS_NSAMPLES; ++t) overflow |= ns[t] < 0;
+    if (overflow) { redo_req.push_back({pass[rr.pass].model, pass[rr.pass].seq, rr.i, rr.j}); redo_at.push_back(er.second); continue; }
+    o.cap = cap; o.nseg.assign(ns, ns + ENS_NSAMPLES); o.segs.assign((size_t)ENS_NSAMPLES * cap, Seg{0, 0, 0, 0});
+    for (int t = 0; t < ENS_NSAMPLES; ++t)
+      for (int d = 0; d < ns[t]; ++d) {                                 // the device walks backwards: last domain first
+        const int32_t *q4 = sg + ((size_t)t * cap + (ns[t] - 1 - d)) * 4;
+        o.segs[(size_t)t * cap + d] = Seg{q4[0], q4[1], q4[2], q4[3]};
+      }
+    const float *n2 = raw + 256 + (size_t)ENS_NSAMPLES * cap * 4;
+    o.n2sum.assign(n2, n2 + Ld);
+  }
+  pool_run(ctx, ds.regres.size(), 1, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) if (!ds.regres[k].nseg.empty()) cluster_ensemble(ds.regres[k]); });
+  if (!redo_req.empty()) {
+    std::vector<RegionRes> r2;
+    run_ensembles(ctx, p, s, redo_req, r2);
+    for (size_t k = 0; k < redo_at.size(); ++k) ds.regres[redo_at[k]] = std::move(r2[k]);
+  }
+  CKM_TRACE_PT("decisions + clustering done");
+  // envelopes in pair order (as the host-driven cascade lists them)
+  {
+    size_t it = 0, ri = 0;
+    // region records of alive pairs, in the order of ds.items
+    std::vector<uint32_t> item_rec;
+    for (uint32_t ro : rorder) { const RegionRec &rr = reg[ro]; if (rr.pass < n_pass && dsidx[rr.pass] >= 0) item_rec.push_back(ro); }
+    for (size_t q = 0; q < ds.pass.size(); ++q) {
+      ds.env_of_pass[q].first = ds.envreq.size();
+      for (; it < ds.items.size() && ds.items[it].pass == q; ++it, ++ri) {
+        const DomItem &im = ds.items[it];
+        const RegionRec &rr = reg[item_rec[ri]];
+        if (im.region < 0) { ds.envreq.push_back({ds.pass[q].model, ds.pass[q].seq, im.i, im.j}); ds.env_region.push_back(-1); env_src.push_back((int32_t)rr.target); continue; }
+        for (const Seg &e : ds.regres[im.region].env) {
+          const int i2 = e.sqfrom + im.i - 1, j2 = e.sqto + im.i - 1;
+          ds.envreq.push_back({ds.pass[q].model, ds.pass[q].seq, i2, j2}); ds.env_region.push_back(im.region); env_src.push_back(-1);
+        }
+      }
+      ds.env_of_pass[q].second = ds.envreq.size() - ds.env_of_pass[q].first;
+    }
+  }
+  ds.envres.resize(ds.envreq.size());
+  {
+    std::vector<EnvReq> second; std::vector<size_t> second_at;
+    for (size_t e = 0; e < ds.envreq.size(); ++e) {
+      if (env_src[e] < 0) { second.push_back(ds.envreq[e]); second_at.push_back(e); continue; }
+      const EnvOut &eo = h_envout[env_src[e]];
+      EnvRes &o = ds.envres[e];
+      const LenEntry &le = s->lentab[s->len[ds.envreq[e].seq]];
+      o.ok = eo.range_err == 0;
+      o.xC = eo.xC; o.nscale = eo.nscale;
+      o.envsc = finish_forward(eo.xC, le.move_u, eev.scales((uint32_t)env_src[e]));
+      o.oasc = eo.oasc; o.hmm_from = eo.hmm_from; o.hmm_to = eo.hmm_to; o.ali_from = eo.ali_from; o.ali_to = eo.ali_to;
+      for (int x = 0; x < K; ++x) o.null2[x] = eo.null2[x];
+    }
+    if (!second.empty()) {                                             // the short second round: envelopes that came out of the ensembles
+      std::vector<EnvRes> r2;
+      rescore_envelopes(ctx, p, s, second, r2);
+      for (size_t k = 0; k < second.size(); ++k) ds.envres[second_at[k]] = r2[k];
+    }
+  }
+  st.envelopes = ds.envreq.size();
+  st.ms_domains = now_ms() - t_host0;
+  CKM_TRACE_PT("envelopes done");
+  const double t_rows0 = now_ms();
+  assemble_hits(ctx, p, s, ds, by_bin_model);
+  st.ms_host = now_ms() - t_rows0;
+  st.ms_total = now_ms() - t_start;
+  CKM_TRACE_PT("cascade done");
+  return true;
 }
 
 static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, const uint32_t *model_off, const uint32_t *model_idx,
@@ -523,7 +952,21 @@ static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, cons
   std::vector<HitMap> maps(nw); std::vector<std::exception_ptr> errs(nw);
   c->ssv_turn = 0;
   trace_begin();
-  auto run = [&](int k) { try { cascade(&c->w[k], c, k, p, s, ranges[k], chunk[k], model_bins, maps[k]); } catch (...) { errs[k] = std::current_exception(); } };
+  // CKM_CASCADE=host keeps the host-driven cascade (a device phase, a copy and a host decision per stage) for comparison and as the
+  // fallback of a lane whose tables or workspace the device-driven one outgrew
+  const char *cascade_env = getenv("CKM_CASCADE");
+  const bool host_cascade = cascade_env && !strcmp(cascade_env, "host");
+  c->ssv_prev_done = nullptr;
+  c->fallbacks = 0;
+  auto run = [&](int k) {
+    try {
+      if (host_cascade) cascade(&c->w[k], c, k, p, s, ranges[k], chunk[k], model_bins, maps[k]);
+      else if (!cascade_dev(&c->w[k], c, k, p, s, ranges[k], chunk[k], model_bins, maps[k])) {
+        c->fallbacks++;
+        cascade(&c->w[k], c, k, p, s, ranges[k], chunk[k], model_bins, maps[k], true);
+      }
+    } catch (...) { errs[k] = std::current_exception(); }
+  };
   std::vector<std::thread> threads;
   for (int k = 1; k < nw; ++k) threads.emplace_back(run, k);
   run(0);
@@ -537,10 +980,11 @@ static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, cons
     const ckm_search_stats &w = c->w[k].stats;
     st.pairs_ssv += w.pairs_ssv; st.pairs_msv_full += w.pairs_msv_full; st.pairs_bias += w.pairs_bias; st.pairs_vit += w.pairs_vit; st.pairs_vit_exact += w.pairs_vit_exact; st.pairs_fwd += w.pairs_fwd;
     st.pairs_dom += w.pairs_dom; st.envelopes += w.envelopes; st.regions_multi += w.regions_multi; st.cells_ssv += w.cells_ssv; st.residue_hmm += w.residue_hmm; st.ssv_launches += w.ssv_launches;
-    st.ms_ssv += w.ms_ssv;                                   // SSV phases are serialised by the mutex: the sum is the kernel time
+    st.ms_ssv += w.ms_ssv;                                   // the lanes' SSV phases run one behind the other: the sum is the kernel time
     st.ms_filters = std::max(st.ms_filters, w.ms_filters); st.ms_fwdbwd = std::max(st.ms_fwdbwd, w.ms_fwdbwd);
     st.ms_domains = std::max(st.ms_domains, w.ms_domains); st.ms_host = std::max(st.ms_host, w.ms_host);
   }
+  st.cascade_fallback_lanes = (uint32_t)c->fallbacks.load();
   const double t_host0 = now_ms();
   // rows, bin by bin, models in the bin's own order
   hits->nbins = nbins;

@@ -50,37 +50,37 @@ int ssv_threads_for(int Q) {
   return 1024;
 }
 
+// Work-groups a launch of the persistent Forward/Backward kernels starts for n queued items: one wavefront each, at most what the
+// device holds at once (256 CUs x a few wavefronts per SIMD); every wavefront keeps taking items until the queue is empty.
+uint32_t fb_grid(size_t n) { return (uint32_t)std::min<size_t>(n, 8192); }
+
 void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, bool do_fwd, bool do_bwd, bool do_oa,
             const std::vector<uint32_t> *subset /* indices into b.work, or null = all */, float *ws_other) {
   const size_t n = b.work.size();
   if (!n) return;
   trace_pt(ctx, "  fb begin");
   ctx->fbwork.ensure(n * sizeof(FbWork));
-  wcopy(ctx, ctx->fbwork.p, b.work.data(), n * sizeof(FbWork), hipMemcpyHostToDevice);
-  // group by canonical Q; inside a group, blocks of 4 wavefronts take 4 items of ONE model (shared LDS table)
-  std::map<int, std::map<uint32_t, std::vector<uint32_t>>> byQ;
-  auto add = [&](uint32_t i) { byQ[p->prof[b.work[i].model].fbQ][b.work[i].model].push_back(i); };
+  HIPCHK(hipMemcpyAsync(ctx->fbwork.p, b.work.data(), n * sizeof(FbWork), hipMemcpyHostToDevice, ctx->stream));
+  // one queue per canonical Q (register class), longest items first; a wavefront reloads its LDS image when the model changes
+  std::map<int, std::vector<uint32_t>> byQ;
+  auto add = [&](uint32_t i) { byQ[p->prof[b.work[i].model].fbQ].push_back(i); };
   if (subset) for (uint32_t i : *subset) add(i); else for (uint32_t i = 0; i < n; ++i) add(i);
-  struct Group { int Q; size_t blk0, nblk; };
-  std::vector<uint32_t> items, blk_model; std::vector<Group> groups;
+  struct Group { int Q; size_t first, count; };
+  std::vector<uint32_t> items; std::vector<Group> groups;
   for (auto it = byQ.rbegin(); it != byQ.rend(); ++it) {      // heaviest register class first: its chain is the longest
-    auto &kq = *it;
-    Group g{kq.first, blk_model.size(), 0};
-    // longest items first inside a model so the four wavefronts of a block finish together
-    for (auto &km : kq.second) {
-      std::vector<uint32_t> &v = km.second;
-      std::stable_sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return b.work[x].Ld > b.work[y].Ld; });
-      for (size_t i = 0; i < v.size(); i += 4) {
-        for (size_t j = 0; j < 4; ++j) items.push_back(i + j < v.size() ? v[i + j] : 0xffffffffu);
-        blk_model.push_back(km.first);
-      }
-    }
-    g.nblk = blk_model.size() - g.blk0;
-    groups.push_back(g);
+    std::vector<uint32_t> &v = it->second;
+    std::stable_sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) {
+      if (b.work[x].Ld != b.work[y].Ld) return b.work[x].Ld > b.work[y].Ld;
+      return b.work[x].model < b.work[y].model; });
+    groups.push_back({it->first, items.size(), v.size()});
+    items.insert(items.end(), v.begin(), v.end());
   }
-  ctx->fbidx.ensure(items.size() * 4); ctx->fbmodel.ensure(blk_model.size() * 4);
-  wcopy(ctx, ctx->fbidx.p, items.data(), items.size() * 4, hipMemcpyHostToDevice);
-  wcopy(ctx, ctx->fbmodel.p, blk_model.data(), blk_model.size() * 4, hipMemcpyHostToDevice);
+  // queue control block per group and stage: [count, head_fwd, head_bwd, head_oa]
+  std::vector<uint32_t> qc(groups.size() * 4, 0u);
+  for (size_t g = 0; g < groups.size(); ++g) qc[g * 4] = (uint32_t)groups[g].count;
+  ctx->fbidx.ensure(items.size() * 4 + 16); ctx->fbmodel.ensure(qc.size() * 4 + 16);
+  HIPCHK(hipMemcpyAsync(ctx->fbidx.p, items.data(), items.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->fbmodel.p, qc.data(), qc.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   ctx->fout.ensure(n * sizeof(FwdOut));
   ctx->rerr.ensure(n * 4);
   ctx->envout.ensure(n * sizeof(EnvOut));
@@ -97,15 +97,18 @@ void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, b
   trace_pt(ctx, "  fb tables uploaded");
   // every register class runs its stages in order on its own stream; classes overlap each other
   size_t gi = 0;
-  for (auto &g : groups) {
+  for (size_t g = 0; g < groups.size(); ++g) {
+    const Group &gr = groups[g];
     hipStream_t st = ctx->side[gi++ % side_streams()];
-    const uint32_t *ix = ctx->fbidx.as<uint32_t>() + g.blk0 * 4, *bm = ctx->fbmodel.as<uint32_t>() + g.blk0;
-    if (do_fwd && launch_fwd(g.Q, (uint32_t)g.nblk, st, ctx->fbwork.as<FbWork>(), ix, bm, dm, lt, res, off, ws, ctx->fout.as<FwdOut>(),
-                             ctx->events.as<ScaleEvent>(), ctx->counters.as<uint32_t>(), cap_events))
+    uint32_t *qcd = ctx->fbmodel.as<uint32_t>() + g * 4;
+    const uint32_t *lst = ctx->fbidx.as<uint32_t>() + gr.first;
+    const uint32_t nb = fb_grid(gr.count);
+    if (do_fwd && launch_fwd(gr.Q, nb, st, WorkQueue{lst, qcd, qcd + 1, (uint32_t)gr.count}, ctx->fbwork.as<FbWork>(), dm, lt, res, off, ws, ctx->fout.as<FwdOut>(),
+                             ctx->events.as<ScaleEvent>(), ctx->counters.as<uint32_t>(), cap_events, nullptr))
       throw Error(CKM_ERANGE, "no Forward kernel instance for this model length");
-    if (do_bwd && launch_bwd(g.Q, (uint32_t)g.nblk, st, ctx->fbwork.as<FbWork>(), ix, bm, dm, lt, res, off, ws, ctx->fout.as<FwdOut>(), ctx->rerr.as<int32_t>()))
+    if (do_bwd && launch_bwd(gr.Q, nb, st, WorkQueue{lst, qcd, qcd + 2, (uint32_t)gr.count}, ctx->fbwork.as<FbWork>(), dm, lt, res, off, ws, ctx->fout.as<FwdOut>(), ctx->rerr.as<int32_t>()))
       throw Error(CKM_ERANGE, "no Backward kernel instance for this model length");
-    if (do_oa && launch_oa(g.Q, (uint32_t)g.nblk, st, ctx->fbwork.as<FbWork>(), ix, bm, dm, ws, ctx->rerr.as<int32_t>(), ctx->envout.as<EnvOut>()))
+    if (do_oa && launch_oa(gr.Q, nb, st, WorkQueue{lst, qcd, qcd + 3, (uint32_t)gr.count}, ctx->fbwork.as<FbWork>(), dm, ws, ctx->rerr.as<int32_t>(), ctx->fout.as<FwdOut>(), ctx->envout.as<EnvOut>()))
       throw Error(CKM_ERANGE, "no OA kernel instance for this model length");
   }
   HIPCHK(hipGetLastError());
@@ -324,7 +327,7 @@ void ens_queue_batch(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, EnsJ
   for (size_t j = range.first; j < range.second; ++j) {
     const RegionReq &r = job.req[j];
     const int Ld = r.jreg - r.ireg + 1, cap = job.cap[j];
-    EnsWork e; memset(&e, 0, sizeof(e));
+    EnsWork e; memset(&e, 0, sizeof(e)); e.host_off = ~0ull;
     e.model = r.model; e.seq = r.seq; e.i0 = r.ireg - 1; e.Ld = Ld; e.Lcfg = s->len[r.seq]; e.cap = cap;
     e.nseg_off = pos; pos += 256;
     e.seg_off = pos;  pos += (uint64_t)ENS_NSAMPLES * cap * 4;
@@ -349,22 +352,31 @@ void ens_queue_batch(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, EnsJ
   run_fb(ctx, p, s, b, true, false, false, nullptr, ctx->ws_ens.as<float>());   // multihit Forward of every region, M, I and D rows kept
   ctx->enswork.ensure(job.ew.size() * sizeof(EnsWork));
   HIPCHK(hipMemcpyAsync(ctx->enswork.p, job.ew.data(), job.ew.size() * sizeof(EnsWork), hipMemcpyHostToDevice, ctx->ens_stream));
-  launch_ensemble(ctx->ens_stream, ctx->enswork.as<EnsWork>(), (uint32_t)job.ew.size(), maxLd, maxMp, p->d_models.as<DevModel>(), s->d_lentab.as<LenEntry>(),
-                  s->d_res.as<uint8_t>(), s->d_off.as<uint64_t>(), ctx->ws_ens.as<float>(), ctx->ensseeds.as<uint32_t>());
+  {
+    const uint32_t nreg = (uint32_t)job.ew.size();
+    ctx->enscount.ensure(16);
+    HIPCHK(hipMemcpyAsync(ctx->enscount.p, &nreg, 4, hipMemcpyHostToDevice, ctx->ens_stream));
+    (void)maxLd;
+    launch_ensemble(ctx->ens_stream, ctx->enswork.as<EnsWork>(), ctx->enscount.as<uint32_t>(), nreg, std::min<uint32_t>(nreg, 256), maxMp, p->d_models.as<DevModel>(),
+                    s->d_lentab.as<LenEntry>(), s->d_res.as<uint8_t>(), s->d_off.as<uint64_t>(), ctx->ws_ens.as<float>(), ctx->ensseeds.as<uint32_t>(), nullptr);
+  }
   HIPCHK(hipGetLastError());
   ctx->h_ens.ensure(job.res_floats * 4);
   HIPCHK(hipMemcpyAsync(ctx->h_ens.p, ctx->ws_ens.p, job.res_floats * 4, hipMemcpyDeviceToHost, ctx->ens_stream));
   job.in_flight = true;
 }
 
+void ensure_ens_seeds(Worker *ctx) {
+  if (ctx->ensseeds.p) return;
+  std::vector<uint32_t> seeds(ENS_NSAMPLES);
+  for (int t = 0; t < ENS_NSAMPLES; ++t) seeds[t] = ens_seed(t);
+  ctx->ensseeds.ensure(seeds.size() * 4);
+  wcopy(ctx, ctx->ensseeds.p, seeds.data(), seeds.size() * 4, hipMemcpyHostToDevice);
+}
+
 void ens_begin(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, EnsJob &job) {
   if (job.req.empty()) return;
-  if (!ctx->ensseeds.p) {
-    std::vector<uint32_t> seeds(ENS_NSAMPLES);
-    for (int t = 0; t < ENS_NSAMPLES; ++t) seeds[t] = ens_seed(t);
-    ctx->ensseeds.ensure(seeds.size() * 4);
-    wcopy(ctx, ctx->ensseeds.p, seeds.data(), seeds.size() * 4, hipMemcpyHostToDevice);
-  }
+  ensure_ens_seeds(ctx);
   auto al = [](uint64_t v) { return (v + 31) & ~(uint64_t)31; };
   const uint64_t budget_floats = ctx->ws_budget / 4;
   job.batches.clear(); job.next_batch = 0;

@@ -6,6 +6,7 @@ namespace ckm {
 
 struct DevModel {
   int32_t M, ssvQ, fbQ, vitQH;
+  int32_t fb_cls, vit_cls;  // index of fbQ / vitQH among the instantiated register classes (queues of the device-driven cascade)
   // MSV
   int32_t base_b, bias_b, tbm_b, tec_b;
   float   scale_b;
@@ -68,7 +69,12 @@ struct FbWork {              // one Forward/Backward/OA work item (whole sequenc
   uint64_t path_off;                   // int32 offset + 1 of Mp entries: residue (1-based, within the envelope) emitted by each match state of the
                                        // OA path, 0 = node not matched (alignment requests); 0 = no path wanted
   uint32_t slot, full;                 // full: 0 parser (specials only), 1 matrix rows M,I, 2 matrix rows M,I,D (trace ensemble)
+  uint32_t cand, pass;                 // device-driven cascade: candidate id of a parser item; id of its record in the pass table
 };
+
+// A queue of work-item indices consumed by a persistent kernel: wavefronts take entries with atomicAdd(head) until *count.
+// Host-built queues (alignment requests, diagnostics, second envelope rounds) and device-built ones (the cascade) look alike.
+struct WorkQueue { const uint32_t *list; const uint32_t *count; uint32_t *head; uint32_t cap; };
 
 constexpr int ENS_NSAMPLES = 200;     // stochastic tracebacks per multi-domain region (HMMER's default)
 
@@ -80,6 +86,7 @@ struct EnsWork {             // one multi-domain region handed to the trace-ense
   uint64_t ratio_off;                  // float  [200][Ld+1] null2 odds ratio per residue and trace
   uint64_t seg_off, nseg_off;          // int32  [200][cap][4] sampled segments (last domain first), int32 [200] counts (-1 = overflow)
   uint64_t n2_off;                     // float  [Ld] sum of the ratios over traces
+  uint64_t host_off;                   // device-driven cascade: float offset of this region's exported results (counts, segments, sums) in the pinned result buffer
 };
 
 struct FinishArgs {
@@ -88,6 +95,55 @@ struct FinishArgs {
   const uint16_t *maxv;                // Smax per pair (0 = degenerate: recompute exactly)
   PairRec *survivors; uint32_t *nsurv; uint32_t cap_surv;
   PairRec *noresult;  uint32_t *nnores; uint32_t cap_nores;
+};
+
+// ---- device-driven cascade (ckm_cascade.hip, kernels_*.hip epilogues) ---------------------------------------------------------
+constexpr int NVC = 12;               // Viterbi-filter register classes  QH in {1,2,3,4,5,6,7,8,10,12,14,16}
+constexpr int NFC = 10;               // Forward/Backward register classes Q in {1,2,3,4,6,8,12,16,24,32}
+
+enum CascadeCounter : int {           // uint32 counters in device memory (count and head arrays share this layout)
+  CC_CAND = 0, CC_NORES, CC_FWORK, CC_EWORK, CC_RWORK, CC_PASS, CC_REG, CC_EVENTS, CC_STATUS, CC_EVENTS_E, CC_EVENTS_R,
+  CC_VQ = 16, CC_VXQ = CC_VQ + NVC, CC_FQ = CC_VXQ + NVC, CC_BQ = CC_FQ + NFC, CC_EQ = CC_BQ + NFC, CC_RQ = CC_EQ + NFC, CC_END = CC_RQ + NFC
+};
+constexpr int CC_SIZE = 128;
+static_assert(CC_END <= CC_SIZE, "counter block too small");
+
+enum CascadeStatus : uint32_t {       // bits of counter CC_STATUS: a table was too small for this search (the host retries with larger ones)
+  CS_CAND = 1, CS_VQ = 2, CS_FWORK = 4, CS_EWORK = 8, CS_RWORK = 16, CS_PASS = 32, CS_REG = 64, CS_EVENTS = 128,
+  CS_WS = 256                         // the float workspace ran out: the host runs this part of the search in workspace-sized batches instead
+};
+
+struct PassRec {                      // one pair the device let through F3 (pinned host memory): everything the host needs to take the
+  uint32_t cand, fwork, model, seq;   // filter decisions again EXACTLY (libm logarithms) and to assemble the rows
+  float    usc, bias_d, bias_e;       // MSV score; bias filter: d0+d1 and its power-of-two exponent
+  float    vit_fast, vit_exact;       // Viterbi filter scores (nats); vit_exact only when route == 2
+  uint32_t vit_flag, route;           // route: 0 Viterbi skipped (MSV P <= F2), 1 fast kernel only, 2 exact kernel ran
+  float    fwd_xC; int32_t nscale;
+};
+
+struct RegionRec {                    // one region found by the posterior heuristics (pinned host memory)
+  uint32_t pass; int32_t i, j;        // residues i..j of the target (1-based)
+  int32_t  multi;                     // 0: one envelope (target = envelope item), 1: trace ensemble (target = region item)
+  uint32_t target;                    // index into the envelope / region work tables, or 0xffffffff: no table entry / workspace left
+  uint32_t pad;                       // multi: float offset of the region's exported ensemble results in the pinned buffer (0xffffffff: none)
+};
+
+struct CascadeDev {                   // by-value kernel argument: where the epilogues of the filter / Forward / Backward kernels put their output
+  PairRec *cand; uint32_t cap_cand;
+  float *bias_raw;                    // [cap_cand][2]
+  float *vit_fast, *vit_exact; uint32_t *vit_flag; uint8_t *route;      // [cap_cand]
+  uint32_t *vq, *vxq; uint32_t cap_vq;                                  // [NVC][cap_vq] candidate ids
+  uint32_t *fq, *bq, *eq, *rq; uint32_t cap_fq, cap_eq, cap_rq;         // [NFC][cap] work-item indices (bq shares cap_fq)
+  uint32_t *cnt;                                                        // [CC_SIZE]
+  FbWork *fwork; uint32_t cap_fwork;
+  FbWork *ework; uint32_t cap_ework;
+  FbWork *rwork; EnsWork *ens; uint32_t cap_rwork;
+  unsigned long long *ws_top; unsigned long long ws_cap;                // bump allocator over the float workspace (units: floats)
+  PassRec *h_pass; uint32_t cap_pass;
+  RegionRec *h_reg; uint32_t cap_reg;
+  unsigned long long *hens_top; unsigned long long hens_cap;            // bump allocator over the pinned buffer the ensemble results are exported to (floats)
+  const int32_t *seq_len;
+  float margin_msv, margin_vit, margin_fwd;                             // bits: widths of the conservative bands around F1/F2/F3
 };
 
 struct EnvOut {

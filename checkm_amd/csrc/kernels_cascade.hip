@@ -1,0 +1,124 @@
+// kernels_cascade.hip -- the posterior domain heuristics of the device-driven cascade, gfx950 only.
+// Replaces, inside the hmmsearch process launched at checkm/hmmer.py:70, the region scan of HMMER's domain definition
+// ("p7_domaindef_ByPosteriorHeuristics": rt1 0.25 / rt2 0.10 / rt3 0.20 on the begin/end/occupancy posteriors) and the hand-over
+// to envelope rescoring, which the host used to do between two device phases.  One thread per pair that passed the Forward
+// filter: it turns the three decoding terms per residue the Backward parser left in the workspace into the running sums
+// btot/etot (in place: the float prefix sums are part of the decision, so they are formed once, in residue order, exactly as the
+// CPU restatement forms them), finds the regions, and for every region allocates the workspace of what comes next --
+//   one envelope (FbWork, full = 1)             -> envelope queue of the model's register class
+//   a multi-domain region (FbWork full = 2 + EnsWork) -> region queue: multihit Forward with M, I, D rows, then the trace ensemble
+// and leaves a RegionRec for the host in pinned memory.  Float compares only: no transcendental.
+#include <hip/hip_runtime.h>
+#include "dev_types.h"
+#include "cascade_dev.h"
+
+namespace ckm {
+
+constexpr float RT1_F = 0.25f, RT2_F = 0.10f, RT3_F = 0.20f;
+constexpr int ENS_CAP0 = 16;         // segment slots per trace on the first attempt (the host repeats a region that needs more)
+
+__device__ __forceinline__ unsigned long long al32(unsigned long long v) { return (v + 31ull) & ~31ull; }
+
+__device__ void emit_region(const CascadeDev &cd, const DevModel &md, const FbWork &pw, int L, int ri, int rj, bool multi) {
+  const uint32_t rid = atomicAdd(&cd.cnt[CC_REG], 1u);
+  if (rid >= cd.cap_reg) { atomicOr(&cd.cnt[CC_STATUS], (uint32_t)CS_REG); return; }
+  RegionRec rec; rec.pass = pw.pass; rec.i = ri; rec.j = rj; rec.multi = multi ? 1 : 0; rec.target = 0xffffffffu; rec.pad = 0;
+  const unsigned long long Mp = (unsigned long long)md.fbQ * 64ull, Ld = (unsigned long long)(rj - ri + 1);
+  unsigned long long off;
+  if (!multi) {
+    // layout of env_floats() (ckm_stages.hip): specials, decoding terms + OA specials, Forward matrix (3 arrays), posterior matrix (2 arrays)
+    unsigned long long pos = 0;
+    const unsigned long long xs = pos; pos = al32(pos + (Ld + 1) * 6);
+    const unsigned long long aux = pos; pos = al32(al32(pos + (Ld + 1) * 3) + (Ld + 1) * 5);
+    const unsigned long long mf = pos; pos = al32(pos + (Ld + 1) * 3 * Mp);
+    const unsigned long long mb = pos; pos = al32(pos + (Ld + 1) * 2 * Mp);
+    if (ws_alloc(cd, pos, off)) {
+      const uint32_t e = atomicAdd(&cd.cnt[CC_EWORK], 1u);
+      if (e < cd.cap_ework) {
+        FbWork w;
+        w.model = pw.model; w.seq = pw.seq; w.i0 = ri - 1; w.Ld = (int32_t)Ld; w.Lcfg = L; w.multihit = 0;
+        w.xs_off = off + xs; w.aux_off = off + aux; w.mxf_off = off + mf; w.mxb_off = off + mb; w.path_off = 0;
+        w.slot = e; w.full = 1; w.cand = pw.cand; w.pass = pw.pass;
+        cd.ework[e] = w;
+        queue_push(cd, cd.eq, CC_EQ, md.fb_cls, cd.cap_eq, e, (uint32_t)CS_EWORK);
+        rec.target = e;
+      } else atomicOr(&cd.cnt[CC_STATUS], (uint32_t)CS_EWORK);
+    }
+  } else {
+    const unsigned long long cap = Ld < (unsigned long long)ENS_CAP0 ? Ld : (unsigned long long)ENS_CAP0;
+    // results (counts, segments, sums) contiguous, then the multihit Forward of the region and the per-trace tables (ens_queue_batch)
+    unsigned long long pos = 0;
+    const unsigned long long nseg = pos; pos += 256;
+    const unsigned long long seg = pos; pos += (unsigned long long)ENS_NSAMPLES * cap * 4;
+    const unsigned long long n2 = pos; pos = al32(pos + Ld);
+    const unsigned long long nres = pos;
+    const unsigned long long xs = pos; pos = al32(pos + (Ld + 1) * 6);
+    const unsigned long long mx = pos; pos = al32(pos + (Ld + 1) * 3 * Mp);
+    const unsigned long long code = pos; pos = al32(pos + ((unsigned long long)ENS_NSAMPLES * (Ld + 1) + 1) / 2);
+    const unsigned long long ratio = pos; pos = al32(pos + (unsigned long long)ENS_NSAMPLES * (Ld + 1));
+    if (ws_alloc(cd, pos, off)) {
+      const uint32_t r = atomicAdd(&cd.cnt[CC_RWORK], 1u);
+      if (r < cd.cap_rwork) {
+        EnsWork e;
+        e.model = pw.model; e.seq = pw.seq; e.i0 = ri - 1; e.Ld = (int32_t)Ld; e.Lcfg = L; e.cap = (int32_t)cap;
+        e.xs_off = off + xs; e.mx_off = off + mx; e.code_off = off + code; e.ratio_off = off + ratio;
+        e.seg_off = off + seg; e.nseg_off = off + nseg; e.n2_off = off + n2;
+        const unsigned long long hoff = atomicAdd(cd.hens_top, nres);
+        e.host_off = (hoff + nres <= cd.hens_cap) ? hoff : ~0ull;
+        if (e.host_off == ~0ull) atomicOr(&cd.cnt[CC_STATUS], (uint32_t)CS_RWORK);
+        rec.pad = (e.host_off == ~0ull) ? 0xffffffffu : (uint32_t)hoff;
+        cd.ens[r] = e;
+        FbWork w;
+        w.model = pw.model; w.seq = pw.seq; w.i0 = ri - 1; w.Ld = (int32_t)Ld; w.Lcfg = L; w.multihit = 1;
+        w.xs_off = e.xs_off; w.aux_off = 0; w.mxf_off = e.mx_off; w.mxb_off = 0; w.path_off = 0;
+        w.slot = r; w.full = 2; w.cand = pw.cand; w.pass = pw.pass;
+        cd.rwork[r] = w;
+        queue_push(cd, cd.rq, CC_RQ, md.fb_cls, cd.cap_rq, r, (uint32_t)CS_RWORK);
+        rec.target = r;
+      } else atomicOr(&cd.cnt[CC_STATUS], (uint32_t)CS_RWORK);
+    }
+  }
+  cd.h_reg[rid] = rec;
+}
+
+// list/count: the Backward queue of one register class (parser items of `fwork` whose decoding terms are complete)
+__global__ void __launch_bounds__(64) region_kernel(const uint32_t *__restrict__ list, const uint32_t *__restrict__ count, uint32_t cap,
+                                                   const FbWork *__restrict__ fwork, CascadeDev cd, const DevModel *__restrict__ models, float *__restrict__ ws) {
+  const uint32_t n = min(*count, cap);
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    const FbWork w = fwork[list[k]];
+    const DevModel &md = models[w.model];
+    const int L = w.Ld;
+    float *aux = ws + w.aux_off;           // row r (1..L): [begin term, end term, N/J/C occupancy]; becomes [btot, etot, .]
+    float btp = 0.f, etp = 0.f;
+    int ri = -1; bool trig = false;
+    for (int j = 1; j <= L; ++j) {
+      const float bt = aux[(size_t)j * 3], et = aux[(size_t)j * 3 + 1], nj = aux[(size_t)j * 3 + 2];
+      const float btn = btp + bt, etn = etp + et, mo = 1.0f - nj;
+      aux[(size_t)j * 3] = btn; aux[(size_t)j * 3 + 1] = etn;
+      if (!trig) {
+        if (mo - (btn - btp) < RT2_F) ri = j; else if (ri == -1) ri = j;
+        if (mo >= RT1_F) trig = true;
+      } else if (mo - (etn - etp) < RT2_F) {
+        const float e0 = (ri - 1 >= 1) ? aux[(size_t)(ri - 1) * 3 + 1] : 0.f;       // etot[ri-1]
+        float mx = -1.0f;
+        for (int z = ri; z <= j; ++z) {
+          const float bz = (z - 1 >= 1) ? aux[(size_t)(z - 1) * 3] : 0.f;           // btot[z-1]
+          const float a = aux[(size_t)z * 3 + 1] - e0, b = btn - bz;
+          const float en = a < b ? a : b;
+          if (en > mx) mx = en;
+        }
+        emit_region(cd, md, w, L, ri, j, mx >= RT3_F);
+        ri = -1; trig = false;
+      }
+      btp = btn; etp = etn;
+    }
+  }
+}
+
+void launch_regions(hipStream_t stream, uint32_t nblocks, const uint32_t *list, const uint32_t *count, uint32_t cap, const FbWork *fwork,
+                    const CascadeDev &cd, const DevModel *models, float *ws) {
+  if (nblocks) hipLaunchKernelGGL(region_kernel, dim3(nblocks), dim3(64), 0, stream, list, count, cap, fwork, cd, models, ws);
+}
+
+}  // namespace ckm

@@ -57,8 +57,10 @@ __device__ __forceinline__ int ens_select_e(const float *__restrict__ cr, int Q,
 
 __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restrict__ work, const DevModel *__restrict__ models,
                                                        const LenEntry *__restrict__ lentab, float *__restrict__ ws,
-                                                       const uint32_t *__restrict__ seeds) {
-  const EnsWork w = work[blockIdx.x];
+                                                       const uint32_t *__restrict__ seeds, const uint32_t *__restrict__ count, uint32_t cap) {
+ const uint32_t nregions = min(*count, cap);
+ for (uint32_t region = blockIdx.x; region < nregions; region += gridDim.x) {
+  const EnsWork w = work[region];
   const int t = threadIdx.x, lane = threadIdx.x & 63;
   const DevModel &md = models[w.model];
   const int Q = md.fbQ, Mp = Q * 64, Ld = w.Ld;
@@ -149,15 +151,19 @@ __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restric
     for (; i >= 1; --i) code[i] = 0;
     nsegp[t] = overflow ? -1 : nseg;
   }
+ }
 #undef CELL
 }
 
 // grid (ENS_N, nregions), 64 threads; dynamic LDS: 2*Mp counters/floats + 32 floats
 __global__ void __launch_bounds__(64) ens_null2_kernel(const EnsWork *__restrict__ work, const DevModel *__restrict__ models,
                                                       const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
-                                                      float *__restrict__ ws) {
+                                                      float *__restrict__ ws, const uint32_t *__restrict__ count, uint32_t cap) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const EnsWork w = work[blockIdx.y];
+ const uint32_t nregions = min(*count, cap);
+ for (uint32_t region = blockIdx.y; region < nregions; region += gridDim.y) {
+  __syncthreads();
+  const EnsWork w = work[region];
   const int t = blockIdx.x, lane = threadIdx.x;
   const DevModel &md = models[w.model];
   const int Q = md.fbQ, Mp = Q * 64, Ld = w.Ld;
@@ -204,25 +210,46 @@ __global__ void __launch_bounds__(64) ens_null2_kernel(const EnsWork *__restrict
     for (int pos = sqfrom + 1 + lane; pos <= sqto; pos += 64) rt[pos] = n2[rd[pos - 1]];
     __syncthreads();
   }
+ }
 }
 
-// grid (ceil(maxLd/256), nregions)
-__global__ void __launch_bounds__(256) ens_sum_kernel(const EnsWork *__restrict__ work, float *__restrict__ ws) {
-  const EnsWork w = work[blockIdx.y];
-  const int pos = 1 + blockIdx.x * 256 + threadIdx.x;
-  if (pos > w.Ld) return;
-  const float *__restrict__ rt = ws + w.ratio_off + pos;
-  float acc = 0.0f;
-  for (int t = 0; t < ENS_N; ++t) acc = acc + rt[(size_t)t * (w.Ld + 1)];
-  (ws + w.n2_off)[pos - 1] = acc;
+// grid (x, regions): one thread per region position (strided), sum over the traces in trace order; then the region's results
+// (200 counts, the segment table, the sums: contiguous in the workspace) are copied to `host_res` when the region has a place there
+__global__ void __launch_bounds__(256) ens_sum_kernel(const EnsWork *__restrict__ work, float *__restrict__ ws, const uint32_t *__restrict__ count, uint32_t cap) {
+  const uint32_t nregions = min(*count, cap);
+  for (uint32_t region = blockIdx.y; region < nregions; region += gridDim.y) {
+    const EnsWork w = work[region];
+    for (int pos = 1 + blockIdx.x * 256 + threadIdx.x; pos <= w.Ld; pos += gridDim.x * 256) {
+      const float *__restrict__ rt = ws + w.ratio_off + pos;
+      float acc = 0.0f;
+      for (int t = 0; t < ENS_N; ++t) acc = acc + rt[(size_t)t * (w.Ld + 1)];
+      (ws + w.n2_off)[pos - 1] = acc;
+    }
+  }
 }
 
-void launch_ensemble(hipStream_t stream, const EnsWork *work, uint32_t nregions, int max_Ld, int max_Mp, const DevModel *models,
-                     const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, const uint32_t *seeds) {
-  if (!nregions) return;
-  hipLaunchKernelGGL(ens_trace_kernel, dim3(nregions), dim3(256), 0, stream, work, models, lentab, ws, seeds);
-  hipLaunchKernelGGL(ens_null2_kernel, dim3(ENS_N, nregions), dim3(64), (size_t)(2 * max_Mp + 32) * 4, stream, work, models, res, seq_off, ws);
-  hipLaunchKernelGGL(ens_sum_kernel, dim3((max_Ld + 255) / 256, nregions), dim3(256), 0, stream, work, ws);
+__global__ void __launch_bounds__(256) ens_export_kernel(const EnsWork *__restrict__ work, const float *__restrict__ ws, float *__restrict__ host_res,
+                                                        const uint32_t *__restrict__ count, uint32_t cap) {
+  const uint32_t nregions = min(*count, cap);
+  for (uint32_t region = blockIdx.y; region < nregions; region += gridDim.y) {
+    const EnsWork w = work[region];
+    if (w.host_off == ~0ull) continue;
+    const size_t n = (size_t)(w.n2_off - w.nseg_off) + (size_t)w.Ld;
+    const float *__restrict__ src = ws + w.nseg_off;
+    float *__restrict__ dst = host_res + w.host_off;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t)gridDim.x * 256) dst[k] = src[k];
+  }
+}
+
+// `count` (device memory) regions of `work`, at most cap; grid_regions workgroups share them
+void launch_ensemble(hipStream_t stream, const EnsWork *work, const uint32_t *count, uint32_t cap, uint32_t grid_regions, int max_Mp,
+                     const DevModel *models, const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, const uint32_t *seeds,
+                     float *host_res) {
+  if (!grid_regions) return;
+  hipLaunchKernelGGL(ens_trace_kernel, dim3(grid_regions), dim3(256), 0, stream, work, models, lentab, ws, seeds, count, cap);
+  hipLaunchKernelGGL(ens_null2_kernel, dim3(ENS_N, grid_regions), dim3(64), (size_t)(2 * max_Mp + 32) * 4, stream, work, models, res, seq_off, ws, count, cap);
+  hipLaunchKernelGGL(ens_sum_kernel, dim3(4, grid_regions), dim3(256), 0, stream, work, ws, count, cap);
+  if (host_res) hipLaunchKernelGGL(ens_export_kernel, dim3(4, grid_regions), dim3(256), 0, stream, work, ws, host_res, count, cap);
 }
 
 }  // namespace ckm

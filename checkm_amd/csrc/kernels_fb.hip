@@ -9,7 +9,9 @@
 // Reference stage replaced: Forward/Backward/domain definition of the hmmsearch per-target pipeline
 // (process launched at checkm/hmmer.py:70).
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include "dev_types.h"
+#include "cascade_dev.h"
 #include "xlane.h"
 
 namespace ckm {
@@ -36,14 +38,14 @@ struct Tr {
   __device__ __forceinline__ float at(int arr, int c) const { return t[arr * Q * 64 + lds_cell<Q>(c)]; }
 };
 
-// Blocks are 4 wavefronts working on (up to) 4 items of the SAME model: one LDS copy of the transition
-// odds serves all four.  blk[4*block + wave] = work index or NO_ITEM; blk_model[block] = the model.
-constexpr uint32_t NO_ITEM = 0xffffffffu;
-constexpr int FB_WAVES = 4;
-
+// A workgroup is ONE wavefront that takes work items from a queue (dev_types.h: WorkQueue) until the queue is empty: the queue
+// may have been written by the host (alignment requests, diagnostics, second envelope rounds) or by the kernels of the previous
+// stage (the device-driven cascade, ckm_cascade.hip), in which case its length is only known on the device.  The wavefront
+// keeps the transition image of its current model in LDS and reloads it when the model changes.
 template <int Q>
 __device__ __forceinline__ void load_tr(float *lds, const float *ftr) {
   constexpr int Mp = Q * 64;
+  __syncthreads();
   for (int i = threadIdx.x; i < 8 * Mp; i += blockDim.x) { const int arr = i / Mp, c = i % Mp; lds[arr * Mp + lds_cell<Q>(c)] = ftr[i]; }
   __syncthreads();
 }
@@ -52,6 +54,7 @@ __device__ __forceinline__ void load_tr(float *lds, const float *ftr) {
 template <int Q>
 __device__ __forceinline__ void load_gates(float *lds, const float *ftr) {
   constexpr int Mp = Q * 64;
+  __syncthreads();
   for (int i = threadIdx.x; i < 8 * Mp; i += blockDim.x) { const int arr = i / Mp, c = i % Mp; lds[arr * Mp + lds_cell<Q>(c)] = (ftr[i] > 0.f) ? 0.0f : -__builtin_inff(); }
   __syncthreads();
 }
@@ -91,19 +94,22 @@ __device__ __forceinline__ float fwd_row(float (&Mv)[Q], float (&Iv)[Q], float (
 }
 
 template <int Q>
-__global__ void __launch_bounds__(256) fwd_kernel(const FbWork *__restrict__ work, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ blk_model,
-                                                 const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
-                                                 const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
-                                                 float *__restrict__ ws, FwdOut *__restrict__ out,
-                                                 ScaleEvent *__restrict__ events, uint32_t *__restrict__ nevents, uint32_t cap_events) {
+__global__ void __launch_bounds__(64) fwd_kernel(WorkQueue queue, FbWork *__restrict__ work,
+                                                const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
+                                                const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
+                                                float *__restrict__ ws, FwdOut *__restrict__ out,
+                                                ScaleEvent *__restrict__ events, uint32_t *__restrict__ nevents, uint32_t cap_events,
+                                                CascadeDev cd, int decide) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int Mp = Q * 64;
-  const int lane = threadIdx.x & 63;
-  const uint32_t item = idx[blockIdx.x * FB_WAVES + (threadIdx.x >> 6)];
-  const DevModel &md = models[blk_model[blockIdx.x]];
-  load_tr<Q>(lds, md.ftr);
-  if (item == NO_ITEM) return;
+  const int lane = threadIdx.x;
+  uint32_t cur_model = 0xffffffffu;
+ for (;;) {
+  const uint32_t item = queue_next(queue, lane);
+  if (item == 0xffffffffu) break;
   const FbWork w = work[item];
+  const DevModel &md = models[w.model];
+  if (w.model != cur_model) { load_tr<Q>(lds, md.ftr); cur_model = w.model; }
   Tr<Q> tr{lds, lane};
   const uint8_t *rp = res + seq_off[w.seq] + w.i0;
   const LenEntry le = lentab[w.Lcfg];
@@ -114,6 +120,7 @@ __global__ void __launch_bounds__(256) fwd_kernel(const FbWork *__restrict__ wor
   for (int q = 0; q < Q; ++q) Mv[q] = Iv[q] = Dv[q] = 0.f;
   float xN = 1.0f, xB = xN * move, xE = 0.f, xJ = 0.f, xC = 0.f;
   int nscale = 0;
+  float lsum = 0.f;                  // approximate log of the product of the rescale factors (conservative F3 test only)
   float *xs = ws + w.xs_off;
   float *mx = w.full ? ws + w.mxf_off : nullptr;
   if (lane == 0) { xs[0] = 0.f; xs[1] = xN; xs[2] = 0.f; xs[3] = xB; xs[4] = 0.f; xs[5] = 1.0f; }
@@ -150,6 +157,7 @@ __global__ void __launch_bounds__(256) fwd_kernel(const FbWork *__restrict__ wor
 #pragma unroll
       for (int q = 0; q < Q; ++q) { Mv[q] *= inv; Iv[q] *= inv; Dv[q] *= inv; }
       scale = xE; xE = 1.0f; ++nscale;
+      lsum += approx_ln(scale);
       if (lane == 0) {
         const uint32_t e = atomicAdd(nevents, 1u);
         if (e < cap_events) { ScaleEvent ev; ev.slot = w.slot; ev.row = i; ev.scale = scale; ev.pad = 0; events[e] = ev; }
@@ -167,6 +175,31 @@ __global__ void __launch_bounds__(256) fwd_kernel(const FbWork *__restrict__ wor
     }
   }
   if (lane == 0) { out[w.slot].xC = xC; out[w.slot].nscale = nscale; }
+  // ---- device-driven cascade: the F3 decision of a whole-sequence parser item, taken conservatively (the threshold is lowered by a
+  // margin that covers the approximate logarithms; the host repeats the test exactly).  A passer gets its pass record, the workspace
+  // of its decoding terms, and a place in the Backward queue of this register class.
+  if (decide && lane == 0) {
+    const PairRec pr = cd.cand[w.cand];
+    const float fwdsc = lsum + approx_ln(xC * move);
+    const float sc = (fwdsc - pr.filtersc) * LOG2E_F;
+    if (sc >= md.thr_fwd_f3 - cd.margin_fwd) {
+      unsigned long long off;
+      if (ws_alloc(cd, (unsigned long long)(w.Ld + 1) * 3ull, off)) {
+        const uint32_t pid = atomicAdd(&cd.cnt[CC_PASS], 1u);
+        if (pid < cd.cap_pass) {
+          PassRec r;
+          r.cand = w.cand; r.fwork = item; r.model = w.model; r.seq = w.seq; r.usc = pr.usc;
+          r.bias_d = cd.bias_raw[2 * (size_t)w.cand]; r.bias_e = cd.bias_raw[2 * (size_t)w.cand + 1];
+          r.vit_fast = cd.vit_fast[w.cand]; r.vit_exact = cd.vit_exact[w.cand]; r.vit_flag = cd.vit_flag[w.cand]; r.route = cd.route[w.cand];
+          r.fwd_xC = xC; r.nscale = nscale;
+          cd.h_pass[pid] = r;
+          work[item].aux_off = off; work[item].pass = pid;
+          queue_push(cd, cd.bq, CC_BQ, md.fb_cls, cd.cap_fq, item, (uint32_t)CS_FWORK);
+        } else atomicOr(&cd.cnt[CC_STATUS], (uint32_t)CS_PASS);
+      }
+    }
+  }
+ }
 }
 
 // ---- Backward -----------------------------------------------------------------------------------
@@ -183,18 +216,20 @@ __device__ __forceinline__ void bwd_dchain(float (&Dn)[Q], const float (&av)[Q],
 }
 
 template <int Q>
-__global__ void __launch_bounds__(256) bwd_kernel(const FbWork *__restrict__ work, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ blk_model,
-                                                 const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
-                                                 const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
-                                                 float *__restrict__ ws, const FwdOut *__restrict__ fout, int32_t *__restrict__ range_err) {
+__global__ void __launch_bounds__(64) bwd_kernel(WorkQueue queue, const FbWork *__restrict__ work,
+                                                const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
+                                                const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
+                                                float *__restrict__ ws, const FwdOut *__restrict__ fout, int32_t *__restrict__ range_err) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int Mp = Q * 64;
-  const int lane = threadIdx.x & 63;
-  const uint32_t item = idx[blockIdx.x * FB_WAVES + (threadIdx.x >> 6)];
-  const DevModel &md = models[blk_model[blockIdx.x]];
-  load_tr<Q>(lds, md.ftr);
-  if (item == NO_ITEM) return;
+  const int lane = threadIdx.x;
+  uint32_t cur_model = 0xffffffffu;
+ for (;;) {
+  const uint32_t item = queue_next(queue, lane);
+  if (item == 0xffffffffu) break;
   const FbWork w = work[item];
+  const DevModel &md = models[w.model];
+  if (w.model != cur_model) { load_tr<Q>(lds, md.ftr); cur_model = w.model; }
   Tr<Q> tr{lds, lane};
   const uint8_t *rp = res + seq_off[w.seq] + w.i0;
   const LenEntry le = lentab[w.Lcfg];
@@ -352,22 +387,26 @@ __global__ void __launch_bounds__(256) bwd_kernel(const FbWork *__restrict__ wor
     const unsigned long long any = __ballot(bad);
     if (lane == 0) range_err[w.slot] = any ? 1 : 0;
   }
+ }
 }
 
 // ---- null2 by expectation + optimal accuracy fill + traceback -------------------------------------
 template <int Q>
-__global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ blk_model,
-                                                const DevModel *__restrict__ models, float *__restrict__ ws,
-                                                const int32_t *__restrict__ range_err, EnvOut *__restrict__ out) {
+__global__ void __launch_bounds__(64) oa_kernel(WorkQueue queue, const FbWork *__restrict__ work,
+                                               const DevModel *__restrict__ models, float *__restrict__ ws,
+                                               const int32_t *__restrict__ range_err, const FwdOut *__restrict__ fout, EnvOut *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int Mp = Q * 64;
-  const int lane = threadIdx.x & 63;
-  const uint32_t item = idx[blockIdx.x * FB_WAVES + (threadIdx.x >> 6)];
-  const DevModel &md = models[blk_model[blockIdx.x]];
-  load_gates<Q>(lds, md.ftr);
-  if (item == NO_ITEM) return;
+  const int lane = threadIdx.x;
+  uint32_t cur_model = 0xffffffffu;
+ for (;;) {
+  const uint32_t item = queue_next(queue, lane);
+  if (item == 0xffffffffu) break;
   const FbWork w = work[item];
-  if (range_err[w.slot]) { if (lane == 0) out[w.slot].range_err = 1; return; }
+  const DevModel &md = models[w.model];
+  if (w.model != cur_model) { load_gates<Q>(lds, md.ftr); cur_model = w.model; }
+  if (lane == 0) { out[w.slot].xC = fout[w.slot].xC; out[w.slot].nscale = fout[w.slot].nscale; }     // the envelope's Forward result travels with its record
+  if (range_err[w.slot]) { if (lane == 0) out[w.slot].range_err = 1; continue; }
   Tr<Q> tr{lds, lane};
   const int M = md.M, L = w.Ld, c0 = lane * Q;
   float *pp = ws + w.mxb_off;       // posterior rows (M, I; D = 0)
@@ -529,39 +568,44 @@ __global__ void __launch_bounds__(256) oa_kernel(const FbWork *__restrict__ work
     o.range_err = 0; o.oasc = oC;
     o.hmm_from = fk; o.hmm_to = lk; o.ali_from = fi + w.i0; o.ali_to = li + w.i0;
   }
+ }
 }
 
 // ---- launchers ----------------------------------------------------------------------------------
+// `nblocks` single-wavefront workgroups are started; each keeps taking items until the queue is empty, so any nblocks >= 1 is
+// correct and nblocks ~ (items, capped at what the device can hold at once) is what the callers pass.
 #define CKM_FB_QS(X) X(1) X(2) X(3) X(4) X(6) X(8) X(12) X(16) X(24) X(32)
 
-int launch_fwd(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const uint32_t *blk_model, const DevModel *models,
+int launch_fwd(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, FbWork *work, const DevModel *models,
                const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, FwdOut *out,
-               ScaleEvent *events, uint32_t *nevents, uint32_t cap_events) {
-  if (!n) return 0;
+               ScaleEvent *events, uint32_t *nevents, uint32_t cap_events, const CascadeDev *cd) {
+  if (!nblocks) return 0;
+  CascadeDev c; memset(&c, 0, sizeof(c));
+  if (cd) c = *cd;
   switch (Q) {
-#define X(QV) case QV: hipLaunchKernelGGL(fwd_kernel<QV>, dim3(n), dim3(256), (size_t)8 * QV * 64 * 4, stream, work, idx, blk_model, models, lentab, res, seq_off, ws, out, events, nevents, cap_events); break;
+#define X(QV) case QV: hipLaunchKernelGGL(fwd_kernel<QV>, dim3(nblocks), dim3(64), (size_t)8 * QV * 64 * 4, stream, queue, work, models, lentab, res, seq_off, ws, out, events, nevents, cap_events, c, cd ? 1 : 0); break;
     CKM_FB_QS(X)
 #undef X
     default: return -1;
   }
   return 0;
 }
-int launch_bwd(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const uint32_t *blk_model, const DevModel *models,
+int launch_bwd(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const FbWork *work, const DevModel *models,
                const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, const FwdOut *fout, int32_t *range_err) {
-  if (!n) return 0;
+  if (!nblocks) return 0;
   switch (Q) {
-#define X(QV) case QV: hipLaunchKernelGGL(bwd_kernel<QV>, dim3(n), dim3(256), (size_t)8 * QV * 64 * 4, stream, work, idx, blk_model, models, lentab, res, seq_off, ws, fout, range_err); break;
+#define X(QV) case QV: hipLaunchKernelGGL(bwd_kernel<QV>, dim3(nblocks), dim3(64), (size_t)8 * QV * 64 * 4, stream, queue, work, models, lentab, res, seq_off, ws, fout, range_err); break;
     CKM_FB_QS(X)
 #undef X
     default: return -1;
   }
   return 0;
 }
-int launch_oa(int Q, uint32_t n, hipStream_t stream, const FbWork *work, const uint32_t *idx, const uint32_t *blk_model, const DevModel *models,
-              float *ws, const int32_t *range_err, EnvOut *out) {
-  if (!n) return 0;
+int launch_oa(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const FbWork *work, const DevModel *models,
+              float *ws, const int32_t *range_err, const FwdOut *fout, EnvOut *out) {
+  if (!nblocks) return 0;
   switch (Q) {
-#define X(QV) case QV: hipLaunchKernelGGL(oa_kernel<QV>, dim3(n), dim3(256), (size_t)8 * QV * 64 * 4, stream, work, idx, blk_model, models, ws, range_err, out); break;
+#define X(QV) case QV: hipLaunchKernelGGL(oa_kernel<QV>, dim3(nblocks), dim3(64), (size_t)8 * QV * 64 * 4, stream, queue, work, models, ws, range_err, fout, out); break;
     CKM_FB_QS(X)
 #undef X
     default: return -1;

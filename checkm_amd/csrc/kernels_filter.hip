@@ -8,7 +8,9 @@
 // Every decision is taken on IEEE basic operations only (no device libm), so it is bit-identical
 // to the host formulation: thresholds were converted to score space on the host (host_profile.cpp).
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include "dev_types.h"
+#include "cascade_dev.h"
 #include "xlane.h"
 
 namespace ckm {
@@ -80,14 +82,19 @@ __global__ void msv_finish_kernel(FinishArgs a, uint32_t nblocks_work) {
 // into LDS once per pair and the residues ride in registers, 64 at a time, so no global load sits on the row-to-row
 // chain (rows of the longest sequence bound the launch).  Cells k = lane + 64*j, previous/current row in LDS.
 // --------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) msv_full_kernel(const PairRec *__restrict__ pairs, uint32_t npairs, const DevModel *__restrict__ models,
+// `queue.list` is unused: entry k of the queue is pairs[k].  With `decide` the kernel is the exact-MSV stage of the device-driven
+// cascade: a pair whose exact score passes F1 (the same IEEE test msv_finish_kernel applies) joins the candidate table.
+__global__ void __launch_bounds__(64) msv_full_kernel(WorkQueue queue, const PairRec *__restrict__ pairs, const DevModel *__restrict__ models,
                                                      const LenEntry *__restrict__ lentab, const uint8_t *__restrict__ res,
                                                      const uint64_t *__restrict__ seq_off, const int32_t *__restrict__ seq_len,
-                                                     int32_t *__restrict__ out_xJ /* -1 overflow */, float *__restrict__ out_usc, int maxMp) {
+                                                     int32_t *__restrict__ out_xJ /* -1 overflow */, float *__restrict__ out_usc, int maxMp,
+                                                     CascadeDev cd, int decide) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
-  const uint32_t pi = blockIdx.x;
-  if (pi >= npairs) return;
+ for (;;) {
+  const uint32_t pi = queue_next_index(queue, lane);
+  if (pi == 0xffffffffu) break;
+  __syncthreads();
   const PairRec pr = pairs[pi];
   const DevModel &md = models[pr.model];
   const int M = md.M, L = seq_len[pr.seq], W = M + 1;
@@ -135,9 +142,15 @@ __global__ void __launch_bounds__(64) msv_full_kernel(const PairRec *__restrict_
     chunk = nxt;
   }
   if (lane == 0) {
-    if (overflow) { out_xJ[pi] = -1; out_usc[pi] = __builtin_inff(); }
-    else { out_xJ[pi] = xJ; out_usc[pi] = msv_score(xJ, le.tjb_b, md.base_b, md.scale_b); }
+    const float usc = overflow ? __builtin_inff() : msv_score(xJ, le.tjb_b, md.base_b, md.scale_b);
+    if (out_xJ) out_xJ[pi] = overflow ? -1 : xJ;
+    if (out_usc) out_usc[pi] = usc;
+    if (decide && to_bits(usc, le.nullsc) >= md.thr_msv_f1) {
+      const uint32_t k = atomicAdd(&cd.cnt[CC_CAND], 1u);
+      if (k < cd.cap_cand) { PairRec r = pr; r.usc = usc; r.filtersc = 0.f; cd.cand[k] = r; } else atomicOr(&cd.cnt[CC_STATUS], (uint32_t)CS_CAND);
+    }
   }
+ }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -169,6 +182,46 @@ __global__ void bias_kernel(const PairRec *__restrict__ pairs, uint32_t npairs, 
   dbg_d[(size_t)pi * 3 + 2] = 0.f;
 }
 
+// The bias filter of the device-driven cascade: same recurrence, one thread per candidate of a table whose length is only known on
+// the device (grid-stride loop), followed by the F1 / F2 decisions in their conservative form.  filtersc is stored in its
+// approximate form (the later device tests use it); the host recomputes it with libm from the two raw numbers.
+//   bits(usc, filtersc) <  F1 - margin            dead
+//   bits >= F2 + margin                           Viterbi filter skipped (HMMER runs it only when the MSV P-value is above F2)
+//   bits <  F2 - margin                           Viterbi filter, fast kernel first
+//   otherwise (within the margin of F2)           the exact Viterbi kernel runs and the pair goes on whatever it says: the host decides
+__global__ void __launch_bounds__(128) bias_filter_kernel(CascadeDev cd, const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
+                                                         const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off) {
+  const uint32_t n = min(cd.cnt[CC_CAND], cd.cap_cand);
+  for (uint32_t pi = blockIdx.x * blockDim.x + threadIdx.x; pi < n; pi += gridDim.x * blockDim.x) {
+    PairRec pr = cd.cand[pi];
+    const DevModel &md = models[pr.model];
+    const int L = cd.seq_len[pr.seq];
+    const uint8_t *rp = res + seq_off[pr.seq];
+    float d0 = md.bpi0, d1 = md.beo1[rp[0]] * md.bpi1;
+    int nexp = 0;
+    for (int i = 1; i < L; ++i) {
+      const float n0 = d0 * md.bt00 + d1 * md.bt10;
+      const float n1 = (d0 * md.bt01 + d1 * md.bt11) * md.beo1[rp[i]];
+      d0 = n0; d1 = n1;
+      const float mx = fmaxf(d0, d1);
+      if (mx < 0x1p-40f) { d0 *= 0x1p64f; d1 *= 0x1p64f; nexp -= 64; }
+      else if (mx > 0x1p40f) { d0 *= 0x1p-64f; d1 *= 0x1p-64f; nexp += 64; }
+    }
+    const float dsum = d0 + d1;
+    cd.bias_raw[2 * (size_t)pi] = dsum; cd.bias_raw[2 * (size_t)pi + 1] = (float)nexp;
+    const float filtersc = (approx_ln(dsum) + (float)nexp * LN2_F) + lentab[L].bias_tail;
+    cd.cand[pi].filtersc = filtersc;
+    cd.vit_fast[pi] = 0.f; cd.vit_exact[pi] = 0.f; cd.vit_flag[pi] = 0u;
+    const float sc = (pr.usc - filtersc) * LOG2E_F;
+    uint8_t route = 0;
+    if (!(sc >= md.thr_msv_f1 - cd.margin_msv)) { cd.route[pi] = 0xffu; continue; }              // dead
+    if (sc >= md.thr_msv_f2 + cd.margin_msv) { cd.route[pi] = 0; pass_to_forward(cd, md, pi, pr.model, pr.seq); continue; }
+    if (sc < md.thr_msv_f2 - cd.margin_msv) { route = 1; queue_push(cd, cd.vq, CC_VQ, md.vit_cls, cd.cap_vq, pi, (uint32_t)CS_VQ); }
+    else { route = 2 | 0x10; queue_push(cd, cd.vxq, CC_VXQ, md.vit_cls, cd.cap_vq, pi, (uint32_t)CS_VQ); }
+    cd.route[pi] = route;
+  }
+}
+
 // --------------------------------------------------------------------------------------------
 // Viterbi filter: one wavefront per pair, packed 2 x i16 saturating arithmetic (v_pk_add_i16 clamp,
 // v_pk_max_i16) -- the same word arithmetic HMMER's striped filter performs, so results are
@@ -194,16 +247,22 @@ __device__ __forceinline__ u32 stripe_shift(u32 v) {
 // reduction: the rows only feed a running element-wise maximum.  The result is exact when max xE + E->J <= base (flag 0);
 // otherwise it is a LOWER bound of the exact score (max / saturating add are monotone in xB) and flag = 1: the caller
 // accepts the pair if the bound already passes F2 and re-runs the exact kernel if it does not.
+// Every wavefront of the 4-wave workgroup takes candidate ids from the queue on its own.  With `decide` the kernel is a stage of the
+// device-driven cascade and its epilogue takes the F2 decision (conservative band of cd.margin_vit bits around the threshold; the
+// host repeats the test exactly on the recorded score):
+//   FAST   score + F2 margin passes -> Forward;  J flag set (score is only a lower bound) -> exact queue of the same class;
+//          within the margin -> Forward (the host decides);  else dead
+//   exact  score within the margin or above -> Forward; pairs whose NEED for the filter was itself within the margin go on regardless
 template <int QH, bool FAST>
-__global__ void __launch_bounds__(256) vit_kernel(const PairRec *__restrict__ pairs, const uint32_t *__restrict__ idx, uint32_t n,
+__global__ void __launch_bounds__(256) vit_kernel(WorkQueue queue, const PairRec *__restrict__ pairs,
                                                   const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
                                                   const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
                                                   const int32_t *__restrict__ seq_len, int32_t *__restrict__ out_xC, float *__restrict__ out_sc,
-                                                  uint32_t *__restrict__ out_flag) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t wi = blockIdx.x * (blockDim.x >> 6) + wave;
-  if (wi >= n) return;
-  const uint32_t pi = idx[wi];
+                                                  uint32_t *__restrict__ out_flag, CascadeDev cd, int decide) {
+  const int lane = threadIdx.x & 63;
+ for (;;) {
+  const uint32_t pi = queue_next(queue, lane);
+  if (pi == 0xffffffffu) break;
   const PairRec pr = pairs[pi];
   const DevModel &md = models[pr.model];
   constexpr int ROW = QH * 64;                      // u32 words per table row
@@ -291,25 +350,41 @@ __global__ void __launch_bounds__(256) vit_kernel(const PairRec *__restrict__ pa
     xC = max(xC, xE + md.wE_move);
     jflag = (xE + md.wE_loop) > xN;
   }
-  if (lane == 0 && out_flag) out_flag[pi] = (jflag && !overflow) ? 1u : 0u;
   if (lane == 0) {
-    if (overflow) { out_xC[pi] = 32767; out_sc[pi] = __builtin_inff(); }
-    else {
-      out_xC[pi] = xC;
-      if (xC > NEG16) { float sc = (float)xC + (float)le.w_move - (float)md.base_w; sc = sc / md.scale_w; sc = sc - 3.0f; out_sc[pi] = sc; }
-      else out_sc[pi] = -__builtin_inff();
+    const uint32_t flag = (jflag && !overflow) ? 1u : 0u;
+    float vsc;
+    if (overflow) vsc = __builtin_inff();
+    else if (xC > NEG16) { float sc = (float)xC + (float)le.w_move - (float)md.base_w; sc = sc / md.scale_w; sc = sc - 3.0f; vsc = sc; }
+    else vsc = -__builtin_inff();
+    if (!decide) {
+      if (out_flag) out_flag[pi] = flag;
+      out_xC[pi] = overflow ? 32767 : xC; out_sc[pi] = vsc;
+    } else {
+      const float v = (vsc - pr.filtersc) * LOG2E_F;
+      if (FAST) {
+        cd.vit_fast[pi] = vsc; cd.vit_flag[pi] = flag;
+        if (v >= md.thr_vit_f2 + cd.margin_vit) pass_to_forward(cd, md, pi, pr.model, pr.seq);
+        else if (flag) { cd.route[pi] = 2; queue_push(cd, cd.vxq, CC_VXQ, md.vit_cls, cd.cap_vq, pi, (uint32_t)CS_VQ); }
+        else if (v >= md.thr_vit_f2 - cd.margin_vit) pass_to_forward(cd, md, pi, pr.model, pr.seq);
+      } else {
+        cd.vit_exact[pi] = vsc;
+        if ((cd.route[pi] & 0x10) || v >= md.thr_vit_f2 - cd.margin_vit) pass_to_forward(cd, md, pi, pr.model, pr.seq);
+      }
     }
   }
+ }
 }
 
 #define CKM_VIT_CASE(QV) case QV: \
-    if (fast) hipLaunchKernelGGL((vit_kernel<QV, true>), dim3((n + 3) / 4), dim3(256), 0, stream, pairs, idx, n, models, lentab, res, seq_off, seq_len, out_xC, out_sc, out_flag); \
-    else hipLaunchKernelGGL((vit_kernel<QV, false>), dim3((n + 3) / 4), dim3(256), 0, stream, pairs, idx, n, models, lentab, res, seq_off, seq_len, out_xC, out_sc, out_flag); \
+    if (fast) hipLaunchKernelGGL((vit_kernel<QV, true>), dim3(nblocks), dim3(256), 0, stream, queue, pairs, models, lentab, res, seq_off, seq_len, out_xC, out_sc, out_flag, c, cd ? 1 : 0); \
+    else hipLaunchKernelGGL((vit_kernel<QV, false>), dim3(nblocks), dim3(256), 0, stream, queue, pairs, models, lentab, res, seq_off, seq_len, out_xC, out_sc, out_flag, c, cd ? 1 : 0); \
     break;
-int launch_vit(int QH, hipStream_t stream, const PairRec *pairs, const uint32_t *idx, uint32_t n, const DevModel *models,
+int launch_vit(int QH, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const PairRec *pairs, const DevModel *models,
                const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xC, float *out_sc,
-               uint32_t *out_flag, bool fast) {
-  if (n == 0) return 0;
+               uint32_t *out_flag, bool fast, const CascadeDev *cd) {
+  if (nblocks == 0) return 0;
+  CascadeDev c; memset(&c, 0, sizeof(c));
+  if (cd) c = *cd;
   switch (QH) {
     CKM_VIT_CASE(1) CKM_VIT_CASE(2) CKM_VIT_CASE(3) CKM_VIT_CASE(4) CKM_VIT_CASE(5) CKM_VIT_CASE(6) CKM_VIT_CASE(7) CKM_VIT_CASE(8)
     CKM_VIT_CASE(10) CKM_VIT_CASE(12) CKM_VIT_CASE(14) CKM_VIT_CASE(16)
@@ -321,19 +396,26 @@ int launch_vit(int QH, hipStream_t stream, const PairRec *pairs, const uint32_t 
 void launch_msv_finish(hipStream_t stream, const FinishArgs &a, uint32_t nblocks) {
   if (nblocks) hipLaunchKernelGGL(msv_finish_kernel, dim3(nblocks), dim3(256), 0, stream, a, nblocks);
 }
-void launch_msv_full(hipStream_t stream, const PairRec *pairs, uint32_t npairs, const DevModel *models, const LenEntry *lentab,
-                     const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xJ, float *out_usc, int maxMp) {
-  if (!npairs) return;
+void launch_msv_full(hipStream_t stream, uint32_t nblocks, WorkQueue queue, const PairRec *pairs, const DevModel *models, const LenEntry *lentab,
+                     const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xJ, float *out_usc, int maxMp,
+                     const CascadeDev *cd) {
+  if (!nblocks) return;
+  CascadeDev c; memset(&c, 0, sizeof(c));
+  if (cd) c = *cd;
   const size_t lds = (((size_t)KP_SYMS * (maxMp + 1) + 15) & ~(size_t)15) + (size_t)2 * maxMp * sizeof(int16_t);
   static size_t attr_bytes = 0;
   if (lds > 48 * 1024 && lds > attr_bytes) { (void)hipFuncSetAttribute((const void *)msv_full_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_bytes = lds; }
-  hipLaunchKernelGGL(msv_full_kernel, dim3(npairs), dim3(64), lds, stream, pairs, npairs, models, lentab, res, seq_off, seq_len, out_xJ, out_usc, maxMp);
+  hipLaunchKernelGGL(msv_full_kernel, dim3(nblocks), dim3(64), lds, stream, queue, pairs, models, lentab, res, seq_off, seq_len, out_xJ, out_usc, maxMp, c, cd ? 1 : 0);
 }
 void launch_bias(hipStream_t stream, PairRec *pairs, uint32_t npairs, const DevModel *models, const LenEntry *lentab,
                  const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, float *raw) {
   if (!npairs) return;
   (void)lentab;
   hipLaunchKernelGGL(bias_kernel, dim3((npairs + 127) / 128), dim3(128), 0, stream, pairs, npairs, models, res, seq_off, seq_len, raw);
+}
+void launch_bias_filter(hipStream_t stream, uint32_t nblocks, const CascadeDev &cd, const DevModel *models, const LenEntry *lentab,
+                        const uint8_t *res, const uint64_t *seq_off) {
+  if (nblocks) hipLaunchKernelGGL(bias_filter_kernel, dim3(nblocks), dim3(128), 0, stream, cd, models, lentab, res, seq_off);
 }
 
 }  // namespace ckm

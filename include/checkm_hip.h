@@ -9,8 +9,10 @@
  *   - the caller owns every input buffer; the library owns every output object and frees it in
  *     the matching *_free().  Column pointers returned by ckm_hits_columns()/ckm_qa_columns() stay
  *     valid until that object is freed.
- *   - one ckm_ctx per (process, device).  Calls on one ctx are not re-entrant; different ctxs are
- *     independent.  The library never falls back to a CPU implementation: without a usable HIP
+ *   - one ckm_ctx per (process, device).  ckm_search / ckm_reduce / ckm_align calls on one ctx are not re-entrant; different ctxs
+ *     are independent.  ckm_seqs_pack / ckm_seqs_from_fasta / ckm_hits_write_domtblout touch no state of the ctx and may run on
+ *     other threads while a search is in flight (MarkerGeneFinder.find reads the next batch of bins and writes the previous batch's
+ *     tables that way).  The library never falls back to a CPU implementation: without a usable HIP
  *     device ckm_ctx_create() fails with CKM_ENODEV and nothing else can be called.
  */
 #ifndef CHECKM_HIP_H
@@ -22,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CKM_ABI_VERSION 2
+#define CKM_ABI_VERSION 3
 
 enum {
   CKM_OK      =  0,
@@ -138,6 +140,8 @@ typedef struct {
   uint64_t residue_hmm;         /* sum over pairs of L */
   double   ms_ssv, ms_filters, ms_fwdbwd, ms_domains, ms_host, ms_total;
   uint32_t ssv_launches;
+  uint32_t cascade_fallback_lanes; /* lanes (length classes) of the last search that outgrew the device-side tables / workspace of the
+                                      device-driven cascade and were run by the host-driven one instead (0 in the normal case) */
 } ckm_search_stats;
 int ckm_last_search_stats(const ckm_ctx *ctx, ckm_search_stats *out);
 

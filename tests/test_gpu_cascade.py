@@ -1,0 +1,62 @@
+"""The device-driven cascade (stages chained on the device, conservative decisions, ONE host synchronisation per lane, exact decisions
+again on the host) against the host-driven one (CKM_CASCADE=host: a device phase, a copy and a host decision per stage): same rows,
+bit for bit, on one lane and on three, with chunked SSV phases -- and when the device-side workspace is too small the lane is handed
+to the host-driven cascade (counted in cascade_fallback_lanes) and the rows still do not change."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CODE = r'''
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np
+from checkm_amd import _lib, synth
+from tests import common
+profs = common.mixed_profiles(); path = common.hmm_file("mixed", profs)
+rng = np.random.default_rng(5)
+bins = [synth.make_bin(profs, 8800 + b, n_orfs=260, dup_frac=0.4) for b in range(6)]
+# a tandem repeat (multi-domain region -> trace ensemble) in every other bin
+for b in range(0, 6, 2):
+    p = profs[3 + b]
+    a, c = p.M * 3 // 4, p.M // 3
+    t = np.concatenate([synth.random_residues(rng, 9), synth.sample_domain(rng, p, 1, a), synth.sample_domain(rng, p, c, p.M), synth.random_residues(rng, 8)])
+    bins[b].append(("tandem%%d_1" %% b, "", synth.to_text(t) + "*"))
+ctx = _lib.Context(0); prof = _lib.Profiles(ctx, path); seqs = _lib.Seqs(ctx, bins)
+hits = _lib.search(ctx, prof, seqs)
+st = ctx.stats()
+f32 = lambda v: int(np.float32(v).view(np.uint32))
+rows = [[b, int(hits.seq[i]), int(hits.model[i]), int(hits.dom_idx[i]), int(hits.ndom[i]), int(hits.hmm_from[i]), int(hits.hmm_to[i]), int(hits.ali_from[i]), int(hits.ali_to[i]),
+         int(hits.env_from[i]), int(hits.env_to[i]), f32(hits.full_score[i]), f32(hits.full_bias[i]), f32(hits.dom_score[i]), f32(hits.dom_bias[i]), f32(hits.acc[i]),
+         float(hits.full_evalue[i]), float(hits.c_evalue[i]), float(hits.i_evalue[i])] for b in range(6) for i in hits.rows(b)]
+print(json.dumps({"rows": rows, "fallback": int(st.cascade_fallback_lanes), "pairs": [int(st.pairs_ssv), int(st.pairs_bias), int(st.pairs_vit), int(st.pairs_fwd), int(st.pairs_dom), int(st.envelopes), int(st.regions_multi)]}))
+''' % ROOT
+
+
+def _run(**extra):
+    env = dict(os.environ, **extra)
+    out = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (extra, out.stderr[-3000:])
+    return json.loads(out.stdout.strip().split("\n")[-1])
+
+
+def test_device_cascade_equals_host_cascade():
+    host = _run(CKM_CASCADE="host", CKM_WORKERS="1")
+    assert len(host["rows"]) > 100 and host["pairs"][6] >= 2           # multi-domain regions are present
+    for extra in (dict(CKM_WORKERS="1"), dict(CKM_WORKERS="3", CKM_WORKER_MIN_PAIRS="1"), dict(CKM_WORKERS="2", CKM_WORKER_MIN_PAIRS="1", CKM_PAIR_BUDGET="9000")):
+        dev = _run(**extra)
+        assert dev["fallback"] == 0, extra
+        assert dev["rows"] == host["rows"], extra
+        assert dev["pairs"][0] == host["pairs"][0]
+        # the device decides conservatively: it may let a few more pairs through a filter than the exact test, never fewer
+        assert dev["pairs"][1] >= host["pairs"][1] and dev["pairs"][3] >= host["pairs"][3] and dev["pairs"][4] >= host["pairs"][4]
+        assert dev["pairs"][4] <= host["pairs"][4] + 5 and dev["pairs"][5] == host["pairs"][5]
+    # workspace far too small for the device-side allocator: the lanes go through the host-driven cascade (which batches)
+    small = _run(CKM_WORKERS="2", CKM_WORKER_MIN_PAIRS="1", CKM_WS_BUDGET_MB="16")
+    assert small["fallback"] >= 1 and small["rows"] == host["rows"]
