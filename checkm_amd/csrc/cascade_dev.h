@@ -14,18 +14,10 @@ namespace ckm {
 
 constexpr float LOG2E_F = 1.44269504088896341f, LN2_F = 0.69314718055994529f;
 
-// next entry of a queue for this wavefront (uniform result), or 0xffffffff when the queue is empty
-__device__ __forceinline__ uint32_t queue_next_index(const WorkQueue &q, int lane) {
-  uint32_t k = 0;
-  if (lane == 0) k = atomicAdd(q.head, 1u);
-  k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-  const uint32_t n = min(*q.count, q.cap);
-  return k < n ? k : 0xffffffffu;
-}
-__device__ __forceinline__ uint32_t queue_next(const WorkQueue &q, int lane) {
-  const uint32_t k = queue_next_index(q, lane);
-  return k == 0xffffffffu ? k : q.list[k];
-}
+// Entries of a queue: wavefront w of the W a launch starts takes entries w, w + W, w + 2W, ...  (The index comes from blockIdx /
+// threadIdx alone, so it is uniform by construction and lives in scalar registers; a dynamic take with atomicAdd + readfirstlane
+// was tried first and the compiler's structurizer turned it into a loop that never left the first entry.)
+__device__ __forceinline__ uint32_t queue_len(const WorkQueue &q) { return min(*q.count, q.cap); }
 
 // natural logarithm for the conservative tests only (v_log_f32, ~1 ulp in log2)
 __device__ __forceinline__ float approx_ln(float x) { return __log2f(x) * LN2_F; }

@@ -45,14 +45,14 @@ extern "C" int ckm_debug_stages(ckm_ctx *ctx_, const ckm_profiles *p, const ckm_
     HIPCHK(hipMemcpyAsync(ctx->cand.p, pr.data(), npairs * sizeof(PairRec), hipMemcpyHostToDevice, ctx->stream));
     std::map<int, std::vector<uint32_t>> vq;
     for (uint32_t i = 0; i < npairs; ++i) vq[p->prof[model[i]].vitQH].push_back(i);
-    // queue control words [count, head] for the exact-MSV launch and one pair per Viterbi register class
-    std::vector<uint32_t> qctl(2 + 2 * 64, 0u);
+    // queue lengths: the exact-MSV launch, then one per Viterbi register class
+    std::vector<uint32_t> qctl(2 + 64, 0u);
     qctl[0] = npairs;
-    { size_t k = 1; for (auto &kv : vq) { qctl[2 * k] = (uint32_t)kv.second.size(); ++k; } }
+    { size_t k = 1; for (auto &kv : vq) { qctl[k] = (uint32_t)kv.second.size(); ++k; } }
     ctx->vitq.ensure(qctl.size() * 4);
     uint32_t *qd = ctx->vitq.as<uint32_t>();
     HIPCHK(hipMemcpyAsync(qd, qctl.data(), qctl.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    launch_msv_full(ctx->stream, std::min<uint32_t>(npairs, 4096), WorkQueue{nullptr, qd, qd + 1, npairs}, ctx->cand.as<PairRec>(), dm, lt, res, off, dlen,
+    launch_msv_full(ctx->stream, std::min<uint32_t>(npairs, 4096), WorkQueue{nullptr, qd, npairs}, ctx->cand.as<PairRec>(), dm, lt, res, off, dlen,
                     ctx->fullx.as<int32_t>(), ctx->fullu.as<float>(), p->maxMp, nullptr);
     launch_bias(ctx->stream, ctx->cand.as<PairRec>(), npairs, dm, lt, res, off, dlen, ctx->raw.as<float>());
     HIPCHK(hipGetLastError());
@@ -69,7 +69,7 @@ extern "C" int ckm_debug_stages(ckm_ctx *ctx_, const ckm_profiles *p, const ckm_
       size_t k = 1;
       for (auto &g : vg) {
         const uint32_t cnt = (uint32_t)g.second.second;
-        if (launch_vit(g.first, std::min<uint32_t>((cnt + 3) / 4, 2048), ctx->stream, WorkQueue{ctx->fbidx.as<uint32_t>() + g.second.first, qd + 2 * k, qd + 2 * k + 1, cnt},
+        if (launch_vit(g.first, std::min<uint32_t>((cnt + 3) / 4, 2048), ctx->stream, WorkQueue{ctx->fbidx.as<uint32_t>() + g.second.first, qd + k, cnt},
                        ctx->cand.as<PairRec>(), dm, lt, res, off, dlen, ctx->vitx.as<int32_t>(), ctx->vits.as<float>(), nullptr, false, nullptr))
           throw Error(CKM_ERANGE, "no Viterbi kernel instance");
         ++k;

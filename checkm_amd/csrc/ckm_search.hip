@@ -277,17 +277,17 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
       // pass 1: the J-free fast kernel (exact, or a lower bound with its flag set); pass 2: the exact kernel for the pairs
       // whose bound fails F2 although the J state could have lifted them
       auto run_vit = [&](const std::vector<std::pair<int, std::pair<size_t, size_t>>> &grp, bool fast) {
-        std::vector<uint32_t> qctl(2 * grp.size(), 0u);             // [count, head] per register class
-        for (size_t k = 0; k < grp.size(); ++k) qctl[2 * k] = (uint32_t)grp[k].second.second;
+        std::vector<uint32_t> qctl(grp.size(), 0u);                 // queue length per register class
+        for (size_t k = 0; k < grp.size(); ++k) qctl[k] = (uint32_t)grp[k].second.second;
         ctx->vitq.ensure(qctl.size() * 4 + 16);
         wcopy(ctx, ctx->vitq.p, qctl.data(), qctl.size() * 4, hipMemcpyHostToDevice);
         int gi = 0;
         for (size_t k = grp.size(); k-- > 0; ++gi) {
           auto &g = grp[k];
-          uint32_t *qd = ctx->vitq.as<uint32_t>() + 2 * k;
+          uint32_t *qd = ctx->vitq.as<uint32_t>() + k;
           const uint32_t cnt = (uint32_t)g.second.second;
           if (launch_vit(g.first, std::min<uint32_t>((cnt + 3) / 4, 2048), ctx->side[gi % std::min(4, side_streams())],
-                         WorkQueue{ctx->fbidx.as<uint32_t>() + g.second.first, qd, qd + 1, cnt}, ctx->cand.as<PairRec>(), dm, lt, res, off, dlen,
+                         WorkQueue{ctx->fbidx.as<uint32_t>() + g.second.first, qd, cnt}, ctx->cand.as<PairRec>(), dm, lt, res, off, dlen,
                          ctx->vitx.as<int32_t>(), ctx->vits.as<float>(), ctx->vitf.as<uint32_t>(), fast, nullptr))
             throw Error(CKM_ERANGE, "no Viterbi kernel instance for this model length");
         }
@@ -459,10 +459,6 @@ namespace {
 template <class T> T *dev_table(DevBuf &b, size_t n) { b.ensure(std::max<size_t>(1, n) * sizeof(T)); return b.as<T>(); }
 template <class T> T *pin_table(PinnedBuf &b, size_t n) { b.ensure(std::max<size_t>(1, n) * sizeof(T)); return b.as<T>(); }
 
-constexpr int HD_MSV = 0, HD_VQ = 1, HD_VXQ = HD_VQ + NVC, HD_FQ = HD_VXQ + NVC, HD_BQ = HD_FQ + NFC, HD_EF = HD_BQ + NFC, HD_EB = HD_EF + NFC,
-              HD_EO = HD_EB + NFC, HD_RQ = HD_EO + NFC, HD_END = HD_RQ + NFC;
-static_assert(HD_END <= CC_SIZE, "head block too small");
-
 }  // namespace
 
 static bool cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles *p, const ckm_seqs *s, const SeqRange &rng,
@@ -526,8 +522,7 @@ static bool cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_prof
     if (ctx->ws.cap < want) ctx->ws.ensure(want);
   }
   const uint64_t ws_floats = ctx->ws.cap / 4;
-  uint32_t *d_cnt = dev_table<uint32_t>(ctx->c_cnt, 2 * CC_SIZE);
-  uint32_t *d_head = d_cnt + CC_SIZE;
+  uint32_t *d_cnt = dev_table<uint32_t>(ctx->c_cnt, CC_SIZE);
   unsigned long long *d_tops = dev_table<unsigned long long>(ctx->c_tops, 4);
   CascadeDev cd; memset(&cd, 0, sizeof(cd));
   cd.cand = dev_table<PairRec>(ctx->c_cand, cp.cand); cd.cap_cand = cp.cand;
@@ -614,7 +609,7 @@ static bool cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_prof
     owner->ssv_cv.wait(lock, [&] { return owner->ssv_turn == my_turn; });
   }
   CKM_TRACE_PT("ssv turn taken");
-  HIPCHK(hipMemsetAsync(d_cnt, 0, 2 * CC_SIZE * sizeof(uint32_t), ms));
+  HIPCHK(hipMemsetAsync(d_cnt, 0, CC_SIZE * sizeof(uint32_t), ms));
   HIPCHK(hipMemsetAsync(d_tops, 0, 4 * sizeof(unsigned long long), ms));
   if (owner->ssv_prev_done) HIPCHK(hipStreamWaitEvent(ms, owner->ssv_prev_done, 0));     // previous lane's SSV launches
   HIPCHK(hipEventRecord(ctx->ev[0], ms));
@@ -649,9 +644,13 @@ static bool cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_prof
   HIPCHK(hipGetLastError());
   CKM_TRACE_PT("ssv queued");
 
+  // (diagnostics: CKM_CHAIN_STOP=n queues only the first n stages of the chain, prints the device counters and hands the lane to the
+  //  host-driven cascade: 1 SSV, 2 exact MSV, 3 bias filter, 4 Viterbi fast, 5 Viterbi exact, 6 Forward parser, 7 Backward parser, 8 regions,
+  //  9-11 envelope Forward / Backward / OA, 12 region Forward, 13 ensembles)
+  const int stop = getenv("CKM_CHAIN_STOP") ? atoi(getenv("CKM_CHAIN_STOP")) : 99;
   // ---- exact MSV of the pairs SSV could not decide, bias filter (+ F1/F2 decisions) ----
-  launch_msv_full(ms, 2048, WorkQueue{nullptr, d_cnt + CC_NORES, d_head + HD_MSV, cp.nores}, d_nores, dm, lt, res, off, dlen, nullptr, nullptr, p->maxMp, &cd);
-  launch_bias_filter(ms, 2048, cd, dm, lt, res, off);
+  if (stop >= 2) launch_msv_full(ms, 2048, WorkQueue{nullptr, d_cnt + CC_NORES, cp.nores}, d_nores, dm, lt, res, off, dlen, nullptr, nullptr, p->maxMp, &cd);
+  if (stop >= 3) launch_bias_filter(ms, 2048, cd, dm, lt, res, off);
   // ---- Viterbi filter: per register class, fast kernel then exact kernel on one stream ----
   HIPCHK(hipEventRecord(ctx->cev[2], ms));
   for (int k = 0; k < NS; ++k) HIPCHK(hipStreamWaitEvent(ctx->side[k], ctx->cev[2], 0));
@@ -659,10 +658,10 @@ static bool cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_prof
     int gi = 0;
     for (int c = NVC - 1; c >= 0; --c) if (vit_present[c]) {
       hipStream_t sv = ctx->side[gi++ % NS];
-      if (launch_vit(kVitQH[c], 2048, sv, WorkQueue{cd.vq + (size_t)c * cp.vq, d_cnt + CC_VQ + c, d_head + HD_VQ + c, cp.vq}, cd.cand, dm, lt, res, off, dlen,
-                     nullptr, nullptr, nullptr, true, &cd) ||
-          launch_vit(kVitQH[c], 1024, sv, WorkQueue{cd.vxq + (size_t)c * cp.vq, d_cnt + CC_VXQ + c, d_head + HD_VXQ + c, cp.vq}, cd.cand, dm, lt, res, off, dlen,
-                     nullptr, nullptr, nullptr, false, &cd))
+      if ((stop >= 4 && launch_vit(kVitQH[c], 2048, sv, WorkQueue{cd.vq + (size_t)c * cp.vq, d_cnt + CC_VQ + c, cp.vq}, cd.cand, dm, lt, res, off, dlen,
+                                   nullptr, nullptr, nullptr, true, &cd)) ||
+          (stop >= 5 && launch_vit(kVitQH[c], 1024, sv, WorkQueue{cd.vxq + (size_t)c * cp.vq, d_cnt + CC_VXQ + c, cp.vq}, cd.cand, dm, lt, res, off, dlen,
+                                   nullptr, nullptr, nullptr, false, &cd)))
         throw Error(CKM_ERANGE, "no Viterbi kernel instance for this model length");
     }
   }
@@ -675,30 +674,36 @@ static bool cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_prof
     for (int c = NFC - 1; c >= 0; --c) if (fb_present[c]) {
       hipStream_t sf = ctx->side[gi++ % NS];
       const int Q = kFbQ[c];
-      const WorkQueue qf{cd.fq + (size_t)c * cp.fwork, d_cnt + CC_FQ + c, d_head + HD_FQ + c, cp.fwork};
-      const WorkQueue qb{cd.bq + (size_t)c * cp.fwork, d_cnt + CC_BQ + c, d_head + HD_BQ + c, cp.fwork};
-      const WorkQueue qef{cd.eq + (size_t)c * cp.ework, d_cnt + CC_EQ + c, d_head + HD_EF + c, cp.ework};
-      const WorkQueue qeb{qef.list, qef.count, d_head + HD_EB + c, cp.ework}, qeo{qef.list, qef.count, d_head + HD_EO + c, cp.ework};
-      const WorkQueue qr{cd.rq + (size_t)c * cp.rwork, d_cnt + CC_RQ + c, d_head + HD_RQ + c, cp.rwork};
+      const WorkQueue qf{cd.fq + (size_t)c * cp.fwork, d_cnt + CC_FQ + c, cp.fwork};
+      const WorkQueue qb{cd.bq + (size_t)c * cp.fwork, d_cnt + CC_BQ + c, cp.fwork};
+      const WorkQueue qef{cd.eq + (size_t)c * cp.ework, d_cnt + CC_EQ + c, cp.ework};
+      const WorkQueue qeb = qef, qeo = qef;
+      const WorkQueue qr{cd.rq + (size_t)c * cp.rwork, d_cnt + CC_RQ + c, cp.rwork};
       int rc = 0;
-      rc |= launch_fwd(Q, 4096, sf, qf, cd.fwork, dm, lt, res, off, ws, d_fout_f, h_events_f, d_cnt + CC_EVENTS, cp.events_f, &cd);
-      rc |= launch_bwd(Q, 4096, sf, qb, cd.fwork, dm, lt, res, off, ws, d_fout_f, nullptr);
-      launch_regions(sf, 256, qb.list, qb.count, cp.fwork, cd.fwork, cd, dm, ws);
-      rc |= launch_fwd(Q, 4096, sf, qef, cd.ework, dm, lt, res, off, ws, d_fout_e, h_events_e, d_cnt + CC_EVENTS_E, cp.events_e, nullptr);
-      rc |= launch_bwd(Q, 4096, sf, qeb, cd.ework, dm, lt, res, off, ws, d_fout_e, d_rerr_e);
-      rc |= launch_oa(Q, 4096, sf, qeo, cd.ework, dm, ws, d_rerr_e, d_fout_e, h_envout);
-      rc |= launch_fwd(Q, 1024, sf, qr, cd.rwork, dm, lt, res, off, ws, d_fout_r, d_events_r, d_cnt + CC_EVENTS_R, 1 << 16, nullptr);
+      if (stop >= 6) rc |= launch_fwd(Q, 4096, sf, qf, cd.fwork, dm, lt, res, off, ws, d_fout_f, h_events_f, d_cnt + CC_EVENTS, cp.events_f, &cd);
+      if (stop >= 7) rc |= launch_bwd(Q, 4096, sf, qb, cd.fwork, dm, lt, res, off, ws, d_fout_f, nullptr);
+      if (stop >= 8) launch_regions(sf, 256, qb.list, qb.count, cp.fwork, cd.fwork, cd, dm, ws);
+      if (stop >= 9) rc |= launch_fwd(Q, 4096, sf, qef, cd.ework, dm, lt, res, off, ws, d_fout_e, h_events_e, d_cnt + CC_EVENTS_E, cp.events_e, nullptr);
+      if (stop >= 10) rc |= launch_bwd(Q, 4096, sf, qeb, cd.ework, dm, lt, res, off, ws, d_fout_e, d_rerr_e);
+      if (stop >= 11) rc |= launch_oa(Q, 4096, sf, qeo, cd.ework, dm, ws, d_rerr_e, d_fout_e, h_envout);
+      if (stop >= 12) rc |= launch_fwd(Q, 1024, sf, qr, cd.rwork, dm, lt, res, off, ws, d_fout_r, d_events_r, d_cnt + CC_EVENTS_R, 1 << 16, nullptr);
       if (rc) throw Error(CKM_ERANGE, "no Forward/Backward kernel instance for this model length");
     }
   }
   for (int k = 0; k < NS; ++k) { HIPCHK(hipEventRecord(ctx->cls_ev[k], ctx->side[k])); HIPCHK(hipStreamWaitEvent(ms, ctx->cls_ev[k], 0)); }
   // ---- trace ensembles of the multi-domain regions, results exported to pinned memory; counters last ----
-  launch_ensemble(ms, cd.ens, d_cnt + CC_RWORK, cp.rwork, 128, p->maxMp, dm, lt, res, off, ws, ctx->ensseeds.as<uint32_t>(), h_hens);
+  if (stop >= 13) launch_ensemble(ms, cd.ens, d_cnt + CC_RWORK, cp.rwork, 128, p->maxMp, dm, lt, res, off, ws, ctx->ensseeds.as<uint32_t>(), h_hens);
   HIPCHK(hipMemcpyAsync(h_cnt, d_cnt, CC_SIZE * sizeof(uint32_t), hipMemcpyDeviceToHost, ms));
   HIPCHK(hipGetLastError());
   CKM_TRACE_PT("chain queued");
   HIPCHK(hipStreamSynchronize(ms));                           // ---- the one synchronisation of the lane ----
   CKM_TRACE_PT("chain drained");
+  if (stop < 99) {
+    fprintf(stderr, "ckm-chain w%d stop=%d:", ctx->id, stop);
+    for (int k = 0; k < CC_END; ++k) if (h_cnt[k]) fprintf(stderr, " c%d=%u", k, h_cnt[k]);
+    fprintf(stderr, "\n");
+    return false;
+  }
   { float msv = 0.f; HIPCHK(hipEventElapsedTime(&msv, ctx->ev[0], ctx->ev[1])); st.ms_ssv = msv; }
   const double t_host0 = now_ms();
   st.ms_filters = t_host0 - t_start;          // (queueing + the whole device chain: the stages are no longer separable by host clocks)

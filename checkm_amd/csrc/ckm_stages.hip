@@ -51,7 +51,7 @@ int ssv_threads_for(int Q) {
 }
 
 // Work-groups a launch of the persistent Forward/Backward kernels starts for n queued items: one wavefront each, at most what the
-// device holds at once (256 CUs x a few wavefronts per SIMD); every wavefront keeps taking items until the queue is empty.
+// device holds at once (256 CUs x a few wavefronts per SIMD); the wavefronts share the queue by striding.
 uint32_t fb_grid(size_t n) { return (uint32_t)std::min<size_t>(n, 8192); }
 
 void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, bool do_fwd, bool do_bwd, bool do_oa,
@@ -75,9 +75,8 @@ void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, b
     groups.push_back({it->first, items.size(), v.size()});
     items.insert(items.end(), v.begin(), v.end());
   }
-  // queue control block per group and stage: [count, head_fwd, head_bwd, head_oa]
-  std::vector<uint32_t> qc(groups.size() * 4, 0u);
-  for (size_t g = 0; g < groups.size(); ++g) qc[g * 4] = (uint32_t)groups[g].count;
+  std::vector<uint32_t> qc(groups.size(), 0u);           // queue lengths
+  for (size_t g = 0; g < groups.size(); ++g) qc[g] = (uint32_t)groups[g].count;
   ctx->fbidx.ensure(items.size() * 4 + 16); ctx->fbmodel.ensure(qc.size() * 4 + 16);
   HIPCHK(hipMemcpyAsync(ctx->fbidx.p, items.data(), items.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->fbmodel.p, qc.data(), qc.size() * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -100,15 +99,15 @@ void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, b
   for (size_t g = 0; g < groups.size(); ++g) {
     const Group &gr = groups[g];
     hipStream_t st = ctx->side[gi++ % side_streams()];
-    uint32_t *qcd = ctx->fbmodel.as<uint32_t>() + g * 4;
+    uint32_t *qcd = ctx->fbmodel.as<uint32_t>() + g;
     const uint32_t *lst = ctx->fbidx.as<uint32_t>() + gr.first;
     const uint32_t nb = fb_grid(gr.count);
-    if (do_fwd && launch_fwd(gr.Q, nb, st, WorkQueue{lst, qcd, qcd + 1, (uint32_t)gr.count}, ctx->fbwork.as<FbWork>(), dm, lt, res, off, ws, ctx->fout.as<FwdOut>(),
+    if (do_fwd && launch_fwd(gr.Q, nb, st, WorkQueue{lst, qcd, (uint32_t)gr.count}, ctx->fbwork.as<FbWork>(), dm, lt, res, off, ws, ctx->fout.as<FwdOut>(),
                              ctx->events.as<ScaleEvent>(), ctx->counters.as<uint32_t>(), cap_events, nullptr))
       throw Error(CKM_ERANGE, "no Forward kernel instance for this model length");
-    if (do_bwd && launch_bwd(gr.Q, nb, st, WorkQueue{lst, qcd, qcd + 2, (uint32_t)gr.count}, ctx->fbwork.as<FbWork>(), dm, lt, res, off, ws, ctx->fout.as<FwdOut>(), ctx->rerr.as<int32_t>()))
+    if (do_bwd && launch_bwd(gr.Q, nb, st, WorkQueue{lst, qcd, (uint32_t)gr.count}, ctx->fbwork.as<FbWork>(), dm, lt, res, off, ws, ctx->fout.as<FwdOut>(), ctx->rerr.as<int32_t>()))
       throw Error(CKM_ERANGE, "no Backward kernel instance for this model length");
-    if (do_oa && launch_oa(gr.Q, nb, st, WorkQueue{lst, qcd, qcd + 3, (uint32_t)gr.count}, ctx->fbwork.as<FbWork>(), dm, ws, ctx->rerr.as<int32_t>(), ctx->fout.as<FwdOut>(), ctx->envout.as<EnvOut>()))
+    if (do_oa && launch_oa(gr.Q, nb, st, WorkQueue{lst, qcd, (uint32_t)gr.count}, ctx->fbwork.as<FbWork>(), dm, ws, ctx->rerr.as<int32_t>(), ctx->fout.as<FwdOut>(), ctx->envout.as<EnvOut>()))
       throw Error(CKM_ERANGE, "no OA kernel instance for this model length");
   }
   HIPCHK(hipGetLastError());

@@ -72,9 +72,10 @@ struct FbWork {              // one Forward/Backward/OA work item (whole sequenc
   uint32_t cand, pass;                 // device-driven cascade: candidate id of a parser item; id of its record in the pass table
 };
 
-// A queue of work-item indices consumed by a persistent kernel: wavefronts take entries with atomicAdd(head) until *count.
-// Host-built queues (alignment requests, diagnostics, second envelope rounds) and device-built ones (the cascade) look alike.
-struct WorkQueue { const uint32_t *list; const uint32_t *count; uint32_t *head; uint32_t cap; };
+// A queue of work-item indices consumed by a persistent kernel: the wavefronts of a launch share its entries by striding (wavefront w
+// of W takes entries w, w + W, ...) up to min(*count, cap).  Host-built queues (alignment requests, diagnostics, second envelope
+// rounds) and device-built ones (the cascade: only the device knows *count when the kernel is launched) look alike.
+struct WorkQueue { const uint32_t *list; const uint32_t *count; uint32_t cap; };
 
 constexpr int ENS_NSAMPLES = 200;     // stochastic tracebacks per multi-domain region (HMMER's default)
 

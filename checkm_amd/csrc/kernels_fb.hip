@@ -104,9 +104,9 @@ __global__ void __launch_bounds__(64) fwd_kernel(WorkQueue queue, FbWork *__rest
   constexpr int Mp = Q * 64;
   const int lane = threadIdx.x;
   uint32_t cur_model = 0xffffffffu;
- for (;;) {
-  const uint32_t item = queue_next(queue, lane);
-  if (item == 0xffffffffu) break;
+ const uint32_t nqueue = queue_len(queue);
+ for (uint32_t qk = blockIdx.x; qk < nqueue; qk += gridDim.x) {
+  const uint32_t item = queue.list[qk];
   const FbWork w = work[item];
   const DevModel &md = models[w.model];
   if (w.model != cur_model) { load_tr<Q>(lds, md.ftr); cur_model = w.model; }
@@ -224,9 +224,9 @@ __global__ void __launch_bounds__(64) bwd_kernel(WorkQueue queue, const FbWork *
   constexpr int Mp = Q * 64;
   const int lane = threadIdx.x;
   uint32_t cur_model = 0xffffffffu;
- for (;;) {
-  const uint32_t item = queue_next(queue, lane);
-  if (item == 0xffffffffu) break;
+ const uint32_t nqueue = queue_len(queue);
+ for (uint32_t qk = blockIdx.x; qk < nqueue; qk += gridDim.x) {
+  const uint32_t item = queue.list[qk];
   const FbWork w = work[item];
   const DevModel &md = models[w.model];
   if (w.model != cur_model) { load_tr<Q>(lds, md.ftr); cur_model = w.model; }
@@ -399,9 +399,9 @@ __global__ void __launch_bounds__(64) oa_kernel(WorkQueue queue, const FbWork *_
   constexpr int Mp = Q * 64;
   const int lane = threadIdx.x;
   uint32_t cur_model = 0xffffffffu;
- for (;;) {
-  const uint32_t item = queue_next(queue, lane);
-  if (item == 0xffffffffu) break;
+ const uint32_t nqueue = queue_len(queue);
+ for (uint32_t qk = blockIdx.x; qk < nqueue; qk += gridDim.x) {
+  const uint32_t item = queue.list[qk];
   const FbWork w = work[item];
   const DevModel &md = models[w.model];
   if (w.model != cur_model) { load_gates<Q>(lds, md.ftr); cur_model = w.model; }

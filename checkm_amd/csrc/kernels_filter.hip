@@ -91,9 +91,8 @@ __global__ void __launch_bounds__(64) msv_full_kernel(WorkQueue queue, const Pai
                                                      CascadeDev cd, int decide) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
- for (;;) {
-  const uint32_t pi = queue_next_index(queue, lane);
-  if (pi == 0xffffffffu) break;
+ const uint32_t nqueue = queue_len(queue);
+ for (uint32_t pi = blockIdx.x; pi < nqueue; pi += gridDim.x) {
   __syncthreads();
   const PairRec pr = pairs[pi];
   const DevModel &md = models[pr.model];
@@ -247,7 +246,7 @@ __device__ __forceinline__ u32 stripe_shift(u32 v) {
 // reduction: the rows only feed a running element-wise maximum.  The result is exact when max xE + E->J <= base (flag 0);
 // otherwise it is a LOWER bound of the exact score (max / saturating add are monotone in xB) and flag = 1: the caller
 // accepts the pair if the bound already passes F2 and re-runs the exact kernel if it does not.
-// Every wavefront of the 4-wave workgroup takes candidate ids from the queue on its own.  With `decide` the kernel is a stage of the
+// Every wavefront of the 4-wave workgroups takes its share of the queue's candidate ids.  With `decide` the kernel is a stage of the
 // device-driven cascade and its epilogue takes the F2 decision (conservative band of cd.margin_vit bits around the threshold; the
 // host repeats the test exactly on the recorded score):
 //   FAST   score + F2 margin passes -> Forward;  J flag set (score is only a lower bound) -> exact queue of the same class;
@@ -260,9 +259,9 @@ __global__ void __launch_bounds__(256) vit_kernel(WorkQueue queue, const PairRec
                                                   const int32_t *__restrict__ seq_len, int32_t *__restrict__ out_xC, float *__restrict__ out_sc,
                                                   uint32_t *__restrict__ out_flag, CascadeDev cd, int decide) {
   const int lane = threadIdx.x & 63;
- for (;;) {
-  const uint32_t pi = queue_next(queue, lane);
-  if (pi == 0xffffffffu) break;
+ const uint32_t nqueue = queue_len(queue);
+ for (uint32_t qk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); qk < nqueue; qk += gridDim.x * (blockDim.x >> 6)) {
+  const uint32_t pi = queue.list[qk];
   const PairRec pr = pairs[pi];
   const DevModel &md = models[pr.model];
   constexpr int ROW = QH * 64;                      // u32 words per table row
