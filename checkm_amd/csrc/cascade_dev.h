@@ -26,13 +26,13 @@ __device__ __forceinline__ float approx_ln(float x) { return __log2f(x) * LN2_F;
 __device__ __forceinline__ bool ws_alloc(const CascadeDev &cd, unsigned long long n, unsigned long long &off) {
   n = (n + 31ull) & ~31ull;
   off = atomicAdd(cd.ws_top, n);
-  if (off + n > cd.ws_cap) { atomicOr(&cd.cnt[CC_STATUS], (uint32_t)CS_WS); return false; }
+  if (off + n > cd.ws_cap) { atomicOr(&cd.gcnt[CC_STATUS], (uint32_t)CS_WS); return false; }
   return true;
 }
 
 __device__ __forceinline__ void queue_push(const CascadeDev &cd, uint32_t *lists, int counter, int cls, uint32_t cap, uint32_t value, uint32_t overflow_bit) {
   const uint32_t pos = atomicAdd(&cd.cnt[counter + cls], 1u);
-  if (pos < cap) lists[(size_t)cls * cap + pos] = value; else atomicOr(&cd.cnt[CC_STATUS], overflow_bit);
+  if (pos < cap) lists[(size_t)cls * cap + pos] = value; else atomicOr(&cd.gcnt[CC_STATUS], overflow_bit);
 }
 
 // A candidate that passed the Viterbi stage (or skipped it) becomes a whole-sequence Forward parser item: special rows in the
@@ -41,8 +41,8 @@ __device__ __forceinline__ void pass_to_forward(const CascadeDev &cd, const DevM
   const int L = cd.seq_len[seq];
   unsigned long long off;
   if (!ws_alloc(cd, (unsigned long long)(L + 1) * 6ull, off)) return;
-  const uint32_t t = atomicAdd(&cd.cnt[CC_FWORK], 1u);
-  if (t >= cd.cap_fwork) { atomicOr(&cd.cnt[CC_STATUS], (uint32_t)CS_FWORK); return; }
+  const uint32_t t = atomicAdd(&cd.gcnt[CC_FWORK], 1u);
+  if (t >= cd.cap_fwork) { atomicOr(&cd.gcnt[CC_STATUS], (uint32_t)CS_FWORK); return; }
   FbWork w;
   w.model = model; w.seq = seq; w.i0 = 0; w.Ld = L; w.Lcfg = L; w.multihit = 1;
   w.xs_off = off; w.aux_off = 0; w.mxf_off = 0; w.mxb_off = 0; w.path_off = 0;

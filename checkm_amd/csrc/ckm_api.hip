@@ -69,11 +69,12 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
       // non-blocking streams: nothing here may synchronise implicitly with the null stream or with another worker's streams
       HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
       w.nside = nside;
-      for (int k = 0; k < 8; ++k) { if (k < nside) HIPCHK(hipStreamCreateWithFlags(&w.side[k], hipStreamNonBlocking)); else w.side[k] = w.side[k % nside]; }
+      for (int k = 0; k < 16; ++k) { if (k < nside) HIPCHK(hipStreamCreateWithFlags(&w.side[k], hipStreamNonBlocking)); else w.side[k] = w.side[k % nside]; }
       w.ens_stream = w.side[nside - 1];
       for (auto &e : w.ev) HIPCHK(hipEventCreate(&e));
       for (auto &e : w.cev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       for (auto &e : w.cls_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      for (auto &e : w.grp_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       memset(&w.stats, 0, sizeof(w.stats));
       w.ws_budget = budget;
       w.pool.reset(new HostPool(host_threads));
@@ -91,6 +92,7 @@ extern "C" void ckm_ctx_destroy(ckm_ctx *ctx) {
     for (auto &e : w.ev) (void)hipEventDestroy(e);
     for (auto &e : w.cev) if (e) (void)hipEventDestroy(e);
     for (auto &e : w.cls_ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : w.grp_ev) if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < w.nside; ++k) (void)hipStreamDestroy(w.side[k]);
     (void)hipStreamDestroy(w.stream);
   }

@@ -451,8 +451,9 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
 // the filter decisions conservatively, the region scan and the workspace allocation of the envelope stage run on the device -- and
 // the host synchronises ONCE, when the chain has drained, to take the decisions again exactly (libm) and assemble the rows.
 // A second, short round follows only for the envelopes that come out of the trace ensembles (clustered on the host).
-// Returns false when a table or the workspace was too small for this search: the caller then runs the lane through the
-// host-driven cascade (which batches by workspace) and the grown capacities serve the next call.
+// Returns 0 when done; 1 when a table or the workspace was too small for this search (the lane's SSV turn has been taken): the caller
+// then runs the lane through the host-driven cascade (which batches by workspace) and the grown capacities serve the next call;
+// 2 when the search was not attempted (more pairs than one SSV pass holds): host-driven cascade, turn still to be taken.
 // ---------------------------------------------------------------------------------------------------------------------------
 namespace {
 
@@ -461,7 +462,7 @@ template <class T> T *pin_table(PinnedBuf &b, size_t n) { b.ensure(std::max<size
 
 }  // namespace
 
-static bool cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles *p, const ckm_seqs *s, const SeqRange &rng,
+static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles *p, const ckm_seqs *s, const SeqRange &rng,
                         const std::vector<uint32_t> &my_models, const std::vector<std::vector<uint32_t>> &model_bins, HitMap &by_bin_model) {
   HIPCHK(hipSetDevice(ctx->device));
   const double t_start = now_ms();
@@ -478,43 +479,94 @@ static bool cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_prof
     ~TurnGuard() { if (*took) return; std::unique_lock<std::mutex> l(o->ssv_mutex); o->ssv_cv.wait(l, [&] { return o->ssv_turn == t; }); o->ssv_turn++; o->ssv_cv.notify_all(); }
   } turn_guard{owner, my_turn, &took_turn};
 
-  // ---- the lane's pairs, SSV chunks (pair budget), register classes present ----
+  // ---- the lane's pairs; a search with more pairs than the SSV budget goes through the host-driven cascade (it works chunk by chunk) ----
   uint64_t pair_budget = (uint64_t)1 << 29;
   if (const char *e = getenv("CKM_PAIR_BUDGET")) pair_budget = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
   struct MW { uint32_t model; uint64_t pair_base; uint64_t npairs; };
-  std::vector<std::vector<MW>> chunks; std::vector<uint64_t> chunk_pairs;
+  std::vector<MW> mws;
   uint64_t total_pairs = 0;
-  bool vit_present[NVC] = {false}, fb_present[NFC] = {false};
-  {
-    std::vector<MW> cur; uint64_t np = 0;
-    for (uint32_t m1 : my_models) {
-      uint64_t n = 0;
-      for (uint32_t b : model_bins[m1]) n += rng.hi[b] - rng.lo[b];
-      if (n == 0) continue;
-      if (np + n > pair_budget && !cur.empty()) { chunks.push_back(cur); chunk_pairs.push_back(np); cur.clear(); np = 0; }
-      cur.push_back({m1, np, n}); np += n; total_pairs += n;
-      vit_present[p->dm[m1].vit_cls] = true; fb_present[p->dm[m1].fb_cls] = true;
-    }
-    if (!cur.empty()) { chunks.push_back(cur); chunk_pairs.push_back(np); }
+  for (uint32_t m1 : my_models) {
+    uint64_t n = 0;
+    for (uint32_t b : model_bins[m1]) n += rng.hi[b] - rng.lo[b];
+    if (n == 0) continue;
+    mws.push_back({m1, total_pairs, n}); total_pairs += n;
   }
-  if (total_pairs == 0) { st.ms_total = now_ms() - t_start; return true; }
+  if (total_pairs == 0) { st.ms_total = now_ms() - t_start; return 0; }
+  if (total_pairs > pair_budget) return 2;
 
-  // ---- capacities (grow-only per worker) and tables ----
+  // ---- SSV block table, grouped by SSV register class = model length class (cached when the previous call on this worker had the same
+  // plan: lineage_wf scans the same bins twice, bench repeats steps).  Each group is one SSV launch AND one sub-cascade: its survivors
+  // go down their own chain of queues as soon as that launch is done, while the SSV launches of the other groups still run. ----
+  hipStream_t ms = ctx->stream;
+  std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;
+  {
+    std::vector<uint64_t> key{p->uid, s->uid, pair_budget, 0ull, rng.tag, 0xdeull};
+    for (auto &mw : mws) { key.push_back(0xffffffffull + mw.model); for (uint32_t b : model_bins[mw.model]) key.push_back(b); }
+    if (key == ctx->plan_key) {
+      groups = ctx->plan_groups;
+      st.pairs_ssv += ctx->plan_pairs; st.residue_hmm += ctx->plan_residue_hmm; st.cells_ssv += ctx->plan_cells;
+    } else {
+      std::map<int, std::vector<SsvBlockWork>> byQ;
+      uint64_t c_pairs = 0, c_res = 0, c_cells = 0;
+      for (auto &mw : mws) {
+        const int Q = p->prof[mw.model].ssvQ; const int threads = ssv_threads_for(Q); const uint32_t per_block = (uint32_t)threads / 64 * 4 * 4;
+        uint64_t pb = mw.pair_base;
+        for (uint32_t b : model_bins[mw.model]) {
+          const uint32_t o0 = rng.lo[b], n = rng.hi[b] - o0;
+          for (uint32_t a = 0; a < n; a += per_block) {
+            SsvBlockWork w; w.model = mw.model; w.list_start = o0 + a; w.count = std::min(per_block, n - a); w.pair_start = (uint32_t)(pb + a);
+            byQ[Q].push_back(w);
+          }
+          pb += n; c_res += rng.res[b]; c_cells += rng.res[b] * (uint64_t)p->prof[mw.model].M;
+        }
+        c_pairs += mw.npairs;
+      }
+      st.pairs_ssv += c_pairs; st.residue_hmm += c_res; st.cells_ssv += c_cells;
+      std::vector<SsvBlockWork> allw;
+      for (auto &kv : byQ) {
+        // longest blocks first inside a launch (a block's time is set by its first = longest sequence)
+        std::stable_sort(kv.second.begin(), kv.second.end(), [&](const SsvBlockWork &x, const SsvBlockWork &y) {
+          return s->len[s->order[x.list_start]] > s->len[s->order[y.list_start]]; });
+        groups.push_back({kv.first, {allw.size(), kv.second.size()}}); allw.insert(allw.end(), kv.second.begin(), kv.second.end());
+      }
+      ctx->work.ensure(allw.size() * sizeof(SsvBlockWork));
+      HIPCHK(hipMemcpyAsync(ctx->work.p, allw.data(), allw.size() * sizeof(SsvBlockWork), hipMemcpyHostToDevice, ms));
+      HIPCHK(hipStreamSynchronize(ms));            // allw goes out of scope (pageable source); nothing of this search is queued on ms yet
+      ctx->plan_key = key; ctx->plan_groups = groups; ctx->plan_nblocks = allw.size(); ctx->plan_pairs = c_pairs; ctx->plan_residue_hmm = c_res; ctx->plan_cells = c_cells;
+    }
+  }
+  // per group: its pairs and the Viterbi / Forward register classes of its models
+  struct Sub { int Q; size_t first, nblocks; uint64_t pairs = 0; bool vit[NVC] = {false}, fb[NFC] = {false};
+               uint32_t cap_cand = 0, cap_nores = 0, cap_f = 0, cap_e = 0, cap_r = 0; size_t o_cand = 0, o_nores = 0, o_vq = 0, o_f = 0, o_e = 0, o_r = 0; };
+  std::vector<Sub> subs;
+  {
+    std::map<int, size_t> at;
+    for (auto &g : groups) { Sub sb; sb.Q = g.first; sb.first = g.second.first; sb.nblocks = g.second.second; at[g.first] = subs.size(); subs.push_back(sb); }
+    for (auto &mw : mws) { Sub &sb = subs[at[p->prof[mw.model].ssvQ]]; sb.pairs += mw.npairs; sb.vit[p->dm[mw.model].vit_cls] = true; sb.fb[p->dm[mw.model].fb_cls] = true; }
+  }
+  const size_t NG = subs.size();
+  if (NG > 32) return 2;
+
+  // ---- capacities: shares of the pairs (the divisors halve when a table overflowed on an earlier call), tables ----
   Worker::CascadeCaps &cp = ctx->caps;
+  size_t tot_cand = 0, tot_nores = 0, tot_f = 0, tot_e = 0, tot_r = 0;
+  for (Sub &sb : subs) {
+    sb.cap_cand = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096, sb.pairs / cp.div_cand), 0x7ffffff0ull);
+    sb.cap_nores = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2048, sb.pairs / cp.div_nores), 0x7ffffff0ull);
+    sb.cap_f = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2048, sb.pairs / cp.div_fwork), 0x7ffffff0ull);
+    sb.cap_e = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1024, sb.pairs / cp.div_ework), 0x7ffffff0ull);
+    sb.cap_r = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(256, sb.pairs / cp.div_rwork), 0x7ffffff0ull);
+    sb.o_cand = tot_cand; tot_cand += sb.cap_cand; sb.o_nores = tot_nores; tot_nores += sb.cap_nores;
+    sb.o_vq = sb.o_cand * NVC;
+    sb.o_f = tot_f * NFC; tot_f += sb.cap_f; sb.o_e = tot_e * NFC; tot_e += sb.cap_e; sb.o_r = tot_r * NFC; tot_r += sb.cap_r;
+  }
   auto grow = [](uint32_t &v, uint64_t want) { if (v < want) v = (uint32_t)std::min<uint64_t>(want, 0xfffffff0ull); };
-  grow(cp.cand, std::max<uint64_t>(1 << 16, total_pairs / 12));
-  grow(cp.nores, std::max<uint64_t>(1 << 14, total_pairs / 48));
-  grow(cp.vq, cp.cand);
-  grow(cp.fwork, std::max<uint64_t>(1 << 14, total_pairs / 96));
-  grow(cp.pass, std::max<uint64_t>(1 << 13, total_pairs / 256));
-  grow(cp.ework, std::max<uint64_t>(1 << 13, total_pairs / 256));
-  grow(cp.rwork, std::max<uint64_t>(1 << 10, total_pairs / 4096));
-  grow(cp.reg, (uint64_t)cp.ework + cp.rwork);
+  grow(cp.fwork, tot_f); grow(cp.ework, tot_e); grow(cp.rwork, tot_r);
+  grow(cp.pass, std::max<uint64_t>(1 << 13, tot_e)); grow(cp.reg, (uint64_t)cp.ework + cp.rwork);
   grow(cp.events_f, std::max<uint64_t>(1 << 18, (uint64_t)cp.fwork * 16));
   grow(cp.events_e, std::max<uint64_t>(1 << 16, (uint64_t)cp.ework * 16));
   cp.hens = std::max<uint64_t>(cp.hens, (uint64_t)cp.rwork * (256 + ENS_NSAMPLES * 16 * 4 + 1024));
-  uint64_t maxchunk = 0; for (uint64_t c : chunk_pairs) maxchunk = std::max(maxchunk, c);
-  ctx->maxv.ensure(maxchunk * 2 + 64);
+  ctx->maxv.ensure(total_pairs * 2 + 64);
   // the float workspace: an estimate from the pairs (special rows of ~0.3 % of them, matrices of ~0.06 %), within the lane's budget
   {
     const uint64_t est = (uint64_t)((double)total_pairs * 2600.0) + ((uint64_t)256 << 20);
@@ -522,207 +574,157 @@ static bool cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_prof
     if (ctx->ws.cap < want) ctx->ws.ensure(want);
   }
   const uint64_t ws_floats = ctx->ws.cap / 4;
-  uint32_t *d_cnt = dev_table<uint32_t>(ctx->c_cnt, CC_SIZE);
+  uint32_t *d_gcnt = dev_table<uint32_t>(ctx->c_cnt, (NG + 1) * CC_SIZE);        // block 0: counters shared by the groups; block 1 + g: group g's
   unsigned long long *d_tops = dev_table<unsigned long long>(ctx->c_tops, 4);
-  CascadeDev cd; memset(&cd, 0, sizeof(cd));
-  cd.cand = dev_table<PairRec>(ctx->c_cand, cp.cand); cd.cap_cand = cp.cand;
-  PairRec *d_nores = dev_table<PairRec>(ctx->c_nores, cp.nores);
-  cd.bias_raw = dev_table<float>(ctx->c_bias, (size_t)cp.cand * 2);
-  cd.vit_fast = dev_table<float>(ctx->c_vfast, cp.cand); cd.vit_exact = dev_table<float>(ctx->c_vexact, cp.cand);
-  cd.vit_flag = dev_table<uint32_t>(ctx->c_vflag, cp.cand); cd.route = dev_table<uint8_t>(ctx->c_route, cp.cand);
-  cd.vq = dev_table<uint32_t>(ctx->c_vq, (size_t)NVC * cp.vq); cd.vxq = dev_table<uint32_t>(ctx->c_vxq, (size_t)NVC * cp.vq); cd.cap_vq = cp.vq;
-  cd.fq = dev_table<uint32_t>(ctx->c_fq, (size_t)NFC * cp.fwork); cd.bq = dev_table<uint32_t>(ctx->c_bq, (size_t)NFC * cp.fwork); cd.cap_fq = cp.fwork;
-  cd.eq = dev_table<uint32_t>(ctx->c_eq, (size_t)NFC * cp.ework); cd.cap_eq = cp.ework;
-  cd.rq = dev_table<uint32_t>(ctx->c_rq, (size_t)NFC * cp.rwork); cd.cap_rq = cp.rwork;
-  cd.cnt = d_cnt;
-  cd.fwork = dev_table<FbWork>(ctx->c_fwork, cp.fwork); cd.cap_fwork = cp.fwork;
-  cd.ework = dev_table<FbWork>(ctx->c_ework, cp.ework); cd.cap_ework = cp.ework;
-  cd.rwork = dev_table<FbWork>(ctx->c_rwork, cp.rwork); cd.ens = dev_table<EnsWork>(ctx->c_ens, cp.rwork); cd.cap_rwork = cp.rwork;
-  cd.ws_top = d_tops; cd.ws_cap = ws_floats;
-  cd.h_pass = pin_table<PassRec>(ctx->h_pass, cp.pass); cd.cap_pass = cp.pass;
-  cd.h_reg = pin_table<RegionRec>(ctx->h_reg, cp.reg); cd.cap_reg = cp.reg;
+  CascadeDev cd0; memset(&cd0, 0, sizeof(cd0));
+  PairRec *d_cand = dev_table<PairRec>(ctx->c_cand, tot_cand), *d_nores = dev_table<PairRec>(ctx->c_nores, tot_nores);
+  float *d_bias = dev_table<float>(ctx->c_bias, tot_cand * 2), *d_vfast = dev_table<float>(ctx->c_vfast, tot_cand), *d_vexact = dev_table<float>(ctx->c_vexact, tot_cand);
+  uint32_t *d_vflag = dev_table<uint32_t>(ctx->c_vflag, tot_cand); uint8_t *d_route = dev_table<uint8_t>(ctx->c_route, tot_cand);
+  uint32_t *d_vq = dev_table<uint32_t>(ctx->c_vq, tot_cand * NVC), *d_vxq = dev_table<uint32_t>(ctx->c_vxq, tot_cand * NVC);
+  uint32_t *d_fq = dev_table<uint32_t>(ctx->c_fq, tot_f * NFC), *d_bq = dev_table<uint32_t>(ctx->c_bq, tot_f * NFC);
+  uint32_t *d_eq = dev_table<uint32_t>(ctx->c_eq, tot_e * NFC), *d_rq = dev_table<uint32_t>(ctx->c_rq, tot_r * NFC);
+  cd0.gcnt = d_gcnt;
+  cd0.fwork = dev_table<FbWork>(ctx->c_fwork, cp.fwork); cd0.cap_fwork = cp.fwork;
+  cd0.ework = dev_table<FbWork>(ctx->c_ework, cp.ework); cd0.cap_ework = cp.ework;
+  cd0.rwork = dev_table<FbWork>(ctx->c_rwork, cp.rwork); cd0.ens = dev_table<EnsWork>(ctx->c_ens, cp.rwork); cd0.cap_rwork = cp.rwork;
+  cd0.ws_top = d_tops; cd0.ws_cap = ws_floats;
+  cd0.h_pass = pin_table<PassRec>(ctx->h_pass, cp.pass); cd0.cap_pass = cp.pass;
+  cd0.h_reg = pin_table<RegionRec>(ctx->h_reg, cp.reg); cd0.cap_reg = cp.reg;
   float *h_hens = pin_table<float>(ctx->h_hens, cp.hens);
-  cd.hens_top = d_tops + 1; cd.hens_cap = cp.hens;
-  cd.seq_len = dlen;
-  cd.margin_msv = 0.01f; cd.margin_vit = 0.01f; cd.margin_fwd = 0.05f;
+  cd0.hens_top = d_tops + 1; cd0.hens_cap = cp.hens;
+  cd0.seq_len = dlen;
+  cd0.margin_msv = 0.01f; cd0.margin_vit = 0.01f; cd0.margin_fwd = 0.05f;
   FwdOut *d_fout_f = dev_table<FwdOut>(ctx->c_fout_f, cp.fwork), *d_fout_e = dev_table<FwdOut>(ctx->c_fout_e, cp.ework), *d_fout_r = dev_table<FwdOut>(ctx->c_fout_r, cp.rwork);
   int32_t *d_rerr_e = dev_table<int32_t>(ctx->c_rerr_e, cp.ework);
   ScaleEvent *d_events_r = dev_table<ScaleEvent>(ctx->c_events_r, 1 << 16);
   EnvOut *h_envout = pin_table<EnvOut>(ctx->h_envout, cp.ework);
   ScaleEvent *h_events_f = pin_table<ScaleEvent>(ctx->h_events_f, cp.events_f), *h_events_e = pin_table<ScaleEvent>(ctx->h_events_e, cp.events_e);
-  uint32_t *h_cnt = pin_table<uint32_t>(ctx->h_cnt, CC_SIZE);
+  uint32_t *h_cnt = pin_table<uint32_t>(ctx->h_cnt, (NG + 1) * CC_SIZE);
   ensure_ens_seeds(ctx);
   float *ws = ctx->ws.as<float>();
-  hipStream_t ms = ctx->stream;
   const int NS = side_streams();
+  const int NSS = std::min(4, NS);                 // streams of the SSV launches
+  const int NCH = NS - NSS;                        // streams of the groups' chains (none left: a chain follows its SSV launch on the same stream)
 
-  // ---- SSV block tables (cached when the previous call on this worker had the same plan: lineage_wf scans the same bins twice, bench
-  // repeats steps).  A search of several chunks (more pairs than the budget) rebuilds the table per chunk and waits in between. ----
-  struct ChunkPlan { std::vector<std::pair<int, std::pair<size_t, size_t>>> groups; size_t nblocks = 0; };
-  auto plan_chunk = [&](size_t ci, ChunkPlan &cpn) {
-    const auto &mws = chunks[ci];
-    std::vector<uint64_t> key{p->uid, s->uid, pair_budget, (uint64_t)ci, rng.tag, 0xdeull};
-    for (auto &mw : mws) { key.push_back(0xffffffffull + mw.model); for (uint32_t b : model_bins[mw.model]) key.push_back(b); }
-    const bool single_chunk = chunks.size() == 1;
-    if (single_chunk && key == ctx->plan_key) {
-      cpn.groups = ctx->plan_groups; cpn.nblocks = ctx->plan_nblocks;
-      st.pairs_ssv += ctx->plan_pairs; st.residue_hmm += ctx->plan_residue_hmm; st.cells_ssv += ctx->plan_cells;
-      return;
-    }
-    std::map<int, std::vector<SsvBlockWork>> byQ;
-    uint64_t c_pairs = 0, c_res = 0, c_cells = 0;
-    for (auto &mw : mws) {
-      const int Q = p->prof[mw.model].ssvQ; const int threads = ssv_threads_for(Q); const uint32_t per_block = (uint32_t)threads / 64 * 4 * 4;
-      uint64_t pb = mw.pair_base;
-      for (uint32_t b : model_bins[mw.model]) {
-        const uint32_t o0 = rng.lo[b], n = rng.hi[b] - o0;
-        for (uint32_t a = 0; a < n; a += per_block) {
-          SsvBlockWork w; w.model = mw.model; w.list_start = o0 + a; w.count = std::min(per_block, n - a); w.pair_start = (uint32_t)(pb + a);
-          byQ[Q].push_back(w);
-        }
-        pb += n; c_res += rng.res[b]; c_cells += rng.res[b] * (uint64_t)p->prof[mw.model].M;
-      }
-      c_pairs += mw.npairs;
-    }
-    st.pairs_ssv += c_pairs; st.residue_hmm += c_res; st.cells_ssv += c_cells;
-    std::vector<SsvBlockWork> allw;
-    for (auto &kv : byQ) {
-      // longest blocks first inside a launch (a block's time is set by its first = longest sequence)
-      std::stable_sort(kv.second.begin(), kv.second.end(), [&](const SsvBlockWork &x, const SsvBlockWork &y) {
-        return s->len[s->order[x.list_start]] > s->len[s->order[y.list_start]]; });
-      cpn.groups.push_back({kv.first, {allw.size(), kv.second.size()}}); allw.insert(allw.end(), kv.second.begin(), kv.second.end());
-    }
-    cpn.nblocks = allw.size();
-    ctx->work.ensure(allw.size() * sizeof(SsvBlockWork));
-    HIPCHK(hipMemcpyAsync(ctx->work.p, allw.data(), allw.size() * sizeof(SsvBlockWork), hipMemcpyHostToDevice, ms));
-    HIPCHK(hipStreamSynchronize(ms));            // allw goes out of scope (pageable source); nothing of this search is queued on ms yet
-    if (single_chunk) { ctx->plan_key = key; ctx->plan_groups = cpn.groups; ctx->plan_nblocks = cpn.nblocks; ctx->plan_pairs = c_pairs; ctx->plan_residue_hmm = c_res; ctx->plan_cells = c_cells; }
-    else ctx->plan_key.clear();
-  };
-  ChunkPlan first_plan;
-  plan_chunk(0, first_plan);
-
-  // ---- SSV phase: wait for the turn (the lanes' SSV phases run one behind the other on the device: VALU-bound, nothing to gain side by
-  // side), chain the launches behind the previous lane's, pass the turn on as soon as everything is queued ----
+  // ---- wait for the turn (the lanes' SSV phases run one behind the other on the device: VALU-bound, nothing to gain side by side),
+  // queue everything behind the previous lane's SSV launches, pass the turn on ----
   {
     std::unique_lock<std::mutex> lock(owner->ssv_mutex);
     owner->ssv_cv.wait(lock, [&] { return owner->ssv_turn == my_turn; });
   }
   CKM_TRACE_PT("ssv turn taken");
-  HIPCHK(hipMemsetAsync(d_cnt, 0, CC_SIZE * sizeof(uint32_t), ms));
+  // (diagnostics: CKM_CHAIN_STOP=n queues only the first n stages of every chain, prints the device counters and hands the lane to the
+  //  host-driven cascade: 1 SSV + finish, 2 exact MSV, 3 bias filter, 4 Viterbi fast, 5 Viterbi exact, 6 Forward parser, 7 Backward
+  //  parser, 8 regions, 9-11 envelope Forward / Backward / OA, 12 region Forward, 13 ensembles)
+  const int stop = getenv("CKM_CHAIN_STOP") ? atoi(getenv("CKM_CHAIN_STOP")) : 99;
+  HIPCHK(hipMemsetAsync(d_gcnt, 0, (NG + 1) * CC_SIZE * sizeof(uint32_t), ms));
   HIPCHK(hipMemsetAsync(d_tops, 0, 4 * sizeof(unsigned long long), ms));
   if (owner->ssv_prev_done) HIPCHK(hipStreamWaitEvent(ms, owner->ssv_prev_done, 0));     // previous lane's SSV launches
   HIPCHK(hipEventRecord(ctx->ev[0], ms));
-  const int NSS = std::min(4, NS);
-  for (size_t ci = 0; ci < chunks.size(); ++ci) {
-    ChunkPlan later;
-    if (ci > 0) { HIPCHK(hipStreamSynchronize(ms)); plan_chunk(ci, later); }      // (the previous chunk's launches read the table that is being replaced)
-    const ChunkPlan &cpn = ci == 0 ? first_plan : later;
-    // register classes round-robin over the side streams, heaviest first; the finish kernel follows on the main stream
-    HIPCHK(hipEventRecord(ctx->cev[0], ms));
-    for (int k = 0; k < NSS; ++k) HIPCHK(hipStreamWaitEvent(ctx->side[k], ctx->cev[0], 0));
+  HIPCHK(hipEventRecord(ctx->cev[0], ms));
+  for (int k = 0; k < NS; ++k) HIPCHK(hipStreamWaitEvent(ctx->side[k], ctx->cev[0], 0));
+  {
     int gi = 0;
-    for (auto it = cpn.groups.rbegin(); it != cpn.groups.rend(); ++it, ++gi) {
-      auto &g = *it;
-      if (launch_ssv(g.first, (int)g.second.second, ssv_threads_for(g.first), ctx->side[gi % NSS], ctx->work.as<SsvBlockWork>() + g.second.first, dm, res, off, dlen,
+    for (size_t g = NG; g-- > 0; ++gi) {                         // heaviest register class first
+      const Sub &sb = subs[g];
+      hipStream_t sv = ctx->side[gi % NSS];
+      if (launch_ssv(sb.Q, (int)sb.nblocks, ssv_threads_for(sb.Q), sv, ctx->work.as<SsvBlockWork>() + sb.first, dm, res, off, dlen,
                      s->d_order.as<uint32_t>(), ctx->maxv.as<uint16_t>()))
         throw Error(CKM_ERANGE, "no SSV kernel instance for this model length");
       st.ssv_launches++;
+      hipStream_t sc = sv;
+      if (NCH > 0) { sc = ctx->side[NSS + gi % NCH]; HIPCHK(hipEventRecord(ctx->grp_ev[g], sv)); HIPCHK(hipStreamWaitEvent(sc, ctx->grp_ev[g], 0)); }
+      // ---- the group's chain ----
+      CascadeDev cd = cd0;
+      uint32_t *cnt = d_gcnt + (1 + g) * CC_SIZE;
+      cd.cnt = cnt;
+      cd.cand = d_cand + sb.o_cand; cd.cap_cand = sb.cap_cand;
+      cd.bias_raw = d_bias + 2 * sb.o_cand; cd.vit_fast = d_vfast + sb.o_cand; cd.vit_exact = d_vexact + sb.o_cand; cd.vit_flag = d_vflag + sb.o_cand; cd.route = d_route + sb.o_cand;
+      cd.vq = d_vq + sb.o_vq; cd.vxq = d_vxq + sb.o_vq; cd.cap_vq = sb.cap_cand;
+      cd.fq = d_fq + sb.o_f; cd.bq = d_bq + sb.o_f; cd.cap_fq = sb.cap_f;
+      cd.eq = d_eq + sb.o_e; cd.cap_eq = sb.cap_e;
+      cd.rq = d_rq + sb.o_r; cd.cap_rq = sb.cap_r;
+      PairRec *nores = d_nores + sb.o_nores;
+      FinishArgs fa{dm, lt, dlen, s->d_order.as<uint32_t>(), ctx->work.as<SsvBlockWork>() + sb.first, ctx->maxv.as<uint16_t>(),
+                    cd.cand, cnt + CC_CAND, sb.cap_cand, nores, cnt + CC_NORES, sb.cap_nores};
+      launch_msv_finish(sc, fa, (uint32_t)sb.nblocks);
+      if (stop >= 2) launch_msv_full(sc, 1024, WorkQueue{nullptr, cnt + CC_NORES, sb.cap_nores}, nores, dm, lt, res, off, dlen, nullptr, nullptr, p->maxMp, &cd);
+      if (stop >= 3) launch_bias_filter(sc, 1024, cd, dm, lt, res, off);
+      int rc = 0;
+      for (int c = NVC - 1; c >= 0; --c) if (sb.vit[c]) {
+        if (stop >= 4) rc |= launch_vit(kVitQH[c], 2048, sc, WorkQueue{cd.vq + (size_t)c * cd.cap_vq, cnt + CC_VQ + c, cd.cap_vq}, cd.cand, dm, lt, res, off, dlen, nullptr, nullptr, nullptr, true, &cd);
+        if (stop >= 5) rc |= launch_vit(kVitQH[c], 512, sc, WorkQueue{cd.vxq + (size_t)c * cd.cap_vq, cnt + CC_VXQ + c, cd.cap_vq}, cd.cand, dm, lt, res, off, dlen, nullptr, nullptr, nullptr, false, &cd);
+      }
+      for (int c = NFC - 1; c >= 0; --c) if (sb.fb[c]) {
+        const int Q = kFbQ[c];
+        const WorkQueue qf{cd.fq + (size_t)c * sb.cap_f, cnt + CC_FQ + c, sb.cap_f}, qb{cd.bq + (size_t)c * sb.cap_f, cnt + CC_BQ + c, sb.cap_f};
+        const WorkQueue qe{cd.eq + (size_t)c * sb.cap_e, cnt + CC_EQ + c, sb.cap_e}, qr{cd.rq + (size_t)c * sb.cap_r, cnt + CC_RQ + c, sb.cap_r};
+        if (stop >= 6) rc |= launch_fwd(Q, 4096, sc, qf, cd.fwork, dm, lt, res, off, ws, d_fout_f, h_events_f, d_gcnt + CC_EVENTS, cp.events_f, &cd);
+        if (stop >= 7) rc |= launch_bwd(Q, 4096, sc, qb, cd.fwork, dm, lt, res, off, ws, d_fout_f, nullptr);
+        if (stop >= 8) launch_regions(sc, 1024, qb.list, qb.count, sb.cap_f, cd.fwork, cd, dm, ws);
+        if (stop >= 9) rc |= launch_fwd(Q, 4096, sc, qe, cd.ework, dm, lt, res, off, ws, d_fout_e, h_events_e, d_gcnt + CC_EVENTS_E, cp.events_e, nullptr);
+        if (stop >= 10) rc |= launch_bwd(Q, 4096, sc, qe, cd.ework, dm, lt, res, off, ws, d_fout_e, d_rerr_e);
+        if (stop >= 11) rc |= launch_oa(Q, 4096, sc, qe, cd.ework, dm, ws, d_rerr_e, d_fout_e, h_envout);
+        if (stop >= 12) rc |= launch_fwd(Q, 512, sc, qr, cd.rwork, dm, lt, res, off, ws, d_fout_r, d_events_r, d_gcnt + CC_EVENTS_R, 1 << 16, nullptr);
+      }
+      if (rc) throw Error(CKM_ERANGE, "no kernel instance for this model length");
     }
-    for (int k = 0; k < NSS; ++k) { HIPCHK(hipEventRecord(ctx->cls_ev[k], ctx->side[k])); HIPCHK(hipStreamWaitEvent(ms, ctx->cls_ev[k], 0)); }
-    FinishArgs fa{dm, lt, dlen, s->d_order.as<uint32_t>(), ctx->work.as<SsvBlockWork>(), ctx->maxv.as<uint16_t>(),
-                  cd.cand, d_cnt + CC_CAND, cp.cand, d_nores, d_cnt + CC_NORES, cp.nores};
-    launch_msv_finish(ms, fa, (uint32_t)cpn.nblocks);
   }
-  HIPCHK(hipEventRecord(ctx->ev[1], ms));                    // ev[0]..ev[1] brackets the lane's SSV launches (+ the tiny finish kernels)
+  // the SSV streams join the main stream first (end of the lane's SSV phase: the next lane may start its own), then the chains
+  for (int k = 0; k < NSS; ++k) { HIPCHK(hipEventRecord(ctx->cls_ev[k], ctx->side[k])); HIPCHK(hipStreamWaitEvent(ms, ctx->cls_ev[k], 0)); }
+  HIPCHK(hipEventRecord(ctx->ev[1], ms));                    // ev[0]..ev[1] brackets the lane's SSV launches (with NCH == 0: and the chains queued behind them)
   HIPCHK(hipEventRecord(ctx->cev[1], ms));
   {
     std::unique_lock<std::mutex> lock(owner->ssv_mutex);
     owner->ssv_prev_done = ctx->cev[1];
     took_turn = true; owner->ssv_turn++; owner->ssv_cv.notify_all();
   }
-  HIPCHK(hipGetLastError());
-  CKM_TRACE_PT("ssv queued");
-
-  // (diagnostics: CKM_CHAIN_STOP=n queues only the first n stages of the chain, prints the device counters and hands the lane to the
-  //  host-driven cascade: 1 SSV, 2 exact MSV, 3 bias filter, 4 Viterbi fast, 5 Viterbi exact, 6 Forward parser, 7 Backward parser, 8 regions,
-  //  9-11 envelope Forward / Backward / OA, 12 region Forward, 13 ensembles)
-  const int stop = getenv("CKM_CHAIN_STOP") ? atoi(getenv("CKM_CHAIN_STOP")) : 99;
-  // ---- exact MSV of the pairs SSV could not decide, bias filter (+ F1/F2 decisions) ----
-  if (stop >= 2) launch_msv_full(ms, 2048, WorkQueue{nullptr, d_cnt + CC_NORES, cp.nores}, d_nores, dm, lt, res, off, dlen, nullptr, nullptr, p->maxMp, &cd);
-  if (stop >= 3) launch_bias_filter(ms, 2048, cd, dm, lt, res, off);
-  // ---- Viterbi filter: per register class, fast kernel then exact kernel on one stream ----
-  HIPCHK(hipEventRecord(ctx->cev[2], ms));
-  for (int k = 0; k < NS; ++k) HIPCHK(hipStreamWaitEvent(ctx->side[k], ctx->cev[2], 0));
-  {
-    int gi = 0;
-    for (int c = NVC - 1; c >= 0; --c) if (vit_present[c]) {
-      hipStream_t sv = ctx->side[gi++ % NS];
-      if ((stop >= 4 && launch_vit(kVitQH[c], 2048, sv, WorkQueue{cd.vq + (size_t)c * cp.vq, d_cnt + CC_VQ + c, cp.vq}, cd.cand, dm, lt, res, off, dlen,
-                                   nullptr, nullptr, nullptr, true, &cd)) ||
-          (stop >= 5 && launch_vit(kVitQH[c], 1024, sv, WorkQueue{cd.vxq + (size_t)c * cp.vq, d_cnt + CC_VXQ + c, cp.vq}, cd.cand, dm, lt, res, off, dlen,
-                                   nullptr, nullptr, nullptr, false, &cd)))
-        throw Error(CKM_ERANGE, "no Viterbi kernel instance for this model length");
-    }
-  }
-  for (int k = 0; k < NS; ++k) { HIPCHK(hipEventRecord(ctx->cls_ev[k], ctx->side[k])); HIPCHK(hipStreamWaitEvent(ms, ctx->cls_ev[k], 0)); }
-  // ---- per register class, one stream: Forward parser (F3) -> Backward parser -> regions -> envelope Forward / Backward / OA -> region Forward ----
-  HIPCHK(hipEventRecord(ctx->cev[3], ms));
-  for (int k = 0; k < NS; ++k) HIPCHK(hipStreamWaitEvent(ctx->side[k], ctx->cev[3], 0));
-  {
-    int gi = 0;
-    for (int c = NFC - 1; c >= 0; --c) if (fb_present[c]) {
-      hipStream_t sf = ctx->side[gi++ % NS];
-      const int Q = kFbQ[c];
-      const WorkQueue qf{cd.fq + (size_t)c * cp.fwork, d_cnt + CC_FQ + c, cp.fwork};
-      const WorkQueue qb{cd.bq + (size_t)c * cp.fwork, d_cnt + CC_BQ + c, cp.fwork};
-      const WorkQueue qef{cd.eq + (size_t)c * cp.ework, d_cnt + CC_EQ + c, cp.ework};
-      const WorkQueue qeb = qef, qeo = qef;
-      const WorkQueue qr{cd.rq + (size_t)c * cp.rwork, d_cnt + CC_RQ + c, cp.rwork};
-      int rc = 0;
-      if (stop >= 6) rc |= launch_fwd(Q, 4096, sf, qf, cd.fwork, dm, lt, res, off, ws, d_fout_f, h_events_f, d_cnt + CC_EVENTS, cp.events_f, &cd);
-      if (stop >= 7) rc |= launch_bwd(Q, 4096, sf, qb, cd.fwork, dm, lt, res, off, ws, d_fout_f, nullptr);
-      if (stop >= 8) launch_regions(sf, 256, qb.list, qb.count, cp.fwork, cd.fwork, cd, dm, ws);
-      if (stop >= 9) rc |= launch_fwd(Q, 4096, sf, qef, cd.ework, dm, lt, res, off, ws, d_fout_e, h_events_e, d_cnt + CC_EVENTS_E, cp.events_e, nullptr);
-      if (stop >= 10) rc |= launch_bwd(Q, 4096, sf, qeb, cd.ework, dm, lt, res, off, ws, d_fout_e, d_rerr_e);
-      if (stop >= 11) rc |= launch_oa(Q, 4096, sf, qeo, cd.ework, dm, ws, d_rerr_e, d_fout_e, h_envout);
-      if (stop >= 12) rc |= launch_fwd(Q, 1024, sf, qr, cd.rwork, dm, lt, res, off, ws, d_fout_r, d_events_r, d_cnt + CC_EVENTS_R, 1 << 16, nullptr);
-      if (rc) throw Error(CKM_ERANGE, "no Forward/Backward kernel instance for this model length");
-    }
-  }
-  for (int k = 0; k < NS; ++k) { HIPCHK(hipEventRecord(ctx->cls_ev[k], ctx->side[k])); HIPCHK(hipStreamWaitEvent(ms, ctx->cls_ev[k], 0)); }
-  // ---- trace ensembles of the multi-domain regions, results exported to pinned memory; counters last ----
-  if (stop >= 13) launch_ensemble(ms, cd.ens, d_cnt + CC_RWORK, cp.rwork, 128, p->maxMp, dm, lt, res, off, ws, ctx->ensseeds.as<uint32_t>(), h_hens);
-  HIPCHK(hipMemcpyAsync(h_cnt, d_cnt, CC_SIZE * sizeof(uint32_t), hipMemcpyDeviceToHost, ms));
+  for (int k = NSS; k < NS; ++k) { HIPCHK(hipEventRecord(ctx->cls_ev[k], ctx->side[k])); HIPCHK(hipStreamWaitEvent(ms, ctx->cls_ev[k], 0)); }
+  // ---- trace ensembles of the multi-domain regions of all groups, results exported to pinned memory; counters last ----
+  if (stop >= 13) launch_ensemble(ms, cd0.ens, d_gcnt + CC_RWORK, cp.rwork, 128, p->maxMp, dm, lt, res, off, ws, ctx->ensseeds.as<uint32_t>(), h_hens);
+  HIPCHK(hipMemcpyAsync(h_cnt, d_gcnt, (NG + 1) * CC_SIZE * sizeof(uint32_t), hipMemcpyDeviceToHost, ms));
   HIPCHK(hipGetLastError());
   CKM_TRACE_PT("chain queued");
   HIPCHK(hipStreamSynchronize(ms));                           // ---- the one synchronisation of the lane ----
   CKM_TRACE_PT("chain drained");
   if (stop < 99) {
     fprintf(stderr, "ckm-chain w%d stop=%d:", ctx->id, stop);
-    for (int k = 0; k < CC_END; ++k) if (h_cnt[k]) fprintf(stderr, " c%d=%u", k, h_cnt[k]);
+    for (int k = 0; k < CC_END; ++k) { uint64_t v = h_cnt[k]; for (size_t g = 0; g < NG; ++g) v += h_cnt[(1 + g) * CC_SIZE + k]; if (v) fprintf(stderr, " c%d=%llu", k, (unsigned long long)v); }
     fprintf(stderr, "\n");
-    return false;
+    return 1;
   }
   { float msv = 0.f; HIPCHK(hipEventElapsedTime(&msv, ctx->ev[0], ctx->ev[1])); st.ms_ssv = msv; }
   const double t_host0 = now_ms();
   st.ms_filters = t_host0 - t_start;          // (queueing + the whole device chain: the stages are no longer separable by host clocks)
 
   // ---- did everything fit? ----
-  const uint32_t n_cand = h_cnt[CC_CAND], n_nores = h_cnt[CC_NORES], n_fwork = h_cnt[CC_FWORK], n_ework = h_cnt[CC_EWORK], n_rwork = h_cnt[CC_RWORK],
+  const uint32_t n_fwork = h_cnt[CC_FWORK], n_ework = h_cnt[CC_EWORK], n_rwork = h_cnt[CC_RWORK],
                  n_pass = h_cnt[CC_PASS], n_reg = h_cnt[CC_REG], n_evf = h_cnt[CC_EVENTS], n_eve = h_cnt[CC_EVENTS_E], status = h_cnt[CC_STATUS];
   bool fits = status == 0;
   auto need = [&](uint32_t &cap, uint32_t n) { if (n > cap) { fits = false; cap = (uint32_t)std::min<uint64_t>((uint64_t)n + n / 4 + 1024, 0xfffffff0ull); } };
-  need(cp.cand, n_cand); need(cp.nores, n_nores); need(cp.fwork, n_fwork); need(cp.ework, n_ework); need(cp.rwork, n_rwork); need(cp.pass, n_pass);
+  need(cp.fwork, n_fwork); need(cp.ework, n_ework); need(cp.rwork, n_rwork); need(cp.pass, n_pass);
   need(cp.reg, n_reg); need(cp.events_f, n_evf); need(cp.events_e, n_eve);
-  for (int c = 0; c < NVC; ++c) { need(cp.vq, h_cnt[CC_VQ + c]); need(cp.vq, h_cnt[CC_VXQ + c]); }
+  auto halve = [&](uint32_t &d) { d = std::max<uint32_t>(1, d / 2); fits = false; };
+  uint64_t n_cand = 0, n_nores = 0;
+  for (size_t g = 0; g < NG; ++g) {
+    const uint32_t *c = h_cnt + (1 + g) * CC_SIZE; const Sub &sb = subs[g];
+    n_cand += c[CC_CAND]; n_nores += c[CC_NORES];
+    if (c[CC_CAND] > sb.cap_cand) halve(cp.div_cand);
+    if (c[CC_NORES] > sb.cap_nores) halve(cp.div_nores);
+    for (int k = 0; k < NVC; ++k) { st.pairs_vit += c[CC_VQ + k]; st.pairs_vit_exact += c[CC_VXQ + k]; if (c[CC_VQ + k] > sb.cap_cand || c[CC_VXQ + k] > sb.cap_cand) halve(cp.div_cand); }
+    for (int k = 0; k < NFC; ++k) {
+      if (c[CC_FQ + k] > sb.cap_f || c[CC_BQ + k] > sb.cap_f) halve(cp.div_fwork);
+      if (c[CC_EQ + k] > sb.cap_e) halve(cp.div_ework);
+      if (c[CC_RQ + k] > sb.cap_r) halve(cp.div_rwork);
+    }
+  }
   if (status & CS_RWORK) cp.hens *= 2;
   if (!fits) {
     if (getenv("CKM_TRACE")) fprintf(stderr, "ckm-trace w%d device cascade did not fit (status 0x%x): host-driven cascade for this lane\n", ctx->id, status);
-    return false;
+    return 1;
   }
   st.pairs_msv_full = n_nores; st.pairs_bias = n_cand; st.pairs_fwd = n_fwork; st.pairs_dom = n_pass; st.regions_multi = n_rwork;
-  for (int c = 0; c < NVC; ++c) { st.pairs_vit += h_cnt[CC_VQ + c]; st.pairs_vit_exact += h_cnt[CC_VXQ + c]; }
+  const CascadeDev &cd = cd0;
 
   // ---- the filter decisions again, exactly (host libm), for the pairs the device let through ----
   const PassRec *pass = cd.h_pass;
@@ -773,7 +775,7 @@ static bool cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_prof
     const RegionRec &rr = reg[ro];
     if (rr.pass >= n_pass || dsidx[rr.pass] < 0) continue;
     const uint32_t q = (uint32_t)dsidx[rr.pass];
-    if (rr.target == 0xffffffffu) return false;                        // no workspace for it on the device (status would have said so)
+    if (rr.target == 0xffffffffu) return 1;                            // no workspace for it on the device (status would have said so)
     ds.nregions[q]++;
     if (!rr.multi) ds.items.push_back({q, rr.i, rr.j, -1});
     else { ds.items.push_back({q, rr.i, rr.j, (int)ds.regres.size()}); ens_list.push_back({ro, (uint32_t)ds.regres.size()}); ds.regres.emplace_back(); }
@@ -782,7 +784,7 @@ static bool cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_prof
   for (auto &er : ens_list) {
     const RegionRec &rr = reg[er.first]; RegionRes &o = ds.regres[er.second];
     const int Ld = rr.j - rr.i + 1, cap = std::min(Ld, 16);
-    if (rr.pad == 0xffffffffu) return false;
+    if (rr.pad == 0xffffffffu) return 1;
     const float *raw = h_hens + rr.pad;
     const int32_t *ns = reinterpret_cast<const int32_t *>(raw);
     const int32_t *sg = reinterpret_cast<const int32_t *>(raw + 256);
@@ -853,7 +855,7 @@ static bool cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_prof
   st.ms_host = now_ms() - t_rows0;
   st.ms_total = now_ms() - t_start;
   CKM_TRACE_PT("cascade done");
-  return true;
+  return 0;
 }
 
 static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, const uint32_t *model_off, const uint32_t *model_idx,
@@ -966,9 +968,9 @@ static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, cons
   auto run = [&](int k) {
     try {
       if (host_cascade) cascade(&c->w[k], c, k, p, s, ranges[k], chunk[k], model_bins, maps[k]);
-      else if (!cascade_dev(&c->w[k], c, k, p, s, ranges[k], chunk[k], model_bins, maps[k])) {
+      else if (const int rc = cascade_dev(&c->w[k], c, k, p, s, ranges[k], chunk[k], model_bins, maps[k])) {
         c->fallbacks++;
-        cascade(&c->w[k], c, k, p, s, ranges[k], chunk[k], model_bins, maps[k], true);
+        cascade(&c->w[k], c, k, p, s, ranges[k], chunk[k], model_bins, maps[k], rc == 1);
       }
     } catch (...) { errs[k] = std::current_exception(); }
   };

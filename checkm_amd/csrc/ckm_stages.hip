@@ -37,8 +37,8 @@ float finish_forward(float xC, float move, const std::vector<float> &scales) {
 static int g_side_streams = 8;
 int side_streams() { return g_side_streams; }
 int choose_side_streams(int nworkers) {
-  int n = std::max(1, std::min(8, 15 / std::max(1, nworkers) - 1));
-  if (const char *e = getenv("CKM_SIDE_STREAMS")) n = std::max(1, std::min(8, atoi(e)));
+  int n = std::max(1, std::min(14, 15 / std::max(1, nworkers) - 1));
+  if (const char *e = getenv("CKM_SIDE_STREAMS")) n = std::max(1, std::min(14, atoi(e)));
   g_side_streams = n;
   return n;
 }

@@ -135,7 +135,8 @@ struct CascadeDev {                   // by-value kernel argument: where the epi
   float *vit_fast, *vit_exact; uint32_t *vit_flag; uint8_t *route;      // [cap_cand]
   uint32_t *vq, *vxq; uint32_t cap_vq;                                  // [NVC][cap_vq] candidate ids
   uint32_t *fq, *bq, *eq, *rq; uint32_t cap_fq, cap_eq, cap_rq;         // [NFC][cap] work-item indices (bq shares cap_fq)
-  uint32_t *cnt;                                                        // [CC_SIZE]
+  uint32_t *cnt;                                                        // [CC_SIZE] counters of THIS group's chain: CC_CAND, CC_NORES and the queue lengths
+  uint32_t *gcnt;                                                       // [CC_SIZE] counters shared by all groups of the lane: work tables, pass / region records, events, status
   FbWork *fwork; uint32_t cap_fwork;
   FbWork *ework; uint32_t cap_ework;
   FbWork *rwork; EnsWork *ens; uint32_t cap_rwork;

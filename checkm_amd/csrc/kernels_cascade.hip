@@ -1,7 +1,7 @@
 // kernels_cascade.hip -- the posterior domain heuristics of the device-driven cascade, gfx950 only.
 // Replaces, inside the hmmsearch process launched at checkm/hmmer.py:70, the region scan of HMMER's domain definition
 // ("p7_domaindef_ByPosteriorHeuristics": rt1 0.25 / rt2 0.10 / rt3 0.20 on the begin/end/occupancy posteriors) and the hand-over
-// to envelope rescoring, which the host used to do between two device phases.  One thread per pair that passed the Forward
+// to envelope rescoring, which the host used to do between two device phases.  One wavefront per pair that passed the Forward
 // filter: it turns the three decoding terms per residue the Backward parser left in the workspace into the running sums
 // btot/etot (in place: the float prefix sums are part of the decision, so they are formed once, in residue order, exactly as the
 // CPU restatement forms them), finds the regions, and for every region allocates the workspace of what comes next --
@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include "dev_types.h"
 #include "cascade_dev.h"
+#include "xlane.h"
 
 namespace ckm {
 
@@ -20,8 +21,8 @@ constexpr int ENS_CAP0 = 16;         // segment slots per trace on the first att
 __device__ __forceinline__ unsigned long long al32(unsigned long long v) { return (v + 31ull) & ~31ull; }
 
 __device__ void emit_region(const CascadeDev &cd, const DevModel &md, const FbWork &pw, int L, int ri, int rj, bool multi) {
-  const uint32_t rid = atomicAdd(&cd.cnt[CC_REG], 1u);
-  if (rid >= cd.cap_reg) { atomicOr(&cd.cnt[CC_STATUS], (uint32_t)CS_REG); return; }
+  const uint32_t rid = atomicAdd(&cd.gcnt[CC_REG], 1u);
+  if (rid >= cd.cap_reg) { atomicOr(&cd.gcnt[CC_STATUS], (uint32_t)CS_REG); return; }
   RegionRec rec; rec.pass = pw.pass; rec.i = ri; rec.j = rj; rec.multi = multi ? 1 : 0; rec.target = 0xffffffffu; rec.pad = 0;
   const unsigned long long Mp = (unsigned long long)md.fbQ * 64ull, Ld = (unsigned long long)(rj - ri + 1);
   unsigned long long off;
@@ -33,7 +34,7 @@ __device__ void emit_region(const CascadeDev &cd, const DevModel &md, const FbWo
     const unsigned long long mf = pos; pos = al32(pos + (Ld + 1) * 3 * Mp);
     const unsigned long long mb = pos; pos = al32(pos + (Ld + 1) * 2 * Mp);
     if (ws_alloc(cd, pos, off)) {
-      const uint32_t e = atomicAdd(&cd.cnt[CC_EWORK], 1u);
+      const uint32_t e = atomicAdd(&cd.gcnt[CC_EWORK], 1u);
       if (e < cd.cap_ework) {
         FbWork w;
         w.model = pw.model; w.seq = pw.seq; w.i0 = ri - 1; w.Ld = (int32_t)Ld; w.Lcfg = L; w.multihit = 0;
@@ -42,7 +43,7 @@ __device__ void emit_region(const CascadeDev &cd, const DevModel &md, const FbWo
         cd.ework[e] = w;
         queue_push(cd, cd.eq, CC_EQ, md.fb_cls, cd.cap_eq, e, (uint32_t)CS_EWORK);
         rec.target = e;
-      } else atomicOr(&cd.cnt[CC_STATUS], (uint32_t)CS_EWORK);
+      } else atomicOr(&cd.gcnt[CC_STATUS], (uint32_t)CS_EWORK);
     }
   } else {
     const unsigned long long cap = Ld < (unsigned long long)ENS_CAP0 ? Ld : (unsigned long long)ENS_CAP0;
@@ -57,7 +58,7 @@ __device__ void emit_region(const CascadeDev &cd, const DevModel &md, const FbWo
     const unsigned long long code = pos; pos = al32(pos + ((unsigned long long)ENS_NSAMPLES * (Ld + 1) + 1) / 2);
     const unsigned long long ratio = pos; pos = al32(pos + (unsigned long long)ENS_NSAMPLES * (Ld + 1));
     if (ws_alloc(cd, pos, off)) {
-      const uint32_t r = atomicAdd(&cd.cnt[CC_RWORK], 1u);
+      const uint32_t r = atomicAdd(&cd.gcnt[CC_RWORK], 1u);
       if (r < cd.cap_rwork) {
         EnsWork e;
         e.model = pw.model; e.seq = pw.seq; e.i0 = ri - 1; e.Ld = (int32_t)Ld; e.Lcfg = L; e.cap = (int32_t)cap;
@@ -65,7 +66,7 @@ __device__ void emit_region(const CascadeDev &cd, const DevModel &md, const FbWo
         e.seg_off = off + seg; e.nseg_off = off + nseg; e.n2_off = off + n2;
         const unsigned long long hoff = atomicAdd(cd.hens_top, nres);
         e.host_off = (hoff + nres <= cd.hens_cap) ? hoff : ~0ull;
-        if (e.host_off == ~0ull) atomicOr(&cd.cnt[CC_STATUS], (uint32_t)CS_RWORK);
+        if (e.host_off == ~0ull) atomicOr(&cd.gcnt[CC_STATUS], (uint32_t)CS_RWORK);
         rec.pad = (e.host_off == ~0ull) ? 0xffffffffu : (uint32_t)hoff;
         cd.ens[r] = e;
         FbWork w;
@@ -75,46 +76,69 @@ __device__ void emit_region(const CascadeDev &cd, const DevModel &md, const FbWo
         cd.rwork[r] = w;
         queue_push(cd, cd.rq, CC_RQ, md.fb_cls, cd.cap_rq, r, (uint32_t)CS_RWORK);
         rec.target = r;
-      } else atomicOr(&cd.cnt[CC_STATUS], (uint32_t)CS_RWORK);
+      } else atomicOr(&cd.gcnt[CC_STATUS], (uint32_t)CS_RWORK);
     }
   }
   cd.h_reg[rid] = rec;
 }
 
-// list/count: the Backward queue of one register class (parser items of `fwork` whose decoding terms are complete)
+// list/count: the Backward queue of one register class (parser items of `fwork` whose decoding terms are complete).  One wavefront per
+// item: 64 rows are loaded at a time; the running sums and the trigger logic are evaluated in residue order on values broadcast
+// from their lanes (uniform control flow: every lane computes the same scalars), the prefix sums go back in place, and the
+// multi-domain test of a region (a maximum, order-independent) is spread over the lanes.
+#define CKM_LD2(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)   /* L2-served: this wave's own stores are visible */
 __global__ void __launch_bounds__(64) region_kernel(const uint32_t *__restrict__ list, const uint32_t *__restrict__ count, uint32_t cap,
                                                    const FbWork *__restrict__ fwork, CascadeDev cd, const DevModel *__restrict__ models, float *__restrict__ ws) {
   const uint32_t n = min(*count, cap);
-  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+  const int lane = threadIdx.x;
+  for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
     const FbWork w = fwork[list[k]];
     const DevModel &md = models[w.model];
     const int L = w.Ld;
     float *aux = ws + w.aux_off;           // row r (1..L): [begin term, end term, N/J/C occupancy]; becomes [btot, etot, .]
-    float btp = 0.f, etp = 0.f;
+    float btp = 0.f, etp = 0.f;            // btot / etot of the row before the current one
     int ri = -1; bool trig = false;
-    for (int j = 1; j <= L; ++j) {
-      const float bt = aux[(size_t)j * 3], et = aux[(size_t)j * 3 + 1], nj = aux[(size_t)j * 3 + 2];
-      const float btn = btp + bt, etn = etp + et, mo = 1.0f - nj;
-      aux[(size_t)j * 3] = btn; aux[(size_t)j * 3 + 1] = etn;
-      if (!trig) {
-        if (mo - (btn - btp) < RT2_F) ri = j; else if (ri == -1) ri = j;
-        if (mo >= RT1_F) trig = true;
-      } else if (mo - (etn - etp) < RT2_F) {
-        const float e0 = (ri - 1 >= 1) ? aux[(size_t)(ri - 1) * 3 + 1] : 0.f;       // etot[ri-1]
-        float mx = -1.0f;
-        for (int z = ri; z <= j; ++z) {
-          const float bz = (z - 1 >= 1) ? aux[(size_t)(z - 1) * 3] : 0.f;           // btot[z-1]
-          const float a = aux[(size_t)z * 3 + 1] - e0, b = btn - bz;
-          const float en = a < b ? a : b;
-          if (en > mx) mx = en;
-        }
-        emit_region(cd, md, w, L, ri, j, mx >= RT3_F);
-        ri = -1; trig = false;
+    for (int base = 1; base <= L; base += 64) {
+      const int row = base + lane;
+      const bool ok = row <= L;
+      const float bt = ok ? aux[(size_t)row * 3] : 0.f, et = ok ? aux[(size_t)row * 3 + 1] : 0.f, nj = ok ? aux[(size_t)row * 3 + 2] : 0.f;
+      const int nrow = min(64, L - base + 1);
+      // running sums in residue order; lane r keeps row base + r's
+      const float btp0 = btp, etp0 = etp;
+      float pb = 0.f, pe = 0.f;
+      for (int r = 0; r < nrow; ++r) {
+        btp = btp + read_lane(bt, r); etp = etp + read_lane(et, r);
+        if (lane == r) { pb = btp; pe = etp; }
       }
-      btp = btn; etp = etn;
+      if (ok) { aux[(size_t)row * 3] = pb; aux[(size_t)row * 3 + 1] = pe; }
+      __threadfence();
+      __builtin_amdgcn_wave_barrier();
+      float pbm = btp0, pem = etp0;
+      for (int r = 0; r < nrow; ++r) {
+        const float btn = read_lane(pb, r), etn = read_lane(pe, r), mo = 1.0f - read_lane(nj, r);
+        const int j = base + r;
+        if (!trig) {
+          if (mo - (btn - pbm) < RT2_F) ri = j; else if (ri == -1) ri = j;
+          if (mo >= RT1_F) trig = true;
+        } else if (mo - (etn - pem) < RT2_F) {
+          const float e0 = (ri - 1 >= 1) ? CKM_LD2(&aux[(size_t)(ri - 1) * 3 + 1]) : 0.f;       // etot[ri-1]
+          float mx = -1.0f;
+          for (int z = ri + lane; z <= j; z += 64) {
+            const float bz = (z - 1 >= 1) ? CKM_LD2(&aux[(size_t)(z - 1) * 3]) : 0.f;           // btot[z-1]
+            const float a = CKM_LD2(&aux[(size_t)z * 3 + 1]) - e0, b = btn - bz;
+            const float en = a < b ? a : b;
+            if (en > mx) mx = en;
+          }
+          mx = wave_max(mx);
+          if (lane == 0) emit_region(cd, md, w, L, ri, j, mx >= RT3_F);
+          ri = -1; trig = false;
+        }
+        pbm = btn; pem = etn;
+      }
     }
   }
 }
+#undef CKM_LD2
 
 void launch_regions(hipStream_t stream, uint32_t nblocks, const uint32_t *list, const uint32_t *count, uint32_t cap, const FbWork *fwork,
                     const CascadeDev &cd, const DevModel *models, float *ws) {

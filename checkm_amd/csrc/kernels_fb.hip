@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(64) fwd_kernel(WorkQueue queue, FbWork *__rest
     if (sc >= md.thr_fwd_f3 - cd.margin_fwd) {
       unsigned long long off;
       if (ws_alloc(cd, (unsigned long long)(w.Ld + 1) * 3ull, off)) {
-        const uint32_t pid = atomicAdd(&cd.cnt[CC_PASS], 1u);
+        const uint32_t pid = atomicAdd(&cd.gcnt[CC_PASS], 1u);
         if (pid < cd.cap_pass) {
           PassRec r;
           r.cand = w.cand; r.fwork = item; r.model = w.model; r.seq = w.seq; r.usc = pr.usc;
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(64) fwd_kernel(WorkQueue queue, FbWork *__rest
           cd.h_pass[pid] = r;
           work[item].aux_off = off; work[item].pass = pid;
           queue_push(cd, cd.bq, CC_BQ, md.fb_cls, cd.cap_fq, item, (uint32_t)CS_FWORK);
-        } else atomicOr(&cd.cnt[CC_STATUS], (uint32_t)CS_PASS);
+        } else atomicOr(&cd.gcnt[CC_STATUS], (uint32_t)CS_PASS);
       }
     }
   }

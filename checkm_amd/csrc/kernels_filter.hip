@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(64) msv_full_kernel(WorkQueue queue, const Pai
     if (out_usc) out_usc[pi] = usc;
     if (decide && to_bits(usc, le.nullsc) >= md.thr_msv_f1) {
       const uint32_t k = atomicAdd(&cd.cnt[CC_CAND], 1u);
-      if (k < cd.cap_cand) { PairRec r = pr; r.usc = usc; r.filtersc = 0.f; cd.cand[k] = r; } else atomicOr(&cd.cnt[CC_STATUS], (uint32_t)CS_CAND);
+      if (k < cd.cap_cand) { PairRec r = pr; r.usc = usc; r.filtersc = 0.f; cd.cand[k] = r; } else atomicOr(&cd.gcnt[CC_STATUS], (uint32_t)CS_CAND);
     }
   }
  }

@@ -51,6 +51,9 @@ def test_device_cascade_equals_host_cascade():
     assert len(host["rows"]) > 100 and host["pairs"][6] >= 2           # multi-domain regions are present
     for extra in (dict(CKM_WORKERS="1"), dict(CKM_WORKERS="3", CKM_WORKER_MIN_PAIRS="1"), dict(CKM_WORKERS="2", CKM_WORKER_MIN_PAIRS="1", CKM_PAIR_BUDGET="9000")):
         dev = _run(**extra)
+        if "CKM_PAIR_BUDGET" in extra:
+            assert dev["fallback"] >= 1 and dev["rows"] == host["rows"]         # more pairs than one SSV pass holds: host-driven, chunk by chunk
+            continue
         assert dev["fallback"] == 0, extra
         assert dev["rows"] == host["rows"], extra
         assert dev["pairs"][0] == host["pairs"][0]
@@ -58,5 +61,5 @@ def test_device_cascade_equals_host_cascade():
         assert dev["pairs"][1] >= host["pairs"][1] and dev["pairs"][3] >= host["pairs"][3] and dev["pairs"][4] >= host["pairs"][4]
         assert dev["pairs"][4] <= host["pairs"][4] + 5 and dev["pairs"][5] == host["pairs"][5]
     # workspace far too small for the device-side allocator: the lanes go through the host-driven cascade (which batches)
-    small = _run(CKM_WORKERS="2", CKM_WORKER_MIN_PAIRS="1", CKM_WS_BUDGET_MB="16")
+    small = _run(CKM_WORKERS="2", CKM_WORKER_MIN_PAIRS="1", CKM_WS_BUDGET_MB="64")
     assert small["fallback"] >= 1 and small["rows"] == host["rows"]
