@@ -617,6 +617,8 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   //  host-driven cascade: 1 SSV + finish, 2 exact MSV, 3 bias filter, 4 Viterbi fast, 5 Viterbi exact, 6 Forward parser, 7 Backward
   //  parser, 8 regions, 9-11 envelope Forward / Backward / OA, 12 region Forward, 13 ensembles)
   const int stop = getenv("CKM_CHAIN_STOP") ? atoi(getenv("CKM_CHAIN_STOP")) : 99;
+  static const uint32_t GRID_FB = getenv("CKM_GRID_FB") ? (uint32_t)atoi(getenv("CKM_GRID_FB")) : 4096, GRID_VIT = getenv("CKM_GRID_VIT") ? (uint32_t)atoi(getenv("CKM_GRID_VIT")) : 2048,
+                        GRID_MSV = getenv("CKM_GRID_MSV") ? (uint32_t)atoi(getenv("CKM_GRID_MSV")) : 1024;
   HIPCHK(hipMemsetAsync(d_gcnt, 0, (NG + 1) * CC_SIZE * sizeof(uint32_t), ms));
   HIPCHK(hipMemsetAsync(d_tops, 0, 4 * sizeof(unsigned long long), ms));
   if (owner->ssv_prev_done) HIPCHK(hipStreamWaitEvent(ms, owner->ssv_prev_done, 0));     // previous lane's SSV launches
@@ -648,24 +650,24 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
       FinishArgs fa{dm, lt, dlen, s->d_order.as<uint32_t>(), ctx->work.as<SsvBlockWork>() + sb.first, ctx->maxv.as<uint16_t>(),
                     cd.cand, cnt + CC_CAND, sb.cap_cand, nores, cnt + CC_NORES, sb.cap_nores};
       launch_msv_finish(sc, fa, (uint32_t)sb.nblocks);
-      if (stop >= 2) launch_msv_full(sc, 1024, WorkQueue{nullptr, cnt + CC_NORES, sb.cap_nores}, nores, dm, lt, res, off, dlen, nullptr, nullptr, p->maxMp, &cd);
-      if (stop >= 3) launch_bias_filter(sc, 1024, cd, dm, lt, res, off);
+      if (stop >= 2) launch_msv_full(sc, GRID_MSV, WorkQueue{nullptr, cnt + CC_NORES, sb.cap_nores}, nores, dm, lt, res, off, dlen, nullptr, nullptr, p->maxMp, &cd);
+      if (stop >= 3) launch_bias_filter(sc, GRID_MSV, cd, dm, lt, res, off);
       int rc = 0;
       for (int c = NVC - 1; c >= 0; --c) if (sb.vit[c]) {
-        if (stop >= 4) rc |= launch_vit(kVitQH[c], 2048, sc, WorkQueue{cd.vq + (size_t)c * cd.cap_vq, cnt + CC_VQ + c, cd.cap_vq}, cd.cand, dm, lt, res, off, dlen, nullptr, nullptr, nullptr, true, &cd);
-        if (stop >= 5) rc |= launch_vit(kVitQH[c], 512, sc, WorkQueue{cd.vxq + (size_t)c * cd.cap_vq, cnt + CC_VXQ + c, cd.cap_vq}, cd.cand, dm, lt, res, off, dlen, nullptr, nullptr, nullptr, false, &cd);
+        if (stop >= 4) rc |= launch_vit(kVitQH[c], GRID_VIT, sc, WorkQueue{cd.vq + (size_t)c * cd.cap_vq, cnt + CC_VQ + c, cd.cap_vq}, cd.cand, dm, lt, res, off, dlen, nullptr, nullptr, nullptr, true, &cd);
+        if (stop >= 5) rc |= launch_vit(kVitQH[c], std::max(64u, GRID_VIT / 4), sc, WorkQueue{cd.vxq + (size_t)c * cd.cap_vq, cnt + CC_VXQ + c, cd.cap_vq}, cd.cand, dm, lt, res, off, dlen, nullptr, nullptr, nullptr, false, &cd);
       }
       for (int c = NFC - 1; c >= 0; --c) if (sb.fb[c]) {
         const int Q = kFbQ[c];
         const WorkQueue qf{cd.fq + (size_t)c * sb.cap_f, cnt + CC_FQ + c, sb.cap_f}, qb{cd.bq + (size_t)c * sb.cap_f, cnt + CC_BQ + c, sb.cap_f};
         const WorkQueue qe{cd.eq + (size_t)c * sb.cap_e, cnt + CC_EQ + c, sb.cap_e}, qr{cd.rq + (size_t)c * sb.cap_r, cnt + CC_RQ + c, sb.cap_r};
-        if (stop >= 6) rc |= launch_fwd(Q, 4096, sc, qf, cd.fwork, dm, lt, res, off, ws, d_fout_f, h_events_f, d_gcnt + CC_EVENTS, cp.events_f, &cd);
-        if (stop >= 7) rc |= launch_bwd(Q, 4096, sc, qb, cd.fwork, dm, lt, res, off, ws, d_fout_f, nullptr);
+        if (stop >= 6) rc |= launch_fwd(Q, GRID_FB, sc, qf, cd.fwork, dm, lt, res, off, ws, d_fout_f, h_events_f, d_gcnt + CC_EVENTS, cp.events_f, &cd);
+        if (stop >= 7) rc |= launch_bwd(Q, GRID_FB, sc, qb, cd.fwork, dm, lt, res, off, ws, d_fout_f, nullptr);
         if (stop >= 8) launch_regions(sc, 1024, qb.list, qb.count, sb.cap_f, cd.fwork, cd, dm, ws);
-        if (stop >= 9) rc |= launch_fwd(Q, 4096, sc, qe, cd.ework, dm, lt, res, off, ws, d_fout_e, h_events_e, d_gcnt + CC_EVENTS_E, cp.events_e, nullptr);
-        if (stop >= 10) rc |= launch_bwd(Q, 4096, sc, qe, cd.ework, dm, lt, res, off, ws, d_fout_e, d_rerr_e);
-        if (stop >= 11) rc |= launch_oa(Q, 4096, sc, qe, cd.ework, dm, ws, d_rerr_e, d_fout_e, h_envout);
-        if (stop >= 12) rc |= launch_fwd(Q, 512, sc, qr, cd.rwork, dm, lt, res, off, ws, d_fout_r, d_events_r, d_gcnt + CC_EVENTS_R, 1 << 16, nullptr);
+        if (stop >= 9) rc |= launch_fwd(Q, GRID_FB, sc, qe, cd.ework, dm, lt, res, off, ws, d_fout_e, h_events_e, d_gcnt + CC_EVENTS_E, cp.events_e, nullptr);
+        if (stop >= 10) rc |= launch_bwd(Q, GRID_FB, sc, qe, cd.ework, dm, lt, res, off, ws, d_fout_e, d_rerr_e);
+        if (stop >= 11) rc |= launch_oa(Q, GRID_FB, sc, qe, cd.ework, dm, ws, d_rerr_e, d_fout_e, h_envout);
+        if (stop >= 12) rc |= launch_fwd(Q, std::max(64u, GRID_FB / 8), sc, qr, cd.rwork, dm, lt, res, off, ws, d_fout_r, d_events_r, d_gcnt + CC_EVENTS_R, 1 << 16, nullptr);
       }
       if (rc) throw Error(CKM_ERANGE, "no kernel instance for this model length");
     }
@@ -970,7 +972,7 @@ static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, cons
       if (host_cascade) cascade(&c->w[k], c, k, p, s, ranges[k], chunk[k], model_bins, maps[k]);
       else if (const int rc = cascade_dev(&c->w[k], c, k, p, s, ranges[k], chunk[k], model_bins, maps[k])) {
         c->fallbacks++;
-        cascade(&c->w[k], c, k, p, s, ranges[k], chunk[k], model_bins, maps[k], rc == 1);
+        cascade(&c->w[k], c, k, p, s, ranges[k], chunk[k], model_bins, maps[k], true);      // (the attempt took and passed the lane's SSV turn, rc 1 or 2)
       }
     } catch (...) { errs[k] = std::current_exception(); }
   };

@@ -198,13 +198,26 @@ __global__ void __launch_bounds__(128) bias_filter_kernel(CascadeDev cd, const D
     const uint8_t *rp = res + seq_off[pr.seq];
     float d0 = md.bpi0, d1 = md.beo1[rp[0]] * md.bpi1;
     int nexp = 0;
-    for (int i = 1; i < L; ++i) {
-      const float n0 = d0 * md.bt00 + d1 * md.bt10;
-      const float n1 = (d0 * md.bt01 + d1 * md.bt11) * md.beo1[rp[i]];
-      d0 = n0; d1 = n1;
-      const float mx = fmaxf(d0, d1);
-      if (mx < 0x1p-40f) { d0 *= 0x1p64f; d1 *= 0x1p64f; nexp -= 64; }
-      else if (mx > 0x1p40f) { d0 *= 0x1p-64f; d1 *= 0x1p-64f; nexp += 64; }
+    // residues 16 at a time (sequences are 16-byte aligned and padded): the row-to-row chain then waits for arithmetic, not for loads
+    const uint4 *rp4 = reinterpret_cast<const uint4 *>(rp);
+    uint4 cur = rp4[0];
+    for (int c0 = 0; c0 < L; c0 += 16) {
+      const uint4 nxt = (c0 + 16 < L) ? rp4[(c0 >> 4) + 1] : cur;
+      const uint32_t wd[4] = {cur.x, cur.y, cur.z, cur.w};
+      const int lim = min(16, L - c0);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int i = c0 + k;
+        if (k < lim && i >= 1) {
+          const float n0 = d0 * md.bt00 + d1 * md.bt10;
+          const float n1 = (d0 * md.bt01 + d1 * md.bt11) * md.beo1[(wd[k >> 2] >> (8 * (k & 3))) & 0xffu];
+          d0 = n0; d1 = n1;
+          const float mx = fmaxf(d0, d1);
+          if (mx < 0x1p-40f) { d0 *= 0x1p64f; d1 *= 0x1p64f; nexp -= 64; }
+          else if (mx > 0x1p40f) { d0 *= 0x1p-64f; d1 *= 0x1p-64f; nexp += 64; }
+        }
+      }
+      cur = nxt;
     }
     const float dsum = d0 + d1;
     cd.bias_raw[2 * (size_t)pi] = dsum; cd.bias_raw[2 * (size_t)pi + 1] = (float)nexp;
