@@ -475,6 +475,7 @@ def bench_cfg3(args, rank, world, workdir, sync, all_sum, all_max):
                           "bins_total": nbins, "parallelism": "bins sharded over %d GPU(s) by MarkerGeneFinder.find (file size x models); 1 all_gather of QA rows" % world},
                "bins_per_hour_lineage_wf_equiv": nbins / per_step * 3600.0,
                "parts_s_rank0": parts, "roofline": roof, "stage_pairs": stage_pairs(tot), "ssv_ms_max_rank": ssv_ms,
+               "searches_rank0": int(tot.get("searches", 0)), "cascade_fallback_lanes_rank0": int(tot.get("cascade_fallback_lanes", 0)), "search_ms_rank0": tot.get("ms_total", 0.0),
                "setup_s": {"world_and_files": t_setup}, "cpu_baseline": None}
         print(json.dumps(out))
     if world > 1:

@@ -121,10 +121,10 @@ struct Worker {
   std::unique_ptr<HostPool> pool;         // host threads of this worker
   // ---- device-driven cascade (ckm_cascade.hip): tables, queues and result buffers of this lane; capacities only grow ----
   struct CascadeCaps { uint32_t fwork = 0, ework = 0, rwork = 0, pass = 0, reg = 0, events_f = 0, events_e = 0; uint64_t hens = 0;
-                       uint32_t div_cand = 12, div_nores = 48, div_fwork = 96, div_ework = 256, div_rwork = 4096; } caps;   // per-group tables hold pairs / div entries
+                       uint32_t div_cand = 12, div_nores = 48, div_fwork = 160, div_ework = 1024, div_rwork = 32768; } caps;   // per-group tables hold pairs / div entries
   DevBuf c_cnt, c_cand, c_nores, c_bias, c_vfast, c_vexact, c_vflag, c_route, c_vq, c_vxq, c_fq, c_bq, c_eq, c_rq, c_fwork, c_ework, c_rwork, c_ens,
-         c_fout_f, c_fout_e, c_fout_r, c_rerr_e, c_rerr_r, c_tops, c_events_r;
-  PinnedBuf h_cnt, h_pass, h_reg, h_envout, h_events_f, h_events_e, h_hens;
+         c_fout_f, c_fout_e, c_fout_r, c_rerr_e, c_rerr_r, c_tops, c_events_r, c_pass, c_reg, c_hens, c_envout, c_events_f, c_events_e;
+  PinnedBuf h_cnt, h_pass, h_reg, h_envout, h_events_f, h_events_e, h_hens, h_tops;
   hipEvent_t cev[4] = {nullptr, nullptr, nullptr, nullptr};      // fork / join points of the lane's chain
   hipEvent_t cls_ev[16] = {};                                    // one per side stream
   hipEvent_t grp_ev[32] = {};                                    // end of the SSV launch of each model-length group
@@ -218,14 +218,20 @@ struct Cand {            // a pair that survived the MSV stage
   PairRec r; float fwdsc; float fwd_xC; uint32_t slot; bool alive;
 };
 
-struct EventIndex {      // rescale events grouped by slot, rows ascending
-  std::vector<std::vector<std::pair<int, float>>> by_slot;
-  void build(const std::vector<ScaleEvent> &ev, size_t nslots) {
-    by_slot.assign(nslots, {});
-    for (const auto &e : ev) if (e.slot < nslots) by_slot[e.slot].push_back({e.row, e.scale});
-    for (auto &v : by_slot) std::sort(v.begin(), v.end());
+struct EventIndex {      // rescale events grouped by slot, rows ascending (flat: one counting sort, no per-slot allocation)
+  std::vector<uint32_t> first;                    // [nslots + 1]
+  std::vector<std::pair<int, float>> ev;          // (row, scale), slot-major
+  void build(const ScaleEvent *e, size_t n, size_t nslots) {
+    first.assign(nslots + 1, 0);
+    for (size_t k = 0; k < n; ++k) if (e[k].slot < nslots) first[e[k].slot + 1]++;
+    for (size_t k = 0; k < nslots; ++k) first[k + 1] += first[k];
+    ev.resize(first[nslots]);
+    std::vector<uint32_t> at(first.begin(), first.end() - 1);
+    for (size_t k = 0; k < n; ++k) if (e[k].slot < nslots) ev[at[e[k].slot]++] = {e[k].row, e[k].scale};
+    for (size_t k = 0; k < nslots; ++k) if (first[k + 1] - first[k] > 1) std::sort(ev.begin() + first[k], ev.begin() + first[k + 1]);
   }
-  std::vector<float> scales(uint32_t slot) const { std::vector<float> r; for (auto &p : by_slot[slot]) r.push_back(p.second); return r; }
+  void build(const std::vector<ScaleEvent> &v, size_t nslots) { build(v.data(), v.size(), nslots); }
+  std::vector<float> scales(uint32_t slot) const { std::vector<float> r; for (uint32_t k = first[slot]; k < first[slot + 1]; ++k) r.push_back(ev[k].second); return r; }
 };
 
 // Runs fwd/bwd(/oa) for a list of work items, grouped by the model's canonical Q.

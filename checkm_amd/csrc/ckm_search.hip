@@ -588,17 +588,18 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   cd0.ework = dev_table<FbWork>(ctx->c_ework, cp.ework); cd0.cap_ework = cp.ework;
   cd0.rwork = dev_table<FbWork>(ctx->c_rwork, cp.rwork); cd0.ens = dev_table<EnsWork>(ctx->c_ens, cp.rwork); cd0.cap_rwork = cp.rwork;
   cd0.ws_top = d_tops; cd0.ws_cap = ws_floats;
-  cd0.h_pass = pin_table<PassRec>(ctx->h_pass, cp.pass); cd0.cap_pass = cp.pass;
-  cd0.h_reg = pin_table<RegionRec>(ctx->h_reg, cp.reg); cd0.cap_reg = cp.reg;
-  float *h_hens = pin_table<float>(ctx->h_hens, cp.hens);
+  // result tables live in device memory; once the counters are known their used prefixes are copied to pinned staging in one go
+  cd0.h_pass = dev_table<PassRec>(ctx->c_pass, cp.pass); cd0.cap_pass = cp.pass;
+  cd0.h_reg = dev_table<RegionRec>(ctx->c_reg, cp.reg); cd0.cap_reg = cp.reg;
+  float *d_hens = dev_table<float>(ctx->c_hens, cp.hens);
   cd0.hens_top = d_tops + 1; cd0.hens_cap = cp.hens;
   cd0.seq_len = dlen;
   cd0.margin_msv = 0.01f; cd0.margin_vit = 0.01f; cd0.margin_fwd = 0.05f;
   FwdOut *d_fout_f = dev_table<FwdOut>(ctx->c_fout_f, cp.fwork), *d_fout_e = dev_table<FwdOut>(ctx->c_fout_e, cp.ework), *d_fout_r = dev_table<FwdOut>(ctx->c_fout_r, cp.rwork);
   int32_t *d_rerr_e = dev_table<int32_t>(ctx->c_rerr_e, cp.ework);
   ScaleEvent *d_events_r = dev_table<ScaleEvent>(ctx->c_events_r, 1 << 16);
-  EnvOut *h_envout = pin_table<EnvOut>(ctx->h_envout, cp.ework);
-  ScaleEvent *h_events_f = pin_table<ScaleEvent>(ctx->h_events_f, cp.events_f), *h_events_e = pin_table<ScaleEvent>(ctx->h_events_e, cp.events_e);
+  EnvOut *d_envout = dev_table<EnvOut>(ctx->c_envout, cp.ework);
+  ScaleEvent *d_events_f = dev_table<ScaleEvent>(ctx->c_events_f, cp.events_f), *d_events_e = dev_table<ScaleEvent>(ctx->c_events_e, cp.events_e);
   uint32_t *h_cnt = pin_table<uint32_t>(ctx->h_cnt, (NG + 1) * CC_SIZE);
   ensure_ens_seeds(ctx);
   float *ws = ctx->ws.as<float>();
@@ -661,12 +662,12 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
         const int Q = kFbQ[c];
         const WorkQueue qf{cd.fq + (size_t)c * sb.cap_f, cnt + CC_FQ + c, sb.cap_f}, qb{cd.bq + (size_t)c * sb.cap_f, cnt + CC_BQ + c, sb.cap_f};
         const WorkQueue qe{cd.eq + (size_t)c * sb.cap_e, cnt + CC_EQ + c, sb.cap_e}, qr{cd.rq + (size_t)c * sb.cap_r, cnt + CC_RQ + c, sb.cap_r};
-        if (stop >= 6) rc |= launch_fwd(Q, GRID_FB, sc, qf, cd.fwork, dm, lt, res, off, ws, d_fout_f, h_events_f, d_gcnt + CC_EVENTS, cp.events_f, &cd);
+        if (stop >= 6) rc |= launch_fwd(Q, GRID_FB, sc, qf, cd.fwork, dm, lt, res, off, ws, d_fout_f, d_events_f, d_gcnt + CC_EVENTS, cp.events_f, &cd);
         if (stop >= 7) rc |= launch_bwd(Q, GRID_FB, sc, qb, cd.fwork, dm, lt, res, off, ws, d_fout_f, nullptr);
         if (stop >= 8) launch_regions(sc, 1024, qb.list, qb.count, sb.cap_f, cd.fwork, cd, dm, ws);
-        if (stop >= 9) rc |= launch_fwd(Q, GRID_FB, sc, qe, cd.ework, dm, lt, res, off, ws, d_fout_e, h_events_e, d_gcnt + CC_EVENTS_E, cp.events_e, nullptr);
+        if (stop >= 9) rc |= launch_fwd(Q, GRID_FB, sc, qe, cd.ework, dm, lt, res, off, ws, d_fout_e, d_events_e, d_gcnt + CC_EVENTS_E, cp.events_e, nullptr);
         if (stop >= 10) rc |= launch_bwd(Q, GRID_FB, sc, qe, cd.ework, dm, lt, res, off, ws, d_fout_e, d_rerr_e);
-        if (stop >= 11) rc |= launch_oa(Q, GRID_FB, sc, qe, cd.ework, dm, ws, d_rerr_e, d_fout_e, h_envout);
+        if (stop >= 11) rc |= launch_oa(Q, GRID_FB, sc, qe, cd.ework, dm, ws, d_rerr_e, d_fout_e, d_envout);
         if (stop >= 12) rc |= launch_fwd(Q, std::max(64u, GRID_FB / 8), sc, qr, cd.rwork, dm, lt, res, off, ws, d_fout_r, d_events_r, d_gcnt + CC_EVENTS_R, 1 << 16, nullptr);
       }
       if (rc) throw Error(CKM_ERANGE, "no kernel instance for this model length");
@@ -683,8 +684,10 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   }
   for (int k = NSS; k < NS; ++k) { HIPCHK(hipEventRecord(ctx->cls_ev[k], ctx->side[k])); HIPCHK(hipStreamWaitEvent(ms, ctx->cls_ev[k], 0)); }
   // ---- trace ensembles of the multi-domain regions of all groups, results exported to pinned memory; counters last ----
-  if (stop >= 13) launch_ensemble(ms, cd0.ens, d_gcnt + CC_RWORK, cp.rwork, 128, p->maxMp, dm, lt, res, off, ws, ctx->ensseeds.as<uint32_t>(), h_hens);
+  if (stop >= 13) launch_ensemble(ms, cd0.ens, d_gcnt + CC_RWORK, cp.rwork, 128, p->maxMp, dm, lt, res, off, ws, ctx->ensseeds.as<uint32_t>(), d_hens);
   HIPCHK(hipMemcpyAsync(h_cnt, d_gcnt, (NG + 1) * CC_SIZE * sizeof(uint32_t), hipMemcpyDeviceToHost, ms));
+  unsigned long long *h_tops = pin_table<unsigned long long>(ctx->h_tops, 4);
+  HIPCHK(hipMemcpyAsync(h_tops, d_tops, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ms));
   HIPCHK(hipGetLastError());
   CKM_TRACE_PT("chain queued");
   HIPCHK(hipStreamSynchronize(ms));                           // ---- the one synchronisation of the lane ----
@@ -728,11 +731,25 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   st.pairs_msv_full = n_nores; st.pairs_bias = n_cand; st.pairs_fwd = n_fwork; st.pairs_dom = n_pass; st.regions_multi = n_rwork;
   const CascadeDev &cd = cd0;
 
+  // ---- the used prefixes of the result tables come over in one batch of copies (second and last wait of the chain) ----
+  const uint64_t n_hens = std::min<uint64_t>(h_tops[1], cp.hens);
+  PassRec *h_pass = pin_table<PassRec>(ctx->h_pass, n_pass);
+  RegionRec *h_reg = pin_table<RegionRec>(ctx->h_reg, n_reg);
+  EnvOut *h_envout = pin_table<EnvOut>(ctx->h_envout, n_ework);
+  ScaleEvent *h_events_f = pin_table<ScaleEvent>(ctx->h_events_f, n_evf), *h_events_e = pin_table<ScaleEvent>(ctx->h_events_e, n_eve);
+  float *h_hens = pin_table<float>(ctx->h_hens, n_hens);
+  if (n_pass) HIPCHK(hipMemcpyAsync(h_pass, cd.h_pass, (size_t)n_pass * sizeof(PassRec), hipMemcpyDeviceToHost, ms));
+  if (n_reg) HIPCHK(hipMemcpyAsync(h_reg, cd.h_reg, (size_t)n_reg * sizeof(RegionRec), hipMemcpyDeviceToHost, ms));
+  if (n_ework) HIPCHK(hipMemcpyAsync(h_envout, d_envout, (size_t)n_ework * sizeof(EnvOut), hipMemcpyDeviceToHost, ms));
+  if (n_evf) HIPCHK(hipMemcpyAsync(h_events_f, d_events_f, (size_t)n_evf * sizeof(ScaleEvent), hipMemcpyDeviceToHost, ms));
+  if (n_eve) HIPCHK(hipMemcpyAsync(h_events_e, d_events_e, (size_t)n_eve * sizeof(ScaleEvent), hipMemcpyDeviceToHost, ms));
+  if (n_hens) HIPCHK(hipMemcpyAsync(h_hens, d_hens, (size_t)n_hens * sizeof(float), hipMemcpyDeviceToHost, ms));
+  HIPCHK(hipStreamSynchronize(ms));
+  CKM_TRACE_PT("results copied");
   // ---- the filter decisions again, exactly (host libm), for the pairs the device let through ----
-  const PassRec *pass = cd.h_pass;
-  std::vector<ScaleEvent> evf(h_events_f, h_events_f + n_evf), eve(h_events_e, h_events_e + n_eve);
-  EventIndex fev; fev.build(evf, n_fwork);
-  EventIndex eev; eev.build(eve, n_ework);
+  const PassRec *pass = h_pass;
+  EventIndex fev; fev.build(h_events_f, n_evf, n_fwork);
+  EventIndex eev; eev.build(h_events_e, n_eve, n_ework);
   std::vector<uint8_t> alive(n_pass, 0); std::vector<float> fwdsc(n_pass, 0.f);
   std::atomic<int> inconsistent{0};
   pool_run(ctx, n_pass, 256, [&](size_t lo, size_t hi) {
@@ -763,7 +780,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   // ---- regions by pair, in sequence order; envelopes of single-domain regions are already rescored, ensembles get clustered ----
   std::vector<uint32_t> rorder(n_reg);
   std::iota(rorder.begin(), rorder.end(), 0u);
-  const RegionRec *reg = cd.h_reg;
+  const RegionRec *reg = h_reg;
   std::sort(rorder.begin(), rorder.end(), [&](uint32_t a, uint32_t b) { return reg[a].pass != reg[b].pass ? reg[a].pass < reg[b].pass : reg[a].i < reg[b].i; });
   DomStage ds;
   std::vector<int32_t> dsidx(n_pass, -1);

@@ -229,7 +229,7 @@ class MarkerGeneFinder(object):
                     hits = _lib.search(ctx, profiles, seqs, bm, 0.1, 0.1)          # -E 0.1 --domE 0.1, markerGeneFinder.py:141
                     st = ctx.stats()
                     for f in ("pairs_ssv", "pairs_msv_full", "pairs_bias", "pairs_vit", "pairs_vit_exact", "pairs_fwd", "pairs_dom", "envelopes", "regions_multi",
-                              "cells_ssv", "residue_hmm", "ms_ssv", "ms_total", "ssv_launches"):
+                              "cells_ssv", "residue_hmm", "ms_ssv", "ms_total", "ssv_launches", "cascade_fallback_lanes"):
                         totals[f] = totals.get(f, 0) + getattr(st, f)
                     totals["searches"] = totals.get("searches", 0) + 1
                     part = dict(seqs=seqs, hits=hits, bins=[binIds[i] for i in batch])
