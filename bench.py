@@ -452,7 +452,7 @@ def bench_cfg3(args, rank, world, workdir, sync, all_sum, all_max):
     t0 = time.perf_counter()
     w, binIds, files, lin = lineage_setup(workdir, nbins, rank, world, sync)
     t_setup = time.perf_counter() - t0
-    warm = min(nbins, 4 * world)
+    warm = min(nbins, 64 * world)           # one full-size batch per rank: contexts, profile DBs, device tables and workspace at their working sizes
     for k in range(max(1, args.warmup)):
         lineage_pass(w, binIds[:warm], files[:warm], lin, os.path.join(workdir, "cfg3_warm"), rank)
     sync()

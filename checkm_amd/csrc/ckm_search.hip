@@ -498,9 +498,36 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   // plan: lineage_wf scans the same bins twice, bench repeats steps).  Each group is one SSV launch AND one sub-cascade: its survivors
   // go down their own chain of queues as soon as that launch is done, while the SSV launches of the other groups still run. ----
   hipStream_t ms = ctx->stream;
-  std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;
+  // Two parts by sequence length: the long sequences of every bin (a prefix of its length-sorted order holding ~CKM_LONG_SHARE of the
+  // residues) are scanned first, so that their chains -- every stage lasts as long as its longest sequence -- run underneath the SSV
+  // launches of the short part, and what is left after the last SSV launch is the chain of short sequences only.
+  const uint32_t nbins = s->nbins;
+  std::vector<uint32_t> mid(rng.hi);                        // part 0 = [lo, mid), part 1 = [mid, hi)
+  int nparts = 1, Lcut = 0;
   {
-    std::vector<uint64_t> key{p->uid, s->uid, pair_budget, 0ull, rng.tag, 0xdeull};
+    uint64_t split_min = 2000000;
+    if (const char *e = getenv("CKM_SPLIT_MIN_PAIRS")) split_min = strtoull(e, nullptr, 10);
+    double share = 0.25;
+    if (const char *e = getenv("CKM_LONG_SHARE")) share = atof(e);
+    if (total_pairs >= split_min && share > 0.0 && share < 1.0) {
+      std::vector<uint64_t> by_len((size_t)s->maxL + 2, 0);
+      uint64_t total = 0;
+      for (uint32_t b = 0; b < nbins; ++b) for (uint32_t k = rng.lo[b]; k < rng.hi[b]; ++k) { const int L = s->len[s->order[k]]; by_len[L] += (uint64_t)L; total += (uint64_t)L; }
+      uint64_t acc = 0;
+      for (int L = s->maxL; L >= 1; --L) { acc += by_len[L]; if ((double)acc >= share * (double)total) { Lcut = L - 1; break; } }
+      if (Lcut > 0) {
+        nparts = 2;
+        for (uint32_t b = 0; b < nbins; ++b) {
+          uint32_t lo = rng.lo[b], hi = rng.hi[b];                 // lengths descend along the order: first position with len <= Lcut
+          while (lo < hi) { const uint32_t m = (lo + hi) / 2; if (s->len[s->order[m]] > Lcut) lo = m + 1; else hi = m; }
+          mid[b] = lo;
+        }
+      }
+    }
+  }
+  std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;      // key = part * 1000 + SSV register class
+  {
+    std::vector<uint64_t> key{p->uid, s->uid, pair_budget, (uint64_t)Lcut, rng.tag, 0xdeull};
     for (auto &mw : mws) { key.push_back(0xffffffffull + mw.model); for (uint32_t b : model_bins[mw.model]) key.push_back(b); }
     if (key == ctx->plan_key) {
       groups = ctx->plan_groups;
@@ -513,9 +540,12 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
         uint64_t pb = mw.pair_base;
         for (uint32_t b : model_bins[mw.model]) {
           const uint32_t o0 = rng.lo[b], n = rng.hi[b] - o0;
-          for (uint32_t a = 0; a < n; a += per_block) {
-            SsvBlockWork w; w.model = mw.model; w.list_start = o0 + a; w.count = std::min(per_block, n - a); w.pair_start = (uint32_t)(pb + a);
-            byQ[Q].push_back(w);
+          for (int part = 0; part < nparts; ++part) {
+            const uint32_t a0 = part == 0 ? 0 : mid[b] - o0, a1 = (part == 0 && nparts == 2) ? mid[b] - o0 : n;
+            for (uint32_t a = a0; a < a1; a += per_block) {
+              SsvBlockWork w; w.model = mw.model; w.list_start = o0 + a; w.count = std::min(per_block, a1 - a); w.pair_start = (uint32_t)(pb + a);
+              byQ[part * 1000 + Q].push_back(w);
+            }
           }
           pb += n; c_res += rng.res[b]; c_cells += rng.res[b] * (uint64_t)p->prof[mw.model].M;
         }
@@ -541,11 +571,21 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   std::vector<Sub> subs;
   {
     std::map<int, size_t> at;
-    for (auto &g : groups) { Sub sb; sb.Q = g.first; sb.first = g.second.first; sb.nblocks = g.second.second; at[g.first] = subs.size(); subs.push_back(sb); }
-    for (auto &mw : mws) { Sub &sb = subs[at[p->prof[mw.model].ssvQ]]; sb.pairs += mw.npairs; sb.vit[p->dm[mw.model].vit_cls] = true; sb.fb[p->dm[mw.model].fb_cls] = true; }
+    for (auto &g : groups) { Sub sb; sb.Q = g.first % 1000; sb.first = g.second.first; sb.nblocks = g.second.second; at[g.first] = subs.size(); subs.push_back(sb); }
+    for (auto &mw : mws) {
+      uint64_t n0 = 0;                                        // the model's pairs in part 0
+      for (uint32_t b : model_bins[mw.model]) n0 += mid[b] - rng.lo[b];
+      for (int part = 0; part < nparts; ++part) {
+        const uint64_t np = part == 0 ? n0 : mw.npairs - n0;
+        auto it = at.find(part * 1000 + p->prof[mw.model].ssvQ);
+        if (it == at.end()) continue;                         // (no sequence of this part in the model's bins)
+        Sub &sb = subs[it->second]; sb.pairs += np; sb.vit[p->dm[mw.model].vit_cls] = true; sb.fb[p->dm[mw.model].fb_cls] = true;
+      }
+    }
   }
   const size_t NG = subs.size();
-  if (NG > 32) return 2;
+  if (NG > 64) return 2;
+  CKM_TRACE_PT("plan ready");
 
   // ---- capacities: shares of the pairs (the divisors halve when a table overflowed on an earlier call), tables ----
   Worker::CascadeCaps &cp = ctx->caps;
@@ -569,11 +609,15 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   ctx->maxv.ensure(total_pairs * 2 + 64);
   // the float workspace: an estimate from the pairs (special rows of ~0.3 % of them, matrices of ~0.06 %), within the lane's budget
   {
-    const uint64_t est = (uint64_t)((double)total_pairs * 2600.0) + ((uint64_t)256 << 20);
+    double mp_sum = 0.0; for (auto &mw : mws) mp_sum += (double)mw.npairs * (double)(p->prof[mw.model].fbQ * NL);
+    // bytes per (pair x padded model length): ~1e-4 envelopes per pair x 5 arrays x ~250 rows x 4 B to begin with (marker genes are a few
+    // hundred of a bin's thousands of ORFs); a search that outgrows it falls back once and the factor grows for the next calls
+    const uint64_t est = (uint64_t)(mp_sum * cp.ws_per_mp + (double)total_pairs * 24.0) + ((uint64_t)256 << 20);
     const size_t want = (size_t)std::min<uint64_t>(std::max<uint64_t>(est, (uint64_t)1 << 30), (uint64_t)ctx->ws_budget);
     if (ctx->ws.cap < want) ctx->ws.ensure(want);
   }
   const uint64_t ws_floats = ctx->ws.cap / 4;
+  CKM_TRACE_PT("workspace ready");
   uint32_t *d_gcnt = dev_table<uint32_t>(ctx->c_cnt, (NG + 1) * CC_SIZE);        // block 0: counters shared by the groups; block 1 + g: group g's
   unsigned long long *d_tops = dev_table<unsigned long long>(ctx->c_tops, 4);
   CascadeDev cd0; memset(&cd0, 0, sizeof(cd0));
@@ -603,6 +647,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   uint32_t *h_cnt = pin_table<uint32_t>(ctx->h_cnt, (NG + 1) * CC_SIZE);
   ensure_ens_seeds(ctx);
   float *ws = ctx->ws.as<float>();
+  CKM_TRACE_PT("tables ready");
   const int NS = side_streams();
   const int NSS = std::min(4, NS);                 // streams of the SSV launches
   const int NCH = NS - NSS;                        // streams of the groups' chains (none left: a chain follows its SSV launch on the same stream)
@@ -627,16 +672,24 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   HIPCHK(hipEventRecord(ctx->cev[0], ms));
   for (int k = 0; k < NS; ++k) HIPCHK(hipStreamWaitEvent(ctx->side[k], ctx->cev[0], 0));
   {
+    std::vector<size_t> launch_order;                            // long part first; inside a part the heaviest register class first
+    {
+      size_t n0 = 0;
+      for (auto &g : groups) if (g.first < 1000) ++n0;
+      for (size_t g = n0; g-- > 0;) launch_order.push_back(g);
+      for (size_t g = NG; g-- > n0;) launch_order.push_back(g);
+    }
     int gi = 0;
-    for (size_t g = NG; g-- > 0; ++gi) {                         // heaviest register class first
+    for (size_t g : launch_order) {
+      const int gi_now = gi++; (void)gi_now;
       const Sub &sb = subs[g];
-      hipStream_t sv = ctx->side[gi % NSS];
+      hipStream_t sv = ctx->side[gi_now % NSS];
       if (launch_ssv(sb.Q, (int)sb.nblocks, ssv_threads_for(sb.Q), sv, ctx->work.as<SsvBlockWork>() + sb.first, dm, res, off, dlen,
                      s->d_order.as<uint32_t>(), ctx->maxv.as<uint16_t>()))
         throw Error(CKM_ERANGE, "no SSV kernel instance for this model length");
       st.ssv_launches++;
       hipStream_t sc = sv;
-      if (NCH > 0) { sc = ctx->side[NSS + gi % NCH]; HIPCHK(hipEventRecord(ctx->grp_ev[g], sv)); HIPCHK(hipStreamWaitEvent(sc, ctx->grp_ev[g], 0)); }
+      if (NCH > 0) { sc = ctx->side[NSS + gi_now % NCH]; HIPCHK(hipEventRecord(ctx->grp_ev[g], sv)); HIPCHK(hipStreamWaitEvent(sc, ctx->grp_ev[g], 0)); }
       // ---- the group's chain ----
       CascadeDev cd = cd0;
       uint32_t *cnt = d_gcnt + (1 + g) * CC_SIZE;
@@ -724,6 +777,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
     }
   }
   if (status & CS_RWORK) cp.hens *= 2;
+  if (status & CS_WS) cp.ws_per_mp *= 2.5f;
   if (!fits) {
     if (getenv("CKM_TRACE")) fprintf(stderr, "ckm-trace w%d device cascade did not fit (status 0x%x): host-driven cascade for this lane\n", ctx->id, status);
     return 1;
