@@ -140,8 +140,9 @@ constexpr int NWORKERS = 8;          // upper bound; CKM_WORKERS (default 3) sel
 
 struct ckm_ctx {
   int device = 0;
-  int nworkers = 3;                // = nclasses * ngroups
-  int nclasses = 3, ngroups = 1;   // length classes (CKM_WORKERS) x bin groups (CKM_BIN_GROUPS)
+  int nworkers = 1;                // = nclasses * ngroups
+  int nclasses = 1, ngroups = 1;   // lanes: length classes (CKM_WORKERS) x bin groups (CKM_BIN_GROUPS).  One lane is the default: the device-driven
+                                   // cascade overlaps the stages of its model-length groups by itself; the host-driven one (CKM_CASCADE=host) gains from 3
   DevBuf reduce_scratch;                  // grow-only device buffer of the reduce kernels
   Worker w[NWORKERS];
   ckm_search_stats stats;

@@ -649,7 +649,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   float *ws = ctx->ws.as<float>();
   CKM_TRACE_PT("tables ready");
   const int NS = side_streams();
-  const int NSS = std::min(4, NS);                 // streams of the SSV launches
+  const int NSS = NS >= 8 ? 4 : std::max(1, NS / 3); // streams of the SSV launches
   const int NCH = NS - NSS;                        // streams of the groups' chains (none left: a chain follows its SSV launch on the same stream)
 
   // ---- wait for the turn (the lanes' SSV phases run one behind the other on the device: VALU-bound, nothing to gain side by side),
