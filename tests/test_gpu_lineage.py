@@ -89,7 +89,7 @@ def test_lineage_marker_file_through_find_and_qa(lineage, capsys, monkeypatch):
         texts[binId] = hs.format_domtblout(rows, [r[0] for r in recs], [r[1] for r in recs])
         got = open(os.path.join(out, "bins", binId, DefaultValues.HMMER_TABLE_OUT)).read()
         assert got == texts[binId], binId
-        assert len(rows) >= 100
+        assert len(rows) >= 50
     hs.close()
     # ---- QA: resident hits, one batched count, table; against the reduce oracle for the checked bins ----
     _bin_stats(out, binIds)
