@@ -379,6 +379,34 @@ def main():
     torch.cuda.synchronize()
     dt_host = all_max(time.perf_counter() - t0)
     seqs2.close()
+    # steady state of a stream of batches: two steps in flight (own context each), so that the end effects of one step -- the chain of
+    # its last model-length groups, the exact decisions and the row assembly on the host -- run under the SSV phase of the next.
+    # MarkerGeneFinder.find works this way on its batches of bins; `value` above is every step ALONE.
+    steady = None
+    if args.pipeline <= 1 and world == 1 and os.environ.get("CKM_BENCH_STEADY", "1") != "0":
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        c2 = _lib.Context(local_rank); p2 = _lib.Profiles(c2, hmm_path); s2 = _lib.Seqs(c2, bins)
+        pl2 = cqa.QAPlan.for_hmm_models(p2, [list(range(p2.n))] * nb)
+        lanes2 = [(ctx, prof, seqs, plan), (c2, p2, s2, pl2)]
+
+        def lane_steps(j, n):
+            c, p_, s_, pl = lanes2[j]
+            for _ in range(n):
+                hits = _lib.search(c, p_, s_)
+                qa = pl.reduce(c, hits, s_)
+                hits.close(); qa.close()
+        nst = max(2, args.steps)
+        with ThreadPoolExecutor(max_workers=2) as ex:
+            list(ex.map(lambda j: lane_steps(j, 1), range(2)))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            list(ex.map(lambda j: lane_steps(j, nst), range(2)))
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - t0
+        steady = {"steps_in_flight": 2, "steps": 2 * nst, "ms_per_step": dts / (2 * nst) * 1e3, "value": float(st.residue_hmm) * 2 * nst / dts,
+                  "note": "two contexts, each running its steps back to back; no gather"}
+        s2.close(); p2.close(); c2.close()
     # lineage_wf-equivalent side measurement (cfg3-shaped inputs, from files, product classes)
     lineage = None
     if args.lineage_bins > 0:
@@ -413,6 +441,7 @@ def main():
             "value_from_host": total_residue_hmm / dt_host,
             "value_from_host_note": "same step with digitise + pack + H2D of the bins inside the clock (host buffers at the boundary); `value` starts from HBM-resident inputs",
             "bins_per_hour_43models": total_bins / per_step * 3600.0,
+            "steady_state": steady,
             "lineage_wf_equiv": lineage,
             "gcups_ssv": float(st.cells_ssv) / max(ssv_ms / args.steps / 1e3, 1e-12) / 1e9,
             "roofline": roof, "roofline_valu": valu,

@@ -533,19 +533,20 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
       groups = ctx->plan_groups;
       st.pairs_ssv += ctx->plan_pairs; st.residue_hmm += ctx->plan_residue_hmm; st.cells_ssv += ctx->plan_cells;
     } else {
-      std::map<int, std::vector<SsvBlockWork>> byQ;
+      // runs = the sequences of one (model, bin, part), already longest first; a launch takes the first block of every run, then the
+      // second of every run, ...: its blocks come out (nearly) longest first without sorting a million of them (a block's time is set
+      // by its first = longest sequence, and the few very long ones must not start last)
+      struct Run { uint32_t model, first, count; uint64_t pair0; };
+      std::map<int, std::vector<Run>> runs;
       uint64_t c_pairs = 0, c_res = 0, c_cells = 0;
       for (auto &mw : mws) {
-        const int Q = p->prof[mw.model].ssvQ; const int threads = ssv_threads_for(Q); const uint32_t per_block = (uint32_t)threads / 64 * 4 * 4;
+        const int Q = p->prof[mw.model].ssvQ;
         uint64_t pb = mw.pair_base;
         for (uint32_t b : model_bins[mw.model]) {
           const uint32_t o0 = rng.lo[b], n = rng.hi[b] - o0;
           for (int part = 0; part < nparts; ++part) {
             const uint32_t a0 = part == 0 ? 0 : mid[b] - o0, a1 = (part == 0 && nparts == 2) ? mid[b] - o0 : n;
-            for (uint32_t a = a0; a < a1; a += per_block) {
-              SsvBlockWork w; w.model = mw.model; w.list_start = o0 + a; w.count = std::min(per_block, a1 - a); w.pair_start = (uint32_t)(pb + a);
-              byQ[part * 1000 + Q].push_back(w);
-            }
+            if (a1 > a0) runs[part * 1000 + Q].push_back({mw.model, o0 + a0, a1 - a0, pb + a0});
           }
           pb += n; c_res += rng.res[b]; c_cells += rng.res[b] * (uint64_t)p->prof[mw.model].M;
         }
@@ -553,11 +554,21 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
       }
       st.pairs_ssv += c_pairs; st.residue_hmm += c_res; st.cells_ssv += c_cells;
       std::vector<SsvBlockWork> allw;
-      for (auto &kv : byQ) {
-        // longest blocks first inside a launch (a block's time is set by its first = longest sequence)
-        std::stable_sort(kv.second.begin(), kv.second.end(), [&](const SsvBlockWork &x, const SsvBlockWork &y) {
-          return s->len[s->order[x.list_start]] > s->len[s->order[y.list_start]]; });
-        groups.push_back({kv.first, {allw.size(), kv.second.size()}}); allw.insert(allw.end(), kv.second.begin(), kv.second.end());
+      for (auto &kv : runs) {
+        const int Q = kv.first % 1000; const uint32_t per_block = (uint32_t)ssv_threads_for(Q) / 64 * 4 * 4;
+        const size_t first = allw.size();
+        std::vector<Run> &rv = kv.second;
+        std::stable_sort(rv.begin(), rv.end(), [&](const Run &x, const Run &y) { return s->len[s->order[x.first]] > s->len[s->order[y.first]]; });
+        for (uint32_t a = 0;; a += per_block) {
+          bool any = false;
+          for (const Run &r : rv) if (a < r.count) {
+            any = true;
+            SsvBlockWork w; w.model = r.model; w.list_start = r.first + a; w.count = std::min(per_block, r.count - a); w.pair_start = (uint32_t)(r.pair0 + a);
+            allw.push_back(w);
+          }
+          if (!any) break;
+        }
+        groups.push_back({kv.first, {first, allw.size() - first}});
       }
       ctx->work.ensure(allw.size() * sizeof(SsvBlockWork));
       HIPCHK(hipMemcpyAsync(ctx->work.p, allw.data(), allw.size() * sizeof(SsvBlockWork), hipMemcpyHostToDevice, ms));

@@ -32,10 +32,10 @@ PROFILE_CACHE = {}
 
 def profiles_for(ctx, db):
     st = os.stat(db)
-    key = (os.path.abspath(db), st.st_mtime_ns, st.st_size)
+    key = (os.path.abspath(db), st.st_mtime_ns, st.st_size, id(ctx))
     p = PROFILE_CACHE.get(key)
     if p is None or not p.h:
-        for k in [k for k in PROFILE_CACHE if k[0] == key[0]]:          # the file changed: drop the stale copy unless a scan still uses it
+        for k in [k for k in PROFILE_CACHE if k[0] == key[0] and k[3] == key[3]]:      # the file changed: drop the stale copy unless a scan still uses it
             if not any(ent["profiles"] is PROFILE_CACHE[k] for ent in SCAN_CACHE.values()):
                 PROFILE_CACHE.pop(k).close()
         p = _lib.Profiles(ctx, db)
@@ -43,9 +43,14 @@ def profiles_for(ctx, db):
     return p
 
 
-def release_scan(outDir=None):
+def release_scan(outDir=None, final=False):
     """Free cached device objects (all, or those of one output directory).  Profile databases stay resident until everything is
-    released (release_scan() without an argument)."""
+    released (release_scan() without an argument).  Hit lists ResultsParser handed out lazily are filled in first (not at interpreter
+    exit: final=True)."""
+    if SCAN_CACHE and not final:
+        mod = sys.modules.get("checkm_amd.resultsParser")
+        if mod is not None:
+            mod.materialize_lazy_hits()
     for key in list(SCAN_CACHE):
         if outDir is None or key[0] == os.path.abspath(outDir):
             ent = SCAN_CACHE.pop(key)
@@ -207,41 +212,55 @@ class MarkerGeneFinder(object):
         sizes = [os.path.getsize(f) if os.path.exists(f) else 0 for f in faa]
         nmod = [len(models_of[b]) if models_of.get(b) is not None else profiles.n for b in binIds]
         batches = plan_batches(sizes, nmod)
-        parts, where, totals = [], {}, {}
+        parts, where, totals = [None] * len(batches), {}, {}
+        # Two batches in flight, one per context (a context runs one search at a time): while one batch is on the GPU the other one's
+        # FASTA files are read / digitised / uploaded, its tables written, and the host part and the tail of its search hidden.
+        lanes = [(ctx, profiles)]
+        if len(batches) >= 2 and os.environ.get("CKM_FIND_PIPELINE", "2") != "1":
+            try:
+                ctx2 = runtime.get_ctx2()
+                lanes.append((ctx2, profiles_for(ctx2, db)))
+            except _lib.CkmError:
+                pass
+        import threading
+        tot_lock = threading.Lock()
 
-        def load(batch):
-            return _lib.Seqs.from_fasta(ctx, [faa[i] for i in batch])             # read, digitized and packed by the library
-
-        def write(part, batch):
+        def scan(k):
+            c, prof = lanes[k % len(lanes)]
+            batch = batches[k]
+            seqs = _lib.Seqs.from_fasta(c, [faa[i] for i in batch])               # read, digitized and packed by the library
+            bm = None if not models_of else [models_of[binIds[i]] if models_of[binIds[i]] is not None else list(range(profiles.n)) for i in batch]
+            hits = _lib.search(c, prof, seqs, bm, 0.1, 0.1)                       # -E 0.1 --domE 0.1, markerGeneFinder.py:141
+            st = c.stats()
+            with tot_lock:
+                for f in ("pairs_ssv", "pairs_msv_full", "pairs_bias", "pairs_vit", "pairs_vit_exact", "pairs_fwd", "pairs_dom", "envelopes", "regions_multi",
+                          "cells_ssv", "residue_hmm", "ms_ssv", "ms_total", "ssv_launches", "cascade_fallback_lanes"):
+                    totals[f] = totals.get(f, 0) + getattr(st, f)
+                totals["searches"] = totals.get("searches", 0) + 1
+            part = dict(seqs=seqs, hits=hits, bins=[binIds[i] for i in batch], profiles=prof)
             for b, i in enumerate(batch):
-                part["hits"].write_domtblout(profiles, part["seqs"], b, os.path.join(outDir, 'bins', binIds[i], tableOut))
+                hits.write_domtblout(prof, seqs, b, os.path.join(outDir, 'bins', binIds[i], tableOut))
                 if bKeepAlignment:
                     with open(os.path.join(outDir, 'bins', binIds[i], hmmerOut), 'w') as f:
                         f.write("# alignments are not produced by the MI355X scan (--noali semantics)\n")
+            parts[k] = part
+
+        def lane_run(j):
+            for k in range(j, len(batches), len(lanes)):
+                scan(k)
         try:
-            with ThreadPoolExecutor(max_workers=1) as loader, ThreadPoolExecutor(max_workers=2) as writer:
-                pending = []
-                nxt = loader.submit(load, batches[0]) if batches else None
-                for k, batch in enumerate(batches):
-                    seqs = nxt.result()
-                    nxt = loader.submit(load, batches[k + 1]) if k + 1 < len(batches) else None
-                    bm = None if not models_of else [models_of[binIds[i]] if models_of[binIds[i]] is not None else list(range(profiles.n)) for i in batch]
-                    hits = _lib.search(ctx, profiles, seqs, bm, 0.1, 0.1)          # -E 0.1 --domE 0.1, markerGeneFinder.py:141
-                    st = ctx.stats()
-                    for f in ("pairs_ssv", "pairs_msv_full", "pairs_bias", "pairs_vit", "pairs_vit_exact", "pairs_fwd", "pairs_dom", "envelopes", "regions_multi",
-                              "cells_ssv", "residue_hmm", "ms_ssv", "ms_total", "ssv_launches", "cascade_fallback_lanes"):
-                        totals[f] = totals.get(f, 0) + getattr(st, f)
-                    totals["searches"] = totals.get("searches", 0) + 1
-                    part = dict(seqs=seqs, hits=hits, bins=[binIds[i] for i in batch])
-                    for b, i in enumerate(batch):
-                        where[binIds[i]] = (len(parts), b)
-                    parts.append(part)
-                    pending.append(writer.submit(write, part, batch))
-                for f in pending:
-                    f.result()
+            if len(lanes) == 1:
+                lane_run(0)
+            else:
+                with ThreadPoolExecutor(max_workers=len(lanes)) as ex:
+                    for f in [ex.submit(lane_run, j) for j in range(len(lanes))]:
+                        f.result()
         except _lib.CkmError as e:
             self.logger.error('marker-gene scan failed: %s' % e)
             sys.exit(1)
+        for k, batch in enumerate(batches):
+            for b, i in enumerate(batch):
+                where[binIds[i]] = (k, b)
         key = (os.path.abspath(outDir), tableOut)
         if key in SCAN_CACHE:
             old = SCAN_CACHE.pop(key)

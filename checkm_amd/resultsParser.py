@@ -382,21 +382,92 @@ def _read_fasta_full_headers(path):
     return {k: ''.join(v) for k, v in seqs.items()}
 
 
-def _marker_hits_from(res, b, keys, row_to_hit):
+def _kept_hit(res, i, row_to_hit):
+    """HmmerHitDOM of kept row i of a QAResult (the merged coordinates of an adjacent pair come from the library)."""
+    base = row_to_hit(int(res.kept_row[i]))
+    h = HmmerHitDOM.from_fields(**base.as_dict())
+    if int(res.kept_row2[i]) != 0xFFFFFFFFFFFFFFFF:
+        other = row_to_hit(int(res.kept_row2[i]))
+        h.target_name = DefaultValues.SEQ_CONCAT_CHAR.join(sorted([base.target_name, other.target_name]))
+    h.target_length = int(res.kept_tlen[i])
+    h.hmm_from, h.hmm_to = int(res.kept_hmm_from[i]), int(res.kept_hmm_to[i])
+    h.ali_from, h.ali_to = int(res.kept_ali_from[i]), int(res.kept_ali_to[i])
+    h.env_from, h.env_to = int(res.kept_env_from[i]), int(res.kept_env_to[i])
+    return h
+
+
+class LazyHits(object):
+    """The hit list of one marker, as ResultsManager.markerHits holds it: a sequence whose HmmerHitDOM objects are built the first time
+    one of them is looked at.  The QA table (formats 1 and 2), geneCounts, countUniqueHits ... only ask for len(); a thousand bins carry
+    ~10^6 kept hits, and building a Python object for each of them used to cost as much as the scan."""
+
+    __slots__ = ("_res", "_idx", "_mk", "_items")
+
+    def __init__(self, res, row_to_hit):
+        self._res, self._idx, self._mk, self._items = res, [], row_to_hit, None
+
+    def materialize(self):
+        if self._items is None:
+            self._items = [_kept_hit(self._res, i, self._mk) for i in self._idx]
+            self._res = self._mk = None
+        return self._items
+
+    def __len__(self):
+        return len(self._idx) if self._items is None else len(self._items)
+
+    def __iter__(self):
+        return iter(self.materialize())
+
+    def __getitem__(self, k):
+        return self.materialize()[k]
+
+    def __setitem__(self, k, v):
+        self.materialize()[k] = v
+
+    def __delitem__(self, k):
+        del self.materialize()[k]
+
+    def append(self, h):
+        self.materialize().append(h)
+
+    def __add__(self, other):
+        return self.materialize() + list(other)
+
+    def __eq__(self, other):
+        return self.materialize() == (other.materialize() if isinstance(other, LazyHits) else other)
+
+    def __repr__(self):
+        return repr(self.materialize())
+
+
+_LIVE_LAZY = []          # weak references to lazy lists whose rows still live in a resident scan
+
+
+def materialize_lazy_hits():
+    """Called before a resident scan is released: lists that were never looked at take their hits now."""
+    import weakref  # noqa: F401
+    for ref in _LIVE_LAZY:
+        lz = ref()
+        if lz is not None:
+            lz.materialize()
+    del _LIVE_LAZY[:]
+
+
+def _marker_hits_from(res, b, keys, row_to_hit, lazy=False):
     """Rebuild ResultsManager.markerHits ({acc: [HmmerHitDOM]}) of bin b from the library's kept rows.
     A defaultdict, as PFAM.filterHitsFromSameClan returns one (pfam.py:94)."""
+    import weakref
     mh = defaultdict(list)
     for i in range(int(res.kept_bin_off[b]), int(res.kept_bin_off[b + 1])):
-        base = row_to_hit(int(res.kept_row[i]))
-        h = HmmerHitDOM.from_fields(**base.as_dict())
-        if int(res.kept_row2[i]) != 0xFFFFFFFFFFFFFFFF:
-            other = row_to_hit(int(res.kept_row2[i]))
-            h.target_name = DefaultValues.SEQ_CONCAT_CHAR.join(sorted([base.target_name, other.target_name]))
-        h.target_length = int(res.kept_tlen[i])
-        h.hmm_from, h.hmm_to = int(res.kept_hmm_from[i]), int(res.kept_hmm_to[i])
-        h.ali_from, h.ali_to = int(res.kept_ali_from[i]), int(res.kept_ali_to[i])
-        h.env_from, h.env_to = int(res.kept_env_from[i]), int(res.kept_env_to[i])
-        mh[keys.names[int(res.kept_key[i])]].append(h)
+        k = keys.names[int(res.kept_key[i])]
+        if lazy:
+            lst = mh.get(k)
+            if lst is None:
+                lst = mh[k] = LazyHits(res, row_to_hit)
+                _LIVE_LAZY.append(weakref.ref(lst))
+            lst._idx.append(i)
+        else:
+            mh[k].append(_kept_hit(res, i, row_to_hit))
     return mh
 
 
@@ -542,7 +613,7 @@ class ResultsParser(object):
                 res = plan.reduce(runtime.get_ctx(), hits, seqs, ignore, evalue, length, skip_pseudo, skip_adj, False, sel)
                 for b, lb in lst:
                     rm = mk(b)
-                    rm.markerHits = _marker_hits_from(res, lb, keys, lambda r, h=hits, q=seqs: _hit_from_columns(h, q, profiles, r))
+                    rm.markerHits = _marker_hits_from(res, lb, keys, lambda r, h=hits, q=seqs: _hit_from_columns(h, q, profiles, r), lazy=True)
                     self.results[b] = rm
                 res.close()
 

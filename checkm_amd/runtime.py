@@ -17,12 +17,28 @@ def get_ctx():
     return _ctx
 
 
+_ctx2 = None
+
+
+def get_ctx2():
+    """A second context on the same device: MarkerGeneFinder.find keeps two batches of bins in flight, one per context (a context
+    runs one search at a time), so that the ingest, the host part and the tail of one batch run under the SSV phase of the other."""
+    global _ctx2
+    if _ctx2 is None:
+        _ctx2 = _lib.Context(get_ctx().device)
+    return _ctx2
+
+
 def close():
     global _ctx
     import sys
     mod = sys.modules.get("checkm_amd.markerGeneFinder")
     if mod is not None:
-        mod.release_scan()              # hits, sequences and profile databases of this context
+        mod.release_scan(final=True)    # hits, sequences and profile databases of this context
+    global _ctx2
+    if _ctx2 is not None:
+        _ctx2.close()
+        _ctx2 = None
     if _ctx is not None:
         _ctx.close()
         _ctx = None
