@@ -401,7 +401,7 @@ class LazyHits(object):
     one of them is looked at.  The QA table (formats 1 and 2), geneCounts, countUniqueHits ... only ask for len(); a thousand bins carry
     ~10^6 kept hits, and building a Python object for each of them used to cost as much as the scan."""
 
-    __slots__ = ("_res", "_idx", "_mk", "_items")
+    __slots__ = ("_res", "_idx", "_mk", "_items", "__weakref__")
 
     def __init__(self, res, row_to_hit):
         self._res, self._idx, self._mk, self._items = res, [], row_to_hit, None
