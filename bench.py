@@ -392,6 +392,8 @@ def main():
 
         def lane_steps(j, n):
             c, p_, s_, pl = lanes2[j]
+            if j == 1 and n > 1:
+                time.sleep(per_step / 2)             # identical steps would otherwise run in lockstep, tails and all
             for _ in range(n):
                 hits = _lib.search(c, p_, s_)
                 qa = pl.reduce(c, hits, s_)
@@ -481,7 +483,7 @@ def bench_cfg3(args, rank, world, workdir, sync, all_sum, all_max):
     t0 = time.perf_counter()
     w, binIds, files, lin = lineage_setup(workdir, nbins, rank, world, sync)
     t_setup = time.perf_counter() - t0
-    warm = min(nbins, 64 * world)           # one full-size batch per rank: contexts, profile DBs, device tables and workspace at their working sizes
+    warm = min(nbins, 128 * world)          # two full-size batches per rank (find keeps two in flight, one per context): contexts, profile DBs, device tables and workspace at their working sizes
     for k in range(max(1, args.warmup)):
         lineage_pass(w, binIds[:warm], files[:warm], lin, os.path.join(workdir, "cfg3_warm"), rank)
     sync()

@@ -619,8 +619,9 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   cp.hens = std::max<uint64_t>(cp.hens, (uint64_t)cp.rwork * (256 + ENS_NSAMPLES * 16 * 4 + 1024));
   ctx->maxv.ensure(total_pairs * 2 + 64);
   // the float workspace: an estimate from the pairs (special rows of ~0.3 % of them, matrices of ~0.06 %), within the lane's budget
+  double mp_sum = 0.0;
   {
-    double mp_sum = 0.0; for (auto &mw : mws) mp_sum += (double)mw.npairs * (double)(p->prof[mw.model].fbQ * NL);
+    for (auto &mw : mws) mp_sum += (double)mw.npairs * (double)(p->prof[mw.model].fbQ * NL);
     // bytes per (pair x padded model length): ~1e-4 envelopes per pair x 5 arrays x ~250 rows x 4 B to begin with (marker genes are a few
     // hundred of a bin's thousands of ORFs); a search that outgrows it falls back once and the factor grows for the next calls
     const uint64_t est = (uint64_t)(mp_sum * cp.ws_per_mp + (double)total_pairs * 24.0) + ((uint64_t)256 << 20);
@@ -788,7 +789,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
     }
   }
   if (status & CS_RWORK) cp.hens *= 2;
-  if (status & CS_WS) cp.ws_per_mp *= 2.5f;
+  if (status & CS_WS) cp.ws_per_mp = std::max(cp.ws_per_mp * 1.5f, (float)(1.25 * (double)h_tops[0] * 4.0 / std::max(mp_sum, 1.0)));    // (the allocator kept counting: h_tops[0] is what the search asked for)
   if (!fits) {
     if (getenv("CKM_TRACE")) fprintf(stderr, "ckm-trace w%d device cascade did not fit (status 0x%x): host-driven cascade for this lane\n", ctx->id, status);
     return 1;

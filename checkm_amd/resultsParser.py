@@ -439,6 +439,14 @@ class LazyHits(object):
     def __repr__(self):
         return repr(self.materialize())
 
+    def __contains__(self, h):
+        return h in self.materialize()
+
+    def __getattr__(self, name):          # sort, extend, insert, pop, index, count, remove, reverse ...: the list's own
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
 
 _LIVE_LAZY = []          # weak references to lazy lists whose rows still live in a resident scan
 
