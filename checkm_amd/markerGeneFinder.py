@@ -226,13 +226,19 @@ class MarkerGeneFinder(object):
         tot_lock = threading.Lock()
 
         def scan(k):
+            import time as _t
             c, prof = lanes[k % len(lanes)]
             batch = batches[k]
+            t0 = _t.perf_counter()
             seqs = _lib.Seqs.from_fasta(c, [faa[i] for i in batch])               # read, digitized and packed by the library
+            t1 = _t.perf_counter()
             bm = None if not models_of else [models_of[binIds[i]] if models_of[binIds[i]] is not None else list(range(profiles.n)) for i in batch]
             hits = _lib.search(c, prof, seqs, bm, 0.1, 0.1)                       # -E 0.1 --domE 0.1, markerGeneFinder.py:141
+            t2 = _t.perf_counter()
             st = c.stats()
             with tot_lock:
+                totals["ingest_s"] = totals.get("ingest_s", 0.0) + (t1 - t0)
+                totals["search_s"] = totals.get("search_s", 0.0) + (t2 - t1)
                 for f in ("pairs_ssv", "pairs_msv_full", "pairs_bias", "pairs_vit", "pairs_vit_exact", "pairs_fwd", "pairs_dom", "envelopes", "regions_multi",
                           "cells_ssv", "residue_hmm", "ms_ssv", "ms_total", "ssv_launches", "cascade_fallback_lanes"):
                     totals[f] = totals.get(f, 0) + getattr(st, f)
@@ -244,6 +250,8 @@ class MarkerGeneFinder(object):
                     with open(os.path.join(outDir, 'bins', binIds[i], hmmerOut), 'w') as f:
                         f.write("# alignments are not produced by the MI355X scan (--noali semantics)\n")
             parts[k] = part
+            with tot_lock:
+                totals["write_s"] = totals.get("write_s", 0.0) + (_t.perf_counter() - t2)
 
         def lane_run(j):
             for k in range(j, len(batches), len(lanes)):
