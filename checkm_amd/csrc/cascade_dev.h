@@ -30,6 +30,15 @@ __device__ __forceinline__ bool ws_alloc(const CascadeDev &cd, unsigned long lon
   return true;
 }
 
+// the second zone (envelope / region matrices): no status bit, the caller defers the region to the host
+__device__ __forceinline__ bool ws2_alloc(const CascadeDev &cd, unsigned long long n, unsigned long long &off) {
+  n = (n + 31ull) & ~31ull;
+  const unsigned long long at = atomicAdd(cd.ws2_top, n);
+  if (at + n > cd.ws2_cap) return false;
+  off = cd.ws2_base + at;
+  return true;
+}
+
 __device__ __forceinline__ void queue_push(const CascadeDev &cd, uint32_t *lists, int counter, int cls, uint32_t cap, uint32_t value, uint32_t overflow_bit) {
   const uint32_t pos = atomicAdd(&cd.cnt[counter + cls], 1u);
   if (pos < cap) lists[(size_t)cls * cap + pos] = value; else atomicOr(&cd.gcnt[CC_STATUS], overflow_bit);

@@ -601,12 +601,16 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   // ---- capacities: shares of the pairs (the divisors halve when a table overflowed on an earlier call), tables ----
   Worker::CascadeCaps &cp = ctx->caps;
   size_t tot_cand = 0, tot_nores = 0, tot_f = 0, tot_e = 0, tot_r = 0;
+  // (tests: CKM_CAP_SHRINK=n makes every table n times smaller than its share and drops the floors, to force the overflow -> host-driven path)
+  const uint64_t shrink = getenv("CKM_CAP_SHRINK") ? std::max(1, atoi(getenv("CKM_CAP_SHRINK"))) : 1;
+  auto capof = [&](uint64_t pairs, uint32_t div, uint64_t floor_) {
+    return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(shrink > 1 ? 8 : floor_, pairs / ((uint64_t)div * shrink)), 0x7ffffff0ull); };
   for (Sub &sb : subs) {
-    sb.cap_cand = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096, sb.pairs / cp.div_cand), 0x7ffffff0ull);
-    sb.cap_nores = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2048, sb.pairs / cp.div_nores), 0x7ffffff0ull);
-    sb.cap_f = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2048, sb.pairs / cp.div_fwork), 0x7ffffff0ull);
-    sb.cap_e = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1024, sb.pairs / cp.div_ework), 0x7ffffff0ull);
-    sb.cap_r = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(256, sb.pairs / cp.div_rwork), 0x7ffffff0ull);
+    sb.cap_cand = capof(sb.pairs, cp.div_cand, 4096);
+    sb.cap_nores = capof(sb.pairs, cp.div_nores, 2048);
+    sb.cap_f = capof(sb.pairs, cp.div_fwork, 2048);
+    sb.cap_e = capof(sb.pairs, cp.div_ework, 1024);
+    sb.cap_r = capof(sb.pairs, cp.div_rwork, 256);
     sb.o_cand = tot_cand; tot_cand += sb.cap_cand; sb.o_nores = tot_nores; tot_nores += sb.cap_nores;
     sb.o_vq = sb.o_cand * NVC;
     sb.o_f = tot_f * NFC; tot_f += sb.cap_f; sb.o_e = tot_e * NFC; tot_e += sb.cap_e; sb.o_r = tot_r * NFC; tot_r += sb.cap_r;
@@ -643,7 +647,12 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   cd0.fwork = dev_table<FbWork>(ctx->c_fwork, cp.fwork); cd0.cap_fwork = cp.fwork;
   cd0.ework = dev_table<FbWork>(ctx->c_ework, cp.ework); cd0.cap_ework = cp.ework;
   cd0.rwork = dev_table<FbWork>(ctx->c_rwork, cp.rwork); cd0.ens = dev_table<EnsWork>(ctx->c_ens, cp.rwork); cd0.cap_rwork = cp.rwork;
-  cd0.ws_top = d_tops; cd0.ws_cap = ws_floats;
+  // zone 1: special rows and decoding terms of the parser items (~a few KB for ~0.3 % of the pairs); zone 2: everything else
+  {
+    const uint64_t z1 = std::min<uint64_t>(ws_floats / 2, ((uint64_t)total_pairs * 64 + ((uint64_t)64 << 20)) / 4) & ~(uint64_t)31;
+    cd0.ws_top = d_tops; cd0.ws_cap = z1;
+    cd0.ws2_top = d_tops + 2; cd0.ws2_base = z1; cd0.ws2_cap = ws_floats - z1;
+  }
   // result tables live in device memory; once the counters are known their used prefixes are copied to pinned staging in one go
   cd0.h_pass = dev_table<PassRec>(ctx->c_pass, cp.pass); cd0.cap_pass = cp.pass;
   cd0.h_reg = dev_table<RegionRec>(ctx->c_reg, cp.reg); cd0.cap_reg = cp.reg;
@@ -789,7 +798,8 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
     }
   }
   if (status & CS_RWORK) cp.hens *= 2;
-  if (status & CS_WS) cp.ws_per_mp = std::max(cp.ws_per_mp * 1.5f, (float)(1.25 * (double)h_tops[0] * 4.0 / std::max(mp_sum, 1.0)));    // (the allocator kept counting: h_tops[0] is what the search asked for)
+  // zone 2 ran out (regions were deferred to the host): size the workspace from what this search asked for, for the next calls
+  if (h_tops[2] > cd0.ws2_cap) cp.ws_per_mp = std::max(cp.ws_per_mp * 1.5f, (float)(1.25 * (double)(h_tops[2] + cd0.ws_cap) * 4.0 / std::max(mp_sum, 1.0)));
   if (!fits) {
     if (getenv("CKM_TRACE")) fprintf(stderr, "ckm-trace w%d device cascade did not fit (status 0x%x): host-driven cascade for this lane\n", ctx->id, status);
     return 1;
@@ -853,17 +863,23 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   for (uint32_t k = 0; k < n_pass; ++k) if (alive[k]) { dsidx[k] = (int32_t)ds.pass.size(); ds.pass.push_back({pass[k].model, pass[k].seq, fwdsc[k]}); }
   ds.nregions.assign(ds.pass.size(), 0);
   ds.env_of_pass.assign(ds.pass.size(), {0, 0});
-  std::vector<RegionReq> redo_req; std::vector<size_t> redo_at;          // ensembles that need more segment slots: host-driven repeat
+  std::vector<RegionReq> redo_req; std::vector<size_t> redo_at;          // ensembles that need more segment slots or found no workspace: host-driven
+  size_t n_deferred = 0;
   std::vector<int32_t> env_src;                                         // per envelope: index into h_envout, or -1 = to be rescored (ensemble envelope)
   std::vector<std::pair<uint32_t, uint32_t>> ens_list;                  // (region record, regres index)
   for (uint32_t ro : rorder) {
     const RegionRec &rr = reg[ro];
     if (rr.pass >= n_pass || dsidx[rr.pass] < 0) continue;
     const uint32_t q = (uint32_t)dsidx[rr.pass];
-    if (rr.target == 0xffffffffu) return 1;                            // no workspace for it on the device (status would have said so)
+    if (rr.target == 0xffffffffu) return 1;                            // no table entry for it on the device (status would have said so)
     ds.nregions[q]++;
     if (!rr.multi) ds.items.push_back({q, rr.i, rr.j, -1});
-    else { ds.items.push_back({q, rr.i, rr.j, (int)ds.regres.size()}); ens_list.push_back({ro, (uint32_t)ds.regres.size()}); ds.regres.emplace_back(); }
+    else {
+      ds.items.push_back({q, rr.i, rr.j, (int)ds.regres.size()});
+      if (rr.target == REGION_DEFERRED) { redo_req.push_back({pass[rr.pass].model, pass[rr.pass].seq, rr.i, rr.j}); redo_at.push_back(ds.regres.size()); ++n_deferred; }
+      else ens_list.push_back({ro, (uint32_t)ds.regres.size()});
+      ds.regres.emplace_back();
+    }
   }
   // ensemble results from the pinned export; clustering on the host threads
   for (auto &er : ens_list) {
@@ -903,7 +919,12 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
       for (; it < ds.items.size() && ds.items[it].pass == q; ++it, ++ri) {
         const DomItem &im = ds.items[it];
         const RegionRec &rr = reg[item_rec[ri]];
-        if (im.region < 0) { ds.envreq.push_back({ds.pass[q].model, ds.pass[q].seq, im.i, im.j}); ds.env_region.push_back(-1); env_src.push_back((int32_t)rr.target); continue; }
+        if (im.region < 0) {
+          ds.envreq.push_back({ds.pass[q].model, ds.pass[q].seq, im.i, im.j}); ds.env_region.push_back(-1);
+          env_src.push_back(rr.target == REGION_DEFERRED ? -1 : (int32_t)rr.target);          // deferred: rescored with the second round, in workspace-sized batches
+          if (rr.target == REGION_DEFERRED) ++n_deferred;
+          continue;
+        }
         for (const Seg &e : ds.regres[im.region].env) {
           const int i2 = e.sqfrom + im.i - 1, j2 = e.sqto + im.i - 1;
           ds.envreq.push_back({ds.pass[q].model, ds.pass[q].seq, i2, j2}); ds.env_region.push_back(im.region); env_src.push_back(-1);
@@ -933,6 +954,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
     }
   }
   st.envelopes = ds.envreq.size();
+  if (n_deferred && getenv("CKM_TRACE")) fprintf(stderr, "ckm-trace w%d %zu regions found no device workspace and were rescored by the host-driven rounds\n", ctx->id, n_deferred);
   st.ms_domains = now_ms() - t_host0;
   CKM_TRACE_PT("envelopes done");
   const double t_rows0 = now_ms();

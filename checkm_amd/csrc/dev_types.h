@@ -122,10 +122,13 @@ struct PassRec {                      // one pair the device let through F3 (pin
   float    fwd_xC; int32_t nscale;
 };
 
+constexpr uint32_t REGION_DEFERRED = 0xfffffffeu;
+
 struct RegionRec {                    // one region found by the posterior heuristics (pinned host memory)
   uint32_t pass; int32_t i, j;        // residues i..j of the target (1-based)
   int32_t  multi;                     // 0: one envelope (target = envelope item), 1: trace ensemble (target = region item)
-  uint32_t target;                    // index into the envelope / region work tables, or 0xffffffff: no table entry / workspace left
+  uint32_t target;                    // index into the envelope / region work tables; REGION_DEFERRED: no workspace left on the device, the host
+                                      // rescores it in workspace-sized batches; 0xffffffff: no table entry left
   uint32_t pad;                       // multi: float offset of the region's exported ensemble results in the pinned buffer (0xffffffff: none)
 };
 
@@ -140,7 +143,9 @@ struct CascadeDev {                   // by-value kernel argument: where the epi
   FbWork *fwork; uint32_t cap_fwork;
   FbWork *ework; uint32_t cap_ework;
   FbWork *rwork; EnsWork *ens; uint32_t cap_rwork;
-  unsigned long long *ws_top; unsigned long long ws_cap;                // bump allocator over the float workspace (units: floats)
+  unsigned long long *ws_top; unsigned long long ws_cap;                // bump allocator over the float workspace (units: floats): rows of the parser items
+  unsigned long long *ws2_top; unsigned long long ws2_base, ws2_cap;    // second zone [ws2_base, ws2_base + ws2_cap): matrices of envelopes and ensemble regions;
+                                                                        // a region that finds no room here is left to the host (RegionRec.target = REGION_DEFERRED)
   PassRec *h_pass; uint32_t cap_pass;
   RegionRec *h_reg; uint32_t cap_reg;
   unsigned long long *hens_top; unsigned long long hens_cap;            // bump allocator over the pinned buffer the ensemble results are exported to (floats)

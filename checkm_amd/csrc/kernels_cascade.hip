@@ -33,7 +33,8 @@ __device__ void emit_region(const CascadeDev &cd, const DevModel &md, const FbWo
     const unsigned long long aux = pos; pos = al32(al32(pos + (Ld + 1) * 3) + (Ld + 1) * 5);
     const unsigned long long mf = pos; pos = al32(pos + (Ld + 1) * 3 * Mp);
     const unsigned long long mb = pos; pos = al32(pos + (Ld + 1) * 2 * Mp);
-    if (ws_alloc(cd, pos, off)) {
+    if (!ws2_alloc(cd, pos, off)) rec.target = REGION_DEFERRED;
+    else {
       const uint32_t e = atomicAdd(&cd.gcnt[CC_EWORK], 1u);
       if (e < cd.cap_ework) {
         FbWork w;
@@ -57,7 +58,8 @@ __device__ void emit_region(const CascadeDev &cd, const DevModel &md, const FbWo
     const unsigned long long mx = pos; pos = al32(pos + (Ld + 1) * 3 * Mp);
     const unsigned long long code = pos; pos = al32(pos + ((unsigned long long)ENS_NSAMPLES * (Ld + 1) + 1) / 2);
     const unsigned long long ratio = pos; pos = al32(pos + (unsigned long long)ENS_NSAMPLES * (Ld + 1));
-    if (ws_alloc(cd, pos, off)) {
+    if (!ws2_alloc(cd, pos, off)) rec.target = REGION_DEFERRED;
+    else {
       const uint32_t r = atomicAdd(&cd.gcnt[CC_RWORK], 1u);
       if (r < cd.cap_rwork) {
         EnsWork e;

@@ -60,6 +60,10 @@ def test_device_cascade_equals_host_cascade():
         # the device decides conservatively: it may let a few more pairs through a filter than the exact test, never fewer
         assert dev["pairs"][1] >= host["pairs"][1] and dev["pairs"][3] >= host["pairs"][3] and dev["pairs"][4] >= host["pairs"][4]
         assert dev["pairs"][4] <= host["pairs"][4] + 5 and dev["pairs"][5] == host["pairs"][5]
-    # workspace far too small for the device-side allocator: the lanes go through the host-driven cascade (which batches)
-    small = _run(CKM_WORKERS="2", CKM_WORKER_MIN_PAIRS="1", CKM_WS_BUDGET_MB="64")
-    assert small["fallback"] >= 1 and small["rows"] == host["rows"]
+    # workspace too small for the matrices of all envelopes at once: the regions that find no room are rescored by the host-driven
+    # rounds (workspace-sized batches) -- no fallback of the lane, same rows
+    small = _run(CKM_WORKERS="1", CKM_WS_BUDGET_MB="64", CKM_TRACE="1")
+    assert small["fallback"] == 0 and small["rows"] == host["rows"]
+    # device-side tables far too small: the lane is handed to the host-driven cascade (and the tables grow for the next call)
+    tiny = _run(CKM_WORKERS="1", CKM_CAP_SHRINK="64")
+    assert tiny["fallback"] >= 1 and tiny["rows"] == host["rows"]
