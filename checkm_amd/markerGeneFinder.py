@@ -96,15 +96,15 @@ GENE_CALLER = None      # a ProdigalRunner-like class (outDir) -> .areORFsCalled
 
 
 def gene_caller():
-    """The class that calls genes for bins given as nucleotide FASTA: GENE_CALLER if set, else the reference's ProdigalRunner when
-    CheckM is importable (the drop-in case), else None."""
+    """The class that calls genes for bins given as nucleotide FASTA: GENE_CALLER if set, else checkm_amd.prodigal.ProdigalRunner (the
+    mirror of checkm/prodigal.py:41-182 that runs the two translation tables side by side) when a `prodigal` binary is on PATH,
+    else None."""
     if GENE_CALLER is not None:
         return GENE_CALLER
-    try:
-        from checkm.prodigal import ProdigalRunner
+    if shutil.which("prodigal") is not None:
+        from checkm_amd.prodigal import ProdigalRunner
         return ProdigalRunner
-    except Exception:
-        return None
+    return None
 
 
 class MarkerGeneFinder(object):
