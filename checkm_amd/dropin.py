@@ -25,3 +25,8 @@ def install():
     from checkm_amd import hmmerAligner as h
     checkm.hmmerAligner.HmmerAligner = h.HmmerAligner
     checkm.aminoAcidIdentity.AminoAcidIdentity = a.AminoAcidIdentity
+    # gene calling in front of the scan: the two translation tables of a bin side by side (same files, same table choice)
+    import checkm.prodigal
+    from checkm_amd import prodigal as pr
+    checkm.prodigal.ProdigalRunner = pr.ProdigalRunner
+    checkm.prodigal.ProdigalGeneFeatureParser = pr.ProdigalGeneFeatureParser

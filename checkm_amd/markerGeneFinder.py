@@ -98,13 +98,17 @@ GENE_CALLER = None      # a ProdigalRunner-like class (outDir) -> .areORFsCalled
 def gene_caller():
     """The class that calls genes for bins given as nucleotide FASTA: GENE_CALLER if set, else checkm_amd.prodigal.ProdigalRunner (the
     mirror of checkm/prodigal.py:41-182 that runs the two translation tables side by side) when a `prodigal` binary is on PATH,
-    else None."""
+    else CheckM's own ProdigalRunner if importable, else None."""
     if GENE_CALLER is not None:
         return GENE_CALLER
     if shutil.which("prodigal") is not None:
         from checkm_amd.prodigal import ProdigalRunner
         return ProdigalRunner
-    return None
+    try:                                    # no prodigal here: CheckM's own runner reports that the way CheckM users know
+        from checkm.prodigal import ProdigalRunner
+        return ProdigalRunner
+    except Exception:
+        return None
 
 
 class MarkerGeneFinder(object):

@@ -69,7 +69,9 @@ def test_dropin_rebinds_the_reference_classes(tmp_path):
             "assert g.HmmModel.__module__ == 'checkm.hmmerModelParser'\n"
             "assert all(hasattr(e.HmmerAligner, n) for n in ('makeAlignmentTopHit', 'makeAlignmentToPhyloMarkers', 'makeAlignmentsOfMultipleHits'))\n"
             "import checkm_amd.markerGeneFinder as h\n"
-            "assert h.gene_caller().__name__ == 'ProdigalRunner' and h.gene_caller().__module__ == 'checkm.prodigal'    # nucleotide bins: CheckM's own gene calling\n"
+            "assert h.gene_caller().__name__ == 'ProdigalRunner' and h.gene_caller().__module__ in ('checkm.prodigal', 'checkm_amd.prodigal')    # nucleotide bins\n"
+            "import checkm.prodigal as pr\n"
+            "assert pr.ProdigalRunner.__module__ == 'checkm_amd.prodigal'\n"
             "print('ok')\n")
     env = dict(os.environ, PYTHONPATH="/root/reference" + os.pathsep + root, CHECKM_DATA_PATH=str(tmp_path), PYTHONDONTWRITEBYTECODE="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
