@@ -9,6 +9,8 @@
 //   ens_sum_kernel     one thread per region position: sum of the ratios over traces, trace order.
 // Float results follow the CPU restatement (trace_ensemble in the test oracle) operation by operation; -ffp-contract=off.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
 #include "dev_types.h"
 #include "xlane.h"
 
@@ -57,7 +59,11 @@ __device__ __forceinline__ int ens_select_e(const float *__restrict__ cr, int Q,
 
 __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restrict__ work, const DevModel *__restrict__ models,
                                                        const LenEntry *__restrict__ lentab, float *__restrict__ ws,
-                                                       const uint32_t *__restrict__ seeds, const uint32_t *__restrict__ count, uint32_t cap) {
+                                                       const uint32_t *__restrict__ seeds, const uint32_t *__restrict__ count, uint32_t cap, int sequential) {
+ // sequential != 0 (CKM_ENS_STREAM=sequential): HMMER's own use of its generator -- ONE stream per region, re-seeded for the region and
+ // carried from the end of trace t into trace t+1 -- instead of one sub-stream per trace: the traces then run one after the other
+ // (the number of draws a trace takes is only known when it ends), ~200 times slower for this rare stage.
+ __shared__ uint32_t stream_rng;
  const uint32_t nregions = min(*count, cap);
  for (uint32_t region = blockIdx.x; region < nregions; region += gridDim.x) {
   const EnsWork w = work[region];
@@ -75,11 +81,14 @@ __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restric
   uint16_t *__restrict__ code = reinterpret_cast<uint16_t *>(ws + w.code_off) + (size_t)(live ? t : 0) * (Ld + 1);
   int32_t *__restrict__ seg = reinterpret_cast<int32_t *>(ws + w.seg_off) + (size_t)(live ? t : 0) * w.cap * 4;
   int32_t *__restrict__ nsegp = reinterpret_cast<int32_t *>(ws + w.nseg_off);
-  uint32_t rng = seeds[live ? t : 0];
 #define CELL(c) (((c) % Q) * 64 + (c) / Q)
   enum { sC, sE, sM, sI, sD, sB, sJ, sN };
+  if (sequential) { __syncthreads(); if (threadIdx.x == 0) stream_rng = seeds[0]; __syncthreads(); }
+ for (int round = 0; round < (sequential ? ENS_N : 1); ++round) {
+  const bool mine = sequential ? (t == round) : live;
+  uint32_t rng = sequential ? stream_rng : seeds[live ? t : 0];
   int st = sC, i = Ld, k = 0, nseg = 0, sqto = 0, hmmto = 0;
-  bool overflow = false, done = !live;
+  bool overflow = false, done = !mine;
   float pth[4];
   for (;;) {
     // E-state choices are made by the whole wavefront, one requesting trace at a time (uniform control flow)
@@ -147,10 +156,13 @@ __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restric
     }
     if (!__ballot(!done)) break;
   }
-  if (live) {
+  if (mine) {
     for (; i >= 1; --i) code[i] = 0;
     nsegp[t] = overflow ? -1 : nseg;
+    if (sequential) stream_rng = rng;
   }
+  if (sequential) __syncthreads();
+ }
  }
 #undef CELL
 }
@@ -246,7 +258,8 @@ void launch_ensemble(hipStream_t stream, const EnsWork *work, const uint32_t *co
                      const DevModel *models, const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, const uint32_t *seeds,
                      float *host_res) {
   if (!grid_regions) return;
-  hipLaunchKernelGGL(ens_trace_kernel, dim3(grid_regions), dim3(256), 0, stream, work, models, lentab, ws, seeds, count, cap);
+  static const int sequential = [] { const char *e = getenv("CKM_ENS_STREAM"); return (e && !strcmp(e, "sequential")) ? 1 : 0; }();
+  hipLaunchKernelGGL(ens_trace_kernel, dim3(grid_regions), dim3(256), 0, stream, work, models, lentab, ws, seeds, count, cap, sequential);
   hipLaunchKernelGGL(ens_null2_kernel, dim3(ENS_N, grid_regions), dim3(64), (size_t)(2 * max_Mp + 32) * 4, stream, work, models, res, seq_off, ws, count, cap);
   hipLaunchKernelGGL(ens_sum_kernel, dim3(4, grid_regions), dim3(256), 0, stream, work, ws, count, cap);
   if (host_res) hipLaunchKernelGGL(ens_export_kernel, dim3(4, grid_regions), dim3(256), 0, stream, work, ws, host_res, count, cap);

@@ -62,6 +62,7 @@ def lib():
         L.p7o_envelope.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                                    C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
         L.p7o_align.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.p7o_set_ensemble_stream.argtypes = [C.c_int]
         L.p7o_ensemble_seed.restype = C.c_uint32
         L.p7o_ensemble_seed.argtypes = [C.c_int]
         L.p7o_region_ensemble.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -941,6 +941,9 @@ static uint32_t lcg_jump(uint32_t x, uint64_t n)
   while (n) { if (n & 1) { ra = A * ra; rc = A * rc + C; } C = A * C + C; A = A * A; n >>= 1; }
   return ra * x + rc;
 }
+static int g_ens_sequential = 0;
+void p7o_set_ensemble_stream(int sequential) { g_ens_sequential = sequential; }
+
 uint32_t p7o_ensemble_seed(int t)
 {
   uint32_t x0 = mix3(42u, 87654321u, 12345678u); if (x0 == 0) x0 = 42u;
@@ -1062,10 +1065,14 @@ static int trace_ensemble(const PROF *p, const uint8_t *dsq, int L, int ireg, in
   float *ratio = malloc(sizeof(float) * (size_t)ENS_NSAMPLES * (Ld+1));
   float *cm = malloc(sizeof(float) * 2 * Mp), *ci = cm + Mp;
   int rc = 0;
+  /* default: every trace has its own sub-stream (deviation D3); p7o_set_ensemble_stream(1): ONE stream per region, carried from
+   * trace to trace as HMMER carries its generator */
+  uint32_t stream_rng = p7o_ensemble_seed(0);
   for (int t = 0; t < ENS_NSAMPLES && rc == 0; t++) {
-    uint32_t rng = p7o_ensemble_seed(t);
+    uint32_t rng = g_ens_sequential ? stream_rng : p7o_ensemble_seed(t);
     P7O_SEG *seg = seg_all + (size_t)t * cap;
     int ns = stochastic_trace(p, &xf, Ld, mx, xs, &rng, code, seg, cap);
+    stream_rng = rng;
     if (ns < 0) { rc = -1; break; }
     for (int a = 0, b = ns-1; a < b; a++, b--) { P7O_SEG tmp = seg[a]; seg[a] = seg[b]; seg[b] = tmp; }
     nseg_all[t] = ns;

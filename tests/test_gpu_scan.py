@@ -490,3 +490,46 @@ def test_empty_bins_and_empty_records(gpu_ctx, tmp_path):
         q.close(); hits.close(); ref.close()
     finally:
         prof.close(); seqs.close(); alone.close(); hs.close()
+
+
+def test_trace_ensemble_single_stream_mode():
+    """CKM_ENS_STREAM=sequential: the 200 tracebacks of a region draw from ONE generator stream carried from trace to trace (HMMER's
+    own use of its generator; the default gives every trace its own sub-stream).  In a fresh process, against the
+    oracle in the same mode: same segments, same null2 sums, same envelopes for a few regions, and the rows of a whole search."""
+    import json
+    import subprocess
+    import sys
+    code = r'''
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np
+from checkm_amd import _lib
+from oracle import p7
+from tests import common
+from tests.test_gpu_scan import _tandem_records
+profs = common.mixed_profiles(); path = common.hmm_file("mixed", profs)
+recs = _tandem_records(profs, 77)[:6]
+p7.lib().p7o_set_ensemble_stream(1)
+ctx = _lib.Context(0); prof = _lib.Profiles(ctx, path); seqs = _lib.Seqs(ctx, [recs])
+hs = p7.HmmSet(path)
+dsq = [p7.digitize(r[2]) for r in recs]
+out = []
+for si in (0, 3):
+    m = int(recs[si][0][len("tandem"):].split("_")[0]); L = len(dsq[si])
+    rc, n2, segs, nseg, env = hs.region_ensemble(m, dsq[si], 1, L)
+    g_n2, g_segs, g_nseg, g_env = _lib.debug_region(ctx, prof, seqs, m, si, 1, L)
+    same_segs = all((segs[t, :nseg[t]] == g_segs[t, :g_nseg[t]]).all() for t in range(200)) if (nseg == g_nseg).all() else False
+    out.append(dict(rc=int(rc), n2=bool((n2.view(np.uint32) == g_n2.view(np.uint32)).all()), segs=bool(same_segs), env=bool(env.tolist() == g_env.tolist()), nenv=int(len(g_env))))
+hits = _lib.search(ctx, prof, seqs)
+rows = hs.search(list(range(hs.n)), dsq, [r[0] for r in recs])
+same = hits.n == len(rows) and all((r.seq_idx, r.model_idx, r.hmm_from, r.hmm_to, r.ali_from, r.ali_to, r.env_from, r.env_to, r.ndom) ==
+                                  (hits.seq[i], hits.model[i], hits.hmm_from[i], hits.hmm_to[i], hits.ali_from[i], hits.ali_to[i], hits.env_from[i], hits.env_to[i], hits.ndom[i]) and
+                                  np.float32(r.dom_score).view(np.uint32) == np.float32(hits.dom_score[i]).view(np.uint32) for i, r in enumerate(rows))
+print(json.dumps(dict(regions=out, rows=int(hits.n), same=bool(same), multi=int(ctx.stats().regions_multi))))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CKM_ENS_STREAM="sequential"), capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads(res.stdout.strip().split("\n")[-1])
+    for o in out["regions"]:
+        assert o["rc"] == 0 and o["n2"] and o["segs"] and o["env"] and o["nenv"] >= 1, o
+    assert out["same"] and out["rows"] > 6 and out["multi"] >= 2, out
