@@ -497,6 +497,7 @@ def test_trace_ensemble_single_stream_mode():
     own use of its generator; the default gives every trace its own sub-stream).  In a fresh process, against the
     oracle in the same mode: same segments, same null2 sums, same envelopes for a few regions, and the rows of a whole search."""
     import json
+    import os
     import subprocess
     import sys
     code = r'''
