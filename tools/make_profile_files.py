@@ -20,19 +20,22 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = lambda name: os.path.join(ROOT, "profiles", "%s_%s" % (tag, name))
     json.dump(last_json(os.path.join(src, "bench_default.json")), open(dst("bench_cfg2_line.json"), "w"), indent=1)
-    json.dump(last_json(os.path.join(src, "bench_w1.json")), open(dst("bench_cfg2_workers1_line.json"), "w"), indent=1)
+    for name, out in (("bench_w1.json", "bench_cfg2_workers1_line.json"), ("bench_hostcascade_w3.json", "bench_cfg2_hostcascade_w3_line.json"),
+                      ("bench_cfg3.json", "bench_cfg3_line.json")):
+        if os.path.exists(os.path.join(src, name)) and os.path.getsize(os.path.join(src, name)) > 0:
+            json.dump(last_json(os.path.join(src, name)), open(dst(out), "w"), indent=1)
     if os.path.exists(os.path.join(src, "bench_1000bins.json")):
         json.dump(last_json(os.path.join(src, "bench_1000bins.json")), open(dst("bench_1000bins_line.json"), "w"), indent=1)
     ks = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), os.path.join(src, "trace", "bench_results.db"), "4"],
                         capture_output=True, text=True).stdout
     open(dst("bench_cfg2_kernel_stats.txt"), "w").write(
-        "# rocprofv3 --kernel-trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline   (MI355X, default = 3 workers)\n"
-        "# summarised by tools/rocprof_summary.py.  NOTE: the three workers keep up to a dozen launches in flight at once, so durations of\n"
-        "# concurrent kernels overlap in time and their SUM (ms_per_step) exceeds the wall time of a step; avg_us is the duration of one\n"
-        "# launch while it shares the device.  The solo figures are in %s_pmc_summary.txt (CKM_WORKERS=1, kernels serialised).\n" % tag + ks)
+        "# rocprofv3 --kernel-trace -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --lineage-bins 0   (MI355X, default: device-driven cascade, one lane)\n"
+        "# summarised by tools/rocprof_summary.py.  NOTE: the chains of the model-length groups run on up to 14 streams underneath the SSV launches, so\n"
+        "# durations of concurrent kernels overlap in time and their SUM (ms_per_step) exceeds the wall time of a step; avg_us is the duration of one\n"
+        "# launch while it shares the device.  The serialised figures are in %s_pmc_summary.txt (counter collection runs one kernel at a time).\n" % tag + ks)
     pm = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py")] + [os.path.join(src, d) for d in ("pmc_fetch", "pmc_write", "pmc_sq")],
                         capture_output=True, text=True).stdout
-    hdr = ("# rocprofv3 --pmc passes, MI355X; ONE step each of: CKM_WORKERS=1 python bench.py --steps 1 --warmup 0 --no-cpu-baseline\n"
+    hdr = ("# rocprofv3 --pmc passes, MI355X; ONE search each of: CKM_WS_PER_MP=5 CKM_BENCH_STEADY=0 CKM_BENCH_FROM_HOST=0 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --lineage-bins 0\n"
            "# (cfg2: 43 profiles x 100 bins x 2000 ORFs; separate passes: --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_*, each with --kernel-trace only;\n"
            "#  collected by tools/collect_profiles.sh, summarised by tools/pmc_summary.py)\n"
            "# FETCH_SIZE / WRITE_SIZE are in KB as reported; MI355X_MICROARCH.md (HBM section): FETCH_SIZE reads 1/2 of the bytes of a wide\n"
@@ -49,7 +52,7 @@ def main():
         return sum(float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(src, d, "p_counter_collection.csv")))
                    if "ssv_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter)
     f, w = total("pmc_fetch", "FETCH_SIZE"), total("pmc_write", "WRITE_SIZE")
-    json.dump({"config": "cfg2: 43 profiles x 100 bins x 2000 ORFs, 1 GPU, CKM_WORKERS=1 (kernels serialised by counter collection)",
+    json.dump({"config": "cfg2: 43 profiles x 100 bins x 2000 ORFs, 1 GPU, one search (kernels serialised by counter collection)",
                "kernel": "ssv_kernel<Q> (all launches of one step)", "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_corrected": 2 * f * 1024 + w * 1024,
                "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads)",
                "valu_insts": valu, "ssv_ms_under_pmc": ms}, open(dst("ssv_traffic.json"), "w"), indent=1)
