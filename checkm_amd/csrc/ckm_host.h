@@ -50,6 +50,12 @@ int launch_bwd(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, con
 int launch_oa(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const FbWork *work, const DevModel *models,
               float *ws, const int32_t *range_err, const FwdOut *fout, EnvOut *out);
 
+int launch_parser(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const FbWork *work, const DevModel *models,
+                  const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws,
+                  ScaleEvent *events, uint32_t *nevents, uint32_t cap_events, const CascadeDev &cd);
+int launch_env(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const FbWork *work, const DevModel *models,
+               const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws,
+               ScaleEvent *events, uint32_t *nevents, uint32_t cap_events, EnvOut *out);
 void launch_ensemble(hipStream_t stream, const EnsWork *work, const uint32_t *count, uint32_t cap, uint32_t grid_regions, int max_Mp,
                      const DevModel *models, const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, const uint32_t *seeds,
                      float *host_res /* pinned buffer the results are exported to, or null */);

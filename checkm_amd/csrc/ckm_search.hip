@@ -736,12 +736,18 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
         const int Q = kFbQ[c];
         const WorkQueue qf{cd.fq + (size_t)c * sb.cap_f, cnt + CC_FQ + c, sb.cap_f}, qb{cd.bq + (size_t)c * sb.cap_f, cnt + CC_BQ + c, sb.cap_f};
         const WorkQueue qe{cd.eq + (size_t)c * sb.cap_e, cnt + CC_EQ + c, sb.cap_e}, qr{cd.rq + (size_t)c * sb.cap_r, cnt + CC_RQ + c, sb.cap_r};
-        if (stop >= 6) rc |= launch_fwd(Q, GRID_FB, sc, qf, cd.fwork, dm, lt, res, off, ws, d_fout_f, d_events_f, d_gcnt + CC_EVENTS, cp.events_f, &cd);
-        if (stop >= 7) rc |= launch_bwd(Q, GRID_FB, sc, qb, cd.fwork, dm, lt, res, off, ws, d_fout_f, nullptr);
-        if (stop >= 8) launch_regions(sc, 1024, qb.list, qb.count, sb.cap_f, cd.fwork, cd, dm, ws);
-        if (stop >= 9) rc |= launch_fwd(Q, GRID_FB, sc, qe, cd.ework, dm, lt, res, off, ws, d_fout_e, d_events_e, d_gcnt + CC_EVENTS_E, cp.events_e, nullptr);
-        if (stop >= 10) rc |= launch_bwd(Q, GRID_FB, sc, qe, cd.ework, dm, lt, res, off, ws, d_fout_e, d_rerr_e);
-        if (stop >= 11) rc |= launch_oa(Q, GRID_FB, sc, qe, cd.ework, dm, ws, d_rerr_e, d_fout_e, d_envout);
+        static const bool unfused = getenv("CKM_UNFUSED") != nullptr;          // (the stage-by-stage launches, for comparison)
+        if (!unfused) {
+          if (stop >= 6) rc |= launch_parser(Q, GRID_FB, sc, qf, cd.fwork, dm, lt, res, off, ws, d_events_f, d_gcnt + CC_EVENTS, cp.events_f, cd);
+          if (stop >= 9) rc |= launch_env(Q, GRID_FB, sc, qe, cd.ework, dm, lt, res, off, ws, d_events_e, d_gcnt + CC_EVENTS_E, cp.events_e, d_envout);
+        } else {
+          if (stop >= 6) rc |= launch_fwd(Q, GRID_FB, sc, qf, cd.fwork, dm, lt, res, off, ws, d_fout_f, d_events_f, d_gcnt + CC_EVENTS, cp.events_f, &cd);
+          if (stop >= 7) rc |= launch_bwd(Q, GRID_FB, sc, qb, cd.fwork, dm, lt, res, off, ws, d_fout_f, nullptr);
+          if (stop >= 8) launch_regions(sc, 1024, qb.list, qb.count, sb.cap_f, cd.fwork, cd, dm, ws);
+          if (stop >= 9) rc |= launch_fwd(Q, GRID_FB, sc, qe, cd.ework, dm, lt, res, off, ws, d_fout_e, d_events_e, d_gcnt + CC_EVENTS_E, cp.events_e, nullptr);
+          if (stop >= 10) rc |= launch_bwd(Q, GRID_FB, sc, qe, cd.ework, dm, lt, res, off, ws, d_fout_e, d_rerr_e);
+          if (stop >= 11) rc |= launch_oa(Q, GRID_FB, sc, qe, cd.ework, dm, ws, d_rerr_e, d_fout_e, d_envout);
+        }
         if (stop >= 12) rc |= launch_fwd(Q, std::max(64u, GRID_FB / 8), sc, qr, cd.rwork, dm, lt, res, off, ws, d_fout_r, d_events_r, d_gcnt + CC_EVENTS_R, 1 << 16, nullptr);
       }
       if (rc) throw Error(CKM_ERANGE, "no kernel instance for this model length");

@@ -12,6 +12,7 @@
 #include <cstring>
 #include "dev_types.h"
 #include "cascade_dev.h"
+#include "cascade_regions.h"
 #include "xlane.h"
 
 namespace ckm {
@@ -93,23 +94,14 @@ __device__ __forceinline__ float fwd_row(float (&Mv)[Q], float (&Iv)[Q], float (
   return s;
 }
 
+// One Forward pass of one work item by one wavefront (the LDS image of the item's model is in place): special rows, optional matrix
+// rows, rescale events; returns the scaled xC, the number of rescales and the approximate log of their product.
 template <int Q>
-__global__ void __launch_bounds__(64) fwd_kernel(WorkQueue queue, FbWork *__restrict__ work,
-                                                const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
-                                                const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
-                                                float *__restrict__ ws, FwdOut *__restrict__ out,
-                                                ScaleEvent *__restrict__ events, uint32_t *__restrict__ nevents, uint32_t cap_events,
-                                                CascadeDev cd, int decide) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void fwd_item(const FbWork &w, const DevModel &md, float *lds, int lane, const LenEntry *__restrict__ lentab,
+                                         const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off, float *__restrict__ ws,
+                                         ScaleEvent *__restrict__ events, uint32_t *__restrict__ nevents, uint32_t cap_events,
+                                         float &o_xC, int &o_nscale, float &o_lsum, float &o_move) {
   constexpr int Mp = Q * 64;
-  const int lane = threadIdx.x;
-  uint32_t cur_model = 0xffffffffu;
- const uint32_t nqueue = queue_len(queue);
- for (uint32_t qk = blockIdx.x; qk < nqueue; qk += gridDim.x) {
-  const uint32_t item = queue.list[qk];
-  const FbWork w = work[item];
-  const DevModel &md = models[w.model];
-  if (w.model != cur_model) { load_tr<Q>(lds, md.ftr); cur_model = w.model; }
   Tr<Q> tr{lds, lane};
   const uint8_t *rp = res + seq_off[w.seq] + w.i0;
   const LenEntry le = lentab[w.Lcfg];
@@ -174,6 +166,28 @@ __global__ void __launch_bounds__(64) fwd_kernel(WorkQueue queue, FbWork *__rest
       }
     }
   }
+  o_xC = xC; o_nscale = nscale; o_lsum = lsum; o_move = move;
+}
+
+template <int Q>
+__global__ void __launch_bounds__(64) fwd_kernel(WorkQueue queue, FbWork *__restrict__ work,
+                                                const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
+                                                const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
+                                                float *__restrict__ ws, FwdOut *__restrict__ out,
+                                                ScaleEvent *__restrict__ events, uint32_t *__restrict__ nevents, uint32_t cap_events,
+                                                CascadeDev cd, int decide) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int Mp = Q * 64;
+  const int lane = threadIdx.x;
+  uint32_t cur_model = 0xffffffffu;
+ const uint32_t nqueue = queue_len(queue);
+ for (uint32_t qk = blockIdx.x; qk < nqueue; qk += gridDim.x) {
+  const uint32_t item = queue.list[qk];
+  const FbWork w = work[item];
+  const DevModel &md = models[w.model];
+  if (w.model != cur_model) { load_tr<Q>(lds, md.ftr); cur_model = w.model; }
+  float xC, lsum, move; int nscale;
+  fwd_item<Q>(w, md, lds, lane, lentab, res, seq_off, ws, events, nevents, cap_events, xC, nscale, lsum, move);
   if (lane == 0) { out[w.slot].xC = xC; out[w.slot].nscale = nscale; }
   // ---- device-driven cascade: the F3 decision of a whole-sequence parser item, taken conservatively (the threshold is lowered by a
   // margin that covers the approximate logarithms; the host repeats the test exactly).  A passer gets its pass record, the workspace
@@ -202,6 +216,7 @@ __global__ void __launch_bounds__(64) fwd_kernel(WorkQueue queue, FbWork *__rest
  }
 }
 
+#define CKM_LD2(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)   /* L2-served: this wave's own stores are visible */
 // ---- Backward -----------------------------------------------------------------------------------
 // D chain, reverse direction: D[c] = av[c] + DD[c]*D[c+1]
 template <int Q>
@@ -215,21 +230,14 @@ __device__ __forceinline__ void bwd_dchain(float (&Dn)[Q], const float (&av)[Q],
   for (int q = Q - 1; q >= 0; --q) { const float t = tr.DD(q) * d; d = av[q] + t; Dn[q] = d; }
 }
 
-template <int Q>
-__global__ void __launch_bounds__(64) bwd_kernel(WorkQueue queue, const FbWork *__restrict__ work,
-                                                const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
-                                                const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
-                                                float *__restrict__ ws, const FwdOut *__restrict__ fout, int32_t *__restrict__ range_err) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+// One Backward pass of one work item by one wavefront.  XL: the Forward pass of the item ran in this very wavefront just before (fused
+// kernels), so the special rows lane 0 stored are read with L2-scope loads.  Parser items (full = 0) leave the three decoding terms
+// per row; envelope items (full = 1) the posterior rows M, I and the N/J/C terms, and report a non-finite posterior through `bad`.
+template <int Q, bool XL>
+__device__ __forceinline__ void bwd_item(const FbWork &w, const DevModel &md, float *lds, int lane, const LenEntry *__restrict__ lentab,
+                                         const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off, float *__restrict__ ws,
+                                         float fwd_xC, bool &o_bad) {
   constexpr int Mp = Q * 64;
-  const int lane = threadIdx.x;
-  uint32_t cur_model = 0xffffffffu;
- const uint32_t nqueue = queue_len(queue);
- for (uint32_t qk = blockIdx.x; qk < nqueue; qk += gridDim.x) {
-  const uint32_t item = queue.list[qk];
-  const FbWork w = work[item];
-  const DevModel &md = models[w.model];
-  if (w.model != cur_model) { load_tr<Q>(lds, md.ftr); cur_model = w.model; }
   Tr<Q> tr{lds, lane};
   const uint8_t *rp = res + seq_off[w.seq] + w.i0;
   const LenEntry le = lentab[w.Lcfg];
@@ -240,7 +248,7 @@ __global__ void __launch_bounds__(64) bwd_kernel(WorkQueue queue, const FbWork *
   const float *fm = w.full ? ws + w.mxf_off : nullptr;
   float *bm = w.full ? ws + w.mxb_off : nullptr;
   const int L = w.Ld;
-  const float invZ = 1.0f / (fout[w.slot].xC * move);
+  const float invZ = 1.0f / (fwd_xC * move);
   // boundary transition odds of the right-hand neighbour cell (c+1)
   float tIMn[Q], tMMn[Q], tDMn[Q];
 #pragma unroll
@@ -279,9 +287,9 @@ __global__ void __launch_bounds__(64) bwd_kernel(WorkQueue queue, const FbWork *
   // forward special rows r+1 (rowU), r (rowC), r-1 (rowD) ride in registers; the next one is requested a row ahead
   float rowU[6], rowC[6], rowD[6];
   auto load_row = [&](float (&dst)[6], int r) {
-    const float *__restrict__ x = xs + (size_t)(r < 0 ? 0 : r) * 6;
+    const float *x = xs + (size_t)(r < 0 ? 0 : r) * 6;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) dst[k] = x[k];
+    for (int k = 0; k < 6; ++k) dst[k] = XL ? CKM_LD2(&x[k]) : x[k];      // (XL: lane 0 of THIS wavefront wrote them a moment ago)
   };
   load_row(rowC, L); load_row(rowD, L - 1);
 #pragma unroll
@@ -383,18 +391,14 @@ __global__ void __launch_bounds__(64) bwd_kernel(WorkQueue queue, const FbWork *
     for (int q = 0; q < Q; ++q) { Mv[q] = Mn[q]; Iv[q] = In[q]; Dv[q] = Dn[q]; }
     emit(i);
   }
-  if (w.full) {
-    const unsigned long long any = __ballot(bad);
-    if (lane == 0) range_err[w.slot] = any ? 1 : 0;
-  }
- }
+  o_bad = bad;
 }
 
-// ---- null2 by expectation + optimal accuracy fill + traceback -------------------------------------
 template <int Q>
-__global__ void __launch_bounds__(64) oa_kernel(WorkQueue queue, const FbWork *__restrict__ work,
-                                               const DevModel *__restrict__ models, float *__restrict__ ws,
-                                               const int32_t *__restrict__ range_err, const FwdOut *__restrict__ fout, EnvOut *__restrict__ out) {
+__global__ void __launch_bounds__(64) bwd_kernel(WorkQueue queue, const FbWork *__restrict__ work,
+                                                const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
+                                                const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
+                                                float *__restrict__ ws, const FwdOut *__restrict__ fout, int32_t *__restrict__ range_err) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int Mp = Q * 64;
   const int lane = threadIdx.x;
@@ -404,9 +408,24 @@ __global__ void __launch_bounds__(64) oa_kernel(WorkQueue queue, const FbWork *_
   const uint32_t item = queue.list[qk];
   const FbWork w = work[item];
   const DevModel &md = models[w.model];
-  if (w.model != cur_model) { load_gates<Q>(lds, md.ftr); cur_model = w.model; }
-  if (lane == 0) { out[w.slot].xC = fout[w.slot].xC; out[w.slot].nscale = fout[w.slot].nscale; }     // the envelope's Forward result travels with its record
-  if (range_err[w.slot]) { if (lane == 0) out[w.slot].range_err = 1; continue; }
+  if (w.model != cur_model) { load_tr<Q>(lds, md.ftr); cur_model = w.model; }
+  bool bad = false;
+  bwd_item<Q, false>(w, md, lds, lane, lentab, res, seq_off, ws, fout[w.slot].xC, bad);
+  if (w.full) {
+    const unsigned long long any = __ballot(bad);
+    if (lane == 0) range_err[w.slot] = any ? 1 : 0;
+  }
+ }
+}
+
+// ---- null2 by expectation + optimal accuracy fill + traceback -------------------------------------
+// null2 by expectation + optimal-accuracy fill + traceback of one envelope by one wavefront (the LDS image holds the 0 / -inf GATES of
+// the item's model).  XL: Backward ran in this very wavefront just before (fused kernel): the N/J/C terms lane 0 stored are read with
+// L2-scope loads.
+#define LD2X(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+template <int Q, bool XL>
+__device__ __forceinline__ void oa_item(const FbWork &w, const DevModel &md, float *lds, int lane, float *__restrict__ ws, EnvOut *outp) {
+  constexpr int Mp = Q * 64;
   Tr<Q> tr{lds, lane};
   const int M = md.M, L = w.Ld, c0 = lane * Q;
   float *pp = ws + w.mxb_off;       // posterior rows (M, I; D = 0)
@@ -429,7 +448,7 @@ __global__ void __launch_bounds__(64) oa_kernel(WorkQueue queue, const FbWork *_
   float n2N = 0.f, n2J = 0.f, n2C = 0.f;
   float ppM[Q], ppI[Q];
   float ax0 = 0.f, ax1 = 0.f, ax2 = 0.f;          // ppN ppJ ppC of the current row
-  if (L >= 1) { ax0 = aux[3]; ax1 = aux[4]; ax2 = aux[5]; }
+  if (L >= 1) { ax0 = XL ? LD2X(&aux[3]) : aux[3]; ax1 = XL ? LD2X(&aux[4]) : aux[4]; ax2 = XL ? LD2X(&aux[5]) : aux[5]; }
   if (L >= 1) {
     const float *__restrict__ p1 = pp + (size_t)1 * 2 * Mp + lane;
 #pragma unroll
@@ -439,7 +458,7 @@ __global__ void __launch_bounds__(64) oa_kernel(WorkQueue queue, const FbWork *_
     // posterior row i is in registers; row i+1 is requested now, before this row's stores
     float ppMn[Q], ppIn[Q];
     const float *__restrict__ axn = aux + (size_t)((i < L) ? i + 1 : i) * 3;
-    const float an0 = axn[0], an1 = axn[1], an2 = axn[2];
+    const float an0 = XL ? LD2X(&axn[0]) : axn[0], an1 = XL ? LD2X(&axn[1]) : axn[1], an2 = XL ? LD2X(&axn[2]) : axn[2];
     {
       const float *__restrict__ pn = pp + (size_t)((i < L) ? i + 1 : i) * 2 * Mp + lane;
 #pragma unroll
@@ -509,7 +528,7 @@ __global__ void __launch_bounds__(64) oa_kernel(WorkQueue queue, const FbWork *_
 #pragma unroll
       for (int q = 0; q < Q; ++q) { const float t = me[q] * rfx[q * 64]; s = s + t; s = s + ie[q]; }
       s = wave_sum(s);
-      if (lane == 0) out[w.slot].null2[x] = s + xfactor;
+      if (lane == 0) outp->null2[x] = s + xfactor;
     }
   }
   __threadfence();
@@ -535,7 +554,7 @@ __global__ void __launch_bounds__(64) oa_kernel(WorkQueue queue, const FbWork *_
     const float *pr = (i > 0) ? oa + (size_t)(i - 1) * 3 * Mp : oa;
     if (st == 0) {
       if (i == 0) { done = true; }
-      else { const float a = LD2(&oax[(size_t)(i - 1) * 5 + 4]) + aux[(size_t)i * 3 + 2], b = LD2(&oax[(size_t)i * 5 + 2]); if (a >= b) --i; else st = 1; }
+      else { const float a = LD2(&oax[(size_t)(i - 1) * 5 + 4]) + (XL ? LD2X(&aux[(size_t)i * 3 + 2]) : aux[(size_t)i * 3 + 2]), b = LD2(&oax[(size_t)i * 5 + 2]); if (a >= b) --i; else st = 1; }
     } else if (st == 1) {
       const float e = LD2(&oax[(size_t)i * 5 + 2]);
       int best = Mp;
@@ -564,11 +583,116 @@ __global__ void __launch_bounds__(64) oa_kernel(WorkQueue queue, const FbWork *_
     }
   }
   if (lane == 0) {
-    EnvOut &o = out[w.slot];
+    EnvOut &o = *outp;
     o.range_err = 0; o.oasc = oC;
     o.hmm_from = fk; o.hmm_to = lk; o.ali_from = fi + w.i0; o.ali_to = li + w.i0;
   }
+}
+
+template <int Q>
+__global__ void __launch_bounds__(64) oa_kernel(WorkQueue queue, const FbWork *__restrict__ work,
+                                               const DevModel *__restrict__ models, float *__restrict__ ws,
+                                               const int32_t *__restrict__ range_err, const FwdOut *__restrict__ fout, EnvOut *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int Mp = Q * 64;
+  const int lane = threadIdx.x;
+  uint32_t cur_model = 0xffffffffu;
+ const uint32_t nqueue = queue_len(queue);
+ for (uint32_t qk = blockIdx.x; qk < nqueue; qk += gridDim.x) {
+  const uint32_t item = queue.list[qk];
+  const FbWork w = work[item];
+  const DevModel &md = models[w.model];
+  if (w.model != cur_model) { load_gates<Q>(lds, md.ftr); cur_model = w.model; }
+  if (lane == 0) { out[w.slot].xC = fout[w.slot].xC; out[w.slot].nscale = fout[w.slot].nscale; }     // the envelope's Forward result travels with its record
+  if (range_err[w.slot]) { if (lane == 0) out[w.slot].range_err = 1; continue; }
+  oa_item<Q, false>(w, md, lds, lane, ws, &out[w.slot]);
  }
+}
+
+// ---- fused kernels of the device-driven cascade ---------------------------------------------------------------------------------
+// One wavefront takes a work item through SEVERAL stages back to back, so that no stage of a chain waits for the slowest item of the
+// stage before it (every launch boundary is such a wait) and a chain is three launches per register class instead of seven.
+// What one lane stores and another lane of the same wavefront reads afterwards (special rows, decoding terms) is read with L2-scope
+// loads after a fence (the XL variants of bwd_item / oa_item / region_scan).
+
+// whole-sequence parser item: Forward -> F3 (conservative, see fwd_kernel) -> Backward -> posterior heuristics -> envelope / region items
+template <int Q>
+__global__ void __launch_bounds__(64) parser_kernel(WorkQueue queue, const FbWork *__restrict__ work,
+                                                   const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
+                                                   const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
+                                                   float *__restrict__ ws, ScaleEvent *__restrict__ events, uint32_t *__restrict__ nevents, uint32_t cap_events,
+                                                   CascadeDev cd) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ uint32_t bc[4];
+  const int lane = threadIdx.x;
+  uint32_t cur_model = 0xffffffffu;
+  const uint32_t nqueue = queue_len(queue);
+  for (uint32_t qk = blockIdx.x; qk < nqueue; qk += gridDim.x) {
+    const uint32_t item = queue.list[qk];
+    FbWork w = work[item];
+    const DevModel &md = models[w.model];
+    if (w.model != cur_model) { load_tr<Q>(lds, md.ftr); cur_model = w.model; }
+    float xC, lsum, move; int nscale;
+    fwd_item<Q>(w, md, lds, lane, lentab, res, seq_off, ws, events, nevents, cap_events, xC, nscale, lsum, move);
+    __syncthreads();
+    if (lane == 0) {
+      uint32_t ok = 0, pid = 0xffffffffu; unsigned long long off = 0;
+      const PairRec pr = cd.cand[w.cand];
+      const float fwdsc = lsum + approx_ln(xC * move);
+      const float sc = (fwdsc - pr.filtersc) * LOG2E_F;
+      if (sc >= md.thr_fwd_f3 - cd.margin_fwd && ws_alloc(cd, (unsigned long long)(w.Ld + 1) * 3ull, off)) {
+        pid = atomicAdd(&cd.gcnt[CC_PASS], 1u);
+        if (pid < cd.cap_pass) {
+          PassRec r;
+          r.cand = w.cand; r.fwork = item; r.model = w.model; r.seq = w.seq; r.usc = pr.usc;
+          r.bias_d = cd.bias_raw[2 * (size_t)w.cand]; r.bias_e = cd.bias_raw[2 * (size_t)w.cand + 1];
+          r.vit_fast = cd.vit_fast[w.cand]; r.vit_exact = cd.vit_exact[w.cand]; r.vit_flag = cd.vit_flag[w.cand]; r.route = cd.route[w.cand];
+          r.fwd_xC = xC; r.nscale = nscale;
+          cd.h_pass[pid] = r;
+          ok = 1;
+        } else atomicOr(&cd.gcnt[CC_STATUS], (uint32_t)CS_PASS);
+      }
+      bc[0] = ok; bc[1] = pid; bc[2] = (uint32_t)off; bc[3] = (uint32_t)(off >> 32);
+    }
+    __syncthreads();
+    const uint32_t ok = bc[0];
+    w.pass = bc[1]; w.aux_off = (unsigned long long)bc[2] | ((unsigned long long)bc[3] << 32);
+    if (!ok) continue;
+    __threadfence();
+    bool bad = false;
+    bwd_item<Q, true>(w, md, lds, lane, lentab, res, seq_off, ws, xC, bad);
+    __threadfence();
+    __builtin_amdgcn_wave_barrier();
+    region_scan<true>(cd, md, w, ws, lane);
+  }
+}
+
+// envelope: unihit Forward -> Backward (posterior rows) -> null2 by expectation + optimal accuracy + traceback
+template <int Q>
+__global__ void __launch_bounds__(64) env_kernel(WorkQueue queue, const FbWork *__restrict__ work,
+                                                const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
+                                                const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
+                                                float *__restrict__ ws, ScaleEvent *__restrict__ events, uint32_t *__restrict__ nevents, uint32_t cap_events,
+                                                EnvOut *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x;
+  const uint32_t nqueue = queue_len(queue);
+  for (uint32_t qk = blockIdx.x; qk < nqueue; qk += gridDim.x) {
+    const FbWork w = work[queue.list[qk]];
+    const DevModel &md = models[w.model];
+    load_tr<Q>(lds, md.ftr);                      // (the previous item left the gate image of the optimal-accuracy stage)
+    float xC, lsum, move; int nscale;
+    fwd_item<Q>(w, md, lds, lane, lentab, res, seq_off, ws, events, nevents, cap_events, xC, nscale, lsum, move);
+    __threadfence();
+    bool bad = false;
+    bwd_item<Q, true>(w, md, lds, lane, lentab, res, seq_off, ws, xC, bad);
+    const bool anybad = __ballot(bad) != 0ull;
+    if (lane == 0) { out[w.slot].xC = xC; out[w.slot].nscale = nscale; if (anybad) out[w.slot].range_err = 1; }
+    if (anybad) continue;
+    __threadfence();
+    load_gates<Q>(lds, md.ftr);
+    oa_item<Q, true>(w, md, lds, lane, ws, &out[w.slot]);
+  }
 }
 
 // ---- launchers ----------------------------------------------------------------------------------
@@ -606,6 +730,31 @@ int launch_oa(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, cons
   if (!nblocks) return 0;
   switch (Q) {
 #define X(QV) case QV: hipLaunchKernelGGL(oa_kernel<QV>, dim3(nblocks), dim3(64), (size_t)8 * QV * 64 * 4, stream, queue, work, models, ws, range_err, fout, out); break;
+    CKM_FB_QS(X)
+#undef X
+    default: return -1;
+  }
+  return 0;
+}
+
+int launch_parser(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const FbWork *work, const DevModel *models,
+                  const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws,
+                  ScaleEvent *events, uint32_t *nevents, uint32_t cap_events, const CascadeDev &cd) {
+  if (!nblocks) return 0;
+  switch (Q) {
+#define X(QV) case QV: hipLaunchKernelGGL(parser_kernel<QV>, dim3(nblocks), dim3(64), (size_t)8 * QV * 64 * 4, stream, queue, work, models, lentab, res, seq_off, ws, events, nevents, cap_events, cd); break;
+    CKM_FB_QS(X)
+#undef X
+    default: return -1;
+  }
+  return 0;
+}
+int launch_env(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const FbWork *work, const DevModel *models,
+               const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws,
+               ScaleEvent *events, uint32_t *nevents, uint32_t cap_events, EnvOut *out) {
+  if (!nblocks) return 0;
+  switch (Q) {
+#define X(QV) case QV: hipLaunchKernelGGL(env_kernel<QV>, dim3(nblocks), dim3(64), (size_t)8 * QV * 64 * 4, stream, queue, work, models, lentab, res, seq_off, ws, events, nevents, cap_events, out); break;
     CKM_FB_QS(X)
 #undef X
     default: return -1;
