@@ -736,7 +736,10 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
         const int Q = kFbQ[c];
         const WorkQueue qf{cd.fq + (size_t)c * sb.cap_f, cnt + CC_FQ + c, sb.cap_f}, qb{cd.bq + (size_t)c * sb.cap_f, cnt + CC_BQ + c, sb.cap_f};
         const WorkQueue qe{cd.eq + (size_t)c * sb.cap_e, cnt + CC_EQ + c, sb.cap_e}, qr{cd.rq + (size_t)c * sb.cap_r, cnt + CC_RQ + c, sb.cap_r};
-        static const bool unfused = getenv("CKM_UNFUSED") != nullptr;          // (the stage-by-stage launches, for comparison)
+        // CKM_FUSED=1: one wavefront takes an item through Forward -> F3 -> Backward -> regions (and an envelope through Forward -> Backward ->
+        // OA) in ONE launch.  Same rows; measured 2-3 % slower on cfg2 (the fused kernels hold 1.5-2x the registers, and the stage
+        // boundaries they remove were already hidden underneath the SSV launches), so the stage-by-stage launches stay the default.
+        static const bool unfused = !(getenv("CKM_FUSED") && atoi(getenv("CKM_FUSED")) != 0);
         if (!unfused) {
           if (stop >= 6) rc |= launch_parser(Q, GRID_FB, sc, qf, cd.fwork, dm, lt, res, off, ws, d_events_f, d_gcnt + CC_EVENTS, cp.events_f, cd);
           if (stop >= 9) rc |= launch_env(Q, GRID_FB, sc, qe, cd.ework, dm, lt, res, off, ws, d_events_e, d_gcnt + CC_EVENTS_E, cp.events_e, d_envout);
