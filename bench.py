@@ -152,8 +152,9 @@ def ssv_roofline(st_like, ssv_ms_per_step, bins, orfs, extra_note=""):
             "note": "the kernel is VALU-issue-bound by design (SURVEY H3), not HBM-bound: see roofline_valu and gcups_ssv" + extra_note}
     valu = None
     tf = None
-    for tag in (PROFILE_TAG, "r01e"):
-        cand = os.path.join(ROOT, "profiles", "%s_ssv_traffic.json" % tag)
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", PROFILE_TAG + "*_ssv_traffic.json")))      # r02a, r02b, ...: the latest pass of this round
+    for cand in found[::-1] + [os.path.join(ROOT, "profiles", "r01e_ssv_traffic.json")]:
         if os.path.exists(cand):
             tf = cand
             break
@@ -166,7 +167,9 @@ def ssv_roofline(st_like, ssv_ms_per_step, bins, orfs, extra_note=""):
         cyc = ssv_s * 2.4e9 / (pm["valu_insts"] / 1024.0)
         valu = {"bound": "valu-issue", "wave_insts_per_step": pm["valu_insts"], "source": src + " (rocprofv3 --pmc SQ_INSTS_VALU pass, recorded)",
                 "cycles_per_inst_per_simd": cyc, "ceiling_cycles_per_inst": 4.0, "frac": 4.0 / cyc,
-                "note": "issue peak = 1 wave64 instruction per 4 cycles per SIMD (measured for packed-i16/DPP/perm ops: tools/ubench/valu_rates.hip); "
+                "measured_ceiling_cycles_per_inst": 4.55, "frac_of_measured_ceiling": min(1.0, 4.55 / cyc),
+                "note": "architectural issue peak = 1 wave64 instruction per 4 cycles per SIMD; the packed-i16 add/max the kernel consists of issue "
+                        "at 4.53-4.60 cycles when measured alone (tools/ubench/valu_rates.hip, profiles/r02_valu_rates.txt); "
                         "time = the SSV launches of this run, HIP events"}
     return roof, valu
 
