@@ -61,6 +61,7 @@ void launch_ensemble(hipStream_t stream, const EnsWork *work, const uint32_t *co
                      float *host_res /* pinned buffer the results are exported to, or null */);
 void launch_bias_filter(hipStream_t stream, uint32_t nblocks, const CascadeDev &cd, const DevModel *models, const LenEntry *lentab,
                         const uint8_t *res, const uint64_t *seq_off);
+void set_chain_prio_fb(int v); void set_chain_prio_filter(int v); void set_chain_prio_cascade(int v);   // CKM_CHAIN_PRIO (kernels_*.hip)
 void launch_regions(hipStream_t stream, uint32_t nblocks, const uint32_t *list, const uint32_t *count, uint32_t cap, const FbWork *fwork,
                     const CascadeDev &cd, const DevModel *models, float *ws);
 #define HIPCHK(expr)                                                                                         \

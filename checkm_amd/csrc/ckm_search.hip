@@ -498,36 +498,63 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   // plan: lineage_wf scans the same bins twice, bench repeats steps).  Each group is one SSV launch AND one sub-cascade: its survivors
   // go down their own chain of queues as soon as that launch is done, while the SSV launches of the other groups still run. ----
   hipStream_t ms = ctx->stream;
-  // Two parts by sequence length: the long sequences of every bin (a prefix of its length-sorted order holding ~CKM_LONG_SHARE of the
-  // residues) are scanned first, so that their chains -- every stage lasts as long as its longest sequence -- run underneath the SSV
-  // launches of the short part, and what is left after the last SSV launch is the chain of short sequences only.
+  // Parts by sequence length: the long sequences of every bin (a prefix of its length-sorted order) are scanned first, so that their
+  // chains -- every stage lasts as long as its longest sequence -- run underneath the SSV launches of the parts behind them, and what
+  // is left after the last SSV launch is the chain of the shortest sequences only.
   const uint32_t nbins = s->nbins;
-  std::vector<uint32_t> mid(rng.hi);                        // part 0 = [lo, mid), part 1 = [mid, hi)
+  // cut[k][b] .. cut[k+1][b] = part k of bin b's length-sorted order (lengths descend along it); CKM_LONG_SHARE="0.25,0.5" gives the
+  // shares of the residues of all parts but the last.  Two parts by default (the longest sequences holding a quarter of the residues,
+  // then the rest); a third part of the shortest sequences, scanned last so that only short chains are left at the end, was measured
+  // and does not pay: 18 more launches and chains cost what the shorter tail gains (cfg2: 86.4-88.0 ms against 85.3).
+  std::vector<std::vector<uint32_t>> cut(1, rng.lo);
   int nparts = 1, Lcut = 0;
+  std::vector<int> Lcuts;
   {
     uint64_t split_min = 2000000;
     if (const char *e = getenv("CKM_SPLIT_MIN_PAIRS")) split_min = strtoull(e, nullptr, 10);
-    double share = 0.25;
-    if (const char *e = getenv("CKM_LONG_SHARE")) share = atof(e);
-    if (total_pairs >= split_min && share > 0.0 && share < 1.0) {
+    std::vector<double> shares{0.25};
+    if (const char *e = getenv("CKM_LONG_SHARE")) {
+      shares.clear();
+      for (const char *q = e; *q;) {
+        char *end = nullptr;
+        const double v = strtod(q, &end);
+        if (end == q) break;
+        if (v > 0.0 && v < 1.0) shares.push_back(v);
+        if (*end != ',') break;
+        q = end + 1;
+      }
+    }
+    if (total_pairs >= split_min && !shares.empty()) {
       std::vector<uint64_t> by_len((size_t)s->maxL + 2, 0);
       uint64_t total = 0;
       for (uint32_t b = 0; b < nbins; ++b) for (uint32_t k = rng.lo[b]; k < rng.hi[b]; ++k) { const int L = s->len[s->order[k]]; by_len[L] += (uint64_t)L; total += (uint64_t)L; }
-      uint64_t acc = 0;
-      for (int L = s->maxL; L >= 1; --L) { acc += by_len[L]; if ((double)acc >= share * (double)total) { Lcut = L - 1; break; } }
-      if (Lcut > 0) {
-        nparts = 2;
-        for (uint32_t b = 0; b < nbins; ++b) {
-          uint32_t lo = rng.lo[b], hi = rng.hi[b];                 // lengths descend along the order: first position with len <= Lcut
-          while (lo < hi) { const uint32_t m = (lo + hi) / 2; if (s->len[s->order[m]] > Lcut) lo = m + 1; else hi = m; }
-          mid[b] = lo;
+      uint64_t acc = 0; double want = 0.0; size_t si = 0;
+      want = shares[0];
+      for (int L = s->maxL; L >= 1 && si < shares.size(); --L) {
+        acc += by_len[L];
+        if ((double)acc >= want * (double)total) {
+          if (L - 1 > 0 && (Lcuts.empty() || L - 1 < Lcuts.back())) Lcuts.push_back(L - 1);      // part boundary: lengths > L-1 | <= L-1
+          if (++si < shares.size()) want += shares[si];
         }
       }
+      for (int lc : Lcuts) {
+        std::vector<uint32_t> c(nbins);
+        for (uint32_t b = 0; b < nbins; ++b) {
+          uint32_t lo = rng.lo[b], hi = rng.hi[b];                 // first position with len <= lc
+          while (lo < hi) { const uint32_t m = (lo + hi) / 2; if (s->len[s->order[m]] > lc) lo = m + 1; else hi = m; }
+          c[b] = lo;
+        }
+        cut.push_back(std::move(c));
+      }
+      nparts = (int)Lcuts.size() + 1;
+      if (!Lcuts.empty()) Lcut = Lcuts[0];
     }
   }
+  cut.push_back(rng.hi);
   std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;      // key = part * 1000 + SSV register class
   {
     std::vector<uint64_t> key{p->uid, s->uid, pair_budget, (uint64_t)Lcut, rng.tag, 0xdeull};
+    for (int lc : Lcuts) key.push_back(0xc0000000ull + (uint64_t)lc);
     for (auto &mw : mws) { key.push_back(0xffffffffull + mw.model); for (uint32_t b : model_bins[mw.model]) key.push_back(b); }
     if (key == ctx->plan_key) {
       groups = ctx->plan_groups;
@@ -545,7 +572,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
         for (uint32_t b : model_bins[mw.model]) {
           const uint32_t o0 = rng.lo[b], n = rng.hi[b] - o0;
           for (int part = 0; part < nparts; ++part) {
-            const uint32_t a0 = part == 0 ? 0 : mid[b] - o0, a1 = (part == 0 && nparts == 2) ? mid[b] - o0 : n;
+            const uint32_t a0 = cut[part][b] - o0, a1 = cut[part + 1][b] - o0;
             if (a1 > a0) runs[part * 1000 + Q].push_back({mw.model, o0 + a0, a1 - a0, pb + a0});
           }
           pb += n; c_res += rng.res[b]; c_cells += rng.res[b] * (uint64_t)p->prof[mw.model].M;
@@ -584,10 +611,9 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
     std::map<int, size_t> at;
     for (auto &g : groups) { Sub sb; sb.Q = g.first % 1000; sb.first = g.second.first; sb.nblocks = g.second.second; at[g.first] = subs.size(); subs.push_back(sb); }
     for (auto &mw : mws) {
-      uint64_t n0 = 0;                                        // the model's pairs in part 0
-      for (uint32_t b : model_bins[mw.model]) n0 += mid[b] - rng.lo[b];
       for (int part = 0; part < nparts; ++part) {
-        const uint64_t np = part == 0 ? n0 : mw.npairs - n0;
+        uint64_t np = 0;                                      // the model's pairs in this part
+        for (uint32_t b : model_bins[mw.model]) np += cut[part + 1][b] - cut[part][b];
         auto it = at.find(part * 1000 + p->prof[mw.model].ssvQ);
         if (it == at.end()) continue;                         // (no sequence of this part in the model's bins)
         Sub &sb = subs[it->second]; sb.pairs += np; sb.vit[p->dm[mw.model].vit_cls] = true; sb.fb[p->dm[mw.model].fb_cls] = true;
@@ -695,14 +721,17 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   {
     std::vector<size_t> launch_order;                            // long part first; inside a part the heaviest register class first
     {
-      size_t n0 = 0;
-      for (auto &g : groups) if (g.first < 1000) ++n0;
-      for (size_t g = n0; g-- > 0;) launch_order.push_back(g);
-      for (size_t g = NG; g-- > n0;) launch_order.push_back(g);
+      size_t g0 = 0;                                             // groups are sorted by key = part * 1000 + class
+      for (int part = 0; part < nparts; ++part) {
+        size_t g1 = g0;
+        while (g1 < NG && groups[g1].first / 1000 == part) ++g1;
+        for (size_t g = g1; g-- > g0;) launch_order.push_back(g);
+        g0 = g1;
+      }
     }
     int gi = 0;
     for (size_t g : launch_order) {
-      const int gi_now = gi++; (void)gi_now;
+      const int gi_now = gi++;
       const Sub &sb = subs[g];
       hipStream_t sv = ctx->side[gi_now % NSS];
       if (launch_ssv(sb.Q, (int)sb.nblocks, ssv_threads_for(sb.Q), sv, ctx->work.as<SsvBlockWork>() + sb.first, dm, res, off, dlen,
@@ -739,7 +768,10 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
         // CKM_FUSED=1: one wavefront takes an item through Forward -> F3 -> Backward -> regions (and an envelope through Forward -> Backward ->
         // OA) in ONE launch.  Same rows; measured 2-3 % slower on cfg2 (the fused kernels hold 1.5-2x the registers, and the stage
         // boundaries they remove were already hidden underneath the SSV launches), so the stage-by-stage launches stay the default.
-        static const bool unfused = !(getenv("CKM_FUSED") && atoi(getenv("CKM_FUSED")) != 0);
+        // CKM_FUSED_TAIL=n fuses only the last n groups of the launch order (their chains run after the last SSV launch, on an idle device).
+        static const bool fused_all = getenv("CKM_FUSED") && atoi(getenv("CKM_FUSED")) != 0;
+        static const int fused_tail = getenv("CKM_FUSED_TAIL") ? atoi(getenv("CKM_FUSED_TAIL")) : 0;
+        const bool unfused = !(fused_all || gi_now >= (int)launch_order.size() - fused_tail);
         if (!unfused) {
           if (stop >= 6) rc |= launch_parser(Q, GRID_FB, sc, qf, cd.fwork, dm, lt, res, off, ws, d_events_f, d_gcnt + CC_EVENTS, cp.events_f, cd);
           if (stop >= 9) rc |= launch_env(Q, GRID_FB, sc, qe, cd.ework, dm, lt, res, off, ws, d_events_e, d_gcnt + CC_EVENTS_E, cp.events_e, d_envout);
@@ -831,8 +863,67 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   if (n_hens) HIPCHK(hipMemcpyAsync(h_hens, d_hens, (size_t)n_hens * sizeof(float), hipMemcpyDeviceToHost, ms));
   HIPCHK(hipStreamSynchronize(ms));
   CKM_TRACE_PT("results copied");
-  // ---- the filter decisions again, exactly (host libm), for the pairs the device let through ----
   const PassRec *pass = h_pass;
+  const RegionRec *reg = h_reg;
+  // ---- ensembles first: their clustered domains are the only envelopes the device has not rescored yet.  Parse the exported traces of
+  // every multi-domain region, cluster them on the host threads, and hand the resulting envelopes to a helper thread that drives the
+  // short second round (Forward / Backward / OA of a few dozen envelopes) while this thread takes the exact decisions below. ----
+  std::vector<RegionRes> pre(n_reg);                                    // by region record; nseg stays empty where nothing was exported
+  std::vector<uint8_t> pre_overflow(n_reg, 0);
+  {
+    std::vector<uint32_t> multi_rec;
+    for (uint32_t ro = 0; ro < n_reg; ++ro) {
+      const RegionRec &rr = reg[ro];
+      if (!rr.multi || rr.pass >= n_pass) continue;
+      if (rr.target == 0xffffffffu || (rr.target != REGION_DEFERRED && rr.pad == 0xffffffffu)) return 1;   // no table entry / no export slot (status would have said so)
+      if (rr.target != REGION_DEFERRED) multi_rec.push_back(ro);
+    }
+    pool_run(ctx, multi_rec.size(), 1, [&](size_t lo, size_t hi) {
+      for (size_t k = lo; k < hi; ++k) {
+        const uint32_t ro = multi_rec[k];
+        const RegionRec &rr = reg[ro]; RegionRes &o = pre[ro];
+        const int Ld = rr.j - rr.i + 1, cap = std::min(Ld, 16);
+        const float *raw = h_hens + rr.pad;
+        const int32_t *ns = reinterpret_cast<const int32_t *>(raw);
+        const int32_t *sg = reinterpret_cast<const int32_t *>(raw + 256);
+        bool overflow = false;
+        for (int t = 0; t < ENS_NSAMPLES; ++t) overflow |= ns[t] < 0;
+        if (overflow) { pre_overflow[ro] = 1; continue; }               // a trace needed more segment slots: the host-driven ensemble repeats the region
+        o.cap = cap; o.nseg.assign(ns, ns + ENS_NSAMPLES); o.segs.assign((size_t)ENS_NSAMPLES * cap, Seg{0, 0, 0, 0});
+        for (int t = 0; t < ENS_NSAMPLES; ++t)
+          for (int d = 0; d < ns[t]; ++d) {                             // the device walks backwards: last domain first
+            const int32_t *q4 = sg + ((size_t)t * cap + (ns[t] - 1 - d)) * 4;
+            o.segs[(size_t)t * cap + d] = Seg{q4[0], q4[1], q4[2], q4[3]};
+          }
+        const float *n2 = raw + 256 + (size_t)ENS_NSAMPLES * cap * 4;
+        o.n2sum.assign(n2, n2 + Ld);
+        cluster_ensemble(o);
+      }
+    });
+  }
+  std::vector<EnvReq> early_req; std::vector<EnvRes> early_res;
+  std::vector<int64_t> early_first(n_reg, -1);                          // region record -> first of its envelopes in early_req
+  for (uint32_t ro = 0; ro < n_reg; ++ro) {
+    if (pre[ro].nseg.empty()) continue;
+    const RegionRec &rr = reg[ro];
+    early_first[ro] = (int64_t)early_req.size();
+    for (const Seg &e : pre[ro].env) early_req.push_back({pass[rr.pass].model, pass[rr.pass].seq, e.sqfrom + rr.i - 1, e.sqto + rr.i - 1});
+  }
+  if (getenv("CKM_TRACE")) {
+    size_t nm = 0, nl = 0;
+    for (uint32_t ro = 0; ro < n_reg; ++ro) if (reg[ro].multi && reg[ro].pass < n_pass) { ++nm; nl += s->len[pass[reg[ro].pass].seq] > Lcut; }
+    fprintf(stderr, "ckm-trace w%d %zu multi-domain regions, %zu of them on sequences of the long part (L > %d); %zu ensemble envelopes\n", ctx->id, nm, nl, Lcut, early_req.size());
+  }
+  CKM_TRACE_PT("clustering done");
+  std::exception_ptr early_err;
+  std::thread early_thread;
+  if (!early_req.empty())
+    early_thread = std::thread([&] {
+      try { HIPCHK(hipSetDevice(ctx->device)); rescore_envelopes(ctx, p, s, early_req, early_res); } catch (...) { early_err = std::current_exception(); }
+    });
+  struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } early_joiner{early_thread};
+
+  // ---- the filter decisions again, exactly (host libm), for the pairs the device let through ----
   EventIndex fev; fev.build(h_events_f, n_evf, n_fwork);
   EventIndex eev; eev.build(h_events_e, n_eve, n_ework);
   std::vector<uint8_t> alive(n_pass, 0); std::vector<float> fwdsc(n_pass, 0.f);
@@ -862,10 +953,9 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   });
   if (inconsistent.load()) throw Error(CKM_EHIP, "device-side filter decision contradicts the exact one (margin too small): please report");
 
-  // ---- regions by pair, in sequence order; envelopes of single-domain regions are already rescored, ensembles get clustered ----
+  // ---- regions by pair, in sequence order; envelopes of single-domain regions are already rescored ----
   std::vector<uint32_t> rorder(n_reg);
   std::iota(rorder.begin(), rorder.end(), 0u);
-  const RegionRec *reg = h_reg;
   std::sort(rorder.begin(), rorder.end(), [&](uint32_t a, uint32_t b) { return reg[a].pass != reg[b].pass ? reg[a].pass < reg[b].pass : reg[a].i < reg[b].i; });
   DomStage ds;
   std::vector<int32_t> dsidx(n_pass, -1);
@@ -874,79 +964,57 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   ds.env_of_pass.assign(ds.pass.size(), {0, 0});
   std::vector<RegionReq> redo_req; std::vector<size_t> redo_at;          // ensembles that need more segment slots or found no workspace: host-driven
   size_t n_deferred = 0;
-  std::vector<int32_t> env_src;                                         // per envelope: index into h_envout, or -1 = to be rescored (ensemble envelope)
-  std::vector<std::pair<uint32_t, uint32_t>> ens_list;                  // (region record, regres index)
+  std::vector<uint32_t> item_rec;                                        // region record of every item of ds.items
   for (uint32_t ro : rorder) {
     const RegionRec &rr = reg[ro];
     if (rr.pass >= n_pass || dsidx[rr.pass] < 0) continue;
     const uint32_t q = (uint32_t)dsidx[rr.pass];
     if (rr.target == 0xffffffffu) return 1;                            // no table entry for it on the device (status would have said so)
     ds.nregions[q]++;
-    if (!rr.multi) ds.items.push_back({q, rr.i, rr.j, -1});
-    else {
-      ds.items.push_back({q, rr.i, rr.j, (int)ds.regres.size()});
-      if (rr.target == REGION_DEFERRED) { redo_req.push_back({pass[rr.pass].model, pass[rr.pass].seq, rr.i, rr.j}); redo_at.push_back(ds.regres.size()); ++n_deferred; }
-      else ens_list.push_back({ro, (uint32_t)ds.regres.size()});
+    item_rec.push_back(ro);
+    if (!rr.multi) { ds.items.push_back({q, rr.i, rr.j, -1}); continue; }
+    ds.items.push_back({q, rr.i, rr.j, (int)ds.regres.size()});
+    if (rr.target == REGION_DEFERRED || pre_overflow[ro]) {
+      redo_req.push_back({pass[rr.pass].model, pass[rr.pass].seq, rr.i, rr.j}); redo_at.push_back(ds.regres.size());
+      if (rr.target == REGION_DEFERRED) ++n_deferred;
       ds.regres.emplace_back();
-    }
+    } else ds.regres.push_back(std::move(pre[ro]));
   }
-  // ensemble results from the pinned export; clustering on the host threads
-  for (auto &er : ens_list) {
-    const RegionRec &rr = reg[er.first]; RegionRes &o = ds.regres[er.second];
-    const int Ld = rr.j - rr.i + 1, cap = std::min(Ld, 16);
-    if (rr.pad == 0xffffffffu) return 1;
-    const float *raw = h_hens + rr.pad;
-    const int32_t *ns = reinterpret_cast<const int32_t *>(raw);
-    const int32_t *sg = reinterpret_cast<const int32_t *>(raw + 256);
-    bool overflow = false;
-    for (int t = 0; t < ENS_NSAMPLES; ++t) overflow |= ns[t] < 0;
-    if (overflow) { redo_req.push_back({pass[rr.pass].model, pass[rr.pass].seq, rr.i, rr.j}); redo_at.push_back(er.second); continue; }
-    o.cap = cap; o.nseg.assign(ns, ns + ENS_NSAMPLES); o.segs.assign((size_t)ENS_NSAMPLES * cap, Seg{0, 0, 0, 0});
-    for (int t = 0; t < ENS_NSAMPLES; ++t)
-      for (int d = 0; d < ns[t]; ++d) {                                 // the device walks backwards: last domain first
-        const int32_t *q4 = sg + ((size_t)t * cap + (ns[t] - 1 - d)) * 4;
-        o.segs[(size_t)t * cap + d] = Seg{q4[0], q4[1], q4[2], q4[3]};
-      }
-    const float *n2 = raw + 256 + (size_t)ENS_NSAMPLES * cap * 4;
-    o.n2sum.assign(n2, n2 + Ld);
-  }
-  pool_run(ctx, ds.regres.size(), 1, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) if (!ds.regres[k].nseg.empty()) cluster_ensemble(ds.regres[k]); });
-  if (!redo_req.empty()) {
-    std::vector<RegionRes> r2;
-    run_ensembles(ctx, p, s, redo_req, r2);
-    for (size_t k = 0; k < redo_at.size(); ++k) ds.regres[redo_at[k]] = std::move(r2[k]);
-  }
-  CKM_TRACE_PT("decisions + clustering done");
-  // envelopes in pair order (as the host-driven cascade lists them)
-  {
-    size_t it = 0, ri = 0;
-    // region records of alive pairs, in the order of ds.items
-    std::vector<uint32_t> item_rec;
-    for (uint32_t ro : rorder) { const RegionRec &rr = reg[ro]; if (rr.pass < n_pass && dsidx[rr.pass] >= 0) item_rec.push_back(ro); }
+  // envelopes in pair order (as the host-driven cascade lists them); source of each: >= 0 index into h_envout (rescored by the chain),
+  // <= -2 index -2 - k into early_res (ensemble envelope, second round under way), -1 still to be rescored (deferred / repeated regions)
+  std::vector<int64_t> env_src;
+  auto list_envelopes = [&]() {
+    ds.envreq.clear(); ds.env_region.clear(); env_src.clear();
+    size_t it = 0;
     for (size_t q = 0; q < ds.pass.size(); ++q) {
       ds.env_of_pass[q].first = ds.envreq.size();
-      for (; it < ds.items.size() && ds.items[it].pass == q; ++it, ++ri) {
+      for (; it < ds.items.size() && ds.items[it].pass == q; ++it) {
         const DomItem &im = ds.items[it];
-        const RegionRec &rr = reg[item_rec[ri]];
+        const uint32_t ro = item_rec[it];
+        const RegionRec &rr = reg[ro];
         if (im.region < 0) {
           ds.envreq.push_back({ds.pass[q].model, ds.pass[q].seq, im.i, im.j}); ds.env_region.push_back(-1);
-          env_src.push_back(rr.target == REGION_DEFERRED ? -1 : (int32_t)rr.target);          // deferred: rescored with the second round, in workspace-sized batches
-          if (rr.target == REGION_DEFERRED) ++n_deferred;
+          env_src.push_back(rr.target == REGION_DEFERRED ? -1 : (int64_t)rr.target);          // deferred: rescored with the late round, in workspace-sized batches
           continue;
         }
+        size_t k = 0;
         for (const Seg &e : ds.regres[im.region].env) {
           const int i2 = e.sqfrom + im.i - 1, j2 = e.sqto + im.i - 1;
-          ds.envreq.push_back({ds.pass[q].model, ds.pass[q].seq, i2, j2}); ds.env_region.push_back(im.region); env_src.push_back(-1);
+          ds.envreq.push_back({ds.pass[q].model, ds.pass[q].seq, i2, j2}); ds.env_region.push_back(im.region);
+          env_src.push_back(early_first[ro] >= 0 && !pre_overflow[ro] && rr.target != REGION_DEFERRED ? -2 - (early_first[ro] + (int64_t)k) : -1);
+          ++k;
         }
       }
       ds.env_of_pass[q].second = ds.envreq.size() - ds.env_of_pass[q].first;
     }
-  }
+  };
+  for (uint32_t ro = 0; ro < n_reg; ++ro) if (!reg[ro].multi && reg[ro].target == REGION_DEFERRED && reg[ro].pass < n_pass && dsidx[reg[ro].pass] >= 0) ++n_deferred;
+  list_envelopes();
   ds.envres.resize(ds.envreq.size());
-  {
-    std::vector<EnvReq> second; std::vector<size_t> second_at;
-    for (size_t e = 0; e < ds.envreq.size(); ++e) {
-      if (env_src[e] < 0) { second.push_back(ds.envreq[e]); second_at.push_back(e); continue; }
+  // first-round results while the second round runs
+  pool_run(ctx, ds.envreq.size(), 64, [&](size_t lo, size_t hi) {
+    for (size_t e = lo; e < hi; ++e) {
+      if (env_src[e] < 0) continue;
       const EnvOut &eo = h_envout[env_src[e]];
       EnvRes &o = ds.envres[e];
       const LenEntry &le = s->lentab[s->len[ds.envreq[e].seq]];
@@ -956,7 +1024,41 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
       o.oasc = eo.oasc; o.hmm_from = eo.hmm_from; o.hmm_to = eo.hmm_to; o.ali_from = eo.ali_from; o.ali_to = eo.ali_to;
       for (int x = 0; x < K; ++x) o.null2[x] = eo.null2[x];
     }
-    if (!second.empty()) {                                             // the short second round: envelopes that came out of the ensembles
+  });
+  CKM_TRACE_PT("decisions done");
+  if (early_thread.joinable()) early_thread.join();
+  if (early_err) std::rethrow_exception(early_err);
+  CKM_TRACE_PT("second round done");
+  if (!redo_req.empty()) {                                              // rare: regions the device could not take (workspace, segment slots)
+    std::vector<RegionRes> r2;
+    run_ensembles(ctx, p, s, redo_req, r2);
+    for (size_t k = 0; k < redo_at.size(); ++k) ds.regres[redo_at[k]] = std::move(r2[k]);
+    list_envelopes();                                                   // the repeated regions now have envelopes: same order, more entries
+    std::vector<EnvRes> keep(ds.envreq.size());
+    {
+      // results computed above stay valid for the entries whose source did not change: redo the cheap conversion instead of tracking moves
+      for (size_t e = 0; e < ds.envreq.size(); ++e) {
+        if (env_src[e] < 0) continue;
+        const EnvOut &eo = h_envout[env_src[e]];
+        EnvRes &o = keep[e];
+        const LenEntry &le = s->lentab[s->len[ds.envreq[e].seq]];
+        o.ok = eo.range_err == 0;
+        o.xC = eo.xC; o.nscale = eo.nscale;
+        o.envsc = finish_forward(eo.xC, le.move_u, eev.scales((uint32_t)env_src[e]));
+        o.oasc = eo.oasc; o.hmm_from = eo.hmm_from; o.hmm_to = eo.hmm_to; o.ali_from = eo.ali_from; o.ali_to = eo.ali_to;
+        for (int x = 0; x < K; ++x) o.null2[x] = eo.null2[x];
+      }
+    }
+    ds.envres.swap(keep);
+  }
+  {
+    std::vector<EnvReq> second; std::vector<size_t> second_at;
+    for (size_t e = 0; e < ds.envreq.size(); ++e) {
+      if (env_src[e] >= 0) continue;
+      if (env_src[e] <= -2) { ds.envres[e] = early_res[(size_t)(-2 - env_src[e])]; continue; }
+      second.push_back(ds.envreq[e]); second_at.push_back(e);
+    }
+    if (!second.empty()) {                                             // late round: deferred regions and the envelopes of repeated ensembles
       std::vector<EnvRes> r2;
       rescore_envelopes(ctx, p, s, second, r2);
       for (size_t k = 0; k < second.size(); ++k) ds.envres[second_at[k]] = r2[k];
@@ -1084,7 +1186,7 @@ static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, cons
   auto run = [&](int k) {
     try {
       if (host_cascade) cascade(&c->w[k], c, k, p, s, ranges[k], chunk[k], model_bins, maps[k]);
-      else if (const int rc = cascade_dev(&c->w[k], c, k, p, s, ranges[k], chunk[k], model_bins, maps[k])) {
+      else if (cascade_dev(&c->w[k], c, k, p, s, ranges[k], chunk[k], model_bins, maps[k])) {
         c->fallbacks++;
         cascade(&c->w[k], c, k, p, s, ranges[k], chunk[k], model_bins, maps[k], true);      // (the attempt took and passed the lane's SSV turn, rc 1 or 2)
       }

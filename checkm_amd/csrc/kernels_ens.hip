@@ -73,8 +73,9 @@ __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restric
   const size_t rowsz = (size_t)3 * Mp;
   const float *__restrict__ mx = ws + w.mx_off;
   const float *__restrict__ xs = ws + w.xs_off;
-  const float *__restrict__ tBM = md.ftr, *tMM = md.ftr + Mp, *tIM = md.ftr + 2 * Mp, *tDM = md.ftr + 3 * Mp,
-              *tMI = md.ftr + 4 * Mp, *tII = md.ftr + 5 * Mp, *tMD = md.ftr + 6 * Mp, *tDD = md.ftr + 7 * Mp;
+  const gp<float> ftr = gptr(md.ftr);
+  const gp<float> tBM = ftr, tMM = ftr + Mp, tIM = ftr + 2 * Mp, tDM = ftr + 3 * Mp,
+                  tMI = ftr + 4 * Mp, tII = ftr + 5 * Mp, tMD = ftr + 6 * Mp, tDD = ftr + 7 * Mp;
   const LenEntry le = lentab[w.Lcfg];
   const float loop = le.loop_m, move = le.move_m, Eloop = md.fE_loop, Emove = md.fE_move;
   const bool live = t < ENS_N;
@@ -203,7 +204,7 @@ __global__ void __launch_bounds__(64) ens_null2_kernel(const EnsWork *__restrict
     for (int c = lane; c < 2 * Mp; c += 64) { const float v = (float)cnt[c] * norm; lds[c] = v; }
     __syncthreads();
     for (int x = 0; x < 20; ++x) {
-      const float *__restrict__ rfx = md.rf + (size_t)x * Mp + lane;
+      const gp<float> rfx = gptr(md.rf) + (size_t)x * Mp + lane;
       float s = 0.f;
       for (int q = 0; q < Q; ++q) { const int idx = lane * Q + q; const float tt = lds[idx] * rfx[q * 64]; s = s + tt; s = s + lds[Mp + idx]; }
       s = wave_sum(s);

@@ -17,6 +17,14 @@
 
 namespace ckm {
 
+// CKM_CHAIN_PRIO=1: the latency-bound kernels of a chain raise their wavefronts' issue priority over the SSV wavefronts they share a
+// SIMD with (one dependent instruction chain per wavefront: a chain that waits its turn behind 7 throughput-bound waves runs several
+// times longer than alone; the SSV waves lose exactly the issue slots the chain needs anyway).
+static __constant__ int c_chain_prio;
+void set_chain_prio_fb(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(c_chain_prio), &v, sizeof(int)); }
+#define CKM_RAISE_PRIO() do { if (c_chain_prio) __builtin_amdgcn_s_setprio(3); } while (0)
+
+
 constexpr float NEGINF_F = -__builtin_inff();
 
 // Transition odds in LDS, transposed to [array][q][lane] so that the 64 lanes of a wave read 64
@@ -47,7 +55,8 @@ template <int Q>
 __device__ __forceinline__ void load_tr(float *lds, const float *ftr) {
   constexpr int Mp = Q * 64;
   __syncthreads();
-  for (int i = threadIdx.x; i < 8 * Mp; i += blockDim.x) { const int arr = i / Mp, c = i % Mp; lds[arr * Mp + lds_cell<Q>(c)] = ftr[i]; }
+  const gp<float> g = gptr(ftr);
+  for (int i = threadIdx.x; i < 8 * Mp; i += blockDim.x) { const int arr = i / Mp, c = i % Mp; lds[arr * Mp + lds_cell<Q>(c)] = g[i]; }
   __syncthreads();
 }
 
@@ -56,7 +65,8 @@ template <int Q>
 __device__ __forceinline__ void load_gates(float *lds, const float *ftr) {
   constexpr int Mp = Q * 64;
   __syncthreads();
-  for (int i = threadIdx.x; i < 8 * Mp; i += blockDim.x) { const int arr = i / Mp, c = i % Mp; lds[arr * Mp + lds_cell<Q>(c)] = (ftr[i] > 0.f) ? 0.0f : -__builtin_inff(); }
+  const gp<float> g = gptr(ftr);
+  for (int i = threadIdx.x; i < 8 * Mp; i += blockDim.x) { const int arr = i / Mp, c = i % Mp; lds[arr * Mp + lds_cell<Q>(c)] = (g[i] > 0.f) ? 0.0f : -__builtin_inff(); }
   __syncthreads();
 }
 
@@ -120,18 +130,20 @@ __device__ __forceinline__ void fwd_item(const FbWork &w, const DevModel &md, fl
 #pragma unroll
     for (int q = 0; q < Q; ++q) { mx[q * 64 + lane] = 0.f; mx[Mp + q * 64 + lane] = 0.f; if (w.full == 2) mx[2 * Mp + q * 64 + lane] = 0.f; }
   }
-  // emission odds of the next row are fetched one row ahead (residue byte -> table row is a dependent pair of loads)
+  // emission odds of the next row are fetched one row ahead; the residues come 64 at a time (xlane.h: ResUp)
+  const gp<float> rf = gptr(md.rf);
+  ResUp feed; feed.init(rp, w.Ld, lane);
   float rfc[Q];
   {
-    const float *__restrict__ r0 = md.rf + (size_t)rp[0] * Mp + lane;
+    const gp<float> r0 = rf + (size_t)feed.get(0) * Mp + lane;
 #pragma unroll
     for (int q = 0; q < Q; ++q) rfc[q] = r0[q * 64];
   }
   for (int i = 1; i <= w.Ld; ++i) {
     float rfn[Q];
     {
-      const int xn = (i < w.Ld) ? rp[i] : rp[i - 1];
-      const float *__restrict__ r1 = md.rf + (size_t)xn * Mp + lane;
+      const int xn = feed.get((i < w.Ld) ? i : i - 1);
+      const gp<float> r1 = rf + (size_t)xn * Mp + lane;
 #pragma unroll
       for (int q = 0; q < Q; ++q) rfn[q] = r1[q * 64];
     }
@@ -176,8 +188,8 @@ __global__ void __launch_bounds__(64) fwd_kernel(WorkQueue queue, FbWork *__rest
                                                 float *__restrict__ ws, FwdOut *__restrict__ out,
                                                 ScaleEvent *__restrict__ events, uint32_t *__restrict__ nevents, uint32_t cap_events,
                                                 CascadeDev cd, int decide) {
+  CKM_RAISE_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int Mp = Q * 64;
   const int lane = threadIdx.x;
   uint32_t cur_model = 0xffffffffu;
  const uint32_t nqueue = queue_len(queue);
@@ -332,9 +344,11 @@ __device__ __forceinline__ void bwd_item(const FbWork &w, const DevModel &md, fl
     }
   };
   emit(L);
+  const gp<float> rf = gptr(md.rf);
+  ResDown feed; feed.init(rp, max(L, 1), lane);
   float rfc[Q];
   if (L >= 1) {
-    const float *__restrict__ r0 = md.rf + (size_t)rp[L - 1] * Mp + lane;    // residue L
+    const gp<float> r0 = rf + (size_t)feed.get(L - 1) * Mp + lane;    // residue L
 #pragma unroll
     for (int q = 0; q < Q; ++q) rfc[q] = r0[q * 64];
   }
@@ -344,8 +358,8 @@ __device__ __forceinline__ void bwd_item(const FbWork &w, const DevModel &md, fl
     load_row(rowD, i - 1);
     float rfn[Q];                                                     // residue i, needed by the next iteration
     {
-      const int xn = (i >= 1) ? rp[i - 1] : rp[0];
-      const float *__restrict__ r1 = md.rf + (size_t)xn * Mp + lane;
+      const int xn = feed.get((i >= 1) ? i - 1 : 0);
+      const gp<float> r1 = rf + (size_t)xn * Mp + lane;
 #pragma unroll
       for (int q = 0; q < Q; ++q) rfn[q] = r1[q * 64];
     }
@@ -399,8 +413,8 @@ __global__ void __launch_bounds__(64) bwd_kernel(WorkQueue queue, const FbWork *
                                                 const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
                                                 const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
                                                 float *__restrict__ ws, const FwdOut *__restrict__ fout, int32_t *__restrict__ range_err) {
+  CKM_RAISE_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int Mp = Q * 64;
   const int lane = threadIdx.x;
   uint32_t cur_model = 0xffffffffu;
  const uint32_t nqueue = queue_len(queue);
@@ -523,7 +537,7 @@ __device__ __forceinline__ void oa_item(const FbWork &w, const DevModel &md, flo
     for (int q = 0; q < Q; ++q) { me[q] *= norm; ie[q] *= norm; }
     const float xfactor = ((n2N + n2C) + n2J) * norm;
     for (int x = 0; x < 20; ++x) {
-      const float *rfx = md.rf + (size_t)x * Mp + lane;
+      const gp<float> rfx = gptr(md.rf) + (size_t)x * Mp + lane;
       float s = 0.f;
 #pragma unroll
       for (int q = 0; q < Q; ++q) { const float t = me[q] * rfx[q * 64]; s = s + t; s = s + ie[q]; }
@@ -593,8 +607,8 @@ template <int Q>
 __global__ void __launch_bounds__(64) oa_kernel(WorkQueue queue, const FbWork *__restrict__ work,
                                                const DevModel *__restrict__ models, float *__restrict__ ws,
                                                const int32_t *__restrict__ range_err, const FwdOut *__restrict__ fout, EnvOut *__restrict__ out) {
+  CKM_RAISE_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int Mp = Q * 64;
   const int lane = threadIdx.x;
   uint32_t cur_model = 0xffffffffu;
  const uint32_t nqueue = queue_len(queue);
@@ -622,6 +636,7 @@ __global__ void __launch_bounds__(64) parser_kernel(WorkQueue queue, const FbWor
                                                    const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
                                                    float *__restrict__ ws, ScaleEvent *__restrict__ events, uint32_t *__restrict__ nevents, uint32_t cap_events,
                                                    CascadeDev cd) {
+  CKM_RAISE_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ uint32_t bc[4];
   const int lane = threadIdx.x;
@@ -674,6 +689,7 @@ __global__ void __launch_bounds__(64) env_kernel(WorkQueue queue, const FbWork *
                                                 const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
                                                 float *__restrict__ ws, ScaleEvent *__restrict__ events, uint32_t *__restrict__ nevents, uint32_t cap_events,
                                                 EnvOut *__restrict__ out) {
+  CKM_RAISE_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x;
   const uint32_t nqueue = queue_len(queue);

@@ -15,6 +15,14 @@
 
 namespace ckm {
 
+// CKM_CHAIN_PRIO=1: the latency-bound kernels of a chain raise their wavefronts' issue priority over the SSV wavefronts they share a
+// SIMD with (one dependent instruction chain per wavefront: a chain that waits its turn behind 7 throughput-bound waves runs several
+// times longer than alone; the SSV waves lose exactly the issue slots the chain needs anyway).
+static __constant__ int c_chain_prio;
+void set_chain_prio_filter(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(c_chain_prio), &v, sizeof(int)); }
+#define CKM_RAISE_PRIO() do { if (c_chain_prio) __builtin_amdgcn_s_setprio(3); } while (0)
+
+
 constexpr int KP_SYMS = 29;    // rows of the byte cost table (one per alphabet symbol)
 
 constexpr double LN2D = 0.69314718055994529;
@@ -34,6 +42,7 @@ __device__ __forceinline__ float to_bits(float sc, float nullsc) {
 }
 
 __global__ void msv_finish_kernel(FinishArgs a, uint32_t nblocks_work) {
+  CKM_RAISE_PRIO();
   const uint32_t wb = blockIdx.x;
   if (wb >= nblocks_work) return;
   const SsvBlockWork w = a.work[wb];
@@ -89,6 +98,7 @@ __global__ void __launch_bounds__(64) msv_full_kernel(WorkQueue queue, const Pai
                                                      const uint64_t *__restrict__ seq_off, const int32_t *__restrict__ seq_len,
                                                      int32_t *__restrict__ out_xJ /* -1 overflow */, float *__restrict__ out_usc, int maxMp,
                                                      CascadeDev cd, int decide) {
+  CKM_RAISE_PRIO();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
  const uint32_t nqueue = queue_len(queue);
@@ -100,7 +110,7 @@ __global__ void __launch_bounds__(64) msv_full_kernel(WorkQueue queue, const Pai
   uint8_t *tab = reinterpret_cast<uint8_t *>(smem);
   int16_t *row = reinterpret_cast<int16_t *>(smem + (((size_t)KP_SYMS * (maxMp + 1) + 15) & ~(size_t)15));
   {
-    const uint32_t *__restrict__ src = reinterpret_cast<const uint32_t *>(md.rbv);     // table start is 256-byte aligned
+    const gp<uint32_t> src = gptr(reinterpret_cast<const uint32_t *>(md.rbv));     // table start is 256-byte aligned
     uint32_t *dst = reinterpret_cast<uint32_t *>(tab);
     const int nw32 = (KP_SYMS * W + 3) >> 2;
     for (int j = lane; j < nw32; j += 64) dst[j] = src[j];
@@ -111,7 +121,9 @@ __global__ void __launch_bounds__(64) msv_full_kernel(WorkQueue queue, const Pai
   int16_t *dp = row, *nw = row + maxMp;
   for (int k = lane; k < M; k += 64) dp[k] = 0;
   __syncthreads();
-  int xJ = 0, xB = max(md.base_b - tjbm, 0);
+  // (copies: after a barrier the compiler has to assume the struct in global memory changed, and would fetch these again in every row)
+  const int bias_b = md.bias_b, tec_b = md.tec_b, base_b = md.base_b;
+  int xJ = 0, xB = max(base_b - tjbm, 0);
   bool overflow = false;
   int chunk = (lane < L) ? (int)rp[lane] : 0;
   for (int i0 = 0; i0 < L && !overflow; i0 += 64) {
@@ -125,16 +137,16 @@ __global__ void __launch_bounds__(64) msv_full_kernel(WorkQueue queue, const Pai
       for (int k = lane; k < M; k += 64) {
         const int mp = (k > 0) ? (int)dp[k - 1] : 0;
         int sv = max(mp, xB);
-        sv = min(sv + md.bias_b, 255);
+        sv = min(sv + bias_b, 255);
         sv = max(sv - (int)cost[k], 0);
         xE = max(xE, sv);
         nw[k] = (int16_t)sv;
       }
       xE = wave_max(xE);
-      if (min(xE + md.bias_b, 255) == 255) { overflow = true; break; }
-      xE = max(xE - md.tec_b, 0);
+      if (min(xE + bias_b, 255) == 255) { overflow = true; break; }
+      xE = max(xE - tec_b, 0);
       xJ = max(xJ, xE);
-      xB = max(max(md.base_b, xJ) - tjbm, 0);
+      xB = max(max(base_b, xJ) - tjbm, 0);
       int16_t *t = dp; dp = nw; nw = t;
       __syncthreads();
     }
@@ -190,35 +202,45 @@ __global__ void bias_kernel(const PairRec *__restrict__ pairs, uint32_t npairs, 
 //   otherwise (within the margin of F2)           the exact Viterbi kernel runs and the pair goes on whatever it says: the host decides
 __global__ void __launch_bounds__(128) bias_filter_kernel(CascadeDev cd, const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
                                                          const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off) {
+  CKM_RAISE_PRIO();
+  // the emission odds of the pair's model sit in the thread's own LDS row (stride 31 words: lanes asking for the same symbol hit 32
+  // different banks) and the four transition odds in registers: nothing on the residue-to-residue chain touches global memory
+  __shared__ float beo_s[128 * 31];
+  float *be = beo_s + threadIdx.x * 31;
   const uint32_t n = min(cd.cnt[CC_CAND], cd.cap_cand);
   for (uint32_t pi = blockIdx.x * blockDim.x + threadIdx.x; pi < n; pi += gridDim.x * blockDim.x) {
     PairRec pr = cd.cand[pi];
     const DevModel &md = models[pr.model];
     const int L = cd.seq_len[pr.seq];
     const uint8_t *rp = res + seq_off[pr.seq];
-    float d0 = md.bpi0, d1 = md.beo1[rp[0]] * md.bpi1;
-    int nexp = 0;
-    // residues 16 at a time (sequences are 16-byte aligned and padded): the row-to-row chain then waits for arithmetic, not for loads
-    const uint4 *rp4 = reinterpret_cast<const uint4 *>(rp);
-    uint4 cur = rp4[0];
-    for (int c0 = 0; c0 < L; c0 += 16) {
-      const uint4 nxt = (c0 + 16 < L) ? rp4[(c0 >> 4) + 1] : cur;
-      const uint32_t wd[4] = {cur.x, cur.y, cur.z, cur.w};
-      const int lim = min(16, L - c0);
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int i = c0 + k;
-        if (k < lim && i >= 1) {
-          const float n0 = d0 * md.bt00 + d1 * md.bt10;
-          const float n1 = (d0 * md.bt01 + d1 * md.bt11) * md.beo1[(wd[k >> 2] >> (8 * (k & 3))) & 0xffu];
-          d0 = n0; d1 = n1;
-          const float mx = fmaxf(d0, d1);
-          if (mx < 0x1p-40f) { d0 *= 0x1p64f; d1 *= 0x1p64f; nexp -= 64; }
-          else if (mx > 0x1p40f) { d0 *= 0x1p-64f; d1 *= 0x1p-64f; nexp += 64; }
-        }
-      }
-      cur = nxt;
+    for (int x = 0; x < 30; ++x) be[x] = md.beo1[x];
+    const float t00 = md.bt00, t01 = md.bt01, t10 = md.bt10, t11 = md.bt11;
+    // residues 16 at a time (sequences are 16-byte aligned and padded)
+    const uint4 *rp4 = reinterpret_cast<const uint4 *>(rp);
+    uint32_t w0, w1, w2, w3;
+    { const uint4 c = rp4[0]; w0 = c.x; w1 = c.y; w2 = c.z; w3 = c.w; }
+    float d0 = md.bpi0, d1 = be[w0 & 0xffu] * md.bpi1;
+    int nexp = 0;
+#define BIAS_STEP(x)                                                                  \
+    {                                                                                 \
+      const float n0 = d0 * t00 + d1 * t10;                                           \
+      const float n1 = (d0 * t01 + d1 * t11) * be[(x)];                               \
+      d0 = n0; d1 = n1;                                                               \
+      const float mx = fmaxf(d0, d1);                                                 \
+      if (mx < 0x1p-40f) { d0 *= 0x1p64f; d1 *= 0x1p64f; nexp -= 64; }                \
+      else if (mx > 0x1p40f) { d0 *= 0x1p-64f; d1 *= 0x1p-64f; nexp += 64; }          \
     }
+#define BIAS_WORD(wv, i0)                                                             \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b) { const int i = (i0) + b; if (i >= 1 && i < L) BIAS_STEP(((wv) >> (8 * b)) & 0xffu) }
+    for (int c0 = 0; c0 < L; c0 += 16) {
+      uint32_t n0w = w0, n1w = w1, n2w = w2, n3w = w3;
+      if (c0 + 16 < L) { const uint4 c = rp4[(c0 >> 4) + 1]; n0w = c.x; n1w = c.y; n2w = c.z; n3w = c.w; }
+      BIAS_WORD(w0, c0) BIAS_WORD(w1, c0 + 4) BIAS_WORD(w2, c0 + 8) BIAS_WORD(w3, c0 + 12)
+      w0 = n0w; w1 = n1w; w2 = n2w; w3 = n3w;
+    }
+#undef BIAS_WORD
+#undef BIAS_STEP
     const float dsum = d0 + d1;
     cd.bias_raw[2 * (size_t)pi] = dsum; cd.bias_raw[2 * (size_t)pi + 1] = (float)nexp;
     const float filtersc = (approx_ln(dsum) + (float)nexp * LN2_F) + lentab[L].bias_tail;
@@ -271,6 +293,7 @@ __global__ void __launch_bounds__(256) vit_kernel(WorkQueue queue, const PairRec
                                                   const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
                                                   const int32_t *__restrict__ seq_len, int32_t *__restrict__ out_xC, float *__restrict__ out_sc,
                                                   uint32_t *__restrict__ out_flag, CascadeDev cd, int decide) {
+  CKM_RAISE_PRIO();
   const int lane = threadIdx.x & 63;
  const uint32_t nqueue = queue_len(queue);
  for (uint32_t qk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); qk < nqueue; qk += gridDim.x * (blockDim.x >> 6)) {
@@ -284,7 +307,7 @@ __global__ void __launch_bounds__(256) vit_kernel(WorkQueue queue, const PairRec
   u32 tBM[QH], tMM[QH], tIM[QH], tDM[QH], tMD[QH], tMI[QH], tII[QH], tDD[QH];
 #pragma unroll
   for (int j = 0; j < QH; ++j) {
-    const u32 *t = md.vit_t + j * 64 + lane;
+    const gp<u32> t = gptr(md.vit_t) + j * 64 + lane;
     tBM[j] = t[0 * ROW]; tMM[j] = t[1 * ROW]; tIM[j] = t[2 * ROW]; tDM[j] = t[3 * ROW];
     tMD[j] = t[4 * ROW]; tMI[j] = t[5 * ROW]; tII[j] = t[6 * ROW]; tDD[j] = t[7 * ROW];
   }
@@ -294,22 +317,24 @@ __global__ void __launch_bounds__(256) vit_kernel(WorkQueue queue, const PairRec
   int xN = md.base_w, xB = xN + le.w_move, xJ = NEG16, xC = NEG16;
   bool overflow = false;
   u32 xEv = NEG2;
-  // emission words one row ahead, residue byte two rows ahead (dependent loads)
+  // emission words one row ahead; the residues come 64 at a time in one register (xlane.h: ResUp), so the address of a row's words
+  // is an SGPR and no load of the row loop depends on another
+  const gp<u32> vit_e = gptr(md.vit_e);
+  ResUp feed; feed.init(rp, L, lane);
   u32 e[QH];
   {
-    const u32 *__restrict__ er = md.vit_e + (size_t)rp[0] * ROW + lane;
+    const gp<u32> er = vit_e + (size_t)feed.get(0) * ROW + lane;
 #pragma unroll
     for (int j = 0; j < QH; ++j) e[j] = er[j * 64];
   }
-  int xn = (L > 1) ? rp[1] : rp[0];
   for (int i = 0; i < L; ++i) {
     u32 en[QH];
     {
-      const u32 *__restrict__ er = md.vit_e + (size_t)xn * ROW + lane;
+      const int xn = feed.get((i + 1 < L) ? i + 1 : L - 1);
+      const gp<u32> er = vit_e + (size_t)xn * ROW + lane;
 #pragma unroll
       for (int j = 0; j < QH; ++j) en[j] = er[j * 64];
     }
-    xn = (i + 2 < L) ? rp[i + 2] : rp[L - 1];
     const u32 ms0 = stripe_shift(Mv[QH - 1]), is0 = stripe_shift(Iv[QH - 1]), ds0 = stripe_shift(Dv[QH - 1]);
     const u32 xBv = ((u32)(xB & 0xffff)) * 0x10001u;        // FAST: loop-invariant
     u32 mdv[QH];

@@ -14,6 +14,41 @@ namespace ckm {
 constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
 constexpr int DPP_ROW_SHL = 0x100, DPP_ROW_SHR = 0x110, DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138;
 
+// A table pointer that was read from a struct in memory (DevModel::rf, ::vit_e, ...) is a generic pointer to the compiler, and a load
+// through it is a FLAT load: it counts against lgkmcnt as well as vmcnt, so every wait for an LDS read also waits for the emission row
+// requested a moment ago -- the whole global latency lands on the row-to-row chain.  gptr() types the pointer as global, and loads
+// through the result (keep it in an `auto` / gp<T> variable) are global_load (vmcnt only).
+template <class T> using gp = const __attribute__((address_space(1))) T *;
+template <class T>
+__device__ __forceinline__ gp<T> gptr(const T *p) { return (gp<T>)p; }
+
+// The residues of a segment, 64 at a time in ONE register of the wavefront (lane l holds residue base + l) and handed out through
+// v_readlane: the row loop of a latency-bound kernel then has no load whose address depends on another load of the same row (residue
+// byte -> table row), and the table row's address is an SGPR.  ResUp serves ascending positions, ResDown descending ones; a position
+// may be asked for repeatedly but never further back (forward) than the current chunk.
+struct ResUp {
+  const uint8_t *rp; int n, base, lane, cur, nxt;
+  __device__ __forceinline__ void init(const uint8_t *p, int n_, int lane_) {
+    rp = p; n = n_; lane = lane_; base = 0;
+    cur = p[min(lane, n - 1)]; nxt = p[min(64 + lane, n - 1)];
+  }
+  __device__ __forceinline__ int get(int r) {
+    if (r >= base + 64) { base += 64; cur = nxt; nxt = rp[min(base + 64 + lane, n - 1)]; }
+    return __builtin_amdgcn_readlane(cur, r - base);
+  }
+};
+struct ResDown {
+  const uint8_t *rp; int n, base, lane, cur, prv;
+  __device__ __forceinline__ void init(const uint8_t *p, int n_, int lane_) {
+    rp = p; n = n_; lane = lane_; base = ((n - 1) >> 6) << 6;
+    cur = p[min(base + lane, n - 1)]; prv = p[max(base - 64, 0) + lane];        // (a first chunk is always 64 readable bytes: sequences are padded)
+  }
+  __device__ __forceinline__ int get(int r) {
+    if (r < base) { base -= 64; cur = prv; prv = rp[max(base - 64, 0) + lane]; }
+    return __builtin_amdgcn_readlane(cur, r - base);
+  }
+};
+
 // lane <- dpp-selected lane of src; lanes whose source is out of range keep `old`
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float old, float src) {
