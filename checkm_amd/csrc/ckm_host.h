@@ -56,7 +56,7 @@ int launch_parser(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, 
 int launch_env(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const FbWork *work, const DevModel *models,
                const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws,
                ScaleEvent *events, uint32_t *nevents, uint32_t cap_events, EnvOut *out);
-void launch_ensemble(hipStream_t stream, const EnsWork *work, const uint32_t *count, uint32_t cap, uint32_t grid_regions, int max_Mp,
+void launch_ensemble(hipStream_t stream, const EnsWork *work, const uint32_t *list /* indices into work, or null */, const uint32_t *count, uint32_t cap, uint32_t grid_regions, int max_Mp,
                      const DevModel *models, const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, const uint32_t *seeds,
                      float *host_res /* pinned buffer the results are exported to, or null */);
 void launch_bias_filter(hipStream_t stream, uint32_t nblocks, const CascadeDev &cd, const DevModel *models, const LenEntry *lentab,

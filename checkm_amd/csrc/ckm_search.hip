@@ -710,6 +710,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   //  host-driven cascade: 1 SSV + finish, 2 exact MSV, 3 bias filter, 4 Viterbi fast, 5 Viterbi exact, 6 Forward parser, 7 Backward
   //  parser, 8 regions, 9-11 envelope Forward / Backward / OA, 12 region Forward, 13 ensembles)
   const int stop = getenv("CKM_CHAIN_STOP") ? atoi(getenv("CKM_CHAIN_STOP")) : 99;
+  static const bool ens_per_group = !(getenv("CKM_ENS_JOINED") && atoi(getenv("CKM_ENS_JOINED")) != 0);     // CKM_ENS_JOINED=1: one set of ensemble launches after all chains (as before)
   static const uint32_t GRID_FB = getenv("CKM_GRID_FB") ? (uint32_t)atoi(getenv("CKM_GRID_FB")) : 4096, GRID_VIT = getenv("CKM_GRID_VIT") ? (uint32_t)atoi(getenv("CKM_GRID_VIT")) : 2048,
                         GRID_MSV = getenv("CKM_GRID_MSV") ? (uint32_t)atoi(getenv("CKM_GRID_MSV")) : 1024;
   HIPCHK(hipMemsetAsync(d_gcnt, 0, (NG + 1) * CC_SIZE * sizeof(uint32_t), ms));
@@ -784,6 +785,9 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
           if (stop >= 11) rc |= launch_oa(Q, GRID_FB, sc, qe, cd.ework, dm, ws, d_rerr_e, d_fout_e, d_envout);
         }
         if (stop >= 12) rc |= launch_fwd(Q, std::max(64u, GRID_FB / 8), sc, qr, cd.rwork, dm, lt, res, off, ws, d_fout_r, d_events_r, d_gcnt + CC_EVENTS_R, 1 << 16, nullptr);
+        // trace ensembles of the multi-domain regions of this group and register class, straight behind their Forward matrices on the
+        // group's chain stream (results exported for the host's clustering): only the last groups' ensembles are left after the SSV phase
+        if (stop >= 13 && ens_per_group) launch_ensemble(sc, cd0.ens, qr.list, qr.count, sb.cap_r, 16, Q * NL, dm, lt, res, off, ws, ctx->ensseeds.as<uint32_t>(), d_hens);
       }
       if (rc) throw Error(CKM_ERANGE, "no kernel instance for this model length");
     }
@@ -799,7 +803,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   }
   for (int k = NSS; k < NS; ++k) { HIPCHK(hipEventRecord(ctx->cls_ev[k], ctx->side[k])); HIPCHK(hipStreamWaitEvent(ms, ctx->cls_ev[k], 0)); }
   // ---- trace ensembles of the multi-domain regions of all groups, results exported to pinned memory; counters last ----
-  if (stop >= 13) launch_ensemble(ms, cd0.ens, d_gcnt + CC_RWORK, cp.rwork, 128, p->maxMp, dm, lt, res, off, ws, ctx->ensseeds.as<uint32_t>(), d_hens);
+  if (stop >= 13 && !ens_per_group) launch_ensemble(ms, cd0.ens, nullptr, d_gcnt + CC_RWORK, cp.rwork, 128, p->maxMp, dm, lt, res, off, ws, ctx->ensseeds.as<uint32_t>(), d_hens);
   HIPCHK(hipMemcpyAsync(h_cnt, d_gcnt, (NG + 1) * CC_SIZE * sizeof(uint32_t), hipMemcpyDeviceToHost, ms));
   unsigned long long *h_tops = pin_table<unsigned long long>(ctx->h_tops, 4);
   HIPCHK(hipMemcpyAsync(h_tops, d_tops, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ms));

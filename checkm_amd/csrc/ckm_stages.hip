@@ -356,7 +356,7 @@ void ens_queue_batch(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, EnsJ
     ctx->enscount.ensure(16);
     HIPCHK(hipMemcpyAsync(ctx->enscount.p, &nreg, 4, hipMemcpyHostToDevice, ctx->ens_stream));
     (void)maxLd;
-    launch_ensemble(ctx->ens_stream, ctx->enswork.as<EnsWork>(), ctx->enscount.as<uint32_t>(), nreg, std::min<uint32_t>(nreg, 256), maxMp, p->d_models.as<DevModel>(),
+    launch_ensemble(ctx->ens_stream, ctx->enswork.as<EnsWork>(), nullptr, ctx->enscount.as<uint32_t>(), nreg, std::min<uint32_t>(nreg, 256), maxMp, p->d_models.as<DevModel>(),
                     s->d_lentab.as<LenEntry>(), s->d_res.as<uint8_t>(), s->d_off.as<uint64_t>(), ctx->ws_ens.as<float>(), ctx->ensseeds.as<uint32_t>(), nullptr);
   }
   HIPCHK(hipGetLastError());

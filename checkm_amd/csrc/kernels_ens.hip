@@ -57,7 +57,7 @@ __device__ __forceinline__ int ens_select_e(const float *__restrict__ cr, int Q,
   return ((zf * Q + (f >> 1)) << 1) | (f & 1);          // (cell << 1) | is_delete
 }
 
-__global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restrict__ work, const DevModel *__restrict__ models,
+__global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restrict__ work, const uint32_t *__restrict__ list, const DevModel *__restrict__ models,
                                                        const LenEntry *__restrict__ lentab, float *__restrict__ ws,
                                                        const uint32_t *__restrict__ seeds, const uint32_t *__restrict__ count, uint32_t cap, int sequential) {
  // sequential != 0 (CKM_ENS_STREAM=sequential): HMMER's own use of its generator -- ONE stream per region, re-seeded for the region and
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restric
  __shared__ uint32_t stream_rng;
  const uint32_t nregions = min(*count, cap);
  for (uint32_t region = blockIdx.x; region < nregions; region += gridDim.x) {
-  const EnsWork w = work[region];
+  const EnsWork w = work[list ? list[region] : region];
   const int t = threadIdx.x, lane = threadIdx.x & 63;
   const DevModel &md = models[w.model];
   const int Q = md.fbQ, Mp = Q * 64, Ld = w.Ld;
@@ -169,14 +169,14 @@ __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restric
 }
 
 // grid (ENS_N, nregions), 64 threads; dynamic LDS: 2*Mp counters/floats + 32 floats
-__global__ void __launch_bounds__(64) ens_null2_kernel(const EnsWork *__restrict__ work, const DevModel *__restrict__ models,
+__global__ void __launch_bounds__(64) ens_null2_kernel(const EnsWork *__restrict__ work, const uint32_t *__restrict__ list, const DevModel *__restrict__ models,
                                                       const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
                                                       float *__restrict__ ws, const uint32_t *__restrict__ count, uint32_t cap) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
  const uint32_t nregions = min(*count, cap);
  for (uint32_t region = blockIdx.y; region < nregions; region += gridDim.y) {
   __syncthreads();
-  const EnsWork w = work[region];
+  const EnsWork w = work[list ? list[region] : region];
   const int t = blockIdx.x, lane = threadIdx.x;
   const DevModel &md = models[w.model];
   const int Q = md.fbQ, Mp = Q * 64, Ld = w.Ld;
@@ -228,10 +228,10 @@ __global__ void __launch_bounds__(64) ens_null2_kernel(const EnsWork *__restrict
 
 // grid (x, regions): one thread per region position (strided), sum over the traces in trace order; then the region's results
 // (200 counts, the segment table, the sums: contiguous in the workspace) are copied to `host_res` when the region has a place there
-__global__ void __launch_bounds__(256) ens_sum_kernel(const EnsWork *__restrict__ work, float *__restrict__ ws, const uint32_t *__restrict__ count, uint32_t cap) {
+__global__ void __launch_bounds__(256) ens_sum_kernel(const EnsWork *__restrict__ work, const uint32_t *__restrict__ list, float *__restrict__ ws, const uint32_t *__restrict__ count, uint32_t cap) {
   const uint32_t nregions = min(*count, cap);
   for (uint32_t region = blockIdx.y; region < nregions; region += gridDim.y) {
-    const EnsWork w = work[region];
+    const EnsWork w = work[list ? list[region] : region];
     for (int pos = 1 + blockIdx.x * 256 + threadIdx.x; pos <= w.Ld; pos += gridDim.x * 256) {
       const float *__restrict__ rt = ws + w.ratio_off + pos;
       float acc = 0.0f;
@@ -241,11 +241,11 @@ __global__ void __launch_bounds__(256) ens_sum_kernel(const EnsWork *__restrict_
   }
 }
 
-__global__ void __launch_bounds__(256) ens_export_kernel(const EnsWork *__restrict__ work, const float *__restrict__ ws, float *__restrict__ host_res,
+__global__ void __launch_bounds__(256) ens_export_kernel(const EnsWork *__restrict__ work, const uint32_t *__restrict__ list, const float *__restrict__ ws, float *__restrict__ host_res,
                                                         const uint32_t *__restrict__ count, uint32_t cap) {
   const uint32_t nregions = min(*count, cap);
   for (uint32_t region = blockIdx.y; region < nregions; region += gridDim.y) {
-    const EnsWork w = work[region];
+    const EnsWork w = work[list ? list[region] : region];
     if (w.host_off == ~0ull) continue;
     const size_t n = (size_t)(w.n2_off - w.nseg_off) + (size_t)w.Ld;
     const float *__restrict__ src = ws + w.nseg_off;
@@ -254,16 +254,17 @@ __global__ void __launch_bounds__(256) ens_export_kernel(const EnsWork *__restri
   }
 }
 
-// `count` (device memory) regions of `work`, at most cap; grid_regions workgroups share them
-void launch_ensemble(hipStream_t stream, const EnsWork *work, const uint32_t *count, uint32_t cap, uint32_t grid_regions, int max_Mp,
+// `count` (device memory) regions, at most cap: entries list[0..count) of `work`, or -- without a list -- work[0..count);
+// grid_regions workgroups share them
+void launch_ensemble(hipStream_t stream, const EnsWork *work, const uint32_t *list, const uint32_t *count, uint32_t cap, uint32_t grid_regions, int max_Mp,
                      const DevModel *models, const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, const uint32_t *seeds,
                      float *host_res) {
   if (!grid_regions) return;
   static const int sequential = [] { const char *e = getenv("CKM_ENS_STREAM"); return (e && !strcmp(e, "sequential")) ? 1 : 0; }();
-  hipLaunchKernelGGL(ens_trace_kernel, dim3(grid_regions), dim3(256), 0, stream, work, models, lentab, ws, seeds, count, cap, sequential);
-  hipLaunchKernelGGL(ens_null2_kernel, dim3(ENS_N, grid_regions), dim3(64), (size_t)(2 * max_Mp + 32) * 4, stream, work, models, res, seq_off, ws, count, cap);
-  hipLaunchKernelGGL(ens_sum_kernel, dim3(4, grid_regions), dim3(256), 0, stream, work, ws, count, cap);
-  if (host_res) hipLaunchKernelGGL(ens_export_kernel, dim3(4, grid_regions), dim3(256), 0, stream, work, ws, host_res, count, cap);
+  hipLaunchKernelGGL(ens_trace_kernel, dim3(grid_regions), dim3(256), 0, stream, work, list, models, lentab, ws, seeds, count, cap, sequential);
+  hipLaunchKernelGGL(ens_null2_kernel, dim3(ENS_N, grid_regions), dim3(64), (size_t)(2 * max_Mp + 32) * 4, stream, work, list, models, res, seq_off, ws, count, cap);
+  hipLaunchKernelGGL(ens_sum_kernel, dim3(4, grid_regions), dim3(256), 0, stream, work, list, ws, count, cap);
+  if (host_res) hipLaunchKernelGGL(ens_export_kernel, dim3(4, grid_regions), dim3(256), 0, stream, work, list, ws, host_res, count, cap);
 }
 
 }  // namespace ckm
