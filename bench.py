@@ -420,9 +420,13 @@ def main():
     lineage = None
     if args.lineage_bins > 0:
         try:
-            w, binIds, files, lin = lineage_setup(workdir, args.lineage_bins, rank, world, sync)
-            lineage_pass(w, binIds[:2 * world], files[:2 * world], lin, os.path.join(workdir, "lw_warm"), rank)      # contexts, profile DBs, plans
+            # twice the bins: the first half is an untimed pass of the same shape (contexts, profile DBs, and the workspace the library
+            # sizes from what the previous search needed -- growing it is a multi-GB hipMalloc, seconds the first time), the second half is timed
+            nl = args.lineage_bins
+            w, binIds, files, lin = lineage_setup(workdir, 2 * nl, rank, world, sync)
+            warm_parts, _ = lineage_pass(w, binIds[:nl], files[:nl], lin, os.path.join(workdir, "lw_warm"), rank)
             sync()
+            binIds, files = binIds[nl:], files[nl:]
             parts, tot = lineage_pass(w, binIds, files, lin, os.path.join(workdir, "lw_out"), rank)
             sync()
             wall = all_max(parts["total_s"])
@@ -431,7 +435,10 @@ def main():
                                    "-> printSummary" % args.lineage_bins,
                        "bins": args.lineage_bins, "seconds": wall, "bins_per_hour": args.lineage_bins / wall * 3600.0, "parts_s_rank0": parts,
                        "residue_hmm": all_sum(tot.get("residue_hmm", 0)), "residue_hmm_per_s": all_sum(tot.get("residue_hmm", 0)) / wall,
-                       "note": "includes FASTA ingest, both scans, domtblout files, reduction and the QA table; the full 1000-bin run is `bench.py --config cfg3`"}
+                       "first_pass_s": warm_parts["total_s"],
+                       "note": "includes FASTA ingest, both scans, domtblout files, reduction and the QA table; timed on the second of two passes over different "
+                               "bins of the same shape (first_pass_s = the first one, with context creation, profile upload and workspace allocation); "
+                               "the full 1000-bin run is `bench.py --config cfg3`"}
         except SystemExit as e:            # the product's error path is logger.error + sys.exit
             lineage = {"error": "lineage_wf-equivalent run failed: exit %s" % (e.code,)}
     if rank == 0:

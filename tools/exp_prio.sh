@@ -1,17 +1,8 @@
 set -u
-OUT=gpurun_out/r3b; mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_cascade.py tests/test_gpu_scan.py tests/test_gpu_fullsize.py -x -q 2>&1 | tail -2
-export CKM_BENCH_STEADY=0 CKM_BENCH_FROM_HOST=0
-B="python bench.py --steps 6 --warmup 2 --no-cpu-baseline --lineage-bins 0"
-run() { name=$1; shift; env "$@" timeout 200 $B > $OUT/$name.json 2> $OUT/$name.err; python - <<PY
-import json
-try:
-    d=json.load(open("$OUT/$name.json")); s=d["stages_ms"]; print("$name", round(d["ms_per_step"],2), "ssv %.1f filters %.1f dom %.1f host %.1f" % (s["ssv"], s["filters"], s["domains"], s["host"]), d["rows"])
-except Exception as e: print("$name failed", e)
-PY
-}
-run joined CKM_ENS_JOINED=1
-run pergroup A=1
-run joined2 CKM_ENS_JOINED=1
-run pergroup2 A=1
+mkdir -p gpurun_out/r02c
+timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+timeout 400 python bench.py --steps 5 --warmup 2 > gpurun_out/r02c/bench_default.json 2> gpurun_out/r02c/bench_default.err
+python -c "
+import json; d=json.loads(open('gpurun_out/r02c/bench_default.json').read().strip().split('\n')[-1]); print(d['ms_per_step'], d['value'], d['steady_state']['ms_per_step'], d['lineage_wf_equiv'].get('bins_per_hour'), d['lineage_wf_equiv'].get('parts_s_rank0'), d['lineage_wf_equiv'].get('first_pass_s'))"
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
