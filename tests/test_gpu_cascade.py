@@ -52,6 +52,9 @@ def test_device_cascade_equals_host_cascade():
     host = _run(CKM_CASCADE="host", CKM_WORKERS="1")
     assert len(host["rows"]) > 100 and host["pairs"][6] >= 2           # multi-domain regions are present
     for extra in (dict(CKM_WORKERS="1"), dict(CKM_WORKERS="1", CKM_SPLIT_MIN_PAIRS="1"), dict(CKM_WORKERS="1", CKM_FUSED="1", CKM_SPLIT_MIN_PAIRS="1"),
+                  dict(CKM_WORKERS="1", CKM_SPLIT_MIN_PAIRS="1", CKM_LONG_SHARE="0.2,0.4"),          # three parts by sequence length
+                  dict(CKM_WORKERS="1", CKM_SPLIT_MIN_PAIRS="1", CKM_ENS_JOINED="1", CKM_FUSED_TAIL="3", CKM_CHAIN_PRIO="1"),   # one ensemble set after the join; knobs
+
                   dict(CKM_WORKERS="3", CKM_WORKER_MIN_PAIRS="1"), dict(CKM_WORKERS="2", CKM_WORKER_MIN_PAIRS="1", CKM_PAIR_BUDGET="9000")):
         dev = _run(**extra)
         if "CKM_PAIR_BUDGET" in extra:
