@@ -29,7 +29,8 @@ __device__ __forceinline__ void emit_region(const CascadeDev &cd, const DevModel
     const unsigned long long xs = pos; pos = al32(pos + (Ld + 1) * 6);
     const unsigned long long aux = pos; pos = al32(al32(pos + (Ld + 1) * 3) + (Ld + 1) * 5);
     const unsigned long long mf = pos; pos = al32(pos + (Ld + 1) * 3 * Mp);
-    const unsigned long long mb = pos; pos = al32(pos + (Ld + 1) * 2 * Mp);
+    unsigned long long mb = mf;                                                    // posterior rows in place over the Forward rows ...
+    if (!cd.env_inplace) { mb = pos; pos = al32(pos + (Ld + 1) * 2 * Mp); }           // ... or in a matrix of their own
     if (!ws2_alloc(cd, pos, off)) rec.target = REGION_DEFERRED;
     else {
       const uint32_t e = atomicAdd(&cd.gcnt[CC_EWORK], 1u);

@@ -288,6 +288,8 @@ void fill_null2(float *null2);
 uint32_t fb_grid(size_t n);
 uint32_t ens_seed(int t);
 void cluster_ensemble(RegionRes &r);
+constexpr bool kEnvInplaceDefault = true;
+bool env_inplace();
 void ensure_ens_seeds(Worker *ctx);
 
 // what the domain stage hands to the row assembly (both cascades fill it)

@@ -686,6 +686,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   cd0.hens_top = d_tops + 1; cd0.hens_cap = cp.hens;
   cd0.seq_len = dlen;
   cd0.margin_msv = 0.01f; cd0.margin_vit = 0.01f; cd0.margin_fwd = 0.05f;
+  cd0.env_inplace = env_inplace() ? 1u : 0u;
   FwdOut *d_fout_f = dev_table<FwdOut>(ctx->c_fout_f, cp.fwork), *d_fout_e = dev_table<FwdOut>(ctx->c_fout_e, cp.ework), *d_fout_r = dev_table<FwdOut>(ctx->c_fout_r, cp.rwork);
   int32_t *d_rerr_e = dev_table<int32_t>(ctx->c_rerr_e, cp.ework);
   ScaleEvent *d_events_r = dev_table<ScaleEvent>(ctx->c_events_r, 1 << 16);

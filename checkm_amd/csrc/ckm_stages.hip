@@ -129,13 +129,17 @@ void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, b
   }
 }
 
+// CKM_ENV_INPLACE=1/0: posterior rows in place over the Forward rows (3 arrays per row) / in a matrix of their own (5 arrays per row)
+bool env_inplace() { static const bool on = [] { const char *e = getenv("CKM_ENV_INPLACE"); return e ? atoi(e) != 0 : kEnvInplaceDefault; }(); return on; }
+
 size_t env_floats(int Mp, int Ld, uint64_t &xs, uint64_t &aux, uint64_t &mf, uint64_t &mb, uint64_t base) {
   auto al = [](uint64_t v) { return (v + 31) & ~(uint64_t)31; };
   uint64_t pos = al(base);
   xs = pos; pos = al(pos + (uint64_t)(Ld + 1) * 6);
   aux = pos; pos = al(al(pos + (uint64_t)(Ld + 1) * 3) + (uint64_t)(Ld + 1) * 5);
   mf = pos; pos = al(pos + (uint64_t)(Ld + 1) * 3 * Mp);
-  mb = pos; pos = al(pos + (uint64_t)(Ld + 1) * 2 * Mp);     // posterior rows: M and I only
+  if (env_inplace()) mb = mf;                                 // posterior rows (M and I) overwrite the Forward rows they come from, OA rows overwrite them in turn
+  else { mb = pos; pos = al(pos + (uint64_t)(Ld + 1) * 2 * Mp); }
   return pos;
 }
 

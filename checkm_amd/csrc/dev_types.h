@@ -151,6 +151,7 @@ struct CascadeDev {                   // by-value kernel argument: where the epi
   unsigned long long *hens_top; unsigned long long hens_cap;            // bump allocator over the pinned buffer the ensemble results are exported to (floats)
   const int32_t *seq_len;
   float margin_msv, margin_vit, margin_fwd;                             // bits: widths of the conservative bands around F1/F2/F3
+  uint32_t env_inplace;                                                 // envelope posterior rows overwrite the Forward rows (3 arrays per row instead of 5)
 };
 
 struct EnvOut {

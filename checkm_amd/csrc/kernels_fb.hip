@@ -259,6 +259,9 @@ __device__ __forceinline__ void bwd_item(const FbWork &w, const DevModel &md, fl
   float *aux = ws + w.aux_off;
   const float *fm = w.full ? ws + w.mxf_off : nullptr;
   float *bm = w.full ? ws + w.mxb_off : nullptr;
+  // posterior rows either have a matrix of their own (2 arrays per row) or overwrite the Forward rows they were computed from (same
+  // offset: the Forward matrix's 3 arrays per row; row r's Forward values are in registers before its posterior is stored)
+  const size_t pst = (w.mxb_off == w.mxf_off) ? (size_t)3 * Mp : (size_t)2 * Mp;
   const int L = w.Ld;
   const float invZ = 1.0f / (fwd_xC * move);
   // boundary transition odds of the right-hand neighbour cell (c+1)
@@ -310,7 +313,7 @@ __device__ __forceinline__ void bwd_item(const FbWork &w, const DevModel &md, fl
     // decoding terms that become available once backward row r is final
     if (w.full) {
       if (r >= 1) {
-        float *__restrict__ b = bm + (size_t)r * 2 * Mp + lane;     // posterior rows hold M and I only
+        float *__restrict__ b = bm + (size_t)r * pst + lane;        // posterior rows hold M and I only
         float pmv[Q], piv[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
@@ -443,6 +446,7 @@ __device__ __forceinline__ void oa_item(const FbWork &w, const DevModel &md, flo
   Tr<Q> tr{lds, lane};
   const int M = md.M, L = w.Ld, c0 = lane * Q;
   float *pp = ws + w.mxb_off;       // posterior rows (M, I; D = 0)
+  const size_t pst = (w.mxb_off == w.mxf_off) ? (size_t)3 * Mp : (size_t)2 * Mp;     // in place: the OA rows below overwrite them row by row, each after it was read
   float *oa = ws + w.mxf_off;       // OA rows overwrite the forward matrix
   const float *aux = ws + w.aux_off;                                   // [ppN ppJ ppC] per row (written by bwd_kernel)
   float *oax = ws + w.aux_off + (((size_t)(w.Ld + 1) * 3 + 31) & ~(size_t)31);   // [oN oB oE oJ oC] per row, own cache lines
@@ -464,7 +468,7 @@ __device__ __forceinline__ void oa_item(const FbWork &w, const DevModel &md, flo
   float ax0 = 0.f, ax1 = 0.f, ax2 = 0.f;          // ppN ppJ ppC of the current row
   if (L >= 1) { ax0 = XL ? LD2X(&aux[3]) : aux[3]; ax1 = XL ? LD2X(&aux[4]) : aux[4]; ax2 = XL ? LD2X(&aux[5]) : aux[5]; }
   if (L >= 1) {
-    const float *__restrict__ p1 = pp + (size_t)1 * 2 * Mp + lane;
+    const float *__restrict__ p1 = pp + (size_t)1 * pst + lane;
 #pragma unroll
     for (int q = 0; q < Q; ++q) { ppM[q] = p1[q * 64]; ppI[q] = p1[Mp + q * 64]; }
   }
@@ -474,7 +478,7 @@ __device__ __forceinline__ void oa_item(const FbWork &w, const DevModel &md, flo
     const float *__restrict__ axn = aux + (size_t)((i < L) ? i + 1 : i) * 3;
     const float an0 = XL ? LD2X(&axn[0]) : axn[0], an1 = XL ? LD2X(&axn[1]) : axn[1], an2 = XL ? LD2X(&axn[2]) : axn[2];
     {
-      const float *__restrict__ pn = pp + (size_t)((i < L) ? i + 1 : i) * 2 * Mp + lane;
+      const float *__restrict__ pn = pp + (size_t)((i < L) ? i + 1 : i) * pst + lane;
 #pragma unroll
       for (int q = 0; q < Q; ++q) { ppMn[q] = pn[q * 64]; ppIn[q] = pn[Mp + q * 64]; }
     }

@@ -1,8 +1,5 @@
 set -u
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r02c
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-timeout 400 python bench.py --steps 5 --warmup 2 > gpurun_out/r02c/bench_default.json 2> gpurun_out/r02c/bench_default.err
-python -c "
-import json; d=json.loads(open('gpurun_out/r02c/bench_default.json').read().strip().split('\n')[-1]); print(d['ms_per_step'], d['value'], d['steady_state']['ms_per_step'], d['lineage_wf_equiv'].get('bins_per_hour'), d['lineage_wf_equiv'].get('parts_s_rank0'), d['lineage_wf_equiv'].get('first_pass_s'))"
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+CKM_ENV_INPLACE=1 timeout 300 python -m pytest tests/test_gpu_scan.py tests/test_gpu_fullsize.py -x -q 2>&1 | tail -2
+export CKM_BENCH_STEADY=0 CKM_BENCH_FROM_HOST=0
+for v in 1 0; do CKM_ENV_INPLACE=$v timeout 100 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --lineage-bins 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('inplace $v', round(d['ms_per_step'],2), d['stages_ms'], d['rows'])"; done
