@@ -171,6 +171,8 @@ def ssv_roofline(st_like, ssv_ms_per_step, bins, orfs, extra_note=""):
                 "note": "architectural issue peak = 1 wave64 instruction per 4 cycles per SIMD; the packed-i16 add/max the kernel consists of issue "
                         "at 4.53-4.60 cycles when measured alone (tools/ubench/valu_rates.hip, profiles/r02_valu_rates.txt); "
                         "time = the SSV launches of this run, HIP events"}
+    if valu is not None and "all_kernels" in pm:
+        valu["all_kernels_of_a_step"] = {"wave_insts": pm["all_kernels"]["valu_insts"], "hbm_bytes": pm["all_kernels"]["hbm_bytes_corrected"], "source": src}
     return roof, valu
 
 
@@ -444,6 +446,16 @@ def main():
     if rank == 0:
         roof, valu = ssv_roofline({"residue_hmm": st.residue_hmm, "pairs_ssv": st.pairs_ssv}, ssv_ms / args.steps, nb, args.orfs)
         roof["launches_per_step"] = int(st.ssv_launches)
+        step_util = None
+        if valu is not None and "all_kernels_of_a_step" in valu:
+            ak = valu.pop("all_kernels_of_a_step")
+            # the whole step against the device: every kernel's VALU instructions over the step's wall time (the SSV launches share the
+            # SIMDs with the chains of the other groups, so the per-kernel fraction above understates how busy the device is)
+            cyc = per_step * 2.4e9 / (ak["wave_insts"] / 1024.0)
+            step_util = {"valu_wave_insts_per_step": ak["wave_insts"], "cycles_per_inst_per_simd": cyc, "valu_frac_of_4_cycle_peak": 4.0 / cyc,
+                         "valu_frac_of_measured_ceiling": min(1.0, 4.55 / cyc), "hbm_bytes_per_step": ak["hbm_bytes"],
+                         "hbm_frac": ak["hbm_bytes"] / per_step / 1e9 / HBM_PEAK_GBS,
+                         "source": ak["source"] + " (recorded PMC passes of this workload) over this run's ms_per_step"}
         out = {
             "metric": "residues*HMMs/s (marker-gene scan+reduce, cfg2: 43 profiles x 100 synthetic 2 Mb bins per GPU)",
             "value": value, "unit": "residue*HMM/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -460,7 +472,7 @@ def main():
             "steady_state": steady,
             "lineage_wf_equiv": lineage,
             "gcups_ssv": float(st.cells_ssv) / max(ssv_ms / args.steps / 1e3, 1e-12) / 1e9,
-            "roofline": roof, "roofline_valu": valu,
+            "roofline": roof, "roofline_valu": valu, "step_utilisation": step_util,
             "stages_ms": {"ssv": st.ms_ssv, "filters": st.ms_filters, "fwdbwd": st.ms_fwdbwd, "domains": st.ms_domains, "host": st.ms_host, "search_total": st.ms_total},
             "step_parts_ms": {k: v / args.steps for k, v in part_ms.items()},
             "stage_pairs": stage_pairs(st),

@@ -52,10 +52,18 @@ def main():
         return sum(float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(src, d, "p_counter_collection.csv")))
                    if "ssv_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter)
     f, w = total("pmc_fetch", "FETCH_SIZE"), total("pmc_write", "WRITE_SIZE")
+
+    def total_all(d, counter):
+        return sum(float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(src, d, "p_counter_collection.csv"))) if r["Counter_Name"] == counter)
+    valu_all = total_all("pmc_sq", "SQ_INSTS_VALU")
+    f_all, w_all = total_all("pmc_fetch", "FETCH_SIZE"), total_all("pmc_write", "WRITE_SIZE")
     json.dump({"config": "cfg2: 43 profiles x 100 bins x 2000 ORFs, 1 GPU, one search (kernels serialised by counter collection)",
                "kernel": "ssv_kernel<Q> (all launches of one step)", "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_corrected": 2 * f * 1024 + w * 1024,
                "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads)",
-               "valu_insts": valu, "ssv_ms_under_pmc": ms}, open(dst("ssv_traffic.json"), "w"), indent=1)
+               "valu_insts": valu, "ssv_ms_under_pmc": ms,
+               "all_kernels": {"valu_insts": valu_all, "FETCH_SIZE_KB": f_all, "WRITE_SIZE_KB": w_all, "hbm_bytes_corrected": 2 * f_all * 1024 + w_all * 1024,
+                               "note": "every kernel of the search (SSV + the chains + ensembles + copies), same passes"}},
+              open(dst("ssv_traffic.json"), "w"), indent=1)
     print(open(dst("ssv_traffic.json")).read())
 
 
