@@ -122,22 +122,34 @@ class MarkerGeneFinder(object):
         """bins/<binId>/genes.faa for every bin (checkm/markerGeneFinder.py:108-127).  Called genes (-g) are copied in; otherwise
         genes already present are reused and the rest are called by the reference's own ProdigalRunner (checkm/prodigal.py:54-153),
         `threads` bins at a time -- gene calling sits BEFORE the accelerated path and is not reimplemented here."""
-        binIds, faa, todo = [], [], []
+        binIds, faa, todo, copies = [], [], [], []
         for binFile in binFiles:
             binId = binIdFromFilename(binFile)
             binDir = os.path.join(outDir, 'bins', binId)
             makeSurePathExists(binDir)
             dst = os.path.join(binDir, DefaultValues.PRODIGAL_AA)
             if bCalledGenes:
-                if binFile.endswith('.gz'):
-                    with gzip.open(binFile, 'rt') as fin, open(dst, 'w') as fout:
-                        shutil.copyfileobj(fin, fout)
-                else:
-                    shutil.copyfile(binFile, dst)
+                copies.append((binFile, dst))
             else:
                 todo.append((binFile, binDir, binId, dst))
             binIds.append(binId)
             faa.append(dst)
+        if copies:
+            # called genes (-g) are copied in, as the reference does per bin (markerGeneFinder.py:118-127) -- on a few host threads: a
+            # thousand bins are a gigabyte of protein text, and both passes of lineage_wf copy it
+            def copy_in(job):
+                src, dst = job
+                if src.endswith('.gz'):
+                    with gzip.open(src, 'rt') as fin, open(dst, 'w') as fout:
+                        shutil.copyfileobj(fin, fout)
+                else:
+                    shutil.copyfile(src, dst)
+            if len(copies) == 1:
+                copy_in(copies[0])
+            else:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=min(8, len(copies))) as pool:
+                    list(pool.map(copy_in, copies))
         if todo:
             runner = gene_caller()
             missing = [t for t in todo if runner is None and not os.path.exists(t[3])]

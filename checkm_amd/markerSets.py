@@ -7,6 +7,7 @@ replaced by an index list into ONE resident profile database, in database order 
 unlike the reference's set-iteration order).
 """
 import ast
+import functools
 import ctypes as C
 import gzip
 import logging
@@ -94,8 +95,17 @@ class BinMarkerSets(object):
     def read(self, line):
         f = line.split('\t')
         for i in range(int(f[1])):
-            uid, lineage, ngen, sets = f[4 * i + 2], f[4 * i + 3], int(f[4 * i + 4]), ast.literal_eval(f[4 * i + 5].strip())
+            uid, lineage, ngen, sets = f[4 * i + 2], f[4 * i + 3], int(f[4 * i + 4]), _parse_marker_sets(f[4 * i + 5].strip())
             self.markerSets.append(MarkerSet(uid, lineage, ngen, [set(s) for s in sets]))
+
+
+@functools.lru_cache(maxsize=8192)
+def _parse_marker_sets(text):
+    """The marker-set literal of one lineage node (`[set([...]), ...]`, kilobytes long), parsed once per distinct string: the bins of a
+    run share a few dozen lineage nodes, and a 1000-bin Lineage marker file holds 3000 of these literals -- 4.4 of the 4.8 s that
+    reading it took went into compiling the same strings again (the reference evals every one, markerSets.py:151).  Returns tuples: the
+    callers build their own sets."""
+    return tuple(tuple(s) for s in ast.literal_eval(text))
 
 
 def count_sets(list_of_sets, hits):
@@ -292,8 +302,34 @@ class MarkerSetParser(object):
         if kind == BinMarkerSets.TAXONOMIC_MARKER_SET:
             accs = expand(self.parseTaxonomicMarkerSetFile(markerFile))
             return {b: accs for b in binIds}
-        per_bin = self.parseLineageMarkerSetFile(markerFile)
-        return {b: expand(per_bin[b]) for b in binIds}
+        # Lineage file: only the union of the marker genes of a bin's sets is needed here, and bins of one lineage carry the same
+        # literals -- key the expansion by the literals themselves instead of building the set objects of every bin
+        by_text, out = {}, {}
+        want = set(binIds)
+        with open(markerFile) as f:
+            f.readline()
+            for line in f:
+                p = line.rstrip('\n').split('\t')
+                if p[0] not in want:
+                    continue
+                key = tuple(p[4 * i + 5].strip() for i in range(int(p[1])))
+                accs = by_text.get(key)
+                if accs is None:
+                    genes = set()
+                    for text in key:
+                        for s in _parse_marker_sets(text):
+                            genes.update(s)
+                    gk = frozenset(genes)
+                    if gk not in cache:
+                        cache[gk] = genes | pfam.genesInSameClan(genes)
+                    accs = by_text[key] = cache[gk]
+                out[p[0]] = accs
+        missing = [b for b in binIds if b not in out]
+        if missing:
+            per_bin = self.parseLineageMarkerSetFile(markerFile)      # (raises the reference's KeyError for a bin the file does not list)
+            for b in missing:
+                out[b] = expand(per_bin[b])
+        return {b: out[b] for b in binIds}
 
     def createHmmModels(self, outDir, binIds, markerFile):
         """{binId: {acc: HmmModel}} without launching anything (markerSets.py:299-324)."""

@@ -581,23 +581,24 @@ class ResultsParser(object):
         # {acc: (acc, leng, ga, tc, nc)}; a bin joins the first group it does not contradict (lineage_wf: every bin has its own
         # model subset, but the thresholds of a model rarely depend on the subset).
         groups = []          # [merged view, members, last dict object seen]
+        group_of = {}        # id(model dict) -> its group: find() hands the SAME dict to every bin with the same model subset
         for b in binIds:
             mb = self.models[b]
-            placed = False
-            for g in groups:
-                if g[2] is mb:
-                    g[1].append(b); placed = True
-                    break
-            if placed:
+            g = group_of.get(id(mb))
+            if g is not None:
+                g[1].append(b)
                 continue
+            placed = False
             view = {a: (m.acc, m.leng, m.ga, m.tc, m.nc) for a, m in mb.items()}
             for g in groups:
                 merged = g[0]
                 if all(merged.get(a, v) == v for a, v in view.items()):
                     merged.update(view); g[1].append(b); g[2] = mb; placed = True
+                    group_of[id(mb)] = g
                     break
             if not placed:
                 groups.append([view, [b], mb])
+                group_of[id(mb)] = groups[-1]
 
         class _Slot(object):
             def __init__(self, acc, leng, v):

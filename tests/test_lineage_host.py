@@ -18,6 +18,10 @@ def test_world_files_parse_through_the_mirrors(tmp_path):
     assert msp.hmmDatabaseFor(lin) == DefaultValues.HMM_MODELS == w.checkm_hmm
     per_bin = msp.parseLineageMarkerSetFile(lin)
     wanted = msp.markerAccessionsForBins(binIds, lin)
+    from checkm_amd.pfam import PFAM
+    pfam = PFAM(DefaultValues.PFAM_CLAN_FILE)
+    sub = msp.markerAccessionsForBins(binIds[5:2:-1], lin)                      # a subset, in the caller's order
+    assert list(sub) == binIds[5:2:-1] and all(sub[b] == wanted[b] for b in sub)
     for k, b in enumerate(binIds):
         fid = w.family_of(k)
         bms = per_bin[b]
@@ -25,6 +29,8 @@ def test_world_files_parse_through_the_mirrors(tmp_path):
         assert bms.getMarkerGenes() == w.lineage.marker_genes(fid)
         assert [sorted(s) for s in bms.selectedMarkerSet().markerSet] == [sorted(s) for s in w.lineage.selected_sets(fid)]
         assert w.lineage.marker_genes(fid) <= wanted[b] <= set(w.accs)
+        # (markerAccessionsForBins keys the expansion by the file's literals instead of building every bin's sets: same result)
+        assert wanted[b] == bms.getMarkerGenes() | pfam.genesInSameClan(bms.getMarkerGenes())
     # clan expansion: a marker in a clan pulls its clan-mates in
     assert any(wanted[b] - w.lineage.marker_genes(w.family_of(k)) for k, b in enumerate(binIds))
     t = msp.markerAccessionsForBins(binIds, tax)
