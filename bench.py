@@ -197,9 +197,7 @@ def lineage_setup(workdir, nbins, rank, world, sync):
     DefaultValues.set_data_root(data)
     binIds = ["bin_%04d" % b for b in range(nbins)]
     files = [os.path.join(workdir, "%s.faa" % b) for b in binIds]
-    for b in range(rank, nbins, world):
-        if not os.path.exists(files[b]):
-            synth.write_fasta(files[b], w.bin_records(b))
+    w.write_bin_files([(b, files[b]) for b in range(rank, nbins, world)], jobs=max(1, min(32, ((os.cpu_count() or 2) - 2) // world)))
     if rank == 0:
         w.write_marker_files(workdir, binIds)
     sync()

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restric
       xr = __shfl(xr, l);
       const int row = __shfl(i, l);
       const int r = ens_select_e(mx + rowsz * row, Q, Mp, (double)xr / 4294967296.0, lane);
-      if (lane == l) { rng = xr; k = (r >> 1) + 1; st = (r & 1) ? sD : sM; sqto = 0; hmmto = k; }    // last model node: the state E was entered from, M or D
+      if (lane == l) { rng = xr; k = (r >> 1) + 1; st = (r & 1) ? sD : sM; sqto = 0; hmmto = 0; }    // (coordinates come from the first MATCH state met on the way back)
     }
     if (!done) {
       const float *cr = mx + rowsz * i, *pr = (i > 0) ? mx + rowsz * (i - 1) : mx;
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restric
       case sM: {
         const int c = k - 1;
         code[i] = (uint16_t)(0x4000 | k);
-        if (!sqto) sqto = i;
+        if (!sqto) { sqto = i; hmmto = k; }      // HMMER's p7_trace_Index takes sqto/hmmto from the last M state; trailing D states do not count
         pth[0] = xs[(size_t)(i - 1) * 6 + 3] * tBM[c];
         if (c > 0) { const int a = CELL(c - 1); pth[1] = pr[a] * tMM[c]; pth[2] = pr[Mp + a] * tIM[c]; pth[3] = pr[2 * Mp + a] * tDM[c]; }
         else pth[1] = pth[2] = pth[3] = 0.0f;

@@ -70,36 +70,55 @@ def _compo(prof):
     return c / c.sum()
 
 
+def _row(vals, probs, n):
+    """`n` numbers of a body line: -ln(p) as %8.5f, '*' for probability 0 (one format call per line, not per number)."""
+    if probs.min() > 0.0:
+        return _ROW_FMT[n] % tuple(vals)
+    return " ".join("       *" if p <= 0.0 else "%8.5f" % v for v, p in zip(vals, probs))
+
+
+_ROW_FMT = {20: " ".join(["%8.5f"] * 20), 7: " ".join(["%8.5f"] * 7)}
+
+
+def hmm_text(p):
+    """One profile as HMMER3/f ASCII text (layout: SURVEY.md appendix B2)."""
+    out = ["HMMER3/f [3.1b2 | February 2015]\n", "NAME  %s\n" % p.name]
+    if p.acc:
+        out.append("ACC   %s\n" % p.acc)
+    out.append("DESC  %s\n" % p.desc)
+    out.append("LENG  %d\n" % p.M)
+    out.append("ALPH  amino\nRF    no\nMM    no\nCONS  no\nCS    no\nMAP   no\n")
+    out.append("NSEQ  1\nEFFN  1.000000\nCKSUM 0\n")
+    for tag in ("ga", "tc", "nc"):
+        v = getattr(p, tag)
+        if v is not None:
+            out.append("%s    %.2f %.2f;\n" % (tag.upper(), v[0], v[1]))
+    if p.stats is not None:
+        out.append("STATS LOCAL MSV      %9.4f %8.5f\n" % (p.stats[0], p.stats[1]))
+        out.append("STATS LOCAL VITERBI  %9.4f %8.5f\n" % (p.stats[2], p.stats[3]))
+        out.append("STATS LOCAL FORWARD  %9.4f %8.5f\n" % (p.stats[4], p.stats[5]))
+    out.append("HMM     " + "".join("     %s   " % a for a in AMINO) + "\n")
+    out.append("            m->m     m->i     m->d     i->m     i->i     d->m     d->d\n")
+    with np.errstate(divide="ignore"):
+        lm, li, lt = 0.0 - np.log(p.mat) + 0.0, 0.0 - np.log(p.ins) + 0.0, 0.0 - np.log(p.t) + 0.0
+        compo = _compo(p)
+        lc = 0.0 - np.log(compo) + 0.0
+    out.append("  COMPO  " + _row(lc, compo, 20) + "\n")
+    out.append("         " + _row(li[0], p.ins[0], 20) + "\n")
+    out.append("         " + _row(lt[0], p.t[0], 7) + "\n")
+    for k in range(1, p.M + 1):
+        out.append("%7d  " % k + _row(lm[k], p.mat[k], 20) + "      - - - - -\n")
+        out.append("         " + _row(li[k], p.ins[k], 20) + "\n")
+        out.append("         " + _row(lt[k], p.t[k], 7) + "\n")
+    out.append("//\n")
+    return "".join(out)
+
+
 def write_hmm(path, profiles, mode="w"):
-    """HMMER3/f ASCII writer (layout: SURVEY.md appendix B2)."""
+    """HMMER3/f ASCII writer."""
     with open(path, mode) as f:
         for p in profiles:
-            f.write("HMMER3/f [3.1b2 | February 2015]\n")
-            f.write("NAME  %s\n" % p.name)
-            if p.acc:
-                f.write("ACC   %s\n" % p.acc)
-            f.write("DESC  %s\n" % p.desc)
-            f.write("LENG  %d\n" % p.M)
-            f.write("ALPH  amino\nRF    no\nMM    no\nCONS  no\nCS    no\nMAP   no\n")
-            f.write("NSEQ  1\nEFFN  1.000000\nCKSUM 0\n")
-            for tag in ("ga", "tc", "nc"):
-                v = getattr(p, tag)
-                if v is not None:
-                    f.write("%s    %.2f %.2f;\n" % (tag.upper(), v[0], v[1]))
-            if p.stats is not None:
-                f.write("STATS LOCAL MSV      %9.4f %8.5f\n" % (p.stats[0], p.stats[1]))
-                f.write("STATS LOCAL VITERBI  %9.4f %8.5f\n" % (p.stats[2], p.stats[3]))
-                f.write("STATS LOCAL FORWARD  %9.4f %8.5f\n" % (p.stats[4], p.stats[5]))
-            f.write("HMM     " + "".join("     %s   " % a for a in AMINO) + "\n")
-            f.write("            m->m     m->i     m->d     i->m     i->i     d->m     d->d\n")
-            f.write("  COMPO  " + " ".join(_fmt(x) for x in _compo(p)) + "\n")
-            f.write("         " + " ".join(_fmt(x) for x in p.ins[0]) + "\n")
-            f.write("         " + " ".join(_fmt(x) for x in p.t[0]) + "\n")
-            for k in range(1, p.M + 1):
-                f.write("%7d  " % k + " ".join(_fmt(x) for x in p.mat[k]) + "      - - - - -\n")
-                f.write("         " + " ".join(_fmt(x) for x in p.ins[k]) + "\n")
-                f.write("         " + " ".join(_fmt(x) for x in p.t[k]) + "\n")
-            f.write("//\n")
+            f.write(hmm_text(p))
 
 
 def _cdf(prof):

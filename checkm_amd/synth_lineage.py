@@ -235,8 +235,8 @@ def make_lineage_bin(profs, planted, seed, n_orfs, phylo=None, dup_frac=0.04, or
 class World(object):
     """Builds the data root and the marker files under `root`; bins are generated on request."""
 
-    def __init__(self, root, n_models=N_MODELS, seed=2000, write=True):
-        self.root, self.seed = root, seed
+    def __init__(self, root, n_models=N_MODELS, seed=2000, write=True, jobs=None):
+        self.root, self.seed, self.n_models = root, seed, n_models
         self.profs = lineage_profiles(n_models, seed)
         self.accs = [p.acc for p in self.profs]
         self.index = {a: i for i, a in enumerate(self.accs)}
@@ -249,7 +249,9 @@ class World(object):
             os.makedirs(os.path.join(root, "hmms"), exist_ok=True)
             os.makedirs(os.path.join(root, "pfam"), exist_ok=True)
             if not os.path.exists(self.checkm_hmm):
-                synth.write_hmm(self.checkm_hmm + ".tmp", self.profs)
+                with open(self.checkm_hmm + ".tmp", "w") as f:
+                    for text in _pool_map(root, seed, n_models, "hmm", [list(range(k, min(k + 25, n_models))) for k in range(0, n_models, 25)], jobs):
+                        f.write(text)
                 os.replace(self.checkm_hmm + ".tmp", self.checkm_hmm)
             if not os.path.exists(self.phylo_hmm):
                 synth.write_hmm(self.phylo_hmm, self.phylo)
@@ -271,6 +273,17 @@ class World(object):
         planted = [self.index[a] for a in sel if rng.random() < frac]
         return make_lineage_bin(self.profs, planted, self.seed * 1000 + b, n_orfs, phylo=self.phylo, **kw)
 
+    def write_bin_files(self, jobs_list, jobs=None):
+        """jobs_list: [(bin index, path)] -- the genes.faa files of those bins, written by a pool of generator processes."""
+        todo = [j for j in jobs_list if not os.path.exists(j[1])]
+        if len(todo) <= 2:
+            for b, path in todo:
+                synth.write_fasta(path, self.bin_records(b))
+            return
+        chunks = [todo[k::max(1, len(todo) // 4)] for k in range(max(1, len(todo) // 4))]
+        for _ in _pool_map(self.root, self.seed, self.n_models, "bins", chunks, jobs):
+            pass
+
     def write_marker_files(self, outdir, binIds, families=None):
         """lineage.ms (one line per bin) and taxon.ms (the p0 phylum set for every bin) in `outdir`."""
         lin = os.path.join(outdir, "lineage.ms")
@@ -285,3 +298,40 @@ class World(object):
             lin_s, ng, sets = self.lineage.nodes[u]
             f.write("\t".join(["Synth1", "1", u, lin_s, str(ng), repr([set(sorted(s)) for s in sets])]) + "\n")
         return lin, tax
+
+
+# ---- generator processes: the synthetic world is a few hundred MB of text; writing it is single-threaded Python otherwise ----
+_WORKER_WORLD = None
+
+
+def _worker_init(root, seed, n_models):
+    global _WORKER_WORLD
+    _WORKER_WORLD = World(root, n_models, seed, write=False)
+
+
+def _worker_task(job):
+    kind, arg = job
+    w = _WORKER_WORLD
+    if kind == "hmm":
+        return "".join(synth.hmm_text(w.profs[i]) for i in arg)
+    for b, path in arg:
+        synth.write_fasta(path + ".tmp", w.bin_records(b))
+        os.replace(path + ".tmp", path)
+    return len(arg)
+
+
+def _pool_map(root, seed, n_models, kind, args, jobs=None):
+    """Results of the tasks in order.  'spawn' processes: the caller may already hold a HIP context, which must not be forked."""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    jobs = jobs or int(os.environ.get("CKM_SYNTH_JOBS", "0")) or min(32, max(1, (os.cpu_count() or 2) - 2))
+    jobs = max(1, min(jobs, len(args)))
+    if jobs == 1 or (kind == "hmm" and n_models <= 400):           # small worlds (tests): not worth starting interpreters
+        _worker_init(root, seed, n_models) if _WORKER_WORLD is None or _WORKER_WORLD.n_models != n_models or _WORKER_WORLD.seed != seed else None
+        for a in args:
+            yield _worker_task((kind, a))
+        return
+    with ProcessPoolExecutor(max_workers=jobs, mp_context=mp.get_context("spawn"), initializer=_worker_init,
+                             initargs=(root, seed, n_models)) as ex:
+        for r in ex.map(_worker_task, [(kind, a) for a in args]):
+            yield r

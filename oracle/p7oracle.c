@@ -1002,14 +1002,14 @@ static int stochastic_trace(const PROF *p, const XF *xf, int Ld, const float *mx
           acc += (double)cr[2*Mp+c]; if (target < base[z] + acc) { pick = c; isd = 1; hit = 1; break; }
         }
       }
-      /* the domain's last model node is the state E was entered from, match or delete (HMMER's trace index counts D states for
-       * the model coordinates); its last residue is set by the first match state met on the way back */
-      k = pick + 1; st = isd ? sD : sM; sqto = 0; hmmto = k;
+      /* HMMER's p7_trace_Index sets sqto AND hmmto in its match-state case only: the domain's last model node is the last MATCH
+       * state of the trace (the first one met on the way back); delete states between it and E do not count */
+      k = pick + 1; st = isd ? sD : sM; sqto = 0; hmmto = 0;
     } break;
     case sM: {
       int c = k - 1;
       code[i] = (uint16_t)(0x4000 | k);
-      if (!sqto) sqto = i;
+      if (!sqto) { sqto = i; hmmto = k; }
       pth[0] = xs[(size_t)(i-1)*6+3] * p->fBM[c];
       if (c > 0) { pth[1] = pr[c-1] * p->fMM[c]; pth[2] = pr[Mp+c-1] * p->fIM[c]; pth[3] = pr[2*Mp+c-1] * p->fDM[c]; }
       else pth[1] = pth[2] = pth[3] = 0.0f;

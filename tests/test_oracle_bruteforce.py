@@ -480,7 +480,7 @@ def _segmentations(M, mat, t, x):
         for em, kexit in doms:                            # em: [(residue, 'M'|'I', node)] of one domain, in order; kexit: node of the state E was entered from (M or D)
             ms = [(i, k) for i, kind, k in em if kind == 'M']
             sqfrom, sqto = ms[0][0], ms[-1][0]
-            key.append((sqfrom, sqto, ms[0][1], kexit))   # model coordinates run to the last node visited, delete states included (HMMER's trace index)
+            key.append((sqfrom, sqto, ms[0][1], ms[-1][1]))   # model coordinates from match states only, as p7_trace_Index takes them (trailing delete states, kexit, do not count)
             inside = [(i, kind, k) for i, kind, k in em if sqfrom <= i <= sqto]
             n = float(len(inside))
             for pos in range(sqfrom + 1, sqto + 1):       # the first residue of a domain keeps ratio 1 (HMMER's `pos <= sqfrom` loop)
