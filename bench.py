@@ -1,7 +1,13 @@
 #!/usr/bin/env python
 """bench.py -- the marker-gene hot path of CheckM on N MI355X, one JSON line (rank 0).
 
-  --config cfg2 (default)  configs[1] of BASELINE.json: cpr_43-shaped 43-profile DB against 100 synthetic 2 Mb bins (~2k ORFs
+  --config cfg3 (default)  configs[2] (N = 1) / configs[3] (N > 1, strong scaling) of BASELINE.json, the configuration "bins/hour
+                           (lineage_wf-equiv)" is quoted on: see below.  One step = one lineage_wf-equivalent pass over ALL --bins-total
+                           bins.  A step lasts tens of seconds, so the number of timed steps is min(--steps, what fits --budget-seconds
+                           judged from the warm pass): the line carries `steps` (run) and `steps_requested`.  At N = 1 the same line
+                           carries `cfg2` (a short run of the configuration below), `cpu_baseline` (the CPU oracle on sampled bins with
+                           their lineage's model subsets) and `emulated_rank0_of_8` (see --emulate-rank).
+  --config cfg2            configs[1] of BASELINE.json: cpr_43-shaped 43-profile DB against 100 synthetic 2 Mb bins (~2k ORFs
                            each) PER GPU.  One step = one pass of the hot path (scan + reduce + the one gather of QA rows) over the
                            rank's bins, inputs resident in HBM.  `--scaling strong --bins-total N` shards N bins over the ranks.
                            The same line carries `lineage_wf_equiv`: a small lineage_wf-shaped run (cfg3 inputs) from FILES through
@@ -10,6 +16,10 @@
                            marker file (43 phylo + 300-1500 lineage models), through the product's own call sequence
                            (find(phylo.hmm) -> find(lineage.ms) -> analyseResults -> printSummary) from genes.faa files; under
                            torchrun the PRODUCT shards the bins over the ranks (strong scaling, cfg4).  --bins-total (default 1000).
+
+  --emulate-rank R/W       cfg3 on ONE GPU as rank R of W would run it: the product shards the bins as under torchrun with W ranks, this
+                           process scans rank R's shard and does every piece of all-bins host work a rank does; no process group, no
+                           collective (the table holds the shard's rows).  The only configs[3] evidence obtainable on one GPU.
 
   python bench.py --gpus 1 --steps 3 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -31,7 +41,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # before torch initialises 
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-PROFILE_TAG = "r02"            # profiles/<tag>_ssv_traffic.json holds the PMC-pass figures of the SSV launches
+PROFILE_TAG = "r03"            # profiles/<tag>*_ssv_traffic.json / <tag>*_cfg3_ssv_traffic.json hold the PMC-pass figures of the SSV launches
+MEASURED_CYCLES_PER_INST = 4.55   # cycles per wave64 instruction per SIMD of the SSV row body run alone (tools/ubench/valu_rates.hip); updated from profiles/r03_valu_rates.txt
 
 
 def parse():
@@ -39,12 +50,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=["cfg2", "cfg3"], default="cfg2")
+    ap.add_argument("--config", choices=["cfg2", "cfg3"], default="cfg3")
+    ap.add_argument("--budget-seconds", type=float, default=float(os.environ.get("CKM_BENCH_BUDGET_S", "75")),
+                    help="cfg3: wall-clock budget of the timed region; the steps actually run are min(--steps, budget / estimated step)")
+    ap.add_argument("--emulate-rank", default=None, help="cfg3: R/W -- run as rank R of W on this one GPU (no collectives)")
+    ap.add_argument("--no-cfg2", action="store_true", help="cfg3: skip the nested cfg2 measurement")
+    ap.add_argument("--no-emulation", action="store_true", help="cfg3: skip the nested rank-0-of-8 emulation")
+    ap.add_argument("--host-profile", default=None, help="cfg3: write a cProfile of the timed steps (host side) to this file")
     ap.add_argument("--bins", type=int, default=100, help="cfg2: bins per GPU (weak scaling)")
     ap.add_argument("--orfs", type=int, default=2000, help="cfg2: ORFs per bin")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="cfg2: strong = --bins-total bins sharded over the ranks")
     ap.add_argument("--bins-total", type=int, default=1000, help="cfg2 strong / cfg3: bins of the whole job")
-    ap.add_argument("--lineage-bins", type=int, default=16, help="cfg2: bins of the lineage_wf-equivalent side measurement (0 = skip)")
+    ap.add_argument("--lineage-bins", type=int, default=0, help="cfg2: bins of a small lineage_wf-equivalent side measurement (0 = skip; cfg3 IS that measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="cfg2: steps in flight at once (own context each); 1 = every step runs alone")
@@ -153,8 +170,8 @@ def ssv_roofline(st_like, ssv_ms_per_step, bins, orfs, extra_note=""):
     valu = None
     tf = None
     import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", PROFILE_TAG + "*_ssv_traffic.json")))      # r02a, r02b, ...: the latest pass of this round
-    for cand in found[::-1] + [os.path.join(ROOT, "profiles", "r01e_ssv_traffic.json")]:
+    found = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", PROFILE_TAG + "*_ssv_traffic.json")) if "cfg3" not in os.path.basename(f))   # the latest cfg2 pass of this round
+    for cand in found[::-1] + [os.path.join(ROOT, "profiles", "r02b_ssv_traffic.json")]:
         if os.path.exists(cand):
             tf = cand
             break
@@ -166,11 +183,11 @@ def ssv_roofline(st_like, ssv_ms_per_step, bins, orfs, extra_note=""):
         roof["traffic_source"] = src + " (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass of this workload, recorded, not measured in this run)"
         cyc = ssv_s * 2.4e9 / (pm["valu_insts"] / 1024.0)
         valu = {"bound": "valu-issue", "wave_insts_per_step": pm["valu_insts"], "source": src + " (rocprofv3 --pmc SQ_INSTS_VALU pass, recorded)",
-                "cycles_per_inst_per_simd": cyc, "ceiling_cycles_per_inst": 4.0, "frac": 4.0 / cyc,
-                "measured_ceiling_cycles_per_inst": 4.55, "frac_of_measured_ceiling": min(1.0, 4.55 / cyc),
-                "note": "architectural issue peak = 1 wave64 instruction per 4 cycles per SIMD; the packed-i16 add/max the kernel consists of issue "
-                        "at 4.53-4.60 cycles when measured alone (tools/ubench/valu_rates.hip, profiles/r02_valu_rates.txt); "
-                        "time = the SSV launches of this run, HIP events"}
+                "cycles_per_inst_per_simd": cyc, "measured_rate_of_this_opcode_mix": MEASURED_CYCLES_PER_INST, "frac_of_measured_rate": min(1.0, MEASURED_CYCLES_PER_INST / cyc),
+                "note": "cycles per wave64 VALU instruction per SIMD over the SSV launches of this run (HIP events; they share the SIMDs with the chain kernels), "
+                        "against the rate the row body of the kernel issues at when it runs alone (tools/ubench/valu_rates.hip, profiles/%s_valu_rates.txt) -- a "
+                        "measured rate of this opcode mix, not an architectural peak (MI355X_MICROARCH.md quotes 2 cycles per wave64 op; f32 add/mul/fma measure "
+                        "2.6-2.7, the packed 16-bit ops 4.4-4.6)" % PROFILE_TAG}
     if valu is not None and "all_kernels" in pm:
         valu["all_kernels_of_a_step"] = {"wave_insts": pm["all_kernels"]["valu_insts"], "hbm_bytes": pm["all_kernels"]["hbm_bytes_corrected"], "source": src}
     return roof, valu
@@ -238,60 +255,83 @@ def lineage_pass(w, binIds, files, lin, out, rank):
     return {"tree_find_s": t1 - t0, "analyze_find_s": t2 - t1, "qa_s": t3 - t2, "total_s": t3 - t0}, tot
 
 
+class Env(object):
+    """What every configuration needs from the launch: rank / world, the device, barrier + sync, sums and maxima over the ranks."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        from checkm_amd import dist as cdist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
+        # (test hooks: CKM_BENCH_DEVICE pins every rank to one device and CKM_BENCH_DIST_BACKEND=gloo keeps the collectives on the host, so
+        #  the multi-rank control flow can be exercised on a one-GPU box; the driver's runs use neither)
+        self.dev_index = int(os.environ.get("CKM_BENCH_DEVICE", local_rank))
+        backend = os.environ.get("CKM_BENCH_DIST_BACKEND", "nccl")
+        os.environ["CHECKM_AMD_DEVICE"] = str(self.dev_index)
+        os.environ.setdefault("CKM_DIST_BACKEND", backend)
+        torch.cuda.set_device(self.dev_index)
+        if self.world > 1:
+            cdist.init_process_group(backend)
+        self.dev = torch.device("cuda", self.dev_index) if backend == "nccl" else None
+        self.torch, self.dist = torch, dist
+        workdir = args.workdir
+        if workdir is None:
+            workdir = tempfile.mkdtemp(prefix="ckm_bench_") if self.rank == 0 else None
+            if self.world > 1:
+                box = [workdir]
+                dist.broadcast_object_list(box, src=0)
+                workdir = box[0]
+        os.makedirs(workdir, exist_ok=True)
+        self.workdir = workdir
+
+    def sync(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def _reduce(self, x, op):
+        if self.world == 1:
+            return float(x)
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.dev if self.dev is not None else "cpu")
+        self.dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    def all_sum(self, x):
+        return self._reduce(x, self.dist.ReduceOp.SUM)
+
+    def all_max(self, x):
+        return self._reduce(x, self.dist.ReduceOp.MAX)
+
+    def finish(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env = Env(args)
+    if args.config == "cfg3":
+        out = bench_cfg3(args, env)
+    else:
+        out = bench_cfg2(args, env)
+    if env.rank == 0 and out is not None:
+        print(json.dumps(out))
+    env.finish()
+
+
+def bench_cfg2(args, env):
+    """configs[1]: returns the line (rank 0) or None."""
     import torch
-    import torch.distributed as dist
     from checkm_amd import _lib, dist as cdist, synth
     from checkm_amd import qa as cqa
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
-    # (test hooks: CKM_BENCH_DEVICE pins every rank to one device and CKM_BENCH_DIST_BACKEND=gloo keeps the collectives on the host, so
-    #  the multi-rank control flow can be exercised on a one-GPU box; the driver's runs use neither)
-    dev_index = int(os.environ.get("CKM_BENCH_DEVICE", local_rank))
-    backend = os.environ.get("CKM_BENCH_DIST_BACKEND", "nccl")
-    os.environ["CHECKM_AMD_DEVICE"] = str(dev_index)
-    os.environ.setdefault("CKM_DIST_BACKEND", backend)
-    torch.cuda.set_device(dev_index)
-    if world > 1:
-        cdist.init_process_group(backend)
-    dev = torch.device("cuda", dev_index) if backend == "nccl" else None
-    local_rank = dev_index
-
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def all_sum(x):
-        if world == 1:
-            return float(x)
-        t = torch.tensor([float(x)], dtype=torch.float64, device=dev if dev is not None else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        return float(t.item())
-
-    def all_max(x):
-        if world == 1:
-            return float(x)
-        t = torch.tensor([float(x)], dtype=torch.float64, device=dev if dev is not None else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    workdir = args.workdir
-    if workdir is None:
-        workdir = tempfile.mkdtemp(prefix="ckm_bench_") if rank == 0 else None
-        if world > 1:
-            box = [workdir]
-            dist.broadcast_object_list(box, src=0)
-            workdir = box[0]
-    os.makedirs(workdir, exist_ok=True)
-
-    if args.config == "cfg3":
-        return bench_cfg3(args, rank, world, workdir, sync, all_sum, all_max)
-
+    rank, world, workdir, dev, local_rank = env.rank, env.world, env.workdir, env.dev, env.dev_index
+    sync, all_sum, all_max = env.sync, env.all_sum, env.all_max
+    out = None
     # ---- cfg2 inputs (synthetic, fixed seeds): profiles + this rank's bins, packed and resident in HBM ----
     profs = synth.cpr43_profiles()
     hmm_path = os.path.join(workdir, "cpr43_synth_rank%d.hmm" % rank)
@@ -379,12 +419,14 @@ def main():
     # "host<->device copies included"); measured once, outside the timed region
     dt_host = None
     if os.environ.get("CKM_BENCH_FROM_HOST", "1") != "0":         # (the counter passes of tools/collect_profiles.sh want exactly one search)
+        saved = dict(part_ms)                   # (this extra step is not one of the timed ones: keep it out of step_parts_ms)
         t0 = time.perf_counter()
         seqs2 = _lib.Seqs(ctx, bins)
         st2, _n2, _t2 = step(seqs2)
         torch.cuda.synchronize()
         dt_host = all_max(time.perf_counter() - t0)
         seqs2.close()
+        part_ms.update(saved)
     # steady state of a stream of batches: two steps in flight (own context each), so that the end effects of one step -- the chain of
     # its last model-length groups, the exact decisions and the row assembly on the host -- run under the SSV phase of the next.
     # MarkerGeneFinder.find works this way on its batches of bins; `value` above is every step ALONE.
@@ -450,8 +492,8 @@ def main():
             # the whole step against the device: every kernel's VALU instructions over the step's wall time (the SSV launches share the
             # SIMDs with the chains of the other groups, so the per-kernel fraction above understates how busy the device is)
             cyc = per_step * 2.4e9 / (ak["wave_insts"] / 1024.0)
-            step_util = {"valu_wave_insts_per_step": ak["wave_insts"], "cycles_per_inst_per_simd": cyc, "valu_frac_of_4_cycle_peak": 4.0 / cyc,
-                         "valu_frac_of_measured_ceiling": min(1.0, 4.55 / cyc), "hbm_bytes_per_step": ak["hbm_bytes"],
+            step_util = {"valu_wave_insts_per_step": ak["wave_insts"], "cycles_per_inst_per_simd": cyc,
+                         "valu_frac_of_measured_rate": min(1.0, MEASURED_CYCLES_PER_INST / cyc), "hbm_bytes_per_step": ak["hbm_bytes"],
                          "hbm_frac": ak["hbm_bytes"] / per_step / 1e9 / HBM_PEAK_GBS,
                          "source": ak["source"] + " (recorded PMC passes of this workload) over this run's ms_per_step"}
         out = {
@@ -494,48 +536,197 @@ def main():
                 out["cpu_baseline"]["hmmsearch_on_path"] = False
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    seqs.close(); prof.close(); ctx.close()
+    return out
 
 
-def bench_cfg3(args, rank, world, workdir, sync, all_sum, all_max):
-    """cfg3 (N=1) / cfg4 (N>1, strong scaling): the lineage_wf marker path over --bins-total bins from files; the product shards them."""
-    import torch.distributed as dist
+def cpu_baseline_cfg3(w, binIds, files, lin, budget_s, threads):
+    """The CPU oracle (kind 'port', NOT HMMER) on sampled cfg3 bins: `threads` host threads, one bin each (the reference runs one hmmsearch
+    process per bin), every thread scanning the first ORFs of its bin against the model subset the bin's lineage asks for -- the analyze
+    pass of lineage_wf, which is 96 % of the path's residue x HMM work."""
+    from concurrent.futures import ThreadPoolExecutor
+    from checkm_amd.markerSets import MarkerSetParser, wanted_model
+    from oracle import p7
+    hs = p7.HmmSet(w.checkm_hmm)
+    threads = max(1, min(threads, len(binIds)))
+    step = max(1, len(binIds) // threads)
+    sample = [k * step for k in range(threads)]
+    wanted = MarkerSetParser().markerAccessionsForBins([binIds[k] for k in sample], lin)
+    work = []
+    for k in sample:
+        acc = wanted[binIds[k]]
+        models = [m for m in range(hs.n) if wanted_model(hs.name(m), hs.acc(m) or None, acc)]
+        recs = w.bin_records(k)
+        work.append((models, [p7.digitize(r[2]) for r in recs], [r[0] for r in recs]))
+    models, dsq, names = work[0]
+    n0 = min(len(dsq), 40)
+    t0 = time.perf_counter()
+    hs.search(models[:20], dsq[:n0], names[:n0])
+    dt = max(time.perf_counter() - t0, 1e-3)
+    cells_per_s = sum(len(d) for d in dsq[:n0]) * sum(hs.M(m) for m in models[:20]) / dt
+    avg_M = sum(sum(hs.M(m) for m in wk[0]) for wk in work) / float(len(work))
+    nseq = int(min(min(len(wk[1]) for wk in work), max(10, budget_s * cells_per_s / (avg_M * 330.0))))
+
+    def one(wk):
+        return hs.search(wk[0], wk[1][:nseq], wk[2][:nseq])                # the C call releases the GIL
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        rows = list(ex.map(one, work))
+    dt = time.perf_counter() - t0
+    residue_hmm = sum(sum(len(d) for d in wk[1][:nseq]) * len(wk[0]) for wk in work)
+    bins_equiv = sum(float(nseq) / len(wk[1]) for wk in work)              # fraction of a bin each thread got through
+    out = {"value": bins_equiv / dt * 3600.0, "unit": "bins/hour", "cores": threads, "kind": "port",
+           "residue_hmm_per_s": residue_hmm / dt,
+           "sample": "restated CPU oracle (NOT HMMER; HMMER is absent from the reference and this image), %d threads x (one sampled cfg3 bin each: the "
+                     "first %d of its %d-%d ORFs against its lineage's %d-%d models, analyze pass only), %d rows, %.1f s; bins/hour = the fraction of a "
+                     "bin each thread finished, summed, per hour on these %d cores"
+                     % (threads, nseq, min(len(wk[1]) for wk in work), max(len(wk[1]) for wk in work), min(len(wk[0]) for wk in work),
+                        max(len(wk[0]) for wk in work), sum(len(r) for r in rows), dt, threads),
+           "hmmsearch_on_path": shutil.which("hmmsearch") is not None}
+    hs.close()
+    return out
+
+
+def cfg3_counters(alg_bytes):
+    """HBM traffic and VALU instruction count of the SSV launches, scaled from the rocprofv3 --pmc passes of a cfg3 SAMPLE
+    (profiles/<tag>_cfg3_ssv_traffic.json: counters and algorithmic bytes of the sample; tools/collect_profiles.sh)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", PROFILE_TAG + "*_cfg3_ssv_traffic.json")))
+    if not found:
+        return None
+    with open(found[-1]) as f:
+        pm = json.load(f)
+    k = alg_bytes / float(pm["algorithmic_bytes"])
+    return {"source": os.path.relpath(found[-1], ROOT), "sample": pm.get("config"), "scale": k,
+            "hbm_bytes": pm["hbm_bytes_corrected"] * k, "valu_insts": pm["valu_insts"] * k,
+            "traffic_over_algorithmic": pm["hbm_bytes_corrected"] / float(pm["algorithmic_bytes"])}
+
+
+def bench_cfg3(args, env):
+    """configs[2] (N = 1) / configs[3] (N > 1, strong scaling): the lineage_wf marker path over --bins-total bins from files; the
+    product shards the bins over the ranks."""
+    rank, world, workdir = env.rank, env.world, env.workdir
     nbins = args.bins_total
+    emu = None
+    if args.emulate_rank:
+        r, wz = (int(x) for x in args.emulate_rank.split("/"))
+        if world != 1:
+            raise SystemExit("--emulate-rank runs on one GPU")
+        emu = (r, wz)
     t0 = time.perf_counter()
-    w, binIds, files, lin = lineage_setup(workdir, nbins, rank, world, sync)
+    w, binIds, files, lin = lineage_setup(workdir, nbins, rank, world, env.sync)
     t_setup = time.perf_counter() - t0
-    warm = min(nbins, 128 * world)          # two full-size batches per rank (find keeps two in flight, one per context): contexts, profile DBs, device tables and workspace at their working sizes
-    for k in range(max(1, args.warmup)):
-        lineage_pass(w, binIds[:warm], files[:warm], lin, os.path.join(workdir, "cfg3_warm"), rank)
-    sync()
+    if emu:
+        os.environ["CKM_EMULATE_RANK"] = "%d/%d" % emu            # checkm_amd/dist.py: the product shards as rank r of w, no process group
+    share = world if not emu else emu[1]
+    # the first pass of the process, on a slice of the bins: contexts, the 2000-profile database, device tables and workspace at working size
+    warm = min(nbins, 128 * share)
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    lineage_pass(w, binIds[:warm], files[:warm], lin, os.path.join(workdir, "cfg3_warm"), rank)
+    env.sync()
+    first_pass_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for k in range(max(0, args.warmup - 1) if warm == nbins else min(1, max(0, args.warmup - 1))):
+        lineage_pass(w, binIds[:warm], files[:warm], lin, os.path.join(workdir, "cfg3_warm"), rank)
+    env.sync()
+    second_pass_s = time.perf_counter() - t0
+    est = (second_pass_s if second_pass_s > 0 else first_pass_s) * nbins / float(warm)
+    steps = int(max(1, min(args.steps, args.budget_seconds // max(est, 1e-3))))
+    prof = None
+    if args.host_profile and rank == 0:
+        import cProfile
+        prof = cProfile.Profile()
+    env.sync()
+    t0 = time.perf_counter()
+    if prof is not None:
+        prof.enable()
+    for k in range(steps):
         parts, tot = lineage_pass(w, binIds, files, lin, os.path.join(workdir, "cfg3_out"), rank)
-    sync()
-    dt = all_max(time.perf_counter() - t0)
-    per_step = dt / args.steps
-    residue_hmm = all_sum(tot.get("residue_hmm", 0))
-    ssv_ms = all_max(tot.get("ms_ssv", 0.0))
-    if rank == 0:
-        roof, _valu = ssv_roofline(tot, tot.get("ms_ssv", 0.0), -1, -1, "; cfg3: summed over the %d ckm_search calls of rank 0's batches" % tot.get("searches", 0))
-        out = {"metric": "bins/hour (lineage_wf-equivalent marker path: tree pass + analyze pass + qa, from genes.faa files) and residues*HMMs/s",
-               "value": residue_hmm / per_step, "unit": "residue*HMM/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
-               "ms_per_step": per_step * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-               "dtype": "i16 (SSV/MSV bytes, Viterbi words) + f32 (Forward/Backward)", "data": "synthetic",
-               "config": {"workload": "configs[%d]: 2000 synthetic profiles (checkm.hmm) + 43 (phylo.hmm) x %d bins of U[1500,6000] ORFs; per-bin model subsets from a "
-                                      "Lineage marker file (marker genes of the bin's lineage chain + clan expansion: 300-1500 models)" % (2 if world == 1 else 3, nbins),
-                          "bins_total": nbins, "parallelism": "bins sharded over %d GPU(s) by MarkerGeneFinder.find (file size x models); 1 all_gather of QA rows" % world},
-               "bins_per_hour_lineage_wf_equiv": nbins / per_step * 3600.0,
-               "parts_s_rank0": parts, "roofline": roof, "stage_pairs": stage_pairs(tot), "ssv_ms_max_rank": ssv_ms,
-               "searches_rank0": int(tot.get("searches", 0)), "cascade_fallback_lanes_rank0": int(tot.get("cascade_fallback_lanes", 0)), "search_ms_rank0": tot.get("ms_total", 0.0), "find_parts_s_rank0": {k: tot.get(k, 0.0) for k in ("ingest_s", "search_s", "write_s")},
-               "setup_s": {"world_and_files": t_setup}, "cpu_baseline": None}
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if prof is not None:
+        prof.disable()
+    env.sync()
+    dt = env.all_max(time.perf_counter() - t0)
+    if prof is not None:
+        import io
+        import pstats
+        buf = io.StringIO()
+        ps = pstats.Stats(prof, stream=buf)
+        ps.sort_stats("cumulative").print_stats(60)
+        ps.sort_stats("tottime").print_stats(40)
+        with open(args.host_profile, "w") as f:
+            f.write("# cProfile of the timed region of `bench.py --config cfg3` (%d step(s) over %d bins), main thread only\n" % (steps, nbins) + buf.getvalue())
+    per_step = dt / steps
+    residue_hmm = env.all_sum(tot.get("residue_hmm", 0))
+    ssv_ms = env.all_max(tot.get("ms_ssv", 0.0))
+    if rank != 0:
+        return None
+    roof, _valu = ssv_roofline(tot, tot.get("ms_ssv", 0.0), -1, -1, "; cfg3: summed over the %d ckm_search calls of rank 0's batches in one step" % tot.get("searches", 0))
+    roof["launches_per_step"] = int(tot.get("ssv_launches", 0))
+    valu = step_util = None
+    cnt = cfg3_counters(roof["algorithmic_bytes"])
+    if cnt is not None:
+        roof["traffic"] = cnt["hbm_bytes"]
+        roof["traffic_source"] = "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a cfg3 sample (%s), scaled by algorithmic bytes x %.1f" % (cnt["source"], cnt["sample"], cnt["scale"])
+        cyc = (tot.get("ms_ssv", 0.0) / 1e3) * 2.4e9 / (cnt["valu_insts"] / 1024.0)
+        valu = {"bound": "valu-issue", "wave_insts_per_step": cnt["valu_insts"], "source": cnt["source"] + " (--pmc SQ_INSTS_VALU pass of the sample, scaled)",
+                "cycles_per_inst_per_simd": cyc, "measured_rate_of_this_opcode_mix": MEASURED_CYCLES_PER_INST, "frac_of_measured_rate": min(1.0, MEASURED_CYCLES_PER_INST / cyc),
+                "note": "time = HIP events over the SSV launches of this run, which share the SIMDs with the chain kernels of the groups ahead of them; the rate is what "
+                        "tools/ubench/valu_rates.hip measures for the row body of the kernel alone (profiles/%s_valu_rates.txt), not an architectural peak" % PROFILE_TAG}
+    out = {"metric": "bins/hour (lineage_wf-equiv marker path: tree pass + analyze pass + qa, from genes.faa files) + residues*HMMs/s",
+           "value": nbins / per_step * 3600.0, "unit": "bins/hour", "n_gpus": world, "steps": steps, "steps_requested": args.steps, "warmup": args.warmup,
+           "ms_per_step": per_step * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f16/i16 (SSV/MSV bytes held exactly, Viterbi words) + f32 (Forward/Backward)", "data": "synthetic",
+           "config": {"workload": "configs[%d]: full lineage_wf marker DB (2000 synthetic profiles = checkm.hmm, + 43 = phylo.hmm) x %d bins of U[1500,6000] ORFs; tree pass "
+                                  "(43 models, every bin) + analyze pass (per-bin model subsets from a Lineage marker file: marker genes of the bin's lineage chain + clan "
+                                  "expansion, 300-1500 models) + qa table, through MarkerGeneFinder.find x2 -> ResultsParser.analyseResults -> printSummary (main.py:969-982)"
+                                  % (2 if world == 1 else 3, nbins),
+                      "bins_total": nbins, "parallelism": "bins sharded over %d GPU(s) by MarkerGeneFinder.find (file size x models); 1 all_gather of QA rows" % world,
+                      "steps_note": "one step = all %d bins; %d step(s) fit the %.0f s budget of the timed region (estimated %.1f s per step from the warm pass)" % (nbins, steps, args.budget_seconds, est)},
+           "residue_hmm_per_s": residue_hmm / per_step, "residue_hmm_per_step": residue_hmm,
+           "first_pass_s": first_pass_s, "first_pass_bins": warm,
+           "parts_s_rank0": parts, "roofline": roof, "roofline_valu": valu, "stage_pairs": stage_pairs(tot), "ssv_ms_max_rank": ssv_ms,
+           "gpu_host_split_s_rank0": {"ssv_kernels": tot.get("ms_ssv", 0.0) / 1e3, "search_calls_sum": tot.get("ms_total", 0.0) / 1e3,
+                                      "ingest": tot.get("ingest_s", 0.0), "search": tot.get("search_s", 0.0), "write": tot.get("write_s", 0.0),
+                                      "tree_find": parts["tree_find_s"], "analyze_find": parts["analyze_find_s"], "qa": parts["qa_s"],
+                                      "note": "ingest/search/write are summed over the two scan lanes (they overlap in time); tree_find + analyze_find + qa = the step"},
+           "searches_rank0": int(tot.get("searches", 0)), "cascade_fallback_lanes_rank0": int(tot.get("cascade_fallback_lanes", 0)),
+           "setup_s": {"world_and_files": t_setup}}
+    if emu:
+        out["emulated_rank"] = "%d/%d" % emu
+        out["metric"] += " -- EMULATION of rank %d of %d on one GPU (shard of the bins, all-bins host work, no collective)" % emu
+        return out
+    if world == 1:
+        if not args.no_emulation:
+            # rank 0 of 8 on this GPU: what configs[3] costs a rank (its shard on the device + every piece of all-bins host work)
+            os.environ["CKM_EMULATE_RANK"] = "0/8"
+            try:
+                lineage_pass(w, binIds, files, lin, os.path.join(workdir, "cfg3_emu"), rank)
+                t0 = time.perf_counter()
+                eparts, etot = lineage_pass(w, binIds, files, lin, os.path.join(workdir, "cfg3_emu"), rank)
+                env.sync()
+                ewall = time.perf_counter() - t0
+                out["emulated_rank0_of_8"] = {"wall_s": ewall, "projected_bins_per_hour_8gpu": nbins / ewall * 3600.0, "parts_s": eparts,
+                                              "ssv_kernels_s": etot.get("ms_ssv", 0.0) / 1e3, "searches": int(etot.get("searches", 0)),
+                                              "note": "this GPU as rank 0 of 8: LPT shard of the %d bins (dist.shard_bins), all-bins host work included, no collective and "
+                                                      "no contention for the shared output directory -- a projection, not a measurement of configs[3]" % nbins}
+            finally:
+                del os.environ["CKM_EMULATE_RANK"]
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_cfg3(w, binIds, files, lin, args.cpu_baseline_seconds, args.cpu_baseline_threads)
+        else:
+            out["cpu_baseline"] = None
+        if not args.no_cfg2:
+            from checkm_amd import markerGeneFinder as mgf
+            mgf.release_scan()
+            import copy
+            a2 = copy.copy(args)
+            a2.steps, a2.warmup, a2.lineage_bins, a2.no_cpu_baseline, a2.scaling, a2.pipeline, a2.bins, a2.orfs = 5, 2, 0, True, "weak", 1, 100, 2000
+            c2 = bench_cfg2(a2, env)
+            out["cfg2"] = {k: c2[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "steady_state", "value_from_host", "gcups_ssv", "roofline",
+                                              "roofline_valu", "step_utilisation", "stages_ms", "step_parts_ms", "stage_pairs", "rows")}
+    else:
+        out["cpu_baseline"] = None
+    return out
 
 
 if __name__ == "__main__":

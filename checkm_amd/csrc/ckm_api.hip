@@ -141,7 +141,7 @@ extern "C" int ckm_profiles_load(ckm_ctx *ctx, const char *hmm_path, ckm_profile
       d.bt00 = hp.bt00; d.bt01 = hp.bt01; d.bt10 = hp.bt10; d.bt11 = hp.bt11; d.bpi0 = hp.bpi0; d.bpi1 = hp.bpi1;
       for (int x = 0; x < NROWS; ++x) d.beo1[x] = hp.beo1[x];
       d.thr_msv_f1 = hp.thr_msv_f1; d.thr_msv_f2 = hp.thr_msv_f2; d.thr_vit_f2 = hp.thr_vit_f2; d.thr_fwd_f3 = hp.thr_fwd_f3;
-      d.ssv_tbl = upload(p.get(), hp.ssv_tbl); d.rbv = upload(p.get(), hp.rbv); d.vit_e = upload(p.get(), hp.vit_e);
+      d.ssv_tbl = upload(p.get(), hp.ssv_tbl); d.ssv_tbl_h = upload(p.get(), hp.ssv_tbl_h); d.rbv = upload(p.get(), hp.rbv); d.vit_e = upload(p.get(), hp.vit_e);
       d.vit_t = upload(p.get(), hp.vit_t); d.rf = upload(p.get(), hp.rf); d.ftr = upload(p.get(), hp.ftr);
       p->dm.push_back(d);
       p->maxMp = std::max(p->maxMp, hp.fbQ * NL);

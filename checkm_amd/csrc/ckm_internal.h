@@ -46,6 +46,7 @@ struct HostProfile {
   float scale_b = 0;
   std::vector<uint8_t> rbv;       // [KP][M+1]
   int ssvQ = 0;                   // packed i16x2 registers per lane (16 lanes per sequence): ceil(M/32) rounded to an instantiated size
+  std::vector<uint16_t> ssv_tbl_h; // the same image as IEEE half bits of (bias - cost)/256
   std::vector<int16_t> ssv_tbl;   // LDS image: [NROWS][ssvQg][16 lanes][4 regs][2 halves]
   // Viterbi filter (signed words, 1/500 bit); contiguous k, padded to vitQ*64
   int vitQH = 0;                  // packed registers per lane: lane z owns cells z*2QH.., register j = (cell j, cell j+QH)

@@ -20,7 +20,8 @@ struct DevModel {
   // filter thresholds (score space)
   float   thr_msv_f1, thr_msv_f2, thr_vit_f2, thr_fwd_f3;
   // tables in HBM
-  const int16_t *ssv_tbl;   // [Qg][30][16][8]
+  const int16_t *ssv_tbl;   // [Qg][30][16][8]  bias - cost as int16 (exact MSV kernel, CKM_SSV=i16)
+  const uint16_t *ssv_tbl_h; // same layout, (bias - cost)/256 as IEEE half bits (ssv_kernel_h)
   const uint8_t *rbv;       // [29][M+1]
   const uint32_t *vit_e;    // [30][vitQH][64] packed emission words (cell j | cell j+QH of each lane)
   const uint32_t *vit_t;    // [8][vitQH][64]  packed transition words: BM MM IM DM (into) MD MI II DD (from)

@@ -234,6 +234,17 @@ int ssv_Q_for(int M) {
   return -1;
 }
 
+// IEEE binary16 bits of k/256 for an integer |k| <= 2047 (exact: k has at most 11 significant bits)
+static uint16_t half_bits_of_256th(int k) {
+  if (k == 0) return 0;
+  const uint16_t sign = k < 0 ? 0x8000u : 0u;
+  unsigned a = (unsigned)(k < 0 ? -k : k);
+  int e = 0;
+  while ((a >> (e + 1)) != 0) ++e;                 // a = 1.xxx * 2^e
+  const unsigned frac = (a << (10 - e)) & 0x3ffu;  // e <= 10
+  return (uint16_t)(sign | (unsigned)((e - 8 + 15) << 10) | frac);
+}
+
 static uint8_t byte_cost(float scale_b, float sc) {
   sc = -1.0f * roundf(scale_b * sc);
   return (sc > 255.f) ? 255 : (uint8_t)(int)sc;
@@ -325,6 +336,8 @@ HostProfile configure_profile(const HostHMM &h) {
             const size_t idx = (((size_t)(q / 4) * NROWS + x) * 16 + z) * 8 + (size_t)(q % 4) * 2 + hh;
             p.ssv_tbl[idx] = (int16_t)(p.bias_b - cost);
           }
+    p.ssv_tbl_h.resize(p.ssv_tbl.size());
+    for (size_t i = 0; i < p.ssv_tbl.size(); ++i) p.ssv_tbl_h[i] = half_bits_of_256th(p.ssv_tbl[i]);
   }
   // ---- Viterbi filter ----
   {

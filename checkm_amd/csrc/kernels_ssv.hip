@@ -24,6 +24,8 @@
 // field) and 2 packed-i16 VALU ops per register (v_pk_add_i16 clamp, v_pk_max_i16); per row the
 // overhead on top of 2Q is 3 VALU ops (address, DPP move, alignbit) plus a quarter op of chunk bookkeeping.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
 #include "dev_types.h"
 
 namespace ckm {
@@ -137,6 +139,118 @@ __global__ void __launch_bounds__(Q > 40 ? 512 : 1024) ssv_kernel(const SsvBlock
     m = max(m, __shfl_xor(m, 4, 16));
     m = max(m, __shfl_xor(m, 8, 16));
     if (valid && z == 0) maxv[w.pair_start + li] = (uint16_t)m;
+  }
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+// Round 3: the same recurrence in packed HALF floats, 1.5 VALU ops per register per row instead of 2.
+// A byte score k (0..255, and 256 = "saturated") is held as the f16 value k/256: every such value, and every sum of two of them,
+// is exact in f16 (11 significant bits), so this is still the integer arithmetic.  v_pk_add_f16 with the clamp modifier clamps to
+// [0, 1]: the floor at 0 of the recurrence AND the byte ceiling (a score that reaches 256 units has overflowed the byte MSV, which
+// passes the filter whatever happens afterwards -- msv_finish_kernel's overflow test fires for every Smax >= 255 - bias - xB).
+// gfx950 has v_pk_maximum3_f16, so the running maximum is taken once per TWO rows: Smax = max3(Smax, U(row a), U(row b)).
+// Rows go in pairs; sequences are padded to a multiple of 16 rows with the all-impossible symbol, so no remainder exists.
+// --------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 pk_add_h_clamp(u32 a, u32 b) { u32 r; asm("v_pk_add_f16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ u32 pk_max3_h(u32 a, u32 b, u32 c) { u32 r; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+template <int Q>
+__device__ __forceinline__ void ssv_load_row(u32 (&e)[((Q + 3) / 4) * 4], u32 addr) {
+  constexpr int Qg = (Q + 3) / 4;
+#pragma unroll
+  for (int g = 0; g < Qg; ++g) {
+    const u32x4 v = *(lds_cu4 *)(size_t)(addr + (u32)(g * SSV_GSTRIDE));
+    e[g * 4 + 0] = v.x; e[g * 4 + 1] = v.y; e[g * 4 + 2] = v.z; e[g * 4 + 3] = v.w;
+  }
+}
+
+template <int Q>
+__device__ __forceinline__ void ssv_rows2_h(u32 (&U)[Q], u32 &xE, u32 &prev, u32 addr_a, u32 addr_b) {
+  constexpr int Qg = (Q + 3) / 4;
+  u32 e[Qg * 4];
+  // row a: in place, no maximum
+  ssv_load_row<Q>(e, addr_a);
+  {
+    const u32 last = U[Q - 1];
+    prev = (u32)__builtin_amdgcn_update_dpp((int)prev, (int)last, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+    const u32 carry = __builtin_amdgcn_alignbit(last, prev, 16);
+#pragma unroll
+    for (int q = Q - 1; q >= 1; --q) U[q] = pk_add_h_clamp(U[q - 1], e[q]);
+    U[0] = pk_add_h_clamp(carry, e[0]);
+  }
+  // row b: U[q] still holds row a's value when its successor is formed, so one max3 covers both rows
+  ssv_load_row<Q>(e, addr_b);
+  {
+    const u32 last = U[Q - 1];
+    prev = (u32)__builtin_amdgcn_update_dpp((int)prev, (int)last, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+    const u32 carry = __builtin_amdgcn_alignbit(last, prev, 16);
+#pragma unroll
+    for (int q = Q - 1; q >= 1; --q) {
+      const u32 v = pk_add_h_clamp(U[q - 1], e[q]);
+      xE = pk_max3_h(xE, U[q], v);
+      U[q] = v;
+    }
+    const u32 v = pk_add_h_clamp(carry, e[0]);
+    xE = pk_max3_h(xE, U[0], v);
+    U[0] = v;
+  }
+}
+
+template <int Q>
+__global__ void __launch_bounds__(Q > 40 ? 512 : 1024) ssv_kernel_h(const SsvBlockWork *__restrict__ work, const DevModel *__restrict__ models,
+                           const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
+                           const int32_t *__restrict__ seq_len, const uint32_t *__restrict__ lists,
+                           uint16_t *__restrict__ maxv) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int Qg = (Q + 3) / 4;
+  constexpr int ROWB = Qg * 256;
+  lds_image_at_zero(smem);
+  const SsvBlockWork w = work[blockIdx.x];
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(models[w.model].ssv_tbl_h);
+    uint4 *dst = reinterpret_cast<uint4 *>(smem);
+    for (int i = threadIdx.x; i < SSV_NROWS * ROWB / 16; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int seg = lane >> 4, z = lane & 15;
+  const u32 lane_off = (u32)z * 16u;
+  for (u32 g = wave; g * 4 < w.count; g += nwaves) {
+    const u32 li = g * 4 + seg;
+    const bool valid = li < w.count;
+    const u32 sid = valid ? lists[w.list_start + li] : 0u;
+    const int L = valid ? seq_len[sid] : 0;
+    const uint8_t *rp = res + seq_off[sid];
+    int Lmax = __builtin_amdgcn_readlane(L, 0);
+    Lmax = max(Lmax, __builtin_amdgcn_readlane(L, 16));
+    Lmax = max(Lmax, __builtin_amdgcn_readlane(L, 32));
+    Lmax = max(Lmax, __builtin_amdgcn_readlane(L, 48));
+    u32 U[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) U[q] = 0u;
+    u32 xE = 0u, prev = 0u;
+    const int nchunk = (Lmax + 15) >> 4;
+    const uint4 padv = make_uint4(PAD4, PAD4, PAD4, PAD4);
+    uint4 cur = padv;
+    if (0 < L) cur = *reinterpret_cast<const uint4 *>(rp);
+    for (int c = 0; c < nchunk; ++c) {
+      uint4 nxt = padv;
+      if ((c + 1) * 16 < L) nxt = *reinterpret_cast<const uint4 *>(rp + (c + 1) * 16);
+#define CKM_SSV_WORD(wd)                                                                     \
+  ssv_rows2_h<Q>(U, xE, prev, ssv_addr<0>(wd, lane_off), ssv_addr<1>(wd, lane_off));           \
+  ssv_rows2_h<Q>(U, xE, prev, ssv_addr<2>(wd, lane_off), ssv_addr<3>(wd, lane_off));
+      CKM_SSV_WORD(cur.x) CKM_SSV_WORD(cur.y) CKM_SSV_WORD(cur.z) CKM_SSV_WORD(cur.w)
+#undef CKM_SSV_WORD
+      cur = nxt;
+    }
+    // k/256 back to k: the f16 bit patterns of non-negative values order like integers, so the maximum is taken on the bits
+    u32 mb = max(xE & 0xffffu, xE >> 16);
+    mb = max(mb, (u32)__shfl_xor((int)mb, 1, 16));
+    mb = max(mb, (u32)__shfl_xor((int)mb, 2, 16));
+    mb = max(mb, (u32)__shfl_xor((int)mb, 4, 16));
+    mb = max(mb, (u32)__shfl_xor((int)mb, 8, 16));
+    const _Float16 hv = __builtin_bit_cast(_Float16, (unsigned short)mb);
+    if (valid && z == 0) maxv[w.pair_start + li] = (uint16_t)(int)((float)hv * 256.0f);
   }
 }
 
@@ -285,11 +399,22 @@ int launch_msv(int Q, int nblocks, hipStream_t stream, const SsvBlockWork *work,
   case QV:                                                                                                       \
     if ((size_t)SSV_NROWS * ((QV + 3) / 4) * 256 > 48 * 1024) {                                                  \
       static bool attr_set = false;                                                                              \
-      if (!attr_set) { (void)hipFuncSetAttribute((const void *)ssv_kernel<QV>, hipFuncAttributeMaxDynamicSharedMemorySize, SSV_NROWS * ((QV + 3) / 4) * 256); attr_set = true; } \
+      if (!attr_set) {                                                                                           \
+        (void)hipFuncSetAttribute((const void *)ssv_kernel<QV>, hipFuncAttributeMaxDynamicSharedMemorySize, SSV_NROWS * ((QV + 3) / 4) * 256);   \
+        (void)hipFuncSetAttribute((const void *)ssv_kernel_h<QV>, hipFuncAttributeMaxDynamicSharedMemorySize, SSV_NROWS * ((QV + 3) / 4) * 256); \
+        attr_set = true;                                                                                         \
+      }                                                                                                          \
     }                                                                                                            \
-    hipLaunchKernelGGL(ssv_kernel<QV>, dim3(nblocks), dim3(threads), (size_t)SSV_NROWS * ((QV + 3) / 4) * 256, stream, \
-                       work, models, res, seq_off, seq_len, lists, maxv);                                        \
+    if (g_ssv_half)                                                                                              \
+      hipLaunchKernelGGL(ssv_kernel_h<QV>, dim3(nblocks), dim3(threads), (size_t)SSV_NROWS * ((QV + 3) / 4) * 256, stream, \
+                         work, models, res, seq_off, seq_len, lists, maxv);                                      \
+    else                                                                                                         \
+      hipLaunchKernelGGL(ssv_kernel<QV>, dim3(nblocks), dim3(threads), (size_t)SSV_NROWS * ((QV + 3) / 4) * 256, stream, \
+                         work, models, res, seq_off, seq_len, lists, maxv);                                      \
     break;
+
+// CKM_SSV=i16 keeps round 1's packed-integer row (2 ops per register per row); the default is the packed-half row (1.5).
+static const bool g_ssv_half = [] { const char *e = getenv("CKM_SSV"); return !(e && strcmp(e, "i16") == 0); }();
 
 int launch_ssv(int Q, int nblocks, int threads, hipStream_t stream, const SsvBlockWork *work, const DevModel *models,
                const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const uint32_t *lists, uint16_t *maxv) {

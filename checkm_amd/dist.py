@@ -38,7 +38,21 @@ def pack_qa_rows(bin_ids, n_markers, n_sets, hist, comp, cont):
     return rows
 
 
+def emulated():
+    """CKM_EMULATE_RANK=R/W: this single process behaves as rank R of W everywhere the product asks for its rank -- it scans rank R's
+    shard and does all the all-bins host work of a rank -- but no process group exists and the gather returns the local rows
+    (bench.py --emulate-rank: what configs[3] costs one rank, measured on one GPU)."""
+    e = os.environ.get("CKM_EMULATE_RANK")
+    if not e:
+        return None
+    r, w = e.split("/")
+    return int(r), int(w)
+
+
 def env_rank():
+    emu = emulated()
+    if emu is not None:
+        return emu[0], int(os.environ.get("LOCAL_RANK", "0")), emu[1]
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
@@ -46,6 +60,8 @@ def init_process_group(backend=None):
     """torch.distributed over RCCL ('nccl' on ROCm) when GPUs are used, gloo for the CPU tests."""
     import torch
     import torch.distributed as dist
+    if emulated() is not None:
+        return None
     rank, local_rank, world = env_rank()
     if world == 1 and not dist.is_initialized():
         return None
@@ -83,6 +99,8 @@ def barrier():
 
 def world_size():
     import torch.distributed as dist
+    if emulated() is not None:
+        return emulated()[1]
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 

@@ -32,7 +32,9 @@ PROFILE_CACHE = {}
 
 def profiles_for(ctx, db):
     st = os.stat(db)
-    key = (os.path.abspath(db), st.st_mtime_ns, st.st_size, id(ctx))
+    # keyed by DEVICE, not context: the tables are read-only device memory, so the two contexts find() alternates between share one
+    # resident copy (and one parse of the text)
+    key = (os.path.abspath(db), st.st_mtime_ns, st.st_size, ctx.device)
     p = PROFILE_CACHE.get(key)
     if p is None or not p.h:
         for k in [k for k in PROFILE_CACHE if k[0] == key[0] and k[3] == key[3]]:      # the file changed: drop the stale copy unless a scan still uses it
@@ -165,7 +167,9 @@ class MarkerGeneFinder(object):
                         prodigal.run(binFile, bNucORFs)
                     return prodigal.aaGeneFile
                 from concurrent.futures import ThreadPoolExecutor
-                with ThreadPoolExecutor(max_workers=max(1, int(self.totalThreads))) as pool:
+                # (the mirror runs the two translation tables of a bin side by side: half as many bins at a time keeps `threads` processes busy)
+                per_bin = 2 if getattr(runner, '__module__', '') == 'checkm_amd.prodigal' else 1
+                with ThreadPoolExecutor(max_workers=max(1, int(self.totalThreads) // per_bin)) as pool:
                     called = list(pool.map(call, todo))
                 for t, aa in zip(todo, called):
                     if os.path.abspath(aa) != os.path.abspath(t[3]):
@@ -287,6 +291,9 @@ class MarkerGeneFinder(object):
                 where[binIds[i]] = (k, b)
         key = (os.path.abspath(outDir), tableOut)
         if key in SCAN_CACHE:
+            mod = sys.modules.get("checkm_amd.resultsParser")
+            if mod is not None:
+                mod.materialize_lazy_hits()       # hit lists handed out lazily still point into the scan that is replaced here
             old = SCAN_CACHE.pop(key)
             for part in old["parts"]:
                 part["hits"].close(); part["seqs"].close()

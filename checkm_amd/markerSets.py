@@ -96,7 +96,9 @@ class BinMarkerSets(object):
         f = line.split('\t')
         for i in range(int(f[1])):
             uid, lineage, ngen, sets = f[4 * i + 2], f[4 * i + 3], int(f[4 * i + 4]), _parse_marker_sets(f[4 * i + 5].strip())
-            self.markerSets.append(MarkerSet(uid, lineage, ngen, [set(s) for s in sets]))
+            ms = MarkerSet(uid, lineage, ngen, [set(s) for s in sets])
+            ms._src = sets                 # the cached literal this set was built from: bins of one lineage share its flattened form
+            self.markerSets.append(ms)
 
 
 @functools.lru_cache(maxsize=8192)
@@ -146,6 +148,33 @@ class MarkerSet(object):
         self.lineageStr = lineageStr
         self.numGenomes = numGenomes
         self.markerSet = markerSet
+        self._src = None            # identity of the parsed literal (shared by the bins of a lineage) while no marker was removed
+        self._flat = None
+
+    def flat(self, keys):
+        """(key id of every marker in set order, 1 where a marker occurs for the first time, length of every set) as numpy arrays,
+        for the batched counting of ResultsParser.batchedGeneCounts.  `keys`: the qa.KeyTable of the reduction the ids refer to."""
+        cache = keys.__dict__.setdefault("_flat_cache", {})
+        ent = cache.get(id(self._src)) if self._src is not None else None
+        if ent is not None and ent[0] is self._src:
+            return ent[1]
+        if self._flat is not None and self._flat[0] is keys and self._flat[1] == self._version():
+            return self._flat[2]
+        ids, first, lens, seen = [], [], [], set()
+        for st in self.markerSet:
+            for m in st:
+                ids.append(keys.get(m))
+                first.append(0 if m in seen else 1)
+                seen.add(m)
+            lens.append(len(st))
+        out = (np.asarray(ids, dtype=np.int64), np.asarray(first, dtype=np.uint8), np.asarray(lens, dtype=np.int64))
+        if self._src is not None:
+            cache[id(self._src)] = (self._src, out)
+        self._flat = (keys, self._version(), out)
+        return out
+
+    def _version(self):
+        return (id(self.markerSet), len(self.markerSet), sum(len(s) for s in self.markerSet))
 
     def __repr__(self):
         return str(self.UID) + '\t' + self.lineageStr + '\t' + str(self.numGenomes) + '\t' + str(self.markerSet)
@@ -166,12 +195,17 @@ class MarkerSet(object):
         return genes
 
     def removeMarkers(self, markersToRemove):
-        kept = []
+        kept, changed = [], False
         for ms in self.markerSet:
             rest = ms - markersToRemove
+            if len(rest) != len(ms):
+                changed = True
             if rest:
                 kept.append(rest)
         self.markerSet = kept
+        if changed:
+            self._src = None
+        self._flat = None
 
     def genomeCheck(self, hits, bIndividualMarkers):
         """Completeness / contamination; counting on the device, float64 division in the reference's order."""

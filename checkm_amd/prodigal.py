@@ -15,6 +15,7 @@ The gene finder itself is still the external `prodigal` binary: a GPU ORF caller
 import logging
 import os
 import shutil
+import signal
 import stat
 import subprocess
 import sys
@@ -101,18 +102,32 @@ class ProdigalRunner(object):
         procedure = 'meta' if totalBases < 100000 else 'single'
         # table 11 and table 4 side by side; table 4 is only waited for (and only kept) when table 11's density leaves it a chance
         cmds = {t: self._cmd(procedure, t, prodigal_input, bNucORFs) for t in (4, 11)}
-        procs = {t: subprocess.Popen(cmds[t], shell=True) for t in (4, 11)}
+        # each in its own session: the command line is a shell pipeline (redirections, as the reference writes it), so stopping table 4
+        # early has to reach the prodigal process behind the shell -- the whole process group is signalled
+        procs = {t: subprocess.Popen(cmds[t], shell=True, start_new_session=True) for t in (4, 11)}
+
+        def stop(proc):
+            if proc.poll() is None:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    pass
+            proc.wait()
         density = {}
-        self._finish_table(11, procs[11].wait() << 8, cmds[11], procedure)          # (os.system's encoding of the exit status, as the reference reports it)
-        density[11] = self._density(11, seqs, totalBases)
-        if density[11] >= 0.95:
-            procs[4].kill(); procs[4].wait()
-            density[4] = None
-            best = 11
-        else:
-            self._finish_table(4, procs[4].wait() << 8, cmds[4], procedure)
-            density[4] = self._density(4, seqs, totalBases)
-            best = 4 if (density[4] - density[11] > 0.05) and density[4] > 0.7 else 11
+        try:
+            self._finish_table(11, procs[11].wait() << 8, cmds[11], procedure)          # (os.system's encoding of the exit status, as the reference reports it)
+            density[11] = self._density(11, seqs, totalBases)
+            if density[11] >= 0.95:
+                stop(procs[4])
+                density[4] = None
+                best = 11
+            else:
+                self._finish_table(4, procs[4].wait() << 8, cmds[4], procedure)
+                density[4] = self._density(4, seqs, totalBases)
+                best = 4 if (density[4] - density[11] > 0.05) and density[4] > 0.7 else 11
+        finally:
+            for t in (4, 11):            # (an error exit above must not leave a gene finder running)
+                stop(procs[t])
         shutil.copyfile(self.aaGeneFile + '.' + str(best), self.aaGeneFile)
         shutil.copyfile(self.gffFile + '.' + str(best), self.gffFile)
         if bNucORFs:

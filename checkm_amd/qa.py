@@ -131,6 +131,18 @@ class QAPlan(object):
         self.n_markers = np.asarray(self.n_markers, dtype=np.int64)
         self.n_sets = np.asarray(self.n_sets, dtype=np.int64)
 
+    def with_empty_bins(self, nbins):
+        """The same model tables for `nbins` bins without marker sets (the reduction of ResultsParser: sets are counted later)."""
+        import copy
+        p = copy.copy(self)
+        p.nbins = nbins
+        p.set_off = np.zeros(nbins + 1, dtype=np.uint32)
+        p.marker_off = np.zeros(1, dtype=np.uint32)
+        p.marker_key = np.zeros(1, dtype=np.uint32)
+        p.n_markers = np.zeros(nbins, dtype=np.int64)
+        p.n_sets = np.zeros(nbins, dtype=np.int64)
+        return p
+
     @classmethod
     def for_hmm_models(cls, profiles, bin_models, clans=None, nested=None):
         """HMM_MODELS_SET shape (markerSets.py:265-274): one set holding every accession of the bin's models."""

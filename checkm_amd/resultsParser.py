@@ -10,6 +10,7 @@ import ast
 import logging
 import os
 import sys
+import weakref
 
 import numpy as np
 
@@ -57,7 +58,8 @@ class ResultsManager(object):
     def __init__(self, binId, models, bIgnoreThresholds=False, evalueThreshold=DefaultValues.E_VAL,
                  lengthThreshold=DefaultValues.LENGTH, bSkipPseudoGeneCorrection=False, binStats=None):
         self.binId = binId
-        self.markerHits = {}
+        self._mh = {}              # markerHits once somebody looked at it (or assigned it)
+        self._lazy = None          # (QAResult, local bin, KeyTable, row -> HmmerHitDOM) while nobody has: see the markerHits property
         self.bIgnoreThresholds = bIgnoreThresholds
         self.evalueThreshold = evalueThreshold
         self.lengthThreshold = lengthThreshold
@@ -65,9 +67,41 @@ class ResultsManager(object):
         self.models = models
         self.binStats = binStats
         self._raw = []
-        self._counts = {}          # (id(markerSet), bIndividualMarkers) -> (len(markerHits), [n0..n5+, comp, cont]) from the batched count
+        self._counts = {}          # bIndividualMarkers -> (markerSet object, [n0..n5+, comp, cont]) from the batched count; only trusted
+                                   # while markerHits has never been handed out (nobody can have changed a hit list)
         self.remote = False        # True on rank 0 for a bin another rank scanned: only its gathered QA row is known here
         self.het = None            # strain heterogeneity gathered from the owning rank
+
+    @property
+    def markerHits(self):
+        """{marker id: [HmmerHitDOM]} as the reference holds it (resultsParser.py:330).  After a batched reduction the dict is built
+        the first time somebody asks for it: the QA table (formats 1 and 2) never does -- it is counted from the kept rows' key ids."""
+        if self._lazy is not None:
+            res, lb, keys, mk = self._lazy
+            self._lazy = None
+            self._counts = {}
+            self._mh = _marker_hits_from(res, lb, keys, mk, lazy=True)
+        return self._mh
+
+    @markerHits.setter
+    def markerHits(self, value):
+        self._lazy = None
+        self._counts = {}
+        self._mh = value
+
+    def _set_lazy(self, res, lb, keys, row_to_hit):
+        self._lazy = (res, lb, keys, row_to_hit)
+        self._counts = {}
+        _LIVE_LAZY.append(weakref.ref(self))
+
+    def materialize(self):
+        return self.markerHits
+
+    def _cached_counts(self, markerSet, bIndividualMarkers):
+        hit = self._counts.get(bool(bIndividualMarkers))
+        if hit is not None and hit[0] is markerSet and (self._lazy is not None or self.remote):
+            return list(hit[1])
+        return None
 
     def vetHit(self, hit):
         """One row against its model's cutoffs (resultsParser.py:340-377); the batched form of this test runs inside ckm_reduce.
@@ -130,15 +164,15 @@ class ResultsManager(object):
         return ret
 
     def geneCountsForSelectedMarkerSet(self, binMarkerSets, bIndividualMarkers):
-        return self.geneCounts(binMarkerSets.selectedMarkerSet(), self.markerHits, bIndividualMarkers)
+        sel = binMarkerSets.selectedMarkerSet()
+        row = self._cached_counts(sel, bIndividualMarkers)
+        if row is not None:
+            return row
+        return self.geneCounts(sel, self.markerHits, bIndividualMarkers)
 
     def geneCounts(self, markerSet, markerHits, bIndividualMarkers):
         """[n0, n1, n2, n3, n4, n5+, completeness, contamination] (resultsParser.py:513-537); counted on the device.  When
         ResultsParser.batchedGeneCounts has already counted this marker set for all bins in one launch, that row is returned."""
-        if markerHits is self.markerHits:
-            hit = self._counts.get((id(markerSet), bool(bIndividualMarkers)))
-            if hit is not None and hit[0] == len(markerHits):         # (out_format 4 inserts keys into the defaultdict: quirk Q11)
-                return list(hit[1])
         _pres, _mult, hist, _pt, _mt, _nm, empty_members = count_sets(markerSet.markerSet, markerHits)
         counts = [int(x) for x in hist]
         comp, cont = markerSet.genomeCheck(markerHits, bIndividualMarkers)
@@ -453,19 +487,26 @@ _LIVE_LAZY = []          # weak references to lazy lists whose rows still live i
 
 def materialize_lazy_hits():
     """Called before a resident scan is released: lists that were never looked at take their hits now."""
-    import weakref  # noqa: F401
-    for ref in _LIVE_LAZY:
+    live = list(_LIVE_LAZY)
+    del _LIVE_LAZY[:]
+    for ref in live:                       # (a ResultsManager's dict first: that registers its lists, which are filled in next)
         lz = ref()
         if lz is not None:
             lz.materialize()
+    live = list(_LIVE_LAZY)
     del _LIVE_LAZY[:]
+    for ref in live:
+        lz = ref()
+        if lz is not None:
+            lz.materialize()
 
 
 def _marker_hits_from(res, b, keys, row_to_hit, lazy=False):
     """Rebuild ResultsManager.markerHits ({acc: [HmmerHitDOM]}) of bin b from the library's kept rows.
     A defaultdict, as PFAM.filterHitsFromSameClan returns one (pfam.py:94)."""
-    import weakref
     mh = defaultdict(list)
+    if len(_LIVE_LAZY) > 4096:
+        _LIVE_LAZY[:] = [r for r in _LIVE_LAZY if r() is not None]
     for i in range(int(res.kept_bin_off[b]), int(res.kept_bin_off[b + 1])):
         k = keys.names[int(res.kept_key[i])]
         if lazy:
@@ -607,6 +648,7 @@ class ResultsParser(object):
         for merged, members, _last in groups:
             mlist = [_Slot(a, hd["leng"], merged.get(a)) for a, hd in zip(slot_acc, profiles.headers)]
             keys, acc, qlen, thr, clans, nested = _plan_for_models(mlist)
+            plan0 = cqa.QAPlan(keys, acc, qlen, thr, [], clans, nested)
             by_part = {}
             for b in members:
                 pi, lb = ent["where"][b]
@@ -615,16 +657,17 @@ class ResultsParser(object):
                 part = ent["parts"][pi]
                 hits, seqs = part["hits"], part["seqs"]
                 nb = hits.nbins
-                plan = cqa.QAPlan(keys, acc, qlen, thr, [[] for _ in range(nb)], clans, nested)
+                plan = plan0.with_empty_bins(nb)
                 sel = np.zeros(nb, dtype=np.uint8)
                 for _b, lb in lst:
                     sel[lb] = 1
                 res = plan.reduce(runtime.get_ctx(), hits, seqs, ignore, evalue, length, skip_pseudo, skip_adj, False, sel)
+                to_hit = lambda r, h=hits, q=seqs: _hit_from_columns(h, q, profiles, r)
                 for b, lb in lst:
                     rm = mk(b)
-                    rm.markerHits = _marker_hits_from(res, lb, keys, lambda r, h=hits, q=seqs: _hit_from_columns(h, q, profiles, r), lazy=True)
+                    rm._set_lazy(res, lb, keys, to_hit)
                     self.results[b] = rm
-                res.close()
+                res.close()                  # (the columns were copied out: QAResult keeps numpy arrays)
 
     # tables written by an earlier command: the library parses the text of all bins at once (ckm_tables_read) and reduces bins
     # that share their model view in one call; rows become HmmerHitDOM objects only for the hits that are kept
@@ -704,36 +747,54 @@ class ResultsParser(object):
     def batchedGeneCounts(self, binIdToBinMarkerSets, bIndividualMarkers, binIds=None):
         """geneCounts of the SELECTED marker set of every bin in ONE ckm_count_sets launch (the reference counts bin by bin in Python,
         resultsParser.py:513-537 + markerSets.py:206-238); the float64 division is finished here in the reference's accumulation
-        order.  The rows are left with each ResultsManager, whose geneCounts() returns them.  Returns {binId: [n0..n5+, comp, cont]}."""
+        order.  The rows are left with each ResultsManager, whose geneCounts() returns them.  Returns {binId: [n0..n5+, comp, cont]}.
+        A bin whose hit dict nobody has looked at yet is counted from the key ids of its kept rows (numpy gathers over the marker
+        set's flattened form, MarkerSet.flat); a bin whose dict exists is counted from the dict, whatever its owner did to it."""
         import ctypes as C
         from checkm_amd import _lib
         bins = [b for b in (binIds if binIds is not None else sorted(self.results)) if not self.results[b].remote]
         if not bins:
             return {}
-        set_off, marker_off, counts, first, member, sets_of = [0], [0], [], [], [], []
+        c_parts, f_parts, m_parts, len_parts, nset, nmark, sets_of = [], [], [], [], [], [], []
         for b in bins:
             ms = binIdToBinMarkerSets[b].selectedMarkerSet()
-            hits = self.results[b].markerHits
-            seen = set()
-            for st in ms.markerSet:
-                for m in st:
-                    present = m in hits
-                    counts.append(len(hits[m]) if present else 0)
-                    member.append(1 if present else 0)
-                    first.append(0 if m in seen else 1)
-                    seen.add(m)
-                marker_off.append(len(counts))
-            set_off.append(len(marker_off) - 1)
+            rm = self.results[b]
             sets_of.append(ms)
-        nb, nsets = len(bins), len(marker_off) - 1
-        c = np.array(counts or [0], dtype=np.int32); fa = np.array(first or [0], dtype=np.uint8); mem = np.array(member or [0], dtype=np.int32)
-        so = np.array(set_off, dtype=np.uint32); mo = np.array(marker_off, dtype=np.uint32); mk = np.arange(max(1, len(counts)), dtype=np.uint32)
+            if rm._lazy is not None:
+                res, lb, keys, _mk = rm._lazy
+                ids, first, lens = ms.flat(keys)
+                o0, o1 = int(res.kept_bin_off[lb]), int(res.kept_bin_off[lb + 1])
+                kc = np.bincount(res.kept_key[o0:o1], minlength=len(keys.names)) if o1 > o0 else np.zeros(len(keys.names), dtype=np.int64)
+                cnt = kc[ids].astype(np.int32)
+                c_parts.append(cnt); m_parts.append((cnt > 0).astype(np.int32)); f_parts.append(first); len_parts.append(lens)
+            else:
+                hits = rm.markerHits
+                counts, member, first, seen, lens = [], [], [], set(), []
+                for st in ms.markerSet:
+                    for m in st:
+                        present = m in hits
+                        counts.append(len(hits[m]) if present else 0)
+                        member.append(1 if present else 0)          # (a key with an empty list counts as present: quirk Q11)
+                        first.append(0 if m in seen else 1)
+                        seen.add(m)
+                    lens.append(len(st))
+                c_parts.append(np.asarray(counts, dtype=np.int32)); m_parts.append(np.asarray(member, dtype=np.int32))
+                f_parts.append(np.asarray(first, dtype=np.uint8)); len_parts.append(np.asarray(lens, dtype=np.int64))
+            nset.append(len(len_parts[-1])); nmark.append(len(c_parts[-1]))
+        nb = len(bins)
+        cat = lambda parts, dt: np.ascontiguousarray(np.concatenate(parts + [np.zeros(1, dtype=dt)]).astype(dt, copy=False))
+        c, fa, mem, lens_all = cat(c_parts, np.int32), cat(f_parts, np.uint8), cat(m_parts, np.int32), cat(len_parts, np.int64)
+        so = np.zeros(nb + 1, dtype=np.uint32); np.cumsum(nset, out=so[1:])
+        nsets = int(so[-1])
+        mo = np.zeros(nsets + 1, dtype=np.uint32); np.cumsum(lens_all[:nsets], out=mo[1:])
+        mk = np.arange(max(1, int(mo[-1])), dtype=np.uint32)
         csr = _lib.MarkerSetsCSR(nb, so.ctypes.data, mo.ctypes.data, mk.ctypes.data)
         pres = np.zeros(max(1, nsets), dtype=np.int32); mult = np.zeros(max(1, nsets), dtype=np.int32)
         hist = np.zeros(nb * 6, dtype=np.int32); pt = np.zeros(nb, dtype=np.int32); mt = np.zeros(nb, dtype=np.int32)
         _lib._chk(_lib.load().ckm_count_sets(runtime.get_ctx().h, C.byref(csr), c.ctypes.data, fa.ctypes.data, pres.ctypes.data, mult.ctypes.data,
                                              hist.ctypes.data, pt.ctypes.data, mt.ctypes.data))
         out = {}
+        flen = lens_all.astype(np.float64)
         for k, b in enumerate(bins):
             ms = sets_of[k]
             s0, s1 = int(so[k]), int(so[k + 1])
@@ -742,16 +803,17 @@ class ResultsParser(object):
                 fk = fa[m0:m1].astype(bool)
                 n_member = int(mem[m0:m1][fk].sum())
                 empty = int(((mem[m0:m1] == 1) & (c[m0:m1] == 0) & fk).sum())
-                comp, cont = 100 * float(n_member) / ms.numMarkers(), 100 * float(int(mt[k]) - empty) / ms.numMarkers()
+                nmk = int(mo[s1] - mo[s0])
+                comp, cont = 100 * float(n_member) / nmk, 100 * float(int(mt[k]) - empty) / nmk
+            elif s1 > s0:
+                # comp += present/len(set) over the sets IN ORDER, in float64 (markerSets.py:219-236): cumsum adds left to right
+                comp = float(np.cumsum(pres[s0:s1] / flen[s0:s1])[-1])
+                cont = float(np.cumsum(mult[s0:s1] / flen[s0:s1])[-1])
+                comp, cont = 100 * comp / (s1 - s0), 100 * cont / (s1 - s0)
             else:
-                comp = cont = 0.0
-                for i, st in enumerate(ms.markerSet):
-                    comp += float(int(pres[s0 + i])) / len(st)
-                    cont += float(int(mult[s0 + i])) / len(st)
-                comp, cont = 100 * comp / len(ms.markerSet), 100 * cont / len(ms.markerSet)
+                comp, cont = 100 * 0.0 / len(ms.markerSet), 100 * 0.0 / len(ms.markerSet)       # (ZeroDivisionError, as the reference raises)
             row = [int(x) for x in hist[k * 6:k * 6 + 6]] + [comp, cont]
-            rm = self.results[b]
-            rm._counts[(id(ms), bool(bIndividualMarkers))] = (len(rm.markerHits), row)
+            self.results[b]._counts[bool(bIndividualMarkers)] = (ms, row)
             out[b] = row
         return out
 
@@ -776,7 +838,7 @@ class ResultsParser(object):
             rm = self._mk(b) if hasattr(self, "_mk") else ResultsManager(b, self.models[b])
             rm.remote = True
             ms = binIdToBinMarkerSets[b].selectedMarkerSet()
-            rm._counts[(id(ms), bool(bIndividualMarkers))] = (0, [int(x) for x in r[3:9]] + [float(r[9]), float(r[10])])
+            rm._counts[bool(bIndividualMarkers)] = (ms, [int(x) for x in r[3:9]] + [float(r[9]), float(r[10])])
             rm.het = float(r[11])
             self.results[b] = rm
 

@@ -50,6 +50,32 @@ OP2(k_dpp_row_shr, "v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf")
 OP3(k_perm, "v_perm_b32 %0, %0, %1, %2")
 OP3(k_sad_u8, "v_sad_u8 %0, %0, %1, %2")
 OP3(k_add3_u32, "v_add3_u32 %0, %0, %1, %2")
+// round 3: candidates for a 1.5-op SSV row (f16 holds k/256, k = 0..256, exactly; clamp = [0, 1] = the byte arithmetic's floor and ceiling)
+OP2(k_pk_add_f16_clamp, "v_pk_add_f16 %0, %0, %1 clamp")
+OP3(k_pk_maximum3_f16, "v_pk_maximum3_f16 %0, %0, %1, %2")
+OP3(k_pk_minimum3_f16, "v_pk_minimum3_f16 %0, %0, %1, %2")
+OP3(k_maximum3_f32, "v_maximum3_f32 %0, %0, %1, %2")
+OP3(k_max3_f32, "v_max3_f32 %0, %0, %1, %2")
+OP3(k_max3_i16, "v_max3_i16 %0, %0, %1, %2")
+OP2(k_pk_add_u16_clamp, "v_pk_add_u16 %0, %0, %1 clamp")
+OP2(k_pk_sub_u16_clamp, "v_pk_sub_u16 %0, %0, %1 clamp")
+OP2(k_pk_max_u16, "v_pk_max_u16 %0, %0, %1")
+OP3(k_pk_mad_i16, "v_pk_mad_i16 %0, %0, %1, %2")
+OP3(k_pk_fma_f16, "v_pk_fma_f16 %0, %0, %1, %2")
+// the two row bodies side by side: 2 rows x (add, max) in packed i16 against 2 rows x add + one max3 in packed f16
+#define MIX(name, body)                                                                                    \
+  __global__ void __launch_bounds__(256) name(unsigned *out, unsigned seed) {                               \
+    unsigned a[CH], m[CH];                                                                                  \
+    for (int c = 0; c < CH; ++c) { a[c] = seed + threadIdx.x * 7 + c * 0x01010101u; m[c] = a[c] ^ 0x5a5au; } \
+    for (int it = 0; it < ITERS / 2; ++it) {                                                                \
+      _Pragma("unroll") for (int c = 0; c < CH; ++c) { unsigned t; asm volatile(body : "+v"(a[c]), "+v"(m[c]), "=&v"(t) : "v"(a[(c + 1) % CH])); } \
+    }                                                                                                       \
+    unsigned r = 0;                                                                                         \
+    for (int c = 0; c < CH; ++c) r ^= a[c] ^ m[c];                                                          \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;                                                         \
+  }
+MIX(k_mix_i16, "v_pk_add_i16 %2, %0, %3 clamp\n v_pk_max_i16 %1, %1, %2\n v_pk_add_i16 %0, %2, %3 clamp\n v_pk_max_i16 %1, %1, %0")
+MIX(k_mix_f16, "v_pk_add_f16 %2, %0, %3 clamp\n v_pk_add_f16 %0, %2, %3 clamp\n v_pk_maximum3_f16 %1, %1, %2, %0")
 
 template <class F>
 double timeit(F launch) {
@@ -77,5 +103,17 @@ int main() {
   RUN(k_add_u32, "v_add_u32") RUN(k_max_i32, "v_max_i32") RUN(k_add_f32, "v_add_f32") RUN(k_mul_f32, "v_mul_f32") RUN(k_max_f32, "v_max_f32")
   RUN(k_fma_f32, "v_fma_f32") RUN(k_max3_i32, "v_max3_i32") RUN(k_max_i16, "v_max_i16") RUN(k_alignbit, "v_alignbit_b32")
   RUN(k_dpp_row_shr, "v_mov_b32_dpp row_shr:1") RUN(k_perm, "v_perm_b32") RUN(k_sad_u8, "v_sad_u8") RUN(k_add3_u32, "v_add3_u32")
+  RUN(k_pk_add_f16_clamp, "v_pk_add_f16 clamp") RUN(k_pk_maximum3_f16, "v_pk_maximum3_f16") RUN(k_pk_minimum3_f16, "v_pk_minimum3_f16")
+  RUN(k_maximum3_f32, "v_maximum3_f32") RUN(k_max3_f32, "v_max3_f32") RUN(k_max3_i16, "v_max3_i16")
+  RUN(k_pk_add_u16_clamp, "v_pk_add_u16 clamp") RUN(k_pk_sub_u16_clamp, "v_pk_sub_u16 clamp") RUN(k_pk_max_u16, "v_pk_max_u16")
+  RUN(k_pk_mad_i16, "v_pk_mad_i16") RUN(k_pk_fma_f16, "v_pk_fma_f16")
+#define RUNMIX(kern, label, ninst)                                                                               \
+  {                                                                                                              \
+    double ms = timeit([&] { hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, 1u); });               \
+    double rows = (double)blocks * 4 * (ITERS / 2) * CH * 2;                                                     \
+    printf("%-26s %8.3f ms  => %.2f cycles per (register, row) per SIMD  (%d instructions per 2 rows)\n", label, ms, \
+           1.0 / (rows / (ms * 1e-3) / (p.multiProcessorCount * 4) / clk), ninst);                               \
+  }
+  RUNMIX(k_mix_i16, "row body packed i16", 4) RUNMIX(k_mix_f16, "row body packed f16+max3", 3)
   return 0;
 }
