@@ -42,7 +42,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PROFILE_TAG = "r03"            # profiles/<tag>*_ssv_traffic.json / <tag>*_cfg3_ssv_traffic.json hold the PMC-pass figures of the SSV launches
-MEASURED_CYCLES_PER_INST = 4.55   # cycles per wave64 instruction per SIMD of the SSV row body run alone (tools/ubench/valu_rates.hip); updated from profiles/r03_valu_rates.txt
+MEASURED_CYCLES_PER_INST = 4.25   # cycles per wave64 instruction per SIMD of the SSV row body (2 x v_pk_add_f16 clamp + v_pk_maximum3_f16 per two rows) run alone: tools/ubench/valu_rates.hip, profiles/r03_valu_rates.txt (6.35 cycles per register-row = 3 instructions per 2 rows)
 
 
 def parse():
@@ -622,7 +622,8 @@ def bench_cfg3(args, env):
     # the first pass of the process, on a slice of the bins: contexts, the 2000-profile database, device tables and workspace at working size
     warm = min(nbins, 128 * share)
     t0 = time.perf_counter()
-    lineage_pass(w, binIds[:warm], files[:warm], lin, os.path.join(workdir, "cfg3_warm"), rank)
+    if os.environ.get("CKM_BENCH_SKIP_WARM") != "1":           # (counter passes of tools/collect_r03.sh want exactly one step's launches)
+        lineage_pass(w, binIds[:warm], files[:warm], lin, os.path.join(workdir, "cfg3_warm"), rank)
     env.sync()
     first_pass_s = time.perf_counter() - t0
     t0 = time.perf_counter()

@@ -1,0 +1,92 @@
+#!/usr/bin/env python
+"""Turns what tools/collect_r03.sh (and the bench runs of a round-3 GPU call) left under gpurun_out/<tag>/ into the files committed
+under profiles/<tag>_*.   usage: python tools/make_profile_files_r03.py <tag>"""
+import collections
+import csv
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = ("# FETCH_SIZE / WRITE_SIZE are in KB as reported; MI355X_MICROARCH.md (HBM section): FETCH_SIZE reads 1/2 of the bytes of a wide\n"
+       "# coalesced streaming read on gfx950 -> corrected HBM read bytes = 2 * FETCH_SIZE * 1024.  WRITE_SIZE is taken as reported.\n"
+       "# SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* are in quad-cycle units.  ssv_kernel = ssv_kernel_h<Q> (packed-half row) unless CKM_SSV=i16.\n")
+
+
+def last_json(path):
+    return json.loads(open(path).read().strip().split("\n")[-1])
+
+
+def counter_total(src, d, counter, only=None):
+    f = os.path.join(src, d, "p_counter_collection.csv")
+    return sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and (only is None or only in r["Kernel_Name"]))
+
+
+def pmc_files(src, dst, prefix, what, line, cmd):
+    dirs = [os.path.join(src, prefix + n) for n in ("fetch", "write", "sq")]
+    if not all(os.path.exists(os.path.join(d, "p_counter_collection.csv")) for d in dirs):
+        return
+    pm = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py")] + dirs, capture_output=True, text=True).stdout
+    open(dst(what + "pmc_summary.txt"), "w").write("# rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*, separate runs, each with --kernel-trace only), MI355X; ONE step each of:\n# " + cmd + "\n" + HDR + pm)
+    f, w = counter_total(src, prefix + "fetch", "FETCH_SIZE", "ssv_kernel"), counter_total(src, prefix + "write", "WRITE_SIZE", "ssv_kernel")
+    valu = counter_total(src, prefix + "sq", "SQ_INSTS_VALU", "ssv_kernel")
+    lds = counter_total(src, prefix + "sq", "SQ_INSTS_LDS", "ssv_kernel")
+    ms = [float(l.split()[2]) for l in pm.split("\n") if l.startswith("ssv_kernel ")][0]
+    fa, wa = counter_total(src, prefix + "fetch", "FETCH_SIZE"), counter_total(src, prefix + "write", "WRITE_SIZE")
+    va = counter_total(src, prefix + "sq", "SQ_INSTS_VALU")
+    json.dump({"config": line["config"]["workload"] if "cfg3" in what else "cfg2: 43 profiles x 100 bins x 2000 ORFs, 1 GPU, one search",
+               "kernel": "ssv_kernel_h<Q> (all launches of one step; kernels serialised by counter collection)",
+               "algorithmic_bytes": line["roofline"]["algorithmic_bytes"], "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_corrected": 2 * f * 1024 + w * 1024,
+               "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); algorithmic bytes = sum over (model, sequence) pairs of (L + 12)",
+               "valu_insts": valu, "lds_insts": lds, "ssv_ms_under_pmc": ms,
+               "all_kernels": {"valu_insts": va, "FETCH_SIZE_KB": fa, "WRITE_SIZE_KB": wa, "hbm_bytes_corrected": 2 * fa * 1024 + wa * 1024,
+                               "note": "every kernel of the step (SSV + the chains + ensembles + copies), same passes"}},
+              open(dst(what + "ssv_traffic.json"), "w"), indent=1)
+    print(open(dst(what + "ssv_traffic.json")).read())
+
+
+def main():
+    tag = sys.argv[1]
+    src = os.path.join(ROOT, "gpurun_out", tag)
+    dst = lambda name: os.path.join(ROOT, "profiles", "%s_%s" % (tag, name))
+    for name, out in (("bench_default.json", "bench_default_line.json"), ("bench_cfg2_i16.json", "bench_cfg2_ssv_i16_line.json"), ("bench_cfg2.json", "bench_cfg2_line.json"),
+                      ("bench_emu.json", "bench_cfg3_emulated_rank0of8_line.json"), ("bench_cfg5.json", "bench_cfg5_slice_line.json")):
+        if os.path.exists(os.path.join(src, name)) and os.path.getsize(os.path.join(src, name)) > 0:
+            json.dump(last_json(os.path.join(src, name)), open(dst(out), "w"), indent=1)
+    for name, out in (("host_profile.txt", "host_profile_cfg3.txt"), ("valu_rates.txt", "valu_rates.txt"), ("pytest_gpu.txt", "pytest_gpu_tail.txt"), ("timeline.txt", "timeline_cfg2.txt")):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copyfile(os.path.join(src, name), dst(out) if name != "valu_rates.txt" else os.path.join(ROOT, "profiles", tag[:3] + "_valu_rates.txt"))
+    ks = os.path.join(src, "stats3", "cfg3_kernel_stats.csv")
+    if os.path.exists(ks):
+        fam, inst = collections.defaultdict(lambda: [0, 0.0]), []
+        for r in csv.DictReader(open(ks)):
+            m = re.search(r'ckm::([a-z0-9_]+kernel(?:_h)?)(<[^>]*>)?', r["Name"])
+            k = m.group(1) if m else r["Name"][:40]
+            fam[k][0] += int(r["Calls"]); fam[k][1] += float(r["TotalDurationNs"])
+            inst.append(((m.group(1) + (m.group(2) or "")) if m else r["Name"][:40], int(r["Calls"]), float(r["TotalDurationNs"]), float(r["AverageNs"])))
+        tot = sum(v[1] for v in fam.values())
+        line = last_json(os.path.join(src, "stats3.json"))
+        with open(dst("cfg3_kernel_stats.txt"), "w") as f:
+            f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --config cfg3 --bins-total 192 --steps 1 --warmup 1 --no-cpu-baseline --no-cfg2 --no-emulation (MI355X)\n"
+                    "# = the warm pass over 128 bins + ONE timed step over 192 bins (bench line of this run: %.0f ms per step, SSV launches %.0f ms by HIP events).\n"
+                    "# Kernels of the two scan lanes and of the chain streams overlap in time: durations SUM to more than the wall time.\n"
+                    % (line["ms_per_step"], line["roofline"]["ms_per_step_kernel"]))
+            f.write("%-28s %8s %12s %12s %6s\n" % ("kernel family", "calls", "total_ms", "avg_us", "pct"))
+            for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+                f.write("%-28s %8d %12.2f %12.1f %6.1f\n" % (k, v[0], v[1] / 1e6, v[1] / v[0] / 1e3, 100 * v[1] / tot))
+            f.write("\n# per template instance (top 40)\n%-34s %8s %12s %12s\n" % ("kernel", "calls", "total_ms", "avg_us"))
+            for n, c, t, a in sorted(inst, key=lambda x: -x[2])[:40]:
+                f.write("%-34s %8d %12.2f %12.1f\n" % (n, c, t / 1e6, a / 1e3))
+    if os.path.exists(os.path.join(src, "pmc3_sq.json")):
+        pmc_files(src, dst, "pmc3_", "cfg3_", last_json(os.path.join(src, "pmc3_sq.json")),
+                  "CKM_BENCH_SKIP_WARM=1 CKM_WS_PER_MP=5 python bench.py --config cfg3 --bins-total 48 --steps 1 --warmup 0 --no-cpu-baseline --no-cfg2 --no-emulation   (a 48-bin SAMPLE of configs[2])")
+    if os.path.exists(os.path.join(src, "pmc_sq.json")):
+        pmc_files(src, dst, "pmc_", "", last_json(os.path.join(src, "pmc_sq.json")),
+                  "CKM_WS_PER_MP=5 CKM_BENCH_STEADY=0 CKM_BENCH_FROM_HOST=0 python bench.py --config cfg2 --steps 1 --warmup 0 --no-cpu-baseline")
+
+
+if __name__ == "__main__":
+    main()

@@ -14,7 +14,7 @@ import sys
 
 def family(name):
     m = re.search(r'ckm\d+([a-z0-9_]+kernel)', name) or re.search(r'ckm::([a-z0-9_]+kernel)', name)
-    return m.group(1) if m else name.split('(')[0][:40]
+    return m.group(1) if m else name.split('(')[0][:40]          # (ssv_kernel_h<Q>, the packed-half row of round 3, counts as ssv_kernel)
 
 
 def main():

@@ -18,7 +18,7 @@ def main():
     fam = collections.defaultdict(lambda: [0, 0])
     for kid, s, e in c.execute("select kernel_id,start,end from rocpd_kernel_dispatch%s" % suf):
         n = ks[kid]
-        m = re.search(r'ckm\d+([a-z_]+kernel)(ILi(\d+)E)?', n)
+        m = re.search(r'ckm\d+([a-z_]+kernel(?:_h)?)(ILi(\d+)E)?', n)
         name = (m.group(1) + ("<%s>" % m.group(3) if m.group(3) else "")) if m else n[:48]
         per[name][0] += 1; per[name][1] += e - s
         f = m.group(1) if m else n[:48]
