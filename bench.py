@@ -691,6 +691,7 @@ def bench_cfg3(args, env):
                                       "tree_find": parts["tree_find_s"], "analyze_find": parts["analyze_find_s"], "qa": parts["qa_s"],
                                       "note": "ingest/search/write are summed over the two scan lanes (they overlap in time); tree_find + analyze_find + qa = the step"},
            "searches_rank0": int(tot.get("searches", 0)), "cascade_fallback_lanes_rank0": int(tot.get("cascade_fallback_lanes", 0)),
+           "workspace_rank0": {"allocated_bytes_max": int(tot.get("ws_cap_bytes", 0)), "high_water_bytes_max": int(tot.get("ws_used_bytes", 0))},
            "setup_s": {"world_and_files": t_setup}}
     if emu:
         out["emulated_rank"] = "%d/%d" % emu

@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcheckm_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class CkmError(RuntimeError):
@@ -48,7 +48,8 @@ class SearchStats(C.Structure):
     _fields_ = [("pairs_ssv", C.c_uint64), ("pairs_msv_full", C.c_uint64), ("pairs_bias", C.c_uint64), ("pairs_vit", C.c_uint64),
                 ("pairs_fwd", C.c_uint64), ("pairs_dom", C.c_uint64), ("envelopes", C.c_uint64), ("regions_multi", C.c_uint64), ("pairs_vit_exact", C.c_uint64), ("cells_ssv", C.c_uint64),
                 ("residue_hmm", C.c_uint64), ("ms_ssv", C.c_double), ("ms_filters", C.c_double), ("ms_fwdbwd", C.c_double),
-                ("ms_domains", C.c_double), ("ms_host", C.c_double), ("ms_total", C.c_double), ("ssv_launches", C.c_uint32), ("cascade_fallback_lanes", C.c_uint32)]
+                ("ms_domains", C.c_double), ("ms_host", C.c_double), ("ms_total", C.c_double), ("ssv_launches", C.c_uint32), ("cascade_fallback_lanes", C.c_uint32),
+                ("ws_cap_bytes", C.c_uint64), ("ws_used_bytes", C.c_uint64)]
 
 
 class StageScores(C.Structure):
@@ -71,7 +72,7 @@ class ModelInfo(C.Structure):
 class ReduceFlags(C.Structure):
     _fields_ = [("ignore_thresholds", C.c_int32), ("skip_pseudogene_correction", C.c_int32), ("skip_adj_correction", C.c_int32),
                 ("individual_markers", C.c_int32), ("evalue_threshold", C.c_double), ("length_threshold", C.c_double),
-                ("bin_select", C.c_void_p)]
+                ("bin_select", C.c_void_p), ("nvariants", C.c_uint32), ("bin_variant", C.c_void_p)]
 
 
 class MarkerSetsCSR(C.Structure):
@@ -97,7 +98,7 @@ class TableColumns(C.Structure):
 
 
 # every symbol include/checkm_hip.h declares
-EXPORTS = ["ckm_last_error", "ckm_abi_version", "ckm_device_count", "ckm_ctx_create", "ckm_ctx_destroy",
+EXPORTS = ["ckm_last_error", "ckm_abi_version", "ckm_device_count", "ckm_ctx_create", "ckm_ctx_destroy", "ckm_ctx_reserve",
            "ckm_profiles_load", "ckm_profiles_count", "ckm_profiles_header", "ckm_profiles_free",
            "ckm_seqs_pack", "ckm_seqs_from_fasta", "ckm_seqs_count", "ckm_seqs_bin_offsets", "ckm_seqs_name", "ckm_seqs_residues", "ckm_seqs_free", "ckm_search", "ckm_hits_columns", "ckm_hits_free",
            "ckm_hits_write_domtblout", "ckm_last_search_stats", "ckm_reduce", "ckm_qa_columns_get", "ckm_qa_free", "ckm_count_sets",
@@ -121,6 +122,7 @@ def load():
     L.ckm_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     L.ckm_ctx_destroy.argtypes = [C.c_void_p]
     L.ckm_ctx_destroy.restype = None
+    L.ckm_ctx_reserve.argtypes = [C.c_void_p, C.c_uint64, C.c_double]
     L.ckm_profiles_load.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
     L.ckm_profiles_count.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.ckm_profiles_header.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ModelHeader)]
@@ -186,6 +188,10 @@ class Context(object):
         if self.h:
             load().ckm_ctx_destroy(self.h)
             self.h = C.c_void_p()
+
+    def reserve(self, pairs, model_positions):
+        """Start allocating the workspace a search of that size will ask for, in the background (ckm_ctx_reserve)."""
+        _chk(load().ckm_ctx_reserve(self.h, int(pairs), float(model_positions)))
 
     def stats(self):
         st = SearchStats()

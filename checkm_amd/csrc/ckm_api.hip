@@ -92,8 +92,26 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
   });
 }
 
+extern "C" int ckm_ctx_reserve(ckm_ctx *ctx, uint64_t pairs, double model_positions) {
+  return guarded([&] {
+    if (!ctx) throw Error(CKM_EINVAL, "ctx is NULL");
+    ctx->settle();
+    Worker &w = ctx->w[0];
+    // the estimate ckm_search itself makes (ckm_search.hip: cascade_dev), for one lane
+    const uint64_t est = (uint64_t)(model_positions * (double)w.caps.ws_per_mp + (double)pairs * 24.0) + ((uint64_t)256 << 20);
+    const size_t want = (size_t)std::min<uint64_t>(std::max<uint64_t>(est, (uint64_t)1 << 30), (uint64_t)w.ws_budget);
+    if (w.ws.cap >= want) return;
+    const int device = ctx->device;
+    ctx->reserve_thread = std::thread([&w, want, device] {
+      if (hipSetDevice(device) != hipSuccess) return;
+      try { w.ws.ensure(want); } catch (const Error &) { /* the search will ask again and report the failure itself */ }
+    });
+  });
+}
+
 extern "C" void ckm_ctx_destroy(ckm_ctx *ctx) {
   if (!ctx) return;
+  ctx->settle();
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   for (auto &w : ctx->w) {
@@ -109,15 +127,19 @@ extern "C" void ckm_ctx_destroy(ckm_ctx *ctx) {
 }
 
 // ---- profiles -----------------------------------------------------------------------------------
-template <class T>
-static const T *upload(ckm_profiles *p, const std::vector<T> &v) {
-  std::unique_ptr<DevBuf> b(new DevBuf());
-  b->ensure(std::max<size_t>(16, v.size() * sizeof(T)));
-  if (!v.empty()) HIPCHK(hipMemcpy(b->p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-  const T *r = b->as<T>();
-  p->tables.push_back(std::move(b));
-  return r;
-}
+// All device tables of a database live in ONE allocation, filled by ONE copy: a 2000-model database has 16 000 tables, and a
+// hipMalloc + synchronous hipMemcpy for each of them used to cost more than the arithmetic of configuring the profiles.
+namespace {
+struct Arena {
+  std::vector<uint8_t> host;
+  template <class T> size_t add(const std::vector<T> &v) {
+    const size_t off = (host.size() + 255) & ~(size_t)255;
+    host.resize(off + std::max<size_t>(16, v.size() * sizeof(T)));
+    if (!v.empty()) memcpy(host.data() + off, v.data(), v.size() * sizeof(T));
+    return off;
+  }
+};
+}  // namespace
 
 extern "C" int ckm_profiles_load(ckm_ctx *ctx, const char *hmm_path, ckm_profiles **out) {
   return guarded([&] {
@@ -127,9 +149,34 @@ extern "C" int ckm_profiles_load(ckm_ctx *ctx, const char *hmm_path, ckm_profile
     std::unique_ptr<ckm_profiles> p(new ckm_profiles());
     p->ctx = ctx;
     p->hmm = read_hmm_file(hmm_path);
-    for (const auto &h : p->hmm) {
-      p->prof.push_back(configure_profile(h));
-      const HostProfile &hp = p->prof.back();
+    const size_t n = p->hmm.size();
+    p->prof.resize(n);
+    {   // configuration is per model (logs, exps, the three striped layouts): host threads
+      std::vector<std::unique_ptr<Error>> errs(n);
+      auto one = [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+          try { p->prof[i] = configure_profile(p->hmm[i]); }
+          catch (const Error &e) { errs[i].reset(new Error(e)); }
+        }
+      };
+      if (ctx->w[0].pool && n > 8) ctx->w[0].pool->run(n, 4, one); else one(0, n);
+      for (size_t i = 0; i < n; ++i) if (errs[i]) throw Error(*errs[i]);
+    }
+    Arena ar;
+    struct Off { size_t ssv, ssvh, rbv, vit_e, vit_t, rf, ftr; };
+    std::vector<Off> off(n);
+    for (size_t i = 0; i < n; ++i) {
+      const HostProfile &hp = p->prof[i];
+      off[i] = Off{ar.add(hp.ssv_tbl), ar.add(hp.ssv_tbl_h), ar.add(hp.rbv), ar.add(hp.vit_e), ar.add(hp.vit_t), ar.add(hp.rf), ar.add(hp.ftr)};
+    }
+    std::unique_ptr<DevBuf> tables(new DevBuf());
+    tables->ensure(std::max<size_t>(256, ar.host.size()));
+    HIPCHK(hipMemcpy(tables->p, ar.host.data(), ar.host.size(), hipMemcpyHostToDevice));
+    const uint8_t *base = tables->as<uint8_t>();
+    p->tables.push_back(std::move(tables));
+    for (size_t i = 0; i < n; ++i) {
+      const HostHMM &h = p->hmm[i];
+      const HostProfile &hp = p->prof[i];
       DevModel d;
       memset(&d, 0, sizeof(d));
       d.M = hp.M; d.ssvQ = hp.ssvQ; d.fbQ = hp.fbQ; d.vitQH = hp.vitQH;
@@ -141,8 +188,10 @@ extern "C" int ckm_profiles_load(ckm_ctx *ctx, const char *hmm_path, ckm_profile
       d.bt00 = hp.bt00; d.bt01 = hp.bt01; d.bt10 = hp.bt10; d.bt11 = hp.bt11; d.bpi0 = hp.bpi0; d.bpi1 = hp.bpi1;
       for (int x = 0; x < NROWS; ++x) d.beo1[x] = hp.beo1[x];
       d.thr_msv_f1 = hp.thr_msv_f1; d.thr_msv_f2 = hp.thr_msv_f2; d.thr_vit_f2 = hp.thr_vit_f2; d.thr_fwd_f3 = hp.thr_fwd_f3;
-      d.ssv_tbl = upload(p.get(), hp.ssv_tbl); d.ssv_tbl_h = upload(p.get(), hp.ssv_tbl_h); d.rbv = upload(p.get(), hp.rbv); d.vit_e = upload(p.get(), hp.vit_e);
-      d.vit_t = upload(p.get(), hp.vit_t); d.rf = upload(p.get(), hp.rf); d.ftr = upload(p.get(), hp.ftr);
+      d.ssv_tbl = reinterpret_cast<const int16_t *>(base + off[i].ssv); d.ssv_tbl_h = reinterpret_cast<const uint16_t *>(base + off[i].ssvh);
+      d.rbv = base + off[i].rbv; d.vit_e = reinterpret_cast<const uint32_t *>(base + off[i].vit_e);
+      d.vit_t = reinterpret_cast<const uint32_t *>(base + off[i].vit_t); d.rf = reinterpret_cast<const float *>(base + off[i].rf);
+      d.ftr = reinterpret_cast<const float *>(base + off[i].ftr);
       p->dm.push_back(d);
       p->maxMp = std::max(p->maxMp, hp.fbQ * NL);
     }
@@ -373,6 +422,7 @@ extern "C" int ckm_align(ckm_ctx *ctx_, const ckm_profiles *p, const ckm_seqs *s
                          const uint64_t *out_off, int32_t *node_residue) {
   return guarded([&] {
     if (!ctx_ || !p || !s || (n && (!model || !seq || !out_off || !node_residue))) throw Error(CKM_EINVAL, "NULL argument");
+    ctx_->settle();
     Worker *ctx = &ctx_->w[0];
     HIPCHK(hipSetDevice(ctx->device));
     std::vector<EnvReq> req; std::vector<uint32_t> which;

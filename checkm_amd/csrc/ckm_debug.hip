@@ -7,6 +7,7 @@ extern "C" int ckm_debug_stages(ckm_ctx *ctx_, const ckm_profiles *p, const ckm_
                                 uint32_t npairs, ckm_stage_scores *out) {
   return guarded([&] {
     if (!ctx_ || !p || !s || !model || !seq || !out) throw Error(CKM_EINVAL, "NULL argument");
+    ctx_->settle();
     Worker *ctx = &ctx_->w[0];
     ctx->plan_key.clear();                 // this entry overwrites the worker's SSV tables
     HIPCHK(hipSetDevice(ctx->device));
@@ -113,6 +114,7 @@ extern "C" int ckm_debug_envelopes(ckm_ctx *ctx_, const ckm_profiles *p, const c
                                    const int32_t *ienv, const int32_t *jenv, uint32_t n, ckm_envelope_result *out) {
   return guarded([&] {
     if (!ctx_ || !p || !s || !model || !seq || !ienv || !jenv || !out) throw Error(CKM_EINVAL, "NULL argument");
+    ctx_->settle();
     Worker *ctx = &ctx_->w[0];
     HIPCHK(hipSetDevice(ctx->device));
     std::vector<EnvReq> req(n); std::vector<EnvRes> res;
@@ -134,6 +136,7 @@ extern "C" int ckm_debug_region(ckm_ctx *ctx_, const ckm_profiles *p, const ckm_
   return guarded([&] {
     if (!ctx_ || !p || !s || !n2sum || !segs || !nseg || !env || !nenv) throw Error(CKM_EINVAL, "NULL argument");
     if (model >= p->hmm.size() || seq >= s->nseq || ireg < 1 || jreg > s->len[seq] || jreg < ireg) throw Error(CKM_EINVAL, "bad region");
+    ctx_->settle();
     Worker *ctx = &ctx_->w[0];
     HIPCHK(hipSetDevice(ctx->device));
     std::vector<RegionReq> req{{model, seq, ireg, jreg}}; std::vector<RegionRes> res;

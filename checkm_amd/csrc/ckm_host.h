@@ -155,6 +155,9 @@ struct ckm_ctx {
   ckm_search_stats stats;
   std::mutex ssv_mutex;                   // SSV phases are VALU-bound: two of them side by side gain nothing
   std::condition_variable ssv_cv; int ssv_turn = 0;    // workers take their first SSV phase in worker order (largest chunk first)
+  std::thread reserve_thread;                          // ckm_ctx_reserve: background allocation of lane 0's float workspace
+  std::string reserve_error;
+  void settle() { if (reserve_thread.joinable()) reserve_thread.join(); }      // every entry point that touches the workspace calls this first
   std::atomic<uint64_t> fallbacks{0};                  // lanes the device-driven cascade handed back to the host-driven one (tables / workspace too small)
   hipEvent_t ssv_prev_done = nullptr;                  // device-driven cascade: end of the previous lane's SSV launches (the next lane's wait on it)
 };

@@ -175,13 +175,13 @@ struct OrderedHits {   // dict key -> list, Python insertion order
   bool has(uint32_t k) const { return lists.count(k) != 0; }
 };
 
-static bool vet_hit(const RHit &h, const ckm_model_info *mi, const ckm_reduce_flags *fl) {
+static bool vet_hit(const RHit &h, const ckm_model_info *mi, const ckm_reduce_flags *fl, size_t voff) {
   if (!fl->skip_pseudogene_correction) {
     const double alen = (double)(h.ali_to - h.ali_from);
     if (alen / (double)h.qlen < 0.3) return false;
   }
-  const int kind = fl->ignore_thresholds ? 0 : mi->thr_kind[h.model];
-  if (kind != 0) return mi->thr_full[h.model] <= h.full_sc && mi->thr_dom[h.model] <= h.dom_sc;
+  const int kind = fl->ignore_thresholds ? 0 : mi->thr_kind[voff + h.model];
+  if (kind != 0) return mi->thr_full[voff + h.model] <= h.full_sc && mi->thr_dom[voff + h.model] <= h.dom_sc;
   if (h.full_e > fl->evalue_threshold) return false;
   const double alen = (double)(h.ali_to - h.ali_from);
   return alen / (double)h.qlen >= fl->length_threshold;
@@ -327,6 +327,11 @@ extern "C" int ckm_reduce(ckm_ctx *ctx, const ckm_hits *h, const ckm_hit_columns
         for (uint32_t i = ms->marker_off[ms->set_off[b]]; i < ms->marker_off[ms->set_off[b + 1]]; ++i) { auto r = seen.emplace(ms->marker_key[i], true); marker_first[i] = r.second ? 1 : 0; }
       }
       if (fl->bin_select && !fl->bin_select[b]) continue;
+      size_t voff = 0;                    // this bin's slice of the threshold tables (ckm_reduce_flags.bin_variant)
+      if (fl->nvariants > 1 && fl->bin_variant) {
+        if (fl->bin_variant[b] >= fl->nvariants) throw Error(CKM_EINVAL, "bin_variant out of range");
+        voff = (size_t)fl->bin_variant[b] * mi->nmodels;
+      }
       OrderedHits mh;
       for (uint64_t r = cols.bin_row_off[b]; r < cols.bin_row_off[b + 1]; ++r) {
         RHit x;
@@ -344,7 +349,7 @@ extern "C" int ckm_reduce(ckm_ctx *ctx, const ckm_hits *h, const ckm_hit_columns
           x.full_sc = cols.full_score_d ? cols.full_score_d[r] : (double)cols.full_score[r];
           x.dom_sc = cols.dom_score_d ? cols.dom_score_d[r] : (double)cols.dom_score[r];
         }
-        if (!vet_hit(x, mi, fl)) continue;
+        if (!vet_hit(x, mi, fl, voff)) continue;
         // addHit: one domain per (marker, ORF); a strictly better one replaces and moves to the tail
         if (mh.has(x.key)) {
           std::vector<RHit> &lst = mh.lists[x.key];

@@ -845,6 +845,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   }
   if (status & CS_RWORK) cp.hens *= 2;
   // zone 2 ran out (regions were deferred to the host): size the workspace from what this search asked for, for the next calls
+  st.ws_cap_bytes = ctx->ws.cap; st.ws_used_bytes = (std::min<uint64_t>(h_tops[0], cd0.ws_cap) + h_tops[2]) * 4;
   if (h_tops[2] > cd0.ws2_cap) cp.ws_per_mp = std::max(cp.ws_per_mp * 1.5f, (float)(1.25 * (double)(h_tops[2] + cd0.ws_cap) * 4.0 / std::max(mp_sum, 1.0)));
   if (!fits) {
     if (getenv("CKM_TRACE")) fprintf(stderr, "ckm-trace w%d device cascade did not fit (status 0x%x): host-driven cascade for this lane\n", ctx->id, status);
@@ -1215,6 +1216,7 @@ static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, cons
     st.ms_domains = std::max(st.ms_domains, w.ms_domains); st.ms_host = std::max(st.ms_host, w.ms_host);
   }
   st.cascade_fallback_lanes = (uint32_t)c->fallbacks.load();
+  for (int k = 0; k < nw; ++k) { st.ws_cap_bytes = std::max(st.ws_cap_bytes, c->w[k].stats.ws_cap_bytes); st.ws_used_bytes = std::max(st.ws_used_bytes, c->w[k].stats.ws_used_bytes); }
   const double t_host0 = now_ms();
   // rows, bin by bin, models in the bin's own order
   hits->nbins = nbins;
@@ -1272,6 +1274,7 @@ extern "C" int ckm_search(ckm_ctx *ctx, const ckm_profiles *p, const ckm_seqs *s
     if (!ctx || !p || !s || !out) throw Error(CKM_EINVAL, "NULL argument");
     if ((model_off == nullptr) != (model_idx == nullptr)) throw Error(CKM_EINVAL, "model_off and model_idx must both be given or both be NULL");
     *out = nullptr;
+    ctx->settle();                          // a workspace reservation still in flight (ckm_ctx_reserve)
     std::unique_ptr<ckm_hits> h(new ckm_hits());
     do_search(ctx, p, s, model_off, model_idx, E, domE, h.get());
     *out = h.release();

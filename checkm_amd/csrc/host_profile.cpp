@@ -8,6 +8,8 @@
 //   Viterbi   signed 16-bit match scores + transition words + D->D prefix sums;
 //   Fwd/Bwd   float odds ratios in the canonical 64-lane blocked layout.
 // All transcendental functions are evaluated here, on the host, once per model.
+#include <thread>
+#include <memory>
 #include "ckm_internal.h"
 #include <cmath>
 #include <cstring>
@@ -57,22 +59,30 @@ void digitize(const char *text, uint64_t n, uint8_t *dsq) {
 // ------------------------------------------------------------------------------------------------
 // a probability field: "*" (zero) or -ln p >= 0.  hmmsearch converts with atof and takes whatever comes out; a token that is
 // not a number, or a "probability" above 1, can only come from a damaged file, so it is refused here instead of scored.
-static bool as_prob(const std::string &tok, float &p) {
-  if (tok == "*") { p = 0.0f; return true; }
-  char *end = nullptr;
-  const double v = strtod(tok.c_str(), &end);
-  if (end == tok.c_str() || *end != 0 || !(v >= 0.0) || std::isinf(v)) return false;
-  p = expf((float)(-1.0 * v));
-  return true;
-}
-
 static void parse_numbers(const std::string &line, size_t skip, float *dst, int n, int lineno, const std::string &path) {
-  std::istringstream is(line);
-  std::string tok;
-  for (size_t i = 0; i < skip; ++i) is >> tok;
+  // whitespace-separated tokens, scanned in place (a 2000-model database is 20 million of these fields)
+  const char *p = line.c_str();
+  auto next_tok = [&](const char *&b, const char *&e) -> bool {
+    while (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n' || *p == '\v' || *p == '\f') ++p;
+    if (!*p) return false;
+    b = p;
+    while (*p && !(*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n' || *p == '\v' || *p == '\f')) ++p;
+    e = p;
+    return true;
+  };
+  const char *b = nullptr, *e = nullptr;
+  for (size_t i = 0; i < skip; ++i) (void)next_tok(b, e);
   for (int i = 0; i < n; ++i) {
-    if (!(is >> tok)) throw Error(CKM_EFORMAT, path + ":" + std::to_string(lineno) + ": expected " + std::to_string(n) + " numeric fields");
-    if (!as_prob(tok, dst[i])) throw Error(CKM_EFORMAT, path + ":" + std::to_string(lineno) + ": '" + tok + "' is not a probability field (-ln p >= 0 or *)");
+    if (!next_tok(b, e)) throw Error(CKM_EFORMAT, path + ":" + std::to_string(lineno) + ": expected " + std::to_string(n) + " numeric fields");
+    bool ok;
+    if (e - b == 1 && *b == '*') { dst[i] = 0.0f; ok = true; }
+    else {
+      char *end = nullptr;
+      const double v = strtod(b, &end);            // (the line is NUL-terminated and a token ends at whitespace, where strtod stops too)
+      ok = !(end == b || end != e || !(v >= 0.0) || std::isinf(v));
+      if (ok) dst[i] = expf((float)(-1.0 * v));
+    }
+    if (!ok) throw Error(CKM_EFORMAT, path + ":" + std::to_string(lineno) + ": '" + std::string(b, e) + "' is not a probability field (-ln p >= 0 or *)");
   }
 }
 
@@ -89,12 +99,10 @@ static void match_occupancy(const HostHMM &h, std::vector<float> &mocc, std::vec
   }
 }
 
-std::vector<HostHMM> read_hmm_file(const std::string &path) {
-  std::ifstream in(path);
-  if (!in) throw Error(CKM_EIO, "cannot open HMM file " + path);
+// every record of a stream (a whole file, or the slice of it one reader thread got); `lineno` = lines before the stream's first one
+static std::vector<HostHMM> read_hmm_stream(std::istream &in, const std::string &path, int lineno) {
   std::vector<HostHMM> out;
   std::string line;
-  int lineno = 0;
   auto fail = [&](const std::string &m) -> Error { return Error(CKM_EFORMAT, path + ":" + std::to_string(lineno) + ": " + m); };
   auto next = [&]() { if (!std::getline(in, line)) throw fail("truncated record"); ++lineno; };
   while (std::getline(in, line)) {
@@ -155,7 +163,7 @@ std::vector<HostHMM> read_hmm_file(const std::string &path) {
     h.mat[0] = 1.0f;
     for (int k = 1; k <= M; ++k) {
       next();
-      { std::istringstream is(line); int idx = -1; is >> idx; if (idx != k) throw fail("node index mismatch"); }
+      { char *endp = nullptr; const long idx = strtol(line.c_str(), &endp, 10); if (endp == line.c_str() || idx != k) throw fail("node index mismatch"); }
       parse_numbers(line, 1, &h.mat[(size_t)k * K], K, lineno, path);
       next(); parse_numbers(line, 0, &h.ins[(size_t)k * K], K, lineno, path);
       next(); parse_numbers(line, 0, &h.t[(size_t)k * 7], 7, lineno, path);
@@ -174,6 +182,54 @@ std::vector<HostHMM> read_hmm_file(const std::string &path) {
       h.has_compo = true;
     }
     out.push_back(std::move(h));
+  }
+  return out;
+}
+
+// The text of a marker database is hundreds of MB (checkm.hmm: ~230 MB for 2000 models) and records are independent: the file is
+// read once, cut at lines that start a record ("HMMER3/"), and the slices are parsed by up to 8 threads; records keep file order and
+// an error reports the line of the FILE.  (The reference's hmmsearch re-reads and re-parses the file for every bin.)
+std::vector<HostHMM> read_hmm_file(const std::string &path) {
+  std::string text;
+  {
+    std::ifstream in(path, std::ios::binary);
+    if (!in) throw Error(CKM_EIO, "cannot open HMM file " + path);
+    in.seekg(0, std::ios::end);
+    const std::streamoff sz = in.tellg();
+    in.seekg(0, std::ios::beg);
+    if (sz > 0) { text.resize((size_t)sz); in.read(&text[0], sz); text.resize((size_t)in.gcount()); }
+  }
+  std::vector<size_t> starts;            // offsets of lines beginning a record
+  for (size_t pos = 0; pos < text.size();) {
+    if (text.compare(pos, 7, "HMMER3/") == 0) starts.push_back(pos);
+    const size_t nl = text.find('\n', pos);
+    if (nl == std::string::npos) break;
+    pos = nl + 1;
+  }
+  const size_t nrec = starts.size();
+  const size_t nthreads = std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)std::thread::hardware_concurrency(), text.size() / (4u << 20) + 1, std::max<size_t>(nrec, 1)}));
+  std::vector<size_t> cut(nthreads + 1, text.size());
+  cut[0] = 0;                                                     // (whatever precedes the first record belongs to the first slice, which rejects it)
+  for (size_t t = 1; t < nthreads; ++t) cut[t] = starts[t * nrec / nthreads];
+  std::vector<std::vector<HostHMM>> parts(nthreads);
+  std::vector<std::unique_ptr<Error>> errs(nthreads);
+  auto work = [&](size_t t) {
+    try {
+      const int lineno = (int)std::count(text.begin(), text.begin() + (std::ptrdiff_t)cut[t], '\n');
+      std::istringstream in(text.substr(cut[t], cut[t + 1] - cut[t]));
+      parts[t] = read_hmm_stream(in, path, lineno);
+    } catch (const Error &e) { errs[t].reset(new Error(e)); }
+  };
+  if (nthreads == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nthreads; ++t) th.emplace_back(work, t);
+    for (auto &x : th) x.join();
+  }
+  std::vector<HostHMM> out;
+  for (size_t t = 0; t < nthreads; ++t) {
+    if (errs[t]) throw Error(*errs[t]);                           // the first error in file order
+    for (auto &h : parts[t]) out.push_back(std::move(h));
   }
   if (out.empty()) throw Error(CKM_EFORMAT, path + ": no HMMER3 records");
   return out;

@@ -271,10 +271,12 @@ typedef unsigned int u32;
 __device__ __forceinline__ u32 pk_adds(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
 __device__ __forceinline__ u32 pk_max(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
 constexpr u32 NEG2 = 0x80008000u;     // two -32768 words
-// value of the previous stripe: low half <- previous lane's high half, high half <- own low half
-__device__ __forceinline__ u32 stripe_shift(u32 v) {
-  const u32 up = (u32)__builtin_amdgcn_update_dpp((int)NEG2, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
-  return __builtin_amdgcn_alignbit(v, up, 16);
+// value of the previous stripe: low half <- previous lane's high half, high half <- own low half.  `hold` is a persistent register
+// that starts as NEG2 in every lane: the DPP move (bound_ctrl off) never writes lane 0, which has no predecessor, so lane 0 keeps
+// -32768 for ever and no constant has to be materialised per shift (one v_mov less per call: 5 per row).
+__device__ __forceinline__ u32 stripe_shift(u32 v, u32 &hold) {
+  hold = (u32)__builtin_amdgcn_update_dpp((int)hold, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+  return __builtin_amdgcn_alignbit(v, hold, 16);
 }
 
 // FAST: the J state is assumed unused (xJ <= xN throughout), which makes xB a constant and removes every per-row
@@ -301,7 +303,7 @@ __global__ void __launch_bounds__(256) vit_kernel(WorkQueue queue, const PairRec
   const PairRec pr = pairs[pi];
   const DevModel &md = models[pr.model];
   constexpr int ROW = QH * 64;                      // u32 words per table row
-  const int L = seq_len[pr.seq];
+  const int L = __builtin_amdgcn_readfirstlane(seq_len[pr.seq]);     // (one pair per wavefront: the length is uniform, and as an SGPR it keeps the row counter and the residue feed's bookkeeping off the VALU)
   const uint8_t *rp = res + seq_off[pr.seq];
   const LenEntry le = lentab[L];
   u32 tBM[QH], tMM[QH], tIM[QH], tDM[QH], tMD[QH], tMI[QH], tII[QH], tDD[QH];
@@ -321,21 +323,23 @@ __global__ void __launch_bounds__(256) vit_kernel(WorkQueue queue, const PairRec
   // is an SGPR and no load of the row loop depends on another
   const gp<u32> vit_e = gptr(md.vit_e);
   ResUp feed; feed.init(rp, L, lane);
-  u32 e[QH];
+  u32 e[QH], e2[QH];
   {
     const gp<u32> er = vit_e + (size_t)feed.get(0) * ROW + lane;
 #pragma unroll
     for (int j = 0; j < QH; ++j) e[j] = er[j * 64];
   }
-  for (int i = 0; i < L; ++i) {
-    u32 en[QH];
+  u32 hm = NEG2, hi = NEG2, hd = NEG2, hc = NEG2;          // stripe_shift's persistent registers
+  // one row; `ec` holds this row's emission words, `en` receives the next row's (the two arrays swap roles from row to row, so no
+  // register copies are needed).  Returns true when the exact variant overflowed.
+  auto row = [&](int i, u32 (&ec)[QH], u32 (&en)[QH]) -> bool {
     {
       const int xn = feed.get((i + 1 < L) ? i + 1 : L - 1);
       const gp<u32> er = vit_e + (size_t)xn * ROW + lane;
 #pragma unroll
       for (int j = 0; j < QH; ++j) en[j] = er[j * 64];
     }
-    const u32 ms0 = stripe_shift(Mv[QH - 1]), is0 = stripe_shift(Iv[QH - 1]), ds0 = stripe_shift(Dv[QH - 1]);
+    const u32 ms0 = stripe_shift(Mv[QH - 1], hm), is0 = stripe_shift(Iv[QH - 1], hi), ds0 = stripe_shift(Dv[QH - 1], hd);
     const u32 xBv = ((u32)(xB & 0xffff)) * 0x10001u;        // FAST: loop-invariant
     u32 mdv[QH];
     if (!FAST) xEv = NEG2;
@@ -346,20 +350,20 @@ __global__ void __launch_bounds__(256) vit_kernel(WorkQueue queue, const PairRec
       sv = pk_max(sv, pk_adds(mp, tMM[j]));
       sv = pk_max(sv, pk_adds(ip, tIM[j]));
       sv = pk_max(sv, pk_adds(dp, tDM[j]));
-      sv = pk_adds(sv, e[j]);
+      sv = pk_adds(sv, ec[j]);
       const u32 ni = pk_max(pk_adds(Mv[j], tMI[j]), pk_adds(Iv[j], tII[j]));
       Iv[j] = ni; Mv[j] = sv;
       xEv = pk_max(xEv, sv);
       mdv[j] = pk_adds(sv, tMD[j]);
     }
     // D, pass 1: the first cell of a stripe takes the M->D word of the previous stripe's last cell
-    Dv[0] = stripe_shift(mdv[QH - 1]);
+    Dv[0] = stripe_shift(mdv[QH - 1], hd);
 #pragma unroll
     for (int j = 1; j < QH; ++j) Dv[j] = pk_max(mdv[j - 1], pk_adds(Dv[j - 1], tDD[j - 1]));
     u32 carry = pk_adds(Dv[QH - 1], tDD[QH - 1]);
     // lazy-F passes: carry stripe ends forward while some first cell still improves
     for (int pass = 0; pass < 128; ++pass) {
-      u32 cs = stripe_shift(carry);
+      u32 cs = stripe_shift(carry, hc);
       const s16x2 c2 = __builtin_bit_cast(s16x2, cs), d2 = __builtin_bit_cast(s16x2, Dv[0]);
       if (!__any((c2.x > d2.x) || (c2.y > d2.y))) break;
 #pragma unroll
@@ -370,13 +374,21 @@ __global__ void __launch_bounds__(256) vit_kernel(WorkQueue queue, const PairRec
       const s16x2 x2 = __builtin_bit_cast(s16x2, xEv);
       int xE = max((int)x2.x, (int)x2.y);
       xE = wave_max(xE);
-      if (xE >= 32767) { overflow = true; break; }
+      if (xE >= 32767) { overflow = true; return true; }
       xC = max(xC, xE + md.wE_move);
       xJ = max(xJ, xE + md.wE_loop);
       xB = max(xJ + le.w_move, xN + le.w_move);
     }
-#pragma unroll
-    for (int j = 0; j < QH; ++j) e[j] = en[j];
+    return false;
+  };
+  {
+    int i = 0;
+    bool stop = false;
+    for (; i + 1 < L; i += 2) {
+      if (row(i, e, e2)) { stop = true; break; }
+      if (row(i + 1, e2, e)) { stop = true; break; }
+    }
+    if (!stop && i < L) (void)row(i, e, e2);
   }
   bool jflag = false;
   if (FAST) {

@@ -244,6 +244,24 @@ class MarkerGeneFinder(object):
                 pass
         import threading
         tot_lock = threading.Lock()
+        # the float workspace of a batch is tens of GB the first time a context meets one (seconds of hipMalloc): start allocating it
+        # now, beside the reading of the first batches' FASTA files (ckm_ctx_reserve; the search waits for it)
+        padded = [64 * ((h["leng"] + 63) // 64) for h in heads]
+        pos_cache = {}
+        for j, (c, _prof) in enumerate(lanes):
+            if j < len(batches):
+                pairs = mpos = 0
+                for i in batches[j]:
+                    m = models_of.get(binIds[i]) if models_of else None
+                    k = id(m)
+                    if k not in pos_cache:
+                        pos_cache[k] = (len(m), sum(padded[x] for x in m)) if m is not None else (len(padded), sum(padded))
+                    norf = max(1, sizes[i] // 320)
+                    pairs += norf * pos_cache[k][0]; mpos += norf * pos_cache[k][1]
+                try:
+                    c.reserve(pairs, mpos)
+                except _lib.CkmError:
+                    pass
 
         def scan(k):
             import time as _t
@@ -262,6 +280,8 @@ class MarkerGeneFinder(object):
                 for f in ("pairs_ssv", "pairs_msv_full", "pairs_bias", "pairs_vit", "pairs_vit_exact", "pairs_fwd", "pairs_dom", "envelopes", "regions_multi",
                           "cells_ssv", "residue_hmm", "ms_ssv", "ms_total", "ssv_launches", "cascade_fallback_lanes"):
                     totals[f] = totals.get(f, 0) + getattr(st, f)
+                for f in ("ws_cap_bytes", "ws_used_bytes"):
+                    totals[f] = max(totals.get(f, 0), getattr(st, f))
                 totals["searches"] = totals.get("searches", 0) + 1
             part = dict(seqs=seqs, hits=hits, bins=[binIds[i] for i in batch], profiles=prof)
             for b, i in enumerate(batch):

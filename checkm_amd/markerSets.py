@@ -96,9 +96,7 @@ class BinMarkerSets(object):
         f = line.split('\t')
         for i in range(int(f[1])):
             uid, lineage, ngen, sets = f[4 * i + 2], f[4 * i + 3], int(f[4 * i + 4]), _parse_marker_sets(f[4 * i + 5].strip())
-            ms = MarkerSet(uid, lineage, ngen, [set(s) for s in sets])
-            ms._src = sets                 # the cached literal this set was built from: bins of one lineage share its flattened form
-            self.markerSets.append(ms)
+            self.markerSets.append(MarkerSet(uid, lineage, ngen, None, sets))     # sets: the cached parsed literal; Python sets on demand
 
 
 @functools.lru_cache(maxsize=8192)
@@ -139,17 +137,46 @@ def count_sets(list_of_sets, hits):
     return pres[:nsets], mult[:nsets], hist, int(pt[0]), int(mt[0]), n_member, empty_members
 
 
-class MarkerSet(object):
-    """Marker genes organised into collocated sets (markerSets.py:157-238)."""
+_SRC_INFO = {}       # id(parsed literal) -> (literal, n markers, frozenset of marker genes): the literals live in _parse_marker_sets' cache
 
-    def __init__(self, UID, lineageStr, numGenomes, markerSet):
+
+def _src_info(src):
+    ent = _SRC_INFO.get(id(src))
+    if ent is None or ent[0] is not src:
+        if len(_SRC_INFO) > 16384:
+            _SRC_INFO.clear()
+        genes = set()
+        for st in src:
+            genes.update(st)
+        ent = _SRC_INFO[id(src)] = (src, sum(len(st) for st in src), frozenset(genes))
+    return ent
+
+
+class MarkerSet(object):
+    """Marker genes organised into collocated sets (markerSets.py:157-238).
+
+    Read from a marker file, the list of Python sets (`markerSet`) is built the first time somebody asks for it: a Lineage marker file
+    of 1000 bins holds 3000 literals of ~500 sets each, of which the QA table needs sizes and a flattened form only (both come from the
+    parsed literal, shared by the bins of a lineage)."""
+
+    def __init__(self, UID, lineageStr, numGenomes, markerSet=None, _src=None):
         self.logger = logging.getLogger('timestamp')
         self.UID = UID
         self.lineageStr = lineageStr
         self.numGenomes = numGenomes
-        self.markerSet = markerSet
-        self._src = None            # identity of the parsed literal (shared by the bins of a lineage) while no marker was removed
+        self._ms = markerSet
+        self._src = _src            # the parsed literal (tuple of tuples) while the sets are as the file holds them
         self._flat = None
+
+    @property
+    def markerSet(self):
+        if self._ms is None:
+            self._ms = [set(s) for s in self._src] if self._src is not None else []
+        return self._ms
+
+    @markerSet.setter
+    def markerSet(self, value):
+        self._ms, self._src, self._flat = value, None, None
 
     def flat(self, keys):
         """(key id of every marker in set order, 1 where a marker occurs for the first time, length of every set) as numpy arrays,
@@ -158,10 +185,10 @@ class MarkerSet(object):
         ent = cache.get(id(self._src)) if self._src is not None else None
         if ent is not None and ent[0] is self._src:
             return ent[1]
-        if self._flat is not None and self._flat[0] is keys and self._flat[1] == self._version():
+        if self._src is None and self._flat is not None and self._flat[0] is keys and self._flat[1] == self._version():
             return self._flat[2]
         ids, first, lens, seen = [], [], [], set()
-        for st in self.markerSet:
+        for st in (self._src if self._src is not None else self.markerSet):
             for m in st:
                 ids.append(keys.get(m))
                 first.append(0 if m in seen else 1)
@@ -170,42 +197,44 @@ class MarkerSet(object):
         out = (np.asarray(ids, dtype=np.int64), np.asarray(first, dtype=np.uint8), np.asarray(lens, dtype=np.int64))
         if self._src is not None:
             cache[id(self._src)] = (self._src, out)
-        self._flat = (keys, self._version(), out)
+        else:
+            self._flat = (keys, self._version(), out)
         return out
 
     def _version(self):
-        return (id(self.markerSet), len(self.markerSet), sum(len(s) for s in self.markerSet))
+        return (id(self._ms), len(self._ms), sum(len(s) for s in self._ms))
 
     def __repr__(self):
         return str(self.UID) + '\t' + self.lineageStr + '\t' + str(self.numGenomes) + '\t' + str(self.markerSet)
 
     def size(self):
+        if self._src is not None:
+            return _src_info(self._src)[1], len(self._src)
         return sum(len(m) for m in self.markerSet), len(self.markerSet)
 
     def numMarkers(self):
         return self.size()[0]
 
     def numSets(self):
-        return len(self.markerSet)
+        return len(self._src) if self._src is not None else len(self.markerSet)
 
     def getMarkerGenes(self):
+        if self._src is not None:
+            return set(_src_info(self._src)[2])
         genes = set()
         for m in self.markerSet:
             genes |= set(m)
         return genes
 
     def removeMarkers(self, markersToRemove):
-        kept, changed = [], False
+        if self._src is not None and _src_info(self._src)[2].isdisjoint(markersToRemove):
+            return                       # nothing of it is here: the sets stay as the file holds them
+        kept = []
         for ms in self.markerSet:
             rest = ms - markersToRemove
-            if len(rest) != len(ms):
-                changed = True
             if rest:
                 kept.append(rest)
-        self.markerSet = kept
-        if changed:
-            self._src = None
-        self._flat = None
+        self.markerSet = kept            # (drops the literal: sizes and the flattened form now come from the sets)
 
     def genomeCheck(self, hits, bIndividualMarkers):
         """Completeness / contamination; counting on the device, float64 division in the reference's order."""

@@ -163,14 +163,30 @@ class QAPlan(object):
         ms = _lib.MarkerSetsCSR(self.nbins, self.set_off.ctypes.data, self.marker_off.ctypes.data, self.marker_key.ctypes.data)
         return mi, ms
 
+    def with_threshold_variants(self, thr_lists):
+        """The same plan with one threshold table per variant (thr_lists: per variant, per model (kind, (full, dom))): bins pick
+        their variant through reduce(bin_variant=...) -- the sticky header view of a bin's own model subset can give a model
+        other cutoffs than another subset does."""
+        import copy
+        p = copy.copy(self)
+        p.nvariants = len(thr_lists)
+        p.thr_kind = np.ascontiguousarray([[t[0] for t in thr] for thr in thr_lists], dtype=np.uint8).reshape(-1)
+        p.thr_full = np.ascontiguousarray([[t[1][0] for t in thr] for thr in thr_lists], dtype=np.float64).reshape(-1)
+        p.thr_dom = np.ascontiguousarray([[t[1][1] for t in thr] for thr in thr_lists], dtype=np.float64).reshape(-1)
+        return p
+
     def reduce(self, ctx, hits, seqs, ignore_thresholds=False, evalue=E_VAL, length=LENGTH, skip_pseudogene=False,
-               skip_adj=False, individual_markers=False, bin_select=None, ext=None):
+               skip_adj=False, individual_markers=False, bin_select=None, ext=None, bin_variant=None):
         """hits: _lib.Hits from a search (then seqs is required), or None with ext = (HitColumns, keepalive)."""
-        sel = None
-        fl = _lib.ReduceFlags(int(ignore_thresholds), int(skip_pseudogene), int(skip_adj), int(individual_markers), float(evalue), float(length), None)
+        sel = var = None
+        fl = _lib.ReduceFlags(int(ignore_thresholds), int(skip_pseudogene), int(skip_adj), int(individual_markers), float(evalue), float(length), None, 0, None)
         if bin_select is not None:
             sel = np.ascontiguousarray(bin_select, dtype=np.uint8)
             fl.bin_select = sel.ctypes.data
+        if bin_variant is not None and getattr(self, "nvariants", 1) > 1:
+            var = np.ascontiguousarray(bin_variant, dtype=np.uint32)
+            fl.nvariants = self.nvariants
+            fl.bin_variant = var.ctypes.data
         mi, ms = self._structs(fl)
         out = C.c_void_p()
         if ext is None:

@@ -597,7 +597,8 @@ class ResultsParser(object):
         from checkm_amd.markerGeneFinder import SCAN_CACHE
         binIds = list(self.models.keys())
         ent = SCAN_CACHE.get((os.path.abspath(outDir), hmmTableFile))
-        mk = lambda b: ResultsManager(b, self.models[b], bIgnoreThresholds, evalueThreshold, lengthThreshold, bSkipPseudoGeneCorrection,
+        models = self.models           # (not `self` in the closure: the parser keeps it, and a cycle would keep a thousand bins' results alive until the collector runs)
+        mk = lambda b: ResultsManager(b, models[b], bIgnoreThresholds, evalueThreshold, lengthThreshold, bSkipPseudoGeneCorrection,
                                       binStats[b] if (binStats is not None and b in binStats) else None)
         self._mk, self._text_args = mk, (outDir, hmmTableFile, bSkipAdjCorrection, bIgnoreThresholds, evalueThreshold, lengthThreshold, bSkipPseudoGeneCorrection)
         self.remote_bins = []
@@ -645,25 +646,37 @@ class ResultsParser(object):
             def __init__(self, acc, leng, v):
                 self.acc, self.leng = (v[0], v[1]) if v else (acc, leng)
                 self.ga, self.tc, self.nc = (v[2], v[3], v[4]) if v else (None, None, None)
+        plans = []
         for merged, members, _last in groups:
             mlist = [_Slot(a, hd["leng"], merged.get(a)) for a, hd in zip(slot_acc, profiles.headers)]
-            keys, acc, qlen, thr, clans, nested = _plan_for_models(mlist)
+            plans.append((_plan_for_models(mlist), members))
+        # Groups that differ in nothing but cutoffs (the sticky header view of another model subset) become threshold VARIANTS of
+        # one plan: every part of the scan is then reduced in ONE library call, each bin under its own variant.
+        (keys, acc, qlen, thr, clans, nested), _m = plans[0]
+        if all(pl[0][1] == acc and pl[0][2] == qlen for pl in plans):
             plan0 = cqa.QAPlan(keys, acc, qlen, thr, [], clans, nested)
+            if len(plans) > 1:
+                plan0 = plan0.with_threshold_variants([pl[0][3] for pl in plans])
+            jobs = [(plan0, keys, [(b, v) for v, pl in enumerate(plans) for b in pl[1]])]
+        else:
+            jobs = [(cqa.QAPlan(k, a, q, t, [], c, n), k, [(b, 0) for b in members]) for (k, a, q, t, c, n), members in plans]
+        for plan0, keys, members in jobs:
             by_part = {}
-            for b in members:
+            for b, v in members:
                 pi, lb = ent["where"][b]
-                by_part.setdefault(pi, []).append((b, lb))
+                by_part.setdefault(pi, []).append((b, lb, v))
             for pi, lst in by_part.items():
                 part = ent["parts"][pi]
                 hits, seqs = part["hits"], part["seqs"]
                 nb = hits.nbins
                 plan = plan0.with_empty_bins(nb)
                 sel = np.zeros(nb, dtype=np.uint8)
-                for _b, lb in lst:
-                    sel[lb] = 1
-                res = plan.reduce(runtime.get_ctx(), hits, seqs, ignore, evalue, length, skip_pseudo, skip_adj, False, sel)
+                var = np.zeros(nb, dtype=np.uint32)
+                for _b, lb, v in lst:
+                    sel[lb] = 1; var[lb] = v
+                res = plan.reduce(runtime.get_ctx(), hits, seqs, ignore, evalue, length, skip_pseudo, skip_adj, False, sel, None, var)
                 to_hit = lambda r, h=hits, q=seqs: _hit_from_columns(h, q, profiles, r)
-                for b, lb in lst:
+                for b, lb, _v in lst:
                     rm = mk(b)
                     rm._set_lazy(res, lb, keys, to_hit)
                     self.results[b] = rm

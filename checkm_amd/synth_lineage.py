@@ -326,12 +326,21 @@ def _pool_map(root, seed, n_models, kind, args, jobs=None):
     from concurrent.futures import ProcessPoolExecutor
     jobs = jobs or int(os.environ.get("CKM_SYNTH_JOBS", "0")) or min(32, max(1, (os.cpu_count() or 2) - 2))
     jobs = max(1, min(jobs, len(args)))
-    if jobs == 1 or (kind == "hmm" and n_models <= 400):           # small worlds (tests): not worth starting interpreters
-        _worker_init(root, seed, n_models) if _WORKER_WORLD is None or _WORKER_WORLD.n_models != n_models or _WORKER_WORLD.seed != seed else None
-        for a in args:
-            yield _worker_task((kind, a))
-        return
-    with ProcessPoolExecutor(max_workers=jobs, mp_context=mp.get_context("spawn"), initializer=_worker_init,
-                             initargs=(root, seed, n_models)) as ex:
-        for r in ex.map(_worker_task, [(kind, a) for a in args]):
-            yield r
+    import sys
+    main_file = getattr(sys.modules.get("__main__"), "__file__", None)
+    spawnable = main_file is None or os.path.exists(main_file)       # 'spawn' re-imports __main__ by path: a script read from stdin has none
+    done = 0
+    if jobs > 1 and spawnable and not (kind == "hmm" and n_models <= 400):           # (small worlds, as in the tests, are not worth starting interpreters for)
+        try:
+            with ProcessPoolExecutor(max_workers=jobs, mp_context=mp.get_context("spawn"), initializer=_worker_init,
+                                     initargs=(root, seed, n_models)) as ex:
+                for r in ex.map(_worker_task, [(kind, a) for a in args]):
+                    done += 1
+                    yield r
+            return
+        except Exception:            # a broken pool (no usable __main__, no process slots ...): finish in this process
+            pass
+    if _WORKER_WORLD is None or _WORKER_WORLD.n_models != n_models or _WORKER_WORLD.seed != seed:
+        _worker_init(root, seed, n_models)
+    for a in args[done:]:
+        yield _worker_task((kind, a))

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CKM_ABI_VERSION 3
+#define CKM_ABI_VERSION 4
 
 enum {
   CKM_OK      =  0,
@@ -142,8 +142,16 @@ typedef struct {
   uint32_t ssv_launches;
   uint32_t cascade_fallback_lanes; /* lanes (length classes) of the last search that outgrew the device-side tables / workspace of the
                                       device-driven cascade and were run by the host-driven one instead (0 in the normal case) */
+  uint64_t ws_cap_bytes, ws_used_bytes;  /* float workspace of the device-driven cascade: allocated, and the high-water mark the search asked for */
 } ckm_search_stats;
 int ckm_last_search_stats(const ckm_ctx *ctx, ckm_search_stats *out);
+
+/* Starts allocating, on a background thread, the float workspace a search of `pairs` (ORF, model) pairs with a summed padded model
+ * length of `model_positions` (sum over pairs of 64 * ceil(M / 64)) will ask for, so that the allocation (tens of GB: seconds of
+ * hipMalloc) runs beside the caller's reading of FASTA files and profile databases instead of inside the first ckm_search.
+ * Returns at once; ckm_search / ckm_align / the diagnostics wait for it.  Replaces nothing of the reference (one hmmsearch process
+ * per bin allocates per process, checkm/hmmer.py:70): it exists because one context serves a whole batch of bins. */
+int ckm_ctx_reserve(ckm_ctx *ctx, uint64_t pairs, double model_positions);
 
 /* ---- the reduction --------------------------------------------------------------------------
  * Replaces ResultsParser.parseBinHits -> ResultsManager.{vetHit,addHit} -> PFAM.filterHitsFromSameClan
@@ -167,6 +175,12 @@ typedef struct {
   int32_t ignore_thresholds, skip_pseudogene_correction, skip_adj_correction, individual_markers;
   double  evalue_threshold, length_threshold;
   const uint8_t *bin_select;    /* NULL = every bin; else only bins with a non-zero byte are reduced */
+  /* Threshold VARIANTS: the reference resolves a model's GA/TC/NC from the header view of the BIN's own model file, and a sticky
+   * header parse (hmmerModelParser.py:54-83) can give the same model different cutoffs in different subsets.  With nvariants > 1,
+   * ckm_model_info.thr_kind / thr_full / thr_dom hold nvariants x nmodels entries (variant-major) and bin b uses variant
+   * bin_variant[b]; nvariants <= 1 or bin_variant == NULL: one table for every bin. */
+  uint32_t        nvariants;
+  const uint32_t *bin_variant;  /* [nbins] or NULL */
 } ckm_reduce_flags;
 
 typedef struct {
