@@ -60,7 +60,8 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
     if (const char *e = getenv("CKM_HOST_THREADS")) host_threads = std::max(1, std::min(64, atoi(e)));
     size_t fre = 0, tot = 0;
     size_t budget = (size_t)8 << 30;
-    if (hipMemGetInfo(&fre, &tot) == hipSuccess) budget = std::min<size_t>((size_t)96 << 30, fre / 2) / ctx->nworkers;
+    // (a quarter of what is free: MarkerGeneFinder.find keeps up to three contexts per device in flight, each with its own workspace)
+    if (hipMemGetInfo(&fre, &tot) == hipSuccess) budget = std::min<size_t>((size_t)96 << 30, fre / 4) / ctx->nworkers;
     if (const char *e = getenv("CKM_WS_BUDGET_MB")) budget = std::max<size_t>(16, strtoull(e, nullptr, 10)) << 20;   // tests: force several envelope batches
     const int nside = choose_side_streams(ctx->nworkers);
     { const int pr = getenv("CKM_CHAIN_PRIO") ? atoi(getenv("CKM_CHAIN_PRIO")) : 0; set_chain_prio_fb(pr); set_chain_prio_filter(pr); set_chain_prio_cascade(pr); }

@@ -76,7 +76,7 @@ struct DevBuf {
     if (bytes <= cap) return;
     if (p) (void)hipFree(p);
     p = nullptr; cap = 0;
-    size_t want = bytes + bytes / 4 + 256;
+    size_t want = bytes + std::min<size_t>(bytes / 4, (size_t)1 << 30) + 256;      // (growth slack, bounded: the float workspace is tens of GB)
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) { p = nullptr; throw Error(CKM_ENOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed: " + hipGetErrorString(e)); }
     cap = want;

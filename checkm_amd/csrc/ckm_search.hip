@@ -756,7 +756,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
       FinishArgs fa{dm, lt, dlen, s->d_order.as<uint32_t>(), ctx->work.as<SsvBlockWork>() + sb.first, ctx->maxv.as<uint16_t>(),
                     cd.cand, cnt + CC_CAND, sb.cap_cand, nores, cnt + CC_NORES, sb.cap_nores};
       launch_msv_finish(sc, fa, (uint32_t)sb.nblocks);
-      if (stop >= 2) launch_msv_full(sc, GRID_MSV, WorkQueue{nullptr, cnt + CC_NORES, sb.cap_nores}, nores, dm, lt, res, off, dlen, nullptr, nullptr, p->maxMp, &cd);
+      if (stop >= 2) launch_msv_full(sc, GRID_MSV, WorkQueue{nullptr, cnt + CC_NORES, sb.cap_nores}, nores, dm, lt, res, off, dlen, nullptr, nullptr, std::min(p->maxMp, 32 * sb.Q) /* the group's models fit its SSV class: a small LDS image, many pairs per CU */, &cd);
       if (stop >= 3) launch_bias_filter(sc, GRID_MSV, cd, dm, lt, res, off);
       int rc = 0;
       for (int c = NVC - 1; c >= 0; --c) if (sb.vit[c]) {

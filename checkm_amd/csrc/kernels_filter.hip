@@ -8,6 +8,7 @@
 // Every decision is taken on IEEE basic operations only (no device libm), so it is bit-identical
 // to the host formulation: thresholds were converted to score space on the host (host_profile.cpp).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstring>
 #include "dev_types.h"
 #include "cascade_dev.h"
@@ -452,8 +453,8 @@ void launch_msv_full(hipStream_t stream, uint32_t nblocks, WorkQueue queue, cons
   CascadeDev c; memset(&c, 0, sizeof(c));
   if (cd) c = *cd;
   const size_t lds = (((size_t)KP_SYMS * (maxMp + 1) + 15) & ~(size_t)15) + (size_t)2 * maxMp * sizeof(int16_t);
-  static size_t attr_bytes = 0;
-  if (lds > 48 * 1024 && lds > attr_bytes) { (void)hipFuncSetAttribute((const void *)msv_full_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_bytes = lds; }
+  static std::atomic<size_t> attr_bytes{0};          // (searches of several contexts launch from their own host threads)
+  if (lds > 48 * 1024 && lds > attr_bytes.load()) { (void)hipFuncSetAttribute((const void *)msv_full_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_bytes.store(lds); }
   hipLaunchKernelGGL(msv_full_kernel, dim3(nblocks), dim3(64), lds, stream, queue, pairs, models, lentab, res, seq_off, seq_len, out_xJ, out_usc, maxMp, c, cd ? 1 : 0);
 }
 void launch_bias(hipStream_t stream, PairRec *pairs, uint32_t npairs, const DevModel *models, const LenEntry *lentab,

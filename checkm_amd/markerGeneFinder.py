@@ -233,15 +233,16 @@ class MarkerGeneFinder(object):
         nmod = [len(models_of[b]) if models_of.get(b) is not None else profiles.n for b in binIds]
         batches = plan_batches(sizes, nmod)
         parts, where, totals = [None] * len(batches), {}, {}
-        # Two batches in flight, one per context (a context runs one search at a time): while one batch is on the GPU the other one's
-        # FASTA files are read / digitised / uploaded, its tables written, and the host part and the tail of its search hidden.
+        # Up to three batches in flight, one per context (a context runs one search at a time): while one batch's SSV launches fill the
+        # device, the FASTA files of another are read / digitised / uploaded, its tables written, and the latency-bound chain tail and the
+        # host part of a third are hidden (CKM_FIND_PIPELINE=n; measured on cfg3: profiles/r03*).
         lanes = [(ctx, profiles)]
-        if len(batches) >= 2 and os.environ.get("CKM_FIND_PIPELINE", "2") != "1":
+        for k in range(1, min(len(batches), max(1, int(os.environ.get("CKM_FIND_PIPELINE", "3"))))):
             try:
-                ctx2 = runtime.get_ctx2()
-                lanes.append((ctx2, profiles_for(ctx2, db)))
+                ck = runtime.get_ctx_k(k)
+                lanes.append((ck, profiles_for(ck, db)))
             except _lib.CkmError:
-                pass
+                break
         import threading
         tot_lock = threading.Lock()
         # the float workspace of a batch is tens of GB the first time a context meets one (seconds of hipMalloc): start allocating it

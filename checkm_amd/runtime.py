@@ -1,4 +1,4 @@
-"""Process-wide device context: one ckm_ctx per (process, device), as the C ABI requires.
+"""Process-wide device contexts: get_ctx() is the context everything single-shot uses; get_ctx_k(k) are the further ones find() alternates between.
 The device is CHECKM_AMD_DEVICE if set, else LOCAL_RANK when launched one-process-per-GPU, else 0."""
 import atexit
 import os
@@ -17,16 +17,23 @@ def get_ctx():
     return _ctx
 
 
-_ctx2 = None
+_extra = []
+
+
+def get_ctx_k(k):
+    """Context number k on the process's device (k = 0: get_ctx()).  MarkerGeneFinder.find keeps several batches of bins in flight, one
+    per context (a context runs one search at a time), so that the ingest, the host part and the chain tail of one batch run under the
+    SSV phase of the others.  The contexts of a device share the resident profile databases (read-only device memory); each has its
+    own streams, tables and float workspace, sized from a quarter of the memory that is free when it is created."""
+    if k == 0:
+        return get_ctx()
+    while len(_extra) < k:
+        _extra.append(_lib.Context(get_ctx().device))
+    return _extra[k - 1]
 
 
 def get_ctx2():
-    """A second context on the same device: MarkerGeneFinder.find keeps two batches of bins in flight, one per context (a context
-    runs one search at a time), so that the ingest, the host part and the tail of one batch run under the SSV phase of the other."""
-    global _ctx2
-    if _ctx2 is None:
-        _ctx2 = _lib.Context(get_ctx().device)
-    return _ctx2
+    return get_ctx_k(1)
 
 
 def close():
@@ -35,10 +42,8 @@ def close():
     mod = sys.modules.get("checkm_amd.markerGeneFinder")
     if mod is not None:
         mod.release_scan(final=True)    # hits, sequences and profile databases of this context
-    global _ctx2
-    if _ctx2 is not None:
-        _ctx2.close()
-        _ctx2 = None
+    while _extra:
+        _extra.pop().close()
     if _ctx is not None:
         _ctx.close()
         _ctx = None

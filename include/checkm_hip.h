@@ -9,8 +9,11 @@
  *   - the caller owns every input buffer; the library owns every output object and frees it in
  *     the matching *_free().  Column pointers returned by ckm_hits_columns()/ckm_qa_columns() stay
  *     valid until that object is freed.
- *   - one ckm_ctx per (process, device).  ckm_search / ckm_reduce / ckm_align calls on one ctx are not re-entrant; different ctxs
- *     are independent.  ckm_seqs_pack / ckm_seqs_from_fasta / ckm_hits_write_domtblout touch no state of the ctx and may run on
+ *   - a ckm_ctx runs ONE ckm_search / ckm_reduce / ckm_align at a time (not re-entrant); different ctxs are independent, also on
+ *     one device: MarkerGeneFinder.find keeps up to three on a device, one batch of bins in flight on each.  A ctx owns its streams,
+ *     tables and float workspace (budget: a quarter of the device memory free at creation, at most 96 GB); ckm_profiles, ckm_seqs
+ *     and ckm_hits are plain device / host memory and may be used with ANY ctx of the device they were created on (the contexts of
+ *     a device share one resident copy of a profile database; ckm_reduce may be called with another ctx than the one that searched).  ckm_seqs_pack / ckm_seqs_from_fasta / ckm_hits_write_domtblout touch no state of the ctx and may run on
  *     other threads while a search is in flight (MarkerGeneFinder.find reads the next batch of bins and writes the previous batch's
  *     tables that way).  The library never falls back to a CPU implementation: without a usable HIP
  *     device ckm_ctx_create() fails with CKM_ENODEV and nothing else can be called.
