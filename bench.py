@@ -272,6 +272,7 @@ class Env(object):
         self.dev_index = int(os.environ.get("CKM_BENCH_DEVICE", local_rank))
         backend = os.environ.get("CKM_BENCH_DIST_BACKEND", "nccl")
         os.environ["CHECKM_AMD_DEVICE"] = str(self.dev_index)
+        os.environ.setdefault("CKM_GPUS", "")           # this launch IS the GPU fan-out (one rank per GPU): find() must not spawn workers of its own
         os.environ.setdefault("CKM_DIST_BACKEND", backend)
         torch.cuda.set_device(self.dev_index)
         if self.world > 1:

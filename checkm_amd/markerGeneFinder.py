@@ -53,11 +53,20 @@ def release_scan(outDir=None, final=False):
         mod = sys.modules.get("checkm_amd.resultsParser")
         if mod is not None:
             mod.materialize_lazy_hits()
+    pools = []
     for key in list(SCAN_CACHE):
         if outDir is None or key[0] == os.path.abspath(outDir):
             ent = SCAN_CACHE.pop(key)
             for part in ent["parts"]:
                 part["hits"].close(); part["seqs"].close()
+            if ent.get("pool") is not None and ent["pool"] not in pools:
+                pools.append(ent["pool"])
+    for pool in pools:                            # the workers hold the resident scans of a multi-GPU find()
+        try:
+            if not final:
+                pool.call("release", dict(outDir=outDir))
+        except Exception:
+            pass
     if outDir is None:
         for k in list(PROFILE_CACHE):
             PROFILE_CACHE.pop(k).close()
@@ -184,6 +193,10 @@ class MarkerGeneFinder(object):
         tables of batch k-1 are written by host threads while batch k is on the GPU."""
         from concurrent.futures import ThreadPoolExecutor
         from checkm_amd import dist as cdist
+        from checkm_amd import workers
+        devs = workers.devices()
+        if devs is not None:
+            return self._find_with_workers(devs, binFiles, outDir, tableOut, hmmerOut, markerFile, bKeepAlignment, bNucORFs, bCalledGenes)
         try:
             ctx = runtime.get_ctx()
         except Exception as e:
@@ -203,15 +216,7 @@ class MarkerGeneFinder(object):
             self.logger.error('marker-gene scan failed: %s' % e)
             sys.exit(1)
         heads = profiles.headers
-        models_of = {}
-        if any(w is not None for w in wanted.values()):
-            cache = {}
-            for b in allIds:
-                w = wanted[b]
-                key = id(w)
-                if key not in cache:
-                    cache[key] = None if w is None else [i for i, h in enumerate(heads) if wanted_model(h["name"], h["acc"], w)]
-                models_of[b] = cache[key]
+        models_of = model_lists(heads, allIds, wanted)
         # ---- this rank's shard (weights = file size x models) ----
         mine = list(range(len(binFiles)))
         if world > 1:
@@ -311,29 +316,83 @@ class MarkerGeneFinder(object):
             for b, i in enumerate(batch):
                 where[binIds[i]] = (k, b)
         key = (os.path.abspath(outDir), tableOut)
-        if key in SCAN_CACHE:
-            mod = sys.modules.get("checkm_amd.resultsParser")
-            if mod is not None:
-                mod.materialize_lazy_hits()       # hit lists handed out lazily still point into the scan that is replaced here
-            old = SCAN_CACHE.pop(key)
-            for part in old["parts"]:
-                part["hits"].close(); part["seqs"].close()
+        release_key(key)
         SCAN_CACHE[key] = dict(ctx=ctx, profiles=profiles, parts=parts, where=where, owned=set(binIds), world=world,
                                all_bins=list(allIds), totals=totals)        # totals: stage counters summed over this rank's ckm_search calls
         if world > 1:
             cdist.barrier()             # every rank's tables are on disk before anyone reads them
-        out = {}
-        subset_cache = {}
-        for b in allIds:
-            m = models_of.get(b) if models_of else None
-            if m is None:
-                if None not in subset_cache:
-                    subset_cache[None] = models_dict(heads)
-                out[b] = subset_cache[None]
-            else:
-                k2 = id(m)
-                if k2 not in subset_cache:
-                    subset_cache[k2] = models_dict([heads[i] for i in m])
-                out[b] = subset_cache[k2]
+        out = models_for_bins(heads, allIds, models_of)
         self.logger.info("    Finished processing %d of %d (100.00%%) bins." % (len(allIds), len(allIds)))
         return out
+
+    def _find_with_workers(self, devs, binFiles, outDir, tableOut, hmmerOut, markerFile, bKeepAlignment, bNucORFs, bCalledGenes):
+        """find() on a multi-GPU node: one worker process per device (checkm_amd/workers.py), spawned here as the reference's find()
+        forks its own workers (checkm/markerGeneFinder.py:59-83); this process keeps everything outside the path to itself."""
+        from checkm_amd import workers
+        try:
+            pool = workers.get_pool(devs)
+            replies = pool.call("find", dict(binFiles=list(binFiles), outDir=outDir, tableOut=tableOut, hmmerOut=hmmerOut, markerFile=markerFile,
+                                             bKeepAlignment=bKeepAlignment, bNucORFs=bNucORFs, bCalledGenes=bCalledGenes, threads=self.totalThreads))
+        except workers.WorkerError as e:
+            self.logger.error('marker-gene scan failed: %s' % e)
+            sys.exit(1)
+        self.logger.info("Identified marker genes in %d bins on %d devices." % (len(binFiles), len(devs)))
+        heads = replies[0]["heads"]
+        allIds = [binIdFromFilename(f) for f in binFiles]
+        wanted = MarkerSetParser(self.totalThreads).markerAccessionsForBins(allIds, markerFile)
+        models_of = model_lists(heads, allIds, wanted)
+        totals = {}
+        for r in replies:
+            for k, v in r["totals"].items():
+                totals[k] = max(totals.get(k, 0), v) if k in ("ws_cap_bytes", "ws_used_bytes") else totals.get(k, 0) + v
+        key = (os.path.abspath(outDir), tableOut)
+        release_key(key)
+        SCAN_CACHE[key] = dict(pool=pool, world=len(devs), owned=set(), parts=[], where={}, all_bins=list(allIds), totals=totals,
+                               owners={b: r for r, rep in enumerate(replies) for b in rep["owned"]}, profiles=None, ctx=None)
+        return models_for_bins(heads, allIds, models_of)
+
+
+def model_lists(heads, allIds, wanted):
+    """{binId: indices into the profile database of the models the bin is scanned against} ({} when every bin takes every model); bins
+    that ask for the same accession set share one list object."""
+    models_of = {}
+    if any(w is not None for w in wanted.values()):
+        cache = {}
+        for b in allIds:
+            w = wanted[b]
+            key = id(w)
+            if key not in cache:
+                cache[key] = None if w is None else [i for i, h in enumerate(heads) if wanted_model(h["name"], h["acc"], w)]
+            models_of[b] = cache[key]
+    return models_of
+
+
+def models_for_bins(heads, allIds, models_of):
+    """find()'s return value, {binId: {acc: HmmModel}}: the (sticky) header view of each bin's model subset; bins with the same subset
+    share one dict."""
+    out = {}
+    subset_cache = {}
+    for b in allIds:
+        m = models_of.get(b) if models_of else None
+        if m is None:
+            if None not in subset_cache:
+                subset_cache[None] = models_dict(heads)
+            out[b] = subset_cache[None]
+        else:
+            k2 = id(m)
+            if k2 not in subset_cache:
+                subset_cache[k2] = models_dict([heads[i] for i in m])
+            out[b] = subset_cache[k2]
+    return out
+
+
+def release_key(key):
+    """Drop one cached scan (hit lists handed out lazily are filled in first)."""
+    if key not in SCAN_CACHE:
+        return
+    mod = sys.modules.get("checkm_amd.resultsParser")
+    if mod is not None:
+        mod.materialize_lazy_hits()       # hit lists handed out lazily still point into the scan that is replaced here
+    old = SCAN_CACHE.pop(key)
+    for part in old["parts"]:
+        part["hits"].close(); part["seqs"].close()

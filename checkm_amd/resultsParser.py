@@ -552,10 +552,13 @@ class ResultsParser(object):
         self.logger = logging.getLogger('timestamp')
         self.results = {}
         self.models = binIdToModels
+        self._binStatsFile = DefaultValues.BIN_STATS_OUT
+        self._pool = None
 
     def analyseResults(self, outDir, binStatsFile, hmmTableFile, bIgnoreThresholds=False, evalueThreshold=DefaultValues.E_VAL,
                        lengthThreshold=DefaultValues.LENGTH, bSkipPseudoGeneCorrection=False, bSkipAdjCorrection=False):
         binStats = self.parseBinStats(outDir, binStatsFile)
+        self._binStatsFile = binStatsFile
         self.parseBinHits(outDir, hmmTableFile, bSkipAdjCorrection, bIgnoreThresholds, evalueThreshold, lengthThreshold,
                           bSkipPseudoGeneCorrection, binStats)
         return binStats
@@ -602,6 +605,22 @@ class ResultsParser(object):
                                       binStats[b] if (binStats is not None and b in binStats) else None)
         self._mk, self._text_args = mk, (outDir, hmmTableFile, bSkipAdjCorrection, bIgnoreThresholds, evalueThreshold, lengthThreshold, bSkipPseudoGeneCorrection)
         self.remote_bins = []
+        self._pool = None
+        if ent is not None and ent.get("pool") is not None:
+            # find() fanned out over worker processes (checkm_amd/workers.py): they reduce the bins they scanned; this process learns the
+            # QA rows in printSummary (one gather among the workers) and reads the workers' tables for anything that needs the hits
+            from checkm_amd import workers
+            self._pool = (ent["pool"], outDir, hmmTableFile)
+            try:
+                ent["pool"].call("analyse", dict(outDir=outDir, binStatsFile=self._binStatsFile, hmmTableFile=hmmTableFile, bIgnoreThresholds=bIgnoreThresholds,
+                                                 evalueThreshold=evalueThreshold, lengthThreshold=lengthThreshold,
+                                                 bSkipPseudoGeneCorrection=bSkipPseudoGeneCorrection, bSkipAdjCorrection=bSkipAdjCorrection))
+            except workers.WorkerError as e:
+                self.logger.error('reduction of the marker-gene hits failed: %s' % e)
+                sys.exit(1)
+            self.remote_bins = list(binIds)
+            self.logger.info('    Finished parsing hits for %d of %d (100.00%%) bins.' % (len(binIds), len(binIds)))
+            return
         if ent is not None and ent.get("world", 1) > 1:
             # one process per GPU: this rank reduces the bins it scanned; the QA rows of the others arrive in printSummary's gather
             self.remote_bins = [b for b in binIds if b not in ent["owned"]]
@@ -613,6 +632,7 @@ class ResultsParser(object):
         if rest:
             self._reduce_text(outDir, hmmTableFile, rest, mk, bSkipAdjCorrection, bIgnoreThresholds, evalueThreshold, lengthThreshold,
                               bSkipPseudoGeneCorrection)
+        self._order_results()
         self.logger.info('    Finished parsing hits for %d of %d (100.00%%) bins.' % (len(binIds), len(binIds)))
 
     # the packed hits of a scan run in this process: no text round-trip
@@ -830,11 +850,10 @@ class ResultsParser(object):
             out[b] = row
         return out
 
-    def _gather_remote_rows(self, aai, binIdToBinMarkerSets, bIndividualMarkers):
-        """One process per GPU: ONE all_gather of fixed-width QA rows (checkm_amd/dist.py) brings the rows of the bins the other
-        ranks scanned; they become ResultsManagers that only know their row (remote = True)."""
+    def _gather_rows(self, aai, binIdToBinMarkerSets, bIndividualMarkers, order):
+        """The QA rows of the bins THIS process reduced, packed to fixed width, exchanged by ONE all_gather (checkm_amd/dist.py);
+        returns the table of all ranks, sorted by bin index into `order`."""
         from checkm_amd import dist as cdist
-        order = sorted(self.models.keys())
         index = {b: i for i, b in enumerate(order)}
         own = [b for b in sorted(self.results) if not self.results[b].remote]
         rows = self.batchedGeneCounts(binIdToBinMarkerSets, bIndividualMarkers, own)
@@ -843,7 +862,15 @@ class ResultsParser(object):
                                     [rows[b][0:6] for b in own] if own else np.zeros((0, 6)), [rows[b][6] for b in own], [rows[b][7] for b in own])
         for k, b in enumerate(own):
             packed[k, 11] = aai.aaiMeanBinHetero.get(b, 0.0) if aai is not None else 0.0
-        table = cdist.gather_qa_rows(packed, len(order), cdist.collective_device())
+        return cdist.gather_qa_rows(packed, len(order), cdist.collective_device())
+
+    def _order_results(self):
+        """self.results in the key order of self.models, as the reference fills it (resultsParser.py:191-217): cacheResults and the
+        per-bin output formats iterate the dict."""
+        self.results = {b: self.results[b] for b in list(self.models) + [b for b in self.results if b not in self.models] if b in self.results}
+
+    def _adopt_rows(self, table, order, binIdToBinMarkerSets, bIndividualMarkers):
+        """Rows of bins reduced elsewhere become ResultsManagers that only know their row (remote = True)."""
         for r in table:
             b = order[int(r[0])]
             if b in self.results and not self.results[b].remote:
@@ -854,6 +881,42 @@ class ResultsParser(object):
             rm._counts[bool(bIndividualMarkers)] = (ms, [int(x) for x in r[3:9]] + [float(r[9]), float(r[10])])
             rm.het = float(r[11])
             self.results[b] = rm
+        self._order_results()
+
+    def _gather_remote_rows(self, aai, binIdToBinMarkerSets, bIndividualMarkers):
+        """One process per GPU: ONE all_gather of fixed-width QA rows brings the rows of the bins the other ranks scanned."""
+        order = sorted(self.models.keys())
+        self._adopt_rows(self._gather_rows(aai, binIdToBinMarkerSets, bIndividualMarkers, order), order, binIdToBinMarkerSets, bIndividualMarkers)
+
+    def _rows_from_workers(self, aai, binIdToBinMarkerSets, bIndividualMarkers):
+        """find() ran on worker processes: each reduces and counts its bins, the workers exchange the rows (one all_gather) and worker
+        0 hands the table over."""
+        from checkm_amd import workers
+        from checkm_amd.markerGeneFinder import SCAN_CACHE
+        pool, outDir, tbl = self._pool
+        order = sorted(self.models.keys())
+        owners = SCAN_CACHE[(os.path.abspath(outDir), tbl)]["owners"]
+        per = [dict(sets={}) for _ in pool.devs]
+        for b in order:
+            per[owners[b]]["sets"][b] = binIdToBinMarkerSets[b].selectedMarkerSet()
+        het = dict(aai.aaiMeanBinHetero) if aai is not None else {}
+        try:
+            replies = pool.call("summary", dict(outDir=outDir, hmmTableFile=tbl, bIndividualMarkers=bIndividualMarkers, order=order, het=het), per)
+        except workers.WorkerError as e:
+            self.logger.error('gathering the QA rows failed: %s' % e)
+            sys.exit(1)
+        self._adopt_rows(replies[0], order, binIdToBinMarkerSets, bIndividualMarkers)
+
+    def _localize_remote(self):
+        """Bins whose hits live in another process (remote rows, or not reduced yet): read the tables their owners wrote."""
+        remote = [b for b in self.models if b not in self.results or self.results[b].remote]
+        if remote and hasattr(self, "_text_args"):
+            outDir, tbl, skip_adj, ignore, ev, ln, skip_ps = self._text_args
+            for b in remote:
+                self.results.pop(b, None)
+            self._reduce_text(outDir, tbl, remote, self._mk, skip_adj, ignore, ev, ln, skip_ps)
+            self.remote_bins = []
+            self._order_results()
 
     def printSummary(self, outputFormat, aai, binIdToBinMarkerSets, bIndividualMarkers, coverageFile, bTabTable, outFile, anaFolder):
         """The QA table in any of the output formats (resultsParser.py:275-319).  Tab mode is byte-compatible with the reference; the framed
@@ -864,7 +927,12 @@ class ResultsParser(object):
             self.logger.error('Coverage profiles are not part of this path.')
             sys.exit(1)
         from checkm_amd import dist as cdist
-        if cdist.world_size() > 1:
+        if self._pool is not None:
+            if outputFormat in (1, 2):
+                self._rows_from_workers(aai, binIdToBinMarkerSets, bIndividualMarkers)
+            else:
+                self._localize_remote()
+        elif cdist.world_size() > 1:
             if outputFormat in (1, 2):
                 self._gather_remote_rows(aai, binIdToBinMarkerSets, bIndividualMarkers)
             elif cdist.env_rank()[0] == 0 and getattr(self, "remote_bins", None):
@@ -904,6 +972,8 @@ class ResultsParser(object):
 
     def cacheResults(self, outDir, binIdToBinMarkerSets, bIndividualMarkers):
         """storage/bin_stats_ext.tsv and storage/marker_gene_stats.tsv (resultsParser.py:121-143)."""
+        if self._pool is not None:
+            self._localize_remote()            # the copy numbers and the per-gene table need the hits themselves
         with open(os.path.join(outDir, 'storage', DefaultValues.BIN_STATS_EXT_OUT), 'w') as fout:
             for binId in self.results:
                 ext = self.results[binId].getSummary(binIdToBinMarkerSets[binId], bIndividualMarkers, outputFormat=2)

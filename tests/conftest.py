@@ -6,6 +6,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the tests drive one device in this process unless a test asks for workers itself (tests/test_gpu_workers.py): on a multi-GPU box
+# MarkerGeneFinder.find would otherwise spawn a worker per visible device (checkm_amd/workers.py)
+os.environ.setdefault("CKM_GPUS", "")
 
 
 def pytest_configure(config):
