@@ -238,11 +238,12 @@ class MarkerGeneFinder(object):
         nmod = [len(models_of[b]) if models_of.get(b) is not None else profiles.n for b in binIds]
         batches = plan_batches(sizes, nmod)
         parts, where, totals = [None] * len(batches), {}, {}
-        # Up to three batches in flight, one per context (a context runs one search at a time): while one batch's SSV launches fill the
-        # device, the FASTA files of another are read / digitised / uploaded, its tables written, and the latency-bound chain tail and the
-        # host part of a third are hidden (CKM_FIND_PIPELINE=n; measured on cfg3: profiles/r03*).
+        # Two batches in flight, one per context (a context runs one search at a time): while one batch's SSV launches fill the device,
+        # the FASTA files of the other are read / digitised / uploaded, its tables written, and its chain tail and host part hidden.
+        # CKM_FIND_PIPELINE=n for n lanes; measured on cfg3 (1000 bins, profiles/r03c_lanes.txt): 2 lanes 15.9 s, 3 lanes 17.2 s (find itself
+        # 0.6 s faster, but releasing three contexts' scans costs 2 s), 4 lanes 16.5 s.
         lanes = [(ctx, profiles)]
-        for k in range(1, min(len(batches), max(1, int(os.environ.get("CKM_FIND_PIPELINE", "3"))))):
+        for k in range(1, min(len(batches), max(1, int(os.environ.get("CKM_FIND_PIPELINE", "2"))))):
             try:
                 ck = runtime.get_ctx_k(k)
                 lanes.append((ck, profiles_for(ck, db)))
