@@ -101,7 +101,7 @@ class TableColumns(C.Structure):
 EXPORTS = ["ckm_last_error", "ckm_abi_version", "ckm_device_count", "ckm_ctx_create", "ckm_ctx_destroy", "ckm_ctx_reserve",
            "ckm_profiles_load", "ckm_profiles_count", "ckm_profiles_header", "ckm_profiles_free",
            "ckm_seqs_pack", "ckm_seqs_from_fasta", "ckm_seqs_count", "ckm_seqs_bin_offsets", "ckm_seqs_name", "ckm_seqs_residues", "ckm_seqs_free", "ckm_search", "ckm_hits_columns", "ckm_hits_free",
-           "ckm_hits_write_domtblout", "ckm_last_search_stats", "ckm_reduce", "ckm_qa_columns_get", "ckm_qa_free", "ckm_count_sets",
+           "ckm_hits_write_domtblout", "ckm_hits_write_alignments", "ckm_last_search_stats", "ckm_reduce", "ckm_qa_columns_get", "ckm_qa_free", "ckm_count_sets",
            "ckm_align", "ckm_tables_read", "ckm_tables_assign_models", "ckm_tables_get", "ckm_tables_free",
            "ckm_debug_stages", "ckm_debug_envelopes", "ckm_debug_region"]
 
@@ -143,6 +143,7 @@ def load():
     L.ckm_hits_free.argtypes = [C.c_void_p]
     L.ckm_hits_free.restype = None
     L.ckm_hits_write_domtblout.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p]
+    L.ckm_hits_write_alignments.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p]
     L.ckm_last_search_stats.argtypes = [C.c_void_p, C.POINTER(SearchStats)]
     L.ckm_reduce.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(HitColumns), C.c_void_p, C.POINTER(ModelInfo),
                              C.POINTER(ReduceFlags), C.POINTER(MarkerSetsCSR), C.POINTER(C.c_void_p)]
@@ -316,6 +317,10 @@ class Hits(object):
 
     def write_domtblout(self, profiles, seqs, b, path):
         _chk(load().ckm_hits_write_domtblout(self.h, profiles.h, seqs.h, b, path.encode()))
+
+    def write_alignments(self, ctx, profiles, seqs, b, path):
+        """hmmsearch-style report of bin b with the domain alignments (what `-o` holds when CheckM keeps alignments)."""
+        _chk(load().ckm_hits_write_alignments(ctx.h, self.h, profiles.h, seqs.h, b, path.encode()))
 
     def close(self):
         if self.h:

@@ -418,6 +418,105 @@ extern "C" int ckm_hits_write_domtblout(const ckm_hits *h, const ckm_profiles *p
   });
 }
 
+// HMMER's amino-acid background (Swiss-Prot 50.8 composition; the same table host_profile.cpp configures profiles with)
+static const float kBgAmino[ckm::K] = {0.0787945f, 0.0151600f, 0.0535222f, 0.0668298f, 0.0397062f, 0.0695071f, 0.0229198f, 0.0590092f, 0.0594422f, 0.0963728f,
+                                       0.0237718f, 0.0414386f, 0.0482904f, 0.0395639f, 0.0540978f, 0.0683364f, 0.0540687f, 0.0673417f, 0.0114135f, 0.0304133f};
+
+// ---- hmmsearch-style report with the domain alignments (bKeepAlignment) ------------------------------------------------
+// What `hmmsearch -o <hmmerOut>` leaves when CheckM keeps alignments (checkm/markerGeneFinder.py:138-142, `--ali`): per query model the
+// score table of the reported sequences, and per domain the alignment of the envelope's optimal-accuracy path.  Nothing in CheckM
+// reads this file back; it is for the user.  The paths come from the same envelope kernels that produced the row's coordinates
+// (rescore_envelopes with traces), the consensus line from the model's match emissions (upper case above 0.5, HMMER's rule for amino
+// acids), the middle line marks identities by the consensus letter and positive log-odds by '+'.  NOT reproduced: the posterior
+// probability line under each alignment and the `exp` column (expected number of domains) -- both would need the per-residue
+// posteriors on the host -- and hmmsearch's line wrapping (the file is written as with --notextw).
+extern "C" int ckm_hits_write_alignments(ckm_ctx *ctx_, const ckm_hits *h, const ckm_profiles *p, const ckm_seqs *s, uint32_t bin, const char *path) {
+  return guarded([&] {
+    if (!ctx_ || !h || !p || !s || !path) throw Error(CKM_EINVAL, "NULL argument");
+    if (bin >= h->nbins) throw Error(CKM_EINVAL, "bin out of range");
+    ctx_->settle();
+    Worker *ctx = &ctx_->w[0];
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t r0 = h->bin_row_off[bin], r1 = h->bin_row_off[bin + 1];
+    std::vector<EnvReq> req;
+    for (uint64_t r = r0; r < r1; ++r) req.push_back({h->model[r], h->seq[r], h->env_from[r], h->env_to[r]});
+    std::vector<EnvRes> res; std::vector<std::vector<int32_t>> paths;
+    if (!req.empty()) rescore_envelopes(ctx, p, s, req, res, &paths);
+    FILE *f = fopen(path, "w");
+    if (!f) throw Error(CKM_EIO, std::string("cannot write ") + path);
+    fprintf(f, "# hmmsearch-style report written by libcheckm_hip (MI355X scan; options -E 0.1 --domE 0.1 --notextw).\n"
+               "# Alignments: optimal-accuracy path of each domain's envelope; the posterior-probability line and the `exp` column of hmmsearch are not produced.\n");
+    static const char kSym[] = "ACDEFGHIKLMNPQRSTVWY-BJZOUX*~";
+    uint64_t r = r0;
+    while (r < r1) {
+      const uint32_t m = h->model[r];
+      uint64_t re = r;
+      while (re < r1 && h->model[re] == m) ++re;
+      const HostHMM &hm = p->hmm[m];
+      // consensus line of the model
+      std::string cons((size_t)hm.M + 1, 'x');
+      for (int k = 1; k <= hm.M; ++k) {
+        int best = 0;
+        for (int x = 1; x < K; ++x) if (hm.mat[(size_t)k * K + x] > hm.mat[(size_t)k * K + best]) best = x;
+        cons[k] = hm.mat[(size_t)k * K + best] > 0.5f ? kSym[best] : (char)tolower(kSym[best]);
+      }
+      fprintf(f, "\nQuery:       %s  [M=%d]\n", hm.name.c_str(), hm.M);
+      if (hm.has_acc && !hm.acc.empty()) fprintf(f, "Accession:   %s\n", hm.acc.c_str());
+      if (hm.has_desc && !hm.desc.empty()) fprintf(f, "Description: %s\n", hm.desc.c_str());
+      fprintf(f, "Scores for complete sequences (score includes all domains):\n   --- full sequence ---   --- best 1 domain ---    -#dom-\n"
+                 "    E-value  score  bias    E-value  score  bias    exp  N  Sequence Description\n"
+                 "    ------- ------ -----    ------- ------ -----   ---- --  -------- -----------\n");
+      for (uint64_t a = r; a < re; ++a) {
+        if (h->dom_idx[a] != 1) continue;
+        uint64_t best = a;                                   // best-scoring domain of this sequence
+        for (uint64_t b = a; b < re && h->seq[b] == h->seq[a]; ++b) if (h->dom_score[b] > h->dom_score[best]) best = b;
+        fprintf(f, "  %9.2g %6.1f %5.1f  %9.2g %6.1f %5.1f   %4s %2d  %s  %s\n", h->full_evalue[a], h->full_score[a], h->full_bias[a], h->i_evalue[best],
+                h->dom_score[best], h->dom_bias[best], "-", h->ndom[a], s->names[h->seq[a]].c_str(), s->descs[h->seq[a]].c_str());
+      }
+      fprintf(f, "\n\nDomain annotation for each sequence (and alignments):\n");
+      for (uint64_t a = r; a < re; ++a) {
+        const uint32_t sq = h->seq[a];
+        if (h->dom_idx[a] == 1) {
+          fprintf(f, ">> %s  %s\n   #    score  bias  c-Evalue  i-Evalue hmmfrom  hmm to    alifrom  ali to    envfrom  env to     acc\n"
+                     " ---   ------ ----- --------- --------- ------- -------    ------- -------    ------- -------    ----\n", s->names[sq].c_str(), s->descs[sq].c_str());
+          for (uint64_t b = a; b < re && h->seq[b] == sq; ++b)
+            fprintf(f, " %3d %c %6.1f %5.1f %9.2g %9.2g %7d %7d %c%c %7d %7d %c%c %7d %7d %c%c %4.2f\n", h->dom_idx[b], '!', h->dom_score[b], h->dom_bias[b], h->c_evalue[b],
+                    h->i_evalue[b], h->hmm_from[b], h->hmm_to[b], h->hmm_from[b] == 1 ? '[' : '.', h->hmm_to[b] == hm.M ? ']' : '.', h->ali_from[b], h->ali_to[b],
+                    h->ali_from[b] == 1 ? '[' : '.', h->ali_to[b] == h->tlen[b] ? ']' : '.', h->env_from[b], h->env_to[b], h->env_from[b] == 1 ? '[' : '.',
+                    h->env_to[b] == h->tlen[b] ? ']' : '.', h->acc[b]);
+          fprintf(f, "\n  Alignments for each domain:\n");
+        }
+        fprintf(f, "  == domain %d  score: %.1f bits;  conditional E-value: %.2g\n", h->dom_idx[a], h->dom_score[a], h->c_evalue[a]);
+        const std::vector<int32_t> &path = paths[a - r0];
+        const uint8_t *dsq = s->dsq.data() + s->off[sq];
+        std::string ml, mid, tl;
+        if (res[a - r0].ok && (int)path.size() >= hm.M) {
+          const int base = h->env_from[a] - 1;                // path entries are 1-based within the envelope
+          int prev_res = 0;
+          for (int k = h->hmm_from[a]; k <= h->hmm_to[a]; ++k) {
+            const int pr = path[(size_t)k - 1];
+            if (pr == 0) { ml += cons[k]; mid += ' '; tl += '-'; continue; }
+            const int i = base + pr;                           // sequence coordinate, 1-based
+            if (prev_res) for (int j = prev_res + 1; j < i; ++j) { ml += '.'; mid += ' '; tl += (char)tolower(kSym[dsq[j - 1]]); }
+            const int x = dsq[i - 1];
+            ml += cons[k]; tl += kSym[x];
+            if (x < K && toupper(cons[k]) == kSym[x]) mid += cons[k];
+            else if (x < K && hm.mat[(size_t)k * K + x] > kBgAmino[x]) mid += '+';
+            else mid += ' ';
+            prev_res = i;
+          }
+        } else ml = mid = tl = "(no alignment: the envelope could not be rescored)";
+        const int w = (int)std::max(hm.name.size(), s->names[sq].size());
+        fprintf(f, "  %*s %7d %s %-7d\n  %*s %7s %s\n  %*s %7d %s %-7d\n\n", w, hm.name.c_str(), h->hmm_from[a], ml.c_str(), h->hmm_to[a], w, "", "", mid.c_str(), w,
+                s->names[sq].c_str(), h->ali_from[a], tl.c_str(), h->ali_to[a]);
+      }
+      r = re;
+    }
+    fprintf(f, "\n//\n[ok]\n");
+    if (fclose(f) != 0) throw Error(CKM_EIO, std::string("error closing ") + path);
+  });
+}
+
 // ---- alignment of marker genes to their models ---------------------------------------------------------
 extern "C" int ckm_align(ckm_ctx *ctx_, const ckm_profiles *p, const ckm_seqs *s, const uint32_t *model, const uint32_t *seq, uint32_t n,
                          const uint64_t *out_off, int32_t *node_residue) {

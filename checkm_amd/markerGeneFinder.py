@@ -231,9 +231,6 @@ class MarkerGeneFinder(object):
             mine = cdist.shard_bins(wts, world)[rank]
         myFiles = [binFiles[i] for i in mine]
         binIds, faa = self._geneFiles(myFiles, outDir, bNucORFs, bCalledGenes)
-        if bKeepAlignment:
-            self.logger.warning("--ali: the MI355X scan runs with --noali semantics; %s holds a note instead of hmmsearch's alignment text "
-                                "(use `checkm_amd.hmmerAligner` for alignments of the marker genes)." % hmmerOut)
         sizes = [os.path.getsize(f) if os.path.exists(f) else 0 for f in faa]
         nmod = [len(models_of[b]) if models_of.get(b) is not None else profiles.n for b in binIds]
         batches = plan_batches(sizes, nmod)
@@ -293,9 +290,8 @@ class MarkerGeneFinder(object):
             part = dict(seqs=seqs, hits=hits, bins=[binIds[i] for i in batch], profiles=prof)
             for b, i in enumerate(batch):
                 hits.write_domtblout(prof, seqs, b, os.path.join(outDir, 'bins', binIds[i], tableOut))
-                if bKeepAlignment:
-                    with open(os.path.join(outDir, 'bins', binIds[i], hmmerOut), 'w') as f:
-                        f.write("# alignments are not produced by the MI355X scan (--noali semantics)\n")
+                if bKeepAlignment:            # hmmsearch's -o text with the domain alignments (markerGeneFinder.py:138-142 drops --noali)
+                    hits.write_alignments(c, prof, seqs, b, os.path.join(outDir, 'bins', binIds[i], hmmerOut))
             parts[k] = part
             with tot_lock:
                 totals["write_s"] = totals.get("write_s", 0.0) + (_t.perf_counter() - t2)

@@ -147,6 +147,12 @@ typedef struct {
                                       device-driven cascade and were run by the host-driven one instead (0 in the normal case) */
   uint64_t ws_cap_bytes, ws_used_bytes;  /* float workspace of the device-driven cascade: allocated, and the high-water mark the search asked for */
 } ckm_search_stats;
+/* Replaces the text `hmmsearch -o <hmmerOut>` leaves when CheckM keeps alignments (bKeepAlignment: checkm/markerGeneFinder.py:138-142
+ * drops --noali): per query model the score table and, per reported domain, the alignment of the envelope's optimal-accuracy path
+ * (model consensus / identity-or-'+' line / target with inserts in lower case).  The posterior-probability line and the `exp` column
+ * of hmmsearch are not produced; CheckM never reads this file back. */
+int ckm_hits_write_alignments(ckm_ctx *ctx, const ckm_hits *h, const ckm_profiles *p, const ckm_seqs *s, uint32_t bin, const char *path);
+
 int ckm_last_search_stats(const ckm_ctx *ctx, ckm_search_stats *out);
 
 /* Starts allocating, on a background thread, the float workspace a search of `pairs` (ORF, model) pairs with a summed padded model

@@ -232,3 +232,41 @@ def test_multi_copy_markers_are_aligned_and_scored(gpu_ctx, tmp_path):
     for binId, v in a.aaiMeanBinHetero.items():
         assert 0.0 <= v <= 100.0
     hs.close(); release_scan()
+
+
+def test_keep_alignment_writes_the_domain_alignments(gpu_ctx, tmp_path):
+    """bKeepAlignment (checkm/markerGeneFinder.py:138-142: hmmsearch without --noali, -o <hmmerOut>): the report holds, per reported
+    domain, the alignment of the envelope's optimal-accuracy path.  Checked against the domtblout rows of the same scan: the target
+    line spells the ORF from ali_from to ali_to, the model line covers hmm_from..hmm_to, gaps and inserts are where the columns say."""
+    from checkm_amd import hmmer as chm
+    profs = synth.small_profiles(11, 12, 40, 300)
+    hmm = common.hmm_file("s11", profs)
+    recs = synth.make_bin(profs, 4711, n_orfs=150, dup_frac=0.6)
+    faa = str(tmp_path / "b.faa")
+    synth.write_fasta(faa, recs)
+    out = str(tmp_path / "out")
+    MarkerGeneFinder(1).find([faa], out, DefaultValues.HMMER_TABLE_OUT, DefaultValues.HMMER_OUT, hmm, True, False, True)
+    rows = list(chm.read_domtblout(os.path.join(out, "bins", "b", DefaultValues.HMMER_TABLE_OUT)))
+    text = open(os.path.join(out, "bins", "b", DefaultValues.HMMER_OUT)).read().split("\n")
+    seqs = {r[0]: r[2] for r in recs}
+    blocks = []                                            # (query, target, model line, target line, coordinates)
+    query = None
+    for i, line in enumerate(text):
+        if line.startswith("Query:"):
+            query = line.split()[1]
+        if line.startswith("  == domain"):
+            ml, tl = text[i + 1].split(), text[i + 3].split()
+            blocks.append((query, tl[0], ml[2], tl[2], int(ml[1]), int(ml[3]), int(tl[1]), int(tl[3])))
+    assert len(blocks) == len(rows) and len(rows) >= 12
+    seen = set()
+    for h in rows:
+        hit = [b for b in blocks if b[0] == h.query_name and b[1] == h.target_name and (b[4], b[5], b[6], b[7]) == (h.hmm_from, h.hmm_to, h.ali_from, h.ali_to)]
+        assert len(hit) >= 1, (h.query_name, h.target_name)
+        _q, _t, ml, tl, hf, ht, af, at = hit[0]
+        seen.add(id(hit[0]))
+        assert len(ml) == len(tl)
+        assert tl.replace("-", "").upper() == seqs[h.target_name][af - 1:at]                  # the aligned stretch of the ORF, inserts in lower case
+        assert sum(1 for c in ml if c != ".") == ht - hf + 1                                    # every node from hmm_from to hmm_to once
+        assert all((a == ".") == b.islower() for a, b in zip(ml, tl) if b != "-")              # inserts: '.' above a lower-case residue
+        assert tl[0] != "-" and tl[-1] != "-" and ml[0] != "." and ml[-1] != "."              # an alignment begins and ends on a match state
+    release_scan()
