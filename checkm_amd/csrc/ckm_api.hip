@@ -54,7 +54,6 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
     ctx->device = device;
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     if (const char *e = getenv("CKM_WORKERS")) ctx->nclasses = std::max(1, std::min(NWORKERS, atoi(e)));
-    if (const char *e = getenv("CKM_BIN_GROUPS")) ctx->ngroups = std::max(1, std::min(NWORKERS / ctx->nclasses, atoi(e)));
     ctx->nworkers = ctx->nclasses * ctx->ngroups;
     int host_threads = std::max(1, std::min(8, (int)std::thread::hardware_concurrency()));
     if (const char *e = getenv("CKM_HOST_THREADS")) host_threads = std::max(1, std::min(64, atoi(e)));
@@ -64,20 +63,15 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
     if (hipMemGetInfo(&fre, &tot) == hipSuccess) budget = std::min<size_t>((size_t)96 << 30, fre / 4) / ctx->nworkers;
     if (const char *e = getenv("CKM_WS_BUDGET_MB")) budget = std::max<size_t>(16, strtoull(e, nullptr, 10)) << 20;   // tests: force several envelope batches
     const int nside = choose_side_streams(ctx->nworkers);
-    { const int pr = getenv("CKM_CHAIN_PRIO") ? atoi(getenv("CKM_CHAIN_PRIO")) : 0; set_chain_prio_fb(pr); set_chain_prio_filter(pr); set_chain_prio_cascade(pr); }
     for (auto &w : ctx->w) {
       w.device = device; w.id = (int)(&w - ctx->w);
       if (&w - ctx->w >= ctx->nworkers) continue;
       // non-blocking streams: nothing here may synchronise implicitly with the null stream or with another worker's streams
       HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
       w.nside = nside;
-      // CKM_STREAM_PRIO=1: the chain streams of the device-driven cascade (side[4..]) get the highest dispatch priority, the SSV streams keep the default
-      int prio_lo = 0, prio_hi = 0;
-      const bool chain_prio = getenv("CKM_STREAM_PRIO") && atoi(getenv("CKM_STREAM_PRIO")) != 0 && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess && prio_hi != prio_lo;
       for (int k = 0; k < 16; ++k) {
         if (k >= nside) { w.side[k] = w.side[k % nside]; continue; }
-        if (chain_prio && nside >= 8 && k >= 4) HIPCHK(hipStreamCreateWithPriority(&w.side[k], hipStreamNonBlocking, prio_hi));
-        else HIPCHK(hipStreamCreateWithFlags(&w.side[k], hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&w.side[k], hipStreamNonBlocking));
       }
       w.ens_stream = w.side[nside - 1];
       for (auto &e : w.ev) HIPCHK(hipEventCreate(&e));

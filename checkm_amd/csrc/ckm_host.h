@@ -50,18 +50,11 @@ int launch_bwd(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, con
 int launch_oa(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const FbWork *work, const DevModel *models,
               float *ws, const int32_t *range_err, const FwdOut *fout, EnvOut *out);
 
-int launch_parser(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const FbWork *work, const DevModel *models,
-                  const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws,
-                  ScaleEvent *events, uint32_t *nevents, uint32_t cap_events, const CascadeDev &cd);
-int launch_env(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const FbWork *work, const DevModel *models,
-               const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws,
-               ScaleEvent *events, uint32_t *nevents, uint32_t cap_events, EnvOut *out);
 void launch_ensemble(hipStream_t stream, const EnsWork *work, const uint32_t *list /* indices into work, or null */, const uint32_t *count, uint32_t cap, uint32_t grid_regions, int max_Mp,
                      const DevModel *models, const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, const uint32_t *seeds,
                      float *host_res /* pinned buffer the results are exported to, or null */);
 void launch_bias_filter(hipStream_t stream, uint32_t nblocks, const CascadeDev &cd, const DevModel *models, const LenEntry *lentab,
                         const uint8_t *res, const uint64_t *seq_off);
-void set_chain_prio_fb(int v); void set_chain_prio_filter(int v); void set_chain_prio_cascade(int v);   // CKM_CHAIN_PRIO (kernels_*.hip)
 void launch_regions(hipStream_t stream, uint32_t nblocks, const uint32_t *list, const uint32_t *count, uint32_t cap, const FbWork *fwork,
                     const CascadeDev &cd, const DevModel *models, float *ws);
 #define HIPCHK(expr)                                                                                         \
@@ -148,7 +141,7 @@ constexpr int NWORKERS = 8;          // upper bound; CKM_WORKERS (default 3) sel
 struct ckm_ctx {
   int device = 0;
   int nworkers = 1;                // = nclasses * ngroups
-  int nclasses = 1, ngroups = 1;   // lanes: length classes (CKM_WORKERS) x bin groups (CKM_BIN_GROUPS).  One lane is the default: the device-driven
+  int nclasses = 1, ngroups = 1;   // lanes: length classes (CKM_WORKERS).  One lane is the default: the device-driven
                                    // cascade overlaps the stages of its model-length groups by itself; the host-driven one (CKM_CASCADE=host) gains from 3
   DevBuf reduce_scratch;                  // grow-only device buffer of the reduce kernels
   Worker w[NWORKERS];

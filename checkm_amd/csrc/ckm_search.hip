@@ -711,9 +711,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   //  host-driven cascade: 1 SSV + finish, 2 exact MSV, 3 bias filter, 4 Viterbi fast, 5 Viterbi exact, 6 Forward parser, 7 Backward
   //  parser, 8 regions, 9-11 envelope Forward / Backward / OA, 12 region Forward, 13 ensembles)
   const int stop = getenv("CKM_CHAIN_STOP") ? atoi(getenv("CKM_CHAIN_STOP")) : 99;
-  static const bool ens_per_group = !(getenv("CKM_ENS_JOINED") && atoi(getenv("CKM_ENS_JOINED")) != 0);     // CKM_ENS_JOINED=1: one set of ensemble launches after all chains (as before)
-  static const uint32_t GRID_FB = getenv("CKM_GRID_FB") ? (uint32_t)atoi(getenv("CKM_GRID_FB")) : 4096, GRID_VIT = getenv("CKM_GRID_VIT") ? (uint32_t)atoi(getenv("CKM_GRID_VIT")) : 2048,
-                        GRID_MSV = getenv("CKM_GRID_MSV") ? (uint32_t)atoi(getenv("CKM_GRID_MSV")) : 1024;
+  constexpr uint32_t GRID_FB = 4096, GRID_VIT = 2048, GRID_MSV = 1024;      // workgroups of the persistent chain kernels (other sizes were measured in round 2: no gain)
   HIPCHK(hipMemsetAsync(d_gcnt, 0, (NG + 1) * CC_SIZE * sizeof(uint32_t), ms));
   HIPCHK(hipMemsetAsync(d_tops, 0, 4 * sizeof(unsigned long long), ms));
   if (owner->ssv_prev_done) HIPCHK(hipStreamWaitEvent(ms, owner->ssv_prev_done, 0));     // previous lane's SSV launches
@@ -767,28 +765,18 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
         const int Q = kFbQ[c];
         const WorkQueue qf{cd.fq + (size_t)c * sb.cap_f, cnt + CC_FQ + c, sb.cap_f}, qb{cd.bq + (size_t)c * sb.cap_f, cnt + CC_BQ + c, sb.cap_f};
         const WorkQueue qe{cd.eq + (size_t)c * sb.cap_e, cnt + CC_EQ + c, sb.cap_e}, qr{cd.rq + (size_t)c * sb.cap_r, cnt + CC_RQ + c, sb.cap_r};
-        // CKM_FUSED=1: one wavefront takes an item through Forward -> F3 -> Backward -> regions (and an envelope through Forward -> Backward ->
-        // OA) in ONE launch.  Same rows; measured 2-3 % slower on cfg2 (the fused kernels hold 1.5-2x the registers, and the stage
-        // boundaries they remove were already hidden underneath the SSV launches), so the stage-by-stage launches stay the default.
-        // CKM_FUSED_TAIL=n fuses only the last n groups of the launch order (their chains run after the last SSV launch, on an idle device).
-        static const bool fused_all = getenv("CKM_FUSED") && atoi(getenv("CKM_FUSED")) != 0;
-        static const int fused_tail = getenv("CKM_FUSED_TAIL") ? atoi(getenv("CKM_FUSED_TAIL")) : 0;
-        const bool unfused = !(fused_all || gi_now >= (int)launch_order.size() - fused_tail);
-        if (!unfused) {
-          if (stop >= 6) rc |= launch_parser(Q, GRID_FB, sc, qf, cd.fwork, dm, lt, res, off, ws, d_events_f, d_gcnt + CC_EVENTS, cp.events_f, cd);
-          if (stop >= 9) rc |= launch_env(Q, GRID_FB, sc, qe, cd.ework, dm, lt, res, off, ws, d_events_e, d_gcnt + CC_EVENTS_E, cp.events_e, d_envout);
-        } else {
-          if (stop >= 6) rc |= launch_fwd(Q, GRID_FB, sc, qf, cd.fwork, dm, lt, res, off, ws, d_fout_f, d_events_f, d_gcnt + CC_EVENTS, cp.events_f, &cd);
-          if (stop >= 7) rc |= launch_bwd(Q, GRID_FB, sc, qb, cd.fwork, dm, lt, res, off, ws, d_fout_f, nullptr);
-          if (stop >= 8) launch_regions(sc, 1024, qb.list, qb.count, sb.cap_f, cd.fwork, cd, dm, ws);
-          if (stop >= 9) rc |= launch_fwd(Q, GRID_FB, sc, qe, cd.ework, dm, lt, res, off, ws, d_fout_e, d_events_e, d_gcnt + CC_EVENTS_E, cp.events_e, nullptr);
-          if (stop >= 10) rc |= launch_bwd(Q, GRID_FB, sc, qe, cd.ework, dm, lt, res, off, ws, d_fout_e, d_rerr_e);
-          if (stop >= 11) rc |= launch_oa(Q, GRID_FB, sc, qe, cd.ework, dm, ws, d_rerr_e, d_fout_e, d_envout);
-        }
+        // one launch per stage (a fused Forward -> F3 -> Backward -> regions kernel was measured in round 2: same rows, 2-3 % slower -- it
+        // holds 1.5-2x the registers and the launch boundaries it removes are hidden underneath the SSV launches -- and removed in round 3)
+        if (stop >= 6) rc |= launch_fwd(Q, GRID_FB, sc, qf, cd.fwork, dm, lt, res, off, ws, d_fout_f, d_events_f, d_gcnt + CC_EVENTS, cp.events_f, &cd);
+        if (stop >= 7) rc |= launch_bwd(Q, GRID_FB, sc, qb, cd.fwork, dm, lt, res, off, ws, d_fout_f, nullptr);
+        if (stop >= 8) launch_regions(sc, 1024, qb.list, qb.count, sb.cap_f, cd.fwork, cd, dm, ws);
+        if (stop >= 9) rc |= launch_fwd(Q, GRID_FB, sc, qe, cd.ework, dm, lt, res, off, ws, d_fout_e, d_events_e, d_gcnt + CC_EVENTS_E, cp.events_e, nullptr);
+        if (stop >= 10) rc |= launch_bwd(Q, GRID_FB, sc, qe, cd.ework, dm, lt, res, off, ws, d_fout_e, d_rerr_e);
+        if (stop >= 11) rc |= launch_oa(Q, GRID_FB, sc, qe, cd.ework, dm, ws, d_rerr_e, d_fout_e, d_envout);
         if (stop >= 12) rc |= launch_fwd(Q, std::max(64u, GRID_FB / 8), sc, qr, cd.rwork, dm, lt, res, off, ws, d_fout_r, d_events_r, d_gcnt + CC_EVENTS_R, 1 << 16, nullptr);
         // trace ensembles of the multi-domain regions of this group and register class, straight behind their Forward matrices on the
         // group's chain stream (results exported for the host's clustering): only the last groups' ensembles are left after the SSV phase
-        if (stop >= 13 && ens_per_group) launch_ensemble(sc, cd0.ens, qr.list, qr.count, sb.cap_r, 16, Q * NL, dm, lt, res, off, ws, ctx->ensseeds.as<uint32_t>(), d_hens);
+        if (stop >= 13) launch_ensemble(sc, cd0.ens, qr.list, qr.count, sb.cap_r, 16, Q * NL, dm, lt, res, off, ws, ctx->ensseeds.as<uint32_t>(), d_hens);
       }
       if (rc) throw Error(CKM_ERANGE, "no kernel instance for this model length");
     }
@@ -803,8 +791,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
     took_turn = true; owner->ssv_turn++; owner->ssv_cv.notify_all();
   }
   for (int k = NSS; k < NS; ++k) { HIPCHK(hipEventRecord(ctx->cls_ev[k], ctx->side[k])); HIPCHK(hipStreamWaitEvent(ms, ctx->cls_ev[k], 0)); }
-  // ---- trace ensembles of the multi-domain regions of all groups, results exported to pinned memory; counters last ----
-  if (stop >= 13 && !ens_per_group) launch_ensemble(ms, cd0.ens, nullptr, d_gcnt + CC_RWORK, cp.rwork, 128, p->maxMp, dm, lt, res, off, ws, ctx->ensseeds.as<uint32_t>(), d_hens);
+  // ---- counters last ----
   HIPCHK(hipMemcpyAsync(h_cnt, d_gcnt, (NG + 1) * CC_SIZE * sizeof(uint32_t), hipMemcpyDeviceToHost, ms));
   unsigned long long *h_tops = pin_table<unsigned long long>(ctx->h_tops, 4);
   HIPCHK(hipMemcpyAsync(h_tops, d_tops, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ms));
@@ -1113,28 +1100,14 @@ static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, cons
   // phase runs first and whose long chains then run underneath the SSV phase of everything else (worker 1).
   std::vector<std::vector<uint32_t>> chunk(nw);
   std::vector<SeqRange> ranges(nw);
-  // cut lengths, descending: class k holds the sequences with cut[k-1] >= L > cut[k].  Default: the cuts that give the
-  // classes fixed shares of the residues (measured best on cfg2: 16 / 45 / 39 % for three classes, 60 / 40 for two);
-  // CKM_SHARES="0.16,0.61" gives the cumulative shares, CKM_LEN_SPLIT the cut lengths themselves.
-  // Worker k = group * nclasses + class: with CKM_BIN_GROUPS=G the bins are cut into G contiguous groups of about equal
-  // residue counts and every group runs its own set of classes (its post-filter stages then overlap the next group's SSV).
-  const int ncl = nw > 1 ? c->nclasses : 1, ngr = nw > 1 ? c->ngroups : 1;
+  // cut lengths, descending: class k holds the sequences with cut[k-1] >= L > cut[k]: the cuts that give the classes fixed shares of
+  // the residues (measured best on cfg2 in round 1: 16 / 45 / 39 % for three classes, 60 / 40 for two).
+  const int ncl = nw > 1 ? c->nclasses : 1, ngr = 1;
   std::vector<int> cuts;
-  if (const char *e = getenv("CKM_LEN_SPLIT")) {
-    const std::string spec = e; size_t pos = 0;
-    while (pos < spec.size()) { size_t q = spec.find(',', pos); if (q == std::string::npos) q = spec.size(); cuts.push_back(atoi(spec.substr(pos, q - pos).c_str())); pos = q + 1; }
-    std::sort(cuts.begin(), cuts.end(), std::greater<int>());
-  } else if (ncl >= 2) {
+  if (ncl >= 2) {
     std::vector<double> sh;
-    if (const char *e = getenv("CKM_SHARES")) {
-      const std::string spec = e; size_t pos = 0;
-      while (pos < spec.size()) { size_t q = spec.find(',', pos); if (q == std::string::npos) q = spec.size(); sh.push_back(atof(spec.substr(pos, q - pos).c_str())); pos = q + 1; }
-      std::sort(sh.begin(), sh.end());
-    }
-    if ((int)sh.size() != ncl - 1) {
-      if (ncl == 2) sh = {0.60}; else if (ncl == 3) sh = {0.16, 0.61}; else if (ncl == 4) sh = {0.10, 0.35, 0.65};
-      else { sh.clear(); for (int k = 1; k < ncl; ++k) sh.push_back((double)k / ncl); }
-    }
+    if (ncl == 2) sh = {0.60}; else if (ncl == 3) sh = {0.16, 0.61}; else if (ncl == 4) sh = {0.10, 0.35, 0.65};
+    else { for (int k = 1; k < ncl; ++k) sh.push_back((double)k / ncl); }
     std::vector<uint64_t> by_len((size_t)s->maxL + 2, 0);
     uint64_t total = 0;
     for (uint32_t i = 0; i < s->nseq; ++i) { by_len[s->len[i]] += (uint64_t)s->len[i]; total += (uint64_t)s->len[i]; }
@@ -1165,8 +1138,7 @@ static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, cons
     }
   } else {
     // models -> workers, by decreasing work, shares ~ ratio^k
-    double ratio = 1.0;
-    if (const char *e = getenv("CKM_SPLIT_RATIO")) ratio = std::min(1.0, std::max(0.01, atof(e)));
+    const double ratio = 1.0;
     std::vector<double> share(nw, 1.0), load(nw, 0.0);
     for (int k = 1; k < nw; ++k) share[k] = share[k - 1] * ratio;
     for (uint32_t m : active) {

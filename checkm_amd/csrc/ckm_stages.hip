@@ -33,12 +33,11 @@ float finish_forward(float xC, float move, const std::vector<float> &scales) {
 // hardware queues of the device (GPU_MAX_HW_QUEUES = 16): streams that share a queue run their kernels one behind the
 // other, and a short launch of one worker then waits behind a long one of another (measured: the Forward parser of the
 // short class, 1 ms of work, finished 12 ms late behind the envelope kernels of the long class).  So a worker creates
-// main stream + NS side streams with nworkers * (1 + NS) <= 15 and aliases the rest; CKM_SIDE_STREAMS overrides NS.
+// main stream + NS side streams with nworkers * (1 + NS) <= 15 and aliases the rest.
 static int g_side_streams = 8;
 int side_streams() { return g_side_streams; }
 int choose_side_streams(int nworkers) {
   int n = std::max(1, std::min(14, 15 / std::max(1, nworkers) - 1));
-  if (const char *e = getenv("CKM_SIDE_STREAMS")) n = std::max(1, std::min(14, atoi(e)));
   g_side_streams = n;
   return n;
 }
@@ -129,8 +128,8 @@ void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, b
   }
 }
 
-// CKM_ENV_INPLACE=1/0: posterior rows in place over the Forward rows (3 arrays per row) / in a matrix of their own (5 arrays per row)
-bool env_inplace() { static const bool on = [] { const char *e = getenv("CKM_ENV_INPLACE"); return e ? atoi(e) != 0 : kEnvInplaceDefault; }(); return on; }
+// posterior rows in place over the Forward rows (3 arrays per row; kEnvInplaceDefault = false at compile time restores a matrix of their own, 5 per row)
+bool env_inplace() { return kEnvInplaceDefault; }
 
 size_t env_floats(int Mp, int Ld, uint64_t &xs, uint64_t &aux, uint64_t &mf, uint64_t &mb, uint64_t base) {
   auto al = [](uint64_t v) { return (v + 31) & ~(uint64_t)31; };

@@ -15,19 +15,12 @@
 
 namespace ckm {
 
-// CKM_CHAIN_PRIO=1: the latency-bound kernels of a chain raise their wavefronts' issue priority over the SSV wavefronts they share a
-// SIMD with (one dependent instruction chain per wavefront: a chain that waits its turn behind 7 throughput-bound waves runs several
-// times longer than alone; the SSV waves lose exactly the issue slots the chain needs anyway).
-static __constant__ int c_chain_prio;
-void set_chain_prio_cascade(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(c_chain_prio), &v, sizeof(int)); }
-#define CKM_RAISE_PRIO() do { if (c_chain_prio) __builtin_amdgcn_s_setprio(3); } while (0)
 
 
 // list/count: a queue of parser items of `fwork` whose decoding terms are complete (the host-visible form of the stage; the cascade
 // itself runs the scan inside the fused parser kernel)
 __global__ void __launch_bounds__(64) region_kernel(const uint32_t *__restrict__ list, const uint32_t *__restrict__ count, uint32_t cap,
                                                    const FbWork *__restrict__ fwork, CascadeDev cd, const DevModel *__restrict__ models, float *__restrict__ ws) {
-  CKM_RAISE_PRIO();
   const uint32_t n = min(*count, cap);
   const int lane = threadIdx.x;
   for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {

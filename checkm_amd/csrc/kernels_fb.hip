@@ -17,12 +17,6 @@
 
 namespace ckm {
 
-// CKM_CHAIN_PRIO=1: the latency-bound kernels of a chain raise their wavefronts' issue priority over the SSV wavefronts they share a
-// SIMD with (one dependent instruction chain per wavefront: a chain that waits its turn behind 7 throughput-bound waves runs several
-// times longer than alone; the SSV waves lose exactly the issue slots the chain needs anyway).
-static __constant__ int c_chain_prio;
-void set_chain_prio_fb(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(c_chain_prio), &v, sizeof(int)); }
-#define CKM_RAISE_PRIO() do { if (c_chain_prio) __builtin_amdgcn_s_setprio(3); } while (0)
 
 
 constexpr float NEGINF_F = -__builtin_inff();
@@ -188,7 +182,6 @@ __global__ void __launch_bounds__(64) fwd_kernel(WorkQueue queue, FbWork *__rest
                                                 float *__restrict__ ws, FwdOut *__restrict__ out,
                                                 ScaleEvent *__restrict__ events, uint32_t *__restrict__ nevents, uint32_t cap_events,
                                                 CascadeDev cd, int decide) {
-  CKM_RAISE_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x;
   uint32_t cur_model = 0xffffffffu;
@@ -416,7 +409,6 @@ __global__ void __launch_bounds__(64) bwd_kernel(WorkQueue queue, const FbWork *
                                                 const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
                                                 const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
                                                 float *__restrict__ ws, const FwdOut *__restrict__ fout, int32_t *__restrict__ range_err) {
-  CKM_RAISE_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x;
   uint32_t cur_model = 0xffffffffu;
@@ -611,7 +603,6 @@ template <int Q>
 __global__ void __launch_bounds__(64) oa_kernel(WorkQueue queue, const FbWork *__restrict__ work,
                                                const DevModel *__restrict__ models, float *__restrict__ ws,
                                                const int32_t *__restrict__ range_err, const FwdOut *__restrict__ fout, EnvOut *__restrict__ out) {
-  CKM_RAISE_PRIO();
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x;
   uint32_t cur_model = 0xffffffffu;
@@ -627,97 +618,6 @@ __global__ void __launch_bounds__(64) oa_kernel(WorkQueue queue, const FbWork *_
  }
 }
 
-// ---- fused kernels of the device-driven cascade ---------------------------------------------------------------------------------
-// One wavefront takes a work item through SEVERAL stages back to back, so that no stage of a chain waits for the slowest item of the
-// stage before it (every launch boundary is such a wait) and a chain is three launches per register class instead of seven.
-// What one lane stores and another lane of the same wavefront reads afterwards (special rows, decoding terms) is read with L2-scope
-// loads after a fence (the XL variants of bwd_item / oa_item / region_scan).
-
-// whole-sequence parser item: Forward -> F3 (conservative, see fwd_kernel) -> Backward -> posterior heuristics -> envelope / region items
-template <int Q>
-__global__ void __launch_bounds__(64) parser_kernel(WorkQueue queue, const FbWork *__restrict__ work,
-                                                   const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
-                                                   const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
-                                                   float *__restrict__ ws, ScaleEvent *__restrict__ events, uint32_t *__restrict__ nevents, uint32_t cap_events,
-                                                   CascadeDev cd) {
-  CKM_RAISE_PRIO();
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ uint32_t bc[4];
-  const int lane = threadIdx.x;
-  uint32_t cur_model = 0xffffffffu;
-  const uint32_t nqueue = queue_len(queue);
-  for (uint32_t qk = blockIdx.x; qk < nqueue; qk += gridDim.x) {
-    const uint32_t item = queue.list[qk];
-    FbWork w = work[item];
-    const DevModel &md = models[w.model];
-    if (w.model != cur_model) { load_tr<Q>(lds, md.ftr); cur_model = w.model; }
-    float xC, lsum, move; int nscale;
-    fwd_item<Q>(w, md, lds, lane, lentab, res, seq_off, ws, events, nevents, cap_events, xC, nscale, lsum, move);
-    __syncthreads();
-    if (lane == 0) {
-      uint32_t ok = 0, pid = 0xffffffffu; unsigned long long off = 0;
-      const PairRec pr = cd.cand[w.cand];
-      const float fwdsc = lsum + approx_ln(xC * move);
-      const float sc = (fwdsc - pr.filtersc) * LOG2E_F;
-      if (sc >= md.thr_fwd_f3 - cd.margin_fwd && ws_alloc(cd, (unsigned long long)(w.Ld + 1) * 3ull, off)) {
-        pid = atomicAdd(&cd.gcnt[CC_PASS], 1u);
-        if (pid < cd.cap_pass) {
-          PassRec r;
-          r.cand = w.cand; r.fwork = item; r.model = w.model; r.seq = w.seq; r.usc = pr.usc;
-          r.bias_d = cd.bias_raw[2 * (size_t)w.cand]; r.bias_e = cd.bias_raw[2 * (size_t)w.cand + 1];
-          r.vit_fast = cd.vit_fast[w.cand]; r.vit_exact = cd.vit_exact[w.cand]; r.vit_flag = cd.vit_flag[w.cand]; r.route = cd.route[w.cand];
-          r.fwd_xC = xC; r.nscale = nscale;
-          cd.h_pass[pid] = r;
-          ok = 1;
-        } else atomicOr(&cd.gcnt[CC_STATUS], (uint32_t)CS_PASS);
-      }
-      bc[0] = ok; bc[1] = pid; bc[2] = (uint32_t)off; bc[3] = (uint32_t)(off >> 32);
-    }
-    __syncthreads();
-    const uint32_t ok = bc[0];
-    w.pass = bc[1]; w.aux_off = (unsigned long long)bc[2] | ((unsigned long long)bc[3] << 32);
-    if (!ok) continue;
-    __threadfence();
-    bool bad = false;
-    bwd_item<Q, true>(w, md, lds, lane, lentab, res, seq_off, ws, xC, bad);
-    __threadfence();
-    __builtin_amdgcn_wave_barrier();
-    region_scan<true>(cd, md, w, ws, lane);
-  }
-}
-
-// envelope: unihit Forward -> Backward (posterior rows) -> null2 by expectation + optimal accuracy + traceback
-template <int Q>
-__global__ void __launch_bounds__(64) env_kernel(WorkQueue queue, const FbWork *__restrict__ work,
-                                                const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
-                                                const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
-                                                float *__restrict__ ws, ScaleEvent *__restrict__ events, uint32_t *__restrict__ nevents, uint32_t cap_events,
-                                                EnvOut *__restrict__ out) {
-  CKM_RAISE_PRIO();
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int lane = threadIdx.x;
-  const uint32_t nqueue = queue_len(queue);
-  for (uint32_t qk = blockIdx.x; qk < nqueue; qk += gridDim.x) {
-    const FbWork w = work[queue.list[qk]];
-    const DevModel &md = models[w.model];
-    load_tr<Q>(lds, md.ftr);                      // (the previous item left the gate image of the optimal-accuracy stage)
-    float xC, lsum, move; int nscale;
-    fwd_item<Q>(w, md, lds, lane, lentab, res, seq_off, ws, events, nevents, cap_events, xC, nscale, lsum, move);
-    __threadfence();
-    bool bad = false;
-    bwd_item<Q, true>(w, md, lds, lane, lentab, res, seq_off, ws, xC, bad);
-    const bool anybad = __ballot(bad) != 0ull;
-    if (lane == 0) { out[w.slot].xC = xC; out[w.slot].nscale = nscale; if (anybad) out[w.slot].range_err = 1; }
-    if (anybad) continue;
-    __threadfence();
-    load_gates<Q>(lds, md.ftr);
-    oa_item<Q, true>(w, md, lds, lane, ws, &out[w.slot]);
-  }
-}
-
-// ---- launchers ----------------------------------------------------------------------------------
-// `nblocks` single-wavefront workgroups are started; each keeps taking items until the queue is empty, so any nblocks >= 1 is
-// correct and nblocks ~ (items, capped at what the device can hold at once) is what the callers pass.
 #define CKM_FB_QS(X) X(1) X(2) X(3) X(4) X(6) X(8) X(12) X(16) X(24) X(32)
 
 int launch_fwd(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, FbWork *work, const DevModel *models,
@@ -757,29 +657,5 @@ int launch_oa(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, cons
   return 0;
 }
 
-int launch_parser(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const FbWork *work, const DevModel *models,
-                  const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws,
-                  ScaleEvent *events, uint32_t *nevents, uint32_t cap_events, const CascadeDev &cd) {
-  if (!nblocks) return 0;
-  switch (Q) {
-#define X(QV) case QV: hipLaunchKernelGGL(parser_kernel<QV>, dim3(nblocks), dim3(64), (size_t)8 * QV * 64 * 4, stream, queue, work, models, lentab, res, seq_off, ws, events, nevents, cap_events, cd); break;
-    CKM_FB_QS(X)
-#undef X
-    default: return -1;
-  }
-  return 0;
-}
-int launch_env(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const FbWork *work, const DevModel *models,
-               const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws,
-               ScaleEvent *events, uint32_t *nevents, uint32_t cap_events, EnvOut *out) {
-  if (!nblocks) return 0;
-  switch (Q) {
-#define X(QV) case QV: hipLaunchKernelGGL(env_kernel<QV>, dim3(nblocks), dim3(64), (size_t)8 * QV * 64 * 4, stream, queue, work, models, lentab, res, seq_off, ws, events, nevents, cap_events, out); break;
-    CKM_FB_QS(X)
-#undef X
-    default: return -1;
-  }
-  return 0;
-}
 
 }  // namespace ckm

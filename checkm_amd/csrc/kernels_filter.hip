@@ -16,12 +16,6 @@
 
 namespace ckm {
 
-// CKM_CHAIN_PRIO=1: the latency-bound kernels of a chain raise their wavefronts' issue priority over the SSV wavefronts they share a
-// SIMD with (one dependent instruction chain per wavefront: a chain that waits its turn behind 7 throughput-bound waves runs several
-// times longer than alone; the SSV waves lose exactly the issue slots the chain needs anyway).
-static __constant__ int c_chain_prio;
-void set_chain_prio_filter(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(c_chain_prio), &v, sizeof(int)); }
-#define CKM_RAISE_PRIO() do { if (c_chain_prio) __builtin_amdgcn_s_setprio(3); } while (0)
 
 
 constexpr int KP_SYMS = 29;    // rows of the byte cost table (one per alphabet symbol)
@@ -43,7 +37,6 @@ __device__ __forceinline__ float to_bits(float sc, float nullsc) {
 }
 
 __global__ void msv_finish_kernel(FinishArgs a, uint32_t nblocks_work) {
-  CKM_RAISE_PRIO();
   const uint32_t wb = blockIdx.x;
   if (wb >= nblocks_work) return;
   const SsvBlockWork w = a.work[wb];
@@ -99,7 +92,6 @@ __global__ void __launch_bounds__(64) msv_full_kernel(WorkQueue queue, const Pai
                                                      const uint64_t *__restrict__ seq_off, const int32_t *__restrict__ seq_len,
                                                      int32_t *__restrict__ out_xJ /* -1 overflow */, float *__restrict__ out_usc, int maxMp,
                                                      CascadeDev cd, int decide) {
-  CKM_RAISE_PRIO();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
  const uint32_t nqueue = queue_len(queue);
@@ -203,7 +195,6 @@ __global__ void bias_kernel(const PairRec *__restrict__ pairs, uint32_t npairs, 
 //   otherwise (within the margin of F2)           the exact Viterbi kernel runs and the pair goes on whatever it says: the host decides
 __global__ void __launch_bounds__(128) bias_filter_kernel(CascadeDev cd, const DevModel *__restrict__ models, const LenEntry *__restrict__ lentab,
                                                          const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off) {
-  CKM_RAISE_PRIO();
   // the emission odds of the pair's model sit in the thread's own LDS row (stride 31 words: lanes asking for the same symbol hit 32
   // different banks) and the four transition odds in registers: nothing on the residue-to-residue chain touches global memory
   __shared__ float beo_s[128 * 31];
@@ -296,7 +287,6 @@ __global__ void __launch_bounds__(256) vit_kernel(WorkQueue queue, const PairRec
                                                   const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
                                                   const int32_t *__restrict__ seq_len, int32_t *__restrict__ out_xC, float *__restrict__ out_sc,
                                                   uint32_t *__restrict__ out_flag, CascadeDev cd, int decide) {
-  CKM_RAISE_PRIO();
   const int lane = threadIdx.x & 63;
  const uint32_t nqueue = queue_len(queue);
  for (uint32_t qk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); qk < nqueue; qk += gridDim.x * (blockDim.x >> 6)) {

@@ -1,6 +1,6 @@
 """The device-driven cascade (stages chained on the device, conservative decisions, ONE host synchronisation per lane, exact decisions
 again on the host) against the host-driven one (CKM_CASCADE=host: a device phase, a copy and a host decision per stage): same rows,
-bit for bit, on one lane and on three, with the long/short split of a lane, with the fused parser / envelope kernels (CKM_FUSED=1),
+bit for bit, on one lane and on three, with the long/short split of a lane,
 with more pairs than one SSV pass holds (host-driven, chunk by chunk) -- and when the device-side workspace is too small the regions
 that find no room are rescored by the host-driven rounds, and when the device-side tables are too small the lane is handed to the
 host-driven cascade (counted in cascade_fallback_lanes); the rows never change."""
@@ -51,10 +51,8 @@ def _run(**extra):
 def test_device_cascade_equals_host_cascade():
     host = _run(CKM_CASCADE="host", CKM_WORKERS="1")
     assert len(host["rows"]) > 100 and host["pairs"][6] >= 2           # multi-domain regions are present
-    for extra in (dict(CKM_WORKERS="1"), dict(CKM_WORKERS="1", CKM_SPLIT_MIN_PAIRS="1"), dict(CKM_WORKERS="1", CKM_FUSED="1", CKM_SPLIT_MIN_PAIRS="1"),
+    for extra in (dict(CKM_WORKERS="1"), dict(CKM_WORKERS="1", CKM_SPLIT_MIN_PAIRS="1"),
                   dict(CKM_WORKERS="1", CKM_SPLIT_MIN_PAIRS="1", CKM_LONG_SHARE="0.2,0.4"),          # three parts by sequence length
-                  dict(CKM_WORKERS="1", CKM_SPLIT_MIN_PAIRS="1", CKM_ENS_JOINED="1", CKM_FUSED_TAIL="3", CKM_CHAIN_PRIO="1"),   # one ensemble set after the join; knobs
-
                   dict(CKM_WORKERS="3", CKM_WORKER_MIN_PAIRS="1"), dict(CKM_WORKERS="2", CKM_WORKER_MIN_PAIRS="1", CKM_PAIR_BUDGET="9000")):
         dev = _run(**extra)
         if "CKM_PAIR_BUDGET" in extra:
