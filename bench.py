@@ -603,6 +603,30 @@ def cfg3_counters(alg_bytes):
             "traffic_over_algorithmic": pm["hbm_bytes_corrected"] / float(pm["algorithmic_bytes"])}
 
 
+def gene_front_end():
+    """SURVEY 8f N1, first slice: the codon-flag kernel of the gene-calling front end (checkm_amd/csrc/kernels_orf.hip) is a pure streaming
+    kernel -- 1 byte read + 1 byte written per base -- so it is the one kernel of this repository priced against the HBM roofline it is
+    bound by; and the node extraction of one synthetic 4 Mb genome for both translation tables (what replaces prodigal's two node scans)."""
+    import numpy as np
+    from checkm_amd import _lib, runtime
+    ctx = runtime.get_ctx()
+    nbytes = 1 << 30                                  # 1 Gbase: four times the 256 MB last-level cache
+    ms = _lib.debug_orf_flags(ctx, nbytes, 10)
+    achieved = 2.0 * nbytes / (ms / 1e3) / 1e9
+    rng = np.random.default_rng(5)
+    genome = [np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(n))].tobytes() for n in rng.integers(20000, 200000, size=40)]
+    t0 = time.perf_counter()
+    n11, st11 = _lib.orf_nodes(ctx, genome, 11)
+    n4, st4 = _lib.orf_nodes(ctx, genome, 4)
+    wall = time.perf_counter() - t0
+    return {"kernel": "orf_flags_kernel", "bases_per_launch": nbytes, "algorithmic_bytes_per_launch": 2 * nbytes, "ms_per_launch": ms,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "note": "1 B read + 1 B written per base; 10 launches over 1 Gbase of device-generated nucleotides, HIP events on the launch stream"},
+            "one_genome": {"bases": st11["bases"], "contigs": len(genome), "nodes_table11": int(len(n11["ndx"])), "nodes_table4": int(len(n4["ndx"])),
+                           "flags_ms": st11["ms_flags"], "chains_ms": st11["ms_chain"], "wall_s_both_tables_incl_copies_and_sort": wall},
+            "note": "front end only (start / stop nodes of six frames); training, scoring and the node DP of the gene finder are not built (DESIGN.md section 10)"}
+
+
 def bench_cfg3(args, env):
     """configs[2] (N = 1) / configs[3] (N > 1, strong scaling): the lineage_wf marker path over --bins-total bins from files; the
     product shards the bins over the ranks."""
@@ -714,6 +738,7 @@ def bench_cfg3(args, env):
                                                       "no contention for the shared output directory -- a projection, not a measurement of configs[3]" % nbins}
             finally:
                 del os.environ["CKM_EMULATE_RANK"]
+        out["gene_front_end"] = gene_front_end()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_cfg3(w, binIds, files, lin, args.cpu_baseline_seconds, args.cpu_baseline_threads)
         else:

@@ -90,6 +90,12 @@ class QAColumns(C.Structure):
                 ("kept_env_from", C.POINTER(C.c_int32)), ("kept_env_to", C.POINTER(C.c_int32))]
 
 
+class OrfColumns(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("contig", C.POINTER(C.c_uint32)), ("ndx", C.POINTER(C.c_int32)), ("stop_val", C.POINTER(C.c_int32)),
+                ("type", C.POINTER(C.c_uint8)), ("strand_rev", C.POINTER(C.c_uint8)), ("edge", C.POINTER(C.c_uint8)),
+                ("ms_flags", C.c_double), ("ms_chain", C.c_double), ("bases", C.c_uint64), ("padded_bytes", C.c_uint64)]
+
+
 class TableColumns(C.Structure):
     _fields_ = [("cols", HitColumns), ("target_accession", C.POINTER(C.c_char_p)), ("query_name", C.POINTER(C.c_char_p)),
                 ("query_accession", C.POINTER(C.c_char_p)), ("description", C.POINTER(C.c_char_p)),
@@ -103,6 +109,7 @@ EXPORTS = ["ckm_last_error", "ckm_abi_version", "ckm_device_count", "ckm_ctx_cre
            "ckm_seqs_pack", "ckm_seqs_from_fasta", "ckm_seqs_count", "ckm_seqs_bin_offsets", "ckm_seqs_name", "ckm_seqs_residues", "ckm_seqs_free", "ckm_search", "ckm_hits_columns", "ckm_hits_free",
            "ckm_hits_write_domtblout", "ckm_hits_write_alignments", "ckm_last_search_stats", "ckm_reduce", "ckm_qa_columns_get", "ckm_qa_free", "ckm_count_sets",
            "ckm_align", "ckm_tables_read", "ckm_tables_assign_models", "ckm_tables_get", "ckm_tables_free",
+           "ckm_orf_scan", "ckm_orf_columns_get", "ckm_orf_free", "ckm_debug_orf_flags",
            "ckm_debug_stages", "ckm_debug_envelopes", "ckm_debug_region"]
 
 _lib = None
@@ -157,6 +164,11 @@ def load():
     L.ckm_tables_get.argtypes = [C.c_void_p, C.POINTER(TableColumns)]
     L.ckm_tables_free.argtypes = [C.c_void_p]
     L.ckm_tables_free.restype = None
+    L.ckm_orf_scan.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.ckm_orf_columns_get.argtypes = [C.c_void_p, C.POINTER(OrfColumns)]
+    L.ckm_orf_free.argtypes = [C.c_void_p]
+    L.ckm_orf_free.restype = None
+    L.ckm_debug_orf_flags.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
     L.ckm_debug_stages.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.ckm_debug_envelopes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_uint32, C.c_void_p]
@@ -442,3 +454,31 @@ def align(ctx, profiles, seqs, model, seq):
     out = np.zeros(max(1, int(off[-1])), dtype=np.int32)
     _chk(load().ckm_align(ctx.h, profiles.h, seqs.h, model.ctypes.data, seq.ctypes.data, len(model), off.ctypes.data, out.ctypes.data))
     return [out[int(off[j]):int(off[j + 1])].copy() for j in range(len(model))]
+
+
+def orf_nodes(ctx, contigs, trans_table=11, closed=False):
+    """Start / stop nodes of all six frames of a bin's contigs (ckm_orf_scan): contigs = list of nucleotide strings (or bytes).
+    Returns (columns dict of numpy arrays: contig, ndx, stop_val, type, strand_rev, edge; stats dict)."""
+    parts = [c.encode() if isinstance(c, str) else bytes(c) for c in contigs]
+    off = np.zeros(len(parts) + 1, dtype=np.uint64)
+    np.cumsum([len(p) for p in parts], out=off[1:])
+    text = b"".join(parts)
+    h = C.c_void_p()
+    _chk(load().ckm_orf_scan(ctx.h, text, off.ctypes.data, len(parts), int(trans_table), 1 if closed else 0, C.byref(h)))
+    try:
+        cols = OrfColumns()
+        _chk(load().ckm_orf_columns_get(h, C.byref(cols)))
+        n = int(cols.n)
+        arr = np.ctypeslib.as_array
+        out = {f: (arr(getattr(cols, f), shape=(n,)).copy() if n else np.zeros(0, dtype=np.int64)) for f in ("contig", "ndx", "stop_val", "type", "strand_rev", "edge")}
+        stats = dict(ms_flags=cols.ms_flags, ms_chain=cols.ms_chain, bases=int(cols.bases), padded_bytes=int(cols.padded_bytes))
+    finally:
+        load().ckm_orf_free(h)
+    return out, stats
+
+
+def debug_orf_flags(ctx, nbytes, reps=10):
+    """Average duration (ms) of one launch of the streaming codon-flag kernel over nbytes of device-generated nucleotides."""
+    ms = C.c_double()
+    _chk(load().ckm_debug_orf_flags(ctx.h, int(nbytes), int(reps), C.byref(ms)))
+    return ms.value

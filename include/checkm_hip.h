@@ -264,6 +264,30 @@ int  ckm_tables_assign_models(ckm_tables *t, const char *const *keys, uint32_t n
 int  ckm_tables_get(const ckm_tables *t, ckm_table_columns *out);
 void ckm_tables_free(ckm_tables *t);
 
+/* ---- gene calling, first slice ------------------------------------------------------
+ * The deterministic front end of the gene finder CheckM runs before the scan -- `prodigal -p single -m -f gff -g <11|4>`, twice per bin,
+ * checkm/prodigal.py:74,86-93,131-133: start / stop codon flags of all six frames and the start / stop NODES the gene finder's dynamic
+ * program works on (Prodigal 2.6.3 node.c: add_nodes), for all contigs of a bin in two kernel launches.  `text` holds the contigs'
+ * nucleotides (ASCII, any case; anything but ACGTU is "no base"), contig c = text[contig_off[c] .. contig_off[c+1]).  What is NOT here:
+ * training, scoring and the dynamic program that turn nodes into genes, and prodigal's -m masking. */
+typedef struct ckm_orf ckm_orf;
+typedef struct {
+  uint64_t        n;            /* nodes, sorted by (contig, position, strand [reverse first], type, stop_val, edge) */
+  const uint32_t *contig;
+  const int32_t  *ndx;          /* position of the codon's first base on the FORWARD strand's coordinates (node.c: ndx) */
+  const int32_t  *stop_val;     /* start node: the stop that closes its ORF; stop node: the previous stop of its frame (node.c: stop_val) */
+  const uint8_t  *type;         /* 0 ATG, 1 GTG, 2 TTG, 3 stop */
+  const uint8_t  *strand_rev;   /* 0 forward, 1 reverse */
+  const uint8_t  *edge;         /* the ORF runs off an end of the contig */
+  double          ms_flags, ms_chain;   /* kernel times of this call (HIP events): the streaming flag kernel, the per-frame chains */
+  uint64_t        bases, padded_bytes;  /* nucleotides given; bytes the flag kernel read (= wrote) */
+} ckm_orf_columns;
+int  ckm_orf_scan(ckm_ctx *ctx, const char *text, const uint64_t *contig_off, uint32_t ncontigs, int trans_table, int closed_ends, ckm_orf **out);
+int  ckm_orf_columns_get(const ckm_orf *o, ckm_orf_columns *out);
+void ckm_orf_free(ckm_orf *o);
+/* measurement hook (bench.py: gene_front_end): the streaming flag kernel over nbytes of device-generated nucleotides, average ms of reps launches */
+int  ckm_debug_orf_flags(ckm_ctx *ctx, uint64_t nbytes, uint32_t reps, double *ms);
+
 /* ---- diagnostics used by the parity tests: every stage of one (model, sequence) pair, no filtering */
 typedef struct {
   int32_t msv_xJ;  float msv_sc, null_sc, bias_sc;
