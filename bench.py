@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=["cfg2", "cfg3"], default="cfg3")
+    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg5"], default="cfg3")
     ap.add_argument("--budget-seconds", type=float, default=float(os.environ.get("CKM_BENCH_BUDGET_S", "75")),
                     help="cfg3: wall-clock budget of the timed region; the steps actually run are min(--steps, budget / estimated step)")
     ap.add_argument("--emulate-rank", default=None, help="cfg3: R/W -- run as rank R of W on this one GPU (no collectives)")
@@ -318,6 +318,8 @@ def main():
     env = Env(args)
     if args.config == "cfg3":
         out = bench_cfg3(args, env)
+    elif args.config == "cfg5":
+        out = bench_cfg5(args, env)
     else:
         out = bench_cfg2(args, env)
     if env.rank == 0 and out is not None:
@@ -601,6 +603,69 @@ def cfg3_counters(alg_bytes):
     return {"source": os.path.relpath(found[-1], ROOT), "sample": pm.get("config"), "scale": k,
             "hbm_bytes": pm["hbm_bytes_corrected"] * k, "valu_insts": pm["valu_insts"] * k,
             "traffic_over_algorithmic": pm["hbm_bytes_corrected"] / float(pm["algorithmic_bytes"])}
+
+
+def bench_cfg5(args, env):
+    """A one-GPU SLICE of configs[4] (10,000 synthetic 5 Mb MAGs x full Pfam/TIGRFAM marker set, 8 GPUs): a 10,000-profile database with
+    a Pfam-like length distribution -- three of its models beyond the kernels' 2048 nodes -- against --bins (default 50) bins of 5000 ORFs,
+    EVERY searchable model against every bin, through MarkerGeneFinder.find from files.  Not a default line: `bench.py --config cfg5`."""
+    import numpy as np
+    from checkm_amd import markerGeneFinder as mgf, synth, synth_lineage as sl
+    from checkm_amd.defaultValues import DefaultValues
+    rank, world, workdir = env.rank, env.world, env.workdir
+    if world != 1:
+        raise SystemExit("cfg5 is a one-GPU slice")
+    nbins = args.bins if args.bins != 100 else 50
+    nmodels = 10000
+    t0 = time.perf_counter()
+    data = os.path.join(workdir, "cfg5_data")
+    w = sl.World(data, n_models=nmodels, seed=5000)
+    DefaultValues.set_data_root(data)
+    hmm = os.path.join(workdir, "pfam_like_%d.hmm" % nmodels)
+    if not os.path.exists(hmm):
+        shutil.copyfile(w.checkm_hmm, hmm)
+        rng = np.random.default_rng(5)
+        longs = [synth.random_profile(rng, M, "long%d" % M, "PF%05d.1" % (90000 + M)) for M in (2049, 3000, 4096)]
+        for p in longs:
+            p.stats = (-8.5 - 0.002 * p.M, 0.71, -9.5 - 0.002 * p.M, 0.71, -3.8, 0.71)
+        synth.write_hmm(hmm, longs, mode="a")
+    files = []
+    rng = np.random.default_rng(77)
+    for b in range(nbins):
+        f = os.path.join(workdir, "mag_%03d.faa" % b)
+        if not os.path.exists(f):
+            planted = sorted(rng.choice(nmodels, size=600, replace=False).tolist())
+            synth.write_fasta(f, sl.make_lineage_bin(w.profs, planted, 900000 + b, n_orfs=5000))
+        files.append(f)
+    t_setup = time.perf_counter() - t0
+    finder = mgf.MarkerGeneFinder(8)
+    warm = files[:min(nbins, 6)]
+    t0 = time.perf_counter()
+    finder.find(warm, os.path.join(workdir, "cfg5_warm"), DefaultValues.HMMER_TABLE_OUT, DefaultValues.HMMER_OUT, hmm, False, False, True)
+    env.sync()
+    first_s = time.perf_counter() - t0
+    mgf.release_scan(os.path.join(workdir, "cfg5_warm"))
+    t0 = time.perf_counter()
+    out_dir = os.path.join(workdir, "cfg5_out")
+    models = finder.find(files, out_dir, DefaultValues.HMMER_TABLE_OUT, DefaultValues.HMMER_OUT, hmm, False, False, True)
+    env.sync()
+    dt = time.perf_counter() - t0
+    ent = mgf.SCAN_CACHE[(os.path.abspath(out_dir), DefaultValues.HMMER_TABLE_OUT)]
+    tot = ent["totals"]
+    heads = ent["profiles"].headers
+    roof, _v = ssv_roofline(tot, tot.get("ms_ssv", 0.0), -1, -1, "; cfg5 slice: summed over the %d ckm_search calls" % tot.get("searches", 0))
+    line = {"metric": "bins/hour + residues*HMMs/s, one-GPU slice of configs[4] (every searchable model of a 10,000-profile database against every bin)",
+            "value": nbins / dt * 3600.0, "unit": "bins/hour", "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f16/i16 (SSV/MSV bytes held exactly, Viterbi words) + f32 (Forward/Backward)", "data": "synthetic",
+            "config": {"workload": "configs[4] slice: %d bins of 5000 ORFs x %d profiles (lognormal lengths, median ~190; %d of them beyond 2048 nodes and left out with a warning)"
+                                   % (nbins, len(heads), sum(1 for h in heads if not h["searchable"])), "bins_total": nbins, "models_per_bin": len(next(iter(models.values())))},
+            "residue_hmm_per_s": tot.get("residue_hmm", 0) / dt, "roofline": roof, "stage_pairs": stage_pairs(tot), "searches": int(tot.get("searches", 0)),
+            "cascade_fallback_lanes": int(tot.get("cascade_fallback_lanes", 0)),
+            "workspace": {"allocated_bytes_max": int(tot.get("ws_cap_bytes", 0)), "high_water_bytes_max": int(tot.get("ws_used_bytes", 0))},
+            "find_parts_s": {k: tot.get(k, 0.0) for k in ("ingest_s", "search_s", "write_s")}, "first_pass_s": first_s, "first_pass_bins": len(warm),
+            "setup_s": {"world_and_files": t_setup}, "cpu_baseline": None}
+    mgf.release_scan()
+    return line
 
 
 def gene_front_end():

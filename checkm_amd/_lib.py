@@ -23,7 +23,7 @@ class CkmError(RuntimeError):
 class ModelHeader(C.Structure):
     _fields_ = [("name", C.c_char_p), ("acc", C.c_char_p), ("desc", C.c_char_p), ("leng", C.c_int32),
                 ("has_ga", C.c_int32), ("has_tc", C.c_int32), ("has_nc", C.c_int32),
-                ("ga", C.c_double * 2), ("tc", C.c_double * 2), ("nc", C.c_double * 2), ("evparam", C.c_float * 6)]
+                ("ga", C.c_double * 2), ("tc", C.c_double * 2), ("nc", C.c_double * 2), ("evparam", C.c_float * 6), ("searchable", C.c_int32)]
 
 
 class HitColumns(C.Structure):
@@ -227,7 +227,7 @@ class Profiles(object):
             self.headers.append({"name": hd.name.decode(), "acc": hd.acc.decode() if hd.acc else None,
                                  "desc": hd.desc.decode() if hd.desc else None, "leng": hd.leng,
                                  "ga": tuple(hd.ga) if hd.has_ga else None, "tc": tuple(hd.tc) if hd.has_tc else None,
-                                 "nc": tuple(hd.nc) if hd.has_nc else None, "evparam": tuple(hd.evparam)})
+                                 "nc": tuple(hd.nc) if hd.has_nc else None, "evparam": tuple(hd.evparam), "searchable": bool(hd.searchable)})
 
     def close(self):
         if self.h:

@@ -146,12 +146,19 @@ extern "C" int ckm_profiles_load(ckm_ctx *ctx, const char *hmm_path, ckm_profile
     p->hmm = read_hmm_file(hmm_path);
     const size_t n = p->hmm.size();
     p->prof.resize(n);
+    p->too_long.assign(n, 0);
     {   // configuration is per model (logs, exps, the three striped layouts): host threads
       std::vector<std::unique_ptr<Error>> errs(n);
       auto one = [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) {
           try { p->prof[i] = configure_profile(p->hmm[i]); }
-          catch (const Error &e) { errs[i].reset(new Error(e)); }
+          catch (const Error &e) {
+            // A model beyond the instantiated kernel classes (M > 2048) does not take the database down: it keeps its place and its
+            // header, and only a search that actually selects it is refused, by name (ckm_search).  CheckM's marker sets hold no such
+            // model; a full Pfam / TIGRFAM file holds a handful.
+            if (e.code == CKM_ERANGE) { p->too_long[i] = 1; p->prof[i] = HostProfile(); p->prof[i].M = p->hmm[i].M; p->prof[i].ssvQ = p->prof[i].fbQ = p->prof[i].vitQH = 1; }
+            else errs[i].reset(new Error(e));
+          }
         }
       };
       if (ctx->w[0].pool && n > 8) ctx->w[0].pool->run(n, 4, one); else one(0, n);
@@ -176,7 +183,7 @@ extern "C" int ckm_profiles_load(ckm_ctx *ctx, const char *hmm_path, ckm_profile
       memset(&d, 0, sizeof(d));
       d.M = hp.M; d.ssvQ = hp.ssvQ; d.fbQ = hp.fbQ; d.vitQH = hp.vitQH;
       d.fb_cls = fb_class_id(hp.fbQ); d.vit_cls = vit_class_id(hp.vitQH);
-      if (d.fb_cls < 0 || d.vit_cls < 0) throw Error(CKM_ERANGE, "model " + h.name + " is longer than the instantiated kernel classes (DESIGN.md limits)");
+      if (!p->too_long[i] && (d.fb_cls < 0 || d.vit_cls < 0)) throw Error(CKM_ERANGE, "model " + h.name + " is longer than the instantiated kernel classes (DESIGN.md limits)");
       d.base_b = hp.base_b; d.bias_b = hp.bias_b; d.tbm_b = hp.tbm_b; d.tec_b = hp.tec_b; d.scale_b = hp.scale_b;
       d.scale_w = hp.scale_w; d.base_w = hp.base_w; d.wE_loop = hp.wE_loop; d.wE_move = hp.wE_move;
       d.fE_loop = hp.fE_loop; d.fE_move = hp.fE_move;
@@ -188,7 +195,7 @@ extern "C" int ckm_profiles_load(ckm_ctx *ctx, const char *hmm_path, ckm_profile
       d.vit_t = reinterpret_cast<const uint32_t *>(base + off[i].vit_t); d.rf = reinterpret_cast<const float *>(base + off[i].rf);
       d.ftr = reinterpret_cast<const float *>(base + off[i].ftr);
       p->dm.push_back(d);
-      p->maxMp = std::max(p->maxMp, hp.fbQ * NL);
+      if (!p->too_long[i]) p->maxMp = std::max(p->maxMp, hp.fbQ * NL);
     }
     p->d_models.ensure(p->dm.size() * sizeof(DevModel));
     HIPCHK(hipMemcpy(p->d_models.p, p->dm.data(), p->dm.size() * sizeof(DevModel), hipMemcpyHostToDevice));
@@ -209,6 +216,7 @@ extern "C" int ckm_profiles_header(const ckm_profiles *p, int32_t i, ckm_model_h
   o->leng = h.M; o->has_ga = h.has_ga; o->has_tc = h.has_tc; o->has_nc = h.has_nc;
   for (int k = 0; k < 2; ++k) { o->ga[k] = h.ga[k]; o->tc[k] = h.tc[k]; o->nc[k] = h.nc[k]; }
   for (int k = 0; k < 6; ++k) o->evparam[k] = h.evparam[k];
+  o->searchable = p->too_long[(size_t)i] ? 0 : 1;
   return CKM_OK;
 }
 
@@ -522,6 +530,7 @@ extern "C" int ckm_align(ckm_ctx *ctx_, const ckm_profiles *p, const ckm_seqs *s
     std::vector<EnvReq> req; std::vector<uint32_t> which;
     for (uint32_t j = 0; j < n; ++j) {
       if (model[j] >= p->hmm.size() || seq[j] >= s->nseq) throw Error(CKM_EINVAL, "pair index out of range");
+      if (p->too_long[model[j]]) throw Error(CKM_ERANGE, "model " + p->hmm[model[j]].name + " is longer than the 2048 nodes the kernels are instantiated for");
       const uint64_t M = (uint64_t)p->hmm[model[j]].M;
       if (out_off[j + 1] - out_off[j] != M) throw Error(CKM_EINVAL, "out_off does not match the model lengths");
       std::fill(node_residue + out_off[j], node_residue + out_off[j + 1], 0);

@@ -7,6 +7,7 @@ extern "C" int ckm_debug_stages(ckm_ctx *ctx_, const ckm_profiles *p, const ckm_
                                 uint32_t npairs, ckm_stage_scores *out) {
   return guarded([&] {
     if (!ctx_ || !p || !s || !model || !seq || !out) throw Error(CKM_EINVAL, "NULL argument");
+    for (uint32_t j = 0; j < npairs; ++j) if (model[j] < p->hmm.size() && p->too_long[model[j]]) throw Error(CKM_ERANGE, "model longer than the instantiated kernel classes");
     ctx_->settle();
     Worker *ctx = &ctx_->w[0];
     ctx->plan_key.clear();                 // this entry overwrites the worker's SSV tables

@@ -163,6 +163,7 @@ struct ckm_profiles {
   std::vector<DevModel> dm;
   DevBuf d_models;
   std::vector<std::unique_ptr<DevBuf>> tables;
+  std::vector<uint8_t> too_long;       // model is longer than the kernels are instantiated for: kept in the database (headers, order), never searched
   int maxMp = 0;
 };
 

@@ -1080,6 +1080,9 @@ static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, cons
     if (model_off) { for (uint32_t k = model_off[b]; k < model_off[b + 1]; ++k) { if (model_idx[k] >= nmodels) throw Error(CKM_EINVAL, "model index out of range"); bin_models[b].push_back(model_idx[k]); } }
     else { bin_models[b].resize(nmodels); std::iota(bin_models[b].begin(), bin_models[b].end(), 0u); }
   }
+  for (uint32_t b = 0; b < nbins; ++b) for (uint32_t m : bin_models[b]) if (p->too_long[m])
+    throw Error(CKM_ERANGE, "model " + p->hmm[m].name + " (LENG " + std::to_string(p->hmm[m].M) + ") is selected for bin " + std::to_string(b) +
+                            " but is longer than the 2048 nodes the kernels are instantiated for (DESIGN.md section 8); leave it out of the bin's model list");
   std::vector<std::vector<uint32_t>> model_bins(nmodels);
   for (uint32_t b = 0; b < nbins; ++b) {
     std::vector<uint32_t> uniq = bin_models[b]; std::sort(uniq.begin(), uniq.end()); uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());

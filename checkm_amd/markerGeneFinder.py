@@ -216,7 +216,7 @@ class MarkerGeneFinder(object):
             self.logger.error('marker-gene scan failed: %s' % e)
             sys.exit(1)
         heads = profiles.headers
-        models_of = model_lists(heads, allIds, wanted)
+        models_of = model_lists(heads, allIds, wanted, self.logger, db)
         # ---- this rank's shard (weights = file size x models) ----
         mine = list(range(len(binFiles)))
         if world > 1:
@@ -336,8 +336,9 @@ class MarkerGeneFinder(object):
         self.logger.info("Identified marker genes in %d bins on %d devices." % (len(binFiles), len(devs)))
         heads = replies[0]["heads"]
         allIds = [binIdFromFilename(f) for f in binFiles]
-        wanted = MarkerSetParser(self.totalThreads).markerAccessionsForBins(allIds, markerFile)
-        models_of = model_lists(heads, allIds, wanted)
+        msp = MarkerSetParser(self.totalThreads)
+        wanted = msp.markerAccessionsForBins(allIds, markerFile)
+        models_of = model_lists(heads, allIds, wanted, None, msp.hmmDatabaseFor(markerFile))      # (the workers already warned about models left out)
         totals = {}
         for r in replies:
             for k, v in r["totals"].items():
@@ -349,7 +350,7 @@ class MarkerGeneFinder(object):
         return models_for_bins(heads, allIds, models_of)
 
 
-def model_lists(heads, allIds, wanted):
+def model_lists(heads, allIds, wanted, logger=None, db=''):
     """{binId: indices into the profile database of the models the bin is scanned against} ({} when every bin takes every model); bins
     that ask for the same accession set share one list object."""
     models_of = {}
@@ -361,6 +362,24 @@ def model_lists(heads, allIds, wanted):
             if key not in cache:
                 cache[key] = None if w is None else [i for i, h in enumerate(heads) if wanted_model(h["name"], h["acc"], w)]
             models_of[b] = cache[key]
+    too_long = [i for i, h in enumerate(heads) if not h.get("searchable", True)]
+    if too_long:
+        # the database holds models beyond the kernels' 2048 nodes: they stay out of every bin's scan, loudly (hmmsearch would search them)
+        hit = sorted(set(too_long) & set(i for m in models_of.values() if m is not None for i in m)) if (models_of and all(m is not None for m in models_of.values())) else too_long
+        if hit:
+            if logger is not None:
+                logger.warning("%d model(s) of %s are longer than 2048 nodes and are NOT searched: %s" %
+                               (len(hit), db, ", ".join("%s (LENG %d)" % (heads[i]["name"], heads[i]["leng"]) for i in hit[:8])))
+            keep = [i for i in range(len(heads)) if heads[i].get("searchable", True)]
+            drop, cache = set(hit), {}
+            for b in allIds:
+                m = models_of.get(b)
+                if m is None:
+                    models_of[b] = keep
+                else:
+                    if id(m) not in cache:
+                        cache[id(m)] = [i for i in m if i not in drop]
+                    models_of[b] = cache[id(m)]
     return models_of
 
 

@@ -68,6 +68,8 @@ typedef struct {
   int32_t     has_ga, has_tc, has_nc;
   double      ga[2], tc[2], nc[2];   /* float64: CheckM compares them as Python floats with text scores */
   float       evparam[6];   /* MSV mu,lambda; VITERBI mu,lambda; FORWARD tau,lambda */
+  int32_t     searchable;   /* 0: the model is longer than the kernels are instantiated for (LENG > 2048): it keeps its place in the database, but a
+                               ckm_search / ckm_align that selects it fails with CKM_ERANGE naming it */
 } ckm_model_header;
 
 int  ckm_profiles_load(ckm_ctx *ctx, const char *hmm_path, ckm_profiles **out);
