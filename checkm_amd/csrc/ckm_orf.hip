@@ -6,7 +6,7 @@
 
 namespace ckm {
 void launch_orf_flags(hipStream_t stream, const uint8_t *text, uint8_t *flags, uint64_t n);
-void launch_orf_chain(hipStream_t stream, const uint8_t *flags, const uint64_t *contig_off, const int32_t *contig_len, uint32_t ncontigs, int tt4, int closed,
+void launch_orf_chain(hipStream_t stream, const uint8_t *planes, uint64_t nwin, const uint64_t *contig_off, const int32_t *contig_len, uint32_t ncontigs, int tt4, int closed,
                       void *nodes, unsigned long long *nnodes, unsigned long long cap);
 void launch_orf_fill(hipStream_t stream, uint8_t *text, uint64_t n, uint32_t seed);
 struct OrfNodeH { uint32_t contig; int32_t ndx, stop_val; uint8_t type, strand_rev, edge, pad; };
@@ -42,7 +42,7 @@ extern "C" int ckm_orf_scan(ckm_ctx *ctx, const char *text, const uint64_t *cont
     std::vector<uint8_t> host(64 + body + 128, (uint8_t)'N');
     for (uint32_t c = 0; c < ncontigs; ++c) memcpy(host.data() + 64 + off[c], text + contig_off[c], (size_t)len[c]);
     DevBuf d_text, d_flags, d_off, d_len, d_nodes, d_cnt;
-    d_text.ensure(host.size()); d_flags.ensure(host.size());
+    d_text.ensure(host.size()); d_flags.ensure(body + 256);                    // eight bit planes of body / 64 words: body bytes
     d_off.ensure(std::max<size_t>(8, ncontigs * 8)); d_len.ensure(std::max<size_t>(4, ncontigs * 4)); d_cnt.ensure(8);
     HIPCHK(hipMemcpyAsync(d_text.p, host.data(), host.size(), hipMemcpyHostToDevice, st));
     if (ncontigs) {
@@ -57,14 +57,14 @@ extern "C" int ckm_orf_scan(ckm_ctx *ctx, const char *text, const uint64_t *cont
     // a bacterial genome carries about one start / stop node per 12 bases; a too-small table is detected and the chain kernel runs again
     unsigned long long cap = std::max<unsigned long long>(1 << 16, bases / 6);
     unsigned long long n = 0;
-    const uint8_t *tx = d_text.as<uint8_t>() + 64; uint8_t *fl = d_flags.as<uint8_t>() + 64;
+    const uint8_t *tx = d_text.as<uint8_t>() + 64; uint8_t *fl = d_flags.as<uint8_t>();
     HIPCHK(hipEventRecord(e0, st));
     launch_orf_flags(st, tx, fl, body);
     HIPCHK(hipEventRecord(e1, st));
     for (int attempt = 0; attempt < 2; ++attempt) {
       d_nodes.ensure((size_t)cap * sizeof(OrfNodeH));
       if (attempt) { HIPCHK(hipMemsetAsync(d_cnt.p, 0, 8, st)); HIPCHK(hipEventRecord(e1, st)); }
-      launch_orf_chain(st, fl, d_off.as<uint64_t>(), d_len.as<int32_t>(), ncontigs, trans_table == 4 ? 1 : 0, closed ? 1 : 0, d_nodes.p, d_cnt.as<unsigned long long>(), cap);
+      launch_orf_chain(st, fl, body / 64, d_off.as<uint64_t>(), d_len.as<int32_t>(), ncontigs, trans_table == 4 ? 1 : 0, closed ? 1 : 0, d_nodes.p, d_cnt.as<unsigned long long>(), cap);
       HIPCHK(hipEventRecord(e2, st));
       HIPCHK(hipGetLastError());
       HIPCHK(hipMemcpyAsync(&n, d_cnt.p, 8, hipMemcpyDeviceToHost, st));
@@ -115,11 +115,11 @@ extern "C" int ckm_debug_orf_flags(ckm_ctx *ctx, uint64_t nbytes, uint32_t reps,
     DevBuf d_text, d_flags;
     d_text.ensure(n + 256); d_flags.ensure(n + 256);
     launch_orf_fill(st, d_text.as<uint8_t>(), n + 192, 12345u);
-    launch_orf_flags(st, d_text.as<uint8_t>() + 64, d_flags.as<uint8_t>() + 64, n);        // warm-up
+    launch_orf_flags(st, d_text.as<uint8_t>() + 64, d_flags.as<uint8_t>(), n);        // warm-up
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, st));
-    for (uint32_t r = 0; r < reps; ++r) launch_orf_flags(st, d_text.as<uint8_t>() + 64, d_flags.as<uint8_t>() + 64, n);
+    for (uint32_t r = 0; r < reps; ++r) launch_orf_flags(st, d_text.as<uint8_t>() + 64, d_flags.as<uint8_t>(), n);
     HIPCHK(hipEventRecord(e1, st));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));

@@ -2,12 +2,10 @@
 // runs before the marker-gene scan (`prodigal -p single -m -g 11|4`, checkm/prodigal.py:74,86-93,131-133): start / stop codon flags
 // of all six frames, and the start / stop NODES prodigal's dynamic program works on (node.c: add_nodes).  gfx950 only.
 //
-//   orf_flags_kernel   one thread per 64 bases: reads the nucleotide text once (1 B / base), writes one flag byte per base
-//                      (1 B / base) -- a pure streaming kernel, bound by HBM: 2 algorithmic bytes per base.
-//                        bit 0     forward codon at i is a stop of table 11 (TAA TAG TGA)      bit 1  ... of table 4 (TAA TAG)
-//                        bits 2-3  forward codon at i is a start: 1 ATG, 2 GTG, 3 TTG
-//                        bits 4-7  the same for the reverse-strand codon whose first base is the complement of base i
-//                      Contigs are laid out with >= 2 separator bytes ('N') between them, so no codon spans two contigs.
+//   orf_flags_kernel   one thread per 64 bases, bit-parallel: reads the nucleotide text once (1 B / base), writes eight bit planes
+//                      (stop of table 11 / of table 4 / start type, both strands: 1 B / base in all) -- a streaming kernel priced
+//                      against the HBM roofline: 2 algorithmic bytes per base.  Contigs are laid out with >= 2 separator bytes ('N')
+//                      between them, so no codon spans two contigs.
 //   orf_chain_kernel   one wavefront per (contig, strand, frame): the frame's codons from the 3' end to the 5' end, 64 per step; the
 //                      sequential registers of add_nodes (last stop, start-seen, minimum length) become wave-wide prefix operations
 //                      on ballots (nearest stop / any start among the lanes scanned before me) plus three carried scalars.
@@ -20,62 +18,76 @@ namespace ckm {
 
 constexpr int ORF_MIN_GENE = 90, ORF_MIN_EDGE_GENE = 60;
 
-__device__ __forceinline__ uint32_t nt_code(uint32_t ch) {        // ASCII -> 0 A, 1 C, 2 G, 3 T/U, 4 other
-  ch &= 0xDFu;                                                    // upper case
-  return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : (ch == 'T' || ch == 'U') ? 3u : 4u;
+// ---- the streaming kernel: 64 bases per thread, bit-parallel ------------------------------------------------------------------------
+// The 64 bases of a window become four 64-bit masks (which positions hold A, C, G, T/U; anything else is in none of them), built four
+// bytes at a time with exact byte-equality tests on 32-bit words; every codon test of the window is then a handful of 64-bit AND / OR
+// operations on shifted masks (bit k = base k of the window, two halo bases on either side).  Output: eight bit planes of one 64-bit
+// word per window -- 1 byte per base in all, as many bytes as were read.
+//   plane 0  forward codon at i is a stop of table 11 (TAA TAG TGA)     plane 1  ... of table 4 (TAA TAG)
+//   plane 2 / 3  low / high bit of the forward start type (1 ATG, 2 GTG, 3 TTG; 0 none)
+//   plane 4-7  the same for the reverse-strand codon whose first base is the complement of base i (its bases are i, i-1, i-2)
+constexpr int ORF_PLANES = 8;
+
+__device__ __forceinline__ uint32_t bytes_equal(uint32_t w, uint32_t letter4) {     // 0x80 in every byte of w that equals the letter
+  const uint32_t z = w ^ letter4;
+  return ~(((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z | 0x7f7f7f7fu);
+}
+__device__ __forceinline__ uint32_t gather4(uint32_t m) {          // bits 7, 15, 23, 31 -> bits 0..3
+  m >>= 7;
+  return (m | (m >> 7) | (m >> 14) | (m >> 21)) & 0xfu;
+}
+struct Masks4 { uint32_t a, c, g, t; };
+__device__ __forceinline__ Masks4 word_masks(uint32_t w) {
+  const uint32_t lc = w | 0x20202020u;                             // lower case
+  Masks4 m;
+  m.a = gather4(bytes_equal(lc, 0x61616161u)); m.c = gather4(bytes_equal(lc, 0x63636363u)); m.g = gather4(bytes_equal(lc, 0x67676767u));
+  m.t = gather4(bytes_equal(lc & 0xfefefefeu, 0x74747474u));       // 't' and 'u' differ in bit 0 only
+  return m;
 }
 
-// flags of a forward codon (b0 b1 b2) -- low nibble layout described above
-__device__ __forceinline__ uint32_t codon_flags(uint32_t b0, uint32_t b1, uint32_t b2) {
-  if ((b0 | b1 | b2) > 3u) return 0u;
-  const uint32_t c = b0 * 16u + b1 * 4u + b2;
-  uint32_t f = 0u;
-  if (c == 48u || c == 50u) f |= 3u;            // TAA TAG: stop in both tables
-  if (c == 56u) f |= 1u;                        // TGA: stop in table 11 only
-  if (c == 14u) f |= 1u << 2;                   // ATG
-  if (c == 46u) f |= 2u << 2;                   // GTG
-  if (c == 62u) f |= 3u << 2;                   // TTG
-  return f;
-}
-
-__global__ void __launch_bounds__(256) orf_flags_kernel(const uint8_t *__restrict__ text, uint8_t *__restrict__ flags, uint64_t n) {
-  const uint64_t w0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 64ull;
-  if (w0 >= n) return;
-  // 64 bases + 2 of halo on either side, as codes in registers (the buffer is padded by 16 bytes of 'N' at both ends)
-  uint32_t code[68];
-  const uint4 *src = reinterpret_cast<const uint4 *>(text + w0);        // w0 is a multiple of 64 and the buffer 16-byte aligned
-  const uint32_t hl = *reinterpret_cast<const uint32_t *>(text + w0 - 4), hr = *reinterpret_cast<const uint32_t *>(text + w0 + 64);
-  code[0] = nt_code((hl >> 16) & 0xff); code[1] = nt_code(hl >> 24);
-  code[66] = nt_code(hr & 0xff); code[67] = nt_code((hr >> 8) & 0xff);
+__global__ void __launch_bounds__(256) orf_flags_kernel(const uint8_t *__restrict__ text, unsigned long long *__restrict__ planes, uint64_t nwin) {
+  const uint64_t win = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (win >= nwin) return;
+  const uint8_t *src = text + win * 64ull;                         // 64-byte aligned; the buffer has >= 64 bytes of 'N' before and after
+  unsigned long long A = 0, C = 0, G = 0, T = 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const uint4 v = src[q];
+    const uint4 v = reinterpret_cast<const uint4 *>(src)[q];
     const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) code[2 + q * 16 + k * 4 + b] = nt_code((wd[k] >> (8 * b)) & 0xff);
+    for (int k = 0; k < 4; ++k) {
+      const Masks4 m = word_masks(wd[k]);
+      const int sh = (q * 4 + k) * 4;
+      A |= (unsigned long long)m.a << sh; C |= (unsigned long long)m.c << sh; G |= (unsigned long long)m.g << sh; T |= (unsigned long long)m.t << sh;
+    }
   }
-  uint32_t outw[16];
-#pragma unroll
-  for (int j = 0; j < 64; ++j) {
-    const uint32_t c0 = code[2 + j], f1 = code[3 + j], f2 = code[4 + j], r1 = code[1 + j], r2 = code[j];
-    const uint32_t fw = codon_flags(c0, f1, f2);
-    // reverse-strand codon starting at i: complements of bases i, i-1, i-2 (complement of code c <= 3 is 3 - c)
-    const uint32_t rv = ((c0 | r1 | r2) > 3u) ? 0u : codon_flags(3u - c0, 3u - r1, 3u - r2);
-    const uint32_t fb = fw | (rv << 4);
-    if ((j & 3) == 0) outw[j >> 2] = fb; else outw[j >> 2] |= fb << (8 * (j & 3));
-  }
-  uint4 *dst = reinterpret_cast<uint4 *>(flags + w0);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) dst[q] = make_uint4(outw[q * 4], outw[q * 4 + 1], outw[q * 4 + 2], outw[q * 4 + 3]);
+  // halo: bases -4..-1 (bit 3 = base -1) and 64..67 (bit 0 = base 64)
+  const Masks4 hp = word_masks(*reinterpret_cast<const uint32_t *>(src - 4)), hn = word_masks(*reinterpret_cast<const uint32_t *>(src + 64));
+#define NEXT1(X, h) (((X) >> 1) | ((unsigned long long)((h) & 1u) << 63))
+#define NEXT2(X, h) (((X) >> 2) | ((unsigned long long)((h) & 3u) << 62))
+#define PREV1(X, h) (((X) << 1) | (unsigned long long)(((h) >> 3) & 1u))
+#define PREV2(X, h) (((X) << 2) | (unsigned long long)(((h) >> 2) & 3u))
+  const unsigned long long A1 = NEXT1(A, hn.a), A2 = NEXT2(A, hn.a), G1 = NEXT1(G, hn.g), G2 = NEXT2(G, hn.g), T1 = NEXT1(T, hn.t);
+  const unsigned long long Tm1 = PREV1(T, hp.t), Tm2 = PREV2(T, hp.t), Cm1 = PREV1(C, hp.c), Cm2 = PREV2(C, hp.c), Am1 = PREV1(A, hp.a);
+#undef NEXT1
+#undef NEXT2
+#undef PREV1
+#undef PREV2
+  const unsigned long long TA = T & A1, T1G2 = T1 & G2;
+  const unsigned long long fTAAG = TA & (A2 | G2), fTGA = T & G1 & A2, fATG = A & T1G2, fGTG = G & T1G2, fTTG = T & T1G2;
+  // reverse strand: the codon read from base i leftwards, complemented (A <-> T, C <-> G): TAA = A T T, TAG = A T C, TGA = A C T,
+  // ATG = T A C, GTG = C A C, TTG = A A C
+  const unsigned long long ATm = A & Tm1, Am1Cm2 = Am1 & Cm2;
+  const unsigned long long rTAAG = ATm & (Tm2 | Cm2), rTGA = A & Cm1 & Tm2, rATG = T & Am1Cm2, rGTG = C & Am1Cm2, rTTG = A & Am1Cm2;
+  planes[0 * nwin + win] = fTAAG | fTGA; planes[1 * nwin + win] = fTAAG; planes[2 * nwin + win] = fATG | fTTG; planes[3 * nwin + win] = fGTG | fTTG;
+  planes[4 * nwin + win] = rTAAG | rTGA; planes[5 * nwin + win] = rTAAG; planes[6 * nwin + win] = rATG | rTTG; planes[7 * nwin + win] = rGTG | rTTG;
 }
 
 struct OrfNode { uint32_t contig; int32_t ndx, stop_val; uint8_t type, strand_rev, edge, pad; };     // type 0 ATG, 1 GTG, 2 TTG, 3 stop
 
 // One wavefront per (contig, strand, frame).  Scan coordinate j = position on the strand being read (forward: j = i; reverse: j is the
 // index into the reverse complement, forward position slen-1-j), descending from the last complete codon of the frame.
-__global__ void __launch_bounds__(64) orf_chain_kernel(const uint8_t *__restrict__ flags, const uint64_t *__restrict__ contig_off /* start of each contig in the padded buffer */,
+__global__ void __launch_bounds__(64) orf_chain_kernel(const unsigned long long *__restrict__ planes, uint64_t nwin, const uint64_t *__restrict__ contig_off /* start of each contig in the padded buffer */,
                                                         const int32_t *__restrict__ contig_len, uint32_t ncontigs, int tt4, int closed,
                                                         OrfNode *__restrict__ nodes, unsigned long long *__restrict__ nnodes, unsigned long long cap) {
   const uint32_t job = blockIdx.x;
@@ -84,10 +96,10 @@ __global__ void __launch_bounds__(64) orf_chain_kernel(const uint8_t *__restrict
   const int rev = sub >= 3u, frame = (int)(sub % 3u);
   const int slen = contig_len[ci];
   if (slen < 3) return;
-  const uint8_t *fl = flags + contig_off[ci];
+  const uint64_t base = contig_off[ci];                          // position of the contig's first base in the padded buffer
   const int lane = threadIdx.x;
-  const int shift = rev ? 4 : 0;
-  const uint32_t stopbit = tt4 ? 2u : 1u;
+  const unsigned long long *p_stop = planes + (uint64_t)((rev ? 4 : 0) + (tt4 ? 1 : 0)) * nwin;
+  const unsigned long long *p_lo = planes + (uint64_t)((rev ? 4 : 0) + 2) * nwin, *p_hi = planes + (uint64_t)((rev ? 4 : 0) + 3) * nwin;
   // the frame's first scanned position: the largest j <= slen-3 with j % 3 == frame
   int jtop = slen - 3; jtop -= ((jtop % 3) - frame + 3) % 3;
   auto emit = [&](int ndx_s, int type, int sv_s, int edge) {
@@ -103,10 +115,13 @@ __global__ void __launch_bounds__(64) orf_chain_kernel(const uint8_t *__restrict
   bool last_real = false, saw = false, any_stop = false;
   for (int jhi = jtop; jhi >= 0; jhi -= 192) {
     const int j = jhi - 3 * lane;
-    uint32_t f = 0;
-    if (j >= 0) f = ((uint32_t)fl[rev ? slen - 1 - j : j] >> shift) & 0xfu;
-    const bool is_stop = j >= 0 && (f & stopbit);
-    const int st = (int)((f >> 2) & 3u) - 1;                      // -1 none, 0 ATG, 1 GTG, 2 TTG
+    bool is_stop = false; int st = -1;                           // st: -1 none, 0 ATG, 1 GTG, 2 TTG
+    if (j >= 0) {
+      const uint64_t pos = base + (uint64_t)(rev ? slen - 1 - j : j);
+      const uint64_t wi = pos >> 6; const int bit = (int)(pos & 63);
+      is_stop = (p_stop[wi] >> bit) & 1ull;
+      st = (int)(((p_lo[wi] >> bit) & 1ull) | (((p_hi[wi] >> bit) & 1ull) << 1)) - 1;
+    }
     const unsigned long long stops = __ballot(is_stop);
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));          // lanes scanned before me
     const unsigned long long sb = stops & below;
@@ -156,13 +171,14 @@ void launch_orf_fill(hipStream_t stream, uint8_t *text, uint64_t n, uint32_t see
   hipLaunchKernelGGL(orf_fill_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, text, n, seed);
 }
 
-void launch_orf_flags(hipStream_t stream, const uint8_t *text, uint8_t *flags, uint64_t n) {
-  const uint64_t threads = (n + 63) / 64;
-  if (threads) hipLaunchKernelGGL(orf_flags_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, text, flags, n);
+// text: n bytes (a multiple of 64) with >= 64 readable bytes before and after; planes: ORF_PLANES x (n / 64) 64-bit words
+void launch_orf_flags(hipStream_t stream, const uint8_t *text, uint8_t *planes, uint64_t n) {
+  const uint64_t nwin = n / 64;
+  if (nwin) hipLaunchKernelGGL(orf_flags_kernel, dim3((unsigned)((nwin + 255) / 256)), dim3(256), 0, stream, text, reinterpret_cast<unsigned long long *>(planes), nwin);
 }
-void launch_orf_chain(hipStream_t stream, const uint8_t *flags, const uint64_t *contig_off, const int32_t *contig_len, uint32_t ncontigs, int tt4, int closed,
+void launch_orf_chain(hipStream_t stream, const uint8_t *planes, uint64_t nwin, const uint64_t *contig_off, const int32_t *contig_len, uint32_t ncontigs, int tt4, int closed,
                       void *nodes, unsigned long long *nnodes, unsigned long long cap) {
-  if (ncontigs) hipLaunchKernelGGL(orf_chain_kernel, dim3(ncontigs * 6), dim3(64), 0, stream, flags, contig_off, contig_len, ncontigs, tt4, closed,
+  if (ncontigs) hipLaunchKernelGGL(orf_chain_kernel, dim3(ncontigs * 6), dim3(64), 0, stream, reinterpret_cast<const unsigned long long *>(planes), nwin, contig_off, contig_len, ncontigs, tt4, closed,
                                    reinterpret_cast<OrfNode *>(nodes), nnodes, cap);
 }
 

@@ -40,7 +40,7 @@ def test_nodes_equal_the_oracle(gpu_ctx):
         for closed in (False, True):
             got, stats = device_nodes(gpu_ctx, contigs, tt, closed)
             want = oracle_nodes(contigs, tt, closed)
-            assert len(got) == len(want) and len(want) > 2000, (len(got), len(want))
+            assert len(got) == len(want) and len(want) > 1000, (len(got), len(want))
             assert got == want, (tt, closed, next((a, b) for a, b in zip(got, want) if a != b))
             assert stats["bases"] == sum(len(c) for c in contigs)
 
