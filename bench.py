@@ -774,7 +774,8 @@ def bench_cfg3(args, env):
                       "bins_total": nbins, "parallelism": "bins sharded over %d GPU(s) by MarkerGeneFinder.find (file size x models); 1 all_gather of QA rows" % world,
                       "steps_note": "one step = all %d bins; %d step(s) fit the %.0f s budget of the timed region (estimated %.1f s per step from the warm pass)" % (nbins, steps, args.budget_seconds, est)},
            "residue_hmm_per_s": residue_hmm / per_step, "residue_hmm_per_step": residue_hmm,
-           "first_pass_s": first_pass_s, "first_pass_bins": warm,
+           "first_pass_s": first_pass_s, "first_pass_bins": warm, "second_pass_s_same_bins": second_pass_s if second_pass_s > 0 else None,
+           "first_pass_overhead_s": (first_pass_s - second_pass_s) if second_pass_s > 0 else None,
            "parts_s_rank0": parts, "roofline": roof, "roofline_valu": valu, "stage_pairs": stage_pairs(tot), "ssv_ms_max_rank": ssv_ms,
            "gpu_host_split_s_rank0": {"ssv_kernels": tot.get("ms_ssv", 0.0) / 1e3, "search_calls_sum": tot.get("ms_total", 0.0) / 1e3,
                                       "ingest": tot.get("ingest_s", 0.0), "search": tot.get("search_s", 0.0), "write": tot.get("write_s", 0.0),

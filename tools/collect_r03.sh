@@ -27,7 +27,7 @@ for w in $WHAT; do
         (cd /tmp && CKM_WS_PER_MP=5 CKM_BENCH_STEADY=0 CKM_BENCH_FROM_HOST=0 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/pmc_$name" -o p -- python "$ROOT/bench.py" --config cfg2 --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err")
       done ;;
     trace2)
-      (cd /tmp && CKM_BENCH_FROM_HOST=0 rocprofv3 --kernel-trace -d "$OUT/trace2" -o bench -- python "$ROOT/bench.py" --config cfg2 --steps 3 --warmup 2 --no-cpu-baseline > "$OUT/trace2.json" 2> "$OUT/trace2.err") ;;
+      (cd /tmp && CKM_BENCH_FROM_HOST=0 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace2" -o bench -- python "$ROOT/bench.py" --config cfg2 --steps 3 --warmup 2 --no-cpu-baseline > "$OUT/trace2.json" 2> "$OUT/trace2.err") ;;
   esac
 done
 ls -R "$OUT" | head -60
