@@ -153,7 +153,7 @@ extern "C" int ckm_profiles_load(ckm_ctx *ctx, const char *hmm_path, ckm_profile
         for (size_t i = lo; i < hi; ++i) {
           try { p->prof[i] = configure_profile(p->hmm[i]); }
           catch (const Error &e) {
-            // A model beyond the instantiated kernel classes (M > 2048) does not take the database down: it keeps its place and its
+            // A model beyond the instantiated kernel classes (M > 4096) does not take the database down: it keeps its place and its
             // header, and only a search that actually selects it is refused, by name (ckm_search).  CheckM's marker sets hold no such
             // model; a full Pfam / TIGRFAM file holds a handful.
             if (e.code == CKM_ERANGE) { p->too_long[i] = 1; p->prof[i] = HostProfile(); p->prof[i].M = p->hmm[i].M; p->prof[i].ssvQ = p->prof[i].fbQ = p->prof[i].vitQH = 1; }
@@ -530,7 +530,7 @@ extern "C" int ckm_align(ckm_ctx *ctx_, const ckm_profiles *p, const ckm_seqs *s
     std::vector<EnvReq> req; std::vector<uint32_t> which;
     for (uint32_t j = 0; j < n; ++j) {
       if (model[j] >= p->hmm.size() || seq[j] >= s->nseq) throw Error(CKM_EINVAL, "pair index out of range");
-      if (p->too_long[model[j]]) throw Error(CKM_ERANGE, "model " + p->hmm[model[j]].name + " is longer than the 2048 nodes the kernels are instantiated for");
+      if (p->too_long[model[j]]) throw Error(CKM_ERANGE, "model " + p->hmm[model[j]].name + " is longer than the 4096 nodes the kernels are instantiated for");
       const uint64_t M = (uint64_t)p->hmm[model[j]].M;
       if (out_off[j + 1] - out_off[j] != M) throw Error(CKM_EINVAL, "out_off does not match the model lengths");
       std::fill(node_residue + out_off[j], node_residue + out_off[j + 1], 0);

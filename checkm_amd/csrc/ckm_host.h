@@ -131,8 +131,9 @@ struct Worker {
 };
 
 // register classes of the Viterbi-filter and Forward/Backward kernels, in queue order (DevModel::vit_cls / fb_cls index these)
-constexpr int kVitQH[ckm::NVC] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16};
-constexpr int kFbQ[ckm::NFC] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+constexpr int kVitQH[ckm::NVC] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 24, 32};
+constexpr int kFbQ[ckm::NFC] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
+constexpr int kSsvNone = 65;          // "SSV class" of a model beyond the 2048 nodes the SSV kernel's LDS image holds: every pair goes to the exact MSV kernel
 inline int vit_class_id(int QH) { for (int i = 0; i < ckm::NVC; ++i) if (kVitQH[i] == QH) return i; return -1; }
 inline int fb_class_id(int Q) { for (int i = 0; i < ckm::NFC; ++i) if (kFbQ[i] == Q) return i; return -1; }
 

@@ -604,7 +604,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
     }
   }
   // per group: its pairs and the Viterbi / Forward register classes of its models
-  struct Sub { int Q; size_t first, nblocks; uint64_t pairs = 0; bool vit[NVC] = {false}, fb[NFC] = {false};
+  struct Sub { int Q; int maxM = 0; size_t first, nblocks; uint64_t pairs = 0; bool vit[NVC] = {false}, fb[NFC] = {false};
                uint32_t cap_cand = 0, cap_nores = 0, cap_f = 0, cap_e = 0, cap_r = 0; size_t o_cand = 0, o_nores = 0, o_vq = 0, o_f = 0, o_e = 0, o_r = 0; };
   std::vector<Sub> subs;
   {
@@ -616,7 +616,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
         for (uint32_t b : model_bins[mw.model]) np += cut[part + 1][b] - cut[part][b];
         auto it = at.find(part * 1000 + p->prof[mw.model].ssvQ);
         if (it == at.end()) continue;                         // (no sequence of this part in the model's bins)
-        Sub &sb = subs[it->second]; sb.pairs += np; sb.vit[p->dm[mw.model].vit_cls] = true; sb.fb[p->dm[mw.model].fb_cls] = true;
+        Sub &sb = subs[it->second]; sb.pairs += np; sb.vit[p->dm[mw.model].vit_cls] = true; sb.fb[p->dm[mw.model].fb_cls] = true; sb.maxM = std::max(sb.maxM, p->prof[mw.model].M);
       }
     }
   }
@@ -754,7 +754,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
       FinishArgs fa{dm, lt, dlen, s->d_order.as<uint32_t>(), ctx->work.as<SsvBlockWork>() + sb.first, ctx->maxv.as<uint16_t>(),
                     cd.cand, cnt + CC_CAND, sb.cap_cand, nores, cnt + CC_NORES, sb.cap_nores};
       launch_msv_finish(sc, fa, (uint32_t)sb.nblocks);
-      if (stop >= 2) launch_msv_full(sc, GRID_MSV, WorkQueue{nullptr, cnt + CC_NORES, sb.cap_nores}, nores, dm, lt, res, off, dlen, nullptr, nullptr, std::min(p->maxMp, 32 * sb.Q) /* the group's models fit its SSV class: a small LDS image, many pairs per CU */, &cd);
+      if (stop >= 2) launch_msv_full(sc, GRID_MSV, WorkQueue{nullptr, cnt + CC_NORES, sb.cap_nores}, nores, dm, lt, res, off, dlen, nullptr, nullptr, std::max(64, sb.maxM) /* sized to the group's longest model: a small LDS image, many pairs per CU */, &cd);
       if (stop >= 3) launch_bias_filter(sc, GRID_MSV, cd, dm, lt, res, off);
       int rc = 0;
       for (int c = NVC - 1; c >= 0; --c) if (sb.vit[c]) {
@@ -1082,7 +1082,7 @@ static void do_search(ckm_ctx *c, const ckm_profiles *p, const ckm_seqs *s, cons
   }
   for (uint32_t b = 0; b < nbins; ++b) for (uint32_t m : bin_models[b]) if (p->too_long[m])
     throw Error(CKM_ERANGE, "model " + p->hmm[m].name + " (LENG " + std::to_string(p->hmm[m].M) + ") is selected for bin " + std::to_string(b) +
-                            " but is longer than the 2048 nodes the kernels are instantiated for (DESIGN.md section 8); leave it out of the bin's model list");
+                            " but is longer than the 4096 nodes the kernels are instantiated for (DESIGN.md section 8); leave it out of the bin's model list");
   std::vector<std::vector<uint32_t>> model_bins(nmodels);
   for (uint32_t b = 0; b < nbins; ++b) {
     std::vector<uint32_t> uniq = bin_models[b]; std::sort(uniq.begin(), uniq.end()); uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());

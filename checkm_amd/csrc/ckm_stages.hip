@@ -198,7 +198,29 @@ void run_msv_exact(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const 
   usc.assign(n, 0.f); if (xJ) xJ->assign(n, 0);
   if (!n) return;
   std::map<int, std::map<uint32_t, std::vector<uint32_t>>> byQ;            // Q -> model -> indices into pairs
-  for (uint32_t i = 0; i < n; ++i) byQ[p->prof[pairs[i].model].ssvQ][pairs[i].model].push_back(i);
+  std::vector<uint32_t> big;                                                // pairs of models beyond 2048 nodes: the wave-per-pair kernel takes any length
+  for (uint32_t i = 0; i < n; ++i) {
+    if (p->prof[pairs[i].model].ssvQ > 64) big.push_back(i);
+    else byQ[p->prof[pairs[i].model].ssvQ][pairs[i].model].push_back(i);
+  }
+  if (!big.empty()) {
+    std::vector<PairRec> bp(big.size());
+    for (size_t k = 0; k < big.size(); ++k) bp[k] = pairs[big[k]];
+    const uint32_t nb = (uint32_t)big.size();
+    DevBuf d_pairs, d_cnt, d_x, d_u;
+    d_pairs.ensure(nb * sizeof(PairRec)); d_cnt.ensure(16); d_x.ensure((size_t)nb * 4); d_u.ensure((size_t)nb * 4);
+    HIPCHK(hipMemcpyAsync(d_pairs.p, bp.data(), nb * sizeof(PairRec), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_cnt.p, &nb, 4, hipMemcpyHostToDevice, ctx->stream));
+    launch_msv_full(ctx->stream, std::min<uint32_t>(nb, 1024), WorkQueue{nullptr, d_cnt.as<uint32_t>(), nb}, d_pairs.as<PairRec>(), p->d_models.as<DevModel>(), s->d_lentab.as<LenEntry>(),
+                    s->d_res.as<uint8_t>(), s->d_off.as<uint64_t>(), s->d_len.as<int32_t>(), d_x.as<int32_t>(), d_u.as<float>(), p->maxMp, nullptr);
+    HIPCHK(hipGetLastError());
+    std::vector<float> ru(nb); std::vector<int32_t> rx(nb);
+    HIPCHK(hipMemcpyAsync(ru.data(), d_u.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(rx.data(), d_x.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (size_t k = 0; k < big.size(); ++k) { usc[big[k]] = ru[k]; if (xJ) (*xJ)[big[k]] = rx[k]; }
+    if (byQ.empty()) return;
+  }
   std::vector<SsvBlockWork> work; std::vector<uint32_t> lists, slot_of(n); std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;
   constexpr uint32_t PER_BLOCK = 16;
   for (auto it = byQ.rbegin(); it != byQ.rend(); ++it) {
@@ -234,7 +256,7 @@ void run_msv_exact(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const 
   HIPCHK(hipMemcpyAsync(raw.data(), ctx->fullu.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (xJ) HIPCHK(hipMemcpyAsync(rawx.data(), ctx->fullx.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  for (size_t i = 0; i < n; ++i) { usc[i] = raw[slot_of[i]]; if (xJ) (*xJ)[i] = rawx[slot_of[i]]; }
+  for (size_t i = 0; i < n; ++i) { if (p->prof[pairs[i].model].ssvQ > 64) continue; usc[i] = raw[slot_of[i]]; if (xJ) (*xJ)[i] = rawx[slot_of[i]]; }
 }
 
 // ---- multi-domain regions: trace ensemble on the device, clustering of the sampled segments here ----------------

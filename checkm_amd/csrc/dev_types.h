@@ -100,8 +100,8 @@ struct FinishArgs {
 };
 
 // ---- device-driven cascade (ckm_cascade.hip, kernels_*.hip epilogues) ---------------------------------------------------------
-constexpr int NVC = 12;               // Viterbi-filter register classes  QH in {1,2,3,4,5,6,7,8,10,12,14,16}
-constexpr int NFC = 10;               // Forward/Backward register classes Q in {1,2,3,4,6,8,12,16,24,32}
+constexpr int NVC = 14;               // Viterbi-filter register classes  QH in {1,2,3,4,5,6,7,8,10,12,14,16, 24,32}   (24, 32: models of 2049..4096 nodes)
+constexpr int NFC = 12;               // Forward/Backward register classes Q in {1,2,3,4,6,8,12,16,24,32, 48,64}
 
 enum CascadeCounter : int {           // uint32 counters in device memory (count and head arrays share this layout)
   CC_CAND = 0, CC_NORES, CC_FWORK, CC_EWORK, CC_RWORK, CC_PASS, CC_REG, CC_EVENTS, CC_STATUS, CC_EVENTS_E, CC_EVENTS_R,

@@ -279,7 +279,7 @@ int canon_Q(int M) {
   for (int q : kCanonQ) if (q * NL >= M) return q;
   return -1;
 }
-static const int kVitQH[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16};
+static const int kVitQH[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 24, 32};
 int vit_QH_for(int M) {
   for (int q : kVitQH) if (q * 128 >= M) return q;
   return -1;
@@ -287,7 +287,7 @@ int vit_QH_for(int M) {
 static const int kSsvQ[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 48, 56, 64};
 int ssv_Q_for(int M) {
   for (int q : kSsvQ) if (q * 32 >= M) return q;
-  return -1;
+  return M <= 4096 ? 65 : -1;          // 65 (kSsvNone): no SSV instance holds the model; the exact MSV kernel takes all of its pairs
 }
 
 // IEEE binary16 bits of k/256 for an integer |k| <= 2047 (exact: k has at most 11 significant bits)
@@ -336,7 +336,7 @@ HostProfile configure_profile(const HostHMM &h) {
   p.fbQ = canon_Q(M);
   p.vitQH = vit_QH_for(M);
   p.ssvQ = ssv_Q_for(M);
-  if (p.fbQ < 0 || p.ssvQ < 0 || p.vitQH < 0) throw Error(CKM_ERANGE, "model " + h.name + ": LENG " + std::to_string(M) + " exceeds the supported maximum of 2048");
+  if (p.fbQ < 0 || p.ssvQ < 0 || p.vitQH < 0) throw Error(CKM_ERANGE, "model " + h.name + ": LENG " + std::to_string(M) + " exceeds the supported maximum of 4096");
   const float NEG = -INFINITY;
   // generic log-odds: transitions indexed by source node 0..M-1; entry B->M_k stored at k-1
   std::vector<float> gBM(M + 1, NEG), gMM(M + 1, NEG), gIM(M + 1, NEG), gDM(M + 1, NEG), gMD(M + 1, NEG), gDD(M + 1, NEG), gMI(M + 1, NEG), gII(M + 1, NEG);
@@ -380,7 +380,7 @@ HostProfile configure_profile(const HostHMM &h) {
     // p = q + Q*(2*z + h) (HMMER-style striping so the diagonal move is a register rename);
     // lane z fetches registers 4g..4g+3 of symbol x with one ds_read_b128 at (g*30 + x)*256 + z*16 (group-major, so
     // that symbol*256 + lane offset is a byte permute and g rides in the instruction's offset field).
-    const int Q = p.ssvQ, Qg = (Q + 3) / 4;
+    const int Q = p.ssvQ > 64 ? 0 : p.ssvQ, Qg = (Q + 3) / 4;         // (no LDS image for a model the SSV kernel cannot hold)
     p.ssv_tbl.assign((size_t)NROWS * Qg * 16 * 8, (int16_t)(p.bias_b - 255));
     for (int x = 0; x < KP; ++x)
       for (int q = 0; q < Q; ++q)

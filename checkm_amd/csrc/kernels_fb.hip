@@ -618,7 +618,13 @@ __global__ void __launch_bounds__(64) oa_kernel(WorkQueue queue, const FbWork *_
  }
 }
 
-#define CKM_FB_QS(X) X(1) X(2) X(3) X(4) X(6) X(8) X(12) X(16) X(24) X(32)
+#define CKM_FB_QS(X) X(1) X(2) X(3) X(4) X(6) X(8) X(12) X(16) X(24) X(32) X(48) X(64)
+
+// the transition image of a model beyond 2048 nodes (Q = 48, 64) is 96 / 128 KB of LDS: above the 64 KB a launch may ask for by default
+template <class K>
+static void allow_big_lds(K kernel, int Q) {
+  if (Q >= 48) (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * Q * 64 * 4);
+}
 
 int launch_fwd(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, FbWork *work, const DevModel *models,
                const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, FwdOut *out,
@@ -627,7 +633,7 @@ int launch_fwd(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, FbW
   CascadeDev c; memset(&c, 0, sizeof(c));
   if (cd) c = *cd;
   switch (Q) {
-#define X(QV) case QV: hipLaunchKernelGGL(fwd_kernel<QV>, dim3(nblocks), dim3(64), (size_t)8 * QV * 64 * 4, stream, queue, work, models, lentab, res, seq_off, ws, out, events, nevents, cap_events, c, cd ? 1 : 0); break;
+#define X(QV) case QV: allow_big_lds(fwd_kernel<QV>, QV); hipLaunchKernelGGL(fwd_kernel<QV>, dim3(nblocks), dim3(64), (size_t)8 * QV * 64 * 4, stream, queue, work, models, lentab, res, seq_off, ws, out, events, nevents, cap_events, c, cd ? 1 : 0); break;
     CKM_FB_QS(X)
 #undef X
     default: return -1;
@@ -638,7 +644,7 @@ int launch_bwd(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, con
                const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, const FwdOut *fout, int32_t *range_err) {
   if (!nblocks) return 0;
   switch (Q) {
-#define X(QV) case QV: hipLaunchKernelGGL(bwd_kernel<QV>, dim3(nblocks), dim3(64), (size_t)8 * QV * 64 * 4, stream, queue, work, models, lentab, res, seq_off, ws, fout, range_err); break;
+#define X(QV) case QV: allow_big_lds(bwd_kernel<QV>, QV); hipLaunchKernelGGL(bwd_kernel<QV>, dim3(nblocks), dim3(64), (size_t)8 * QV * 64 * 4, stream, queue, work, models, lentab, res, seq_off, ws, fout, range_err); break;
     CKM_FB_QS(X)
 #undef X
     default: return -1;
@@ -649,7 +655,7 @@ int launch_oa(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, cons
               float *ws, const int32_t *range_err, const FwdOut *fout, EnvOut *out) {
   if (!nblocks) return 0;
   switch (Q) {
-#define X(QV) case QV: hipLaunchKernelGGL(oa_kernel<QV>, dim3(nblocks), dim3(64), (size_t)8 * QV * 64 * 4, stream, queue, work, models, ws, range_err, fout, out); break;
+#define X(QV) case QV: allow_big_lds(oa_kernel<QV>, QV); hipLaunchKernelGGL(oa_kernel<QV>, dim3(nblocks), dim3(64), (size_t)8 * QV * 64 * 4, stream, queue, work, models, ws, range_err, fout, out); break;
     CKM_FB_QS(X)
 #undef X
     default: return -1;

@@ -427,7 +427,7 @@ int launch_vit(int QH, uint32_t nblocks, hipStream_t stream, WorkQueue queue, co
   if (cd) c = *cd;
   switch (QH) {
     CKM_VIT_CASE(1) CKM_VIT_CASE(2) CKM_VIT_CASE(3) CKM_VIT_CASE(4) CKM_VIT_CASE(5) CKM_VIT_CASE(6) CKM_VIT_CASE(7) CKM_VIT_CASE(8)
-    CKM_VIT_CASE(10) CKM_VIT_CASE(12) CKM_VIT_CASE(14) CKM_VIT_CASE(16)
+    CKM_VIT_CASE(10) CKM_VIT_CASE(12) CKM_VIT_CASE(14) CKM_VIT_CASE(16) CKM_VIT_CASE(24) CKM_VIT_CASE(32)
     default: return -1;
   }
   return 0;

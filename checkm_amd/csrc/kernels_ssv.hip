@@ -416,8 +416,17 @@ int launch_msv(int Q, int nblocks, hipStream_t stream, const SsvBlockWork *work,
 // CKM_SSV=i16 keeps round 1's packed-integer row (2 ops per register per row); the default is the packed-half row (1.5).
 static const bool g_ssv_half = [] { const char *e = getenv("CKM_SSV"); return !(e && strcmp(e, "i16") == 0); }();
 
+// Models beyond 2048 nodes have no SSV instance (the LDS image of their emission words would not fit): Smax = 0 for all of their
+// pairs sends every one of them to the exact MSV kernel ("no cell rose above xB: recompute exactly" in msv_finish_kernel), which takes
+// any model length that fits 160 KB of LDS.  Exact, just slow -- such models are a handful of a full Pfam / TIGRFAM file.
+__global__ void ssv_none_kernel(const SsvBlockWork *__restrict__ work, uint16_t *__restrict__ maxv) {
+  const SsvBlockWork w = work[blockIdx.x];
+  for (uint32_t li = threadIdx.x; li < w.count; li += blockDim.x) maxv[w.pair_start + li] = 0;
+}
+
 int launch_ssv(int Q, int nblocks, int threads, hipStream_t stream, const SsvBlockWork *work, const DevModel *models,
                const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const uint32_t *lists, uint16_t *maxv) {
+  if (Q > 64) { if (nblocks > 0) hipLaunchKernelGGL(ssv_none_kernel, dim3(nblocks), dim3(64), 0, stream, work, maxv); return 0; }
   switch (Q) {
     CKM_SSV_CASE(1) CKM_SSV_CASE(2) CKM_SSV_CASE(3) CKM_SSV_CASE(4) CKM_SSV_CASE(5) CKM_SSV_CASE(6) CKM_SSV_CASE(7)
     CKM_SSV_CASE(8) CKM_SSV_CASE(9) CKM_SSV_CASE(10) CKM_SSV_CASE(11) CKM_SSV_CASE(12) CKM_SSV_CASE(13) CKM_SSV_CASE(14)

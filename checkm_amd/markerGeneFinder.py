@@ -364,11 +364,11 @@ def model_lists(heads, allIds, wanted, logger=None, db=''):
             models_of[b] = cache[key]
     too_long = [i for i, h in enumerate(heads) if not h.get("searchable", True)]
     if too_long:
-        # the database holds models beyond the kernels' 2048 nodes: they stay out of every bin's scan, loudly (hmmsearch would search them)
+        # the database holds models beyond the kernels' 4096 nodes: they stay out of every bin's scan, loudly (hmmsearch would search them)
         hit = sorted(set(too_long) & set(i for m in models_of.values() if m is not None for i in m)) if (models_of and all(m is not None for m in models_of.values())) else too_long
         if hit:
             if logger is not None:
-                logger.warning("%d model(s) of %s are longer than 2048 nodes and are NOT searched: %s" %
+                logger.warning("%d model(s) of %s are longer than the 4096 nodes the kernels are instantiated for and are NOT searched: %s" %
                                (len(hit), db, ", ".join("%s (LENG %d)" % (heads[i]["name"], heads[i]["leng"]) for i in hit[:8])))
             keep = [i for i in range(len(heads)) if heads[i].get("searchable", True)]
             drop, cache = set(hit), {}

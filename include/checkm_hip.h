@@ -68,7 +68,7 @@ typedef struct {
   int32_t     has_ga, has_tc, has_nc;
   double      ga[2], tc[2], nc[2];   /* float64: CheckM compares them as Python floats with text scores */
   float       evparam[6];   /* MSV mu,lambda; VITERBI mu,lambda; FORWARD tau,lambda */
-  int32_t     searchable;   /* 0: the model is longer than the kernels are instantiated for (LENG > 2048): it keeps its place in the database, but a
+  int32_t     searchable;   /* 0: the model is longer than the kernels are instantiated for (LENG > 4096; models of 2049..4096 nodes are searched, through the exact MSV kernel instead of SSV): it keeps its place in the database, but a
                                ckm_search / ckm_align that selects it fails with CKM_ERANGE naming it */
 } ckm_model_header;
 

@@ -171,65 +171,66 @@ def test_taxon_marker_file_and_phylo_pass(lineage, capsys):
     hp.close()
 
 
-def test_large_database_with_overlong_models(gpu_ctx, tmp_path):
-    """configs[4]-shaped slice: a 3000-profile database that also holds three models beyond the kernels' 2048 nodes (LENG 2049, 3000,
-    4096).  The database loads (the long models keep their place and their headers, flagged unsearchable), find() leaves them out of
-    every bin's scan with a warning, batching never runs out of memory, and two sampled bins equal the oracle row for row on a model
-    subset; a search that names a long model is refused with CKM_ERANGE."""
-    import numpy as np
-    from checkm_amd import _lib
+def test_large_database_with_long_and_overlong_models(gpu_ctx, tmp_path):
+    """configs[4]-shaped slice: a 2000+-profile database that also holds models of 2049, 3000 and 4096 nodes -- beyond the 2048 the SSV
+    kernel's LDS image holds, searched through the exact-MSV route and the Q = 48 / 64, QH = 24 / 32 kernel classes -- and one of 4500
+    nodes, beyond every class.  The database loads, the 4500-node model keeps its place and header but is flagged unsearchable and left
+    out of every bin's scan with a warning, batching never runs out of memory, the rows of the three long models and of a sample of the
+    others equal the oracle's in two bins, and a search that names the 4500-node model is refused with CKM_ERANGE by name."""
     rng = np.random.default_rng(5150)
     profs = []
-    for i in range(3000):
+    for i in range(2000):
         M = int(np.clip(np.rint(rng.lognormal(4.0, 0.5)), 20, 400))
         profs.append(synth.random_profile(rng, M, "m%05d" % i, "PF%05d.1" % (30000 + i)))
-    for k, M in enumerate((2049, 3000, 4096)):
-        profs.insert(1000 * k + 500, synth.random_profile(rng, M, "long%d" % M, "PF%05d.1" % (39000 + k)))
+    longs = {}
+    for k, M in enumerate((2049, 3000, 4096, 4500)):
+        lp = synth.random_profile(rng, M, "long%d" % M, "PF%05d.1" % (39000 + k))
+        longs[M] = lp
+        profs.insert(400 * k + 300, lp)
     for p in profs:
         p.stats = (-8.5 - 0.002 * p.M, 0.71, -9.5 - 0.002 * p.M, 0.71, -3.8, 0.71)
         p.ga = (25.0, 25.0)
     hmm = str(tmp_path / "big.hmm")
     synth.write_hmm(hmm, profs)
     prof = _lib.Profiles(gpu_ctx, hmm)
-    assert prof.n == 3003
-    long_idx = [i for i, h in enumerate(prof.headers) if not h["searchable"]]
-    assert [prof.headers[i]["leng"] for i in long_idx] == [2049, 3000, 4096]
-    short = [p for p in profs if p.M <= 400]
+    assert prof.n == 2004
+    unsearchable = [i for i, h in enumerate(prof.headers) if not h["searchable"]]
+    assert [prof.headers[i]["leng"] for i in unsearchable] == [4500]
+    searchable = [p for p in profs if p.M <= 4096]
+    long_pos = [i for i, p in enumerate(searchable) if p.M > 2048]
     files = []
-    for b in range(6):
-        planted = sorted(rng.choice(len(short), size=120, replace=False).tolist())
-        recs = sl.make_lineage_bin(short, planted, 7000 + b, n_orfs=500)
+    for b in range(4):
+        planted = sorted(set(rng.choice(len(searchable), size=80, replace=False).tolist()) | set(long_pos))
+        recs = sl.make_lineage_bin(searchable, planted, 7000 + b, n_orfs=400)
         f = str(tmp_path / ("bin%d.faa" % b))
         synth.write_fasta(f, recs)
         files.append((f, recs, planted))
-    # a search that selects a long model is refused, by name
     seqs = _lib.Seqs(gpu_ctx, [files[0][1][:20]])
     with pytest.raises(_lib.CkmError) as err:
-        _lib.search(gpu_ctx, prof, seqs, [[0, long_idx[1]]])
-    assert err.value.code != 0 and "long3000" in str(err.value)
+        _lib.search(gpu_ctx, prof, seqs, [[0, unsearchable[0]]])
+    assert err.value.code != 0 and "long4500" in str(err.value)
     seqs.close(); prof.close()
     out = str(tmp_path / "out")
     budget = mgf.PAIR_BUDGET
-    mgf.PAIR_BUDGET = 4 * 1000 * 1000                                    # several batches
+    mgf.PAIR_BUDGET = 500 * 1000                                          # several batches
     try:
         models = mgf.MarkerGeneFinder(4).find([f for f, _r, _p in files], out, DefaultValues.HMMER_TABLE_OUT, DefaultValues.HMMER_OUT, hmm, False, False, True)
     finally:
         mgf.PAIR_BUDGET = budget
-    assert all(len(m) == 3000 for m in models.values())                                     # the three long models are in no bin's view
+    assert all(len(m) == 2003 for m in models.values())                                     # the 4500-node model is in no bin's view
     hs = p7.HmmSet(hmm)
-    for b in (1, 4):
+    names = [p.name for p in searchable]
+    for b in (1, 3):
         f, recs, planted = files[b]
-        names = [p.name for p in short]
-        subset = sorted(set(planted[:25] + list(range(0, 3000, 200))))
-        chosen = set(names[j] for j in subset)
+        chosen = set(names[j] for j in sorted(set(planted[:20] + list(range(0, 2000, 150)) + long_pos)))
         idx = [i for i in range(hs.n) if hs.name(i) in chosen]
         rows = common.oracle_search_threaded(hs, idx, [p7.digitize(r[2]) for r in recs], [r[0] for r in recs])
         want = hs.format_domtblout(rows, [r[0] for r in recs], [r[1] for r in recs])
-        wanted_names = set(hs.name(i) for i in idx)
-        got = [l for l in open(os.path.join(out, "bins", "bin%d" % b, DefaultValues.HMMER_TABLE_OUT)) if not l.startswith("#") and l.split()[3] in wanted_names]
-        ref = [l for l in want.split("\n") if l and not l.startswith("#")]
+        got = [l for l in open(os.path.join(out, "bins", "bin%d" % b, DefaultValues.HMMER_TABLE_OUT)) if not l.startswith("#") and l.split()[3] in chosen]
+        ref = [l + "\n" for l in want.split("\n") if l and not l.startswith("#")]
         key = lambda l: (l.split()[3], l.split()[0], int(l.split()[9]))
         # (E-values depend on Z = sequences of the bin, the same on both sides; domZ per model likewise)
-        assert sorted(got, key=key) == sorted((l + "\n" for l in ref), key=key) and len(ref) >= 20
+        assert sorted(got, key=key) == sorted(ref, key=key) and len(ref) >= 20
+        assert sum(1 for l in ref if l.split()[3].startswith("long")) >= 3                 # each long model finds its planted ORF
     hs.close()
     mgf.release_scan()
