@@ -251,7 +251,7 @@ def lineage_pass(w, binIds, files, lin, out, rank):
     rp.printSummary(1, None, sets, False, None, True, os.path.join(out, "qa_table.tsv") if rank == 0 else None, None)
     t3 = time.perf_counter()
     del rp, sets, models                 # (hit lists nobody looked at need not be filled in before the scan is released)
-    mgf.release_scan(out)
+    mgf.release_scan(out, background=True)          # (the device memory of the scans is returned by a helper thread while the next pass starts)
     return {"tree_find_s": t1 - t0, "analyze_find_s": t2 - t1, "qa_s": t3 - t2, "total_s": t3 - t0}, tot
 
 

@@ -45,22 +45,43 @@ def profiles_for(ctx, db):
     return p
 
 
-def release_scan(outDir=None, final=False):
+_RELEASERS = []
+
+
+def _join_releasers():
+    while _RELEASERS:
+        _RELEASERS.pop().join()
+
+
+def release_scan(outDir=None, final=False, background=False):
     """Free cached device objects (all, or those of one output directory).  Profile databases stay resident until everything is
     released (release_scan() without an argument).  Hit lists ResultsParser handed out lazily are filled in first (not at interpreter
-    exit: final=True)."""
+    exit: final=True).  background=True frees the hits and sequences on a helper thread (hipFree waits for the device: 0.3 s for a
+    thousand bins' scans) -- the next find() or release waits for it."""
+    _join_releasers()
     if SCAN_CACHE and not final:
         mod = sys.modules.get("checkm_amd.resultsParser")
         if mod is not None:
             mod.materialize_lazy_hits()
-    pools = []
+    pools, doomed = [], []
     for key in list(SCAN_CACHE):
         if outDir is None or key[0] == os.path.abspath(outDir):
             ent = SCAN_CACHE.pop(key)
             for part in ent["parts"]:
-                part["hits"].close(); part["seqs"].close()
+                doomed.append(part["hits"]); doomed.append(part["seqs"])
             if ent.get("pool") is not None and ent["pool"] not in pools:
                 pools.append(ent["pool"])
+
+    def free():
+        for obj in doomed:
+            obj.close()
+    if background and doomed and outDir is not None and not final:
+        import threading
+        t = threading.Thread(target=free, daemon=True)
+        t.start()
+        _RELEASERS.append(t)
+    else:
+        free()
     for pool in pools:                            # the workers hold the resident scans of a multi-GPU find()
         try:
             if not final:
@@ -145,9 +166,14 @@ class MarkerGeneFinder(object):
                 todo.append((binFile, binDir, binId, dst))
             binIds.append(binId)
             faa.append(dst)
+        self._pending_copies, self._copy_pool = [], None
+        read_from = list(faa)                    # the file each bin's scan reads
         if copies:
-            # called genes (-g) are copied in, as the reference does per bin (markerGeneFinder.py:118-127) -- on a few host threads: a
-            # thousand bins are a gigabyte of protein text, and both passes of lineage_wf copy it
+            # called genes (-g) are copied in, as the reference does per bin (markerGeneFinder.py:118-127) -- a thousand bins are a gigabyte
+            # of protein text, and both passes of lineage_wf copy it.  Plain files are copied by host threads WHILE the scan reads the
+            # source (same bytes); find() waits for the copies before it returns.  Compressed files are unpacked first, as before.
+            from concurrent.futures import ThreadPoolExecutor
+
             def copy_in(job):
                 src, dst = job
                 if src.endswith('.gz'):
@@ -155,12 +181,16 @@ class MarkerGeneFinder(object):
                         shutil.copyfileobj(fin, fout)
                 else:
                     shutil.copyfile(src, dst)
-            if len(copies) == 1:
-                copy_in(copies[0])
-            else:
-                from concurrent.futures import ThreadPoolExecutor
-                with ThreadPoolExecutor(max_workers=min(8, len(copies))) as pool:
-                    list(pool.map(copy_in, copies))
+            packed = [j for j in copies if j[0].endswith('.gz')]
+            plain = [j for j in copies if not j[0].endswith('.gz')]
+            if packed:
+                with ThreadPoolExecutor(max_workers=min(8, len(packed))) as pool:
+                    list(pool.map(copy_in, packed))
+            if plain:
+                self._copy_pool = ThreadPoolExecutor(max_workers=min(4, len(plain)))
+                self._pending_copies = [self._copy_pool.submit(copy_in, j) for j in plain]
+                src_of = {dst: src for src, dst in plain}
+                read_from = [src_of.get(f, f) for f in faa]
         if todo:
             runner = gene_caller()
             missing = [t for t in todo if runner is None and not os.path.exists(t[3])]
@@ -183,7 +213,7 @@ class MarkerGeneFinder(object):
                 for t, aa in zip(todo, called):
                     if os.path.abspath(aa) != os.path.abspath(t[3]):
                         shutil.copyfile(aa, t[3])
-        return binIds, faa
+        return binIds, faa, read_from
 
     def find(self, binFiles, outDir, tableOut, hmmerOut, markerFile, bKeepAlignment, bNucORFs, bCalledGenes):
         """checkm/markerGeneFinder.py:45-96.  One process per GPU: under torchrun (WORLD_SIZE > 1) every rank calls find() with the
@@ -230,8 +260,8 @@ class MarkerGeneFinder(object):
                 wts.append(sz * max(1, nm))
             mine = cdist.shard_bins(wts, world)[rank]
         myFiles = [binFiles[i] for i in mine]
-        binIds, faa = self._geneFiles(myFiles, outDir, bNucORFs, bCalledGenes)
-        sizes = [os.path.getsize(f) if os.path.exists(f) else 0 for f in faa]
+        binIds, faa, read_from = self._geneFiles(myFiles, outDir, bNucORFs, bCalledGenes)
+        sizes = [os.path.getsize(f) if os.path.exists(f) else 0 for f in read_from]
         nmod = [len(models_of[b]) if models_of.get(b) is not None else profiles.n for b in binIds]
         batches = plan_batches(sizes, nmod)
         parts, where, totals = [None] * len(batches), {}, {}
@@ -272,7 +302,7 @@ class MarkerGeneFinder(object):
             c, prof = lanes[k % len(lanes)]
             batch = batches[k]
             t0 = _t.perf_counter()
-            seqs = _lib.Seqs.from_fasta(c, [faa[i] for i in batch])               # read, digitized and packed by the library
+            seqs = _lib.Seqs.from_fasta(c, [read_from[i] for i in batch])         # read, digitized and packed by the library
             t1 = _t.perf_counter()
             bm = None if not models_of else [models_of[binIds[i]] if models_of[binIds[i]] is not None else list(range(profiles.n)) for i in batch]
             hits = _lib.search(c, prof, seqs, bm, 0.1, 0.1)                       # -E 0.1 --domE 0.1, markerGeneFinder.py:141
@@ -309,6 +339,12 @@ class MarkerGeneFinder(object):
         except _lib.CkmError as e:
             self.logger.error('marker-gene scan failed: %s' % e)
             sys.exit(1)
+        finally:
+            for f in self._pending_copies:           # bins/<binId>/genes.faa is complete before find() returns
+                f.result()
+            if self._copy_pool is not None:
+                self._copy_pool.shutdown()
+            self._pending_copies, self._copy_pool = [], None
         for k, batch in enumerate(batches):
             for b, i in enumerate(batch):
                 where[binIds[i]] = (k, b)

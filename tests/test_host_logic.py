@@ -136,7 +136,11 @@ def test_gene_files_step_of_find(tmp_path, monkeypatch):
     with gzip.open(tmp_path / "b.faa.gz", "wt") as f:
         f.write(">h_1\nMAA*\n")
     finder = mgf.MarkerGeneFinder(3)
-    ids, faa = finder._geneFiles([str(prot), str(tmp_path / "b.faa.gz")], str(out), False, True)
+    ids, faa, read_from = finder._geneFiles([str(prot), str(tmp_path / "b.faa.gz")], str(out), False, True)
+    # the plain file is copied in the background while the scan reads the source; the compressed one is unpacked first
+    assert read_from == [str(prot), faa[1]]
+    for f in finder._pending_copies:
+        f.result()
     assert ids == ["a", "b"] and [open(p).read() for p in faa] == [">g_1\nMKV*\n", ">h_1\nMAA*\n"]
 
     calls = []
@@ -157,7 +161,7 @@ def test_gene_files_step_of_find(tmp_path, monkeypatch):
     for p in nuc:
         p.write_text(">c\nACGT\n")
     monkeypatch.setattr(mgf, "GENE_CALLER", FakeProdigal)
-    ids, faa = finder._geneFiles([str(p) for p in nuc], str(out), True, False)
+    ids, faa, _read = finder._geneFiles([str(p) for p in nuc], str(out), True, False)
     assert ids == ["n%d" % i for i in range(5)] and sorted(calls) == [("n%d.fna" % i, True) for i in range(5)]
     assert open(faa[3]).read() == ">n3.fna_1\nMSS*\n"
     del calls[:]
