@@ -165,8 +165,8 @@ def ssv_roofline(st_like, ssv_ms_per_step, bins, orfs, extra_note=""):
     ssv_s = max(ssv_ms_per_step, 1e-9) / 1e3
     achieved = alg_bytes / ssv_s / 1e9
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "algorithmic_bytes": alg_bytes, "kernel": "ssv_kernel<Q>", "ms_per_step_kernel": ssv_ms_per_step,
-            "note": "the kernel is VALU-issue-bound by design (SURVEY H3), not HBM-bound: see roofline_valu and gcups_ssv" + extra_note}
+            "algorithmic_bytes": alg_bytes, "kernel": "ssv_kernel_h<Q>", "ms_per_step_kernel": ssv_ms_per_step,
+            "note": "the kernel is VALU-issue-bound by design (SURVEY H3), not HBM-bound: see roofline_valu / step_utilisation" + extra_note}
     valu = None
     tf = None
     import glob
@@ -602,6 +602,7 @@ def cfg3_counters(alg_bytes):
     k = alg_bytes / float(pm["algorithmic_bytes"])
     return {"source": os.path.relpath(found[-1], ROOT), "sample": pm.get("config"), "scale": k,
             "hbm_bytes": pm["hbm_bytes_corrected"] * k, "valu_insts": pm["valu_insts"] * k,
+            "all_valu_insts": pm["all_kernels"]["valu_insts"] * k, "all_hbm_bytes": pm["all_kernels"]["hbm_bytes_corrected"] * k,
             "traffic_over_algorithmic": pm["hbm_bytes_corrected"] / float(pm["algorithmic_bytes"])}
 
 
@@ -761,8 +762,15 @@ def bench_cfg3(args, env):
         cyc = (tot.get("ms_ssv", 0.0) / 1e3) * 2.4e9 / (cnt["valu_insts"] / 1024.0)
         valu = {"bound": "valu-issue", "wave_insts_per_step": cnt["valu_insts"], "source": cnt["source"] + " (--pmc SQ_INSTS_VALU pass of the sample, scaled)",
                 "cycles_per_inst_per_simd": cyc, "measured_rate_of_this_opcode_mix": MEASURED_CYCLES_PER_INST, "frac_of_measured_rate": min(1.0, MEASURED_CYCLES_PER_INST / cyc),
-                "note": "time = HIP events over the SSV launches of this run, which share the SIMDs with the chain kernels of the groups ahead of them; the rate is what "
+                "note": "time = HIP events over the SSV launches of every search of this run, SUMMED: the two scan lanes' SSV phases overlap in time (the sum can exceed the step) and "
+                        "share the SIMDs with the chain kernels of the groups ahead of them -- step_utilisation prices the whole step instead; the rate is what "
                         "tools/ubench/valu_rates.hip measures for the row body of the kernel alone (profiles/%s_valu_rates.txt), not an architectural peak" % PROFILE_TAG}
+    if cnt is not None:
+        # the whole step against the device: every kernel's VALU instructions (scaled from the sample's PMC passes) over the step's wall time
+        cyc = per_step * 2.4e9 / (cnt["all_valu_insts"] / 1024.0)
+        step_util = {"valu_wave_insts_per_step": cnt["all_valu_insts"], "cycles_per_inst_per_simd": cyc, "valu_frac_of_measured_rate": min(1.0, MEASURED_CYCLES_PER_INST / cyc),
+                     "hbm_bytes_per_step": cnt["all_hbm_bytes"], "hbm_frac": cnt["all_hbm_bytes"] / per_step / 1e9 / HBM_PEAK_GBS,
+                     "source": cnt["source"] + " (all kernels of the 48-bin sample's step, scaled by algorithmic bytes) over this run's ms_per_step"}
     out = {"metric": "bins/hour (lineage_wf-equiv marker path: tree pass + analyze pass + qa, from genes.faa files) + residues*HMMs/s",
            "value": nbins / per_step * 3600.0, "unit": "bins/hour", "n_gpus": world, "steps": steps, "steps_requested": args.steps, "warmup": args.warmup,
            "ms_per_step": per_step * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -776,7 +784,7 @@ def bench_cfg3(args, env):
            "residue_hmm_per_s": residue_hmm / per_step, "residue_hmm_per_step": residue_hmm,
            "first_pass_s": first_pass_s, "first_pass_bins": warm, "second_pass_s_same_bins": second_pass_s if second_pass_s > 0 else None,
            "first_pass_overhead_s": (first_pass_s - second_pass_s) if second_pass_s > 0 else None,
-           "parts_s_rank0": parts, "roofline": roof, "roofline_valu": valu, "stage_pairs": stage_pairs(tot), "ssv_ms_max_rank": ssv_ms,
+           "parts_s_rank0": parts, "roofline": roof, "roofline_valu": valu, "step_utilisation": step_util, "stage_pairs": stage_pairs(tot), "ssv_ms_max_rank": ssv_ms,
            "gpu_host_split_s_rank0": {"ssv_kernels": tot.get("ms_ssv", 0.0) / 1e3, "search_calls_sum": tot.get("ms_total", 0.0) / 1e3,
                                       "ingest": tot.get("ingest_s", 0.0), "search": tot.get("search_s", 0.0), "write": tot.get("write_s", 0.0),
                                       "tree_find": parts["tree_find_s"], "analyze_find": parts["analyze_find_s"], "qa": parts["qa_s"],
