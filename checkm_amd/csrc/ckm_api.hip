@@ -165,11 +165,11 @@ extern "C" int ckm_profiles_load(ckm_ctx *ctx, const char *hmm_path, ckm_profile
       for (size_t i = 0; i < n; ++i) if (errs[i]) throw Error(*errs[i]);
     }
     Arena ar;
-    struct Off { size_t ssv, ssvh, rbv, vit_e, vit_t, rf, ftr; };
+    struct Off { size_t ssv, ssvh, rbv, vit_e, vit_t, rf, ftr, v16e, v16t; };
     std::vector<Off> off(n);
     for (size_t i = 0; i < n; ++i) {
       const HostProfile &hp = p->prof[i];
-      off[i] = Off{ar.add(hp.ssv_tbl), ar.add(hp.ssv_tbl_h), ar.add(hp.rbv), ar.add(hp.vit_e), ar.add(hp.vit_t), ar.add(hp.rf), ar.add(hp.ftr)};
+      off[i] = Off{ar.add(hp.ssv_tbl), ar.add(hp.ssv_tbl_h), ar.add(hp.rbv), ar.add(hp.vit_e), ar.add(hp.vit_t), ar.add(hp.rf), ar.add(hp.ftr), ar.add(hp.vit16_e), ar.add(hp.vit16_t)};
     }
     std::unique_ptr<DevBuf> tables(new DevBuf());
     tables->ensure(std::max<size_t>(256, ar.host.size()));
@@ -182,7 +182,8 @@ extern "C" int ckm_profiles_load(ckm_ctx *ctx, const char *hmm_path, ckm_profile
       DevModel d;
       memset(&d, 0, sizeof(d));
       d.M = hp.M; d.ssvQ = hp.ssvQ; d.fbQ = hp.fbQ; d.vitQH = hp.vitQH;
-      d.fb_cls = fb_class_id(hp.fbQ); d.vit_cls = vit_class_id(hp.vitQH);
+      d.fb_cls = fb_class_id(hp.fbQ); d.vitx_cls = vit_class_id(hp.vitQH); d.vit16Q = hp.vit16Q;
+      d.vit_cls = hp.vit16Q ? vit16_class_id(hp.vit16Q) : d.vitx_cls;      // short models take the 16-lane FAST kernel
       if (!p->too_long[i] && (d.fb_cls < 0 || d.vit_cls < 0)) throw Error(CKM_ERANGE, "model " + h.name + " is longer than the instantiated kernel classes (DESIGN.md limits)");
       d.base_b = hp.base_b; d.bias_b = hp.bias_b; d.tbm_b = hp.tbm_b; d.tec_b = hp.tec_b; d.scale_b = hp.scale_b;
       d.scale_w = hp.scale_w; d.base_w = hp.base_w; d.wE_loop = hp.wE_loop; d.wE_move = hp.wE_move;
@@ -194,6 +195,7 @@ extern "C" int ckm_profiles_load(ckm_ctx *ctx, const char *hmm_path, ckm_profile
       d.rbv = base + off[i].rbv; d.vit_e = reinterpret_cast<const uint32_t *>(base + off[i].vit_e);
       d.vit_t = reinterpret_cast<const uint32_t *>(base + off[i].vit_t); d.rf = reinterpret_cast<const float *>(base + off[i].rf);
       d.ftr = reinterpret_cast<const float *>(base + off[i].ftr);
+      d.vit16_e = reinterpret_cast<const uint32_t *>(base + off[i].v16e); d.vit16_t = reinterpret_cast<const uint32_t *>(base + off[i].v16t);
       p->dm.push_back(d);
       if (!p->too_long[i]) p->maxMp = std::max(p->maxMp, hp.fbQ * NL);
     }

@@ -39,6 +39,8 @@ void launch_msv_full(hipStream_t stream, uint32_t nblocks, WorkQueue queue, cons
                      const CascadeDev *cd /* null: scores only */);
 void launch_bias(hipStream_t stream, PairRec *pairs, uint32_t npairs, const DevModel *models, const LenEntry *lentab,
                  const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, float *raw);
+int launch_vit16(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const PairRec *pairs, const DevModel *models, const LenEntry *lentab,
+                 const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const CascadeDev &cd);
 int launch_vit(int QH, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const PairRec *pairs, const DevModel *models,
                const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xC, float *out_sc,
                uint32_t *out_flag, bool fast, const CascadeDev *cd /* null: scores only */);
@@ -131,10 +133,12 @@ struct Worker {
 };
 
 // register classes of the Viterbi-filter and Forward/Backward kernels, in queue order (DevModel::vit_cls / fb_cls index these)
-constexpr int kVitQH[ckm::NVC] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 24, 32};
+constexpr int kVitQH[ckm::NVW] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 24, 32};
+constexpr int kVit16Q[ckm::NV16] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16};
 constexpr int kFbQ[ckm::NFC] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
 constexpr int kSsvNone = 65;          // "SSV class" of a model beyond the 2048 nodes the SSV kernel's LDS image holds: every pair goes to the exact MSV kernel
-inline int vit_class_id(int QH) { for (int i = 0; i < ckm::NVC; ++i) if (kVitQH[i] == QH) return i; return -1; }
+inline int vit_class_id(int QH) { for (int i = 0; i < ckm::NVW; ++i) if (kVitQH[i] == QH) return ckm::NV16 + i; return -1; }
+inline int vit16_class_id(int Q16) { for (int i = 0; i < ckm::NV16; ++i) if (kVit16Q[i] == Q16) return i; return -1; }
 inline int fb_class_id(int Q) { for (int i = 0; i < ckm::NFC; ++i) if (kFbQ[i] == Q) return i; return -1; }
 
 constexpr int NWORKERS = 8;          // upper bound; CKM_WORKERS (default 3) selects how many a large search uses

@@ -51,6 +51,8 @@ struct HostProfile {
   // Viterbi filter (signed words, 1/500 bit); contiguous k, padded to vitQ*64
   int vitQH = 0;                  // packed registers per lane: lane z owns cells z*2QH.., register j = (cell j, cell j+QH)
   float scale_w = 0; int base_w = 12000; int wE_loop = 0, wE_move = 0;
+  int vit16Q = 0;                 // 16-lane striping (four pairs per wavefront): packed registers per lane, 0 for models beyond 512 nodes
+  std::vector<uint32_t> vit16_e, vit16_t;   // [NROWS][vit16Q][16], [8][vit16Q][16]
   std::vector<uint32_t> vit_e;    // [NROWS][vitQH][64]
   std::vector<uint32_t> vit_t;    // [8][vitQH][64]: BM MM IM DM (into k) MD MI II DD (from k)
   // Forward/Backward odds, canonical padded layout (fbQ*64)

@@ -616,7 +616,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
         for (uint32_t b : model_bins[mw.model]) np += cut[part + 1][b] - cut[part][b];
         auto it = at.find(part * 1000 + p->prof[mw.model].ssvQ);
         if (it == at.end()) continue;                         // (no sequence of this part in the model's bins)
-        Sub &sb = subs[it->second]; sb.pairs += np; sb.vit[p->dm[mw.model].vit_cls] = true; sb.fb[p->dm[mw.model].fb_cls] = true; sb.maxM = std::max(sb.maxM, p->prof[mw.model].M);
+        Sub &sb = subs[it->second]; sb.pairs += np; sb.vit[p->dm[mw.model].vit_cls] = true; sb.vit[p->dm[mw.model].vitx_cls] = true; sb.fb[p->dm[mw.model].fb_cls] = true; sb.maxM = std::max(sb.maxM, p->prof[mw.model].M);
       }
     }
   }
@@ -757,10 +757,15 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
       if (stop >= 2) launch_msv_full(sc, GRID_MSV, WorkQueue{nullptr, cnt + CC_NORES, sb.cap_nores}, nores, dm, lt, res, off, dlen, nullptr, nullptr, std::max(64, sb.maxM) /* sized to the group's longest model: a small LDS image, many pairs per CU */, &cd);
       if (stop >= 3) launch_bias_filter(sc, GRID_MSV, cd, dm, lt, res, off);
       int rc = 0;
-      for (int c = NVC - 1; c >= 0; --c) if (sb.vit[c]) {
-        if (stop >= 4) rc |= launch_vit(kVitQH[c], GRID_VIT, sc, WorkQueue{cd.vq + (size_t)c * cd.cap_vq, cnt + CC_VQ + c, cd.cap_vq}, cd.cand, dm, lt, res, off, dlen, nullptr, nullptr, nullptr, true, &cd);
-        if (stop >= 5) rc |= launch_vit(kVitQH[c], std::max(64u, GRID_VIT / 4), sc, WorkQueue{cd.vxq + (size_t)c * cd.cap_vq, cnt + CC_VXQ + c, cd.cap_vq}, cd.cand, dm, lt, res, off, dlen, nullptr, nullptr, nullptr, false, &cd);
+      // FAST filter of every class first (short models: four pairs per wavefront on 16 lanes each), then the exact kernel for the pairs
+      // whose bound did not decide -- those of the 16-lane classes join the wave-per-pair queue of their model's class
+      for (int c = NVC - 1; c >= 0; --c) if (sb.vit[c] && stop >= 4) {
+        const WorkQueue qv{cd.vq + (size_t)c * cd.cap_vq, cnt + CC_VQ + c, cd.cap_vq};
+        if (c < NV16) rc |= launch_vit16(kVit16Q[c], GRID_VIT, sc, qv, cd.cand, dm, lt, res, off, dlen, cd);
+        else rc |= launch_vit(kVitQH[c - NV16], GRID_VIT, sc, qv, cd.cand, dm, lt, res, off, dlen, nullptr, nullptr, nullptr, true, &cd);
       }
+      for (int c = NVC - 1; c >= NV16; --c) if (sb.vit[c] && stop >= 5)
+        rc |= launch_vit(kVitQH[c - NV16], std::max(64u, GRID_VIT / 4), sc, WorkQueue{cd.vxq + (size_t)c * cd.cap_vq, cnt + CC_VXQ + c, cd.cap_vq}, cd.cand, dm, lt, res, off, dlen, nullptr, nullptr, nullptr, false, &cd);
       for (int c = NFC - 1; c >= 0; --c) if (sb.fb[c]) {
         const int Q = kFbQ[c];
         const WorkQueue qf{cd.fq + (size_t)c * sb.cap_f, cnt + CC_FQ + c, sb.cap_f}, qb{cd.bq + (size_t)c * sb.cap_f, cnt + CC_BQ + c, sb.cap_f};

@@ -6,7 +6,8 @@ namespace ckm {
 
 struct DevModel {
   int32_t M, ssvQ, fbQ, vitQH;
-  int32_t fb_cls, vit_cls;  // index of fbQ / vitQH among the instantiated register classes (queues of the device-driven cascade)
+  int32_t fb_cls, vit_cls;  // index of fbQ / of the FAST Viterbi kernel's class among the instantiated classes (queues of the device-driven cascade)
+  int32_t vitx_cls, vit16Q; // class of the EXACT Viterbi kernel (always the wave-per-pair kernel); packed registers per lane of the 16-lane kernel (0: none)
   // MSV
   int32_t base_b, bias_b, tbm_b, tec_b;
   float   scale_b;
@@ -25,6 +26,8 @@ struct DevModel {
   const uint8_t *rbv;       // [29][M+1]
   const uint32_t *vit_e;    // [30][vitQH][64] packed emission words (cell j | cell j+QH of each lane)
   const uint32_t *vit_t;    // [8][vitQH][64]  packed transition words: BM MM IM DM (into) MD MI II DD (from)
+  const uint32_t *vit16_e;  // [30][vit16Q][16] the same words striped over 16 lanes (models of <= 512 nodes: four pairs per wavefront)
+  const uint32_t *vit16_t;  // [8][vit16Q][16]
   const float   *rf;        // [30][Mp]
   const float   *ftr;       // [8][Mp]
 };
@@ -100,7 +103,9 @@ struct FinishArgs {
 };
 
 // ---- device-driven cascade (ckm_cascade.hip, kernels_*.hip epilogues) ---------------------------------------------------------
-constexpr int NVC = 14;               // Viterbi-filter register classes  QH in {1,2,3,4,5,6,7,8,10,12,14,16, 24,32}   (24, 32: models of 2049..4096 nodes)
+constexpr int NV16 = 12;              // Viterbi filter, 16 lanes per pair: packed registers per lane Q16 in {1,2,3,4,5,6,7,8,10,12,14,16} (models of <= 512 nodes)
+constexpr int NVW = 14;               // Viterbi filter, wavefront per pair: QH in {1,2,3,4,5,6,7,8,10,12,14,16, 24,32}   (24, 32: models of 2049..4096 nodes)
+constexpr int NVC = NV16 + NVW;       // queue classes: the 16-lane classes first, then the wave classes
 constexpr int NFC = 12;               // Forward/Backward register classes Q in {1,2,3,4,6,8,12,16,24,32, 48,64}
 
 enum CascadeCounter : int {           // uint32 counters in device memory (count and head arrays share this layout)

@@ -428,6 +428,19 @@ HostProfile configure_profile(const HostHMM &h) {
       for (int j = 0; j < QH; ++j)
         for (int z = 0; z < NL; ++z)
           p.vit_t[((size_t)w * QH + j) * NL + z] = pack(trans(w, z * CELLS + j), trans(w, z * CELLS + j + QH));
+    // the same words striped over 16 lanes (lane z owns cells z*2Q .. z*2Q+2Q-1, register j = (cell j, cell j+Q) of the lane)
+    p.vit16Q = 0;
+    static const int kVit16Q[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16};
+    for (int q : kVit16Q) if (q * 32 >= M) { p.vit16Q = q; break; }
+    if (p.vit16Q) {
+      const int Q = p.vit16Q, C16 = 2 * Q;
+      p.vit16_e.assign((size_t)NROWS * Q * 16, pack(-32768, -32768));
+      for (int x = 0; x < KP; ++x) for (int j = 0; j < Q; ++j) for (int z = 0; z < 16; ++z)
+        p.vit16_e[((size_t)x * Q + j) * 16 + z] = pack(emis(x, z * C16 + j), emis(x, z * C16 + j + Q));
+      p.vit16_t.assign((size_t)8 * Q * 16, pack(-32768, -32768));
+      for (int w = 0; w < 8; ++w) for (int j = 0; j < Q; ++j) for (int z = 0; z < 16; ++z)
+        p.vit16_t[((size_t)w * Q + j) * 16 + z] = pack(trans(w, z * C16 + j), trans(w, z * C16 + j + Q));
+    }
     p.wE_loop = word_score(p.scale_w, (float)(-kLn2));
     p.wE_move = word_score(p.scale_w, (float)(-kLn2));
   }

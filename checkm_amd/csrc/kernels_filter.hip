@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(128) bias_filter_kernel(CascadeDev cd, const D
     if (!(sc >= md.thr_msv_f1 - cd.margin_msv)) { cd.route[pi] = 0xffu; continue; }              // dead
     if (sc >= md.thr_msv_f2 + cd.margin_msv) { cd.route[pi] = 0; pass_to_forward(cd, md, pi, pr.model, pr.seq); continue; }
     if (sc < md.thr_msv_f2 - cd.margin_msv) { route = 1; queue_push(cd, cd.vq, CC_VQ, md.vit_cls, cd.cap_vq, pi, (uint32_t)CS_VQ); }
-    else { route = 2 | 0x10; queue_push(cd, cd.vxq, CC_VXQ, md.vit_cls, cd.cap_vq, pi, (uint32_t)CS_VQ); }
+    else { route = 2 | 0x10; queue_push(cd, cd.vxq, CC_VXQ, md.vitx_cls, cd.cap_vq, pi, (uint32_t)CS_VQ); }
     cd.route[pi] = route;
   }
 }
@@ -404,7 +404,7 @@ __global__ void __launch_bounds__(256) vit_kernel(WorkQueue queue, const PairRec
       if (FAST) {
         cd.vit_fast[pi] = vsc; cd.vit_flag[pi] = flag;
         if (v >= md.thr_vit_f2 + cd.margin_vit) pass_to_forward(cd, md, pi, pr.model, pr.seq);
-        else if (flag) { cd.route[pi] = 2; queue_push(cd, cd.vxq, CC_VXQ, md.vit_cls, cd.cap_vq, pi, (uint32_t)CS_VQ); }
+        else if (flag) { cd.route[pi] = 2; queue_push(cd, cd.vxq, CC_VXQ, md.vitx_cls, cd.cap_vq, pi, (uint32_t)CS_VQ); }
         else if (v >= md.thr_vit_f2 - cd.margin_vit) pass_to_forward(cd, md, pi, pr.model, pr.seq);
       } else {
         cd.vit_exact[pi] = vsc;
@@ -413,6 +413,141 @@ __global__ void __launch_bounds__(256) vit_kernel(WorkQueue queue, const PairRec
     }
   }
  }
+}
+
+// --------------------------------------------------------------------------------------------
+// The FAST Viterbi filter on 16 lanes per pair, FOUR pairs per wavefront (round 3): a model of cfg3's median length (190 nodes) fills 74 % of
+// the 128 stripes a wavefront holds and pays the per-row fixed part alone; here it takes 32 stripes of Q cells (lane z of a DPP row
+// owns cells z*2Q .. z*2Q+2Q-1, register j = (cell j, cell j+Q): M <= 32 Q <= 512) and four pairs share every instruction.  Same word
+// arithmetic, so the same score whatever the layout.  The four pairs of a wavefront are independent (own model, own sequence, own
+// tables: per-lane pointers); rows run to the longest of the four sequences, a pair that has ended reads the all-impossible pad symbol
+// (its running maximum no longer moves) -- the queue is close to length-sorted, because the SSV blocks it descends from run longest
+// slices first.  stripe moves are row_shr:1 inside the DPP row (lane 0 of a row has no predecessor and keeps -32768).
+// Only the device-driven cascade uses it (decide): pairs whose bound needs the exact kernel go to the wave-per-pair queue of their model.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 stripe_shift16(u32 v, u32 &hold) {
+  hold = (u32)__builtin_amdgcn_update_dpp((int)hold, (int)v, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+  return __builtin_amdgcn_alignbit(v, hold, 16);
+}
+
+template <int Q>
+__global__ void __launch_bounds__(256) vit16_kernel(WorkQueue queue, const PairRec *__restrict__ pairs, const DevModel *__restrict__ models,
+                                                    const LenEntry *__restrict__ lentab, const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
+                                                    const int32_t *__restrict__ seq_len, CascadeDev cd) {
+  const int lane = threadIdx.x & 63, z = lane & 15, g = lane >> 4;
+  constexpr int ROW = Q * 16;                       // u32 words per table row
+  const uint32_t nqueue = queue_len(queue);
+  for (uint32_t q4 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); q4 * 4u < nqueue; q4 += gridDim.x * (blockDim.x >> 6)) {
+    const uint32_t qk = q4 * 4u + (uint32_t)g;
+    const bool valid = qk < nqueue;
+    const uint32_t pi = queue.list[valid ? qk : q4 * 4u];          // (a group beyond the queue's end repeats the wavefront's first pair and reports nothing)
+    const PairRec pr = pairs[pi];
+    const DevModel &md = models[pr.model];
+    const int L = seq_len[pr.seq];
+    int Lmax = __builtin_amdgcn_readlane(L, 0);
+    Lmax = max(Lmax, __builtin_amdgcn_readlane(L, 16));
+    Lmax = max(Lmax, __builtin_amdgcn_readlane(L, 32));
+    Lmax = max(Lmax, __builtin_amdgcn_readlane(L, 48));
+    const uint8_t *rp = res + seq_off[pr.seq];
+    const LenEntry le = lentab[L];
+    u32 tBM[Q], tMM[Q], tIM[Q], tDM[Q], tMD[Q], tMI[Q], tII[Q], tDD[Q];
+    {
+      const gp<u32> t = gptr(md.vit16_t) + z;
+#pragma unroll
+      for (int j = 0; j < Q; ++j) {
+        tBM[j] = t[0 * ROW + j * 16]; tMM[j] = t[1 * ROW + j * 16]; tIM[j] = t[2 * ROW + j * 16]; tDM[j] = t[3 * ROW + j * 16];
+        tMD[j] = t[4 * ROW + j * 16]; tMI[j] = t[5 * ROW + j * 16]; tII[j] = t[6 * ROW + j * 16]; tDD[j] = t[7 * ROW + j * 16];
+      }
+    }
+    u32 Mv[Q], Iv[Q], Dv[Q];
+#pragma unroll
+    for (int j = 0; j < Q; ++j) Mv[j] = Iv[j] = Dv[j] = NEG2;
+    const int xN = md.base_w, xB = xN + le.w_move;
+    const u32 xBv = ((u32)(xB & 0xffff)) * 0x10001u;
+    u32 xEv = NEG2;
+    const gp<u32> vit_e = gptr(md.vit16_e) + z;
+    // residues four at a time (sequences are 16-byte aligned); rows beyond the pair's own length read the pad symbol
+    auto sym = [&](u32 word, int i) -> u32 { return (i < L) ? ((word >> (8 * (i & 3))) & 0xffu) : 29u; };
+    u32 rw = *reinterpret_cast<const u32 *>(rp);
+    u32 e[Q], e2[Q];
+    {
+      const gp<u32> er = vit_e + (size_t)sym(rw, 0) * ROW;
+#pragma unroll
+      for (int j = 0; j < Q; ++j) e[j] = er[j * 16];
+    }
+    u32 hm = NEG2, hi = NEG2, hd = NEG2, hc = NEG2;
+    auto row = [&](int i, u32 (&ec)[Q], u32 (&en)[Q]) {
+      {
+        const int i1 = i + 1;
+        if ((i1 & 3) == 0 && i1 < L) rw = *reinterpret_cast<const u32 *>(rp + i1);      // (i1 < L: never reads past the pair's own sequence)
+        const gp<u32> er = vit_e + (size_t)sym(rw, i1) * ROW;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) en[j] = er[j * 16];
+      }
+      const u32 ms0 = stripe_shift16(Mv[Q - 1], hm), is0 = stripe_shift16(Iv[Q - 1], hi), ds0 = stripe_shift16(Dv[Q - 1], hd);
+      u32 mdv[Q];
+#pragma unroll
+      for (int j = Q - 1; j >= 0; --j) {
+        const u32 mp = j ? Mv[j - 1] : ms0, ip = j ? Iv[j - 1] : is0, dp = j ? Dv[j - 1] : ds0;
+        u32 sv = pk_adds(xBv, tBM[j]);
+        sv = pk_max(sv, pk_adds(mp, tMM[j]));
+        sv = pk_max(sv, pk_adds(ip, tIM[j]));
+        sv = pk_max(sv, pk_adds(dp, tDM[j]));
+        sv = pk_adds(sv, ec[j]);
+        const u32 ni = pk_max(pk_adds(Mv[j], tMI[j]), pk_adds(Iv[j], tII[j]));
+        Iv[j] = ni; Mv[j] = sv;
+        xEv = pk_max(xEv, sv);
+        mdv[j] = pk_adds(sv, tMD[j]);
+      }
+      Dv[0] = stripe_shift16(mdv[Q - 1], hd);
+#pragma unroll
+      for (int j = 1; j < Q; ++j) Dv[j] = pk_max(mdv[j - 1], pk_adds(Dv[j - 1], tDD[j - 1]));
+      u32 carry = pk_adds(Dv[Q - 1], tDD[Q - 1]);
+      for (int pass = 0; pass < 32; ++pass) {                       // lazy-F: at most 32 stripes to cross
+        u32 cs = stripe_shift16(carry, hc);
+        const s16x2 c2 = __builtin_bit_cast(s16x2, cs), d2 = __builtin_bit_cast(s16x2, Dv[0]);
+        if (!__any((c2.x > d2.x) || (c2.y > d2.y))) break;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) { Dv[j] = pk_max(Dv[j], cs); cs = pk_adds(cs, tDD[j]); }
+        carry = cs;
+      }
+    };
+    {
+      int i = 0;
+      for (; i + 1 < Lmax; i += 2) { row(i, e, e2); row(i + 1, e2, e); }
+      if (i < Lmax) row(i, e, e2);
+    }
+    const s16x2 x2 = __builtin_bit_cast(s16x2, xEv);
+    int xE = max((int)x2.x, (int)x2.y);
+    xE = max(xE, __shfl_xor(xE, 1, 16)); xE = max(xE, __shfl_xor(xE, 2, 16)); xE = max(xE, __shfl_xor(xE, 4, 16)); xE = max(xE, __shfl_xor(xE, 8, 16));
+    if (valid && z == 0) {
+      const bool overflow = xE >= 32767;
+      const int xC = max((int)NEG16, xE + md.wE_move);
+      const bool jflag = (xE + md.wE_loop) > xN;
+      const uint32_t flag = (jflag && !overflow) ? 1u : 0u;
+      float vsc;
+      if (overflow) vsc = __builtin_inff();
+      else if (xC > NEG16) { float sc = (float)xC + (float)le.w_move - (float)md.base_w; sc = sc / md.scale_w; sc = sc - 3.0f; vsc = sc; }
+      else vsc = -__builtin_inff();
+      const float v = (vsc - pr.filtersc) * LOG2E_F;
+      cd.vit_fast[pi] = vsc; cd.vit_flag[pi] = flag;
+      if (v >= md.thr_vit_f2 + cd.margin_vit) pass_to_forward(cd, md, pi, pr.model, pr.seq);
+      else if (flag) { cd.route[pi] = 2; queue_push(cd, cd.vxq, CC_VXQ, md.vitx_cls, cd.cap_vq, pi, (uint32_t)CS_VQ); }
+      else if (v >= md.thr_vit_f2 - cd.margin_vit) pass_to_forward(cd, md, pi, pr.model, pr.seq);
+    }
+  }
+}
+
+int launch_vit16(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const PairRec *pairs, const DevModel *models, const LenEntry *lentab,
+                 const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const CascadeDev &cd) {
+  if (nblocks == 0) return 0;
+  switch (Q) {
+#define X(QV) case QV: hipLaunchKernelGGL(vit16_kernel<QV>, dim3(nblocks), dim3(256), 0, stream, queue, pairs, models, lentab, res, seq_off, seq_len, cd); break;
+    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(10) X(12) X(14) X(16)
+#undef X
+    default: return -1;
+  }
+  return 0;
 }
 
 #define CKM_VIT_CASE(QV) case QV: \
