@@ -165,11 +165,11 @@ extern "C" int ckm_profiles_load(ckm_ctx *ctx, const char *hmm_path, ckm_profile
       for (size_t i = 0; i < n; ++i) if (errs[i]) throw Error(*errs[i]);
     }
     Arena ar;
-    struct Off { size_t ssv, ssvh, rbv, vit_e, vit_t, rf, ftr, v16e, v16t; };
+    struct Off { size_t ssv, ssvh, rbv, vit_e, vit_t, rf, ftr, v16e, v16t, ssv8; };
     std::vector<Off> off(n);
     for (size_t i = 0; i < n; ++i) {
       const HostProfile &hp = p->prof[i];
-      off[i] = Off{ar.add(hp.ssv_tbl), ar.add(hp.ssv_tbl_h), ar.add(hp.rbv), ar.add(hp.vit_e), ar.add(hp.vit_t), ar.add(hp.rf), ar.add(hp.ftr), ar.add(hp.vit16_e), ar.add(hp.vit16_t)};
+      off[i] = Off{ar.add(hp.ssv_tbl), ar.add(hp.ssv_tbl_h), ar.add(hp.rbv), ar.add(hp.vit_e), ar.add(hp.vit_t), ar.add(hp.rf), ar.add(hp.ftr), ar.add(hp.vit16_e), ar.add(hp.vit16_t), ar.add(hp.ssv8_tbl_h)};
     }
     std::unique_ptr<DevBuf> tables(new DevBuf());
     tables->ensure(std::max<size_t>(256, ar.host.size()));
@@ -195,6 +195,7 @@ extern "C" int ckm_profiles_load(ckm_ctx *ctx, const char *hmm_path, ckm_profile
       d.rbv = base + off[i].rbv; d.vit_e = reinterpret_cast<const uint32_t *>(base + off[i].vit_e);
       d.vit_t = reinterpret_cast<const uint32_t *>(base + off[i].vit_t); d.rf = reinterpret_cast<const float *>(base + off[i].rf);
       d.ftr = reinterpret_cast<const float *>(base + off[i].ftr);
+      d.ssv8_tbl_h = hp.ssv8Q ? reinterpret_cast<const uint16_t *>(base + off[i].ssv8) : nullptr;
       d.vit16_e = reinterpret_cast<const uint32_t *>(base + off[i].v16e); d.vit16_t = reinterpret_cast<const uint32_t *>(base + off[i].v16t);
       p->dm.push_back(d);
       if (!p->too_long[i]) p->maxMp = std::max(p->maxMp, hp.fbQ * NL);

@@ -23,7 +23,7 @@ extern "C" int ckm_debug_stages(ckm_ctx *ctx_, const ckm_profiles *p, const ckm_
     std::map<int, std::vector<uint32_t>> byQ;
     for (uint32_t i = 0; i < npairs; ++i) {
       if (model[i] >= p->hmm.size() || seq[i] >= s->nseq) throw Error(CKM_EINVAL, "pair index out of range");
-      work[i].model = model[i]; work[i].list_start = i; work[i].count = 1; work[i].pair_start = i; byQ[p->prof[model[i]].ssvQ].push_back(i);
+      work[i].model = model[i]; work[i].list_start = i; work[i].count = 1; work[i].pair_start = i; byQ[ssv_class(p->prof[model[i]])].push_back(i);
     }
     std::vector<SsvBlockWork> sorted; std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;
     for (auto &kv : byQ) { groups.push_back({kv.first, {sorted.size(), kv.second.size()}}); for (uint32_t i : kv.second) sorted.push_back(work[i]); }

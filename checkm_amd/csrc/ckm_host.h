@@ -276,6 +276,8 @@ double now_ms();
 float bits(float sc, float nullsc);
 float finish_forward(float xC, float move, const std::vector<float> &scales);
 int ssv_threads_for(int Q);
+int ssv_class(const HostProfile &hp);
+uint32_t ssv_per_block(int cls);
 int side_streams();
 int choose_side_streams(int nworkers);
 void trace_pt(const Worker *w, const char *label);      // CKM_TRACE=1: worker / ms since the search began / label on stderr

@@ -47,6 +47,8 @@ struct HostProfile {
   std::vector<uint8_t> rbv;       // [KP][M+1]
   int ssvQ = 0;                   // packed i16x2 registers per lane (16 lanes per sequence): ceil(M/32) rounded to an instantiated size
   std::vector<uint16_t> ssv_tbl_h; // the same image as IEEE half bits of (bias - cost)/256
+  int ssv8Q = 0;                   // 8 lanes per sequence (models of <= 512 nodes): packed registers per lane, ceil(M/16) rounded up to an instance; 0 = none
+  std::vector<uint16_t> ssv8_tbl_h; // LDS image [ssv8Qg][NROWS][2 copies][8 lanes][4 regs][2 halves]
   std::vector<int16_t> ssv_tbl;   // LDS image: [NROWS][ssvQg][16 lanes][4 regs][2 halves]
   // Viterbi filter (signed words, 1/500 bit); contiguous k, padded to vitQ*64
   int vitQH = 0;                  // packed registers per lane: lane z owns cells z*2QH.., register j = (cell j, cell j+QH)

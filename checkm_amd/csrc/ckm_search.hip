@@ -142,7 +142,7 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
         std::map<int, std::vector<SsvBlockWork>> byQ;
         uint64_t c_pairs = 0, c_res = 0, c_cells = 0;
         for (auto &mw : mws) {
-          const int Q = p->prof[mw.model].ssvQ; const int threads = ssv_threads_for(Q); const uint32_t per_block = (uint32_t)threads / 64 * 4 * 4;
+          const int Q = ssv_class(p->prof[mw.model]); const uint32_t per_block = ssv_per_block(Q);
           uint64_t pb = mw.pair_base;
           for (uint32_t b : model_bins[mw.model]) {
             const uint32_t o0 = rng.lo[b], n = rng.hi[b] - o0;
@@ -551,7 +551,11 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
     }
   }
   cut.push_back(rng.hi);
-  std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;      // key = part * 1000 + SSV register class
+  // key = part * 1000 + code of the SSV launch class, the code growing with the length of the models (groups are launched heaviest first):
+  // 8-lane classes 100 + Q8 (models of <= 512 nodes) -> Q8, 16-lane classes Q -> 40 + Q, kSsvNone -> 105
+  auto enc = [](int cls) { return cls >= 100 ? cls - 100 : 40 + cls; };
+  auto dec = [](int code) { return code < 40 ? 100 + code : code - 40; };
+  std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;
   {
     std::vector<uint64_t> key{p->uid, s->uid, pair_budget, (uint64_t)Lcut, rng.tag, 0xdeull};
     for (int lc : Lcuts) key.push_back(0xc0000000ull + (uint64_t)lc);
@@ -567,13 +571,13 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
       std::map<int, std::vector<Run>> runs;
       uint64_t c_pairs = 0, c_res = 0, c_cells = 0;
       for (auto &mw : mws) {
-        const int Q = p->prof[mw.model].ssvQ;
+        const int Q = ssv_class(p->prof[mw.model]);
         uint64_t pb = mw.pair_base;
         for (uint32_t b : model_bins[mw.model]) {
           const uint32_t o0 = rng.lo[b], n = rng.hi[b] - o0;
           for (int part = 0; part < nparts; ++part) {
             const uint32_t a0 = cut[part][b] - o0, a1 = cut[part + 1][b] - o0;
-            if (a1 > a0) runs[part * 1000 + Q].push_back({mw.model, o0 + a0, a1 - a0, pb + a0});
+            if (a1 > a0) runs[part * 1000 + enc(Q)].push_back({mw.model, o0 + a0, a1 - a0, pb + a0});
           }
           pb += n; c_res += rng.res[b]; c_cells += rng.res[b] * (uint64_t)p->prof[mw.model].M;
         }
@@ -582,7 +586,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
       st.pairs_ssv += c_pairs; st.residue_hmm += c_res; st.cells_ssv += c_cells;
       std::vector<SsvBlockWork> allw;
       for (auto &kv : runs) {
-        const int Q = kv.first % 1000; const uint32_t per_block = (uint32_t)ssv_threads_for(Q) / 64 * 4 * 4;
+        const int Q = dec(kv.first % 1000); const uint32_t per_block = ssv_per_block(Q);
         const size_t first = allw.size();
         std::vector<Run> &rv = kv.second;
         std::stable_sort(rv.begin(), rv.end(), [&](const Run &x, const Run &y) { return s->len[s->order[x.first]] > s->len[s->order[y.first]]; });
@@ -609,12 +613,12 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   std::vector<Sub> subs;
   {
     std::map<int, size_t> at;
-    for (auto &g : groups) { Sub sb; sb.Q = g.first % 1000; sb.first = g.second.first; sb.nblocks = g.second.second; at[g.first] = subs.size(); subs.push_back(sb); }
+    for (auto &g : groups) { Sub sb; sb.Q = dec(g.first % 1000); sb.first = g.second.first; sb.nblocks = g.second.second; at[g.first] = subs.size(); subs.push_back(sb); }
     for (auto &mw : mws) {
       for (int part = 0; part < nparts; ++part) {
         uint64_t np = 0;                                      // the model's pairs in this part
         for (uint32_t b : model_bins[mw.model]) np += cut[part + 1][b] - cut[part][b];
-        auto it = at.find(part * 1000 + p->prof[mw.model].ssvQ);
+        auto it = at.find(part * 1000 + enc(ssv_class(p->prof[mw.model])));
         if (it == at.end()) continue;                         // (no sequence of this part in the model's bins)
         Sub &sb = subs[it->second]; sb.pairs += np; sb.vit[p->dm[mw.model].vit_cls] = true; sb.vit[p->dm[mw.model].vitx_cls] = true; sb.fb[p->dm[mw.model].fb_cls] = true; sb.maxM = std::max(sb.maxM, p->prof[mw.model].M);
       }

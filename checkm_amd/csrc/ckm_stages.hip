@@ -42,7 +42,14 @@ int choose_side_streams(int nworkers) {
   return n;
 }
 
+// The SSV LAUNCH CLASS of a model: its 16-lane register class (1..64), 100 + its 8-lane class for models of up to 512 nodes when the
+// packed-half kernels are in use, kSsvNone (65) when no SSV instance holds it.
+bool ssv_half_mode();
+int ssv_class(const HostProfile &hp) { return (hp.ssv8Q && ssv_half_mode()) ? 100 + hp.ssv8Q : hp.ssvQ; }
+uint32_t ssv_per_block(int cls) { return (uint32_t)ssv_threads_for(cls) / 64u * (cls >= 100 ? 8u : 4u) * 4u; }      // sequences a workgroup takes: four rounds of its wavefronts
+
 int ssv_threads_for(int Q) {
+  if (Q >= 100) Q -= 100;
   const size_t lds = (size_t)NROWS * ((Q + 3) / 4) * 256;
   if (lds <= 40 * 1024) return 256;
   if (lds <= 80 * 1024 || Q > 40) return 512;   // kernels with Q > 40 are compiled for <= 512 threads (256 VGPRs)

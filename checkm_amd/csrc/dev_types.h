@@ -23,6 +23,7 @@ struct DevModel {
   // tables in HBM
   const int16_t *ssv_tbl;   // [Qg][30][16][8]  bias - cost as int16 (exact MSV kernel, CKM_SSV=i16)
   const uint16_t *ssv_tbl_h; // same layout, (bias - cost)/256 as IEEE half bits (ssv_kernel_h)
+  const uint16_t *ssv8_tbl_h; // [Qg8][30][2 copies][8 lanes][8] the 8-lane image of models of <= 512 nodes (ssv_kernel_h8), or null
   const uint8_t *rbv;       // [29][M+1]
   const uint32_t *vit_e;    // [30][vitQH][64] packed emission words (cell j | cell j+QH of each lane)
   const uint32_t *vit_t;    // [8][vitQH][64]  packed transition words: BM MM IM DM (into) MD MI II DD (from)

@@ -394,6 +394,20 @@ HostProfile configure_profile(const HostHMM &h) {
           }
     p.ssv_tbl_h.resize(p.ssv_tbl.size());
     for (size_t i = 0; i < p.ssv_tbl.size(); ++i) p.ssv_tbl_h[i] = half_bits_of_256th(p.ssv_tbl[i]);
+    // the 8-lane image (ssv_kernel_h8): position p = q + Q8 * (2 z + half), z = 0..7; both copies of a (group, symbol) row are the same
+    static const int kSsv8Q[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 26, 28, 30, 32};
+    p.ssv8Q = 0;
+    for (int q : kSsv8Q) if (q * 16 >= M) { p.ssv8Q = q; break; }
+    if (p.ssv8Q) {
+      const int Q8 = p.ssv8Q, Qg8 = (Q8 + 3) / 4;
+      p.ssv8_tbl_h.assign((size_t)NROWS * Qg8 * 128, half_bits_of_256th(p.bias_b - 255));
+      for (int x = 0; x < KP; ++x) for (int q = 0; q < Q8; ++q) for (int z = 0; z < 8; ++z) for (int hh = 0; hh < 2; ++hh) {
+        const int k = q + Q8 * (2 * z + hh) + 1;
+        const int cost = (k <= M) ? p.rbv[(size_t)x * (M + 1) + k] : 255;
+        for (int c = 0; c < 2; ++c)
+          p.ssv8_tbl_h[(((((size_t)(q / 4) * NROWS + x) * 2 + c) * 8 + z) * 8) + (size_t)(q % 4) * 2 + hh] = half_bits_of_256th(p.bias_b - cost);
+      }
+    }
   }
   // ---- Viterbi filter ----
   {

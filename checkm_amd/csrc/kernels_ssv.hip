@@ -164,7 +164,7 @@ __device__ __forceinline__ void ssv_load_row(u32 (&e)[((Q + 3) / 4) * 4], u32 ad
   }
 }
 
-template <int Q>
+template <int Q, int SHR = 0x111 /* row_shr:1; 0x112 = row_shr:2 for the 8-lane mapping */>
 __device__ __forceinline__ void ssv_rows2_h(u32 (&U)[Q], u32 &xE, u32 &prev, u32 addr_a, u32 addr_b) {
   constexpr int Qg = (Q + 3) / 4;
   u32 e[Qg * 4];
@@ -172,7 +172,7 @@ __device__ __forceinline__ void ssv_rows2_h(u32 (&U)[Q], u32 &xE, u32 &prev, u32
   ssv_load_row<Q>(e, addr_a);
   {
     const u32 last = U[Q - 1];
-    prev = (u32)__builtin_amdgcn_update_dpp((int)prev, (int)last, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+    prev = (u32)__builtin_amdgcn_update_dpp((int)prev, (int)last, SHR, 0xf, 0xf, false);
     const u32 carry = __builtin_amdgcn_alignbit(last, prev, 16);
 #pragma unroll
     for (int q = Q - 1; q >= 1; --q) U[q] = pk_add_h_clamp(U[q - 1], e[q]);
@@ -182,7 +182,7 @@ __device__ __forceinline__ void ssv_rows2_h(u32 (&U)[Q], u32 &xE, u32 &prev, u32
   ssv_load_row<Q>(e, addr_b);
   {
     const u32 last = U[Q - 1];
-    prev = (u32)__builtin_amdgcn_update_dpp((int)prev, (int)last, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+    prev = (u32)__builtin_amdgcn_update_dpp((int)prev, (int)last, SHR, 0xf, 0xf, false);
     const u32 carry = __builtin_amdgcn_alignbit(last, prev, 16);
 #pragma unroll
     for (int q = Q - 1; q >= 1; --q) {
@@ -246,6 +246,71 @@ __global__ void __launch_bounds__(Q > 40 ? 512 : 1024) ssv_kernel_h(const SsvBlo
     // k/256 back to k: the f16 bit patterns of non-negative values order like integers, so the maximum is taken on the bits
     u32 mb = max(xE & 0xffffu, xE >> 16);
     mb = max(mb, (u32)__shfl_xor((int)mb, 1, 16));
+    mb = max(mb, (u32)__shfl_xor((int)mb, 2, 16));
+    mb = max(mb, (u32)__shfl_xor((int)mb, 4, 16));
+    mb = max(mb, (u32)__shfl_xor((int)mb, 8, 16));
+    const _Float16 hv = __builtin_bit_cast(_Float16, (unsigned short)mb);
+    if (valid && z == 0) maxv[w.pair_start + li] = (uint16_t)(int)((float)hv * 256.0f);
+  }
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+// The packed-half row on EIGHT lanes per sequence, eight sequences per wavefront, for models of up to 512 nodes (round 3).  The row's
+// fixed part (address, DPP move, alignbit) and the padding to a whole register per lane are what short models pay most for: 1.5 Q + 3.25
+// instructions per four sequence-rows at Q = ceil(M / 32).  Here a DPP row holds TWO sequences, interleaved (even lanes one, odd lanes the
+// other), so "the previous lane of my sequence" is row_shr:2 -- lanes 0 and 1 of a row have no source and keep U = 0 -- and a sequence's
+// 16 stripes of Q8 = ceil(M / 16) cells give 1.5 Q8 + 3.25 instructions per EIGHT sequence-rows.  The LDS image keeps 256 bytes per
+// (register group, symbol): the eight 16-byte columns of the model, twice, so that the odd lanes read the upper copy and the 16 lanes of a
+// row still hit 16 different bank groups whatever the two residues are.
+// --------------------------------------------------------------------------------------------------------------------
+template <int Q>
+__global__ void __launch_bounds__(Q > 40 ? 512 : 1024) ssv_kernel_h8(const SsvBlockWork *__restrict__ work, const DevModel *__restrict__ models,
+                           const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
+                           const int32_t *__restrict__ seq_len, const uint32_t *__restrict__ lists,
+                           uint16_t *__restrict__ maxv) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int Qg = (Q + 3) / 4;
+  constexpr int ROWB = Qg * 256;
+  lds_image_at_zero(smem);
+  const SsvBlockWork w = work[blockIdx.x];
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(models[w.model].ssv8_tbl_h);
+    uint4 *dst = reinterpret_cast<uint4 *>(smem);
+    for (int i = threadIdx.x; i < SSV_NROWS * ROWB / 16; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int z16 = lane & 15, sub = z16 & 1, z = z16 >> 1;
+  const u32 lane_off = (u32)sub * 128u + (u32)z * 16u;
+  for (u32 g = wave; g * 8 < w.count; g += nwaves) {
+    const u32 li = g * 8 + (u32)(lane >> 4) * 2u + (u32)sub;
+    const bool valid = li < w.count;
+    const u32 sid = valid ? lists[w.list_start + li] : 0u;
+    const int L = valid ? seq_len[sid] : 0;
+    const uint8_t *rp = res + seq_off[sid];
+    int Lmax = max(__builtin_amdgcn_readlane(L, 0), __builtin_amdgcn_readlane(L, 1));
+    Lmax = max(Lmax, max(__builtin_amdgcn_readlane(L, 16), __builtin_amdgcn_readlane(L, 17)));
+    Lmax = max(Lmax, max(__builtin_amdgcn_readlane(L, 32), __builtin_amdgcn_readlane(L, 33)));
+    Lmax = max(Lmax, max(__builtin_amdgcn_readlane(L, 48), __builtin_amdgcn_readlane(L, 49)));
+    u32 U[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) U[q] = 0u;
+    u32 xE = 0u, prev = 0u;
+    const int nchunk = (Lmax + 15) >> 4;
+    const uint4 padv = make_uint4(PAD4, PAD4, PAD4, PAD4);
+    uint4 cur = padv;
+    if (0 < L) cur = *reinterpret_cast<const uint4 *>(rp);
+    for (int c = 0; c < nchunk; ++c) {
+      uint4 nxt = padv;
+      if ((c + 1) * 16 < L) nxt = *reinterpret_cast<const uint4 *>(rp + (c + 1) * 16);
+#define CKM_SSV_WORD(wd)                                                                            \
+  ssv_rows2_h<Q, 0x112>(U, xE, prev, ssv_addr<0>(wd, lane_off), ssv_addr<1>(wd, lane_off));           \
+  ssv_rows2_h<Q, 0x112>(U, xE, prev, ssv_addr<2>(wd, lane_off), ssv_addr<3>(wd, lane_off));
+      CKM_SSV_WORD(cur.x) CKM_SSV_WORD(cur.y) CKM_SSV_WORD(cur.z) CKM_SSV_WORD(cur.w)
+#undef CKM_SSV_WORD
+      cur = nxt;
+    }
+    u32 mb = max(xE & 0xffffu, xE >> 16);
     mb = max(mb, (u32)__shfl_xor((int)mb, 2, 16));
     mb = max(mb, (u32)__shfl_xor((int)mb, 4, 16));
     mb = max(mb, (u32)__shfl_xor((int)mb, 8, 16));
@@ -415,6 +480,7 @@ int launch_msv(int Q, int nblocks, hipStream_t stream, const SsvBlockWork *work,
 
 // CKM_SSV=i16 keeps round 1's packed-integer row (2 ops per register per row); the default is the packed-half row (1.5).
 static const bool g_ssv_half = [] { const char *e = getenv("CKM_SSV"); return !(e && strcmp(e, "i16") == 0); }();
+bool ssv_half_mode() { return g_ssv_half; }
 
 // Models beyond 2048 nodes have no SSV instance (the LDS image of their emission words would not fit): Smax = 0 for all of their
 // pairs sends every one of them to the exact MSV kernel ("no cell rose above xB: recompute exactly" in msv_finish_kernel), which takes
@@ -426,6 +492,21 @@ __global__ void ssv_none_kernel(const SsvBlockWork *__restrict__ work, uint16_t 
 
 int launch_ssv(int Q, int nblocks, int threads, hipStream_t stream, const SsvBlockWork *work, const DevModel *models,
                const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const uint32_t *lists, uint16_t *maxv) {
+  if (Q >= 100) {                      // launch classes 100 + Q8: eight lanes per sequence
+    switch (Q - 100) {
+#define X(QV) case QV:                                                                                           \
+      if ((size_t)SSV_NROWS * ((QV + 3) / 4) * 256 > 48 * 1024) {                                                \
+        static bool attr8 = false;                                                                               \
+        if (!attr8) { (void)hipFuncSetAttribute((const void *)ssv_kernel_h8<QV>, hipFuncAttributeMaxDynamicSharedMemorySize, SSV_NROWS * ((QV + 3) / 4) * 256); attr8 = true; } \
+      }                                                                                                          \
+      hipLaunchKernelGGL(ssv_kernel_h8<QV>, dim3(nblocks), dim3(threads), (size_t)SSV_NROWS * ((QV + 3) / 4) * 256, stream, work, models, res, seq_off, seq_len, lists, maxv); \
+      break;
+      X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32)
+#undef X
+      default: return -1;
+    }
+    return 0;
+  }
   if (Q > 64) { if (nblocks > 0) hipLaunchKernelGGL(ssv_none_kernel, dim3(nblocks), dim3(64), 0, stream, work, maxv); return 0; }
   switch (Q) {
     CKM_SSV_CASE(1) CKM_SSV_CASE(2) CKM_SSV_CASE(3) CKM_SSV_CASE(4) CKM_SSV_CASE(5) CKM_SSV_CASE(6) CKM_SSV_CASE(7)
