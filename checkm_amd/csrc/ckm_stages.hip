@@ -51,12 +51,9 @@ uint32_t ssv_per_block(int cls) { return (uint32_t)ssv_threads_for(cls) / 64u * 
 int ssv_threads_for(int Q) {
   if (Q >= 100) Q -= 100;
   const size_t lds = (size_t)NROWS * ((Q + 3) / 4) * 256;
-  // One LDS image per workgroup: the more wavefronts share it, the more of them a CU holds (160 KB of LDS, part of it taken by the chain
-  // kernels of other groups).  CKM_SSV_THREADS=a,b overrides the two image-size limits (KB) below which 256 / 512 threads are used.
-  static const int lim256 = [] { const char *e = getenv("CKM_SSV_THREADS"); return e ? atoi(e) : 16; }();
-  static const int lim512 = [] { const char *e = getenv("CKM_SSV_THREADS"); const char *c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 32; }();
-  if (lds <= (size_t)lim256 * 1024) return 256;
-  if (lds <= (size_t)lim512 * 1024 || Q > 40) return 512;   // kernels with Q > 40 are compiled for <= 512 threads (256 VGPRs)
+  // (other limits -- 16 / 32 KB, 8 / 16 KB -- were measured in round 3, profiles/r03m_ssv_threads.txt: no difference beyond noise)
+  if (lds <= 40 * 1024) return 256;
+  if (lds <= 80 * 1024 || Q > 40) return 512;   // kernels with Q > 40 are compiled for <= 512 threads (256 VGPRs)
   return 1024;
 }
 
