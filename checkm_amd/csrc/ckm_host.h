@@ -39,6 +39,8 @@ void launch_msv_full(hipStream_t stream, uint32_t nblocks, WorkQueue queue, cons
                      const CascadeDev *cd /* null: scores only */);
 void launch_bias(hipStream_t stream, PairRec *pairs, uint32_t npairs, const DevModel *models, const LenEntry *lentab,
                  const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, float *raw);
+int launch_msv16(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const PairRec *pairs, const DevModel *models, const LenEntry *lentab,
+                 const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const CascadeDev &cd);
 int launch_vit16(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const PairRec *pairs, const DevModel *models, const LenEntry *lentab,
                  const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const CascadeDev &cd);
 int launch_vit(int QH, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const PairRec *pairs, const DevModel *models,

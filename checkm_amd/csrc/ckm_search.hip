@@ -758,7 +758,13 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
       FinishArgs fa{dm, lt, dlen, s->d_order.as<uint32_t>(), ctx->work.as<SsvBlockWork>() + sb.first, ctx->maxv.as<uint16_t>(),
                     cd.cand, cnt + CC_CAND, sb.cap_cand, nores, cnt + CC_NORES, sb.cap_nores};
       launch_msv_finish(sc, fa, (uint32_t)sb.nblocks);
-      if (stop >= 2) launch_msv_full(sc, GRID_MSV, WorkQueue{nullptr, cnt + CC_NORES, sb.cap_nores}, nores, dm, lt, res, off, dlen, nullptr, nullptr, std::max(64, sb.maxM) /* sized to the group's longest model: a small LDS image, many pairs per CU */, &cd);
+      if (stop >= 2) {
+        // exact MSV of the pairs SSV could not decide: packed, four pairs per wavefront, for every model that has a 16-lane image (an 8-lane
+        // class 100 + Q8 holds models of exactly the 16-lane class ceil(Q8 / 2)); the wave-per-pair kernel for models beyond 2048 nodes
+        const WorkQueue qn{nullptr, cnt + CC_NORES, sb.cap_nores};
+        if (sb.Q == kSsvNone) launch_msv_full(sc, GRID_MSV, qn, nores, dm, lt, res, off, dlen, nullptr, nullptr, std::max(64, sb.maxM), &cd);
+        else if (launch_msv16(sb.Q >= 100 ? (sb.Q - 100 + 1) / 2 : sb.Q, GRID_MSV, sc, qn, nores, dm, lt, res, off, dlen, cd)) throw Error(CKM_ERANGE, "no exact-MSV kernel instance for this model length");
+      }
       if (stop >= 3) launch_bias_filter(sc, GRID_MSV, cd, dm, lt, res, off);
       int rc = 0;
       // FAST filter of every class first (short models: four pairs per wavefront on 16 lanes each), then the exact kernel for the pairs

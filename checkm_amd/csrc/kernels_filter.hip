@@ -550,6 +550,120 @@ int launch_vit16(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, c
   return 0;
 }
 
+// --------------------------------------------------------------------------------------------
+// Exact multi-hit MSV for the pairs SSV cannot decide, packed (round 3): 16 lanes per pair, four pairs per wavefront, SSV's lane mapping
+// and the byte recurrence carried in full -- sv = max(prev, xB) + (bias - cost), floored by the clamped add (offset -32768), every row
+// ending with the 16-lane maximum that feeds xJ and xB (msv_kernel<Q> of kernels_ssv.hip, which the host-driven cascade uses, does the
+// same from an LDS image for 16 pairs of ONE model).  Here the four pairs of a wavefront are whatever the queue holds -- own model, own
+// sequence -- so the emission words come from the model's i16 image in global memory (L2: a group's models are few), one row ahead.
+// 3 packed ops per register per row + ~25, for four pairs: ~6x fewer instructions than the wave-per-pair msv_full_kernel and no 50 KB
+// LDS image per pair; msv_full_kernel stays for models beyond 2048 nodes (no 16-lane image) and for the diagnostics.
+// --------------------------------------------------------------------------------------------
+constexpr u32 U_ZERO16 = 0x80008000u;
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+constexpr int MSV16_GSTRIDE = 30 * 256;       // bytes per register group of the image: [group][30 symbols][16 lanes][16 B]
+
+template <int Q>
+__global__ void __launch_bounds__(256) msv16_kernel(WorkQueue queue, const PairRec *__restrict__ pairs, const DevModel *__restrict__ models,
+                                                    const LenEntry *__restrict__ lentab, const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
+                                                    const int32_t *__restrict__ seq_len, CascadeDev cd) {
+  constexpr int Qg = (Q + 3) / 4;
+  const int lane = threadIdx.x & 63, z = lane & 15, g = lane >> 4;
+  const uint32_t nqueue = queue_len(queue);
+  for (uint32_t q4 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); q4 * 4u < nqueue; q4 += gridDim.x * (blockDim.x >> 6)) {
+    const uint32_t pi = q4 * 4u + (uint32_t)g;
+    const bool valid = pi < nqueue;
+    const PairRec pr = pairs[valid ? pi : q4 * 4u];
+    const DevModel &md = models[pr.model];
+    const int L = seq_len[pr.seq];
+    int Lmax = __builtin_amdgcn_readlane(L, 0);
+    Lmax = max(Lmax, __builtin_amdgcn_readlane(L, 16));
+    Lmax = max(Lmax, __builtin_amdgcn_readlane(L, 32));
+    Lmax = max(Lmax, __builtin_amdgcn_readlane(L, 48));
+    const uint8_t *rp = res + seq_off[pr.seq];
+    const LenEntry le = lentab[L];
+    const int base = md.base_b, bias = md.bias_b, tec = md.tec_b;
+    const int tjbm = (le.tjb_b + md.tbm_b) & 0xff;
+    const gp<char> img = gptr(reinterpret_cast<const char *>(md.ssv_tbl)) + z * 16;
+    u32 U[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) U[q] = U_ZERO16;
+    u32 prev = U_ZERO16;
+    int xJ = 0, xB = max(base - tjbm, 0);
+    bool overflow = false;
+    auto sym = [&](u32 word, int i) -> u32 { return (i < L) ? ((word >> (8 * (i & 3))) & 0xffu) : 29u; };
+    auto load_row = [&](u32 (&e)[Qg * 4], u32 x) {
+#pragma unroll
+      for (int gq = 0; gq < Qg; ++gq) {
+        const u32x4v v = *(gp<u32x4v>)(img + (size_t)gq * MSV16_GSTRIDE + (size_t)x * 256u);
+        e[gq * 4 + 0] = v.x; e[gq * 4 + 1] = v.y; e[gq * 4 + 2] = v.z; e[gq * 4 + 3] = v.w;
+      }
+    };
+    u32 rw = *reinterpret_cast<const u32 *>(rp);
+    u32 ea[Qg * 4], eb[Qg * 4];
+    load_row(ea, sym(rw, 0));
+    auto row = [&](int i, u32 (&ec)[Qg * 4], u32 (&en)[Qg * 4]) {
+      {
+        const int i1 = i + 1;
+        if ((i1 & 3) == 0 && i1 < L) rw = *reinterpret_cast<const u32 *>(rp + i1);
+        load_row(en, sym(rw, i1));
+      }
+      const u32 xBv = (0x8000u + (u32)xB) * 0x10001u;
+      const u32 last = U[Q - 1];
+      prev = (u32)__builtin_amdgcn_update_dpp((int)prev, (int)last, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+      const u32 carry = __builtin_amdgcn_alignbit(last, prev, 16);
+      u32 xE = U_ZERO16;
+#pragma unroll
+      for (int q = Q - 1; q >= 1; --q) {
+        const u32 v = pk_adds(pk_max(U[q - 1], xBv), ec[q]);
+        xE = pk_max(xE, v);
+        U[q] = v;
+      }
+      {
+        const u32 v = pk_adds(pk_max(carry, xBv), ec[0]);
+        xE = pk_max(xE, v);
+        U[0] = v;
+      }
+      xE = pk_max(xE, (u32)__builtin_amdgcn_update_dpp((int)xE, (int)xE, 0xB1, 0xf, 0xf, false));
+      xE = pk_max(xE, (u32)__builtin_amdgcn_update_dpp((int)xE, (int)xE, 0x4E, 0xf, 0xf, false));
+      xE = pk_max(xE, (u32)__builtin_amdgcn_update_dpp((int)xE, (int)xE, 0x141, 0xf, 0xf, false));
+      xE = pk_max(xE, (u32)__builtin_amdgcn_update_dpp((int)xE, (int)xE, 0x140, 0xf, 0xf, false));
+      xE = pk_max(xE, __builtin_amdgcn_alignbit(xE, xE, 16));
+      if (i < L) {                                  // (a pair that has ended keeps its score: the pad rows change nothing it reports)
+        const int xe = (int)(short)(xE & 0xffffu) + 32768;
+        overflow = overflow || (xe + bias >= 255);
+        const int xe2 = max(xe - tec, 0);
+        xJ = max(xJ, xe2);
+        xB = max(max(base, xJ) - tjbm, 0);
+      }
+    };
+    {
+      int i = 0;
+      for (; i + 1 < Lmax; i += 2) { row(i, ea, eb); row(i + 1, eb, ea); }
+      if (i < Lmax) row(i, ea, eb);
+    }
+    if (valid && z == 0) {
+      const float usc = overflow ? __builtin_inff() : msv_score(xJ, le.tjb_b, md.base_b, md.scale_b);
+      if (to_bits(usc, le.nullsc) >= md.thr_msv_f1) {
+        const uint32_t k = atomicAdd(&cd.cnt[CC_CAND], 1u);
+        if (k < cd.cap_cand) { PairRec r = pr; r.usc = usc; r.filtersc = 0.f; cd.cand[k] = r; } else atomicOr(&cd.gcnt[CC_STATUS], (uint32_t)CS_CAND);
+      }
+    }
+  }
+}
+
+int launch_msv16(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const PairRec *pairs, const DevModel *models, const LenEntry *lentab,
+                 const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const CascadeDev &cd) {
+  if (nblocks == 0) return 0;
+  switch (Q) {
+#define X(QV) case QV: hipLaunchKernelGGL(msv16_kernel<QV>, dim3(nblocks), dim3(256), 0, stream, queue, pairs, models, lentab, res, seq_off, seq_len, cd); break;
+    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32) X(36) X(40) X(48) X(56) X(64)
+#undef X
+    default: return -1;
+  }
+  return 0;
+}
+
 #define CKM_VIT_CASE(QV) case QV: \
     if (fast) hipLaunchKernelGGL((vit_kernel<QV, true>), dim3(nblocks), dim3(256), 0, stream, queue, pairs, models, lentab, res, seq_off, seq_len, out_xC, out_sc, out_flag, c, cd ? 1 : 0); \
     else hipLaunchKernelGGL((vit_kernel<QV, false>), dim3(nblocks), dim3(256), 0, stream, queue, pairs, models, lentab, res, seq_off, seq_len, out_xC, out_sc, out_flag, c, cd ? 1 : 0); \
