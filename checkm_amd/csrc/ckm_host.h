@@ -131,7 +131,7 @@ struct Worker {
   PinnedBuf h_cnt, h_pass, h_reg, h_envout, h_events_f, h_events_e, h_hens, h_tops;
   hipEvent_t cev[4] = {nullptr, nullptr, nullptr, nullptr};      // fork / join points of the lane's chain
   hipEvent_t cls_ev[16] = {};                                    // one per side stream
-  hipEvent_t grp_ev[64] = {};                                    // end of the SSV launch of each model-length group
+  hipEvent_t grp_ev[192] = {};                                    // end of the SSV launch of each model-length group
 };
 
 // register classes of the Viterbi-filter and Forward/Backward kernels, in queue order (DevModel::vit_cls / fb_cls index these)

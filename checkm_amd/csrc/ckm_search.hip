@@ -625,7 +625,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
     }
   }
   const size_t NG = subs.size();
-  if (NG > 64) return 2;
+  if (NG > 192) return 2;                          // (grp_ev; 2 parts x (30 eight-lane + 29 sixteen-lane SSV classes + 1) at most)
   CKM_TRACE_PT("plan ready");
 
   // ---- capacities: shares of the pairs (the divisors halve when a table overflowed on an earlier call), tables ----
@@ -637,7 +637,8 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
     return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(shrink > 1 ? 8 : floor_, pairs / ((uint64_t)div * shrink)), 0x7ffffff0ull); };
   for (Sub &sb : subs) {
     sb.cap_cand = capof(sb.pairs, cp.div_cand, 4096);
-    sb.cap_nores = capof(sb.pairs, cp.div_nores, 2048);
+    sb.cap_nores = sb.Q == kSsvNone ? (uint32_t)std::min<uint64_t>(sb.pairs + 64, 0x7ffffff0ull)     // no SSV for these models: every pair is recomputed exactly
+                                    : capof(sb.pairs, cp.div_nores, 2048);
     sb.cap_f = capof(sb.pairs, cp.div_fwork, 2048);
     sb.cap_e = capof(sb.pairs, cp.div_ework, 1024);
     sb.cap_r = capof(sb.pairs, cp.div_rwork, 256);
@@ -828,23 +829,35 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   const uint32_t n_fwork = h_cnt[CC_FWORK], n_ework = h_cnt[CC_EWORK], n_rwork = h_cnt[CC_RWORK],
                  n_pass = h_cnt[CC_PASS], n_reg = h_cnt[CC_REG], n_evf = h_cnt[CC_EVENTS], n_eve = h_cnt[CC_EVENTS_E], status = h_cnt[CC_STATUS];
   bool fits = status == 0;
-  auto need = [&](uint32_t &cap, uint32_t n) { if (n > cap) { fits = false; cap = (uint32_t)std::min<uint64_t>((uint64_t)n + n / 4 + 1024, 0xfffffff0ull); } };
-  need(cp.fwork, n_fwork); need(cp.ework, n_ework); need(cp.rwork, n_rwork); need(cp.pass, n_pass);
-  need(cp.reg, n_reg); need(cp.events_f, n_evf); need(cp.events_e, n_eve);
-  auto halve = [&](uint32_t &d) { d = std::max<uint32_t>(1, d / 2); fits = false; };
+  const bool tr = getenv("CKM_TRACE") != nullptr;
+  auto over = [&](const char *what, int g, int k, uint64_t n, uint64_t cap) {
+    fits = false; if (tr) fprintf(stderr, "ckm-trace w%d table %s (group %d, class %d) wanted %llu of %llu\n", ctx->id, what, g, k, (unsigned long long)n, (unsigned long long)cap); };
+  auto need = [&](const char *what, uint32_t &cap, uint32_t n) { if (n > cap) { over(what, -1, -1, n, cap); cap = (uint32_t)std::min<uint64_t>((uint64_t)n + n / 4 + 1024, 0xfffffff0ull); } };
+  need("fwork", cp.fwork, n_fwork); need("ework", cp.ework, n_ework); need("rwork", cp.rwork, n_rwork); need("pass", cp.pass, n_pass);
+  need("reg", cp.reg, n_reg); need("events_f", cp.events_f, n_evf); need("events_e", cp.events_e, n_eve);
+  auto halve = [&](uint32_t &d) { d = std::max<uint32_t>(1, d / 2); };
   uint64_t n_cand = 0, n_nores = 0;
+  bool o_cand = false, o_nores = false, o_f = false, o_e = false, o_r = false;   // (a divisor halves once per search, however many groups overflowed)
   for (size_t g = 0; g < NG; ++g) {
     const uint32_t *c = h_cnt + (1 + g) * CC_SIZE; const Sub &sb = subs[g];
     n_cand += c[CC_CAND]; n_nores += c[CC_NORES];
-    if (c[CC_CAND] > sb.cap_cand) halve(cp.div_cand);
-    if (c[CC_NORES] > sb.cap_nores) halve(cp.div_nores);
-    for (int k = 0; k < NVC; ++k) { st.pairs_vit += c[CC_VQ + k]; st.pairs_vit_exact += c[CC_VXQ + k]; if (c[CC_VQ + k] > sb.cap_cand || c[CC_VXQ + k] > sb.cap_cand) halve(cp.div_cand); }
+    if (c[CC_CAND] > sb.cap_cand) { over("cand", (int)g, -1, c[CC_CAND], sb.cap_cand); o_cand = true; }
+    if (c[CC_NORES] > sb.cap_nores) { over("nores", (int)g, -1, c[CC_NORES], sb.cap_nores); if (sb.Q != kSsvNone) o_nores = true; }
+    for (int k = 0; k < NVC; ++k) {
+      st.pairs_vit += c[CC_VQ + k]; st.pairs_vit_exact += c[CC_VXQ + k];
+      if (c[CC_VQ + k] > sb.cap_cand || c[CC_VXQ + k] > sb.cap_cand) { over("vq", (int)g, k, std::max(c[CC_VQ + k], c[CC_VXQ + k]), sb.cap_cand); o_cand = true; }
+    }
     for (int k = 0; k < NFC; ++k) {
-      if (c[CC_FQ + k] > sb.cap_f || c[CC_BQ + k] > sb.cap_f) halve(cp.div_fwork);
-      if (c[CC_EQ + k] > sb.cap_e) halve(cp.div_ework);
-      if (c[CC_RQ + k] > sb.cap_r) halve(cp.div_rwork);
+      if (c[CC_FQ + k] > sb.cap_f || c[CC_BQ + k] > sb.cap_f) { over("fq", (int)g, k, std::max(c[CC_FQ + k], c[CC_BQ + k]), sb.cap_f); o_f = true; }
+      if (c[CC_EQ + k] > sb.cap_e) { over("eq", (int)g, k, c[CC_EQ + k], sb.cap_e); o_e = true; }
+      if (c[CC_RQ + k] > sb.cap_r) { over("rq", (int)g, k, c[CC_RQ + k], sb.cap_r); o_r = true; }
     }
   }
+  if (o_cand) halve(cp.div_cand);
+  if (o_nores) halve(cp.div_nores);
+  if (o_f) halve(cp.div_fwork);
+  if (o_e) halve(cp.div_ework);
+  if (o_r) halve(cp.div_rwork);
   if (status & CS_RWORK) cp.hens *= 2;
   // zone 2 ran out (regions were deferred to the host): size the workspace from what this search asked for, for the next calls
   st.ws_cap_bytes = ctx->ws.cap; st.ws_used_bytes = (std::min<uint64_t>(h_tops[0], cd0.ws_cap) + h_tops[2]) * 4;

@@ -21,7 +21,16 @@ sys.path.insert(0, %r)
 import numpy as np
 from checkm_amd import _lib, synth
 from tests import common
-profs = common.mixed_profiles(); path = common.hmm_file("mixed", profs)
+import os
+if os.environ.get("CKM_TEST_SHAPE") == "classes":
+    # one model per SSV launch class and more (lengths 24, 48, ... 2040, and 2100 beyond the SSV image): with the long / short split
+    # of the lane that is > 100 groups of queues and streams in ONE search
+    prng = np.random.default_rng(77)
+    profs = [synth.random_profile(prng, M, "c%%04d" %% M, "PF%%05d.1" %% (50000 + M)) for M in list(range(24, 2049, 24)) + [2100]]
+    for p in profs: p.stats = (-8.5 - 0.002 * p.M, 0.71, -9.5 - 0.002 * p.M, 0.71, -3.8, 0.71); p.ga = (25.0, 25.0)
+    path = common.hmm_file("classes", profs)
+else:
+    profs = common.mixed_profiles(); path = common.hmm_file("mixed", profs)
 rng = np.random.default_rng(5)
 bins = [synth.make_bin(profs, 8800 + b, n_orfs=260, dup_frac=0.4) for b in range(6)]
 # a tandem repeat (multi-domain region -> trace ensemble) in every other bin
@@ -71,3 +80,13 @@ def test_device_cascade_equals_host_cascade():
     # device-side tables far too small: the lane is handed to the host-driven cascade (and the tables grow for the next call)
     tiny = _run(CKM_WORKERS="1", CKM_CAP_SHRINK="64")
     assert tiny["fallback"] >= 1 and tiny["rows"] == host["rows"]
+
+
+def test_one_search_with_every_model_length_class():
+    """A database whose models fall into every SSV launch class (the 8-lane classes, the 16-lane classes, and the no-SSV class beyond 2048
+    nodes): more than a hundred groups in one device-driven search -- no fallback (round 3's first 8-lane build overran a 64-group limit
+    and quietly ran configs[4]-shaped searches on the host-driven cascade), rows equal to the host-driven cascade's."""
+    host = _run(CKM_CASCADE="host", CKM_WORKERS="1", CKM_TEST_SHAPE="classes")
+    dev = _run(CKM_WORKERS="1", CKM_SPLIT_MIN_PAIRS="1", CKM_TEST_SHAPE="classes")
+    assert len(host["rows"]) >= 6 * 86
+    assert dev["fallback"] == 0 and dev["rows"] == host["rows"] and dev["pairs"][0] == host["pairs"][0]
