@@ -74,6 +74,14 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
         HIPCHK(hipStreamCreateWithFlags(&w.side[k], hipStreamNonBlocking));
       }
       w.ens_stream = w.side[nside - 1];
+      {
+        // the rounds after a search's drain (envelopes of the ensembles' clustering, deferred regions: milliseconds of device work the
+        // host waits for) must not queue behind ANOTHER context's SSV launches, whose backlog holds the normal-priority hardware queues
+        // for the whole SSV phase (measured: 5 ms of kernels returned after 490 ms, profiles/r03t_lane_trace.txt)
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        for (auto &st : w.late) HIPCHK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
+      }
       for (auto &e : w.ev) HIPCHK(hipEventCreate(&e));
       for (auto &e : w.cev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       for (auto &e : w.cls_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -116,6 +124,7 @@ extern "C" void ckm_ctx_destroy(ckm_ctx *ctx) {
     for (auto &e : w.cls_ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : w.grp_ev) if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < w.nside; ++k) (void)hipStreamDestroy(w.side[k]);
+    for (auto &st : w.late) if (st) (void)hipStreamDestroy(st);
     (void)hipStreamDestroy(w.stream);
   }
   delete ctx;
@@ -258,13 +267,29 @@ static void finish_seqs(ckm_seqs *s) {
   }
   s->order_off[nbins] = (uint32_t)s->order.size();
   build_lentab(s);
-  s->d_res.ensure(s->dsq.size()); HIPCHK(hipMemcpy(s->d_res.p, s->dsq.data(), s->dsq.size(), hipMemcpyHostToDevice));
-  s->d_off.ensure(std::max<size_t>(8, (size_t)nseq * 8)); if (nseq) HIPCHK(hipMemcpy(s->d_off.p, s->off.data(), (size_t)nseq * 8, hipMemcpyHostToDevice));
-  s->d_len.ensure(std::max<size_t>(4, (size_t)nseq * 4)); if (nseq) HIPCHK(hipMemcpy(s->d_len.p, s->len.data(), (size_t)nseq * 4, hipMemcpyHostToDevice));
-  s->d_order.ensure(std::max<size_t>(4, s->order.size() * 4));
-  if (!s->order.empty()) HIPCHK(hipMemcpy(s->d_order.p, s->order.data(), s->order.size() * 4, hipMemcpyHostToDevice));
-  s->d_lentab.ensure(s->lentab.size() * sizeof(LenEntry));
-  HIPCHK(hipMemcpy(s->d_lentab.p, s->lentab.data(), s->lentab.size() * sizeof(LenEntry), hipMemcpyHostToDevice));
+  // uploads on one of the context's high-priority streams: a plain hipMemcpy travels on the null stream, whose hardware queue it shares
+  // with whatever streams were mapped onto it -- behind another context's SSV backlog the 40 ms ingest of a batch took 420 ms
+  // (profiles/r03t_lane_trace.txt)
+  hipStream_t up = s->ctx->w[0].late[3];
+  trace_pt(&s->ctx->w[0], "seqs: tables built");
+  s->d_res.ensure(s->dsq.size() + 16); s->d_off.ensure((size_t)nseq * 8 + 16); s->d_len.ensure((size_t)nseq * 4 + 16);       // (+16: the copy kernel moves 16-byte words)
+  s->d_order.ensure(s->order.size() * 4 + 16); s->d_lentab.ensure(s->lentab.size() * sizeof(LenEntry) + 16);
+  trace_pt(&s->ctx->w[0], "seqs: device buffers allocated");
+  // ... and by a KERNEL that reads a page-locked staging buffer of the context over the bus: the runtime's copy path (pageable or
+  // pinned source alike) was seen to wait until the device had drained -- one upload in three took 370 ms instead of 3 -- while kernels
+  // on the high-priority streams start within a millisecond
+  {
+    std::lock_guard<std::mutex> lock(s->ctx->upload_mutex);
+    struct Part { DevBuf *d; const void *src; size_t bytes; };
+    const Part parts[5] = {{&s->d_res, s->dsq.data(), s->dsq.size()}, {&s->d_off, s->off.data(), (size_t)nseq * 8}, {&s->d_len, s->len.data(), (size_t)nseq * 4},
+                           {&s->d_order, s->order.data(), s->order.size() * 4}, {&s->d_lentab, s->lentab.data(), s->lentab.size() * sizeof(LenEntry)}};
+    size_t tot = 0;
+    for (auto &pt : parts) tot += (pt.bytes + 255) & ~(size_t)255;
+    s->ctx->upload.begin(tot);
+    for (auto &pt : parts) s->ctx->upload.put(up, pt.d->p, pt.src, pt.bytes);
+    HIPCHK(hipStreamSynchronize(up));
+  }
+  trace_pt(&s->ctx->w[0], "seqs: uploaded");
 }
 
 extern "C" int ckm_seqs_pack(ckm_ctx *ctx, const char *text, const uint64_t *seq_off, uint32_t nseq,
@@ -305,6 +330,7 @@ extern "C" int ckm_seqs_from_fasta(ckm_ctx *ctx, const char *const *paths, uint3
   return guarded([&] {
     if (!ctx || !paths || !out) throw Error(CKM_EINVAL, "NULL argument");
     *out = nullptr;
+    trace_pt(&ctx->w[0], "seqs: begin");
     if (nbins == 0) throw Error(CKM_EINVAL, "no bins");
     HIPCHK(hipSetDevice(ctx->device));
     std::unique_ptr<ckm_seqs> s(new ckm_seqs());
@@ -312,6 +338,7 @@ extern "C" int ckm_seqs_from_fasta(ckm_ctx *ctx, const char *const *paths, uint3
     s->bin_off.assign(nbins + 1, 0);
     // the files are read and digitised on a few threads (fasta_ingest.cpp), then laid end to end
     std::vector<FastaBin> bins = read_fasta_bins(paths, nbins, (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+    trace_pt(&ctx->w[0], "seqs: files read");
     uint64_t pos = 0; size_t nrec = 0;
     for (auto &fb : bins) { if (fb.err_code) throw Error(fb.err_code, fb.err); pos += fb.dsq.size(); nrec += fb.names.size(); }
     s->dsq.reserve(pos + 16); s->names.reserve(nrec); s->descs.reserve(nrec); s->len.reserve(nrec); s->off.reserve(nrec);

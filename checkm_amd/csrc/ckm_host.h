@@ -97,6 +97,22 @@ struct PinnedBuf {      // grow-only page-locked host staging buffer (pageable D
 };
 
 
+// Host -> device through a page-locked staging area and a copy KERNEL on the caller's stream.  The runtime's own copy path
+// (hipMemcpyAsync, pageable or pinned source alike) was seen to hold a 3 ms upload for 370 ms -- until another context's SSV launches and
+// chains had drained -- about one time in three (profiles/r03t_lane_trace.txt); kernels on the high-priority streams start at once.
+void launch_upload(hipStream_t st, void *dst, const void *src_pinned, size_t bytes);
+struct Stager {
+  PinnedBuf buf; size_t top = 0;
+  void begin(size_t total) { buf.ensure(total + 2048); top = 0; }            // (nothing of the previous round may still be in flight)
+  void put(hipStream_t st, void *dst, const void *src, size_t bytes) {
+    if (!bytes) return;
+    if (top + bytes > buf.cap) throw Error(CKM_EINVAL, "staging area too small (Stager::begin)");
+    memcpy(buf.as<uint8_t>() + top, src, bytes);
+    launch_upload(st, dst, buf.as<uint8_t>() + top, bytes);
+    top += (bytes + 255) & ~(size_t)255;
+  }
+};
+
 }  // namespace ckm
 
 using namespace ckm;      // internal header: every includer is one of the four files above
@@ -131,6 +147,9 @@ struct Worker {
   PinnedBuf h_cnt, h_pass, h_reg, h_envout, h_events_f, h_events_e, h_hens, h_tops;
   hipEvent_t cev[4] = {nullptr, nullptr, nullptr, nullptr};      // fork / join points of the lane's chain
   hipEvent_t cls_ev[16] = {};                                    // one per side stream
+  Stager stager;                                                 // staging of the per-search uploads (plan, late rounds)
+  hipStream_t late[4] = {};                                      // high-priority streams of the short rounds that follow a search's drain (run_fb with late_round set)
+  bool late_round = false;
   hipEvent_t grp_ev[192] = {};                                    // end of the SSV launch of each model-length group
 };
 
@@ -155,6 +174,7 @@ struct ckm_ctx {
   ckm_search_stats stats;
   std::mutex ssv_mutex;                   // SSV phases are VALU-bound: two of them side by side gain nothing
   std::condition_variable ssv_cv; int ssv_turn = 0;    // workers take their first SSV phase in worker order (largest chunk first)
+  std::mutex upload_mutex; Stager upload;               // staging of the sequence uploads (finish_seqs)
   std::thread reserve_thread;                          // ckm_ctx_reserve: background allocation of lane 0's float workspace
   std::string reserve_error;
   void settle() { if (reserve_thread.joinable()) reserve_thread.join(); }      // every entry point that touches the workspace calls this first

@@ -462,6 +462,12 @@ template <class T> T *pin_table(PinnedBuf &b, size_t n) { b.ensure(std::max<size
 
 }  // namespace
 
+// One SSV phase at a time per device, across contexts (see cascade_dev).  The events belong to the baton and live as long as the process.
+struct DeviceBaton { std::mutex m; hipEvent_t ev[2] = {nullptr, nullptr}; int k = 0; bool recorded = false; };
+static DeviceBaton &device_baton(int dev) { static DeviceBaton b[64]; return b[(unsigned)dev & 63]; }
+static bool late_on() { static const bool on = !(getenv("CKM_LATE_PRIO") && atoi(getenv("CKM_LATE_PRIO")) == 0); return on; }
+static bool baton_on() { static const bool on = !(getenv("CKM_SSV_BATON") && atoi(getenv("CKM_SSV_BATON")) == 0); return on; }
+
 static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles *p, const ckm_seqs *s, const SeqRange &rng,
                         const std::vector<uint32_t> &my_models, const std::vector<std::vector<uint32_t>> &model_bins, HitMap &by_bin_model) {
   HIPCHK(hipSetDevice(ctx->device));
@@ -602,8 +608,10 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
         groups.push_back({kv.first, {first, allw.size() - first}});
       }
       ctx->work.ensure(allw.size() * sizeof(SsvBlockWork));
-      HIPCHK(hipMemcpyAsync(ctx->work.p, allw.data(), allw.size() * sizeof(SsvBlockWork), hipMemcpyHostToDevice, ms));
-      HIPCHK(hipStreamSynchronize(ms));            // allw goes out of scope (pageable source); nothing of this search is queued on ms yet
+      // (staged, copied by a kernel on a high-priority stream: see Stager)
+      ctx->stager.begin(allw.size() * sizeof(SsvBlockWork));
+      ctx->stager.put(ctx->late[2], ctx->work.p, allw.data(), allw.size() * sizeof(SsvBlockWork));
+      HIPCHK(hipStreamSynchronize(ctx->late[2]));  // the host waits, so everything queued below comes after
       ctx->plan_key = key; ctx->plan_groups = groups; ctx->plan_nblocks = allw.size(); ctx->plan_pairs = c_pairs; ctx->plan_residue_hmm = c_res; ctx->plan_cells = c_cells;
     }
   }
@@ -720,6 +728,17 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   HIPCHK(hipMemsetAsync(d_gcnt, 0, (NG + 1) * CC_SIZE * sizeof(uint32_t), ms));
   HIPCHK(hipMemsetAsync(d_tops, 0, 4 * sizeof(unsigned long long), ms));
   if (owner->ssv_prev_done) HIPCHK(hipStreamWaitEvent(ms, owner->ssv_prev_done, 0));     // previous lane's SSV launches
+  // ... and the SSV launches of whichever search was queued on this DEVICE before this one, another context's included (find() keeps two
+  // contexts in flight): two SSV phases side by side finish together, the two host threads then do their between-searches work at the
+  // same time and the device waits for both (measured: 18.6 % of a 1000-bin step idle, profiles/r03r_timeline_cfg3_1000bins.txt);
+  // one behind the other, each search's tail, copies and host work lie underneath the other's SSV phase.  CKM_SSV_BATON=0: off.
+  DeviceBaton &baton = device_baton(owner->device);
+  std::unique_lock<std::mutex> baton_lock(baton.m, std::defer_lock);
+  if (baton_on()) {
+    baton_lock.lock();
+    if (!baton.ev[0]) for (auto &e : baton.ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (baton.recorded) HIPCHK(hipStreamWaitEvent(ms, baton.ev[baton.k], 0));
+  }
   HIPCHK(hipEventRecord(ctx->ev[0], ms));
   HIPCHK(hipEventRecord(ctx->cev[0], ms));
   for (int k = 0; k < NS; ++k) HIPCHK(hipStreamWaitEvent(ctx->side[k], ctx->cev[0], 0));
@@ -801,6 +820,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   for (int k = 0; k < NSS; ++k) { HIPCHK(hipEventRecord(ctx->cls_ev[k], ctx->side[k])); HIPCHK(hipStreamWaitEvent(ms, ctx->cls_ev[k], 0)); }
   HIPCHK(hipEventRecord(ctx->ev[1], ms));                    // ev[0]..ev[1] brackets the lane's SSV launches (with NCH == 0: and the chains queued behind them)
   HIPCHK(hipEventRecord(ctx->cev[1], ms));
+  if (baton_lock.owns_lock()) { baton.k ^= 1; HIPCHK(hipEventRecord(baton.ev[baton.k], ms)); baton.recorded = true; baton_lock.unlock(); }
   {
     std::unique_lock<std::mutex> lock(owner->ssv_mutex);
     owner->ssv_prev_done = ctx->cev[1];
@@ -937,6 +957,8 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   }
   CKM_TRACE_PT("clustering done");
   std::exception_ptr early_err;
+  struct LateGuard { Worker *w; ~LateGuard() { w->late_round = false; } } late_guard{ctx};
+  ctx->late_round = late_on();
   std::thread early_thread;
   if (!early_req.empty())
     early_thread = std::thread([&] {

@@ -13,10 +13,27 @@ void wcopy(Worker *w, void *dst, const void *src, size_t bytes, hipMemcpyKind ki
   HIPCHK(hipStreamSynchronize(w->stream));
 }
 
+typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+__global__ void upload_kernel(u32x4s *__restrict__ dst, const u32x4s *__restrict__ src, size_t n16, uint32_t tail) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+  if (blockIdx.x == 0 && threadIdx.x < tail) reinterpret_cast<uint8_t *>(dst + n16)[threadIdx.x] = reinterpret_cast<const uint8_t *>(src + n16)[threadIdx.x];
+}
+void launch_upload(hipStream_t st, void *dst, const void *src_pinned, size_t bytes) {
+  if (!bytes) return;
+  const size_t n16 = bytes / 16;
+  upload_kernel<<<(unsigned)std::max<size_t>(1, std::min<size_t>(1024, (n16 + 255) / 256)), 256, 0, st>>>(
+      reinterpret_cast<u32x4s *>(dst), reinterpret_cast<const u32x4s *>(src_pinned), n16, (uint32_t)(bytes % 16));
+  HIPCHK(hipGetLastError());
+}
+
 static const bool g_trace_on = getenv("CKM_TRACE") != nullptr;
 static double g_trace_origin = 0;
 void trace_begin() { g_trace_origin = now_ms(); }
-void trace_pt(const Worker *w, const char *label) { if (g_trace_on) fprintf(stderr, "ckm-trace w%d %8.3f %s\n", w->id, now_ms() - g_trace_origin, label); }
+static const bool g_trace_abs = g_trace_on && atoi(getenv("CKM_TRACE")) >= 2;    // CKM_TRACE=2: the monotonic clock itself (ms, as Python's time.monotonic()) + the worker's address
+void trace_pt(const Worker *w, const char *label) {
+  if (g_trace_abs) fprintf(stderr, "ckm-trace %p %12.3f %s\n", (const void *)w, now_ms(), label);
+  else if (g_trace_on) fprintf(stderr, "ckm-trace w%d %8.3f %s\n", w->id, now_ms() - g_trace_origin, label);
+}
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -66,8 +83,10 @@ void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, b
   const size_t n = b.work.size();
   if (!n) return;
   trace_pt(ctx, "  fb begin");
+  const bool late = ctx->late_round;          // (set by the device-driven cascade for the rounds after its drain: high-priority streams)
+  hipStream_t su = late ? ctx->late[3] : ctx->stream;       // uploads: staged + copied by a kernel in the late rounds (see Stager), the runtime's copies otherwise
   ctx->fbwork.ensure(n * sizeof(FbWork));
-  HIPCHK(hipMemcpyAsync(ctx->fbwork.p, b.work.data(), n * sizeof(FbWork), hipMemcpyHostToDevice, ctx->stream));
+  if (!late) HIPCHK(hipMemcpyAsync(ctx->fbwork.p, b.work.data(), n * sizeof(FbWork), hipMemcpyHostToDevice, su));
   // one queue per canonical Q (register class), longest items first; a wavefront reloads its LDS image when the model changes
   std::map<int, std::vector<uint32_t>> byQ;
   auto add = [&](uint32_t i) { byQ[p->prof[b.work[i].model].fbQ].push_back(i); };
@@ -85,8 +104,15 @@ void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, b
   std::vector<uint32_t> qc(groups.size(), 0u);           // queue lengths
   for (size_t g = 0; g < groups.size(); ++g) qc[g] = (uint32_t)groups[g].count;
   ctx->fbidx.ensure(items.size() * 4 + 16); ctx->fbmodel.ensure(qc.size() * 4 + 16);
-  HIPCHK(hipMemcpyAsync(ctx->fbidx.p, items.data(), items.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->fbmodel.p, qc.data(), qc.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (late) {
+    ctx->stager.begin(n * sizeof(FbWork) + items.size() * 4 + qc.size() * 4 + 1024);
+    ctx->stager.put(su, ctx->fbwork.p, b.work.data(), n * sizeof(FbWork));
+    ctx->stager.put(su, ctx->fbidx.p, items.data(), items.size() * 4);
+    ctx->stager.put(su, ctx->fbmodel.p, qc.data(), qc.size() * 4);
+  } else {
+    HIPCHK(hipMemcpyAsync(ctx->fbidx.p, items.data(), items.size() * 4, hipMemcpyHostToDevice, su));
+    HIPCHK(hipMemcpyAsync(ctx->fbmodel.p, qc.data(), qc.size() * 4, hipMemcpyHostToDevice, su));
+  }
   ctx->fout.ensure(n * sizeof(FwdOut));
   ctx->rerr.ensure(n * 4);
   ctx->envout.ensure(n * sizeof(EnvOut));
@@ -98,14 +124,14 @@ void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, b
   const uint8_t *res = s->d_res.as<uint8_t>();
   const uint64_t *off = s->d_off.as<uint64_t>();
   float *ws = ws_other ? ws_other : ctx->ws.as<float>();
-  if (do_fwd) HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (do_fwd) HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 64, su));
+  HIPCHK(hipStreamSynchronize(su));
   trace_pt(ctx, "  fb tables uploaded");
   // every register class runs its stages in order on its own stream; classes overlap each other
   size_t gi = 0;
   for (size_t g = 0; g < groups.size(); ++g) {
     const Group &gr = groups[g];
-    hipStream_t st = ctx->side[gi++ % side_streams()];
+    hipStream_t st = late ? ctx->late[gi++ % 4] : ctx->side[gi++ % side_streams()];
     uint32_t *qcd = ctx->fbmodel.as<uint32_t>() + g;
     const uint32_t *lst = ctx->fbidx.as<uint32_t>() + gr.first;
     const uint32_t nb = fb_grid(gr.count);
@@ -119,7 +145,8 @@ void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, b
   }
   HIPCHK(hipGetLastError());
   trace_pt(ctx, "  fb launched");
-  for (auto &st : ctx->side) HIPCHK(hipStreamSynchronize(st));
+  if (late) { for (auto &st : ctx->late) HIPCHK(hipStreamSynchronize(st)); }
+  else for (auto &st : ctx->side) HIPCHK(hipStreamSynchronize(st));
   trace_pt(ctx, "  fb kernels done");
   if (do_fwd) {
     b.fout.resize(n);

@@ -318,11 +318,16 @@ class MarkerGeneFinder(object):
                     totals[f] = max(totals.get(f, 0), getattr(st, f))
                 totals["searches"] = totals.get("searches", 0) + 1
             part = dict(seqs=seqs, hits=hits, bins=[binIds[i] for i in batch], profiles=prof)
+            if os.environ.get("CKM_TRACE") == "2":      # (same clock as the library's trace points)
+                m0 = _t.monotonic() - _t.perf_counter()
+                sys.stderr.write("find-trace lane %d batch %d ingest %.3f search %.3f .. %.3f\n" % (k % len(lanes), k, 1e3 * (m0 + t0), 1e3 * (m0 + t1), 1e3 * (m0 + t2)))
             for b, i in enumerate(batch):
                 hits.write_domtblout(prof, seqs, b, os.path.join(outDir, 'bins', binIds[i], tableOut))
                 if bKeepAlignment:            # hmmsearch's -o text with the domain alignments (markerGeneFinder.py:138-142 drops --noali)
                     hits.write_alignments(c, prof, seqs, b, os.path.join(outDir, 'bins', binIds[i], hmmerOut))
             parts[k] = part
+            if os.environ.get("CKM_TRACE") == "2":
+                sys.stderr.write("find-trace lane %d batch %d written %.3f\n" % (k % len(lanes), k, 1e3 * _t.monotonic()))
             with tot_lock:
                 totals["write_s"] = totals.get("write_s", 0.0) + (_t.perf_counter() - t2)
 
