@@ -156,7 +156,7 @@ def hmmer_leg(hmm_path, bins, threads, workdir):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def ssv_roofline(st_like, ssv_ms_per_step, bins, orfs, extra_note=""):
+def ssv_roofline(st_like, ssv_ms_per_step, bins, orfs, extra_note="", clock_hz=2.4e9):
     """roofline of the dominant kernel ssv_kernel<Q>: algorithmic bytes = sum over (model, sequence) pairs of (L + 12) over the
     kernel's time measured with HIP events on the library's streams.  HBM traffic and the VALU instruction count come from separate
     rocprofv3 --pmc passes recorded in profiles/ (tools/collect_profiles.sh); they are quoted -- with their source -- only for the
@@ -181,8 +181,8 @@ def ssv_roofline(st_like, ssv_ms_per_step, bins, orfs, extra_note=""):
         src = os.path.relpath(tf, ROOT)
         roof["traffic"] = pm["hbm_bytes_corrected"]
         roof["traffic_source"] = src + " (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass of this workload, recorded, not measured in this run)"
-        cyc = ssv_s * 2.4e9 / (pm["valu_insts"] / 1024.0)
-        valu = {"bound": "valu-issue", "wave_insts_per_step": pm["valu_insts"], "source": src + " (rocprofv3 --pmc SQ_INSTS_VALU pass, recorded)",
+        cyc = ssv_s * clock_hz / (pm["valu_insts"] / 1024.0)
+        valu = {"bound": "valu-issue", "clock_hz": clock_hz, "wave_insts_per_step": pm["valu_insts"], "source": src + " (rocprofv3 --pmc SQ_INSTS_VALU pass, recorded)",
                 "cycles_per_inst_per_simd": cyc, "measured_rate_of_this_opcode_mix": MEASURED_CYCLES_PER_INST, "frac_of_measured_rate": min(1.0, MEASURED_CYCLES_PER_INST / cyc),
                 "note": "cycles per wave64 VALU instruction per SIMD over the SSV launches of this run (HIP events; they share the SIMDs with the chain kernels), "
                         "against the rate the row body of the kernel issues at when it runs alone (tools/ubench/valu_rates.hip, profiles/%s_valu_rates.txt) -- a "
@@ -378,6 +378,7 @@ def bench_cfg2(args, env):
     for k in part_ms:
         part_ms[k] = 0.0
     ssv_ms = 0.0
+    sampler = ClockSampler(int(os.environ.get("LOCAL_RANK", "0"))).start() if rank == 0 else None
     if args.pipeline <= 1:
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -414,6 +415,7 @@ def bench_cfg2(args, env):
             sync()
             dt = time.perf_counter() - t0
     dt = all_max(dt)
+    device_state = sampler.stop() if sampler is not None else None
     per_step = dt / args.steps
     total_residue_hmm = all_sum(float(st.residue_hmm))        # every rank reports what IT scanned
     total_bins = all_sum(nb)
@@ -487,15 +489,16 @@ def bench_cfg2(args, env):
         except SystemExit as e:            # the product's error path is logger.error + sys.exit
             lineage = {"error": "lineage_wf-equivalent run failed: exit %s" % (e.code,)}
     if rank == 0:
-        roof, valu = ssv_roofline({"residue_hmm": st.residue_hmm, "pairs_ssv": st.pairs_ssv}, ssv_ms / args.steps, nb, args.orfs)
+        clock_hz = sampled_clock_hz(device_state)
+        roof, valu = ssv_roofline({"residue_hmm": st.residue_hmm, "pairs_ssv": st.pairs_ssv}, ssv_ms / args.steps, nb, args.orfs, clock_hz=clock_hz)
         roof["launches_per_step"] = int(st.ssv_launches)
         step_util = None
         if valu is not None and "all_kernels_of_a_step" in valu:
             ak = valu.pop("all_kernels_of_a_step")
             # the whole step against the device: every kernel's VALU instructions over the step's wall time (the SSV launches share the
             # SIMDs with the chains of the other groups, so the per-kernel fraction above understates how busy the device is)
-            cyc = per_step * 2.4e9 / (ak["wave_insts"] / 1024.0)
-            step_util = {"valu_wave_insts_per_step": ak["wave_insts"], "cycles_per_inst_per_simd": cyc,
+            cyc = per_step * clock_hz / (ak["wave_insts"] / 1024.0)
+            step_util = {"clock_hz": clock_hz, "valu_wave_insts_per_step": ak["wave_insts"], "cycles_per_inst_per_simd": cyc,
                          "valu_frac_of_measured_rate": min(1.0, MEASURED_CYCLES_PER_INST / cyc), "hbm_bytes_per_step": ak["hbm_bytes"],
                          "hbm_frac": ak["hbm_bytes"] / per_step / 1e9 / HBM_PEAK_GBS,
                          "source": ak["source"] + " (recorded PMC passes of this workload) over this run's ms_per_step"}
@@ -503,6 +506,7 @@ def bench_cfg2(args, env):
             "metric": "residues*HMMs/s (marker-gene scan+reduce, cfg2: 43 profiles x 100 synthetic 2 Mb bins per GPU)",
             "value": value, "unit": "residue*HMM/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": per_step * 1e3, "steps_in_flight": args.pipeline, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "device_state_timed_region": device_state,
             "dtype": "i16 (SSV/MSV bytes, Viterbi words) + f32 (Forward/Backward)", "data": "synthetic",
             "config": {"workload": "configs[1]: cpr_43-shaped 43 synthetic profiles (M 63..900, sum M %d) x %d bins x %d ORFs %s"
                                    % (sum(p.M for p in profs), nb if args.scaling == "weak" else args.bins_total, args.orfs,
@@ -669,6 +673,72 @@ def bench_cfg5(args, env):
     return line
 
 
+def sampled_clock_hz(device_state):
+    """Mean shader clock of the timed region (ClockSampler), or the 2.4 GHz boost clock of MI355X_MICROARCH.md when it was not sampled."""
+    try:
+        return float(device_state["sclk_mhz"]["mean"]) * 1e6
+    except (TypeError, KeyError):
+        return 2.4e9
+
+
+class ClockSampler(object):
+    """Shader clock / board power / temperature of this rank's GPU from the amdgpu hwmon files, sampled twice a second while the timed
+    region runs (a saturated device may sit below its boost clock: the cycle counts of `roofline_valu` assume 2.4 GHz).  None when the
+    files are not there."""
+
+    def __init__(self, index=0):
+        import glob
+        self.files, self.samples, self._stop, self._thread = None, [], False, None
+        cards = []
+        for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            try:
+                if open(os.path.join(d, "vendor")).read().strip() == "0x1002":
+                    cards.append(d)
+            except OSError:
+                pass
+        if index < len(cards):
+            hw = sorted(glob.glob(os.path.join(cards[index], "hwmon", "hwmon*")))
+            if hw:
+                pick = lambda names: next((os.path.join(hw[0], n) for n in names if os.path.exists(os.path.join(hw[0], n))), None)
+                self.files = {"sclk_mhz": (pick(["freq1_input"]), 1e-6), "power_w": (pick(["power1_average", "power1_input"]), 1e-6),
+                              "temp_c": (pick(["temp2_input", "temp1_input"]), 1e-3)}
+
+    def _read(self):
+        row = {}
+        for k, (f, scale) in self.files.items():
+            try:
+                row[k] = float(open(f).read().strip()) * scale if f else None
+            except (OSError, ValueError):
+                row[k] = None
+        return row
+
+    def start(self):
+        if self.files is None:
+            return self
+        import threading
+
+        def loop():
+            while not self._stop:
+                self.samples.append(self._read())
+                time.sleep(0.5)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        if self._thread is None:
+            return None
+        self._stop = True
+        self._thread.join()
+        out = {"samples": len(self.samples)}
+        for k in ("sclk_mhz", "power_w", "temp_c"):
+            v = [r[k] for r in self.samples if r.get(k) is not None]
+            if v:
+                out[k] = {"min": round(min(v), 1), "mean": round(sum(v) / len(v), 1), "max": round(max(v), 1)}
+        out["note"] = "amdgpu hwmon (freq1_input, power1_average, junction temperature), every 0.5 s over the timed region"
+        return out
+
+
 def gene_front_end():
     """SURVEY 8f N1, first slice: the codon-flag kernel of the gene-calling front end (checkm_amd/csrc/kernels_orf.hip) is a pure streaming
     kernel -- 1 byte read + 1 byte written per base -- so it is the one kernel of this repository priced against the HBM roofline it is
@@ -729,6 +799,7 @@ def bench_cfg3(args, env):
         import cProfile
         prof = cProfile.Profile()
     env.sync()
+    sampler = ClockSampler(int(os.environ.get("LOCAL_RANK", "0"))).start() if rank == 0 else None
     t0 = time.perf_counter()
     if prof is not None:
         prof.enable()
@@ -738,6 +809,7 @@ def bench_cfg3(args, env):
         prof.disable()
     env.sync()
     dt = env.all_max(time.perf_counter() - t0)
+    device_state = sampler.stop() if sampler is not None else None
     if prof is not None:
         import io
         import pstats
@@ -755,20 +827,23 @@ def bench_cfg3(args, env):
     roof, _valu = ssv_roofline(tot, tot.get("ms_ssv", 0.0), -1, -1, "; cfg3: summed over the %d ckm_search calls of rank 0's batches in one step" % tot.get("searches", 0))
     roof["launches_per_step"] = int(tot.get("ssv_launches", 0))
     valu = step_util = None
+    clock_hz = sampled_clock_hz(device_state)
     cnt = cfg3_counters(roof["algorithmic_bytes"])
     if cnt is not None:
         roof["traffic"] = cnt["hbm_bytes"]
         roof["traffic_source"] = "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a cfg3 sample (%s), scaled by algorithmic bytes x %.1f" % (cnt["source"], cnt["sample"], cnt["scale"])
-        cyc = (tot.get("ms_ssv", 0.0) / 1e3) * 2.4e9 / (cnt["valu_insts"] / 1024.0)
-        valu = {"bound": "valu-issue", "wave_insts_per_step": cnt["valu_insts"], "source": cnt["source"] + " (--pmc SQ_INSTS_VALU pass of the sample, scaled)",
+        cyc = (tot.get("ms_ssv", 0.0) / 1e3) * clock_hz / (cnt["valu_insts"] / 1024.0)
+        valu = {"bound": "valu-issue", "clock_hz": clock_hz, "wave_insts_per_step": cnt["valu_insts"], "source": cnt["source"] + " (--pmc SQ_INSTS_VALU pass of the sample, scaled)",
                 "cycles_per_inst_per_simd": cyc, "measured_rate_of_this_opcode_mix": MEASURED_CYCLES_PER_INST, "frac_of_measured_rate": min(1.0, MEASURED_CYCLES_PER_INST / cyc),
-                "note": "time = HIP events over the SSV launches of every search of this run, SUMMED: the two scan lanes' SSV phases overlap in time (the sum can exceed the step) and "
-                        "share the SIMDs with the chain kernels of the groups ahead of them -- step_utilisation prices the whole step instead; the rate is what "
+                "note": "time = HIP events over the SSV launches of every search of this run, summed (one SSV phase at a time per device since the contexts share a baton); "
+                        "the launches share the SIMDs with the chain kernels of the groups ahead of them and of the other context's search -- step_utilisation prices "
+                        "the whole step instead; the rate is what "
                         "tools/ubench/valu_rates.hip measures for the row body of the kernel alone (profiles/%s_valu_rates.txt), not an architectural peak" % PROFILE_TAG}
     if cnt is not None:
         # the whole step against the device: every kernel's VALU instructions (scaled from the sample's PMC passes) over the step's wall time
-        cyc = per_step * 2.4e9 / (cnt["all_valu_insts"] / 1024.0)
-        step_util = {"valu_wave_insts_per_step": cnt["all_valu_insts"], "cycles_per_inst_per_simd": cyc, "valu_frac_of_measured_rate": min(1.0, MEASURED_CYCLES_PER_INST / cyc),
+        cyc = per_step * clock_hz / (cnt["all_valu_insts"] / 1024.0)
+        step_util = {"clock_hz": clock_hz, "clock_note": "mean shader clock sampled over the timed region (device_state_timed_region); 2.4 GHz when the hwmon files are absent",
+                     "valu_wave_insts_per_step": cnt["all_valu_insts"], "cycles_per_inst_per_simd": cyc, "valu_frac_of_measured_rate": min(1.0, MEASURED_CYCLES_PER_INST / cyc),
                      "hbm_bytes_per_step": cnt["all_hbm_bytes"], "hbm_frac": cnt["all_hbm_bytes"] / per_step / 1e9 / HBM_PEAK_GBS,
                      "source": cnt["source"] + " (all kernels of the 48-bin sample's step, scaled by algorithmic bytes) over this run's ms_per_step"}
     out = {"metric": "bins/hour (lineage_wf-equiv marker path: tree pass + analyze pass + qa, from genes.faa files) + residues*HMMs/s",
@@ -791,7 +866,7 @@ def bench_cfg3(args, env):
                                       "note": "ingest/search/write are summed over the two scan lanes (they overlap in time); tree_find + analyze_find + qa = the step"},
            "searches_rank0": int(tot.get("searches", 0)), "cascade_fallback_lanes_rank0": int(tot.get("cascade_fallback_lanes", 0)),
            "workspace_rank0": {"allocated_bytes_max": int(tot.get("ws_cap_bytes", 0)), "high_water_bytes_max": int(tot.get("ws_used_bytes", 0))},
-           "setup_s": {"world_and_files": t_setup}}
+           "device_state_timed_region": device_state, "setup_s": {"world_and_files": t_setup}}
     if emu:
         out["emulated_rank"] = "%d/%d" % emu
         out["metric"] += " -- EMULATION of rank %d of %d on one GPU (shard of the bins, all-bins host work, no collective)" % emu
@@ -825,7 +900,7 @@ def bench_cfg3(args, env):
             a2.steps, a2.warmup, a2.lineage_bins, a2.no_cpu_baseline, a2.scaling, a2.pipeline, a2.bins, a2.orfs = 5, 2, 0, True, "weak", 1, 100, 2000
             c2 = bench_cfg2(a2, env)
             out["cfg2"] = {k: c2[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "steady_state", "value_from_host", "gcups_ssv", "roofline",
-                                              "roofline_valu", "step_utilisation", "stages_ms", "step_parts_ms", "stage_pairs", "rows")}
+                                              "roofline_valu", "step_utilisation", "stages_ms", "step_parts_ms", "stage_pairs", "rows", "device_state_timed_region")}
     else:
         out["cpu_baseline"] = None
     return out

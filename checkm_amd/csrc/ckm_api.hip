@@ -80,6 +80,7 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
         // for the whole SSV phase (measured: 5 ms of kernels returned after 490 ms, profiles/r03t_lane_trace.txt)
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        if (getenv("CKM_LATE_NORMAL")) hi = 0;           // (experiment: the same streams at normal priority)
         for (auto &st : w.late) HIPCHK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
       }
       for (auto &e : w.ev) HIPCHK(hipEventCreate(&e));

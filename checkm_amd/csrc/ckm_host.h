@@ -147,6 +147,7 @@ struct Worker {
   PinnedBuf h_cnt, h_pass, h_reg, h_envout, h_events_f, h_events_e, h_hens, h_tops;
   hipEvent_t cev[4] = {nullptr, nullptr, nullptr, nullptr};      // fork / join points of the lane's chain
   hipEvent_t cls_ev[16] = {};                                    // one per side stream
+  PinnedBuf wstage; std::mutex wstage_mutex;                     // wcopy's staging buffer
   Stager stager;                                                 // staging of the per-search uploads (plan, late rounds)
   hipStream_t late[4] = {};                                      // high-priority streams of the short rounds that follow a search's drain (run_fb with late_round set)
   bool late_round = false;

@@ -8,9 +8,21 @@ namespace ckm {
 void pool_run(Worker *w, size_t n, size_t chunk, const std::function<void(size_t, size_t)> &f) { if (w->pool) w->pool->run(n, chunk, f); else if (n) f(0, n); }
 
 // blocking copy on the worker's own stream (a plain hipMemcpy would wait for every blocking stream of the device)
+// Through the worker's own page-locked staging buffer: a copy to or from pageable memory has the runtime pin or stage that memory per call
+// (measured in a process that holds a few hundred device allocations: 1.5 ms per small copy, 7.6 ms for the four of a late round).
 void wcopy(Worker *w, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
-  HIPCHK(hipMemcpyAsync(dst, src, bytes, kind, w->stream));
-  HIPCHK(hipStreamSynchronize(w->stream));
+  if (!bytes) return;
+  std::lock_guard<std::mutex> lock(w->wstage_mutex);
+  w->wstage.ensure(bytes);
+  if (kind == hipMemcpyDeviceToHost) {
+    HIPCHK(hipMemcpyAsync(w->wstage.p, src, bytes, kind, w->stream));
+    HIPCHK(hipStreamSynchronize(w->stream));
+    memcpy(dst, w->wstage.p, bytes);
+  } else {
+    memcpy(w->wstage.p, src, bytes);
+    HIPCHK(hipMemcpyAsync(dst, w->wstage.p, bytes, kind, w->stream));
+    HIPCHK(hipStreamSynchronize(w->stream));
+  }
 }
 
 typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
