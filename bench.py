@@ -378,7 +378,7 @@ def bench_cfg2(args, env):
     for k in part_ms:
         part_ms[k] = 0.0
     ssv_ms = 0.0
-    sampler = ClockSampler(int(os.environ.get("LOCAL_RANK", "0"))).start() if rank == 0 else None
+    sampler = ClockSampler(env.dev_index).start() if rank == 0 else None
     if args.pipeline <= 1:
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -689,19 +689,19 @@ class ClockSampler(object):
     def __init__(self, index=0):
         import glob
         self.files, self.samples, self._stop, self._thread = None, [], False, None
-        cards = []
-        for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
-            try:
-                if open(os.path.join(d, "vendor")).read().strip() == "0x1002":
-                    cards.append(d)
-            except OSError:
-                pass
-        if index < len(cards):
-            hw = sorted(glob.glob(os.path.join(cards[index], "hwmon", "hwmon*")))
-            if hw:
-                pick = lambda names: next((os.path.join(hw[0], n) for n in names if os.path.exists(os.path.join(hw[0], n))), None)
-                self.files = {"sclk_mhz": (pick(["freq1_input"]), 1e-6), "power_w": (pick(["power1_average", "power1_input"]), 1e-6),
-                              "temp_c": (pick(["temp2_input", "temp1_input"]), 1e-3)}
+        # the hwmon directory of THIS device, found through its PCI address (the box may show other GPUs in sysfs that are not ours)
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(index)
+            addr = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            return
+        hw = sorted(glob.glob(os.path.join("/sys/bus/pci/devices", addr, "hwmon", "hwmon*")))
+        if hw:
+            pick = lambda names: next((os.path.join(hw[0], n) for n in names if os.path.exists(os.path.join(hw[0], n))), None)
+            self.files = {"sclk_mhz": (pick(["freq1_input"]), 1e-6), "power_w": (pick(["power1_average", "power1_input"]), 1e-6),
+                          "temp_c": (pick(["temp2_input", "temp1_input"]), 1e-3)}
+            self.addr = addr
 
     def _read(self):
         row = {}
@@ -735,7 +735,7 @@ class ClockSampler(object):
             v = [r[k] for r in self.samples if r.get(k) is not None]
             if v:
                 out[k] = {"min": round(min(v), 1), "mean": round(sum(v) / len(v), 1), "max": round(max(v), 1)}
-        out["note"] = "amdgpu hwmon (freq1_input, power1_average, junction temperature), every 0.5 s over the timed region"
+        out["note"] = "amdgpu hwmon of PCI device %s (freq1_input, power1_average, junction temperature), every 0.5 s over the timed region" % self.addr
         return out
 
 
@@ -799,7 +799,7 @@ def bench_cfg3(args, env):
         import cProfile
         prof = cProfile.Profile()
     env.sync()
-    sampler = ClockSampler(int(os.environ.get("LOCAL_RANK", "0"))).start() if rank == 0 else None
+    sampler = ClockSampler(env.dev_index).start() if rank == 0 else None
     t0 = time.perf_counter()
     if prof is not None:
         prof.enable()

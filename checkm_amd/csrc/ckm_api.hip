@@ -80,8 +80,11 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
         // for the whole SSV phase (measured: 5 ms of kernels returned after 490 ms, profiles/r03t_lane_trace.txt)
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        if (getenv("CKM_LATE_NORMAL")) hi = 0;           // (experiment: the same streams at normal priority)
-        for (auto &st : w.late) HIPCHK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
+        // ONE such stream per worker (late[1..3] are the same stream): every high-priority stream is a hardware queue of its own, and with
+        // four per worker a process holding four contexts oversubscribed the device's queue slots -- every idle -> busy transition then
+        // waits for the scheduler's time slice (cfg2 measured after cfg3 in one process: 75.9 -> 98 ms per step)
+        HIPCHK(hipStreamCreateWithPriority(&w.late[0], hipStreamNonBlocking, hi));
+        for (int k = 1; k < 4; ++k) w.late[k] = w.late[0];
       }
       for (auto &e : w.ev) HIPCHK(hipEventCreate(&e));
       for (auto &e : w.cev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -125,7 +128,7 @@ extern "C" void ckm_ctx_destroy(ckm_ctx *ctx) {
     for (auto &e : w.cls_ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : w.grp_ev) if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < w.nside; ++k) (void)hipStreamDestroy(w.side[k]);
-    for (auto &st : w.late) if (st) (void)hipStreamDestroy(st);
+    if (w.late[0]) (void)hipStreamDestroy(w.late[0]);
     (void)hipStreamDestroy(w.stream);
   }
   delete ctx;

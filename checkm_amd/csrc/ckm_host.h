@@ -102,15 +102,32 @@ struct PinnedBuf {      // grow-only page-locked host staging buffer (pageable D
 // chains had drained -- about one time in three (profiles/r03t_lane_trace.txt); kernels on the high-priority streams start at once.
 void launch_upload(hipStream_t st, void *dst, const void *src_pinned, size_t bytes);
 struct Stager {
-  PinnedBuf buf; size_t top = 0;
-  void begin(size_t total) { buf.ensure(total + 2048); top = 0; }            // (nothing of the previous round may still be in flight)
-  void put(hipStream_t st, void *dst, const void *src, size_t bytes) {
-    if (!bytes) return;
-    if (top + bytes > buf.cap) throw Error(CKM_EINVAL, "staging area too small (Stager::begin)");
-    memcpy(buf.as<uint8_t>() + top, src, bytes);
-    launch_upload(st, dst, buf.as<uint8_t>() + top, bytes);
-    top += (bytes + 255) & ~(size_t)255;
+  // two page-locked halves of 16 MB, filled in turn: while the kernel that reads one half is in flight the host copies the next piece
+  // into the other (a staging area as large as a batch -- 150 MB and growing with the batches -- cost seconds of page locking in the
+  // first pass of a process).  All puts between begin() and the caller's synchronisation of the stream go to ONE stream.
+  static constexpr size_t HALF = (size_t)16 << 20;
+  PinnedBuf buf; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy[2] = {false, false}; int half = 0; size_t top = 0;
+  void begin(size_t /*total*/) {                                              // (the previous round's stream has been synchronised by its caller)
+    if (!buf.p) { buf.ensure(2 * HALF); for (auto &e : ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+    busy[0] = busy[1] = false; half = 0; top = 0;
   }
+  void put(hipStream_t st, void *dst, const void *src, size_t bytes) {
+    const uint8_t *from = static_cast<const uint8_t *>(src); uint8_t *to = static_cast<uint8_t *>(dst);
+    while (bytes) {
+      if (top == HALF) {                                                        // this half is full: mark its readers, take the other one
+        HIPCHK(hipEventRecord(ev[half], st)); busy[half] = true;
+        half ^= 1; top = 0;
+        if (busy[half]) { HIPCHK(hipEventSynchronize(ev[half])); busy[half] = false; }
+      }
+      const size_t n = std::min(bytes, HALF - top);
+      uint8_t *stage = buf.as<uint8_t>() + (size_t)half * HALF + top;
+      memcpy(stage, from, n);
+      launch_upload(st, to, stage, n);
+      top = std::min(HALF, (top + n + 255) & ~(size_t)255);
+      from += n; to += n; bytes -= n;
+    }
+  }
+  ~Stager() { for (auto &e : ev) if (e) (void)hipEventDestroy(e); }
 };
 
 }  // namespace ckm

@@ -463,7 +463,7 @@ template <class T> T *pin_table(PinnedBuf &b, size_t n) { b.ensure(std::max<size
 }  // namespace
 
 // One SSV phase at a time per device, across contexts (see cascade_dev).  The events belong to the baton and live as long as the process.
-struct DeviceBaton { std::mutex m; hipEvent_t ev[2] = {nullptr, nullptr}; int k = 0; bool recorded = false; };
+struct DeviceBaton { std::mutex m; hipEvent_t ev[2] = {nullptr, nullptr}; int k = 0; bool recorded = false; std::atomic<int> searches{0}; };
 static DeviceBaton &device_baton(int dev) { static DeviceBaton b[64]; return b[(unsigned)dev & 63]; }
 static bool late_on() { static const bool on = !(getenv("CKM_LATE_PRIO") && atoi(getenv("CKM_LATE_PRIO")) == 0); return on; }
 static bool baton_on() { static const bool on = !(getenv("CKM_SSV_BATON") && atoi(getenv("CKM_SSV_BATON")) == 0); return on; }
@@ -733,6 +733,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   // same time and the device waits for both (measured: 18.6 % of a 1000-bin step idle, profiles/r03r_timeline_cfg3_1000bins.txt);
   // one behind the other, each search's tail, copies and host work lie underneath the other's SSV phase.  CKM_SSV_BATON=0: off.
   DeviceBaton &baton = device_baton(owner->device);
+  struct InFlight { DeviceBaton &b; InFlight(DeviceBaton &x) : b(x) { b.searches++; } ~InFlight() { b.searches--; } } in_flight{baton};
   std::unique_lock<std::mutex> baton_lock(baton.m, std::defer_lock);
   if (baton_on()) {
     baton_lock.lock();
@@ -957,8 +958,9 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   }
   CKM_TRACE_PT("clustering done");
   std::exception_ptr early_err;
+  // (only when another search is in flight on the device: alone, the normal streams run the round's register classes side by side)
   struct LateGuard { Worker *w; ~LateGuard() { w->late_round = false; } } late_guard{ctx};
-  ctx->late_round = late_on();
+  ctx->late_round = late_on() && baton.searches.load() > 1;
   std::thread early_thread;
   if (!early_req.empty())
     early_thread = std::thread([&] {

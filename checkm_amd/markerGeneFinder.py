@@ -22,6 +22,7 @@ from checkm_amd.markerSets import MarkerSetParser, wanted_model
 SCAN_CACHE = {}
 
 PAIR_BUDGET = int(os.environ.get("CKM_FIND_PAIR_BUDGET", str(250 * 1000 * 1000)))   # (ORF, model) pairs per ckm_search call
+RAMP = (0.125, 0.25, 0.5)            # shares of the budgets the first batches of a find() stop at (plan_batches)
 RES_BUDGET = int(os.environ.get("CKM_FIND_RES_BUDGET", str(400 * 1000 * 1000)))      # residues (~ bytes of genes.faa) per call
 
 
@@ -96,13 +97,17 @@ def release_scan(outDir=None, final=False, background=False):
 def plan_batches(sizes, nmodels, pair_budget=None, res_budget=None):
     """Cut the bins (given order) into contiguous batches of one ckm_search call each: the Forward/Backward workspace of a call grows
     with its (ORF, model) pairs, so a batch stops before PAIR_BUDGET pairs (ORFs estimated from the file size at ~320 bytes per
-    record) or RES_BUDGET residues.  Returns a list of index lists."""
+    record) or RES_BUDGET residues.  The first three batches stop at 1/8, 1/4 and 1/2 of the budgets: the device has nothing to do
+    until the first batch's files are read (0.4 s at the start of a 1000-bin tree pass with full-size batches,
+    profiles/r03y_timeline_cfg3_1000bins.txt), and lanes that start on batches of different size do not finish together.
+    Returns a list of index lists."""
     pair_budget = PAIR_BUDGET if pair_budget is None else pair_budget
     res_budget = RES_BUDGET if res_budget is None else res_budget
     batches, cur, pairs, res = [], [], 0, 0
     for i, (sz, nm) in enumerate(zip(sizes, nmodels)):
         p = max(1, sz // 320) * max(1, nm)
-        if cur and (pairs + p > pair_budget or res + sz > res_budget):
+        f = RAMP[len(batches)] if len(batches) < len(RAMP) else 1.0
+        if cur and (pairs + p > pair_budget * f or res + sz > res_budget * f):
             batches.append(cur); cur, pairs, res = [], 0, 0
         cur.append(i); pairs += p; res += sz
     if cur:
@@ -282,18 +287,22 @@ class MarkerGeneFinder(object):
         # now, beside the reading of the first batches' FASTA files (ckm_ctx_reserve; the search waits for it)
         padded = [64 * ((h["leng"] + 63) // 64) for h in heads]
         pos_cache = {}
+        need = []                                  # per batch: (pairs, pairs x padded model positions)
+        for batch in batches:
+            pairs = mpos = 0
+            for i in batch:
+                m = models_of.get(binIds[i]) if models_of else None
+                k = id(m)
+                if k not in pos_cache:
+                    pos_cache[k] = (len(m), sum(padded[x] for x in m)) if m is not None else (len(padded), sum(padded))
+                norf = max(1, sizes[i] // 320)
+                pairs += norf * pos_cache[k][0]; mpos += norf * pos_cache[k][1]
+            need.append((pairs, mpos))
         for j, (c, _prof) in enumerate(lanes):
-            if j < len(batches):
-                pairs = mpos = 0
-                for i in batches[j]:
-                    m = models_of.get(binIds[i]) if models_of else None
-                    k = id(m)
-                    if k not in pos_cache:
-                        pos_cache[k] = (len(m), sum(padded[x] for x in m)) if m is not None else (len(padded), sum(padded))
-                    norf = max(1, sizes[i] // 320)
-                    pairs += norf * pos_cache[k][0]; mpos += norf * pos_cache[k][1]
+            mine = need[j::len(lanes)]             # the largest batch this lane will meet (the first ones are small: plan_batches)
+            if mine:
                 try:
-                    c.reserve(pairs, mpos)
+                    c.reserve(max(x[0] for x in mine), max(x[1] for x in mine))
                 except _lib.CkmError:
                     pass
 
