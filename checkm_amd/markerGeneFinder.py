@@ -21,7 +21,7 @@ from checkm_amd.markerSets import MarkerSetParser, wanted_model
 #                                 owned=set(binId) scanned by THIS rank, world)
 SCAN_CACHE = {}
 
-PAIR_BUDGET = int(os.environ.get("CKM_FIND_PAIR_BUDGET", str(250 * 1000 * 1000)))   # (ORF, model) pairs per ckm_search call
+PAIR_BUDGET = int(os.environ.get("CKM_FIND_PAIR_BUDGET", str(125 * 1000 * 1000)))   # (ORF, model) pairs per ckm_search call
 RAMP = (0.125, 0.25, 0.5)            # shares of the budgets the first batches of a find() stop at (plan_batches)
 RES_BUDGET = int(os.environ.get("CKM_FIND_RES_BUDGET", str(400 * 1000 * 1000)))      # residues (~ bytes of genes.faa) per call
 
