@@ -13,9 +13,11 @@
  *     one device: MarkerGeneFinder.find keeps up to three on a device, one batch of bins in flight on each.  A ctx owns its streams,
  *     tables and float workspace (budget: a quarter of the device memory free at creation, at most 96 GB); ckm_profiles, ckm_seqs
  *     and ckm_hits are plain device / host memory and may be used with ANY ctx of the device they were created on (the contexts of
- *     a device share one resident copy of a profile database; ckm_reduce may be called with another ctx than the one that searched).  ckm_seqs_pack / ckm_seqs_from_fasta / ckm_hits_write_domtblout touch no state of the ctx and may run on
- *     other threads while a search is in flight (MarkerGeneFinder.find reads the next batch of bins and writes the previous batch's
- *     tables that way).  The library never falls back to a CPU implementation: without a usable HIP
+ *     a device share one resident copy of a profile database; ckm_reduce may be called with another ctx than the one that searched).  ckm_seqs_pack / ckm_seqs_from_fasta use only the ctx's upload
+ *     staging area and high-priority stream (serialised by a mutex of the ctx), ckm_hits_write_domtblout touches no state of the ctx: all
+ *     three may run on other threads while a search is in flight (MarkerGeneFinder.find reads the next batch of bins and writes the previous batch's
+ *     tables that way).  Searches of different ctxs of ONE device run concurrently but take their SSV phases one after the other
+ *     (a device-wide baton inside the library).  The library never falls back to a CPU implementation: without a usable HIP
  *     device ckm_ctx_create() fails with CKM_ENODEV and nothing else can be called.
  */
 #ifndef CHECKM_HIP_H
