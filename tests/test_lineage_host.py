@@ -58,6 +58,10 @@ def test_batches_and_shards():
     assert all(sum(sizes[i] // 320 * nm[i] for i in part) <= 2 * 1000 * 1000 or len(part) == 1 for part in b)
     assert len(mgf.plan_batches(sizes, nm, pair_budget=10 ** 15, res_budget=10 ** 15)) == 1
     assert mgf.plan_batches([], []) == []
+    # the first three batches of a pass stop at 1/8, 1/4, 1/2 of the budgets (the device starts after a short ingest; lanes start staggered)
+    many = [320 * 1000] * 400
+    r = mgf.plan_batches(many, [500] * 400, pair_budget=40 * 1000 * 500, res_budget=10 ** 15)
+    assert [len(x) for x in r[:5]] == [5, 10, 20, 40, 40] and sum(len(x) for x in r) == 400
     assert len(mgf.plan_batches(sizes, nm, pair_budget=10 ** 15, res_budget=320 * 2000)) >= 8
     sh = cdist.shard_bins([s * n for s, n in zip(sizes, nm)], 4)
     assert sorted(i for s in sh for i in s) == list(range(13))
