@@ -92,6 +92,7 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
       for (auto &e : w.grp_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       memset(&w.stats, 0, sizeof(w.stats));
       w.ws_budget = budget;
+      if (getenv("CKM_WS_VMM") && atoi(getenv("CKM_WS_VMM")) != 0) { w.ws.vmm = true; w.ws.va_bytes = budget + ((size_t)8 << 30); }   // (opt-in until it has run the whole GPU suite)
       if (const char *e = getenv("CKM_WS_PER_MP")) w.caps.ws_per_mp = (float)atof(e);     // first workspace size of the device-driven cascade (bytes per pair x padded model length)
       w.pool.reset(new HostPool(host_threads));
     }

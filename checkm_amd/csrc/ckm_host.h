@@ -69,8 +69,13 @@ void launch_regions(hipStream_t stream, uint32_t nblocks, const uint32_t *list, 
 
 struct DevBuf {
   void *p = nullptr; size_t cap = 0;
+  // vmm (the float workspace, CKM_WS_VMM=1): an address range is reserved once and physical 1 GB chunks are mapped into it as the buffer
+  // grows -- measured on MI355X (tools/ubench/vmm_probe.hip, profiles/r03z_vmm_probe.txt): 0.2 ms per GB against hipMalloc's 30 ms per GB,
+  // and growth keeps the contents and the address (no free + malloc).  Mapping waits for kernels already running, like hipFree.
+  bool vmm = false; size_t va_bytes = (size_t)128 << 30, chunk_bytes = 0; std::vector<hipMemGenericAllocationHandle_t> chunks;
   void ensure(size_t bytes) {
     if (bytes <= cap) return;
+    if (vmm) { grow_mapped(bytes); return; }
     if (p) (void)hipFree(p);
     p = nullptr; cap = 0;
     size_t want = bytes + std::min<size_t>(bytes / 4, (size_t)1 << 30) + 256;      // (growth slack, bounded: the float workspace is tens of GB)
@@ -78,8 +83,43 @@ struct DevBuf {
     if (e != hipSuccess) { p = nullptr; throw Error(CKM_ENOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed: " + hipGetErrorString(e)); }
     cap = want;
   }
+  void grow_mapped(size_t bytes) {
+    int dev = 0; (void)hipGetDevice(&dev);
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+    auto fail = [&](const char *what, hipError_t e) { throw Error(CKM_ENOMEM, std::string(what) + " failed while growing a mapped buffer to " + std::to_string(bytes) + " bytes: " + hipGetErrorString(e)); };
+    if (!p) {
+      size_t gran = 0;
+      hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+      if (e != hipSuccess || !gran) fail("hipMemGetAllocationGranularity", e);
+      chunk_bytes = (((size_t)1 << 30) + gran - 1) / gran * gran;
+      va_bytes = (va_bytes + chunk_bytes - 1) / chunk_bytes * chunk_bytes;
+      e = hipMemAddressReserve(&p, va_bytes, 0, nullptr, 0);
+      if (e != hipSuccess) { p = nullptr; fail("hipMemAddressReserve", e); }
+    }
+    const size_t want = (bytes + 256 + chunk_bytes - 1) / chunk_bytes * chunk_bytes;
+    if (want > va_bytes) throw Error(CKM_ENOMEM, "a mapped buffer cannot grow beyond its " + std::to_string(va_bytes) + " reserved bytes");
+    hipMemAccessDesc acc = {}; acc.location.type = hipMemLocationTypeDevice; acc.location.id = dev; acc.flags = hipMemAccessFlagsProtReadWrite;
+    while (cap < want) {
+      hipMemGenericAllocationHandle_t h;
+      hipError_t e = hipMemCreate(&h, chunk_bytes, &prop, 0);
+      if (e != hipSuccess) fail("hipMemCreate", e);
+      e = hipMemMap(static_cast<char *>(p) + cap, chunk_bytes, 0, h, 0);
+      if (e != hipSuccess) { (void)hipMemRelease(h); fail("hipMemMap", e); }
+      e = hipMemSetAccess(static_cast<char *>(p) + cap, chunk_bytes, &acc, 1);
+      if (e != hipSuccess) { (void)hipMemUnmap(static_cast<char *>(p) + cap, chunk_bytes); (void)hipMemRelease(h); fail("hipMemSetAccess", e); }
+      chunks.push_back(h); cap += chunk_bytes;
+    }
+  }
   template <class T> T *as() const { return reinterpret_cast<T *>(p); }
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  ~DevBuf() {
+    if (vmm) {
+      if (p && cap) (void)hipMemUnmap(p, cap);
+      for (auto h : chunks) (void)hipMemRelease(h);
+      if (p) (void)hipMemAddressFree(p, va_bytes);
+    } else if (p) (void)hipFree(p);
+  }
+  DevBuf() = default; DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
 };
 
 struct PinnedBuf {      // grow-only page-locked host staging buffer (pageable D2H copies run at a fraction of PCIe speed)
