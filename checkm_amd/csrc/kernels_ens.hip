@@ -2,8 +2,11 @@
 // Replaces, inside the hmmsearch process launched at checkm/hmmer.py:70, HMMER's "region_trace_ensemble":
 // 200 stochastic tracebacks, null2 by trace, per-position null2 odds; the sampled segments go back to the host,
 // which clusters them (integer work on a few hundred segments).
-//   ens_trace_kernel   one workgroup per region, one LANE per trace: every trace is an independent walk through
-//                      the (L2-resident) Forward matrix, driven by its own substream of HMMER's fast generator.
+//   ens_trace_seq_kernel  (default) one WAVEFRONT per region: the 200 traces of a region run one after the other on ONE generator
+//                      stream, re-seeded for the region and carried from trace to trace exactly as hmmsearch carries its generator
+//                      (the number of draws a trace takes is only known when it ends).  The parallelism is over REGIONS.
+//   ens_trace_kernel   (CKM_ENS_STREAM=substream, opt-in) one workgroup per region, one LANE per trace: every trace draws from
+//                      its own substream of the generator -- independent lanes, but not hmmsearch's stream.
 //   ens_null2_kernel   one wavefront per (region, trace): state usage counts in LDS, null2 odds in the canonical
 //                      64-lane order, per-position odds ratio of this trace.
 //   ens_sum_kernel     one thread per region position: sum of the ratios over traces, trace order.
@@ -11,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include "dev_types.h"
 #include "xlane.h"
 
@@ -59,11 +63,7 @@ __device__ __forceinline__ int ens_select_e(const float *__restrict__ cr, int Q,
 
 __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restrict__ work, const uint32_t *__restrict__ list, const DevModel *__restrict__ models,
                                                        const LenEntry *__restrict__ lentab, float *__restrict__ ws,
-                                                       const uint32_t *__restrict__ seeds, const uint32_t *__restrict__ count, uint32_t cap, int sequential) {
- // sequential != 0 (CKM_ENS_STREAM=sequential): HMMER's own use of its generator -- ONE stream per region, re-seeded for the region and
- // carried from the end of trace t into trace t+1 -- instead of one sub-stream per trace: the traces then run one after the other
- // (the number of draws a trace takes is only known when it ends), ~200 times slower for this rare stage.
- __shared__ uint32_t stream_rng;
+                                                       const uint32_t *__restrict__ seeds, const uint32_t *__restrict__ count, uint32_t cap) {
  const uint32_t nregions = min(*count, cap);
  for (uint32_t region = blockIdx.x; region < nregions; region += gridDim.x) {
   const EnsWork w = work[list ? list[region] : region];
@@ -84,10 +84,8 @@ __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restric
   int32_t *__restrict__ nsegp = reinterpret_cast<int32_t *>(ws + w.nseg_off);
 #define CELL(c) (((c) % Q) * 64 + (c) / Q)
   enum { sC, sE, sM, sI, sD, sB, sJ, sN };
-  if (sequential) { __syncthreads(); if (threadIdx.x == 0) stream_rng = seeds[0]; __syncthreads(); }
- for (int round = 0; round < (sequential ? ENS_N : 1); ++round) {
-  const bool mine = sequential ? (t == round) : live;
-  uint32_t rng = sequential ? stream_rng : seeds[live ? t : 0];
+  const bool mine = live;
+  uint32_t rng = seeds[live ? t : 0];
   int st = sC, i = Ld, k = 0, nseg = 0, sqto = 0, hmmto = 0;
   bool overflow = false, done = !mine;
   float pth[4];
@@ -160,12 +158,168 @@ __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restric
   if (mine) {
     for (; i >= 1; --i) code[i] = 0;
     nsegp[t] = overflow ? -1 : nseg;
-    if (sequential) stream_rng = rng;
   }
-  if (sequential) __syncthreads();
- }
  }
 #undef CELL
+}
+
+// ---- default: ONE generator stream per region (hmmsearch's own use of its generator) ----------------------------------------------
+// One wavefront per region; every value of the walk (state, row, node, generator) is wave-uniform -- forced through
+// v_readfirstlane after each choice so that the state machine branches on SGPRs -- and the 64 lanes are used for what a single walk
+// can share: the E-state choice over the 2M exit weights of a row (ens_select_e), the state codes of 64 residues riding in one register
+// (lane = residue & 63, stored 128 contiguous bytes at a time), and a LOOK-AHEAD load every sixteen rows that touches the cache lines
+// the walk will most likely read next (rows i-16 .. i-31 around the diagonal it is on, M / I / D planes and the special rows): a step is
+// one dependent load round, and the 200 walks of ~500 regions do not stay in L2 from one trace to the next, so without the look-ahead
+// a step costs an HBM latency.  Same draws, same choices as the oracle's single-stream mode: every state but N takes exactly one draw.
+__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__global__ void __launch_bounds__(64) ens_trace_seq_kernel(const EnsWork *__restrict__ work, const uint32_t *__restrict__ list, const DevModel *__restrict__ models,
+                                                          const LenEntry *__restrict__ lentab, float *__restrict__ ws,
+                                                          const uint32_t *__restrict__ seeds, const uint32_t *__restrict__ count, uint32_t cap, int warm) {
+ const uint32_t nregions = min(*count, cap);
+ const int lane = threadIdx.x;
+ float sink = 0.0f, pf0 = 0.0f, pf1 = 0.0f, pf2 = 0.0f;
+ for (uint32_t region = blockIdx.x; region < nregions; region += gridDim.x) {
+  const EnsWork w = work[list ? list[region] : region];
+  const DevModel &md = models[w.model];
+  const int Q = uni_i(md.fbQ), Mp = Q * 64, Ld = uni_i(w.Ld), segcap = uni_i(w.cap);
+  const size_t rowsz = (size_t)3 * Mp;
+  const gp<float> mx = gptr(ws + w.mx_off);
+  const gp<float> xs = gptr(ws + w.xs_off);
+  const gp<float> ftr = gptr(md.ftr);
+  const gp<float> tBM = ftr, tMM = ftr + Mp, tIM = ftr + 2 * Mp, tDM = ftr + 3 * Mp,
+                  tMI = ftr + 4 * Mp, tII = ftr + 5 * Mp, tMD = ftr + 6 * Mp, tDD = ftr + 7 * Mp;
+  const LenEntry le = lentab[w.Lcfg];
+  const float loop = le.loop_m, move = le.move_m, Eloop = md.fE_loop, Emove = md.fE_move;
+  uint16_t *__restrict__ codes = reinterpret_cast<uint16_t *>(ws + w.code_off);
+  int32_t *__restrict__ segs = reinterpret_cast<int32_t *>(ws + w.seg_off);
+  int32_t *__restrict__ nsegp = reinterpret_cast<int32_t *>(ws + w.nseg_off);
+  const float invQ = 1.0f / (float)Q;
+  auto cellq = [&](int c) { int z = (int)((float)c * invQ); z += ((z + 1) * Q <= c) ? 1 : 0; z -= (z * Q > c) ? 1 : 0; return (c - z * Q) * 64 + z; };
+  enum { sC, sE, sM, sI, sD, sB, sJ, sN };
+  uint32_t rng = (uint32_t)uni_i((int)seeds[0]);            // the region's stream: re-seeded here, carried from trace to trace below
+  for (int t = 0; t < ENS_N; ++t) {
+    uint16_t *__restrict__ code = codes + (size_t)t * (Ld + 1);
+    int32_t *__restrict__ seg = segs + (size_t)t * segcap * 4;
+    int st = sC, i = Ld, k = 0, nseg = 0, sqto = 0, hmmto = 0;
+    int kq = 0, kz = 0;                                      // cell k-1 of the striped rows is float kq*64 + kz: kept up to date as k falls, no division per step
+    bool overflow = false;
+    uint32_t mycode = 0;                                     // lane (r & 63) holds the code of residue r of the 64-block the walk is in
+    // residue i is done: its block goes to memory when the walk leaves it
+#define CELL_K()  (kq * 64 + kz)                                         /* cell k-1 */
+#define CELL_KM() (kq > 0 ? (kq - 1) * 64 + kz : (Q - 1) * 64 + kz - 1)   /* cell k-2 */
+#define DEC_K()   { if (kq > 0) --kq; else { kq = Q - 1; --kz; } --k; }
+#define SET_CODE(v) { if (lane == (i & 63)) mycode = (v); }
+#define LEAVE_ROW() { if ((i & 63) == 0) { const int pos_ = i + lane; if (pos_ >= 1 && pos_ <= Ld) code[pos_] = (uint16_t)mycode; } --i; }
+    for (;;) {
+      float pth0, pth1, pth2 = 0.0f, pth3 = 0.0f; int n = 2;
+      if (st == sE) {
+        rng = rng * 69069u + 1u;
+        const int r = uni_i(ens_select_e((const float *)(mx + rowsz * i), Q, Mp, (double)rng / 4294967296.0, lane));
+        k = (r >> 1) + 1; st = (r & 1) ? sD : sM; sqto = 0; hmmto = 0;
+        kz = (r >> 1) / Q; kq = (r >> 1) - kz * Q;
+      } else if (st == sN) {
+        break;
+      } else {
+        const gp<float> cr = mx + rowsz * i, pr = (i > 0) ? mx + rowsz * (i - 1) : mx;
+        if (st == sC) {
+          pth0 = xs[(size_t)(i - 1) * 6 + 4] * loop;
+          pth1 = (xs[(size_t)i * 6 + 0] * Emove) * xs[(size_t)i * 6 + 5];
+        } else if (st == sJ) {
+          pth0 = xs[(size_t)(i - 1) * 6 + 2] * loop;
+          pth1 = (xs[(size_t)i * 6 + 0] * Eloop) * xs[(size_t)i * 6 + 5];
+        } else if (st == sM) {
+          const int c = k - 1;
+          n = 4;
+          pth0 = xs[(size_t)(i - 1) * 6 + 3] * tBM[c];
+          if (c > 0) { const int a = CELL_KM(); pth1 = pr[a] * tMM[c]; pth2 = pr[Mp + a] * tIM[c]; pth3 = pr[2 * Mp + a] * tDM[c]; }
+          else pth1 = pth2 = pth3 = 0.0f;
+          if (warm && (i & 15) == 0 && i > 16) {
+            // rows i-16-d (d = lane >> 2 = 0..15) of the diagonal the walk is on, and the diagonals one insert / one delete away;
+            // lane & 3: M, I, D plane of the predecessor cell, special row.  The values are consumed at the NEXT look-ahead (they
+            // have long arrived by then: loads return in order and sixteen rows of demand loads were waited for in between).
+            sink = sink + pf0; sink = sink + pf1; sink = sink + pf2;
+            const int d = 16 + (lane >> 2), ri = max(i - d, 0), what = lane & 3;
+            const gp<float> rowp = mx + rowsz * ri + (what == 3 ? 0 : what) * Mp;
+            const int c0 = max(c - 1 - d, 0), c1 = min(c0 + 1, Mp - 1), c2 = max(c0 - 1, 0);
+            pf0 = (what == 3) ? xs[(size_t)ri * 6] : rowp[cellq(c0)];
+            pf1 = rowp[cellq(c1)];
+            pf2 = rowp[cellq(c2)];
+          }
+        } else if (st == sI) {
+          const int a = CELL_K();
+          pth0 = pr[a] * tMI[k - 1]; pth1 = pr[Mp + a] * tII[k - 1];
+        } else if (st == sD) {
+          const int c = k - 1;
+          if (c > 0) { const int a = CELL_KM(); pth0 = cr[a] * tMD[c - 1]; pth1 = cr[2 * Mp + a] * tDD[c - 1]; } else pth0 = pth1 = 0.0f;
+        } else {   // sB
+          pth0 = xs[(size_t)i * 6 + 1] * move; pth1 = xs[(size_t)i * 6 + 2] * move;
+        }
+        // the draw and the choice (ens_choose's order of operations: float sum of the weights, double running sum)
+        rng = rng * 69069u + 1u;
+        const double roll = (double)rng / 4294967296.0;
+        int ch;
+        {
+          float norm = pth0 + pth1;
+          if (n == 4) { norm = norm + pth2; norm = norm + pth3; }
+          if (!(norm > 0.0f)) ch = 0;
+          else {
+            const double target = roll * (double)norm;
+            double sum = (double)pth0;
+            if (target < sum) ch = 0;
+            else { sum += (double)pth1;
+              if (target < sum) ch = 1;
+              else if (n == 2) ch = (pth1 > 0.0f) ? 1 : 0;
+              else { sum += (double)pth2;
+                if (target < sum) ch = 2;
+                else { sum += (double)pth3;
+                  if (target < sum) ch = 3;
+                  else ch = (pth3 > 0.0f) ? 3 : (pth2 > 0.0f) ? 2 : (pth1 > 0.0f) ? 1 : 0; } } }
+          }
+        }
+        ch = uni_i(ch);
+        if (st == sC || st == sJ) {
+          if (ch == 0) { SET_CODE(0u) LEAVE_ROW() } else st = sE;
+        } else if (st == sM) {
+          SET_CODE(0x4000u | (uint32_t)k)
+          if (!sqto) { sqto = i; hmmto = k; }
+          if (ch == 0) {
+            if (nseg == segcap) { overflow = true; break; }
+            if (lane == 0) { seg[nseg * 4 + 0] = i; seg[nseg * 4 + 1] = sqto; seg[nseg * 4 + 2] = k; seg[nseg * 4 + 3] = hmmto; }
+            ++nseg;
+            st = sB;
+          } else st = (ch == 1) ? sM : (ch == 2) ? sI : sD;
+          LEAVE_ROW() DEC_K()
+        } else if (st == sI) {
+          SET_CODE(0x8000u | (uint32_t)k)
+          st = (ch == 0) ? sM : sI;
+          LEAVE_ROW()
+        } else if (st == sD) {
+          st = (ch == 0) ? sM : sD;
+          DEC_K()
+        } else {
+          st = (ch == 0) ? sN : sJ;
+        }
+      }
+      // a numerically impossible move ends the trace
+      if (i < 0 || k < 0 || ((st == sM || st == sI) && (k < 1 || i < 1)) || (st == sD && k < 1) || ((st == sC || st == sJ || st == sE) && i < 1)) break;
+    }
+    // residues i .. 1 lie outside every domain: code 0 (the block the walk stopped in, then everything below it)
+    if (i >= 0) {
+      const int b = i & ~63;
+      if (lane <= (i & 63)) mycode = 0;
+      { const int pos_ = b + lane; if (pos_ >= 1 && pos_ <= Ld) code[pos_] = (uint16_t)mycode; }
+      for (int pos_ = 1 + lane; pos_ < b; pos_ += 64) code[pos_] = 0;
+    }
+    if (lane == 0) nsegp[t] = overflow ? -1 : nseg;
+#undef SET_CODE
+#undef CELL_K
+#undef CELL_KM
+#undef DEC_K
+#undef LEAVE_ROW
+  }
+ }
+ if (nregions == 0xffffffffu) ws[0] = sink + pf0 + pf1 + pf2;      // (never true) keeps the look-ahead loads alive
 }
 
 // grid (ENS_N, nregions), 64 threads; dynamic LDS: 2*Mp counters/floats + 32 floats
@@ -260,8 +414,11 @@ void launch_ensemble(hipStream_t stream, const EnsWork *work, const uint32_t *li
                      const DevModel *models, const LenEntry *lentab, const uint8_t *res, const uint64_t *seq_off, float *ws, const uint32_t *seeds,
                      float *host_res) {
   if (!grid_regions) return;
-  static const int sequential = [] { const char *e = getenv("CKM_ENS_STREAM"); return (e && !strcmp(e, "sequential")) ? 1 : 0; }();
-  hipLaunchKernelGGL(ens_trace_kernel, dim3(grid_regions), dim3(256), 0, stream, work, list, models, lentab, ws, seeds, count, cap, sequential);
+  // CKM_ENS_STREAM=substream: one generator sub-stream per trace (round 1-3's default; NOT hmmsearch's stream).  Default: one stream per region.
+  static const int substream = [] { const char *e = getenv("CKM_ENS_STREAM"); return (e && !strcmp(e, "substream")) ? 1 : 0; }();
+  static const int warm = [] { const char *e = getenv("CKM_ENS_WARM"); return (e && !strcmp(e, "0")) ? 0 : 1; }();
+  if (substream) hipLaunchKernelGGL(ens_trace_kernel, dim3(grid_regions), dim3(256), 0, stream, work, list, models, lentab, ws, seeds, count, cap);
+  else hipLaunchKernelGGL(ens_trace_seq_kernel, dim3(std::min<uint32_t>(cap, 4096u)), dim3(64), 0, stream, work, list, models, lentab, ws, seeds, count, cap, warm);
   hipLaunchKernelGGL(ens_null2_kernel, dim3(ENS_N, grid_regions), dim3(64), (size_t)(2 * max_Mp + 32) * 4, stream, work, list, models, res, seq_off, ws, count, cap);
   hipLaunchKernelGGL(ens_sum_kernel, dim3(4, grid_regions), dim3(256), 0, stream, work, list, ws, count, cap);
   if (host_res) hipLaunchKernelGGL(ens_export_kernel, dim3(4, grid_regions), dim3(256), 0, stream, work, list, ws, host_res, count, cap);

@@ -28,13 +28,13 @@
  * per cell.  Known deviations from HMMER, all flagged "DEV" below:
  *   DEV1 bias-filter Forward rescales by exact powers of two instead of dividing by the row max;
  *   DEV2 optimal-accuracy fill gates impossible transitions with -inf instead of *FLT_MIN;
- *   DEV3 multi-domain regions (rt3 test) are resolved as HMMER does -- 200 stochastic tracebacks of a
+ *   DEV3 (closed in round 4) multi-domain regions (rt3 test) are resolved as HMMER does -- 200 stochastic tracebacks of a
  *        multihit Forward matrix of the region, null2 by trace, single-linkage clustering of the sampled
  *        segments (overlap .8 of the smaller, diagonal 4, posterior .25, endpoint .02) -- with HMMER's fast
- *        generator (x*69069+1, seed 42 mixed as Easel does), BUT trace t draws from its own substream
- *        (start + t*15485863 steps) instead of continuing where trace t-1 stopped, so that traces are
- *        independent work items; HMMER's own result is not reproducible across its SIMD builds either,
- *        because one roll that lands differently shifts every later draw;
+ *        generator (x*69069+1, seed 42 mixed as Easel does), re-seeded for every region and carried from the end of trace t
+ *        into trace t+1, as hmmsearch carries its generator (every state of a trace but N takes one draw).  Rounds 1-3
+ *        gave trace t its own substream (start + t*15485863 steps) by default; that mode survives only as an opt-in
+ *        (p7o_set_ensemble_stream(0); product: CKM_ENS_STREAM=substream);
  *   DEV4 exp() for the probability-space tables uses libm expf, not HMMER's SSE polynomial.
  */
 #define _GNU_SOURCE
@@ -941,7 +941,7 @@ static uint32_t lcg_jump(uint32_t x, uint64_t n)
   while (n) { if (n & 1) { ra = A * ra; rc = A * rc + C; } C = A * C + C; A = A * A; n >>= 1; }
   return ra * x + rc;
 }
-static int g_ens_sequential = 0;
+static int g_ens_sequential = 1;     /* one stream per region (hmmsearch's own use of its generator); 0: one sub-stream per trace */
 void p7o_set_ensemble_stream(int sequential) { g_ens_sequential = sequential; }
 
 uint32_t p7o_ensemble_seed(int t)
@@ -1065,7 +1065,7 @@ static int trace_ensemble(const PROF *p, const uint8_t *dsq, int L, int ireg, in
   float *ratio = malloc(sizeof(float) * (size_t)ENS_NSAMPLES * (Ld+1));
   float *cm = malloc(sizeof(float) * 2 * Mp), *ci = cm + Mp;
   int rc = 0;
-  /* default: every trace has its own sub-stream (deviation D3); p7o_set_ensemble_stream(1): ONE stream per region, carried from
+  /* default: ONE stream per region, carried from trace to trace; p7o_set_ensemble_stream(0): every trace has its own sub-stream
    * trace to trace as HMMER carries its generator */
   uint32_t stream_rng = p7o_ensemble_seed(0);
   for (int t = 0; t < ENS_NSAMPLES && rc == 0; t++) {

@@ -115,7 +115,7 @@ int p7o_align(const P7O_HMM *hmm, const uint8_t *dsq, int L, int32_t *path);
  * sampled segments in region-local coordinates.  env/nenv: clustered envelopes (region-local), sorted by start. */
 typedef struct { int32_t sqfrom, sqto, hmmfrom, hmmto; } P7O_SEG;
 uint32_t p7o_ensemble_seed(int t);
-/* 0 (default): one generator sub-stream per trace; 1: one stream per region carried from trace to trace (HMMER's own use) */
+/* 1 (default): one stream per region carried from trace to trace (HMMER's own use of its generator); 0: one generator sub-stream per trace (rounds 1-3) */
 void p7o_set_ensemble_stream(int sequential);
 int p7o_region_ensemble(const P7O_HMM *hmm, const uint8_t *dsq, int L, int ireg, int jreg,
                         float *n2sum, P7O_SEG *seg_all, int32_t *nseg_all, int cap, P7O_SEG *env, int envcap, int32_t *nenv);

@@ -491,10 +491,11 @@ def test_empty_bins_and_empty_records(gpu_ctx, tmp_path):
         prof.close(); seqs.close(); alone.close(); hs.close()
 
 
-def test_trace_ensemble_single_stream_mode():
-    """CKM_ENS_STREAM=sequential: the 200 tracebacks of a region draw from ONE generator stream carried from trace to trace (HMMER's
-    own use of its generator; the default gives every trace its own sub-stream).  In a fresh process, against the
-    oracle in the same mode: same segments, same null2 sums, same envelopes for a few regions, and the rows of a whole search."""
+def test_trace_ensemble_substream_mode():
+    """CKM_ENS_STREAM=substream (opt-in; rounds 1-3's default): every one of the 200 tracebacks draws from its own sub-stream of the
+    generator.  The DEFAULT -- one stream per region, carried from trace to trace as hmmsearch carries its generator -- is what every
+    other test of this file runs.  In a fresh process, against the oracle in the same mode: same segments, same null2 sums, same
+    envelopes for a few regions, and the rows of a whole search."""
     import json
     import os
     import subprocess
@@ -509,7 +510,7 @@ from tests import common
 from tests.test_gpu_scan import _tandem_records
 profs = common.mixed_profiles(); path = common.hmm_file("mixed", profs)
 recs = _tandem_records(profs, 77)[:6]
-p7.lib().p7o_set_ensemble_stream(1)
+p7.lib().p7o_set_ensemble_stream(0)
 ctx = _lib.Context(0); prof = _lib.Profiles(ctx, path); seqs = _lib.Seqs(ctx, [recs])
 hs = p7.HmmSet(path)
 dsq = [p7.digitize(r[2]) for r in recs]
@@ -527,7 +528,7 @@ same = hits.n == len(rows) and all((r.seq_idx, r.model_idx, r.hmm_from, r.hmm_to
                                   np.float32(r.dom_score).view(np.uint32) == np.float32(hits.dom_score[i]).view(np.uint32) for i, r in enumerate(rows))
 print(json.dumps(dict(regions=out, rows=int(hits.n), same=bool(same), multi=int(ctx.stats().regions_multi))))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CKM_ENS_STREAM="sequential"), capture_output=True, text=True, timeout=300)
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CKM_ENS_STREAM="substream"), capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
     out = json.loads(res.stdout.strip().split("\n")[-1])
     for o in out["regions"]:
