@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--bins-total", type=int, default=1000, help="cfg2 strong / cfg3: bins of the whole job")
     ap.add_argument("--lineage-bins", type=int, default=0, help="cfg2: bins of a small lineage_wf-equivalent side measurement (0 = skip; cfg3 IS that measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", type=int, default=3, help="cfg3 / cfg5: bins of the last timed step whose written tables are diffed against the CPU oracle after the timed region (0 = off)")
+    ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="cfg2: steps in flight at once (own context each); 1 = every step runs alone")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)

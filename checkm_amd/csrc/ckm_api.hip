@@ -204,7 +204,7 @@ extern "C" int ckm_profiles_load(ckm_ctx *ctx, const char *hmm_path, ckm_profile
       d.fE_loop = hp.fE_loop; d.fE_move = hp.fE_move;
       d.bt00 = hp.bt00; d.bt01 = hp.bt01; d.bt10 = hp.bt10; d.bt11 = hp.bt11; d.bpi0 = hp.bpi0; d.bpi1 = hp.bpi1;
       for (int x = 0; x < NROWS; ++x) d.beo1[x] = hp.beo1[x];
-      d.thr_msv_f1 = hp.thr_msv_f1; d.thr_msv_f2 = hp.thr_msv_f2; d.thr_vit_f2 = hp.thr_vit_f2; d.thr_fwd_f3 = hp.thr_fwd_f3;
+      d.thr_msv_f1 = hp.thr_msv_f1; d.thr_msv_f1_nat = hp.thr_msv_f1_nat; d.thr_msv_f2 = hp.thr_msv_f2; d.thr_vit_f2 = hp.thr_vit_f2; d.thr_fwd_f3 = hp.thr_fwd_f3;
       d.ssv_tbl = reinterpret_cast<const int16_t *>(base + off[i].ssv); d.ssv_tbl_h = reinterpret_cast<const uint16_t *>(base + off[i].ssvh);
       d.rbv = base + off[i].rbv; d.vit_e = reinterpret_cast<const uint32_t *>(base + off[i].vit_e);
       d.vit_t = reinterpret_cast<const uint32_t *>(base + off[i].vit_t); d.rf = reinterpret_cast<const float *>(base + off[i].rf);

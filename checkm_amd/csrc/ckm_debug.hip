@@ -30,14 +30,16 @@ extern "C" int ckm_debug_stages(ckm_ctx *ctx_, const ckm_profiles *p, const ckm_
     ctx->work.ensure(npairs * sizeof(SsvBlockWork)); ctx->idx.ensure(npairs * 4); ctx->maxv.ensure(npairs * 2 + 64);
     wcopy(ctx, ctx->work.p, sorted.data(), npairs * sizeof(SsvBlockWork), hipMemcpyHostToDevice);
     wcopy(ctx, ctx->idx.p, ids.data(), npairs * 4, hipMemcpyHostToDevice);
+    SsvEpi epi; memset(&epi, 0, sizeof(epi));
+    epi.lentab = lt; epi.maxv = ctx->maxv.as<uint16_t>();              // diagnostics: Smax per pair, no finish
     for (auto &g : groups)
       if (launch_ssv(g.first, (int)g.second.second, ssv_threads_for(g.first), ctx->stream, ctx->work.as<SsvBlockWork>() + g.second.first, dm, res, off, dlen,
-                     ctx->idx.as<uint32_t>(), ctx->maxv.as<uint16_t>()))
+                     ctx->idx.as<uint32_t>(), epi))
         throw Error(CKM_ERANGE, "no SSV kernel instance");
     HIPCHK(hipGetLastError());
     std::vector<uint16_t> maxv(npairs);
     HIPCHK(hipMemcpyAsync(maxv.data(), ctx->maxv.p, npairs * 2, hipMemcpyDeviceToHost, ctx->stream));
-    // full MSV on every pair: first with the packed kernel the search uses, then with the plain reference kernel
+    // full MSV on every pair: first with the packed kernel the search uses (msv16_kernel, scores only), then with the wave-per-pair kernel
     std::vector<PairRec> pr(npairs);
     for (uint32_t i = 0; i < npairs; ++i) { pr[i].model = model[i]; pr[i].seq = seq[i]; pr[i].usc = 0; pr[i].filtersc = 0; }
     HIPCHK(hipStreamSynchronize(ctx->stream));

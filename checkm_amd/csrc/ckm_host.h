@@ -30,17 +30,14 @@ namespace ckm {
 
 // ---- kernel launchers (kernels_*.hip) ------------------------------------------------------------
 int launch_ssv(int Q, int nblocks, int threads, hipStream_t stream, const SsvBlockWork *work, const DevModel *models,
-               const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const uint32_t *lists, uint16_t *maxv);
-void launch_msv_finish(hipStream_t stream, const FinishArgs &a, uint32_t nblocks);
-int launch_msv(int Q, int nblocks, hipStream_t stream, const SsvBlockWork *work, const DevModel *models, const LenEntry *lentab,
-               const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const uint32_t *lists, int32_t *out_xJ, float *out_usc);
+               const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const uint32_t *lists, const SsvEpi &epi /* where the fused MSV finish appends */);
 void launch_msv_full(hipStream_t stream, uint32_t nblocks, WorkQueue queue, const PairRec *pairs, const DevModel *models, const LenEntry *lentab,
                      const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xJ, float *out_usc, int maxMp,
                      const CascadeDev *cd /* null: scores only */);
 void launch_bias(hipStream_t stream, PairRec *pairs, uint32_t npairs, const DevModel *models, const LenEntry *lentab,
                  const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, float *raw);
 int launch_msv16(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const PairRec *pairs, const DevModel *models, const LenEntry *lentab,
-                 const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const CascadeDev &cd);
+                 const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const CascadeDev &cd, int32_t *out_xJ = nullptr /* scores only, no decision */, float *out_usc = nullptr);
 int launch_vit16(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const PairRec *pairs, const DevModel *models, const LenEntry *lentab,
                  const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const CascadeDev &cd);
 int launch_vit(int QH, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const PairRec *pairs, const DevModel *models,

@@ -67,6 +67,7 @@ struct HostProfile {
   float beo1[NROWS];
   // score-space thresholds equivalent to P<=F1 / P<=F2 / P<=F3 (smallest passing float)
   float thr_msv_f1, thr_msv_f2, thr_vit_f2, thr_fwd_f3;
+  float thr_msv_f1_nat;     // smallest float v with (float)((double)v / ln 2) >= thr_msv_f1 (the SSV epilogue tests usc - nullsc against it)
 };
 
 HostProfile configure_profile(const HostHMM &h);

@@ -170,37 +170,35 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
         if (single_chunk) { ctx->plan_key = key; ctx->plan_groups = groups; ctx->plan_nblocks = nblocks_total; ctx->plan_pairs = c_pairs; ctx->plan_residue_hmm = c_res; ctx->plan_cells = c_cells; }
         else ctx->plan_key.clear();
       }
-      ctx->maxv.ensure(npairs * 2 + 64);
       uint32_t cap_surv = (uint32_t)std::max<uint64_t>(1 << 16, npairs / 8), cap_nores = (uint32_t)std::max<uint64_t>(1 << 14, npairs / 64);
       for (int attempt = 0;; ++attempt) {
         ctx->surv.ensure((size_t)cap_surv * sizeof(PairRec)); ctx->nores.ensure((size_t)cap_nores * sizeof(PairRec)); ctx->counters.ensure(64);
         HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
         HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
-        if (attempt == 0) {
+        {
           // register classes go round-robin over 4 streams (heaviest first) so the tail of one launch -- a few very long
-          // sequences -- is covered by the next launch; ev[0]..ev[1] on the main stream brackets all of them
+          // sequences -- is covered by the next launch; ev[0]..ev[1] on the main stream brackets all of them.  The SSV lanes finish
+          // the MSV stage themselves (survivor / exact-MSV tables); a table that overflowed means the launches run again with larger ones.
+          const SsvEpi epi{lt, ctx->surv.as<PairRec>(), ctx->counters.as<uint32_t>(), cap_surv, ctx->nores.as<PairRec>(), ctx->counters.as<uint32_t>() + 1, cap_nores, nullptr};
           const int NS = std::min(4, side_streams());
           for (int k = 0; k < NS; ++k) HIPCHK(hipStreamWaitEvent(ctx->side[k], ctx->ev[0], 0));
           int gi = 0;
           for (auto it = groups.rbegin(); it != groups.rend(); ++it, ++gi) {
             auto &g = *it;
             if (launch_ssv(g.first, (int)g.second.second, ssv_threads_for(g.first), ctx->side[gi % NS], ctx->work.as<SsvBlockWork>() + g.second.first, dm, res, off, dlen,
-                           s->d_order.as<uint32_t>(), ctx->maxv.as<uint16_t>()))
+                           s->d_order.as<uint32_t>(), epi))
               throw Error(CKM_ERANGE, "no SSV kernel instance for this model length");
-            st.ssv_launches++;
+            if (attempt == 0) st.ssv_launches++;
           }
           for (int k = 0; k < NS; ++k) { HIPCHK(hipEventRecord(ctx->ev[2 + k], ctx->side[k])); HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev[2 + k], 0)); }
         }
         HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
-        FinishArgs fa{dm, lt, dlen, s->d_order.as<uint32_t>(), ctx->work.as<SsvBlockWork>(), ctx->maxv.as<uint16_t>(),
-                      ctx->surv.as<PairRec>(), ctx->counters.as<uint32_t>(), cap_surv, ctx->nores.as<PairRec>(), ctx->counters.as<uint32_t>() + 1, cap_nores};
-        launch_msv_finish(ctx->stream, fa, (uint32_t)nblocks_total);
         HIPCHK(hipGetLastError());
         uint32_t cnt[2] = {0, 0};
         HIPCHK(hipMemcpyAsync(cnt, ctx->counters.p, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (attempt == 0) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); st.ms_ssv += ms; }
-        CKM_TRACE_PT("ssv + msv_finish done");
+        CKM_TRACE_PT("ssv (+ fused finish) done");
         if (cnt[0] > cap_surv || cnt[1] > cap_nores) { cap_surv = std::max(cap_surv, cnt[0]); cap_nores = std::max(cap_nores, cnt[1]); continue; }
         std::vector<PairRec> nr(cnt[1]);
         ctx->h_a.ensure((size_t)cnt[0] * sizeof(PairRec) + 16);
@@ -228,7 +226,7 @@ static void cascade(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profiles
   //  ordered at the end, so no sort is needed here)
   const double t_filters0 = now_ms();
 
-  CKM_TRACE_PT("stage1 done (ssv, msv_finish, msv_full)");
+  CKM_TRACE_PT("stage1 done (ssv, exact msv)");
   // ---- stage 2: bias filter ----
   std::vector<PairRec> cr(cands.size());
   for (size_t i = 0; i < cands.size(); ++i) cr[i] = cands[i].r;
@@ -660,7 +658,6 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   grow(cp.events_f, std::max<uint64_t>(1 << 18, (uint64_t)cp.fwork * 16));
   grow(cp.events_e, std::max<uint64_t>(1 << 16, (uint64_t)cp.ework * 16));
   cp.hens = std::max<uint64_t>(cp.hens, (uint64_t)cp.rwork * (256 + ENS_NSAMPLES * 16 * 4 + 1024));
-  ctx->maxv.ensure(total_pairs * 2 + 64);
   // the float workspace: an estimate from the pairs (special rows of ~0.3 % of them, matrices of ~0.06 %), within the lane's budget
   double mp_sum = 0.0;
   {
@@ -759,13 +756,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
       const int gi_now = gi++;
       const Sub &sb = subs[g];
       hipStream_t sv = ctx->side[gi_now % NSS];
-      if (launch_ssv(sb.Q, (int)sb.nblocks, ssv_threads_for(sb.Q), sv, ctx->work.as<SsvBlockWork>() + sb.first, dm, res, off, dlen,
-                     s->d_order.as<uint32_t>(), ctx->maxv.as<uint16_t>()))
-        throw Error(CKM_ERANGE, "no SSV kernel instance for this model length");
-      st.ssv_launches++;
-      hipStream_t sc = sv;
-      if (NCH > 0) { sc = ctx->side[NSS + gi_now % NCH]; HIPCHK(hipEventRecord(ctx->grp_ev[g], sv)); HIPCHK(hipStreamWaitEvent(sc, ctx->grp_ev[g], 0)); }
-      // ---- the group's chain ----
+      // ---- the group's tables; its SSV launch appends survivors (-> candidate table) and undecided pairs (-> exact-MSV table) itself ----
       CascadeDev cd = cd0;
       uint32_t *cnt = d_gcnt + (1 + g) * CC_SIZE;
       cd.cnt = cnt;
@@ -776,9 +767,14 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
       cd.eq = d_eq + sb.o_e; cd.cap_eq = sb.cap_e;
       cd.rq = d_rq + sb.o_r; cd.cap_rq = sb.cap_r;
       PairRec *nores = d_nores + sb.o_nores;
-      FinishArgs fa{dm, lt, dlen, s->d_order.as<uint32_t>(), ctx->work.as<SsvBlockWork>() + sb.first, ctx->maxv.as<uint16_t>(),
-                    cd.cand, cnt + CC_CAND, sb.cap_cand, nores, cnt + CC_NORES, sb.cap_nores};
-      launch_msv_finish(sc, fa, (uint32_t)sb.nblocks);
+      const SsvEpi epi{lt, cd.cand, cnt + CC_CAND, sb.cap_cand, nores, cnt + CC_NORES, sb.cap_nores, nullptr};
+      if (launch_ssv(sb.Q, (int)sb.nblocks, ssv_threads_for(sb.Q), sv, ctx->work.as<SsvBlockWork>() + sb.first, dm, res, off, dlen,
+                     s->d_order.as<uint32_t>(), epi))
+        throw Error(CKM_ERANGE, "no SSV kernel instance for this model length");
+      st.ssv_launches++;
+      hipStream_t sc = sv;
+      if (NCH > 0) { sc = ctx->side[NSS + gi_now % NCH]; HIPCHK(hipEventRecord(ctx->grp_ev[g], sv)); HIPCHK(hipStreamWaitEvent(sc, ctx->grp_ev[g], 0)); }
+      // ---- the group's chain ----
       if (stop >= 2) {
         // exact MSV of the pairs SSV could not decide: packed, four pairs per wavefront, for every model that has a 16-lane image (an 8-lane
         // class 100 + Q8 holds models of exactly the 16-lane class ceil(Q8 / 2)); the wave-per-pair kernel for models beyond 2048 nodes

@@ -71,10 +71,9 @@ int choose_side_streams(int nworkers) {
   return n;
 }
 
-// The SSV LAUNCH CLASS of a model: its 16-lane register class (1..64), 100 + its 8-lane class for models of up to 512 nodes when the
-// packed-half kernels are in use, kSsvNone (65) when no SSV instance holds it.
-bool ssv_half_mode();
-int ssv_class(const HostProfile &hp) { return (hp.ssv8Q && ssv_half_mode()) ? 100 + hp.ssv8Q : hp.ssvQ; }
+// The SSV LAUNCH CLASS of a model: its 16-lane register class (1..64), 100 + its 8-lane class for models of up to 512 nodes,
+// kSsvNone (65) when no SSV instance holds it.
+int ssv_class(const HostProfile &hp) { return hp.ssv8Q ? 100 + hp.ssv8Q : hp.ssvQ; }
 uint32_t ssv_per_block(int cls) { return (uint32_t)ssv_threads_for(cls) / 64u * (cls >= 100 ? 8u : 4u) * 4u; }      // sequences a workgroup takes: four rounds of its wavefronts
 
 int ssv_threads_for(int Q) {
@@ -241,61 +240,43 @@ void rescore_envelopes(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, co
 // emission image per workgroup), longest sequences first, 16 sequences per workgroup (4 wavefronts x 4).  Results land in
 // usc/xJ in the order of `pairs`.
 void run_msv_exact(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<PairRec> &pairs, std::vector<float> &usc, std::vector<int32_t> *xJ) {
+  // The exact multi-hit MSV bytes of arbitrary pairs (host-driven cascade, diagnostics): the kernels of the device-driven cascade in their
+  // scores-only mode -- msv16_kernel (four pairs per wavefront) per 16-lane register class, msv_full_kernel (wave per pair) for models
+  // beyond 2048 nodes -- over host-built queues: the pairs sorted by class, inside a class by model and longest sequence first.
   const size_t n = pairs.size();
   usc.assign(n, 0.f); if (xJ) xJ->assign(n, 0);
   if (!n) return;
-  std::map<int, std::map<uint32_t, std::vector<uint32_t>>> byQ;            // Q -> model -> indices into pairs
-  std::vector<uint32_t> big;                                                // pairs of models beyond 2048 nodes: the wave-per-pair kernel takes any length
-  for (uint32_t i = 0; i < n; ++i) {
-    if (p->prof[pairs[i].model].ssvQ > 64) big.push_back(i);
-    else byQ[p->prof[pairs[i].model].ssvQ][pairs[i].model].push_back(i);
+  std::map<int, std::vector<uint32_t>> byQ;                                 // class -> indices into pairs (1000: wave-per-pair kernel)
+  for (uint32_t i = 0; i < n; ++i) { const int q = p->prof[pairs[i].model].ssvQ; byQ[q > 64 ? 1000 : q].push_back(i); }
+  std::vector<PairRec> sorted; sorted.reserve(n);
+  std::vector<uint32_t> slot_of(n), counts;
+  std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;             // class, (first, count)
+  for (auto &kv : byQ) {
+    std::vector<uint32_t> &v = kv.second;
+    std::stable_sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) {
+      if (pairs[a].model != pairs[b].model) return pairs[a].model < pairs[b].model;
+      return s->len[pairs[a].seq] > s->len[pairs[b].seq]; });
+    groups.push_back({kv.first, {sorted.size(), v.size()}});
+    counts.push_back((uint32_t)v.size());
+    for (uint32_t i : v) { slot_of[i] = (uint32_t)sorted.size(); sorted.push_back(pairs[i]); }
   }
-  if (!big.empty()) {
-    std::vector<PairRec> bp(big.size());
-    for (size_t k = 0; k < big.size(); ++k) bp[k] = pairs[big[k]];
-    const uint32_t nb = (uint32_t)big.size();
-    DevBuf d_pairs, d_cnt, d_x, d_u;
-    d_pairs.ensure(nb * sizeof(PairRec)); d_cnt.ensure(16); d_x.ensure((size_t)nb * 4); d_u.ensure((size_t)nb * 4);
-    HIPCHK(hipMemcpyAsync(d_pairs.p, bp.data(), nb * sizeof(PairRec), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d_cnt.p, &nb, 4, hipMemcpyHostToDevice, ctx->stream));
-    launch_msv_full(ctx->stream, std::min<uint32_t>(nb, 1024), WorkQueue{nullptr, d_cnt.as<uint32_t>(), nb}, d_pairs.as<PairRec>(), p->d_models.as<DevModel>(), s->d_lentab.as<LenEntry>(),
-                    s->d_res.as<uint8_t>(), s->d_off.as<uint64_t>(), s->d_len.as<int32_t>(), d_x.as<int32_t>(), d_u.as<float>(), p->maxMp, nullptr);
-    HIPCHK(hipGetLastError());
-    std::vector<float> ru(nb); std::vector<int32_t> rx(nb);
-    HIPCHK(hipMemcpyAsync(ru.data(), d_u.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(rx.data(), d_x.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    for (size_t k = 0; k < big.size(); ++k) { usc[big[k]] = ru[k]; if (xJ) (*xJ)[big[k]] = rx[k]; }
-    if (byQ.empty()) return;
-  }
-  std::vector<SsvBlockWork> work; std::vector<uint32_t> lists, slot_of(n); std::vector<std::pair<int, std::pair<size_t, size_t>>> groups;
-  constexpr uint32_t PER_BLOCK = 16;
-  for (auto it = byQ.rbegin(); it != byQ.rend(); ++it) {
-    const size_t first = work.size();
-    std::vector<SsvBlockWork> blocks;
-    for (auto &km : it->second) {
-      std::vector<uint32_t> &v = km.second;
-      std::stable_sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return s->len[pairs[a].seq] > s->len[pairs[b].seq]; });
-      for (size_t a = 0; a < v.size(); a += PER_BLOCK) {
-        SsvBlockWork w; w.model = km.first; w.list_start = (uint32_t)lists.size(); w.count = (uint32_t)std::min<size_t>(PER_BLOCK, v.size() - a); w.pair_start = w.list_start;
-        for (uint32_t k = 0; k < w.count; ++k) { slot_of[v[a + k]] = (uint32_t)lists.size(); lists.push_back(pairs[v[a + k]].seq); }
-        blocks.push_back(w);
-      }
-    }
-    // longest workgroups first inside a launch
-    std::stable_sort(blocks.begin(), blocks.end(), [&](const SsvBlockWork &x, const SsvBlockWork &y) { return s->len[lists[x.list_start]] > s->len[lists[y.list_start]]; });
-    work.insert(work.end(), blocks.begin(), blocks.end());
-    groups.push_back({it->first, {first, work.size() - first}});
-  }
-  ctx->msvwork.ensure(work.size() * sizeof(SsvBlockWork)); ctx->msvlist.ensure(lists.size() * 4);
+  ctx->msvwork.ensure(n * sizeof(PairRec)); ctx->msvlist.ensure(counts.size() * 4 + 16);
   ctx->fullx.ensure(n * 4); ctx->fullu.ensure(n * 4);
-  HIPCHK(hipMemcpyAsync(ctx->msvwork.p, work.data(), work.size() * sizeof(SsvBlockWork), hipMemcpyHostToDevice, ctx->stream));
-  wcopy(ctx, ctx->msvlist.p, lists.data(), lists.size() * 4, hipMemcpyHostToDevice);
+  wcopy(ctx, ctx->msvwork.p, sorted.data(), n * sizeof(PairRec), hipMemcpyHostToDevice);
+  wcopy(ctx, ctx->msvlist.p, counts.data(), counts.size() * 4, hipMemcpyHostToDevice);
+  CascadeDev none; memset(&none, 0, sizeof(none));
   int gi = 0;
   for (auto &g : groups) {
-    if (launch_msv(g.first, (int)g.second.second, ctx->side[gi++ % side_streams()], ctx->msvwork.as<SsvBlockWork>() + g.second.first, p->d_models.as<DevModel>(), s->d_lentab.as<LenEntry>(),
-                   s->d_res.as<uint8_t>(), s->d_off.as<uint64_t>(), s->d_len.as<int32_t>(), ctx->msvlist.as<uint32_t>(), ctx->fullx.as<int32_t>(), ctx->fullu.as<float>()))
-      throw Error(CKM_ERANGE, "no MSV kernel instance for this model length");
+    const size_t first = g.second.first; const uint32_t cnt = (uint32_t)g.second.second;
+    hipStream_t st = ctx->side[gi % side_streams()];
+    const WorkQueue q{nullptr, ctx->msvlist.as<uint32_t>() + gi, cnt};
+    ++gi;
+    if (g.first == 1000)
+      launch_msv_full(st, std::min<uint32_t>(cnt, 1024), q, ctx->msvwork.as<PairRec>() + first, p->d_models.as<DevModel>(), s->d_lentab.as<LenEntry>(),
+                      s->d_res.as<uint8_t>(), s->d_off.as<uint64_t>(), s->d_len.as<int32_t>(), ctx->fullx.as<int32_t>() + first, ctx->fullu.as<float>() + first, p->maxMp, nullptr);
+    else if (launch_msv16(g.first, std::min<uint32_t>((cnt + 15) / 16, 1024), st, q, ctx->msvwork.as<PairRec>() + first, p->d_models.as<DevModel>(), s->d_lentab.as<LenEntry>(),
+                          s->d_res.as<uint8_t>(), s->d_off.as<uint64_t>(), s->d_len.as<int32_t>(), none, ctx->fullx.as<int32_t>() + first, ctx->fullu.as<float>() + first))
+      throw Error(CKM_ERANGE, "no exact-MSV kernel instance for this model length");
   }
   HIPCHK(hipGetLastError());
   for (auto &st : ctx->side) HIPCHK(hipStreamSynchronize(st));
@@ -303,7 +284,7 @@ void run_msv_exact(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const 
   HIPCHK(hipMemcpyAsync(raw.data(), ctx->fullu.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (xJ) HIPCHK(hipMemcpyAsync(rawx.data(), ctx->fullx.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  for (size_t i = 0; i < n; ++i) { if (p->prof[pairs[i].model].ssvQ > 64) continue; usc[i] = raw[slot_of[i]]; if (xJ) (*xJ)[i] = rawx[slot_of[i]]; }
+  for (size_t i = 0; i < n; ++i) { usc[i] = raw[slot_of[i]]; if (xJ) (*xJ)[i] = rawx[slot_of[i]]; }
 }
 
 // ---- multi-domain regions: trace ensemble on the device, clustering of the sampled segments here ----------------

@@ -20,8 +20,9 @@ struct DevModel {
   float   beo1[30];
   // filter thresholds (score space)
   float   thr_msv_f1, thr_msv_f2, thr_vit_f2, thr_fwd_f3;
+  float   thr_msv_f1_nat;   // smallest float v with (float)((double)v / ln 2) >= thr_msv_f1: the F1 test of the SSV epilogue, in nats
   // tables in HBM
-  const int16_t *ssv_tbl;   // [Qg][30][16][8]  bias - cost as int16 (exact MSV kernel, CKM_SSV=i16)
+  const int16_t *ssv_tbl;   // [Qg][30][16][8]  bias - cost as int16 (msv16_kernel, the exact MSV stage)
   const uint16_t *ssv_tbl_h; // same layout, (bias - cost)/256 as IEEE half bits (ssv_kernel_h)
   const uint16_t *ssv8_tbl_h; // [Qg8][30][2 copies][8 lanes][8] the 8-lane image of models of <= 512 nodes (ssv_kernel_h8), or null
   const uint8_t *rbv;       // [29][M+1]
@@ -95,12 +96,11 @@ struct EnsWork {             // one multi-domain region handed to the trace-ense
   uint64_t host_off;                   // device-driven cascade: float offset of this region's exported results (counts, segments, sums) in the pinned result buffer
 };
 
-struct FinishArgs {
-  const DevModel *models; const LenEntry *lentab; const int32_t *seq_len; const uint32_t *lists;
-  const SsvBlockWork *work;            // the table the SSV launches used (one entry per SSV block)
-  const uint16_t *maxv;                // Smax per pair (0 = degenerate: recompute exactly)
-  PairRec *survivors; uint32_t *nsurv; uint32_t cap_surv;
-  PairRec *noresult;  uint32_t *nnores; uint32_t cap_nores;
+struct SsvEpi {               // by-value argument of the SSV launches: where the fused finish of the MSV stage puts its output
+  const LenEntry *lentab;
+  PairRec *survivors; uint32_t *nsurv; uint32_t cap_surv;      // pairs that pass F1 (or overflowed the byte score)
+  PairRec *noresult;  uint32_t *nnores; uint32_t cap_nores;    // pairs SSV cannot decide (J state usable, or Smax = 0): exact MSV kernel
+  uint16_t *maxv;                      // diagnostics only (ckm_debug_stages): Smax per pair is stored and NOTHING else happens; null in the product
 };
 
 // ---- device-driven cascade (ckm_cascade.hip, kernels_*.hip epilogues) ---------------------------------------------------------

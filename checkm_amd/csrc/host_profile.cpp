@@ -498,6 +498,10 @@ HostProfile configure_profile(const HostHMM &h) {
     p.thr_msv_f2 = passing_threshold([&](double x) { return gumbel_surv(x, mmu, mlam); }, 1e-3);
     p.thr_vit_f2 = passing_threshold([&](double x) { return gumbel_surv(x, vmu, vlam); }, 1e-3);
     p.thr_fwd_f3 = passing_threshold([&](double x) { return exp_surv(x, ftau, flam); }, 1e-5);
+    // the first F1 test in NATS: bits(usc, nullsc) = (float)((double)(usc - nullsc) / ln 2) is monotone in the float usc - nullsc, so the
+    // smallest such float whose bits reach thr_msv_f1 decides exactly as the bit-space test does, without a double divide per pair
+    const float thr = p.thr_msv_f1;
+    p.thr_msv_f1_nat = passing_threshold([&](double v) { return ((float)(v / kLn2) >= thr) ? 0.0 : 1.0; }, 0.5);
   }
   return p;
 }

@@ -1,5 +1,4 @@
 // kernels_filter.hip -- the rest of the acceleration-filter cascade, gfx950 only:
-//   msv_finish_kernel  turns SSV maxV into the MSV byte score, applies F1, appends survivors
 //   msv_full_kernel    full multi-hit MSV for the rare pairs whose J state could be used
 //   bias_kernel        2-state composition filter (Forward, power-of-two rescaling); F1/F2 tests follow on the host
 //   vit_kernel<QH>     16-bit Viterbi filter, one wavefront per pair, packed words, lazy-F D->D passes
@@ -9,6 +8,7 @@
 // to the host formulation: thresholds were converted to score space on the host (host_profile.cpp).
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <mutex>
 #include <cstring>
 #include "dev_types.h"
 #include "cascade_dev.h"
@@ -24,7 +24,7 @@ constexpr double LN2D = 0.69314718055994529;
 constexpr int NEG16 = -32768;
 
 // --------------------------------------------------------------------------------------------
-// MSV finish
+// MSV score arithmetic of the exact kernels (the SSV kernels finish their own pairs: kernels_ssv.hip, ssv_finish)
 // --------------------------------------------------------------------------------------------
 __device__ __forceinline__ float msv_score(int xJ, int tjb, int base, float scale_b) {
   float sc = (float)(xJ - tjb) - (float)base;
@@ -36,57 +36,13 @@ __device__ __forceinline__ float to_bits(float sc, float nullsc) {
   return (float)((double)(sc - nullsc) / LN2D);
 }
 
-__global__ void msv_finish_kernel(FinishArgs a, uint32_t nblocks_work) {
-  const uint32_t wb = blockIdx.x;
-  if (wb >= nblocks_work) return;
-  const SsvBlockWork w = a.work[wb];
-  const DevModel &md = a.models[w.model];
-  for (uint32_t li = threadIdx.x; li < w.count; li += blockDim.x) {
-    const uint32_t sid = a.lists[w.list_start + li];
-    const int L = a.seq_len[sid];
-    if (L <= 0) continue;
-    const LenEntry le = a.lentab[L];
-    const int maxV = a.maxv[w.pair_start + li];
-    const int tjbm = (le.tjb_b + md.tbm_b) & 0xff;
-    const int xB = max(md.base_b - tjbm, 0);
-    const int xEi = xB + maxV;
-    PairRec r; r.model = w.model; r.seq = sid; r.filtersc = 0.f;
-    if (maxV == 0) {                             // no cell ever rose above xB: the floored recurrence lost max V; exact kernel
-      r.usc = 0.f;
-      const uint32_t k = atomicAdd(a.nnores, 1u);
-      if (k < a.cap_nores) a.noresult[k] = r;
-      continue;
-    }
-    if (xEi + md.bias_b >= 255) {               // byte overflow: score is +inf, passes every MSV test
-      r.usc = __builtin_inff();
-      const uint32_t k = atomicAdd(a.nsurv, 1u);
-      if (k < a.cap_surv) a.survivors[k] = r;
-      continue;
-    }
-    const int xE = max(xEi, 0);
-    const int xJ = max(xE - md.tec_b, 0);
-    if (xJ > md.base_b) {                        // J could have been used: exact multi-hit MSV needed
-      r.usc = 0.f;
-      const uint32_t k = atomicAdd(a.nnores, 1u);
-      if (k < a.cap_nores) a.noresult[k] = r;
-      continue;
-    }
-    const float usc = msv_score(xJ, le.tjb_b, md.base_b, md.scale_b);
-    if (to_bits(usc, le.nullsc) >= md.thr_msv_f1) {
-      r.usc = usc;
-      const uint32_t k = atomicAdd(a.nsurv, 1u);
-      if (k < a.cap_surv) a.survivors[k] = r;
-    }
-  }
-}
-
 // --------------------------------------------------------------------------------------------
 // full multi-hit MSV: one wavefront (= one workgroup) per pair.  The model's byte costs for all 29 symbols are copied
 // into LDS once per pair and the residues ride in registers, 64 at a time, so no global load sits on the row-to-row
 // chain (rows of the longest sequence bound the launch).  Cells k = lane + 64*j, previous/current row in LDS.
 // --------------------------------------------------------------------------------------------
 // `queue.list` is unused: entry k of the queue is pairs[k].  With `decide` the kernel is the exact-MSV stage of the device-driven
-// cascade: a pair whose exact score passes F1 (the same IEEE test msv_finish_kernel applies) joins the candidate table.
+// cascade: a pair whose exact score passes F1 (the bit-space form of the test the SSV epilogue takes in nats) joins the candidate table.
 __global__ void __launch_bounds__(64) msv_full_kernel(WorkQueue queue, const PairRec *__restrict__ pairs, const DevModel *__restrict__ models,
                                                      const LenEntry *__restrict__ lentab, const uint8_t *__restrict__ res,
                                                      const uint64_t *__restrict__ seq_off, const int32_t *__restrict__ seq_len,
@@ -553,8 +509,7 @@ int launch_vit16(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, c
 // --------------------------------------------------------------------------------------------
 // Exact multi-hit MSV for the pairs SSV cannot decide, packed (round 3): 16 lanes per pair, four pairs per wavefront, SSV's lane mapping
 // and the byte recurrence carried in full -- sv = max(prev, xB) + (bias - cost), floored by the clamped add (offset -32768), every row
-// ending with the 16-lane maximum that feeds xJ and xB (msv_kernel<Q> of kernels_ssv.hip, which the host-driven cascade uses, does the
-// same from an LDS image for 16 pairs of ONE model).  Here the four pairs of a wavefront are whatever the queue holds -- own model, own
+// ending with the 16-lane maximum that feeds xJ and xB.  The four pairs of a wavefront are whatever the queue holds -- own model, own
 // sequence -- so the emission words come from the model's i16 image in global memory (L2: a group's models are few), one row ahead.
 // 3 packed ops per register per row + ~25, for four pairs: ~6x fewer instructions than the wave-per-pair msv_full_kernel and no 50 KB
 // LDS image per pair; msv_full_kernel stays for models beyond 2048 nodes (no 16-lane image) and for the diagnostics.
@@ -566,7 +521,8 @@ constexpr int MSV16_GSTRIDE = 30 * 256;       // bytes per register group of the
 template <int Q>
 __global__ void __launch_bounds__(256) msv16_kernel(WorkQueue queue, const PairRec *__restrict__ pairs, const DevModel *__restrict__ models,
                                                     const LenEntry *__restrict__ lentab, const uint8_t *__restrict__ res, const uint64_t *__restrict__ seq_off,
-                                                    const int32_t *__restrict__ seq_len, CascadeDev cd) {
+                                                    const int32_t *__restrict__ seq_len, CascadeDev cd,
+                                                    int32_t *__restrict__ out_xJ /* scores only: xJ (-1 overflow) and the score of entry pi, no decision */, float *__restrict__ out_usc) {
   constexpr int Qg = (Q + 3) / 4;
   const int lane = threadIdx.x & 63, z = lane & 15, g = lane >> 4;
   const uint32_t nqueue = queue_len(queue);
@@ -644,7 +600,8 @@ __global__ void __launch_bounds__(256) msv16_kernel(WorkQueue queue, const PairR
     }
     if (valid && z == 0) {
       const float usc = overflow ? __builtin_inff() : msv_score(xJ, le.tjb_b, md.base_b, md.scale_b);
-      if (to_bits(usc, le.nullsc) >= md.thr_msv_f1) {
+      if (out_usc) { out_xJ[pi] = overflow ? -1 : xJ; out_usc[pi] = usc; }
+      else if (to_bits(usc, le.nullsc) >= md.thr_msv_f1) {
         const uint32_t k = atomicAdd(&cd.cnt[CC_CAND], 1u);
         if (k < cd.cap_cand) { PairRec r = pr; r.usc = usc; r.filtersc = 0.f; cd.cand[k] = r; } else atomicOr(&cd.gcnt[CC_STATUS], (uint32_t)CS_CAND);
       }
@@ -653,10 +610,10 @@ __global__ void __launch_bounds__(256) msv16_kernel(WorkQueue queue, const PairR
 }
 
 int launch_msv16(int Q, uint32_t nblocks, hipStream_t stream, WorkQueue queue, const PairRec *pairs, const DevModel *models, const LenEntry *lentab,
-                 const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const CascadeDev &cd) {
+                 const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, const CascadeDev &cd, int32_t *out_xJ, float *out_usc) {
   if (nblocks == 0) return 0;
   switch (Q) {
-#define X(QV) case QV: hipLaunchKernelGGL(msv16_kernel<QV>, dim3(nblocks), dim3(256), 0, stream, queue, pairs, models, lentab, res, seq_off, seq_len, cd); break;
+#define X(QV) case QV: hipLaunchKernelGGL(msv16_kernel<QV>, dim3(nblocks), dim3(256), 0, stream, queue, pairs, models, lentab, res, seq_off, seq_len, cd, out_xJ, out_usc); break;
     X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32) X(36) X(40) X(48) X(56) X(64)
 #undef X
     default: return -1;
@@ -682,9 +639,6 @@ int launch_vit(int QH, uint32_t nblocks, hipStream_t stream, WorkQueue queue, co
   return 0;
 }
 
-void launch_msv_finish(hipStream_t stream, const FinishArgs &a, uint32_t nblocks) {
-  if (nblocks) hipLaunchKernelGGL(msv_finish_kernel, dim3(nblocks), dim3(256), 0, stream, a, nblocks);
-}
 void launch_msv_full(hipStream_t stream, uint32_t nblocks, WorkQueue queue, const PairRec *pairs, const DevModel *models, const LenEntry *lentab,
                      const uint8_t *res, const uint64_t *seq_off, const int32_t *seq_len, int32_t *out_xJ, float *out_usc, int maxMp,
                      const CascadeDev *cd) {
@@ -692,8 +646,12 @@ void launch_msv_full(hipStream_t stream, uint32_t nblocks, WorkQueue queue, cons
   CascadeDev c; memset(&c, 0, sizeof(c));
   if (cd) c = *cd;
   const size_t lds = (((size_t)KP_SYMS * (maxMp + 1) + 15) & ~(size_t)15) + (size_t)2 * maxMp * sizeof(int16_t);
-  static std::atomic<size_t> attr_bytes{0};          // (searches of several contexts launch from their own host threads)
-  if (lds > 48 * 1024 && lds > attr_bytes.load()) { (void)hipFuncSetAttribute((const void *)msv_full_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_bytes.store(lds); }
+  {
+    // (searches of several contexts launch from their own host threads: the limit only ever grows, and check + set + launch are one critical section)
+    static std::mutex attr_mutex; static size_t attr_bytes = 0;
+    std::lock_guard<std::mutex> lock(attr_mutex);
+    if (lds > 48 * 1024 && lds > attr_bytes) { (void)hipFuncSetAttribute((const void *)msv_full_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_bytes = lds; }
+  }
   hipLaunchKernelGGL(msv_full_kernel, dim3(nblocks), dim3(64), lds, stream, queue, pairs, models, lentab, res, seq_off, seq_len, out_xJ, out_usc, maxMp, c, cd ? 1 : 0);
 }
 void launch_bias(hipStream_t stream, PairRec *pairs, uint32_t npairs, const DevModel *models, const LenEntry *lentab,
