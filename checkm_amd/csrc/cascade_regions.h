@@ -75,6 +75,7 @@ __device__ __forceinline__ void emit_region(const CascadeDev &cd, const DevModel
         w.slot = r; w.full = 2; w.cand = pw.cand; w.pass = pw.pass;
         cd.rwork[r] = w;
         queue_push(cd, cd.rq, CC_RQ, md.fb_cls, cd.cap_rq, r, (uint32_t)CS_RWORK);
+        if (cd.ensq) { const uint32_t k = atomicAdd(cd.ensq_cnt, 1u); if (k < cd.cap_rwork) cd.ensq[k] = r; }      // the part's trace-ensemble launch
         rec.target = r;
       } else atomicOr(&cd.gcnt[CC_STATUS], (uint32_t)CS_RWORK);
     }

@@ -90,6 +90,7 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
       for (auto &e : w.cev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       for (auto &e : w.cls_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       for (auto &e : w.grp_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      for (auto &e : w.ens_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       memset(&w.stats, 0, sizeof(w.stats));
       w.ws_budget = budget;
       if (getenv("CKM_WS_VMM") && atoi(getenv("CKM_WS_VMM")) != 0) { w.ws.vmm = true; w.ws.va_bytes = budget + ((size_t)8 << 30); }   // (opt-in until it has run the whole GPU suite)
@@ -128,6 +129,7 @@ extern "C" void ckm_ctx_destroy(ckm_ctx *ctx) {
     for (auto &e : w.cev) if (e) (void)hipEventDestroy(e);
     for (auto &e : w.cls_ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : w.grp_ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : w.ens_ev) if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < w.nside; ++k) (void)hipStreamDestroy(w.side[k]);
     if (w.late[0]) (void)hipStreamDestroy(w.late[0]);
     (void)hipStreamDestroy(w.stream);

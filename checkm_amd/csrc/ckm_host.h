@@ -196,11 +196,13 @@ struct Worker {
   // ---- device-driven cascade (ckm_cascade.hip): tables, queues and result buffers of this lane; capacities only grow ----
   struct CascadeCaps { uint32_t fwork = 0, ework = 0, rwork = 0, pass = 0, reg = 0, events_f = 0, events_e = 0; uint64_t hens = 0;
                        uint32_t div_cand = 12, div_nores = 48, div_fwork = 160, div_ework = 256, div_rwork = 32768; float ws_per_mp = 0.8f; } caps;   // per-group tables hold pairs / div entries
-  DevBuf c_cnt, c_cand, c_nores, c_bias, c_vfast, c_vexact, c_vflag, c_route, c_vq, c_vxq, c_fq, c_bq, c_eq, c_rq, c_fwork, c_ework, c_rwork, c_ens,
+  DevBuf c_cnt, c_cand, c_nores, c_bias, c_vfast, c_vexact, c_vflag, c_route, c_vq, c_vxq, c_fq, c_bq, c_eq, c_rq, c_fwork, c_ework, c_rwork, c_ens, c_ensq,
          c_fout_f, c_fout_e, c_fout_r, c_rerr_e, c_rerr_r, c_tops, c_events_r, c_pass, c_reg, c_hens, c_envout, c_events_f, c_events_e;
   PinnedBuf h_cnt, h_pass, h_reg, h_envout, h_events_f, h_events_e, h_hens, h_tops;
   hipEvent_t cev[4] = {nullptr, nullptr, nullptr, nullptr};      // fork / join points of the lane's chain
   hipEvent_t cls_ev[16] = {};                                    // one per side stream
+  bool ens_pending = false;
+  hipEvent_t ens_ev[17] = {};                                    // chain streams -> the trace-ensemble launch of a sequence part; [16]: that launch -> main stream
   PinnedBuf wstage; std::mutex wstage_mutex;                     // wcopy's staging buffer
   Stager stager;                                                 // staging of the per-search uploads (plan, late rounds)
   hipStream_t late[4] = {};                                      // high-priority streams of the short rounds that follow a search's drain (run_fb with late_round set)

@@ -683,6 +683,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   cd0.fwork = dev_table<FbWork>(ctx->c_fwork, cp.fwork); cd0.cap_fwork = cp.fwork;
   cd0.ework = dev_table<FbWork>(ctx->c_ework, cp.ework); cd0.cap_ework = cp.ework;
   cd0.rwork = dev_table<FbWork>(ctx->c_rwork, cp.rwork); cd0.ens = dev_table<EnsWork>(ctx->c_ens, cp.rwork); cd0.cap_rwork = cp.rwork;
+  uint32_t *d_ensq = dev_table<uint32_t>(ctx->c_ensq, (size_t)4 * cp.rwork);       // region ids by sequence part
   // zone 1: special rows and decoding terms of the parser items (~a few KB for ~0.3 % of the pairs); zone 2: everything else
   {
     const uint64_t z1 = std::min<uint64_t>(ws_floats / 2, ((uint64_t)total_pairs * 64 + ((uint64_t)64 << 20)) / 4) & ~(uint64_t)31;
@@ -751,10 +752,32 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
         g0 = g1;
       }
     }
-    int gi = 0;
+    // The trace ensembles of the multi-domain regions: ONE set of launches per sequence PART, behind the chains of all of the part's
+    // groups, on the worker's high-priority stream.  A region's 200 traces run one after the other (one generator stream per region, as
+    // hmmsearch carries it), so a launch lasts as long as its longest region -- tens of milliseconds; per group and register class, on the
+    // group's chain stream (round 3, when a launch took 2 ms), those latencies queued up behind each other (measured: 11.5 -> 14.1 s per
+    // 1000 bins).  The long part's ensembles run underneath the SSV launches of the short part; what is left after the last SSV launch
+    // are the regions of the short sequences.
+    int ens_Mp = NL;
+    for (const Sub &sb : subs) for (int c = 0; c < NFC; ++c) if (sb.fb[c]) ens_Mp = std::max(ens_Mp, kFbQ[c] * NL);
+    hipStream_t es = ctx->late[0];
+    bool ens_launched = false;
+    auto ens_slot = [](int part) { return std::min(part, 3); };
+    auto flush_part = [&](int part) {
+      if (stop < 13) return;
+      const int k0 = NCH > 0 ? NSS : 0, k1 = NCH > 0 ? NS : NSS;
+      for (int k = k0; k < k1; ++k) { HIPCHK(hipEventRecord(ctx->ens_ev[k], ctx->side[k])); HIPCHK(hipStreamWaitEvent(es, ctx->ens_ev[k], 0)); }
+      const int sl = ens_slot(part);
+      launch_ensemble(es, cd0.ens, d_ensq + (size_t)sl * cp.rwork, d_gcnt + CC_ENSQ + sl, cp.rwork, 64, ens_Mp, dm, lt, res, off, ws, ctx->ensseeds.as<uint32_t>(), d_hens);
+      ens_launched = true;
+    };
+    int gi = 0, cur_part = -1;
     for (size_t g : launch_order) {
       const int gi_now = gi++;
       const Sub &sb = subs[g];
+      const int part = groups[g].first / 1000;
+      if (cur_part >= 0 && ens_slot(part) != ens_slot(cur_part)) flush_part(cur_part);
+      cur_part = part;
       hipStream_t sv = ctx->side[gi_now % NSS];
       // ---- the group's tables; its SSV launch appends survivors (-> candidate table) and undecided pairs (-> exact-MSV table) itself ----
       CascadeDev cd = cd0;
@@ -766,6 +789,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
       cd.fq = d_fq + sb.o_f; cd.bq = d_bq + sb.o_f; cd.cap_fq = sb.cap_f;
       cd.eq = d_eq + sb.o_e; cd.cap_eq = sb.cap_e;
       cd.rq = d_rq + sb.o_r; cd.cap_rq = sb.cap_r;
+      cd.ensq = d_ensq + (size_t)ens_slot(part) * cp.rwork; cd.ensq_cnt = d_gcnt + CC_ENSQ + ens_slot(part);
       PairRec *nores = d_nores + sb.o_nores;
       const SsvEpi epi{lt, cd.cand, cnt + CC_CAND, sb.cap_cand, nores, cnt + CC_NORES, sb.cap_nores, nullptr};
       if (launch_ssv(sb.Q, (int)sb.nblocks, ssv_threads_for(sb.Q), sv, ctx->work.as<SsvBlockWork>() + sb.first, dm, res, off, dlen,
@@ -806,12 +830,12 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
         if (stop >= 10) rc |= launch_bwd(Q, GRID_FB, sc, qe, cd.ework, dm, lt, res, off, ws, d_fout_e, d_rerr_e);
         if (stop >= 11) rc |= launch_oa(Q, GRID_FB, sc, qe, cd.ework, dm, ws, d_rerr_e, d_fout_e, d_envout);
         if (stop >= 12) rc |= launch_fwd(Q, std::max(64u, GRID_FB / 8), sc, qr, cd.rwork, dm, lt, res, off, ws, d_fout_r, d_events_r, d_gcnt + CC_EVENTS_R, 1 << 16, nullptr);
-        // trace ensembles of the multi-domain regions of this group and register class, straight behind their Forward matrices on the
-        // group's chain stream (results exported for the host's clustering): only the last groups' ensembles are left after the SSV phase
-        if (stop >= 13) launch_ensemble(sc, cd0.ens, qr.list, qr.count, sb.cap_r, 16, Q * NL, dm, lt, res, off, ws, ctx->ensseeds.as<uint32_t>(), d_hens);
       }
       if (rc) throw Error(CKM_ERANGE, "no kernel instance for this model length");
     }
+    if (cur_part >= 0) flush_part(cur_part);
+    if (ens_launched) HIPCHK(hipEventRecord(ctx->ens_ev[16], es));
+    ctx->ens_pending = ens_launched;
   }
   // the SSV streams join the main stream first (end of the lane's SSV phase: the next lane may start its own), then the chains
   for (int k = 0; k < NSS; ++k) { HIPCHK(hipEventRecord(ctx->cls_ev[k], ctx->side[k])); HIPCHK(hipStreamWaitEvent(ms, ctx->cls_ev[k], 0)); }
@@ -824,6 +848,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
     took_turn = true; owner->ssv_turn++; owner->ssv_cv.notify_all();
   }
   for (int k = NSS; k < NS; ++k) { HIPCHK(hipEventRecord(ctx->cls_ev[k], ctx->side[k])); HIPCHK(hipStreamWaitEvent(ms, ctx->cls_ev[k], 0)); }
+  if (ctx->ens_pending) { HIPCHK(hipStreamWaitEvent(ms, ctx->ens_ev[16], 0)); ctx->ens_pending = false; }
   // ---- counters last ----
   HIPCHK(hipMemcpyAsync(h_cnt, d_gcnt, (NG + 1) * CC_SIZE * sizeof(uint32_t), hipMemcpyDeviceToHost, ms));
   unsigned long long *h_tops = pin_table<unsigned long long>(ctx->h_tops, 4);

@@ -111,6 +111,7 @@ constexpr int NFC = 12;               // Forward/Backward register classes Q in 
 
 enum CascadeCounter : int {           // uint32 counters in device memory (count and head arrays share this layout)
   CC_CAND = 0, CC_NORES, CC_FWORK, CC_EWORK, CC_RWORK, CC_PASS, CC_REG, CC_EVENTS, CC_STATUS, CC_EVENTS_E, CC_EVENTS_R,
+  CC_ENSQ = 11,                       // 11..14: multi-domain regions of sequence part 0, 1, 2, >= 3 (one trace-ensemble launch per part)
   CC_VQ = 16, CC_VXQ = CC_VQ + NVC, CC_FQ = CC_VXQ + NVC, CC_BQ = CC_FQ + NFC, CC_EQ = CC_BQ + NFC, CC_RQ = CC_EQ + NFC, CC_END = CC_RQ + NFC
 };
 constexpr int CC_SIZE = 128;
@@ -150,6 +151,7 @@ struct CascadeDev {                   // by-value kernel argument: where the epi
   FbWork *fwork; uint32_t cap_fwork;
   FbWork *ework; uint32_t cap_ework;
   FbWork *rwork; EnsWork *ens; uint32_t cap_rwork;
+  uint32_t *ensq; uint32_t *ensq_cnt;                                  // [cap_rwork] region ids of this group's sequence PART, and their count (shared by the part's groups)
   unsigned long long *ws_top; unsigned long long ws_cap;                // bump allocator over the float workspace (units: floats): rows of the parser items
   unsigned long long *ws2_top; unsigned long long ws2_base, ws2_cap;    // second zone [ws2_base, ws2_base + ws2_cap): matrices of envelopes and ensemble regions;
                                                                         // a region that finds no room here is left to the host (RegionRec.target = REGION_DEFERRED)
