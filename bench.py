@@ -596,6 +596,43 @@ def cpu_baseline_cfg3(w, binIds, files, lin, budget_s, threads):
     return out
 
 
+def verify_tables(out_dir, table, hmm_path, lin, binIds, files, k_bins, with_qa, workdir, seed=4):
+    """--verify: after the timed region, K random bins of the LAST timed step's output directory are diffed against the CPU oracles
+    (tools/verify_sample.py): the written domtblout lines of >= 40 sampled models per bin (every SSV launch class of the bin's model
+    list represented) against oracle/p7oracle.c, and -- cfg3 -- the bin's row of the QA table against oracle/reduce_oracle.py.
+    The per-bin model dictionaries come from an (untimed) find() over just those bins into a scratch directory: host logic only decides
+    them, and that second set of tables must equal the first as well."""
+    from checkm_amd import markerGeneFinder as mgf
+    from checkm_amd.defaultValues import DefaultValues
+    from checkm_amd.markerSets import MarkerSetParser
+    from tools import verify_sample as vs
+    rng = np.random.default_rng(seed)
+    pick = sorted(rng.choice(len(binIds), size=min(k_bins, len(binIds)), replace=False).tolist())
+    sub_ids, sub_files = [binIds[b] for b in pick], [files[b] for b in pick]
+    t0 = time.perf_counter()
+    scratch = os.path.join(workdir, "verify_scratch")
+    models = mgf.MarkerGeneFinder(8).find(sub_files, scratch, table, DefaultValues.HMMER_OUT, lin, False, False, True)
+    mgf.release_scan(scratch)
+    again = all(open(os.path.join(scratch, "bins", b, table)).read() == open(os.path.join(out_dir, "bins", b, table)).read() for b in sub_ids)
+    sets = qa_rows = pfam = None
+    if with_qa:
+        sets = MarkerSetParser().getMarkerSets(out_dir, sub_ids, lin)
+        with open(os.path.join(out_dir, "qa_table.tsv")) as f:
+            qa_rows = {ln.split("\t")[0]: ln.rstrip("\n") for ln in f.read().split("\n")[1:] if ln.strip()}
+        pfam = open(DefaultValues.PFAM_CLAN_FILE).read()
+    res = vs.verify(out_dir, table, hmm_path, sub_ids, sub_files, models, k_bins=len(sub_ids), n_models=40, seed=seed,
+                    marker_sets=sets, qa_rows=qa_rows, pfam_text=pfam)
+    res["same_tables_when_scanned_alone"] = bool(again)
+    res["identical"] = bool(res["identical"] and again)
+    res["seconds"] = time.perf_counter() - t0
+    return res
+
+
+def DefaultValues_HMMER_TABLE_OUT():
+    from checkm_amd.defaultValues import DefaultValues
+    return DefaultValues.HMMER_TABLE_OUT
+
+
 def cfg3_counters(alg_bytes):
     """HBM traffic and VALU instruction count of the SSV launches, scaled from the rocprofv3 --pmc passes of a cfg3 SAMPLE
     (profiles/<tag>_cfg3_ssv_traffic.json: counters and algorithmic bytes of the sample; tools/collect_profiles.sh)."""
@@ -672,6 +709,9 @@ def bench_cfg5(args, env):
             "find_parts_s": {k: tot.get(k, 0.0) for k in ("ingest_s", "search_s", "write_s")}, "first_pass_s": first_s, "first_pass_bins": len(warm),
             "setup_s": {"world_and_files": t_setup}, "cpu_baseline": None}
     mgf.release_scan()
+    line["verify"] = None
+    if args.verify > 0 and not args.no_verify:
+        line["verify"] = verify_tables(out_dir, DefaultValues.HMMER_TABLE_OUT, hmm, hmm, ["mag_%03d" % b for b in range(nbins)], files, min(args.verify, 2), False, workdir)
     return line
 
 
@@ -873,6 +913,10 @@ def bench_cfg3(args, env):
         out["emulated_rank"] = "%d/%d" % emu
         out["metric"] += " -- EMULATION of rank %d of %d on one GPU (shard of the bins, all-bins host work, no collective)" % emu
         return out
+    if world == 1 and args.verify > 0 and not args.no_verify:
+        out["verify"] = verify_tables(os.path.join(workdir, "cfg3_out"), DefaultValues_HMMER_TABLE_OUT(), w.checkm_hmm, lin, binIds, files, args.verify, True, workdir)
+    else:
+        out["verify"] = None
     if world == 1:
         if not args.no_emulation:
             # rank 0 of 8 on this GPU: what configs[3] costs a rank (its shard on the device + every piece of all-bins host work)

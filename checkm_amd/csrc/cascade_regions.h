@@ -53,7 +53,7 @@ __device__ __forceinline__ void emit_region(const CascadeDev &cd, const DevModel
     const unsigned long long n2 = pos; pos = al32(pos + Ld);
     const unsigned long long nres = pos;
     const unsigned long long xs = pos; pos = al32(pos + (Ld + 1) * 6);
-    const unsigned long long mx = pos; pos = al32(pos + (Ld + 1) * 3 * Mp);
+    const unsigned long long mx = pos; pos = al32(pos + (Ld + 1) * 4 * Mp);      // cell-major rows of float4 {M, I, D, 0}
     const unsigned long long code = pos; pos = al32(pos + ((unsigned long long)ENS_NSAMPLES * (Ld + 1) + 1) / 2);
     const unsigned long long ratio = pos; pos = al32(pos + (unsigned long long)ENS_NSAMPLES * (Ld + 1));
     if (!ws2_alloc(cd, pos, off)) rec.target = REGION_DEFERRED;

@@ -391,7 +391,7 @@ void ens_queue_batch(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, EnsJ
     EnsWork &e = job.ew[k];
     const int Mp = p->prof[e.model].fbQ * NL, Ld = e.Ld;
     e.xs_off = pos;    pos = al(pos + (uint64_t)(Ld + 1) * 6);
-    e.mx_off = pos;    pos = al(pos + (uint64_t)(Ld + 1) * 3 * Mp);
+    e.mx_off = pos;    pos = al(pos + (uint64_t)(Ld + 1) * 4 * Mp);        // cell-major rows of float4 {M, I, D, 0}
     e.code_off = pos;  pos = al(pos + ((uint64_t)ENS_NSAMPLES * (Ld + 1) + 1) / 2);
     e.ratio_off = pos; pos = al(pos + (uint64_t)ENS_NSAMPLES * (Ld + 1));
     FbWork w; memset(&w, 0, sizeof(w));
@@ -436,7 +436,7 @@ void ens_begin(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, EnsJob &jo
   for (size_t j = 0; j < job.req.size(); ++j) {
     const RegionReq &r = job.req[j];
     const uint64_t Mp = p->prof[r.model].fbQ * NL, Ld = r.jreg - r.ireg + 1;
-    const uint64_t need = 256 + (uint64_t)ENS_NSAMPLES * job.cap[j] * 4 + al(Ld) + al((Ld + 1) * 6) + al((Ld + 1) * 3 * Mp) +
+    const uint64_t need = 256 + (uint64_t)ENS_NSAMPLES * job.cap[j] * 4 + al(Ld) + al((Ld + 1) * 6) + al((Ld + 1) * 4 * Mp) +
                           al((ENS_NSAMPLES * (Ld + 1) + 1) / 2) + al(ENS_NSAMPLES * (Ld + 1)) + 64;
     if (need > budget_floats) throw Error(CKM_ENOMEM, "one multi-domain region needs more workspace than the device budget allows");
     if (pos + need > budget_floats) { job.batches.push_back({first, j}); first = j; pos = 0; }

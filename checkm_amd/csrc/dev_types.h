@@ -71,7 +71,7 @@ struct FbWork {              // one Forward/Backward/OA work item (whole sequenc
   uint64_t xs_off;                     // float offset: forward special rows (Ld+1)*6  [E N J B C scale]
   uint64_t aux_off;                    // float offset: parser mode -> decoding terms (Ld+1)*3 [bt et njcp];
                                        // full mode -> (Ld+1)*3 [ppN ppJ ppC], then 128B-aligned (Ld+1)*5 [oN oB oE oJ oC]
-  uint64_t mxf_off, mxb_off;           // float offsets of the (Ld+1) x 3*Mp matrices (full mode only)
+  uint64_t mxf_off, mxb_off;           // float offsets of the (Ld+1) x 3*Mp matrices (full == 1: q-major planes; full == 2: (Ld+1) x 4*Mp, cell-major float4 {M, I, D, 0})
   uint64_t path_off;                   // int32 offset + 1 of Mp entries: residue (1-based, within the envelope) emitted by each match state of the
                                        // OA path, 0 = node not matched (alignment requests); 0 = no path wanted
   uint32_t slot, full;                 // full: 0 parser (specials only), 1 matrix rows M,I, 2 matrix rows M,I,D (trace ensemble)
@@ -88,7 +88,7 @@ constexpr int ENS_NSAMPLES = 200;     // stochastic tracebacks per multi-domain 
 struct EnsWork {             // one multi-domain region handed to the trace-ensemble kernels (offsets in floats into the workspace)
   uint32_t model, seq;
   int32_t  i0, Ld, Lcfg, cap;          // residues [i0, i0+Ld) of the target; cap = segment slots per trace
-  uint64_t xs_off, mx_off;             // multihit Forward of the region: special rows (Ld+1)*6, matrix (Ld+1) x 3*Mp (M I D)
+  uint64_t xs_off, mx_off;             // multihit Forward of the region: special rows (Ld+1)*6, matrix (Ld+1) x Mp nodes of float4 {M, I, D, 0} (cell-major)
   uint64_t code_off;                   // uint16 [200][Ld+1] state codes per residue
   uint64_t ratio_off;                  // float  [200][Ld+1] null2 odds ratio per residue and trace
   uint64_t seg_off, nseg_off;          // int32  [200][cap][4] sampled segments (last domain first), int32 [200] counts (-1 = overflow)

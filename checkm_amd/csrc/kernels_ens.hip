@@ -20,6 +20,8 @@
 
 namespace ckm {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));     // a node of a cell-major region row: {M, I, D, 0}
+
 constexpr int ENS_N = ENS_NSAMPLES;
 
 __device__ __forceinline__ double ens_roll(uint32_t &x) { x = x * 69069u + 1u; return (double)x / 4294967296.0; }
@@ -37,13 +39,13 @@ __device__ __forceinline__ int ens_choose(double roll, const float *pth, int n) 
 }
 
 // E-state choice, evaluated by the whole wavefront for one of its traces.  Canonical order: lane z owns cells
-// z*Q .. z*Q+Q-1; weights in cell order are M(c) then D(c); local[z] = sequential double sum of the lane's 2Q weights;
+// z*Q .. z*Q+Q-1 (Q consecutive float4 of the cell-major row); weights in cell order are M(c) then D(c); local[z] = sequential double sum of the lane's 2Q weights;
 // base[z] = local[0] + .. + local[z-1] accumulated in lane order; total = base[64]; the choice is the first position
 // (cell order) whose cumulative weight base[z] + running sum exceeds roll * total; none -> node 1, match.
-__device__ __forceinline__ int ens_select_e(const float *__restrict__ cr, int Q, int Mp, double roll, int lane) {
-  const float *__restrict__ mrow = cr + lane, *__restrict__ drow = cr + 2 * Mp + lane;
+__device__ __forceinline__ int ens_select_e(const f32x4 *__restrict__ row4 /* the row's Mp nodes {M, I, D, 0} */, int Q, double roll, int lane) {
+  const f32x4 *__restrict__ mine = row4 + lane * Q;
   double local = 0.0;
-  for (int q = 0; q < Q; ++q) { local += (double)mrow[q * 64]; local += (double)drow[q * 64]; }
+  for (int q = 0; q < Q; ++q) { const f32x4 v = mine[q]; local += (double)v.x; local += (double)v.z; }
   double base = 0.0, run = 0.0;
 #pragma unroll
   for (int z = 0; z < 64; ++z) { const double tz = __shfl(local, z); if (lane == z) base = run; run += tz; }
@@ -51,8 +53,9 @@ __device__ __forceinline__ int ens_select_e(const float *__restrict__ cr, int Q,
   int found = -1;
   double acc = 0.0;
   for (int q = 0; q < Q; ++q) {
-    acc += (double)mrow[q * 64]; if (found < 0 && target < base + acc) found = 2 * q;
-    acc += (double)drow[q * 64]; if (found < 0 && target < base + acc) found = 2 * q + 1;
+    const f32x4 v = mine[q];
+    acc += (double)v.x; if (found < 0 && target < base + acc) found = 2 * q;
+    acc += (double)v.z; if (found < 0 && target < base + acc) found = 2 * q + 1;
   }
   const unsigned long long any = __ballot(found >= 0);
   if (!any) return 0;                                   // cell 0, match
@@ -70,7 +73,7 @@ __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restric
   const int t = threadIdx.x, lane = threadIdx.x & 63;
   const DevModel &md = models[w.model];
   const int Q = md.fbQ, Mp = Q * 64, Ld = w.Ld;
-  const size_t rowsz = (size_t)3 * Mp;
+  const size_t rowsz = (size_t)4 * Mp;                  // cell-major rows: f32x4 {M, I, D, 0} per node
   const float *__restrict__ mx = ws + w.mx_off;
   const float *__restrict__ xs = ws + w.xs_off;
   const gp<float> ftr = gptr(md.ftr);
@@ -82,7 +85,7 @@ __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restric
   uint16_t *__restrict__ code = reinterpret_cast<uint16_t *>(ws + w.code_off) + (size_t)(live ? t : 0) * (Ld + 1);
   int32_t *__restrict__ seg = reinterpret_cast<int32_t *>(ws + w.seg_off) + (size_t)(live ? t : 0) * w.cap * 4;
   int32_t *__restrict__ nsegp = reinterpret_cast<int32_t *>(ws + w.nseg_off);
-#define CELL(c) (((c) % Q) * 64 + (c) / Q)
+#define CELL(c) (4 * (c))
   enum { sC, sE, sM, sI, sD, sB, sJ, sN };
   const bool mine = live;
   uint32_t rng = seeds[live ? t : 0];
@@ -98,7 +101,7 @@ __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restric
       uint32_t xr = rng * 69069u + 1u;
       xr = __shfl(xr, l);
       const int row = __shfl(i, l);
-      const int r = ens_select_e(mx + rowsz * row, Q, Mp, (double)xr / 4294967296.0, lane);
+      const int r = ens_select_e(reinterpret_cast<const f32x4 *>(mx + rowsz * row), Q, (double)xr / 4294967296.0, lane);
       if (lane == l) { rng = xr; k = (r >> 1) + 1; st = (r & 1) ? sD : sM; sqto = 0; hmmto = 0; }    // (coordinates come from the first MATCH state met on the way back)
     }
     if (!done) {
@@ -119,7 +122,7 @@ __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restric
         code[i] = (uint16_t)(0x4000 | k);
         if (!sqto) { sqto = i; hmmto = k; }      // HMMER's p7_trace_Index takes sqto/hmmto from the last M state; trailing D states do not count
         pth[0] = xs[(size_t)(i - 1) * 6 + 3] * tBM[c];
-        if (c > 0) { const int a = CELL(c - 1); pth[1] = pr[a] * tMM[c]; pth[2] = pr[Mp + a] * tIM[c]; pth[3] = pr[2 * Mp + a] * tDM[c]; }
+        if (c > 0) { const int a = CELL(c - 1); pth[1] = pr[a] * tMM[c]; pth[2] = pr[a + 1] * tIM[c]; pth[3] = pr[a + 2] * tDM[c]; }
         else pth[1] = pth[2] = pth[3] = 0.0f;
         const int ch = ens_choose(ens_roll(rng), pth, 4);
         if (ch == 0) {
@@ -132,13 +135,13 @@ __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restric
       case sI: {
         const int a = CELL(k - 1);
         code[i] = (uint16_t)(0x8000 | k);
-        pth[0] = pr[a] * tMI[k - 1]; pth[1] = pr[Mp + a] * tII[k - 1];
+        pth[0] = pr[a] * tMI[k - 1]; pth[1] = pr[a + 1] * tII[k - 1];
         st = (ens_choose(ens_roll(rng), pth, 2) == 0) ? sM : sI;
         --i;
       } break;
       case sD: {
         const int c = k - 1;
-        if (c > 0) { const int a = CELL(c - 1); pth[0] = cr[a] * tMD[c - 1]; pth[1] = cr[2 * Mp + a] * tDD[c - 1]; } else pth[0] = pth[1] = 0.0f;
+        if (c > 0) { const int a = CELL(c - 1); pth[0] = cr[a] * tMD[c - 1]; pth[1] = cr[a + 2] * tDD[c - 1]; } else pth[0] = pth[1] = 0.0f;
         st = (ens_choose(ens_roll(rng), pth, 2) == 0) ? sM : sD;
         --k;
       } break;
@@ -164,96 +167,148 @@ __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restric
 }
 
 // ---- default: ONE generator stream per region (hmmsearch's own use of its generator) ----------------------------------------------
-// One wavefront per region; every value of the walk (state, row, node, generator) is wave-uniform -- forced through
-// v_readfirstlane after each choice so that the state machine branches on SGPRs -- and the 64 lanes are used for what a single walk
-// can share: the E-state choice over the 2M exit weights of a row (ens_select_e), the state codes of 64 residues riding in one register
-// (lane = residue & 63, stored 128 contiguous bytes at a time), and a LOOK-AHEAD load every sixteen rows that touches the cache lines
-// the walk will most likely read next (rows i-16 .. i-31 around the diagonal it is on, M / I / D planes and the special rows): a step is
-// one dependent load round, and the 200 walks of ~500 regions do not stay in L2 from one trace to the next, so without the look-ahead
-// a step costs an HBM latency.  Same draws, same choices as the oracle's single-stream mode: every state but N takes exactly one draw.
+// One wavefront per region; the 200 traces run one after the other, every value of the walk (state, row, node, generator) wave-uniform and
+// forced into SGPRs after each choice (v_readfirstlane), so the state machine branches on scalars.  A step is one draw and one choice among
+// two or four weights, and its operands depend on the previous choice: its latency IS the latency of fetching them.  From global memory
+// that is one (often two) round trips to L2 / HBM per step (the first version of this kernel: 96 ms per launch on average, 400 ms for the
+// longest regions -- the 200 walks of ~500 regions do not stay in any cache).  So the walk reads LDS:
+//   * the region's Forward matrix is cell-major (kernels_fb.hip writes f32x4 {M, I, D, 0} per node), and a WINDOW of it -- 17 rows x 48
+//     nodes around the diagonal the walk is on, 13 KB -- is staged by all 64 lanes (13 f32x4 each), with the transition odds of those
+//     nodes (8 x 49 floats);
+//   * the NEXT window down the diagonal is already in flight into registers when the walk enters a window, so leaving it at the bottom
+//     (the normal case) costs LDS writes, not a memory round trip; a walk that drifted more than 7 nodes off the diagonal inside one
+//     window (inserts minus deletes), or that starts a new domain (E state), loads its window synchronously;
+//   * the special rows (64 at a time) are staged the same way for the N/J/C stretches between domains.
+// The lanes also share the E-state choice over the 2M exit weights of a row (ens_select_e) and hold the state codes of 64 residues in one
+// register (lane = residue & 63, stored 128 contiguous bytes at a time).  Same draws, same choices as the oracle: every state but N takes
+// exactly one draw; float products and sums in the oracle's order.
 __device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+constexpr int EW_R = 16;                 // window rows below its top row
+constexpr int EW_NR = EW_R + 1;
+constexpr int EW_CW = 48;                // nodes per window row
+constexpr int EW_LO = 31;                // window nodes [anchor - EW_LO, anchor + 16]: the diagonal runs 16 nodes down, 15 spare for deletes, 16 for inserts
+constexpr int EW_TOL_LO = 7, EW_TOL_HI = 8;   // drift of the walk against the diagonal the pre-loaded window tolerates
+constexpr int EW_NG = (EW_NR * EW_CW + 63) / 64;          // f32x4 per lane per window (13)
+constexpr int EW_NT = (8 * (EW_CW + 1) + 63) / 64;        // transition floats per lane per window (7)
+constexpr int EW_XR = 64;                // special rows per staging: rows [x_r0, x_r0 + EW_XR]
+
+struct EnsWindowRegs { f32x4 g[EW_NG]; float t[EW_NT]; int r0, c0; bool valid; };
+
+// window with top row `top` and anchor node `anchor`: rows [top - EW_R, top], nodes [anchor - EW_LO, anchor + EW_HI]
+__device__ __forceinline__ void ens_window_load(EnsWindowRegs &w, const gp<f32x4> mx4, const gp<float> ftr, int Mp, int top, int anchor, int lane) {
+  w.r0 = top - EW_R; w.c0 = anchor - EW_LO; w.valid = true;
+#pragma unroll
+  for (int j = 0; j < EW_NG; ++j) {
+    const int idx = j * 64 + lane, row = idx / EW_CW, col = idx - row * EW_CW;
+    const int gr = w.r0 + row, gc = w.c0 + col;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (row < EW_NR && gr >= 0 && gc >= 0 && gc < Mp) v = mx4[(size_t)gr * Mp + gc];
+    w.g[j] = v;
+  }
+#pragma unroll
+  for (int j = 0; j < EW_NT; ++j) {
+    const int idx = j * 64 + lane, arr = idx / (EW_CW + 1), col = idx - arr * (EW_CW + 1);
+    const int gc = w.c0 + col;
+    float v = 0.f;
+    if (arr < 8 && gc >= 0 && gc < Mp) v = ftr[(size_t)arr * Mp + gc];
+    w.t[j] = v;
+  }
+}
+__device__ __forceinline__ void ens_window_store(const EnsWindowRegs &w, f32x4 *Wg, float *Wt, int lane) {
+#pragma unroll
+  for (int j = 0; j < EW_NG; ++j) { const int idx = j * 64 + lane; if (idx < EW_NR * EW_CW) Wg[idx] = w.g[j]; }
+#pragma unroll
+  for (int j = 0; j < EW_NT; ++j) { const int idx = j * 64 + lane; if (idx < 8 * (EW_CW + 1)) Wt[idx] = w.t[j]; }
+}
 
 __global__ void __launch_bounds__(64) ens_trace_seq_kernel(const EnsWork *__restrict__ work, const uint32_t *__restrict__ list, const DevModel *__restrict__ models,
                                                           const LenEntry *__restrict__ lentab, float *__restrict__ ws,
-                                                          const uint32_t *__restrict__ seeds, const uint32_t *__restrict__ count, uint32_t cap, int warm) {
+                                                          const uint32_t *__restrict__ seeds, const uint32_t *__restrict__ count, uint32_t cap) {
+ __shared__ f32x4 Wg[EW_NR * EW_CW];
+ __shared__ float Wt[8 * (EW_CW + 1)];
+ __shared__ float Wx[(EW_XR + 1) * 6 + 6];
  const uint32_t nregions = min(*count, cap);
  const int lane = threadIdx.x;
- float sink = 0.0f, pf0 = 0.0f, pf1 = 0.0f, pf2 = 0.0f;
  for (uint32_t region = blockIdx.x; region < nregions; region += gridDim.x) {
   const EnsWork w = work[list ? list[region] : region];
   const DevModel &md = models[w.model];
   const int Q = uni_i(md.fbQ), Mp = Q * 64, Ld = uni_i(w.Ld), segcap = uni_i(w.cap);
-  const size_t rowsz = (size_t)3 * Mp;
-  const gp<float> mx = gptr(ws + w.mx_off);
+  const gp<f32x4> mx4 = (gp<f32x4>)gptr(ws + w.mx_off);
   const gp<float> xs = gptr(ws + w.xs_off);
   const gp<float> ftr = gptr(md.ftr);
-  const gp<float> tBM = ftr, tMM = ftr + Mp, tIM = ftr + 2 * Mp, tDM = ftr + 3 * Mp,
-                  tMI = ftr + 4 * Mp, tII = ftr + 5 * Mp, tMD = ftr + 6 * Mp, tDD = ftr + 7 * Mp;
   const LenEntry le = lentab[w.Lcfg];
   const float loop = le.loop_m, move = le.move_m, Eloop = md.fE_loop, Emove = md.fE_move;
   uint16_t *__restrict__ codes = reinterpret_cast<uint16_t *>(ws + w.code_off);
   int32_t *__restrict__ segs = reinterpret_cast<int32_t *>(ws + w.seg_off);
   int32_t *__restrict__ nsegp = reinterpret_cast<int32_t *>(ws + w.nseg_off);
-  const float invQ = 1.0f / (float)Q;
-  auto cellq = [&](int c) { int z = (int)((float)c * invQ); z += ((z + 1) * Q <= c) ? 1 : 0; z -= (z * Q > c) ? 1 : 0; return (c - z * Q) * 64 + z; };
   enum { sC, sE, sM, sI, sD, sB, sJ, sN };
   uint32_t rng = (uint32_t)uni_i((int)seeds[0]);            // the region's stream: re-seeded here, carried from trace to trace below
+  int w_r0 = 0x40000000, w_c0 = 0;                          // rows [w_r0, w_r0 + EW_NR), nodes [w_c0, w_c0 + EW_CW) of the matrix are in LDS (none yet)
+  int x_r0 = 0x40000000;                                    // special rows [x_r0, x_r0 + EW_XR] are in LDS (none yet)
+  EnsWindowRegs nx; nx.valid = false; nx.r0 = 0; nx.c0 = 0;
+  __syncthreads();
   for (int t = 0; t < ENS_N; ++t) {
     uint16_t *__restrict__ code = codes + (size_t)t * (Ld + 1);
     int32_t *__restrict__ seg = segs + (size_t)t * segcap * 4;
     int st = sC, i = Ld, k = 0, nseg = 0, sqto = 0, hmmto = 0;
-    int kq = 0, kz = 0;                                      // cell k-1 of the striped rows is float kq*64 + kz: kept up to date as k falls, no division per step
     bool overflow = false;
     uint32_t mycode = 0;                                     // lane (r & 63) holds the code of residue r of the 64-block the walk is in
-    // residue i is done: its block goes to memory when the walk leaves it
-#define CELL_K()  (kq * 64 + kz)                                         /* cell k-1 */
-#define CELL_KM() (kq > 0 ? (kq - 1) * 64 + kz : (Q - 1) * 64 + kz - 1)   /* cell k-2 */
-#define DEC_K()   { if (kq > 0) --kq; else { kq = Q - 1; --kz; } --k; }
 #define SET_CODE(v) { if (lane == (i & 63)) mycode = (v); }
 #define LEAVE_ROW() { if ((i & 63) == 0) { const int pos_ = i + lane; if (pos_ >= 1 && pos_ <= Ld) code[pos_] = (uint16_t)mycode; } --i; }
     for (;;) {
-      float pth0, pth1, pth2 = 0.0f, pth3 = 0.0f; int n = 2;
+      float pth0 = 0.0f, pth1 = 0.0f, pth2 = 0.0f, pth3 = 0.0f; int n = 2;
       if (st == sE) {
         rng = rng * 69069u + 1u;
-        const int r = uni_i(ens_select_e((const float *)(mx + rowsz * i), Q, Mp, (double)rng / 4294967296.0, lane));
+        const int r = uni_i(ens_select_e((const f32x4 *)(mx4 + (size_t)i * Mp), Q, (double)rng / 4294967296.0, lane));
         k = (r >> 1) + 1; st = (r & 1) ? sD : sM; sqto = 0; hmmto = 0;
-        kz = (r >> 1) / Q; kq = (r >> 1) - kz * Q;
       } else if (st == sN) {
         break;
       } else {
-        const gp<float> cr = mx + rowsz * i, pr = (i > 0) ? mx + rowsz * (i - 1) : mx;
-        if (st == sC) {
-          pth0 = xs[(size_t)(i - 1) * 6 + 4] * loop;
-          pth1 = (xs[(size_t)i * 6 + 0] * Emove) * xs[(size_t)i * 6 + 5];
-        } else if (st == sJ) {
-          pth0 = xs[(size_t)(i - 1) * 6 + 2] * loop;
-          pth1 = (xs[(size_t)i * 6 + 0] * Eloop) * xs[(size_t)i * 6 + 5];
-        } else if (st == sM) {
-          const int c = k - 1;
-          n = 4;
-          pth0 = xs[(size_t)(i - 1) * 6 + 3] * tBM[c];
-          if (c > 0) { const int a = CELL_KM(); pth1 = pr[a] * tMM[c]; pth2 = pr[Mp + a] * tIM[c]; pth3 = pr[2 * Mp + a] * tDM[c]; }
-          else pth1 = pth2 = pth3 = 0.0f;
-          if (warm && (i & 15) == 0 && i > 16) {
-            // rows i-16-d (d = lane >> 2 = 0..15) of the diagonal the walk is on, and the diagonals one insert / one delete away;
-            // lane & 3: M, I, D plane of the predecessor cell, special row.  The values are consumed at the NEXT look-ahead (they
-            // have long arrived by then: loads return in order and sixteen rows of demand loads were waited for in between).
-            sink = sink + pf0; sink = sink + pf1; sink = sink + pf2;
-            const int d = 16 + (lane >> 2), ri = max(i - d, 0), what = lane & 3;
-            const gp<float> rowp = mx + rowsz * ri + (what == 3 ? 0 : what) * Mp;
-            const int c0 = max(c - 1 - d, 0), c1 = min(c0 + 1, Mp - 1), c2 = max(c0 - 1, 0);
-            pf0 = (what == 3) ? xs[(size_t)ri * 6] : rowp[cellq(c0)];
-            pf1 = rowp[cellq(c1)];
-            pf2 = rowp[cellq(c2)];
+        if (st == sM || st == sI || st == sD) {
+          // the node of row nr this step reads: M(i,k) <- row i-1, node k-2 (and the transitions INTO node k-1); I(i,k) <- row i-1, node k-1;
+          // D(i,k) <- row i, node k-2.  Node -1 (k = 1) reads as zero, as the window's out-of-range nodes do.
+          const int nr = (st == sD) ? i : i - 1, nc = (st == sI) ? k - 1 : k - 2;
+          if (nr < w_r0 || nr >= w_r0 + EW_NR || nc < w_c0 || nc + 1 >= w_c0 + EW_CW) {
+            // leave the window: the pre-loaded one if the walk left through the bottom near the diagonal, else a synchronous load
+            if (!(nx.valid && nx.r0 + EW_R == nr && nc - (EW_R + EW_TOL_LO) >= nx.c0 && nc + EW_TOL_HI + 1 < nx.c0 + EW_CW))
+              ens_window_load(nx, mx4, ftr, Mp, nr, nc, lane);
+            __syncthreads();
+            ens_window_store(nx, Wg, Wt, lane);
+            w_r0 = uni_i(nx.r0); w_c0 = uni_i(nx.c0);
+            __syncthreads();
+            ens_window_load(nx, mx4, ftr, Mp, w_r0 - 1, nc - (EW_R + 1), lane);       // next window down the diagonal: in flight while this one is walked
           }
-        } else if (st == sI) {
-          const int a = CELL_K();
-          pth0 = pr[a] * tMI[k - 1]; pth1 = pr[Mp + a] * tII[k - 1];
-        } else if (st == sD) {
-          const int c = k - 1;
-          if (c > 0) { const int a = CELL_KM(); pth0 = cr[a] * tMD[c - 1]; pth1 = cr[2 * Mp + a] * tDD[c - 1]; } else pth0 = pth1 = 0.0f;
-        } else {   // sB
-          pth0 = xs[(size_t)i * 6 + 1] * move; pth1 = xs[(size_t)i * 6 + 2] * move;
+          const f32x4 g = Wg[(nr - w_r0) * EW_CW + (nc - w_c0)];
+          const float *T = Wt + (nc - w_c0);              // transitions of node nc; node nc + 1 at T[1]
+          if (st == sM) {
+            if (i - 1 < x_r0 || i - 1 > x_r0 + EW_XR) {
+              __syncthreads();
+              x_r0 = max(i - EW_XR, 0);
+              for (int e = lane; e < (EW_XR + 1) * 6; e += 64) { const int gr = x_r0 + e / 6; Wx[e] = (gr <= Ld) ? xs[(size_t)x_r0 * 6 + e] : 0.f; }
+              __syncthreads();
+            }
+            n = 4;
+            pth0 = Wx[(i - 1 - x_r0) * 6 + 3] * T[0 * (EW_CW + 1) + 1];
+            if (k > 1) { pth1 = g.x * T[1 * (EW_CW + 1) + 1]; pth2 = g.y * T[2 * (EW_CW + 1) + 1]; pth3 = g.z * T[3 * (EW_CW + 1) + 1]; }
+          } else if (st == sI) {
+            pth0 = g.x * T[4 * (EW_CW + 1)]; pth1 = g.y * T[5 * (EW_CW + 1)];
+          } else {
+            if (k > 1) { pth0 = g.x * T[6 * (EW_CW + 1)]; pth1 = g.z * T[7 * (EW_CW + 1)]; }
+          }
+        } else {
+          // C, J, B: special rows i-1 and i
+          const int lo = (st == sB) ? i : i - 1;
+          if (lo < x_r0 || i > x_r0 + EW_XR) {
+            __syncthreads();
+            x_r0 = max(i - EW_XR, 0);
+            for (int e = lane; e < (EW_XR + 1) * 6; e += 64) { const int gr = x_r0 + e / 6; Wx[e] = (gr <= Ld) ? xs[(size_t)x_r0 * 6 + e] : 0.f; }
+            __syncthreads();
+          }
+          const float *X1 = Wx + (i - x_r0) * 6, *X0 = X1 - 6;
+          if (st == sC) { pth0 = X0[4] * loop; pth1 = (X1[0] * Emove) * X1[5]; }
+          else if (st == sJ) { pth0 = X0[2] * loop; pth1 = (X1[0] * Eloop) * X1[5]; }
+          else { pth0 = X1[1] * move; pth1 = X1[2] * move; }
         }
         // the draw and the choice (ens_choose's order of operations: float sum of the weights, double running sum)
         rng = rng * 69069u + 1u;
@@ -289,14 +344,14 @@ __global__ void __launch_bounds__(64) ens_trace_seq_kernel(const EnsWork *__rest
             ++nseg;
             st = sB;
           } else st = (ch == 1) ? sM : (ch == 2) ? sI : sD;
-          LEAVE_ROW() DEC_K()
+          LEAVE_ROW() --k;
         } else if (st == sI) {
           SET_CODE(0x8000u | (uint32_t)k)
           st = (ch == 0) ? sM : sI;
           LEAVE_ROW()
         } else if (st == sD) {
           st = (ch == 0) ? sM : sD;
-          DEC_K()
+          --k;
         } else {
           st = (ch == 0) ? sN : sJ;
         }
@@ -313,13 +368,9 @@ __global__ void __launch_bounds__(64) ens_trace_seq_kernel(const EnsWork *__rest
     }
     if (lane == 0) nsegp[t] = overflow ? -1 : nseg;
 #undef SET_CODE
-#undef CELL_K
-#undef CELL_KM
-#undef DEC_K
 #undef LEAVE_ROW
   }
  }
- if (nregions == 0xffffffffu) ws[0] = sink + pf0 + pf1 + pf2;      // (never true) keeps the look-ahead loads alive
 }
 
 // grid (ENS_N, nregions), 64 threads; dynamic LDS: 2*Mp counters/floats + 32 floats
@@ -416,9 +467,8 @@ void launch_ensemble(hipStream_t stream, const EnsWork *work, const uint32_t *li
   if (!grid_regions) return;
   // CKM_ENS_STREAM=substream: one generator sub-stream per trace (round 1-3's default; NOT hmmsearch's stream).  Default: one stream per region.
   static const int substream = [] { const char *e = getenv("CKM_ENS_STREAM"); return (e && !strcmp(e, "substream")) ? 1 : 0; }();
-  static const int warm = [] { const char *e = getenv("CKM_ENS_WARM"); return (e && !strcmp(e, "0")) ? 0 : 1; }();
   if (substream) hipLaunchKernelGGL(ens_trace_kernel, dim3(grid_regions), dim3(256), 0, stream, work, list, models, lentab, ws, seeds, count, cap);
-  else hipLaunchKernelGGL(ens_trace_seq_kernel, dim3(std::min<uint32_t>(cap, 4096u)), dim3(64), 0, stream, work, list, models, lentab, ws, seeds, count, cap, warm);
+  else hipLaunchKernelGGL(ens_trace_seq_kernel, dim3(std::min<uint32_t>(cap, 4096u)), dim3(64), 0, stream, work, list, models, lentab, ws, seeds, count, cap);
   hipLaunchKernelGGL(ens_null2_kernel, dim3(ENS_N, grid_regions), dim3(64), (size_t)(2 * max_Mp + 32) * 4, stream, work, list, models, res, seq_off, ws, count, cap);
   hipLaunchKernelGGL(ens_sum_kernel, dim3(4, grid_regions), dim3(256), 0, stream, work, list, ws, count, cap);
   if (host_res) hipLaunchKernelGGL(ens_export_kernel, dim3(4, grid_regions), dim3(256), 0, stream, work, list, ws, host_res, count, cap);

@@ -120,9 +120,20 @@ __device__ __forceinline__ void fwd_item(const FbWork &w, const DevModel &md, fl
   float *xs = ws + w.xs_off;
   float *mx = w.full ? ws + w.mxf_off : nullptr;
   if (lane == 0) { xs[0] = 0.f; xs[1] = xN; xs[2] = 0.f; xs[3] = xB; xs[4] = 0.f; xs[5] = 1.0f; }
+  // Matrix rows.  full == 1 (envelopes): three (two used) q-major planes per row, [plane][q][lane].  full == 2 (multihit Forward of a
+  // multi-domain region, read only by the trace ensemble): CELL-major, one float4 {M, I, D, 0} per node, rows of 4 * Mp floats -- a
+  // stochastic traceback follows a diagonal, and with the node index running fastest the cells it will visit next lie side by side
+  // (kernels_ens.hip stages windows of them in LDS); lane z owns the Q consecutive nodes z*Q .. z*Q+Q-1, so every store is 16 B and the
+  // lanes' stores are contiguous.
   if (mx) {
+    if (w.full == 2) {
+      float4 *r4 = reinterpret_cast<float4 *>(mx) + lane * Q;
 #pragma unroll
-    for (int q = 0; q < Q; ++q) { mx[q * 64 + lane] = 0.f; mx[Mp + q * 64 + lane] = 0.f; if (w.full == 2) mx[2 * Mp + q * 64 + lane] = 0.f; }
+      for (int q = 0; q < Q; ++q) r4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) { mx[q * 64 + lane] = 0.f; mx[Mp + q * 64 + lane] = 0.f; }
+    }
   }
   // emission odds of the next row are fetched one row ahead; the residues come 64 at a time (xlane.h: ResUp)
   const gp<float> rf = gptr(md.rf);
@@ -163,12 +174,14 @@ __device__ __forceinline__ void fwd_item(const FbWork &w, const DevModel &md, fl
     }
     if (lane == 0) { float *r = xs + (size_t)i * 6; r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; r[5] = scale; }
     if (mx) {
-      float *r = mx + (size_t)i * 3 * Mp + lane;
-#pragma unroll
-      for (int q = 0; q < Q; ++q) { r[q * 64] = Mv[q]; r[Mp + q * 64] = Iv[q]; }
       if (w.full == 2) {      // the trace ensemble also walks delete states
+        float4 *r4 = reinterpret_cast<float4 *>(mx) + (size_t)i * Mp + lane * Q;
 #pragma unroll
-        for (int q = 0; q < Q; ++q) r[2 * Mp + q * 64] = Dv[q];
+        for (int q = 0; q < Q; ++q) r4[q] = make_float4(Mv[q], Iv[q], Dv[q], 0.f);
+      } else {
+        float *r = mx + (size_t)i * 3 * Mp + lane;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { r[q * 64] = Mv[q]; r[Mp + q * 64] = Iv[q]; }
       }
     }
   }
