@@ -73,7 +73,9 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
         if (k >= nside) { w.side[k] = w.side[k % nside]; continue; }
         HIPCHK(hipStreamCreateWithFlags(&w.side[k], hipStreamNonBlocking));
       }
-      w.ens_stream = w.side[nside - 1];
+      // the trace ensembles of a search get a stream of their own: a launch lasts as long as its longest region (tens of milliseconds), and
+      // neither a chain stream nor the priority stream (which carries the NEXT batch's uploads) may queue behind it
+      HIPCHK(hipStreamCreateWithFlags(&w.ens_stream, hipStreamNonBlocking));
       {
         // the rounds after a search's drain (envelopes of the ensembles' clustering, deferred regions: milliseconds of device work the
         // host waits for) must not queue behind ANOTHER context's SSV launches, whose backlog holds the normal-priority hardware queues
@@ -132,6 +134,7 @@ extern "C" void ckm_ctx_destroy(ckm_ctx *ctx) {
     for (auto &e : w.ens_ev) if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < w.nside; ++k) (void)hipStreamDestroy(w.side[k]);
     if (w.late[0]) (void)hipStreamDestroy(w.late[0]);
+    if (w.ens_stream) (void)hipStreamDestroy(w.ens_stream);
     (void)hipStreamDestroy(w.stream);
   }
   delete ctx;

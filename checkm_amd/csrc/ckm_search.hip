@@ -753,14 +753,14 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
       }
     }
     // The trace ensembles of the multi-domain regions: ONE set of launches per sequence PART, behind the chains of all of the part's
-    // groups, on the worker's high-priority stream.  A region's 200 traces run one after the other (one generator stream per region, as
+    // groups, on a stream of their own.  A region's 200 traces run one after the other (one generator stream per region, as
     // hmmsearch carries it), so a launch lasts as long as its longest region -- tens of milliseconds; per group and register class, on the
     // group's chain stream (round 3, when a launch took 2 ms), those latencies queued up behind each other (measured: 11.5 -> 14.1 s per
     // 1000 bins).  The long part's ensembles run underneath the SSV launches of the short part; what is left after the last SSV launch
     // are the regions of the short sequences.
     int ens_Mp = NL;
     for (const Sub &sb : subs) for (int c = 0; c < NFC; ++c) if (sb.fb[c]) ens_Mp = std::max(ens_Mp, kFbQ[c] * NL);
-    hipStream_t es = ctx->late[0];
+    hipStream_t es = ctx->ens_stream;
     bool ens_launched = false;
     auto ens_slot = [](int part) { return std::min(part, 3); };
     auto flush_part = [&](int part) {

@@ -215,11 +215,15 @@ __device__ __forceinline__ void ens_window_load(EnsWindowRegs &w, const gp<f32x4
     w.t[j] = v;
   }
 }
+// LDS images: Wg[row][node] {M, I, D, 0}; Wt[node][8] = {BM, MM, IM, DM | MI, II, MD, DD} of node c0 + node (two 16-byte reads)
 __device__ __forceinline__ void ens_window_store(const EnsWindowRegs &w, f32x4 *Wg, float *Wt, int lane) {
 #pragma unroll
   for (int j = 0; j < EW_NG; ++j) { const int idx = j * 64 + lane; if (idx < EW_NR * EW_CW) Wg[idx] = w.g[j]; }
 #pragma unroll
-  for (int j = 0; j < EW_NT; ++j) { const int idx = j * 64 + lane; if (idx < 8 * (EW_CW + 1)) Wt[idx] = w.t[j]; }
+  for (int j = 0; j < EW_NT; ++j) {
+    const int idx = j * 64 + lane, arr = idx / (EW_CW + 1), col = idx - arr * (EW_CW + 1);
+    if (arr < 8) Wt[col * 8 + arr] = w.t[j];
+  }
 }
 
 __global__ void __launch_bounds__(64) ens_trace_seq_kernel(const EnsWork *__restrict__ work, const uint32_t *__restrict__ list, const DevModel *__restrict__ models,
@@ -256,7 +260,52 @@ __global__ void __launch_bounds__(64) ens_trace_seq_kernel(const EnsWork *__rest
     uint32_t mycode = 0;                                     // lane (r & 63) holds the code of residue r of the 64-block the walk is in
 #define SET_CODE(v) { if (lane == (i & 63)) mycode = (v); }
 #define LEAVE_ROW() { if ((i & 63) == 0) { const int pos_ = i + lane; if (pos_ >= 1 && pos_ <= Ld) code[pos_] = (uint16_t)mycode; } --i; }
+#define IMPOSSIBLE() (i < 0 || k < 0 || ((st == sM || st == sI) && (k < 1 || i < 1)) || (st == sD && k < 1) || ((st == sC || st == sJ || st == sE) && i < 1))
     for (;;) {
+      // ---- fast path: a run of match states inside the staged windows.  Nine steps in ten are M -> M along the diagonal: LDS index, node
+      // and special row fall by constants, and the only questions per step are "still M?" and "still inside?" ----
+      if (st == sM && k >= 2) {
+        int rrow = i - 1 - w_r0, ccol = k - 2 - w_c0, xrow = i - 1 - x_r0;
+        if (rrow >= 0 && rrow < EW_NR && ccol >= 0 && ccol + 1 < EW_CW && xrow >= 0 && xrow < EW_XR) {
+          int gidx = rrow * EW_CW + ccol;
+          bool stop_trace = false;
+          for (;;) {
+            const f32x4 g = Wg[gidx];
+            const f32x4 ta = *reinterpret_cast<const f32x4 *>(Wt + (ccol + 1) * 8);
+            const float pth0 = Wx[xrow * 6 + 3] * ta.x, pth1 = g.x * ta.y, pth2 = g.y * ta.z, pth3 = g.z * ta.w;
+            rng = rng * 69069u + 1u;
+            const double roll = (double)rng / 4294967296.0;
+            int ch;
+            {
+              float norm = pth0 + pth1; norm = norm + pth2; norm = norm + pth3;
+              if (!(norm > 0.0f)) ch = 0;
+              else {
+                const double target = roll * (double)norm;
+                const double s0 = (double)pth0, s1 = s0 + (double)pth1, s2 = s1 + (double)pth2, s3 = s2 + (double)pth3;
+                ch = (target < s0) ? 0 : (target < s1) ? 1 : (target < s2) ? 2 : (target < s3) ? 3 : (pth3 > 0.0f) ? 3 : (pth2 > 0.0f) ? 2 : (pth1 > 0.0f) ? 1 : 0;
+              }
+            }
+            ch = uni_i(ch);
+            SET_CODE(0x4000u | (uint32_t)k)
+            if (!sqto) { sqto = i; hmmto = k; }
+            if (ch != 1) {
+              if (ch == 0) {
+                if (nseg == segcap) { overflow = true; stop_trace = true; break; }
+                if (lane == 0) { seg[nseg * 4 + 0] = i; seg[nseg * 4 + 1] = sqto; seg[nseg * 4 + 2] = k; seg[nseg * 4 + 3] = hmmto; }
+                ++nseg;
+                st = sB;
+              } else st = (ch == 2) ? sI : sD;
+              LEAVE_ROW() --k;
+              break;
+            }
+            LEAVE_ROW() --k;
+            --rrow; --ccol; --xrow; gidx -= EW_CW + 1;
+            if (rrow < 0 || ccol < 0 || xrow < 0 || k < 2) break;
+          }
+          if (stop_trace || IMPOSSIBLE()) break;
+          continue;
+        }
+      }
       float pth0 = 0.0f, pth1 = 0.0f, pth2 = 0.0f, pth3 = 0.0f; int n = 2;
       if (st == sE) {
         rng = rng * 69069u + 1u;
@@ -280,21 +329,21 @@ __global__ void __launch_bounds__(64) ens_trace_seq_kernel(const EnsWork *__rest
             ens_window_load(nx, mx4, ftr, Mp, w_r0 - 1, nc - (EW_R + 1), lane);       // next window down the diagonal: in flight while this one is walked
           }
           const f32x4 g = Wg[(nr - w_r0) * EW_CW + (nc - w_c0)];
-          const float *T = Wt + (nc - w_c0);              // transitions of node nc; node nc + 1 at T[1]
+          const float *T = Wt + (nc - w_c0) * 8;          // transitions of node nc; node nc + 1 at T + 8
           if (st == sM) {
-            if (i - 1 < x_r0 || i - 1 > x_r0 + EW_XR) {
+            if (i - 1 < x_r0 || i - 1 >= x_r0 + EW_XR) {
               __syncthreads();
               x_r0 = max(i - EW_XR, 0);
               for (int e = lane; e < (EW_XR + 1) * 6; e += 64) { const int gr = x_r0 + e / 6; Wx[e] = (gr <= Ld) ? xs[(size_t)x_r0 * 6 + e] : 0.f; }
               __syncthreads();
             }
             n = 4;
-            pth0 = Wx[(i - 1 - x_r0) * 6 + 3] * T[0 * (EW_CW + 1) + 1];
-            if (k > 1) { pth1 = g.x * T[1 * (EW_CW + 1) + 1]; pth2 = g.y * T[2 * (EW_CW + 1) + 1]; pth3 = g.z * T[3 * (EW_CW + 1) + 1]; }
+            pth0 = Wx[(i - 1 - x_r0) * 6 + 3] * T[8 + 0];
+            if (k > 1) { pth1 = g.x * T[8 + 1]; pth2 = g.y * T[8 + 2]; pth3 = g.z * T[8 + 3]; }
           } else if (st == sI) {
-            pth0 = g.x * T[4 * (EW_CW + 1)]; pth1 = g.y * T[5 * (EW_CW + 1)];
+            pth0 = g.x * T[4]; pth1 = g.y * T[5];
           } else {
-            if (k > 1) { pth0 = g.x * T[6 * (EW_CW + 1)]; pth1 = g.z * T[7 * (EW_CW + 1)]; }
+            if (k > 1) { pth0 = g.x * T[6]; pth1 = g.z * T[7]; }
           }
         } else {
           // C, J, B: special rows i-1 and i
@@ -357,8 +406,9 @@ __global__ void __launch_bounds__(64) ens_trace_seq_kernel(const EnsWork *__rest
         }
       }
       // a numerically impossible move ends the trace
-      if (i < 0 || k < 0 || ((st == sM || st == sI) && (k < 1 || i < 1)) || (st == sD && k < 1) || ((st == sC || st == sJ || st == sE) && i < 1)) break;
+      if (IMPOSSIBLE()) break;
     }
+#undef IMPOSSIBLE
     // residues i .. 1 lie outside every domain: code 0 (the block the walk stopped in, then everything below it)
     if (i >= 0) {
       const int b = i & ~63;

@@ -96,6 +96,7 @@ def verify(out_dir, table, hmm_path, bin_ids, files, models_by_bin, k_bins=3, n_
         accs = [a for a in models_by_bin[binId] if a in index]
         lengths = {a: hs.M(index[a]) for a in accs}
         sample, _ncls = sample_models(lengths, n_models, rng)
+        sample = sorted(sample, key=lambda a: index[a])          # rows come in HMM-file order (hmmsearch: one query after the other)
         classes_seen |= {launch_class(lengths[a]) for a in sample}
         recs = read_fasta(files[b])
         dsq = [p7.digitize(r[2]) for r in recs]
