@@ -234,6 +234,9 @@ __global__ void __launch_bounds__(64) ens_trace_seq_kernel(const EnsWork *__rest
  __shared__ float Wx[(EW_XR + 1) * 6 + 6];
  const uint32_t nregions = min(*count, cap);
  const int lane = threadIdx.x;
+ // one latency-bound wavefront among the VALU-bound ones of the SSV launches: it issues a few hundred instructions per microsecond, and
+ // every cycle it waits for an issue slot lengthens the search's tail -- highest wave priority (its share of the SIMD's issue slots is < 1 %)
+ __builtin_amdgcn_s_setprio(3);
  for (uint32_t region = blockIdx.x; region < nregions; region += gridDim.x) {
   const EnsWork w = work[list ? list[region] : region];
   const DevModel &md = models[w.model];
@@ -303,6 +306,32 @@ __global__ void __launch_bounds__(64) ens_trace_seq_kernel(const EnsWork *__rest
             if (rrow < 0 || ccol < 0 || xrow < 0 || k < 2) break;
           }
           if (stop_trace || IMPOSSIBLE()) break;
+          continue;
+        }
+      }
+      // ---- fast path: a run of C (or J) states over the staged special rows: stay (emit residue i outside every domain) or go to E ----
+      if ((st == sC || st == sJ) && i >= 1) {
+        int xrow = i - x_r0;
+        if (xrow >= 1 && xrow <= EW_XR) {
+          const int col = (st == sC) ? 4 : 2; const float em = (st == sC) ? Emove : Eloop;
+          for (;;) {
+            const float *X1 = Wx + xrow * 6;
+            const float pth0 = X1[col - 6] * loop, pth1 = (X1[0] * em) * X1[5];
+            rng = rng * 69069u + 1u;
+            const double roll = (double)rng / 4294967296.0;
+            int ch;
+            {
+              const float norm = pth0 + pth1;
+              if (!(norm > 0.0f)) ch = 0;
+              else { const double target = roll * (double)norm; const double s0 = (double)pth0, s1 = s0 + (double)pth1; ch = (target < s0) ? 0 : (target < s1) ? 1 : (pth1 > 0.0f) ? 1 : 0; }
+            }
+            ch = uni_i(ch);
+            if (ch != 0) { st = sE; break; }
+            SET_CODE(0u) LEAVE_ROW()
+            --xrow;
+            if (xrow < 1 || i < 1) break;
+          }
+          if (IMPOSSIBLE()) break;
           continue;
         }
       }
