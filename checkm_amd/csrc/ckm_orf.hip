@@ -78,11 +78,11 @@ extern "C" int ckm_orf_scan(ckm_ctx *ctx, const char *text, const uint64_t *cont
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
     std::vector<OrfNodeH> nodes((size_t)n);
     if (n) HIPCHK(hipMemcpy(nodes.data(), d_nodes.p, (size_t)n * sizeof(OrfNodeH), hipMemcpyDeviceToHost));
-    // prodigal's working order (node.c: compare_nodes -- position, then strand with the reverse strand first), made total
+    // prodigal's working order (node.c: compare_nodes -- position, then the forward strand first), made total
     std::sort(nodes.begin(), nodes.end(), [](const OrfNodeH &x, const OrfNodeH &y) {
       if (x.contig != y.contig) return x.contig < y.contig;
       if (x.ndx != y.ndx) return x.ndx < y.ndx;
-      if (x.strand_rev != y.strand_rev) return x.strand_rev > y.strand_rev;
+      if (x.strand_rev != y.strand_rev) return x.strand_rev < y.strand_rev;
       if (x.type != y.type) return x.type < y.type;
       if (x.stop_val != y.stop_val) return x.stop_val < y.stop_val;
       return x.edge < y.edge;

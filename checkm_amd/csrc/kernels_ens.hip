@@ -167,43 +167,41 @@ __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restric
 }
 
 // ---- default: ONE generator stream per region (hmmsearch's own use of its generator) ----------------------------------------------
-// One wavefront per region; the 200 traces run one after the other, every value of the walk (state, row, node, generator) wave-uniform and
-// forced into SGPRs after each choice (v_readfirstlane), so the state machine branches on scalars.  A step is one draw and one choice among
-// two or four weights, and its operands depend on the previous choice: its latency IS the latency of fetching them.  From global memory
-// that is one (often two) round trips to L2 / HBM per step (the first version of this kernel: 96 ms per launch on average, 400 ms for the
-// longest regions -- the 200 walks of ~500 regions do not stay in any cache).  So the walk reads LDS:
-//   * the region's Forward matrix is cell-major (kernels_fb.hip writes f32x4 {M, I, D, 0} per node), and a WINDOW of it -- 17 rows x 48
-//     nodes around the diagonal the walk is on, 13 KB -- is staged by all 64 lanes (13 f32x4 each), with the transition odds of those
-//     nodes (8 x 49 floats);
-//   * the NEXT window down the diagonal is already in flight into registers when the walk enters a window, so leaving it at the bottom
-//     (the normal case) costs LDS writes, not a memory round trip; a walk that drifted more than 7 nodes off the diagonal inside one
-//     window (inserts minus deletes), or that starts a new domain (E state), loads its window synchronously;
-//   * the special rows (64 at a time) are staged the same way for the N/J/C stretches between domains.
-// The lanes also share the E-state choice over the 2M exit weights of a row (ens_select_e) and hold the state codes of 64 residues in one
-// register (lane = residue & 63, stored 128 contiguous bytes at a time).  Same draws, same choices as the oracle: every state but N takes
-// exactly one draw; float products and sums in the oracle's order.
+// One wavefront per region; the 200 traces of a region run one after the other on one generator stream, re-seeded for the region and
+// carried from trace to trace (every state of a trace but N takes exactly one draw).  A single walk is a chain of dependent choices, but
+// most of it is RUNS whose states are known in advance as long as every choice comes out the likely way:
+//   * a run of match states down a diagonal: M(i,k) -> M(i-1,k-1) -> ...  Lane l evaluates the step at (i-l, k-l) with the draw the
+//     sequential walk would use there (the generator is linear: x[n+l+1] = A^(l+1) x[n] + C(l+1), one multiply-add per lane); the first
+//     lane whose choice is not "match again" ends the run, and the walk advances by that many steps at once.  Exactly the sequential
+//     walk -- each lane's step only assumes that all earlier steps stayed on the diagonal, which is what the first deviating lane decides;
+//   * a run of C (or J) states over the residues outside the domains, the same way.
+// Insert / delete / begin states and the E state's choice over the 2M exit weights of a row (ens_select_e, all lanes) are single steps.
+// The operands come from LDS: the region's Forward matrix is cell-major (kernels_fb.hip writes float4 {M, I, D, 0} per node), a WINDOW
+// of 33 rows x 64 nodes around the diagonal (33 KB) is staged by all lanes together with the transition odds of those nodes, the NEXT
+// window down the diagonal is in flight into registers while one is walked, and the special rows are staged 128 at a time.  (The first
+// version walked global memory one step at a time: 96 ms per launch, 400 ms for the longest regions; a step-at-a-time LDS walk: 45 ms.)
 __device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-constexpr int EW_R = 16;                 // window rows below its top row
+constexpr int EW_R = 32;                 // window rows below its top row
 constexpr int EW_NR = EW_R + 1;
-constexpr int EW_CW = 48;                // nodes per window row
-constexpr int EW_LO = 31;                // window nodes [anchor - EW_LO, anchor + 16]: the diagonal runs 16 nodes down, 15 spare for deletes, 16 for inserts
+constexpr int EW_CW = 64;                // nodes per window row
+constexpr int EW_LO = 47;                // window nodes [anchor - EW_LO, anchor + 16]: the diagonal runs 32 nodes down, 15 spare for deletes, 16 for inserts
 constexpr int EW_TOL_LO = 7, EW_TOL_HI = 8;   // drift of the walk against the diagonal the pre-loaded window tolerates
-constexpr int EW_NG = (EW_NR * EW_CW + 63) / 64;          // f32x4 per lane per window (13)
-constexpr int EW_NT = (8 * (EW_CW + 1) + 63) / 64;        // transition floats per lane per window (7)
-constexpr int EW_XR = 64;                // special rows per staging: rows [x_r0, x_r0 + EW_XR]
+constexpr int EW_NG = (EW_NR * EW_CW + 63) / 64;          // float4 per lane per window (33)
+constexpr int EW_NT = (8 * (EW_CW + 1) + 63) / 64;        // transition floats per lane per window (9)
+constexpr int EW_XR = 128;               // special rows per staging: rows [x_r0, x_r0 + EW_XR]
 
 struct EnsWindowRegs { f32x4 g[EW_NG]; float t[EW_NT]; int r0, c0; bool valid; };
 
-// window with top row `top` and anchor node `anchor`: rows [top - EW_R, top], nodes [anchor - EW_LO, anchor + EW_HI]
+// window with top row `top` and anchor node `anchor`: rows [top - EW_R, top], nodes [anchor - EW_LO, anchor - EW_LO + EW_CW)
 __device__ __forceinline__ void ens_window_load(EnsWindowRegs &w, const gp<f32x4> mx4, const gp<float> ftr, int Mp, int top, int anchor, int lane) {
   w.r0 = top - EW_R; w.c0 = anchor - EW_LO; w.valid = true;
 #pragma unroll
   for (int j = 0; j < EW_NG; ++j) {
-    const int idx = j * 64 + lane, row = idx / EW_CW, col = idx - row * EW_CW;
+    const int row = j, col = lane;                          // EW_CW == 64: one window row per register
     const int gr = w.r0 + row, gc = w.c0 + col;
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (row < EW_NR && gr >= 0 && gc >= 0 && gc < Mp) v = mx4[(size_t)gr * Mp + gc];
+    if (gr >= 0 && gc >= 0 && gc < Mp) v = mx4[(size_t)gr * Mp + gc];
     w.g[j] = v;
   }
 #pragma unroll
@@ -218,25 +216,41 @@ __device__ __forceinline__ void ens_window_load(EnsWindowRegs &w, const gp<f32x4
 // LDS images: Wg[row][node] {M, I, D, 0}; Wt[node][8] = {BM, MM, IM, DM | MI, II, MD, DD} of node c0 + node (two 16-byte reads)
 __device__ __forceinline__ void ens_window_store(const EnsWindowRegs &w, f32x4 *Wg, float *Wt, int lane) {
 #pragma unroll
-  for (int j = 0; j < EW_NG; ++j) { const int idx = j * 64 + lane; if (idx < EW_NR * EW_CW) Wg[idx] = w.g[j]; }
+  for (int j = 0; j < EW_NG; ++j) Wg[j * 64 + lane] = w.g[j];
 #pragma unroll
   for (int j = 0; j < EW_NT; ++j) {
     const int idx = j * 64 + lane, arr = idx / (EW_CW + 1), col = idx - arr * (EW_CW + 1);
     if (arr < 8) Wt[col * 8 + arr] = w.t[j];
   }
 }
+// first index whose cumulative weight exceeds roll * total (ens_choose's order of operations: float sum of the weights, double running sum)
+__device__ __forceinline__ int ens_choice4(float p0, float p1, float p2, float p3, double roll) {
+  float norm = p0 + p1; norm = norm + p2; norm = norm + p3;
+  if (!(norm > 0.0f)) return 0;
+  const double target = roll * (double)norm;
+  const double s0 = (double)p0, s1 = s0 + (double)p1, s2 = s1 + (double)p2, s3 = s2 + (double)p3;
+  return (target < s0) ? 0 : (target < s1) ? 1 : (target < s2) ? 2 : (target < s3) ? 3 : (p3 > 0.0f) ? 3 : (p2 > 0.0f) ? 2 : (p1 > 0.0f) ? 1 : 0;
+}
+__device__ __forceinline__ int ens_choice2(float p0, float p1, double roll) {
+  const float norm = p0 + p1;
+  if (!(norm > 0.0f)) return 0;
+  const double target = roll * (double)norm;
+  const double s0 = (double)p0, s1 = s0 + (double)p1;
+  return (target < s0) ? 0 : (target < s1) ? 1 : (p1 > 0.0f) ? 1 : 0;
+}
 
 __global__ void __launch_bounds__(64) ens_trace_seq_kernel(const EnsWork *__restrict__ work, const uint32_t *__restrict__ list, const DevModel *__restrict__ models,
                                                           const LenEntry *__restrict__ lentab, float *__restrict__ ws,
                                                           const uint32_t *__restrict__ seeds, const uint32_t *__restrict__ count, uint32_t cap) {
  __shared__ f32x4 Wg[EW_NR * EW_CW];
- __shared__ float Wt[8 * (EW_CW + 1)];
+ __shared__ float Wt[8 * (EW_CW + 1) + 8];
  __shared__ float Wx[(EW_XR + 1) * 6 + 6];
  const uint32_t nregions = min(*count, cap);
  const int lane = threadIdx.x;
- // one latency-bound wavefront among the VALU-bound ones of the SSV launches: it issues a few hundred instructions per microsecond, and
- // every cycle it waits for an issue slot lengthens the search's tail -- highest wave priority (its share of the SIMD's issue slots is < 1 %)
- __builtin_amdgcn_s_setprio(3);
+ __builtin_amdgcn_s_setprio(3);          // one latency-bound wavefront among the VALU-bound ones of the SSV launches
+ // generator jump of this lane: x[n + lane + 1] = jA * x[n] + jC
+ uint32_t jA = 69069u, jC = 1u;
+ for (int l = 0; l < lane; ++l) { jC = jC * 69069u + 1u; jA = jA * 69069u; }
  for (uint32_t region = blockIdx.x; region < nregions; region += gridDim.x) {
   const EnsWork w = work[list ? list[region] : region];
   const DevModel &md = models[w.model];
@@ -255,82 +269,66 @@ __global__ void __launch_bounds__(64) ens_trace_seq_kernel(const EnsWork *__rest
   int x_r0 = 0x40000000;                                    // special rows [x_r0, x_r0 + EW_XR] are in LDS (none yet)
   EnsWindowRegs nx; nx.valid = false; nx.r0 = 0; nx.c0 = 0;
   __syncthreads();
+#define STAGE_X(TOP) { __syncthreads(); x_r0 = max((TOP) - EW_XR, 0); \
+    for (int e = lane; e < (EW_XR + 1) * 6; e += 64) { const int gr = x_r0 + e / 6; Wx[e] = (gr <= Ld) ? xs[(size_t)x_r0 * 6 + e] : 0.f; } __syncthreads(); }
+#define IMPOSSIBLE() (i < 0 || k < 0 || ((st == sM || st == sI) && (k < 1 || i < 1)) || (st == sD && k < 1) || ((st == sC || st == sJ || st == sE) && i < 1))
   for (int t = 0; t < ENS_N; ++t) {
     uint16_t *__restrict__ code = codes + (size_t)t * (Ld + 1);
     int32_t *__restrict__ seg = segs + (size_t)t * segcap * 4;
     int st = sC, i = Ld, k = 0, nseg = 0, sqto = 0, hmmto = 0;
     bool overflow = false;
-    uint32_t mycode = 0;                                     // lane (r & 63) holds the code of residue r of the 64-block the walk is in
-#define SET_CODE(v) { if (lane == (i & 63)) mycode = (v); }
-#define LEAVE_ROW() { if ((i & 63) == 0) { const int pos_ = i + lane; if (pos_ >= 1 && pos_ <= Ld) code[pos_] = (uint16_t)mycode; } --i; }
-#define IMPOSSIBLE() (i < 0 || k < 0 || ((st == sM || st == sI) && (k < 1 || i < 1)) || (st == sD && k < 1) || ((st == sC || st == sJ || st == sE) && i < 1))
     for (;;) {
-      // ---- fast path: a run of match states inside the staged windows.  Nine steps in ten are M -> M along the diagonal: LDS index, node
-      // and special row fall by constants, and the only questions per step are "still M?" and "still inside?" ----
-      if (st == sM && k >= 2) {
-        int rrow = i - 1 - w_r0, ccol = k - 2 - w_c0, xrow = i - 1 - x_r0;
+      // ---- a run of match states down the diagonal, one step per lane ----
+      if (st == sM && k >= 2 && i >= 1) {
+        const int rrow = i - 1 - w_r0, ccol = k - 2 - w_c0, xrow = i - 1 - x_r0;
         if (rrow >= 0 && rrow < EW_NR && ccol >= 0 && ccol + 1 < EW_CW && xrow >= 0 && xrow < EW_XR) {
-          int gidx = rrow * EW_CW + ccol;
-          bool stop_trace = false;
-          for (;;) {
-            const f32x4 g = Wg[gidx];
-            const f32x4 ta = *reinterpret_cast<const f32x4 *>(Wt + (ccol + 1) * 8);
-            const float pth0 = Wx[xrow * 6 + 3] * ta.x, pth1 = g.x * ta.y, pth2 = g.y * ta.z, pth3 = g.z * ta.w;
-            rng = rng * 69069u + 1u;
-            const double roll = (double)rng / 4294967296.0;
-            int ch;
-            {
-              float norm = pth0 + pth1; norm = norm + pth2; norm = norm + pth3;
-              if (!(norm > 0.0f)) ch = 0;
-              else {
-                const double target = roll * (double)norm;
-                const double s0 = (double)pth0, s1 = s0 + (double)pth1, s2 = s1 + (double)pth2, s3 = s2 + (double)pth3;
-                ch = (target < s0) ? 0 : (target < s1) ? 1 : (target < s2) ? 2 : (target < s3) ? 3 : (pth3 > 0.0f) ? 3 : (pth2 > 0.0f) ? 2 : (pth1 > 0.0f) ? 1 : 0;
-              }
-            }
-            ch = uni_i(ch);
-            SET_CODE(0x4000u | (uint32_t)k)
-            if (!sqto) { sqto = i; hmmto = k; }
-            if (ch != 1) {
-              if (ch == 0) {
-                if (nseg == segcap) { overflow = true; stop_trace = true; break; }
-                if (lane == 0) { seg[nseg * 4 + 0] = i; seg[nseg * 4 + 1] = sqto; seg[nseg * 4 + 2] = k; seg[nseg * 4 + 3] = hmmto; }
-                ++nseg;
-                st = sB;
-              } else st = (ch == 2) ? sI : sD;
-              LEAVE_ROW() --k;
-              break;
-            }
-            LEAVE_ROW() --k;
-            --rrow; --ccol; --xrow; gidx -= EW_CW + 1;
-            if (rrow < 0 || ccol < 0 || xrow < 0 || k < 2) break;
-          }
-          if (stop_trace || IMPOSSIBLE()) break;
+          const int R = min(min(rrow + 1, ccol + 1), min(min(xrow + 1, i), min(k - 1, 64)));      // steps that stay inside the windows and the matrix
+          const bool in = lane < R;
+          const int l = in ? lane : 0;
+          const f32x4 g = Wg[(rrow - l) * EW_CW + (ccol - l)];
+          const f32x4 ta = *reinterpret_cast<const f32x4 *>(Wt + (ccol + 1 - l) * 8);
+          const float xB = Wx[(xrow - l) * 6 + 3];
+          const uint32_t x = jA * rng + jC;
+          const int ch = ens_choice4(xB * ta.x, g.x * ta.y, g.y * ta.z, g.z * ta.w, (double)x / 4294967296.0);
+          const unsigned long long stay = __ballot(in && ch == 1);
+          const int r = (stay == ~0ull) ? 64 : (int)__builtin_ctzll(~stay);      // first lane that does not continue the run (r >= R: all R stayed)
+          const int last = min(r, R - 1);                       // lane of the last step taken
+          if (!sqto) { sqto = i; hmmto = k; }
+          if (lane <= last) code[i - lane] = (uint16_t)(0x4000u | (uint32_t)(k - lane));
+          rng = (uint32_t)__builtin_amdgcn_readlane((int)x, last);
+          if (r < R) {
+            const int chr = __builtin_amdgcn_readlane(ch, r);
+            const int ir = i - r, kr = k - r;
+            if (chr == 0) {
+              if (nseg == segcap) { overflow = true; break; }
+              if (lane == 0) { seg[nseg * 4 + 0] = ir; seg[nseg * 4 + 1] = sqto; seg[nseg * 4 + 2] = kr; seg[nseg * 4 + 3] = hmmto; }
+              ++nseg;
+              st = sB;
+            } else st = (chr == 2) ? sI : sD;
+            i = ir - 1; k = kr - 1;
+          } else { i -= R; k -= R; }
+          if (IMPOSSIBLE()) break;
           continue;
         }
       }
-      // ---- fast path: a run of C (or J) states over the staged special rows: stay (emit residue i outside every domain) or go to E ----
+      // ---- a run of C (or J) states over the special rows ----
       if ((st == sC || st == sJ) && i >= 1) {
-        int xrow = i - x_r0;
+        const int xrow = i - x_r0;
         if (xrow >= 1 && xrow <= EW_XR) {
+          const int R = min(min(xrow, i), 64);
+          const bool in = lane < R;
+          const int l = in ? lane : 0;
           const int col = (st == sC) ? 4 : 2; const float em = (st == sC) ? Emove : Eloop;
-          for (;;) {
-            const float *X1 = Wx + xrow * 6;
-            const float pth0 = X1[col - 6] * loop, pth1 = (X1[0] * em) * X1[5];
-            rng = rng * 69069u + 1u;
-            const double roll = (double)rng / 4294967296.0;
-            int ch;
-            {
-              const float norm = pth0 + pth1;
-              if (!(norm > 0.0f)) ch = 0;
-              else { const double target = roll * (double)norm; const double s0 = (double)pth0, s1 = s0 + (double)pth1; ch = (target < s0) ? 0 : (target < s1) ? 1 : (pth1 > 0.0f) ? 1 : 0; }
-            }
-            ch = uni_i(ch);
-            if (ch != 0) { st = sE; break; }
-            SET_CODE(0u) LEAVE_ROW()
-            --xrow;
-            if (xrow < 1 || i < 1) break;
-          }
+          const float *X1 = Wx + (xrow - l) * 6;
+          const uint32_t x = jA * rng + jC;
+          const int ch = ens_choice2(X1[col - 6] * loop, (X1[0] * em) * X1[5], (double)x / 4294967296.0);
+          const unsigned long long stay = __ballot(in && ch == 0);
+          const int r = (stay == ~0ull) ? 64 : (int)__builtin_ctzll(~stay);
+          const int nstay = min(r, R);
+          if (lane < nstay) code[i - lane] = 0;
+          rng = (uint32_t)__builtin_amdgcn_readlane((int)x, min(r, R - 1));
+          i -= nstay;
+          if (r < R) st = sE;
           if (IMPOSSIBLE()) break;
           continue;
         }
@@ -357,18 +355,13 @@ __global__ void __launch_bounds__(64) ens_trace_seq_kernel(const EnsWork *__rest
             __syncthreads();
             ens_window_load(nx, mx4, ftr, Mp, w_r0 - 1, nc - (EW_R + 1), lane);       // next window down the diagonal: in flight while this one is walked
           }
+          if (st == sM && (i - 1 < x_r0 || i - 1 >= x_r0 + EW_XR)) STAGE_X(i)
+          if (st == sM && k >= 2) continue;                 // (the run above takes it from here)
           const f32x4 g = Wg[(nr - w_r0) * EW_CW + (nc - w_c0)];
           const float *T = Wt + (nc - w_c0) * 8;          // transitions of node nc; node nc + 1 at T + 8
-          if (st == sM) {
-            if (i - 1 < x_r0 || i - 1 >= x_r0 + EW_XR) {
-              __syncthreads();
-              x_r0 = max(i - EW_XR, 0);
-              for (int e = lane; e < (EW_XR + 1) * 6; e += 64) { const int gr = x_r0 + e / 6; Wx[e] = (gr <= Ld) ? xs[(size_t)x_r0 * 6 + e] : 0.f; }
-              __syncthreads();
-            }
+          if (st == sM) {                                 // k == 1: no predecessor node
             n = 4;
             pth0 = Wx[(i - 1 - x_r0) * 6 + 3] * T[8 + 0];
-            if (k > 1) { pth1 = g.x * T[8 + 1]; pth2 = g.y * T[8 + 2]; pth3 = g.z * T[8 + 3]; }
           } else if (st == sI) {
             pth0 = g.x * T[4]; pth1 = g.y * T[5];
           } else {
@@ -377,44 +370,17 @@ __global__ void __launch_bounds__(64) ens_trace_seq_kernel(const EnsWork *__rest
         } else {
           // C, J, B: special rows i-1 and i
           const int lo = (st == sB) ? i : i - 1;
-          if (lo < x_r0 || i > x_r0 + EW_XR) {
-            __syncthreads();
-            x_r0 = max(i - EW_XR, 0);
-            for (int e = lane; e < (EW_XR + 1) * 6; e += 64) { const int gr = x_r0 + e / 6; Wx[e] = (gr <= Ld) ? xs[(size_t)x_r0 * 6 + e] : 0.f; }
-            __syncthreads();
-          }
-          const float *X1 = Wx + (i - x_r0) * 6, *X0 = X1 - 6;
-          if (st == sC) { pth0 = X0[4] * loop; pth1 = (X1[0] * Emove) * X1[5]; }
-          else if (st == sJ) { pth0 = X0[2] * loop; pth1 = (X1[0] * Eloop) * X1[5]; }
-          else { pth0 = X1[1] * move; pth1 = X1[2] * move; }
+          if (lo < x_r0 || i > x_r0 + EW_XR) STAGE_X(i)
+          if (st != sB) continue;                           // (the run above takes C and J from here)
+          const float *X1 = Wx + (i - x_r0) * 6;
+          pth0 = X1[1] * move; pth1 = X1[2] * move;
         }
-        // the draw and the choice (ens_choose's order of operations: float sum of the weights, double running sum)
         rng = rng * 69069u + 1u;
         const double roll = (double)rng / 4294967296.0;
-        int ch;
-        {
-          float norm = pth0 + pth1;
-          if (n == 4) { norm = norm + pth2; norm = norm + pth3; }
-          if (!(norm > 0.0f)) ch = 0;
-          else {
-            const double target = roll * (double)norm;
-            double sum = (double)pth0;
-            if (target < sum) ch = 0;
-            else { sum += (double)pth1;
-              if (target < sum) ch = 1;
-              else if (n == 2) ch = (pth1 > 0.0f) ? 1 : 0;
-              else { sum += (double)pth2;
-                if (target < sum) ch = 2;
-                else { sum += (double)pth3;
-                  if (target < sum) ch = 3;
-                  else ch = (pth3 > 0.0f) ? 3 : (pth2 > 0.0f) ? 2 : (pth1 > 0.0f) ? 1 : 0; } } }
-          }
-        }
+        int ch = (n == 4) ? ens_choice4(pth0, pth1, pth2, pth3, roll) : ens_choice2(pth0, pth1, roll);
         ch = uni_i(ch);
-        if (st == sC || st == sJ) {
-          if (ch == 0) { SET_CODE(0u) LEAVE_ROW() } else st = sE;
-        } else if (st == sM) {
-          SET_CODE(0x4000u | (uint32_t)k)
+        if (st == sM) {
+          if (lane == 0) code[i] = (uint16_t)(0x4000u | (uint32_t)k);
           if (!sqto) { sqto = i; hmmto = k; }
           if (ch == 0) {
             if (nseg == segcap) { overflow = true; break; }
@@ -422,11 +388,11 @@ __global__ void __launch_bounds__(64) ens_trace_seq_kernel(const EnsWork *__rest
             ++nseg;
             st = sB;
           } else st = (ch == 1) ? sM : (ch == 2) ? sI : sD;
-          LEAVE_ROW() --k;
+          --i; --k;
         } else if (st == sI) {
-          SET_CODE(0x8000u | (uint32_t)k)
+          if (lane == 0) code[i] = (uint16_t)(0x8000u | (uint32_t)k);
           st = (ch == 0) ? sM : sI;
-          LEAVE_ROW()
+          --i;
         } else if (st == sD) {
           st = (ch == 0) ? sM : sD;
           --k;
@@ -437,18 +403,12 @@ __global__ void __launch_bounds__(64) ens_trace_seq_kernel(const EnsWork *__rest
       // a numerically impossible move ends the trace
       if (IMPOSSIBLE()) break;
     }
-#undef IMPOSSIBLE
-    // residues i .. 1 lie outside every domain: code 0 (the block the walk stopped in, then everything below it)
-    if (i >= 0) {
-      const int b = i & ~63;
-      if (lane <= (i & 63)) mycode = 0;
-      { const int pos_ = b + lane; if (pos_ >= 1 && pos_ <= Ld) code[pos_] = (uint16_t)mycode; }
-      for (int pos_ = 1 + lane; pos_ < b; pos_ += 64) code[pos_] = 0;
-    }
+    // residues i .. 1 lie outside every domain: code 0
+    for (int pos_ = 1 + lane; pos_ <= i; pos_ += 64) code[pos_] = 0;
     if (lane == 0) nsegp[t] = overflow ? -1 : nseg;
-#undef SET_CODE
-#undef LEAVE_ROW
   }
+#undef IMPOSSIBLE
+#undef STAGE_X
  }
 }
 

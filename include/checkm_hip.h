@@ -272,11 +272,11 @@ void ckm_tables_free(ckm_tables *t);
  * The deterministic front end of the gene finder CheckM runs before the scan -- `prodigal -p single -m -f gff -g <11|4>`, twice per bin,
  * checkm/prodigal.py:74,86-93,131-133: start / stop codon flags of all six frames and the start / stop NODES the gene finder's dynamic
  * program works on (Prodigal 2.6.3 node.c: add_nodes), for all contigs of a bin in two kernel launches.  `text` holds the contigs'
- * nucleotides (ASCII, any case; anything but ACGTU is "no base"), contig c = text[contig_off[c] .. contig_off[c+1]).  What is NOT here:
- * training, scoring and the dynamic program that turn nodes into genes, and prodigal's -m masking. */
+ * nucleotides (ASCII, any case; anything but ACGTU is "no base"), contig c = text[contig_off[c] .. contig_off[c+1]).  The rest of the gene
+ * finder is ckm_genes_call below. */
 typedef struct ckm_orf ckm_orf;
 typedef struct {
-  uint64_t        n;            /* nodes, sorted by (contig, position, strand [reverse first], type, stop_val, edge) */
+  uint64_t        n;            /* nodes, sorted by (contig, position, strand [forward first: node.c compare_nodes], type, stop_val, edge) */
   const uint32_t *contig;
   const int32_t  *ndx;          /* position of the codon's first base on the FORWARD strand's coordinates (node.c: ndx) */
   const int32_t  *stop_val;     /* start node: the stop that closes its ORF; stop node: the previous stop of its frame (node.c: stop_val) */
@@ -291,6 +291,39 @@ int  ckm_orf_columns_get(const ckm_orf *o, ckm_orf_columns *out);
 void ckm_orf_free(ckm_orf *o);
 /* measurement hook (bench.py: gene_front_end): the streaming flag kernel over nbytes of device-generated nucleotides, average ms of reps launches */
 int  ckm_debug_orf_flags(ckm_ctx *ctx, uint64_t nbytes, uint32_t reps, double *ms);
+
+/* ---- gene calling, the body -----------------------------------------------------------
+ * Replaces the two `prodigal -p single -q -m -f gff -g <table> -a genes.faa -i <bin>` processes per bin of checkm/prodigal.py:80-93
+ * (ProdigalRunner.run) for a BATCH of bins and ONE translation table per call: training on each bin's own sequence (GC-frame bias, hexamer
+ * coding statistics, start-site model), node scoring, the dynamic program over the nodes, gene records and their translations -- the
+ * single-genome mode of Prodigal 2.6.3 as restated in oracle/gene_full.c (parity unpinned: no prodigal exists next to the reference).
+ * NOT built: `-p meta` (checkm/prodigal.py:80-83 uses it below 100 kb; prodigal refuses to train below 20 kb): such a bin comes back with
+ * bin_trained = 0 and no genes, and the caller decides (checkm_amd/prodigal.py falls back to an external binary or reports the bin).
+ * text: all contigs' nucleotides (ASCII, any case; anything but ACGTU is an unknown base); contig c = text[contig_off[c] .. contig_off[c+1]);
+ * bin b owns contigs bin_first[b] .. bin_first[b+1]-1.  mask_n_runs = prodigal's -m (runs of >= 50 unknown bases hide the genes crossing them). */
+typedef struct ckm_genes ckm_genes;
+typedef struct {
+  uint64_t        n;                 /* genes, bin by bin, contig by contig, in order along the contig */
+  const uint32_t *bin, *contig;      /* contig: index into the call's contig table */
+  const int32_t  *begin, *end;       /* 1-based, inclusive, on the contig's forward strand (GFF columns 4 and 5) */
+  const int8_t   *strand;            /* +1 / -1 */
+  const uint8_t  *start_type;        /* 0 ATG, 1 GTG, 2 TTG, 3 Edge */
+  const uint8_t  *partial_left, *partial_right;
+  const int32_t  *rbs_bin;           /* Shine-Dalgarno bin 0..27 the start was credited with, or -1 (upstream motif / none) */
+  const int32_t  *mot_len, *mot_ndx, *mot_spacer;   /* upstream motif of organisms without SD: length 3..6 (0 none), its base-4 index, spacer */
+  const double   *gc_cont, *conf, *score, *cscore, *sscore, *rscore, *uscore, *tscore;
+  const uint64_t *prot_off;          /* [n + 1] */
+  const char     *prot;              /* translations, '*' for the stop of a complete gene */
+  uint64_t        nbins;
+  const uint8_t  *bin_trained, *bin_uses_sd;
+  const double   *bin_gc;
+  const uint64_t *bin_bases, *bin_coding, *bin_nodes;   /* nucleotides, bases inside genes (sum of gene lengths), start/stop nodes of the contigs */
+  double          ms_nodes, ms_dp_train, ms_score, ms_dp_find, ms_total;   /* wall to the nodes; kernel times (HIP events) of both dynamic programs and of the per-node scores; wall of the call */
+} ckm_genes_columns;
+int  ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *contig_off, uint32_t ncontigs, const uint32_t *bin_first, uint32_t nbins,
+                    int trans_table, int closed_ends, int mask_n_runs, ckm_genes **out);
+int  ckm_genes_columns_get(const ckm_genes *g, ckm_genes_columns *out);
+void ckm_genes_free(ckm_genes *g);
 
 /* ---- diagnostics used by the parity tests: every stage of one (model, sequence) pair, no filtering */
 typedef struct {

@@ -89,11 +89,11 @@ int go_nodes(const uint8_t *seq, int slen, int trans_table, int closed, go_node 
   return n;
 }
 
-/* prodigal's working order: qsort by ndx, then strand (node.c: compare_nodes); ties beyond that keep emission order here */
+/* prodigal's working order: qsort by ndx, then strand with the forward strand first (node.c: compare_nodes) */
 static int cmp(const void *a, const void *b) {
   const go_node *x = (const go_node *)a, *y = (const go_node *)b;
   if (x->ndx != y->ndx) return x->ndx < y->ndx ? -1 : 1;
-  if (x->strand != y->strand) return x->strand < y->strand ? -1 : 1;
+  if (x->strand != y->strand) return x->strand > y->strand ? -1 : 1;      /* forward strand first */
   if (x->type != y->type) return x->type < y->type ? -1 : 1;
   if (x->stop_val != y->stop_val) return x->stop_val < y->stop_val ? -1 : 1;
   return x->edge - y->edge;
