@@ -96,6 +96,18 @@ class OrfColumns(C.Structure):
                 ("ms_flags", C.c_double), ("ms_chain", C.c_double), ("bases", C.c_uint64), ("padded_bytes", C.c_uint64)]
 
 
+class GeneColumns(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("bin", C.POINTER(C.c_uint32)), ("contig", C.POINTER(C.c_uint32)), ("begin", C.POINTER(C.c_int32)), ("end", C.POINTER(C.c_int32)),
+                ("strand", C.POINTER(C.c_int8)), ("start_type", C.POINTER(C.c_uint8)), ("partial_left", C.POINTER(C.c_uint8)), ("partial_right", C.POINTER(C.c_uint8)),
+                ("rbs_bin", C.POINTER(C.c_int32)), ("mot_len", C.POINTER(C.c_int32)), ("mot_ndx", C.POINTER(C.c_int32)), ("mot_spacer", C.POINTER(C.c_int32)),
+                ("gc_cont", C.POINTER(C.c_double)), ("conf", C.POINTER(C.c_double)), ("score", C.POINTER(C.c_double)), ("cscore", C.POINTER(C.c_double)),
+                ("sscore", C.POINTER(C.c_double)), ("rscore", C.POINTER(C.c_double)), ("uscore", C.POINTER(C.c_double)), ("tscore", C.POINTER(C.c_double)),
+                ("prot_off", C.POINTER(C.c_uint64)), ("prot", C.POINTER(C.c_char)),
+                ("nbins", C.c_uint64), ("bin_trained", C.POINTER(C.c_uint8)), ("bin_uses_sd", C.POINTER(C.c_uint8)), ("bin_gc", C.POINTER(C.c_double)),
+                ("bin_bases", C.POINTER(C.c_uint64)), ("bin_coding", C.POINTER(C.c_uint64)), ("bin_nodes", C.POINTER(C.c_uint64)),
+                ("ms_nodes", C.c_double), ("ms_dp_train", C.c_double), ("ms_score", C.c_double), ("ms_dp_find", C.c_double), ("ms_total", C.c_double)]
+
+
 class TableColumns(C.Structure):
     _fields_ = [("cols", HitColumns), ("target_accession", C.POINTER(C.c_char_p)), ("query_name", C.POINTER(C.c_char_p)),
                 ("query_accession", C.POINTER(C.c_char_p)), ("description", C.POINTER(C.c_char_p)),
@@ -109,7 +121,7 @@ EXPORTS = ["ckm_last_error", "ckm_abi_version", "ckm_device_count", "ckm_ctx_cre
            "ckm_seqs_pack", "ckm_seqs_from_fasta", "ckm_seqs_count", "ckm_seqs_bin_offsets", "ckm_seqs_name", "ckm_seqs_residues", "ckm_seqs_free", "ckm_search", "ckm_hits_columns", "ckm_hits_free",
            "ckm_hits_write_domtblout", "ckm_hits_write_alignments", "ckm_last_search_stats", "ckm_reduce", "ckm_qa_columns_get", "ckm_qa_free", "ckm_count_sets",
            "ckm_align", "ckm_tables_read", "ckm_tables_assign_models", "ckm_tables_get", "ckm_tables_free",
-           "ckm_orf_scan", "ckm_orf_columns_get", "ckm_orf_free", "ckm_debug_orf_flags",
+           "ckm_orf_scan", "ckm_orf_columns_get", "ckm_orf_free", "ckm_debug_orf_flags", "ckm_genes_call", "ckm_genes_columns_get", "ckm_genes_free",
            "ckm_debug_stages", "ckm_debug_envelopes", "ckm_debug_region"]
 
 _lib = None
@@ -168,6 +180,10 @@ def load():
     L.ckm_orf_columns_get.argtypes = [C.c_void_p, C.POINTER(OrfColumns)]
     L.ckm_orf_free.argtypes = [C.c_void_p]
     L.ckm_orf_free.restype = None
+    L.ckm_genes_call.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.ckm_genes_columns_get.argtypes = [C.c_void_p, C.POINTER(GeneColumns)]
+    L.ckm_genes_free.argtypes = [C.c_void_p]
+    L.ckm_genes_free.restype = None
     L.ckm_debug_orf_flags.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
     L.ckm_debug_stages.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.ckm_debug_envelopes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -475,6 +491,44 @@ def orf_nodes(ctx, contigs, trans_table=11, closed=False):
     finally:
         load().ckm_orf_free(h)
     return out, stats
+
+
+GENE_FIELDS = ("bin", "contig", "begin", "end", "strand", "start_type", "partial_left", "partial_right", "rbs_bin", "mot_len", "mot_ndx", "mot_spacer",
+               "gc_cont", "conf", "score", "cscore", "sscore", "rscore", "uscore", "tscore")
+
+
+def call_genes(ctx, bins, trans_table=11, closed=False, mask=True):
+    """Gene calling for a batch of bins (ckm_genes_call): bins = list of lists of nucleotide strings / bytes (the contigs of each bin).
+    Returns (columns dict of numpy arrays over all genes + 'proteins' list of str, per-bin dict, stats dict); `contig` is the contig's
+    index inside its bin."""
+    parts, bin_first = [], [0]
+    for contigs in bins:
+        for c in contigs:
+            parts.append(c.encode() if isinstance(c, str) else bytes(c))
+        bin_first.append(len(parts))
+    off = np.zeros(len(parts) + 1, dtype=np.uint64)
+    if parts:
+        np.cumsum([len(p) for p in parts], out=off[1:])
+    bf = np.asarray(bin_first, dtype=np.uint32)
+    text = b"".join(parts)
+    h = C.c_void_p()
+    _chk(load().ckm_genes_call(ctx.h, text, off.ctypes.data, len(parts), bf.ctypes.data, len(bins), int(trans_table), 1 if closed else 0, 1 if mask else 0, C.byref(h)))
+    try:
+        cols = GeneColumns()
+        _chk(load().ckm_genes_columns_get(h, C.byref(cols)))
+        n, nb = int(cols.n), int(cols.nbins)
+        arr = np.ctypeslib.as_array
+        out = {f: (arr(getattr(cols, f), shape=(n,)).copy() if n else np.zeros(0, dtype=np.int64)) for f in GENE_FIELDS}
+        if n:
+            out["contig"] = out["contig"] - bf[out["bin"]]
+        po = arr(cols.prot_off, shape=(n + 1,)).copy() if n else np.zeros(1, dtype=np.uint64)
+        blob = C.string_at(cols.prot, int(po[-1])) if n else b""
+        out["proteins"] = [blob[int(po[k]):int(po[k + 1])].decode() for k in range(n)]
+        per_bin = {f: (arr(getattr(cols, "bin_" + f), shape=(nb,)).copy() if nb else np.zeros(0)) for f in ("trained", "uses_sd", "gc", "bases", "coding", "nodes")}
+        stats = dict(ms_nodes=cols.ms_nodes, ms_dp_train=cols.ms_dp_train, ms_score=cols.ms_score, ms_dp_find=cols.ms_dp_find, ms_total=cols.ms_total)
+    finally:
+        load().ckm_genes_free(h)
+    return out, per_bin, stats
 
 
 def debug_orf_flags(ctx, nbytes, reps=10):

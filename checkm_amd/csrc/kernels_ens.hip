@@ -171,58 +171,18 @@ __global__ void __launch_bounds__(256) ens_trace_kernel(const EnsWork *__restric
 // carried from trace to trace (every state of a trace but N takes exactly one draw).  A single walk is a chain of dependent choices, but
 // most of it is RUNS whose states are known in advance as long as every choice comes out the likely way:
 //   * a run of match states down a diagonal: M(i,k) -> M(i-1,k-1) -> ...  Lane l evaluates the step at (i-l, k-l) with the draw the
-//     sequential walk would use there (the generator is linear: x[n+l+1] = A^(l+1) x[n] + C(l+1), one multiply-add per lane); the first
-//     lane whose choice is not "match again" ends the run, and the walk advances by that many steps at once.  Exactly the sequential
-//     walk -- each lane's step only assumes that all earlier steps stayed on the diagonal, which is what the first deviating lane decides;
+//     sequential walk would use there (the generator is linear: x[n+l+1] = A^(l+1) x[n] + C(l+1), one multiply-add per lane), on operands
+//     it GATHERS itself -- the region's Forward matrix is cell-major (kernels_fb.hip writes float4 {M, I, D, 0} per node), so a step's
+//     three predecessor values are one 16-byte load; the first lane whose choice is not "match again" ends the run, and the walk advances
+//     by that many steps at once.  Exactly the sequential walk: each lane's step only assumes that all earlier steps stayed on the
+//     diagonal, which is what the first deviating lane decides.  One memory round trip per up to 64 steps;
 //   * a run of C (or J) states over the residues outside the domains, the same way.
 // Insert / delete / begin states and the E state's choice over the 2M exit weights of a row (ens_select_e, all lanes) are single steps.
-// The operands come from LDS: the region's Forward matrix is cell-major (kernels_fb.hip writes float4 {M, I, D, 0} per node), a WINDOW
-// of 33 rows x 64 nodes around the diagonal (33 KB) is staged by all lanes together with the transition odds of those nodes, the NEXT
-// window down the diagonal is in flight into registers while one is walked, and the special rows are staged 128 at a time.  (The first
-// version walked global memory one step at a time: 96 ms per launch, 400 ms for the longest regions; a step-at-a-time LDS walk: 45 ms.)
+// (History of this kernel, per launch = per longest region: one step at a time from global memory 96 ms (up to 400); one step at a time
+// from LDS windows 45 ms; lockstep runs over LDS windows 33 rows deep ~25 ms -- the windows cost more than they saved: a diagonal uses
+// 33 of the 2112 nodes staged.)
 __device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-constexpr int EW_R = 32;                 // window rows below its top row
-constexpr int EW_NR = EW_R + 1;
-constexpr int EW_CW = 64;                // nodes per window row
-constexpr int EW_LO = 47;                // window nodes [anchor - EW_LO, anchor + 16]: the diagonal runs 32 nodes down, 15 spare for deletes, 16 for inserts
-constexpr int EW_TOL_LO = 7, EW_TOL_HI = 8;   // drift of the walk against the diagonal the pre-loaded window tolerates
-constexpr int EW_NG = (EW_NR * EW_CW + 63) / 64;          // float4 per lane per window (33)
-constexpr int EW_NT = (8 * (EW_CW + 1) + 63) / 64;        // transition floats per lane per window (9)
-constexpr int EW_XR = 128;               // special rows per staging: rows [x_r0, x_r0 + EW_XR]
-
-struct EnsWindowRegs { f32x4 g[EW_NG]; float t[EW_NT]; int r0, c0; bool valid; };
-
-// window with top row `top` and anchor node `anchor`: rows [top - EW_R, top], nodes [anchor - EW_LO, anchor - EW_LO + EW_CW)
-__device__ __forceinline__ void ens_window_load(EnsWindowRegs &w, const gp<f32x4> mx4, const gp<float> ftr, int Mp, int top, int anchor, int lane) {
-  w.r0 = top - EW_R; w.c0 = anchor - EW_LO; w.valid = true;
-#pragma unroll
-  for (int j = 0; j < EW_NG; ++j) {
-    const int row = j, col = lane;                          // EW_CW == 64: one window row per register
-    const int gr = w.r0 + row, gc = w.c0 + col;
-    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (gr >= 0 && gc >= 0 && gc < Mp) v = mx4[(size_t)gr * Mp + gc];
-    w.g[j] = v;
-  }
-#pragma unroll
-  for (int j = 0; j < EW_NT; ++j) {
-    const int idx = j * 64 + lane, arr = idx / (EW_CW + 1), col = idx - arr * (EW_CW + 1);
-    const int gc = w.c0 + col;
-    float v = 0.f;
-    if (arr < 8 && gc >= 0 && gc < Mp) v = ftr[(size_t)arr * Mp + gc];
-    w.t[j] = v;
-  }
-}
-// LDS images: Wg[row][node] {M, I, D, 0}; Wt[node][8] = {BM, MM, IM, DM | MI, II, MD, DD} of node c0 + node (two 16-byte reads)
-__device__ __forceinline__ void ens_window_store(const EnsWindowRegs &w, f32x4 *Wg, float *Wt, int lane) {
-#pragma unroll
-  for (int j = 0; j < EW_NG; ++j) Wg[j * 64 + lane] = w.g[j];
-#pragma unroll
-  for (int j = 0; j < EW_NT; ++j) {
-    const int idx = j * 64 + lane, arr = idx / (EW_CW + 1), col = idx - arr * (EW_CW + 1);
-    if (arr < 8) Wt[col * 8 + arr] = w.t[j];
-  }
-}
 // first index whose cumulative weight exceeds roll * total (ens_choose's order of operations: float sum of the weights, double running sum)
 __device__ __forceinline__ int ens_choice4(float p0, float p1, float p2, float p3, double roll) {
   float norm = p0 + p1; norm = norm + p2; norm = norm + p3;
@@ -242,9 +202,6 @@ __device__ __forceinline__ int ens_choice2(float p0, float p1, double roll) {
 __global__ void __launch_bounds__(64) ens_trace_seq_kernel(const EnsWork *__restrict__ work, const uint32_t *__restrict__ list, const DevModel *__restrict__ models,
                                                           const LenEntry *__restrict__ lentab, float *__restrict__ ws,
                                                           const uint32_t *__restrict__ seeds, const uint32_t *__restrict__ count, uint32_t cap) {
- __shared__ f32x4 Wg[EW_NR * EW_CW];
- __shared__ float Wt[8 * (EW_CW + 1) + 8];
- __shared__ float Wx[(EW_XR + 1) * 6 + 6];
  const uint32_t nregions = min(*count, cap);
  const int lane = threadIdx.x;
  __builtin_amdgcn_s_setprio(3);          // one latency-bound wavefront among the VALU-bound ones of the SSV launches
@@ -258,6 +215,7 @@ __global__ void __launch_bounds__(64) ens_trace_seq_kernel(const EnsWork *__rest
   const gp<f32x4> mx4 = (gp<f32x4>)gptr(ws + w.mx_off);
   const gp<float> xs = gptr(ws + w.xs_off);
   const gp<float> ftr = gptr(md.ftr);
+  const gp<float> tBM = ftr, tMM = ftr + Mp, tIM = ftr + 2 * Mp, tDM = ftr + 3 * Mp, tMI = ftr + 4 * Mp, tII = ftr + 5 * Mp, tMD = ftr + 6 * Mp, tDD = ftr + 7 * Mp;
   const LenEntry le = lentab[w.Lcfg];
   const float loop = le.loop_m, move = le.move_m, Eloop = md.fE_loop, Emove = md.fE_move;
   uint16_t *__restrict__ codes = reinterpret_cast<uint16_t *>(ws + w.code_off);
@@ -265,12 +223,6 @@ __global__ void __launch_bounds__(64) ens_trace_seq_kernel(const EnsWork *__rest
   int32_t *__restrict__ nsegp = reinterpret_cast<int32_t *>(ws + w.nseg_off);
   enum { sC, sE, sM, sI, sD, sB, sJ, sN };
   uint32_t rng = (uint32_t)uni_i((int)seeds[0]);            // the region's stream: re-seeded here, carried from trace to trace below
-  int w_r0 = 0x40000000, w_c0 = 0;                          // rows [w_r0, w_r0 + EW_NR), nodes [w_c0, w_c0 + EW_CW) of the matrix are in LDS (none yet)
-  int x_r0 = 0x40000000;                                    // special rows [x_r0, x_r0 + EW_XR] are in LDS (none yet)
-  EnsWindowRegs nx; nx.valid = false; nx.r0 = 0; nx.c0 = 0;
-  __syncthreads();
-#define STAGE_X(TOP) { __syncthreads(); x_r0 = max((TOP) - EW_XR, 0); \
-    for (int e = lane; e < (EW_XR + 1) * 6; e += 64) { const int gr = x_r0 + e / 6; Wx[e] = (gr <= Ld) ? xs[(size_t)x_r0 * 6 + e] : 0.f; } __syncthreads(); }
 #define IMPOSSIBLE() (i < 0 || k < 0 || ((st == sM || st == sI) && (k < 1 || i < 1)) || (st == sD && k < 1) || ((st == sC || st == sJ || st == sE) && i < 1))
   for (int t = 0; t < ENS_N; ++t) {
     uint16_t *__restrict__ code = codes + (size_t)t * (Ld + 1);
@@ -280,104 +232,75 @@ __global__ void __launch_bounds__(64) ens_trace_seq_kernel(const EnsWork *__rest
     for (;;) {
       // ---- a run of match states down the diagonal, one step per lane ----
       if (st == sM && k >= 2 && i >= 1) {
-        const int rrow = i - 1 - w_r0, ccol = k - 2 - w_c0, xrow = i - 1 - x_r0;
-        if (rrow >= 0 && rrow < EW_NR && ccol >= 0 && ccol + 1 < EW_CW && xrow >= 0 && xrow < EW_XR) {
-          const int R = min(min(rrow + 1, ccol + 1), min(min(xrow + 1, i), min(k - 1, 64)));      // steps that stay inside the windows and the matrix
-          const bool in = lane < R;
-          const int l = in ? lane : 0;
-          const f32x4 g = Wg[(rrow - l) * EW_CW + (ccol - l)];
-          const f32x4 ta = *reinterpret_cast<const f32x4 *>(Wt + (ccol + 1 - l) * 8);
-          const float xB = Wx[(xrow - l) * 6 + 3];
-          const uint32_t x = jA * rng + jC;
-          const int ch = ens_choice4(xB * ta.x, g.x * ta.y, g.y * ta.z, g.z * ta.w, (double)x / 4294967296.0);
-          const unsigned long long stay = __ballot(in && ch == 1);
-          const int r = (stay == ~0ull) ? 64 : (int)__builtin_ctzll(~stay);      // first lane that does not continue the run (r >= R: all R stayed)
-          const int last = min(r, R - 1);                       // lane of the last step taken
-          if (!sqto) { sqto = i; hmmto = k; }
-          if (lane <= last) code[i - lane] = (uint16_t)(0x4000u | (uint32_t)(k - lane));
-          rng = (uint32_t)__builtin_amdgcn_readlane((int)x, last);
-          if (r < R) {
-            const int chr = __builtin_amdgcn_readlane(ch, r);
-            const int ir = i - r, kr = k - r;
-            if (chr == 0) {
-              if (nseg == segcap) { overflow = true; break; }
-              if (lane == 0) { seg[nseg * 4 + 0] = ir; seg[nseg * 4 + 1] = sqto; seg[nseg * 4 + 2] = kr; seg[nseg * 4 + 3] = hmmto; }
-              ++nseg;
-              st = sB;
-            } else st = (chr == 2) ? sI : sD;
-            i = ir - 1; k = kr - 1;
-          } else { i -= R; k -= R; }
-          if (IMPOSSIBLE()) break;
-          continue;
-        }
+        const int R = min(min(i, k - 1), 64);                 // steps that stay inside the matrix with a predecessor node (k - l >= 2)
+        const bool in = lane < R;
+        const int l = in ? lane : 0;
+        const int ri = i - l, c = k - 1 - l;                  // lane l's state: M(ri, c + 1)
+        const f32x4 g = mx4[(size_t)(ri - 1) * Mp + (c - 1)];
+        const float xB = xs[(size_t)(ri - 1) * 6 + 3];
+        const float p0 = xB * tBM[c], p1 = g.x * tMM[c], p2 = g.y * tIM[c], p3 = g.z * tDM[c];
+        const uint32_t x = jA * rng + jC;
+        const int ch = ens_choice4(p0, p1, p2, p3, (double)x / 4294967296.0);
+        const unsigned long long stay = __ballot(in && ch == 1);
+        const int r = (stay == ~0ull) ? 64 : (int)__builtin_ctzll(~stay);      // first lane that does not continue the run (r >= R: all R stayed)
+        const int last = min(r, R - 1);                       // lane of the last step taken
+        if (!sqto) { sqto = i; hmmto = k; }
+        if (lane <= last) code[i - lane] = (uint16_t)(0x4000u | (uint32_t)(k - lane));
+        rng = (uint32_t)__builtin_amdgcn_readlane((int)x, last);
+        if (r < R) {
+          const int chr = __builtin_amdgcn_readlane(ch, r);
+          const int ir = i - r, kr = k - r;
+          if (chr == 0) {
+            if (nseg == segcap) { overflow = true; break; }
+            if (lane == 0) { seg[nseg * 4 + 0] = ir; seg[nseg * 4 + 1] = sqto; seg[nseg * 4 + 2] = kr; seg[nseg * 4 + 3] = hmmto; }
+            ++nseg;
+            st = sB;
+          } else st = (chr == 2) ? sI : sD;
+          i = ir - 1; k = kr - 1;
+        } else { i -= R; k -= R; }
+        if (IMPOSSIBLE()) break;
+        continue;
       }
       // ---- a run of C (or J) states over the special rows ----
       if ((st == sC || st == sJ) && i >= 1) {
-        const int xrow = i - x_r0;
-        if (xrow >= 1 && xrow <= EW_XR) {
-          const int R = min(min(xrow, i), 64);
-          const bool in = lane < R;
-          const int l = in ? lane : 0;
-          const int col = (st == sC) ? 4 : 2; const float em = (st == sC) ? Emove : Eloop;
-          const float *X1 = Wx + (xrow - l) * 6;
-          const uint32_t x = jA * rng + jC;
-          const int ch = ens_choice2(X1[col - 6] * loop, (X1[0] * em) * X1[5], (double)x / 4294967296.0);
-          const unsigned long long stay = __ballot(in && ch == 0);
-          const int r = (stay == ~0ull) ? 64 : (int)__builtin_ctzll(~stay);
-          const int nstay = min(r, R);
-          if (lane < nstay) code[i - lane] = 0;
-          rng = (uint32_t)__builtin_amdgcn_readlane((int)x, min(r, R - 1));
-          i -= nstay;
-          if (r < R) st = sE;
-          if (IMPOSSIBLE()) break;
-          continue;
-        }
+        const int R = min(i, 64);
+        const bool in = lane < R;
+        const int l = in ? lane : 0;
+        const int col = (st == sC) ? 4 : 2; const float em = (st == sC) ? Emove : Eloop;
+        const gp<float> X1 = xs + (size_t)(i - l) * 6;
+        const uint32_t x = jA * rng + jC;
+        const int ch = ens_choice2(X1[col - 6] * loop, (X1[0] * em) * X1[5], (double)x / 4294967296.0);
+        const unsigned long long stay = __ballot(in && ch == 0);
+        const int r = (stay == ~0ull) ? 64 : (int)__builtin_ctzll(~stay);
+        const int nstay = min(r, R);
+        if (lane < nstay) code[i - lane] = 0;
+        rng = (uint32_t)__builtin_amdgcn_readlane((int)x, min(r, R - 1));
+        i -= nstay;
+        if (r < R) st = sE;
+        if (IMPOSSIBLE()) break;
+        continue;
       }
-      float pth0 = 0.0f, pth1 = 0.0f, pth2 = 0.0f, pth3 = 0.0f; int n = 2;
+      if (st == sN) break;
       if (st == sE) {
         rng = rng * 69069u + 1u;
         const int r = uni_i(ens_select_e((const f32x4 *)(mx4 + (size_t)i * Mp), Q, (double)rng / 4294967296.0, lane));
         k = (r >> 1) + 1; st = (r & 1) ? sD : sM; sqto = 0; hmmto = 0;
-      } else if (st == sN) {
-        break;
       } else {
-        if (st == sM || st == sI || st == sD) {
-          // the node of row nr this step reads: M(i,k) <- row i-1, node k-2 (and the transitions INTO node k-1); I(i,k) <- row i-1, node k-1;
-          // D(i,k) <- row i, node k-2.  Node -1 (k = 1) reads as zero, as the window's out-of-range nodes do.
-          const int nr = (st == sD) ? i : i - 1, nc = (st == sI) ? k - 1 : k - 2;
-          if (nr < w_r0 || nr >= w_r0 + EW_NR || nc < w_c0 || nc + 1 >= w_c0 + EW_CW) {
-            // leave the window: the pre-loaded one if the walk left through the bottom near the diagonal, else a synchronous load
-            if (!(nx.valid && nx.r0 + EW_R == nr && nc - (EW_R + EW_TOL_LO) >= nx.c0 && nc + EW_TOL_HI + 1 < nx.c0 + EW_CW))
-              ens_window_load(nx, mx4, ftr, Mp, nr, nc, lane);
-            __syncthreads();
-            ens_window_store(nx, Wg, Wt, lane);
-            w_r0 = uni_i(nx.r0); w_c0 = uni_i(nx.c0);
-            __syncthreads();
-            ens_window_load(nx, mx4, ftr, Mp, w_r0 - 1, nc - (EW_R + 1), lane);       // next window down the diagonal: in flight while this one is walked
-          }
-          if (st == sM && (i - 1 < x_r0 || i - 1 >= x_r0 + EW_XR)) STAGE_X(i)
-          if (st == sM && k >= 2) continue;                 // (the run above takes it from here)
-          const f32x4 g = Wg[(nr - w_r0) * EW_CW + (nc - w_c0)];
-          const float *T = Wt + (nc - w_c0) * 8;          // transitions of node nc; node nc + 1 at T + 8
-          if (st == sM) {                                 // k == 1: no predecessor node
-            n = 4;
-            pth0 = Wx[(i - 1 - x_r0) * 6 + 3] * T[8 + 0];
-          } else if (st == sI) {
-            pth0 = g.x * T[4]; pth1 = g.y * T[5];
-          } else {
-            if (k > 1) { pth0 = g.x * T[6]; pth1 = g.z * T[7]; }
-          }
+        // single steps: M at node 1, I, D, B
+        float pth0 = 0.0f, pth1 = 0.0f;
+        if (st == sM) {                                      // k == 1: no predecessor node, only the entry from B
+          pth0 = xs[(size_t)(i - 1) * 6 + 3] * tBM[0];
+        } else if (st == sI) {
+          const f32x4 g = mx4[(size_t)(i - 1) * Mp + (k - 1)];
+          pth0 = g.x * tMI[k - 1]; pth1 = g.y * tII[k - 1];
+        } else if (st == sD) {
+          if (k > 1) { const f32x4 g = mx4[(size_t)i * Mp + (k - 2)]; pth0 = g.x * tMD[k - 2]; pth1 = g.z * tDD[k - 2]; }
         } else {
-          // C, J, B: special rows i-1 and i
-          const int lo = (st == sB) ? i : i - 1;
-          if (lo < x_r0 || i > x_r0 + EW_XR) STAGE_X(i)
-          if (st != sB) continue;                           // (the run above takes C and J from here)
-          const float *X1 = Wx + (i - x_r0) * 6;
-          pth0 = X1[1] * move; pth1 = X1[2] * move;
+          pth0 = xs[(size_t)i * 6 + 1] * move; pth1 = xs[(size_t)i * 6 + 2] * move;
         }
         rng = rng * 69069u + 1u;
         const double roll = (double)rng / 4294967296.0;
-        int ch = (n == 4) ? ens_choice4(pth0, pth1, pth2, pth3, roll) : ens_choice2(pth0, pth1, roll);
+        int ch = (st == sM) ? ens_choice4(pth0, 0.0f, 0.0f, 0.0f, roll) : ens_choice2(pth0, pth1, roll);
         ch = uni_i(ch);
         if (st == sM) {
           if (lane == 0) code[i] = (uint16_t)(0x4000u | (uint32_t)k);
@@ -408,7 +331,6 @@ __global__ void __launch_bounds__(64) ens_trace_seq_kernel(const EnsWork *__rest
     if (lane == 0) nsegp[t] = overflow ? -1 : nseg;
   }
 #undef IMPOSSIBLE
-#undef STAGE_X
  }
 }
 

@@ -1,13 +1,15 @@
-"""First slice of gene calling on the MI355X: the deterministic front end of the gene finder CheckM runs in front of
-the marker-gene scan.
+"""Gene calling on the MI355X: what CheckM runs in front of the marker-gene scan when bins arrive as nucleotides.
 
 The reference calls `prodigal -p single|meta -q -m -f gff -g <table> -a genes.faa -i <bin>` twice per bin, tables 11 and 4
 (checkm/prodigal.py:74,86-93,131-133), and keeps table 4 when it raises the coding density enough.  Prodigal is a third-party C
 program that is in neither /root/reference nor this image; what it does falls into (1) a byte scan that finds the start / stop NODES of
-all six frames, (2) a per-genome training pass, (3) a dynamic program over the nodes.  This module offers (1) on the device -- both
-translation tables from one upload of the bin -- through libcheckm_hip's ckm_orf_scan; (2) and (3) are not built (DESIGN.md section
-10), so `checkm_amd.prodigal.ProdigalRunner` still runs the external binary to produce genes.faa.  There is no CPU implementation
-here: without a gfx950 device the library raises."""
+all six frames, (2) a per-genome training pass, (3) scoring and a dynamic program over the nodes, (4) gene records and translations.
+This module is the Python face of all four on the device: `OrfNodes` (1, libcheckm_hip's ckm_orf_scan) and `call_bins` /
+`call_bin_files` (1-4 for a batch of bins, ckm_genes_call: both dynamic programs, the hexamer sums and the Shine-Dalgarno bins as
+kernels, the ordered sweeps on the library's host threads), writing genes.faa / genes.gff in prodigal's layout and applying the
+reference's choice between the tables.  The single-genome mode only: `-p meta` (pre-trained models, used by CheckM below 100 kb) is
+not built -- bins of 20-100 kb are trained on themselves here, smaller ones are refused.  The oracle is oracle/gene_full.c (parity
+unpinned: a restatement of Prodigal 2.6.3 from memory).  There is no CPU implementation here: without a gfx950 device the library raises."""
 from checkm_amd import _lib, runtime
 
 ATG, GTG, TTG, STOP = 0, 1, 2, 3
@@ -46,3 +48,141 @@ class OrfNodes(object):
         the candidates the gene finder's dynamic program chooses among."""
         sel = (self.type != STOP) & (self.edge == 0) & (abs(self.stop_val - self.ndx) + 3 >= minLength)
         return list(zip(self.contig[sel].tolist(), self.ndx[sel].tolist(), self.stop_val[sel].tolist(), (1 - 2 * self.strand_rev[sel].astype(int)).tolist()))
+
+
+# ---- the gene finder's body on the device (round 4): genes.faa / genes.gff without an external binary ---------------------------------
+SD_MOTIF = ["None", "GGA/GAG/AGG", "3Base/5BMM", "4Base/6BMM", "AGxAG", "AGxAG", "GGA/GAG/AGG", "GGxGG", "GGxGG", "AGxAG", "AGGAG(G)/GGAGG",
+            "AGGA/GGAG/GAGG", "AGGA/GGAG/GAGG", "GGA/GAG/AGG", "GGxGG", "AGGA", "GGAG/GAGG", "AGxAGG/AGGxGG", "AGxAGG/AGGxGG", "AGxAGG/AGGxGG",
+            "AGGAG/GGAGG", "AGGAG", "AGGAG", "GGAGG", "GGAGG", "AGGAGG", "AGGAGG", "AGGAGG"]
+SD_SPACER = ["None", "3-4bp", "13-15bp", "13-15bp", "11-12bp", "3-4bp", "11-12bp", "11-12bp", "3-4bp", "5-10bp", "13-15bp", "3-4bp", "11-12bp", "5-10bp",
+             "5-10bp", "5-10bp", "5-10bp", "11-12bp", "3-4bp", "5-10bp", "11-12bp", "3-4bp", "5-10bp", "3-4bp", "5-10bp", "11-12bp", "3-4bp", "5-10bp"]
+START_TYPE = ["ATG", "GTG", "TTG", "Edge"]
+MIN_SINGLE_GENOME = 20000          # prodigal refuses to train on less; CheckM itself switches to `-p meta` below 100 kb (checkm/prodigal.py:80-83)
+
+
+def _motif_text(length, ndx):
+    return "".join("ACGT"[(ndx >> (2 * i)) & 3] for i in range(length))
+
+
+class BinGenes(object):
+    """Genes of one bin for one translation table, as the device returned them, with prodigal's text outputs."""
+
+    def __init__(self, contigs, table, cols, sel, trained, uses_sd, gc):
+        self.contigs, self.table, self.trained, self.uses_sd, self.gc = contigs, table, bool(trained), int(uses_sd), float(gc)
+        self.rows = [{f: (cols[f][k].item() if hasattr(cols[f][k], "item") else cols[f][k]) for f in cols} for k in sel]
+
+    def coding_bases(self):
+        """Bases covered by genes, overlaps counted once: what ProdigalGeneFeatureParser.codingBases sums over the contigs
+        (checkm/prodigal.py:246-274)."""
+        total = 0
+        by = {}
+        for r in self.rows:
+            by.setdefault(r["contig"], []).append((r["begin"] - 1, r["end"]))
+        for iv in by.values():
+            last = -1
+            for s, e in sorted(iv):
+                s = max(s, last)
+                if e > s:
+                    total += e - s
+                    last = e
+        return total
+
+    def _attrs(self, seqnum, k, r):
+        if r["rbs_bin"] >= 0:
+            motif, spacer = SD_MOTIF[r["rbs_bin"]], SD_SPACER[r["rbs_bin"]]
+        elif r["mot_len"] > 0:
+            motif, spacer = _motif_text(r["mot_len"], r["mot_ndx"]), "%dbp" % r["mot_spacer"]
+        else:
+            motif, spacer = "None", "None"
+        return "ID=%d_%d;partial=%d%d;start_type=%s;rbs_motif=%s;rbs_spacer=%s;gc_cont=%.3f" % (
+            seqnum, k, r["partial_left"], r["partial_right"], START_TYPE[r["start_type"]], motif, spacer, r["gc_cont"])
+
+    def write(self, aaFile, gffFile, ntFile=None):
+        """genes.faa / genes.gff (/ genes.fna) in prodigal's layout: `>contig_n # begin # end # strand # attributes`, GFF3 CDS lines."""
+        comp = bytes.maketrans(b"ACGTacgtNn", b"TGCAtgcaNn")
+        per = {}
+        for r in self.rows:
+            per.setdefault(r["contig"], []).append(r)
+        with open(aaFile, "w") as fa, open(gffFile, "w") as fg:
+            fn = open(ntFile, "w") if ntFile else None
+            fg.write("##gff-version  3\n")
+            for ci, (cid, seq) in enumerate(self.contigs):
+                fg.write('# Sequence Data: seqnum=%d;seqlen=%d;seqhdr="%s"\n' % (ci + 1, len(seq), cid))
+                fg.write('# Model Data: version=checkm_amd.device.gene_caller;run_type=Single;model="Ab initio";gc_cont=%.2f;transl_table=%d;uses_sd=%d\n'
+                         % (100.0 * self.gc, self.table, self.uses_sd))
+                for k, r in enumerate(per.get(ci, []), 1):
+                    at = self._attrs(ci + 1, k, r)
+                    strand = "+" if r["strand"] == 1 else "-"
+                    fg.write("%s\tcheckm_amd_device\tCDS\t%d\t%d\t%.1f\t%s\t0\t%s;conf=%.2f;score=%.2f;cscore=%.2f;sscore=%.2f;rscore=%.2f;uscore=%.2f;tscore=%.2f;\n"
+                             % (cid, r["begin"], r["end"], r["score"], strand, at, r["conf"], r["score"], r["cscore"], r["sscore"], r["rscore"], r["uscore"], r["tscore"]))
+                    head = ">%s_%d # %d # %d # %d # %s\n" % (cid, k, r["begin"], r["end"], r["strand"], at)
+                    p = r["proteins"]
+                    fa.write(head)
+                    for i in range(0, len(p), 60):
+                        fa.write(p[i:i + 60] + "\n")
+                    if fn is not None:
+                        nt = seq[r["begin"] - 1:r["end"]]
+                        if r["strand"] != 1:
+                            nt = nt.encode().translate(comp)[::-1].decode()
+                        fn.write(head)
+                        for i in range(0, len(nt), 70):
+                            fn.write(nt[i:i + 70] + "\n")
+            if fn is not None:
+                fn.close()
+
+
+def call_bins(bins, table, mask=True):
+    """Genes of many bins for one translation table in ONE device call (ckm_genes_call): bins = [[(contig id, sequence), ...], ...].
+    Returns a list of BinGenes."""
+    ctx = runtime.get_ctx()
+    cols, per_bin, stats = _lib.call_genes(ctx, [[s for _c, s in contigs] for contigs in bins], table, False, mask)
+    n = len(cols["begin"])
+    by_bin = [[] for _ in bins]
+    for k in range(n):
+        by_bin[int(cols["bin"][k])].append(k)
+    out = [BinGenes(bins[b], table, cols, by_bin[b], per_bin["trained"][b], per_bin["uses_sd"][b], per_bin["gc"][b]) for b in range(len(bins))]
+    call_bins.last_stats = stats
+    return out
+
+
+def best_table(genes11, genes4, total_bases):
+    """checkm/prodigal.py:117-133: table 4 only when its coding density beats table 11's by more than 0.05 and exceeds 0.7."""
+    d11 = float(genes11.coding_bases()) / total_bases if total_bases else 0
+    d4 = float(genes4.coding_bases()) / total_bases if total_bases else 0
+    return (4 if (d4 - d11 > 0.05) and d4 > 0.7 else 11), {11: d11, 4: d4}
+
+
+def call_bin_files(jobs, bNucORFs=False, max_bases=1 << 30, logger=None):
+    """jobs = [(nucleotide FASTA of a bin, directory for genes.faa / genes.gff [/ genes.fna])].  Both translation tables per bin from the
+    device, the reference's choice between them, prodigal's file layout.  Returns {binFile: (best table, {11: density, 4: density})}.
+    A bin below 20 kb cannot be trained on (and the pre-trained `-p meta` models CheckM would use below 100 kb are not built): it raises."""
+    import os
+    from checkm_amd.defaultValues import DefaultValues
+    out = {}
+    batch, size = [], 0
+
+    def flush():
+        nonlocal batch, size
+        if not batch:
+            return
+        bins = [b[2] for b in batch]
+        g11 = call_bins(bins, 11)
+        g4 = call_bins(bins, 4)
+        for (binFile, binDir, contigs, total), a, b in zip(batch, g11, g4):
+            if not a.trained:
+                raise ValueError("bin %s holds %d bases: the device gene caller trains on the bin itself and needs %d (the pre-trained models of "
+                                 "`prodigal -p meta`, which CheckM uses below 100 kb, are not built); provide called genes (-g) or a prodigal binary"
+                                 % (binFile, total, MIN_SINGLE_GENOME))
+            best, dens = best_table(a, b, total)
+            (a if best == 11 else b).write(os.path.join(binDir, DefaultValues.PRODIGAL_AA), os.path.join(binDir, DefaultValues.PRODIGAL_GFF),
+                                            os.path.join(binDir, DefaultValues.PRODIGAL_NT) if bNucORFs else None)
+            out[binFile] = (best, dens)
+        batch, size = [], 0
+    for binFile, binDir in jobs:
+        contigs = read_contigs(binFile)
+        total = sum(len(s) for _c, s in contigs)
+        if batch and size + total > max_bases:
+            flush()
+        batch.append((binFile, binDir, contigs, total)); size += total
+    flush()
+    return out

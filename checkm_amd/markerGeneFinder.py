@@ -133,19 +133,19 @@ GENE_CALLER = None      # a ProdigalRunner-like class (outDir) -> .areORFsCalled
 
 
 def gene_caller():
-    """The class that calls genes for bins given as nucleotide FASTA: GENE_CALLER if set, else checkm_amd.prodigal.ProdigalRunner (the
-    mirror of checkm/prodigal.py:41-182 that runs the two translation tables side by side) when a `prodigal` binary is on PATH,
-    else CheckM's own ProdigalRunner if importable, else None."""
+    """The class that calls genes for bins given as nucleotide FASTA: GENE_CALLER if set; 'device' (the library's own gene finder,
+    checkm_amd/geneFinder.py: both translation tables of all bins in batched device calls) when CKM_GENE_CALLER=device or when no
+    `prodigal` binary is on PATH; else checkm_amd.prodigal.ProdigalRunner (the mirror of checkm/prodigal.py:41-182 that runs the two
+    translation tables of a bin side by side)."""
     if GENE_CALLER is not None:
         return GENE_CALLER
+    want = os.environ.get("CKM_GENE_CALLER", "")
+    if want == "device" or (want != "prodigal" and shutil.which("prodigal") is None):
+        return "device"
     if shutil.which("prodigal") is not None:
         from checkm_amd.prodigal import ProdigalRunner
         return ProdigalRunner
-    try:                                    # no prodigal here: CheckM's own runner reports that the way CheckM users know
-        from checkm.prodigal import ProdigalRunner
-        return ProdigalRunner
-    except Exception:
-        return None
+    return None
 
 
 class MarkerGeneFinder(object):
@@ -203,7 +203,16 @@ class MarkerGeneFinder(object):
                 self.logger.error("No called genes for bin %s and no gene caller available: run with -g/--genes, provide %s, or install prodigal "
                                   "next to CheckM (gene calling is outside the accelerated path)." % (missing[0][2], missing[0][3]))
                 sys.exit(1)
-            if runner is not None:
+            if runner == "device":
+                # every bin that still lacks its genes, both translation tables, in batched device calls (checkm/prodigal.py:72-133)
+                from checkm_amd import geneFinder
+                jobs = [(t[0], t[1]) for t in todo if not (os.path.exists(t[3]) and os.stat(t[3]).st_size != 0)]
+                try:
+                    geneFinder.call_bin_files(jobs, bNucORFs)
+                except ValueError as e:
+                    self.logger.error(str(e))
+                    sys.exit(1)
+            elif runner is not None:
                 def call(t):
                     binFile, binDir, _binId, _dst = t
                     prodigal = runner(binDir)

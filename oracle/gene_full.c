@@ -1144,3 +1144,37 @@ int pg_translate(const uint8_t *contig, int slen, const pg_gene *g, int tt, char
 
 int pg_sizeof_training(void) { return (int)sizeof(pg_training); }
 int pg_sizeof_gene(void) { return (int)sizeof(pg_gene); }
+
+/* ---- test hooks (tests/test_gene_full_oracle.py) ---- */
+void pg_test_rbs(const uint8_t *raw, int slen, int start, int *exact, int *mm) {
+  uint8_t *seq = malloc((size_t)slen + 16), *unk = malloc((size_t)slen + 16), *rseq = malloc((size_t)slen + 16), *runk = malloc((size_t)slen + 16);
+  make_seq(raw, slen, seq, unk, rseq, runk);
+  double rwt[28]; for (int i = 0; i < 28; ++i) rwt[i] = 0.0;
+  int r0 = 0, r1 = 0;
+  for (int j = start - 20; j <= start - 6; ++j) {
+    if (j < 0) continue;
+    const int c0 = shine_dalgarno(seq, unk, j, start, rwt, 0), c1 = shine_dalgarno(seq, unk, j, start, rwt, 1);
+    if (c0 > r0) r0 = c0;
+    if (c1 > r1) r1 = c1;
+  }
+  *exact = r0; *mm = r1;
+  free(seq); free(unk); free(rseq); free(runk);
+}
+/* nodes of one contig in working order and the first candidate predecessor dprog gives each of them */
+int pg_test_window(const uint8_t *raw, int slen, int tt, int32_t *ndx, int32_t *sv, int32_t *strand, int32_t *type, int32_t *mn, int cap) {
+  uint8_t *seq = malloc((size_t)slen + 16), *unk = malloc((size_t)slen + 16), *rseq = malloc((size_t)slen + 16), *runk = malloc((size_t)slen + 16);
+  make_seq(raw, slen, seq, unk, rseq, runk);
+  pg_seq s = {seq, rseq, unk, runk, slen};
+  pg_node *nod = malloc(sizeof(pg_node) * ((size_t)slen * 2 / 3 + 64) + 64);
+  const int nn = add_nodes(&s, nod, 0, NULL, 0, tt);
+  qsort(nod, (size_t)nn, sizeof(pg_node), cmp_nodes);
+  for (int i = 0; i < nn && i < cap; ++i) {
+    int min = i < MAX_NODE_DIST ? 0 : i - MAX_NODE_DIST;
+    if (nod[i].strand == -1 && nod[i].type != STOP && nod[min].ndx >= nod[i].stop_val) while (min >= 0 && nod[min].ndx != nod[i].stop_val) min--;
+    if (nod[i].strand == 1 && nod[i].type == STOP && nod[min].ndx >= nod[i].stop_val) while (min >= 0 && nod[min].ndx != nod[i].stop_val) min--;
+    min = min < MAX_NODE_DIST ? 0 : min - MAX_NODE_DIST;
+    ndx[i] = nod[i].ndx; sv[i] = nod[i].stop_val; strand[i] = nod[i].strand; type[i] = nod[i].type; mn[i] = min;
+  }
+  free(nod); free(seq); free(unk); free(rseq); free(runk);
+  return nn;
+}

@@ -18,7 +18,7 @@ def oracle_nodes(contigs, tt, closed):
     for c, s in enumerate(contigs):
         for ndx, typ, strand, sv, edge in genes.nodes(s, tt, closed, sort=False):
             out.append((c, ndx, 1 if strand == -1 else 0, typ, sv, edge))
-    return sorted(out, key=lambda n: (n[0], n[1], -n[2], n[3], n[4], n[5]))
+    return sorted(out, key=lambda n: (n[0], n[1], n[2], n[3], n[4], n[5]))        # (position, forward strand first: node.c compare_nodes)
 
 
 def device_nodes(ctx, contigs, tt, closed):
