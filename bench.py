@@ -6,7 +6,7 @@
                            bins.  A step lasts tens of seconds, so the number of timed steps is min(--steps, what fits --budget-seconds
                            judged from the warm pass): the line carries `steps` (run) and `steps_requested`.  At N = 1 the same line
                            carries `cfg2` (a short run of the configuration below), `cpu_baseline` (the CPU oracle on sampled bins with
-                           their lineage's model subsets) and `emulated_rank0_of_8` (see --emulate-rank).
+                           their lineage's model subsets) and `emulated_ranks_of_8` (see --emulate-rank).
   --config cfg2            configs[1] of BASELINE.json: cpr_43-shaped 43-profile DB against 100 synthetic 2 Mb bins (~2k ORFs
                            each) PER GPU.  One step = one pass of the hot path (scan + reduce + the one gather of QA rows) over the
                            rank's bins, inputs resident in HBM.  `--scaling strong --bins-total N` shards N bins over the ranks.
@@ -42,6 +42,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PROFILE_TAG = "r03"            # profiles/<tag>*_ssv_traffic.json / <tag>*_cfg3_ssv_traffic.json hold the PMC-pass figures of the SSV launches
+NOMINAL_CYCLES_PER_INST = 2.0     # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD (the architectural figure; the packed 16-bit ops of the SSV row measure 4.2-4.6)
 MEASURED_CYCLES_PER_INST = 4.25   # cycles per wave64 instruction per SIMD of the SSV row body (2 x v_pk_add_f16 clamp + v_pk_maximum3_f16 per two rows) run alone: tools/ubench/valu_rates.hip, profiles/r03_valu_rates.txt (6.35 cycles per register-row = 3 instructions per 2 rows)
 
 
@@ -51,7 +52,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg5"], default="cfg3")
-    ap.add_argument("--budget-seconds", type=float, default=float(os.environ.get("CKM_BENCH_BUDGET_S", "75")),
+    ap.add_argument("--budget-seconds", type=float, default=float(os.environ.get("CKM_BENCH_BUDGET_S", "300")),
                     help="cfg3: wall-clock budget of the timed region; the steps actually run are min(--steps, budget / estimated step)")
     ap.add_argument("--emulate-rank", default=None, help="cfg3: R/W -- run as rank R of W on this one GPU (no collectives)")
     ap.add_argument("--no-cfg2", action="store_true", help="cfg3: skip the nested cfg2 measurement")
@@ -117,7 +118,7 @@ def cpu_baseline(hmm_path, bins, budget_s, threads):
         ro.reduce_bin(t, omodels, "", [sorted(omodels)])
     dt_red = time.perf_counter() - t0
     out = {"value": residues * len(models) / dt, "unit": "residue*HMM/s", "cores": threads, "kind": "port",
-           "sample": "restated CPU oracle (NOT HMMER; HMMER is absent from the reference and this image), %d threads x (all %d models x first %d ORFs of "
+           "sample": "restated CPU oracle: a SCALAR port (no SIMD), NOT HMMER (absent from the reference and this image); %d threads x (all %d models x first %d ORFs of "
                      "one bin each), %d residues, %d rows, %.1f s" % (threads, len(models), nseq, residues, nrows, dt),
            "reduce": {"kind": "port", "what": "oracle/reduce_oracle.py (Python restatement pinned against the reference's classes; 1 thread)",
                       "bins": len(texts), "rows": nrows, "seconds": dt_red, "bins_per_s": len(texts) / max(dt_red, 1e-9)}}
@@ -186,6 +187,7 @@ def ssv_roofline(st_like, ssv_ms_per_step, bins, orfs, extra_note="", clock_hz=2
         cyc = ssv_s * clock_hz / (pm["valu_insts"] / 1024.0)
         valu = {"bound": "valu-issue", "clock_hz": clock_hz, "wave_insts_per_step": pm["valu_insts"], "source": src + " (rocprofv3 --pmc SQ_INSTS_VALU pass, recorded)",
                 "cycles_per_inst_per_simd": cyc, "measured_rate_of_this_opcode_mix": MEASURED_CYCLES_PER_INST, "frac_of_measured_rate": min(1.0, MEASURED_CYCLES_PER_INST / cyc),
+                "nominal_cycles_per_inst": NOMINAL_CYCLES_PER_INST, "frac_of_nominal_issue": min(1.0, NOMINAL_CYCLES_PER_INST / cyc),
                 "note": "cycles per wave64 VALU instruction per SIMD over the SSV launches of this run (HIP events; they share the SIMDs with the chain kernels), "
                         "against the rate the row body of the kernel issues at when it runs alone (tools/ubench/valu_rates.hip, profiles/%s_valu_rates.txt) -- a "
                         "measured rate of this opcode mix, not an architectural peak (MI355X_MICROARCH.md quotes 2 cycles per wave64 op; f32 add/mul/fma measure "
@@ -586,7 +588,7 @@ def cpu_baseline_cfg3(w, binIds, files, lin, budget_s, threads):
     bins_equiv = sum(float(nseq) / len(wk[1]) for wk in work)              # fraction of a bin each thread got through
     out = {"value": bins_equiv / dt * 3600.0, "unit": "bins/hour", "cores": threads, "kind": "port",
            "residue_hmm_per_s": residue_hmm / dt,
-           "sample": "restated CPU oracle (NOT HMMER; HMMER is absent from the reference and this image), %d threads x (one sampled cfg3 bin each: the "
+           "sample": "restated CPU oracle: a SCALAR port (no SIMD; ~0.4 GCUPS per thread in its byte filter, where hmmsearch's SSE MSV filter runs one to two orders of magnitude faster) -- NOT HMMER, which is absent from the reference and this image; the GPU/CPU ratio of this line is therefore not a result, the roofline figures are. %d threads x (one sampled cfg3 bin each: the "
                      "first %d of its %d-%d ORFs against its lineage's %d-%d models, analyze pass only), %d rows, %.1f s; bins/hour = the fraction of a "
                      "bin each thread finished, summed, per hour on these %d cores"
                      % (threads, nseq, min(len(wk[1]) for wk in work), max(len(wk[1]) for wk in work), min(len(wk[0]) for wk in work),
@@ -847,6 +849,8 @@ def bench_cfg3(args, env):
         prof.enable()
     for k in range(steps):
         parts, tot = lineage_pass(w, binIds, files, lin, os.path.join(workdir, "cfg3_out"), rank)
+    from checkm_amd import markerGeneFinder as _mgf
+    _mgf._join_releasers()               # the background release of the last step's scans belongs to the timed region (every earlier one is waited for by the next find())
     if prof is not None:
         prof.disable()
     env.sync()
@@ -877,6 +881,7 @@ def bench_cfg3(args, env):
         cyc = (tot.get("ms_ssv", 0.0) / 1e3) * clock_hz / (cnt["valu_insts"] / 1024.0)
         valu = {"bound": "valu-issue", "clock_hz": clock_hz, "wave_insts_per_step": cnt["valu_insts"], "source": cnt["source"] + " (--pmc SQ_INSTS_VALU pass of the sample, scaled)",
                 "cycles_per_inst_per_simd": cyc, "measured_rate_of_this_opcode_mix": MEASURED_CYCLES_PER_INST, "frac_of_measured_rate": min(1.0, MEASURED_CYCLES_PER_INST / cyc),
+                "nominal_cycles_per_inst": NOMINAL_CYCLES_PER_INST, "frac_of_nominal_issue": min(1.0, NOMINAL_CYCLES_PER_INST / cyc),
                 "note": "time = HIP events over the SSV launches of every search of this run, summed (one SSV phase at a time per device since the contexts share a baton); "
                         "the launches share the SIMDs with the chain kernels of the groups ahead of them and of the other context's search -- step_utilisation prices "
                         "the whole step instead; the rate is what "
@@ -886,6 +891,7 @@ def bench_cfg3(args, env):
         cyc = per_step * clock_hz / (cnt["all_valu_insts"] / 1024.0)
         step_util = {"clock_hz": clock_hz, "clock_note": "mean shader clock sampled over the timed region (device_state_timed_region); 2.4 GHz when the hwmon files are absent",
                      "valu_wave_insts_per_step": cnt["all_valu_insts"], "cycles_per_inst_per_simd": cyc, "valu_frac_of_measured_rate": min(1.0, MEASURED_CYCLES_PER_INST / cyc),
+                     "valu_frac_of_nominal_issue": min(1.0, NOMINAL_CYCLES_PER_INST / cyc),
                      "hbm_bytes_per_step": cnt["all_hbm_bytes"], "hbm_frac": cnt["all_hbm_bytes"] / per_step / 1e9 / HBM_PEAK_GBS,
                      "source": cnt["source"] + " (all kernels of the 48-bin sample's step, scaled by algorithmic bytes) over this run's ms_per_step"}
     out = {"metric": "bins/hour (lineage_wf-equiv marker path: tree pass + analyze pass + qa, from genes.faa files) + residues*HMMs/s",
@@ -919,20 +925,31 @@ def bench_cfg3(args, env):
         out["verify"] = None
     if world == 1:
         if not args.no_emulation:
-            # rank 0 of 8 on this GPU: what configs[3] costs a rank (its shard on the device + every piece of all-bins host work)
-            os.environ["CKM_EMULATE_RANK"] = "0/8"
+            # EVERY rank of 8 on this GPU, one after the other: what configs[3] costs each rank (its LPT shard on the device + the host work a
+            # rank does), so that the projection is the SLOWEST rank's wall, not rank 0's
+            from checkm_amd import markerGeneFinder as mgf
+            walls, parts8, ssv8, searches8 = [], [], [], []
             try:
-                lineage_pass(w, binIds, files, lin, os.path.join(workdir, "cfg3_emu"), rank)
-                t0 = time.perf_counter()
-                eparts, etot = lineage_pass(w, binIds, files, lin, os.path.join(workdir, "cfg3_emu"), rank)
-                env.sync()
-                ewall = time.perf_counter() - t0
-                out["emulated_rank0_of_8"] = {"wall_s": ewall, "projected_bins_per_hour_8gpu": nbins / ewall * 3600.0, "parts_s": eparts,
-                                              "ssv_kernels_s": etot.get("ms_ssv", 0.0) / 1e3, "searches": int(etot.get("searches", 0)),
-                                              "note": "this GPU as rank 0 of 8: LPT shard of the %d bins (dist.shard_bins), all-bins host work included, no collective and "
-                                                      "no contention for the shared output directory -- a projection, not a measurement of configs[3]" % nbins}
+                os.environ["CKM_EMULATE_RANK"] = "0/8"
+                lineage_pass(w, binIds, files, lin, os.path.join(workdir, "cfg3_emu"), rank)       # (warm: tables and workspace at a rank's size)
+                for r in range(8):
+                    os.environ["CKM_EMULATE_RANK"] = "%d/8" % r
+                    mgf._join_releasers()
+                    env.sync()
+                    t0 = time.perf_counter()
+                    eparts, etot = lineage_pass(w, binIds, files, lin, os.path.join(workdir, "cfg3_emu"), rank)
+                    mgf._join_releasers()
+                    env.sync()
+                    walls.append(time.perf_counter() - t0); parts8.append(eparts); ssv8.append(etot.get("ms_ssv", 0.0) / 1e3); searches8.append(int(etot.get("searches", 0)))
             finally:
                 del os.environ["CKM_EMULATE_RANK"]
+            mx, mn, mean = max(walls), min(walls), sum(walls) / len(walls)
+            out["emulated_ranks_of_8"] = {"per_rank_wall_s": walls, "max_wall_s": mx, "min_wall_s": mn, "mean_wall_s": mean, "imbalance_max_over_mean": mx / mean,
+                                          "per_rank_ssv_kernels_s": ssv8, "per_rank_searches": searches8, "slowest_rank": int(walls.index(mx)), "parts_s_slowest_rank": parts8[walls.index(mx)],
+                                          "projected_bins_per_hour_8gpu": nbins / mx * 3600.0, "projected_speedup_over_1gpu": per_step / mx,
+                                          "note": "this ONE GPU as rank r of 8 for r = 0..7 in turn: LPT shard of the %d bins (dist.shard_bins: file size x models), the host work a rank "
+                                                  "does, no collective (the one all_gather of QA rows) and no contention for the shared output directory -- a projection from the "
+                                                  "slowest emulated rank, not a measurement of configs[3]; no N > 1 run has ever happened on hardware" % nbins}
         out["gene_front_end"] = gene_front_end()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_cfg3(w, binIds, files, lin, args.cpu_baseline_seconds, args.cpu_baseline_threads)

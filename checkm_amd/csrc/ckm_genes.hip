@@ -1032,7 +1032,9 @@ extern "C" int ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *co
             const uint32_t s = jobs0[j].first; const size_t f = jobs0[j].second;
             std::vector<GNode> &nod = sn[s].nodes;
             const uint32_t b = TF.bin[f < TF.n() ? f : 0];
-            for (size_t i = 0; i < nod.size(); ++i) { nod[i].cscore = TF.cscore[f + i]; nod[i].rbs[0] = TF.rbs0[f + i]; nod[i].rbs[1] = TF.rbs1[f + i]; }
+            // (score_nodes looks for Shine-Dalgarno sites only in organisms that use them: elsewhere every node keeps bin 0)
+            const bool sdm = tr[b].uses_sd == 1;
+            for (size_t i = 0; i < nod.size(); ++i) { nod[i].cscore = TF.cscore[f + i]; nod[i].rbs[0] = sdm ? TF.rbs0[f + i] : 0; nod[i].rbs[1] = sdm ? TF.rbs1[f + i] : 0; }
             score_nodes_rest(gseq(s), nod, tr[b], closed);
             record_overlapping_starts(nod, tr[b], 1);
           }

@@ -238,6 +238,7 @@ class MarkerGeneFinder(object):
         from concurrent.futures import ThreadPoolExecutor
         from checkm_amd import dist as cdist
         from checkm_amd import workers
+        _join_releasers()                   # (a background release of an earlier scan is over before this one's searches start)
         devs = workers.devices()
         if devs is not None:
             return self._find_with_workers(devs, binFiles, outDir, tableOut, hmmerOut, markerFile, bKeepAlignment, bNucORFs, bCalledGenes)

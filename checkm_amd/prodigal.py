@@ -10,7 +10,8 @@ case, so no further run can be skipped without changing results.
 ProdigalGeneFeatureParser (checkm/prodigal.py:208-274) is restated with interval arithmetic instead of one numpy mask per
 contig; pinned against the reference's class by tools/gen_prodigal_golden.py -> tests/golden/prodigal_cases.json.
 
-The gene finder itself is still the external `prodigal` binary: a GPU ORF caller is DESIGN.md section 10, not this file.
+The gene finder itself is the external `prodigal` binary when one is on PATH, and the library's own (checkm_amd/geneFinder.py: training,
+scoring and the dynamic program on the device) when none is or when CKM_GENE_CALLER=device.
 """
 import logging
 import os
@@ -56,7 +57,12 @@ class ProdigalRunner(object):
 
     def __init__(self, outDir):
         self.logger = logging.getLogger('timestamp')
-        self.checkForProdigal()
+        # the gene finder on the device (checkm_amd/geneFinder.py) when asked for (CKM_GENE_CALLER=device) or when no prodigal binary exists
+        want = os.environ.get("CKM_GENE_CALLER", "")
+        self.use_device = want == "device" or (want != "prodigal" and shutil.which("prodigal") is None)
+        if not self.use_device:
+            self.checkForProdigal()
+        self.outDir = outDir
         self.aaGeneFile = os.path.join(outDir, DefaultValues.PRODIGAL_AA)
         self.ntGeneFile = os.path.join(outDir, DefaultValues.PRODIGAL_NT)
         self.gffFile = os.path.join(outDir, DefaultValues.PRODIGAL_GFF)
@@ -90,6 +96,15 @@ class ProdigalRunner(object):
         return float(coding) / totalBases if totalBases != 0 else 0
 
     def run(self, query, bNucORFs=True):
+        if self.use_device:
+            from checkm_amd import geneFinder
+            try:
+                best, density = geneFinder.call_bin_files([(query, self.outDir)], bNucORFs)[query]
+            except ValueError as e:
+                self.logger.error(str(e))
+                sys.exit(1)
+            self.tableCodingDensity = density
+            return best
         prodigal_input = query
         seqs, totalBases = _read_fasta_lengths(prodigal_input)
         tmp_dir = None

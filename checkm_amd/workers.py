@@ -34,6 +34,11 @@ def devices():
         devs = [int(x) for x in spec.split(",") if x.strip() != ""]
     if len(devs) < 2:
         return None
+    # never from a process that is itself being spawned: a caller whose script has no `if __name__ == "__main__"` guard re-runs its top
+    # level in every 'spawn' child, and a find() reached that way must scan in place instead of starting workers of its own
+    cur = mp.current_process()
+    if cur.name != "MainProcess" or getattr(cur, "_inheriting", False) or sys.modules.get("__mp_main__") is not None:
+        return None
     main_file = getattr(sys.modules.get("__main__"), "__file__", None)
     if main_file is not None and not os.path.exists(main_file):
         return None                           # 'spawn' re-imports __main__ by path: a script read from stdin cannot have workers
@@ -61,23 +66,53 @@ class Pool(object):
         backend = os.environ.get("CKM_DIST_BACKEND") or ("gloo" if len(set(devs)) < len(devs) else "nccl")
         defaults = {k: getattr(DefaultValues, k) for k in dir(DefaultValues) if k.isupper() and isinstance(getattr(DefaultValues, k), (str, int, float))}
         self.conns, self.procs = [], []
-        for r, d in enumerate(self.devs):
-            pc, cc = ctx.Pipe()
-            p = ctx.Process(target=_worker_main, args=(r, len(self.devs), d, cc, port, backend, defaults, list(sys.path)), daemon=True)
-            p.start()
-            cc.close()
-            self.conns.append(pc); self.procs.append(p)
-        for c in self.conns:                     # every worker reports in (library loaded, device usable) before any work is sent
-            self._reply(c)
-
-    def _reply(self, conn):
+        # CKM_WORKER travels in the environment the children are spawned with (they re-import __main__ BEFORE _worker_main runs)
+        had = os.environ.get("CKM_WORKER")
+        os.environ["CKM_WORKER"] = "1"
         try:
-            kind, payload = conn.recv()
-        except EOFError:
-            raise WorkerError("a GPU worker process died")
-        if kind != "ok":
-            raise WorkerError(payload)
-        return payload
+            for r, d in enumerate(self.devs):
+                pc, cc = ctx.Pipe()
+                p = ctx.Process(target=_worker_main, args=(r, len(self.devs), d, cc, port, backend, defaults, list(sys.path)), daemon=True)
+                p.start()
+                cc.close()
+                self.conns.append(pc); self.procs.append(p)
+        finally:
+            if had is None:
+                os.environ.pop("CKM_WORKER", None)
+            else:
+                os.environ["CKM_WORKER"] = had
+        self._collect()                          # every worker reports in (library loaded, device usable) before any work is sent
+
+    def _collect(self):
+        """One reply from every worker, in whatever order they arrive.  A worker that reports an error or dies ends the WHOLE pool at once:
+        its peers may be blocked in a collective that will never complete (they are terminated), and the parent must not wait on them."""
+        import time
+        out, pending = [None] * len(self.conns), set(range(len(self.conns)))
+        limit = float(os.environ.get("CKM_WORKER_TIMEOUT_S", "3600"))
+        t0 = time.monotonic()
+        while pending:
+            progressed = False
+            for r in sorted(pending):
+                conn, proc = self.conns[r], self.procs[r]
+                try:
+                    if conn.poll(0):
+                        kind, payload = conn.recv()
+                        if kind != "ok":
+                            self.abort()
+                            raise WorkerError(payload)
+                        out[r] = payload; pending.discard(r); progressed = True
+                    elif not proc.is_alive():
+                        self.abort()
+                        raise WorkerError("GPU worker %d (device %d) died (exit code %s)" % (r, self.devs[r], proc.exitcode))
+                except (EOFError, OSError):
+                    self.abort()
+                    raise WorkerError("GPU worker %d (device %d) died" % (r, self.devs[r]))
+            if pending and not progressed:
+                if time.monotonic() - t0 > limit:
+                    self.abort()
+                    raise WorkerError("GPU workers did not answer within %.0f s (CKM_WORKER_TIMEOUT_S)" % limit)
+                time.sleep(0.002)
+        return out
 
     def call(self, cmd, args=None, per_worker=None):
         """Send `cmd` to every worker (args: dict for all; per_worker: list of dicts merged into it), wait for all, return the replies."""
@@ -86,16 +121,24 @@ class Pool(object):
             if per_worker is not None:
                 a.update(per_worker[r])
             c.send((cmd, a))
-        out, err = [], None
+        return self._collect()
+
+    def abort(self):
+        """Terminate every worker (one failed: the others may sit in a collective) and forget the pool."""
+        global _POOL
+        for p in self.procs:
+            if p.is_alive():
+                p.terminate()
+        for p in self.procs:
+            p.join(timeout=10)
         for c in self.conns:
             try:
-                out.append(self._reply(c))
-            except WorkerError as e:
-                err = err or e
-                out.append(None)
-        if err is not None:
-            raise err
-        return out
+                c.close()
+            except Exception:
+                pass
+        self.conns, self.procs = [], []
+        if _POOL is self:
+            _POOL = None
 
     def close(self):
         for c in self.conns:

@@ -69,7 +69,9 @@ def test_dropin_rebinds_the_reference_classes(tmp_path):
             "assert g.HmmModel.__module__ == 'checkm.hmmerModelParser'\n"
             "assert all(hasattr(e.HmmerAligner, n) for n in ('makeAlignmentTopHit', 'makeAlignmentToPhyloMarkers', 'makeAlignmentsOfMultipleHits'))\n"
             "import checkm_amd.markerGeneFinder as h\n"
-            "assert h.gene_caller().__name__ == 'ProdigalRunner' and h.gene_caller().__module__ in ('checkm.prodigal', 'checkm_amd.prodigal')    # nucleotide bins\n"
+            "import shutil\n"
+            "gc = h.gene_caller()            # nucleotide bins: the device gene finder when no prodigal binary exists, else the mirror of ProdigalRunner\n"
+            "assert gc == 'device' if shutil.which('prodigal') is None else gc.__module__ == 'checkm_amd.prodigal'\n"
             "import checkm.prodigal as pr\n"
             "assert pr.ProdigalRunner.__module__ == 'checkm_amd.prodigal'\n"
             "print('ok')\n")
