@@ -664,7 +664,11 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
     for (auto &mw : mws) mp_sum += (double)mw.npairs * (double)(p->prof[mw.model].fbQ * NL);
     // bytes per (pair x padded model length): ~1e-4 envelopes per pair x 5 arrays x ~250 rows x 4 B to begin with (marker genes are a few
     // hundred of a bin's thousands of ORFs); a search that outgrows it falls back once and the factor grows for the next calls
-    const uint64_t est = (uint64_t)(mp_sum * cp.ws_per_mp + (double)total_pairs * 24.0) + ((uint64_t)256 << 20);
+    // two estimates, by the kind of search: a few models against every sequence (the tree pass: 43 phylogenetic markers, one planted in
+    // every bin -- dense hits) asks for ten times the bytes per position that a lineage's hundreds of models do; one factor learned on the
+    // first kind sized the second kind's workspace at the budget cap (round 3: 156 GB allocated for 76 GB used)
+    float &ws_factor = mws.size() <= 64 ? cp.ws_per_mp_dense : cp.ws_per_mp;
+    const uint64_t est = (uint64_t)(mp_sum * ws_factor + (double)total_pairs * 24.0) + ((uint64_t)256 << 20);
     const size_t want = (size_t)std::min<uint64_t>(std::max<uint64_t>(est, (uint64_t)1 << 30), (uint64_t)ctx->ws_budget);
     if (ctx->ws.cap < want) ctx->ws.ensure(want);
   }
@@ -903,7 +907,12 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   if (status & CS_RWORK) cp.hens *= 2;
   // zone 2 ran out (regions were deferred to the host): size the workspace from what this search asked for, for the next calls
   st.ws_cap_bytes = ctx->ws.cap; st.ws_used_bytes = (std::min<uint64_t>(h_tops[0], cd0.ws_cap) + h_tops[2]) * 4;
-  if (h_tops[2] > cd0.ws2_cap) cp.ws_per_mp = std::max(cp.ws_per_mp * 1.5f, (float)(1.25 * (double)(h_tops[2] + cd0.ws_cap) * 4.0 / std::max(mp_sum, 1.0)));
+  // the bump allocator counts every request, granted or not: after an overflow the search's whole demand is known, and the next one of its
+  // kind gets that (+15 %) instead of a blind x1.5
+  if (h_tops[2] > cd0.ws2_cap) {
+    float &f = mws.size() <= 64 ? cp.ws_per_mp_dense : cp.ws_per_mp;
+    f = std::max(f, (float)(1.15 * (double)(h_tops[2] + cd0.ws_cap) * 4.0 / std::max(mp_sum, 1.0)));
+  }
   if (!fits) {
     if (getenv("CKM_TRACE")) fprintf(stderr, "ckm-trace w%d device cascade did not fit (status 0x%x): host-driven cascade for this lane\n", ctx->id, status);
     return 1;

@@ -37,7 +37,7 @@ def devices():
     # never from a process that is itself being spawned: a caller whose script has no `if __name__ == "__main__"` guard re-runs its top
     # level in every 'spawn' child, and a find() reached that way must scan in place instead of starting workers of its own
     cur = mp.current_process()
-    if cur.name != "MainProcess" or getattr(cur, "_inheriting", False) or sys.modules.get("__mp_main__") is not None:
+    if cur.name != "MainProcess" or getattr(cur, "_inheriting", False):
         return None
     main_file = getattr(sys.modules.get("__main__"), "__file__", None)
     if main_file is not None and not os.path.exists(main_file):

@@ -53,3 +53,34 @@ def test_find_with_two_workers_equals_the_single_process_run(gpu_ctx, tmp_path):
     for name in ("bin_stats_ext.tsv", "marker_gene_stats.tsv"):
         a = open(os.path.join(work, "out_one", "storage", name)).read()
         assert a == open(os.path.join(work, "out_two", "storage", name)).read() and len(a) > 100
+
+
+def test_find_with_eight_workers_equals_the_single_process_run(gpu_ctx, tmp_path):
+    """The 8-GPU shape on the one device of the test box: CKM_GPUS=0,0,0,0,0,0,0,0 -- eight worker processes, LPT shards, the tables of the
+    bins written by their owners into ONE output directory, the QA rows exchanged by one all_gather (gloo here) -- through the unmodified
+    find -> analyseResults -> printSummary -> cacheResults, byte-equal to the run without workers."""
+    profs = synth.small_profiles(11, 12, 40, 300)
+    hmm = common.hmm_file("s11", profs)
+    work = str(tmp_path)
+    os.makedirs(os.path.join(work, "data", "pfam"))
+    with open(os.path.join(work, "data", "pfam", "Pfam-A.hmm.dat"), "w") as f:
+        for i, p in enumerate(p for p in profs if p.acc.startswith("PF")):
+            f.write("# STOCKHOLM 1.0\n#=GF ID   fam%d\n#=GF AC   %s\n%s//\n" % (i, p.acc, "#=GF CL   CL0001\n" if i < 2 else ""))
+    nb = 19
+    for b in range(nb):
+        synth.write_fasta(os.path.join(work, "bin_%02d.faa" % b), synth.make_bin(profs, 900 + b, n_orfs=40 + 17 * b, dup_frac=0.5))
+    _run(work, hmm, "one", "", fmts="1,2")
+    _run(work, hmm, "eight", "0,0,0,0,0,0,0,0", fmts="1,2")
+    mode = open(os.path.join(work, "mode_eight.txt")).read().split("\n")
+    assert mode[0] == "workers 8"
+    owners = dict(kv.split(":") for kv in mode[1].split()[1:])
+    assert len(owners) == nb and set(owners.values()) == {str(r) for r in range(8)}        # every worker owns bins; every bin has one owner
+    for fmt in (1, 2):
+        one = open(os.path.join(work, "table_one_fmt%d.tsv" % fmt)).read()
+        assert one == open(os.path.join(work, "table_eight_fmt%d.tsv" % fmt)).read() and len(one.strip().split("\n")) == nb + 1
+    for b in range(nb):
+        a = open(os.path.join(work, "out_one", "bins", "bin_%02d" % b, "hmmer.analyze.txt")).read()
+        assert a == open(os.path.join(work, "out_eight", "bins", "bin_%02d" % b, "hmmer.analyze.txt")).read()
+    for name in ("bin_stats_ext.tsv", "marker_gene_stats.tsv"):
+        a = open(os.path.join(work, "out_one", "storage", name)).read()
+        assert a == open(os.path.join(work, "out_eight", "storage", name)).read() and len(a) > 100
