@@ -804,7 +804,63 @@ def gene_front_end():
                          "note": "1 B read + 1 B written per base; 10 launches over 1 Gbase of device-generated nucleotides, HIP events on the launch stream"},
             "one_genome": {"bases": st11["bases"], "contigs": len(genome), "nodes_table11": int(len(n11["ndx"])), "nodes_table4": int(len(n4["ndx"])),
                            "flags_ms": st11["ms_flags"], "chains_ms": st11["ms_chain"], "wall_s_both_tables_incl_copies_and_sort": wall},
-            "note": "front end only (start / stop nodes of six frames); training, scoring and the node DP of the gene finder are not built (DESIGN.md section 10)"}
+            "note": "the front end alone (start / stop nodes of six frames): the streaming kernel of the gene finder, priced against the HBM roofline; the whole gene finder is the gene_calling leg"}
+
+
+def gene_calling(workdir, nbins=48, cpu_bins=4):
+    """SURVEY 8f N1, the body: bins/hour of the device gene finder from NUCLEOTIDE FASTA files to genes.faa / genes.gff -- both
+    translation tables of every bin (checkm/prodigal.py:72-133: two prodigal runs per bin and the coding-density rule), training, node
+    scores, both dynamic programs, translations (checkm_amd/geneFinder.py -> ckm_genes_call), on synthetic 2 Mb bins of 20 contigs; the
+    kernel times of the last call; and the same work by the CPU oracle (oracle/gene_full.c, one thread per bin) on a few of the bins."""
+    from concurrent.futures import ThreadPoolExecutor
+    from checkm_amd import geneFinder, synth_genome as sg
+    d = os.path.join(workdir, "gene_bins")
+    os.makedirs(d, exist_ok=True)
+    jobs, bases = [], 0
+    t0 = time.perf_counter()
+    for b in range(nbins):
+        f = os.path.join(d, "gbin_%03d.fna" % b)
+        g = sg.make_genome(5000 + b, n_contigs=20, contig_len=(80000, 120000), gc=0.35 + 0.3 * (b % 11) / 10.0, sd_frac=0.6 if b % 3 else 0.0, table=4 if b % 16 == 7 else 11)
+        bases += sum(len(s) for _c, s in g)
+        if not os.path.exists(f):
+            sg.write_fasta(f, g)
+        od = os.path.join(d, "out_%03d" % b)
+        os.makedirs(od, exist_ok=True)
+        jobs.append((f, od))
+    t_setup = time.perf_counter() - t0
+    geneFinder.call_bin_files(jobs[:4])                                   # warm: kernels loaded, buffers at size
+    t0 = time.perf_counter()
+    res = geneFinder.call_bin_files(jobs)
+    dt = time.perf_counter() - t0
+    st = dict(geneFinder.call_bins.last_stats)
+    ngenes = 0
+    for f, od in jobs:
+        with open(os.path.join(od, "genes.faa")) as fh:
+            ngenes += sum(1 for ln in fh if ln.startswith(">"))
+    out = {"value": nbins / dt * 3600.0, "unit": "bins/hour", "bins": nbins, "bases": bases, "genes_written": ngenes, "seconds": dt,
+           "bases_per_s": bases * 2 / dt, "tables_per_bin": 2, "table_4_chosen": sum(1 for v in res.values() if v[0] == 4),
+           "last_call_kernel_ms": {k: st[k] for k in ("ms_dp_train", "ms_score", "ms_dp_find")}, "last_call_wall_ms": {"to_nodes": st["ms_nodes"], "total": st["ms_total"]},
+           "setup_s": t_setup,
+           "note": "from nucleotide FASTA files to genes.faa / genes.gff, tables 11 and 4 for every bin in two batched device calls per <= 1 Gbase of bins; the dynamic "
+                   "programs are latency-bound (one wavefront per sequence, nodes in order, 64 predecessor candidates per step), the codon-flag kernel is the "
+                   "HBM-bound one (gene_front_end.roofline); single-genome mode only (-p meta is not built)"}
+    try:
+        from oracle import genes as og
+        sample = [geneFinder.read_contigs(jobs[b][0]) for b in range(min(cpu_bins, nbins))]
+
+        def one(contigs):
+            for tt in (11, 4):
+                og.find_genes([s for _c, s in contigs], tt)
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=len(sample)) as ex:
+            list(ex.map(one, sample))
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": len(sample) / dtc * 3600.0, "unit": "bins/hour", "cores": len(sample), "kind": "port",
+                               "sample": "oracle/gene_full.c (a restatement of Prodigal 2.6.3's single-genome mode, NOT prodigal itself: none exists here), %d bins x both "
+                                         "tables, one thread per bin, %.1f s" % (len(sample), dtc)}
+    except Exception as e:            # (the oracle is the checker; the leg stands without it)
+        out["cpu_baseline"] = {"error": str(e)}
+    return out
 
 
 def bench_cfg3(args, env):
@@ -951,6 +1007,7 @@ def bench_cfg3(args, env):
                                                   "does, no collective (the one all_gather of QA rows) and no contention for the shared output directory -- a projection from the "
                                                   "slowest emulated rank, not a measurement of configs[3]; no N > 1 run has ever happened on hardware" % nbins}
         out["gene_front_end"] = gene_front_end()
+        out["gene_calling"] = gene_calling(workdir)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_cfg3(w, binIds, files, lin, args.cpu_baseline_seconds, args.cpu_baseline_threads)
         else:

@@ -75,7 +75,7 @@ def _omodels(models):
 
 
 def verify(out_dir, table, hmm_path, bin_ids, files, models_by_bin, k_bins=3, n_models=40, seed=1, threads=None,
-           marker_sets=None, qa_rows=None, pfam_text=None):
+           marker_sets=None, qa_rows=None, pfam_text=None, with_rows=16):
     """out_dir/bins/<binId>/<table> against the oracles for `k_bins` sampled bins.
     models_by_bin: what find() returned ({binId: {acc: HmmModel}}).  marker_sets ({binId: BinMarkerSets}) + qa_rows ({binId: tab-separated
     row of printSummary format 1}) + pfam_text switch the reduce half on."""
@@ -96,6 +96,12 @@ def verify(out_dir, table, hmm_path, bin_ids, files, models_by_bin, k_bins=3, n_
         accs = [a for a in models_by_bin[binId] if a in index]
         lengths = {a: hs.M(index[a]) for a in accs}
         sample, _ncls = sample_models(lengths, n_models, rng)
+        # ... and up to `with_rows` models that HAVE rows in the written table (a random model of a large database mostly has none, and
+        # "no rows on either side" is the weakest kind of agreement)
+        name_to_acc = {hs.name(index[a]): a for a in accs}
+        hit_accs = sorted({name_to_acc[ln.split()[3]] for ln in table_lines(os.path.join(out_dir, "bins", binId, table)) if ln.split()[3] in name_to_acc} - set(sample))
+        rng.shuffle(hit_accs)
+        sample = sample + hit_accs[:with_rows]
         sample = sorted(sample, key=lambda a: index[a])          # rows come in HMM-file order (hmmsearch: one query after the other)
         classes_seen |= {launch_class(lengths[a]) for a in sample}
         recs = read_fasta(files[b])
