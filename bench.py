@@ -41,7 +41,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # before torch initialises 
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-PROFILE_TAG = "r03"            # profiles/<tag>*_ssv_traffic.json / <tag>*_cfg3_ssv_traffic.json hold the PMC-pass figures of the SSV launches
+PROFILE_TAG = "r0"             # profiles/<tag>*_ssv_traffic.json / <tag>*_cfg3_ssv_traffic.json hold the PMC-pass figures of the SSV launches
 NOMINAL_CYCLES_PER_INST = 2.0     # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD (the architectural figure; the packed 16-bit ops of the SSV row measure 4.2-4.6)
 MEASURED_CYCLES_PER_INST = 4.25   # cycles per wave64 instruction per SIMD of the SSV row body (2 x v_pk_add_f16 clamp + v_pk_maximum3_f16 per two rows) run alone: tools/ubench/valu_rates.hip, profiles/r03_valu_rates.txt (6.35 cycles per register-row = 3 instructions per 2 rows)
 
@@ -162,7 +162,7 @@ def hmmer_leg(hmm_path, bins, threads, workdir):
 def ssv_roofline(st_like, ssv_ms_per_step, bins, orfs, extra_note="", clock_hz=2.4e9):
     """roofline of the dominant kernel ssv_kernel<Q>: algorithmic bytes = sum over (model, sequence) pairs of (L + 12) over the
     kernel's time measured with HIP events on the library's streams.  HBM traffic and the VALU instruction count come from separate
-    rocprofv3 --pmc passes recorded in profiles/ (tools/collect_profiles.sh); they are quoted -- with their source -- only for the
+    rocprofv3 --pmc passes recorded in profiles/ (tools/gpu_collect.sh); they are quoted -- with their source -- only for the
     workload that was profiled."""
     alg_bytes = float(st_like["residue_hmm"]) + 12.0 * float(st_like["pairs_ssv"])
     ssv_s = max(ssv_ms_per_step, 1e-9) / 1e3
@@ -189,9 +189,9 @@ def ssv_roofline(st_like, ssv_ms_per_step, bins, orfs, extra_note="", clock_hz=2
                 "cycles_per_inst_per_simd": cyc, "measured_rate_of_this_opcode_mix": MEASURED_CYCLES_PER_INST, "frac_of_measured_rate": min(1.0, MEASURED_CYCLES_PER_INST / cyc),
                 "nominal_cycles_per_inst": NOMINAL_CYCLES_PER_INST, "frac_of_nominal_issue": min(1.0, NOMINAL_CYCLES_PER_INST / cyc),
                 "note": "cycles per wave64 VALU instruction per SIMD over the SSV launches of this run (HIP events; they share the SIMDs with the chain kernels), "
-                        "against the rate the row body of the kernel issues at when it runs alone (tools/ubench/valu_rates.hip, profiles/%s_valu_rates.txt) -- a "
+                        "against the rate the row body of the kernel issues at when it runs alone (tools/ubench/valu_rates.hip, profiles/r03_valu_rates.txt) -- a "
                         "measured rate of this opcode mix, not an architectural peak (MI355X_MICROARCH.md quotes 2 cycles per wave64 op; f32 add/mul/fma measure "
-                        "2.6-2.7, the packed 16-bit ops 4.4-4.6)" % PROFILE_TAG}
+                        "2.6-2.7, the packed 16-bit ops 4.4-4.6)"}
     if valu is not None and "all_kernels" in pm:
         valu["all_kernels_of_a_step"] = {"wave_insts": pm["all_kernels"]["valu_insts"], "hbm_bytes": pm["all_kernels"]["hbm_bytes_corrected"], "source": src}
     return roof, valu
@@ -427,7 +427,7 @@ def bench_cfg2(args, env):
     # the same step when the boundary hands over HOST buffers: digitise + pack + H2D of the rank's bins, then the step (SURVEY 8d:
     # "host<->device copies included"); measured once, outside the timed region
     dt_host = None
-    if os.environ.get("CKM_BENCH_FROM_HOST", "1") != "0":         # (the counter passes of tools/collect_profiles.sh want exactly one search)
+    if os.environ.get("CKM_BENCH_FROM_HOST", "1") != "0":         # (the counter passes of tools/gpu_collect.sh want exactly one search)
         saved = dict(part_ms)                   # (this extra step is not one of the timed ones: keep it out of step_parts_ms)
         t0 = time.perf_counter()
         seqs2 = _lib.Seqs(ctx, bins)
@@ -637,7 +637,7 @@ def DefaultValues_HMMER_TABLE_OUT():
 
 def cfg3_counters(alg_bytes):
     """HBM traffic and VALU instruction count of the SSV launches, scaled from the rocprofv3 --pmc passes of a cfg3 SAMPLE
-    (profiles/<tag>_cfg3_ssv_traffic.json: counters and algorithmic bytes of the sample; tools/collect_profiles.sh)."""
+    (profiles/<tag>_cfg3_ssv_traffic.json: counters and algorithmic bytes of the sample; tools/gpu_collect.sh)."""
     import glob
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", PROFILE_TAG + "*_cfg3_ssv_traffic.json")))
     if not found:
@@ -883,7 +883,7 @@ def bench_cfg3(args, env):
     # the first pass of the process, on a slice of the bins: contexts, the 2000-profile database, device tables and workspace at working size
     warm = min(nbins, 128 * share)
     t0 = time.perf_counter()
-    if os.environ.get("CKM_BENCH_SKIP_WARM") != "1":           # (counter passes of tools/collect_r03.sh want exactly one step's launches)
+    if os.environ.get("CKM_BENCH_SKIP_WARM") != "1":           # (counter passes of tools/gpu_collect.sh want exactly one step's launches)
         lineage_pass(w, binIds[:warm], files[:warm], lin, os.path.join(workdir, "cfg3_warm"), rank)
     env.sync()
     first_pass_s = time.perf_counter() - t0
@@ -941,7 +941,7 @@ def bench_cfg3(args, env):
                 "note": "time = HIP events over the SSV launches of every search of this run, summed (one SSV phase at a time per device since the contexts share a baton); "
                         "the launches share the SIMDs with the chain kernels of the groups ahead of them and of the other context's search -- step_utilisation prices "
                         "the whole step instead; the rate is what "
-                        "tools/ubench/valu_rates.hip measures for the row body of the kernel alone (profiles/%s_valu_rates.txt), not an architectural peak" % PROFILE_TAG}
+                        "tools/ubench/valu_rates.hip measures for the row body of the kernel alone (profiles/r03_valu_rates.txt), not an architectural peak"}
     if cnt is not None:
         # the whole step against the device: every kernel's VALU instructions (scaled from the sample's PMC passes) over the step's wall time
         cyc = per_step * clock_hz / (cnt["all_valu_insts"] / 1024.0)

@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcheckm_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class CkmError(RuntimeError):

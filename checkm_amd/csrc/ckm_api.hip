@@ -113,9 +113,10 @@ extern "C" int ckm_ctx_reserve(ckm_ctx *ctx, uint64_t pairs, double model_positi
     const size_t want = (size_t)std::min<uint64_t>(std::max<uint64_t>(est, (uint64_t)1 << 30), (uint64_t)w.ws_budget);
     if (w.ws.cap >= want) return;
     const int device = ctx->device;
+    std::lock_guard<std::mutex> lock(ctx->reserve_mutex);
     ctx->reserve_thread = std::thread([&w, want, device] {
       if (hipSetDevice(device) != hipSuccess) return;
-      try { w.ws.ensure(want); } catch (const Error &) { /* the search will ask again and report the failure itself */ }
+      try { w.ws.ensure(want); } catch (...) { /* whatever went wrong (out of memory, a driver error): the search will ask again and report the failure itself */ }
     });
   });
 }

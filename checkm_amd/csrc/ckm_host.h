@@ -234,7 +234,8 @@ struct ckm_ctx {
   std::mutex upload_mutex; Stager upload;               // staging of the sequence uploads (finish_seqs)
   std::thread reserve_thread;                          // ckm_ctx_reserve: background allocation of lane 0's float workspace
   std::string reserve_error;
-  void settle() { if (reserve_thread.joinable()) reserve_thread.join(); }      // every entry point that touches the workspace calls this first
+  std::mutex reserve_mutex;
+  void settle() { std::lock_guard<std::mutex> lock(reserve_mutex); if (reserve_thread.joinable()) reserve_thread.join(); }      // every entry point that touches the workspace calls this first
   std::atomic<uint64_t> fallbacks{0};                  // lanes the device-driven cascade handed back to the host-driven one (tables / workspace too small)
   hipEvent_t ssv_prev_done = nullptr;                  // device-driven cascade: end of the previous lane's SSV launches (the next lane's wait on it)
 };

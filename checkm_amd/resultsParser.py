@@ -839,6 +839,8 @@ class ResultsParser(object):
                 nmk = int(mo[s1] - mo[s0])
                 comp, cont = 100 * float(n_member) / nmk, 100 * float(int(mt[k]) - empty) / nmk
             elif s1 > s0:
+                if (lens_all[s0:s1] == 0).any():
+                    raise ZeroDivisionError("float division by zero")        # an empty collocated set: present / len(ms) in the reference's loop (markerSets.py:219-236)
                 # comp += present/len(set) over the sets IN ORDER, in float64 (markerSets.py:219-236): cumsum adds left to right
                 comp = float(np.cumsum(pres[s0:s1] / flen[s0:s1])[-1])
                 cont = float(np.cumsum(mult[s0:s1] / flen[s0:s1])[-1])
@@ -895,7 +897,12 @@ class ResultsParser(object):
         from checkm_amd.markerGeneFinder import SCAN_CACHE
         pool, outDir, tbl = self._pool
         order = sorted(self.models.keys())
-        owners = SCAN_CACHE[(os.path.abspath(outDir), tbl)]["owners"]
+        ent = SCAN_CACHE.get((os.path.abspath(outDir), tbl))
+        if ent is None or not pool.conns:
+            # the scan was released (release_scan(outDir)) or the workers are gone: read the tables they wrote, as a later `checkm qa` would
+            self._localize_remote()
+            return
+        owners = ent["owners"]
         per = [dict(sets={}) for _ in pool.devs]
         for b in order:
             per[owners[b]]["sets"][b] = binIdToBinMarkerSets[b].selectedMarkerSet()

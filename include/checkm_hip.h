@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CKM_ABI_VERSION 4
+#define CKM_ABI_VERSION 5
 
 enum {
   CKM_OK      =  0,

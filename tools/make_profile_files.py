@@ -1,71 +1,96 @@
 #!/usr/bin/env python
-"""Turns what tools/collect_profiles.sh left under gpurun_out/<tag>/ into the files committed under profiles/<tag>_*.
-usage: python tools/make_profile_files.py <tag>"""
+"""Turns what tools/gpu_collect.sh left under gpurun_out/<tag>/ into the files committed under profiles/<tag>_*.
+usage: python tools/make_profile_files.py <tag> [<tag> ...]
+  bench<k>.json            -> <tag>_bench<k>_line.json (the JSON line, indented)
+  pytest_tail.txt, smoke.txt, timeline3.txt, valu_rates.txt -> copied
+  stats3/ (+ stats3.json)  -> <tag>_cfg3_kernel_stats.txt   per kernel family / template instance: calls, total, average duration
+  pmc3_{fetch,write,sq}/   -> <tag>_cfg3_pmc_summary.txt + <tag>_cfg3_ssv_traffic.json (what bench.py scales roofline.traffic / roofline_valu from)
+  pmc_{fetch,write,sq}/    -> <tag>_pmc_summary.txt + <tag>_ssv_traffic.json (cfg2)"""
+import collections
 import csv
 import json
 import os
 import re
+import shutil
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = ("# FETCH_SIZE / WRITE_SIZE are in KB as reported; MI355X_MICROARCH.md (HBM section): FETCH_SIZE reads 1/2 of the bytes of a wide\n"
+       "# coalesced streaming read on gfx950 -> corrected HBM read bytes = 2 * FETCH_SIZE * 1024.  WRITE_SIZE is taken as reported.\n"
+       "# SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* are in quad-cycle units.  ssv_kernel = ssv_kernel_h<Q> + ssv_kernel_h8<Q8> (packed-half rows).\n")
 
 
 def last_json(path):
     return json.loads(open(path).read().strip().split("\n")[-1])
 
 
-def main():
-    tag = sys.argv[1]
+def counter_total(src, d, counter, only=None):
+    f = os.path.join(src, d, "p_counter_collection.csv")
+    return sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and (only is None or only in r["Kernel_Name"]))
+
+
+def pmc_files(src, dst, prefix, what, line, cmd):
+    dirs = [os.path.join(src, prefix + n) for n in ("fetch", "write", "sq")]
+    if not all(os.path.exists(os.path.join(d, "p_counter_collection.csv")) for d in dirs):
+        return
+    pm = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py")] + dirs, capture_output=True, text=True).stdout
+    open(dst(what + "pmc_summary.txt"), "w").write("# rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*, separate runs, each with --kernel-trace only), MI355X; ONE step each of:\n# " + cmd + "\n" + HDR + pm)
+    f, w = counter_total(src, prefix + "fetch", "FETCH_SIZE", "ssv_kernel"), counter_total(src, prefix + "write", "WRITE_SIZE", "ssv_kernel")
+    valu = counter_total(src, prefix + "sq", "SQ_INSTS_VALU", "ssv_kernel")
+    lds = counter_total(src, prefix + "sq", "SQ_INSTS_LDS", "ssv_kernel")
+    ms = [float(l.split()[2]) for l in pm.split("\n") if l.startswith("ssv_kernel ")][0]
+    fa, wa = counter_total(src, prefix + "fetch", "FETCH_SIZE"), counter_total(src, prefix + "write", "WRITE_SIZE")
+    va = counter_total(src, prefix + "sq", "SQ_INSTS_VALU")
+    json.dump({"config": line["config"]["workload"] if "cfg3" in what else "cfg2: 43 profiles x 100 bins x 2000 ORFs, 1 GPU, one search",
+               "kernel": "ssv_kernel_h<Q> / ssv_kernel_h8<Q8> (all launches of one step; kernels serialised by counter collection)",
+               "algorithmic_bytes": line["roofline"]["algorithmic_bytes"], "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_corrected": 2 * f * 1024 + w * 1024,
+               "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); algorithmic bytes = sum over (model, sequence) pairs of (L + 12)",
+               "valu_insts": valu, "lds_insts": lds, "ssv_ms_under_pmc": ms,
+               "all_kernels": {"valu_insts": va, "FETCH_SIZE_KB": fa, "WRITE_SIZE_KB": wa, "hbm_bytes_corrected": 2 * fa * 1024 + wa * 1024,
+                               "note": "every kernel of the step (SSV + the chains + ensembles + copies), same passes"}},
+              open(dst(what + "ssv_traffic.json"), "w"), indent=1)
+
+
+def one(tag):
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = lambda name: os.path.join(ROOT, "profiles", "%s_%s" % (tag, name))
-    json.dump(last_json(os.path.join(src, "bench_default.json")), open(dst("bench_cfg2_line.json"), "w"), indent=1)
-    for name, out in (("bench_w1.json", "bench_cfg2_workers1_line.json"), ("bench_hostcascade_w3.json", "bench_cfg2_hostcascade_w3_line.json"),
-                      ("bench_cfg3.json", "bench_cfg3_line.json")):
-        if os.path.exists(os.path.join(src, name)) and os.path.getsize(os.path.join(src, name)) > 0:
-            json.dump(last_json(os.path.join(src, name)), open(dst(out), "w"), indent=1)
-    if os.path.exists(os.path.join(src, "bench_1000bins.json")):
-        json.dump(last_json(os.path.join(src, "bench_1000bins.json")), open(dst("bench_1000bins_line.json"), "w"), indent=1)
-    ks = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), os.path.join(src, "trace", "bench_results.db"), "4"],
-                        capture_output=True, text=True).stdout
-    open(dst("bench_cfg2_kernel_stats.txt"), "w").write(
-        "# rocprofv3 --kernel-trace -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --lineage-bins 0   (MI355X, default: device-driven cascade, one lane)\n"
-        "# summarised by tools/rocprof_summary.py.  NOTE: the chains of the model-length groups run on up to 14 streams underneath the SSV launches, so\n"
-        "# durations of concurrent kernels overlap in time and their SUM (ms_per_step) exceeds the wall time of a step; avg_us is the duration of one\n"
-        "# launch while it shares the device.  The serialised figures are in %s_pmc_summary.txt (counter collection runs one kernel at a time).\n" % tag + ks)
-    pm = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py")] + [os.path.join(src, d) for d in ("pmc_fetch", "pmc_write", "pmc_sq")],
-                        capture_output=True, text=True).stdout
-    hdr = ("# rocprofv3 --pmc passes, MI355X; ONE search each of: CKM_WS_PER_MP=5 CKM_BENCH_STEADY=0 CKM_BENCH_FROM_HOST=0 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --lineage-bins 0\n"
-           "# (cfg2: 43 profiles x 100 bins x 2000 ORFs; separate passes: --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_*, each with --kernel-trace only;\n"
-           "#  collected by tools/collect_profiles.sh, summarised by tools/pmc_summary.py)\n"
-           "# FETCH_SIZE / WRITE_SIZE are in KB as reported; MI355X_MICROARCH.md (HBM section): FETCH_SIZE reads 1/2 of the bytes of a wide\n"
-           "# coalesced streaming read on gfx950 -> corrected HBM read bytes = 2 * FETCH_SIZE * 1024.  WRITE_SIZE is taken as reported.\n"
-           "# SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* are in quad-cycle units.\n")
-    line = [l for l in pm.split("\n") if l.startswith("ssv_kernel ")][0]
-    valu = float(re.search(r"SQ_INSTS_VALU=(\d+)", line).group(1)); ms = float(line.split()[2])
-    tail = ("\n# ssv_kernel: VALU wave-instructions per SIMD = %.0f / 1024 = %.3e ; kernel time %.2f ms (serialised, under the counters) -> %.2f cycles per VALU\n"
-            "# instruction per SIMD at 2.4 GHz; the architectural issue peak is 1 wave64 instruction per 4 cycles per SIMD (64 lanes over a 16-lane SIMD).\n"
-            % (valu, valu / 1024, ms, ms * 1e-3 * 2.4e9 / (valu / 1024)))
-    open(dst("pmc_summary.txt"), "w").write(hdr + pm + tail)
-
-    def total(d, counter):
-        return sum(float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(src, d, "p_counter_collection.csv")))
-                   if "ssv_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter)
-    f, w = total("pmc_fetch", "FETCH_SIZE"), total("pmc_write", "WRITE_SIZE")
-
-    def total_all(d, counter):
-        return sum(float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(src, d, "p_counter_collection.csv"))) if r["Counter_Name"] == counter)
-    valu_all = total_all("pmc_sq", "SQ_INSTS_VALU")
-    f_all, w_all = total_all("pmc_fetch", "FETCH_SIZE"), total_all("pmc_write", "WRITE_SIZE")
-    json.dump({"config": "cfg2: 43 profiles x 100 bins x 2000 ORFs, 1 GPU, one search (kernels serialised by counter collection)",
-               "kernel": "ssv_kernel<Q> (all launches of one step)", "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_corrected": 2 * f * 1024 + w * 1024,
-               "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads)",
-               "valu_insts": valu, "ssv_ms_under_pmc": ms,
-               "all_kernels": {"valu_insts": valu_all, "FETCH_SIZE_KB": f_all, "WRITE_SIZE_KB": w_all, "hbm_bytes_corrected": 2 * f_all * 1024 + w_all * 1024,
-                               "note": "every kernel of the search (SSV + the chains + ensembles + copies), same passes"}},
-              open(dst("ssv_traffic.json"), "w"), indent=1)
-    print(open(dst("ssv_traffic.json")).read())
+    for name in sorted(os.listdir(src)):
+        m = re.match(r"bench(\d+)\.json$", name)
+        if m and os.path.getsize(os.path.join(src, name)) > 0:
+            json.dump(last_json(os.path.join(src, name)), open(dst("bench%s_line.json" % m.group(1)), "w"), indent=1)
+    for name, out in (("pytest_tail.txt", "pytest_gpu_tail.txt"), ("smoke.txt", "smoke.txt"), ("timeline3.txt", "timeline_cfg3.txt"), ("valu_rates.txt", "valu_rates.txt")):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copyfile(os.path.join(src, name), dst(out))
+    ks = os.path.join(src, "stats3", "cfg3_kernel_stats.csv")
+    if os.path.exists(ks):
+        fam, inst = collections.defaultdict(lambda: [0, 0.0]), []
+        for r in csv.DictReader(open(ks)):
+            m = re.search(r'ckm::([a-z0-9_]+kernel(?:_h8|_h)?)(<[^>]*>)?', r["Name"])
+            k = m.group(1) if m else r["Name"][:40]
+            fam[k][0] += int(r["Calls"]); fam[k][1] += float(r["TotalDurationNs"])
+            inst.append(((m.group(1) + (m.group(2) or "")) if m else r["Name"][:40], int(r["Calls"]), float(r["TotalDurationNs"]), float(r["AverageNs"])))
+        tot = sum(v[1] for v in fam.values())
+        line = last_json(os.path.join(src, "stats3.json"))
+        with open(dst("cfg3_kernel_stats.txt"), "w") as f:
+            f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --config cfg3 --bins-total %d --steps 1 --warmup 1 --no-cpu-baseline --no-cfg2 --no-emulation --no-verify (MI355X)\n"
+                    "# = the warm pass over 128 bins + ONE timed step (bench line of this run: %.0f ms per step, SSV launches %.0f ms by HIP events).\n"
+                    "# Kernels of the two scan lanes and of the chain streams overlap in time: durations SUM to more than the wall time.\n"
+                    % (line["config"]["bins_total"], line["ms_per_step"], line["roofline"]["ms_per_step_kernel"]))
+            f.write("%-28s %8s %12s %12s %6s\n" % ("kernel family", "calls", "total_ms", "avg_us", "pct"))
+            for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+                f.write("%-28s %8d %12.2f %12.1f %6.1f\n" % (k, v[0], v[1] / 1e6, v[1] / v[0] / 1e3, 100 * v[1] / tot))
+            f.write("\n# per template instance (top 40)\n%-34s %8s %12s %12s\n" % ("kernel", "calls", "total_ms", "avg_us"))
+            for n, c, t, a in sorted(inst, key=lambda x: -x[2])[:40]:
+                f.write("%-34s %8d %12.2f %12.1f\n" % (n, c, t / 1e6, a / 1e3))
+    if os.path.exists(os.path.join(src, "pmc3_sq.json")):
+        pmc_files(src, dst, "pmc3_", "cfg3_", last_json(os.path.join(src, "pmc3_sq.json")),
+                  "CKM_BENCH_SKIP_WARM=1 CKM_WS_PER_MP=5 python bench.py --config cfg3 --bins-total 48 --steps 1 --warmup 0 --no-cpu-baseline --no-cfg2 --no-emulation --no-verify   (a 48-bin SAMPLE of configs[2])")
+    if os.path.exists(os.path.join(src, "pmc_sq.json")):
+        pmc_files(src, dst, "pmc_", "", last_json(os.path.join(src, "pmc_sq.json")),
+                  "CKM_WS_PER_MP=5 CKM_BENCH_STEADY=0 CKM_BENCH_FROM_HOST=0 python bench.py --config cfg2 --steps 1 --warmup 0 --no-cpu-baseline --no-verify")
 
 
 if __name__ == "__main__":
-    main()
+    for t in sys.argv[1:]:
+        one(t)
