@@ -138,7 +138,9 @@ extern "C" void ckm_ctx_destroy(ckm_ctx *ctx) {
     if (w.ens_stream) (void)hipStreamDestroy(w.ens_stream);
     (void)hipStreamDestroy(w.stream);
   }
+  const int device = ctx->device;
   delete ctx;
+  dev_cache_trim(device);                 // (blocks the context's buffers left in the cache)
 }
 
 // ---- profiles -----------------------------------------------------------------------------------

@@ -64,19 +64,62 @@ void launch_regions(hipStream_t stream, uint32_t nblocks, const uint32_t *list, 
     if (e_ != hipSuccess) throw Error(CKM_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
   } while (0)
 
+// Device blocks given back by a DevBuf are kept for the next DevBuf of about that size instead of going through hipFree / hipMalloc:
+// hipFree waits for every kernel running on the device, and a lineage_wf pass over a thousand bins frees (and re-allocates) a few
+// thousand sequence, hit and table buffers -- 1.7 s per 1000-bin step once the release is counted.  Per device; blocks of >= 2 GB (the
+// float workspace) and anything beyond 64 GB cached are freed as before.  dev_cache_trim() empties it (ckm_ctx_destroy).
+struct DevCache {
+  std::mutex m;
+  std::multimap<size_t, void *> free_[16];
+  size_t cached[16] = {0};
+  static DevCache &get() { static DevCache c; return c; }
+  void *take(int dev, size_t want, size_t &got) {
+    std::lock_guard<std::mutex> lock(m);
+    auto &f = free_[dev & 15];
+    auto it = f.lower_bound(want);
+    if (it != f.end() && it->first <= want + want / 2 + (1 << 20)) { void *p = it->second; got = it->first; cached[dev & 15] -= got; f.erase(it); return p; }
+    return nullptr;
+  }
+  bool give(int dev, void *p, size_t cap) {
+    if (cap >= ((size_t)2 << 30)) return false;
+    std::lock_guard<std::mutex> lock(m);
+    if (cached[dev & 15] + cap > ((size_t)64 << 30)) return false;
+    free_[dev & 15].emplace(cap, p); cached[dev & 15] += cap;
+    return true;
+  }
+  void trim(int dev) {
+    std::multimap<size_t, void *> f;
+    { std::lock_guard<std::mutex> lock(m); f.swap(free_[dev & 15]); cached[dev & 15] = 0; }
+    for (auto &kv : f) (void)hipFree(kv.second);
+  }
+};
+inline void dev_cache_trim(int dev) { DevCache::get().trim(dev); }
+
 struct DevBuf {
-  void *p = nullptr; size_t cap = 0;
+  void *p = nullptr; size_t cap = 0; int dev = -1;
   // vmm (the float workspace, CKM_WS_VMM=1): an address range is reserved once and physical 1 GB chunks are mapped into it as the buffer
   // grows -- measured on MI355X (tools/ubench/vmm_probe.hip, profiles/r03z_vmm_probe.txt): 0.2 ms per GB against hipMalloc's 30 ms per GB,
   // and growth keeps the contents and the address (no free + malloc).  Mapping waits for kernels already running, like hipFree.
   bool vmm = false; size_t va_bytes = (size_t)128 << 30, chunk_bytes = 0; std::vector<hipMemGenericAllocationHandle_t> chunks;
+  void drop() {
+    if (!p) return;
+    if (dev < 0 || !DevCache::get().give(dev, p, cap)) (void)hipFree(p);
+    p = nullptr; cap = 0;
+  }
   void ensure(size_t bytes) {
     if (bytes <= cap) return;
     if (vmm) { grow_mapped(bytes); return; }
-    if (p) (void)hipFree(p);
-    p = nullptr; cap = 0;
+    drop();
+    (void)hipGetDevice(&dev);
     size_t want = bytes + std::min<size_t>(bytes / 4, (size_t)1 << 30) + 256;      // (growth slack, bounded: the float workspace is tens of GB)
+    size_t got = 0;
+    if (void *q = DevCache::get().take(dev, want, got)) { p = q; cap = got; return; }
     hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      // device memory held by the cache may be what is missing
+      DevCache::get().trim(dev);
+      e = hipMalloc(&p, want);
+    }
     if (e != hipSuccess) { p = nullptr; throw Error(CKM_ENOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed: " + hipGetErrorString(e)); }
     cap = want;
   }
@@ -114,7 +157,7 @@ struct DevBuf {
       if (p && cap) (void)hipMemUnmap(p, cap);
       for (auto h : chunks) (void)hipMemRelease(h);
       if (p) (void)hipMemAddressFree(p, va_bytes);
-    } else if (p) (void)hipFree(p);
+    } else drop();
   }
   DevBuf() = default; DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
 };
