@@ -145,18 +145,55 @@ __global__ void __launch_bounds__(256) gene_rbs_kernel(GeneSeqDev seqs, GeneNode
 }
 
 // ---- the dynamic program ----
-struct DpNode { int ndx, sv, strand, stop; };     // stop: type == STOP
-__device__ __forceinline__ DpNode dp_load(const GeneNodesDev &nd, uint32_t k) {
-  DpNode n; n.ndx = nd.ndx[k]; n.sv = nd.stop_val[k]; n.strand = nd.strand[k]; n.stop = nd.type[k] == 3; return n;
-}
-__device__ __forceinline__ double dp_igm(const GeneNodesDev &nd, double st_wt, uint32_t k1, const DpNode &n1, uint32_t k2, const DpNode &n2) {
+// The nodes of a sequence go in order; node i looks back over about a thousand predecessors (dprog.c: 500 nodes, and 500 more behind the
+// node that far back), and scoring one connection is a chain of dependent reads: the predecessor's position / strand / type, its score and
+// trace-back, the start nodes it overlaps, their coding scores.  From global memory that chain is ~3 us per round of 64 candidates
+// (measured: 30 us per node, 3.1 s for the training pass of 2 Mb bins).  So the last 2048 nodes live in an LDS RING -- 36 bytes per node:
+// position, stop position, trace-back, {flags, three overlapping-start offsets} packed in a word, score, connection value (GC-frame bias
+// x GC score in the training pass, coding + start score in the final pass) -- filled 64 nodes ahead of the sweep by all lanes; what lies
+// further back (behind a giant ORF) and the two doubles only operon neighbours need (rscore, uscore) are read from global memory.
+constexpr int DPW = 2048;
+struct DpRing { int ndx[DPW], sv[DPW], tb[DPW], pk[DPW], lo[DPW]; double score[DPW], val[DPW]; };
+struct DpNode { int ndx, sv, strand, stop; };
+
+struct DpSrc {
+  const GeneNodesDev &nd; DpRing &r; uint32_t first; int lo_rel, hi_rel; int flag;      // nodes with relative index in [lo_rel, hi_rel) are in the ring
+  __device__ __forceinline__ bool ring(int rel) const { return rel >= lo_rel && rel < hi_rel; }
+  __device__ __forceinline__ DpNode node(int rel) const {
+    DpNode n;
+    if (ring(rel)) { const int k = rel & (DPW - 1); const int pk = r.pk[k]; n.ndx = r.ndx[k]; n.sv = r.sv[k]; n.strand = (pk & 2) ? -1 : 1; n.stop = pk & 1; }
+    else { const uint32_t g = first + (uint32_t)rel; n.ndx = nd.ndx[g]; n.sv = nd.stop_val[g]; n.strand = nd.strand[g]; n.stop = nd.type[g] == 3; }
+    return n;
+  }
+  __device__ __forceinline__ int ndx(int rel) const { return ring(rel) ? r.ndx[rel & (DPW - 1)] : nd.ndx[first + (uint32_t)rel]; }
+  __device__ __forceinline__ int star(int rel, int f) const {           // relative index of the overlapping start of frame f, or -1
+    if (ring(rel)) { const int pk = r.pk[rel & (DPW - 1)]; if (!(pk & 8)) { const int o = (int)(int8_t)((pk >> (8 + 8 * f)) & 0xff); return o == -128 ? -1 : rel + o; } }
+    return nd.star_ptr[(size_t)(first + (uint32_t)rel) * 3 + f];
+  }
+  __device__ __forceinline__ double val(int rel) const { return ring(rel) ? r.val[rel & (DPW - 1)] : (flag == 0 ? nd.gcb[first + (uint32_t)rel] : nd.csc[first + (uint32_t)rel]); }
+  __device__ __forceinline__ double score(int rel) const {
+    if (ring(rel)) return r.score[rel & (DPW - 1)];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    return GLD(&nd.score[first + (uint32_t)rel]);
+  }
+  __device__ __forceinline__ int tb(int rel) const {                     // relative, or -1
+    if (ring(rel)) return r.tb[rel & (DPW - 1)];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    const int t = GLD(&nd.traceb[first + (uint32_t)rel]);
+    return t < 0 ? -1 : t - (int)first;
+  }
+  __device__ __forceinline__ double rscore(int rel) const { return nd.rscore[first + (uint32_t)rel]; }
+  __device__ __forceinline__ double uscore(int rel) const { return nd.uscore[first + (uint32_t)rel]; }
+};
+
+__device__ __forceinline__ double dp_igm(const DpSrc &S, double st_wt, int k1, const DpNode &n1, int k2, const DpNode &n2) {
   double rval = 0.0; int ovlp = 0;
   if ((n1.strand == 1 && n2.strand == 1 && (n1.ndx + 2 == n2.ndx || n1.ndx - 1 == n2.ndx)) ||
       (n1.strand == -1 && n2.strand == -1 && (n1.ndx + 2 == n2.ndx || n1.ndx - 1 == n2.ndx))) {
-    if (n1.strand == 1 && nd.rscore[k2] < 0) rval -= nd.rscore[k2];
-    if (n1.strand == -1 && nd.rscore[k1] < 0) rval -= nd.rscore[k1];
-    if (n1.strand == 1 && nd.uscore[k2] < 0) rval -= nd.uscore[k2];
-    if (n1.strand == -1 && nd.uscore[k1] < 0) rval -= nd.uscore[k1];
+    if (n1.strand == 1 && S.rscore(k2) < 0) rval -= S.rscore(k2);
+    if (n1.strand == -1 && S.rscore(k1) < 0) rval -= S.rscore(k1);
+    if (n1.strand == 1 && S.uscore(k2) < 0) rval -= S.uscore(k2);
+    if (n1.strand == -1 && S.uscore(k1) < 0) rval -= S.uscore(k1);
   }
   const int dist = abs(n1.ndx - n2.ndx);
   if (n1.strand == 1 && n2.strand == 1 && n1.ndx + 2 >= n2.ndx) ovlp = 1;
@@ -165,9 +202,10 @@ __device__ __forceinline__ double dp_igm(const GeneNodesDev &nd, double st_wt, u
   else if ((dist <= 60 && ovlp == 0) || dist < 0.25 * 60) rval += (2.0 - (double)dist / 60) * 0.15 * st_wt;
   return rval;
 }
-// score of the connection p1 -> p2 (absolute node indices; first = first node of the sequence); false: no such connection
-__device__ __forceinline__ bool dp_connection(const GeneNodesDev &nd, double st_wt, int flag, uint32_t first, uint32_t p1, uint32_t p2, const DpNode &n2, double &total, int &mark) {
-  const DpNode n1 = dp_load(nd, p1);
+// score of the connection p1 -> p2 (node indices relative to the sequence's first node); false: no such connection
+__device__ __forceinline__ bool dp_connection(const DpSrc &S, double st_wt, int p1, int p2, const DpNode &n2, double &total, int &mark) {
+  const int flag = S.flag;
+  const DpNode n1 = S.node(p1);
   int left = n1.ndx, right = n2.ndx, ovlp = 0, maxfr = -1;
   double score = 0.0, scr_mod = 0.0;
   const int s1 = n1.strand, s2 = n2.strand; const bool st1 = n1.stop, st2 = n2.stop;
@@ -175,77 +213,74 @@ __device__ __forceinline__ bool dp_connection(const GeneNodesDev &nd, double st_
   else if (s1 == 1 && !st1 && s2 == -1) return false;
   else if (s1 == -1 && st1 && s2 == 1) return false;
   else if (s1 == -1 && !st1 && s2 == 1 && st2) return false;
-  const int tb1 = GLD(&nd.traceb[p1]);                       // -1 or absolute index
+  const int tb1 = S.tb(p1);
   if (tb1 == -1 && s1 == 1 && st1) return false;
   if (tb1 == -1 && s1 == -1 && !st1) return false;
   if (s1 == s2 && s1 == 1 && !st1 && st2) {
     if (n2.sv >= n1.ndx) return false;
     if (n1.ndx % 3 != n2.ndx % 3) return false;
     right += 2;
-    if (flag == 0) scr_mod = nd.gcb[p1]; else score = nd.csc[p1];
+    if (flag == 0) scr_mod = S.val(p1); else score = S.val(p1);
   } else if (s1 == s2 && s1 == -1 && st1 && !st2) {
     if (n1.sv <= n2.ndx) return false;
     if (n1.ndx % 3 != n2.ndx % 3) return false;
     left -= 2;
-    if (flag == 0) scr_mod = nd.gcb[p2]; else score = nd.csc[p2];
+    if (flag == 0) scr_mod = S.val(p2); else score = S.val(p2);
   } else if (s1 == 1 && st1 && s2 == 1 && !st2) {
     left += 2;
     if (left >= right) return false;
-    if (flag == 1) score = dp_igm(nd, st_wt, p1, n1, p2, n2);
+    if (flag == 1) score = dp_igm(S, st_wt, p1, n1, p2, n2);
   } else if (s1 == 1 && st1 && s2 == -1 && st2) {
     left += 2; right -= 2;
     if (left >= right) return false;
     double maxval = 0.0; int best_ov = 0;
     for (int i = 0; i < 3; ++i) {
-      const int sp = nd.star_ptr[(size_t)p2 * 3 + i];
-      if (sp == -1) continue;
-      const uint32_t p3 = first + (uint32_t)sp;
-      const DpNode n3 = dp_load(nd, p3);
+      const int p3 = S.star(p2, i);
+      if (p3 == -1) continue;
+      const DpNode n3 = S.node(p3);
       const int ov = left - n3.sv + 1;
       if (ov <= 0 || ov >= 200) continue;
       if (ov >= n3.ndx - left) continue;
       if (tb1 == -1) continue;
-      if (ov >= n3.sv - nd.ndx[tb1] - 2) continue;
-      const double v = flag == 1 ? nd.csc[p3] + dp_igm(nd, st_wt, p3, n3, p2, n2) : nd.gcb[p3];
+      if (ov >= n3.sv - S.ndx(tb1) - 2) continue;
+      const double v = flag == 1 ? S.val(p3) + dp_igm(S, st_wt, p3, n3, p2, n2) : S.val(p3);
       if (v > maxval) { maxfr = i; maxval = v; best_ov = ov; }
     }
     if (maxfr != -1) { ovlp = best_ov; if (flag == 0) scr_mod = maxval; else score = maxval; }
-    else if (flag == 1) score = dp_igm(nd, st_wt, p1, n1, p2, n2);
+    else if (flag == 1) score = dp_igm(S, st_wt, p1, n1, p2, n2);
   } else if (s1 == -1 && !st1 && s2 == -1 && st2) {
     right -= 2;
     if (left >= right) return false;
-    if (flag == 1) score = dp_igm(nd, st_wt, p1, n1, p2, n2);
+    if (flag == 1) score = dp_igm(S, st_wt, p1, n1, p2, n2);
   } else if (s1 == -1 && !st1 && s2 == 1 && !st2) {
     if (left >= right) return false;
-    if (flag == 1) score = dp_igm(nd, st_wt, p1, n1, p2, n2);
+    if (flag == 1) score = dp_igm(S, st_wt, p1, n1, p2, n2);
   } else if (s1 == 1 && st1 && s2 == -1 && !st2) {
     if (n2.sv - 2 >= n1.ndx + 2) return false;
     ovlp = (n1.ndx + 2) - (n2.sv - 2) + 1;
     if (ovlp >= 200) return false;
     if ((n1.ndx + 2 - n2.sv - 2 + 1) >= (n2.ndx - n1.ndx + 3 + 1)) return false;
-    const int bnd = tb1 == -1 ? 0 : nd.ndx[tb1];
+    const int bnd = tb1 == -1 ? 0 : S.ndx(tb1);
     if ((n1.ndx + 2 - n2.sv - 2 + 1) >= (n2.sv - 3 - bnd + 1)) return false;
     left = n2.sv - 2;
-    if (flag == 0) scr_mod = nd.gcb[p2]; else score = nd.csc[p2] - 0.15 * st_wt;
+    if (flag == 0) scr_mod = S.val(p2); else score = S.val(p2) - 0.15 * st_wt;
   } else if (s1 == s2 && s1 == 1 && st1 && st2) {
     if (n2.sv >= n1.ndx) return false;
-    const int sp = nd.star_ptr[(size_t)p1 * 3 + (n2.ndx % 3)];
-    if (sp == -1) return false;
-    const uint32_t p3 = first + (uint32_t)sp;
-    const DpNode n3 = dp_load(nd, p3);
+    const int p3 = S.star(p1, n2.ndx % 3);
+    if (p3 == -1) return false;
+    const DpNode n3 = S.node(p3);
     left = n3.ndx; right += 2;
-    if (flag == 0) scr_mod = nd.gcb[p3]; else score = nd.csc[p3] + dp_igm(nd, st_wt, p1, n1, p3, n3);
+    if (flag == 0) scr_mod = S.val(p3); else score = S.val(p3) + dp_igm(S, st_wt, p1, n1, p3, n3);
   } else if (s1 == s2 && s1 == -1 && st1 && st2) {
     if (n1.sv <= n2.ndx) return false;
-    const int sp = nd.star_ptr[(size_t)p2 * 3 + (n1.ndx % 3)];
-    if (sp == -1) return false;
-    const uint32_t p3 = first + (uint32_t)sp;
-    const DpNode n3 = dp_load(nd, p3);
+    const int p3 = S.star(p2, n1.ndx % 3);
+    if (p3 == -1) return false;
+    const DpNode n3 = S.node(p3);
     left -= 2; right = n3.ndx;
-    if (flag == 0) scr_mod = nd.gcb[p3]; else score = nd.csc[p3] + dp_igm(nd, st_wt, p3, n3, p2, n2);
+    if (flag == 0) scr_mod = S.val(p3); else score = S.val(p3) + dp_igm(S, st_wt, p3, n3, p2, n2);
   }
   if (flag == 0) score = ((double)(right - left + 1 - (ovlp * 2))) * scr_mod;
-  total = GLD(&nd.score[p1]) + score;
+  total = S.score(p1) + score;
   mark = maxfr;
   return true;
 }
@@ -253,30 +288,56 @@ __device__ __forceinline__ bool dp_connection(const GeneNodesDev &nd, double st_
 // one wavefront per sequence; seq_first[s] .. seq_first[s+1] are its nodes (already in working order); traceb is written as an ABSOLUTE
 // node index (-1: none); score / traceb / ov_mark must arrive zero / -1 / -1 from the host
 __global__ void __launch_bounds__(64) gene_dp_kernel(GeneNodesDev nd, const uint32_t *__restrict__ seq_first, const double *__restrict__ st_wt_of_seq, uint32_t nseq, int flag) {
+  __shared__ DpRing ring;
   const int lane = threadIdx.x;
   for (uint32_t s = blockIdx.x; s < nseq; s += gridDim.x) {
     const uint32_t first = seq_first[s], end = seq_first[s + 1];
+    const int nn = (int)(end - first);
     const double st_wt = st_wt_of_seq[s];
-    for (uint32_t i = first; i < end; ++i) {
-      if (nd.type[i] == 255) continue;                         // (padding node)
-      const DpNode n2 = dp_load(nd, i);
-      const uint32_t lo = first + nd.dp_min[i];
-      double best = -1.0; int bj = -1, bmark = -1;             // best candidate of this lane: the LAST j of the lane's that reaches its maximum (j ascends)
-      for (uint32_t j = lo + (uint32_t)lane; j < i; j += 64) {
-        if (nd.type[j] == 255) continue;
-        double tot; int mark;
-        if (!dp_connection(nd, st_wt, flag, first, j, i, n2, tot, mark)) continue;
-        if (tot >= 0.0 && tot >= best) { best = tot; bj = (int)j; bmark = mark; }
+    __syncthreads();
+    for (int i0 = 0; i0 < nn; i0 += 64) {
+      // the next 64 nodes enter the ring (their static fields; score 0, no trace-back yet): overwrites nodes i0 - DPW .. i0 + 63 - DPW
+      {
+        const int rel = i0 + lane;
+        if (rel < nn) {
+          const uint32_t g = first + (uint32_t)rel; const int k = rel & (DPW - 1);
+          ring.ndx[k] = nd.ndx[g]; ring.sv[k] = nd.stop_val[g]; ring.tb[k] = -1; ring.score[k] = 0.0;
+          ring.val[k] = flag == 0 ? nd.gcb[g] : nd.csc[g];
+          int pk = (nd.type[g] == 3 ? 1 : 0) | (nd.strand[g] == -1 ? 2 : 0) | (nd.type[g] == 255 ? 4 : 0);
+          for (int f = 0; f < 3; ++f) {
+            const int sp = nd.star_ptr[(size_t)g * 3 + f]; const int o = sp < 0 ? -128 : sp - rel;
+            if (sp >= 0 && (o < -127 || o > 127)) pk |= 8;          // (does not fit the packed offset: this node's overlapping starts are read from global memory)
+            pk |= (o & 0xff) << (8 + 8 * f);
+          }
+          ring.pk[k] = pk; ring.lo[k] = (int)nd.dp_min[g];
+        }
       }
-      // wave reduction: maximum total, ties to the larger j (the reference loop keeps the last candidate that is >= the running best)
+      __syncthreads();
+      const int i1 = min(nn, i0 + 64);
+      const DpSrc S{nd, ring, first, max(0, i0 + 64 - DPW), i1, flag};
+      for (int i = i0; i < i1; ++i) {
+        const int pki = ring.pk[i & (DPW - 1)];
+        if (pki & 4) continue;                                   // (padding node)
+        const DpNode n2 = S.node(i);
+        const int lo = ring.lo[i & (DPW - 1)];
+        double best = -1.0; int bj = -1, bmark = -1;             // best candidate of this lane: the LAST j of the lane's that reaches its maximum (j ascends)
+        for (int j = lo + lane; j < i; j += 64) {
+          double tot; int mark;
+          if (!dp_connection(S, st_wt, j, i, n2, tot, mark)) continue;
+          if (tot >= 0.0 && tot >= best) { best = tot; bj = j; bmark = mark; }
+        }
+        // wave reduction: maximum total, ties to the larger j (the reference loop keeps the last candidate that is >= the running best)
 #pragma unroll
-      for (int sft = 32; sft >= 1; sft >>= 1) {
-        const double ob = __shfl_xor(best, sft); const int oj = __shfl_xor(bj, sft), om = __shfl_xor(bmark, sft);
-        if (oj >= 0 && (bj < 0 || ob > best || (ob == best && oj > bj))) { best = ob; bj = oj; bmark = om; }
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+          const double ob = __shfl_xor(best, sft); const int oj = __shfl_xor(bj, sft), om = __shfl_xor(bmark, sft);
+          if (oj >= 0 && (bj < 0 || ob > best || (ob == best && oj > bj))) { best = ob; bj = oj; bmark = om; }
+        }
+        if (lane == 0 && bj >= 0) {
+          ring.score[i & (DPW - 1)] = best; ring.tb[i & (DPW - 1)] = bj;
+          GST(&nd.score[first + (uint32_t)i], best); GST(&nd.traceb[first + (uint32_t)i], (int)first + bj); GST(&nd.ov_mark[first + (uint32_t)i], bmark);
+        }
+        __syncthreads();
       }
-      if (lane == 0 && bj >= 0) { GST(&nd.score[i], best); GST(&nd.traceb[i], bj); GST(&nd.ov_mark[i], bmark); }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      __builtin_amdgcn_wave_barrier();
     }
   }
 }

@@ -69,22 +69,32 @@ class BinGenes(object):
 
     def __init__(self, contigs, table, cols, sel, trained, uses_sd, gc):
         self.contigs, self.table, self.trained, self.uses_sd, self.gc = contigs, table, bool(trained), int(uses_sd), float(gc)
-        self.rows = [{f: (cols[f][k].item() if hasattr(cols[f][k], "item") else cols[f][k]) for f in cols} for k in sel]
+        import numpy as np
+        sel = np.asarray(sel, dtype=np.int64)
+        self.cols = {f: (cols[f][sel] if f != "proteins" else [cols[f][k] for k in sel]) for f in cols}
+        self.n = len(sel)
+
+    @property
+    def rows(self):
+        """One dict per gene (tests; the writers below use the columns)."""
+        keys = list(self.cols)
+        return [{f: (self.cols[f][k].item() if hasattr(self.cols[f][k], "item") else self.cols[f][k]) for f in keys} for k in range(self.n)]
 
     def coding_bases(self):
         """Bases covered by genes, overlaps counted once: what ProdigalGeneFeatureParser.codingBases sums over the contigs
         (checkm/prodigal.py:246-274)."""
+        import numpy as np
+        if self.n == 0:
+            return 0
+        c, s, e = self.cols["contig"].astype(np.int64), self.cols["begin"].astype(np.int64) - 1, self.cols["end"].astype(np.int64)
+        order = np.lexsort((s, c))
+        c, s, e = c[order], s[order], e[order]
         total = 0
-        by = {}
-        for r in self.rows:
-            by.setdefault(r["contig"], []).append((r["begin"] - 1, r["end"]))
-        for iv in by.values():
-            last = -1
-            for s, e in sorted(iv):
-                s = max(s, last)
-                if e > s:
-                    total += e - s
-                    last = e
+        for ci in np.unique(c):
+            m = c == ci
+            ss, ee = s[m], e[m]
+            prev = np.concatenate(([-1], np.maximum.accumulate(ee)[:-1]))
+            total += int(np.maximum(0, ee - np.maximum(ss, prev)).sum())
         return total
 
     def _attrs(self, seqnum, k, r):
@@ -103,32 +113,33 @@ class BinGenes(object):
         per = {}
         for r in self.rows:
             per.setdefault(r["contig"], []).append(r)
-        with open(aaFile, "w") as fa, open(gffFile, "w") as fg:
-            fn = open(ntFile, "w") if ntFile else None
-            fg.write("##gff-version  3\n")
-            for ci, (cid, seq) in enumerate(self.contigs):
-                fg.write('# Sequence Data: seqnum=%d;seqlen=%d;seqhdr="%s"\n' % (ci + 1, len(seq), cid))
-                fg.write('# Model Data: version=checkm_amd.device.gene_caller;run_type=Single;model="Ab initio";gc_cont=%.2f;transl_table=%d;uses_sd=%d\n'
-                         % (100.0 * self.gc, self.table, self.uses_sd))
-                for k, r in enumerate(per.get(ci, []), 1):
-                    at = self._attrs(ci + 1, k, r)
-                    strand = "+" if r["strand"] == 1 else "-"
-                    fg.write("%s\tcheckm_amd_device\tCDS\t%d\t%d\t%.1f\t%s\t0\t%s;conf=%.2f;score=%.2f;cscore=%.2f;sscore=%.2f;rscore=%.2f;uscore=%.2f;tscore=%.2f;\n"
-                             % (cid, r["begin"], r["end"], r["score"], strand, at, r["conf"], r["score"], r["cscore"], r["sscore"], r["rscore"], r["uscore"], r["tscore"]))
-                    head = ">%s_%d # %d # %d # %d # %s\n" % (cid, k, r["begin"], r["end"], r["strand"], at)
-                    p = r["proteins"]
-                    fa.write(head)
-                    for i in range(0, len(p), 60):
-                        fa.write(p[i:i + 60] + "\n")
-                    if fn is not None:
-                        nt = seq[r["begin"] - 1:r["end"]]
-                        if r["strand"] != 1:
-                            nt = nt.encode().translate(comp)[::-1].decode()
-                        fn.write(head)
-                        for i in range(0, len(nt), 70):
-                            fn.write(nt[i:i + 70] + "\n")
-            if fn is not None:
-                fn.close()
+        aa, gf, nt_out = [], ["##gff-version  3\n"], []
+        for ci, (cid, seq) in enumerate(self.contigs):
+            gf.append('# Sequence Data: seqnum=%d;seqlen=%d;seqhdr="%s"\n' % (ci + 1, len(seq), cid))
+            gf.append('# Model Data: version=checkm_amd.device.gene_caller;run_type=Single;model="Ab initio";gc_cont=%.2f;transl_table=%d;uses_sd=%d\n'
+                      % (100.0 * self.gc, self.table, self.uses_sd))
+            for k, r in enumerate(per.get(ci, []), 1):
+                at = self._attrs(ci + 1, k, r)
+                strand = "+" if r["strand"] == 1 else "-"
+                gf.append("%s\tcheckm_amd_device\tCDS\t%d\t%d\t%.1f\t%s\t0\t%s;conf=%.2f;score=%.2f;cscore=%.2f;sscore=%.2f;rscore=%.2f;uscore=%.2f;tscore=%.2f;\n"
+                          % (cid, r["begin"], r["end"], r["score"], strand, at, r["conf"], r["score"], r["cscore"], r["sscore"], r["rscore"], r["uscore"], r["tscore"]))
+                head = ">%s_%d # %d # %d # %d # %s\n" % (cid, k, r["begin"], r["end"], r["strand"], at)
+                p = r["proteins"]
+                aa.append(head)
+                aa.extend(p[i:i + 60] + "\n" for i in range(0, len(p), 60))
+                if ntFile:
+                    nt = seq[r["begin"] - 1:r["end"]]
+                    if r["strand"] != 1:
+                        nt = nt.encode().translate(comp)[::-1].decode()
+                    nt_out.append(head)
+                    nt_out.extend(nt[i:i + 70] + "\n" for i in range(0, len(nt), 70))
+        with open(aaFile, "w") as f:
+            f.write("".join(aa))
+        with open(gffFile, "w") as f:
+            f.write("".join(gf))
+        if ntFile:
+            with open(ntFile, "w") as f:
+                f.write("".join(nt_out))
 
 
 def call_bins(bins, table, mask=True):
