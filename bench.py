@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg5"], default="cfg3")
-    ap.add_argument("--budget-seconds", type=float, default=float(os.environ.get("CKM_BENCH_BUDGET_S", "300")),
+    ap.add_argument("--budget-seconds", type=float, default=float(os.environ.get("CKM_BENCH_BUDGET_S", "240")),
                     help="cfg3: wall-clock budget of the timed region; the steps actually run are min(--steps, budget / estimated step)")
     ap.add_argument("--emulate-rank", default=None, help="cfg3: R/W -- run as rank R of W on this one GPU (no collectives)")
     ap.add_argument("--no-cfg2", action="store_true", help="cfg3: skip the nested cfg2 measurement")
@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--bins-total", type=int, default=1000, help="cfg2 strong / cfg3: bins of the whole job")
     ap.add_argument("--lineage-bins", type=int, default=0, help="cfg2: bins of a small lineage_wf-equivalent side measurement (0 = skip; cfg3 IS that measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-genes", action="store_true", help="cfg3: skip the gene-calling side legs (gene_front_end, gene_calling)")
     ap.add_argument("--verify", type=int, default=3, help="cfg3 / cfg5: bins of the last timed step whose written tables are diffed against the CPU oracle after the timed region (0 = off)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--pipeline", type=int, default=1,
@@ -899,6 +900,17 @@ def bench_cfg3(args, env):
     env.sync()
     second_pass_s = time.perf_counter() - t0
     est = (second_pass_s if second_pass_s > 0 else first_pass_s) * nbins / float(warm)
+    # warmup steps proper: whole steps (all the bins), untimed -- the first one at full size still grows tables and the workspace
+    # (first_full_step_s on the line); at most two, however many were asked for, so that the run stays within minutes
+    full_warm = 0 if (warm == nbins or os.environ.get("CKM_BENCH_SKIP_WARM") == "1") else min(args.warmup, 2)
+    full_warm_walls = []
+    for k in range(full_warm):
+        ts = time.perf_counter()
+        lineage_pass(w, binIds, files, lin, os.path.join(workdir, "cfg3_out"), rank)
+        env.sync()
+        full_warm_walls.append(time.perf_counter() - ts)
+    if full_warm_walls:
+        est = full_warm_walls[-1]
     steps = int(max(1, min(args.steps, args.budget_seconds // max(est, 1e-3))))
     prof = None
     if args.host_profile and rank == 0:
@@ -909,10 +921,15 @@ def bench_cfg3(args, env):
     t0 = time.perf_counter()
     if prof is not None:
         prof.enable()
+    step_walls = []
     for k in range(steps):
+        ts = time.perf_counter()
         parts, tot = lineage_pass(w, binIds, files, lin, os.path.join(workdir, "cfg3_out"), rank)
+        step_walls.append(time.perf_counter() - ts)
     from checkm_amd import markerGeneFinder as _mgf
+    tj = time.perf_counter()
     _mgf._join_releasers()               # the background release of the last step's scans belongs to the timed region (every earlier one is waited for by the next find())
+    last_release_s = time.perf_counter() - tj
     if prof is not None:
         prof.disable()
     env.sync()
@@ -969,7 +986,7 @@ def bench_cfg3(args, env):
            "residue_hmm_per_s": residue_hmm / per_step, "residue_hmm_per_step": residue_hmm,
            "first_pass_s": first_pass_s, "first_pass_bins": warm, "second_pass_s_same_bins": second_pass_s if second_pass_s > 0 else None,
            "first_pass_overhead_s": (first_pass_s - second_pass_s) if second_pass_s > 0 else None,
-           "parts_s_rank0": parts, "roofline": roof, "roofline_valu": valu, "step_utilisation": step_util, "stage_pairs": stage_pairs(tot), "ssv_ms_max_rank": ssv_ms,
+           "parts_s_rank0": parts, "step_walls_s_rank0": step_walls, "last_release_wait_s": last_release_s, "warmup_full_steps_s_rank0": full_warm_walls, "roofline": roof, "roofline_valu": valu, "step_utilisation": step_util, "stage_pairs": stage_pairs(tot), "ssv_ms_max_rank": ssv_ms,
            "gpu_host_split_s_rank0": {"ssv_kernels": tot.get("ms_ssv", 0.0) / 1e3, "search_calls_sum": tot.get("ms_total", 0.0) / 1e3,
                                       "ingest": tot.get("ingest_s", 0.0), "search": tot.get("search_s", 0.0), "write": tot.get("write_s", 0.0),
                                       "tree_find": parts["tree_find_s"], "analyze_find": parts["analyze_find_s"], "qa": parts["qa_s"],
@@ -1012,8 +1029,9 @@ def bench_cfg3(args, env):
                                           "note": "this ONE GPU as rank r of 8 for r = 0..7 in turn: LPT shard of the %d bins (dist.shard_bins: file size x models), the host work a rank "
                                                   "does, no collective (the one all_gather of QA rows) and no contention for the shared output directory -- a projection from the "
                                                   "slowest emulated rank, not a measurement of configs[3]; no N > 1 run has ever happened on hardware" % nbins}
-        out["gene_front_end"] = gene_front_end()
-        out["gene_calling"] = gene_calling(workdir)
+        if not args.no_genes:
+            out["gene_front_end"] = gene_front_end()
+            out["gene_calling"] = gene_calling(workdir)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_cfg3(w, binIds, files, lin, args.cpu_baseline_seconds, args.cpu_baseline_threads)
         else:

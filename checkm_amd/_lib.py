@@ -218,9 +218,10 @@ class Context(object):
             load().ckm_ctx_destroy(self.h)
             self.h = C.c_void_p()
 
-    def reserve(self, pairs, model_positions):
-        """Start allocating the workspace a search of that size will ask for, in the background (ckm_ctx_reserve)."""
-        _chk(load().ckm_ctx_reserve(self.h, int(pairs), float(model_positions)))
+    def reserve(self, pairs, cells):
+        """Start allocating the workspace a search of that size will ask for, in the background (ckm_ctx_reserve: `cells` = sum over
+        the bins, over the models a bin is scanned against, of (Mp + 64) * Mp, Mp the model length padded to 64)."""
+        _chk(load().ckm_ctx_reserve(self.h, int(pairs), float(cells)))
 
     def stats(self):
         st = SearchStats()

@@ -55,7 +55,9 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     if (const char *e = getenv("CKM_WORKERS")) ctx->nclasses = std::max(1, std::min(NWORKERS, atoi(e)));
     ctx->nworkers = ctx->nclasses * ctx->ngroups;
-    int host_threads = std::max(1, std::min(8, (int)std::thread::hardware_concurrency()));
+    // 8 threads, or an eighth of the machine up to 16: eight contexts (one per GPU) must fit the node's cores together
+    const int hw = (int)std::thread::hardware_concurrency();
+    int host_threads = std::max(1, std::min(hw, std::max(8, std::min(16, hw / 8))));
     if (const char *e = getenv("CKM_HOST_THREADS")) host_threads = std::max(1, std::min(64, atoi(e)));
     size_t fre = 0, tot = 0;
     size_t budget = (size_t)8 << 30;
@@ -96,20 +98,20 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
       memset(&w.stats, 0, sizeof(w.stats));
       w.ws_budget = budget;
       if (getenv("CKM_WS_VMM") && atoi(getenv("CKM_WS_VMM")) != 0) { w.ws.vmm = true; w.ws.va_bytes = budget + ((size_t)8 << 30); }   // (opt-in until it has run the whole GPU suite)
-      if (const char *e = getenv("CKM_WS_PER_MP")) w.caps.ws_per_mp = (float)atof(e);     // first workspace size of the device-driven cascade (bytes per pair x padded model length)
+      if (const char *e = getenv("CKM_WS_PER_CELL")) w.caps.ws_per_cell = (float)atof(e);  // first workspace size of the device-driven cascade (bytes per expected cell, ckm_search.hip)
       w.pool.reset(new HostPool(host_threads));
     }
     *out = ctx.release();
   });
 }
 
-extern "C" int ckm_ctx_reserve(ckm_ctx *ctx, uint64_t pairs, double model_positions) {
+extern "C" int ckm_ctx_reserve(ckm_ctx *ctx, uint64_t pairs, double cells) {
   return guarded([&] {
     if (!ctx) throw Error(CKM_EINVAL, "ctx is NULL");
     ctx->settle();
     Worker &w = ctx->w[0];
     // the estimate ckm_search itself makes (ckm_search.hip: cascade_dev), for one lane
-    const uint64_t est = (uint64_t)(model_positions * (double)w.caps.ws_per_mp + (double)pairs * 24.0) + ((uint64_t)256 << 20);
+    const uint64_t est = (uint64_t)(1.05 * cells * (double)w.caps.ws_per_cell + (double)pairs * 24.0) + ((uint64_t)256 << 20);
     const size_t want = (size_t)std::min<uint64_t>(std::max<uint64_t>(est, (uint64_t)1 << 30), (uint64_t)w.ws_budget);
     if (w.ws.cap >= want) return;
     const int device = ctx->device;

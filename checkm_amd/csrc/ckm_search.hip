@@ -659,16 +659,19 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   grow(cp.events_e, std::max<uint64_t>(1 << 16, (uint64_t)cp.ework * 16));
   cp.hens = std::max<uint64_t>(cp.hens, (uint64_t)cp.rwork * (256 + ENS_NSAMPLES * 16 * 4 + 1024));
   // the float workspace: an estimate from the pairs (special rows of ~0.3 % of them, matrices of ~0.06 %), within the lane's budget
-  double mp_sum = 0.0;
+  // the float workspace, estimated from the cells the search is expected to fill: a marker model finds about one domain in a bin it is
+  // scanned against, and a domain costs its envelope's matrix (about M rows of Mp floats, three arrays in place) -- so the demand follows
+  // sum over models of (bins scanned against the model) x (Mp + 64) x Mp, whatever the number of ORFs in those bins and whichever kind
+  // of search it is (43 phylogenetic markers against hundreds of bins, or a lineage's hundreds of models against a few bins).  Rounds
+  // 2-4 priced it per (pair x model position), which follows the ORF count instead: one factor could not fit both kinds (round 3: 156 GB
+  // allocated for 76 GB used), two factors still overshot 2x.  Measured on the 1000-bin workload (profiles/r04r_workspace_per_cell.txt):
+  // 9.78-9.82 B per cell where every model is present in every bin (the 43 phylogenetic markers), 4.1-4.7 where about half of a
+  // lineage's models are; the first estimate is 12 B (the first kind + 20 %).  A search that outgrows the estimate falls back once
+  // (deferred regions) and leaves its measured bytes per cell (+15 %) for the next calls.
+  double cell_sum = 0.0;
   {
-    for (auto &mw : mws) mp_sum += (double)mw.npairs * (double)(p->prof[mw.model].fbQ * NL);
-    // bytes per (pair x padded model length): ~1e-4 envelopes per pair x 5 arrays x ~250 rows x 4 B to begin with (marker genes are a few
-    // hundred of a bin's thousands of ORFs); a search that outgrows it falls back once and the factor grows for the next calls
-    // two estimates, by the kind of search: a few models against every sequence (the tree pass: 43 phylogenetic markers, one planted in
-    // every bin -- dense hits) asks for ten times the bytes per position that a lineage's hundreds of models do; one factor learned on the
-    // first kind sized the second kind's workspace at the budget cap (round 3: 156 GB allocated for 76 GB used)
-    float &ws_factor = mws.size() <= 64 ? cp.ws_per_mp_dense : cp.ws_per_mp;
-    const uint64_t est = (uint64_t)(mp_sum * ws_factor + (double)total_pairs * 24.0) + ((uint64_t)256 << 20);
+    for (auto &mw : mws) { const double Mp = (double)(p->prof[mw.model].fbQ * NL); cell_sum += (double)model_bins[mw.model].size() * (Mp + 64.0) * Mp; }
+    const uint64_t est = (uint64_t)(cell_sum * cp.ws_per_cell + (double)total_pairs * 24.0) + ((uint64_t)256 << 20);
     const size_t want = (size_t)std::min<uint64_t>(std::max<uint64_t>(est, (uint64_t)1 << 30), (uint64_t)ctx->ws_budget);
     if (ctx->ws.cap < want) ctx->ws.ensure(want);
   }
@@ -909,10 +912,11 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   st.ws_cap_bytes = ctx->ws.cap; st.ws_used_bytes = (std::min<uint64_t>(h_tops[0], cd0.ws_cap) + h_tops[2]) * 4;
   // the bump allocator counts every request, granted or not: after an overflow the search's whole demand is known, and the next one of its
   // kind gets that (+15 %) instead of a blind x1.5
-  if (h_tops[2] > cd0.ws2_cap) {
-    float &f = mws.size() <= 64 ? cp.ws_per_mp_dense : cp.ws_per_mp;
-    f = std::max(f, (float)(1.15 * (double)(h_tops[2] + cd0.ws_cap) * 4.0 / std::max(mp_sum, 1.0)));
-  }
+  if (h_tops[2] > cd0.ws2_cap)
+    cp.ws_per_cell = std::max(cp.ws_per_cell, (float)(1.15 * (double)(h_tops[2] + cd0.ws_cap) * 4.0 / std::max(cell_sum, 1.0)));
+  if (tr) fprintf(stderr, "ckm-trace w%d workspace: %.3f GB held, %.3f GB asked for by this search (zone 1 %.3f of %.3f, zone 2 %.3f of %.3f), %.3e cells -> %.2f B per cell (estimate %.2f)\n", ctx->id,
+                  (double)ctx->ws.cap / 1e9, (double)(h_tops[0] + h_tops[2]) * 4 / 1e9, (double)h_tops[0] * 4 / 1e9, (double)cd0.ws_cap * 4 / 1e9, (double)h_tops[2] * 4 / 1e9,
+                  (double)cd0.ws2_cap * 4 / 1e9, cell_sum, (double)(h_tops[0] + h_tops[2]) * 4 / std::max(cell_sum, 1.0), (double)cp.ws_per_cell);
   if (!fits) {
     if (getenv("CKM_TRACE")) fprintf(stderr, "ckm-trace w%d device cascade did not fit (status 0x%x): host-driven cascade for this lane\n", ctx->id, status);
     return 1;
@@ -927,13 +931,19 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   EnvOut *h_envout = pin_table<EnvOut>(ctx->h_envout, n_ework);
   ScaleEvent *h_events_f = pin_table<ScaleEvent>(ctx->h_events_f, n_evf), *h_events_e = pin_table<ScaleEvent>(ctx->h_events_e, n_eve);
   float *h_hens = pin_table<float>(ctx->h_hens, n_hens);
-  if (n_pass) HIPCHK(hipMemcpyAsync(h_pass, cd.h_pass, (size_t)n_pass * sizeof(PassRec), hipMemcpyDeviceToHost, ms));
-  if (n_reg) HIPCHK(hipMemcpyAsync(h_reg, cd.h_reg, (size_t)n_reg * sizeof(RegionRec), hipMemcpyDeviceToHost, ms));
-  if (n_ework) HIPCHK(hipMemcpyAsync(h_envout, d_envout, (size_t)n_ework * sizeof(EnvOut), hipMemcpyDeviceToHost, ms));
-  if (n_evf) HIPCHK(hipMemcpyAsync(h_events_f, d_events_f, (size_t)n_evf * sizeof(ScaleEvent), hipMemcpyDeviceToHost, ms));
-  if (n_eve) HIPCHK(hipMemcpyAsync(h_events_e, d_events_e, (size_t)n_eve * sizeof(ScaleEvent), hipMemcpyDeviceToHost, ms));
-  if (n_hens) HIPCHK(hipMemcpyAsync(h_hens, d_hens, (size_t)n_hens * sizeof(float), hipMemcpyDeviceToHost, ms));
-  HIPCHK(hipStreamSynchronize(ms));
+  // (on the priority stream, which is a hardware queue of this context's own: the normal-priority streams of all the contexts of a process
+  //  share 16 hardware queues, and whichever of them `ms` shares with another context's streams is held by that context's queued SSV
+  //  launches and waiting chain kernels for its whole SSV phase -- measured: these six copies ran 214 ms after the drain, at the end of
+  //  the other context's SSV phase, and this context was then 77 ms late for its own turn, every turn: profiles/r04n_timeline_cfg3.txt.
+  //  The host has just waited for `ms`, so the copies need no event.)
+  hipStream_t rs = ctx->late[0];
+  if (n_pass) HIPCHK(hipMemcpyAsync(h_pass, cd.h_pass, (size_t)n_pass * sizeof(PassRec), hipMemcpyDeviceToHost, rs));
+  if (n_reg) HIPCHK(hipMemcpyAsync(h_reg, cd.h_reg, (size_t)n_reg * sizeof(RegionRec), hipMemcpyDeviceToHost, rs));
+  if (n_ework) HIPCHK(hipMemcpyAsync(h_envout, d_envout, (size_t)n_ework * sizeof(EnvOut), hipMemcpyDeviceToHost, rs));
+  if (n_evf) HIPCHK(hipMemcpyAsync(h_events_f, d_events_f, (size_t)n_evf * sizeof(ScaleEvent), hipMemcpyDeviceToHost, rs));
+  if (n_eve) HIPCHK(hipMemcpyAsync(h_events_e, d_events_e, (size_t)n_eve * sizeof(ScaleEvent), hipMemcpyDeviceToHost, rs));
+  if (n_hens) HIPCHK(hipMemcpyAsync(h_hens, d_hens, (size_t)n_hens * sizeof(float), hipMemcpyDeviceToHost, rs));
+  HIPCHK(hipStreamSynchronize(rs));
   CKM_TRACE_PT("results copied");
   const PassRec *pass = h_pass;
   const RegionRec *reg = h_reg;

@@ -14,14 +14,18 @@ void wcopy(Worker *w, void *dst, const void *src, size_t bytes, hipMemcpyKind ki
   if (!bytes) return;
   std::lock_guard<std::mutex> lock(w->wstage_mutex);
   w->wstage.ensure(bytes);
+  // in the rounds after a search's drain, on the priority stream like the kernels of those rounds: the hardware queue underneath the
+  // worker's normal stream is shared with other contexts' streams and held by their queued launches for a whole SSV phase (measured:
+  // the four result copies of a 12 ms round returned 190 ms later, every search of one lane, profiles/r04p_lane_trace.txt)
+  hipStream_t st = w->late_round ? w->late[0] : w->stream;
   if (kind == hipMemcpyDeviceToHost) {
-    HIPCHK(hipMemcpyAsync(w->wstage.p, src, bytes, kind, w->stream));
-    HIPCHK(hipStreamSynchronize(w->stream));
+    HIPCHK(hipMemcpyAsync(w->wstage.p, src, bytes, kind, st));
+    HIPCHK(hipStreamSynchronize(st));
     memcpy(dst, w->wstage.p, bytes);
   } else {
     memcpy(w->wstage.p, src, bytes);
-    HIPCHK(hipMemcpyAsync(dst, w->wstage.p, bytes, kind, w->stream));
-    HIPCHK(hipStreamSynchronize(w->stream));
+    HIPCHK(hipMemcpyAsync(dst, w->wstage.p, bytes, kind, st));
+    HIPCHK(hipStreamSynchronize(st));
   }
 }
 

@@ -295,19 +295,20 @@ class MarkerGeneFinder(object):
         tot_lock = threading.Lock()
         # the float workspace of a batch is tens of GB the first time a context meets one (seconds of hipMalloc): start allocating it
         # now, beside the reading of the first batches' FASTA files (ckm_ctx_reserve; the search waits for it)
-        padded = [64 * ((h["leng"] + 63) // 64) for h in heads]
+        fb_classes = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64)        # rows of 64 floats per model node block (csrc/ckm_host.h: kFbQ)
+        padded = [64 * next((q for q in fb_classes if 64 * q >= h["leng"]), 64) for h in heads]
         pos_cache = {}
-        need = []                                  # per batch: (pairs, pairs x padded model positions)
+        need = []                                  # per batch: (pairs, expected cells -- include/checkm_hip.h: ckm_ctx_reserve)
+        cells_of = [(x + 64) * x for x in padded]
         for batch in batches:
-            pairs = mpos = 0
+            pairs = cells = 0
             for i in batch:
                 m = models_of.get(binIds[i]) if models_of else None
                 k = id(m)
                 if k not in pos_cache:
-                    pos_cache[k] = (len(m), sum(padded[x] for x in m)) if m is not None else (len(padded), sum(padded))
-                norf = max(1, sizes[i] // 320)
-                pairs += norf * pos_cache[k][0]; mpos += norf * pos_cache[k][1]
-            need.append((pairs, mpos))
+                    pos_cache[k] = (len(m), sum(cells_of[x] for x in m)) if m is not None else (len(padded), sum(cells_of))
+                pairs += max(1, sizes[i] // 320) * pos_cache[k][0]; cells += pos_cache[k][1]
+            need.append((pairs, cells))
         for j, (c, _prof) in enumerate(lanes):
             mine = need[j::len(lanes)]             # the largest batch this lane will meet (the first ones are small: plan_batches)
             if mine:

@@ -159,12 +159,14 @@ int ckm_hits_write_alignments(ckm_ctx *ctx, const ckm_hits *h, const ckm_profile
 
 int ckm_last_search_stats(const ckm_ctx *ctx, ckm_search_stats *out);
 
-/* Starts allocating, on a background thread, the float workspace a search of `pairs` (ORF, model) pairs with a summed padded model
- * length of `model_positions` (sum over pairs of 64 * ceil(M / 64)) will ask for, so that the allocation (tens of GB: seconds of
- * hipMalloc) runs beside the caller's reading of FASTA files and profile databases instead of inside the first ckm_search.
- * Returns at once; ckm_search / ckm_align / the diagnostics wait for it.  Replaces nothing of the reference (one hmmsearch process
- * per bin allocates per process, checkm/hmmer.py:70): it exists because one context serves a whole batch of bins. */
-int ckm_ctx_reserve(ckm_ctx *ctx, uint64_t pairs, double model_positions);
+/* Starts allocating, on a background thread, the float workspace a search of `pairs` (ORF, model) pairs will ask for, so that the
+ * allocation (tens of GB: seconds of hipMalloc) runs beside the caller's reading of FASTA files and profile databases instead of
+ * inside the first ckm_search.  `cells` is what ckm_search sizes the workspace from: the sum, over the bins of the search and over the
+ * models each bin is scanned against, of (Mp + 64) * Mp with Mp = 64 * ceil(M / 64) -- a marker model finds about one domain per bin
+ * and a domain costs its envelope's matrices.  Returns at once; ckm_search / ckm_align / the diagnostics wait for it.  Replaces nothing
+ * of the reference (one hmmsearch process per bin allocates per process, checkm/hmmer.py:70): it exists because one context serves a
+ * whole batch of bins. */
+int ckm_ctx_reserve(ckm_ctx *ctx, uint64_t pairs, double cells);
 
 /* ---- the reduction --------------------------------------------------------------------------
  * Replaces ResultsParser.parseBinHits -> ResultsManager.{vetHit,addHit} -> PFAM.filterHitsFromSameClan

@@ -30,12 +30,12 @@ for item in "$@"; do
     bench)  nbench=$((nbench + 1)); python bench.py ${arg//,/ } > "$OUT/bench$nbench.json" 2> "$OUT/bench$nbench.err"; tail -c 600 "$OUT/bench$nbench.json" ;;
     stats3) (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats3" -o cfg3 -- python "$ROOT/bench.py" $C3 --bins-total "${arg:-192}" --steps 1 --warmup 1 > "$OUT/stats3.json" 2> "$OUT/stats3.err") ;;
     trace3) (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace3" -o cfg3 -- python "$ROOT/bench.py" $C3 --bins-total "${arg:-1000}" --steps 2 --warmup 1 > "$OUT/trace3.json" 2> "$OUT/trace3.err")
-            python tools/occupancy_timeline.py "$OUT/trace3" last-step > "$OUT/timeline3.txt" 2>&1; head -12 "$OUT/timeline3.txt" ;;
+            python tools/occupancy_timeline.py "$OUT"/trace3/*_kernel_trace.csv 50 last-step > "$OUT/timeline3.txt" 2>&1; head -12 "$OUT/timeline3.txt" ;;
     pmc3)   for pass in "${PMC_PASSES[@]}"; do set -- $pass; name=$1; shift
-              (cd /tmp && CKM_BENCH_SKIP_WARM=1 CKM_WS_PER_MP=5 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/pmc3_$name" -o p -- python "$ROOT/bench.py" $C3 --bins-total "${arg:-48}" --steps 1 --warmup 0 > "$OUT/pmc3_$name.json" 2> "$OUT/pmc3_$name.err")
+              (cd /tmp && CKM_BENCH_SKIP_WARM=1 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/pmc3_$name" -o p -- python "$ROOT/bench.py" $C3 --bins-total "${arg:-48}" --steps 1 --warmup 0 > "$OUT/pmc3_$name.json" 2> "$OUT/pmc3_$name.err")
             done ;;
     pmc2)   for pass in "${PMC_PASSES[@]}"; do set -- $pass; name=$1; shift
-              (cd /tmp && CKM_WS_PER_MP=5 CKM_BENCH_STEADY=0 CKM_BENCH_FROM_HOST=0 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/pmc_$name" -o p -- python "$ROOT/bench.py" --config cfg2 --steps 1 --warmup 0 --no-cpu-baseline --no-verify > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err")
+              (cd /tmp && CKM_BENCH_STEADY=0 CKM_BENCH_FROM_HOST=0 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/pmc_$name" -o p -- python "$ROOT/bench.py" --config cfg2 --steps 1 --warmup 0 --no-cpu-baseline --no-verify > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err")
             done ;;
     valu)   (cd tools/ubench && hipcc --offload-arch=gfx950 -O3 -o valu_rates valu_rates.hip 2>/dev/null; ./valu_rates) > "$OUT/valu_rates.txt" 2>&1; tail -20 "$OUT/valu_rates.txt" ;;
     *)      echo "unknown item: $item" ;;

@@ -85,10 +85,10 @@ def one(tag):
                 f.write("%-34s %8d %12.2f %12.1f\n" % (n, c, t / 1e6, a / 1e3))
     if os.path.exists(os.path.join(src, "pmc3_sq.json")):
         pmc_files(src, dst, "pmc3_", "cfg3_", last_json(os.path.join(src, "pmc3_sq.json")),
-                  "CKM_BENCH_SKIP_WARM=1 CKM_WS_PER_MP=5 python bench.py --config cfg3 --bins-total 48 --steps 1 --warmup 0 --no-cpu-baseline --no-cfg2 --no-emulation --no-verify   (a 48-bin SAMPLE of configs[2])")
+                  "CKM_BENCH_SKIP_WARM=1 python bench.py --config cfg3 --bins-total 48 --steps 1 --warmup 0 --no-cpu-baseline --no-cfg2 --no-emulation --no-verify   (a 48-bin SAMPLE of configs[2])")
     if os.path.exists(os.path.join(src, "pmc_sq.json")):
         pmc_files(src, dst, "pmc_", "", last_json(os.path.join(src, "pmc_sq.json")),
-                  "CKM_WS_PER_MP=5 CKM_BENCH_STEADY=0 CKM_BENCH_FROM_HOST=0 python bench.py --config cfg2 --steps 1 --warmup 0 --no-cpu-baseline --no-verify")
+                  "CKM_BENCH_STEADY=0 CKM_BENCH_FROM_HOST=0 python bench.py --config cfg2 --steps 1 --warmup 0 --no-cpu-baseline --no-verify")
 
 
 if __name__ == "__main__":
