@@ -241,7 +241,7 @@ def lineage_pass(w, binIds, files, lin, out, rank):
     tot = {}
     for tbl in (DefaultValues.HMMER_TABLE_PHYLO_OUT, DefaultValues.HMMER_TABLE_OUT):
         for k, v in mgf.SCAN_CACHE[(os.path.abspath(out), tbl)]["totals"].items():
-            tot[k] = tot.get(k, 0) + v
+            tot[k] = max(tot.get(k, 0), v) if k in ("ws_cap_bytes", "ws_used_bytes") else tot.get(k, 0) + v
     if rank == 0:
         os.makedirs(os.path.join(out, "storage"), exist_ok=True)
         with open(os.path.join(out, "storage", DefaultValues.BIN_STATS_OUT), "w") as f:
@@ -992,7 +992,10 @@ def bench_cfg3(args, env):
                                       "tree_find": parts["tree_find_s"], "analyze_find": parts["analyze_find_s"], "qa": parts["qa_s"],
                                       "note": "ingest/search/write are summed over the two scan lanes (they overlap in time); tree_find + analyze_find + qa = the step"},
            "searches_rank0": int(tot.get("searches", 0)), "cascade_fallback_lanes_rank0": int(tot.get("cascade_fallback_lanes", 0)),
-           "workspace_rank0": {"allocated_bytes_max": int(tot.get("ws_cap_bytes", 0)), "high_water_bytes_max": int(tot.get("ws_used_bytes", 0))},
+           "workspace_rank0": {"allocated_bytes_max": int(tot.get("ws_cap_bytes", 0)), "high_water_bytes_max": int(tot.get("ws_used_bytes", 0)),
+                               "note": "per context (find() keeps two on the device, each with a workspace of its own): the largest workspace a context held and the most a "
+                                       "single search asked of it, over the searches of the last timed step.  Rounds 3-4 printed the tree pass's and the analyze pass's maxima "
+                                       "ADDED UP under these names (131.7 / 63.2 GB in round 4's early runs were 65.8 + 65.8 and 15.2 + 48.0)"},
            "device_state_timed_region": device_state, "setup_s": {"world_and_files": t_setup}}
     if emu:
         out["emulated_rank"] = "%d/%d" % emu

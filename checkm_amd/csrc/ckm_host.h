@@ -238,7 +238,7 @@ struct Worker {
   std::unique_ptr<HostPool> pool;         // host threads of this worker
   // ---- device-driven cascade (ckm_cascade.hip): tables, queues and result buffers of this lane; capacities only grow ----
   struct CascadeCaps { uint32_t fwork = 0, ework = 0, rwork = 0, pass = 0, reg = 0, events_f = 0, events_e = 0; uint64_t hens = 0;
-                       uint32_t div_cand = 12, div_nores = 48, div_fwork = 160, div_ework = 256, div_rwork = 32768; float ws_per_cell = 12.f; } caps;   // per-group tables hold pairs / div entries
+                       uint32_t div_cand = 12, div_nores = 48, div_fwork = 160, div_ework = 256, div_rwork = 32768; float ws_per_cell = 11.f; } caps;   // per-group tables hold pairs / div entries
   DevBuf c_cnt, c_cand, c_nores, c_bias, c_vfast, c_vexact, c_vflag, c_route, c_vq, c_vxq, c_fq, c_bq, c_eq, c_rq, c_fwork, c_ework, c_rwork, c_ens, c_ensq,
          c_fout_f, c_fout_e, c_fout_r, c_rerr_e, c_rerr_r, c_tops, c_events_r, c_pass, c_reg, c_hens, c_envout, c_events_f, c_events_e;
   PinnedBuf h_cnt, h_pass, h_reg, h_envout, h_events_f, h_events_e, h_hens, h_tops;

@@ -666,7 +666,7 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   // 2-4 priced it per (pair x model position), which follows the ORF count instead: one factor could not fit both kinds (round 3: 156 GB
   // allocated for 76 GB used), two factors still overshot 2x.  Measured on the 1000-bin workload (profiles/r04r_workspace_per_cell.txt):
   // 9.78-9.82 B per cell where every model is present in every bin (the 43 phylogenetic markers), 4.1-4.7 where about half of a
-  // lineage's models are; the first estimate is 12 B (the first kind + 20 %).  A search that outgrows the estimate falls back once
+  // lineage's models are; the first estimate is 11 B (the first kind + 12 %).  A search that outgrows the estimate falls back once
   // (deferred regions) and leaves its measured bytes per cell (+15 %) for the next calls.
   double cell_sum = 0.0;
   {

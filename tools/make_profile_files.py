@@ -25,9 +25,13 @@ def last_json(path):
     return json.loads(open(path).read().strip().split("\n")[-1])
 
 
+NOT_THE_STEP = ("gene_", "orf_")      # kernels of bench.py's gene-calling side legs, when a collection ran them in the same process: not part of a cfg3 step
+
+
 def counter_total(src, d, counter, only=None):
     f = os.path.join(src, d, "p_counter_collection.csv")
-    return sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and (only is None or only in r["Kernel_Name"]))
+    return sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and (only is None or only in r["Kernel_Name"])
+               and not any("ckm::" + x in r["Kernel_Name"] for x in NOT_THE_STEP))
 
 
 def pmc_files(src, dst, prefix, what, line, cmd):
@@ -48,7 +52,7 @@ def pmc_files(src, dst, prefix, what, line, cmd):
                "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); algorithmic bytes = sum over (model, sequence) pairs of (L + 12)",
                "valu_insts": valu, "lds_insts": lds, "ssv_ms_under_pmc": ms,
                "all_kernels": {"valu_insts": va, "FETCH_SIZE_KB": fa, "WRITE_SIZE_KB": wa, "hbm_bytes_corrected": 2 * fa * 1024 + wa * 1024,
-                               "note": "every kernel of the step (SSV + the chains + ensembles + copies), same passes"}},
+                               "note": "every kernel of the step (SSV + the chains + ensembles + copies), same passes; the gene_* / orf_* kernels of bench.py's gene-calling side legs, which ran in the same process, are left out"}},
               open(dst(what + "ssv_traffic.json"), "w"), indent=1)
 
 
