@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg5"], default="cfg3")
+    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg5", "genes"], default="cfg3")
     ap.add_argument("--budget-seconds", type=float, default=float(os.environ.get("CKM_BENCH_BUDGET_S", "240")),
                     help="cfg3: wall-clock budget of the timed region; the steps actually run are min(--steps, budget / estimated step)")
     ap.add_argument("--emulate-rank", default=None, help="cfg3: R/W -- run as rank R of W on this one GPU (no collectives)")
@@ -325,6 +325,8 @@ def main():
     env = Env(args)
     if args.config == "cfg3":
         out = bench_cfg3(args, env)
+    elif args.config == "genes":            # the gene-calling side legs of the cfg3 line alone (not a BASELINE.json configuration)
+        out = {"gene_front_end": gene_front_end(), "gene_calling": gene_calling(env.workdir, cpu_bins=0 if args.no_cpu_baseline else 8)} if env.rank == 0 else None
     elif args.config == "cfg5":
         out = bench_cfg5(args, env)
     else:
@@ -847,10 +849,13 @@ def gene_calling(workdir, nbins=192, cpu_bins=8):
     out = {"value": nbins / dt * 3600.0, "unit": "bins/hour", "bins": nbins, "bases": bases, "genes_written": ngenes, "seconds": dt,
            "bases_per_s": bases * 2 / dt, "tables_per_bin": 2, "table_4_chosen": sum(1 for v in res.values() if v[0] == 4),
            "last_call_kernel_ms": {k: st[k] for k in ("ms_dp_train", "ms_score", "ms_dp_find")}, "last_call_wall_ms": {"to_nodes": st["ms_nodes"], "total": st["ms_total"]},
-           "setup_s": t_setup,
+           "setup_s": t_setup, "python_phases_s": dict(geneFinder.call_bin_files.last_phases),
            "note": "from nucleotide FASTA files to genes.faa / genes.gff, tables 11 and 4 for every bin in two batched device calls per <= 1 Gbase of bins; the dynamic "
-                   "programs are latency-bound (one wavefront per sequence, nodes in order, 64 predecessor candidates per step), the codon-flag kernel is the "
+                   "programs are latency-bound (one workgroup per sequence, nodes in order, 256 predecessor candidates per step), the codon-flag kernel is the "
                    "HBM-bound one (gene_front_end.roofline); single-genome mode only (-p meta is not built)"}
+    if cpu_bins <= 0:
+        out["cpu_baseline"] = None
+        return out
     try:
         from oracle import genes as og
         sample = [geneFinder.read_contigs(jobs[b][0]) for b in range(min(cpu_bins, nbins))]

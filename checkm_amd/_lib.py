@@ -524,7 +524,8 @@ def call_genes(ctx, bins, trans_table=11, closed=False, mask=True):
             out["contig"] = out["contig"] - bf[out["bin"]]
         po = arr(cols.prot_off, shape=(n + 1,)).copy() if n else np.zeros(1, dtype=np.uint64)
         blob = C.string_at(cols.prot, int(po[-1])) if n else b""
-        out["proteins"] = [blob[int(po[k]):int(po[k + 1])].decode() for k in range(n)]
+        txt, pl = blob.decode("ascii"), po.tolist()
+        out["proteins"] = [txt[a:b] for a, b in zip(pl[:-1], pl[1:])]
         per_bin = {f: (arr(getattr(cols, "bin_" + f), shape=(nb,)).copy() if nb else np.zeros(0)) for f in ("trained", "uses_sd", "gc", "bases", "coding", "nodes")}
         stats = dict(ms_nodes=cols.ms_nodes, ms_dp_train=cols.ms_dp_train, ms_score=cols.ms_score, ms_dp_find=cols.ms_dp_find, ms_total=cols.ms_total)
     finally:

@@ -5,7 +5,7 @@
 // Division of the work (one call = one translation table for a batch of bins):
 //   device   start / stop nodes of the bins' training sequences and of their contigs (kernels_orf.hip: one flag pass serves both);
 //            hexamer coding sums and Shine-Dalgarno bins of every start node (kernels_genes.hip); both dynamic programs -- the training
-//            pass over a whole bin and the final pass per contig -- one wavefront per sequence, all sequences of the batch side by side.
+//            pass over a whole bin and the final pass per contig -- one workgroup per sequence, all sequences of the batch side by side.
 //   host     (the context's thread pool, a bin or a contig per task) everything that is a single ordered sweep over a bin's nodes or
 //            bases: node order and -m masks, GC-frame plot and bias, overlapping-start tables, path untangling, hexamer statistics, the
 //            start-site training iterations, node scores, gene records, start tweaks, translation.
@@ -32,14 +32,20 @@ namespace {
 constexpr int G_STOP = 3, MAX_SAM_OVLP = 60, MAX_NODE_DIST = 500, OPER_DIST = 60, MASK_SIZE = 50, GC_WINDOW = 120;
 constexpr double EDGE_BONUS = 0.74, EDGE_UPS = -1.00;
 
+// (field order: what the training iterations sweep over 30-50 times per bin -- kind, position, coding score, SD bins, then the motif --
+//  sits in the first 88 bytes; with the declaration order of the reference's struct a sweep touched two to three cache lines per node and
+//  the start-site training of a 192-bin batch was memory-bound: more threads made it slower)
 struct GNode {
   int32_t type = 0, edge = 0, ndx = 0, strand = 1, stop_val = 0;
-  int32_t star_ptr[3] = {-1, -1, -1}, gc_bias = 0;
-  double gc_score[3] = {0, 0, 0}, cscore = 0, gc_cont = 0;
   int32_t rbs[2] = {0, 0};
+  int32_t gc_bias = 0;
+  double cscore = 0;
+  int32_t star_ptr[3] = {-1, -1, -1}; int32_t traceb = -1;
+  double score = 0;
   int32_t mot_ndx = 0, mot_len = 0, mot_spacer = 0, mot_spacendx = 0; double mot_score = 0;
+  double gc_score[3] = {0, 0, 0}, gc_cont = 0;
   double uscore = 0, tscore = 0, rscore = 0, sscore = 0;
-  int32_t traceb = -1, tracef = -1, ov_mark = -1; double score = 0; int32_t elim = 0;
+  int32_t tracef = -1, ov_mark = -1, elim = 0;
 };
 struct GTrain {
   double gc = 0; int trans_table = 11; double st_wt = 4.35; double bias[3] = {0, 0, 0}; double type_wt[3] = {0, 0, 0}; int uses_sd = 0;
@@ -104,10 +110,11 @@ void finish_nodes(std::vector<GNode> &nodes, const std::vector<Mask> &masks) {
       nodes.push_back(n);
     }
   }
-  std::sort(nodes.begin(), nodes.end(), [](const GNode &x, const GNode &y) {
+  auto before = [](const GNode &x, const GNode &y) {
     if (x.ndx != y.ndx) return x.ndx < y.ndx;
     return x.strand > y.strand;                                  // forward strand first
-  });
+  };
+  if (!std::is_sorted(nodes.begin(), nodes.end(), before)) std::sort(nodes.begin(), nodes.end(), before);      // (the caller hands them over in order; the filter above keeps it)
 }
 
 std::vector<int> calc_most_gc_frame(const GSeq &s) {
@@ -478,6 +485,33 @@ void update_motif_counts(MotTab &mcnt, double &zero, const GSeq &s, const GNode 
     }
   } else mcnt.at(n.mot_len - 3, n.mot_spacendx, n.mot_ndx) += 1.0;
 }
+// The 52 upstream words of a start node (lengths 6..3, thirteen positions each) do not change over the 20 training iterations: they are
+// read off the sequence once per node (0xffff: before the sequence start) and every iteration only looks the weights up, in the order of
+// find_best_upstream_motif (so the first maximum wins as there).  Entry k = (3 - i) * 13 + d: word length i + 3 at start - 18 - i + d.
+constexpr int MOT_WORDS = 52;
+inline int mot_sp_of_d(int d) { return d <= 2 ? 3 : d <= 4 ? 2 : d >= 11 ? 1 : 0; }       // spacer_ndx(start - 18 - i + d, start, i)
+void upstream_words(const GSeq &s, const GNode &n, uint16_t *w) {
+  const int start = n.strand == 1 ? n.ndx : s.slen - 1 - n.ndx;
+  int k = 0;
+  for (int i = 3; i >= 0; --i) for (int d = 0; d <= 12; ++d) { const int j = start - 18 - i + d; w[k++] = j < 0 ? (uint16_t)0xffff : (uint16_t)s.mer(n.strand, i + 3, j); }
+}
+void find_best_upstream_motif_w(const GTrain &t, const uint16_t *w, GNode &n, int stage) {
+  int max_spacer = 0, max_spacendx = 0, max_len = 0, max_ndx = 0; double max_sc = -100.0;
+  int k = 0;
+  for (int i = 3; i >= 0; --i) for (int d = 0; d <= 12; ++d, ++k) {
+    if (w[k] == 0xffff) continue;
+    const int sp = mot_sp_of_d(d), index = w[k];
+    const double score = t.mw(i, sp, index);
+    if (score > max_sc) { max_sc = score; max_spacendx = sp; max_spacer = 15 - d; max_ndx = index; max_len = i + 3; }
+  }
+  if (stage == 2 && (max_sc == -4.0 || max_sc < t.no_mot + 0.69)) { n.mot_ndx = 0; n.mot_len = 0; n.mot_spacendx = 0; n.mot_spacer = 0; n.mot_score = t.no_mot; }
+  else { n.mot_ndx = max_ndx; n.mot_len = max_len; n.mot_spacendx = max_spacendx; n.mot_spacer = max_spacer; n.mot_score = max_sc; }
+}
+void update_motif_counts_stage0_w(MotTab &mcnt, double &zero, const uint16_t *w, const GNode &n) {
+  if (n.mot_len == 0) { zero += 1.0; return; }
+  int k = 0;
+  for (int i = 3; i >= 0; --i) for (int d = 0; d <= 12; ++d, ++k) { if (w[k] == 0xffff) continue; for (int q = 0; q < 4; ++q) mcnt.at(i, q, w[k]) += 1.0; }
+}
 void build_coverage_map(MotTab &real, std::vector<int> &good, double ng) {
   auto G = [&](int a, int b, int c) -> int & { return good[((size_t)a * 4 + b) * 4096 + c]; };
   const double thresh = 0.2; int decomp[3];
@@ -510,13 +544,18 @@ void train_starts_nonsd(const GSeq &s, std::vector<GNode> &nod, GTrain &t) {
   std::fill(t.mot_wt.begin(), t.mot_wt.end(), 0.0); t.no_mot = 0.0;
   memset(t.ups_comp, 0, sizeof(t.ups_comp));
   type_bg(nod, tbg);
+  std::vector<int32_t> wof(nn, -1); std::vector<uint16_t> words;
+  { size_t ns = 0; for (int j = 0; j < nn; ++j) if (!(nod[j].type == G_STOP || nod[j].edge == 1)) wof[j] = (int32_t)(ns++);
+    words.resize(ns * MOT_WORDS);
+    for (int j = 0; j < nn; ++j) if (wof[j] >= 0) upstream_words(s, nod[j], words.data() + (size_t)wof[j] * MOT_WORDS); }
   for (int it = 0; it < 20; ++it) {
     stage = it < 4 ? 0 : it < 12 ? 1 : 2;
     mbg.zero(); zbg = 0.0;
     for (int j = 0; j < nn; ++j) {
       if (nod[j].type == G_STOP || nod[j].edge == 1) continue;
-      find_best_upstream_motif(t, s, nod[j], stage);
-      update_motif_counts(mbg, zbg, s, nod[j], stage);
+      const uint16_t *w = words.data() + (size_t)wof[j] * MOT_WORDS;
+      find_best_upstream_motif_w(t, w, nod[j], stage);
+      if (stage == 0) update_motif_counts_stage0_w(mbg, zbg, w, nod[j]); else update_motif_counts(mbg, zbg, s, nod[j], stage);
     }
     sum = zbg;
     for (double x : mbg.v) sum += x;
@@ -733,10 +772,6 @@ struct NodeTable {
   std::vector<double> st_wt_of_seq;
   DevBuf d_bin, d_seq, d_dpmin, d_ndx, d_sv, d_star, d_tb, d_ov, d_strand, d_type, d_edge, d_rbs0, d_rbs1, d_cscore, d_gcb, d_csc, d_rs, d_us, d_score, d_first, d_stwt;
   size_t n() const { return ndx.size(); }
-  void push(uint32_t b, uint32_t s, const GNode &g) {
-    bin.push_back(b); seq.push_back(s); ndx.push_back(g.ndx); stop_val.push_back(g.stop_val); strand.push_back((int8_t)g.strand); type.push_back((uint8_t)g.type); edge.push_back((uint8_t)g.edge);
-  }
-  void pad_to_block(uint32_t b, uint32_t s) { while (ndx.size() % 256) { bin.push_back(b); seq.push_back(s); ndx.push_back(0); stop_val.push_back(0); strand.push_back(1); type.push_back(255); edge.push_back(0); } }
   template <class T> static void up(DevBuf &d, const std::vector<T> &v, hipStream_t st) { d.ensure(std::max<size_t>(64, v.size() * sizeof(T))); if (!v.empty()) HIPCHK(hipMemcpyAsync(d.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st)); }
   void upload_static(hipStream_t st) {
     up(d_bin, bin, st); up(d_seq, seq, st); up(d_ndx, ndx, st); up(d_sv, stop_val, st); up(d_strand, strand, st); up(d_type, type, st); up(d_edge, edge, st);
@@ -785,6 +820,16 @@ extern "C" int ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *co
     Worker *w = &ctx->w[0];
     hipStream_t st = w->stream;
     const double t_begin = now_ms();
+    // most of a call is ordered sweeps on host threads (a bin or a contig per task): a pool of its own for the call.  Measured on a
+    // 256-thread host with two tables side by side (192 bins of 2 Mb, seconds for both): 12 threads 9.4, 16 8.9, 24 9.8, 32 10.1, 48 10.6 --
+    // the sweeps are bound by memory, not by cores.  CKM_GENE_THREADS overrides.
+    int gthreads = std::max(8, std::min(16, (int)std::thread::hardware_concurrency() / 8));
+    if (const char *e = getenv("CKM_GENE_THREADS")) gthreads = std::max(1, std::min(128, atoi(e)));
+    HostPool gpool(gthreads);
+    auto prun = [&](size_t n, size_t chunk, const std::function<void(size_t, size_t)> &f) { gpool.run(n, chunk, f); };
+    const bool tr_on = getenv("CKM_TRACE") != nullptr;
+    auto tp = [&](const char *label) { if (tr_on) fprintf(stderr, "ckm-trace genes table %d %9.1f ms  %s\n", trans_table, now_ms() - t_begin, label); };
+    if (tr_on) fprintf(stderr, "ckm-trace genes table %d: %d host threads (hardware_concurrency %u), %u bins, %u contigs\n", trans_table, gthreads, std::thread::hardware_concurrency(), nbins, ncontigs);
     static const char sep[13] = "TTAATTAATTAA";
     // ---- layout: one training sequence per bin (its contigs joined and, beyond one contig, closed by the separator); contigs are sub-ranges ----
     std::vector<uint64_t> seq_off; std::vector<int32_t> seq_len;          // sequence table: [0, nbins) training sequences, then the contigs
@@ -809,7 +854,7 @@ extern "C" int ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *co
     const uint64_t body = (pos + 63) & ~(uint64_t)63;
     std::vector<uint8_t> ascii(64 + body + 128, (uint8_t)'N'), code(body + 64, (uint8_t)5);
     std::vector<uint64_t> bin_gc_count(nbins, 0);
-    pool_run(w, nbins, 1, [&](size_t lo, size_t hi) {
+    prun(nbins, 1, [&](size_t lo, size_t hi) {
       for (size_t b = lo; b < hi; ++b) {
         const uint32_t c0 = bin_first[b], c1 = bin_first[b + 1]; const bool multi = c1 - c0 > 1;
         uint64_t gcc = 0;
@@ -828,6 +873,7 @@ extern "C" int ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *co
         bin_gc_count[b] = gcc;
       }
     });
+    tp("text packed");
     // ---- device: text, flags, nodes of the training sequences and of the contigs ----
     DevBuf d_ascii, d_flags, d_code, d_off, d_len, d_nodes, d_cnt;
     const uint32_t nseq = nbins + ncontigs;
@@ -854,22 +900,31 @@ extern "C" int ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *co
     raw.resize((size_t)n_all);
     if (n_all) HIPCHK(hipMemcpy(raw.data(), d_nodes.p, (size_t)n_all * sizeof(OrfNodeG), hipMemcpyDeviceToHost));
     const double t_nodes = now_ms();
-    // per sequence: nodes in working order, masks applied
+    tp("nodes on the host");
+    // per sequence: nodes in working order (position, forward strand first), masks applied.  The device appends nodes in no particular order:
+    // they are dealt to their sequences and sorted as the 16-byte records they arrive as (sorting the working structs, ~200 bytes each,
+    // took 2 s of a 192-bin call).
     std::vector<SeqNodes> sn(nseq);
-    {
-      std::vector<uint32_t> cnt(nseq + 1, 0);
-      for (const OrfNodeG &x : raw) cnt[x.contig + 1]++;
-      for (uint32_t s = 0; s < nseq; ++s) sn[s].nodes.reserve(cnt[s + 1]);
-      for (const OrfNodeG &x : raw) { GNode g; g.type = x.type; g.edge = x.edge; g.ndx = x.ndx; g.strand = x.strand_rev ? -1 : 1; g.stop_val = x.stop_val; sn[x.contig].nodes.push_back(g); }
-      raw.clear(); raw.shrink_to_fit();
-    }
     auto gseq = [&](uint32_t s) { GSeq q; q.c = code.data() + seq_off[s]; q.slen = seq_len[s]; return q; };
-    pool_run(w, nseq, 1, [&](size_t lo, size_t hi) {
-      for (size_t s = lo; s < hi; ++s) {
-        std::vector<Mask> m; if (mask_runs) m = find_masks(gseq((uint32_t)s));
-        finish_nodes(sn[s].nodes, m);
-      }
-    });
+    {
+      std::vector<size_t> at(nseq + 1, 0);
+      for (const OrfNodeG &x : raw) at[x.contig + 1]++;
+      for (uint32_t s = 0; s < nseq; ++s) at[s + 1] += at[s];
+      std::vector<OrfNodeG> flat(raw.size());
+      { std::vector<size_t> cur(at.begin(), at.end() - 1); for (const OrfNodeG &x : raw) flat[cur[x.contig]++] = x; }
+      raw.clear(); raw.shrink_to_fit();
+      prun(nseq, 1, [&](size_t lo, size_t hi) {
+        for (size_t s = lo; s < hi; ++s) {
+          OrfNodeG *f0 = flat.data() + at[s], *f1 = flat.data() + at[s + 1];
+          std::sort(f0, f1, [](const OrfNodeG &x, const OrfNodeG &y) { return x.ndx != y.ndx ? x.ndx < y.ndx : x.strand_rev < y.strand_rev; });
+          std::vector<GNode> &nod = sn[s].nodes; nod.resize((size_t)(f1 - f0));
+          for (size_t k = 0; k < nod.size(); ++k) { const OrfNodeG &x = f0[k]; GNode &g = nod[k]; g.type = x.type; g.edge = x.edge; g.ndx = x.ndx; g.strand = x.strand_rev ? -1 : 1; g.stop_val = x.stop_val; }
+          std::vector<Mask> m; if (mask_runs) m = find_masks(gseq((uint32_t)s));
+          finish_nodes(nod, m);
+        }
+      });
+    }
+    tp("nodes sorted, masks applied");
     // ---- training ----
     std::vector<GTrain> tr(nbins);
     std::vector<uint8_t> trained(nbins, 0);
@@ -877,7 +932,7 @@ extern "C" int ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *co
       tr[b].trans_table = trans_table; tr[b].gc = seq_len[b] ? (double)bin_gc_count[b] / (double)seq_len[b] : 0.0;
       trained[b] = bin_total[b] >= 20000 ? 1 : 0;                         // (prodigal refuses to train on less; CheckM switches to -p meta below 100 kb, which is not built)
     }
-    pool_run(w, nbins, 1, [&](size_t lo, size_t hi) {
+    prun(nbins, 1, [&](size_t lo, size_t hi) {
       for (size_t b = lo; b < hi; ++b) {
         if (!trained[b]) continue;
         const GSeq q = gseq((uint32_t)b);
@@ -886,20 +941,40 @@ extern "C" int ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *co
         record_overlapping_starts(sn[b].nodes, tr[b], 0);
       }
     });
+    tp("gc frames, overlapping starts");
     GeneSeqDev sd; sd.txt = d_code.as<uint8_t>(); sd.off = d_off.as<uint64_t>(); sd.len = d_len.as<int32_t>();
     auto build_table = [&](NodeTable &T, bool training, int flag) {
       // training: sequences [0, nbins) of trained bins; else: contigs of trained bins.  Static columns + the dynamic program's inputs.
+      // The layout first (a bin's sequences one behind the other, the bin padded to a multiple of 256 nodes), then the columns, a sequence per task.
+      struct Job { uint32_t b, s; size_t first; };
+      struct Pad { size_t from, to; uint32_t b, s; };
+      std::vector<Job> jobs; std::vector<Pad> pads;
+      size_t k = 0;
       for (uint32_t b = 0; b < nbins; ++b) {
         if (!trained[b]) continue;
         const uint32_t s0 = training ? b : nbins + bin_first[b], s1 = training ? b + 1 : nbins + bin_first[b + 1];
         for (uint32_t s = s0; s < s1; ++s) {
-          T.seq_first.push_back((uint32_t)T.n()); T.st_wt_of_seq.push_back(tr[b].st_wt);
-          for (const GNode &g : sn[s].nodes) T.push(b, s, g);
+          T.seq_first.push_back((uint32_t)k); T.st_wt_of_seq.push_back(tr[b].st_wt);
+          jobs.push_back({b, s, k}); k += sn[s].nodes.size();
         }
-        T.seq_first.push_back((uint32_t)T.n());          // (closes the bin's last sequence; the next bin opens a new entry: ranges with gaps for the padding)
+        T.seq_first.push_back((uint32_t)k);              // (closes the bin's last sequence; the next bin opens a new entry: ranges with gaps for the padding)
         T.st_wt_of_seq.push_back(tr[b].st_wt);
-        T.pad_to_block(b, s0);
+        const size_t k2 = (k + 255) & ~(size_t)255;
+        pads.push_back({k, k2, b, s0}); k = k2;
       }
+      if (k > 0xfffffff0ull) throw Error(CKM_ERANGE, "more than 2^32 nodes in one gene-calling batch");
+      T.bin.resize(k); T.seq.resize(k); T.ndx.resize(k); T.stop_val.resize(k); T.strand.resize(k); T.type.resize(k); T.edge.resize(k);
+      prun(jobs.size(), 1, [&](size_t lo, size_t hi) {
+        for (size_t j = lo; j < hi; ++j) {
+          const Job &jb = jobs[j]; const std::vector<GNode> &nod = sn[jb.s].nodes;
+          for (size_t i = 0; i < nod.size(); ++i) {
+            const GNode &g = nod[i]; const size_t x = jb.first + i;
+            T.bin[x] = jb.b; T.seq[x] = jb.s; T.ndx[x] = g.ndx; T.stop_val[x] = g.stop_val; T.strand[x] = (int8_t)g.strand; T.type[x] = (uint8_t)g.type; T.edge[x] = (uint8_t)g.edge;
+          }
+        }
+      });
+      for (const Pad &pd : pads)
+        for (size_t x = pd.from; x < pd.to; ++x) { T.bin[x] = pd.b; T.seq[x] = pd.s; T.ndx[x] = 0; T.stop_val[x] = 0; T.strand[x] = 1; T.type[x] = 255; T.edge[x] = 0; }
       (void)flag;
     };
     // NOTE on seq_first: entries come in (first, ..., first, END) groups per bin; the kernel treats [seq_first[k], seq_first[k+1]) as a sequence, so the END -> next bin's first
@@ -914,7 +989,7 @@ extern "C" int ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *co
         for (uint32_t s = s0; s < s1; ++s) { jobs.push_back({s, k}); k += sn[s].nodes.size(); }
         k = (k + 255) & ~(size_t)255;
       }
-      pool_run(w, jobs.size(), 1, [&](size_t lo, size_t hi) {
+      prun(jobs.size(), 1, [&](size_t lo, size_t hi) {
         for (size_t j = lo; j < hi; ++j) {
           const uint32_t s = jobs[j].first; const size_t f = jobs[j].second;
           const std::vector<GNode> &nod = sn[s].nodes;
@@ -935,10 +1010,12 @@ extern "C" int ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *co
       HIPCHK(hipMemcpyAsync(T.traceb.data(), T.d_tb.p, T.n() * 4, hipMemcpyDeviceToHost, st));
       HIPCHK(hipMemcpyAsync(T.ov_mark.data(), T.d_ov.p, T.n() * 4, hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
-      for (const auto &jb : jobs) {
-        std::vector<GNode> &nod = sn[jb.first].nodes; const size_t f = jb.second;
-        for (size_t i = 0; i < nod.size(); ++i) { nod[i].score = T.score[f + i]; nod[i].traceb = T.traceb[f + i] < 0 ? -1 : T.traceb[f + i] - (int32_t)f; nod[i].ov_mark = T.ov_mark[f + i]; nod[i].tracef = -1; }
-      }
+      prun(jobs.size(), 1, [&](size_t lo, size_t hi) {
+        for (size_t j = lo; j < hi; ++j) {
+          std::vector<GNode> &nod = sn[jobs[j].first].nodes; const size_t f = jobs[j].second;
+          for (size_t i = 0; i < nod.size(); ++i) { nod[i].score = T.score[f + i]; nod[i].traceb = T.traceb[f + i] < 0 ? -1 : T.traceb[f + i] - (int32_t)f; nod[i].ov_mark = T.ov_mark[f + i]; nod[i].tracef = -1; }
+        }
+      });
     };
     auto run_dp = [&](NodeTable &T, int flag, double &ms) {
       hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -954,12 +1031,15 @@ extern "C" int ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *co
     std::vector<int> ipath(nbins, -1);
     if (TT.n()) {
       const auto jobs = fill_dp(TT, true, 0);
+      tp("training table built");
       TT.upload_static(st); TT.upload_dp(st);
       run_dp(TT, 0, o->ms_dp_train);
+      tp("training dp done");
       read_dp(TT, jobs);
+      tp("training dp read back");
       // hexamer statistics of the first gene set; their sums and the SD bins per start node
       std::vector<double> dc_all((size_t)nbins * 4096, 0.0), rw_all((size_t)nbins * 28, 0.0);
-      pool_run(w, nbins, 1, [&](size_t lo, size_t hi) {
+      prun(nbins, 1, [&](size_t lo, size_t hi) {
         for (size_t b = lo; b < hi; ++b) {
           if (!trained[b]) continue;
           ipath[b] = dprog_finish(sn[b].nodes);
@@ -967,6 +1047,7 @@ extern "C" int ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *co
           memcpy(dc_all.data() + b * 4096, tr[b].gene_dc, sizeof(double) * 4096);
         }
       });
+      tp("hexamer statistics");
       DevBuf d_dc, d_rw;
       d_dc.ensure(dc_all.size() * 8); d_rw.ensure(rw_all.size() * 8);
       HIPCHK(hipMemcpyAsync(d_dc.p, dc_all.data(), dc_all.size() * 8, hipMemcpyHostToDevice, st));
@@ -982,7 +1063,7 @@ extern "C" int ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *co
       HIPCHK(hipMemcpyAsync(TT.rbs1.data(), TT.d_rbs1.p, TT.n(), hipMemcpyDeviceToHost, st));
       HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(st));
       { float t = 0.f; HIPCHK(hipEventElapsedTime(&t, e0, e1)); o->ms_score += t; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
-      pool_run(w, jobs.size(), 1, [&](size_t lo, size_t hi) {
+      prun(jobs.size(), 1, [&](size_t lo, size_t hi) {
         for (size_t j = lo; j < hi; ++j) {
           const uint32_t b = jobs[j].first; const size_t f = jobs[j].second;
           std::vector<GNode> &nod = sn[b].nodes;
@@ -996,9 +1077,11 @@ extern "C" int ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *co
         }
       });
     }
+    tp("start-site training done");
     // ---- gene finding, contig by contig ----
     NodeTable TF;
     build_table(TF, false, 1);
+    tp("contig table built");
     std::vector<std::vector<GeneRec>> genes_of(nseq);
     if (TF.n()) {
       std::vector<double> dc_all((size_t)nbins * 4096, 0.0), rw_all((size_t)nbins * 28, 0.0);
@@ -1019,6 +1102,7 @@ extern "C" int ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *co
       HIPCHK(hipMemcpyAsync(TF.rbs1.data(), TF.d_rbs1.p, TF.n(), hipMemcpyDeviceToHost, st));
       HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(st));
       { float t = 0.f; HIPCHK(hipEventElapsedTime(&t, e0, e1)); o->ms_score += t; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+      tp("contig coding sums and SD bins from the device");
       // node scores, overlapping starts; then the dynamic program's inputs
       {
         std::vector<std::pair<uint32_t, size_t>> jobs0; size_t k = 0;
@@ -1027,7 +1111,7 @@ extern "C" int ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *co
           for (uint32_t s = nbins + bin_first[b]; s < nbins + bin_first[b + 1]; ++s) { jobs0.push_back({s, k}); k += sn[s].nodes.size(); }
           k = (k + 255) & ~(size_t)255;
         }
-        pool_run(w, jobs0.size(), 1, [&](size_t lo, size_t hi) {
+        prun(jobs0.size(), 1, [&](size_t lo, size_t hi) {
           for (size_t j = lo; j < hi; ++j) {
             const uint32_t s = jobs0[j].first; const size_t f = jobs0[j].second;
             std::vector<GNode> &nod = sn[s].nodes;
@@ -1037,20 +1121,20 @@ extern "C" int ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *co
             for (size_t i = 0; i < nod.size(); ++i) { nod[i].cscore = TF.cscore[f + i]; nod[i].rbs[0] = sdm ? TF.rbs0[f + i] : 0; nod[i].rbs[1] = sdm ? TF.rbs1[f + i] : 0; }
             score_nodes_rest(gseq(s), nod, tr[b], closed);
             record_overlapping_starts(nod, tr[b], 1);
+            for (size_t i = 0; i < nod.size(); ++i) TF.edge[f + i] = (uint8_t)nod[i].edge;
           }
         });
+        NodeTable::up(TF.d_edge, TF.edge, st);
       }
-      // (score_nodes turns starts at the sequence edges into edge nodes: the static columns change)
-      { size_t k = 0;
-        for (uint32_t b = 0; b < nbins; ++b) { if (!trained[b]) continue;
-          for (uint32_t s = nbins + bin_first[b]; s < nbins + bin_first[b + 1]; ++s) for (const GNode &g : sn[s].nodes) TF.edge[k++] = (uint8_t)g.edge;
-          k = (k + 255) & ~(size_t)255; }
-        NodeTable::up(TF.d_edge, TF.edge, st); }
+      // (score_nodes turns starts at the sequence edges into edge nodes: that static column changes)
+      tp("node scores");
       const auto jobs = fill_dp(TF, false, 1);
       TF.upload_dp(st);
+      tp("final dp inputs up");
       run_dp(TF, 1, o->ms_dp_find);
+      tp("final dp done");
       read_dp(TF, jobs);
-      pool_run(w, jobs.size(), 1, [&](size_t lo, size_t hi) {
+      prun(jobs.size(), 1, [&](size_t lo, size_t hi) {
         for (size_t j = lo; j < hi; ++j) {
           const uint32_t s = jobs[j].first; const size_t f = jobs[j].second;
           std::vector<GNode> &nod = sn[s].nodes;
@@ -1062,15 +1146,19 @@ extern "C" int ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *co
         }
       });
     }
+    tp("genes picked, starts tweaked");
     // ---- records ----
     o->bin_trained.assign(trained.begin(), trained.end()); o->bin_uses_sd.resize(nbins); o->bin_gc.resize(nbins); o->bin_bases.assign(bin_total.begin(), bin_total.end());
     o->bin_coding.assign(nbins, 0); o->bin_nodes_train.assign(nbins, 0); o->bin_nodes_find.assign(nbins, 0);
-    for (uint32_t b = 0; b < nbins; ++b) {
-      o->bin_uses_sd[b] = (uint8_t)tr[b].uses_sd; o->bin_gc[b] = tr[b].gc;
+    // (a bin per task into a record set of its own -- the translations are most of the work -- then appended in bin order)
+    std::vector<ckm_genes> part(nbins);
+    prun(nbins, 1, [&](size_t blo, size_t bhi) {
+    for (uint32_t b = (uint32_t)blo; b < (uint32_t)bhi; ++b) {
+      ckm_genes *o = &part[b];
+      o->bin_coding.assign(1, 0);                                // (of this bin)
       for (uint32_t c = bin_first[b]; c < bin_first[b + 1]; ++c) {
         const uint32_t s = nbins + c;
         const std::vector<GNode> &nod = sn[s].nodes; const GTrain &t = tr[b]; const GSeq q = gseq(s);
-        o->bin_nodes_find[b] += nod.size();
         for (const GeneRec &g : genes_of[s]) {
           const GNode &sn_ = nod[g.start_ndx], &sp = nod[g.stop_ndx];
           o->bin.push_back(b); o->contig.push_back(c); o->begin.push_back(g.begin); o->end.push_back(g.end); o->strand.push_back((int8_t)sn_.strand);
@@ -1091,11 +1179,28 @@ extern "C" int ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *co
           const bool partial5 = strand == 1 ? o->partial_left.back() : o->partial_right.back();
           o->prot_off.push_back(o->prot.size());
           for (int i = pb; i + 2 <= pe; i += 3) { char a = amino(q, strand, i, trans_table); if (i == pb && !partial5) a = 'M'; o->prot.push_back(a); }
-          o->bin_coding[b] += (uint64_t)(g.end - g.begin + 1);
+          o->bin_coding[0] += (uint64_t)(g.end - g.begin + 1);
         }
       }
     }
+    });
+    auto app = [](auto &dst, const auto &src) { dst.insert(dst.end(), src.begin(), src.end()); };
+    for (uint32_t b = 0; b < nbins; ++b) {
+      o->bin_uses_sd[b] = (uint8_t)tr[b].uses_sd; o->bin_gc[b] = tr[b].gc;
+      for (uint32_t c = bin_first[b]; c < bin_first[b + 1]; ++c) o->bin_nodes_find[b] += sn[nbins + c].nodes.size();
+      const ckm_genes &q = part[b];
+      o->bin_coding[b] = q.bin_coding[0];
+      const uint64_t p0 = o->prot.size();
+      app(o->bin, q.bin); app(o->contig, q.contig); app(o->begin, q.begin); app(o->end, q.end); app(o->strand, q.strand); app(o->start_type, q.start_type);
+      app(o->partial_left, q.partial_left); app(o->partial_right, q.partial_right); app(o->rbs_bin, q.rbs_bin); app(o->mot_len, q.mot_len); app(o->mot_ndx, q.mot_ndx);
+      app(o->mot_spacer, q.mot_spacer); app(o->gc_cont, q.gc_cont); app(o->cscore, q.cscore); app(o->sscore, q.sscore); app(o->rscore, q.rscore); app(o->uscore, q.uscore);
+      app(o->tscore, q.tscore); app(o->score, q.score); app(o->conf, q.conf);
+      for (uint64_t x : q.prot_off) o->prot_off.push_back(p0 + x);
+      o->prot.append(q.prot);
+      part[b] = ckm_genes();
+    }
     o->prot_off.push_back(o->prot.size());
+    tp("records and proteins");
     o->ms_nodes = t_nodes - t_begin; o->ms_host = now_ms() - t_begin;
     *out = o.release();
   });

@@ -6,10 +6,10 @@
 //                        is the oracle's bit for bit); the 4096-entry table of the bin sits in LDS.
 //   gene_rbs_kernel      thread per START node: the best Shine-Dalgarno bin (exact and one-mismatch) in the 20 bases upstream
 //                        (sequence.c: shine_dalgarno_exact / _mm), against the bin's 28 weights.
-//   gene_dp_kernel       the dynamic program over the nodes (dprog.c: dprog, node.c: score_connection): ONE WAVEFRONT per sequence (the
-//                        whole bin in the training pass, a contig in the final pass); the nodes go in order, and the up to 500 (and, behind
-//                        a giant ORF, more) predecessor candidates of a node are scored 64 at a time, one per lane, then reduced to the
-//                        best connection with the reference's tie rule (the LAST candidate that reaches the maximum wins).
+//   gene_dp_kernel       the dynamic program over the nodes (dprog.c: dprog, node.c: score_connection): ONE WORKGROUP (four wavefronts)
+//                        per sequence (the whole bin in the training pass, a contig in the final pass); the nodes go in order, and the up
+//                        to 500 (and, behind a giant ORF, more) predecessor candidates of a node are scored 256 at a time, one per thread,
+//                        then reduced to the best connection with the reference's tie rule (the LAST candidate that reaches the maximum wins).
 // The oracle is oracle/gene_full.c (a restatement of Prodigal 2.6.3's single-genome mode; parity unpinned: no prodigal exists here).
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -285,11 +285,17 @@ __device__ __forceinline__ bool dp_connection(const DpSrc &S, double st_wt, int 
   return true;
 }
 
-// one wavefront per sequence; seq_first[s] .. seq_first[s+1] are its nodes (already in working order); traceb is written as an ABSOLUTE
-// node index (-1: none); score / traceb / ov_mark must arrive zero / -1 / -1 from the host
-__global__ void __launch_bounds__(64) gene_dp_kernel(GeneNodesDev nd, const uint32_t *__restrict__ seq_first, const double *__restrict__ st_wt_of_seq, uint32_t nseq, int flag) {
+// one workgroup of DP_NT threads per sequence; seq_first[s] .. seq_first[s+1] are its nodes (already in working order); traceb is written as
+// an ABSOLUTE node index (-1: none); score / traceb / ov_mark must arrive zero / -1 / -1 from the host.
+// A node's ~1000 candidates are spread over the workgroup's wavefronts (a round of 64 candidates costs ~1 us of dependent LDS reads and
+// divergent cases, 16 rounds per node with one wavefront: 39 us per node measured); every wavefront reduces its own best candidate by
+// shuffles, the leaders' results meet in LDS and thread 0 applies the reference's tie rule across them (maximum total, then the LARGEST j:
+// the sequential loop keeps the last candidate that reaches the running maximum).
+constexpr int DP_NT = 256, DP_NW = DP_NT / 64;
+__global__ void __launch_bounds__(DP_NT) gene_dp_kernel(GeneNodesDev nd, const uint32_t *__restrict__ seq_first, const double *__restrict__ st_wt_of_seq, uint32_t nseq, int flag) {
   __shared__ DpRing ring;
-  const int lane = threadIdx.x;
+  __shared__ double red_best[DP_NW]; __shared__ int red_j[DP_NW], red_mark[DP_NW];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   for (uint32_t s = blockIdx.x; s < nseq; s += gridDim.x) {
     const uint32_t first = seq_first[s], end = seq_first[s + 1];
     const int nn = (int)(end - first);
@@ -298,8 +304,8 @@ __global__ void __launch_bounds__(64) gene_dp_kernel(GeneNodesDev nd, const uint
     for (int i0 = 0; i0 < nn; i0 += 64) {
       // the next 64 nodes enter the ring (their static fields; score 0, no trace-back yet): overwrites nodes i0 - DPW .. i0 + 63 - DPW
       {
-        const int rel = i0 + lane;
-        if (rel < nn) {
+        const int rel = i0 + tid;
+        if (tid < 64 && rel < nn) {
           const uint32_t g = first + (uint32_t)rel; const int k = rel & (DPW - 1);
           ring.ndx[k] = nd.ndx[g]; ring.sv[k] = nd.stop_val[g]; ring.tb[k] = -1; ring.score[k] = 0.0;
           ring.val[k] = flag == 0 ? nd.gcb[g] : nd.csc[g];
@@ -317,24 +323,32 @@ __global__ void __launch_bounds__(64) gene_dp_kernel(GeneNodesDev nd, const uint
       const DpSrc S{nd, ring, first, max(0, i0 + 64 - DPW), i1, flag};
       for (int i = i0; i < i1; ++i) {
         const int pki = ring.pk[i & (DPW - 1)];
-        if (pki & 4) continue;                                   // (padding node)
+        if (pki & 4) continue;                                   // (padding node; the same word for every thread)
         const DpNode n2 = S.node(i);
         const int lo = ring.lo[i & (DPW - 1)];
-        double best = -1.0; int bj = -1, bmark = -1;             // best candidate of this lane: the LAST j of the lane's that reaches its maximum (j ascends)
-        for (int j = lo + lane; j < i; j += 64) {
+        double best = -1.0; int bj = -1, bmark = -1;             // best candidate of this thread: the LAST j of the thread's that reaches its maximum (j ascends)
+        for (int j = lo + tid; j < i; j += DP_NT) {
           double tot; int mark;
           if (!dp_connection(S, st_wt, j, i, n2, tot, mark)) continue;
           if (tot >= 0.0 && tot >= best) { best = tot; bj = j; bmark = mark; }
         }
-        // wave reduction: maximum total, ties to the larger j (the reference loop keeps the last candidate that is >= the running best)
+        // reduction: maximum total, ties to the larger j
 #pragma unroll
         for (int sft = 32; sft >= 1; sft >>= 1) {
           const double ob = __shfl_xor(best, sft); const int oj = __shfl_xor(bj, sft), om = __shfl_xor(bmark, sft);
           if (oj >= 0 && (bj < 0 || ob > best || (ob == best && oj > bj))) { best = ob; bj = oj; bmark = om; }
         }
-        if (lane == 0 && bj >= 0) {
-          ring.score[i & (DPW - 1)] = best; ring.tb[i & (DPW - 1)] = bj;
-          GST(&nd.score[first + (uint32_t)i], best); GST(&nd.traceb[first + (uint32_t)i], (int)first + bj); GST(&nd.ov_mark[first + (uint32_t)i], bmark);
+        if (lane == 0) { red_best[wv] = best; red_j[wv] = bj; red_mark[wv] = bmark; }
+        __syncthreads();
+        if (tid == 0) {
+          for (int k = 1; k < DP_NW; ++k) {
+            const double ob = red_best[k]; const int oj = red_j[k], om = red_mark[k];
+            if (oj >= 0 && (bj < 0 || ob > best || (ob == best && oj > bj))) { best = ob; bj = oj; bmark = om; }
+          }
+          if (bj >= 0) {
+            ring.score[i & (DPW - 1)] = best; ring.tb[i & (DPW - 1)] = bj;
+            GST(&nd.score[first + (uint32_t)i], best); GST(&nd.traceb[first + (uint32_t)i], (int)first + bj); GST(&nd.ov_mark[first + (uint32_t)i], bmark);
+          }
         }
         __syncthreads();
       }
@@ -349,7 +363,7 @@ void launch_gene_rbs(hipStream_t st, const GeneSeqDev &seqs, const GeneNodesDev 
   if (nnodes) hipLaunchKernelGGL(gene_rbs_kernel, dim3((nnodes + 255) / 256), dim3(256), 0, st, seqs, nd, rbs_wt, nnodes);
 }
 void launch_gene_dp(hipStream_t st, const GeneNodesDev &nd, const uint32_t *seq_first, const double *st_wt_of_seq, uint32_t nseq, int flag) {
-  if (nseq) hipLaunchKernelGGL(gene_dp_kernel, dim3(nseq), dim3(64), 0, st, nd, seq_first, st_wt_of_seq, nseq, flag);
+  if (nseq) hipLaunchKernelGGL(gene_dp_kernel, dim3(nseq), dim3(DP_NT), 0, st, nd, seq_first, st_wt_of_seq, nseq, flag);
 }
 
 }  // namespace ckm

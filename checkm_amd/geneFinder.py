@@ -70,9 +70,13 @@ class BinGenes(object):
     def __init__(self, contigs, table, cols, sel, trained, uses_sd, gc):
         self.contigs, self.table, self.trained, self.uses_sd, self.gc = contigs, table, bool(trained), int(uses_sd), float(gc)
         import numpy as np
-        sel = np.asarray(sel, dtype=np.int64)
-        self.cols = {f: (cols[f][sel] if f != "proteins" else [cols[f][k] for k in sel]) for f in cols}
-        self.n = len(sel)
+        if isinstance(sel, slice):                     # (a bin's genes are one run of the batch's columns)
+            self.cols = {f: cols[f][sel] for f in cols}
+            self.n = sel.stop - sel.start
+        else:
+            sel = np.asarray(sel, dtype=np.int64)
+            self.cols = {f: (cols[f][sel] if f != "proteins" else [cols[f][k] for k in sel]) for f in cols}
+            self.n = len(sel)
 
     @property
     def rows(self):
@@ -97,39 +101,39 @@ class BinGenes(object):
             total += int(np.maximum(0, ee - np.maximum(ss, prev)).sum())
         return total
 
-    def _attrs(self, seqnum, k, r):
-        if r["rbs_bin"] >= 0:
-            motif, spacer = SD_MOTIF[r["rbs_bin"]], SD_SPACER[r["rbs_bin"]]
-        elif r["mot_len"] > 0:
-            motif, spacer = _motif_text(r["mot_len"], r["mot_ndx"]), "%dbp" % r["mot_spacer"]
-        else:
-            motif, spacer = "None", "None"
-        return "ID=%d_%d;partial=%d%d;start_type=%s;rbs_motif=%s;rbs_spacer=%s;gc_cont=%.3f" % (
-            seqnum, k, r["partial_left"], r["partial_right"], START_TYPE[r["start_type"]], motif, spacer, r["gc_cont"])
-
     def write(self, aaFile, gffFile, ntFile=None):
         """genes.faa / genes.gff (/ genes.fna) in prodigal's layout: `>contig_n # begin # end # strand # attributes`, GFF3 CDS lines."""
         comp = bytes.maketrans(b"ACGTacgtNn", b"TGCAtgcaNn")
+        L = {f: (v.tolist() if hasattr(v, "tolist") else v) for f, v in self.cols.items()}      # plain lists: one conversion per column, not one per field of every gene
         per = {}
-        for r in self.rows:
-            per.setdefault(r["contig"], []).append(r)
+        for k, c in enumerate(L["contig"]):
+            per.setdefault(c, []).append(k)
+        begin, end, strand_c, score, conf = L["begin"], L["end"], L["strand"], L["score"], L["conf"]
+        cs, ss, rs, us, ts, gcc = L["cscore"], L["sscore"], L["rscore"], L["uscore"], L["tscore"], L["gc_cont"]
+        rbs_bin, mot_len, mot_ndx, mot_sp, pl, pr, stt, prot = L["rbs_bin"], L["mot_len"], L["mot_ndx"], L["mot_spacer"], L["partial_left"], L["partial_right"], L["start_type"], L["proteins"]
         aa, gf, nt_out = [], ["##gff-version  3\n"], []
         for ci, (cid, seq) in enumerate(self.contigs):
             gf.append('# Sequence Data: seqnum=%d;seqlen=%d;seqhdr="%s"\n' % (ci + 1, len(seq), cid))
             gf.append('# Model Data: version=checkm_amd.device.gene_caller;run_type=Single;model="Ab initio";gc_cont=%.2f;transl_table=%d;uses_sd=%d\n'
                       % (100.0 * self.gc, self.table, self.uses_sd))
-            for k, r in enumerate(per.get(ci, []), 1):
-                at = self._attrs(ci + 1, k, r)
-                strand = "+" if r["strand"] == 1 else "-"
+            for k, g in enumerate(per.get(ci, []), 1):
+                if rbs_bin[g] >= 0:
+                    motif, spacer = SD_MOTIF[rbs_bin[g]], SD_SPACER[rbs_bin[g]]
+                elif mot_len[g] > 0:
+                    motif, spacer = _motif_text(mot_len[g], mot_ndx[g]), "%dbp" % mot_sp[g]
+                else:
+                    motif, spacer = "None", "None"
+                at = "ID=%d_%d;partial=%d%d;start_type=%s;rbs_motif=%s;rbs_spacer=%s;gc_cont=%.3f" % (
+                    ci + 1, k, pl[g], pr[g], START_TYPE[stt[g]], motif, spacer, gcc[g])
                 gf.append("%s\tcheckm_amd_device\tCDS\t%d\t%d\t%.1f\t%s\t0\t%s;conf=%.2f;score=%.2f;cscore=%.2f;sscore=%.2f;rscore=%.2f;uscore=%.2f;tscore=%.2f;\n"
-                          % (cid, r["begin"], r["end"], r["score"], strand, at, r["conf"], r["score"], r["cscore"], r["sscore"], r["rscore"], r["uscore"], r["tscore"]))
-                head = ">%s_%d # %d # %d # %d # %s\n" % (cid, k, r["begin"], r["end"], r["strand"], at)
-                p = r["proteins"]
+                          % (cid, begin[g], end[g], score[g], "+" if strand_c[g] == 1 else "-", at, conf[g], score[g], cs[g], ss[g], rs[g], us[g], ts[g]))
+                head = ">%s_%d # %d # %d # %d # %s\n" % (cid, k, begin[g], end[g], strand_c[g], at)
+                p = prot[g]
                 aa.append(head)
                 aa.extend(p[i:i + 60] + "\n" for i in range(0, len(p), 60))
                 if ntFile:
-                    nt = seq[r["begin"] - 1:r["end"]]
-                    if r["strand"] != 1:
+                    nt = seq[begin[g] - 1:end[g]]
+                    if strand_c[g] != 1:
                         nt = nt.encode().translate(comp)[::-1].decode()
                     nt_out.append(head)
                     nt_out.extend(nt[i:i + 70] + "\n" for i in range(0, len(nt), 70))
@@ -142,17 +146,15 @@ class BinGenes(object):
                 f.write("".join(nt_out))
 
 
-def call_bins(bins, table, mask=True):
+def call_bins(bins, table, mask=True, ctx=None):
     """Genes of many bins for one translation table in ONE device call (ckm_genes_call): bins = [[(contig id, sequence), ...], ...].
     Returns a list of BinGenes."""
-    ctx = runtime.get_ctx()
+    ctx = ctx if ctx is not None else runtime.get_ctx()
     cols, per_bin, stats = _lib.call_genes(ctx, [[s for _c, s in contigs] for contigs in bins], table, False, mask)
-    n = len(cols["begin"])
-    by_bin = [[] for _ in bins]
-    for k in range(n):
-        by_bin[int(cols["bin"][k])].append(k)
-    out = [BinGenes(bins[b], table, cols, by_bin[b], per_bin["trained"][b], per_bin["uses_sd"][b], per_bin["gc"][b]) for b in range(len(bins))]
-    call_bins.last_stats = stats
+    import numpy as np
+    at = np.searchsorted(cols["bin"], np.arange(len(bins) + 1))        # the records come in bin order
+    out = [BinGenes(bins[b], table, cols, slice(int(at[b]), int(at[b + 1])), per_bin["trained"][b], per_bin["uses_sd"][b], per_bin["gc"][b]) for b in range(len(bins))]
+    call_bins.last_stats = stats          # (of whichever table finished last when two run side by side: diagnostics only)
     return out
 
 
@@ -168,17 +170,27 @@ def call_bin_files(jobs, bNucORFs=False, max_bases=1 << 30, logger=None):
     device, the reference's choice between them, prodigal's file layout.  Returns {binFile: (best table, {11: density, 4: density})}.
     A bin below 20 kb cannot be trained on (and the pre-trained `-p meta` models CheckM would use below 100 kb are not built): it raises."""
     import os
+    import time
     from checkm_amd.defaultValues import DefaultValues
     out = {}
     batch, size = [], 0
+    phases = {"read_s": 0.0, "device_calls_s": 0.0, "choose_and_write_s": 0.0}
+    call_bin_files.last_phases = phases
 
     def flush():
         nonlocal batch, size
         if not batch:
             return
         bins = [b[2] for b in batch]
-        g11 = call_bins(bins, 11)
-        g4 = call_bins(bins, 4)
+        # the two tables side by side, a context each: the dynamic programs are latency-bound (a workgroup per bin) and most of a call is
+        # host threads, so the device phases of one table run underneath the host phases of the other
+        from concurrent.futures import ThreadPoolExecutor
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=2) as ex:
+            f11 = ex.submit(call_bins, bins, 11, True, runtime.get_ctx())
+            f4 = ex.submit(call_bins, bins, 4, True, runtime.get_ctx_k(1))
+            g11, g4 = f11.result(), f4.result()
+        t1 = time.perf_counter()
         for (binFile, binDir, contigs, total), a, b in zip(batch, g11, g4):
             if not a.trained:
                 raise ValueError("bin %s holds %d bases: the device gene caller trains on the bin itself and needs %d (the pre-trained models of "
@@ -188,9 +200,12 @@ def call_bin_files(jobs, bNucORFs=False, max_bases=1 << 30, logger=None):
             (a if best == 11 else b).write(os.path.join(binDir, DefaultValues.PRODIGAL_AA), os.path.join(binDir, DefaultValues.PRODIGAL_GFF),
                                             os.path.join(binDir, DefaultValues.PRODIGAL_NT) if bNucORFs else None)
             out[binFile] = (best, dens)
+        phases["device_calls_s"] += t1 - t0; phases["choose_and_write_s"] += time.perf_counter() - t1
         batch, size = [], 0
     for binFile, binDir in jobs:
+        t0 = time.perf_counter()
         contigs = read_contigs(binFile)
+        phases["read_s"] += time.perf_counter() - t0
         total = sum(len(s) for _c, s in contigs)
         if batch and size + total > max_bases:
             flush()

@@ -11,6 +11,7 @@
 #   pmc3[:BINS]      three separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*) of ONE cfg3 step (default 48 bins)    -> pmc3_{fetch,write,sq}/
 #   pmc2             the same three passes of ONE cfg2 search                                                           -> pmc_{fetch,write,sq}/
 #   valu             tools/ubench/valu_rates (VALU issue rates of the SSV row body)                                     -> valu_rates.txt
+#   genes[:THREADS]  the gene-calling tests + `bench.py --config genes` with CKM_TRACE=1 (phase times of a call on stderr)     -> pytest_genes.txt, genes.json / .err
 # Counter passes never combine --pmc with anything but --kernel-trace (the pool's gpurun refuses other combinations).
 set -u
 TAG=${1:?tag}; shift
@@ -37,6 +38,8 @@ for item in "$@"; do
     pmc2)   for pass in "${PMC_PASSES[@]}"; do set -- $pass; name=$1; shift
               (cd /tmp && CKM_BENCH_STEADY=0 CKM_BENCH_FROM_HOST=0 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/pmc_$name" -o p -- python "$ROOT/bench.py" --config cfg2 --steps 1 --warmup 0 --no-cpu-baseline --no-verify > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err")
             done ;;
+    genes)  python -m pytest tests/test_gpu_genes.py tests/test_gpu_orf.py -m gpu -x -q 2>&1 | tail -5 > "$OUT/pytest_genes.txt"; cat "$OUT/pytest_genes.txt"
+            ( [ -n "$arg" ] && export CKM_GENE_THREADS=$arg; CKM_TRACE=1 python bench.py --config genes > "$OUT/genes.json" 2> "$OUT/genes.err" ); tail -c 700 "$OUT/genes.json" ;;
     valu)   (cd tools/ubench && hipcc --offload-arch=gfx950 -O3 -o valu_rates valu_rates.hip 2>/dev/null; ./valu_rates) > "$OUT/valu_rates.txt" 2>&1; tail -20 "$OUT/valu_rates.txt" ;;
     *)      echo "unknown item: $item" ;;
   esac
