@@ -97,7 +97,11 @@ extern "C" int ckm_ctx_create(int device, ckm_ctx **out) {
       for (auto &e : w.ens_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       memset(&w.stats, 0, sizeof(w.stats));
       w.ws_budget = budget;
-      if (getenv("CKM_WS_VMM") && atoi(getenv("CKM_WS_VMM")) != 0) { w.ws.vmm = true; w.ws.va_bytes = budget + ((size_t)8 << 30); }   // (opt-in until it has run the whole GPU suite)
+      // the float workspace is an address reservation with 1 GB chunks mapped in as it grows (DevBuf::grow_mapped): find() reserves the
+      // largest batch's size before its first search, when the device is idle, and mapping then costs 0.2 ms per GB against hipMalloc's
+      // 30 -- measured on the first full-size step of a process: 0.9 s over a steady step instead of 3.4 s (profiles/r04v_*; the whole
+      // GPU suite ran in this mode).  CKM_WS_VMM=0: one hipMalloc per growth, as rounds 1-3 had it.
+      if (!(getenv("CKM_WS_VMM") && atoi(getenv("CKM_WS_VMM")) == 0)) { w.ws.vmm = true; w.ws.va_bytes = budget + ((size_t)8 << 30); }
       if (const char *e = getenv("CKM_WS_PER_CELL")) w.caps.ws_per_cell = (float)atof(e);  // first workspace size of the device-driven cascade (bytes per expected cell, ckm_search.hip)
       w.pool.reset(new HostPool(host_threads));
     }

@@ -108,7 +108,11 @@ struct DevBuf {
   }
   void ensure(size_t bytes) {
     if (bytes <= cap) return;
-    if (vmm) { grow_mapped(bytes); return; }
+    if (vmm) {
+      if (p) { grow_mapped(bytes); return; }
+      try { grow_mapped(bytes); return; }
+      catch (const Error &) { if (p || cap) throw; vmm = false; }      // no address range to be had (nothing is mapped yet): a plain allocation instead
+    }
     drop();
     (void)hipGetDevice(&dev);
     size_t want = bytes + std::min<size_t>(bytes / 4, (size_t)1 << 30) + 256;      // (growth slack, bounded: the float workspace is tens of GB)
