@@ -916,6 +916,7 @@ def bench_cfg3(args, env):
         full_warm_walls.append(time.perf_counter() - ts)
     if full_warm_walls:
         est = full_warm_walls[-1]
+    est = env.all_max(est)                  # (every rank must run the same number of steps: each one holds a collective)
     steps = int(max(1, min(args.steps, args.budget_seconds // max(est, 1e-3))))
     prof = None
     if args.host_profile and rank == 0:

@@ -147,6 +147,7 @@ struct DevBuf {
     while (cap < want) {
       hipMemGenericAllocationHandle_t h;
       hipError_t e = hipMemCreate(&h, chunk_bytes, &prop, 0);
+      if (e != hipSuccess) { DevCache::get().trim(dev); e = hipMemCreate(&h, chunk_bytes, &prop, 0); }      // (device memory held by the block cache may be what is missing)
       if (e != hipSuccess) fail("hipMemCreate", e);
       e = hipMemMap(static_cast<char *>(p) + cap, chunk_bytes, 0, h, 0);
       if (e != hipSuccess) { (void)hipMemRelease(h); fail("hipMemMap", e); }
