@@ -47,3 +47,44 @@ def test_lane_trace_merges_the_two_clocks(tmp_path):
     assert out[0].split()[1] == "L0" and out[2].split()[1] == "12340"
     every = _run([os.path.join(ROOT, "tools", "lane_trace.py"), str(f), "10000", "all"])
     assert "results copied" in every
+
+
+def test_collection_script_parses():
+    out = subprocess.run(["bash", "-n", os.path.join(ROOT, "tools", "gpu_collect.sh")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+
+
+def test_profile_files_from_counter_passes(tmp_path):
+    """tools/make_profile_files.py on a hand-made collection: the SSV figures bench.py scales (FETCH doubled + WRITE, VALU instructions of the
+    ssv kernels only) and the step totals, which leave out the gene-calling legs' kernels when a collection ran them in the same process."""
+    import json
+    src, dst = tmp_path / "out", tmp_path / "prof"
+    tag = src / "t1"
+    dst.mkdir()
+    head = '"Correlation_Id","Dispatch_Id","Agent_Id","Queue_Id","Process_Id","Thread_Id","Grid_Size","Kernel_Id","Kernel_Name","Workgroup_Size","LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Counter_Name","Counter_Value","Start_Timestamp","End_Timestamp"\n'
+    kernels = [("void ckm::ssv_kernel_h<4>(ckm::X)", 100.0), ("void ckm::ssv_kernel_h8<2>(ckm::X)", 50.0), ("void ckm::fwd_kernel<4>(ckm::X)", 30.0),
+               ("ckm::gene_dp_kernel(ckm::GeneNodesDev, unsigned int const*)", 1000.0), ("ckm::orf_flags_kernel(unsigned char const*)", 500.0)]
+
+    def write(pass_name, counters):
+        d = tag / ("pmc3_" + pass_name)
+        d.mkdir(parents=True)
+        with open(d / "p_counter_collection.csv", "w") as f:
+            f.write(head)
+            for k, (name, v) in enumerate(kernels):
+                for c, scale in counters:
+                    f.write('%d,%d,"Agent 2",1,1,1,64,1,"%s",64,0,0,8,0,16,"%s",%f,%d,%d\n' % (k, k, name, c, v * scale, 1000 * k, 1000 * k + 500000))
+        (tag / ("pmc3_%s.json" % pass_name)).write_text(json.dumps({"config": {"workload": "w", "bins_total": 48}, "ms_per_step": 1.0,
+                                                                     "roofline": {"algorithmic_bytes": 1e6, "ms_per_step_kernel": 1.0}}) + "\n")
+    write("fetch", [("FETCH_SIZE", 1.0)])
+    write("write", [("WRITE_SIZE", 0.5)])
+    write("sq", [("SQ_INSTS_VALU", 10.0), ("SQ_INSTS_LDS", 2.0)])
+    env = dict(os.environ, CKM_PROFILE_SRC=str(src), CKM_PROFILE_DST=str(dst))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_profile_files.py"), "t1"], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.load(open(dst / "t1_cfg3_ssv_traffic.json"))
+    assert d["FETCH_SIZE_KB"] == 150.0 and d["WRITE_SIZE_KB"] == 75.0                      # the two SSV kernel families only
+    assert d["hbm_bytes_corrected"] == 2 * 150.0 * 1024 + 75.0 * 1024                      # FETCH doubled (MI355X_MICROARCH.md), WRITE as reported
+    assert d["valu_insts"] == 1500.0 and d["lds_insts"] == 300.0 and d["algorithmic_bytes"] == 1e6
+    assert d["all_kernels"]["valu_insts"] == 1800.0 and d["all_kernels"]["FETCH_SIZE_KB"] == 180.0       # + fwd; gene_* / orf_* left out
+    text = open(dst / "t1_cfg3_pmc_summary.txt").read()
+    assert "ssv_kernel" in text and "gene_dp_kernel" in text                                   # (the per-kernel table itself lists everything)

@@ -57,8 +57,10 @@ def pmc_files(src, dst, prefix, what, line, cmd):
 
 
 def one(tag):
-    src = os.path.join(ROOT, "gpurun_out", tag)
-    dst = lambda name: os.path.join(ROOT, "profiles", "%s_%s" % (tag, name))
+    # (CKM_PROFILE_SRC / CKM_PROFILE_DST: other directories than gpurun_out/ and profiles/ -- tests/test_tools.py)
+    src = os.path.join(os.environ.get("CKM_PROFILE_SRC", os.path.join(ROOT, "gpurun_out")), tag)
+    out_dir = os.environ.get("CKM_PROFILE_DST", os.path.join(ROOT, "profiles"))
+    dst = lambda name: os.path.join(out_dir, "%s_%s" % (tag, name))
     for name in sorted(os.listdir(src)):
         m = re.match(r"bench(\d+)\.json$", name)
         if m and os.path.getsize(os.path.join(src, name)) > 0:
