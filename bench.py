@@ -934,7 +934,7 @@ def bench_cfg3(args, env):
         step_walls.append(time.perf_counter() - ts)
     from checkm_amd import markerGeneFinder as _mgf
     tj = time.perf_counter()
-    _mgf._join_releasers()               # the background release of the last step's scans belongs to the timed region (every earlier one is waited for by the next find())
+    _mgf._join_releasers()               # the background release of the last step's scans belongs to the timed region (every earlier one is waited for by the release that follows it)
     last_release_s = time.perf_counter() - tj
     if prof is not None:
         prof.disable()

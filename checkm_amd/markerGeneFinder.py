@@ -58,7 +58,7 @@ def release_scan(outDir=None, final=False, background=False):
     """Free cached device objects (all, or those of one output directory).  Profile databases stay resident until everything is
     released (release_scan() without an argument).  Hit lists ResultsParser handed out lazily are filled in first (not at interpreter
     exit: final=True).  background=True frees the hits and sequences on a helper thread (hipFree waits for the device: 0.3 s for a
-    thousand bins' scans) -- the next find() or release waits for it."""
+    thousand bins' scans before the block cache of round 4) -- the next release waits for it; find() does not."""
     _join_releasers()
     if SCAN_CACHE and not final:
         mod = sys.modules.get("checkm_amd.resultsParser")
@@ -238,7 +238,10 @@ class MarkerGeneFinder(object):
         from concurrent.futures import ThreadPoolExecutor
         from checkm_amd import dist as cdist
         from checkm_amd import workers
-        _join_releasers()                   # (a background release of an earlier scan is over before this one's searches start)
+        # (a background release of an earlier scan -- release_scan(background=True) -- is NOT waited for here: freed blocks go to the
+        #  library's block cache, no hipFree and no device-wide wait, so it may run underneath this scan's first batches; the next
+        #  release, runtime.close() and bench.py's timed region wait for it.  Waiting here kept the device idle for 0.25-0.28 s at the
+        #  start of every 1000-bin pass that follows another: profiles/r04x_timeline_cfg3.txt.)
         devs = workers.devices()
         if devs is not None:
             return self._find_with_workers(devs, binFiles, outDir, tableOut, hmmerOut, markerFile, bKeepAlignment, bNucORFs, bCalledGenes)
