@@ -257,7 +257,7 @@ def lineage_pass(w, binIds, files, lin, out, rank):
     t3 = time.perf_counter()
     del rp, sets, models                 # (hit lists nobody looked at need not be filled in before the scan is released)
     t4 = time.perf_counter()
-    mgf.release_scan(out, background=True)          # (the memory of the scans is returned by a helper thread while the next pass starts; the next find() waits for it)
+    mgf.release_scan(out, background=True)          # (the memory of the scans is returned by a helper thread while the next pass starts; the next release waits for it, find() does not)
     t5 = time.perf_counter()
     return {"tree_find_s": t1 - t0, "analyze_find_s": t2 - t1, "qa_s": t3 - t2, "total_s": t3 - t0, "drop_python_objects_s": t4 - t3, "release_call_s": t5 - t4}, tot
 
