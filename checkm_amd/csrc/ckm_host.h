@@ -101,9 +101,13 @@ struct DevBuf {
   // grows -- measured on MI355X (tools/ubench/vmm_probe.hip, profiles/r03z_vmm_probe.txt): 0.2 ms per GB against hipMalloc's 30 ms per GB,
   // and growth keeps the contents and the address (no free + malloc).  Mapping waits for kernels already running, like hipFree.
   bool vmm = false; size_t va_bytes = (size_t)128 << 30, chunk_bytes = 0; std::vector<hipMemGenericAllocationHandle_t> chunks;
-  void drop() {
+  // A block goes to the cache only from places where its owner's work is known to have drained: the destructor on the normal path (the
+  // free entry points and the ends of the calls, all behind their stream synchronisations).  Growth while work may still be queued, and
+  // destructors that run while an exception unwinds a call (kernels and copies of the call possibly still in flight), use hipFree, which
+  // waits for the device -- the cache hands a block to the next taker at once, with no synchronisation of its own.
+  void drop(bool drained = false) {
     if (!p) return;
-    if (dev < 0 || !DevCache::get().give(dev, p, cap)) (void)hipFree(p);
+    if (!drained || dev < 0 || !DevCache::get().give(dev, p, cap)) (void)hipFree(p);
     p = nullptr; cap = 0;
   }
   void ensure(size_t bytes) {
@@ -162,7 +166,7 @@ struct DevBuf {
       if (p && cap) (void)hipMemUnmap(p, cap);
       for (auto h : chunks) (void)hipMemRelease(h);
       if (p) (void)hipMemAddressFree(p, va_bytes);
-    } else drop();
+    } else drop(std::uncaught_exceptions() == 0);
   }
   DevBuf() = default; DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
 };
@@ -330,11 +334,18 @@ struct ckm_hits {
   uint32_t nbins = 0;
 };
 
+// An entry point that fails may have kernels and copies queued (a HIPCHK that throws in the middle of a cascade, with trace ensembles on
+// their own stream, chains behind SSV launches ...): nothing of the failed call may still be running when the caller frees or reuses the
+// objects it passed in, so the device is drained before the error code goes back.  Argument errors (CKM_EINVAL: thrown before any launch)
+// and a missing device skip the wait.
+static inline void drain_after_error(int code) {
+  if (code != CKM_EINVAL && code != CKM_ENODEV) (void)hipDeviceSynchronize();
+}
 template <class F>
 static inline int guarded(F &&f) {
   try { f(); return CKM_OK; }
-  catch (const Error &e) { set_last_error(e.what()); return e.code; }
-  catch (const std::bad_alloc &) { set_last_error("out of host memory"); return CKM_ENOMEM; }
+  catch (const Error &e) { set_last_error(e.what()); drain_after_error(e.code); return e.code; }
+  catch (const std::bad_alloc &) { set_last_error("out of host memory"); drain_after_error(CKM_ENOMEM); return CKM_ENOMEM; }
   catch (const std::exception &e) { set_last_error(e.what()); return CKM_EINVAL; }
 }
 

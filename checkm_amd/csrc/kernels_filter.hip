@@ -647,10 +647,12 @@ void launch_msv_full(hipStream_t stream, uint32_t nblocks, WorkQueue queue, cons
   if (cd) c = *cd;
   const size_t lds = (((size_t)KP_SYMS * (maxMp + 1) + 15) & ~(size_t)15) + (size_t)2 * maxMp * sizeof(int16_t);
   {
-    // (searches of several contexts launch from their own host threads: the limit only ever grows, and check + set + launch are one critical section)
-    static std::mutex attr_mutex; static size_t attr_bytes = 0;
+    // (searches of several contexts launch from their own host threads: the limit only ever grows, so check + set are one critical section and
+    //  a launch that follows sees a limit at least as large as it needs; the attribute belongs to the CURRENT DEVICE's code object, hence per device)
+    static std::mutex attr_mutex; static size_t attr_bytes[16] = {0};
+    int dev = 0; (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(attr_mutex);
-    if (lds > 48 * 1024 && lds > attr_bytes) { (void)hipFuncSetAttribute((const void *)msv_full_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_bytes = lds; }
+    if (lds > 48 * 1024 && lds > attr_bytes[dev & 15]) { (void)hipFuncSetAttribute((const void *)msv_full_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_bytes[dev & 15] = lds; }
   }
   hipLaunchKernelGGL(msv_full_kernel, dim3(nblocks), dim3(64), lds, stream, queue, pairs, models, lentab, res, seq_off, seq_len, out_xJ, out_usc, maxMp, c, cd ? 1 : 0);
 }

@@ -291,18 +291,20 @@ __global__ void ssv_none_kernel(const SsvBlockWork *__restrict__ work, const int
   }
 }
 
-// the dynamic-LDS limit of an instance is raised once, under a lock: searches of several contexts launch from different host threads
+// the dynamic-LDS limit of an instance is raised once PER DEVICE (the attribute belongs to the current device's code object), under a
+// lock: searches of several contexts launch from different host threads
 static std::mutex g_attr_mutex;
 template <class K>
-static void raise_lds_limit(K kernel, size_t bytes, bool &done) {
+static void raise_lds_limit(K kernel, size_t bytes, uint32_t &done_devices) {
   if (bytes <= 48 * 1024) return;
+  int dev = 0; (void)hipGetDevice(&dev);
   std::lock_guard<std::mutex> lock(g_attr_mutex);
-  if (!done) { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); done = true; }
+  if (!(done_devices & (1u << (dev & 31)))) { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); done_devices |= 1u << (dev & 31); }
 }
 
 #define CKM_SSV_CASE(QV)                                                                                         \
   case QV: {                                                                                                     \
-    static bool attr_set = false;                                                                                \
+    static uint32_t attr_set = 0;                                                                                  \
     raise_lds_limit(ssv_kernel_h<QV>, (size_t)SSV_NROWS * ((QV + 3) / 4) * 256, attr_set);                       \
     hipLaunchKernelGGL(ssv_kernel_h<QV>, dim3(nblocks), dim3(threads), (size_t)SSV_NROWS * ((QV + 3) / 4) * 256, stream, \
                        work, models, res, seq_off, seq_len, lists, epi);                                         \
