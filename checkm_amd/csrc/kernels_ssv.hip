@@ -316,7 +316,7 @@ int launch_ssv(int Q, int nblocks, int threads, hipStream_t stream, const SsvBlo
   if (Q >= 100) {                      // launch classes 100 + Q8: eight lanes per sequence
     switch (Q - 100) {
 #define X(QV) case QV: {                                                                                         \
-      static bool attr8 = false;                                                                                 \
+      static uint32_t attr8 = 0;                                                                                 \
       raise_lds_limit(ssv_kernel_h8<QV>, (size_t)SSV_NROWS * ((QV + 3) / 4) * 256, attr8);                       \
       hipLaunchKernelGGL(ssv_kernel_h8<QV>, dim3(nblocks), dim3(threads), (size_t)SSV_NROWS * ((QV + 3) / 4) * 256, stream, work, models, res, seq_off, seq_len, lists, epi); \
     } break;
