@@ -1,0 +1,104 @@
+// gene_exec.h -- what gene_pipe.h runs on: the device (HIP streams, device buffers, kernels) in libcheckm_hip.so, or plain loops over host
+// memory in the test-only emulation (tests/emu, CKM_GENE_EMU).  A "map" is one thread per index with no cooperation between threads; the
+// few kernels that do cooperate (wave ballots, LDS histograms, ordered sums, the dynamic program, scans) are declared here and
+// implemented twice: kernels_genes.hip for the device, tests/emu/gene_emu.cpp as scalar loops.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "gene_dev.h"
+
+#ifdef CKM_GENE_EMU
+#include <stdexcept>
+namespace ckm {
+namespace gene {
+struct GExec { int dummy = 0; };
+struct GTimer { void begin(GExec &) {} double end(GExec &) { return 0.0; } };
+struct GBuf {
+  std::vector<uint8_t> v; void *p = nullptr;
+  void ensure(size_t bytes) { if (v.size() < bytes + 64) { v.resize(bytes + 64); } p = v.data(); }
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+inline void g_zero(GExec &, void *p, int byte, size_t n) { memset(p, byte, n); }
+inline void g_h2d(GExec &, void *dst, const void *src, size_t n) { if (n) memcpy(dst, src, n); }
+inline void g_d2h(GExec &, void *dst, const void *src, size_t n) { if (n) memcpy(dst, src, n); }
+inline void g_sync(GExec &) {}
+template <class F> inline void g_map(GExec &, size_t n, F f) { for (size_t i = 0; i < n; ++i) f(i); }
+template <class T> inline T g_atomic_add(T *p, T v) { const T o = *p; *p = o + v; return o; }
+inline void g_atomic_or(unsigned long long *p, unsigned long long v) { *p |= v; }
+[[noreturn]] inline void g_fail(const char *msg) { throw std::runtime_error(msg); }
+}  // namespace gene
+}  // namespace ckm
+#else
+#include "ckm_host.h"
+namespace ckm {
+namespace gene {
+struct GExec { hipStream_t st = nullptr; };
+struct GTimer {          // HIP events on the stream the kernels run on; end() waits for the stream
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  void begin(GExec &e) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, e.st)); }
+  double end(GExec &e) {
+    HIPCHK(hipEventRecord(e1, e.st)); HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(e.st));
+    float t = 0.f; HIPCHK(hipEventElapsedTime(&t, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); e0 = e1 = nullptr;
+    return t;
+  }
+  ~GTimer() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+};
+using GBuf = DevBuf;
+inline void g_zero(GExec &e, void *p, int byte, size_t n) { if (n) HIPCHK(hipMemsetAsync(p, byte, n, e.st)); }
+inline void g_h2d(GExec &e, void *dst, const void *src, size_t n) { if (n) HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, e.st)); }
+inline void g_d2h(GExec &e, void *dst, const void *src, size_t n) { if (n) HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, e.st)); }
+inline void g_sync(GExec &e) { HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(e.st)); }
+template <class F> __global__ void __launch_bounds__(256) g_map_kernel(size_t n, F f) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) f(i);
+}
+template <class F> inline void g_map(GExec &e, size_t n, F f) {
+  if (!n) return;
+  if (n > (size_t)0x7fffffff * 256) throw Error(CKM_ERANGE, "gene-calling batch too large for one launch");
+  hipLaunchKernelGGL(g_map_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e.st, n, f);
+}
+template <class T> __device__ __forceinline__ T g_atomic_add(T *p, T v) { return atomicAdd(p, v); }
+__device__ __forceinline__ void g_atomic_or(unsigned long long *p, unsigned long long v) { atomicOr(p, v); }
+[[noreturn]] inline void g_fail(const char *msg) { throw Error(CKM_ERANGE, msg); }
+}  // namespace gene
+}  // namespace ckm
+#endif
+
+namespace ckm {
+namespace gene {
+
+// ---- cooperating kernels (kernels_genes.hip / tests/emu/gene_emu.cpp) ----
+// eight codon-flag bit planes of the ascii text (kernels_orf.hip)
+void x_orf_flags(GExec &e, const uint8_t *ascii, unsigned long long *planes, uint64_t body);
+// in-place exclusive prefix sum of n + 1 entries (entry n receives the total)
+void x_scan_u32(GExec &e, uint32_t *a, size_t n, GBuf &scratch);
+
+struct ChainArgs {
+  const unsigned long long *planes; uint64_t nwin;                    // codon flags
+  const uint64_t *seq_off; const int32_t *seq_len; uint32_t nseq, nbins;        // sequences [0, nbins): training, [nbins, nseq): contigs
+  int tt4;
+  const unsigned long long *r50; const uint32_t *pr50;                // starts of 50-runs of unknown bases and their prefix counts (null: no masking)
+  unsigned long long *node_planes;                                    // [set][strand][nwin] bit per node position (atomic OR)
+  uint32_t *chain_cnt;                                                // [nseq * 6] events of the chain
+  void *rec; uint32_t *rec_t; unsigned long long *nrec; unsigned long long cap;      // unsorted 16-byte records + their event numbers
+};
+// start / stop nodes of every (sequence, strand, frame) chain (node.c: add_nodes with -m masks), open ends
+void x_chain(GExec &e, const ChainArgs &a);
+
+// t.bias of every bin: the ordered sum over the bin's start nodes (node.c: record_gc_bias), then scaled to a sum of 3
+void x_gc_bias(GExec &e, const Nodes &nd, const uint32_t *seq_lo, const uint32_t *seq_n, uint32_t nbins, double *bias /* [nbins][3] */);
+
+// the dynamic program (dprog.c: the forward sweep) for sequences s = 0 .. nseq-1 with nodes [seq_lo[s], seq_lo[s] + seq_n[s]); traceb comes back
+// RELATIVE to the sequence's first node; score / traceb / ov_mark must arrive 0 / -1 / -1
+void x_dp(GExec &e, const Nodes &nd, const uint32_t *seq_lo, const uint32_t *seq_n, const uint32_t *seq_bin, const double *st_wt, uint32_t nseq, int flag);
+
+// hexamer counts of both strands of every bin's training sequence: hist[b][f] = number of positions whose forward hexamer is f
+void x_hexamer_background(GExec &e, const uint8_t *code, const uint64_t *seq_off, const int32_t *seq_len, uint32_t nbins, int max_len, uint32_t *hist /* [nbins][4096] */);
+
+// hexamer sums (bin tables staged in LDS on the device) and Shine-Dalgarno bins of every start node
+void x_cscore(GExec &e, const uint8_t *code, const uint64_t *seq_off, const int32_t *seq_len, const Nodes &nd, const double *gene_dc, uint32_t n);
+void x_rbs(GExec &e, const uint8_t *code, const uint64_t *seq_off, const int32_t *seq_len, const Nodes &nd, const double *rbs_wt, uint32_t n);
+
+}  // namespace gene
+}  // namespace ckm
