@@ -145,11 +145,14 @@ GFN double dp_igm(const S &src, double st_wt, int k1, const DpNode &n1, int k2, 
   else if ((dist <= 60 && ovlp == 0) || dist < 0.25 * 60) rval += (2.0 - (double)dist / 60) * 0.15 * st_wt;
   return rval;
 }
-// score of the connection p1 -> p2 (node indices relative to the sequence's first node); false: no such connection
-template <class S>
-GFN bool dp_connection(const S &src, double st_wt, int p1, int p2, const DpNode &n2, double &total, int &mark) {
+// score of the connection p1 -> p2 (node indices relative to the sequence's first node); false: no such connection.
+// KNOWN: the caller enumerates p1 by class (strand KS1, stop KST1), so the twelve cases fold to the ones that class can take -- the
+// same statements either way.
+template <class S, bool KNOWN, int KS1, bool KST1>
+GFN bool dp_connection_x(const S &src, double st_wt, int p1, int p2, const DpNode &n2, double &total, int &mark) {
   const int flag = src.flag;
-  const DpNode n1 = src.node(p1);
+  DpNode n1 = src.node(p1);
+  if (KNOWN) { n1.strand = KS1; n1.stop = KST1; }
   int left = n1.ndx, right = n2.ndx, ovlp = 0, maxfr = -1;
   double score = 0.0, scr_mod = 0.0;
   const int s1 = n1.strand, s2 = n2.strand; const bool st1 = n1.stop, st2 = n2.stop;
@@ -227,6 +230,33 @@ GFN bool dp_connection(const S &src, double st_wt, int p1, int p2, const DpNode 
   total = src.score(p1) + score;
   mark = maxfr;
   return true;
+}
+template <class S>
+GFN bool dp_connection(const S &src, double st_wt, int p1, int p2, const DpNode &n2, double &total, int &mark) {
+  return dp_connection_x<S, false, 0, false>(src, st_wt, p1, p2, n2, total, mark);
+}
+// node classes of the dynamic program: 0 forward start, 1 forward stop, 2 reverse start, 3 reverse stop
+GFN int dp_class(int strand, bool stop) { return (strand == -1 ? 2 : 0) + (stop ? 1 : 0); }
+// can a node of class c1 precede one of class c2 at all (the four early exits of score_connection)?
+GFN bool dp_pair_possible(int c1, int c2) {
+  const unsigned ok = (1u << (1 * 4 + 0)) | (1u << (2 * 4 + 0)) |                    // -> forward start: forward stop, reverse start
+                      (1u << (0 * 4 + 1)) | (1u << (1 * 4 + 1)) |                    // -> forward stop: forward start, forward stop
+                      (1u << (1 * 4 + 2)) | (1u << (3 * 4 + 2)) |                    // -> reverse start: forward stop, reverse stop
+                      (1u << (1 * 4 + 3)) | (1u << (2 * 4 + 3)) | (1u << (3 * 4 + 3));   // -> reverse stop: forward stop, reverse start, reverse stop
+  return (ok >> (c1 * 4 + c2)) & 1u;
+}
+template <class S>
+GFN bool dp_connection_class(int c1, const S &src, double st_wt, int p1, int p2, const DpNode &n2, double &total, int &mark) {
+  switch (c1) {
+    case 0: return dp_connection_x<S, true, 1, false>(src, st_wt, p1, p2, n2, total, mark);
+    case 1: return dp_connection_x<S, true, 1, true>(src, st_wt, p1, p2, n2, total, mark);
+    case 2: return dp_connection_x<S, true, -1, false>(src, st_wt, p1, p2, n2, total, mark);
+    default: return dp_connection_x<S, true, -1, true>(src, st_wt, p1, p2, n2, total, mark);
+  }
+}
+// the reference keeps the LAST candidate (largest index) that reaches the running maximum; candidates may arrive in any order here
+GFN void dp_take(double tot, int j, int mark, double &best, int &bj, int &bmark) {
+  if (tot >= 0.0 && (bj < 0 || tot > best || (tot == best && j > bj))) { best = tot; bj = j; bmark = mark; }
 }
 
 // ---- per-node bodies ----

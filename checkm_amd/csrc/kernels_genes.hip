@@ -269,16 +269,22 @@ void x_hexamer_background(GExec &e, const uint8_t *code, const uint64_t *seq_off
 
 // ---- the dynamic program ----
 // The nodes of a sequence go in order; node i looks back over about a thousand predecessors (dprog.c: 500 nodes, and 500 more behind the
-// node that far back), and scoring one connection is a chain of dependent reads: the predecessor's position / strand / type, its score and
-// trace-back, the start nodes it overlaps, their coding scores.  The last 2048 nodes live in an LDS RING -- 36 bytes per node: position,
-// stop position, trace-back, {flags, three overlapping-start offsets} packed in a word, score, connection value (GC-frame bias x GC score
-// in the training pass, coding + start score in the final pass) -- filled 64 nodes ahead of the sweep by all lanes; what lies further back
-// (behind a giant ORF) and the two doubles only operon neighbours need (rscore, uscore) are read from global memory.
-constexpr int DPW = 2048;
-struct DpRing { int ndx[DPW], sv[DPW], tb[DPW], pk[DPW], lo[DPW]; double score[DPW], val[DPW]; };
+// node that far back).  Round 4 scored all of them with the twelve-case connection function, every lane on its own case: ~1000 VALU
+// instructions per 64 candidates, 11-16 us per node.  Now the candidates are enumerated BY CLASS (forward / reverse, start / stop):
+//   * the last 2048 nodes live in an LDS ring (position, stop position, trace-back, packed flags and overlapping-start offsets, window
+//     start, score, connection value, and the number of nodes of each class before the node), filled 64 nodes ahead of the sweep;
+//   * four more rings hold the indices of the last 1024 nodes of each class, so the class-c candidates of node i are ring entries
+//     [count_c(window start), count_c(i)) -- a wavefront's 64 candidates share one class, the connection function folds to that class's
+//     cases (gene_dev.h: dp_connection_x<KNOWN>), and classes that cannot precede node i (6 of the 16 pairs) are never touched;
+//   * one barrier per node: the wavefronts' partial results are double-buffered by node parity and combined by every thread, the ring
+//     entry of node i is written by thread 0 while the others already score node i + 1 (node i itself is served from registers).
+// What does not fit the rings (a window that starts behind a giant open reading frame) goes through the generic loop over global memory.
+constexpr int DPW = 2048, DPC = 1024;
+struct DpRing { int ndx[DPW], sv[DPW], tb[DPW], pk[DPW], lo[DPW]; double score[DPW], val[DPW]; uint32_t cnt[DPW][4]; int cls[4][DPC]; };
 
 struct DpSrc {
   const Nodes &nd; DpRing &r; uint32_t first; int lo_rel, hi_rel; int flag;      // nodes with relative index in [lo_rel, hi_rel) are in the ring
+  int pend; double pend_score; int pend_tb;                                       // the node scored last: its ring entry may still be on its way
   __device__ __forceinline__ bool ring(int rel) const { return rel >= lo_rel && rel < hi_rel; }
   __device__ __forceinline__ DpNode node(int rel) const {
     DpNode n;
@@ -293,11 +299,13 @@ struct DpSrc {
   }
   __device__ __forceinline__ double val(int rel) const { return ring(rel) ? r.val[rel & (DPW - 1)] : (flag == 0 ? nd.gcb[first + (uint32_t)rel] : nd.csc[first + (uint32_t)rel]); }
   __device__ __forceinline__ double score(int rel) const {
+    if (rel == pend) return pend_score;
     if (ring(rel)) return r.score[rel & (DPW - 1)];
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
     return GLD(&nd.score[first + (uint32_t)rel]);
   }
   __device__ __forceinline__ int tb(int rel) const {                     // relative, or -1
+    if (rel == pend) return pend_tb;
     if (ring(rel)) return r.tb[rel & (DPW - 1)];
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
     return GLD(&nd.traceb[first + (uint32_t)rel]);
@@ -306,68 +314,105 @@ struct DpSrc {
   __device__ __forceinline__ double uscore(int rel) const { return nd.uscore[first + (uint32_t)rel]; }
 };
 
-// one workgroup of DP_NT threads per sequence; score / traceb / ov_mark must arrive zero / -1 / -1.  A node's ~1000 candidates are spread
-// over the workgroup's wavefronts; every wavefront reduces its own best candidate by shuffles, the leaders' results meet in LDS and thread 0
-// applies the reference's tie rule across them (maximum total, then the LARGEST j: the sequential loop keeps the last candidate that
-// reaches the running maximum).
 constexpr int DP_NT = 256, DP_NW = DP_NT / 64;
 __global__ void __launch_bounds__(DP_NT) gene_dp_kernel(Nodes nd, const uint32_t *__restrict__ seq_lo, const uint32_t *__restrict__ seq_n, const uint32_t *__restrict__ seq_bin,
                                                         const double *__restrict__ st_wt_of_bin, uint32_t nseq, int flag) {
   __shared__ DpRing ring;
-  __shared__ double red_best[DP_NW]; __shared__ int red_j[DP_NW], red_mark[DP_NW];
+  __shared__ double red_best[2][DP_NW]; __shared__ int red_j[2][DP_NW], red_mark[2][DP_NW];
+  __shared__ uint32_t ring_tot[4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   for (uint32_t s = blockIdx.x; s < nseq; s += gridDim.x) {
     const uint32_t first = seq_lo[s];
     const int nn = (int)seq_n[s];
     const double st_wt = st_wt_of_bin[seq_bin[s]];
     __syncthreads();
+    if (tid < 4) ring_tot[tid] = 0;
+    __syncthreads();
+    int pend = -1, pend_tb = -1; double pend_score = 0.0;
     for (int i0 = 0; i0 < nn; i0 += 64) {
-      {
-        const int rel = i0 + tid;
-        if (tid < 64 && rel < nn) {
-          const uint32_t g = first + (uint32_t)rel; const int k = rel & (DPW - 1);
+      // the next 64 nodes enter the rings (wavefront 0; the entries they overwrite are 2048 nodes / 1024 class members back)
+      if (wv == 0) {
+        const int rel = i0 + lane; const bool in = rel < nn;
+        int cls = -1, pk = 0; uint32_t g = first + (uint32_t)(in ? rel : 0);
+        if (in) { const bool st = nd.type[g] == 3; const int str = nd.strand[g]; cls = dp_class(str, st); pk = (st ? 1 : 0) | (str == -1 ? 2 : 0); }
+        const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+        uint32_t before[4], tot[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const unsigned long long m = __ballot(cls == c); tot[c] = ring_tot[c]; before[c] = tot[c] + (uint32_t)__popcll(m & below); tot[c] += (uint32_t)__popcll(m); }
+        if (in) {
+          const int k = rel & (DPW - 1);
           ring.ndx[k] = nd.ndx[g]; ring.sv[k] = nd.sv[g]; ring.tb[k] = -1; ring.score[k] = 0.0;
           ring.val[k] = flag == 0 ? nd.gcb[g] : nd.csc[g];
-          int pk = (nd.type[g] == 3 ? 1 : 0) | (nd.strand[g] == -1 ? 2 : 0);
           for (int f = 0; f < 3; ++f) {
             const int sp = nd.star[(size_t)g * 3 + f]; const int o = sp < 0 ? -128 : sp - rel;
             if (sp >= 0 && (o < -127 || o > 127)) pk |= 8;          // (does not fit the packed offset: this node's overlapping starts are read from global memory)
             pk |= (o & 0xff) << (8 + 8 * f);
           }
           ring.pk[k] = pk; ring.lo[k] = (int)nd.dp_min[g];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) ring.cnt[k][c] = before[c];
+          ring.cls[cls][before[cls] & (DPC - 1)] = rel;
         }
+        if (lane == 0) { for (int c = 0; c < 4; ++c) ring_tot[c] = tot[c]; }
       }
       __syncthreads();
       const int i1 = min(nn, i0 + 64);
-      const DpSrc S{nd, ring, first, max(0, i0 + 64 - DPW), i1, flag};
+      const int ring_lo = max(0, i0 + 64 - DPW);
       for (int i = i0; i < i1; ++i) {
+        const DpSrc S{nd, ring, first, ring_lo, i1, flag, pend, pend_score, pend_tb};
         const DpNode n2 = S.node(i);
         const int lo = ring.lo[i & (DPW - 1)];
-        double best = -1.0; int bj = -1, bmark = -1;             // best candidate of this thread: the LAST j of the thread's that reaches its maximum (j ascends)
-        for (int j = lo + tid; j < i; j += DP_NT) {
-          double tot; int mark;
-          if (!dp_connection(S, st_wt, j, i, n2, tot, mark)) continue;
-          if (tot >= 0.0 && tot >= best) { best = tot; bj = j; bmark = mark; }
+        const int c2 = dp_class(n2.strand, n2.stop);
+        double best = -1.0; int bj = -1, bmark = -1;
+        // class ranges; all of them must still be in the class rings, and the window's first node in the node ring
+        bool by_class = lo >= ring_lo;
+        uint32_t a[4], b[4];
+        if (by_class) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { a[c] = ring.cnt[lo & (DPW - 1)][c]; b[c] = ring.cnt[i & (DPW - 1)][c]; if (a[c] + DPC < ring_tot[c]) by_class = false; }
+        }
+        if (by_class) {
+#pragma unroll
+          for (int c1 = 0; c1 < 4; ++c1) {
+            if (!dp_pair_possible(c1, c2)) continue;
+            for (uint32_t k = a[c1] + (uint32_t)tid; k < b[c1]; k += DP_NT) {
+              const int j = ring.cls[c1][k & (DPC - 1)];
+              double tot; int mark; bool ok;
+              if (c1 == 0) ok = dp_connection_x<DpSrc, true, 1, false>(S, st_wt, j, i, n2, tot, mark);
+              else if (c1 == 1) ok = dp_connection_x<DpSrc, true, 1, true>(S, st_wt, j, i, n2, tot, mark);
+              else if (c1 == 2) ok = dp_connection_x<DpSrc, true, -1, false>(S, st_wt, j, i, n2, tot, mark);
+              else ok = dp_connection_x<DpSrc, true, -1, true>(S, st_wt, j, i, n2, tot, mark);
+              if (ok) dp_take(tot, j, mark, best, bj, bmark);
+            }
+          }
+        } else {
+          for (int j = lo + tid; j < i; j += DP_NT) {
+            double tot; int mark;
+            if (dp_connection(S, st_wt, j, i, n2, tot, mark)) dp_take(tot, j, mark, best, bj, bmark);
+          }
         }
 #pragma unroll
         for (int sft = 32; sft >= 1; sft >>= 1) {
           const double ob = __shfl_xor(best, sft); const int oj = __shfl_xor(bj, sft), om = __shfl_xor(bmark, sft);
           if (oj >= 0 && (bj < 0 || ob > best || (ob == best && oj > bj))) { best = ob; bj = oj; bmark = om; }
         }
-        if (lane == 0) { red_best[wv] = best; red_j[wv] = bj; red_mark[wv] = bmark; }
+        const int par = i & 1;
+        if (lane == 0) { red_best[par][wv] = best; red_j[par][wv] = bj; red_mark[par][wv] = bmark; }
         __syncthreads();
-        if (tid == 0) {
-          for (int k = 1; k < DP_NW; ++k) {
-            const double ob = red_best[k]; const int oj = red_j[k], om = red_mark[k];
-            if (oj >= 0 && (bj < 0 || ob > best || (ob == best && oj > bj))) { best = ob; bj = oj; bmark = om; }
-          }
-          if (bj >= 0) {
-            ring.score[i & (DPW - 1)] = best; ring.tb[i & (DPW - 1)] = bj;
-            GST(&nd.score[first + (uint32_t)i], best); GST(&nd.traceb[first + (uint32_t)i], bj); GST(&nd.ov_mark[first + (uint32_t)i], bmark);
-          }
+        best = red_best[par][0]; bj = red_j[par][0]; bmark = red_mark[par][0];
+#pragma unroll
+        for (int k = 1; k < DP_NW; ++k) {
+          const double ob = red_best[par][k]; const int oj = red_j[par][k], om = red_mark[par][k];
+          if (oj >= 0 && (bj < 0 || ob > best || (ob == best && oj > bj))) { best = ob; bj = oj; bmark = om; }
         }
-        __syncthreads();
+        // node i is final: every thread knows it; thread 0 publishes it (ring + global), the rest go on with node i + 1
+        pend = i; pend_score = bj >= 0 ? best : 0.0; pend_tb = bj >= 0 ? bj : -1;
+        if (tid == 0 && bj >= 0) {
+          ring.score[i & (DPW - 1)] = best; ring.tb[i & (DPW - 1)] = bj;
+          GST(&nd.score[first + (uint32_t)i], best); GST(&nd.traceb[first + (uint32_t)i], bj); GST(&nd.ov_mark[first + (uint32_t)i], bmark);
+        }
       }
+      __syncthreads();              // (the last node of the batch is in the ring before the next 64 enter)
     }
   }
 }

@@ -111,11 +111,18 @@ void x_dp(GExec &, const Nodes &nd, const uint32_t *seq_lo, const uint32_t *seq_
     const DpFlat S{nd, seq_lo[s], flag}; const int nn = (int)seq_n[s]; const double w = st_wt[seq_bin[s]];
     for (int i = 0; i < nn; ++i) {
       const DpNode n2 = S.node(i);
+      // candidates class by class, as the device kernel enumerates them (the class-folded connection score, the order-free tie rule)
       double best = -1.0; int bj = -1, bmark = -1;
-      for (int j = (int)nd.dp_min[S.first + i]; j < i; ++j) {
-        double tot; int mark;
-        if (!dp_connection(S, w, j, i, n2, tot, mark)) continue;
-        if (tot >= 0.0 && tot >= best) { best = tot; bj = j; bmark = mark; }
+      const int c2 = dp_class(n2.strand, n2.stop);
+      for (int c1 = 0; c1 < 4; ++c1) {
+        if (!dp_pair_possible(c1, c2)) continue;
+        for (int j = i - 1; j >= (int)nd.dp_min[S.first + i]; --j) {          // (descending on purpose: the tie rule must not lean on the order)
+          const DpNode n1 = S.node(j);
+          if (dp_class(n1.strand, n1.stop) != c1) continue;
+          double tot; int mark;
+          if (!dp_connection_class(c1, S, w, j, i, n2, tot, mark)) continue;
+          dp_take(tot, j, mark, best, bj, bmark);
+        }
       }
       if (bj >= 0) { nd.score[S.first + i] = best; nd.traceb[S.first + i] = bj; nd.ov_mark[S.first + i] = bmark; }
     }
