@@ -280,7 +280,7 @@ void x_hexamer_background(GExec &e, const uint8_t *code, const uint64_t *seq_off
 //     entry of node i is written by thread 0 while the others already score node i + 1 (node i itself is served from registers).
 // What does not fit the rings (a window that starts behind a giant open reading frame) goes through the generic loop over global memory.
 constexpr int DPW = 2048, DPC = 1024;
-struct DpRing { int ndx[DPW], sv[DPW], tb[DPW], pk[DPW], lo[DPW]; double score[DPW], val[DPW]; uint32_t cnt[DPW][4]; int cls[4][DPC]; };
+struct DpRing { int ndx[DPW], sv[DPW], tb[DPW], pk[DPW], lo[DPW], mark[DPW]; double score[DPW], val[DPW]; uint32_t cnt[DPW][4]; int cls[4][DPC]; };
 
 struct DpSrc {
   const Nodes &nd; DpRing &r; uint32_t first; int lo_rel, hi_rel; int flag;      // nodes with relative index in [lo_rel, hi_rel) are in the ring
@@ -407,12 +407,17 @@ __global__ void __launch_bounds__(DP_NT) gene_dp_kernel(Nodes nd, const uint32_t
         }
         // node i is final: every thread knows it; thread 0 publishes it (ring + global), the rest go on with node i + 1
         pend = i; pend_score = bj >= 0 ? best : 0.0; pend_tb = bj >= 0 ? bj : -1;
-        if (tid == 0 && bj >= 0) {
-          ring.score[i & (DPW - 1)] = best; ring.tb[i & (DPW - 1)] = bj;
-          GST(&nd.score[first + (uint32_t)i], best); GST(&nd.traceb[first + (uint32_t)i], bj); GST(&nd.ov_mark[first + (uint32_t)i], bmark);
-        }
+        if (tid == 0 && bj >= 0) { ring.score[i & (DPW - 1)] = best; ring.tb[i & (DPW - 1)] = bj; ring.mark[i & (DPW - 1)] = bmark; }
       }
       __syncthreads();              // (the last node of the batch is in the ring before the next 64 enter)
+      // the batch's results go to global memory together (a store per node made every node's barrier wait for the memory system)
+      if (wv == 1) {
+        const int rel = i0 + lane;
+        if (rel < nn) {
+          const int k = rel & (DPW - 1); const int t = ring.tb[k];
+          if (t >= 0) { GST(&nd.score[first + (uint32_t)rel], ring.score[k]); GST(&nd.traceb[first + (uint32_t)rel], t); GST(&nd.ov_mark[first + (uint32_t)rel], ring.mark[k]); }
+        }
+      }
     }
   }
 }
