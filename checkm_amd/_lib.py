@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcheckm_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class CkmError(RuntimeError):
@@ -121,7 +121,7 @@ EXPORTS = ["ckm_last_error", "ckm_abi_version", "ckm_device_count", "ckm_ctx_cre
            "ckm_seqs_pack", "ckm_seqs_from_fasta", "ckm_seqs_count", "ckm_seqs_bin_offsets", "ckm_seqs_name", "ckm_seqs_residues", "ckm_seqs_free", "ckm_search", "ckm_hits_columns", "ckm_hits_free",
            "ckm_hits_write_domtblout", "ckm_hits_write_alignments", "ckm_last_search_stats", "ckm_reduce", "ckm_qa_columns_get", "ckm_qa_free", "ckm_count_sets",
            "ckm_align", "ckm_tables_read", "ckm_tables_assign_models", "ckm_tables_get", "ckm_tables_free",
-           "ckm_orf_scan", "ckm_orf_columns_get", "ckm_orf_free", "ckm_debug_orf_flags", "ckm_genes_call", "ckm_genes_columns_get", "ckm_genes_free",
+           "ckm_orf_scan", "ckm_orf_columns_get", "ckm_orf_free", "ckm_debug_orf_flags", "ckm_genes_call", "ckm_genes_columns_get", "ckm_genes_free", "ckm_genes_coding_union", "ckm_genes_write_bin",
            "ckm_debug_stages", "ckm_debug_envelopes", "ckm_debug_region"]
 
 _lib = None
@@ -184,6 +184,8 @@ def load():
     L.ckm_genes_columns_get.argtypes = [C.c_void_p, C.POINTER(GeneColumns)]
     L.ckm_genes_free.argtypes = [C.c_void_p]
     L.ckm_genes_free.restype = None
+    L.ckm_genes_coding_union.argtypes = [C.c_void_p, C.c_void_p]
+    L.ckm_genes_write_bin.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]
     L.ckm_debug_orf_flags.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
     L.ckm_debug_stages.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.ckm_debug_envelopes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -498,39 +500,95 @@ GENE_FIELDS = ("bin", "contig", "begin", "end", "strand", "start_type", "partial
                "gc_cont", "conf", "score", "cscore", "sscore", "rscore", "uscore", "tscore")
 
 
-def call_genes(ctx, bins, trans_table=11, closed=False, mask=True):
-    """Gene calling for a batch of bins (ckm_genes_call): bins = list of lists of nucleotide strings / bytes (the contigs of each bin).
-    Returns (columns dict of numpy arrays over all genes + 'proteins' list of str, per-bin dict, stats dict); `contig` is the contig's
-    index inside its bin."""
-    parts, bin_first = [], [0]
-    for contigs in bins:
-        for c in contigs:
-            parts.append(c.encode() if isinstance(c, str) else bytes(c))
-        bin_first.append(len(parts))
-    off = np.zeros(len(parts) + 1, dtype=np.uint64)
-    if parts:
-        np.cumsum([len(p) for p in parts], out=off[1:])
-    bf = np.asarray(bin_first, dtype=np.uint32)
-    text = b"".join(parts)
-    h = C.c_void_p()
-    _chk(load().ckm_genes_call(ctx.h, text, off.ctypes.data, len(parts), bf.ctypes.data, len(bins), int(trans_table), 1 if closed else 0, 1 if mask else 0, C.byref(h)))
-    try:
+class GeneBatch(object):
+    """The nucleotides of a batch of bins laid out for ckm_genes_call: bins = [[(contig id, sequence as str or bytes), ...], ...]
+    (or plain sequences).  One batch serves both translation tables and the writers."""
+
+    def __init__(self, bins):
+        parts, ids, bin_first = [], [], [0]
+        for contigs in bins:
+            for c in contigs:
+                cid, seq = c if isinstance(c, tuple) else ("", c)
+                parts.append(seq.encode() if isinstance(seq, str) else bytes(seq))
+                ids.append(cid.encode() if isinstance(cid, str) else bytes(cid))
+            bin_first.append(len(parts))
+        self.nbins, self.ncontigs = len(bins), len(parts)
+        self.off = np.zeros(len(parts) + 1, dtype=np.uint64)
+        if parts:
+            np.cumsum([len(p) for p in parts], out=self.off[1:])
+        self.bin_first = np.asarray(bin_first, dtype=np.uint32)
+        self.text = b"".join(parts)
+        self.ids = (C.c_char_p * max(1, len(ids)))(*ids)
+        self.bases = [int(self.off[bin_first[b + 1]] - self.off[bin_first[b]]) for b in range(self.nbins)]
+
+
+class GeneCall(object):
+    """Result of one ckm_genes_call (a batch of bins, one translation table); close() frees it."""
+
+    def __init__(self, ctx, batch, trans_table=11, closed=False, mask=True):
+        self.batch, self.table = batch, int(trans_table)
+        self.h = C.c_void_p()
+        _chk(load().ckm_genes_call(ctx.h, batch.text, batch.off.ctypes.data, batch.ncontigs, batch.bin_first.ctypes.data, batch.nbins, self.table, 1 if closed else 0, 1 if mask else 0, C.byref(self.h)))
         cols = GeneColumns()
-        _chk(load().ckm_genes_columns_get(h, C.byref(cols)))
-        n, nb = int(cols.n), int(cols.nbins)
+        _chk(load().ckm_genes_columns_get(self.h, C.byref(cols)))
+        self._cols = cols
+        nb = int(cols.nbins)
+        arr = np.ctypeslib.as_array
+        self.per_bin = {f: (arr(getattr(cols, "bin_" + f), shape=(nb,)).copy() if nb else np.zeros(0)) for f in ("trained", "uses_sd", "gc", "bases", "coding", "nodes")}
+        self.stats = dict(ms_nodes=cols.ms_nodes, ms_dp_train=cols.ms_dp_train, ms_score=cols.ms_score, ms_dp_find=cols.ms_dp_find, ms_total=cols.ms_total)
+        self.ngenes = int(cols.n)
+
+    def columns(self):
+        """Columns dict of numpy arrays over all genes + 'proteins' list of str; `contig` is the contig's index inside its bin."""
+        cols, n = self._cols, self.ngenes
         arr = np.ctypeslib.as_array
         out = {f: (arr(getattr(cols, f), shape=(n,)).copy() if n else np.zeros(0, dtype=np.int64)) for f in GENE_FIELDS}
         if n:
-            out["contig"] = out["contig"] - bf[out["bin"]]
+            out["contig"] = out["contig"] - self.batch.bin_first[out["bin"]]
         po = arr(cols.prot_off, shape=(n + 1,)).copy() if n else np.zeros(1, dtype=np.uint64)
         blob = C.string_at(cols.prot, int(po[-1])) if n else b""
         txt, pl = blob.decode("ascii"), po.tolist()
         out["proteins"] = [txt[a:b] for a, b in zip(pl[:-1], pl[1:])]
-        per_bin = {f: (arr(getattr(cols, "bin_" + f), shape=(nb,)).copy() if nb else np.zeros(0)) for f in ("trained", "uses_sd", "gc", "bases", "coding", "nodes")}
-        stats = dict(ms_nodes=cols.ms_nodes, ms_dp_train=cols.ms_dp_train, ms_score=cols.ms_score, ms_dp_find=cols.ms_dp_find, ms_total=cols.ms_total)
+        return out
+
+    def genes_per_bin(self):
+        if not self.ngenes:
+            return np.zeros(self.batch.nbins, dtype=np.int64)
+        b = np.ctypeslib.as_array(self._cols.bin, shape=(self.ngenes,))
+        return np.bincount(b, minlength=self.batch.nbins)
+
+    def coding_union(self):
+        """Bases of every bin covered by at least one gene (checkm/prodigal.py:246-274)."""
+        out = np.zeros(max(1, self.batch.nbins), dtype=np.uint64)
+        _chk(load().ckm_genes_coding_union(self.h, out.ctypes.data))
+        return out[:self.batch.nbins]
+
+    def write_bin(self, b, aaFile, gffFile, ntFile=None):
+        bt = self.batch
+        _chk(load().ckm_genes_write_bin(self.h, int(b), self.table, bt.ids, bt.text, bt.off.ctypes.data, bt.bin_first.ctypes.data,
+                                        aaFile.encode(), gffFile.encode(), ntFile.encode() if ntFile else None))
+
+    def close(self):
+        if self.h:
+            load().ckm_genes_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def call_genes(ctx, bins, trans_table=11, closed=False, mask=True):
+    """Gene calling for a batch of bins (ckm_genes_call): bins = list of lists of nucleotide strings / bytes (the contigs of each bin).
+    Returns (columns dict of numpy arrays over all genes + 'proteins' list of str, per-bin dict, stats dict); `contig` is the contig's
+    index inside its bin."""
+    call = GeneCall(ctx, GeneBatch(bins), trans_table, closed, mask)
+    try:
+        return call.columns(), call.per_bin, call.stats
     finally:
-        load().ckm_genes_free(h)
-    return out, per_bin, stats
+        call.close()
 
 
 def debug_orf_flags(ctx, nbytes, reps=10):

@@ -5,9 +5,11 @@ The reference calls `prodigal -p single|meta -q -m -f gff -g <table> -a genes.fa
 program that is in neither /root/reference nor this image; what it does falls into (1) a byte scan that finds the start / stop NODES of
 all six frames, (2) a per-genome training pass, (3) scoring and a dynamic program over the nodes, (4) gene records and translations.
 This module is the Python face of all four on the device: `OrfNodes` (1, libcheckm_hip's ckm_orf_scan) and `call_bins` /
-`call_bin_files` (1-4 for a batch of bins, ckm_genes_call: both dynamic programs, the hexamer sums and the Shine-Dalgarno bins as
-kernels, the ordered sweeps on the library's host threads), writing genes.faa / genes.gff in prodigal's layout and applying the
-reference's choice between the tables.  The single-genome mode only: `-p meta` (pre-trained models, used by CheckM below 100 kb) is
+`call_bin_files` (1-4 for a batch of bins, ckm_genes_call: the nodes stay on the device from the codon flags to the gene records, the
+host only takes the logarithms of the training tables), writing genes.faa / genes.gff in prodigal's layout (ckm_genes_write_bin) and
+applying the reference's choice between the tables.  The pipeline is latency-bound (a workgroup per bin in the dynamic programs, a thread
+per contig in the trace-back walks), so `call_bin_files` keeps several calls in flight: sub-batches of bins x both tables on CKM_GENE_LANES
+host threads, each call on a stream of its own.  The single-genome mode only: `-p meta` (pre-trained models, used by CheckM below 100 kb) is
 not built -- bins of 20-100 kb are trained on themselves here, smaller ones are refused.  The oracle is oracle/gene_full.c (parity
 unpinned: a restatement of Prodigal 2.6.3 from memory).  There is no CPU implementation here: without a gfx950 device the library raises."""
 from checkm_amd import _lib, runtime
@@ -15,23 +17,27 @@ from checkm_amd import _lib, runtime
 ATG, GTG, TTG, STOP = 0, 1, 2, 3
 
 
-def read_contigs(fastaFile):
-    """[(id, sequence)] of a nucleotide FASTA file (plain or gzip), ids cut at the first whitespace as the reference's readFasta does
-    (checkm/util/seqUtils.py:180-211)."""
+def read_contigs_bytes(fastaFile):
+    """[(id bytes, sequence bytes)] of a nucleotide FASTA file (plain or gzip), ids cut at the first whitespace as the reference's
+    readFasta does (checkm/util/seqUtils.py:180-211).  Whole-file byte operations: a 2 Mb bin takes a millisecond or two."""
     import gzip
     opener = gzip.open if fastaFile.endswith('.gz') else open
-    out, name, seq = [], None, []
-    with opener(fastaFile, 'rt') as f:
-        for line in f:
-            if line.startswith('>'):
-                if name is not None:
-                    out.append((name, ''.join(seq)))
-                name, seq = line[1:].split(None, 1)[0] if line[1:].strip() else '', []
-            elif name is not None:
-                seq.append(line.strip())
-    if name is not None:
-        out.append((name, ''.join(seq)))
+    with opener(fastaFile, 'rb') as f:
+        data = f.read()
+    out = []
+    start = data.find(b'>') if not data.startswith(b'>') else 0
+    if start < 0:
+        return out
+    for rec in data[start + 1:].split(b'\n>'):
+        head, _nl, body = rec.partition(b'\n')
+        hs = head.split(None, 1)
+        out.append((hs[0] if hs else b'', body.translate(None, b'\n\r \t')))
     return out
+
+
+def read_contigs(fastaFile):
+    """[(id, sequence)] as str (tests, diagnostics); the batch path uses read_contigs_bytes."""
+    return [(c.decode(), s.decode()) for c, s in read_contigs_bytes(fastaFile)]
 
 
 class OrfNodes(object):
@@ -103,7 +109,7 @@ class BinGenes(object):
 
     def write(self, aaFile, gffFile, ntFile=None):
         """genes.faa / genes.gff (/ genes.fna) in prodigal's layout: `>contig_n # begin # end # strand # attributes`, GFF3 CDS lines."""
-        comp = bytes.maketrans(b"ACGTacgtNn", b"TGCAtgcaNn")
+        comp = bytes.maketrans(b"ACGTRYKMSWBDHVNacgtrykmswbdhvn", b"TGCAYRMKSWVHDBNtgcayrmkswvhdbn")      # (IUPAC codes complement too)
         L = {f: (v.tolist() if hasattr(v, "tolist") else v) for f, v in self.cols.items()}      # plain lists: one conversion per column, not one per field of every gene
         per = {}
         for k, c in enumerate(L["contig"]):
@@ -148,13 +154,13 @@ class BinGenes(object):
 
 def call_bins(bins, table, mask=True, ctx=None):
     """Genes of many bins for one translation table in ONE device call (ckm_genes_call): bins = [[(contig id, sequence), ...], ...].
-    Returns a list of BinGenes."""
+    Returns a list of BinGenes (the columns copied out; diagnostics and tests -- call_bin_files keeps the results in the library)."""
     ctx = ctx if ctx is not None else runtime.get_ctx()
     cols, per_bin, stats = _lib.call_genes(ctx, [[s for _c, s in contigs] for contigs in bins], table, False, mask)
     import numpy as np
     at = np.searchsorted(cols["bin"], np.arange(len(bins) + 1))        # the records come in bin order
     out = [BinGenes(bins[b], table, cols, slice(int(at[b]), int(at[b + 1])), per_bin["trained"][b], per_bin["uses_sd"][b], per_bin["gc"][b]) for b in range(len(bins))]
-    call_bins.last_stats = stats          # (of whichever table finished last when two run side by side: diagnostics only)
+    call_bins.last_stats = stats
     return out
 
 
@@ -165,50 +171,109 @@ def best_table(genes11, genes4, total_bases):
     return (4 if (d4 - d11 > 0.05) and d4 > 0.7 else 11), {11: d11, 4: d4}
 
 
-def call_bin_files(jobs, bNucORFs=False, max_bases=1 << 30, logger=None):
+META_RANGE = 100000            # below this CheckM runs `prodigal -p meta` (checkm/prodigal.py:80-83)
+
+
+def _lanes():
+    import os
+    return max(1, min(16, int(os.environ.get("CKM_GENE_LANES", "6"))))
+
+
+def call_bin_files(jobs, bNucORFs=False, max_bases=None, logger=None):
     """jobs = [(nucleotide FASTA of a bin, directory for genes.faa / genes.gff [/ genes.fna])].  Both translation tables per bin from the
     device, the reference's choice between them, prodigal's file layout.  Returns {binFile: (best table, {11: density, 4: density})}.
-    A bin below 20 kb cannot be trained on (and the pre-trained `-p meta` models CheckM would use below 100 kb are not built): it raises."""
+    The bins go through the device in sub-batches of <= max_bases (CKM_GENE_BATCH_MB, default 64 Mbase), several calls in flight.
+    Raises ValueError -- before anything is written -- when a bin is below the 20 kb the gene finder can train on (the pre-trained
+    `-p meta` models CheckM would use below 100 kb are not built), and after the other bins' files are written when a trained bin
+    yields no genes (the reference treats empty prodigal output as a failure, checkm/prodigal.py:96-115)."""
     import os
+    import threading
     import time
+    from concurrent.futures import ThreadPoolExecutor
     from checkm_amd.defaultValues import DefaultValues
-    out = {}
-    batch, size = [], 0
-    phases = {"read_s": 0.0, "device_calls_s": 0.0, "choose_and_write_s": 0.0}
+    if max_bases is None:
+        max_bases = int(os.environ.get("CKM_GENE_BATCH_MB", "64")) << 20
+    lanes = _lanes()
+    phases = {"read_s": 0.0, "device_calls_s": 0.0, "choose_and_write_s": 0.0, "lanes": lanes, "calls": 0, "wall_s": 0.0}
     call_bin_files.last_phases = phases
+    t_wall = time.perf_counter()
+    out, lock = {}, threading.Lock()
+    if not jobs:
+        return out
+    # ---- read (host threads: file reads and byte operations release the interpreter) ----
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+        contigs_of = list(ex.map(lambda j: read_contigs_bytes(j[0]), jobs))
+    totals = [sum(len(s) for _c, s in c) for c in contigs_of]
+    phases["read_s"] = time.perf_counter() - t0
+    small = [(jobs[k][0], totals[k]) for k in range(len(jobs)) if totals[k] < MIN_SINGLE_GENOME]
+    if small:
+        raise ValueError("bin %s holds %d bases%s: the device gene caller trains on the bin itself and needs %d (the pre-trained models of "
+                         "`prodigal -p meta`, which CheckM uses below 100 kb, are not built); provide called genes (-g) or a prodigal binary"
+                         % (small[0][0], small[0][1], " (and %d more such bins)" % (len(small) - 1) if len(small) > 1 else "", MIN_SINGLE_GENOME))
+    if logger is not None:
+        for k in range(len(jobs)):
+            if totals[k] < META_RANGE:
+                logger.warning("Bin %s holds %d bases: its genes are called with a model trained on the bin itself (prodigal -p single); "
+                               "CheckM runs `prodigal -p meta` below %d bases (checkm/prodigal.py:80-83), so its gene set may differ."
+                               % (jobs[k][0], totals[k], META_RANGE))
+    # ---- sub-batches ----
+    batches, cur, size = [], [], 0
+    for k in range(len(jobs)):
+        if cur and size + totals[k] > max_bases:
+            batches.append(cur); cur, size = [], 0
+        cur.append(k); size += totals[k]
+    if cur:
+        batches.append(cur)
+    ctx = runtime.get_ctx()
+    empty, stats_last = [], {}
 
-    def flush():
-        nonlocal batch, size
-        if not batch:
-            return
-        bins = [b[2] for b in batch]
-        # the two tables side by side, a context each: the dynamic programs are latency-bound (a workgroup per bin) and most of a call is
-        # host threads, so the device phases of one table run underneath the host phases of the other
-        from concurrent.futures import ThreadPoolExecutor
-        t0 = time.perf_counter()
-        with ThreadPoolExecutor(max_workers=2) as ex:
-            f11 = ex.submit(call_bins, bins, 11, True, runtime.get_ctx())
-            f4 = ex.submit(call_bins, bins, 4, True, runtime.get_ctx_k(1))
-            g11, g4 = f11.result(), f4.result()
+    def finish(ks, batch, calls):
         t1 = time.perf_counter()
-        for (binFile, binDir, contigs, total), a, b in zip(batch, g11, g4):
-            if not a.trained:
-                raise ValueError("bin %s holds %d bases: the device gene caller trains on the bin itself and needs %d (the pre-trained models of "
-                                 "`prodigal -p meta`, which CheckM uses below 100 kb, are not built); provide called genes (-g) or a prodigal binary"
-                                 % (binFile, total, MIN_SINGLE_GENOME))
-            best, dens = best_table(a, b, total)
-            (a if best == 11 else b).write(os.path.join(binDir, DefaultValues.PRODIGAL_AA), os.path.join(binDir, DefaultValues.PRODIGAL_GFF),
-                                            os.path.join(binDir, DefaultValues.PRODIGAL_NT) if bNucORFs else None)
-            out[binFile] = (best, dens)
-        phases["device_calls_s"] += t1 - t0; phases["choose_and_write_s"] += time.perf_counter() - t1
-        batch, size = [], 0
-    for binFile, binDir in jobs:
-        t0 = time.perf_counter()
-        contigs = read_contigs(binFile)
-        phases["read_s"] += time.perf_counter() - t0
-        total = sum(len(s) for _c, s in contigs)
-        if batch and size + total > max_bases:
-            flush()
-        batch.append((binFile, binDir, contigs, total)); size += total
-    flush()
+        c11, c4 = calls[11], calls[4]
+        u11, u4, n11, n4 = c11.coding_union(), c4.coding_union(), c11.genes_per_bin(), c4.genes_per_bin()
+        for b, k in enumerate(ks):
+            binFile, binDir = jobs[k]
+            total = totals[k]
+            d11 = float(u11[b]) / total if total else 0
+            d4 = float(u4[b]) / total if total else 0
+            best = 4 if (d4 - d11 > 0.05) and d4 > 0.7 else 11
+            call = c11 if best == 11 else c4
+            call.write_bin(b, os.path.join(binDir, DefaultValues.PRODIGAL_AA), os.path.join(binDir, DefaultValues.PRODIGAL_GFF),
+                           os.path.join(binDir, DefaultValues.PRODIGAL_NT) if bNucORFs else None)
+            with lock:
+                out[binFile] = (best, {11: d11, 4: d4})
+                if (n11 if best == 11 else n4)[b] == 0:
+                    empty.append(binFile)
+        c11.close(); c4.close()
+        with lock:
+            phases["choose_and_write_s"] += time.perf_counter() - t1
+
+    def run_table(ks, batch, calls, table):
+        t1 = time.perf_counter()
+        call = _lib.GeneCall(ctx, batch, table, False, True)
+        with lock:
+            phases["device_calls_s"] += time.perf_counter() - t1; phases["calls"] += 1
+            stats_last.update(call.stats)
+            calls[table] = call
+            both = len(calls) == 2
+        if both:
+            finish(ks, batch, calls)
+
+    with ThreadPoolExecutor(max_workers=lanes) as pool:
+        futs = []
+        for ks in batches:
+            batch = _lib.GeneBatch([contigs_of[k] for k in ks])
+            for k in ks:
+                contigs_of[k] = None                                        # (the batch holds the text now)
+            calls = {}
+            for table in (11, 4):
+                futs.append(pool.submit(run_table, ks, batch, calls, table))
+        for f in futs:
+            f.result()
+    call_bins.last_stats = stats_last
+    phases["wall_s"] = time.perf_counter() - t_wall
+    if empty:
+        raise ValueError("the device gene caller found no genes in bin %s%s (the reference treats empty prodigal output as a failure, checkm/prodigal.py:96-115)"
+                         % (empty[0], " and %d more" % (len(empty) - 1) if len(empty) > 1 else ""))
     return out

@@ -140,7 +140,14 @@ def gene_caller():
     if GENE_CALLER is not None:
         return GENE_CALLER
     want = os.environ.get("CKM_GENE_CALLER", "")
-    if want == "device" or (want != "prodigal" and shutil.which("prodigal") is None):
+    if want == "device":
+        return "device"
+    if want != "prodigal" and shutil.which("prodigal") is None:
+        # chosen implicitly: say so -- the device gene finder restates Prodigal 2.6.3's single-genome mode (parity unpinned: no prodigal was
+        # available to pin it against), so completeness / contamination may differ from a run that calls genes with the prodigal binary
+        logging.getLogger('timestamp').warning("No `prodigal` on PATH: genes are called by the library's own gene finder on the device (a restatement of "
+                                               "Prodigal 2.6.3's single-genome mode, not validated against a prodigal binary; set CKM_GENE_CALLER=device to "
+                                               "choose it explicitly, or install prodigal / pass called genes with -g).")
         return "device"
     if shutil.which("prodigal") is not None:
         from checkm_amd.prodigal import ProdigalRunner
@@ -206,9 +213,12 @@ class MarkerGeneFinder(object):
             if runner == "device":
                 # every bin that still lacks its genes, both translation tables, in batched device calls (checkm/prodigal.py:72-133)
                 from checkm_amd import geneFinder
-                jobs = [(t[0], t[1]) for t in todo if not (os.path.exists(t[3]) and os.stat(t[3]).st_size != 0)]
+                def called(t):      # ProdigalRunner.areORFsCalled (checkm/prodigal.py:155-164): genes.fna decides when nucleotide ORFs are asked for
+                    f = os.path.join(t[1], DefaultValues.PRODIGAL_NT) if bNucORFs else t[3]
+                    return os.path.exists(f) and os.stat(f).st_size != 0
+                jobs = [(t[0], t[1]) for t in todo if not called(t)]
                 try:
-                    geneFinder.call_bin_files(jobs, bNucORFs)
+                    geneFinder.call_bin_files(jobs, bNucORFs, logger=self.logger)
                 except ValueError as e:
                     self.logger.error(str(e))
                     sys.exit(1)

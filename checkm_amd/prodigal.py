@@ -99,7 +99,7 @@ class ProdigalRunner(object):
         if self.use_device:
             from checkm_amd import geneFinder
             try:
-                best, density = geneFinder.call_bin_files([(query, self.outDir)], bNucORFs)[query]
+                best, density = geneFinder.call_bin_files([(query, self.outDir)], bNucORFs, logger=self.logger)[query]
             except ValueError as e:
                 self.logger.error(str(e))
                 sys.exit(1)

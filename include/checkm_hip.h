@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CKM_ABI_VERSION 5
+#define CKM_ABI_VERSION 6
 
 enum {
   CKM_OK      =  0,
@@ -326,6 +326,16 @@ int  ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *contig_off, 
                     int trans_table, int closed_ends, int mask_n_runs, ckm_genes **out);
 int  ckm_genes_columns_get(const ckm_genes *g, ckm_genes_columns *out);
 void ckm_genes_free(ckm_genes *g);
+/* Several ckm_genes_call may run at once on one context (each takes a stream of its own): the gene finder is latency-bound, its
+ * throughput comes from calls in flight.  closed_ends must be 0 (CheckM never passes prodigal's -c; ABI 6 refuses it).
+ * ckm_genes_coding_union: bases of every bin covered by at least one gene -- ProdigalGeneFeatureParser.codingBases summed over the
+ * bin's contigs (checkm/prodigal.py:246-274), the numerator of the coding density that picks the translation table (:117-133).
+ * ckm_genes_write_bin: genes.faa / genes.gff (/ genes.fna when nt_path is not NULL) of one bin in prodigal's layout, the files
+ * ProdigalRunner.run leaves in bins/<binId>/ (checkm/prodigal.py:86-93,136-153); contig_ids[c] = header of contig c up to the first
+ * white space (checkm/util/seqUtils.py:180-211), text / contig_off / bin_first as passed to ckm_genes_call. */
+int  ckm_genes_coding_union(const ckm_genes *g, uint64_t *bases /* [nbins] */);
+int  ckm_genes_write_bin(const ckm_genes *g, uint32_t bin, int trans_table, const char *const *contig_ids, const char *text, const uint64_t *contig_off,
+                         const uint32_t *bin_first, const char *aa_path, const char *gff_path, const char *nt_path);
 
 /* ---- diagnostics used by the parity tests: every stage of one (model, sequence) pair, no filtering */
 typedef struct {

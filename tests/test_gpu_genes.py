@@ -98,3 +98,72 @@ def test_find_from_nucleotide_bins_writes_prodigal_files(gpu_ctx, tmp_path, monk
         names = [ln[1:].split()[0] for ln in open(faa) if ln.startswith(">")]
         assert names[0].rsplit("_", 1)[1] == "1" and len(names) == len((a if best == 11 else b4).rows)
     mgf.release_scan(out)
+
+
+def test_library_writer_equals_the_python_writer(gpu_ctx, tmp_path):
+    """ckm_genes_write_bin (what call_bin_files uses) writes the bytes BinGenes.write writes -- genes.faa, genes.gff, genes.fna, reverse
+    complements of IUPAC codes and lower case included -- and ckm_genes_coding_union is the interval union the table choice needs."""
+    genomes = [sg.make_genome(410, n_contigs=3, contig_len=(25000, 40000)), sg.make_genome(411, n_contigs=2, contig_len=(30000, 40000), sd_frac=0.0, gc=0.4)]
+    s0 = list(genomes[0][1][1])
+    for k, ch in zip(range(500, 20000, 377), "RYKMSWBDHVNrykmacgt" * 10):          # ambiguity codes and lower case inside genes
+        s0[k] = ch
+    genomes[0][1] = (genomes[0][1][0], "".join(s0))
+    batch = _lib.GeneBatch(genomes)
+    for table in (11, 4):
+        call = _lib.GeneCall(gpu_ctx, batch, table)
+        cols = call.columns()
+        at = np.searchsorted(cols["bin"], np.arange(len(genomes) + 1))
+        union = call.coding_union()
+        assert call.genes_per_bin().tolist() == [int(at[b + 1] - at[b]) for b in range(len(genomes))]
+        for b, g in enumerate(genomes):
+            bg = geneFinder.BinGenes(g, table, cols, slice(int(at[b]), int(at[b + 1])), call.per_bin["trained"][b], call.per_bin["uses_sd"][b], call.per_bin["gc"][b])
+            assert int(union[b]) == bg.coding_bases()
+            py = [str(tmp_path / ("py_%d_%d.%s" % (table, b, e))) for e in ("faa", "gff", "fna")]
+            cc = [str(tmp_path / ("c_%d_%d.%s" % (table, b, e))) for e in ("faa", "gff", "fna")]
+            bg.write(*py)
+            call.write_bin(b, *cc)
+            for x, y in zip(py, cc):
+                with open(x, "rb") as fx, open(y, "rb") as fy:
+                    assert fx.read() == fy.read(), (table, b, x)
+            assert os.path.getsize(cc[0]) > 10000
+        call.close()
+
+
+def test_batched_files_path_warns_refuses_and_matches_single_calls(gpu_ctx, tmp_path, caplog):
+    """call_bin_files: sub-batches and several calls in flight give the files single calls give; a 20-100 kb bin is called with a
+    warning that names CheckM's `-p meta` (checkm/prodigal.py:80-83); a bin below 20 kb is refused before anything is written."""
+    import logging
+    from checkm_amd.defaultValues import DefaultValues
+    jobs, genomes = [], []
+    for k in range(7):
+        g = sg.make_genome(500 + k, n_contigs=2 + k % 3, contig_len=(20000, 35000), gc=0.4 + 0.03 * k, table=4 if k == 5 else 11)
+        f = tmp_path / ("b%d.fna" % k)
+        sg.write_fasta(str(f), g)
+        d = tmp_path / ("o%d" % k)
+        d.mkdir()
+        jobs.append((str(f), str(d))); genomes.append(g)
+    logger = logging.getLogger("test_gene_files")
+    with caplog.at_level(logging.WARNING, logger="test_gene_files"):
+        res = geneFinder.call_bin_files(jobs, bNucORFs=True, max_bases=150000, logger=logger)
+    assert geneFinder.call_bin_files.last_phases["calls"] >= 6                        # several sub-batches x two tables
+    assert any("-p meta" in r.getMessage() for r in caplog.records)                    # the 40-100 kb bins say what CheckM would have done
+    for (f, d), g in zip(jobs, genomes):
+        total = sum(len(s) for _c, s in g)
+        a, b4 = geneFinder.call_bins([g], 11)[0], geneFinder.call_bins([g], 4)[0]
+        best, dens = geneFinder.best_table(a, b4, total)
+        assert res[f] == (best, dens)
+        ref = [str(tmp_path / ("ref.%s" % e)) for e in ("faa", "gff", "fna")]
+        (a if best == 11 else b4).write(*ref)
+        for x, name in zip(ref, (DefaultValues.PRODIGAL_AA, DefaultValues.PRODIGAL_GFF, DefaultValues.PRODIGAL_NT)):
+            with open(x, "rb") as fx, open(os.path.join(d, name), "rb") as fy:
+                assert fx.read() == fy.read(), (f, name)
+    # refusal comes before any device call or file
+    tiny = tmp_path / "tiny.fna"
+    tiny.write_text(">c1\n" + "ACGT" * 2000 + "\n")
+    od = tmp_path / "otiny"
+    od.mkdir()
+    od2 = tmp_path / "o_after"
+    od2.mkdir()
+    with pytest.raises(ValueError, match="-p meta"):
+        geneFinder.call_bin_files([(jobs[0][0], str(od2)), (str(tiny), str(od))])
+    assert not os.listdir(str(od)) and not os.listdir(str(od2))
