@@ -268,45 +268,53 @@ void x_hexamer_background(GExec &e, const uint8_t *code, const uint64_t *seq_off
 }
 
 // ---- the dynamic program ----
-// The nodes of a sequence go in order; node i looks back over about a thousand predecessors (dprog.c: 500 nodes, and 500 more behind the
-// node that far back).  Round 4 scored all of them with the twelve-case connection function, every lane on its own case: ~1000 VALU
-// instructions per 64 candidates, 11-16 us per node.  Now the candidates are enumerated BY CLASS (forward / reverse, start / stop):
-//   * the last 2048 nodes live in an LDS ring (position, stop position, trace-back, packed flags and overlapping-start offsets, window
-//     start, score, connection value, and the number of nodes of each class before the node), filled 64 nodes ahead of the sweep;
-//   * four more rings hold the indices of the last 1024 nodes of each class, so the class-c candidates of node i are ring entries
+// The nodes of a sequence go in order; node i looks back over the 1000 nodes before it (dprog.c: 500 nodes, and 500 more behind the node
+// that far back; further when a giant open reading frame sits there).  Round 4 scored all of them with the twelve-case connection function,
+// every lane on its own case: ~1000 VALU instructions per 64 candidates, 11-16 us per node.  Now:
+//   * candidates are enumerated BY CLASS (forward / reverse, start / stop): four LDS rings hold the indices of the last 512 nodes of each
+//     class, a node's record holds how many nodes of each class precede it, so the class-c candidates of node i are ring entries
 //     [count_c(window start), count_c(i)) -- a wavefront's 64 candidates share one class, the connection function folds to that class's
 //     cases (gene_dev.h: dp_connection_x<KNOWN>), and classes that cannot precede node i (6 of the 16 pairs) are never touched;
+//   * the last 1152 nodes live in an LDS ring of 40-byte records read with three wide loads: {position, stop position, flags + packed
+//     overlapping-start offsets, trace-back and window start as 16-bit distances}, {score, connection value}, {class counts}; 50 KB per
+//     workgroup, three workgroups per compute unit (the kernel is latency-bound: a sequence's nodes are strictly in order);
 //   * one barrier per node: the wavefronts' partial results are double-buffered by node parity and combined by every thread, the ring
-//     entry of node i is written by thread 0 while the others already score node i + 1 (node i itself is served from registers).
-// What does not fit the rings (a window that starts behind a giant open reading frame) goes through the generic loop over global memory.
-constexpr int DPW = 2048, DPC = 1024;
-struct DpRing { int ndx[DPW], sv[DPW], tb[DPW], pk[DPW], lo[DPW], mark[DPW]; double score[DPW], val[DPW]; uint32_t cnt[DPW][4]; int cls[4][DPC]; };
+//     entry of node i is written by thread 0 while the others already score node i + 1 (node i itself is served from registers);
+//   * results leave the ring for global memory once per 64 nodes.
+// What does not fit the rings (a window that starts behind a giant open reading frame, more than 512 nodes of one class in a window) goes
+// through the generic loop with global-memory fall-backs.
+constexpr int DPW = 1152, DPC = 512, DP_FAR = 0xffff;
+struct DpRec { int ndx, sv, pk; uint32_t tbl; };            // pk: bit 0 stop, 1 reverse, 3 stars-in-global, 4-5 (overlap mark + 1), 8.. three signed byte offsets; tbl: trace-back distance | window distance << 16
+struct DpRing { DpRec rec[DPW]; double2 sv2[DPW]; ushort4 cnt[DPW]; unsigned short cls[4][DPC]; };
+__device__ __forceinline__ int dp_slot(int rel) { return rel % DPW; }
 
+template <int FLAG>
 struct DpSrc {
-  const Nodes &nd; DpRing &r; uint32_t first; int lo_rel, hi_rel; int flag;      // nodes with relative index in [lo_rel, hi_rel) are in the ring
+  static constexpr int flag = FLAG;
+  const Nodes &nd; DpRing &r; uint32_t first; int lo_rel, hi_rel;                 // nodes with relative index in [lo_rel, hi_rel) are in the ring
   int pend; double pend_score; int pend_tb;                                       // the node scored last: its ring entry may still be on its way
   __device__ __forceinline__ bool ring(int rel) const { return rel >= lo_rel && rel < hi_rel; }
   __device__ __forceinline__ DpNode node(int rel) const {
     DpNode n;
-    if (ring(rel)) { const int k = rel & (DPW - 1); const int pk = r.pk[k]; n.ndx = r.ndx[k]; n.sv = r.sv[k]; n.strand = (pk & 2) ? -1 : 1; n.stop = pk & 1; }
+    if (ring(rel)) { const DpRec q = r.rec[dp_slot(rel)]; n.ndx = q.ndx; n.sv = q.sv; n.strand = (q.pk & 2) ? -1 : 1; n.stop = q.pk & 1; }
     else { const uint32_t g = first + (uint32_t)rel; n.ndx = nd.ndx[g]; n.sv = nd.sv[g]; n.strand = nd.strand[g]; n.stop = nd.type[g] == 3; }
     return n;
   }
-  __device__ __forceinline__ int ndx(int rel) const { return ring(rel) ? r.ndx[rel & (DPW - 1)] : nd.ndx[first + (uint32_t)rel]; }
+  __device__ __forceinline__ int ndx(int rel) const { return ring(rel) ? r.rec[dp_slot(rel)].ndx : nd.ndx[first + (uint32_t)rel]; }
   __device__ __forceinline__ int star(int rel, int f) const {           // relative index of the overlapping start of frame f, or -1
-    if (ring(rel)) { const int pk = r.pk[rel & (DPW - 1)]; if (!(pk & 8)) { const int o = (int)(int8_t)((pk >> (8 + 8 * f)) & 0xff); return o == -128 ? -1 : rel + o; } }
+    if (ring(rel)) { const int pk = r.rec[dp_slot(rel)].pk; if (!(pk & 8)) { const int o = (int)(int8_t)((pk >> (8 + 8 * f)) & 0xff); return o == -128 ? -1 : rel + o; } }
     return nd.star[(size_t)(first + (uint32_t)rel) * 3 + f];
   }
-  __device__ __forceinline__ double val(int rel) const { return ring(rel) ? r.val[rel & (DPW - 1)] : (flag == 0 ? nd.gcb[first + (uint32_t)rel] : nd.csc[first + (uint32_t)rel]); }
+  __device__ __forceinline__ double val(int rel) const { return ring(rel) ? r.sv2[dp_slot(rel)].y : (FLAG == 0 ? nd.gcb[first + (uint32_t)rel] : nd.csc[first + (uint32_t)rel]); }
   __device__ __forceinline__ double score(int rel) const {
     if (rel == pend) return pend_score;
-    if (ring(rel)) return r.score[rel & (DPW - 1)];
+    if (ring(rel)) return r.sv2[dp_slot(rel)].x;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
     return GLD(&nd.score[first + (uint32_t)rel]);
   }
   __device__ __forceinline__ int tb(int rel) const {                     // relative, or -1
     if (rel == pend) return pend_tb;
-    if (ring(rel)) return r.tb[rel & (DPW - 1)];
+    if (ring(rel)) { const uint32_t d = r.rec[dp_slot(rel)].tbl & 0xffffu; if (d != (uint32_t)DP_FAR) return d == 0 ? -1 : rel - (int)d; }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
     return GLD(&nd.traceb[first + (uint32_t)rel]);
   }
@@ -315,10 +323,11 @@ struct DpSrc {
 };
 
 constexpr int DP_NT = 256, DP_NW = DP_NT / 64;
+template <int FLAG>
 __global__ void __launch_bounds__(DP_NT) gene_dp_kernel(Nodes nd, const uint32_t *__restrict__ seq_lo, const uint32_t *__restrict__ seq_n, const uint32_t *__restrict__ seq_bin,
-                                                        const double *__restrict__ st_wt_of_bin, uint32_t nseq, int flag) {
+                                                        const double *__restrict__ st_wt_of_bin, uint32_t nseq) {
   __shared__ DpRing ring;
-  __shared__ double red_best[2][DP_NW]; __shared__ int red_j[2][DP_NW], red_mark[2][DP_NW];
+  __shared__ double red_best[2][DP_NW]; __shared__ int red_j[2][DP_NW];
   __shared__ uint32_t ring_tot[4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   for (uint32_t s = blockIdx.x; s < nseq; s += gridDim.x) {
@@ -330,28 +339,28 @@ __global__ void __launch_bounds__(DP_NT) gene_dp_kernel(Nodes nd, const uint32_t
     __syncthreads();
     int pend = -1, pend_tb = -1; double pend_score = 0.0;
     for (int i0 = 0; i0 < nn; i0 += 64) {
-      // the next 64 nodes enter the rings (wavefront 0; the entries they overwrite are 2048 nodes / 1024 class members back)
+      // the next 64 nodes enter the rings (wavefront 0; the slots they take over are 1152 nodes / 512 class members back)
       if (wv == 0) {
         const int rel = i0 + lane; const bool in = rel < nn;
-        int cls = -1, pk = 0; uint32_t g = first + (uint32_t)(in ? rel : 0);
+        int cls = -1, pk = 0; const uint32_t g = first + (uint32_t)(in ? rel : 0);
         if (in) { const bool st = nd.type[g] == 3; const int str = nd.strand[g]; cls = dp_class(str, st); pk = (st ? 1 : 0) | (str == -1 ? 2 : 0); }
         const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
         uint32_t before[4], tot[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) { const unsigned long long m = __ballot(cls == c); tot[c] = ring_tot[c]; before[c] = tot[c] + (uint32_t)__popcll(m & below); tot[c] += (uint32_t)__popcll(m); }
         if (in) {
-          const int k = rel & (DPW - 1);
-          ring.ndx[k] = nd.ndx[g]; ring.sv[k] = nd.sv[g]; ring.tb[k] = -1; ring.score[k] = 0.0;
-          ring.val[k] = flag == 0 ? nd.gcb[g] : nd.csc[g];
+          const int k = dp_slot(rel);
           for (int f = 0; f < 3; ++f) {
             const int sp = nd.star[(size_t)g * 3 + f]; const int o = sp < 0 ? -128 : sp - rel;
             if (sp >= 0 && (o < -127 || o > 127)) pk |= 8;          // (does not fit the packed offset: this node's overlapping starts are read from global memory)
             pk |= (o & 0xff) << (8 + 8 * f);
           }
-          ring.pk[k] = pk; ring.lo[k] = (int)nd.dp_min[g];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) ring.cnt[k][c] = before[c];
-          ring.cls[cls][before[cls] & (DPC - 1)] = rel;
+          const int lo = (int)nd.dp_min[g]; const uint32_t lod = rel - lo < DP_FAR ? (uint32_t)(rel - lo) : (uint32_t)DP_FAR;
+          DpRec q; q.ndx = nd.ndx[g]; q.sv = nd.sv[g]; q.pk = pk; q.tbl = lod << 16;                 // trace-back distance 0: none yet
+          ring.rec[k] = q;
+          ring.sv2[k] = make_double2(0.0, FLAG == 0 ? nd.gcb[g] : nd.csc[g]);
+          ring.cnt[k] = make_ushort4((unsigned short)before[0], (unsigned short)before[1], (unsigned short)before[2], (unsigned short)before[3]);
+          ring.cls[cls][before[cls] & (DPC - 1)] = (unsigned short)rel;
         }
         if (lane == 0) { for (int c = 0; c < 4; ++c) ring_tot[c] = tot[c]; }
       }
@@ -359,29 +368,35 @@ __global__ void __launch_bounds__(DP_NT) gene_dp_kernel(Nodes nd, const uint32_t
       const int i1 = min(nn, i0 + 64);
       const int ring_lo = max(0, i0 + 64 - DPW);
       for (int i = i0; i < i1; ++i) {
-        const DpSrc S{nd, ring, first, ring_lo, i1, flag, pend, pend_score, pend_tb};
-        const DpNode n2 = S.node(i);
-        const int lo = ring.lo[i & (DPW - 1)];
+        const DpSrc<FLAG> S{nd, ring, first, ring_lo, i1, pend, pend_score, pend_tb};
+        const DpRec qi = ring.rec[dp_slot(i)];
+        DpNode n2; n2.ndx = qi.ndx; n2.sv = qi.sv; n2.strand = (qi.pk & 2) ? -1 : 1; n2.stop = qi.pk & 1;
+        const uint32_t lod = qi.tbl >> 16;
+        const int lo = lod == (uint32_t)DP_FAR ? (int)nd.dp_min[first + (uint32_t)i] : i - (int)lod;
         const int c2 = dp_class(n2.strand, n2.stop);
         double best = -1.0; int bj = -1, bmark = -1;
-        // class ranges; all of them must still be in the class rings, and the window's first node in the node ring
+        // class ranges: the window's first node must be in the node ring, every class's members of the window in the class rings
         bool by_class = lo >= ring_lo;
-        uint32_t a[4], b[4];
+        unsigned short a[4], n[4];
         if (by_class) {
+          const ushort4 ca = ring.cnt[dp_slot(lo)], cb = ring.cnt[dp_slot(i)];
+          a[0] = ca.x; a[1] = ca.y; a[2] = ca.z; a[3] = ca.w;
+          n[0] = (unsigned short)(cb.x - ca.x); n[1] = (unsigned short)(cb.y - ca.y); n[2] = (unsigned short)(cb.z - ca.z); n[3] = (unsigned short)(cb.w - ca.w);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) { a[c] = ring.cnt[lo & (DPW - 1)][c]; b[c] = ring.cnt[i & (DPW - 1)][c]; if (a[c] + DPC < ring_tot[c]) by_class = false; }
+          for (int c = 0; c < 4; ++c) if ((unsigned short)((unsigned short)ring_tot[c] - a[c]) > DPC) by_class = false;
         }
         if (by_class) {
 #pragma unroll
           for (int c1 = 0; c1 < 4; ++c1) {
             if (!dp_pair_possible(c1, c2)) continue;
-            for (uint32_t k = a[c1] + (uint32_t)tid; k < b[c1]; k += DP_NT) {
-              const int j = ring.cls[c1][k & (DPC - 1)];
+            for (int t = tid; t < (int)n[c1]; t += DP_NT) {
+              const int jl = ring.cls[c1][(a[c1] + t) & (DPC - 1)];                           // low 16 bits of the index
+              const int j = i - ((i - jl) & 0xffff);
               double tot; int mark; bool ok;
-              if (c1 == 0) ok = dp_connection_x<DpSrc, true, 1, false>(S, st_wt, j, i, n2, tot, mark);
-              else if (c1 == 1) ok = dp_connection_x<DpSrc, true, 1, true>(S, st_wt, j, i, n2, tot, mark);
-              else if (c1 == 2) ok = dp_connection_x<DpSrc, true, -1, false>(S, st_wt, j, i, n2, tot, mark);
-              else ok = dp_connection_x<DpSrc, true, -1, true>(S, st_wt, j, i, n2, tot, mark);
+              if (c1 == 0) ok = dp_connection_x<DpSrc<FLAG>, true, 1, false>(S, st_wt, j, i, n2, tot, mark);
+              else if (c1 == 1) ok = dp_connection_x<DpSrc<FLAG>, true, 1, true>(S, st_wt, j, i, n2, tot, mark);
+              else if (c1 == 2) ok = dp_connection_x<DpSrc<FLAG>, true, -1, false>(S, st_wt, j, i, n2, tot, mark);
+              else ok = dp_connection_x<DpSrc<FLAG>, true, -1, true>(S, st_wt, j, i, n2, tot, mark);
               if (ok) dp_take(tot, j, mark, best, bj, bmark);
             }
           }
@@ -391,38 +406,52 @@ __global__ void __launch_bounds__(DP_NT) gene_dp_kernel(Nodes nd, const uint32_t
             if (dp_connection(S, st_wt, j, i, n2, tot, mark)) dp_take(tot, j, mark, best, bj, bmark);
           }
         }
+        int key = bj < 0 ? -1 : bj * 4 + (bmark + 1);                 // candidate index and overlap mark travel together
 #pragma unroll
         for (int sft = 32; sft >= 1; sft >>= 1) {
-          const double ob = __shfl_xor(best, sft); const int oj = __shfl_xor(bj, sft), om = __shfl_xor(bmark, sft);
-          if (oj >= 0 && (bj < 0 || ob > best || (ob == best && oj > bj))) { best = ob; bj = oj; bmark = om; }
+          const double ob = __shfl_xor(best, sft); const int ok = __shfl_xor(key, sft);
+          if (ok >= 0 && (key < 0 || ob > best || (ob == best && ok > key))) { best = ob; key = ok; }
         }
         const int par = i & 1;
-        if (lane == 0) { red_best[par][wv] = best; red_j[par][wv] = bj; red_mark[par][wv] = bmark; }
+        if (lane == 0) { red_best[par][wv] = best; red_j[par][wv] = key; }
         __syncthreads();
-        best = red_best[par][0]; bj = red_j[par][0]; bmark = red_mark[par][0];
+        best = red_best[par][0]; key = red_j[par][0];
 #pragma unroll
         for (int k = 1; k < DP_NW; ++k) {
-          const double ob = red_best[par][k]; const int oj = red_j[par][k], om = red_mark[par][k];
-          if (oj >= 0 && (bj < 0 || ob > best || (ob == best && oj > bj))) { best = ob; bj = oj; bmark = om; }
+          const double ob = red_best[par][k]; const int ok = red_j[par][k];
+          if (ok >= 0 && (key < 0 || ob > best || (ob == best && ok > key))) { best = ob; key = ok; }
         }
-        // node i is final: every thread knows it; thread 0 publishes it (ring + global), the rest go on with node i + 1
+        bj = key < 0 ? -1 : key >> 2; bmark = key < 0 ? -1 : (key & 3) - 1;
+        // node i is final: every thread knows it; thread 0 publishes it to the ring, the rest go on with node i + 1
         pend = i; pend_score = bj >= 0 ? best : 0.0; pend_tb = bj >= 0 ? bj : -1;
-        if (tid == 0 && bj >= 0) { ring.score[i & (DPW - 1)] = best; ring.tb[i & (DPW - 1)] = bj; ring.mark[i & (DPW - 1)] = bmark; }
+        if (tid == 0 && bj >= 0) {
+          const int k = dp_slot(i);
+          ring.sv2[k].x = best;
+          const uint32_t d = i - bj < DP_FAR ? (uint32_t)(i - bj) : (uint32_t)DP_FAR;
+          ring.rec[k].tbl = (qi.tbl & 0xffff0000u) | d;
+          ring.rec[k].pk = qi.pk | ((bmark + 1) << 4);
+          if (d == (uint32_t)DP_FAR) GST(&nd.traceb[first + (uint32_t)i], bj);                  // (a trace-back the 16-bit distance cannot hold is read from global memory)
+        }
       }
       __syncthreads();              // (the last node of the batch is in the ring before the next 64 enter)
       // the batch's results go to global memory together (a store per node made every node's barrier wait for the memory system)
       if (wv == 1) {
         const int rel = i0 + lane;
         if (rel < nn) {
-          const int k = rel & (DPW - 1); const int t = ring.tb[k];
-          if (t >= 0) { GST(&nd.score[first + (uint32_t)rel], ring.score[k]); GST(&nd.traceb[first + (uint32_t)rel], t); GST(&nd.ov_mark[first + (uint32_t)rel], ring.mark[k]); }
+          const int k = dp_slot(rel); const DpRec q = ring.rec[k]; const uint32_t d = q.tbl & 0xffffu;
+          if (d != 0) {
+            GST(&nd.score[first + (uint32_t)rel], ring.sv2[k].x); GST(&nd.ov_mark[first + (uint32_t)rel], ((q.pk >> 4) & 3) - 1);
+            if (d != (uint32_t)DP_FAR) GST(&nd.traceb[first + (uint32_t)rel], rel - (int)d);
+          }
         }
       }
     }
   }
 }
 void x_dp(GExec &e, const Nodes &nd, const uint32_t *seq_lo, const uint32_t *seq_n, const uint32_t *seq_bin, const double *st_wt, uint32_t nseq, int flag) {
-  if (nseq) hipLaunchKernelGGL(gene_dp_kernel, dim3(nseq), dim3(DP_NT), 0, e.st, nd, seq_lo, seq_n, seq_bin, st_wt, nseq, flag);
+  if (!nseq) return;
+  if (flag == 0) hipLaunchKernelGGL(gene_dp_kernel<0>, dim3(nseq), dim3(DP_NT), 0, e.st, nd, seq_lo, seq_n, seq_bin, st_wt, nseq);
+  else hipLaunchKernelGGL(gene_dp_kernel<1>, dim3(nseq), dim3(DP_NT), 0, e.st, nd, seq_lo, seq_n, seq_bin, st_wt, nseq);
 }
 
 }  // namespace gene
