@@ -60,13 +60,15 @@ extern "C" int ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *co
     if (const char *e = getenv("CKM_GENE_THREADS")) gthreads = std::max(1, std::min(128, atoi(e)));
     HostPool gpool(gthreads);
     const bool tr_on = getenv("CKM_TRACE") != nullptr;
+    static std::atomic<int> call_no{0};
+    const int call_id = call_no++;
     double t_nodes = 0.0;
     ckm::gene::PipeInput in;
     in.text = text; in.contig_off = contig_off; in.ncontigs = ncontigs; in.bin_first = bin_first; in.nbins = nbins; in.trans_table = trans_table; in.mask_runs = mask_runs;
     in.pfor = [&](size_t n, const std::function<void(size_t)> &f) { gpool.run(n, 1, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) f(i); }); };
     in.trace = [&](const char *label) {
       if (!strcmp(label, "nodes in working order")) t_nodes = now_ms();
-      if (tr_on) fprintf(stderr, "ckm-trace genes table %d %9.1f ms  %s\n", trans_table, now_ms() - t_begin, label);
+      if (tr_on) fprintf(stderr, "ckm-trace genes call %d table %d %9.1f ms  %s\n", call_id, trans_table, now_ms() - t_begin, label);
     };
     std::unique_ptr<ckm_genes> o(new ckm_genes());
     ckm::gene::GExec ex; ex.st = lease.st;

@@ -24,6 +24,7 @@ inline void g_h2d(GExec &, void *dst, const void *src, size_t n) { if (n) memcpy
 inline void g_d2h(GExec &, void *dst, const void *src, size_t n) { if (n) memcpy(dst, src, n); }
 inline void g_sync(GExec &) {}
 template <class F> inline void g_map(GExec &, size_t n, F f) { for (size_t i = 0; i < n; ++i) f(i); }
+template <class F> inline void g_map_waves(GExec &, size_t n, F f) { for (size_t i = 0; i < n; ++i) f(i); }
 template <class T> inline T g_atomic_add(T *p, T v) { const T o = *p; *p = o + v; return o; }
 inline void g_atomic_or(unsigned long long *p, unsigned long long v) { *p |= v; }
 [[noreturn]] inline void g_fail(const char *msg) { throw std::runtime_error(msg); }
@@ -58,6 +59,16 @@ template <class F> inline void g_map(GExec &e, size_t n, F f) {
   if (n > (size_t)0x7fffffff * 256) throw Error(CKM_ERANGE, "gene-calling batch too large for one launch");
   hipLaunchKernelGGL(g_map_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e.st, n, f);
 }
+// one index per WAVEFRONT (lane 0 works): the ordered walks over a sequence's nodes are chains of dependent loads -- a walk that shares its
+// wavefront with 63 others moves in lockstep with the slowest of them
+template <class F> __global__ void __launch_bounds__(64) g_map_waves_kernel(size_t n, F f) {
+  if (threadIdx.x == 0 && blockIdx.x < n) f((size_t)blockIdx.x);
+}
+template <class F> inline void g_map_waves(GExec &e, size_t n, F f) {
+  if (!n) return;
+  if (n > (size_t)0x7fffffff) throw Error(CKM_ERANGE, "gene-calling batch too large for one launch");
+  hipLaunchKernelGGL(g_map_waves_kernel<F>, dim3((unsigned)n), dim3(64), 0, e.st, n, f);
+}
 template <class T> __device__ __forceinline__ T g_atomic_add(T *p, T v) { return atomicAdd(p, v); }
 __device__ __forceinline__ void g_atomic_or(unsigned long long *p, unsigned long long v) { atomicOr(p, v); }
 [[noreturn]] inline void g_fail(const char *msg) { throw Error(CKM_ERANGE, msg); }
@@ -74,16 +85,23 @@ void x_orf_flags(GExec &e, const uint8_t *ascii, unsigned long long *planes, uin
 // in-place exclusive prefix sum of n + 1 entries (entry n receives the total)
 void x_scan_u32(GExec &e, uint32_t *a, size_t n, GBuf &scratch);
 
+// One scan of x_chain: the codons of one reading frame of one strand of a sequence from strand position `top` down to `bottom`.  A whole
+// chain starts at the sequence's last codon with the open-end state of add_nodes (after_stop = 0); a bin's training sequence is cut at
+// the TTAATTAATTAA separators between its contigs -- every frame of both strands has a stop there, so the scan state behind one is known:
+// such a piece starts just below that stop (top = the stop's position, after_stop = 1) and ends with the stop event of the next separator
+// (bottom = that stop's position).  Every piece is a chain of its own in the chain array (an open reading frame never spans a stop).
+struct SubChain { uint32_t seq, chain; int32_t top, bottom; uint8_t rev, frame, after_stop, pad; };
 struct ChainArgs {
   const unsigned long long *planes; uint64_t nwin;                    // codon flags
-  const uint64_t *seq_off; const int32_t *seq_len; uint32_t nseq, nbins;        // sequences [0, nbins): training, [nbins, nseq): contigs
+  const uint64_t *seq_off; const int32_t *seq_len; uint32_t nbins;    // sequences [0, nbins): training, the rest contigs
+  const SubChain *sc; uint32_t nsc;
   int tt4;
   const unsigned long long *r50; const uint32_t *pr50;                // starts of 50-runs of unknown bases and their prefix counts (null: no masking)
   unsigned long long *node_planes;                                    // [set][strand][nwin] bit per node position (atomic OR)
-  uint32_t *chain_cnt;                                                // [nseq * 6] events of the chain
-  void *rec; uint32_t *rec_t; unsigned long long *nrec; unsigned long long cap;      // unsorted 16-byte records + their event numbers
+  uint32_t *chain_cnt;                                                // [chains] events of the chain
+  void *rec; uint32_t *rec_t, *rec_c; unsigned long long *nrec; unsigned long long cap;      // unsorted 16-byte records, their event numbers and chains
 };
-// start / stop nodes of every (sequence, strand, frame) chain (node.c: add_nodes with -m masks), open ends
+// start / stop nodes of every chain piece (node.c: add_nodes with -m masks), open ends
 void x_chain(GExec &e, const ChainArgs &a);
 
 // t.bias of every bin: the ordered sum over the bin's start nodes (node.c: record_gc_bias), then scaled to a sum of 3
@@ -92,6 +110,10 @@ void x_gc_bias(GExec &e, const Nodes &nd, const uint32_t *seq_lo, const uint32_t
 // the dynamic program (dprog.c: the forward sweep) for sequences s = 0 .. nseq-1 with nodes [seq_lo[s], seq_lo[s] + seq_n[s]); traceb comes back
 // RELATIVE to the sequence's first node; score / traceb / ov_mark must arrive 0 / -1 / -1
 void x_dp(GExec &e, const Nodes &nd, const uint32_t *seq_lo, const uint32_t *seq_n, const uint32_t *seq_bin, const double *st_wt, uint32_t nseq, int flag);
+
+// where the trace-back of every sequence begins (dprog.c: the highest-scoring node that may end a path -- not a forward start, not a
+// reverse stop -- the LAST of equals in node order); -1: none
+void x_path_ends(GExec &e, const Nodes &nd, const uint32_t *seq_lo, const uint32_t *seq_n, uint32_t nseq, int32_t *end_rel);
 
 // hexamer counts of both strands of every bin's training sequence: hist[b][f] = number of positions whose forward hexamer is f
 void x_hexamer_background(GExec &e, const uint8_t *code, const uint64_t *seq_off, const int32_t *seq_len, uint32_t nbins, int max_len, uint32_t *hist /* [nbins][4096] */);

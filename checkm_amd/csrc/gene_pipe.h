@@ -78,15 +78,10 @@ struct NodeSet {
 };
 
 // ---- ordered walks over one sequence's nodes (relative indices; dprog.c / gene.c), a thread per sequence ----
-GFN int walk_dprog_finish(const NView &V) {
+// max_ndx: where the path ends (x_path_ends: the scan over all of the sequence's nodes is a kernel of its own)
+GFN int walk_dprog_finish(const NView &V, int max_ndx) {
   const Nodes &n = V.n; const uint32_t lo = V.lo; const int nn = V.nn;
-  int max_ndx = -1; double max_sc = -1.0;
   if (nn == 0) return -1;
-  for (int i = nn - 1; i >= 0; --i) {
-    if (V.strand(i) == 1 && !V.stop(i)) continue;
-    if (V.strand(i) == -1 && V.stop(i)) continue;
-    if (n.score[lo + i] > max_sc) { max_sc = n.score[lo + i]; max_ndx = i; }
-  }
   if (max_ndx < 0) return -1;
   int path = max_ndx;
   while (n.traceb[lo + path] != -1) {
@@ -437,17 +432,59 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
   x_scan_u32(e, p0, ntw, d_scan); x_scan_u32(e, p1, ntw, d_scan);
 
   // ---- nodes ----
-  GBuf d_np, d_ccnt, d_rec, d_rect, d_nrec, d_pn, d_rk;
-  d_np.ensure(4 * nwin * 8 + 64); d_ccnt.ensure(((size_t)nseq * 6 + 2) * 4); d_nrec.ensure(16); d_pn.ensure(2 * (nwin + 2) * 4); d_rk.ensure((size_t)nseq * 8 + 64);
+  // the scans: one per (contig, strand, frame); a training sequence of several contigs is cut at its separators (one piece per contig)
+  std::vector<SubChain> subs;
+  const uint32_t nchains = (nseq + ncontigs) * 6;
+  subs.reserve((size_t)ncontigs * 12 + (size_t)nbins * 6);
+  auto whole = [&](uint32_t s, uint32_t chain0) {
+    const int sl = seq_len[s];
+    if (sl < 3) return;
+    for (int sub = 0; sub < 6; ++sub) {
+      const int frame = sub % 3; int jtop = sl - 3; jtop -= ((jtop % 3) - frame + 3) % 3;
+      SubChain q; q.seq = s; q.chain = chain0 + (uint32_t)sub; q.top = jtop; q.bottom = 0; q.rev = sub >= 3; q.frame = (uint8_t)frame; q.after_stop = 0; q.pad = 0;
+      subs.push_back(q);
+    }
+  };
+  for (uint32_t b = 0; b < nbins; ++b) {
+    const uint32_t c0 = in.bin_first[b], c1 = in.bin_first[b + 1];
+    for (uint32_t c = c0; c < c1; ++c) whole(nbins + c, (nbins + c) * 6);
+    if (c1 - c0 <= 1) { whole(b, b * 6); continue; }
+    // the stop of frame f inside the separator that begins at strand position p: TAA at p + 1, p + 5, p + 9
+    auto sep_stop = [](long long p, int f) { for (int k = 1; k <= 9; k += 4) if ((p + k) % 3 == f) return (int)(p + k); return -1; };
+    const int sl = seq_len[b];
+    for (uint32_t c = c0; c < c1; ++c) {
+      const long long cbeg = (long long)(seq_off[nbins + c] - seq_off[b]), cend = cbeg + seq_len[nbins + c];      // the contig in the training sequence; its separator is [cend, cend + 12)
+      for (int sub = 0; sub < 6; ++sub) {
+        const int frame = sub % 3; const bool rev = sub >= 3;
+        SubChain q; q.seq = b; q.chain = (nseq + c) * 6 + (uint32_t)sub; q.rev = rev; q.frame = (uint8_t)frame; q.pad = 0;
+        if (!rev) {
+          q.after_stop = 1; q.top = sep_stop(cend, frame);                                   // below the separator behind the contig ...
+          q.bottom = c == c0 ? 0 : sep_stop(cbeg - 12, frame);                               // ... down to the stop of the separator before it (the first contig: to the sequence's start)
+        } else {
+          // strand positions: the separator [p, p + 12) of the forward strand is [sl - 12 - p, sl - p) here and reads the same
+          if (c == c0) { int jtop = sl - 3; jtop -= ((jtop % 3) - frame + 3) % 3; q.after_stop = 0; q.top = jtop; }
+          else { q.after_stop = 1; q.top = sep_stop((long long)sl - 12 - (cbeg - 12), frame); }
+          q.bottom = sep_stop((long long)sl - 12 - cend, frame);
+        }
+        subs.push_back(q);
+      }
+    }
+  }
+  GBuf d_np, d_ccnt, d_rec, d_rect, d_recc, d_nrec, d_pn, d_rk, d_subs;
+  d_np.ensure(4 * nwin * 8 + 64); d_ccnt.ensure(((size_t)nchains + 2) * 4); d_nrec.ensure(16); d_pn.ensure(2 * (nwin + 2) * 4); d_rk.ensure((size_t)nseq * 8 + 64);
+  d_subs.ensure(std::max<size_t>(1, subs.size()) * sizeof(SubChain));
+  g_h2d(e, d_subs.p, subs.data(), subs.size() * sizeof(SubChain));
   uint64_t bases = 0; for (uint32_t b = 0; b < nbins; ++b) bases += (uint64_t)seq_len[b];
   unsigned long long cap = std::max<unsigned long long>(1 << 16, bases / 2), n_all = 0;
   ChainArgs ca;
-  ca.planes = d_flags.as<unsigned long long>(); ca.nwin = nwin; ca.seq_off = soff; ca.seq_len = slen_d; ca.nseq = nseq; ca.nbins = nbins; ca.tt4 = tt == 4 ? 1 : 0;
+  ca.planes = d_flags.as<unsigned long long>(); ca.nwin = nwin; ca.seq_off = soff; ca.seq_len = slen_d; ca.nbins = nbins; ca.tt4 = tt == 4 ? 1 : 0;
+  ca.sc = reinterpret_cast<const SubChain *>(d_subs.p); ca.nsc = (uint32_t)subs.size();
   ca.r50 = in.mask_runs ? r50 : nullptr; ca.pr50 = in.mask_runs ? pr : nullptr;
   for (int attempt = 0; attempt < 2; ++attempt) {
-    d_rec.ensure((size_t)cap * sizeof(OrfRec)); d_rect.ensure((size_t)cap * 4);
-    g_zero(e, d_np.p, 0, 4 * nwin * 8); g_zero(e, d_ccnt.p, 0, ((size_t)nseq * 6 + 2) * 4); g_zero(e, d_nrec.p, 0, 16);
-    ca.node_planes = d_np.as<unsigned long long>(); ca.chain_cnt = d_ccnt.as<uint32_t>(); ca.rec = d_rec.p; ca.rec_t = d_rect.as<uint32_t>(); ca.nrec = d_nrec.as<unsigned long long>(); ca.cap = cap;
+    d_rec.ensure((size_t)cap * sizeof(OrfRec)); d_rect.ensure((size_t)cap * 4); d_recc.ensure((size_t)cap * 4);
+    g_zero(e, d_np.p, 0, 4 * nwin * 8); g_zero(e, d_ccnt.p, 0, ((size_t)nchains + 2) * 4); g_zero(e, d_nrec.p, 0, 16);
+    ca.node_planes = d_np.as<unsigned long long>(); ca.chain_cnt = d_ccnt.as<uint32_t>(); ca.rec = d_rec.p; ca.rec_t = d_rect.as<uint32_t>(); ca.rec_c = d_recc.as<uint32_t>();
+    ca.nrec = d_nrec.as<unsigned long long>(); ca.cap = cap;
     x_chain(e, ca);
     g_d2h(e, &n_all, d_nrec.p, 8); g_sync(e);
     if (n_all <= cap) break;
@@ -459,9 +496,9 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
   {
     const uint64_t nw = nwin;
     g_map(e, 2 * nwin, [=] GLAM(size_t k) { const size_t set = k / nw, w = k % nw; pn[set * (nw + 2) + w] = (uint32_t)(popc64(np[(set * 2) * nw + w]) + popc64(np[(set * 2 + 1) * nw + w])); });
-    g_map(e, (size_t)nseq * 6, [=] GLAM(size_t c) { ccnt[c] += 1; });
+    g_map(e, (size_t)nchains, [=] GLAM(size_t c) { ccnt[c] += 1; });
   }
-  x_scan_u32(e, pn, nwin, d_scan); x_scan_u32(e, pn + (nwin + 2), nwin, d_scan); x_scan_u32(e, ccnt, (size_t)nseq * 6, d_scan);
+  x_scan_u32(e, pn, nwin, d_scan); x_scan_u32(e, pn + (nwin + 2), nwin, d_scan); x_scan_u32(e, ccnt, (size_t)nchains, d_scan);
   uint32_t *rk = d_rk.as<uint32_t>();
   {
     const uint32_t nb = nbins; const uint64_t nw = nwin;
@@ -474,7 +511,7 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
     });
   }
   std::vector<uint32_t> h_rk((size_t)nseq * 2); uint32_t n_chain_slots = 0;
-  g_d2h(e, h_rk.data(), rk, (size_t)nseq * 8); g_d2h(e, &n_chain_slots, ccnt + (size_t)nseq * 6, 4); g_sync(e);
+  g_d2h(e, h_rk.data(), rk, (size_t)nseq * 8); g_d2h(e, &n_chain_slots, ccnt + (size_t)nchains, 4); g_sync(e);
   // node ranges: a bin's nodes start at a multiple of 256; untrained bins keep none
   std::vector<uint32_t> seq_lo(nseq, 0), seq_n(nseq, 0); std::vector<long long> xbase(nseq, -1);
   size_t NT[2] = {0, 0};
@@ -505,7 +542,7 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
   NodeSet TS, FS;
   TS.alloc(e, NT[0], true); FS.alloc(e, NT[1], false);
   {
-    const Nodes t0 = TS.dev(), t1 = FS.dev(); const OrfRec *rec = reinterpret_cast<const OrfRec *>(d_rec.p); const uint32_t *rect = d_rect.as<uint32_t>();
+    const Nodes t0 = TS.dev(), t1 = FS.dev(); const OrfRec *rec = reinterpret_cast<const OrfRec *>(d_rec.p); const uint32_t *rect = d_rect.as<uint32_t>(), *recc = d_recc.as<uint32_t>();
     const uint32_t nb = nbins; const uint64_t nw = nwin;
     g_map(e, (size_t)n_all, [=] GLAM(size_t r) {
       const OrfRec q = rec[r]; const uint32_t s = q.seq;
@@ -517,9 +554,7 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
       const uint32_t rank = P[g >> 6] + (uint32_t)popc64(F[g >> 6] & below64(bit)) + (uint32_t)popc64(R[g >> 6] & below64(bit)) + (q.strand_rev ? (uint32_t)((F[g >> 6] >> bit) & 1ull) : 0u);
       const uint32_t x = (uint32_t)(xb[s] + (long long)rank);
       nd.bin[x] = sbin[s]; nd.seq[x] = s; nd.ndx[x] = q.ndx; nd.sv[x] = q.sv; nd.strand[x] = q.strand_rev ? -1 : 1; nd.type[x] = q.type; nd.edge[x] = q.edge;
-      const int sl = slen_d[s]; const int fr = q.strand_rev ? (sl - 1 - q.ndx) % 3 : q.ndx % 3;
-      const uint32_t c = s * 6 + (q.strand_rev ? 3 : 0) + (uint32_t)fr;
-      const uint32_t slot = ccnt[c] + 1 + rect[r];
+      const uint32_t slot = ccnt[recc[r]] + 1 + rect[r];
       CH[slot] = x; nd.chx[x] = slot;
     });
   }
@@ -667,11 +702,12 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
     // trace-back of every bin and the genes of the first pass, as (strand, left, right) intervals in the bin's own node slots
     d_gi.ensure(std::max<size_t>(NT[0], 64) * 12);
     int32_t *gi = reinterpret_cast<int32_t *>(d_gi.p); uint32_t *gcnt = d_gcnt.as<uint32_t>(); int32_t *ipath = d_ipath.as<int32_t>();
-    g_map(e, nbins, [=] GLAM(size_t b) {
-      gcnt[b] = 0; ipath[b] = -1;
-      if (sn[b] == 0) return;
+    x_path_ends(e, tn, slo, sn, nbins, ipath);
+    g_map_waves(e, nbins, [=] GLAM(size_t b) {
+      gcnt[b] = 0;
+      if (sn[b] == 0) { ipath[b] = -1; return; }
       const NView V{tn, slo[b], (int)sn[b]}; const int sl = slen_d[b];
-      const int dbeg = walk_dprog_finish(V);
+      const int dbeg = walk_dprog_finish(V, ipath[b]);
       ipath[b] = dbeg;
       int left = -1, right = -1, in_gene = 0; uint32_t ng = 0;
       for (int path = dbeg; path != -1; path = tn.traceb[V.lo + path]) {
@@ -1045,17 +1081,18 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
     run_dp(fn2, nbins, ncontigs, 1, out.ms_dp_find);
     tp("final dp done");
     // trace-back, bad genes, gene list, start tweaks: a thread per contig; the genes of a contig sit in its own node slots
-    GBuf d_gl, d_gc2;
-    d_gl.ensure(std::max<size_t>(NT[1], 64) * sizeof(GeneSlot)); d_gc2.ensure((size_t)(ncontigs + 1) * 4);
-    GeneSlot *gl = reinterpret_cast<GeneSlot *>(d_gl.p); uint32_t *gcn = d_gc2.as<uint32_t>();
+    GBuf d_gl, d_gc2, d_pend;
+    d_gl.ensure(std::max<size_t>(NT[1], 64) * sizeof(GeneSlot)); d_gc2.ensure((size_t)(ncontigs + 1) * 4); d_pend.ensure((size_t)(ncontigs + 1) * 4);
+    GeneSlot *gl = reinterpret_cast<GeneSlot *>(d_gl.p); uint32_t *gcn = d_gc2.as<uint32_t>(); int32_t *pend = d_pend.as<int32_t>();
     {
       const uint32_t nb = nbins;
-      g_map(e, ncontigs, [=] GLAM(size_t c) {
+      x_path_ends(e, fn2, slo + nb, sn + nb, ncontigs, pend);
+      g_map_waves(e, ncontigs, [=] GLAM(size_t c) {
         const uint32_t s = nb + (uint32_t)c;
         gcn[c] = 0;
         if (sn[s] == 0) return;
         const NView V{fn2, slo[s], (int)sn[s]}; const double st_wt = stwt[sbin[s]];
-        const int ip = walk_dprog_finish(V);
+        const int ip = walk_dprog_finish(V, pend[c]);
         walk_eliminate_bad_genes(V, ip, st_wt);
         const int ng = walk_add_genes(V, ip, gl + V.lo);
         walk_tweak_final_starts(V, gl + V.lo, ng, st_wt);

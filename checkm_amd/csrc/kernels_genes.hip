@@ -87,10 +87,10 @@ struct OrfRecK { uint32_t seq; int32_t ndx, sv; uint8_t type, strand_rev, edge, 
 // Scan coordinate j = position on the strand being read (forward: j = i; reverse: j is the index into the reverse complement, forward
 // position slen-1-j), descending from the last complete codon of the frame.  Open ends only (CheckM never passes -c).
 __global__ void __launch_bounds__(64) chain_kernel(ChainArgs a) {
-  const uint32_t job = blockIdx.x;
-  const uint32_t si = job / 6u, sub = job % 6u;
-  if (si >= a.nseq) return;
-  const int rev = sub >= 3u, frame = (int)(sub % 3u);
+  if (blockIdx.x >= a.nsc) return;
+  const SubChain sc = a.sc[blockIdx.x];
+  const uint32_t si = sc.seq;
+  const int rev = sc.rev, frame = sc.frame;
   const int slen = a.seq_len[si];
   if (slen < 3) return;
   const uint64_t base = a.seq_off[si];
@@ -100,7 +100,6 @@ __global__ void __launch_bounds__(64) chain_kernel(ChainArgs a) {
   const unsigned long long *p_lo = a.planes + (uint64_t)((rev ? 4 : 0) + 2) * nwin, *p_hi = a.planes + (uint64_t)((rev ? 4 : 0) + 3) * nwin;
   unsigned long long *node_plane = a.node_planes + (uint64_t)((si < a.nbins ? 0 : 2) + (rev ? 1 : 0)) * nwin;
   OrfRecK *rec = reinterpret_cast<OrfRecK *>(a.rec);
-  int jtop = slen - 3; jtop -= ((jtop % 3) - frame + 3) % 3;
   uint32_t tbase = 0;                                               // events of this chain so far
   auto emit = [&](int ndx_s, int type, int sv_s, int edge, uint32_t t) {
     const int ndx = rev ? slen - 1 - ndx_s : ndx_s;
@@ -110,15 +109,17 @@ __global__ void __launch_bounds__(64) chain_kernel(ChainArgs a) {
     if (k < a.cap) {
       OrfRecK nd; nd.seq = si; nd.type = (uint8_t)type; nd.strand_rev = (uint8_t)rev; nd.edge = (uint8_t)edge; nd.pad = 0;
       nd.ndx = ndx; nd.sv = rev ? slen - 1 - sv_s : sv_s;
-      rec[k] = nd; a.rec_t[k] = t;
+      rec[k] = nd; a.rec_t[k] = t; a.rec_c[k] = sc.chain;
     }
   };
-  int last = jtop;
-  bool last_real = false, saw = false, any_stop = false;
-  for (int jhi = jtop; jhi >= 0; jhi -= 192) {
+  int last = sc.top;
+  bool last_real = sc.after_stop, saw = false, any_stop = sc.after_stop;
+  const int bottom = sc.bottom;
+  for (int jhi = sc.after_stop ? sc.top - 3 : sc.top; jhi >= bottom; jhi -= 192) {
     const int j = jhi - 3 * lane;
+    const bool in = j >= bottom;
     bool is_stop = false; int st = -1;                           // st: -1 none, 0 ATG, 1 GTG, 2 TTG
-    if (j >= 0) {
+    if (in) {
       const uint64_t pos = base + (uint64_t)(rev ? slen - 1 - j : j);
       const uint64_t wi = pos >> 6; const int bit = (int)(pos & 63);
       is_stop = (p_stop[wi] >> bit) & 1ull;
@@ -133,7 +134,7 @@ __global__ void __launch_bounds__(64) chain_kernel(ChainArgs a) {
     const bool my_any_stop = any_stop || sb != 0ull;
     const int mind = my_any_stop ? ORF_MIN_GENE : ORF_MIN_EDGE_GENE;
     bool start_node = false, edge_node = false;
-    if (j >= 0 && !is_stop && my_last < slen) {
+    if (in && !is_stop && my_last < slen) {
       if (st >= 0 && my_last - j + 3 >= mind) start_node = true;
       else if (j <= 2 && (my_last - j) > ORF_MIN_EDGE_GENE) edge_node = true;
     }
@@ -163,10 +164,10 @@ __global__ void __launch_bounds__(64) chain_kernel(ChainArgs a) {
     } else saw = saw || starts != 0ull;
   }
   if (saw) { if (lane == 0) emit(last, 3, frame - 6, last_real ? 0 : 1, tbase); tbase++; }
-  if (lane == 0) a.chain_cnt[(size_t)si * 6 + sub] = tbase;
+  if (lane == 0) a.chain_cnt[sc.chain] = tbase;
 }
 void x_chain(GExec &e, const ChainArgs &a) {
-  if (a.nseq) hipLaunchKernelGGL(chain_kernel, dim3(a.nseq * 6), dim3(64), 0, e.st, a);
+  if (a.nsc) hipLaunchKernelGGL(chain_kernel, dim3(a.nsc), dim3(64), 0, e.st, a);
 }
 
 // ---- ordered GC-bias sums ----
@@ -195,6 +196,29 @@ __global__ void __launch_bounds__(64) gc_bias_kernel(Nodes nd, const uint32_t *_
 }
 void x_gc_bias(GExec &e, const Nodes &nd, const uint32_t *seq_lo, const uint32_t *seq_n, uint32_t nbins, double *bias) {
   if (nbins) hipLaunchKernelGGL(gc_bias_kernel, dim3(nbins), dim3(64), 0, e.st, nd, seq_lo, seq_n, nbins, bias);
+}
+
+// ---- where a sequence's trace-back begins: one wavefront per sequence ----
+__global__ void __launch_bounds__(64) path_ends_kernel(Nodes nd, const uint32_t *__restrict__ seq_lo, const uint32_t *__restrict__ seq_n, uint32_t nseq, int32_t *__restrict__ end_rel) {
+  const uint32_t s = blockIdx.x;
+  if (s >= nseq) return;
+  const uint32_t lo = seq_lo[s]; const int nn = (int)seq_n[s], lane = threadIdx.x;
+  double best = -1.0; int bi = -1;                        // (the reference starts from max_sc = -1 and takes strictly greater scores, scanning from the last node down)
+  for (int i = lane; i < nn; i += 64) {
+    const int str = nd.strand[lo + i]; const bool st = nd.type[lo + i] == G_STOP;
+    if ((str == 1 && !st) || (str == -1 && st)) continue;
+    const double sc = nd.score[lo + i];
+    if (sc > best || (sc == best && bi >= 0 && i > bi)) { if (sc > -1.0) { best = sc; bi = i; } }
+  }
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) {
+    const double ob = __shfl_xor(best, sft); const int oi = __shfl_xor(bi, sft);
+    if (oi >= 0 && (bi < 0 || ob > best || (ob == best && oi > bi))) { best = ob; bi = oi; }
+  }
+  if (lane == 0) end_rel[s] = bi;
+}
+void x_path_ends(GExec &e, const Nodes &nd, const uint32_t *seq_lo, const uint32_t *seq_n, uint32_t nseq, int32_t *end_rel) {
+  if (nseq) hipLaunchKernelGGL(path_ends_kernel, dim3(nseq), dim3(64), 0, e.st, nd, seq_lo, seq_n, nseq, end_rel);
 }
 
 // ---- hexamer sums and Shine-Dalgarno bins ----

@@ -45,24 +45,24 @@ void x_scan_u32(GExec &, uint32_t *a, size_t n, GBuf &) {
 
 void x_chain(GExec &, const ChainArgs &a) {
   OrfRec *rec = reinterpret_cast<OrfRec *>(a.rec);
-  for (uint32_t si = 0; si < a.nseq; ++si) for (uint32_t sub = 0; sub < 6; ++sub) {
-    const int rev = sub >= 3, frame = (int)(sub % 3), slen = a.seq_len[si];
+  for (uint32_t q = 0; q < a.nsc; ++q) {
+    const SubChain sc = a.sc[q];
+    const uint32_t si = sc.seq; const int rev = sc.rev, frame = sc.frame, slen = a.seq_len[si];
     if (slen < 3) continue;
     const uint64_t base = a.seq_off[si], nwin = a.nwin;
     const unsigned long long *p_stop = a.planes + (uint64_t)((rev ? 4 : 0) + (a.tt4 ? 1 : 0)) * nwin;
     const unsigned long long *p_lo = a.planes + (uint64_t)((rev ? 4 : 0) + 2) * nwin, *p_hi = a.planes + (uint64_t)((rev ? 4 : 0) + 3) * nwin;
     unsigned long long *node_plane = a.node_planes + (uint64_t)((si < a.nbins ? 0 : 2) + (rev ? 1 : 0)) * nwin;
-    int jtop = slen - 3; jtop -= ((jtop % 3) - frame + 3) % 3;
     uint32_t t = 0;
     auto emit = [&](int ndx_s, int type, int sv_s, int edge) {
       const int ndx = rev ? slen - 1 - ndx_s : ndx_s; const uint64_t g = base + (uint64_t)ndx;
       node_plane[g >> 6] |= 1ull << (g & 63);
       const unsigned long long k = (*a.nrec)++;
-      if (k < a.cap) { OrfRec nd; nd.seq = si; nd.type = (uint8_t)type; nd.strand_rev = (uint8_t)rev; nd.edge = (uint8_t)edge; nd.pad = 0; nd.ndx = ndx; nd.sv = rev ? slen - 1 - sv_s : sv_s; rec[k] = nd; a.rec_t[k] = t; }
+      if (k < a.cap) { OrfRec nd; nd.seq = si; nd.type = (uint8_t)type; nd.strand_rev = (uint8_t)rev; nd.edge = (uint8_t)edge; nd.pad = 0; nd.ndx = ndx; nd.sv = rev ? slen - 1 - sv_s : sv_s; rec[k] = nd; a.rec_t[k] = t; a.rec_c[k] = sc.chain; }
       t++;
     };
-    int last = jtop; bool last_real = false, saw = false, any_stop = false;
-    for (int j = jtop; j >= 0; j -= 3) {
+    int last = sc.top; bool last_real = sc.after_stop, saw = false, any_stop = sc.after_stop;
+    for (int j = sc.after_stop ? sc.top - 3 : sc.top; j >= sc.bottom; j -= 3) {
       const uint64_t pos = base + (uint64_t)(rev ? slen - 1 - j : j); const uint64_t wi = pos >> 6; const int bit = (int)(pos & 63);
       const bool is_stop = (p_stop[wi] >> bit) & 1ull;
       const int st = (int)(((p_lo[wi] >> bit) & 1ull) | (((p_hi[wi] >> bit) & 1ull) << 1)) - 1;
@@ -81,7 +81,7 @@ void x_chain(GExec &, const ChainArgs &a) {
       if (is_stop) { if (saw) emit(last, 3, j, last_real ? 0 : 1); last = j; last_real = true; any_stop = true; saw = false; }
     }
     if (saw) emit(last, 3, frame - 6, last_real ? 0 : 1);
-    a.chain_cnt[(size_t)si * 6 + sub] = t;
+    a.chain_cnt[sc.chain] = t;
   }
 }
 
@@ -126,6 +126,19 @@ void x_dp(GExec &, const Nodes &nd, const uint32_t *seq_lo, const uint32_t *seq_
       }
       if (bj >= 0) { nd.score[S.first + i] = best; nd.traceb[S.first + i] = bj; nd.ov_mark[S.first + i] = bmark; }
     }
+  }
+}
+
+void x_path_ends(GExec &, const Nodes &nd, const uint32_t *seq_lo, const uint32_t *seq_n, uint32_t nseq, int32_t *end_rel) {
+  for (uint32_t s = 0; s < nseq; ++s) {
+    double best = -1.0; int bi = -1;
+    for (int i = 0; i < (int)seq_n[s]; ++i) {           // (ascending on purpose: the tie rule -- the last of equals -- must not lean on the order)
+      const uint32_t g = seq_lo[s] + (uint32_t)i; const int str = nd.strand[g]; const bool st = nd.type[g] == G_STOP;
+      if ((str == 1 && !st) || (str == -1 && st)) continue;
+      const double sc = nd.score[g];
+      if (sc > -1.0 && (sc > best || (sc == best && i > bi))) { best = sc; bi = i; }
+    }
+    end_rel[s] = bi;
   }
 }
 
