@@ -64,7 +64,8 @@ def parse():
     ap.add_argument("--bins-total", type=int, default=1000, help="cfg2 strong / cfg3: bins of the whole job")
     ap.add_argument("--lineage-bins", type=int, default=0, help="cfg2: bins of a small lineage_wf-equivalent side measurement (0 = skip; cfg3 IS that measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-genes", action="store_true", help="cfg3: skip the gene-calling side legs (gene_front_end, gene_calling)")
+    ap.add_argument("--no-genes", action="store_true", help="cfg3: skip the gene-calling side legs (gene_front_end, gene_calling, from_fasta)")
+    ap.add_argument("--from-fasta-bins", type=int, default=256, help="cfg3 / genes: bins of the from_fasta leg (nucleotide bins -> genes -> tree pass -> analyze pass -> qa table); 0 skips it")
     ap.add_argument("--verify", type=int, default=3, help="cfg3 / cfg5: bins of the last timed step whose written tables are diffed against the CPU oracle after the timed region (0 = off)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--pipeline", type=int, default=1,
@@ -226,17 +227,18 @@ def lineage_setup(workdir, nbins, rank, world, sync):
     return w, binIds, files, os.path.join(workdir, "lineage.ms")
 
 
-def lineage_pass(w, binIds, files, lin, out, rank):
-    """One lineage_wf-equivalent pass over the marker path: tree pass (phylo.hmm), analyze pass (lineage marker file), qa table."""
+def lineage_pass(w, binIds, files, lin, out, rank, called=True):
+    """One lineage_wf-equivalent pass over the marker path: tree pass (phylo.hmm), analyze pass (lineage marker file), qa table.
+    called=False: `files` are nucleotide bins, find() calls their genes (checkm/markerGeneFinder.py:113-127)."""
     from checkm_amd import markerGeneFinder as mgf
     from checkm_amd.defaultValues import DefaultValues
     from checkm_amd.markerSets import MarkerSetParser
     from checkm_amd.resultsParser import ResultsParser
     t0 = time.perf_counter()
     finder = mgf.MarkerGeneFinder(8)
-    finder.find(files, out, DefaultValues.HMMER_TABLE_PHYLO_OUT, DefaultValues.HMMER_PHYLO_OUT, w.phylo_hmm, False, False, True)
+    finder.find(files, out, DefaultValues.HMMER_TABLE_PHYLO_OUT, DefaultValues.HMMER_PHYLO_OUT, w.phylo_hmm, False, False, called)
     t1 = time.perf_counter()
-    models = finder.find(files, out, DefaultValues.HMMER_TABLE_OUT, DefaultValues.HMMER_OUT, lin, False, False, True)
+    models = finder.find(files, out, DefaultValues.HMMER_TABLE_OUT, DefaultValues.HMMER_OUT, lin, False, False, called)
     t2 = time.perf_counter()
     tot = {}
     for tbl in (DefaultValues.HMMER_TABLE_PHYLO_OUT, DefaultValues.HMMER_TABLE_OUT):
@@ -837,7 +839,11 @@ def gene_calling(workdir, nbins=192, cpu_bins=8):
         os.makedirs(od, exist_ok=True)
         jobs.append((f, od))
     t_setup = time.perf_counter() - t0
-    geneFinder.call_bin_files(jobs[:4])                                   # warm: kernels loaded, buffers at size
+    # untimed warm-up pass at full size: kernels loaded, device blocks of the calls' sizes in the library's block cache (a first pass of a process
+    # spends 0.3-0.5 s per call in hipMalloc, serialised over the calls in flight; `first_pass_seconds` is that pass)
+    t0 = time.perf_counter()
+    geneFinder.call_bin_files(jobs)
+    first_pass = time.perf_counter() - t0
     t0 = time.perf_counter()
     res = geneFinder.call_bin_files(jobs)
     dt = time.perf_counter() - t0
@@ -849,10 +855,16 @@ def gene_calling(workdir, nbins=192, cpu_bins=8):
     out = {"value": nbins / dt * 3600.0, "unit": "bins/hour", "bins": nbins, "bases": bases, "genes_written": ngenes, "seconds": dt,
            "bases_per_s": bases * 2 / dt, "tables_per_bin": 2, "table_4_chosen": sum(1 for v in res.values() if v[0] == 4),
            "last_call_kernel_ms": {k: st[k] for k in ("ms_dp_train", "ms_score", "ms_dp_find")}, "last_call_wall_ms": {"to_nodes": st["ms_nodes"], "total": st["ms_total"]},
-           "setup_s": t_setup, "python_phases_s": dict(geneFinder.call_bin_files.last_phases),
-           "note": "from nucleotide FASTA files to genes.faa / genes.gff, tables 11 and 4 for every bin in two batched device calls per <= 1 Gbase of bins; the dynamic "
-                   "programs are latency-bound (one workgroup per sequence, nodes in order, 256 predecessor candidates per step), the codon-flag kernel is the "
-                   "HBM-bound one (gene_front_end.roofline); single-genome mode only (-p meta is not built)"}
+           "setup_s": t_setup, "first_pass_seconds": first_pass, "python_phases_s": dict(geneFinder.call_bin_files.last_phases),
+           "device_fraction_of_wall": None,
+           "note": "from nucleotide FASTA files to genes.faa / genes.gff, tables 11 and 4 for every bin: sub-batches of <= 64 Mbase x both tables as calls in flight on "
+                   "CKM_GENE_LANES host threads (each call on a stream of its own; nodes resident on the device from the codon flags to the gene records, the host takes "
+                   "the logarithms of the training tables, reads the files and asks the library to write them).  The pipeline is latency-bound (a workgroup per bin in the "
+                   "dynamic programs, nodes strictly in order), the codon-flag kernel is the HBM-bound one (gene_front_end.roofline); single-genome mode only (-p meta is "
+                   "not built).  python_phases_s: device_calls_s is summed over the calls in flight, wall_s is the pass"}
+    ph = out["python_phases_s"]
+    if ph.get("wall_s"):
+        out["device_fraction_of_wall"] = max(0.0, ph["wall_s"] - ph["read_s"] - ph["choose_and_write_s"] / max(1, ph["lanes"])) / ph["wall_s"]
     if cpu_bins <= 0:
         out["cpu_baseline"] = None
         return out
@@ -873,6 +885,50 @@ def gene_calling(workdir, nbins=192, cpu_bins=8):
     except Exception as e:            # (the oracle is the checker; the leg stands without it)
         out["cpu_baseline"] = {"error": str(e)}
     return out
+
+
+def from_fasta(w, workdir, nbins):
+    """lineage_wf's marker path from NUCLEOTIDE bins (what CheckM is normally given): find(phylo.hmm) calls the genes of every bin on the
+    device (both translation tables, checkm/prodigal.py:72-133) while it scans the bins whose genes are ready, then find(lineage.ms),
+    analyseResults, printSummary -- `nbins` synthetic genomes that carry the proteins of the first `nbins` bins of the lineage world."""
+    from checkm_amd import geneFinder, markerGeneFinder as mgf
+    d = os.path.join(workdir, "fasta_bins")
+    os.makedirs(d, exist_ok=True)
+    binIds = ["bin_%04d" % b for b in range(nbins)]
+    files = [os.path.join(d, "%s.fna" % b) for b in binIds]
+    t0 = time.perf_counter()
+    w.write_nucleotide_bins([(b, files[b]) for b in range(nbins)])
+    md = os.path.join(d, "markers")
+    os.makedirs(md, exist_ok=True)
+    lin, _tax = w.write_marker_files(md, binIds)
+    bases = sum(os.path.getsize(f) for f in files) * 70 // 71
+    t_setup = time.perf_counter() - t0
+    mgf.release_scan()
+    warm = os.path.join(d, "out_warm")                      # the gene finder's kernels loaded, its buffers in the block cache: a first pass over some of the bins
+    shutil.rmtree(warm, ignore_errors=True)
+    nw = min(nbins, 96)
+    lineage_pass(w, binIds[:nw], files[:nw], lin, warm, 0, called=False)
+    mgf.release_scan()
+    out = os.path.join(d, "out")
+    shutil.rmtree(out, ignore_errors=True)
+    t0 = time.perf_counter()
+    parts, _tot = lineage_pass(w, binIds, files, lin, out, 0, called=False)
+    mgf.release_scan()
+    dt = time.perf_counter() - t0
+    ngenes = comp = 0
+    with open(os.path.join(out, "qa_table.tsv")) as fh:
+        rows = [ln.rstrip("\n").split("\t") for ln in fh][1:]
+    for r in rows:
+        comp += float(r[-3])
+    for b in binIds[:32]:
+        with open(os.path.join(out, "bins", b, "genes.faa")) as fh:
+            ngenes += sum(1 for ln in fh if ln.startswith(">"))
+    return {"seconds": dt, "bins": nbins, "seconds_per_1000_bins": dt * 1000.0 / nbins, "bins_per_hour": nbins / dt * 3600.0, "bases": bases, "mbase_per_s": bases / dt / 1e6,
+            "parts_s": parts, "gene_phases_s": dict(geneFinder.call_bin_files.last_phases), "setup_s": t_setup, "warm_bins": nw,
+            "genes_per_bin_first_32": ngenes / 32.0, "mean_completeness": comp / max(1, len(rows)),
+            "note": "nucleotide FASTA -> genes.faa / genes.gff (device gene finder, tables 11 and 4) -> hmmer.tree.txt -> hmmer.analyze.txt -> QA table, through "
+                    "MarkerGeneFinder.find(bCalledGenes=False) x 2 + ResultsParser; the tree pass's scan runs beside the gene calling, the analyze pass reuses the called genes "
+                    "(checkm/markerGeneFinder.py:113-117); genomes of ~0.9 coding density carrying the lineage world's proteins"}
 
 
 def bench_cfg3(args, env):
@@ -1041,6 +1097,8 @@ def bench_cfg3(args, env):
         if not args.no_genes:
             out["gene_front_end"] = gene_front_end()
             out["gene_calling"] = gene_calling(workdir)
+            if args.from_fasta_bins > 0:
+                out["from_fasta"] = from_fasta(w, workdir, min(args.from_fasta_bins, nbins))
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_cfg3(w, binIds, files, lin, args.cpu_baseline_seconds, args.cpu_baseline_threads)
         else:

@@ -179,13 +179,14 @@ def _lanes():
     return max(1, min(16, int(os.environ.get("CKM_GENE_LANES", "12"))))
 
 
-def call_bin_files(jobs, bNucORFs=False, max_bases=None, logger=None):
+def call_bin_files(jobs, bNucORFs=False, max_bases=None, logger=None, on_bin_done=None):
     """jobs = [(nucleotide FASTA of a bin, directory for genes.faa / genes.gff [/ genes.fna])].  Both translation tables per bin from the
     device, the reference's choice between them, prodigal's file layout.  Returns {binFile: (best table, {11: density, 4: density})}.
     The bins go through the device in sub-batches of <= max_bases (CKM_GENE_BATCH_MB, default 64 Mbase), several calls in flight.
     Raises ValueError -- before anything is written -- when a bin is below the 20 kb the gene finder can train on (the pre-trained
     `-p meta` models CheckM would use below 100 kb are not built), and after the other bins' files are written when a trained bin
-    yields no genes (the reference treats empty prodigal output as a failure, checkm/prodigal.py:96-115)."""
+    yields no genes (the reference treats empty prodigal output as a failure, checkm/prodigal.py:96-115).  on_bin_done(binFile) is called
+    from a worker thread as soon as a bin's files are complete (MarkerGeneFinder.find scans the first bins while the last are called)."""
     import os
     import threading
     import time
@@ -245,6 +246,8 @@ def call_bin_files(jobs, bNucORFs=False, max_bases=None, logger=None):
                 out[binFile] = (best, {11: d11, 4: d4})
                 if (n11 if best == 11 else n4)[b] == 0:
                     empty.append(binFile)
+            if on_bin_done is not None:
+                on_bin_done(binFile)
         c11.close(); c4.close()
         with lock:
             phases["choose_and_write_s"] += time.perf_counter() - t1

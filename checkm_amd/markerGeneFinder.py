@@ -217,11 +217,30 @@ class MarkerGeneFinder(object):
                     f = os.path.join(t[1], DefaultValues.PRODIGAL_NT) if bNucORFs else t[3]
                     return os.path.exists(f) and os.stat(f).st_size != 0
                 jobs = [(t[0], t[1]) for t in todo if not called(t)]
-                try:
-                    geneFinder.call_bin_files(jobs, bNucORFs, logger=self.logger)
-                except ValueError as e:
-                    self.logger.error(str(e))
-                    sys.exit(1)
+                # The gene finder is latency-bound (a workgroup per bin in its dynamic programs), the scan is VALU-bound: they share the
+                # device well.  The bins' genes are called on a helper thread, sub-batch by sub-batch in bin order; the scan of a batch
+                # waits for its bins' files (find(): scan()).  CKM_GENE_OVERLAP=0: call all genes first.
+                import threading
+                dst_of = {t[0]: t[3] for t in todo}
+                self._gene_events = {dst_of[j[0]]: threading.Event() for j in jobs}
+                self._gene_sizes = {dst_of[j[0]]: int(0.36 * (os.path.getsize(j[0]) if os.path.exists(j[0]) else 0) * (3.2 if j[0].endswith('.gz') else 1.0)) for j in jobs}
+                self._gene_error = []
+                events, errors = self._gene_events, self._gene_error
+
+                def run_genes():
+                    try:
+                        geneFinder.call_bin_files(jobs, bNucORFs, logger=self.logger, on_bin_done=lambda f: events[dst_of[f]].set())
+                    except BaseException as e:          # (reported by find() on the main thread)
+                        errors.append(e)
+                    finally:
+                        for ev in events.values():
+                            ev.set()
+                if os.environ.get("CKM_GENE_OVERLAP", "1") == "0":
+                    run_genes()
+                    self._check_genes()
+                else:
+                    self._gene_thread = threading.Thread(target=run_genes, name="ckm-genes", daemon=True)
+                    self._gene_thread.start()
             elif runner is not None:
                 def call(t):
                     binFile, binDir, _binId, _dst = t
@@ -238,6 +257,22 @@ class MarkerGeneFinder(object):
                     if os.path.abspath(aa) != os.path.abspath(t[3]):
                         shutil.copyfile(aa, t[3])
         return binIds, faa, read_from
+
+    _gene_events, _gene_sizes, _gene_error, _gene_thread = {}, {}, [], None
+
+    def _check_genes(self):
+        """An error of the gene-calling helper ends the run the way the reference ends it (logger.error + sys.exit, checkm/prodigal.py:100-115)."""
+        if self._gene_error:
+            e = self._gene_error[0]
+            self.logger.error(str(e) if isinstance(e, ValueError) else "gene calling failed: %r" % (e,))
+            sys.exit(1)
+
+    def _wait_genes(self, path):
+        ev = self._gene_events.get(path)
+        if ev is not None:
+            ev.wait()
+            if self._gene_error:
+                raise _lib.CkmError(-1, "gene calling failed")
 
     def find(self, binFiles, outDir, tableOut, hmmerOut, markerFile, bKeepAlignment, bNucORFs, bCalledGenes):
         """checkm/markerGeneFinder.py:45-96.  One process per GPU: under torchrun (WORLD_SIZE > 1) every rank calls find() with the
@@ -288,8 +323,10 @@ class MarkerGeneFinder(object):
                 wts.append(sz * max(1, nm))
             mine = cdist.shard_bins(wts, world)[rank]
         myFiles = [binFiles[i] for i in mine]
+        self._gene_events, self._gene_sizes, self._gene_error, self._gene_thread = {}, {}, [], None
         binIds, faa, read_from = self._geneFiles(myFiles, outDir, bNucORFs, bCalledGenes)
-        sizes = [os.path.getsize(f) if os.path.exists(f) else 0 for f in read_from]
+        # (a bin whose genes are still being called is planned with an estimate: proteins of a bacterial genome take about 0.36 of its bases)
+        sizes = [self._gene_sizes[f] if f in self._gene_events else (os.path.getsize(f) if os.path.exists(f) else 0) for f in read_from]
         nmod = [len(models_of[b]) if models_of.get(b) is not None else profiles.n for b in binIds]
         batches = plan_batches(sizes, nmod)
         parts, where, totals = [None] * len(batches), {}, {}
@@ -334,6 +371,8 @@ class MarkerGeneFinder(object):
             import time as _t
             c, prof = lanes[k % len(lanes)]
             batch = batches[k]
+            for i in batch:
+                self._wait_genes(read_from[i])                                    # (genes of this batch's bins still being called: find() overlaps the two)
             t0 = _t.perf_counter()
             seqs = _lib.Seqs.from_fasta(c, [read_from[i] for i in batch])         # read, digitized and packed by the library
             t1 = _t.perf_counter()
@@ -375,14 +414,21 @@ class MarkerGeneFinder(object):
                     for f in [ex.submit(lane_run, j) for j in range(len(lanes))]:
                         f.result()
         except _lib.CkmError as e:
+            if self._gene_thread is not None:
+                self._gene_thread.join()
+            self._check_genes()
             self.logger.error('marker-gene scan failed: %s' % e)
             sys.exit(1)
         finally:
+            if self._gene_thread is not None:
+                self._gene_thread.join()
             for f in self._pending_copies:           # bins/<binId>/genes.faa is complete before find() returns
                 f.result()
             if self._copy_pool is not None:
                 self._copy_pool.shutdown()
             self._pending_copies, self._copy_pool = [], None
+        self._check_genes()
+        self._gene_events, self._gene_thread = {}, None
         for k, batch in enumerate(batches):
             for b, i in enumerate(batch):
                 where[binIds[i]] = (k, b)

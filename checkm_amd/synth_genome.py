@@ -61,3 +61,69 @@ def write_fasta(path, contigs, width=70):
             f.write(">%s\n" % cid)
             for i in range(0, len(s), width):
                 f.write(s[i:i + width] + "\n")
+
+
+# ---- nucleotide bins that carry a given set of proteins (bench.py: the from_fasta leg) ------------------------------------------------------
+_AA_CODONS = {
+    'A': ('GCT', 'GCC', 'GCA', 'GCG'), 'R': ('CGT', 'CGC', 'CGA', 'CGG', 'AGA', 'AGG'), 'N': ('AAT', 'AAC'), 'D': ('GAT', 'GAC'), 'C': ('TGT', 'TGC'),
+    'Q': ('CAA', 'CAG'), 'E': ('GAA', 'GAG'), 'G': ('GGT', 'GGC', 'GGA', 'GGG'), 'H': ('CAT', 'CAC'), 'I': ('ATT', 'ATC', 'ATA'),
+    'L': ('TTA', 'TTG', 'CTT', 'CTC', 'CTA', 'CTG'), 'K': ('AAA', 'AAG'), 'M': ('ATG',), 'F': ('TTT', 'TTC'), 'P': ('CCT', 'CCC', 'CCA', 'CCG'),
+    'S': ('TCT', 'TCC', 'TCA', 'TCG', 'AGT', 'AGC'), 'T': ('ACT', 'ACC', 'ACA', 'ACG'), 'W': ('TGG',), 'Y': ('TAT', 'TAC'), 'V': ('GTT', 'GTC', 'GTA', 'GTG')}
+
+
+def _codon_lut(gc):
+    """[256][6] codon numbers (index into a 64 x 3 byte table) per amino-acid letter, synonymous codons repeated by a GC-skewed weight
+    so that a uniform draw of a column follows a codon usage: enough for the gene finder's hexamer statistics to separate coding from
+    intergenic sequence."""
+    codons = [a + b + c for a in "ACGT" for b in "ACGT" for c in "ACGT"]
+    num = {c: i for i, c in enumerate(codons)}
+    lut = np.zeros((256, 6), dtype=np.uint8)
+    lut[:] = num['GCC']
+    for aa, cs in _AA_CODONS.items():
+        w = np.asarray([(gc if c[2] in "GC" else 1.0 - gc) * 1.6 + 0.2 for c in cs])
+        k = np.maximum(1, np.round(6 * w / w.sum()).astype(int))
+        cols = [num[c] for c, n in zip(cs, k) for _ in range(n)][:6]
+        while len(cols) < 6:
+            cols.append(cols[len(cols) % len(cs)])
+        lut[ord(aa)] = cols
+    tab = np.frombuffer("".join(codons).encode(), dtype=np.uint8).reshape(64, 3)
+    return lut, tab
+
+
+def genome_from_proteins(proteins, seed, n_contigs=20, gc=0.5, sd_frac=0.6):
+    """[(contig id, nucleotide sequence as bytes)] carrying `proteins` (amino-acid strings; a trailing '*' is dropped) as genes: ATG + one
+    codon per residue + a stop, both strands, optional Shine-Dalgarno site, 20-160 intergenic bases."""
+    rng = np.random.default_rng(seed)
+    lut, tab = _codon_lut(gc)
+    prots = [p[:-1] if p.endswith('*') else p for p in proteins]
+    lens = np.asarray([len(p) for p in prots], dtype=np.int64)
+    aa = np.frombuffer("".join(prots).encode(), dtype=np.uint8)
+    col = rng.integers(0, 6, size=len(aa))
+    nuc = tab[lut[aa, col]].reshape(-1).tobytes()                      # all coding bodies, back to back
+    off = np.concatenate(([0], np.cumsum(lens))) * 3
+    base_p = [(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2]
+    ig_len = rng.integers(20, 160, size=len(prots) + n_contigs)
+    ig_all = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.choice(4, p=base_p, size=int(ig_len.sum()) + 16 * len(prots))].tobytes()
+    stops, flip, sd = rng.integers(0, 3, size=len(prots)), rng.random(len(prots)) < 0.5, rng.random(len(prots)) < sd_frac
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    per = (len(prots) + n_contigs - 1) // max(1, n_contigs)
+    out, igp = [], 0
+    for c in range(n_contigs):
+        parts = []
+        for g in range(c * per, min(len(prots), (c + 1) * per)):
+            n = int(ig_len[g]); ig = ig_all[igp:igp + n]; igp += n
+            if sd[g]:
+                ig += b"AGGAGG" + ig_all[igp:igp + 7]; igp += 7
+            unit = ig + b"ATG" + nuc[off[g]:off[g + 1]] + (b"TAA", b"TAG", b"TGA")[stops[g]]
+            parts.append(unit.translate(comp)[::-1] if flip[g] else unit)
+        if parts:
+            n = int(ig_len[len(prots) + c]); parts.append(ig_all[igp:igp + n]); igp += n
+            out.append((("c%06d" % (c + 1)).encode(), b"".join(parts)))
+    return out
+
+
+def write_fasta_bytes(path, contigs, width=70):
+    with open(path, "wb") as f:
+        for cid, s in contigs:
+            f.write(b">" + cid + b"\n")
+            f.write(b"\n".join(s[i:i + width] for i in range(0, len(s), width)) + b"\n")

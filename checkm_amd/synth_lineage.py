@@ -284,6 +284,15 @@ class World(object):
         for _ in _pool_map(self.root, self.seed, self.n_models, "bins", chunks, jobs):
             pass
 
+    def write_nucleotide_bins(self, jobs_list, jobs=None):
+        """jobs_list: [(bin index, path)] -- nucleotide FASTA files whose genes are the bins' proteins (synth_genome.genome_from_proteins)."""
+        todo = [j for j in jobs_list if not os.path.exists(j[1])]
+        if not todo:
+            return
+        chunks = [todo[k::max(1, len(todo) // 4)] for k in range(max(1, len(todo) // 4))]
+        for _ in _pool_map(self.root, self.seed, self.n_models, "fna", chunks, jobs):
+            pass
+
     def write_marker_files(self, outdir, binIds, families=None):
         """lineage.ms (one line per bin) and taxon.ms (the p0 phylum set for every bin) in `outdir`."""
         lin = os.path.join(outdir, "lineage.ms")
@@ -314,6 +323,14 @@ def _worker_task(job):
     w = _WORKER_WORLD
     if kind == "hmm":
         return "".join(synth.hmm_text(w.profs[i]) for i in arg)
+    if kind == "fna":            # the bin's proteins carried by a synthetic genome (bench.py: the from_fasta leg)
+        from checkm_amd import synth_genome as sg
+        for b, path in arg:
+            prots = [r[2] for r in w.bin_records(b)]
+            g = sg.genome_from_proteins(prots, 7000 + b, n_contigs=20, gc=0.35 + 0.3 * (b % 11) / 10.0, sd_frac=0.0 if b % 6 == 5 else 0.6)
+            sg.write_fasta_bytes(path + ".tmp", g)
+            os.replace(path + ".tmp", path)
+        return len(arg)
     for b, path in arg:
         synth.write_fasta(path + ".tmp", w.bin_records(b))
         os.replace(path + ".tmp", path)
