@@ -857,7 +857,7 @@ def gene_calling(workdir, nbins=192, cpu_bins=8):
            "last_call_kernel_ms": {k: st[k] for k in ("ms_dp_train", "ms_score", "ms_dp_find")}, "last_call_wall_ms": {"to_nodes": st["ms_nodes"], "total": st["ms_total"]},
            "setup_s": t_setup, "first_pass_seconds": first_pass, "python_phases_s": dict(geneFinder.call_bin_files.last_phases),
            "device_fraction_of_wall": None,
-           "note": "from nucleotide FASTA files to genes.faa / genes.gff, tables 11 and 4 for every bin: sub-batches of <= 64 Mbase x both tables as calls in flight on "
+           "note": "from nucleotide FASTA files to genes.faa / genes.gff, tables 11 and 4 for every bin: sub-batches of <= 128 Mbase x both tables as calls in flight on "
                    "CKM_GENE_LANES host threads (each call on a stream of its own; nodes resident on the device from the codon flags to the gene records, the host takes "
                    "the logarithms of the training tables, reads the files and asks the library to write them).  The pipeline is latency-bound (a workgroup per bin in the "
                    "dynamic programs, nodes strictly in order), the codon-flag kernel is the HBM-bound one (gene_front_end.roofline); single-genome mode only (-p meta is "
@@ -906,7 +906,7 @@ def from_fasta(w, workdir, nbins):
     mgf.release_scan()
     warm = os.path.join(d, "out_warm")                      # the gene finder's kernels loaded, its buffers in the block cache: a first pass over some of the bins
     shutil.rmtree(warm, ignore_errors=True)
-    nw = min(nbins, 96)
+    nw = nbins                           # (a whole pass: the block cache holds what the calls in flight of a steady pass need)
     lineage_pass(w, binIds[:nw], files[:nw], lin, warm, 0, called=False)
     mgf.release_scan()
     out = os.path.join(d, "out")

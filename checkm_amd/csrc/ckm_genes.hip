@@ -56,7 +56,7 @@ extern "C" int ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *co
     HIPCHK(hipSetDevice(ctx->device));
     StreamLease lease(ctx->device);
     const double t_begin = now_ms();
-    int gthreads = std::max(4, std::min(16, (int)std::thread::hardware_concurrency() / 8));
+    int gthreads = std::max(2, std::min(6, (int)std::thread::hardware_concurrency() / 16));      // (table arithmetic of the training loops; many calls run side by side)
     if (const char *e = getenv("CKM_GENE_THREADS")) gthreads = std::max(1, std::min(128, atoi(e)));
     HostPool gpool(gthreads);
     const bool tr_on = getenv("CKM_TRACE") != nullptr;

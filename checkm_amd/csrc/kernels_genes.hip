@@ -222,22 +222,16 @@ void x_path_ends(GExec &e, const Nodes &nd, const uint32_t *seq_lo, const uint32
 }
 
 // ---- hexamer sums and Shine-Dalgarno bins ----
+// (the bin's 32 KB table is read through the caches, not staged in LDS: many calls are in flight, the dynamic programs of the others hold
+//  most of every compute unit's LDS, and a kernel that asks for 32 KB of it waits for them)
 __global__ void __launch_bounds__(256) cscore_kernel(const uint8_t *__restrict__ code, const uint64_t *__restrict__ seq_off, const int32_t *__restrict__ seq_len, Nodes nd,
                                                      const double *__restrict__ gene_dc /* [nbins][4096] */, uint32_t nnodes) {
-  __shared__ double dc[4096];
-  // a block works on nodes of ONE bin (every bin's node range starts at a multiple of the block size)
-  const uint32_t i0 = blockIdx.x * blockDim.x;
-  if (i0 >= nnodes) return;
-  if (nd.type[i0] == G_PAD) return;                                  // (no bin begins with padding; a block of padding only has nothing to do)
-  const uint32_t bin = nd.bin[i0];
-  for (int k = threadIdx.x; k < 4096; k += blockDim.x) dc[k] = gene_dc[(size_t)bin * 4096 + k];
-  __syncthreads();
-  const uint32_t i = i0 + threadIdx.x;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nnodes || nd.type[i] >= G_STOP) return;
   const uint32_t sq = nd.seq[i];
   const int slen = seq_len[sq], strand = nd.strand[i];
   const int ps = strand == 1 ? nd.ndx[i] : slen - 1 - nd.ndx[i], pe = strand == 1 ? nd.sv[i] : slen - 1 - nd.sv[i];
-  nd.cscore[i] = node_cscore(code + seq_off[sq], slen, strand, ps, pe, dc);
+  nd.cscore[i] = node_cscore(code + seq_off[sq], slen, strand, ps, pe, gene_dc + (size_t)nd.bin[i] * 4096);
 }
 __global__ void __launch_bounds__(256) rbs_kernel(const uint8_t *__restrict__ code, const uint64_t *__restrict__ seq_off, const int32_t *__restrict__ seq_len, Nodes nd,
                                                   const double *__restrict__ rbs_wt /* [nbins][28] */, uint32_t nnodes) {
@@ -299,15 +293,15 @@ void x_hexamer_background(GExec &e, const uint8_t *code, const uint64_t *seq_off
 //     class, a node's record holds how many nodes of each class precede it, so the class-c candidates of node i are ring entries
 //     [count_c(window start), count_c(i)) -- a wavefront's 64 candidates share one class, the connection function folds to that class's
 //     cases (gene_dev.h: dp_connection_x<KNOWN>), and classes that cannot precede node i (6 of the 16 pairs) are never touched;
-//   * the last 1152 nodes live in an LDS ring of 40-byte records read with three wide loads: {position, stop position, flags + packed
-//     overlapping-start offsets, trace-back and window start as 16-bit distances}, {score, connection value}, {class counts}; 50 KB per
-//     workgroup, three workgroups per compute unit (the kernel is latency-bound: a sequence's nodes are strictly in order);
+//   * the last 1088 nodes live in an LDS ring of 40-byte records read with three wide loads: {position, stop position, flags + packed
+//     overlapping-start offsets, trace-back and window start as 16-bit distances}, {score, connection value}, {class counts}; 47 KB per
+//     workgroup, three workgroups per compute unit with room left for the histogram kernels of other calls (the kernel is latency-bound: a sequence's nodes are strictly in order);
 //   * one barrier per node: the wavefronts' partial results are double-buffered by node parity and combined by every thread, the ring
 //     entry of node i is written by thread 0 while the others already score node i + 1 (node i itself is served from registers);
 //   * results leave the ring for global memory once per 64 nodes.
 // What does not fit the rings (a window that starts behind a giant open reading frame, more than 512 nodes of one class in a window) goes
 // through the generic loop with global-memory fall-backs.
-constexpr int DPW = 1152, DPC = 512, DP_FAR = 0xffff;
+constexpr int DPW = 1088, DPC = 512, DP_FAR = 0xffff;      // 1088 = the 1000-node window + the 64 nodes entered ahead (+ slack); 47 KB with the class rings
 struct DpRec { int ndx, sv, pk; uint32_t tbl; };            // pk: bit 0 stop, 1 reverse, 3 stars-in-global, 4-5 (overlap mark + 1), 8.. three signed byte offsets; tbl: trace-back distance | window distance << 16
 struct DpRing { DpRec rec[DPW]; double2 sv2[DPW]; ushort4 cnt[DPW]; unsigned short cls[4][DPC]; };
 __device__ __forceinline__ int dp_slot(int rel) { return rel % DPW; }
@@ -363,7 +357,7 @@ __global__ void __launch_bounds__(DP_NT) gene_dp_kernel(Nodes nd, const uint32_t
     __syncthreads();
     int pend = -1, pend_tb = -1; double pend_score = 0.0;
     for (int i0 = 0; i0 < nn; i0 += 64) {
-      // the next 64 nodes enter the rings (wavefront 0; the slots they take over are 1152 nodes / 512 class members back)
+      // the next 64 nodes enter the rings (wavefront 0; the slots they take over are 1088 nodes / 512 class members back)
       if (wv == 0) {
         const int rel = i0 + lane; const bool in = rel < nn;
         int cls = -1, pk = 0; const uint32_t g = first + (uint32_t)(in ? rel : 0);

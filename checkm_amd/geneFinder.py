@@ -176,13 +176,13 @@ META_RANGE = 100000            # below this CheckM runs `prodigal -p meta` (chec
 
 def _lanes():
     import os
-    return max(1, min(16, int(os.environ.get("CKM_GENE_LANES", "12"))))
+    return max(1, min(32, int(os.environ.get("CKM_GENE_LANES", "16"))))
 
 
 def call_bin_files(jobs, bNucORFs=False, max_bases=None, logger=None, on_bin_done=None):
     """jobs = [(nucleotide FASTA of a bin, directory for genes.faa / genes.gff [/ genes.fna])].  Both translation tables per bin from the
     device, the reference's choice between them, prodigal's file layout.  Returns {binFile: (best table, {11: density, 4: density})}.
-    The bins go through the device in sub-batches of <= max_bases (CKM_GENE_BATCH_MB, default 64 Mbase), several calls in flight.
+    The bins go through the device in sub-batches of <= max_bases (CKM_GENE_BATCH_MB, default 128 Mbase), several calls in flight.
     Raises ValueError -- before anything is written -- when a bin is below the 20 kb the gene finder can train on (the pre-trained
     `-p meta` models CheckM would use below 100 kb are not built), and after the other bins' files are written when a trained bin
     yields no genes (the reference treats empty prodigal output as a failure, checkm/prodigal.py:96-115).  on_bin_done(binFile) is called
@@ -193,14 +193,14 @@ def call_bin_files(jobs, bNucORFs=False, max_bases=None, logger=None, on_bin_don
     from concurrent.futures import ThreadPoolExecutor
     from checkm_amd.defaultValues import DefaultValues
     if max_bases is None:
-        max_bases = int(os.environ.get("CKM_GENE_BATCH_MB", "64")) << 20
+        max_bases = int(os.environ.get("CKM_GENE_BATCH_MB", "128")) << 20
     lanes = _lanes()
-    phases = {"read_s": 0.0, "device_calls_s": 0.0, "choose_and_write_s": 0.0, "lanes": lanes, "calls": 0, "wall_s": 0.0}
-    call_bin_files.last_phases = phases
-    t_wall = time.perf_counter()
     out, lock = {}, threading.Lock()
     if not jobs:
         return out
+    phases = {"read_s": 0.0, "device_calls_s": 0.0, "choose_and_write_s": 0.0, "lanes": lanes, "calls": 0, "wall_s": 0.0}
+    call_bin_files.last_phases = phases
+    t_wall = time.perf_counter()
     # ---- read (host threads: file reads and byte operations release the interpreter) ----
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
