@@ -104,11 +104,13 @@ def world_size():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
-def gather_qa_rows(rows, max_rows, device=None):
-    """all_gather of per-rank QA rows padded to max_rows; returns the concatenated valid rows (every rank)."""
+def gather_qa_rows(rows, max_rows, device=None, even_alone=False):
+    """all_gather of per-rank QA rows padded to max_rows; returns the concatenated valid rows (every rank).  A world of one rank returns
+    its rows without touching the collective library unless even_alone is set (tests/test_gpu_dist.py pushes a QA buffer through RCCL
+    that way: the only execution of the collective a one-GPU box allows)."""
     import torch
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size() == 1 and not even_alone):
         return rows
     world = dist.get_world_size()
     buf = torch.full((max_rows, QA_WIDTH), -1.0, dtype=torch.float64)
