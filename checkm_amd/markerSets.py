@@ -258,6 +258,51 @@ def wanted_model(name, acc, keys):
     return (acc is not None and acc in keys) or (name is not None and name in keys)
 
 
+class _LazyLineageSets(dict):
+    """{binId: BinMarkerSets} whose values are built from their marker-file line the first time they are looked at; every way of
+    reaching a value goes through _make (iteration over values / items parses what is left)."""
+
+    def __init__(self, parser, lines):
+        dict.__init__(self, ((b, None) for b in lines))
+        self._parser, self._lines, self._selected = parser, lines, None
+
+    def _make(self, binId):
+        line = self._lines.pop(binId)
+        bms = BinMarkerSets(binId, BinMarkerSets.TREE_MARKER_SET)
+        bms.read(line)
+        if self._selected is None:
+            self._selected = self._parser.parseSelectedMarkerSetMap()     # parsed once, not once per line (markerSets.py:506)
+        bms.setLineageSpecificSelectedMarkerSet(self._selected)
+        removed = getattr(self, "_exclude", None)
+        if removed:
+            bms.removeMarkers(removed)
+        dict.__setitem__(self, binId, bms)
+        return bms
+
+    def exclude(self, markers):
+        """removeMarkers for every bin: applied to the bins already built now, to the others when they are built."""
+        self._exclude = set(markers)
+        for b, v in dict.items(self):
+            if v is not None:
+                v.removeMarkers(self._exclude)
+
+    def __getitem__(self, binId):
+        v = dict.__getitem__(self, binId)
+        return v if v is not None else self._make(binId)
+
+    def get(self, binId, default=None):
+        return self[binId] if binId in self else default
+
+    def values(self):
+        return [self[b] for b in list(self.keys())]
+
+    def items(self):
+        return [(b, self[b]) for b in list(self.keys())]
+
+    def __reduce__(self):
+        return (dict, (dict(self.items()),))
+
+
 class MarkerSetParser(object):
     """Marker-file parsing (markerSets.py:241-540)."""
 
@@ -286,6 +331,9 @@ class MarkerSetParser(object):
         if excludeMarkersFile:
             exclude = self.readExcludeMarkersFile(excludeMarkersFile)
         exclude.update(DefaultValues.MARKERS_TO_EXCLUDE)
+        if isinstance(out, _LazyLineageSets):
+            out.exclude(exclude)
+            return out
         for b in out.values():
             b.removeMarkers(exclude)
         return out
@@ -320,19 +368,15 @@ class MarkerSetParser(object):
         return bms
 
     def parseLineageMarkerSetFile(self, markerSetFile):
-        out = {}
-        selected = None
+        """{binId: BinMarkerSets} of a Lineage marker file (markerSets.py:478-511).  The lines are split off here and PARSED WHEN A BIN
+        IS ASKED FOR: one process per GPU reduces an eighth of the bins and has no use for the other lines' sets (rank 0 asks for all
+        of them when it prints the table)."""
+        lines = {}
         with open(markerSetFile) as f:
             f.readline()
             for line in f:
-                binId = line.split('\t')[0]
-                bms = BinMarkerSets(binId, BinMarkerSets.TREE_MARKER_SET)
-                bms.read(line)
-                if selected is None:
-                    selected = self.parseSelectedMarkerSetMap()     # parsed once, not once per line (markerSets.py:506)
-                bms.setLineageSpecificSelectedMarkerSet(selected)
-                out[binId] = bms
-        return out
+                lines[line[:line.find('\t')] if '\t' in line else line.split('\t')[0]] = line
+        return _LazyLineageSets(self, lines)
 
     def parseSelectedMarkerSetMap(self):
         m = {}
