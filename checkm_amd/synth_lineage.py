@@ -284,6 +284,15 @@ class World(object):
         for _ in _pool_map(self.root, self.seed, self.n_models, "bins", chunks, jobs):
             pass
 
+    def write_mag_files(self, jobs_list, jobs=None):
+        """jobs_list: [(bin index, path)] -- cfg5's bins (5000 ORFs, 600 planted models of the whole database), by the generator pool."""
+        todo = [j for j in jobs_list if not os.path.exists(j[1])]
+        if not todo:
+            return
+        chunks = [todo[k::max(1, len(todo) // 2)] for k in range(max(1, len(todo) // 2))]
+        for _ in _pool_map(self.root, self.seed, self.n_models, "mags", chunks, jobs):
+            pass
+
     def write_nucleotide_bins(self, jobs_list, jobs=None):
         """jobs_list: [(bin index, path)] -- nucleotide FASTA files whose genes are the bins' proteins (synth_genome.genome_from_proteins)."""
         todo = [j for j in jobs_list if not os.path.exists(j[1])]
@@ -323,6 +332,13 @@ def _worker_task(job):
     w = _WORKER_WORLD
     if kind == "hmm":
         return "".join(synth.hmm_text(w.profs[i]) for i in arg)
+    if kind == "mags":           # cfg5: bins of 5000 ORFs with 600 of the database's models planted (bench.py: bench_cfg5)
+        import numpy as np
+        for b, path in arg:
+            planted = sorted(np.random.default_rng(77000 + b).choice(w.n_models, size=600, replace=False).tolist())
+            synth.write_fasta(path + ".tmp", make_lineage_bin(w.profs, planted, 900000 + b, n_orfs=5000))
+            os.replace(path + ".tmp", path)
+        return len(arg)
     if kind == "fna":            # the bin's proteins carried by a synthetic genome (bench.py: the from_fasta leg)
         from checkm_amd import synth_genome as sg
         for b, path in arg:

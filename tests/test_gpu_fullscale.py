@@ -69,7 +69,7 @@ def test_cfg5_slice_10003_profiles_sampled_oracle_diff(gpu_ctx, tmp_path):
     for p in longs:
         p.stats = (-8.5 - 0.002 * p.M, 0.71, -9.5 - 0.002 * p.M, 0.71, -3.8, 0.71)
     synth.write_hmm(hmm, longs, mode="a")
-    nb = 6
+    nb = 50
     files = []
     rng = np.random.default_rng(77)
     for b in range(nb):
