@@ -55,3 +55,69 @@ def hit_key(hits, i, seq_base=0):
             int(float_bits(hits.full_bias[i])), int(hits.dom_idx[i]), int(hits.ndom[i]), float(hits.c_evalue[i]), float(hits.i_evalue[i]),
             int(float_bits(hits.dom_score[i])), int(float_bits(hits.dom_bias[i])), int(hits.hmm_from[i]), int(hits.hmm_to[i]), int(hits.ali_from[i]),
             int(hits.ali_to[i]), int(hits.env_from[i]), int(hits.env_to[i]), int(float_bits(hits.acc[i])))
+
+
+def real_format_hmm_text(profs):
+    """The synthetic profiles as the HMM files CheckM actually ships look (checkm_data_2015_01_16: hmms/checkm.hmm is HMMER3/b text written by
+    HMMER 3.0, Pfam / TIGRFAM records; checkm/hmmerModelParser.py:54-83 reads their headers): version-b and version-f headers in one file,
+    DATE / NSEQ / EFFN / CKSUM / BM / SM / COM lines, a DESC with spaces, GA / TC / NC with the trailing semicolon, RF / CS / MAP switched
+    on with their annotation columns on every match line (three columns in 3/b, five in 3/f), records without a COMPO line, and records
+    without ACC and cutoffs of their own (the sticky carry-over of CheckM's parser)."""
+    import re
+    out = []
+    for i, p in enumerate(profs):
+        txt = synth.hmm_text(p)
+        head, body = txt.split("HMM     ", 1)
+        ver_b = i % 2 == 0
+        lines = [ln for ln in head.split("\n") if ln]
+        keep = []
+        for ln in lines:
+            tag = ln.split()[0]
+            if tag.startswith("HMMER3"):
+                keep.append("HMMER3/b [3.0 | March 2010]" if ver_b else "HMMER3/f [3.1b1 | May 2013]")
+            elif tag in ("RF", "MM", "CONS", "CS", "MAP", "NSEQ", "EFFN", "CKSUM"):
+                continue
+            elif tag == "ACC" and i % 4 == 3:
+                continue                                      # no accession of its own: CheckM's parser carries the previous record's over
+            elif tag in ("GA", "TC", "NC") and i % 4 == 3:
+                continue
+            elif tag == "DESC":
+                keep.append("DESC  Ribosomal protein L%d, N-terminal domain (synthetic %s)" % (i + 1, p.name))
+            elif tag == "LENG":
+                keep.append(ln)
+            else:
+                keep.append(ln)
+        keep = [k for k in keep if k]
+        at = next(k for k, ln in enumerate(keep) if ln.startswith("ALPH")) + 1
+        extra = ["RF    no", "CS    yes", "MAP   yes", "DATE  Fri Jan 16 12:00:%02d 2015" % (i % 60), "NSEQ  %d" % (20 + 7 * i), "EFFN  %.6f" % (1.5 + 0.37 * i),
+                 "CKSUM %d" % (1234567 + 97 * i)]
+        if not ver_b:
+            extra.insert(1, "MM    no"); extra.insert(2, "CONS  yes")
+        keep[at:at] = extra
+        st = next(k for k, ln in enumerate(keep) if ln.startswith("STATS"))
+        keep[st:st] = ["BM    hmmbuild --hand -o /dev/null HMM SEED", "SM    hmmsearch -Z 9421015 -E 1000 --cpu 4 HMM pfamseq"] if ver_b else \
+                      ["COM   [1] hmmbuild -n %s HMM.ann SEED.ann" % p.name, "BM    hmmbuild HMM.ann SEED.ann", "SM    hmmsearch -Z 45638612 -E 1000 --cpu 4 HMM pfamseq"]
+        blines = body.split("\n")
+        new_body = []
+        for ln in blines:
+            if ln.lstrip().startswith("COMPO") and i % 3 == 1:
+                continue                                      # a record without a composition line (hmmbuild writes one, hand-edited files may not)
+            m = re.match(r"^(\s*\d+\s+.*?)\s+- - - - -\s*$", ln)
+            if m:
+                k = int(ln.split()[0])
+                ann = "%6d %s %s" % (k * 2 + 1, "-", "HEC"[k % 3]) if ver_b else "%6d %s %s %s %s" % (k * 2 + 1, "acdefg"[k % 6], "-", "-", "HEC"[k % 3])
+                new_body.append(m.group(1) + " " + ann)
+            else:
+                new_body.append(ln)
+        out.append("\n".join(keep) + "\nHMM     " + "\n".join(new_body))
+    return "".join(out)
+
+
+def real_format_hmm_file(tag, profs):
+    if tag not in _CACHE:
+        d = tempfile.mkdtemp(prefix="ckm_test_")
+        path = os.path.join(d, tag + ".hmm")
+        with open(path, "w") as f:
+            f.write(real_format_hmm_text(profs))
+        _CACHE[tag] = path
+    return _CACHE[tag]

@@ -188,3 +188,56 @@ def test_biased_composition_and_paralog_family(world):
     assert sum(1 for g in mine if g[1] == 7) >= 20                                   # the paralog family is reported copy by copy
     assert st.pairs_dom >= 43 + 20 and st.envelopes >= 43 + 20                       # the paralogs reach the domain stage one by one
     hs.close(); hits.close(); seqs.close()
+
+
+def test_low_complexity_and_tandem_repeat_proteins(world):
+    """What real proteomes hold and iid-background ORFs do not: homopolymer and dipeptide runs, proteins that are one short motif over
+    and over, linkers of two or three residue types around real domains, and tandem arrays of one domain (2-8 copies: every array is a
+    multi-domain region for the trace ensemble, the repeats' null2 correction sees a composition dominated by the domain itself).  The
+    bias filter, null2 and the region heuristics do their real work here.  Every row against the oracle, as bit patterns."""
+    w = world
+    ctx, prof, profs = w["ctx"], w["prof"], w["profs"]
+    rng = np.random.default_rng(77)
+    AAS = synth.AMINO
+    recs = []
+
+    def add(seq):
+        recs.append(("lc%04d_%d" % (len(recs) // 40 + 1, len(recs) % 40 + 1), "", seq + "*"))
+    for k in range(30):                                               # pure low complexity
+        a, b, c = (AAS[i] for i in rng.choice(20, 3, replace=False))
+        kind = k % 5
+        n = int(rng.integers(60, 500))
+        if kind == 0:
+            add(a * n)
+        elif kind == 1:
+            add((a + b) * (n // 2))
+        elif kind == 2:
+            add("".join(rng.choice([a, b, c], p=[0.6, 0.3, 0.1], size=n)))
+        elif kind == 3:
+            motif = "".join(rng.choice(list(AAS), size=int(rng.integers(3, 9))))
+            add(motif * (n // len(motif)))
+        else:
+            add(synth.to_text(synth.random_residues(rng, 40)) + a * (n // 2) + synth.to_text(synth.random_residues(rng, 40)) + (b + c) * (n // 6))
+    for k in range(40):                                               # domains inside low-complexity linkers, tandem arrays of one domain
+        p = profs[int(rng.integers(0, len(profs)))]
+        copies = int(rng.integers(1, 9)) if p.M < 200 else int(rng.integers(1, 4))
+        link = lambda: "".join(rng.choice(list("QSGTPN"), p=[0.35, 0.25, 0.2, 0.1, 0.05, 0.05], size=int(rng.integers(0, 30))))
+        s = link()
+        for _ in range(copies):
+            lo = 1 if rng.random() < 0.7 else int(rng.integers(1, max(2, p.M // 3)))
+            s += synth.to_text(synth.sample_domain(rng, p, lo, p.M if rng.random() < 0.7 else int(rng.integers(max(lo + 10, 2 * p.M // 3), p.M + 1)))) + link()
+        add(s)
+    for _ in range(130):                                              # ordinary background around them (Z, the tail statistics)
+        add(synth.to_text(synth.random_residues(rng, int(rng.integers(60, 600)))))
+    seqs = _lib.Seqs(ctx, [recs])
+    hits = _lib.search(ctx, prof, seqs)
+    st = ctx.stats()
+    hs = p7.HmmSet(w["path"])
+    rows = common.oracle_search_threaded(hs, range(hs.n), [p7.digitize(r[2]) for r in recs], [r[0] for r in recs])
+    mine = [common.hit_key(hits, i) for i in hits.rows(0)]
+    assert len(rows) == len(mine) >= 60
+    for o, g in zip(rows, mine):
+        assert common.row_key(o) == g, (o.seq_idx, o.model_idx)
+    assert st.regions_multi >= 10                                                     # the tandem arrays went through the trace ensemble
+    assert max(g[8] for g in mine) >= 3                                               # some target carries three or more reported domains of one model
+    hs.close(); hits.close(); seqs.close()

@@ -534,3 +534,26 @@ print(json.dumps(dict(regions=out, rows=int(hits.n), same=bool(same), multi=int(
     for o in out["regions"]:
         assert o["rc"] == 0 and o["n2"] and o["segs"] and o["env"] and o["nenv"] >= 1, o
     assert out["same"] and out["rows"] > 6 and out["multi"] >= 2, out
+
+
+def test_real_format_hmm_file_searched(gpu_ctx, tmp_path):
+    """The library's reader on an HMM file laid out like CheckM's data bundle (tests/common.py:real_format_hmm_text: 3/b and 3/f headers, DATE /
+    NSEQ / EFFN / CKSUM / BM / SM / COM, DESC with spaces, annotation columns, records without COMPO, records without ACC): the headers the
+    mirror of checkm/hmmerModelParser.py sees, and a search whose domtblout text equals the oracle's on the same file."""
+    profs = synth.small_profiles(11, 12, 40, 300)[:8]
+    path = common.real_format_hmm_file("real8", profs)
+    prof = _lib.Profiles(gpu_ctx, path)
+    assert prof.n == len(profs)
+    assert [h["name"] for h in prof.headers] == [p.name for p in profs] and [h["leng"] for h in prof.headers] == [p.M for p in profs]
+    assert not prof.headers[3]["acc"] and not prof.headers[7]["acc"] and prof.headers[0]["acc"] == profs[0].acc
+    recs = synth.make_bin(profs, 5, n_orfs=60, dup_frac=0.3)
+    seqs = _lib.Seqs(gpu_ctx, [recs])
+    hits = _lib.search(gpu_ctx, prof, seqs)
+    hs = p7.HmmSet(path)
+    names, descs = [r[0] for r in recs], [r[1] for r in recs]
+    rows = hs.search(list(range(hs.n)), [p7.digitize(r[2]) for r in recs], names)
+    assert hits.n == len(rows) >= len(profs)
+    out = str(tmp_path / "real.txt")
+    hits.write_domtblout(prof, seqs, 0, out)
+    assert open(out).read() == hs.format_domtblout(rows, names, descs)
+    hits.close(); seqs.close(); prof.close(); hs.close()
