@@ -136,7 +136,7 @@ def hmmer_leg(hmm_path, bins, threads, workdir):
     if exe is None:
         return None
     from concurrent.futures import ThreadPoolExecutor
-    from checkm_amd import synth
+    from synthdata import synth
     sample = bins[:max(1, threads)]
     faa = []
     for b, recs in enumerate(sample):
@@ -152,7 +152,7 @@ def hmmer_leg(hmm_path, bins, threads, workdir):
         list(ex.map(run, faa))
     dt = time.perf_counter() - t0
     residues = sum(sum(len(r[2]) for r in recs) for recs in sample)
-    from checkm_amd import synth as _s  # noqa: F401
+    from synthdata import synth as _s  # noqa: F401
     nmodels = sum(1 for line in open(hmm_path) if line.startswith("NAME"))
     ver = subprocess.run([exe, "-h"], stdout=subprocess.PIPE).stdout.decode(errors="replace").split("\n")[1:2]
     return {"value": residues * nmodels / dt, "unit": "residue*HMM/s", "cores": min(threads, len(sample)), "kind": "reference",
@@ -210,7 +210,7 @@ def stage_pairs(st):
 # ---------------------------------------------------------------------------------------------------------------------
 def lineage_setup(workdir, nbins, rank, world, sync):
     """The synthetic lineage world + `nbins` genes.faa files (every rank writes a slice of them)."""
-    from checkm_amd import synth, synth_lineage as sl
+    from synthdata import synth, synth_lineage as sl
     from checkm_amd.defaultValues import DefaultValues
     data = os.path.join(workdir, "lineage_data")
     if rank == 0:
@@ -341,7 +341,8 @@ def main():
 def bench_cfg2(args, env):
     """configs[1]: returns the line (rank 0) or None."""
     import torch
-    from checkm_amd import _lib, dist as cdist, synth
+    from checkm_amd import _lib, dist as cdist
+    from synthdata import synth
     from checkm_amd import qa as cqa
     rank, world, workdir, dev, local_rank = env.rank, env.world, env.workdir, env.dev, env.dev_index
     sync, all_sum, all_max = env.sync, env.all_sum, env.all_max
@@ -663,7 +664,8 @@ def bench_cfg5(args, env):
     a Pfam-like length distribution -- three of its models beyond the kernels' 2048 nodes -- against --bins (default 50) bins of 5000 ORFs,
     EVERY searchable model against every bin, through MarkerGeneFinder.find from files.  Not a default line: `bench.py --config cfg5`."""
     import numpy as np
-    from checkm_amd import markerGeneFinder as mgf, synth, synth_lineage as sl
+    from checkm_amd import markerGeneFinder as mgf
+    from synthdata import synth, synth_lineage as sl
     from checkm_amd.defaultValues import DefaultValues
     rank, world, workdir = env.rank, env.world, env.workdir
     if world != 1:
@@ -828,7 +830,8 @@ def gene_calling(workdir, nbins=192, cpu_bins=8):
     scores, both dynamic programs, translations (checkm_amd/geneFinder.py -> ckm_genes_call), on synthetic 2 Mb bins of 20 contigs (24 distinct genomes under 192 names); the
     kernel times of the last call; and the same work by the CPU oracle (oracle/gene_full.c, one thread per bin) on a few of the bins."""
     from concurrent.futures import ThreadPoolExecutor
-    from checkm_amd import geneFinder, synth_genome as sg
+    from checkm_amd import geneFinder
+    from synthdata import synth_genome as sg
     d = os.path.join(workdir, "gene_bins")
     os.makedirs(d, exist_ok=True)
     jobs, bases = [], 0

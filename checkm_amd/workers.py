@@ -10,8 +10,10 @@ workers share a device, as in the tests) and rank 0 hands the table to the paren
 parent (output formats 3-9, cacheResults, the aligner) reads the tables the workers wrote, as a later `checkm qa` would.
 
 `torchrun`-style launches (WORLD_SIZE > 1 in the environment: bench.py --gpus N) keep working as before: every rank is then a full
-process and no workers are spawned.  CKM_GPUS selects the devices ("all" = every visible device, the default; "0,2,5"; one device or
-an empty value = scan in this process)."""
+process and no workers are spawned.  The fan-out is OPT-IN: CKM_GPUS selects the devices ("all" = every visible device; "0,2,5"); unset,
+empty or a single device = scan in this process on one GPU (a find() that quietly spawns a process per GPU is not what a caller of
+the reference's API expects, and no multi-GPU hardware run of this path exists yet: the driver measures scaling through torchrun).
+A worker error tears the whole pool down (peers may sit in a collective); CKM_WORKER_TIMEOUT_S bounds the time WITHOUT any reply."""
 import atexit
 import multiprocessing as mp
 import os
@@ -26,7 +28,7 @@ def devices():
     """The devices find() fans out over, or None to scan in this process."""
     if os.environ.get("CKM_WORKER") or os.environ.get("CKM_EMULATE_RANK") or int(os.environ.get("WORLD_SIZE", "1")) > 1:
         return None
-    spec = os.environ.get("CKM_GPUS", "all").strip()
+    spec = os.environ.get("CKM_GPUS", "").strip()
     if spec == "all":
         from checkm_amd import _lib
         devs = list(range(_lib.device_count()))
@@ -101,6 +103,7 @@ class Pool(object):
                             self.abort()
                             raise WorkerError(payload)
                         out[r] = payload; pending.discard(r); progressed = True
+                        t0 = time.monotonic()              # (the limit is on silence, not on the length of a call: a long find over many bins keeps answering)
                     elif not proc.is_alive():
                         self.abort()
                         raise WorkerError("GPU worker %d (device %d) died (exit code %s)" % (r, self.devs[r], proc.exitcode))

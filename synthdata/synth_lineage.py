@@ -20,7 +20,7 @@ import os
 
 import numpy as np
 
-from checkm_amd import synth
+from synthdata import synth
 
 _STATS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "synth_stats_cfg3.json")
 
@@ -340,7 +340,7 @@ def _worker_task(job):
             os.replace(path + ".tmp", path)
         return len(arg)
     if kind == "fna":            # the bin's proteins carried by a synthetic genome (bench.py: the from_fasta leg)
-        from checkm_amd import synth_genome as sg
+        from synthdata import synth_genome as sg
         for b, path in arg:
             prots = [r[2] for r in w.bin_records(b)]
             g = sg.genome_from_proteins(prots, 7000 + b, n_contigs=20, gc=0.35 + 0.3 * (b % 11) / 10.0, sd_frac=0.0 if b % 6 == 5 else 0.6)

@@ -4,7 +4,7 @@ import tempfile
 
 import numpy as np
 
-from checkm_amd import synth
+from synthdata import synth
 
 _CACHE = {}
 

@@ -7,7 +7,7 @@ training loops, the -m masks as range counts, the record builder.  The kernels t
 import numpy as np
 import pytest
 
-from checkm_amd import synth_genome as sg
+from synthdata import synth_genome as sg
 from oracle import genes as og
 from tests import emu
 

@@ -4,7 +4,7 @@ properties any gene finder of this shape must have on designed genomes (planted 
 N-run masking, the table-4 signal)."""
 import numpy as np
 
-from checkm_amd import synth_genome as sg
+from synthdata import synth_genome as sg
 from oracle import genes as og
 
 CODON = {}

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from checkm_amd import synth
+from synthdata import synth
 from checkm_amd.defaultValues import DefaultValues
 from checkm_amd.markerGeneFinder import MarkerGeneFinder, release_scan
 from checkm_amd.markerSets import MarkerSetParser

@@ -19,7 +19,8 @@ CODE = r'''
 import sys, json
 sys.path.insert(0, %r)
 import numpy as np
-from checkm_amd import _lib, synth
+from checkm_amd import _lib
+from synthdata import synth
 from tests import common
 import os
 if os.environ.get("CKM_TEST_SHAPE") == "classes":

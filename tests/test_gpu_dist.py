@@ -7,7 +7,7 @@ import sys
 
 import pytest
 
-from checkm_amd import synth
+from synthdata import synth
 from tests import common
 
 pytestmark = pytest.mark.gpu

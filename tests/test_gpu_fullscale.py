@@ -8,7 +8,8 @@ import os
 import numpy as np
 import pytest
 
-from checkm_amd import markerGeneFinder as mgf, synth, synth_lineage as sl
+from checkm_amd import markerGeneFinder as mgf
+from synthdata import synth, synth_lineage as sl
 from checkm_amd.defaultValues import DefaultValues
 from checkm_amd.markerSets import MarkerSetParser
 from checkm_amd.resultsParser import ResultsParser

@@ -5,7 +5,8 @@ oracle spot checks on sampled pairs."""
 import numpy as np
 import pytest
 
-from checkm_amd import _lib, qa as cqa, synth
+from checkm_amd import _lib, qa as cqa
+from synthdata import synth
 from oracle import p7
 from tests import common
 
@@ -170,7 +171,7 @@ def test_biased_composition_and_paralog_family(world):
     """A bin whose background is far from Swiss-Prot (skewed Dirichlet draw: the null models and the bias filter work on a
     composition they were not calibrated for) and which carries 20 paralogous copies of one family (the Forward / domain
     definition / null2 stages see a family-rich proteome).  All rows against the oracle."""
-    from checkm_amd import synth_lineage as sl
+    from synthdata import synth_lineage as sl
     w = world
     ctx, prof, profs = w["ctx"], w["prof"], w["profs"]
     rng = np.random.default_rng(5)

@@ -7,7 +7,8 @@ import os
 import numpy as np
 import pytest
 
-from checkm_amd import _lib, geneFinder, synth_genome as sg
+from checkm_amd import _lib, geneFinder
+from synthdata import synth_genome as sg
 from oracle import genes as og
 
 pytestmark = pytest.mark.gpu
@@ -65,7 +66,8 @@ def test_genes_identical_to_the_oracle(gpu_ctx, table):
 def test_find_from_nucleotide_bins_writes_prodigal_files(gpu_ctx, tmp_path, monkeypatch):
     """MarkerGeneFinder.find on nucleotide bins with no prodigal on PATH: genes.faa / genes.gff come from the device caller, the table
     choice follows checkm/prodigal.py:117-133, ProdigalGeneFeatureParser reads the GFF, and the scan runs on the written proteins."""
-    from checkm_amd import markerGeneFinder as mgf, synth
+    from checkm_amd import markerGeneFinder as mgf
+    from synthdata import synth
     from checkm_amd.defaultValues import DefaultValues
     from checkm_amd.prodigal import ProdigalGeneFeatureParser
     from tests import common

@@ -8,7 +8,8 @@ import os
 import numpy as np
 import pytest
 
-from checkm_amd import _lib, synth, synth_lineage as sl
+from checkm_amd import _lib
+from synthdata import synth, synth_lineage as sl
 from checkm_amd.defaultValues import DefaultValues
 from checkm_amd import markerGeneFinder as mgf
 from checkm_amd.markerSets import MarkerSetParser

@@ -8,7 +8,8 @@ import os
 import numpy as np
 import pytest
 
-from checkm_amd import _lib, qa as cqa, synth
+from checkm_amd import _lib, qa as cqa
+from synthdata import synth
 from checkm_amd.defaultValues import DefaultValues
 from checkm_amd.hmmerModelParser import HmmModel
 from checkm_amd.markerSets import MarkerSet

@@ -7,7 +7,8 @@ compared as bit patterns, not within a tolerance.
 import numpy as np
 import pytest
 
-from checkm_amd import _lib, synth
+from checkm_amd import _lib
+from synthdata import synth
 from oracle import p7
 from tests import common
 
@@ -233,7 +234,8 @@ def test_chunked_and_multi_worker_execution_equal_single_pass(world):
 import sys, json
 sys.path.insert(0, %r)
 import numpy as np
-from checkm_amd import _lib, synth
+from checkm_amd import _lib
+from synthdata import synth
 from tests import common
 profs = common.mixed_profiles(); path = common.hmm_file("mixed", profs)
 bins = [synth.make_bin(profs, 1000 + b, n_orfs=160, dup_frac=0.4) for b in range(2)]
@@ -415,7 +417,8 @@ def test_ragged_model_subsets_single_and_multi_worker(gpu_ctx):
 import sys, json
 sys.path.insert(0, %r)
 import numpy as np
-from checkm_amd import _lib, synth
+from checkm_amd import _lib
+from synthdata import synth
 from tests import common
 profs = common.mixed_profiles(); path = common.hmm_file("mixed", profs)
 rng = np.random.default_rng(123)

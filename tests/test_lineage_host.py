@@ -3,7 +3,8 @@
 matched by NAME or ACC as `hmmfetch -f` matches (markerSets.py:326-343), and find()'s batch plan / rank shards."""
 import os
 
-from checkm_amd import dist as cdist, markerGeneFinder as mgf, synth_lineage as sl
+from checkm_amd import dist as cdist, markerGeneFinder as mgf
+from synthdata import synth_lineage as sl
 from checkm_amd.defaultValues import DefaultValues
 from checkm_amd.markerSets import BinMarkerSets, MarkerSetParser, wanted_model
 

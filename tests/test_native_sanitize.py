@@ -8,7 +8,7 @@ import subprocess
 
 import pytest
 
-from checkm_amd import synth
+from synthdata import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "checkm_amd", "csrc")

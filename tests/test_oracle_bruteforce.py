@@ -9,7 +9,7 @@ import math
 import numpy as np
 import pytest
 
-from checkm_amd import synth
+from synthdata import synth
 from oracle import p7
 
 

@@ -21,7 +21,7 @@ import os
 
 import numpy as np
 
-from checkm_amd import synth
+from synthdata import synth
 from oracle import p7
 
 _m = ctypes.CDLL("libm.so.6")

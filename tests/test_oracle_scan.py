@@ -3,7 +3,7 @@ check internal consistency and the properties the domain offers."""
 import numpy as np
 import pytest
 
-from checkm_amd import synth
+from synthdata import synth
 from oracle import p7
 from tests import common
 

@@ -72,7 +72,7 @@ def test_device_against_prodigal_gff(fna, gff, table, tmp_path, gpu_ctx):
 def test_the_comparison_itself_on_a_hand_made_pair(tmp_path):
     """The machinery above on a synthetic 'prodigal' file made from the oracle's own genes with prodigal's source column and ID numbering:
     equal apart from the ID, and a changed coordinate or score is seen."""
-    from checkm_amd import synth_genome as sg
+    from synthdata import synth_genome as sg
     contigs = sg.make_genome(77, n_contigs=2, contig_len=(15000, 20000))
     cols = oracle_columns(contigs, 11)
     ours = written_by_us(contigs, 11, cols, tmp_path)

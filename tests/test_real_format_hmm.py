@@ -2,7 +2,7 @@
 annotation columns behind every match line, records without COMPO, records without ACC and cutoffs of their own): the oracle's reader and
 the mirror of CheckM's header parser (checkm/hmmerModelParser.py:46-83) on a fixture in that layout (tests/common.py:real_format_hmm_text).
 The device reader is checked on the same fixture by tests/test_gpu_scan.py::test_real_format_hmm_file_searched."""
-from checkm_amd import synth
+from synthdata import synth
 from checkm_amd.hmmerModelParser import HmmModelParser
 from oracle import p7
 from tests import common

@@ -5,7 +5,7 @@ import shutil
 
 import pytest
 
-from checkm_amd import synth
+from synthdata import synth
 from tests import common
 from tools import diff_vs_hmmsearch as dvh
 

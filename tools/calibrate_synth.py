@@ -15,7 +15,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from checkm_amd import synth  # noqa: E402
+from synthdata import synth  # noqa: E402
 from oracle import p7  # noqa: E402
 
 LN2 = float(np.log(2.0))
@@ -72,7 +72,7 @@ def calibrate(profs, rng):
 
 def main_cfg3():
     """STATS LOCAL lines of the 2000-profile lineage world (checkm_amd/synth_lineage.py) -> checkm_amd/synth_stats_cfg3.json."""
-    from checkm_amd import synth_lineage as sl
+    from synthdata import synth_lineage as sl
     rng = np.random.default_rng(20250925)
     profs = sl.lineage_profiles(with_stats=False)
     stats = {}

@@ -7,7 +7,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
-from checkm_amd import _lib, synth  # noqa: E402
+from checkm_amd import _lib  # noqa: E402
+from synthdata import synth  # noqa: E402
 from tests import common  # noqa: E402
 
 profs = common.mixed_profiles()

@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--bins", type=int, default=100)
     ap.add_argument("--orfs", type=int, default=2000)
     args = ap.parse_args()
-    from checkm_amd import synth
+    from synthdata import synth
     from checkm_amd.defaultValues import DefaultValues
     from checkm_amd.markerGeneFinder import MarkerGeneFinder, release_scan
     from checkm_amd.markerSets import MarkerSetParser

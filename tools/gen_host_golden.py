@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 from checkm.hmmerModelParser import HmmModelParser  # noqa: E402
 from checkm.markerSets import MarkerSetParser  # noqa: E402
 from checkm.common import binIdFromFilename  # noqa: E402
-from checkm_amd import synth  # noqa: E402
+from synthdata import synth  # noqa: E402
 
 
 def hmm_text():

@@ -13,7 +13,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from checkm_amd import synth          # noqa: E402
+from synthdata import synth          # noqa: E402
 from oracle import p7                 # noqa: E402
 from tests import common             # noqa: E402
 

@@ -5,7 +5,8 @@ import sys
 import time
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from checkm_amd import _lib, runtime, synth_genome as sg      # noqa: E402
+from checkm_amd import _lib, runtime      # noqa: E402
+from synthdata import synth_genome as sg  # noqa: E402
 
 nbins = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 table = int(sys.argv[2]) if len(sys.argv) > 2 else 11

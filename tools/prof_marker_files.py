@@ -11,7 +11,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from checkm_amd import synth_lineage as sl                    # noqa: E402
+from synthdata import synth_lineage as sl                    # noqa: E402
 from checkm_amd.defaultValues import DefaultValues            # noqa: E402
 from checkm_amd.markerSets import MarkerSetParser, _parse_marker_sets   # noqa: E402
 
