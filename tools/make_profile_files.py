@@ -90,8 +90,10 @@ def one(tag):
             for n, c, t, a in sorted(inst, key=lambda x: -x[2])[:40]:
                 f.write("%-34s %8d %12.2f %12.1f\n" % (n, c, t / 1e6, a / 1e3))
     if os.path.exists(os.path.join(src, "pmc3_sq.json")):
-        pmc_files(src, dst, "pmc3_", "cfg3_", last_json(os.path.join(src, "pmc3_sq.json")),
-                  "CKM_BENCH_SKIP_WARM=1 python bench.py --config cfg3 --bins-total 48 --steps 1 --warmup 0 --no-cpu-baseline --no-cfg2 --no-emulation --no-verify   (a 48-bin SAMPLE of configs[2])")
+        line3 = last_json(os.path.join(src, "pmc3_sq.json"))
+        nb3 = int(line3["config"].get("bins_total", 48))
+        pmc_files(src, dst, "pmc3_", "cfg3_", line3,
+                  "CKM_BENCH_SKIP_WARM=1 python bench.py --config cfg3 --bins-total %d --steps 1 --warmup 0 --no-cpu-baseline --no-cfg2 --no-emulation --no-verify   (%d of the 1000 bins of configs[2], default batching)" % (nb3, nb3))
     if os.path.exists(os.path.join(src, "pmc_sq.json")):
         pmc_files(src, dst, "pmc_", "", last_json(os.path.join(src, "pmc_sq.json")),
                   "CKM_BENCH_STEADY=0 CKM_BENCH_FROM_HOST=0 python bench.py --config cfg2 --steps 1 --warmup 0 --no-cpu-baseline --no-verify")
