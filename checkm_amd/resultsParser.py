@@ -662,14 +662,27 @@ class ResultsParser(object):
                 groups.append([view, [b], mb])
                 group_of[id(mb)] = groups[-1]
 
-        class _Slot(object):
-            def __init__(self, acc, leng, v):
-                self.acc, self.leng = (v[0], v[1]) if v else (acc, leng)
-                self.ga, self.tc, self.nc = (v[2], v[3], v[4]) if v else (None, None, None)
+        # one plan per group: the model slots of the whole database, a slot's cutoffs from the group's (sticky) view where the group knows the
+        # model, none elsewhere.  Built from two shared base lists with only the known slots written over (a lineage_wf run has ~120 groups of
+        # ~600 known models among 2000 slots: a Python object per slot and group took 0.1 s of every pass), cutoff cascades resolved once
+        # per distinct (acc, ga, tc, nc).
+        clans, nested = _pfam_tables()
+        base_acc, base_len = list(slot_acc), [hd["leng"] for hd in profiles.headers]
+        none_thr = cqa.resolve_threshold("", None, None, None)
+        slots_of = {}
+        for k, a in enumerate(slot_acc):
+            slots_of.setdefault(a, []).append(k)
+        thr_cache = {}
         plans = []
         for merged, members, _last in groups:
-            mlist = [_Slot(a, hd["leng"], merged.get(a)) for a, hd in zip(slot_acc, profiles.headers)]
-            plans.append((_plan_for_models(mlist), members))
+            acc_l, len_l, thr_l = list(base_acc), list(base_len), [none_thr] * len(base_acc)
+            for a, v in merged.items():
+                t = thr_cache.get(v)
+                if t is None:
+                    t = thr_cache[v] = cqa.resolve_threshold(v[0], v[2], v[3], v[4])
+                for k in slots_of.get(a, ()):
+                    acc_l[k], len_l[k], thr_l[k] = v[0], v[1], t
+            plans.append(((cqa.KeyTable(), acc_l, len_l, thr_l, clans, nested), members))
         # Groups that differ in nothing but cutoffs (the sticky header view of another model subset) become threshold VARIANTS of
         # one plan: every part of the scan is then reduced in ONE library call, each bin under its own variant.
         (keys, acc, qlen, thr, clans, nested), _m = plans[0]
