@@ -146,6 +146,8 @@ GFN double dp_igm(const S &src, double st_wt, int k1, const DpNode &n1, int k2, 
   return rval;
 }
 // score of the connection p1 -> p2 (node indices relative to the sequence's first node); false: no such connection.
+// The source serves p1 and p2 through node / val / score / tb (a device source may assume both are in its LDS ring) and everything reached
+// THROUGH them -- an overlapping start p3, the node a trace-back points to -- through node3 / val3 / ndx_any (anywhere in the sequence).
 // KNOWN: the caller enumerates p1 by class (strand KS1, stop KST1), so the twelve cases fold to the ones that class can take -- the
 // same statements either way.
 template <class S, bool KNOWN, int KS1, bool KST1>
@@ -184,13 +186,13 @@ GFN bool dp_connection_x(const S &src, double st_wt, int p1, int p2, const DpNod
     for (int i = 0; i < 3; ++i) {
       const int p3 = src.star(p2, i);
       if (p3 == -1) continue;
-      const DpNode n3 = src.node(p3);
+      const DpNode n3 = src.node3(p3);
       const int ov = left - n3.sv + 1;
       if (ov <= 0 || ov >= 200) continue;
       if (ov >= n3.ndx - left) continue;
       if (tb1 == -1) continue;
-      if (ov >= n3.sv - src.ndx(tb1) - 2) continue;
-      const double v = flag == 1 ? src.val(p3) + dp_igm(src, st_wt, p3, n3, p2, n2) : src.val(p3);
+      if (ov >= n3.sv - src.ndx_any(tb1) - 2) continue;
+      const double v = flag == 1 ? src.val3(p3) + dp_igm(src, st_wt, p3, n3, p2, n2) : src.val3(p3);
       if (v > maxval) { maxfr = i; maxval = v; best_ov = ov; }
     }
     if (maxfr != -1) { ovlp = best_ov; if (flag == 0) scr_mod = maxval; else score = maxval; }
@@ -207,7 +209,7 @@ GFN bool dp_connection_x(const S &src, double st_wt, int p1, int p2, const DpNod
     ovlp = (n1.ndx + 2) - (n2.sv - 2) + 1;
     if (ovlp >= 200) return false;
     if ((n1.ndx + 2 - n2.sv - 2 + 1) >= (n2.ndx - n1.ndx + 3 + 1)) return false;
-    const int bnd = tb1 == -1 ? 0 : src.ndx(tb1);
+    const int bnd = tb1 == -1 ? 0 : src.ndx_any(tb1);
     if ((n1.ndx + 2 - n2.sv - 2 + 1) >= (n2.sv - 3 - bnd + 1)) return false;
     left = n2.sv - 2;
     if (flag == 0) scr_mod = src.val(p2); else score = src.val(p2) - 0.15 * st_wt;
@@ -215,16 +217,16 @@ GFN bool dp_connection_x(const S &src, double st_wt, int p1, int p2, const DpNod
     if (n2.sv >= n1.ndx) return false;
     const int p3 = src.star(p1, n2.ndx % 3);
     if (p3 == -1) return false;
-    const DpNode n3 = src.node(p3);
+    const DpNode n3 = src.node3(p3);
     left = n3.ndx; right += 2;
-    if (flag == 0) scr_mod = src.val(p3); else score = src.val(p3) + dp_igm(src, st_wt, p1, n1, p3, n3);
+    if (flag == 0) scr_mod = src.val3(p3); else score = src.val3(p3) + dp_igm(src, st_wt, p1, n1, p3, n3);
   } else if (s1 == s2 && s1 == -1 && st1 && st2) {
     if (n1.sv <= n2.ndx) return false;
     const int p3 = src.star(p2, n1.ndx % 3);
     if (p3 == -1) return false;
-    const DpNode n3 = src.node(p3);
+    const DpNode n3 = src.node3(p3);
     left -= 2; right = n3.ndx;
-    if (flag == 0) scr_mod = src.val(p3); else score = src.val(p3) + dp_igm(src, st_wt, p3, n3, p2, n2);
+    if (flag == 0) scr_mod = src.val3(p3); else score = src.val3(p3) + dp_igm(src, st_wt, p3, n3, p2, n2);
   }
   if (flag == 0) score = ((double)(right - left + 1 - (ovlp * 2))) * scr_mod;
   total = src.score(p1) + score;

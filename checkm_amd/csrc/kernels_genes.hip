@@ -338,7 +338,64 @@ struct DpSrc {
   }
   __device__ __forceinline__ double rscore(int rel) const { return nd.rscore[first + (uint32_t)rel]; }
   __device__ __forceinline__ double uscore(int rel) const { return nd.uscore[first + (uint32_t)rel]; }
+  __device__ __forceinline__ DpNode node3(int rel) const { return node(rel); }
+  __device__ __forceinline__ double val3(int rel) const { return val(rel); }
+  __device__ __forceinline__ int ndx_any(int rel) const { return ndx(rel); }
 };
+// The same source for candidates that are KNOWN to sit in the ring (the class path: every candidate comes out of a class ring, node i is
+// in the ring): position, stop position, flags, trace-back distance in ONE 16-byte LDS read, score and value in another, no
+// ring-or-global question on the way.  What is reached through a candidate (overlapping starts, the node its trace-back points to) may lie
+// outside and goes through the general accessors.
+template <int FLAG>
+struct DpRingSrc {
+  static constexpr int flag = FLAG;
+  const DpSrc<FLAG> &g; mutable int last_rel; mutable DpRec last;
+  __device__ __forceinline__ const DpRec &rec(int rel) const { if (rel != last_rel) { last = g.r.rec[dp_slot(rel)]; last_rel = rel; } return last; }
+  __device__ __forceinline__ DpNode node(int rel) const { const DpRec &q = rec(rel); DpNode n; n.ndx = q.ndx; n.sv = q.sv; n.strand = (q.pk & 2) ? -1 : 1; n.stop = q.pk & 1; return n; }
+  __device__ __forceinline__ int star(int rel, int f) const {
+    const int pk = rec(rel).pk;
+    if (!(pk & 8)) { const int o = (int)(int8_t)((pk >> (8 + 8 * f)) & 0xff); return o == -128 ? -1 : rel + o; }
+    return g.nd.star[(size_t)(g.first + (uint32_t)rel) * 3 + f];
+  }
+  __device__ __forceinline__ double val(int rel) const { return g.r.sv2[dp_slot(rel)].y; }
+  __device__ __forceinline__ double score(int rel) const { return rel == g.pend ? g.pend_score : g.r.sv2[dp_slot(rel)].x; }
+  __device__ __forceinline__ int tb(int rel) const {
+    if (rel == g.pend) return g.pend_tb;
+    const uint32_t d = rec(rel).tbl & 0xffffu;
+    if (d != (uint32_t)DP_FAR) return d == 0 ? -1 : rel - (int)d;
+    return g.tb(rel);
+  }
+  __device__ __forceinline__ double rscore(int rel) const { return g.rscore(rel); }
+  __device__ __forceinline__ double uscore(int rel) const { return g.uscore(rel); }
+  __device__ __forceinline__ DpNode node3(int rel) const { return g.node(rel); }
+  __device__ __forceinline__ double val3(int rel) const { return g.val(rel); }
+  __device__ __forceinline__ int ndx_any(int rel) const { return g.ndx(rel); }
+};
+
+// (best total, candidate key) of the wavefront: xor butterfly on data-parallel-primitive moves and lane swaps -- no LDS round trip (ds_bpermute, what
+// __shfl_xor compiles to, is six dependent ~100-cycle trips per node)
+template <int CTRL> __device__ __forceinline__ int dp_dpp(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ void dp_merge(double &best, int &key, double ob, int ok) {
+  if (ok >= 0 && (key < 0 || ob > best || (ob == best && ok > key))) { best = ob; key = ok; }
+}
+__device__ __forceinline__ void dp_wave_best(double &best, int &key) {
+  auto lo = [](double d) { return (int)(__builtin_bit_cast(unsigned long long, d) & 0xffffffffull); };
+  auto hi = [](double d) { return (int)(__builtin_bit_cast(unsigned long long, d) >> 32); };
+  auto mk = [](int l, int h) { return __builtin_bit_cast(double, ((unsigned long long)(unsigned)h << 32) | (unsigned)l); };
+#define CKM_DP_STEP(CTRL) { const double ob = mk(dp_dpp<CTRL>(lo(best)), dp_dpp<CTRL>(hi(best))); const int ok = dp_dpp<CTRL>(key); dp_merge(best, key, ob, ok); }
+  CKM_DP_STEP(0xB1)      /* quad_perm [1,0,3,2]: partner xor 1 */
+  CKM_DP_STEP(0x4E)      /* quad_perm [2,3,0,1]: partner xor 2 */
+  CKM_DP_STEP(0x141)     /* row_half_mirror: pairs the two quads of a half row */
+  CKM_DP_STEP(0x140)     /* row_mirror: pairs the two halves of a row */
+#undef CKM_DP_STEP
+  {   // across the rows of 16 lanes: the row leaders' values through readlane (uniform), merged by every lane
+    double b1 = mk(__builtin_amdgcn_readlane(lo(best), 16), __builtin_amdgcn_readlane(hi(best), 16)); int k1 = __builtin_amdgcn_readlane(key, 16);
+    double b2 = mk(__builtin_amdgcn_readlane(lo(best), 32), __builtin_amdgcn_readlane(hi(best), 32)); int k2 = __builtin_amdgcn_readlane(key, 32);
+    double b3 = mk(__builtin_amdgcn_readlane(lo(best), 48), __builtin_amdgcn_readlane(hi(best), 48)); int k3 = __builtin_amdgcn_readlane(key, 48);
+    double b0 = mk(__builtin_amdgcn_readlane(lo(best), 0), __builtin_amdgcn_readlane(hi(best), 0)); int k0 = __builtin_amdgcn_readlane(key, 0);
+    best = b0; key = k0; dp_merge(best, key, b1, k1); dp_merge(best, key, b2, k2); dp_merge(best, key, b3, k3);
+  }
+}
 
 constexpr int DP_NT = 256, DP_NW = DP_NT / 64;
 template <int FLAG>
@@ -404,6 +461,7 @@ __global__ void __launch_bounds__(DP_NT) gene_dp_kernel(Nodes nd, const uint32_t
           for (int c = 0; c < 4; ++c) if ((unsigned short)((unsigned short)ring_tot[c] - a[c]) > DPC) by_class = false;
         }
         if (by_class) {
+          const DpRingSrc<FLAG> R{S, -1, DpRec{0, 0, 0, 0}};
 #pragma unroll
           for (int c1 = 0; c1 < 4; ++c1) {
             if (!dp_pair_possible(c1, c2)) continue;
@@ -411,10 +469,10 @@ __global__ void __launch_bounds__(DP_NT) gene_dp_kernel(Nodes nd, const uint32_t
               const int jl = ring.cls[c1][(a[c1] + t) & (DPC - 1)];                           // low 16 bits of the index
               const int j = i - ((i - jl) & 0xffff);
               double tot; int mark; bool ok;
-              if (c1 == 0) ok = dp_connection_x<DpSrc<FLAG>, true, 1, false>(S, st_wt, j, i, n2, tot, mark);
-              else if (c1 == 1) ok = dp_connection_x<DpSrc<FLAG>, true, 1, true>(S, st_wt, j, i, n2, tot, mark);
-              else if (c1 == 2) ok = dp_connection_x<DpSrc<FLAG>, true, -1, false>(S, st_wt, j, i, n2, tot, mark);
-              else ok = dp_connection_x<DpSrc<FLAG>, true, -1, true>(S, st_wt, j, i, n2, tot, mark);
+              if (c1 == 0) ok = dp_connection_x<DpRingSrc<FLAG>, true, 1, false>(R, st_wt, j, i, n2, tot, mark);
+              else if (c1 == 1) ok = dp_connection_x<DpRingSrc<FLAG>, true, 1, true>(R, st_wt, j, i, n2, tot, mark);
+              else if (c1 == 2) ok = dp_connection_x<DpRingSrc<FLAG>, true, -1, false>(R, st_wt, j, i, n2, tot, mark);
+              else ok = dp_connection_x<DpRingSrc<FLAG>, true, -1, true>(R, st_wt, j, i, n2, tot, mark);
               if (ok) dp_take(tot, j, mark, best, bj, bmark);
             }
           }
@@ -425,11 +483,7 @@ __global__ void __launch_bounds__(DP_NT) gene_dp_kernel(Nodes nd, const uint32_t
           }
         }
         int key = bj < 0 ? -1 : bj * 4 + (bmark + 1);                 // candidate index and overlap mark travel together
-#pragma unroll
-        for (int sft = 32; sft >= 1; sft >>= 1) {
-          const double ob = __shfl_xor(best, sft); const int ok = __shfl_xor(key, sft);
-          if (ok >= 0 && (key < 0 || ob > best || (ob == best && ok > key))) { best = ob; key = ok; }
-        }
+        dp_wave_best(best, key);
         const int par = i & 1;
         if (lane == 0) { red_best[par][wv] = best; red_j[par][wv] = key; }
         __syncthreads();

@@ -99,6 +99,9 @@ struct DpFlat {
   const Nodes &nd; uint32_t first; int flag;
   DpNode node(int rel) const { const uint32_t g = first + (uint32_t)rel; DpNode n; n.ndx = nd.ndx[g]; n.sv = nd.sv[g]; n.strand = nd.strand[g]; n.stop = nd.type[g] == 3; return n; }
   int ndx(int rel) const { return nd.ndx[first + (uint32_t)rel]; }
+  int ndx_any(int rel) const { return ndx(rel); }
+  DpNode node3(int rel) const { return node(rel); }
+  double val3(int rel) const { return val(rel); }
   int star(int rel, int f) const { return nd.star[(size_t)(first + (uint32_t)rel) * 3 + f]; }
   double val(int rel) const { return flag == 0 ? nd.gcb[first + (uint32_t)rel] : nd.csc[first + (uint32_t)rel]; }
   double score(int rel) const { return nd.score[first + (uint32_t)rel]; }
