@@ -101,11 +101,12 @@ __global__ void __launch_bounds__(64) chain_kernel(ChainArgs a) {
   unsigned long long *node_plane = a.node_planes + (uint64_t)((si < a.nbins ? 0 : 2) + (rev ? 1 : 0)) * nwin;
   OrfRecK *rec = reinterpret_cast<OrfRecK *>(a.rec);
   uint32_t tbase = 0;                                               // events of this chain so far
-  auto emit = [&](int ndx_s, int type, int sv_s, int edge, uint32_t t) {
+  // (record slots are taken once per wavefront and step -- one atomic on the shared counter for all the nodes of 64 codons: a counter bumped
+  //  node by node was the kernel's whole duration, 7 M same-address atomics at ~9 ns for a 48-bin call)
+  auto emit = [&](int ndx_s, int type, int sv_s, int edge, uint32_t t, unsigned long long k) {
     const int ndx = rev ? slen - 1 - ndx_s : ndx_s;
     const uint64_t g = base + (uint64_t)ndx;
     atomicOr(&node_plane[g >> 6], 1ull << (g & 63));
-    const unsigned long long k = atomicAdd(a.nrec, 1ull);
     if (k < a.cap) {
       OrfRecK nd; nd.seq = si; nd.type = (uint8_t)type; nd.strand_rev = (uint8_t)rev; nd.edge = (uint8_t)edge; nd.pad = 0;
       nd.ndx = ndx; nd.sv = rev ? slen - 1 - sv_s : sv_s;
@@ -152,18 +153,24 @@ __global__ void __launch_bounds__(64) chain_kernel(ChainArgs a) {
       stop_node = (between != 0ull) || (qlane < 0 && saw);
     }
     const unsigned long long events = starts | __ballot(stop_node);
-    const uint32_t t = tbase + (uint32_t)__popcll(events & below);
-    if (start_node) emit(j, st, my_last, 0, t);
-    if (edge_node) emit(j, 0, my_last, 1, t);
-    if (stop_node) emit(my_last, 3, j, my_last_real ? 0 : 1, t);
-    tbase += (uint32_t)__popcll(events);
+    const uint32_t before = (uint32_t)__popcll(events & below), nev = (uint32_t)__popcll(events);
+    const uint32_t t = tbase + before;
+    unsigned long long slot0 = 0;
+    if (nev) {
+      if (lane == 0) slot0 = atomicAdd(a.nrec, (unsigned long long)nev);
+      slot0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(slot0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(slot0 & 0xffffffffull));
+    }
+    if (start_node) emit(j, st, my_last, 0, t, slot0 + before);
+    if (edge_node) emit(j, 0, my_last, 1, t, slot0 + before);
+    if (stop_node) emit(my_last, 3, j, my_last_real ? 0 : 1, t, slot0 + before);
+    tbase += nev;
     if (stops) {
       const int ql = 63 - __clzll((long long)stops);
       last = jhi - 3 * ql; last_real = true; any_stop = true;
       saw = (starts & (ql == 63 ? 0ull : (~0ull << (ql + 1)))) != 0ull;
     } else saw = saw || starts != 0ull;
   }
-  if (saw) { if (lane == 0) emit(last, 3, frame - 6, last_real ? 0 : 1, tbase); tbase++; }
+  if (saw) { if (lane == 0) emit(last, 3, frame - 6, last_real ? 0 : 1, tbase, atomicAdd(a.nrec, 1ull)); tbase++; }
   if (lane == 0) a.chain_cnt[sc.chain] = tbase;
 }
 void x_chain(GExec &e, const ChainArgs &a) {
