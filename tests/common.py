@@ -121,3 +121,21 @@ def real_format_hmm_file(tag, profs):
             f.write(real_format_hmm_text(profs))
         _CACHE[tag] = path
     return _CACHE[tag]
+
+
+def edge_genomes():
+    """Bins (lists of contig strings) around the gene finder's edges: empty and one-to-three-base contigs, a contig of unknown bases only,
+    lower case and IUPAC codes, hundreds of contigs too short for any node, one base short of / exactly at the 20 kb training limit, runs of
+    49 and 50 unknown bases inside contigs (prodigal's -m masks from 50), a single reading frame shorter than 20 kb, a repeat genome."""
+    from synthdata import synth_genome as sg
+    rng = np.random.default_rng(4)
+    base = [s for _c, s in sg.make_genome(700, n_contigs=3, contig_len=(20000, 30000))]
+    return [base + ["", "A", "AC", "ACG"],
+            ["N" * 500] + base,
+            [base[0].lower(), base[1][:5000] + "RYKMSWBDHVN" * 20 + base[1][5000:], base[2]],
+            ["".join(rng.choice(list("ACGT"), 80)) for _ in range(300)] + base[:1],
+            [base[0][:19999]],
+            [base[0][:20000]],
+            [base[0] + "N" * 49 + base[1], base[2][:100] + "N" * 50 + base[2][100:]],
+            ["ATG" + "GCA" * 400 + "TAA"],
+            [("ATG" + "GCT" * 300 + "TAA" + "CCGGTTAACC") * 30]]

@@ -29,16 +29,21 @@ def _okey(g):
     return (g.contig, g.begin, g.end, g.strand, g.start_type, g.partial_left, g.partial_right, g.rbs_bin, g.mot_len, g.mot_ndx, g.mot_spacer)
 
 
+def _plain(g):
+    return [c[1] if isinstance(c, tuple) else c for c in g]
+
+
 @pytest.mark.parametrize("table", [11, 4])
 def test_emulated_pipeline_equals_the_oracle(table):
-    genomes = _genomes()
-    cols, per_bin = emu.call_genes([[s for _c, s in g] for g in genomes], table)
+    from tests import common
+    genomes = [_plain(g) for g in _genomes()] + common.edge_genomes()
+    cols, per_bin = emu.call_genes(genomes, table)
     by_bin = {}
     for k in range(len(cols["begin"])):
         by_bin.setdefault(int(cols["bin"][k]), []).append(k)
     ngenes, kinds = 0, set()
     for b, g in enumerate(genomes):
-        t, ogenes, oprots = og.find_genes([s for _c, s in g], table)
+        t, ogenes, oprots = og.find_genes(g, table)
         ks = by_bin.get(b, [])
         if t is None:
             assert not per_bin["trained"][b] and not ks

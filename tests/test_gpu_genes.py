@@ -37,7 +37,8 @@ def _okey(g):
 
 @pytest.mark.parametrize("table", [11, 4])
 def test_genes_identical_to_the_oracle(gpu_ctx, table):
-    genomes = _genomes()
+    from tests import common
+    genomes = _genomes() + [[("e%d" % k, s) for k, s in enumerate(g)] for g in common.edge_genomes()]      # + empty / tiny / all-N contigs, IUPAC, mask edges, the 20 kb limit
     cols, per_bin, stats = _lib.call_genes(gpu_ctx, [[s for _c, s in g] for g in genomes], table)
     by_bin = {}
     for k in range(len(cols["begin"])):
@@ -58,7 +59,8 @@ def test_genes_identical_to_the_oracle(gpu_ctx, table):
             assert (got == want).all(), (b, f, np.nonzero(got != want)[0][:3])
         assert [cols["proteins"][k] for k in ks] == oprots, b
         ngenes += len(ks)
-        assert len(ks) >= sum(len(s) for _c, s in g) // 2500                 # the planted genes are found (about one per kb)
+        if b < 22:
+            assert len(ks) >= sum(len(s) for _c, s in g) // 2500             # the planted genes are found (about one per kb)
     assert ngenes > 2000
     assert stats["ms_dp_train"] > 0 and stats["ms_dp_find"] > 0
 
