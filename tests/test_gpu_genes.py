@@ -171,3 +171,32 @@ def test_batched_files_path_warns_refuses_and_matches_single_calls(gpu_ctx, tmp_
     with pytest.raises(ValueError, match="-p meta"):
         geneFinder.call_bin_files([(jobs[0][0], str(od2)), (str(tiny), str(od))])
     assert not os.listdir(str(od)) and not os.listdir(str(od2))
+
+
+def test_find_ends_the_run_when_a_bin_cannot_be_called(gpu_ctx, tmp_path, monkeypatch, caplog):
+    """A bin below the 20 kb the gene finder trains on, among good ones, through MarkerGeneFinder.find: the helper thread's refusal reaches the
+    main thread as logger.error + sys.exit(1) -- the reference's ending for a failed prodigal (checkm/prodigal.py:100-115) -- and no bin's
+    gene files exist afterwards (the refusal comes before any call); the message names what CheckM would have done (-p meta)."""
+    import logging
+    from checkm_amd import markerGeneFinder as mgf
+    from synthdata import synth
+    from tests import common
+    monkeypatch.setenv("CKM_GENE_CALLER", "device")
+    files = []
+    for k, seed in enumerate((601, 602)):
+        f = tmp_path / ("ok_%d.fna" % k)
+        sg.write_fasta(str(f), sg.make_genome(seed, n_contigs=2, contig_len=(25000, 30000)))
+        files.append(str(f))
+    tiny = tmp_path / "tiny.fna"
+    tiny.write_text(">c1\n" + "ACGT" * 1500 + "\n")
+    files.append(str(tiny))
+    hmm = common.hmm_file("mixed", common.mixed_profiles())
+    out = str(tmp_path / "out")
+    with caplog.at_level(logging.ERROR, logger="timestamp"):
+        with pytest.raises(SystemExit) as e:
+            mgf.MarkerGeneFinder(4).find(files, out, "hmmer.analyze.txt", "hmmer.analyze.ali.txt", hmm, False, False, False)
+    assert e.value.code == 1
+    assert any("-p meta" in r.getMessage() and "tiny.fna" in r.getMessage() for r in caplog.records)
+    for b in ("ok_0", "ok_1", "tiny"):
+        assert not os.path.exists(os.path.join(out, "bins", b, "genes.faa"))
+    mgf.release_scan()
