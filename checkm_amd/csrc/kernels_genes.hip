@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include "gene_exec.h"
 
 namespace ckm {
@@ -404,10 +405,10 @@ __device__ __forceinline__ void dp_wave_best(double &best, int &key) {
   }
 }
 
-constexpr int DP_NT = 256, DP_NW = DP_NT / 64;
-template <int FLAG>
+template <int FLAG, int DP_NT>
 __global__ void __launch_bounds__(DP_NT) gene_dp_kernel(Nodes nd, const uint32_t *__restrict__ seq_lo, const uint32_t *__restrict__ seq_n, const uint32_t *__restrict__ seq_bin,
                                                         const double *__restrict__ st_wt_of_bin, uint32_t nseq) {
+  constexpr int DP_NW = DP_NT / 64;
   __shared__ DpRing ring;
   __shared__ double red_best[2][DP_NW]; __shared__ int red_j[2][DP_NW];
   __shared__ uint32_t ring_tot[4];
@@ -529,8 +530,12 @@ __global__ void __launch_bounds__(DP_NT) gene_dp_kernel(Nodes nd, const uint32_t
 }
 void x_dp(GExec &e, const Nodes &nd, const uint32_t *seq_lo, const uint32_t *seq_n, const uint32_t *seq_bin, const double *st_wt, uint32_t nseq, int flag) {
   if (!nseq) return;
-  if (flag == 0) hipLaunchKernelGGL(gene_dp_kernel<0>, dim3(nseq), dim3(DP_NT), 0, e.st, nd, seq_lo, seq_n, seq_bin, st_wt, nseq);
-  else hipLaunchKernelGGL(gene_dp_kernel<1>, dim3(nseq), dim3(DP_NT), 0, e.st, nd, seq_lo, seq_n, seq_bin, st_wt, nseq);
+  // threads per sequence: 256 (four wavefronts share a node's candidates); CKM_GENE_DP_THREADS=128|512 for measurements
+  static const int nt = [] { const char *v = getenv("CKM_GENE_DP_THREADS"); const int n = v ? atoi(v) : 256; return n == 128 || n == 512 ? n : 256; }();
+#define CKM_DP_LAUNCH(F, T) hipLaunchKernelGGL((gene_dp_kernel<F, T>), dim3(nseq), dim3(T), 0, e.st, nd, seq_lo, seq_n, seq_bin, st_wt, nseq)
+  if (flag == 0) { if (nt == 128) CKM_DP_LAUNCH(0, 128); else if (nt == 512) CKM_DP_LAUNCH(0, 512); else CKM_DP_LAUNCH(0, 256); }
+  else { if (nt == 128) CKM_DP_LAUNCH(1, 128); else if (nt == 512) CKM_DP_LAUNCH(1, 512); else CKM_DP_LAUNCH(1, 256); }
+#undef CKM_DP_LAUNCH
 }
 
 }  // namespace gene
