@@ -201,23 +201,37 @@ def call_bin_files(jobs, bNucORFs=False, max_bases=None, logger=None, on_bin_don
     phases = {"read_s": 0.0, "device_calls_s": 0.0, "choose_and_write_s": 0.0, "lanes": lanes, "calls": 0, "wall_s": 0.0}
     call_bin_files.last_phases = phases
     t_wall = time.perf_counter()
-    # ---- read (host threads: file reads and byte operations release the interpreter) ----
+    # ---- sizes first, text later: a sub-batch's files are read when its turn comes (reading 1000 bins up front kept the device idle for 2.5 s).
+    # Small and compressed files are read now -- their base counts decide refusals and warnings, which come BEFORE anything is written; a
+    # plain file of 200 kB or more is taken to hold at least the 100 kb below which CheckM switches to `-p meta` (a file that size with fewer
+    # than 20 kb of bases -- thousands of headers around a few bases each -- is still refused, when its sub-batch is read).
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
-        contigs_of = list(ex.map(lambda j: read_contigs_bytes(j[0]), jobs))
-    totals = [sum(len(s) for _c, s in c) for c in contigs_of]
+    fsize = [os.path.getsize(j[0]) if os.path.exists(j[0]) else 0 for j in jobs]
+    early = [k for k in range(len(jobs)) if fsize[k] < 200000 or jobs[k][0].endswith('.gz')]
+    contigs_of = [None] * len(jobs)
+    if early:
+        with ThreadPoolExecutor(max_workers=min(8, len(early))) as ex:
+            for k, c in zip(early, ex.map(lambda k: read_contigs_bytes(jobs[k][0]), early)):
+                contigs_of[k] = c
+    totals = [sum(len(s) for _c, s in contigs_of[k]) if contigs_of[k] is not None else fsize[k] * 70 // 71 for k in range(len(jobs))]
     phases["read_s"] = time.perf_counter() - t0
-    small = [(jobs[k][0], totals[k]) for k in range(len(jobs)) if totals[k] < MIN_SINGLE_GENOME]
-    if small:
-        raise ValueError("bin %s holds %d bases%s: the device gene caller trains on the bin itself and needs %d (the pre-trained models of "
-                         "`prodigal -p meta`, which CheckM uses below 100 kb, are not built); provide called genes (-g) or a prodigal binary"
-                         % (small[0][0], small[0][1], " (and %d more such bins)" % (len(small) - 1) if len(small) > 1 else "", MIN_SINGLE_GENOME))
-    if logger is not None:
-        for k in range(len(jobs)):
-            if totals[k] < META_RANGE:
-                logger.warning("Bin %s holds %d bases: its genes are called with a model trained on the bin itself (prodigal -p single); "
-                               "CheckM runs `prodigal -p meta` below %d bases (checkm/prodigal.py:80-83), so its gene set may differ."
-                               % (jobs[k][0], totals[k], META_RANGE))
+
+    def refuse_small(ks):
+        small = [(jobs[k][0], totals[k]) for k in ks if totals[k] < MIN_SINGLE_GENOME]
+        if small:
+            raise ValueError("bin %s holds %d bases%s: the device gene caller trains on the bin itself and needs %d (the pre-trained models of "
+                             "`prodigal -p meta`, which CheckM uses below 100 kb, are not built); provide called genes (-g) or a prodigal binary"
+                             % (small[0][0], small[0][1], " (and %d more such bins)" % (len(small) - 1) if len(small) > 1 else "", MIN_SINGLE_GENOME))
+
+    def warn_meta(ks):
+        if logger is not None:
+            for k in ks:
+                if totals[k] < META_RANGE:
+                    logger.warning("Bin %s holds %d bases: its genes are called with a model trained on the bin itself (prodigal -p single); "
+                                   "CheckM runs `prodigal -p meta` below %d bases (checkm/prodigal.py:80-83), so its gene set may differ."
+                                   % (jobs[k][0], totals[k], META_RANGE))
+    refuse_small(early)
+    warn_meta(early)
     # ---- sub-batches ----
     batches, cur, size = [], [], 0
     for k in range(len(jobs)):
@@ -228,6 +242,23 @@ def call_bin_files(jobs, bNucORFs=False, max_bases=None, logger=None, on_bin_don
         batches.append(cur)
     ctx = runtime.get_ctx()
     empty, stats_last = [], {}
+    ahead = threading.Semaphore(max(4, lanes))              # sub-batches read but not yet finished (bounds the text held in memory)
+
+    def prepare(ks):
+        ahead.acquire()
+        t1 = time.perf_counter()
+        late = [k for k in ks if contigs_of[k] is None]
+        for k in late:
+            contigs_of[k] = read_contigs_bytes(jobs[k][0])
+            totals[k] = sum(len(s) for _c, s in contigs_of[k])
+        refuse_small(late)
+        warn_meta(late)
+        batch = _lib.GeneBatch([contigs_of[k] for k in ks])
+        for k in ks:
+            contigs_of[k] = None                                            # (the batch holds the text now)
+        with lock:
+            phases["read_s"] += time.perf_counter() - t1
+        return batch
 
     def finish(ks, batch, calls):
         t1 = time.perf_counter()
@@ -249,10 +280,12 @@ def call_bin_files(jobs, bNucORFs=False, max_bases=None, logger=None, on_bin_don
             if on_bin_done is not None:
                 on_bin_done(binFile)
         c11.close(); c4.close()
+        ahead.release()
         with lock:
             phases["choose_and_write_s"] += time.perf_counter() - t1
 
-    def run_table(ks, batch, calls, table):
+    def run_table(ks, prep, calls, table):
+        batch = prep.result()
         t1 = time.perf_counter()
         call = _lib.GeneCall(ctx, batch, table, False, True)
         with lock:
@@ -263,17 +296,21 @@ def call_bin_files(jobs, bNucORFs=False, max_bases=None, logger=None, on_bin_don
         if both:
             finish(ks, batch, calls)
 
-    with ThreadPoolExecutor(max_workers=lanes) as pool:
+    with ThreadPoolExecutor(max_workers=lanes) as pool, ThreadPoolExecutor(max_workers=4) as readers:
         futs = []
         for ks in batches:
-            batch = _lib.GeneBatch([contigs_of[k] for k in ks])
-            for k in ks:
-                contigs_of[k] = None                                        # (the batch holds the text now)
+            prep = readers.submit(prepare, ks)
             calls = {}
-            for table in (11, 4):
-                futs.append(pool.submit(run_table, ks, batch, calls, table))
+            for table in (4, 11):                                           # (table 4 first: TGA is no stop there, its calls hold more nodes and take longer)
+                futs.append(pool.submit(run_table, ks, prep, calls, table))
+        err = None
         for f in futs:
-            f.result()
+            try:
+                f.result()
+            except BaseException as e:                                      # (a refusal while a sub-batch was read: let the calls in flight end, then raise it)
+                err = err or e
+        if err is not None:
+            raise err
     call_bins.last_stats = stats_last
     phases["wall_s"] = time.perf_counter() - t_wall
     if empty:
