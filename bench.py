@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg5", "genes"], default="cfg3")
+    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg5", "genes", "fasta"], default="cfg3")
     ap.add_argument("--budget-seconds", type=float, default=float(os.environ.get("CKM_BENCH_BUDGET_S", "240")),
                     help="cfg3: wall-clock budget of the timed region; the steps actually run are min(--steps, budget / estimated step)")
     ap.add_argument("--emulate-rank", default=None, help="cfg3: R/W -- run as rank R of W on this one GPU (no collectives)")
@@ -329,6 +329,15 @@ def main():
         out = bench_cfg3(args, env)
     elif args.config == "genes":            # the gene-calling side legs of the cfg3 line alone (not a BASELINE.json configuration)
         out = {"gene_front_end": gene_front_end(), "gene_calling": gene_calling(env.workdir, cpu_bins=0 if args.no_cpu_baseline else 8)} if env.rank == 0 else None
+    elif args.config == "fasta":            # the from_fasta leg of the cfg3 line alone (nucleotide bins -> genes -> tree pass -> analyze pass -> QA table)
+        out = None
+        if env.rank == 0:
+            from synthdata import synth_lineage as sl
+            from checkm_amd.defaultValues import DefaultValues
+            data = os.path.join(env.workdir, "lineage_data")
+            w = sl.World(data)
+            DefaultValues.set_data_root(data)
+            out = {"from_fasta": from_fasta(w, env.workdir, args.from_fasta_bins)}
     elif args.config == "cfg5":
         out = bench_cfg5(args, env)
     else:
