@@ -176,7 +176,7 @@ META_RANGE = 100000            # below this CheckM runs `prodigal -p meta` (chec
 
 def _lanes():
     import os
-    return max(1, min(32, int(os.environ.get("CKM_GENE_LANES", "16"))))
+    return max(1, min(32, int(os.environ.get("CKM_GENE_LANES", "24"))))
 
 
 def call_bin_files(jobs, bNucORFs=False, max_bases=None, logger=None, on_bin_done=None):
