@@ -11,6 +11,7 @@
 //   gene_dp_kernel      the dynamic program (dprog.c: dprog, node.c: score_connection): one workgroup per sequence, the last 2048 nodes in LDS
 //   hexbg_kernel        hexamer histogram of a bin's training sequence in LDS (4096 counters), flushed by atomics
 //   cscore / rbs        per start node: hexamer log-odds sum with the bin's table in LDS; Shine-Dalgarno bins against the bin's 28 weights
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>
@@ -530,9 +531,14 @@ __global__ void __launch_bounds__(DP_NT) gene_dp_kernel(Nodes nd, const uint32_t
 }
 void x_dp(GExec &e, const Nodes &nd, const uint32_t *seq_lo, const uint32_t *seq_n, const uint32_t *seq_bin, const double *st_wt, uint32_t nseq, int flag) {
   if (!nseq) return;
-  // threads per sequence: 256 (four wavefronts share a node's candidates); CKM_GENE_DP_THREADS=128|512 for measurements
+  // threads per sequence: 256 (four wavefronts share a node's candidates); CKM_GENE_DP_THREADS=128|512 for measurements.
+  // CKM_GENE_DP_LDS_PAD_KB asks for that much unused dynamic LDS on top of the ring, which lowers how many sequences the dispatcher may
+  // put on one compute unit (ring + classes ~ 48 KB of the 160 KB: three by default)
   static const int nt = [] { const char *v = getenv("CKM_GENE_DP_THREADS"); const int n = v ? atoi(v) : 256; return n == 128 || n == 512 ? n : 256; }();
-#define CKM_DP_LAUNCH(F, T) hipLaunchKernelGGL((gene_dp_kernel<F, T>), dim3(nseq), dim3(T), 0, e.st, nd, seq_lo, seq_n, seq_bin, st_wt, nseq)
+  static const size_t pad = [] { const char *v = getenv("CKM_GENE_DP_LDS_PAD_KB"); const int n = v ? atoi(v) : 0; return (size_t)(n < 0 ? 0 : n > 100 ? 100 : n) << 10; }();
+#define CKM_DP_LAUNCH(F, T) do { if (pad) { static std::mutex mu; static uint32_t done = 0; int dev = 0; (void)hipGetDevice(&dev); std::lock_guard<std::mutex> lk(mu);   \
+                                   if (!(done & (1u << (dev & 31)))) { (void)hipFuncSetAttribute((const void *)gene_dp_kernel<F, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad); done |= 1u << (dev & 31); } } \
+                                 hipLaunchKernelGGL((gene_dp_kernel<F, T>), dim3(nseq), dim3(T), pad, e.st, nd, seq_lo, seq_n, seq_bin, st_wt, nseq); } while (0)
   if (flag == 0) { if (nt == 128) CKM_DP_LAUNCH(0, 128); else if (nt == 512) CKM_DP_LAUNCH(0, 512); else CKM_DP_LAUNCH(0, 256); }
   else { if (nt == 128) CKM_DP_LAUNCH(1, 128); else if (nt == 512) CKM_DP_LAUNCH(1, 512); else CKM_DP_LAUNCH(1, 256); }
 #undef CKM_DP_LAUNCH
