@@ -408,8 +408,11 @@ __device__ __forceinline__ void dp_wave_best(double &best, int &key) {
 
 template <int FLAG, int DP_NT>
 __global__ void __launch_bounds__(DP_NT) gene_dp_kernel(Nodes nd, const uint32_t *__restrict__ seq_lo, const uint32_t *__restrict__ seq_n, const uint32_t *__restrict__ seq_bin,
-                                                        const double *__restrict__ st_wt_of_bin, uint32_t nseq) {
+                                                        const double *__restrict__ st_wt_of_bin, uint32_t nseq, uint32_t prio) {
   constexpr int DP_NW = DP_NT / 64;
+  // a sequence's nodes are scored strictly one after the other, so these wavefronts are the latency-critical ones of whatever shares their
+  // SIMD (the per-index kernels of other calls, the scan's kernels): let them win the issue arbitration
+  if (prio) __builtin_amdgcn_s_setprio(3);
   __shared__ DpRing ring;
   __shared__ double red_best[2][DP_NW]; __shared__ int red_j[2][DP_NW];
   __shared__ uint32_t ring_tot[4];
@@ -535,10 +538,11 @@ void x_dp(GExec &e, const Nodes &nd, const uint32_t *seq_lo, const uint32_t *seq
   // CKM_GENE_DP_LDS_PAD_KB asks for that much unused dynamic LDS on top of the ring, which lowers how many sequences the dispatcher may
   // put on one compute unit (ring + classes ~ 48 KB of the 160 KB: three by default)
   static const int nt = [] { const char *v = getenv("CKM_GENE_DP_THREADS"); const int n = v ? atoi(v) : 256; return n == 128 || n == 512 ? n : 256; }();
+  static const uint32_t prio = [] { const char *v = getenv("CKM_GENE_DP_PRIO"); return (uint32_t)(v ? atoi(v) != 0 : 0); }();
   static const size_t pad = [] { const char *v = getenv("CKM_GENE_DP_LDS_PAD_KB"); const int n = v ? atoi(v) : 0; return (size_t)(n < 0 ? 0 : n > 100 ? 100 : n) << 10; }();
 #define CKM_DP_LAUNCH(F, T) do { if (pad) { static std::mutex mu; static uint32_t done = 0; int dev = 0; (void)hipGetDevice(&dev); std::lock_guard<std::mutex> lk(mu);   \
                                    if (!(done & (1u << (dev & 31)))) { (void)hipFuncSetAttribute((const void *)gene_dp_kernel<F, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad); done |= 1u << (dev & 31); } } \
-                                 hipLaunchKernelGGL((gene_dp_kernel<F, T>), dim3(nseq), dim3(T), pad, e.st, nd, seq_lo, seq_n, seq_bin, st_wt, nseq); } while (0)
+                                 hipLaunchKernelGGL((gene_dp_kernel<F, T>), dim3(nseq), dim3(T), pad, e.st, nd, seq_lo, seq_n, seq_bin, st_wt, nseq, prio); } while (0)
   if (flag == 0) { if (nt == 128) CKM_DP_LAUNCH(0, 128); else if (nt == 512) CKM_DP_LAUNCH(0, 512); else CKM_DP_LAUNCH(0, 256); }
   else { if (nt == 128) CKM_DP_LAUNCH(1, 128); else if (nt == 512) CKM_DP_LAUNCH(1, 512); else CKM_DP_LAUNCH(1, 256); }
 #undef CKM_DP_LAUNCH
