@@ -244,23 +244,35 @@ def call_bin_files(jobs, bNucORFs=False, max_bases=None, logger=None, on_bin_don
     empty, stats_last = [], {}
     ahead = threading.Semaphore(max(4, lanes))              # sub-batches read but not yet finished (bounds the text held in memory)
 
+    failed = []                                             # the first error; once set, nothing new starts and the permits still come back
+
+    def record(e):
+        with lock:
+            failed.append(e)
+
     def prepare(ks):
         ahead.acquire()
-        t1 = time.perf_counter()
-        late = [k for k in ks if contigs_of[k] is None]
-        for k in late:
-            contigs_of[k] = read_contigs_bytes(jobs[k][0])
-            totals[k] = sum(len(s) for _c, s in contigs_of[k])
-        refuse_small(late)
-        warn_meta(late)
-        batch = _lib.GeneBatch([contigs_of[k] for k in ks])
-        for k in ks:
-            contigs_of[k] = None                                            # (the batch holds the text now)
-        with lock:
-            phases["read_s"] += time.perf_counter() - t1
-        return batch
+        try:
+            if failed:
+                raise RuntimeError("an earlier sub-batch failed")
+            t1 = time.perf_counter()
+            late = [k for k in ks if contigs_of[k] is None]
+            for k in late:
+                contigs_of[k] = read_contigs_bytes(jobs[k][0])
+                totals[k] = sum(len(s) for _c, s in contigs_of[k])
+            refuse_small(late)
+            warn_meta(late)
+            batch = _lib.GeneBatch([contigs_of[k] for k in ks])
+            for k in ks:
+                contigs_of[k] = None                                        # (the batch holds the text now)
+            with lock:
+                phases["read_s"] += time.perf_counter() - t1
+            return batch
+        except BaseException:
+            ahead.release()                                                 # (no call will run for this sub-batch)
+            raise
 
-    def finish(ks, batch, calls):
+    def finish(ks, calls):
         t1 = time.perf_counter()
         c11, c4 = calls[11], calls[4]
         u11, u4, n11, n4 = c11.coding_union(), c4.coding_union(), c11.genes_per_bin(), c4.genes_per_bin()
@@ -279,22 +291,41 @@ def call_bin_files(jobs, bNucORFs=False, max_bases=None, logger=None, on_bin_don
                     empty.append(binFile)
             if on_bin_done is not None:
                 on_bin_done(binFile)
-        c11.close(); c4.close()
-        ahead.release()
         with lock:
             phases["choose_and_write_s"] += time.perf_counter() - t1
 
     def run_table(ks, prep, calls, table):
-        batch = prep.result()
-        t1 = time.perf_counter()
-        call = _lib.GeneCall(ctx, batch, table, False, True)
+        """One (sub-batch, table) call.  Whichever of a sub-batch's two calls ends last -- well or not -- picks the tables and writes the
+        files if both exist, frees both calls and hands the sub-batch's permit back: an error never strands a permit or a device result."""
+        try:
+            batch = prep.result()
+        except BaseException as e:                                          # (prepare gave the permit back itself)
+            record(e)
+            return
+        call = None
+        try:
+            if not failed:
+                t1 = time.perf_counter()
+                call = _lib.GeneCall(ctx, batch, table, False, True)
+                with lock:
+                    phases["device_calls_s"] += time.perf_counter() - t1; phases["calls"] += 1
+                    stats_last.update(call.stats)
+        except BaseException as e:
+            record(e)
         with lock:
-            phases["device_calls_s"] += time.perf_counter() - t1; phases["calls"] += 1
-            stats_last.update(call.stats)
             calls[table] = call
-            both = len(calls) == 2
-        if both:
-            finish(ks, batch, calls)
+            last = len(calls) == 2
+        if last:
+            try:
+                if calls[11] is not None and calls[4] is not None and not failed:
+                    finish(ks, calls)
+            except BaseException as e:
+                record(e)
+            finally:
+                for c in calls.values():
+                    if c is not None:
+                        c.close()
+                ahead.release()
 
     with ThreadPoolExecutor(max_workers=lanes) as pool, ThreadPoolExecutor(max_workers=4) as readers:
         futs = []
@@ -303,14 +334,11 @@ def call_bin_files(jobs, bNucORFs=False, max_bases=None, logger=None, on_bin_don
             calls = {}
             for table in (4, 11):                                           # (table 4 first: TGA is no stop there, its calls hold more nodes and take longer)
                 futs.append(pool.submit(run_table, ks, prep, calls, table))
-        err = None
         for f in futs:
-            try:
-                f.result()
-            except BaseException as e:                                      # (a refusal while a sub-batch was read: let the calls in flight end, then raise it)
-                err = err or e
-        if err is not None:
-            raise err
+            f.result()                                                      # (run_table records errors instead of raising: every permit comes back)
+    if failed:
+        first = [e for e in failed if not (isinstance(e, RuntimeError) and str(e) == "an earlier sub-batch failed")]
+        raise (first or failed)[0]
     call_bins.last_stats = stats_last
     phases["wall_s"] = time.perf_counter() - t_wall
     if empty:
