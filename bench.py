@@ -1140,7 +1140,10 @@ def bench_cfg3(args, env):
                       "from_fasta_seconds_per_1000_bins": ff.get("seconds_per_1000_bins"), "from_fasta_bins": ff.get("bins"),
                       "emulated_8_ranks_max_wall_s": em.get("max_wall_s"), "emulated_8_ranks_projected_speedup_over_1gpu": em.get("projected_speedup_over_1gpu"),
                       "verify_identical": ver.get("identical"), "verify_qa_rows_identical": ver.get("qa_rows_identical"),
-                      "n_gpus_ever_run": 1, "note": "no N > 1 run exists: the 8-rank figures are one GPU emulating each rank in turn, without the collective"}
+                      "n_gpus_this_run": world,
+                      "note": ("the 8-rank figures are one GPU emulating each rank in turn, without the collective; before this round's end no N > 1 run existed"
+                               if world == 1 else "this line IS an N > 1 run: %d ranks, bins sharded by the product, one all_gather of QA rows per step; the one-GPU legs "
+                                                  "(verify, emulation, gene calling, from_fasta, cfg2, cpu_baseline) are not run at N > 1" % world)}
     return out
 
 

@@ -1,5 +1,5 @@
 """The bench line's contract, checked without a GPU: the flags the driver passes parse, and the line recorded by the round's driver-shaped
-run (profiles/r04y_bench1_line.json = `python bench.py --gpus 1 --steps 20 --warmup 5` on one MI355X) carries every field the contract
+run (profiles/r05z_bench_driver_shaped_line.json = `python bench.py --gpus 1 --steps 20 --warmup 5` on one MI355X) carries every field the contract
 names, with figures that agree with each other."""
 import json
 import os
@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINE = os.path.join(ROOT, "profiles", "r04y_bench1_line.json")
+LINE = os.path.join(ROOT, "profiles", "r05z_bench_driver_shaped_line.json")
 
 
 def test_driver_flags_parse():
@@ -46,5 +46,12 @@ def test_recorded_line_meets_the_contract():
     assert d["cascade_fallback_lanes_rank0"] == 0
     e = d["emulated_ranks_of_8"]
     assert len(e["per_rank_wall_s"]) == 8 and e["max_wall_s"] == max(e["per_rank_wall_s"])
+    sm = d["summary"]                                                         # (the figures a reader needs first, early in the line)
+    assert sm["verify_identical"] is True and abs(sm["emulated_8_ranks_max_wall_s"] - e["max_wall_s"]) < 1e-9
+    g = d["gene_calling"]
+    assert g["unit"] == "bins/hour" and abs(sm["gene_calling_bins_per_hour"] - g["value"]) < 1e-6 and g["tables_per_bin"] == 2
+    assert abs(g["value"] - g["bins"] / g["seconds"] * 3600) / g["value"] < 1e-6 and 0 < g["device_fraction_of_wall"] <= 1
+    ff = d["from_fasta"]
+    assert abs(ff["seconds_per_1000_bins"] - ff["seconds"] / ff["bins"] * 1000) < 1e-6 and ff["parts_s"]["total_s"] <= ff["seconds"]
     w = d["workspace_rank0"]
     assert w["high_water_bytes_max"] <= w["allocated_bytes_max"] <= 1.3 * w["high_water_bytes_max"]
