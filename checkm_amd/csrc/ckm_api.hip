@@ -478,9 +478,11 @@ static const float kBgAmino[ckm::K] = {0.0787945f, 0.0151600f, 0.0535222f, 0.066
 // score table of the reported sequences, and per domain the alignment of the envelope's optimal-accuracy path.  Nothing in CheckM
 // reads this file back; it is for the user.  The paths come from the same envelope kernels that produced the row's coordinates
 // (rescore_envelopes with traces), the consensus line from the model's match emissions (upper case above 0.5, HMMER's rule for amino
-// acids), the middle line marks identities by the consensus letter and positive log-odds by '+'.  NOT reproduced: the posterior
-// probability line under each alignment and the `exp` column (expected number of domains) -- both would need the per-residue
-// posteriors on the host -- and hmmsearch's line wrapping (the file is written as with --notextw).
+// acids), the middle line marks identities by the consensus letter and positive log-odds by '+', the PP line under each alignment is the
+// posterior probability of every aligned residue in the state that emits it, in hmmsearch's code (0-9: tenths, rounded; '*': >= 0.95;
+// '.': a deleted node), read from the posterior matrix of the same envelope computation.  NOT reproduced: the `exp` column (expected
+// number of domains, a by-product of the domain definition that the rows do not carry) and hmmsearch's line wrapping (the file is
+// written as with --notextw).
 extern "C" int ckm_hits_write_alignments(ckm_ctx *ctx_, const ckm_hits *h, const ckm_profiles *p, const ckm_seqs *s, uint32_t bin, const char *path) {
   return guarded([&] {
     if (!ctx_ || !h || !p || !s || !path) throw Error(CKM_EINVAL, "NULL argument");
@@ -491,12 +493,12 @@ extern "C" int ckm_hits_write_alignments(ckm_ctx *ctx_, const ckm_hits *h, const
     const uint64_t r0 = h->bin_row_off[bin], r1 = h->bin_row_off[bin + 1];
     std::vector<EnvReq> req;
     for (uint64_t r = r0; r < r1; ++r) req.push_back({h->model[r], h->seq[r], h->env_from[r], h->env_to[r]});
-    std::vector<EnvRes> res; std::vector<std::vector<int32_t>> paths;
-    if (!req.empty()) rescore_envelopes(ctx, p, s, req, res, &paths);
+    std::vector<EnvRes> res; std::vector<std::vector<int32_t>> paths; std::vector<std::vector<float>> pps;
+    if (!req.empty()) rescore_envelopes(ctx, p, s, req, res, &paths, &pps);
     FILE *f = fopen(path, "w");
     if (!f) throw Error(CKM_EIO, std::string("cannot write ") + path);
     fprintf(f, "# hmmsearch-style report written by libcheckm_hip (MI355X scan; options -E 0.1 --domE 0.1 --notextw).\n"
-               "# Alignments: optimal-accuracy path of each domain's envelope; the posterior-probability line and the `exp` column of hmmsearch are not produced.\n");
+               "# Alignments: optimal-accuracy path of each domain's envelope with its posterior-probability (PP) line; the `exp` column of hmmsearch is not produced.\n");
     static const char kSym[] = "ACDEFGHIKLMNPQRSTVWY-BJZOUX*~";
     uint64_t r = r0;
     while (r < r1) {
@@ -540,26 +542,31 @@ extern "C" int ckm_hits_write_alignments(ckm_ctx *ctx_, const ckm_hits *h, const
         fprintf(f, "  == domain %d  score: %.1f bits;  conditional E-value: %.2g\n", h->dom_idx[a], h->dom_score[a], h->c_evalue[a]);
         const std::vector<int32_t> &path = paths[a - r0];
         const uint8_t *dsq = s->dsq.data() + s->off[sq];
-        std::string ml, mid, tl;
+        const std::vector<float> &ppv = pps[a - r0];
+        auto pp_code = [&](int pr) {                           // p7_alidisplay_EncodePostProb (hmmer/src/p7_alidisplay.c)
+          const float pv = (pr >= 0 && (size_t)pr < ppv.size()) ? ppv[(size_t)pr] : 0.f;
+          return (pv + 0.05 >= 1.0) ? '*' : (char)((int)((pv + 0.05) * 10.0) + '0');
+        };
+        std::string ml, mid, tl, ppl;
         if (res[a - r0].ok && (int)path.size() >= hm.M) {
           const int base = h->env_from[a] - 1;                // path entries are 1-based within the envelope
           int prev_res = 0;
           for (int k = h->hmm_from[a]; k <= h->hmm_to[a]; ++k) {
             const int pr = path[(size_t)k - 1];
-            if (pr == 0) { ml += cons[k]; mid += ' '; tl += '-'; continue; }
+            if (pr == 0) { ml += cons[k]; mid += ' '; tl += '-'; ppl += '.'; continue; }
             const int i = base + pr;                           // sequence coordinate, 1-based
-            if (prev_res) for (int j = prev_res + 1; j < i; ++j) { ml += '.'; mid += ' '; tl += (char)tolower(kSym[dsq[j - 1]]); }
+            if (prev_res) for (int j = prev_res + 1; j < i; ++j) { ml += '.'; mid += ' '; tl += (char)tolower(kSym[dsq[j - 1]]); ppl += pp_code(j - base); }
             const int x = dsq[i - 1];
-            ml += cons[k]; tl += kSym[x];
+            ml += cons[k]; tl += kSym[x]; ppl += pp_code(pr);
             if (x < K && toupper(cons[k]) == kSym[x]) mid += cons[k];
             else if (x < K && hm.mat[(size_t)k * K + x] > kBgAmino[x]) mid += '+';
             else mid += ' ';
             prev_res = i;
           }
-        } else ml = mid = tl = "(no alignment: the envelope could not be rescored)";
+        } else ml = mid = tl = ppl = "(no alignment: the envelope could not be rescored)";
         const int w = (int)std::max(hm.name.size(), s->names[sq].size());
-        fprintf(f, "  %*s %7d %s %-7d\n  %*s %7s %s\n  %*s %7d %s %-7d\n\n", w, hm.name.c_str(), h->hmm_from[a], ml.c_str(), h->hmm_to[a], w, "", "", mid.c_str(), w,
-                s->names[sq].c_str(), h->ali_from[a], tl.c_str(), h->ali_to[a]);
+        fprintf(f, "  %*s %7d %s %-7d\n  %*s %7s %s\n  %*s %7d %s %-7d\n  %*s %7s %s PP\n\n", w, hm.name.c_str(), h->hmm_from[a], ml.c_str(), h->hmm_to[a], w, "", "", mid.c_str(), w,
+                s->names[sq].c_str(), h->ali_from[a], tl.c_str(), h->ali_to[a], w, "", "", ppl.c_str());
       }
       r = re;
     }

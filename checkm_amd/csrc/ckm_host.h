@@ -424,7 +424,7 @@ void trace_begin();
 void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, bool do_fwd, bool do_bwd, bool do_oa,
             const std::vector<uint32_t> *subset /* indices into b.work, or null = all */, float *ws_other = nullptr);
 void rescore_envelopes(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<EnvReq> &req, std::vector<EnvRes> &out,
-                       std::vector<std::vector<int32_t>> *paths = nullptr);
+                       std::vector<std::vector<int32_t>> *paths = nullptr, std::vector<std::vector<float>> *pps = nullptr);
 void run_msv_exact(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<PairRec> &pairs, std::vector<float> &usc, std::vector<int32_t> *xJ);
 void run_ensembles(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<RegionReq> &req, std::vector<RegionRes> &out);
 void fill_null2(float *null2);

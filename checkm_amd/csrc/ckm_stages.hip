@@ -181,13 +181,13 @@ void run_fb(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, FbBatch &b, b
 // posterior rows in place over the Forward rows (3 arrays per row; kEnvInplaceDefault = false at compile time restores a matrix of their own, 5 per row)
 bool env_inplace() { return kEnvInplaceDefault; }
 
-size_t env_floats(int Mp, int Ld, uint64_t &xs, uint64_t &aux, uint64_t &mf, uint64_t &mb, uint64_t base) {
+size_t env_floats(int Mp, int Ld, uint64_t &xs, uint64_t &aux, uint64_t &mf, uint64_t &mb, uint64_t base, bool inplace) {
   auto al = [](uint64_t v) { return (v + 31) & ~(uint64_t)31; };
   uint64_t pos = al(base);
   xs = pos; pos = al(pos + (uint64_t)(Ld + 1) * 6);
   aux = pos; pos = al(al(pos + (uint64_t)(Ld + 1) * 3) + (uint64_t)(Ld + 1) * 5);
   mf = pos; pos = al(pos + (uint64_t)(Ld + 1) * 3 * Mp);
-  if (env_inplace()) mb = mf;                                 // posterior rows (M and I) overwrite the Forward rows they come from, OA rows overwrite them in turn
+  if (inplace) mb = mf;                                       // posterior rows (M and I) overwrite the Forward rows they come from, OA rows overwrite them in turn
   else { mb = pos; pos = al(pos + (uint64_t)(Ld + 1) * 2 * Mp); }
   return pos;
 }
@@ -195,9 +195,13 @@ size_t env_floats(int Mp, int Ld, uint64_t &xs, uint64_t &aux, uint64_t &mf, uin
 // Rescore envelopes on the device; returns one Domain per envelope (ok flag via envsc NaN on range error)
 
 void rescore_envelopes(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, const std::vector<EnvReq> &req, std::vector<EnvRes> &out,
-                       std::vector<std::vector<int32_t>> *paths) {
+                       std::vector<std::vector<int32_t>> *paths, std::vector<std::vector<float>> *pps) {
+  // pps (with paths): the posterior probability of every residue on the OA path, [0..Ld] per envelope -- these items keep their posterior rows
+  // in a matrix of their own, so that the rows outlive the OA fill (the scan's items overwrite them in place)
   out.resize(req.size());
+  if (!paths) pps = nullptr;
   if (paths) paths->assign(req.size(), {});
+  if (pps) pps->assign(req.size(), {});
   size_t done = 0;
   const uint64_t budget_floats = ctx->ws_budget / 4;
   while (done < req.size()) {
@@ -206,12 +210,13 @@ void rescore_envelopes(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, co
       const EnvReq &r = req[j];
       const int Mp = p->prof[r.model].fbQ * NL, Ld = r.jenv - r.ienv + 1;
       FbWork w; memset(&w, 0, sizeof(w));
-      const uint64_t end = env_floats(Mp, Ld, w.xs_off, w.aux_off, w.mxf_off, w.mxb_off, pos);
-      const uint64_t need = end + path_total + (paths ? (uint64_t)Mp : 0);
+      const uint64_t end = env_floats(Mp, Ld, w.xs_off, w.aux_off, w.mxf_off, w.mxb_off, pos, pps ? false : env_inplace());
+      const uint64_t path_len = paths ? (uint64_t)Mp + (pps ? (uint64_t)Ld + 1 : 0) : 0;
+      const uint64_t need = end + path_total + path_len;
       if (need > budget_floats && j > done) break;
       if (need > budget_floats) throw Error(CKM_ENOMEM, "one envelope needs more workspace than the device budget allows");
       w.model = r.model; w.seq = r.seq; w.i0 = r.ienv - 1; w.Ld = Ld; w.Lcfg = s->len[r.seq]; w.multihit = 0; w.slot = (uint32_t)(j - done); w.full = 1;
-      if (paths) { w.path_off = path_total + 1; path_total += (uint64_t)Mp; }      // relative for now: the zone starts behind the last item
+      if (paths) { w.path_off = path_total + 1; path_total += path_len; }      // relative for now: the zone starts behind the last item
       b.work.push_back(w); pos = end;
     }
     const uint64_t zone = (pos + 31) & ~(uint64_t)31;          // match-state residues of the OA paths (alignment requests), one copy back
@@ -233,7 +238,14 @@ void rescore_envelopes(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, co
       if (paths) {
         std::vector<int32_t> &pv = (*paths)[done + k];
         pv.assign((size_t)p->hmm[r.model].M, 0);
-        if (o.ok) std::copy(zone_host.begin() + (b.work[k].path_off - 1 - zone), zone_host.begin() + (b.work[k].path_off - 1 - zone) + pv.size(), pv.begin());
+        const size_t at = (size_t)(b.work[k].path_off - 1 - zone);
+        if (o.ok) std::copy(zone_host.begin() + at, zone_host.begin() + at + pv.size(), pv.begin());
+        if (pps) {
+          std::vector<float> &qv = (*pps)[done + k];
+          const int Mp = p->prof[r.model].fbQ * NL, Ld = r.jenv - r.ienv + 1;
+          qv.assign((size_t)Ld + 1, 0.f);
+          if (o.ok) memcpy(qv.data(), zone_host.data() + at + Mp, sizeof(float) * ((size_t)Ld + 1));
+        }
       }
     }
     done = j;

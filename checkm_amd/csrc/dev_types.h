@@ -73,7 +73,8 @@ struct FbWork {              // one Forward/Backward/OA work item (whole sequenc
                                        // full mode -> (Ld+1)*3 [ppN ppJ ppC], then 128B-aligned (Ld+1)*5 [oN oB oE oJ oC]
   uint64_t mxf_off, mxb_off;           // float offsets of the (Ld+1) x 3*Mp matrices (full == 1: q-major planes; full == 2: (Ld+1) x 4*Mp, cell-major float4 {M, I, D, 0})
   uint64_t path_off;                   // int32 offset + 1 of Mp entries: residue (1-based, within the envelope) emitted by each match state of the
-                                       // OA path, 0 = node not matched (alignment requests); 0 = no path wanted
+                                       // OA path, 0 = node not matched (alignment requests); 0 = no path wanted.  When the item's posterior rows have a matrix of
+                                       // their own (mxb_off != mxf_off) Ld + 1 floats follow: the posterior probability of each residue on the path
   uint32_t slot, full;                 // full: 0 parser (specials only), 1 matrix rows M,I, 2 matrix rows M,I,D (trace ensemble)
   uint32_t cand, pass;                 // device-driven cascade: candidate id of a parser item; id of its record in the pass table
 };

@@ -562,7 +562,10 @@ __device__ __forceinline__ void oa_item(const FbWork &w, const DevModel &md, flo
   int fi = 0, fk = 0, li = 0, lk = 0;
   bool done = false;
   int32_t *path = w.path_off ? reinterpret_cast<int32_t *>(ws) + (w.path_off - 1) : nullptr;    // alignment requests: residue of every match state
-  if (path) { for (int c = lane; c < Mp; c += 64) path[c] = 0; __threadfence(); __builtin_amdgcn_wave_barrier(); }
+  // ... followed, when the posterior rows have a matrix of their own (they survive the OA fill), by L + 1 floats: the posterior probability of
+  // every residue on the path in the state that emits it (what hmmsearch prints as the PP line of a domain alignment)
+  float *ppres = (path && w.mxb_off != w.mxf_off) ? reinterpret_cast<float *>(path + Mp) : nullptr;
+  if (path) { for (int c = lane; c < Mp; c += 64) path[c] = 0; if (ppres) for (int c = lane; c <= L; c += 64) ppres[c] = 0.f; __threadfence(); __builtin_amdgcn_wave_barrier(); }
 #define tBM_(c) tr.at(0, (c))
 #define tMM_(c) tr.at(1, (c))
 #define tIM_(c) tr.at(2, (c))
@@ -587,7 +590,7 @@ __device__ __forceinline__ void oa_item(const FbWork &w, const DevModel &md, flo
       if (best >= Mp) done = true; else { k = best; st = 2; li = i; lk = k + 1; }
     } else if (st == 2) {
       fi = i; fk = k + 1;
-      if (path && lane == 0) path[k] = i;
+      if (path && lane == 0) { path[k] = i; if (ppres) ppres[i] = LD2(&pp[(size_t)i * pst + lds_cell<Q>(k)]); }
       float p0 = NEGINF_F, p1 = NEGINF_F, p2 = NEGINF_F, p3 = NEGINF_F;
       if (k > 0) { if (tMM_(k) == 0.f) p0 = LD2(&pr[lds_cell<Q>(k - 1)]); if (tIM_(k) == 0.f) p1 = LD2(&pr[Mp + lds_cell<Q>(k - 1)]); if (tDM_(k) == 0.f) p2 = LD2(&pr[2 * Mp + lds_cell<Q>(k - 1)]); }
       if (tBM_(k) == 0.f) p3 = LD2(&oax[(size_t)(i - 1) * 5 + 1]);
@@ -598,6 +601,7 @@ __device__ __forceinline__ void oa_item(const FbWork &w, const DevModel &md, flo
       --i;
       if (best == 0) { --k; st = 2; } else if (best == 1) { --k; st = 3; } else if (best == 2) { --k; st = 4; } else done = true;
     } else if (st == 3) {
+      if (ppres && lane == 0) ppres[i] = LD2(&pp[(size_t)i * pst + Mp + lds_cell<Q>(k)]);
       const float a = (tMI_(k) == 0.f) ? LD2(&pr[lds_cell<Q>(k)]) : NEGINF_F, b = (tII_(k) == 0.f) ? LD2(&pr[Mp + lds_cell<Q>(k)]) : NEGINF_F;
       --i; st = (a >= b) ? 2 : 3;
     } else {

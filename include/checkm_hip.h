@@ -153,8 +153,9 @@ typedef struct {
 } ckm_search_stats;
 /* Replaces the text `hmmsearch -o <hmmerOut>` leaves when CheckM keeps alignments (bKeepAlignment: checkm/markerGeneFinder.py:138-142
  * drops --noali): per query model the score table and, per reported domain, the alignment of the envelope's optimal-accuracy path
- * (model consensus / identity-or-'+' line / target with inserts in lower case).  The posterior-probability line and the `exp` column
- * of hmmsearch are not produced; CheckM never reads this file back. */
+ * (model consensus / identity-or-'+' line / target with inserts in lower case / PP line: the posterior probability of every aligned
+ * residue in the state that emits it, in hmmsearch's one-character code).  The `exp` column of hmmsearch's score table is not produced;
+ * CheckM never reads this file back. */
 int ckm_hits_write_alignments(ckm_ctx *ctx, const ckm_hits *h, const ckm_profiles *p, const ckm_seqs *s, uint32_t bin, const char *path);
 
 int ckm_last_search_stats(const ckm_ctx *ctx, ckm_search_stats *out);

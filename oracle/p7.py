@@ -62,6 +62,7 @@ def lib():
         L.p7o_envelope.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                                    C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
         L.p7o_align.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.p7o_envelope_alignment.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.p7o_set_ensemble_stream.argtypes = [C.c_int]
         L.p7o_ensemble_seed.restype = C.c_uint32
         L.p7o_ensemble_seed.argtypes = [C.c_int]
@@ -120,6 +121,15 @@ class HmmSet(object):
         path = np.zeros(self.M(i), dtype=np.int32)
         rc = lib().p7o_align(self.model(i), d.ctypes.data, len(d), path.ctypes.data)
         return rc, path
+
+    def envelope_alignment(self, i, dsq, ienv, jenv):
+        """The domain alignment hmmsearch prints: (rc, path[M] -- envelope-local residue of each match state, 0 = none --, pp[Ld + 1] --
+        posterior probability of each residue on the path in its emitting state)."""
+        d = np.ascontiguousarray(dsq, dtype=np.uint8)
+        path = np.zeros(self.M(i), dtype=np.int32)
+        pp = np.zeros(jenv - ienv + 2, dtype=np.float32)
+        rc = lib().p7o_envelope_alignment(self.model(i), d.ctypes.data, len(d), ienv, jenv, path.ctypes.data, pp.ctypes.data)
+        return rc, path, pp
 
     def region_ensemble(self, i, dsq, ireg, jreg, cap=64):
         """200-trace ensemble of region ireg..jreg: (rc, n2sum[Lr], segs[200][cap][4], nseg[200], envelopes[n][4])."""

@@ -771,6 +771,8 @@ static void null2_fill_degenerate(float *null2)
 }
 
 static int32_t *g_oa_path = NULL;    /* when set: receives, per model node (0-based), the envelope-local residue its match state emits (0 = none) */
+static float *g_oa_pp = NULL;        /* when set: receives, per envelope-local residue on the path, its posterior probability in the emitting state (M or I):
+                                      * what hmmsearch's OA trace carries as tr->pp and prints as the PP line (p7_OATrace, p7_alidisplay_Create) */
 
 static int rescore_envelope(const PROF *p, const uint8_t *dsq_full, int L_full, int ienv, int jenv,
                             float *n2sc /* per-position, 1-based, may be NULL */, int null2_done, DOMAIN *dom,
@@ -871,6 +873,7 @@ static int rescore_envelope(const PROF *p, const uint8_t *dsq_full, int L_full, 
       case 2: {
         firstM_i = i; firstM_k = k+1;
         if (g_oa_path) g_oa_path[k] = i;
+        if (g_oa_pp) g_oa_pp[i] = bmx[rowsz*i + k];
         float path[4] = { NEGINF, NEGINF, NEGINF, NEGINF };
         if (k > 0) { if (p->fMM[k] > 0.f) path[0] = pr[k-1]; if (p->fIM[k] > 0.f) path[1] = pr[Mp+k-1]; if (p->fDM[k] > 0.f) path[2] = pr[2*Mp+k-1]; }
         if (p->fBM[k] > 0.f) path[3] = oB[i-1];
@@ -878,7 +881,7 @@ static int rescore_envelope(const PROF *p, const uint8_t *dsq_full, int L_full, 
         i--;
         if (best == 0) { k--; st = 2; } else if (best == 1) { k--; st = 3; } else if (best == 2) { k--; st = 4; } else done = 1;
       } break;
-      case 3: { float a = (p->fMI[k] > 0.f) ? pr[k] : NEGINF, b = (p->fII[k] > 0.f) ? pr[Mp+k] : NEGINF; i--; st = (a >= b) ? 2 : 3; } break;
+      case 3: { if (g_oa_pp) g_oa_pp[i] = bmx[rowsz*i + Mp + k]; float a = (p->fMI[k] > 0.f) ? pr[k] : NEGINF, b = (p->fII[k] > 0.f) ? pr[Mp+k] : NEGINF; i--; st = (a >= b) ? 2 : 3; } break;
       case 4: { float a = (p->fMD[k-1] > 0.f) ? cr[k-1] : NEGINF, b = (p->fDD[k-1] > 0.f) ? cr[2*Mp+k-1] : NEGINF; k--; st = (a >= b) ? 2 : 4; } break;
       }
     }
@@ -898,6 +901,22 @@ int p7o_envelope(const P7O_HMM *hmm, const uint8_t *dsq, int L_full, int ienv, i
   *envsc = d.envsc; *oasc = d.oasc; coords[0] = d.hmm_from; coords[1] = d.hmm_to; coords[2] = d.ali_from; coords[3] = d.ali_to;
   if (nscale) *nscale = ns;
   prof_free(p); return rc;
+}
+
+/* The alignment hmmsearch prints for a domain (hmmsearch without --noali: checkm/markerGeneFinder.py:138-142 under bKeepAlignment): the
+ * optimal-accuracy path of the envelope ienv..jenv and the posterior probability of every residue on it.  path[k] (k = 0..M-1) = residue
+ * (1-based within the envelope) emitted by match state k+1, 0 = none; pp[i] (i = 1..Ld, pp[0] unused) = posterior probability of residue i
+ * in the state that emits it on the path, 0 off the path.  Not thread-safe (file-scope hooks into the traceback). */
+int p7o_envelope_alignment(const P7O_HMM *hmm, const uint8_t *dsq, int L_full, int ienv, int jenv, int32_t *path, float *pp)
+{
+  PROF *p = prof_create(hmm); DOMAIN d;
+  memset(path, 0, sizeof(int32_t) * hmm->M);
+  memset(pp, 0, sizeof(float) * (size_t)(jenv - ienv + 2));
+  g_oa_path = path; g_oa_pp = pp;
+  int rc = rescore_envelope(p, dsq, L_full, ienv, jenv, NULL, 0, &d, NULL, NULL, NULL);
+  g_oa_path = NULL; g_oa_pp = NULL;
+  prof_free(p);
+  return rc;
 }
 
 /* hmmalign's per-sequence computation (checkm/hmmer.py:76-95 runs `hmmalign --outformat Pfam`): unihit local profile with the

@@ -109,6 +109,7 @@ int p7o_envelope(const P7O_HMM *hmm, const uint8_t *dsq, int L_full, int ienv, i
 /* hmmalign restated: optimal-accuracy alignment of the whole sequence to the unihit local profile; path[M] = residue (1-based)
  * emitted by each match state, 0 = none */
 int p7o_align(const P7O_HMM *hmm, const uint8_t *dsq, int L, int32_t *path);
+int p7o_envelope_alignment(const P7O_HMM *hmm, const uint8_t *dsq, int L_full, int ienv, int jenv, int32_t *path, float *pp);
 
 /* multi-domain regions: 200-trace ensemble of region ireg..jreg (1-based, inclusive) of a sequence of length L.
  * n2sum[Lr]: per position, sum over traces of the null2 odds ratio.  seg_all[200*cap] / nseg_all[200]: each trace's

@@ -251,13 +251,47 @@ def test_keep_alignment_writes_the_domain_alignments(gpu_ctx, tmp_path):
     seqs = {r[0]: r[2] for r in recs}
     blocks = []                                            # (query, target, model line, target line, coordinates)
     query = None
+    query_at = {}
     for i, line in enumerate(text):
         if line.startswith("Query:"):
             query = line.split()[1]
+        query_at[i] = query
         if line.startswith("  == domain"):
             ml, tl = text[i + 1].split(), text[i + 3].split()
             blocks.append((query, tl[0], ml[2], tl[2], int(ml[1]), int(ml[3]), int(tl[1]), int(tl[3])))
     assert len(blocks) == len(rows) and len(rows) >= 12
+    # the PP line of every block against the oracle: posterior probability of each aligned residue in its emitting state, hmmsearch's code
+    hs = p7.HmmSet(hmm)
+    index_of = {hs.name(m): m for m in range(hs.n)}
+    pp_lines = {}
+    for i, line in enumerate(text):
+        if line.startswith("  == domain"):
+            f = text[i + 4].split()
+            assert len(f) == 2 and f[1] == "PP", text[i + 4]
+            ml, tl = text[i + 1].split(), text[i + 3].split()
+            pp_lines[(query_at[i], tl[0], int(ml[1]), int(ml[3]), int(tl[1]), int(tl[3]))] = f[0]
+
+    def code(v):
+        v = float(v) + 0.05
+        return '*' if v >= 1.0 else chr(int(v * 10.0) + 48)
+    stars = digits = dots = 0
+    for h in rows:
+        rc, path, pp = hs.envelope_alignment(index_of[h.query_name], p7.digitize(seqs[h.target_name]), h.env_from, h.env_to)
+        assert rc == 0
+        want, prev = "", 0
+        for k in range(h.hmm_from, h.hmm_to + 1):
+            pr = int(path[k - 1])
+            if pr == 0:
+                want += "."
+                continue
+            if prev:
+                want += "".join(code(pp[j]) for j in range(prev + 1, pr))
+            want += code(pp[pr])
+            prev = pr
+        got = pp_lines[(h.query_name, h.target_name, h.hmm_from, h.hmm_to, h.ali_from, h.ali_to)]
+        assert got == want, (h.query_name, h.target_name)
+        stars += want.count("*"); dots += want.count("."); digits += sum(c.isdigit() for c in want)
+    assert stars > 100 and digits > 20                      # (confident cores and uncertain edges both occur)
     seen = set()
     for h in rows:
         hit = [b for b in blocks if b[0] == h.query_name and b[1] == h.target_name and (b[4], b[5], b[6], b[7]) == (h.hmm_from, h.hmm_to, h.ali_from, h.ali_to)]

@@ -577,6 +577,40 @@ def test_alignment_to_the_model_is_the_optimal_accuracy_path(tiny):
             assert rc == 0 and [int(v) for v in path] == want, (m, x)
 
 
+def test_posterior_line_of_a_domain_alignment(tiny):
+    """What hmmsearch prints under a domain alignment (the PP line): the posterior probability of every residue on the optimal-accuracy
+    path in the state that emits it (p7o_envelope_alignment).  By enumeration: the share of the path weights in which that state
+    emits that residue."""
+    hs, models, rng = tiny
+    checked = inserts = 0
+    for m, (M, mat, t) in enumerate(models):
+        for L in (3, 4, 5, 6):
+            for trial in range(3):
+                x = [int(v) for v in rng.integers(0, 20, size=L)]
+                for k in range(1, min(M, L - 1) + 1):
+                    if trial != 2 or k != 2:             # (third trial: a foreign residue in the middle, an insert or a weak match)
+                        x[k] = int(np.argmax(mat[k]))
+                ppM, ppI, _ppX, best = _decode(M, mat, t, x, L)
+                rc, path, pp = hs.envelope_alignment(m, np.array(x, dtype=np.uint8), 1, L)
+                rc2, path2 = hs.align(m, np.array(x, dtype=np.uint8))
+                assert rc == 0 and rc2 == 0 and [int(v) for v in path] == [int(v) for v in path2]
+                matched = {int(i): k + 1 for k, i in enumerate(path) if i}
+                assert matched == {i + 1: k for i, k in best[5]}
+                lo, hi = min(matched), max(matched)
+                node = 0
+                for i in range(1, L + 1):
+                    if i in matched:
+                        node = matched[i]
+                        assert float(pp[i]) == pytest.approx(ppM[i - 1][node], rel=2e-4, abs=1e-6), (m, x, i)
+                        checked += 1
+                    elif lo < i < hi:                    # between two matched residues and not matched itself: emitted by the insert state of the node before
+                        assert float(pp[i]) == pytest.approx(ppI[i - 1][node], rel=2e-4, abs=1e-6), (m, x, i)
+                        inserts += 1
+                    else:
+                        assert float(pp[i]) == 0.0       # flanks: not on the path
+    assert checked > 100
+
+
 def _cluster(segs, nseg, nsamples=200):
     """Sampled segments -> envelopes, restated from the description of HMMER's ensemble clustering (single linkage; two segments link
     when they overlap by >= 0.8 of the shorter one in the sequence AND in the model and their diagonals differ by <= 4; a cluster
