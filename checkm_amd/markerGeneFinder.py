@@ -360,16 +360,24 @@ class MarkerGeneFinder(object):
                 pairs += max(1, sizes[i] // 320) * pos_cache[k][0]; cells += pos_cache[k][1]
             need.append((pairs, cells))
         for j, (c, _prof) in enumerate(lanes):
-            mine = need[j::len(lanes)]             # the largest batch this lane will meet (the first ones are small: plan_batches)
+            mine = need[j:]                        # the largest batch this lane may meet: its first is batch j, after that whichever comes next
             if mine:
                 try:
                     c.reserve(max(x[0] for x in mine), max(x[1] for x in mine))
                 except _lib.CkmError:
                     pass
 
-        def scan(k):
+        # A lane takes the next batch when it is free (not every other one: with batches of unequal cost one lane used to run the last two
+        # alone, profiles/r05F_emulated_rank_trace.txt).  The return value is built on this thread once every lane is inside its first
+        # search: built at once, its 0.06 s of Python held the interpreter lock while the lanes tried to hand their first batches to the
+        # library, and the device waited (60-70 ms at the start of each pass of that trace).
+        import itertools
+        next_batch = itertools.count()
+        started = [threading.Event() for _ in lanes]
+
+        def scan(k, lane):
             import time as _t
-            c, prof = lanes[k % len(lanes)]
+            c, prof = lanes[lane]
             batch = batches[k]
             for i in batch:
                 self._wait_genes(read_from[i])                                    # (genes of this batch's bins still being called: find() overlaps the two)
@@ -377,6 +385,7 @@ class MarkerGeneFinder(object):
             seqs = _lib.Seqs.from_fasta(c, [read_from[i] for i in batch])         # read, digitized and packed by the library
             t1 = _t.perf_counter()
             bm = None if not models_of else [models_of[binIds[i]] if models_of[binIds[i]] is not None else list(range(profiles.n)) for i in batch]
+            started[lane].set()
             hits = _lib.search(c, prof, seqs, bm, 0.1, 0.1)                       # -E 0.1 --domE 0.1, markerGeneFinder.py:141
             t2 = _t.perf_counter()
             st = c.stats()
@@ -392,20 +401,26 @@ class MarkerGeneFinder(object):
             part = dict(seqs=seqs, hits=hits, bins=[binIds[i] for i in batch], profiles=prof)
             if os.environ.get("CKM_TRACE") == "2":      # (same clock as the library's trace points)
                 m0 = _t.monotonic() - _t.perf_counter()
-                sys.stderr.write("find-trace lane %d batch %d ingest %.3f search %.3f .. %.3f\n" % (k % len(lanes), k, 1e3 * (m0 + t0), 1e3 * (m0 + t1), 1e3 * (m0 + t2)))
+                sys.stderr.write("find-trace lane %d batch %d ingest %.3f search %.3f .. %.3f\n" % (lane, k, 1e3 * (m0 + t0), 1e3 * (m0 + t1), 1e3 * (m0 + t2)))
             for b, i in enumerate(batch):
                 hits.write_domtblout(prof, seqs, b, os.path.join(outDir, 'bins', binIds[i], tableOut))
                 if bKeepAlignment:            # hmmsearch's -o text with the domain alignments (markerGeneFinder.py:138-142 drops --noali)
                     hits.write_alignments(c, prof, seqs, b, os.path.join(outDir, 'bins', binIds[i], hmmerOut))
             parts[k] = part
             if os.environ.get("CKM_TRACE") == "2":
-                sys.stderr.write("find-trace lane %d batch %d written %.3f\n" % (k % len(lanes), k, 1e3 * _t.monotonic()))
+                sys.stderr.write("find-trace lane %d batch %d written %.3f\n" % (lane, k, 1e3 * _t.monotonic()))
             with tot_lock:
                 totals["write_s"] = totals.get("write_s", 0.0) + (_t.perf_counter() - t2)
 
         def lane_run(j):
-            for k in range(j, len(batches), len(lanes)):
-                scan(k)
+            try:
+                while True:
+                    k = next(next_batch)
+                    if k >= len(batches):
+                        break
+                    scan(k, j)
+            finally:
+                started[j].set()
         out = None
         try:
             if len(lanes) == 1:
@@ -413,6 +428,8 @@ class MarkerGeneFinder(object):
             else:
                 with ThreadPoolExecutor(max_workers=len(lanes)) as ex:
                     futs = [ex.submit(lane_run, j) for j in range(len(lanes))]
+                    for ev in started:
+                        ev.wait(30.0)
                     out = models_for_bins(heads, allIds, models_of)          # (the return value is built while the lanes scan: 0.06 s per pass of a 1000-bin run)
                     for f in futs:
                         f.result()

@@ -77,33 +77,37 @@ class PFAM(object):
                     kept[h.query_accession].append(h)
         return kept
 
+    def _clan_maps(self):
+        """(family -> clan, clan -> families) of the clan file, read ONCE per PFAM object: the reference reads the file twice per call of
+        genesInSameClan (pfam.py:149-168), i.e. per distinct marker set of a run -- 0.1 s of every analyze pass's start here."""
+        maps = getattr(self, '_maps', None)
+        if maps is None:
+            to_clan, members = {}, defaultdict(set)
+            acc = None
+            with open(self.pfamClanFile) as f:
+                for line in f:
+                    if '#=GF AC' in line:
+                        acc = line.split()[2].strip()
+                    elif '#=GF CL' in line:
+                        c = line.split()[2].strip()
+                        to_clan[acc] = c
+                        members[c].add(acc)
+            maps = self._maps = (to_clan, members)
+        return maps
+
     def pfamIdToClanId(self):
-        d = {}
-        acc = None
-        with open(self.pfamClanFile) as f:
-            for line in f:
-                if '#=GF AC' in line:
-                    acc = line.split()[2].strip()
-                elif '#=GF CL' in line:
-                    d[acc] = line.split()[2].strip()
-        return d
+        return dict(self._clan_maps()[0])
 
     def genesInClan(self):
         d = defaultdict(set)
-        acc = None
-        with open(self.pfamClanFile) as f:
-            for line in f:
-                if '#=GF AC' in line:
-                    acc = line.split()[2].strip()
-                elif '#=GF CL' in line:
-                    d[line.split()[2].strip()].add(acc)
+        for c, fams in self._clan_maps()[1].items():
+            d[c] = set(fams)
         return d
 
     def genesInSameClan(self, genes):
         """All other families of the clans the given genes span (pfam.py:149-168)."""
-        to_clan = self.pfamIdToClanId()
+        to_clan, members = self._clan_maps()
         clans = set(to_clan[g] for g in genes if g in to_clan)
-        members = self.genesInClan()
         out = set()
         for c in clans:
             out.update(members[c])
