@@ -152,7 +152,6 @@ def hmmer_leg(hmm_path, bins, threads, workdir):
         list(ex.map(run, faa))
     dt = time.perf_counter() - t0
     residues = sum(sum(len(r[2]) for r in recs) for recs in sample)
-    from synthdata import synth as _s  # noqa: F401
     nmodels = sum(1 for line in open(hmm_path) if line.startswith("NAME"))
     ver = subprocess.run([exe, "-h"], stdout=subprocess.PIPE).stdout.decode(errors="replace").split("\n")[1:2]
     return {"value": residues * nmodels / dt, "unit": "residue*HMM/s", "cores": min(threads, len(sample)), "kind": "reference",

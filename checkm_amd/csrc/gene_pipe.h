@@ -972,7 +972,6 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
   // =====================================================  gene finding, contig by contig  =====================================================
   if (NT[1]) {
     const Nodes fn = FS.dev();
-    const uint32_t *ch = CH;
     // tables of the trained bins
     std::vector<double> h_dc((size_t)nbins * 4096, 0.0), h_rw((size_t)nbins * 28, 0.0), h_tw((size_t)nbins * 3, 0.0), h_ups((size_t)nbins * 128, 0.0), h_nm(nbins, 0.0);
     std::vector<uint8_t> h_sd(nbins, 0); std::vector<int32_t> slot_of(nbins, -1); std::vector<uint32_t> ns_bins;

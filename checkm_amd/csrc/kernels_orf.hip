@@ -26,7 +26,7 @@ constexpr int ORF_MIN_GENE = 90, ORF_MIN_EDGE_GENE = 60;
 //   plane 0  forward codon at i is a stop of table 11 (TAA TAG TGA)     plane 1  ... of table 4 (TAA TAG)
 //   plane 2 / 3  low / high bit of the forward start type (1 ATG, 2 GTG, 3 TTG; 0 none)
 //   plane 4-7  the same for the reverse-strand codon whose first base is the complement of base i (its bases are i, i-1, i-2)
-constexpr int ORF_PLANES = 8;
+// (8 planes of n / 64 words each)
 
 __device__ __forceinline__ uint32_t bytes_equal(uint32_t w, uint32_t letter4) {     // 0x80 in every byte of w that equals the letter
   const uint32_t z = w ^ letter4;
@@ -171,7 +171,7 @@ void launch_orf_fill(hipStream_t stream, uint8_t *text, uint64_t n, uint32_t see
   hipLaunchKernelGGL(orf_fill_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, text, n, seed);
 }
 
-// text: n bytes (a multiple of 64) with >= 64 readable bytes before and after; planes: ORF_PLANES x (n / 64) 64-bit words
+// text: n bytes (a multiple of 64) with >= 64 readable bytes before and after; planes: 8 x (n / 64) 64-bit words
 void launch_orf_flags(hipStream_t stream, const uint8_t *text, uint8_t *planes, uint64_t n) {
   const uint64_t nwin = n / 64;
   if (nwin) hipLaunchKernelGGL(orf_flags_kernel, dim3((unsigned)((nwin + 255) / 256)), dim3(256), 0, stream, text, reinterpret_cast<unsigned long long *>(planes), nwin);

@@ -179,7 +179,6 @@ def test_find_ends_the_run_when_a_bin_cannot_be_called(gpu_ctx, tmp_path, monkey
     gene files exist afterwards (the refusal comes before any call); the message names what CheckM would have done (-p meta)."""
     import logging
     from checkm_amd import markerGeneFinder as mgf
-    from synthdata import synth
     from tests import common
     monkeypatch.setenv("CKM_GENE_CALLER", "device")
     files = []

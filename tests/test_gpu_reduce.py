@@ -5,7 +5,6 @@ import ast
 import json
 import os
 
-import numpy as np
 import pytest
 
 from checkm_amd import _lib, qa as cqa

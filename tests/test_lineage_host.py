@@ -1,8 +1,6 @@
 """Host logic of the lineage_wf-shaped path that needs no device: the synthetic lineage world parses through the marker-file mirrors
 (checkm/markerSets.py:428-522), the model subset of a bin is its chain's marker genes plus the clan expansion (markerSets.py:443-457)
 matched by NAME or ACC as `hmmfetch -f` matches (markerSets.py:326-343), and find()'s batch plan / rank shards."""
-import os
-
 from checkm_amd import dist as cdist, markerGeneFinder as mgf
 from synthdata import synth_lineage as sl
 from checkm_amd.defaultValues import DefaultValues
