@@ -272,19 +272,14 @@ static void build_lentab(ckm_seqs *s) {
   }
 }
 
+static SeqColumns seq_columns(ckm_seqs *s) {
+  return SeqColumns{&s->bin_off, &s->seq_bin, &s->order, &s->order_off, &s->len, &s->off, &s->bin_res, &s->dsq, &s->names, &s->descs, &s->total_res, &s->maxL};
+}
+
 // shared tail of the two constructors: s->len / s->off / s->dsq / names are filled; build the order, tables and upload
 static void finish_seqs(ckm_seqs *s) {
-  const uint32_t nbins = s->nbins, nseq = s->nseq;
-  s->seq_bin.resize(nseq);
-  for (uint32_t b = 0; b < nbins; ++b) for (uint32_t i = s->bin_off[b]; i < s->bin_off[b + 1]; ++i) s->seq_bin[i] = b;
-  s->order_off.assign(nbins + 1, 0); s->bin_res.assign(nbins, 0);
-  for (uint32_t b = 0; b < nbins; ++b) {
-    s->order_off[b] = (uint32_t)s->order.size();
-    const size_t first = s->order.size();
-    for (uint32_t i = s->bin_off[b]; i < s->bin_off[b + 1]; ++i) if (s->len[i] > 0) { s->order.push_back(i); s->bin_res[b] += (uint64_t)s->len[i]; }
-    std::stable_sort(s->order.begin() + first, s->order.end(), [&](uint32_t x, uint32_t y) { return s->len[x] > s->len[y]; });
-  }
-  s->order_off[nbins] = (uint32_t)s->order.size();
+  const uint32_t nseq = s->nseq;
+  build_seq_order(ingest_threads(), seq_columns(s));
   build_lentab(s);
   // uploads on one of the context's high-priority streams: a plain hipMemcpy travels on the null stream, whose hardware queue it shares
   // with whatever streams were mapped onto it -- behind another context's SSV backlog the 40 ms ingest of a batch took 420 ms
@@ -355,26 +350,11 @@ extern "C" int ckm_seqs_from_fasta(ckm_ctx *ctx, const char *const *paths, uint3
     std::unique_ptr<ckm_seqs> s(new ckm_seqs());
     s->ctx = ctx; s->nbins = nbins; s->uid = g_uid++;
     s->bin_off.assign(nbins + 1, 0);
-    // the files are read and digitised on a few threads (fasta_ingest.cpp), then laid end to end
-    std::vector<FastaBin> bins = read_fasta_bins(paths, nbins, (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+    // the files are read and digitised a file per thread, then laid end to end a bin per thread (fasta_ingest.cpp)
+    std::vector<FastaBin> bins = read_fasta_bins(paths, nbins, ingest_threads());
     trace_pt(&ctx->w[0], "seqs: files read");
-    uint64_t pos = 0; size_t nrec = 0;
-    for (auto &fb : bins) { if (fb.err_code) throw Error(fb.err_code, fb.err); pos += fb.dsq.size(); nrec += fb.names.size(); }
-    s->dsq.reserve(pos + 16); s->names.reserve(nrec); s->descs.reserve(nrec); s->len.reserve(nrec); s->off.reserve(nrec);
-    pos = 0;
-    for (uint32_t b = 0; b < nbins; ++b) {
-      FastaBin &fb = bins[b];
-      for (size_t r = 0; r < fb.names.size(); ++r) {
-        s->names.push_back(std::move(fb.names[r])); s->descs.push_back(std::move(fb.descs[r]));
-        s->len.push_back(fb.len[r]); s->off.push_back(pos + fb.off[r]);
-      }
-      s->dsq.insert(s->dsq.end(), fb.dsq.begin(), fb.dsq.end());
-      pos += fb.dsq.size(); s->total_res += fb.total_res; s->maxL = std::max(s->maxL, fb.maxL);
-      s->bin_off[b + 1] = (uint32_t)s->names.size();
-      FastaBin().dsq.swap(fb.dsq);                   // release the per-file copy as soon as it is merged
-    }
+    merge_fasta_bins(bins, ingest_threads(), seq_columns(s.get()));
     s->nseq = (uint32_t)s->names.size();
-    s->dsq.resize(pos + 16, (uint8_t)PADCODE);
     finish_seqs(s.get());
     *out = s.release();
   });

@@ -92,6 +92,18 @@ struct FastaBin {
   int err_code = 0; std::string err;      // err_code != 0: the file could not be read
 };
 std::vector<FastaBin> read_fasta_bins(const char *const *paths, uint32_t nbins, int nthreads);
+// The host columns of a batch of sequences (ckm_host.h: ckm_seqs), by address, so that fasta_ingest.cpp stays free of device types
+struct SeqColumns {
+  std::vector<uint32_t> *bin_off, *seq_bin, *order, *order_off;
+  std::vector<int32_t> *len;
+  std::vector<uint64_t> *off, *bin_res;
+  std::vector<uint8_t> *dsq;
+  std::vector<std::string> *names, *descs;
+  uint64_t *total_res; int *maxL;
+};
+void merge_fasta_bins(std::vector<FastaBin> &bins, int nthreads, const SeqColumns &o);    // fills bin_off, len, off, dsq, names, descs; adds to total_res / maxL
+void build_seq_order(int nthreads, const SeqColumns &o);                                  // from bin_off + len: seq_bin, order, order_off, bin_res
+int ingest_threads();                                                                     // host threads one ingest may use
 
 // statistics
 double gumbel_surv(double x, double mu, double lambda);

@@ -56,6 +56,41 @@ def test_domtblout_reader_survives_damaged_tables(harness):
     assert got["accepted"] >= 1 and got["rejected"] >= 50
 
 
+def test_parallel_merge_of_a_batch_equals_the_serial_loop(harness, tmp_path):
+    """The files of a batch are laid end to end and ordered by length a bin per thread (fasta_ingest.cpp: merge_fasta_bins, build_seq_order);
+    on 1 and on 7 threads the columns must equal the serial loop they replaced, under ASan/UBSan -- an empty file, records without residues
+    and an unreadable file among them."""
+    exe, d = harness
+    profs = synth.small_profiles(21, 6, 40, 120)
+    recs = synth.make_bin(profs, 99, n_orfs=400, dup_frac=0.3)
+    path = str(tmp_path / "valid.faa")
+    synth.write_fasta(path, recs)
+    got = _run(exe, "merge", path, tmp_path, 23, 5)
+    assert got["mode"] == "merge" and got["files"] == 23 and got["nseq"] > 3000 and got["empty_records"] >= 2
+
+
+def test_parallel_merge_under_thread_sanitizer(tmp_path):
+    """The same merge under TSan: the threads write disjoint stretches of shared columns."""
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("g++ not available")
+    exe = str(tmp_path / "fuzz_tsan")
+    cmd = [gxx, "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", "-I", CSRC, os.path.join(ROOT, "tests", "native", "fuzz_host.cpp"),
+           os.path.join(CSRC, "host_profile.cpp"), os.path.join(CSRC, "ckm_tables.cpp"), os.path.join(CSRC, "fasta_ingest.cpp"), "-o", exe]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if out.returncode != 0 and "tsan" in out.stderr.lower():
+        pytest.skip("ThreadSanitizer runtime not available")
+    assert out.returncode == 0, out.stderr[-3000:]
+    profs = synth.small_profiles(22, 6, 40, 120)
+    path = str(tmp_path / "valid.faa")
+    synth.write_fasta(path, synth.make_bin(profs, 98, n_orfs=300, dup_frac=0.3))
+    run = subprocess.run([exe, "merge", path, str(tmp_path), "17", "9"], capture_output=True, text=True, timeout=600)
+    if run.returncode != 0 and "unexpected memory mapping" in run.stderr:
+        pytest.skip("ThreadSanitizer cannot run in this container")
+    assert run.returncode == 0 and "ThreadSanitizer" not in run.stderr, run.stderr[-3000:]
+    assert json.loads(run.stdout.strip().split("\n")[-1])["files"] == 17
+
+
 def test_hmm_reader_refuses_fields_that_are_not_probabilities(harness):
     """hmmsearch would atof() these and score with the result; a damaged number is refused here, with file:line in the message."""
     exe, d = harness
