@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--lineage-bins", type=int, default=0, help="cfg2: bins of a small lineage_wf-equivalent side measurement (0 = skip; cfg3 IS that measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-genes", action="store_true", help="cfg3: skip the gene-calling side legs (gene_front_end, gene_calling, from_fasta)")
-    ap.add_argument("--from-fasta-bins", type=int, default=256, help="cfg3 / genes: bins of the from_fasta leg (nucleotide bins -> genes -> tree pass -> analyze pass -> qa table); 0 skips it")
+    ap.add_argument("--from-fasta-bins", type=int, default=512, help="cfg3 / genes: bins of the from_fasta leg (nucleotide bins -> genes -> tree pass -> analyze pass -> qa table); 0 skips it.  256 bins are mostly the ramp of the calls in flight (31 - 34 s per 1000), 512 read 28 s, 1000 read 27.4 s (profiles/r05C, r05w)")
     ap.add_argument("--verify", type=int, default=3, help="cfg3 / cfg5: bins of the last timed step whose written tables are diffed against the CPU oracle after the timed region (0 = off)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--pipeline", type=int, default=1,
