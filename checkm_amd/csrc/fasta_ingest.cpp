@@ -12,6 +12,7 @@
 #include <cstring>
 #include <exception>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include "ckm_internal.h"
 
@@ -85,7 +86,9 @@ static void for_each_bin(uint32_t n, int nthreads, F f) {
     }
   };
   std::vector<std::thread> th;
-  for (unsigned k = 1; k < nth; ++k) th.emplace_back(body);
+  for (unsigned k = 1; k < nth; ++k) {
+    try { th.emplace_back(body); } catch (const std::system_error &) { break; }       // (no more threads to be had: the ones that exist do the work)
+  }
   body();
   for (auto &t : th) t.join();
   if (err) std::rethrow_exception(err);
