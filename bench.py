@@ -883,7 +883,12 @@ def gene_calling(workdir, nbins=192, cpu_bins=8):
                    "not built).  python_phases_s: device_calls_s is summed over the calls in flight, wall_s is the pass"}
     ph = out["python_phases_s"]
     if ph.get("wall_s"):
-        out["device_fraction_of_wall"] = max(0.0, ph["wall_s"] - ph["read_s"] - ph["choose_and_write_s"] / max(1, ph["lanes"])) / ph["wall_s"]
+        # the share of the pass during which at least one device call was in flight (the files are read and written beside the calls, so
+        # their summed thread times say nothing about the device; lines recorded before this figure existed subtracted them from the wall)
+        if ph.get("device_busy_s"):
+            out["device_fraction_of_wall"] = min(1.0, ph["device_busy_s"] / ph["wall_s"])
+        else:
+            out["device_fraction_of_wall"] = max(0.0, ph["wall_s"] - ph["read_s"] - ph["choose_and_write_s"] / max(1, ph["lanes"])) / ph["wall_s"]
     if cpu_bins <= 0:
         out["cpu_baseline"] = None
         return out

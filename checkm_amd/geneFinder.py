@@ -198,7 +198,8 @@ def call_bin_files(jobs, bNucORFs=False, max_bases=None, logger=None, on_bin_don
     out, lock = {}, threading.Lock()
     if not jobs:
         return out
-    phases = {"read_s": 0.0, "device_calls_s": 0.0, "choose_and_write_s": 0.0, "lanes": lanes, "calls": 0, "wall_s": 0.0}
+    phases = {"read_s": 0.0, "device_calls_s": 0.0, "choose_and_write_s": 0.0, "lanes": lanes, "calls": 0, "wall_s": 0.0, "device_busy_s": 0.0}
+    in_flight = [0, 0.0]                                    # device calls running now, and since when at least one is
     call_bin_files.last_phases = phases
     t_wall = time.perf_counter()
     # ---- sizes first, text later: a sub-batch's files are read when its turn comes (reading 1000 bins up front kept the device idle for 2.5 s).
@@ -306,9 +307,20 @@ def call_bin_files(jobs, bNucORFs=False, max_bases=None, logger=None, on_bin_don
         try:
             if not failed:
                 t1 = time.perf_counter()
-                call = _lib.GeneCall(ctx, batch, table, False, True)
                 with lock:
-                    phases["device_calls_s"] += time.perf_counter() - t1; phases["calls"] += 1
+                    if in_flight[0] == 0:
+                        in_flight[1] = t1
+                    in_flight[0] += 1
+                try:
+                    call = _lib.GeneCall(ctx, batch, table, False, True)
+                finally:
+                    t2 = time.perf_counter()
+                    with lock:
+                        in_flight[0] -= 1
+                        if in_flight[0] == 0:
+                            phases["device_busy_s"] += t2 - in_flight[1]        # (the pass's time with at least one call in flight)
+                        phases["device_calls_s"] += t2 - t1; phases["calls"] += 1
+                with lock:
                     stats_last.update(call.stats)
         except BaseException as e:
             record(e)

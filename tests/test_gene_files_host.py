@@ -5,6 +5,7 @@ The device path itself is tests/test_gpu_genes.py."""
 import logging
 import os
 import threading
+import time
 
 import numpy as np
 import pytest
@@ -24,6 +25,7 @@ class _FakeCall(object):
             raise err
         self.batch, self.table, self.h = batch, table, 1
         self.stats = {"table": table}
+        time.sleep(0.01)
         with _FakeCall.lock:
             _FakeCall.live += 1
             _FakeCall.made += 1
@@ -96,7 +98,9 @@ def test_sub_batches_tables_and_files(tmp_path, fake_device):
         for name in ("genes.faa", "genes.gff", "genes.fna"):
             assert open(os.path.join(d, name)).read().startswith("table %d " % t)
     assert fake_device.live == 0 and fake_device.made == 6
-    assert geneFinder.call_bin_files.last_phases["calls"] == 6                # 3 sub-batches (<= 600 kb each) x 2 tables
+    ph = geneFinder.call_bin_files.last_phases
+    assert ph["calls"] == 6                                                   # 3 sub-batches (<= 600 kb each) x 2 tables
+    assert 0.0 < ph["device_busy_s"] <= ph["wall_s"] and ph["device_busy_s"] <= ph["device_calls_s"] + 1e-9    # some call in flight <= the calls' summed times
     warned = [r.getMessage() for r in records if r.levelno == logging.WARNING]
     assert len(warned) == 1 and "bin002.fna" in warned[0] and "-p meta" in warned[0]          # the 30 kb bin
 
