@@ -150,8 +150,12 @@ GFN double dp_igm(const S &src, double st_wt, int k1, const DpNode &n1, int k2, 
 // THROUGH them -- an overlapping start p3, the node a trace-back points to -- through node3 / val3 / ndx_any (anywhere in the sequence).
 // KNOWN: the caller enumerates p1 by class (strand KS1, stop KST1), so the twelve cases fold to the ones that class can take -- the
 // same statements either way.
+// dp_connection_s is the connection WITHOUT the predecessor's own score (score_connection's `score`, the term added to n1->score): of
+// the dynamic program's state it reads only tb(p1) -- as "has p1 a predecessor at all" for a forward stop or a reverse start, and as the
+// position of that predecessor in the two cases dp_pair_dynamic names.  Everything else is fixed before the sweep starts, which is what
+// lets the sweep take its nodes 64 at a time (kernels_genes.hip: gene_dp_kernel).
 template <class S, bool KNOWN, int KS1, bool KST1>
-GFN bool dp_connection_x(const S &src, double st_wt, int p1, int p2, const DpNode &n2, double &total, int &mark) {
+GFN bool dp_connection_s(const S &src, double st_wt, int p1, int p2, const DpNode &n2, double &score_out, int &mark) {
   const int flag = src.flag;
   DpNode n1 = src.node(p1);
   if (KNOWN) { n1.strand = KS1; n1.stop = KST1; }
@@ -229,8 +233,15 @@ GFN bool dp_connection_x(const S &src, double st_wt, int p1, int p2, const DpNod
     if (flag == 0) scr_mod = src.val3(p3); else score = src.val3(p3) + dp_igm(src, st_wt, p3, n3, p2, n2);
   }
   if (flag == 0) score = ((double)(right - left + 1 - (ovlp * 2))) * scr_mod;
-  total = src.score(p1) + score;
+  score_out = score;
   mark = maxfr;
+  return true;
+}
+template <class S, bool KNOWN, int KS1, bool KST1>
+GFN bool dp_connection_x(const S &src, double st_wt, int p1, int p2, const DpNode &n2, double &total, int &mark) {
+  double score;
+  if (!dp_connection_s<S, KNOWN, KS1, KST1>(src, st_wt, p1, p2, n2, score, mark)) return false;
+  total = src.score(p1) + score;
   return true;
 }
 template <class S>
@@ -246,6 +257,26 @@ GFN bool dp_pair_possible(int c1, int c2) {
                       (1u << (1 * 4 + 2)) | (1u << (3 * 4 + 2)) |                    // -> reverse start: forward stop, reverse stop
                       (1u << (1 * 4 + 3)) | (1u << (2 * 4 + 3)) | (1u << (3 * 4 + 3));   // -> reverse stop: forward stop, reverse start, reverse stop
   return (ok >> (c1 * 4 + c2)) & 1u;
+}
+// the class pairs whose connection reads the POSITION of p1's predecessor (forward stop -> reverse start: the bound on the overlap;
+// forward stop -> reverse stop: which overlapping starts qualify)
+GFN bool dp_pair_dynamic(int c1, int c2) { return c1 == 1 && c2 >= 2; }
+// does a class need a predecessor of its own to be one (score_connection's "edge artifacts")?
+GFN bool dp_class_needs_tb(int c1) { return c1 == 1 || c1 == 2; }
+// A forward stop or a reverse start i connects only to nodes at positions > sv(i) - 4 (its own open reading frame's starts and the stops
+// inside it; a reverse gene's own stop and the forward stops that overlap it): the tests of score_connection that say so are
+// `n2.sv >= n1.ndx`, `n2.sv - 2 >= n1.ndx + 2` and, for reverse stop -> reverse start in one frame, `n1.sv <= n2.ndx` (then sv(i) is
+// that stop).  Nodes are in position order, so the candidates of such a node begin at the first node with ndx >= dp_pos_floor.
+GFN bool dp_class_pos_bounded(int c2) { return c2 == 1 || c2 == 2; }
+GFN int dp_pos_floor(int sv) { return sv - 3; }
+template <class S>
+GFN bool dp_connection_s_class(int c1, const S &src, double st_wt, int p1, int p2, const DpNode &n2, double &score, int &mark) {
+  switch (c1) {
+    case 0: return dp_connection_s<S, true, 1, false>(src, st_wt, p1, p2, n2, score, mark);
+    case 1: return dp_connection_s<S, true, 1, true>(src, st_wt, p1, p2, n2, score, mark);
+    case 2: return dp_connection_s<S, true, -1, false>(src, st_wt, p1, p2, n2, score, mark);
+    default: return dp_connection_s<S, true, -1, true>(src, st_wt, p1, p2, n2, score, mark);
+  }
 }
 template <class S>
 GFN bool dp_connection_class(int c1, const S &src, double st_wt, int p1, int p2, const DpNode &n2, double &total, int &mark) {

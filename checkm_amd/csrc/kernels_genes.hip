@@ -296,30 +296,45 @@ void x_hexamer_background(GExec &e, const uint8_t *code, const uint64_t *seq_off
 
 // ---- the dynamic program ----
 // The nodes of a sequence go in order; node i looks back over the 1000 nodes before it (dprog.c: 500 nodes, and 500 more behind the node
-// that far back; further when a giant open reading frame sits there).  Round 4 scored all of them with the twelve-case connection function,
-// every lane on its own case: ~1000 VALU instructions per 64 candidates, 11-16 us per node.  Now:
-//   * candidates are enumerated BY CLASS (forward / reverse, start / stop): four LDS rings hold the indices of the last 512 nodes of each
-//     class, a node's record holds how many nodes of each class precede it, so the class-c candidates of node i are ring entries
-//     [count_c(window start), count_c(i)) -- a wavefront's 64 candidates share one class, the connection function folds to that class's
-//     cases (gene_dev.h: dp_connection_x<KNOWN>), and classes that cannot precede node i (6 of the 16 pairs) are never touched;
-//   * the last 1088 nodes live in an LDS ring of 40-byte records read with three wide loads: {position, stop position, flags + packed
-//     overlapping-start offsets, trace-back and window start as 16-bit distances}, {score, connection value}, {class counts}; 47 KB per
-//     workgroup, three workgroups per compute unit with room left for the histogram kernels of other calls (the kernel is latency-bound: a sequence's nodes are strictly in order);
-//   * one barrier per node: the wavefronts' partial results are double-buffered by node parity and combined by every thread, the ring
-//     entry of node i is written by thread 0 while the others already score node i + 1 (node i itself is served from registers);
-//   * results leave the ring for global memory once per 64 nodes.
+// that far back; further when a giant open reading frame sits there).  Of the sweep's own state a connection j -> i reads the score of j
+// and -- for four of the ten class pairs -- whether j has a predecessor and where it lies (gene_dev.h: dp_connection_s); everything else
+// is fixed before the sweep starts.  Rounds 4-5 took the nodes one at a time, a barrier per node (3.6-4.8 us per node, 58 % of the
+// wavefronts' cycles waiting: profiles/r05t).  Round 6 takes them 64 at a time:
+//   (A) all wavefronts, no barrier: a wavefront takes a node i of the block (heaviest classes first, dealt by an LDS counter) and scores
+//       its candidates class by class out of four LDS rings of node indices -- a wavefront's 64 candidates share one class, so the
+//       connection function folds to that class's cases, and the six class pairs that cannot connect are never touched.  A candidate
+//       BEFORE the block is final: connection + score, into the wavefront's running best (one DPP reduction per node).  A candidate INSIDE
+//       the block is not: its connection WITHOUT its score goes into a 64 x 64 table in LDS (the pairs that read the candidate's
+//       predecessor -- dp_pair_dynamic -- are left out).  A forward stop's / reverse start's candidates begin at the first node its open
+//       reading frame can reach (dp_pos_floor: a binary search over the ring when the node enters), not 1000 nodes back;
+//   (B) one wavefront, lane per node of the block: for t = 0 .. 63 node t is final (every candidate before it has been offered), its score
+//       and predecessor are broadcast by v_readlane, and every lane behind t takes `score(t) + table[t][lane]` -- one LDS read, one add, one
+//       compare; only a forward stop t meeting reverse nodes runs the connection function here.  Meanwhile another wavefront enters the
+//       NEXT 64 nodes into the rings (their global-memory reads hide behind (B)); the block's results leave for global memory during the
+//       next block's (A).
+// Two barriers per 64 nodes.  The last 1152 nodes live in an LDS ring of 40-byte records read with wide loads: {position, stop position,
+// flags + packed overlapping-start offsets, trace-back and window start as 16-bit distances}, {score, connection value}, {class counts}.
 // What does not fit the rings (a window that starts behind a giant open reading frame, more than 512 nodes of one class in a window) goes
 // through the generic loop with global-memory fall-backs.
-constexpr int DPW = 1088, DPC = 512, DP_FAR = 0xffff;      // 1088 = the 1000-node window + the 64 nodes entered ahead (+ slack); 47 KB with the class rings
+constexpr int DPB = 64;                                       // nodes per block
+constexpr int DPW = 1152, DPC = 512, DP_FAR = 0xffff;        // 1152 = the 1000-node window + this block + the block entered ahead (+ slack)
 struct DpRec { int ndx, sv, pk; uint32_t tbl; };            // pk: bit 0 stop, 1 reverse, 3 stars-in-global, 4-5 (overlap mark + 1), 8.. three signed byte offsets; tbl: trace-back distance | window distance << 16
 struct DpRing { DpRec rec[DPW]; double2 sv2[DPW]; ushort4 cnt[DPW]; unsigned short cls[4][DPC]; };
+struct DpBlock {
+  double table[DPB * DPB];                                   // [t][(l + t) & 63]: connection t -> l without t's score; -inf: none
+  double pbest[DPB]; int pkey[DPB];                          // (A)'s result per node of the block
+  int lo_eff[DPB];                                           // where the node's candidates begin (window start, or the position floor)
+  unsigned char order[DPB];                                  // the block's nodes, heaviest class first
+  uint32_t next;                                             // (A)'s dealer
+};
 __device__ __forceinline__ int dp_slot(int rel) { return rel % DPW; }
+__device__ __forceinline__ int dp_tab(int t, int l) { return t * DPB + ((l + t) & (DPB - 1)); }      // (the rotation spreads a column over the banks)
 
 template <int FLAG>
 struct DpSrc {
   static constexpr int flag = FLAG;
   const Nodes &nd; DpRing &r; uint32_t first; int lo_rel, hi_rel;                 // nodes with relative index in [lo_rel, hi_rel) are in the ring
-  int pend; double pend_score; int pend_tb;                                       // the node scored last: its ring entry may still be on its way
+  int blk0;                                                                       // nodes from here on are not final: (A) is told "has a predecessor", (B) decides
   __device__ __forceinline__ bool ring(int rel) const { return rel >= lo_rel && rel < hi_rel; }
   __device__ __forceinline__ DpNode node(int rel) const {
     DpNode n;
@@ -334,13 +349,12 @@ struct DpSrc {
   }
   __device__ __forceinline__ double val(int rel) const { return ring(rel) ? r.sv2[dp_slot(rel)].y : (FLAG == 0 ? nd.gcb[first + (uint32_t)rel] : nd.csc[first + (uint32_t)rel]); }
   __device__ __forceinline__ double score(int rel) const {
-    if (rel == pend) return pend_score;
     if (ring(rel)) return r.sv2[dp_slot(rel)].x;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
     return GLD(&nd.score[first + (uint32_t)rel]);
   }
   __device__ __forceinline__ int tb(int rel) const {                     // relative, or -1
-    if (rel == pend) return pend_tb;
+    if (rel >= blk0) return 0;
     if (ring(rel)) { const uint32_t d = r.rec[dp_slot(rel)].tbl & 0xffffu; if (d != (uint32_t)DP_FAR) return d == 0 ? -1 : rel - (int)d; }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
     return GLD(&nd.traceb[first + (uint32_t)rel]);
@@ -367,9 +381,9 @@ struct DpRingSrc {
     return g.nd.star[(size_t)(g.first + (uint32_t)rel) * 3 + f];
   }
   __device__ __forceinline__ double val(int rel) const { return g.r.sv2[dp_slot(rel)].y; }
-  __device__ __forceinline__ double score(int rel) const { return rel == g.pend ? g.pend_score : g.r.sv2[dp_slot(rel)].x; }
+  __device__ __forceinline__ double score(int rel) const { return g.r.sv2[dp_slot(rel)].x; }
   __device__ __forceinline__ int tb(int rel) const {
-    if (rel == g.pend) return g.pend_tb;
+    if (rel >= g.blk0) return 0;
     const uint32_t d = rec(rel).tbl & 0xffffu;
     if (d != (uint32_t)DP_FAR) return d == 0 ? -1 : rel - (int)d;
     return g.tb(rel);
@@ -387,34 +401,81 @@ template <int CTRL> __device__ __forceinline__ int dp_dpp(int v) { return __buil
 __device__ __forceinline__ void dp_merge(double &best, int &key, double ob, int ok) {
   if (ok >= 0 && (key < 0 || ob > best || (ob == best && ok > key))) { best = ob; key = ok; }
 }
+__device__ __forceinline__ int dp_lo32(double d) { return (int)(__builtin_bit_cast(unsigned long long, d) & 0xffffffffull); }
+__device__ __forceinline__ int dp_hi32(double d) { return (int)(__builtin_bit_cast(unsigned long long, d) >> 32); }
+__device__ __forceinline__ double dp_mk64(int l, int h) { return __builtin_bit_cast(double, ((unsigned long long)(unsigned)h << 32) | (unsigned)l); }
 __device__ __forceinline__ void dp_wave_best(double &best, int &key) {
-  auto lo = [](double d) { return (int)(__builtin_bit_cast(unsigned long long, d) & 0xffffffffull); };
-  auto hi = [](double d) { return (int)(__builtin_bit_cast(unsigned long long, d) >> 32); };
-  auto mk = [](int l, int h) { return __builtin_bit_cast(double, ((unsigned long long)(unsigned)h << 32) | (unsigned)l); };
-#define CKM_DP_STEP(CTRL) { const double ob = mk(dp_dpp<CTRL>(lo(best)), dp_dpp<CTRL>(hi(best))); const int ok = dp_dpp<CTRL>(key); dp_merge(best, key, ob, ok); }
+#define CKM_DP_STEP(CTRL) { const double ob = dp_mk64(dp_dpp<CTRL>(dp_lo32(best)), dp_dpp<CTRL>(dp_hi32(best))); const int ok = dp_dpp<CTRL>(key); dp_merge(best, key, ob, ok); }
   CKM_DP_STEP(0xB1)      /* quad_perm [1,0,3,2]: partner xor 1 */
   CKM_DP_STEP(0x4E)      /* quad_perm [2,3,0,1]: partner xor 2 */
   CKM_DP_STEP(0x141)     /* row_half_mirror: pairs the two quads of a half row */
   CKM_DP_STEP(0x140)     /* row_mirror: pairs the two halves of a row */
 #undef CKM_DP_STEP
   {   // across the rows of 16 lanes: the row leaders' values through readlane (uniform), merged by every lane
-    double b1 = mk(__builtin_amdgcn_readlane(lo(best), 16), __builtin_amdgcn_readlane(hi(best), 16)); int k1 = __builtin_amdgcn_readlane(key, 16);
-    double b2 = mk(__builtin_amdgcn_readlane(lo(best), 32), __builtin_amdgcn_readlane(hi(best), 32)); int k2 = __builtin_amdgcn_readlane(key, 32);
-    double b3 = mk(__builtin_amdgcn_readlane(lo(best), 48), __builtin_amdgcn_readlane(hi(best), 48)); int k3 = __builtin_amdgcn_readlane(key, 48);
-    double b0 = mk(__builtin_amdgcn_readlane(lo(best), 0), __builtin_amdgcn_readlane(hi(best), 0)); int k0 = __builtin_amdgcn_readlane(key, 0);
+    double b1 = dp_mk64(__builtin_amdgcn_readlane(dp_lo32(best), 16), __builtin_amdgcn_readlane(dp_hi32(best), 16)); int k1 = __builtin_amdgcn_readlane(key, 16);
+    double b2 = dp_mk64(__builtin_amdgcn_readlane(dp_lo32(best), 32), __builtin_amdgcn_readlane(dp_hi32(best), 32)); int k2 = __builtin_amdgcn_readlane(key, 32);
+    double b3 = dp_mk64(__builtin_amdgcn_readlane(dp_lo32(best), 48), __builtin_amdgcn_readlane(dp_hi32(best), 48)); int k3 = __builtin_amdgcn_readlane(key, 48);
+    double b0 = dp_mk64(__builtin_amdgcn_readlane(dp_lo32(best), 0), __builtin_amdgcn_readlane(dp_hi32(best), 0)); int k0 = __builtin_amdgcn_readlane(key, 0);
     best = b0; key = k0; dp_merge(best, key, b1, k1); dp_merge(best, key, b2, k2); dp_merge(best, key, b3, k3);
+  }
+}
+__device__ __forceinline__ int dp_ring_lo(int i0) { const int v = i0 + 2 * DPB - DPW; return v > 0 ? v : 0; }     // (the oldest node no entering block overwrites)
+
+// the 64 nodes from e0 on enter the rings (one wavefront; the slots they take over are 1152 nodes / 512 class members back)
+template <int FLAG>
+__device__ __forceinline__ void dp_enter(const Nodes &nd, DpRing &ring, DpBlock &blk, uint32_t *ring_tot, uint32_t first, int nn, int e0, int lane) {
+  const int rel = e0 + lane; const bool in = rel < nn;
+  int cls = -1, pk = 0; const uint32_t g = first + (uint32_t)(in ? rel : 0);
+  if (in) { const bool st = nd.type[g] == 3; const int str = nd.strand[g]; cls = dp_class(str, st); pk = (st ? 1 : 0) | (str == -1 ? 2 : 0); }
+  const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  uint32_t before[4], tot[4];
+  unsigned long long m[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { m[c] = __ballot(cls == c); tot[c] = ring_tot[c]; before[c] = tot[c] + (uint32_t)__popcll(m[c] & below); tot[c] += (uint32_t)__popcll(m[c]); }
+  int lo = 0, sv = 0;
+  if (in) {
+    const int k = dp_slot(rel);
+    for (int f = 0; f < 3; ++f) {
+      const int sp = nd.star[(size_t)g * 3 + f]; const int o = sp < 0 ? -128 : sp - rel;
+      if (sp >= 0 && (o < -127 || o > 127)) pk |= 8;          // (does not fit the packed offset: this node's overlapping starts are read from global memory)
+      pk |= (o & 0xff) << (8 + 8 * f);
+    }
+    lo = (int)nd.dp_min[g]; const uint32_t lod = rel - lo < DP_FAR ? (uint32_t)(rel - lo) : (uint32_t)DP_FAR;
+    sv = nd.sv[g];
+    DpRec q; q.ndx = nd.ndx[g]; q.sv = sv; q.pk = pk; q.tbl = lod << 16;                 // trace-back distance 0: none yet
+    ring.rec[k] = q;
+    ring.sv2[k] = make_double2(0.0, FLAG == 0 ? nd.gcb[g] : nd.csc[g]);
+    ring.cnt[k] = make_ushort4((unsigned short)before[0], (unsigned short)before[1], (unsigned short)before[2], (unsigned short)before[3]);
+    ring.cls[cls][before[cls] & (DPC - 1)] = (unsigned short)rel;
+  }
+  if (lane == 0) { for (int c = 0; c < 4; ++c) ring_tot[c] = tot[c]; }
+  // where the node's candidates begin: a forward stop / reverse start reaches back to dp_pos_floor only (the records of this block are in
+  // the ring by now -- LDS operations of one wavefront complete in order)
+  if (in) {
+    int le = lo;
+    if (dp_class_pos_bounded(cls) && lo >= dp_ring_lo(e0)) {
+      const int fl = dp_pos_floor(sv);
+      int a = lo, b = rel;                                     // smallest j in [lo, rel] with j == rel or ndx(j) >= fl
+      while (a < b) { const int mid = (a + b) >> 1; if (ring.rec[dp_slot(mid)].ndx >= fl) b = mid; else a = mid + 1; }
+      le = a;
+    }
+    blk.lo_eff[lane] = le;
+  }
+  // heaviest first: reverse stops (three classes of candidates, the overlapping-start loop), forward starts (two), the position-bounded rest
+  const unsigned long long h0 = m[3], h1 = m[0], h2 = m[1] | m[2];
+  if (in) {
+    const int pos = cls == 3 ? __popcll(h0 & below) : cls == 0 ? __popcll(h0) + __popcll(h1 & below) : __popcll(h0) + __popcll(h1) + __popcll(h2 & below);
+    blk.order[pos] = (unsigned char)lane;
   }
 }
 
 template <int FLAG, int DP_NT>
 __global__ void __launch_bounds__(DP_NT) gene_dp_kernel(Nodes nd, const uint32_t *__restrict__ seq_lo, const uint32_t *__restrict__ seq_n, const uint32_t *__restrict__ seq_bin,
-                                                        const double *__restrict__ st_wt_of_bin, uint32_t nseq, uint32_t prio) {
+                                                        const double *__restrict__ st_wt_of_bin, uint32_t nseq) {
   constexpr int DP_NW = DP_NT / 64;
-  // a sequence's nodes are scored strictly one after the other, so these wavefronts are the latency-critical ones of whatever shares their
-  // SIMD (the per-index kernels of other calls, the scan's kernels): let them win the issue arbitration
-  if (prio) __builtin_amdgcn_s_setprio(3);
+  constexpr int W_ENTER = 1 % DP_NW, W_FLUSH = 2 % DP_NW;
   __shared__ DpRing ring;
-  __shared__ double red_best[2][DP_NW]; __shared__ int red_j[2][DP_NW];
+  __shared__ DpBlock blk;
   __shared__ uint32_t ring_tot[4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   for (uint32_t s = blockIdx.x; s < nseq; s += gridDim.x) {
@@ -423,110 +484,139 @@ __global__ void __launch_bounds__(DP_NT) gene_dp_kernel(Nodes nd, const uint32_t
     const double st_wt = st_wt_of_bin[seq_bin[s]];
     __syncthreads();
     if (tid < 4) ring_tot[tid] = 0;
+    if (tid == 0) blk.next = 0;
     __syncthreads();
-    int pend = -1, pend_tb = -1; double pend_score = 0.0;
-    for (int i0 = 0; i0 < nn; i0 += 64) {
-      // the next 64 nodes enter the rings (wavefront 0; the slots they take over are 1088 nodes / 512 class members back)
-      if (wv == 0) {
-        const int rel = i0 + lane; const bool in = rel < nn;
-        int cls = -1, pk = 0; const uint32_t g = first + (uint32_t)(in ? rel : 0);
-        if (in) { const bool st = nd.type[g] == 3; const int str = nd.strand[g]; cls = dp_class(str, st); pk = (st ? 1 : 0) | (str == -1 ? 2 : 0); }
-        const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-        uint32_t before[4], tot[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { const unsigned long long m = __ballot(cls == c); tot[c] = ring_tot[c]; before[c] = tot[c] + (uint32_t)__popcll(m & below); tot[c] += (uint32_t)__popcll(m); }
-        if (in) {
-          const int k = dp_slot(rel);
-          for (int f = 0; f < 3; ++f) {
-            const int sp = nd.star[(size_t)g * 3 + f]; const int o = sp < 0 ? -128 : sp - rel;
-            if (sp >= 0 && (o < -127 || o > 127)) pk |= 8;          // (does not fit the packed offset: this node's overlapping starts are read from global memory)
-            pk |= (o & 0xff) << (8 + 8 * f);
-          }
-          const int lo = (int)nd.dp_min[g]; const uint32_t lod = rel - lo < DP_FAR ? (uint32_t)(rel - lo) : (uint32_t)DP_FAR;
-          DpRec q; q.ndx = nd.ndx[g]; q.sv = nd.sv[g]; q.pk = pk; q.tbl = lod << 16;                 // trace-back distance 0: none yet
-          ring.rec[k] = q;
-          ring.sv2[k] = make_double2(0.0, FLAG == 0 ? nd.gcb[g] : nd.csc[g]);
-          ring.cnt[k] = make_ushort4((unsigned short)before[0], (unsigned short)before[1], (unsigned short)before[2], (unsigned short)before[3]);
-          ring.cls[cls][before[cls] & (DPC - 1)] = (unsigned short)rel;
+    if (wv == W_ENTER && nn > 0) dp_enter<FLAG>(nd, ring, blk, ring_tot, first, nn, 0, lane);
+    __syncthreads();
+    for (int i0 = 0; i0 < nn; i0 += DPB) {
+      const int cnt = min(DPB, nn - i0), i1 = i0 + cnt;
+      const int ring_lo = dp_ring_lo(i0);
+      // ---- the previous block's results go to global memory (its ring entries are final) ----
+      if (wv == W_FLUSH && i0 > 0) {
+        const int rel = i0 - DPB + lane;
+        const int k = dp_slot(rel); const DpRec q = ring.rec[k]; const uint32_t d = q.tbl & 0xffffu;
+        if (d != 0) {
+          GST(&nd.score[first + (uint32_t)rel], ring.sv2[k].x); GST(&nd.ov_mark[first + (uint32_t)rel], ((q.pk >> 4) & 3) - 1);
+          if (d != (uint32_t)DP_FAR) GST(&nd.traceb[first + (uint32_t)rel], rel - (int)d);
         }
-        if (lane == 0) { for (int c = 0; c < 4; ++c) ring_tot[c] = tot[c]; }
       }
-      __syncthreads();
-      const int i1 = min(nn, i0 + 64);
-      const int ring_lo = max(0, i0 + 64 - DPW);
-      for (int i = i0; i < i1; ++i) {
-        const DpSrc<FLAG> S{nd, ring, first, ring_lo, i1, pend, pend_score, pend_tb};
-        const DpRec qi = ring.rec[dp_slot(i)];
-        DpNode n2; n2.ndx = qi.ndx; n2.sv = qi.sv; n2.strand = (qi.pk & 2) ? -1 : 1; n2.stop = qi.pk & 1;
-        const uint32_t lod = qi.tbl >> 16;
-        const int lo = lod == (uint32_t)DP_FAR ? (int)nd.dp_min[first + (uint32_t)i] : i - (int)lod;
-        const int c2 = dp_class(n2.strand, n2.stop);
-        double best = -1.0; int bj = -1, bmark = -1;
-        // class ranges: the window's first node must be in the node ring, every class's members of the window in the class rings
-        bool by_class = lo >= ring_lo;
-        unsigned short a[4], n[4];
-        if (by_class) {
-          const ushort4 ca = ring.cnt[dp_slot(lo)], cb = ring.cnt[dp_slot(i)];
-          a[0] = ca.x; a[1] = ca.y; a[2] = ca.z; a[3] = ca.w;
-          n[0] = (unsigned short)(cb.x - ca.x); n[1] = (unsigned short)(cb.y - ca.y); n[2] = (unsigned short)(cb.z - ca.z); n[3] = (unsigned short)(cb.w - ca.w);
+      // ---- (A) ----
+      {
+        const DpSrc<FLAG> S{nd, ring, first, ring_lo, i1, i0};
+        const ushort4 c0 = ring.cnt[dp_slot(i0)];                                    // class counts at the block's first node
+        (void)c0;
+        for (;;) {
+          uint32_t u = 0;
+          if (lane == 0) u = atomicAdd(&blk.next, 1u);
+          u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
+          if (u >= (uint32_t)cnt) break;
+          const int l = blk.order[u], i = i0 + l;
+          const DpRec qi = ring.rec[dp_slot(i)];
+          DpNode n2; n2.ndx = qi.ndx; n2.sv = qi.sv; n2.strand = (qi.pk & 2) ? -1 : 1; n2.stop = qi.pk & 1;
+          const uint32_t lod = qi.tbl >> 16;
+          const int lo = lod == (uint32_t)DP_FAR ? (int)nd.dp_min[first + (uint32_t)i] : i - (int)lod;
+          const int le = blk.lo_eff[l];
+          const int c2 = dp_class(n2.strand, n2.stop);
+          if (lane < l) blk.table[dp_tab(lane, l)] = -__builtin_inf();
+          double best = -1.0; int bj = -1, bmark = -1;
+          // class ranges: the first candidate must be in the node ring, every class's members behind it in the class rings
+          bool by_class = le >= ring_lo;
+          unsigned short a[4], n[4];
+          if (by_class) {
+            const ushort4 ca = ring.cnt[dp_slot(le)], cb = ring.cnt[dp_slot(i)];
+            a[0] = ca.x; a[1] = ca.y; a[2] = ca.z; a[3] = ca.w;
+            n[0] = (unsigned short)(cb.x - ca.x); n[1] = (unsigned short)(cb.y - ca.y); n[2] = (unsigned short)(cb.z - ca.z); n[3] = (unsigned short)(cb.w - ca.w);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) if ((unsigned short)((unsigned short)ring_tot[c] - a[c]) > DPC) by_class = false;
-        }
-        if (by_class) {
-          const DpRingSrc<FLAG> R{S, -1, DpRec{0, 0, 0, 0}};
+            for (int c = 0; c < 4; ++c) if ((unsigned short)((unsigned short)ring_tot[c] - a[c]) > DPC) by_class = false;
+          }
+          if (by_class) {
+            const DpRingSrc<FLAG> R{S, -1, DpRec{0, 0, 0, 0}};
 #pragma unroll
-          for (int c1 = 0; c1 < 4; ++c1) {
-            if (!dp_pair_possible(c1, c2)) continue;
-            for (int t = tid; t < (int)n[c1]; t += DP_NT) {
-              const int jl = ring.cls[c1][(a[c1] + t) & (DPC - 1)];                           // low 16 bits of the index
-              const int j = i - ((i - jl) & 0xffff);
-              double tot; int mark; bool ok;
-              if (c1 == 0) ok = dp_connection_x<DpRingSrc<FLAG>, true, 1, false>(R, st_wt, j, i, n2, tot, mark);
-              else if (c1 == 1) ok = dp_connection_x<DpRingSrc<FLAG>, true, 1, true>(R, st_wt, j, i, n2, tot, mark);
-              else if (c1 == 2) ok = dp_connection_x<DpRingSrc<FLAG>, true, -1, false>(R, st_wt, j, i, n2, tot, mark);
-              else ok = dp_connection_x<DpRingSrc<FLAG>, true, -1, true>(R, st_wt, j, i, n2, tot, mark);
-              if (ok) dp_take(tot, j, mark, best, bj, bmark);
+            for (int c1 = 0; c1 < 4; ++c1) {
+              if (!dp_pair_possible(c1, c2)) continue;
+              const bool dyn = dp_pair_dynamic(c1, c2);
+              for (int t = lane; t < (int)n[c1]; t += 64) {
+                const int jl = ring.cls[c1][(a[c1] + t) & (DPC - 1)];                           // low 16 bits of the index
+                const int j = i - ((i - jl) & 0xffff);
+                const bool inblk = j >= i0;
+                if (inblk && dyn) continue;
+                double sc; int mark; bool ok;
+                if (c1 == 0) ok = dp_connection_s<DpRingSrc<FLAG>, true, 1, false>(R, st_wt, j, i, n2, sc, mark);
+                else if (c1 == 1) ok = dp_connection_s<DpRingSrc<FLAG>, true, 1, true>(R, st_wt, j, i, n2, sc, mark);
+                else if (c1 == 2) ok = dp_connection_s<DpRingSrc<FLAG>, true, -1, false>(R, st_wt, j, i, n2, sc, mark);
+                else ok = dp_connection_s<DpRingSrc<FLAG>, true, -1, true>(R, st_wt, j, i, n2, sc, mark);
+                if (ok) {
+                  if (inblk) blk.table[dp_tab(j - i0, l)] = sc;
+                  else dp_take(R.score(j) + sc, j, mark, best, bj, bmark);
+                }
+              }
+            }
+          } else {
+            for (int j = lo + lane; j < i; j += 64) {
+              const bool inblk = j >= i0;
+              const DpNode n1 = S.node(j);
+              if (inblk && dp_pair_dynamic(dp_class(n1.strand, n1.stop), c2)) continue;
+              double sc; int mark;
+              if (dp_connection_s<DpSrc<FLAG>, false, 0, false>(S, st_wt, j, i, n2, sc, mark)) {
+                if (inblk) blk.table[dp_tab(j - i0, l)] = sc;
+                else dp_take(S.score(j) + sc, j, mark, best, bj, bmark);
+              }
             }
           }
-        } else {
-          for (int j = lo + tid; j < i; j += DP_NT) {
-            double tot; int mark;
-            if (dp_connection(S, st_wt, j, i, n2, tot, mark)) dp_take(tot, j, mark, best, bj, bmark);
-          }
-        }
-        int key = bj < 0 ? -1 : bj * 4 + (bmark + 1);                 // candidate index and overlap mark travel together
-        dp_wave_best(best, key);
-        const int par = i & 1;
-        if (lane == 0) { red_best[par][wv] = best; red_j[par][wv] = key; }
-        __syncthreads();
-        best = red_best[par][0]; key = red_j[par][0];
-#pragma unroll
-        for (int k = 1; k < DP_NW; ++k) {
-          const double ob = red_best[par][k]; const int ok = red_j[par][k];
-          if (ok >= 0 && (key < 0 || ob > best || (ob == best && ok > key))) { best = ob; key = ok; }
-        }
-        bj = key < 0 ? -1 : key >> 2; bmark = key < 0 ? -1 : (key & 3) - 1;
-        // node i is final: every thread knows it; thread 0 publishes it to the ring, the rest go on with node i + 1
-        pend = i; pend_score = bj >= 0 ? best : 0.0; pend_tb = bj >= 0 ? bj : -1;
-        if (tid == 0 && bj >= 0) {
-          const int k = dp_slot(i);
-          ring.sv2[k].x = best;
-          const uint32_t d = i - bj < DP_FAR ? (uint32_t)(i - bj) : (uint32_t)DP_FAR;
-          ring.rec[k].tbl = (qi.tbl & 0xffff0000u) | d;
-          ring.rec[k].pk = qi.pk | ((bmark + 1) << 4);
-          if (d == (uint32_t)DP_FAR) GST(&nd.traceb[first + (uint32_t)i], bj);                  // (a trace-back the 16-bit distance cannot hold is read from global memory)
+          int key = bj < 0 ? -1 : bj * 4 + (bmark + 1);                 // candidate index and overlap mark travel together
+          dp_wave_best(best, key);
+          if (lane == 0) { blk.pbest[l] = best; blk.pkey[l] = key; }
         }
       }
-      __syncthreads();              // (the last node of the batch is in the ring before the next 64 enter)
-      // the batch's results go to global memory together (a store per node made every node's barrier wait for the memory system)
-      if (wv == 1) {
-        const int rel = i0 + lane;
-        if (rel < nn) {
-          const int k = dp_slot(rel); const DpRec q = ring.rec[k]; const uint32_t d = q.tbl & 0xffffu;
-          if (d != 0) {
-            GST(&nd.score[first + (uint32_t)rel], ring.sv2[k].x); GST(&nd.ov_mark[first + (uint32_t)rel], ((q.pk >> 4) & 3) - 1);
-            if (d != (uint32_t)DP_FAR) GST(&nd.traceb[first + (uint32_t)rel], rel - (int)d);
+      __syncthreads();
+      // ---- (B) ----
+      if (wv == 0) {
+        const DpSrc<FLAG> S{nd, ring, first, ring_lo, i1, 0x7fffffff};
+        const DpRingSrc<FLAG> R{S, -1, DpRec{0, 0, 0, 0}};
+        const bool in = lane < cnt;
+        const int i = i0 + (in ? lane : 0);
+        const int k = dp_slot(i);
+        const DpRec qi = ring.rec[k];
+        DpNode n2; n2.ndx = qi.ndx; n2.sv = qi.sv; n2.strand = (qi.pk & 2) ? -1 : 1; n2.stop = qi.pk & 1;
+        const int c2 = dp_class(n2.strand, n2.stop);
+        double best = in ? blk.pbest[lane] : -1.0; const int key0 = in ? blk.pkey[lane] : -1;
+        int bj = key0 < 0 ? -1 : key0 >> 2, bmark = key0 < 0 ? -1 : (key0 & 3) - 1;
+        if (lane == 0) blk.next = 0;
+        for (int t = 0; t < cnt; ++t) {
+          // node i0 + t is final: every lane learns it, its own lane publishes it to the ring
+          const double bt = dp_mk64(__builtin_amdgcn_readlane(dp_lo32(best), t), __builtin_amdgcn_readlane(dp_hi32(best), t));
+          const int jt = __builtin_amdgcn_readlane(bj, t), c1 = __builtin_amdgcn_readlane(c2, t);
+          if (lane == t && bj >= 0) {
+            ring.sv2[k].x = best;
+            const uint32_t d = i - bj < DP_FAR ? (uint32_t)(i - bj) : (uint32_t)DP_FAR;
+            ring.rec[k].tbl = (qi.tbl & 0xffff0000u) | d;
+            ring.rec[k].pk = qi.pk | ((bmark + 1) << 4);
+            if (d == (uint32_t)DP_FAR) GST(&nd.traceb[first + (uint32_t)i], bj);                  // (a trace-back the 16-bit distance cannot hold is read from global memory)
           }
+          if (dp_class_needs_tb(c1) && jt < 0) continue;
+          const double sc_t = jt >= 0 ? bt : 0.0;
+          if (in && lane > t) {
+            dp_take(sc_t + blk.table[dp_tab(t, lane)], i0 + t, -1, best, bj, bmark);
+            if (dp_pair_dynamic(c1, c2)) {
+              double tot; int mark;
+              if (dp_connection_x<DpRingSrc<FLAG>, true, 1, true>(R, st_wt, i0 + t, i, n2, tot, mark)) dp_take(tot, i0 + t, mark, best, bj, bmark);
+            }
+          }
+        }
+      } else if (wv == W_ENTER && i1 < nn) {
+        dp_enter<FLAG>(nd, ring, blk, ring_tot, first, nn, i1, lane);
+      }
+      if (DP_NW == 1 && i1 < nn) dp_enter<FLAG>(nd, ring, blk, ring_tot, first, nn, i1, lane);
+      __syncthreads();
+    }
+    // the last block's results
+    if (wv == W_FLUSH && nn > 0) {
+      const int i0 = ((nn - 1) / DPB) * DPB, rel = i0 + lane;
+      if (rel < nn) {
+        const int k = dp_slot(rel); const DpRec q = ring.rec[k]; const uint32_t d = q.tbl & 0xffffu;
+        if (d != 0) {
+          GST(&nd.score[first + (uint32_t)rel], ring.sv2[k].x); GST(&nd.ov_mark[first + (uint32_t)rel], ((q.pk >> 4) & 3) - 1);
+          if (d != (uint32_t)DP_FAR) GST(&nd.traceb[first + (uint32_t)rel], rel - (int)d);
         }
       }
     }
@@ -534,17 +624,11 @@ __global__ void __launch_bounds__(DP_NT) gene_dp_kernel(Nodes nd, const uint32_t
 }
 void x_dp(GExec &e, const Nodes &nd, const uint32_t *seq_lo, const uint32_t *seq_n, const uint32_t *seq_bin, const double *st_wt, uint32_t nseq, int flag) {
   if (!nseq) return;
-  // threads per sequence: 256 (four wavefronts share a node's candidates); CKM_GENE_DP_THREADS=128|512 for measurements.
-  // CKM_GENE_DP_LDS_PAD_KB asks for that much unused dynamic LDS on top of the ring, which lowers how many sequences the dispatcher may
-  // put on one compute unit (ring + classes ~ 48 KB of the 160 KB: three by default)
-  static const int nt = [] { const char *v = getenv("CKM_GENE_DP_THREADS"); const int n = v ? atoi(v) : 256; return n == 128 || n == 512 ? n : 256; }();
-  static const uint32_t prio = [] { const char *v = getenv("CKM_GENE_DP_PRIO"); return (uint32_t)(v ? atoi(v) != 0 : 0); }();
-  static const size_t pad = [] { const char *v = getenv("CKM_GENE_DP_LDS_PAD_KB"); const int n = v ? atoi(v) : 0; return (size_t)(n < 0 ? 0 : n > 100 ? 100 : n) << 10; }();
-#define CKM_DP_LAUNCH(F, T) do { if (pad) { static std::mutex mu; static uint32_t done = 0; int dev = 0; (void)hipGetDevice(&dev); std::lock_guard<std::mutex> lk(mu);   \
-                                   if (!(done & (1u << (dev & 31)))) { (void)hipFuncSetAttribute((const void *)gene_dp_kernel<F, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad); done |= 1u << (dev & 31); } } \
-                                 hipLaunchKernelGGL((gene_dp_kernel<F, T>), dim3(nseq), dim3(T), pad, e.st, nd, seq_lo, seq_n, seq_bin, st_wt, nseq, prio); } while (0)
-  if (flag == 0) { if (nt == 128) CKM_DP_LAUNCH(0, 128); else if (nt == 512) CKM_DP_LAUNCH(0, 512); else CKM_DP_LAUNCH(0, 256); }
-  else { if (nt == 128) CKM_DP_LAUNCH(1, 128); else if (nt == 512) CKM_DP_LAUNCH(1, 512); else CKM_DP_LAUNCH(1, 256); }
+  // threads per sequence: CKM_GENE_DP_THREADS = 256 | 512 | 1024 for measurements
+  static const int nt = [] { const char *v = getenv("CKM_GENE_DP_THREADS"); const int n = v ? atoi(v) : 1024; return n == 256 || n == 512 ? n : 1024; }();
+#define CKM_DP_LAUNCH(F, T) hipLaunchKernelGGL((gene_dp_kernel<F, T>), dim3(nseq), dim3(T), 0, e.st, nd, seq_lo, seq_n, seq_bin, st_wt, nseq)
+  if (flag == 0) { if (nt == 256) CKM_DP_LAUNCH(0, 256); else if (nt == 512) CKM_DP_LAUNCH(0, 512); else CKM_DP_LAUNCH(0, 1024); }
+  else { if (nt == 256) CKM_DP_LAUNCH(1, 256); else if (nt == 512) CKM_DP_LAUNCH(1, 512); else CKM_DP_LAUNCH(1, 1024); }
 #undef CKM_DP_LAUNCH
 }
 

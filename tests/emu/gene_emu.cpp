@@ -109,25 +109,58 @@ struct DpFlat {
   double rscore(int rel) const { return nd.rscore[first + (uint32_t)rel]; }
   double uscore(int rel) const { return nd.uscore[first + (uint32_t)rel]; }
 };
+// The sweep as the device kernel takes it (kernels_genes.hip: gene_dp_kernel): 64 nodes at a time.  For a block, (A) every node's candidates
+// BEFORE the block are final and scored in any order; the connection of a candidate INSIDE the block to it is scored WITHOUT the
+// candidate's own score (dp_connection_s) into a 64 x 64 table -- except the pairs whose connection reads the candidate's predecessor
+// (dp_pair_dynamic); a forward stop's / reverse start's candidates begin at dp_pos_floor.  (B) the block's nodes are then resolved one
+// after the other: node t is final once t - 1 is, and is offered to the nodes behind it with its table entry or, for the dynamic pairs,
+// the whole connection function.
+struct DpFlatBlk : DpFlat {
+  int blk0;
+  DpFlatBlk(const Nodes &n, uint32_t f, int fl, int b0) : DpFlat{n, f, fl}, blk0(b0) {}
+  int tb(int rel) const { return rel >= blk0 ? 0 : DpFlat::tb(rel); }      // (a node of the block: "has a predecessor" is decided in (B))
+};
 void x_dp(GExec &, const Nodes &nd, const uint32_t *seq_lo, const uint32_t *seq_n, const uint32_t *seq_bin, const double *st_wt, uint32_t nseq, int flag) {
+  constexpr int B = 64;
+  std::vector<double> table(B * B), best(B); std::vector<int> bj(B), bm(B), cls(B);
   for (uint32_t s = 0; s < nseq; ++s) {
     const DpFlat S{nd, seq_lo[s], flag}; const int nn = (int)seq_n[s]; const double w = st_wt[seq_bin[s]];
-    for (int i = 0; i < nn; ++i) {
-      const DpNode n2 = S.node(i);
-      // candidates class by class, as the device kernel enumerates them (the class-folded connection score, the order-free tie rule)
-      double best = -1.0; int bj = -1, bmark = -1;
-      const int c2 = dp_class(n2.strand, n2.stop);
-      for (int c1 = 0; c1 < 4; ++c1) {
-        if (!dp_pair_possible(c1, c2)) continue;
-        for (int j = i - 1; j >= (int)nd.dp_min[S.first + i]; --j) {          // (descending on purpose: the tie rule must not lean on the order)
-          const DpNode n1 = S.node(j);
-          if (dp_class(n1.strand, n1.stop) != c1) continue;
-          double tot; int mark;
-          if (!dp_connection_class(c1, S, w, j, i, n2, tot, mark)) continue;
-          dp_take(tot, j, mark, best, bj, bmark);
+    for (int i0 = 0; i0 < nn; i0 += B) {
+      const int cnt = nn - i0 < B ? nn - i0 : B;
+      const DpFlatBlk SB(nd, seq_lo[s], flag, i0);
+      for (int k = 0; k < B * B; ++k) table[k] = -__builtin_inf();
+      for (int l = 0; l < cnt; ++l) {
+        const int i = i0 + l; const DpNode n2 = S.node(i); const int c2 = dp_class(n2.strand, n2.stop);
+        best[l] = -1.0; bj[l] = -1; bm[l] = -1; cls[l] = c2;
+        int lo = (int)nd.dp_min[S.first + i];
+        if (dp_class_pos_bounded(c2)) { while (lo < i && S.ndx(lo) < dp_pos_floor(n2.sv)) ++lo; }
+        for (int c1 = 0; c1 < 4; ++c1) {
+          if (!dp_pair_possible(c1, c2)) continue;
+          for (int j = i - 1; j >= lo; --j) {          // (descending on purpose: the tie rule must not lean on the order)
+            const DpNode n1 = S.node(j);
+            if (dp_class(n1.strand, n1.stop) != c1) continue;
+            double v; int mark;
+            if (j >= i0) {
+              if (dp_pair_dynamic(c1, c2)) continue;
+              if (dp_connection_s_class(c1, SB, w, j, i, n2, v, mark)) { if (mark != -1) g_fail("a static connection with an overlap mark"); table[(j - i0) * B + l] = v; }
+            } else if (dp_connection_class(c1, S, w, j, i, n2, v, mark)) dp_take(v, j, mark, best[l], bj[l], bm[l]);
+          }
         }
       }
-      if (bj >= 0) { nd.score[S.first + i] = best; nd.traceb[S.first + i] = bj; nd.ov_mark[S.first + i] = bmark; }
+      for (int t = 0; t < cnt; ++t) {
+        const uint32_t g = S.first + (uint32_t)(i0 + t);
+        if (bj[t] >= 0) { nd.score[g] = best[t]; nd.traceb[g] = bj[t]; nd.ov_mark[g] = bm[t]; }
+        const int c1 = cls[t];
+        if (dp_class_needs_tb(c1) && bj[t] < 0) continue;
+        const double sc_t = nd.score[g];
+        for (int l = t + 1; l < cnt; ++l) {
+          dp_take(sc_t + table[t * B + l], i0 + t, -1, best[l], bj[l], bm[l]);
+          if (dp_pair_dynamic(c1, cls[l])) {
+            double v; int mark;
+            if (dp_connection_class(c1, S, w, i0 + t, i0 + l, S.node(i0 + l), v, mark)) dp_take(v, i0 + t, mark, best[l], bj[l], bm[l]);
+          }
+        }
+      }
     }
   }
 }
