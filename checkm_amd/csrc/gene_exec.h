@@ -26,6 +26,7 @@ inline void g_sync(GExec &) {}
 template <class F> inline void g_map(GExec &, size_t n, F f) { for (size_t i = 0; i < n; ++i) f(i); }
 template <class F> inline void g_map_waves(GExec &, size_t n, F f) { for (size_t i = 0; i < n; ++i) f(i); }
 template <class T> inline T g_atomic_add(T *p, T v) { const T o = *p; *p = o + v; return o; }
+inline void g_count(uint32_t *p) { ++*p; }
 inline void g_atomic_or(unsigned long long *p, unsigned long long v) { *p |= v; }
 [[noreturn]] inline void g_fail(const char *msg) { throw std::runtime_error(msg); }
 }  // namespace gene
@@ -70,6 +71,18 @@ template <class F> inline void g_map_waves(GExec &e, size_t n, F f) {
   hipLaunchKernelGGL(g_map_waves_kernel<F>, dim3((unsigned)n), dim3(64), 0, e.st, n, f);
 }
 template <class T> __device__ __forceinline__ T g_atomic_add(T *p, T v) { return atomicAdd(p, v); }
+// ++*p for counters that most lanes of a wavefront share (the few dozen histogram bins of a bin's start-site training): one atomic per
+// distinct address and wavefront, carrying the number of lanes that named it.  The lanes that are active here may be any subset.
+__device__ __forceinline__ void g_count(uint32_t *p) {
+  const unsigned long long pv = (unsigned long long)p;
+  const unsigned me = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  for (;;) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pv), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pv >> 32));
+    const bool mine = (unsigned)pv == lo && (unsigned)(pv >> 32) == hi;
+    const unsigned long long same = __ballot(mine);
+    if (mine) { if (me == (unsigned)(__ffsll((long long)same) - 1)) atomicAdd(p, (uint32_t)__popcll(same)); break; }
+  }
+}
 __device__ __forceinline__ void g_atomic_or(unsigned long long *p, unsigned long long v) { atomicOr(p, v); }
 [[noreturn]] inline void g_fail(const char *msg) { throw Error(CKM_ERANGE, msg); }
 }  // namespace gene

@@ -475,7 +475,7 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
   d_subs.ensure(std::max<size_t>(1, subs.size()) * sizeof(SubChain));
   g_h2d(e, d_subs.p, subs.data(), subs.size() * sizeof(SubChain));
   uint64_t bases = 0; for (uint32_t b = 0; b < nbins; ++b) bases += (uint64_t)seq_len[b];
-  unsigned long long cap = std::max<unsigned long long>(1 << 16, bases / 2), n_all = 0;
+  unsigned long long cap = std::max<unsigned long long>(1 << 16, bases / 2) + (unsigned long long)subs.size() * 256, n_all = 0;      // (a chain takes its record slots 256 at a time)
   ChainArgs ca;
   ca.planes = d_flags.as<unsigned long long>(); ca.nwin = nwin; ca.seq_off = soff; ca.seq_len = slen_d; ca.nbins = nbins; ca.tt4 = tt == 4 ? 1 : 0;
   ca.sc = reinterpret_cast<const SubChain *>(d_subs.p); ca.nsc = (uint32_t)subs.size();
@@ -546,6 +546,7 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
     const uint32_t nb = nbins; const uint64_t nw = nwin;
     g_map(e, (size_t)n_all, [=] GLAM(size_t r) {
       const OrfRec q = rec[r]; const uint32_t s = q.seq;
+      if (s == 0xffffffffu) return;                                      // (a slot its chain reserved and did not use)
       if (xb[s] == -1 && sn[s] == 0) return;                            // (sequence of an untrained bin, or one without nodes)
       const size_t set = s < nb ? 0 : 1;
       const Nodes &nd = set == 0 ? t0 : t1;
@@ -774,7 +775,7 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
     std::vector<double> h_rw((size_t)nbins * 28, 0.0), h_tw((size_t)nbins * 3, 0.0), h_sth(nbins, 35.0);
     std::vector<std::array<double, 3>> tbg(nbins);
     g_zero(e, d_cnt.p, 0, (size_t)nbins * TC_SIZE * 4);
-    g_map(e, NT[0], [=] GLAM(size_t x) { if (tn.type[x] < G_STOP) g_atomic_add(&cnt[(size_t)tn.bin[x] * TC_SIZE + TC_TBG + tn.type[x]], 1u); });
+    g_map(e, NT[0], [=] GLAM(size_t x) { if (tn.type[x] < G_STOP) g_count(&cnt[(size_t)tn.bin[x] * TC_SIZE + TC_TBG + tn.type[x]]); });
     g_d2h(e, h_cnt.data(), cnt, h_cnt.size() * 4); g_sync(e);
     for (uint32_t b = 0; b < nbins; ++b) {
       double sum = 0.0;
@@ -790,7 +791,7 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
         const int t = tn.type[x];
         if (t == G_PAD) return;
         const uint32_t b = tn.bin[x]; const double *rwb = rw + (size_t)b * 28; uint32_t *cb = cnt + (size_t)b * TC_SIZE;
-        if (t != G_STOP) { if (tn.edge[x] != 1) g_atomic_add(&cb[TC_RBG + best_rbs(tn.rbs0[x], tn.rbs1[x], rwb)], 1u); return; }
+        if (t != G_STOP) { if (tn.edge[x] != 1) g_count(&cb[TC_RBG + best_rbs(tn.rbs0[x], tn.rbs1[x], rwb)]); return; }
         const double wt = stwt[b], *twb = tw + (size_t)b * 3;
         double best = 0.0; int bx = -1, brbs = 0, btype = 0; uint32_t by = 0;
         for_orf_starts(tn, ch, (uint32_t)x, [&](uint32_t y) {
@@ -800,12 +801,12 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
           if (v >= best) { best = tn.cscore[y] + wt * rwb[mr]; best += wt * twb[tn.type[y]]; bx = 1; by = y; btype = tn.type[y]; brbs = mr; }
         });
         if (bx == 1 && best >= sth[b]) {
-          g_atomic_add(&cb[TC_RREAL + brbs], 1u); g_atomic_add(&cb[TC_TREAL + btype], 1u);
+          g_count(&cb[TC_RREAL + brbs]); g_count(&cb[TC_TREAL + btype]);
           if (last) {
             const uint32_t s = tn.seq[by]; const GSeq q{code + soff[s], slen_d[s]};
             const int str = tn.strand[by], start = str == 1 ? tn.ndx[by] : q.slen - 1 - tn.ndx[by];
             int count = 0;
-            for (int i = 1; i < 45; ++i) { if (i > 2 && i < 15) continue; if (start - i >= 0) g_atomic_add(&cb[TC_UPS + count * 4 + q.at(str, start - i)], 1u); count++; }
+            for (int i = 1; i < 45; ++i) { if (i > 2 && i < 15) continue; if (start - i >= 0) g_count(&cb[TC_UPS + count * 4 + q.at(str, start - i)]); count++; }
           }
         }
       });
@@ -872,7 +873,7 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
           tn.mot[x] = m; tn.mot_score[x] = ms;
           uint32_t *cb = cnt + (size_t)b * TC_SIZE;
           if (stage == 0 && !count_bg0) return;
-          if (mot_len(m) == 0) { g_atomic_add(&cb[TC_ZBG], 1u); return; }
+          if (mot_len(m) == 0) { g_count(&cb[TC_ZBG]); return; }
           if (stage == 0) {
             for (int i = 3; i >= 0; --i) for (int j = start - 18 - i; j <= start - 6 - i; ++j) { if (j < 0) continue; g_atomic_add(&bg0[((size_t)k * 4 + i) * 4096 + upw_mer(upw, start, i + 3, j)], 1u); }
           } else if (stage == 1) {
@@ -897,11 +898,11 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
             if (v >= best) { best = tn.cscore[y] + wt * tn.mot_score[y]; best += wt * twb[tn.type[y]]; bx = 1; by = y; }
           });
           if (bx != 1 || !(best >= sth[b])) return;
-          g_atomic_add(&cb[TC_NGENES], 1u); g_atomic_add(&cb[TC_TREAL + tn.type[by]], 1u);
+          g_count(&cb[TC_NGENES]); g_count(&cb[TC_TREAL + tn.type[by]]);
           const uint32_t s = tn.seq[by]; const GSeq q{code + soff[s], slen_d[s]};
           const int str = tn.strand[by], start = str == 1 ? tn.ndx[by] : q.slen - 1 - tn.ndx[by];
           const uint32_t m = tn.mot[by]; const unsigned long long upw = tn.upw[by];
-          if (mot_len(m) == 0) g_atomic_add(&cb[TC_ZREAL], 1u);
+          if (mot_len(m) == 0) g_count(&cb[TC_ZREAL]);
           else if (stage == 0) {
             for (int i = 3; i >= 0; --i) for (int j = start - 18 - i; j <= start - 6 - i; ++j) { if (j < 0) continue; g_atomic_add(&real0[((size_t)k * 4 + i) * 4096 + upw_mer(upw, start, i + 3, j)], 1u); }
           } else if (stage == 1) {
@@ -914,7 +915,7 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
           } else g_atomic_add(&mreal[(size_t)k * MOT_N + ((size_t)(mot_len(m) - 3) * 4 + mot_spacendx(m)) * 4096 + mot_ndx(m)], 1u);
           if (last) {
             int count = 0;
-            for (int i = 1; i < 45; ++i) { if (i > 2 && i < 15) continue; if (start - i >= 0) g_atomic_add(&cb[TC_UPS + count * 4 + q.at(str, start - i)], 1u); count++; }
+            for (int i = 1; i < 45; ++i) { if (i > 2 && i < 15) continue; if (start - i >= 0) g_count(&cb[TC_UPS + count * 4 + q.at(str, start - i)]); count++; }
           }
         });
         g_d2h(e, h_cnt.data(), cnt, h_cnt.size() * 4);

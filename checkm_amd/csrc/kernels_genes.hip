@@ -103,8 +103,24 @@ __global__ void __launch_bounds__(64) chain_kernel(ChainArgs a) {
   unsigned long long *node_plane = a.node_planes + (uint64_t)((si < a.nbins ? 0 : 2) + (rev ? 1 : 0)) * nwin;
   OrfRecK *rec = reinterpret_cast<OrfRecK *>(a.rec);
   uint32_t tbase = 0;                                               // events of this chain so far
-  // (record slots are taken once per wavefront and step -- one atomic on the shared counter for all the nodes of 64 codons: a counter bumped
-  //  node by node was the kernel's whole duration, 7 M same-address atomics at ~9 ns for a 48-bin call)
+  // Record slots are taken from the shared counter CHUNK at a time (round 6): one atomic per ~20 steps.  Round 5 took them once per step
+  // -- 6 M same-address atomics at ~7 ns WERE the kernel's 42 ms for a 48-bin call, with every wavefront of the call asleep on the
+  // counter (31 % of the call's wavefront-cycles: profiles/r06d) -- round 4 once per node.  The slots a wavefront does not use are
+  // marked (seq = ~0) and skipped by the scatter.
+  constexpr unsigned long long CHUNK = 256;
+  unsigned long long chunk_next = 0, chunk_end = 0;                 // uniform
+  auto take = [&](uint32_t nev) -> unsigned long long {
+    if (chunk_next + nev > chunk_end) {
+      for (unsigned long long k = chunk_next + (unsigned)lane; k < chunk_end; k += 64) if (k < a.cap) rec[k].seq = 0xffffffffu;
+      const unsigned long long need = nev > CHUNK ? nev : CHUNK;
+      unsigned long long slot = 0;
+      if (lane == 0) slot = atomicAdd(a.nrec, need);
+      slot = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(slot >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(slot & 0xffffffffull));
+      chunk_next = slot; chunk_end = slot + need;
+    }
+    const unsigned long long s0 = chunk_next; chunk_next += nev;
+    return s0;
+  };
   auto emit = [&](int ndx_s, int type, int sv_s, int edge, uint32_t t, unsigned long long k) {
     const int ndx = rev ? slen - 1 - ndx_s : ndx_s;
     const uint64_t g = base + (uint64_t)ndx;
@@ -158,10 +174,7 @@ __global__ void __launch_bounds__(64) chain_kernel(ChainArgs a) {
     const uint32_t before = (uint32_t)__popcll(events & below), nev = (uint32_t)__popcll(events);
     const uint32_t t = tbase + before;
     unsigned long long slot0 = 0;
-    if (nev) {
-      if (lane == 0) slot0 = atomicAdd(a.nrec, (unsigned long long)nev);
-      slot0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(slot0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(slot0 & 0xffffffffull));
-    }
+    if (nev) slot0 = take(nev);
     if (start_node) emit(j, st, my_last, 0, t, slot0 + before);
     if (edge_node) emit(j, 0, my_last, 1, t, slot0 + before);
     if (stop_node) emit(my_last, 3, j, my_last_real ? 0 : 1, t, slot0 + before);
@@ -172,7 +185,8 @@ __global__ void __launch_bounds__(64) chain_kernel(ChainArgs a) {
       saw = (starts & (ql == 63 ? 0ull : (~0ull << (ql + 1)))) != 0ull;
     } else saw = saw || starts != 0ull;
   }
-  if (saw) { if (lane == 0) emit(last, 3, frame - 6, last_real ? 0 : 1, tbase, atomicAdd(a.nrec, 1ull)); tbase++; }
+  if (saw) { const unsigned long long k = take(1); if (lane == 0) emit(last, 3, frame - 6, last_real ? 0 : 1, tbase, k); tbase++; }
+  for (unsigned long long k = chunk_next + (unsigned)lane; k < chunk_end; k += 64) if (k < a.cap) rec[k].seq = 0xffffffffu;
   if (lane == 0) a.chain_cnt[sc.chain] = tbase;
 }
 void x_chain(GExec &e, const ChainArgs &a) {

@@ -11,6 +11,8 @@
 #   pmc3[:BINS]      three separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*) of ONE cfg3 step (default 48 bins)    -> pmc3_{fetch,write,sq}/
 #   pmc2             the same three passes of ONE cfg2 search                                                           -> pmc_{fetch,write,sq}/
 #   valu             tools/ubench/valu_rates (VALU issue rates of the SSV row body)                                     -> valu_rates.txt
+#   genes_prof[:BINS] one ckm_genes_call over BINS (default 48) synthetic 2 Mb bins (tools/gene_profile.py): plain with CKM_TRACE=1, rocprofv3 --kernel-trace --stats,
+#                    and a separate --pmc pass (SQ counters)                                                             -> genes_prof/{plain.txt,stats/,pmc/}, genes_prof.txt
 #   genes[:THREADS]  the gene-calling tests + `bench.py --config genes` with CKM_TRACE=1 (phase times of a call on stderr)     -> pytest_genes.txt, genes.json / .err
 # Counter passes never combine --pmc with anything but --kernel-trace (the pool's gpurun refuses other combinations).
 set -u
@@ -40,6 +42,12 @@ for item in "$@"; do
             done ;;
     genes)  python -m pytest tests/test_gpu_genes.py tests/test_gpu_orf.py -m gpu -x -q 2>&1 | tail -5 > "$OUT/pytest_genes.txt"; cat "$OUT/pytest_genes.txt"
             ( [ -n "$arg" ] && export CKM_GENE_THREADS=$arg; CKM_TRACE=1 python bench.py --config genes > "$OUT/genes.json" 2> "$OUT/genes.err" ); tail -c 700 "$OUT/genes.json" ;;
+    genes_prof) G="$OUT/genes_prof"; mkdir -p "$G"
+            CKM_TRACE=1 python tools/gene_profile.py "${arg:-48}" 11 2 > "$G/plain.txt" 2>&1
+            (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$G/stats" -o g -- python "$ROOT/tools/gene_profile.py" "${arg:-48}" 11 2 > "$G/stats.txt" 2>&1)
+            (cd /tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d "$G/pmc" -o g -- python "$ROOT/tools/gene_profile.py" "${arg:-48}" 11 1 > "$G/pmc.txt" 2>&1)
+            rm -f "$G"/stats/*kernel_trace.csv "$G"/pmc/*kernel_trace.csv
+            python tools/gene_profile_summary.py "$G" > "$OUT/genes_prof.txt" 2>&1; head -60 "$OUT/genes_prof.txt" ;;
     valu)   (cd tools/ubench && hipcc --offload-arch=gfx950 -O3 -o valu_rates valu_rates.hip 2>/dev/null; ./valu_rates) > "$OUT/valu_rates.txt" 2>&1; tail -20 "$OUT/valu_rates.txt" ;;
     *)      echo "unknown item: $item" ;;
   esac
