@@ -848,6 +848,12 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
       const int32_t *slot = d_slot.as<int32_t>(); double *mw = d_mw.as<double>(), *nm = d_nm.as<double>();
       uint32_t *mbg = d_mbg.as<uint32_t>(), *mreal = d_mreal.as<uint32_t>(), *bg0 = d_bg0.as<uint32_t>(), *real0 = d_real0.as<uint32_t>();
       upstream_windows(tn, NT[0]);
+      // the twenty rounds visit the nodes of THESE bins only: their 256-node blocks, one after the other (a bin's range starts at a multiple of 256)
+      std::vector<uint32_t> h_blk;
+      for (uint32_t b : ns_bins) for (uint32_t k = 0; k < (seq_n[b] + 255) / 256; ++k) h_blk.push_back(seq_lo[b] + k * 256);
+      GBuf d_blk; d_blk.ensure(std::max<size_t>(1, h_blk.size()) * 4);
+      g_h2d(e, d_blk.p, h_blk.data(), h_blk.size() * 4);
+      const uint32_t *blk = d_blk.as<uint32_t>(); const size_t n_ns = h_blk.size() * 256;
       std::vector<std::vector<double>> h_mw(nsl, std::vector<double>(MOT_N, 0.0));
       std::vector<double> h_nm(nbins, 0.0);
       std::vector<uint32_t> h_mbg(nsl * MOT_N), h_mreal(nsl * MOT_N), h_bg0(nsl * 4 * 4096), h_real0(nsl * 4 * 4096);
@@ -863,7 +869,8 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
         else { g_zero(e, d_mbg.p, 0, nsl * MOT_N * 4); g_zero(e, d_mreal.p, 0, nsl * MOT_N * 4); }
         const int count_bg0 = it == 0;
         // the best motif of every start node under the current weights, and the background counts
-        g_map(e, NT[0], [=] GLAM(size_t x) {
+        g_map(e, n_ns, [=] GLAM(size_t xi) {
+          const size_t x = (size_t)blk[xi >> 8] + (xi & 255);
           if (tn.type[x] >= G_STOP || tn.edge[x] == 1) return;
           const uint32_t b = tn.bin[x]; const int k = slot[b];
           if (k < 0) return;
@@ -886,7 +893,8 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
           } else g_atomic_add(&mbg[(size_t)k * MOT_N + ((size_t)(mot_len(m) - 3) * 4 + mot_spacendx(m)) * 4096 + mot_ndx(m)], 1u);
         });
         // the best start of every open reading frame, and the counts of the ones above the threshold
-        g_map(e, NT[0], [=] GLAM(size_t x) {
+        g_map(e, n_ns, [=] GLAM(size_t xi) {
+          const size_t x = (size_t)blk[xi >> 8] + (xi & 255);
           if (tn.type[x] != G_STOP) return;
           const uint32_t b = tn.bin[x]; const int k = slot[b];
           if (k < 0) return;

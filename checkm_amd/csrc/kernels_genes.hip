@@ -205,9 +205,13 @@ __global__ void __launch_bounds__(64) gc_bias_kernel(Nodes nd, const uint32_t *_
     const uint32_t i = i0 + lane;
     int cls = 3; double term = 0.0;                                 // class 3: not a start node
     if (i < nn && nd.type[lo + i] < G_STOP) { cls = nd.gcb_cls[lo + i]; term = nd.gcb_term[lo + i]; }
-    const int cnt = (int)(nn - i0 < 64u ? nn - i0 : 64u);
-    for (int l = 0; l < cnt; ++l) {
-      const int c = __shfl(cls, l); const double v = __shfl(term, l);
+    // one after the other, in node order: lane l's class and term through v_readlane (uniform), a scalar branch, one add -- a __shfl per
+    // element (ds_bpermute: an LDS round trip) made this kernel 16 ms of a 48-bin call's critical path
+    const int tlo = (int)(__builtin_bit_cast(unsigned long long, term) & 0xffffffffull), thi = (int)(__builtin_bit_cast(unsigned long long, term) >> 32);
+#pragma unroll
+    for (int l = 0; l < 64; ++l) {
+      const int c = __builtin_amdgcn_readlane(cls, l);
+      const double v = __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(thi, l) << 32) | (unsigned)__builtin_amdgcn_readlane(tlo, l));
       if (c == 0) acc0 += v; else if (c == 1) acc1 += v; else if (c == 2) acc2 += v;
     }
   }
