@@ -1,6 +1,6 @@
-"""TreeParser.getBinMarkerSets and its lookups on a hand-built genome tree (the reference: checkm/treeParser.py:151-629).  The expected
-values are derived by hand from the reference's rules; the reference itself cannot run here (it needs dendropy), so this pins the
-restatement against the rules, not against the reference's output."""
+"""TreeParser.getBinMarkerSets and its lookups (the reference: checkm/treeParser.py:151-629): hand-derived cases on a hand-built genome
+tree, and -- round 6 -- goldens written by the REFERENCE's own class on synthetic placed trees (tools/gen_tree_golden.py; the reference
+needs DendroPy, which this image lacks: tests/shim/dendropy.py stands in for the calls it makes)."""
 import os
 
 import pytest
@@ -162,28 +162,81 @@ def test_report_lookups(world):
     assert meta['binD']['taxonomy'] == 'unresolved' and meta['binD']['# genomes'] == 'NA'
 
 
+def _run_mirror_on(case, tmp_path):
+    data = tmp_path / 'data'
+    (data / 'genome_tree').mkdir(parents=True)
+    (data / 'genome_tree' / 'genome_tree.metadata.tsv').write_text(case['metadata'])
+    (data / 'genome_tree' / 'missing_duplicate_genes_50.tsv').write_text(case['missing_duplicate'])
+    out = tmp_path / 'out'
+    for b in case['bins']:
+        (out / 'bins' / b).mkdir(parents=True)
+    (out / 'storage' / 'tree').mkdir(parents=True)
+    (out / 'storage' / 'tree' / 'concatenated.tre').write_text(case['tree'])
+    return str(data), str(out)
+
+
+def _rows(p):
+    out = {}
+    lines = open(p).read().splitlines()
+    assert lines[0] == DefaultValues.LINEAGE_MARKER_FILE_HEADER
+    for line in lines[1:]:
+        t = line.split('\t')
+        out[t[0]] = [[t[2 + 4 * i], t[3 + 4 * i], t[4 + 4 * i], sorted(sorted(s) for s in parse_set_literal(t[5 + 4 * i]))] for i in range(int(t[1]))]
+    return out, [ln.split('\t')[0] for ln in lines[1:]]
+
+
+def test_reference_goldens(tmp_path):
+    """checkm/treeParser.py itself, run by tools/gen_tree_golden.py on synthetic placed trees (bins on random edges, on the two branches
+    below the root, beside each other, absent; sparse and dense taxonomy; every selection switch), wrote tests/golden/tree_cases.json:
+    the mirror must write the same lineage.ms rows in the same order and return the same taxonomy / branch / lineage statistics."""
+    import json
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'tree_cases.json')))
+    old = DefaultValues.CHECKM_DATA_DIR
+    try:
+        nsets = 0
+        for k, case in enumerate(gold['cases']):
+            data, out = _run_mirror_on(case, tmp_path / ('c%d' % k))
+            DefaultValues.set_data_root(data)
+            res = _Results(**{b: tuple(v) for b, v in case['hits'].items()})
+            tp = TreeParser()
+            for call in case['marker_sets']:
+                a = call['args']
+                path = os.path.join(out, 'lineage.ms')
+                tp.getBinMarkerSets(out, path, a['numGenomesMarkers'], a['bootstrap'], a['bNoLineageSpecificRefinement'], a['bForceDomain'], a['bRequireTaxonomy'],
+                                    res, a['minUnique'], a['maxMulti'])
+                rows, order = _rows(path)
+                assert order == call['order'], (k, a)
+                assert rows == call['rows'], (k, a)
+                nsets += sum(len(v) for v in rows.values())
+            srt = sorted(case['bins'])
+            assert tp.getBinTaxonomy(out, srt) == case['taxonomy'], k
+            assert tp.getInsertionBranchId(out, srt) == case['branch'], k
+            assert tp.readLineageMetadata(out, srt) == case['lineage_metadata'], k
+        assert nsets > 500
+    finally:
+        DefaultValues.set_data_root(old)
+
+
 def test_with_the_reference_when_it_can_run(world):
-    """Where dendropy exists (not in this image) the reference's own TreeParser must write the same file."""
-    pytest.importorskip('dendropy')
+    """Where the reference package is on disk (this container, not the GPU box) its own TreeParser -- on tests/shim/dendropy.py, the
+    stand-in for the DendroPy calls it makes -- must write the same file for the hand-built tree of this module."""
     if not os.path.isdir('/root/reference/checkm'):
         pytest.skip('no reference package')
     import subprocess
     import sys
     data = DefaultValues.CHECKM_DATA_DIR
+    tre = os.path.join(world, 'storage', 'tree', 'concatenated.tre')
+    import re
+    text = open(tre).read()
+    open(tre, 'w').write(re.sub(r'\{\d+\}', '', text))            # (pplacer's edge numbers: the mirror's reader skips them, DendroPy would not take them)
     code = ("import sys\nfrom checkm.treeParser import TreeParser\n"
             "class H:\n    def countUniqueHits(self): return (40, 0)\n"
             "class R:\n    results = {b: H() for b in ('binA', 'binB', 'binC', 'binD')}\n"
             "TreeParser().getBinMarkerSets(%r, %r, 30, 0, False, False, False, R(), 10, 10)\n" % (world, os.path.join(world, 'ref.ms')))
-    env = dict(os.environ, PYTHONPATH='/root/reference', CHECKM_DATA_PATH=data)
+    shim = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'shim')
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join(['/root/reference', shim]), CHECKM_DATA_PATH=data, PYTHONDONTWRITEBYTECODE='1')
     r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-1000:]
     res = _Results(binA=(40, 0), binB=(40, 0), binC=(40, 0), binD=(40, 0))
     _got, path = _select(world, res, bNoLineageSpecificRefinement=False)
-
-    def rows(p):
-        out = {}
-        for line in open(p).read().splitlines()[1:]:
-            t = line.split('\t')
-            out[t[0]] = [(t[2 + 4 * i], t[3 + 4 * i], t[4 + 4 * i], sorted(sorted(s) for s in parse_set_literal(t[5 + 4 * i]))) for i in range(int(t[1]))]
-        return out
-    assert rows(path) == rows(os.path.join(world, 'ref.ms'))
+    assert _rows(path) == _rows(os.path.join(world, 'ref.ms'))
