@@ -220,7 +220,7 @@ void rescore_envelopes(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, co
       b.work.push_back(w); pos = end;
     }
     const uint64_t zone = (pos + 31) & ~(uint64_t)31;          // match-state residues of the OA paths (alignment requests), one copy back
-    if (paths) for (auto &w : b.work) w.path_off += zone;
+    if (paths) for (auto &w : b.work) { w.path_off += zone; if (pps) w.path_off |= FB_PATH_WITH_PP; }
     ctx->ws.ensure((zone + path_total) * 4 + 256);
     run_fb(ctx, p, s, b, true, true, true, nullptr);
     std::vector<int32_t> zone_host;
@@ -238,7 +238,7 @@ void rescore_envelopes(Worker *ctx, const ckm_profiles *p, const ckm_seqs *s, co
       if (paths) {
         std::vector<int32_t> &pv = (*paths)[done + k];
         pv.assign((size_t)p->hmm[r.model].M, 0);
-        const size_t at = (size_t)(b.work[k].path_off - 1 - zone);
+        const size_t at = (size_t)((b.work[k].path_off & ~FB_PATH_WITH_PP) - 1 - zone);
         if (o.ok) std::copy(zone_host.begin() + at, zone_host.begin() + at + pv.size(), pv.begin());
         if (pps) {
           std::vector<float> &qv = (*pps)[done + k];

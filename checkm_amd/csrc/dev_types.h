@@ -65,6 +65,7 @@ struct FwdOut {              // per pair slot
   float xC; int32_t nscale;
 };
 
+constexpr uint64_t FB_PATH_WITH_PP = 1ull << 63;      // FbWork::path_off: the posterior floats behind the path were asked for
 struct FbWork {              // one Forward/Backward/OA work item (whole sequence, or one envelope)
   uint32_t model, seq;
   int32_t  i0, Ld, Lcfg, multihit;     // subsequence [i0, i0+Ld) of the target; length model configured for Lcfg
@@ -73,8 +74,9 @@ struct FbWork {              // one Forward/Backward/OA work item (whole sequenc
                                        // full mode -> (Ld+1)*3 [ppN ppJ ppC], then 128B-aligned (Ld+1)*5 [oN oB oE oJ oC]
   uint64_t mxf_off, mxb_off;           // float offsets of the (Ld+1) x 3*Mp matrices (full == 1: q-major planes; full == 2: (Ld+1) x 4*Mp, cell-major float4 {M, I, D, 0})
   uint64_t path_off;                   // int32 offset + 1 of Mp entries: residue (1-based, within the envelope) emitted by each match state of the
-                                       // OA path, 0 = node not matched (alignment requests); 0 = no path wanted.  When the item's posterior rows have a matrix of
-                                       // their own (mxb_off != mxf_off) Ld + 1 floats follow: the posterior probability of each residue on the path
+                                       // OA path, 0 = node not matched (alignment requests); 0 = no path wanted.  With FB_PATH_WITH_PP set (the host
+                                       // reserved them; the item's posterior rows then have a matrix of their own, mxb_off != mxf_off) Ld + 1 floats
+                                       // follow: the posterior probability of each residue on the path
   uint32_t slot, full;                 // full: 0 parser (specials only), 1 matrix rows M,I, 2 matrix rows M,I,D (trace ensemble)
   uint32_t cand, pass;                 // device-driven cascade: candidate id of a parser item; id of its record in the pass table
 };

@@ -1144,6 +1144,7 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
         pl[r] = pe - pb >= 2 ? (uint32_t)((pe - pb - 2) / 3 + 1) : 0u;
       });
     }
+    if (2 * bases / 3 + ngenes >= 0xfffffff0ull) g_fail("more than 2^32 amino acids in one gene-calling batch");      // (32-bit protein offsets)
     x_scan_u32(e, pl, ngenes, d_scan);
     std::vector<uint32_t> h_pl(ngenes + 1);
     g_d2h(e, h_pl.data(), pl, (ngenes + 1) * 4); g_sync(e);
@@ -1180,6 +1181,7 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
     tp("records and proteins");
   } else {
     for (uint32_t b = 0; b < nbins; ++b) { out.bin_uses_sd[b] = (uint8_t)(trained[b] ? tr[b].uses_sd : 0); out.bin_gc[b] = tr[b].gc; }
+    g_sync(e);          // (the buffers of this function go back to the block cache when it returns: nothing of this call may still be queued)
   }
 }
 

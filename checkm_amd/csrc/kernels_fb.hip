@@ -561,10 +561,12 @@ __device__ __forceinline__ void oa_item(const FbWork &w, const DevModel &md, flo
   int i = L, k = 0, st = 0;      // 0=C 1=E 2=M 3=I 4=D
   int fi = 0, fk = 0, li = 0, lk = 0;
   bool done = false;
-  int32_t *path = w.path_off ? reinterpret_cast<int32_t *>(ws) + (w.path_off - 1) : nullptr;    // alignment requests: residue of every match state
+  const uint64_t path_at = w.path_off & ~FB_PATH_WITH_PP;
+  int32_t *path = path_at ? reinterpret_cast<int32_t *>(ws) + (path_at - 1) : nullptr;    // alignment requests: residue of every match state
   // ... followed, when the posterior rows have a matrix of their own (they survive the OA fill), by L + 1 floats: the posterior probability of
   // every residue on the path in the state that emits it (what hmmsearch prints as the PP line of a domain alignment)
-  float *ppres = (path && w.mxb_off != w.mxf_off) ? reinterpret_cast<float *>(path + Mp) : nullptr;
+  // (the L + 1 posterior floats behind the path exist only where the host reserved them -- FB_PATH_WITH_PP -- and need rows that outlive the fill)
+  float *ppres = (path && (w.path_off & FB_PATH_WITH_PP) && w.mxb_off != w.mxf_off) ? reinterpret_cast<float *>(path + Mp) : nullptr;
   if (path) { for (int c = lane; c < Mp; c += 64) path[c] = 0; if (ppres) for (int c = lane; c <= L; c += 64) ppres[c] = 0.f; __threadfence(); __builtin_amdgcn_wave_barrier(); }
 #define tBM_(c) tr.at(0, (c))
 #define tMM_(c) tr.at(1, (c))

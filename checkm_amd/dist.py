@@ -97,6 +97,22 @@ def barrier():
         dist.barrier()
 
 
+def agree(ok):
+    """Every rank says whether it is well; True only if all are (one all_reduce -- it also is the barrier of the place it stands at).
+    A rank that has failed calls agree(False) BEFORE it exits, so that its peers, who meet it here, end too instead of waiting in a
+    collective for a rank that is gone."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dev = collective_device()
+    if dev is not None:
+        t = t.to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.cpu()[0]))
+
+
 def world_size():
     import torch.distributed as dist
     if emulated() is not None:

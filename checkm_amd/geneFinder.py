@@ -25,9 +25,13 @@ def read_contigs_bytes(fastaFile):
     with opener(fastaFile, 'rb') as f:
         data = f.read()
     out = []
-    start = data.find(b'>') if not data.startswith(b'>') else 0
-    if start < 0:
-        return out
+    # a record begins with '>' at the START OF A LINE (readFasta looks at line[0]); whatever precedes the first one is skipped
+    if data.startswith(b'>'):
+        start = 0
+    else:
+        start = data.find(b'\n>') + 1
+        if start <= 0:
+            return out
     for rec in data[start + 1:].split(b'\n>'):
         head, _nl, body = rec.partition(b'\n')
         hs = head.split(None, 1)
@@ -183,9 +187,11 @@ def call_bin_files(jobs, bNucORFs=False, max_bases=None, logger=None, on_bin_don
     """jobs = [(nucleotide FASTA of a bin, directory for genes.faa / genes.gff [/ genes.fna])].  Both translation tables per bin from the
     device, the reference's choice between them, prodigal's file layout.  Returns {binFile: (best table, {11: density, 4: density})}.
     The bins go through the device in sub-batches of <= max_bases (CKM_GENE_BATCH_MB, default 128 Mbase), several calls in flight.
-    Raises ValueError -- before anything is written -- when a bin is below the 20 kb the gene finder can train on (the pre-trained
-    `-p meta` models CheckM would use below 100 kb are not built), and after the other bins' files are written when a trained bin
-    yields no genes (the reference treats empty prodigal output as a failure, checkm/prodigal.py:96-115).  on_bin_done(binFile) is called
+    Raises ValueError when a bin is below the 20 kb the gene finder can train on (the pre-trained `-p meta` models CheckM would use
+    below 100 kb are not built): BEFORE anything is written for files below 200 kB and for compressed files, whose bases are counted
+    up front; a larger plain file is taken to hold enough and is counted when its sub-batch is read, so one that is mostly headers is
+    refused then -- earlier sub-batches' files exist and on_bin_done has fired for them.  Raises after the other bins' files are written
+    when a trained bin yields no genes (the reference treats empty prodigal output as a failure, checkm/prodigal.py:96-115).  on_bin_done(binFile) is called
     from a worker thread as soon as a bin's files are complete (MarkerGeneFinder.find scans the first bins while the last are called)."""
     import os
     import threading

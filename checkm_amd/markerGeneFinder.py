@@ -264,8 +264,18 @@ class MarkerGeneFinder(object):
         """An error of the gene-calling helper ends the run the way the reference ends it (logger.error + sys.exit, checkm/prodigal.py:100-115)."""
         if self._gene_error:
             e = self._gene_error[0]
-            self.logger.error(str(e) if isinstance(e, ValueError) else "gene calling failed: %r" % (e,))
-            sys.exit(1)
+            self._fail(str(e) if isinstance(e, ValueError) else "gene calling failed: %r" % (e,))
+
+    def _fail(self, msg):
+        """logger.error + sys.exit(1), the reference's way out (checkm/hmmer.py:131-137) -- after telling the other ranks of a multi-GPU
+        run, who would otherwise wait for this one in find()'s closing collective until it times out."""
+        from checkm_amd import dist as cdist
+        self.logger.error(msg)
+        try:
+            cdist.agree(False)
+        except Exception:               # noqa: BLE001  (the process group itself may be what failed)
+            pass
+        sys.exit(1)
 
     def _wait_genes(self, path):
         ev = self._gene_events.get(path)
@@ -306,8 +316,7 @@ class MarkerGeneFinder(object):
         try:
             profiles = profiles_for(ctx, db)
         except _lib.CkmError as e:
-            self.logger.error('marker-gene scan failed: %s' % e)
-            sys.exit(1)
+            self._fail('marker-gene scan failed: %s' % e)
         heads = profiles.headers
         models_of = model_lists(heads, allIds, wanted, self.logger, db)
         # ---- this rank's shard (weights = file size x models) ----
@@ -325,6 +334,48 @@ class MarkerGeneFinder(object):
         myFiles = [binFiles[i] for i in mine]
         self._gene_events, self._gene_sizes, self._gene_error, self._gene_thread = {}, {}, [], None
         binIds, faa, read_from = self._geneFiles(myFiles, outDir, bNucORFs, bCalledGenes)
+        # (from here to the end of the scan an exception of any kind must first wait for the gene-calling helper thread, which keeps issuing
+        #  device calls: _scan_batches' finally)
+        try:
+            out, batches, parts, totals = self._scan_batches(ctx, profiles, db, heads, allIds, models_of, binIds, read_from, outDir, tableOut, hmmerOut, bKeepAlignment)
+        except _lib.CkmError as e:
+            self._check_genes()
+            self._fail('marker-gene scan failed: %s' % e)
+        self._check_genes()
+        self._gene_events, self._gene_thread = {}, None
+        where = {}
+        for k, batch in enumerate(batches):
+            for b, i in enumerate(batch):
+                where[binIds[i]] = (k, b)
+        key = (os.path.abspath(outDir), tableOut)
+        release_key(key)
+        SCAN_CACHE[key] = dict(ctx=ctx, profiles=profiles, parts=parts, where=where, owned=set(binIds), world=world,
+                               all_bins=list(allIds), totals=totals)        # totals: stage counters summed over this rank's ckm_search calls
+        if world > 1 and not cdist.agree(True):      # every rank's tables are on disk before anyone reads them -- or some rank has failed
+            self.logger.error('marker-gene scan failed on another rank')
+            sys.exit(1)
+        if out is None:
+            out = models_for_bins(heads, allIds, models_of)
+        self.logger.info("    Finished processing %d of %d (100.00%%) bins." % (len(allIds), len(allIds)))
+        return out
+
+    def _scan_batches(self, ctx, profiles, db, heads, allIds, models_of, binIds, read_from, outDir, tableOut, hmmerOut, bKeepAlignment):
+        """The scan of this rank's bins, batch by batch on two lanes; returns (find()'s return value if it was built beside the scan,
+        batches, parts, totals).  Whatever ends it, the gene-calling helper thread has been joined and the pending copies are done."""
+        from concurrent.futures import ThreadPoolExecutor
+        try:
+            return self._scan_batches_body(ctx, profiles, db, heads, allIds, models_of, binIds, read_from, outDir, tableOut, hmmerOut, bKeepAlignment)
+        finally:
+            if self._gene_thread is not None:
+                self._gene_thread.join()
+            for f in self._pending_copies:           # bins/<binId>/genes.faa is complete before find() returns
+                f.result()
+            if self._copy_pool is not None:
+                self._copy_pool.shutdown()
+            self._pending_copies, self._copy_pool = [], None
+
+    def _scan_batches_body(self, ctx, profiles, db, heads, allIds, models_of, binIds, read_from, outDir, tableOut, hmmerOut, bKeepAlignment):
+        from concurrent.futures import ThreadPoolExecutor
         # (a bin whose genes are still being called is planned with an estimate: proteins of a bacterial genome take about 0.36 of its bases)
         sizes = [self._gene_sizes[f] if f in self._gene_events else (os.path.getsize(f) if os.path.exists(f) else 0) for f in read_from]
         nmod = [len(models_of[b]) if models_of.get(b) is not None else profiles.n for b in binIds]
@@ -422,46 +473,17 @@ class MarkerGeneFinder(object):
             finally:
                 started[j].set()
         out = None
-        try:
-            if len(lanes) == 1:
-                lane_run(0)
-            else:
-                with ThreadPoolExecutor(max_workers=len(lanes)) as ex:
-                    futs = [ex.submit(lane_run, j) for j in range(len(lanes))]
-                    for ev in started:
-                        ev.wait(30.0)
-                    out = models_for_bins(heads, allIds, models_of)          # (the return value is built while the lanes scan: 0.06 s per pass of a 1000-bin run)
-                    for f in futs:
-                        f.result()
-        except _lib.CkmError as e:
-            if self._gene_thread is not None:
-                self._gene_thread.join()
-            self._check_genes()
-            self.logger.error('marker-gene scan failed: %s' % e)
-            sys.exit(1)
-        finally:
-            if self._gene_thread is not None:
-                self._gene_thread.join()
-            for f in self._pending_copies:           # bins/<binId>/genes.faa is complete before find() returns
-                f.result()
-            if self._copy_pool is not None:
-                self._copy_pool.shutdown()
-            self._pending_copies, self._copy_pool = [], None
-        self._check_genes()
-        self._gene_events, self._gene_thread = {}, None
-        for k, batch in enumerate(batches):
-            for b, i in enumerate(batch):
-                where[binIds[i]] = (k, b)
-        key = (os.path.abspath(outDir), tableOut)
-        release_key(key)
-        SCAN_CACHE[key] = dict(ctx=ctx, profiles=profiles, parts=parts, where=where, owned=set(binIds), world=world,
-                               all_bins=list(allIds), totals=totals)        # totals: stage counters summed over this rank's ckm_search calls
-        if world > 1:
-            cdist.barrier()             # every rank's tables are on disk before anyone reads them
-        if out is None:
-            out = models_for_bins(heads, allIds, models_of)
-        self.logger.info("    Finished processing %d of %d (100.00%%) bins." % (len(allIds), len(allIds)))
-        return out
+        if len(lanes) == 1:
+            lane_run(0)
+        else:
+            with ThreadPoolExecutor(max_workers=len(lanes)) as ex:
+                futs = [ex.submit(lane_run, j) for j in range(len(lanes))]
+                for ev in started:
+                    ev.wait(30.0)
+                out = models_for_bins(heads, allIds, models_of)          # (the return value is built while the lanes scan: 0.06 s per pass of a 1000-bin run)
+                for f in futs:
+                    f.result()
+        return out, batches, parts, totals
 
     def _find_with_workers(self, devs, binFiles, outDir, tableOut, hmmerOut, markerFile, bKeepAlignment, bNucORFs, bCalledGenes):
         """find() on a multi-GPU node: one worker process per device (checkm_amd/workers.py), spawned here as the reference's find()

@@ -11,6 +11,8 @@ import functools
 import ctypes as C
 import gzip
 import logging
+import threading
+from collections.abc import MutableMapping
 import os
 import pickle
 import sys
@@ -258,49 +260,82 @@ def wanted_model(name, acc, keys):
     return (acc is not None and acc in keys) or (name is not None and name in keys)
 
 
-class _LazyLineageSets(dict):
-    """{binId: BinMarkerSets} whose values are built from their marker-file line the first time they are looked at; every way of
-    reaching a value goes through _make (iteration over values / items parses what is left)."""
+class _LazyLineageSets(MutableMapping):
+    """{binId: BinMarkerSets} whose values are built from their marker-file line the first time they are looked at.  NOT a dict subclass
+    (round 5's was, and dict(d) / d.copy() / d.pop(b) / {**d} read the raw storage and handed out None for bins not yet built): a
+    Mapping whose every access path goes through __getitem__; copies and pickles are plain dicts of built values, as the reference
+    returns (checkm/markerSets.py:478-511)."""
 
     def __init__(self, parser, lines):
-        dict.__init__(self, ((b, None) for b in lines))
-        self._parser, self._lines, self._selected = parser, lines, None
+        self._parser, self._lines, self._built, self._selected, self._exclude = parser, dict(lines), {}, None, None
+        self._order = list(lines)                         # the file's order, whatever has been built or assigned since
+        self._lock = threading.RLock()
 
     def _make(self, binId):
-        line = self._lines.pop(binId)
-        bms = BinMarkerSets(binId, BinMarkerSets.TREE_MARKER_SET)
-        bms.read(line)
-        if self._selected is None:
-            self._selected = self._parser.parseSelectedMarkerSetMap()     # parsed once, not once per line (markerSets.py:506)
-        bms.setLineageSpecificSelectedMarkerSet(self._selected)
-        removed = getattr(self, "_exclude", None)
-        if removed:
-            bms.removeMarkers(removed)
-        dict.__setitem__(self, binId, bms)
-        return bms
+        with self._lock:
+            if binId in self._built:
+                return self._built[binId]
+            line = self._lines.pop(binId)
+            bms = BinMarkerSets(binId, BinMarkerSets.TREE_MARKER_SET)
+            bms.read(line)
+            if self._selected is None:
+                self._selected = self._parser.parseSelectedMarkerSetMap()     # parsed once, not once per line (markerSets.py:506)
+            bms.setLineageSpecificSelectedMarkerSet(self._selected)
+            if self._exclude:
+                bms.removeMarkers(self._exclude)
+            self._built[binId] = bms
+            return bms
 
     def exclude(self, markers):
         """removeMarkers for every bin: applied to the bins already built now, to the others when they are built."""
-        self._exclude = set(markers)
-        for b, v in dict.items(self):
-            if v is not None:
+        with self._lock:
+            self._exclude = set(markers)
+            for v in self._built.values():
                 v.removeMarkers(self._exclude)
 
     def __getitem__(self, binId):
-        v = dict.__getitem__(self, binId)
-        return v if v is not None else self._make(binId)
+        with self._lock:
+            if binId in self._built:
+                return self._built[binId]
+            if binId in self._lines:
+                return self._make(binId)
+        raise KeyError(binId)
 
-    def get(self, binId, default=None):
-        return self[binId] if binId in self else default
+    def __setitem__(self, binId, value):
+        with self._lock:
+            if binId not in self._built and binId not in self._lines:
+                self._order.append(binId)
+            self._lines.pop(binId, None)
+            self._built[binId] = value
 
-    def values(self):
-        return [self[b] for b in list(self.keys())]
+    def __delitem__(self, binId):
+        with self._lock:
+            if binId in self._built:
+                del self._built[binId]
+                self._lines.pop(binId, None)
+            elif binId in self._lines:
+                del self._lines[binId]
+            else:
+                raise KeyError(binId)
+            self._order.remove(binId)
 
-    def items(self):
-        return [(b, self[b]) for b in list(self.keys())]
+    def __contains__(self, binId):
+        return binId in self._built or binId in self._lines
+
+    def __iter__(self):
+        return iter(list(self._order))
+
+    def __len__(self):
+        return len(self._order)
+
+    def copy(self):
+        return dict(self.items())
 
     def __reduce__(self):
         return (dict, (dict(self.items()),))
+
+    def __repr__(self):
+        return '_LazyLineageSets(%d bins, %d built)' % (len(self._order), len(self._built))
 
 
 class MarkerSetParser(object):

@@ -54,3 +54,34 @@ def test_gather_qa_rows_world_size_2_gloo(tmp_path):
         out, _ = p.communicate(timeout=240)
         assert p.returncode == 0, out.decode()
         assert b"ok" in out
+
+
+AGREE_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+from checkm_amd import dist as cdist
+d = cdist.init_process_group("gloo")
+rank = d.get_rank()
+assert cdist.agree(True) is True                      # everyone well
+got = cdist.agree(rank != 1)                          # rank 1 reports a failure: every rank learns it in the same collective
+assert got is False, got
+d.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_a_failed_rank_is_heard_by_its_peers(tmp_path):
+    """find()'s closing collective (checkm_amd/markerGeneFinder.py: cdist.agree) -- a rank that fails says so before it exits, so the
+    others end with an error instead of waiting for it (ADVICE r5)."""
+    assert cdist.agree(True) is True and cdist.agree(False) is False          # no process group: the caller's own state
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "agree.py"
+    script.write_text(AGREE_WORKER % ROOT)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=240)
+        assert p.returncode == 0, out.decode()
+        assert b"ok" in out

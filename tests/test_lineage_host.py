@@ -66,3 +66,54 @@ def test_batches_and_shards():
     assert sorted(i for s in sh for i in s) == list(range(13))
     loads = [sum(sizes[i] for i in s) for s in sh]
     assert max(loads) <= 1.6 * min(loads)
+
+
+def test_lineage_sets_behave_like_the_dict_the_reference_returns(tmp_path):
+    """getMarkerSets / parseLineageMarkerSetFile build a bin's sets when the bin is first asked for (checkm/markerSets.py:478-511 builds
+    all of them): every way a caller of the reference may reach a value must build it -- dict(d), d.copy(), {**d}, pop, setdefault,
+    deepcopy, pickle, two threads asking for one bin."""
+    import copy
+    import pickle
+    import threading
+    w = sl.World(str(tmp_path / "data"), n_models=240, seed=78)
+    DefaultValues.set_data_root(str(tmp_path / "data"))
+    binIds = ["b%d" % i for i in range(10)]
+    lin, _tax = w.write_marker_files(str(tmp_path), binIds)
+    msp = MarkerSetParser()
+
+    def fresh():
+        return msp.getMarkerSets(str(tmp_path), binIds, lin)
+    ref = {b: fresh()[b].getMarkerGenes() for b in binIds}
+    for view in (dict(fresh()), fresh().copy(), {**fresh()}, copy.deepcopy(fresh()), pickle.loads(pickle.dumps(fresh())), dict(fresh().items())):
+        assert type(view) is dict and list(view) == binIds
+        assert all(isinstance(v, BinMarkerSets) and v.getMarkerGenes() == ref[b] for b, v in view.items())
+    d = fresh()
+    assert len(d) == 10 and "b3" in d and "zz" not in d and d.get("zz") is None and list(d.keys()) == binIds
+    assert d.pop("b3").getMarkerGenes() == ref["b3"] and "b3" not in d and len(d) == 9 and list(d) == [b for b in binIds if b != "b3"]
+    assert d.setdefault("b4", None).getMarkerGenes() == ref["b4"]
+    assert d.setdefault("new", 5) == 5 and d["new"] == 5 and list(d)[-1] == "new"
+    assert all(v is not None for v in d.values())
+    try:
+        d["zz"]
+        assert False
+    except KeyError:
+        pass
+    d2 = fresh()
+    assert d2 == d2.copy() and d2.copy() == d2                 # (Mapping equality over the built values)
+    # the excluded markers apply to bins built before and after the call (TIGR00398 / TIGR00399 always, markerSets.py:277-297)
+    assert all(not ({"TIGR00398", "TIGR00399"} & g) for g in ref.values())
+    # two threads, one bin
+    d = fresh()
+    got, errs = [], []
+
+    def ask():
+        try:
+            got.append(d["b7"])
+        except Exception as e:          # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=ask) for _ in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs and len(got) == 8 and all(g is got[0] for g in got)
