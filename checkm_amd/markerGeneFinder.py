@@ -309,6 +309,8 @@ class MarkerGeneFinder(object):
         if world > 1:
             cdist.init_process_group()          # RCCL ('nccl') unless CKM_DIST_BACKEND says otherwise; no-op when the caller already did
         self.logger.info("Identifying marker genes in %d bins on device %d:" % (len(binFiles), ctx.device))
+        from checkm_amd import parity
+        self.logger.info(parity.log_line())
         parser = MarkerSetParser(self.totalThreads)
         db = parser.hmmDatabaseFor(markerFile)
         allIds = [binIdFromFilename(f) for f in binFiles]

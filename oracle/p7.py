@@ -10,7 +10,7 @@ _LIB = os.path.join(_HERE, "_build", "libp7oracle.so")
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("p7oracle.c", "p7oracle.h", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("p7oracle.c", "p7oracle.h", "p7simd.c", "p7simd.h", "Makefile")]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src):
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _LIB
@@ -64,12 +64,24 @@ def lib():
         L.p7o_align.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.p7o_envelope_alignment.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.p7o_set_ensemble_stream.argtypes = [C.c_int]
+        L.p7o_set_simd.argtypes = [C.c_int]
+        L.p7o_simd_available.restype = C.c_int
+        L.p7o_get_simd.restype = C.c_int
+        L.p7o_msv_probe.restype = C.c_int64
+        L.p7o_msv_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
         L.p7o_ensemble_seed.restype = C.c_uint32
         L.p7o_ensemble_seed.argtypes = [C.c_int]
         L.p7o_region_ensemble.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32)]
         _lib = L
     return _lib
+
+
+def set_simd(on):
+    """The integer filters in their striped AVX2 form (oracle/p7simd.c) instead of the scalar loops -- same results (the tests check it);
+    bench.py's cpu_baseline times the search that way (kind "port-simd").  Returns whether it is in force (False on a CPU without AVX2)."""
+    lib().p7o_set_simd(1 if on else 0)
+    return bool(lib().p7o_get_simd())
 
 
 def digitize(text):
@@ -165,6 +177,17 @@ class HmmSet(object):
         if n.value:
             lib().p7o_free(rows)
         return out
+
+    def msv_probe(self, model_idx, seqs):
+        """The MSV filter alone over every pair: (cells scored, sum of the final bytes)."""
+        offs = np.zeros(len(seqs) + 1, dtype=np.int64)
+        for i, s in enumerate(seqs):
+            offs[i + 1] = offs[i] + len(s)
+        cat = np.ascontiguousarray(np.concatenate(seqs) if seqs else np.zeros(0, dtype=np.uint8), dtype=np.uint8)
+        mi = np.ascontiguousarray(model_idx, dtype=np.int32)
+        chk = C.c_int64()
+        cells = lib().p7o_msv_probe(self.h, mi.ctypes.data, len(mi), cat.ctypes.data, offs.ctypes.data, len(seqs), C.byref(chk))
+        return int(cells), int(chk.value)
 
     def format_domtblout(self, rows, names, descs):
         arr = (Row * max(1, len(rows)))(*rows)

@@ -39,6 +39,7 @@
  */
 #define _GNU_SOURCE
 #include "p7oracle.h"
+#include "p7simd.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -252,7 +253,15 @@ typedef struct {
   /* Forward/Backward odds, canonical padded layout idx = k-1 in [0,Mp) */
   float *rf; float *fBM, *fMM, *fIM, *fDM, *fMI, *fII, *fMD, *fDD;
   float fE_loop, fE_move;                        /* multihit E->J, E->C */
+  P7S_PROF *simd;                                /* the integer filters' striped tables (p7o_set_simd(1) on a CPU with AVX2), else NULL */
 } PROF;
+
+/* The integer filters in their striped AVX2 form (oracle/p7simd.c) instead of the scalar loops: same bytes, same words, so the same rows
+ * -- what bench.py times as cpu_baseline kind "port-simd".  Off by default: the scalar loops are the oracle the GPU path is diffed with. */
+static int g_simd = 0;
+int p7o_simd_available(void) { __builtin_cpu_init(); return __builtin_cpu_supports("avx2") ? 1 : 0; }
+void p7o_set_simd(int on) { g_simd = on && p7o_simd_available(); }
+int p7o_get_simd(void) { return g_simd; }
 
 static uint8_t unbiased_byteify(float scale_b, float sc)
 { sc = -1.0f * roundf(scale_b * sc); return (sc > 255.f) ? 255 : (uint8_t)(int)sc; }
@@ -264,6 +273,7 @@ static int16_t wordify(float scale_w, float sc)
 static void prof_free(PROF *p)
 {
   if (!p) return;
+  p7s_free(p->simd);
   free(p->msc); free(p->gBM); free(p->rbv); free(p->rwv); free(p->wBM); free(p->rf); free(p->fBM); free(p);
 }
 
@@ -364,6 +374,7 @@ static PROF *prof_create(const P7O_HMM *h)
     }
     p->fE_loop = expf((float)(-LOG2C)); p->fE_move = expf((float)(-LOG2C));
   }
+  if (g_simd) p->simd = p7s_create(M, p->rbv, p->bias_b, p->base_b, p->tbm_b, p->tec_b, p->rwv, p->wBM, p->base_w, p->wE_loop, p->wE_move);
   return p;
 }
 
@@ -406,6 +417,16 @@ static inline int sat_subu8(int a, int b) { int s = a - b; return s < 0 ? 0 : s;
 static int msv_filter(const PROF *p, const LENCFG *lc, const uint8_t *dsq, int L, int *ret_xJ, float *ret_sc)
 {
   int M = p->M;
+  if (p->simd) {
+    int xJ;
+    if (p7s_msv(p->simd, dsq, L, lc->tjb_b, &xJ)) { *ret_xJ = -1; *ret_sc = INFINITY; return 1; }
+    *ret_xJ = xJ;
+    float sc = ((float)(xJ - lc->tjb_b) - (float)p->base_b);
+    sc /= p->scale_b;
+    sc -= 3.0f;
+    *ret_sc = sc;
+    return 0;
+  }
   uint8_t *dp = calloc((size_t)M + 1, 1), *nw = calloc((size_t)M + 1, 1);
   int tjbm = (lc->tjb_b + p->tbm_b) & 0xff;     /* _mm_set1_epi8(tjb_b + tbm_b): low byte of the sum */
   int xJ = 0, xB = sat_subu8(p->base_b, tjbm);
@@ -483,6 +504,18 @@ static inline int sat16(int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768
 static int vit_filter(const PROF *p, const LENCFG *lc, const uint8_t *dsq, int L, int *ret_xC, float *ret_sc)
 {
   int M = p->M;
+  if (p->simd) {
+    int xC;
+    if (p7s_vit(p->simd, dsq, L, lc->w_move, &xC)) { *ret_xC = 32767; *ret_sc = INFINITY; return 1; }
+    *ret_xC = xC;
+    if (xC > -32768) {
+      float sc = (float)xC + (float)lc->w_move - (float)p->base_w;
+      sc /= p->scale_w;
+      sc -= 3.0f;
+      *ret_sc = sc;
+    } else *ret_sc = NEGINF;
+    return 0;
+  }
   int16_t *vbase = malloc(sizeof(int16_t) * 6 * (size_t)(M+1));
   int16_t *mm = vbase;
   int16_t *im = mm + (M+1), *dm = im + (M+1), *mn = dm + (M+1), *in = mn + (M+1), *dn = in + (M+1);
@@ -1422,6 +1455,28 @@ int p7o_search(const P7O_HMMSET *set, const int32_t *model_idx, int nmodels,
   }
   *rows_out = rows; *nrows_out = nrows;
   return 0;
+}
+
+/* The MSV filter alone over every (model, sequence) pair: returns the cells (residues x model nodes) it scored and, in *checksum, the sum of
+ * the final bytes (so that the scalar and the striped form can be seen to agree on the sample they are timed on).  bench.py's cpu_baseline:
+ * GCUPS of the stage every pair goes through. */
+int64_t p7o_msv_probe(const P7O_HMMSET *set, const int32_t *model_idx, int nmodels, const uint8_t *dsq, const int64_t *offsets, int nseq, int64_t *checksum)
+{
+  int64_t cells = 0, sum = 0;
+  for (int mi = 0; mi < nmodels; mi++) {
+    const P7O_HMM *hmm = set->hmm[model_idx[mi]];
+    PROF *p = prof_create(hmm);
+    for (int s = 0; s < nseq; s++) {
+      int L = (int)(offsets[s+1] - offsets[s]); if (L == 0) continue;
+      LENCFG lc; lencfg(p, L, 1, &lc);
+      int xJ; float sc;
+      msv_filter(p, &lc, dsq + offsets[s], L, &xJ, &sc);
+      sum += xJ; cells += (int64_t)L * hmm->M;
+    }
+    prof_free(p);
+  }
+  if (checksum) *checksum = sum;
+  return cells;
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -101,6 +101,14 @@ char *p7o_format_domtblout(const P7O_HMMSET *set, const P7O_ROW *rows, int nrows
  * all pairs, return number of rows reported. */
 void p7o_free(void *p);
 
+/* the integer filters (byte MSV, word Viterbi) in their striped AVX2 form (oracle/p7simd.c) -- same results; for bench.py's cpu_baseline
+ * kind "port-simd".  p7o_set_simd(1) is a no-op on a CPU without AVX2. */
+int  p7o_simd_available(void);
+void p7o_set_simd(int on);
+int  p7o_get_simd(void);
+/* the MSV filter alone over every pair: cells scored (return) and the sum of the final bytes (*checksum) */
+int64_t p7o_msv_probe(const P7O_HMMSET *set, const int32_t *model_idx, int nmodels, const uint8_t *dsq, const int64_t *offsets, int nseq, int64_t *checksum);
+
 /* canonical-order float DP pieces exposed for kernel unit parity */
 int p7o_envelope(const P7O_HMM *hmm, const uint8_t *dsq, int L_full, int ienv, int jenv,
                  float *envsc, float *oasc, float *null2 /*[20]*/, int32_t *coords /*[4] hmmfrom,hmmto,alifrom,alito*/,

@@ -40,7 +40,7 @@ def test_recorded_line_meets_the_contract():
     assert r["traffic"] is None or r["traffic"] > 0
     assert r["ms_per_step_kernel"] < d["ms_per_step"]                        # the dominant kernel's time lies inside the step
     c = d["cpu_baseline"]
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and "scalar" in c["sample"].lower()
+    assert c["kind"] in ("port", "port-simd", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and "scalar" in c["sample"].lower()
     v = d["verify"]
     assert v["identical"] is True and v["qa_rows_identical"] is True and v["same_tables_when_scanned_alone"] is True and v["mismatches"] == []
     assert d["cascade_fallback_lanes_rank0"] == 0

@@ -42,6 +42,7 @@ def check(d, opts):
     assert d["rows_hmmsearch"] > 0, d
     assert d["only_hmmsearch"] == 0 and d["only_ours"] == 0 and d["coords"] == 0, d          # hit-for-hit, coordinate-for-coordinate
     assert d["last_digit"] <= opts.get("allow_last_digit_fraction", 0.02) * d["rows_hmmsearch"], d
+    assert d.get("decision_relevant", 0) == 0, d          # (no row whose printed digits put it on the other side of a GA / TC / NC cutoff: checkm/resultsParser.py:340-377)
 
 
 def test_loader_finds_complete_triples_only(tmp_path, monkeypatch):
@@ -64,7 +65,7 @@ def test_oracle_against_hmmsearch_tables(tmp_path):
         ours = str(tmp_path / (os.path.basename(base) + ".oracle.tbl"))
         with open(ours, "w") as f:
             f.write(hs.format_domtblout(rows, [r[0] for r in recs], [r[1] for r in recs]))
-        check(dvh.diff_tables(base + ".domtblout", ours), opts)
+        check(dvh.diff_tables(base + ".domtblout", ours, base + ".hmm"), opts)
         hs.close()
 
 
@@ -77,4 +78,4 @@ def test_gpu_scan_against_hmmsearch_tables(gpu_ctx, tmp_path):
     for base, opts in found:
         ours = str(tmp_path / (os.path.basename(base) + ".gpu.tbl"))
         scan_files(base + ".hmm", [base + ".faa"], [ours])
-        check(dvh.diff_tables(base + ".domtblout", ours), opts)
+        check(dvh.diff_tables(base + ".domtblout", ours, base + ".hmm"), opts)

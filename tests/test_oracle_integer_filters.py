@@ -176,3 +176,47 @@ def test_second_formulation_agrees_with_the_oracle(tmp_path):
             high += 1 if (b is None or b > 200) else 0
     assert checked >= 100 and high >= 5           # some of the pairs carry real hits (bytes well above the base of 190)
     hs.close()
+
+
+def test_striped_avx2_filters_equal_the_scalar_ones(tmp_path):
+    """oracle/p7simd.c (the striped AVX2 byte MSV / word Viterbi filters bench.py times as cpu_baseline kind "port-simd") against the
+    scalar loops of oracle/p7oracle.c: the final xJ byte and xC word -- and so every stage decision and every row -- must be the same,
+    on models of every striping remainder (M mod 32, M mod 16), on hits, non-hits, overflowing pairs and degenerate residues."""
+    import pytest
+    if not p7.lib().p7o_simd_available():
+        pytest.skip("no AVX2 on this CPU")
+    rng = np.random.default_rng(31)
+    lens = [1, 2, 7, 15, 16, 17, 31, 32, 33, 47, 64, 65, 100, 129, 255, 300, 511, 700]
+    profs = [synth.random_profile(rng, m, "m%d" % m, "PF%05d.1" % m) for m in lens]
+    for p in profs:                      # (any calibration will do: the filters' integers do not depend on it, the pass flags must agree either way)
+        p.stats = (-8.5, 0.71, -9.6, 0.71, -3.8, 0.71)
+    path = str(tmp_path / "s.hmm")
+    synth.write_hmm(path, profs)
+    recs = synth.make_bin(profs, 77, n_orfs=60, dup_frac=0.3)
+    seqs = [p7.digitize(r[2]) for r in recs]
+    # a sequence with ambiguity codes and a long exact copy of a model's consensus several times over (byte overflow)
+    seqs.append(p7.digitize("ACDEFGHIKLMNPQRSTVWYBJZOUX*" * 8))
+    seqs.append(np.concatenate([seqs[3]] * 6))
+    names = ["s%d" % i for i in range(len(seqs))]
+    hs = p7.HmmSet(path)
+    try:
+        n = over = passed = 0
+        for i in range(hs.n):
+            for d in seqs:
+                assert not p7.set_simd(False)
+                a = hs.stages(i, d)
+                assert p7.set_simd(True)
+                b = hs.stages(i, d)
+                assert (a.msv_xJ, a.vit_xC, a.pass_msv, a.pass_bias, a.pass_vit, a.pass_fwd) == (b.msv_xJ, b.vit_xC, b.pass_msv, b.pass_bias, b.pass_vit, b.pass_fwd), (lens[i], len(d))
+                assert np.float32(a.msv_sc).view(np.uint32) == np.float32(b.msv_sc).view(np.uint32) and np.float32(a.vit_sc).view(np.uint32) == np.float32(b.vit_sc).view(np.uint32)
+                n += 1; over += a.msv_xJ < 0; passed += a.pass_fwd
+        assert n == len(lens) * len(seqs) and over > 0 and passed > 10
+        p7.set_simd(False)
+        r0 = hs.search(list(range(hs.n)), seqs, names)
+        p7.set_simd(True)
+        r1 = hs.search(list(range(hs.n)), seqs, names)
+        assert len(r0) == len(r1) > 10
+        assert hs.format_domtblout(r0, names, [""] * len(names)) == hs.format_domtblout(r1, names, [""] * len(names))
+    finally:
+        p7.set_simd(False)
+        hs.close()

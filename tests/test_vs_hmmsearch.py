@@ -32,6 +32,35 @@ def test_diff_tool_classifies_rows(tmp_path):
     assert dvh.merge([d, d])["last_digit"] == 2
 
 
+def test_diff_tool_counts_the_rows_that_would_flip_a_vethit_decision(tmp_path):
+    """A last-digit difference matters to CheckM only where the printed score sits on a model's cutoff (checkm/resultsParser.py:340-377
+    compares the PRINTED full / domain scores with GA, TC or NC): the tool counts those rows, so that the first real hmmsearch table says
+    in one command "N rows differ, K of them decision-relevant"."""
+    hmm = tmp_path / "m.hmm"
+    hmm.write_text("HMMER3/f [3.1b2]\nNAME  SYN000\nACC   PF90000.1\nLENG  63\nGA    70.4 68.0;\nHMM   A\n//\n"
+                   "HMMER3/f [3.1b2]\nNAME  NOCUT\nACC   PF90001.1\nLENG  63\nHMM   A\n//\n")
+    assert dvh.models_of(str(hmm))["PF90000.1"][1] == (70.4, 68.0)
+    # the sticky header view: the second record has no cutoffs of its own and inherits GA of the first (hmmerModelParser.py:54-83)
+    assert dvh.models_of(str(hmm))["PF90001.1"][1] == (70.4, 68.0)
+    a = _tbl(tmp_path / "a.tbl", [ROW])                                                    # full score 70.3 < GA 70.4: rejected
+    b = _tbl(tmp_path / "b.tbl", [ROW.replace(" 70.3 ", " 70.4 ")])                        # 70.4: accepted
+    d = dvh.diff_tables(a, b, str(hmm))
+    assert (d["last_digit"], d["decision_relevant"], d["decision_relevant_last_digit"]) == (1, 1, 1)
+    assert d["decision_examples"][0]["vet_theirs"] is False and d["decision_examples"][0]["vet_ours"] is True
+    c = _tbl(tmp_path / "c.tbl", [ROW.replace(" 70.3 ", " 70.2 ")])                        # both below the cutoff: differs, does not matter
+    d = dvh.diff_tables(a, c, str(hmm))
+    assert (d["last_digit"], d["decision_relevant"]) == (1, 0)
+    # a row only one side reports counts when it would be accepted; the pseudogene cut (aligned fraction < 0.3) comes before the cutoffs
+    passing = ROW.replace(" 70.3 ", " 75.0 ")
+    d = dvh.diff_tables(_tbl(tmp_path / "e.tbl", []), _tbl(tmp_path / "f.tbl", [passing]), str(hmm))
+    assert (d["only_ours"], d["decision_relevant"]) == (1, 1)
+    short = passing.replace("    20    84 ", "    20    30 ")
+    d = dvh.diff_tables(_tbl(tmp_path / "g.tbl", []), _tbl(tmp_path / "h.tbl", [short]), str(hmm))
+    assert (d["only_ours"], d["decision_relevant"]) == (1, 0)
+    assert dvh.merge([dvh.diff_tables(a, b, str(hmm))] * 2)["decision_relevant"] == 2
+    assert set(dvh.KNOWN_DEVIATIONS) == {"D1", "D2", "D4", "D5"}
+
+
 @pytest.mark.gpu
 def test_rows_against_real_hmmsearch(gpu_ctx, tmp_path):
     if shutil.which("hmmsearch") is None:
