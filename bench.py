@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-genes", action="store_true", help="cfg3: skip the gene-calling side legs (gene_front_end, gene_calling, from_fasta)")
     ap.add_argument("--from-fasta-bins", type=int, default=512, help="cfg3 / genes: bins of the from_fasta leg (nucleotide bins -> genes -> tree pass -> analyze pass -> qa table); 0 skips it.  256 bins are mostly the ramp of the calls in flight (31 - 34 s per 1000), 512 read 28 s, 1000 read 27.4 s (profiles/r05C, r05w)")
+    ap.add_argument("--hard-bins", type=int, default=128, help="cfg3: bins of the hard_workload side leg (the lineage pass over a HARDER synthetic world: per-bin composition skew, 5 %% low-complexity ORFs, 3-5 diverged paralogs per planted marker -- synthdata/synth_lineage.py: make_lineage_bin(hard=True)); 0 skips it")
     ap.add_argument("--verify", type=int, default=3, help="cfg3 / cfg5: bins of the last timed step whose written tables are diffed against the CPU oracle after the timed region (0 = off)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--pipeline", type=int, default=1,
@@ -1001,6 +1002,62 @@ def from_fasta(w, workdir, nbins):
                     "(checkm/markerGeneFinder.py:113-117); genomes of ~0.9 coding density carrying the lineage world's proteins"}
 
 
+def hard_workload(w, workdir, nbins, base_pairs, base_bins, verify_bins):
+    """The lineage pass over `nbins` bins of a HARDER world (make_lineage_bin(hard=True)): the plain world's sequences are iid draws from
+    one background with one planted copy per marker, so its survivor rates (F1 1.9 %, Forward 0.12 %) are the generator's; real
+    proteomes -- composition of their own, low-complexity stretches, paralog families around every marker -- send more pairs into the
+    expensive stages.  Untimed side leg (a warm pass, then one measured pass); survivors per bin are set against the plain world's."""
+    from checkm_amd import markerGeneFinder as mgf
+    d = os.path.join(workdir, "hard_bins")
+    os.makedirs(d, exist_ok=True)
+    binIds = ["hbin_%04d" % b for b in range(nbins)]
+    files = [os.path.join(d, "%s.faa" % b) for b in binIds]
+    t0 = time.perf_counter()
+    w.write_bin_files([(b, files[b]) for b in range(nbins)], hard=True)
+    md = os.path.join(d, "markers")
+    os.makedirs(md, exist_ok=True)
+    lin, _tax = w.write_marker_files(md, binIds)
+    t_setup = time.perf_counter() - t0
+    mgf.release_scan()
+    out = os.path.join(d, "out")
+    # the plain world's first `nbins` bins by the same procedure, for the ratio at equal size (a pass of this size is mostly ramp and tail)
+    pids = ["bin_%04d" % b for b in range(nbins)]
+    pfiles = [os.path.join(workdir, "%s.faa" % b) for b in pids]
+    mp = os.path.join(d, "markers_plain")
+    os.makedirs(mp, exist_ok=True)
+    plin, _t = w.write_marker_files(mp, pids)
+    lineage_pass(w, pids, pfiles, plin, os.path.join(d, "out_plain"), 0)
+    mgf._join_releasers()
+    t0 = time.perf_counter()
+    lineage_pass(w, pids, pfiles, plin, os.path.join(d, "out_plain"), 0)
+    mgf._join_releasers()
+    dt_plain = time.perf_counter() - t0
+    # two warm passes: the first meets tables sized for the plain world (a table that overflows sends its lane through the host-driven
+    # cascade once and is larger from then on -- the fallbacks of every pass are on the line)
+    fb = []
+    for _ in range(2):
+        _p, t_w = lineage_pass(w, binIds, files, lin, out, 0)
+        fb.append(int(t_w.get("cascade_fallback_lanes", 0)))
+        mgf._join_releasers()
+    t0 = time.perf_counter()
+    parts, tot = lineage_pass(w, binIds, files, lin, out, 0)
+    mgf._join_releasers()
+    dt = time.perf_counter() - t0
+    fb.append(int(tot.get("cascade_fallback_lanes", 0)))
+    sp = stage_pairs(tot)
+    ratio = {k: (sp[k] / float(nbins)) / (base_pairs[k] / float(base_bins)) for k in sp if base_pairs.get(k)}
+    res = {"bins": nbins, "seconds": dt, "seconds_per_1000_bins": dt * 1000.0 / nbins, "bins_per_hour": nbins / dt * 3600.0, "parts_s": parts, "stage_pairs": sp,
+           "plain_world_same_bins_seconds": dt_plain, "slowdown_vs_plain_world_same_bins": dt / dt_plain,
+           "per_bin_vs_plain_world": ratio, "ssv_kernels_s": tot.get("ms_ssv", 0.0) / 1e3, "cascade_fallback_lanes": fb[-1], "cascade_fallback_lanes_by_pass": fb, "setup_s": t_setup,
+           "note": "per-bin composition ~ Dirichlet(40 x Swiss-Prot), 5 % low-complexity ORFs, per planted marker 3-5 paralogs (35-75 % of a sampled domain's residues kept) and "
+                   "2-4 block-scrambled copies; per_bin_vs_plain_world = this leg's pairs per bin at each stage over the headline workload's; the slowdown is against the plain "
+                   "world's first bins in a pass of the same size; cascade_fallback_lanes_by_pass = two warm passes, then the measured one"}
+    if verify_bins > 0:
+        res["verify"] = verify_tables(out, DefaultValues_HMMER_TABLE_OUT(), w.checkm_hmm, lin, binIds, files, verify_bins, True, d)
+    mgf.release_scan()
+    return res
+
+
 def bench_cfg3(args, env):
     """configs[2] (N = 1) / configs[3] (N > 1, strong scaling): the lineage_wf marker path over --bins-total bins from files; the
     product shards the bins over the ranks."""
@@ -1170,6 +1227,8 @@ def bench_cfg3(args, env):
             out["gene_calling"] = gene_calling(workdir)
             if args.from_fasta_bins > 0:
                 out["from_fasta"] = from_fasta(w, workdir, min(args.from_fasta_bins, nbins))
+        if args.hard_bins > 0:
+            out["hard_workload"] = hard_workload(w, workdir, args.hard_bins, out["stage_pairs"], nbins, 0 if args.no_verify else min(2, args.verify))
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_cfg3(w, binIds, files, lin, args.cpu_baseline_seconds, args.cpu_baseline_threads)
         else:
@@ -1186,7 +1245,9 @@ def bench_cfg3(args, env):
     else:
         out["cpu_baseline"] = None
     g, ff, em, ver = out.get("gene_calling") or {}, out.get("from_fasta") or {}, out.get("emulated_ranks_of_8") or {}, out.get("verify") or {}
-    out["summary"] = {"gene_calling_bins_per_hour": g.get("value"), "gene_calling_device_fraction_of_wall": g.get("device_fraction_of_wall"),
+    hw = out.get("hard_workload") or {}
+    out["summary"] = {"hard_workload_seconds_per_1000_bins": hw.get("seconds_per_1000_bins"), "hard_workload_pairs_per_bin_vs_plain": hw.get("per_bin_vs_plain_world"),
+                      "gene_calling_bins_per_hour": g.get("value"), "gene_calling_device_fraction_of_wall": g.get("device_fraction_of_wall"),
                       "from_fasta_seconds_per_1000_bins": ff.get("seconds_per_1000_bins"), "from_fasta_bins": ff.get("bins"),
                       "emulated_8_ranks_max_wall_s": em.get("max_wall_s"), "emulated_8_ranks_projected_speedup_over_1gpu": em.get("projected_speedup_over_1gpu"),
                       "verify_identical": ver.get("identical"), "verify_qa_rows_identical": ver.get("qa_rows_identical"),

@@ -393,10 +393,38 @@ __global__ void __launch_bounds__(256) vit16_kernel(WorkQueue queue, const PairR
   const int lane = threadIdx.x & 63, z = lane & 15, g = lane >> 4;
   constexpr int ROW = Q * 16;                       // u32 words per table row
   const uint32_t nqueue = queue_len(queue);
-  for (uint32_t q4 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); q4 * 4u < nqueue; q4 += gridDim.x * (blockDim.x >> 6)) {
-    const uint32_t qk = q4 * 4u + (uint32_t)g;
-    const bool valid = qk < nqueue;
-    const uint32_t pi = queue.list[valid ? qk : q4 * 4u];          // (a group beyond the queue's end repeats the wavefront's first pair and reports nothing)
+  // Round 6: the four pairs of a wavefront run to the LONGEST of their sequences, and the queue -- appended to by atomics from many
+  // blocks -- holds lengths in no particular order (the mean of the longest of four log-normal lengths is ~1.5 x the mean length).  A
+  // wavefront therefore takes a CHUNK of 64 queue entries, sorts them by length in its lanes (a bitonic network over ds_swizzle /
+  // ds_bpermute moves: ~130 instructions per chunk against ~36,000 per quad of pairs) and runs neighbours of the sorted order together.
+  // S wavefronts share a chunk (each sorts it and takes every S-th quad) when the queue has fewer chunks than the launch has wavefronts.
+  const uint32_t nchunks = (nqueue + 63u) >> 6, nwaves = gridDim.x * (blockDim.x >> 6), wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  uint32_t S = 1;
+  while (S < 16u && nchunks * S < nwaves) S <<= 1;
+  for (uint32_t u = wid; u < nchunks * S; u += nwaves) {
+    const uint32_t chunk = u / S, sub0 = u % S;
+    const uint32_t qe = chunk * 64u + (uint32_t)lane;
+    const uint32_t pi_l = qe < nqueue ? queue.list[qe] : 0u;
+    // key: (length + 1) << 6 | lane for a real entry, the bare lane for one beyond the queue's end (sorts behind every real one)
+    uint32_t key = (uint32_t)lane;
+    if (qe < nqueue) key |= ((uint32_t)seq_len[pairs[pi_l].seq] + 1u) << 6;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)key, j);
+        const bool desc = (lane & k) == 0;                    // (descending overall: the last merge, k = 64, has every lane in a descending block)
+        const bool lower = (lane & j) == 0;
+        const uint32_t mx = key > other ? key : other, mn = key > other ? other : key;
+        key = (lower == desc) ? mx : mn;
+      }
+    }
+   for (uint32_t sub = sub0; sub < 16u; sub += S) {
+    const uint32_t kq = (uint32_t)__shfl((int)key, (int)(sub * 4u));              // the quad's first (longest) entry
+    if ((kq >> 6) == 0u) break;                                                   // (uniform: nothing real from here on)
+    const uint32_t kg = (uint32_t)__shfl((int)key, (int)(sub * 4u) + g);
+    const bool valid = (kg >> 6) != 0u;
+    const uint32_t pi = (uint32_t)__shfl((int)pi_l, (int)((valid ? kg : kq) & 63u));   // (a group beyond the queue's end repeats the quad's first pair and reports nothing)
     const PairRec pr = pairs[pi];
     const DevModel &md = models[pr.model];
     const int L = seq_len[pr.seq];
@@ -491,6 +519,7 @@ __global__ void __launch_bounds__(256) vit16_kernel(WorkQueue queue, const PairR
       else if (flag) { cd.route[pi] = 2; queue_push(cd, cd.vxq, CC_VXQ, md.vitx_cls, cd.cap_vq, pi, (uint32_t)CS_VQ); }
       else if (v >= md.thr_vit_f2 - cd.margin_vit) pass_to_forward(cd, md, pi, pr.model, pr.seq);
     }
+   }
   }
 }
 

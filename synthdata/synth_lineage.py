@@ -198,29 +198,85 @@ def sample_domain_fast(rng, prof):
     return np.concatenate(parts).astype(np.int64)
 
 
-def make_lineage_bin(profs, planted, seed, n_orfs, phylo=None, dup_frac=0.04, orfs_per_contig=40, composition=None, paralogs=None):
+def diverged(rng, dom, bg, keep):
+    """A paralog of a sampled domain: each residue kept with probability `keep`, else redrawn from the background; a few short
+    deletions.  What a marker family's other members look like to the marker's profile: a weak hit that passes the first filters."""
+    out = dom.copy()
+    redo = rng.random(len(out)) >= keep
+    out[redo] = rng.choice(20, size=int(redo.sum()), p=bg)
+    if len(out) > 60:
+        for _ in range(int(rng.integers(0, 3))):
+            a = int(rng.integers(5, len(out) - 20)); out = np.concatenate([out[:a], out[a + int(rng.integers(1, 12)):]])
+    return out
+
+
+def scrambled(rng, dom):
+    """A domain cut into blocks of 10-25 residues and put back in random order: every block still draws an ungapped diagonal (the MSV
+    filter adds those up in any order), the co-linear path the Viterbi and Forward stages ask for is gone."""
+    cuts, a = [], 0
+    while a < len(dom):
+        b = a + int(rng.integers(10, 26)); cuts.append(dom[a:b]); a = b
+    order = rng.permutation(len(cuts))
+    return np.concatenate([cuts[int(k)] for k in order])
+
+
+def low_complexity(rng, n):
+    """An ORF of biased composition: a two- to four-letter alphabet, a short repeated motif, or a homopolymer run between them."""
+    kind = int(rng.integers(0, 3))
+    if kind == 0:
+        letters = rng.choice(20, size=int(rng.integers(2, 5)), replace=False)
+        return rng.choice(letters, size=n, p=rng.dirichlet(np.ones(len(letters)) * 2.0))
+    if kind == 1:
+        motif = rng.choice(20, size=int(rng.integers(2, 8)))
+        s = np.tile(motif, n // len(motif) + 1)[:n].copy()
+        flip = rng.random(n) < 0.08
+        s[flip] = rng.choice(20, size=int(flip.sum()))
+        return s
+    s = rng.choice(20, size=n, p=synth.BGF)
+    a = int(rng.integers(0, max(1, n // 2))); s[a:a + int(rng.integers(15, max(16, n // 2)))] = int(rng.integers(0, 20))
+    return s
+
+
+def make_lineage_bin(profs, planted, seed, n_orfs, phylo=None, dup_frac=0.04, orfs_per_contig=40, composition=None, paralogs=None, hard=False):
     """One bin: list of (name, desc, protein + '*').  `planted`: indices into profs that get one full-length ORF (a dup_frac share of
     them a second copy: contamination).  `phylo`: profiles of the tree pass, one ORF each as well.  `composition`: residue
-    frequencies of the background (default Swiss-Prot); `paralogs` = (profile, copies): a family present many times."""
+    frequencies of the background (default Swiss-Prot); `paralogs` = (profile, copies): a family present many times.
+    `hard` (round 6, bench.py's hard_workload leg): what real proteomes do to the filter cascade and the plain world does not -- a
+    background composition of the bin's own (a Dirichlet draw around Swiss-Prot's: the GC skew of a genome shows in its amino acids),
+    5 % of the ORFs of low complexity, and for every planted marker 3-5 diverged paralogs (35-75 % of the residues kept) and 2-4 block-scrambled
+    copies besides it (as many as half the bin's ORFs hold; the real copies come first)."""
     rng = np.random.default_rng(seed)
     lens = synth.orf_lengths(rng, n_orfs)
     bg = synth.BGF if composition is None else np.asarray(composition, dtype=np.float64) / np.sum(composition)
+    if hard and composition is None:
+        bg = rng.dirichlet(np.asarray(synth.BGF, dtype=np.float64) * 40.0)
     flat = rng.choice(20, size=int(lens.sum()), p=bg)
     seqs = np.split(flat, np.cumsum(lens)[:-1])
+    if hard:
+        for s in rng.permutation(n_orfs)[:max(1, n_orfs // 20)]:
+            seqs[int(s)] = low_complexity(rng, len(seqs[int(s)]))
     todo = list(phylo or []) + [profs[i] for i in planted]            # (a bin too small for all its plants loses lineage markers, never the 43 phylogenetic ones)
     copies = []
     for p in todo:
-        copies.append(p)
+        copies.append((p, 1.0))
         if rng.random() < dup_frac:
-            copies.append(p)
+            copies.append((p, 1.0))
+    if hard:
+        for p in todo:
+            for _ in range(int(rng.integers(3, 6))):
+                copies.append((p, float(rng.uniform(0.35, 0.75))))              # paralogs, close to remote
+        for p in todo:
+            for _ in range(int(rng.integers(2, 5))):
+                copies.append((p, -1.0))                                        # scrambled homologs: filter survivors that end nowhere
     if paralogs is not None:
-        copies += [paralogs[0]] * int(paralogs[1])
+        copies += [(paralogs[0], 1.0)] * int(paralogs[1])
     copies = copies[:max(0, (n_orfs - 1) // 2)]
     slots = rng.permutation(n_orfs)[:len(copies)]
-    for s, p in zip(slots, copies):
+    for s, (p, keep) in zip(slots, copies):
         fl = rng.choice(20, size=int(rng.integers(5, 40)), p=bg)
         fr = rng.choice(20, size=int(rng.integers(5, 40)), p=bg)
-        seqs[int(s)] = np.concatenate([fl, sample_domain_fast(rng, p), fr])
+        dom = sample_domain_fast(rng, p)
+        seqs[int(s)] = np.concatenate([fl, dom if keep >= 1.0 else (scrambled(rng, dom) if keep < 0 else diverged(rng, dom, bg, keep)), fr])
     lut = np.frombuffer(synth.AMINO.encode(), dtype=np.uint8)
     out, pos = [], 1
     for i, sq in enumerate(seqs):
@@ -273,15 +329,16 @@ class World(object):
         planted = [self.index[a] for a in sel if rng.random() < frac]
         return make_lineage_bin(self.profs, planted, self.seed * 1000 + b, n_orfs, phylo=self.phylo, **kw)
 
-    def write_bin_files(self, jobs_list, jobs=None):
-        """jobs_list: [(bin index, path)] -- the genes.faa files of those bins, written by a pool of generator processes."""
+    def write_bin_files(self, jobs_list, jobs=None, hard=False):
+        """jobs_list: [(bin index, path)] -- the genes.faa files of those bins, written by a pool of generator processes.
+        hard: the harder world of make_lineage_bin (composition skew, low-complexity ORFs, paralog families)."""
         todo = [j for j in jobs_list if not os.path.exists(j[1])]
         if len(todo) <= 2:
             for b, path in todo:
-                synth.write_fasta(path, self.bin_records(b))
+                synth.write_fasta(path, self.bin_records(b, hard=hard))
             return
         chunks = [todo[k::max(1, len(todo) // 4)] for k in range(max(1, len(todo) // 4))]
-        for _ in _pool_map(self.root, self.seed, self.n_models, "bins", chunks, jobs):
+        for _ in _pool_map(self.root, self.seed, self.n_models, "hardbins" if hard else "bins", chunks, jobs):
             pass
 
     def write_mag_files(self, jobs_list, jobs=None):
@@ -348,7 +405,7 @@ def _worker_task(job):
             os.replace(path + ".tmp", path)
         return len(arg)
     for b, path in arg:
-        synth.write_fasta(path + ".tmp", w.bin_records(b))
+        synth.write_fasta(path + ".tmp", w.bin_records(b, hard=(kind == "hardbins")))
         os.replace(path + ".tmp", path)
     return len(arg)
 
