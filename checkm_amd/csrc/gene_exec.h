@@ -27,6 +27,7 @@ template <class F> inline void g_map(GExec &, size_t n, F f) { for (size_t i = 0
 template <class F> inline void g_map_waves(GExec &, size_t n, F f) { for (size_t i = 0; i < n; ++i) f(i); }
 template <class T> inline T g_atomic_add(T *p, T v) { const T o = *p; *p = o + v; return o; }
 inline void g_count(uint32_t *p) { ++*p; }
+inline void g_count_n(uint32_t *p, uint32_t n) { *p += n; }
 inline void g_atomic_or(unsigned long long *p, unsigned long long v) { *p |= v; }
 [[noreturn]] inline void g_fail(const char *msg) { throw std::runtime_error(msg); }
 }  // namespace gene
@@ -81,6 +82,23 @@ __device__ __forceinline__ void g_count(uint32_t *p) {
     const bool mine = (unsigned)pv == lo && (unsigned)(pv >> 32) == hi;
     const unsigned long long same = __ballot(mine);
     if (mine) { if (me == (unsigned)(__ffsll((long long)same) - 1)) atomicAdd(p, (uint32_t)__popcll(same)); break; }
+  }
+}
+// *p += n (n < 32) the same way: the lanes that name one address add their sum with one atomic (five ballots, one per bit of n)
+__device__ __forceinline__ void g_count_n(uint32_t *p, uint32_t n) {
+  const unsigned long long pv = (unsigned long long)p;
+  const unsigned me = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  for (;;) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pv), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pv >> 32));
+    const bool mine = (unsigned)pv == lo && (unsigned)(pv >> 32) == hi;
+    const unsigned long long same = __ballot(mine);
+    if (mine) {
+      uint32_t sum = 0;
+#pragma unroll
+      for (int b = 0; b < 5; ++b) sum += (uint32_t)__popcll(__ballot((n >> b) & 1u)) << b;
+      if (me == (unsigned)(__ffsll((long long)same) - 1) && sum) atomicAdd(p, sum);
+      break;
+    }
   }
 }
 __device__ __forceinline__ void g_atomic_or(unsigned long long *p, unsigned long long v) { atomicOr(p, v); }

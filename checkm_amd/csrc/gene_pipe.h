@@ -282,6 +282,7 @@ inline double host_confidence(double score, double st_wt) {
 // counters of one bin during the start-site training (uint32 each)
 constexpr int TC_RBG = 0, TC_RREAL = 28, TC_TREAL = 56, TC_TBG = 59, TC_UPS = 62, TC_NGENES = 190, TC_ZBG = 191, TC_ZREAL = 192, TC_SIZE = 200;
 constexpr size_t MOT_N = (size_t)4 * 4 * 4096;
+constexpr int TEXT_PIECE = 1024;          // bases of a contig one wavefront lays out (16 steps of 64)
 
 // walk over the starts of the open reading frame whose STOP node is x, outermost first (the order of the reference's frame sweeps):
 // the chain array holds [sentinel][starts of ORF 1, inner to outer][its stop][starts of ORF 2 ...]
@@ -311,7 +312,7 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
       const uint64_t n = in.contig_off[c + 1] - in.contig_off[c];
       if (n > 0x7ffffff0ull) g_fail("contig longer than 2^31 bases");
       seq_off[nbins + c] = p; seq_len[nbins + c] = (int32_t)n; seq_bin[nbins + c] = b; bin_total[b] += n;
-      piece_first[c + 1] = piece_first[c] + (uint32_t)std::max<uint64_t>(1, (n + 63) / 64);
+      piece_first[c + 1] = piece_first[c] + (uint32_t)std::max<uint64_t>(1, (n + TEXT_PIECE - 1) / TEXT_PIECE);
       p += n + (multi ? 12 : 0);
     }
     if (p - pos > 0x7ffffff0ull) g_fail("bin longer than 2^31 bases");
@@ -329,7 +330,7 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
   if (!nbins) return;
 
   // ---- device: text ----
-  GBuf d_raw, d_coff, d_pf, d_bfirst, d_ascii, d_code, d_off, d_len, d_sbin, d_gcc, d_flags, d_gcw, d_uw, d_r50, d_pg, d_pr, d_scan;
+  GBuf d_raw, d_coff, d_pf, d_pc, d_bfirst, d_ascii, d_code, d_off, d_len, d_sbin, d_gcc, d_flags, d_gcw, d_uw, d_r50, d_pg, d_pr, d_scan;
   d_raw.ensure(raw_bytes + 64); d_coff.ensure((size_t)(ncontigs + 1) * 8); d_pf.ensure((size_t)(ncontigs + 1) * 4); d_bfirst.ensure((size_t)(nbins + 1) * 4);
   d_ascii.ensure(64 + body + 128); d_code.ensure(body + 64); d_off.ensure((size_t)nseq * 8); d_len.ensure((size_t)nseq * 4); d_sbin.ensure((size_t)nseq * 4); d_gcc.ensure((size_t)nbins * 8);
   d_flags.ensure(body + 256); d_gcw.ensure((nwin + 8) * 8); d_uw.ensure((nwin + 2) * 8); d_r50.ensure((nwin + 2) * 8); d_pg.ensure((nwin + 2) * 4); d_pr.ensure((nwin + 2) * 4);
@@ -344,26 +345,40 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
     const uint8_t *raw = d_raw.as<uint8_t>(); const uint64_t *coff = d_coff.as<uint64_t>(); const uint32_t *pf = d_pf.as<uint32_t>(), *bfirst = d_bfirst.as<uint32_t>();
     uint8_t *ascii = d_ascii.as<uint8_t>() + 64; unsigned long long *gcc = d_gcc.as<unsigned long long>();
     const uint32_t nb = nbins, nc = ncontigs;
-    g_map(e, piece_first[ncontigs], [=] GLAM(size_t p) {
-      uint32_t lo = 0, hi = nc;
-      while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (pf[mid] <= p) lo = mid; else hi = mid; }
-      const uint32_t c = lo; const uint64_t k = p - pf[c], len = coff[c + 1] - coff[c];
-      const uint64_t done = 64 * k; const int n = (int)(len - done < 64 ? len - done : 64);
+    // a wavefront per 1024-base piece of a contig, 64 bases at a time (round 5: a thread per 64-base piece, whose 64 byte reads and
+    // 128 byte writes touched a cache line each -- 14 % of a call's wavefront-cycles, profiles/r06e; a wavefront per 64 bases paid the
+    // piece's six dependent look-ups for one line of text, profiles/r06n): the bytes of a step are one line, the G + C count one atomic
+    // per wavefront.  The contig of every piece comes from the host.
+    uint32_t *gcc32 = reinterpret_cast<uint32_t *>(gcc);          // (low words of the 64-bit sums: a bin holds fewer than 2^31 bases)
+    std::vector<uint32_t> h_pc(piece_first[ncontigs]);
+    for (uint32_t c = 0; c < ncontigs; ++c) std::fill(h_pc.begin() + piece_first[c], h_pc.begin() + piece_first[c + 1], c);
+    d_pc.ensure(std::max<size_t>(1, h_pc.size()) * 4);
+    g_h2d(e, d_pc.p, h_pc.data(), h_pc.size() * 4);
+    const uint32_t *pc = d_pc.as<uint32_t>();
+    (void)nc;
+    g_map(e, (size_t)piece_first[ncontigs] * 64, [=] GLAM(size_t t) {
+      const size_t p = t >> 6; const int lane = (int)(t & 63);
+      const uint32_t c = pc[p]; const uint64_t k = p - pf[c], len = coff[c + 1] - coff[c];
+      const uint64_t done = (uint64_t)TEXT_PIECE * k; const int n = (int)(len - done < (uint64_t)TEXT_PIECE ? len - done : (uint64_t)TEXT_PIECE);
       const uint8_t *src = raw + coff[c] + done; const uint64_t o = soff[nb + c] + done;
-      unsigned long long gc = 0;
-      for (int i = 0; i < n; ++i) {
+      uint32_t gc = 0;
+      for (int i = lane; i < n; i += 64) {
         const uint8_t ch = src[i]; uint8_t v;
         switch (ch) { case 'A': case 'a': v = 0; break; case 'C': case 'c': v = 1; gc++; break; case 'G': case 'g': v = 2; gc++; break;
                       case 'T': case 't': case 'U': case 'u': v = 3; break; default: v = 5; }
         ascii[o + i] = ch; code[o + i] = v;
       }
-      const uint32_t b = sbin[nb + c];
-      if (done + n == len && bfirst[b + 1] - bfirst[b] > 1) {
-        const char sep[13] = "TTAATTAATTAA";
-        for (int i = 0; i < 12; ++i) { ascii[o + n + i] = (uint8_t)sep[i]; code[o + n + i] = sep[i] == 'T' ? 3 : 0; }
-      }
-      if (gc) g_atomic_add(&gcc[b], gc);
+      g_count_n(&gcc32[2 * (size_t)sbin[nb + c]], gc);
     });
+    {
+      // the separator behind every contig of a bin of several
+      g_map(e, (size_t)ncontigs, [=] GLAM(size_t c) {
+        const uint64_t len = coff[c + 1] - coff[c]; const uint32_t b = sbin[nb + c];
+        if (bfirst[b + 1] - bfirst[b] <= 1) return;
+        const uint64_t o = soff[nb + c] + len; const char sep[13] = "TTAATTAATTAA";
+        for (int i = 0; i < 12; ++i) { ascii[o + i] = (uint8_t)sep[i]; code[o + i] = sep[i] == 'T' ? 3 : 0; }
+      });
+    }
   }
   x_orf_flags(e, d_ascii.as<uint8_t>() + 64, d_flags.as<unsigned long long>(), body);
   unsigned long long *gcw = d_gcw.as<unsigned long long>() + 2, *uw = d_uw.as<unsigned long long>(), *r50 = d_r50.as<unsigned long long>();
