@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <vector>
 #include "ckm_host.h"
@@ -24,23 +25,28 @@ namespace {
 // Several gene-calling calls may run side by side on one context (the pipeline is latency-bound: a workgroup per bin in the dynamic
 // programs, a thread per contig in the trace-back walks -- throughput comes from calls in flight, checkm_amd/geneFinder.py keeps several):
 // each takes a stream of its own from this per-device pool for its duration.
+// A slot also keeps the call's two page-locked exchange areas (gene_exec.h: g_host_reserve) from call to call: page-locking tens of
+// megabytes costs milliseconds.
+struct GeneSlot { hipStream_t st = nullptr; bool busy = false; PinnedBuf pin[2]; };
 struct GeneStreams {
-  std::mutex m; std::vector<std::pair<hipStream_t, bool>> s[16];
+  std::mutex m; std::deque<GeneSlot> s[16];
   static GeneStreams &get() { static GeneStreams g; return g; }
-  hipStream_t take(int dev) {
+  GeneSlot *take(int dev) {
     std::lock_guard<std::mutex> lock(m);
-    for (auto &p : s[dev & 15]) if (!p.second) { p.second = true; return p.first; }
+    for (auto &p : s[dev & 15]) if (!p.busy) { p.busy = true; return &p; }
     hipStream_t st = nullptr;
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    s[dev & 15].push_back({st, true});
-    return st;
+    s[dev & 15].emplace_back();
+    GeneSlot &g = s[dev & 15].back();
+    g.st = st; g.busy = true;
+    return &g;
   }
-  void give(int dev, hipStream_t st) { std::lock_guard<std::mutex> lock(m); for (auto &p : s[dev & 15]) if (p.first == st) p.second = false; }
+  void give(GeneSlot *g) { std::lock_guard<std::mutex> lock(m); g->busy = false; }
 };
 struct StreamLease {
-  int dev; hipStream_t st;
-  explicit StreamLease(int d) : dev(d), st(GeneStreams::get().take(d)) {}
-  ~StreamLease() { (void)hipStreamSynchronize(st); GeneStreams::get().give(dev, st); }
+  GeneSlot *slot; hipStream_t st;
+  explicit StreamLease(int d) : slot(GeneStreams::get().take(d)), st(slot->st) {}
+  ~StreamLease() { (void)hipStreamSynchronize(st); GeneStreams::get().give(slot); }
 };
 }  // namespace
 
@@ -71,7 +77,7 @@ extern "C" int ckm_genes_call(ckm_ctx *ctx, const char *text, const uint64_t *co
       if (tr_on) fprintf(stderr, "ckm-trace genes call %d table %d %9.1f ms  %s\n", call_id, trans_table, now_ms() - t_begin, label);
     };
     std::unique_ptr<ckm_genes> o(new ckm_genes());
-    ckm::gene::GExec ex; ex.st = lease.st;
+    ckm::gene::GExec ex; ex.st = lease.st; ex.pin[0] = &lease.slot->pin[0]; ex.pin[1] = &lease.slot->pin[1];
     ckm::gene::gene_pipeline(ex, in, o->r);
     HIPCHK(hipStreamSynchronize(lease.st));
     o->ms_nodes = t_nodes ? t_nodes - t_begin : 0.0; o->ms_host = now_ms() - t_begin;

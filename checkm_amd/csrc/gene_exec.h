@@ -12,7 +12,12 @@
 #include <stdexcept>
 namespace ckm {
 namespace gene {
-struct GExec { int dummy = 0; };
+struct GExec { int dummy = 0; std::vector<std::vector<uint8_t>> host_blocks; };
+// host memory the training rounds exchange with the device every round (page-locked in the library); g_up / g_down move it
+inline void g_host_reserve(GExec &, int, size_t) {}
+inline void *g_host_raw(GExec &e, int, size_t bytes) { e.host_blocks.emplace_back(bytes + 64); return e.host_blocks.back().data(); }
+inline void g_up(GExec &, void *dst, const void *src, size_t n) { if (n) memcpy(dst, src, n); }
+inline void g_down(GExec &, void *dst, const void *src, size_t n) { if (n) memcpy(dst, src, n); }
 struct GTimer { void begin(GExec &) {} double end(GExec &) { return 0.0; } };
 struct GBuf {
   std::vector<uint8_t> v; void *p = nullptr;
@@ -25,6 +30,7 @@ inline void g_d2h(GExec &, void *dst, const void *src, size_t n) { if (n) memcpy
 inline void g_sync(GExec &) {}
 template <class F> inline void g_map(GExec &, size_t n, F f) { for (size_t i = 0; i < n; ++i) f(i); }
 template <class F> inline void g_map_waves(GExec &, size_t n, F f) { for (size_t i = 0; i < n; ++i) f(i); }
+template <class T> inline T *g_host(GExec &e, int which, size_t n) { return reinterpret_cast<T *>(g_host_raw(e, which, n * sizeof(T))); }
 template <class T> inline T g_atomic_add(T *p, T v) { const T o = *p; *p = o + v; return o; }
 inline void g_count(uint32_t *p) { ++*p; }
 inline void g_count_n(uint32_t *p, uint32_t n) { *p += n; }
@@ -36,7 +42,20 @@ inline void g_atomic_or(unsigned long long *p, unsigned long long v) { *p |= v; 
 #include "ckm_host.h"
 namespace ckm {
 namespace gene {
-struct GExec { hipStream_t st = nullptr; };
+// pin[0], pin[1]: page-locked, device-mapped host arenas of the call (the stream's slot keeps them from call to call): what the training
+// rounds exchange with the device -- weights up, counts down, thirty times -- moves by a copy KERNEL on the call's stream (g_up / g_down)
+// instead of the runtime's copy path: with two dozen calls in flight every hipMemcpyAsync / hipMemsetAsync of a round stood 1.3-1.5 ms in
+// the queue of the runtime's own copy kernels (profiles/r06c), ten to twenty-five of them per round.
+struct GExec { hipStream_t st = nullptr; PinnedBuf *pin[2] = {nullptr, nullptr}; size_t pin_top[2] = {0, 0}; };
+inline void g_host_reserve(GExec &e, int which, size_t bytes) { e.pin[which]->ensure(bytes + 4096); e.pin_top[which] = 0; }      // (before the first g_host_raw of that arena: growing moves it)
+inline void *g_host_raw(GExec &e, int which, size_t bytes) {
+  const size_t at = (e.pin_top[which] + 255) & ~(size_t)255;
+  if (at + bytes > e.pin[which]->cap) throw Error(CKM_ENOMEM, "gene calling: the page-locked exchange area was reserved too small");
+  e.pin_top[which] = at + bytes;
+  return e.pin[which]->as<uint8_t>() + at;
+}
+inline void g_up(GExec &e, void *dst, const void *src_pinned, size_t n) { launch_upload(e.st, dst, src_pinned, n); }
+inline void g_down(GExec &e, void *dst_pinned, const void *src, size_t n) { launch_upload(e.st, dst_pinned, src, n); }
 struct GTimer {          // HIP events on the stream the kernels run on; end() waits for the stream
   hipEvent_t e0 = nullptr, e1 = nullptr;
   void begin(GExec &e) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, e.st)); }
@@ -71,6 +90,7 @@ template <class F> inline void g_map_waves(GExec &e, size_t n, F f) {
   if (n > (size_t)0x7fffffff) throw Error(CKM_ERANGE, "gene-calling batch too large for one launch");
   hipLaunchKernelGGL(g_map_waves_kernel<F>, dim3((unsigned)n), dim3(64), 0, e.st, n, f);
 }
+template <class T> inline T *g_host(GExec &e, int which, size_t n) { return reinterpret_cast<T *>(g_host_raw(e, which, n * sizeof(T))); }
 template <class T> __device__ __forceinline__ T g_atomic_add(T *p, T v) { return atomicAdd(p, v); }
 // ++*p for counters that most lanes of a wavefront share (the few dozen histogram bins of a bin's start-site training): one atomic per
 // distinct address and wavefront, carrying the number of lanes that named it.  The lanes that are active here may be any subset.

@@ -678,9 +678,14 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
 
   // =====================================================  training  =====================================================
   const Nodes tn = TS.dev();
-  GBuf d_bias, d_dc, d_rw, d_tw, d_cnt, d_sth, d_gi, d_gcnt, d_hex, d_hcnt, d_ipath;
-  d_bias.ensure((size_t)nbins * 24); d_dc.ensure((size_t)nbins * 4096 * 8); d_rw.ensure((size_t)nbins * 28 * 8); d_tw.ensure((size_t)nbins * 24); d_cnt.ensure((size_t)nbins * TC_SIZE * 4);
-  d_sth.ensure((size_t)nbins * 8); d_gcnt.ensure((size_t)nbins * 4); d_hex.ensure((size_t)nbins * 4096 * 4); d_hcnt.ensure((size_t)nbins * 4096 * 4); d_ipath.ensure((size_t)nbins * 4);
+  GBuf d_bias, d_dc, d_par, d_cnt, d_gi, d_gcnt, d_hex, d_hcnt, d_ipath;
+  d_bias.ensure((size_t)nbins * 24); d_dc.ensure((size_t)nbins * 4096 * 8); d_cnt.ensure((size_t)nbins * TC_SIZE * 4);
+  d_gcnt.ensure((size_t)nbins * 4); d_hex.ensure((size_t)nbins * 4096 * 4); d_hcnt.ensure((size_t)nbins * 4096 * 4); d_ipath.ensure((size_t)nbins * 4);
+  // the start-site weights of every bin in ONE block -- [28 Shine-Dalgarno bins][3 start types][threshold] x nbins -- so that a training
+  // round uploads them with one copy
+  const size_t npar = (size_t)nbins * 32;
+  d_par.ensure(npar * 8);
+  double *const rw_dev = d_par.as<double>(), *const tw_dev = rw_dev + (size_t)nbins * 28, *const sth_dev = tw_dev + (size_t)nbins * 3;
   double *bias = d_bias.as<double>();
   if (NT[0]) {
     // GC-frame codon counts of every start node's reading frame, its bias class and its term of the ordered sum (node.c: record_gc_bias)
@@ -776,22 +781,26 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
     });
     tp("hexamer statistics");
     g_h2d(e, d_dc.p, h_dc.data(), h_dc.size() * 8);
-    g_zero(e, d_rw.p, 0, (size_t)nbins * 28 * 8);
+    g_zero(e, rw_dev, 0, (size_t)nbins * 28 * 8);
     {
       GTimer t; t.begin(e);
       x_cscore(e, code, soff, slen_d, tn, d_dc.as<double>(), (uint32_t)NT[0]);
-      x_rbs(e, code, soff, slen_d, tn, d_rw.as<double>(), (uint32_t)NT[0]);
+      x_rbs(e, code, soff, slen_d, tn, rw_dev, (uint32_t)NT[0]);
       out.ms_score += t.end(e);
     }
     coding_passes(tn, NT[0]);
     // ---- start-site model: Shine-Dalgarno bins (node.c: train_starts_sd); counts on the device, logarithms on the host ----
-    uint32_t *cnt = d_cnt.as<uint32_t>(); double *rw = d_rw.as<double>(), *tw = d_tw.as<double>(), *sth = d_sth.as<double>();
-    std::vector<uint32_t> h_cnt((size_t)nbins * TC_SIZE);
-    std::vector<double> h_rw((size_t)nbins * 28, 0.0), h_tw((size_t)nbins * 3, 0.0), h_sth(nbins, 35.0);
+    uint32_t *cnt = d_cnt.as<uint32_t>(); double *rw = rw_dev, *tw = tw_dev, *sth = sth_dev;
+    g_host_reserve(e, 0, npar * 8 + (size_t)nbins * TC_SIZE * 4 + 1024);
+    uint32_t *h_cnt = g_host<uint32_t>(e, 0, (size_t)nbins * TC_SIZE);
+    double *h_par = g_host<double>(e, 0, npar), *h_rw = h_par, *h_tw = h_par + (size_t)nbins * 28, *h_sth = h_tw + (size_t)nbins * 3;
+    for (size_t k = 0; k < (size_t)nbins * 31; ++k) h_par[k] = 0.0;
+    for (uint32_t b = 0; b < nbins; ++b) h_sth[b] = 35.0;
+    const size_t cnt_bytes = (size_t)nbins * TC_SIZE * 4;
     std::vector<std::array<double, 3>> tbg(nbins);
-    g_zero(e, d_cnt.p, 0, (size_t)nbins * TC_SIZE * 4);
+    g_zero(e, d_cnt.p, 0, cnt_bytes);
     g_map(e, NT[0], [=] GLAM(size_t x) { if (tn.type[x] < G_STOP) g_count(&cnt[(size_t)tn.bin[x] * TC_SIZE + TC_TBG + tn.type[x]]); });
-    g_d2h(e, h_cnt.data(), cnt, h_cnt.size() * 4); g_sync(e);
+    g_down(e, h_cnt, cnt, cnt_bytes); g_sync(e);
     for (uint32_t b = 0; b < nbins; ++b) {
       double sum = 0.0;
       for (int i = 0; i < 3; ++i) { tbg[b][i] = (double)h_cnt[(size_t)b * TC_SIZE + TC_TBG + i]; sum += tbg[b][i]; }
@@ -799,8 +808,8 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
     }
     const uint32_t *ch = CH;
     for (int it = 0; it < 10; ++it) {
-      g_h2d(e, rw, h_rw.data(), h_rw.size() * 8); g_h2d(e, tw, h_tw.data(), h_tw.size() * 8); g_h2d(e, sth, h_sth.data(), (size_t)nbins * 8);
-      g_zero(e, d_cnt.p, 0, (size_t)nbins * TC_SIZE * 4);
+      g_up(e, rw_dev, h_par, npar * 8);
+      g_zero(e, d_cnt.p, 0, cnt_bytes);
       const int last = it == 9;
       g_map(e, NT[0], [=] GLAM(size_t x) {
         const int t = tn.type[x];
@@ -825,10 +834,10 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
           }
         }
       });
-      g_d2h(e, h_cnt.data(), cnt, h_cnt.size() * 4); g_sync(e);
+      g_down(e, h_cnt, cnt, cnt_bytes); g_sync(e);
       for (uint32_t b = 0; b < nbins; ++b) {
         if (!trained[b]) continue;
-        const uint32_t *c = h_cnt.data() + (size_t)b * TC_SIZE; GTrainH &t = tr[b];
+        const uint32_t *c = h_cnt + (size_t)b * TC_SIZE; GTrainH &t = tr[b];
         double rbg[28], rreal[28], treal[3], sum = 0.0;
         for (int j = 0; j < 28; ++j) { rbg[j] = (double)c[TC_RBG + j]; sum += rbg[j]; }
         for (int j = 0; j < 28; ++j) rbg[j] = sum ? rbg[j] / sum : 0.0;
@@ -856,12 +865,19 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
     for (uint32_t b = 0; b < nbins; ++b) if (trained[b] && tr[b].uses_sd == 0) { slot_of[b] = (int32_t)ns_bins.size(); ns_bins.push_back(b); }
     if (!ns_bins.empty()) {
       const size_t nsl = ns_bins.size();
-      GBuf d_slot, d_mw, d_nm, d_mbg, d_mreal, d_bg0, d_real0;
-      d_slot.ensure((size_t)nbins * 4); d_mw.ensure(nsl * MOT_N * 8); d_nm.ensure((size_t)nbins * 8); d_mbg.ensure(nsl * MOT_N * 4); d_mreal.ensure(nsl * MOT_N * 4);
-      d_bg0.ensure(nsl * 4 * 4096 * 4); d_real0.ensure(nsl * 4 * 4096 * 4);
+      // One block of weights going up -- [motif tables of the bins without Shine-Dalgarno sites][no-motif weight of every bin] -- and one
+      // block of counters coming down -- [stage-0 background][per-bin counters][stage-0 real][stage 1-2 background][stage 1-2 real] -- so
+      // that a round is two uploads, one clear, two kernels and one download.
+      GBuf d_slot, d_mpar, d_mall;
+      const size_t n_mpar = nsl * MOT_N + nbins, n_s0 = nsl * 4 * 4096, n_cnt = (size_t)nbins * TC_SIZE, n_mall = 2 * n_s0 + n_cnt + 2 * nsl * MOT_N;
+      d_slot.ensure((size_t)nbins * 4); d_mpar.ensure(n_mpar * 8); d_mall.ensure(n_mall * 4);
       g_h2d(e, d_slot.p, slot_of.data(), (size_t)nbins * 4);
-      const int32_t *slot = d_slot.as<int32_t>(); double *mw = d_mw.as<double>(), *nm = d_nm.as<double>();
-      uint32_t *mbg = d_mbg.as<uint32_t>(), *mreal = d_mreal.as<uint32_t>(), *bg0 = d_bg0.as<uint32_t>(), *real0 = d_real0.as<uint32_t>();
+      const int32_t *slot = d_slot.as<int32_t>(); double *mw = d_mpar.as<double>(), *nm = mw + nsl * MOT_N;
+      uint32_t *bg0 = d_mall.as<uint32_t>(), *cnt = bg0 + n_s0, *real0 = cnt + n_cnt, *mbg = real0 + n_s0, *mreal = mbg + nsl * MOT_N;       // (`cnt`: the rounds' own counters from here on)
+      g_host_reserve(e, 1, n_mpar * 8 + n_mall * 4 + 4096);
+      double *h_mpar = g_host<double>(e, 1, n_mpar), *h_nm = h_mpar + nsl * MOT_N;
+      uint32_t *h_mall = g_host<uint32_t>(e, 1, n_mall), *h_bg0 = h_mall, *h_cnt = h_bg0 + n_s0, *h_real0 = h_cnt + n_cnt, *h_mbg = h_real0 + n_s0, *h_mreal = h_mbg + nsl * MOT_N;
+      for (size_t k = 0; k < n_mpar; ++k) h_mpar[k] = 0.0;
       upstream_windows(tn, NT[0]);
       // the twenty rounds visit the nodes of THESE bins only: their 256-node blocks, one after the other (a bin's range starts at a multiple of 256)
       std::vector<uint32_t> h_blk;
@@ -869,19 +885,16 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
       GBuf d_blk; d_blk.ensure(std::max<size_t>(1, h_blk.size()) * 4);
       g_h2d(e, d_blk.p, h_blk.data(), h_blk.size() * 4);
       const uint32_t *blk = d_blk.as<uint32_t>(); const size_t n_ns = h_blk.size() * 256;
-      std::vector<std::vector<double>> h_mw(nsl, std::vector<double>(MOT_N, 0.0));
-      std::vector<double> h_nm(nbins, 0.0);
-      std::vector<uint32_t> h_mbg(nsl * MOT_N), h_mreal(nsl * MOT_N), h_bg0(nsl * 4 * 4096), h_real0(nsl * 4 * 4096);
       std::vector<double> zbg0(nsl, 0.0);
       std::vector<std::vector<int>> h_good(nsl, std::vector<int>(MOT_N, 0));
       for (uint32_t b : ns_bins) { GTrainH &t = tr[b]; for (int j = 0; j < 3; ++j) t.type_wt[j] = 0.0; t.no_mot = 0.0; memset(t.ups_comp, 0, sizeof(t.ups_comp)); h_sth[b] = 35.0; for (int j = 0; j < 3; ++j) h_tw[(size_t)b * 3 + j] = 0.0; }
       for (int it = 0; it < 20; ++it) {
         const int stage = it < 4 ? 0 : it < 12 ? 1 : 2, last = it == 19;
-        for (size_t k = 0; k < nsl; ++k) g_h2d(e, mw + k * MOT_N, h_mw[k].data(), MOT_N * 8);
-        g_h2d(e, nm, h_nm.data(), (size_t)nbins * 8); g_h2d(e, tw, h_tw.data(), h_tw.size() * 8); g_h2d(e, sth, h_sth.data(), (size_t)nbins * 8);
-        g_zero(e, d_cnt.p, 0, (size_t)nbins * TC_SIZE * 4);
-        if (stage == 0) { if (it == 0) g_zero(e, d_bg0.p, 0, nsl * 4 * 4096 * 4); g_zero(e, d_real0.p, 0, nsl * 4 * 4096 * 4); }
-        else { g_zero(e, d_mbg.p, 0, nsl * MOT_N * 4); g_zero(e, d_mreal.p, 0, nsl * MOT_N * 4); }
+        g_up(e, mw, h_mpar, n_mpar * 8);
+        g_up(e, rw_dev, h_par, npar * 8);
+        // counters: stage 0 keeps its background of the first round; the later stages clear (and fetch) everything behind it
+        uint32_t *const c_lo = it == 0 ? bg0 : cnt; uint32_t *const c_hi = stage == 0 ? real0 + n_s0 : mreal + nsl * MOT_N;
+        g_zero(e, c_lo, 0, (size_t)(c_hi - c_lo) * 4);
         const int count_bg0 = it == 0;
         // the best motif of every start node under the current weights, and the background counts
         g_map(e, n_ns, [=] GLAM(size_t xi) {
@@ -941,12 +954,10 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
             for (int i = 1; i < 45; ++i) { if (i > 2 && i < 15) continue; if (start - i >= 0) g_count(&cb[TC_UPS + count * 4 + q.at(str, start - i)]); count++; }
           }
         });
-        g_d2h(e, h_cnt.data(), cnt, h_cnt.size() * 4);
-        if (stage == 0) { if (it == 0) g_d2h(e, h_bg0.data(), bg0, h_bg0.size() * 4); g_d2h(e, h_real0.data(), real0, h_real0.size() * 4); }
-        else { g_d2h(e, h_mbg.data(), mbg, h_mbg.size() * 4); g_d2h(e, h_mreal.data(), mreal, h_mreal.size() * 4); }
+        g_down(e, h_mall + (c_lo - bg0), c_lo, (size_t)(c_hi - c_lo) * 4);
         g_sync(e);
         in.pfor(nsl, [&](size_t k) {
-          const uint32_t b = ns_bins[k]; GTrainH &t = tr[b]; const uint32_t *c = h_cnt.data() + (size_t)b * TC_SIZE;
+          const uint32_t b = ns_bins[k]; GTrainH &t = tr[b]; const uint32_t *c = h_cnt + (size_t)b * TC_SIZE;
           std::vector<double> vbg(MOT_N), vreal(MOT_N); std::vector<int> &good = h_good[k];
           if (it == 0) zbg0[k] = (double)c[TC_ZBG];
           double zbg = stage == 0 ? zbg0[k] : (double)c[TC_ZBG], zreal = (double)c[TC_ZREAL];
@@ -965,8 +976,8 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
           if (stage < 2) host_build_coverage_map(vreal, good, ngenes);
           sum = zreal;
           for (double x : vreal) sum += x;
-          std::vector<double> &mwt = h_mw[k];
-          if (sum == 0.0) { std::fill(mwt.begin(), mwt.end(), 0.0); t.no_mot = 0.0; }
+          double *mwt = h_mpar + k * MOT_N;
+          if (sum == 0.0) { std::fill(mwt, mwt + MOT_N, 0.0); t.no_mot = 0.0; }
           else {
             for (size_t q = 0; q < MOT_N; ++q) {
               if (good[q] == 0) { zreal += vreal[q]; zbg += vreal[q]; vreal[q] = 0.0; vbg[q] = 0.0; }
@@ -985,7 +996,7 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
           if (sum <= (double)seq_n[b] / 2000.0) h_sth[b] /= 2.0;
           h_nm[b] = t.no_mot;
           for (int j = 0; j < 3; ++j) h_tw[(size_t)b * 3 + j] = t.type_wt[j];
-          if (last) { for (int i = 0; i < 32; ++i) for (int j = 0; j < 4; ++j) t.ups_comp[i][j] = (double)c[TC_UPS + i * 4 + j]; host_ups_to_log(t); t.mot_wt = mwt; }
+          if (last) { for (int i = 0; i < 32; ++i) for (int j = 0; j < 4; ++j) t.ups_comp[i][j] = (double)c[TC_UPS + i * 4 + j]; host_ups_to_log(t); t.mot_wt.assign(mwt, mwt + MOT_N); }
         });
       }
       tp("upstream-motif training");
@@ -1012,13 +1023,13 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
     for (uint32_t b = 0; b < nbins; ++b) if (!trained[b]) { out.bin_uses_sd[b] = 0; out.bin_gc[b] = tr[b].gc; }
     GBuf d_ups, d_nm, d_sd, d_slot, d_mw;
     d_ups.ensure((size_t)nbins * 128 * 8); d_nm.ensure((size_t)nbins * 8); d_sd.ensure(nbins); d_slot.ensure((size_t)nbins * 4); d_mw.ensure(std::max<size_t>(1, ns_bins.size()) * MOT_N * 8);
-    g_h2d(e, d_dc.p, h_dc.data(), h_dc.size() * 8); g_h2d(e, d_rw.p, h_rw.data(), h_rw.size() * 8); g_h2d(e, d_tw.p, h_tw.data(), h_tw.size() * 8); g_h2d(e, d_ups.p, h_ups.data(), h_ups.size() * 8);
+    g_h2d(e, d_dc.p, h_dc.data(), h_dc.size() * 8); g_h2d(e, rw_dev, h_rw.data(), h_rw.size() * 8); g_h2d(e, tw_dev, h_tw.data(), h_tw.size() * 8); g_h2d(e, d_ups.p, h_ups.data(), h_ups.size() * 8);
     g_h2d(e, d_nm.p, h_nm.data(), (size_t)nbins * 8); g_h2d(e, d_sd.p, h_sd.data(), nbins); g_h2d(e, d_slot.p, slot_of.data(), (size_t)nbins * 4);
     for (size_t k = 0; k < ns_bins.size(); ++k) {
       const std::vector<double> &m = tr[ns_bins[k]].mot_wt;
       if (m.size() == MOT_N) g_h2d(e, d_mw.as<double>() + k * MOT_N, m.data(), MOT_N * 8); else g_zero(e, d_mw.as<double>() + k * MOT_N, 0, MOT_N * 8);
     }
-    const double *rw = d_rw.as<double>(), *tw = d_tw.as<double>(), *ups = d_ups.as<double>(), *nm = d_nm.as<double>(), *mw = d_mw.as<double>();
+    const double *rw = rw_dev, *tw = tw_dev, *ups = d_ups.as<double>(), *nm = d_nm.as<double>(), *mw = d_mw.as<double>();
     const uint8_t *uses_sd = d_sd.as<uint8_t>(); const int32_t *slot = d_slot.as<int32_t>();
     {
       GTimer t; t.begin(e);
