@@ -246,8 +246,9 @@ struct Worker {
   size_t ws_budget = (size_t)8 << 30;     // float workspace budget (bytes) for Forward/Backward matrices
   std::unique_ptr<HostPool> pool;         // host threads of this worker
   // ---- device-driven cascade (ckm_cascade.hip): tables, queues and result buffers of this lane; capacities only grow ----
-  struct CascadeCaps { uint32_t fwork = 0, ework = 0, rwork = 0, pass = 0, reg = 0, events_f = 0, events_e = 0; uint64_t hens = 0;
-                       uint32_t div_cand = 12, div_nores = 48, div_fwork = 160, div_ework = 256, div_rwork = 32768; float ws_per_cell = 11.f; } caps;   // per-group tables hold pairs / div entries
+  struct CascadeCaps { uint32_t fwork = 0, ework = 0, rwork = 0, pass = 0, reg = 0, events_f = 0, events_e = 0, seen_rwork = 0; uint64_t hens = 0;
+                       uint32_t div_cand = 12, div_nores = 48, div_fwork = 160, div_ework = 256, div_rwork = 32768;        // per-group tables hold max(pairs / div, floor) entries
+                       uint32_t fl_cand = 4096, fl_nores = 2048, fl_fwork = 2048, fl_ework = 1024, fl_rwork = 256; float ws_per_cell = 11.f; } caps;
   DevBuf c_cnt, c_cand, c_nores, c_bias, c_vfast, c_vexact, c_vflag, c_route, c_vq, c_vxq, c_fq, c_bq, c_eq, c_rq, c_fwork, c_ework, c_rwork, c_ens, c_ensq,
          c_fout_f, c_fout_e, c_fout_r, c_rerr_e, c_rerr_r, c_tops, c_events_r, c_pass, c_reg, c_hens, c_envout, c_events_f, c_events_e;
   PinnedBuf h_cnt, h_pass, h_reg, h_envout, h_events_f, h_events_e, h_hens, h_tops;

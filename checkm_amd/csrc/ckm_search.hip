@@ -642,12 +642,12 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   auto capof = [&](uint64_t pairs, uint32_t div, uint64_t floor_) {
     return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(shrink > 1 ? 8 : floor_, pairs / ((uint64_t)div * shrink)), 0x7ffffff0ull); };
   for (Sub &sb : subs) {
-    sb.cap_cand = capof(sb.pairs, cp.div_cand, 4096);
+    sb.cap_cand = capof(sb.pairs, cp.div_cand, cp.fl_cand);
     sb.cap_nores = sb.Q == kSsvNone ? (uint32_t)std::min<uint64_t>(sb.pairs + 64, 0x7ffffff0ull)     // no SSV for these models: every pair is recomputed exactly
-                                    : capof(sb.pairs, cp.div_nores, 2048);
-    sb.cap_f = capof(sb.pairs, cp.div_fwork, 2048);
-    sb.cap_e = capof(sb.pairs, cp.div_ework, 1024);
-    sb.cap_r = capof(sb.pairs, cp.div_rwork, 256);
+                                    : capof(sb.pairs, cp.div_nores, cp.fl_nores);
+    sb.cap_f = capof(sb.pairs, cp.div_fwork, cp.fl_fwork);
+    sb.cap_e = capof(sb.pairs, cp.div_ework, cp.fl_ework);
+    sb.cap_r = capof(sb.pairs, cp.div_rwork, cp.fl_rwork);
     sb.o_cand = tot_cand; tot_cand += sb.cap_cand; sb.o_nores = tot_nores; tot_nores += sb.cap_nores;
     sb.o_vq = sb.o_cand * NVC;
     sb.o_f = tot_f * NFC; tot_f += sb.cap_f; sb.o_e = tot_e * NFC; tot_e += sb.cap_e; sb.o_r = tot_r * NFC; tot_r += sb.cap_r;
@@ -657,7 +657,9 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   grow(cp.pass, std::max<uint64_t>(1 << 13, tot_e)); grow(cp.reg, (uint64_t)cp.ework + cp.rwork);
   grow(cp.events_f, std::max<uint64_t>(1 << 18, (uint64_t)cp.fwork * 16));
   grow(cp.events_e, std::max<uint64_t>(1 << 16, (uint64_t)cp.ework * 16));
-  cp.hens = std::max<uint64_t>(cp.hens, (uint64_t)cp.rwork * (256 + ENS_NSAMPLES * 16 * 4 + 1024));
+  // (the export buffer of the ensembles is sized for the regions SEEN so far, with room -- not for the region tables' capacity, which is
+  //  a floor per group times the groups; an overflow doubles it: CS_RWORK)
+  cp.hens = std::max<uint64_t>(cp.hens, std::min<uint64_t>(cp.rwork, (uint64_t)4 * cp.seen_rwork + 8192) * (256 + ENS_NSAMPLES * 16 * 4 + 1024));
   // the float workspace: an estimate from the pairs (special rows of ~0.3 % of them, matrices of ~0.06 %), within the lane's budget
   // the float workspace, estimated from the cells the search is expected to fill: a marker model finds about one domain in a bin it is
   // scanned against, and a domain costs its envelope's matrix (about M rows of Mp floats, three arrays in place) -- so the demand follows
@@ -882,31 +884,40 @@ static int cascade_dev(Worker *ctx, ckm_ctx *owner, int my_turn, const ckm_profi
   auto over = [&](const char *what, int g, int k, uint64_t n, uint64_t cap) {
     fits = false; if (tr) fprintf(stderr, "ckm-trace w%d table %s (group %d, class %d) wanted %llu of %llu\n", ctx->id, what, g, k, (unsigned long long)n, (unsigned long long)cap); };
   auto need = [&](const char *what, uint32_t &cap, uint32_t n) { if (n > cap) { over(what, -1, -1, n, cap); cap = (uint32_t)std::min<uint64_t>((uint64_t)n + n / 4 + 1024, 0xfffffff0ull); } };
+  cp.seen_rwork = std::max(cp.seen_rwork, n_rwork);
   need("fwork", cp.fwork, n_fwork); need("ework", cp.ework, n_ework); need("rwork", cp.rwork, n_rwork); need("pass", cp.pass, n_pass);
   need("reg", cp.reg, n_reg); need("events_f", cp.events_f, n_evf); need("events_e", cp.events_e, n_eve);
-  auto halve = [&](uint32_t &d) { d = std::max<uint32_t>(1, d / 2); };
+  // A per-group table that overflowed is sized from what the group ASKED for (round 6): its divisor follows the observed share of the
+  // pairs and its floor the observed count (+25 %), so that the same kind of search fits the next time.  Rounds 2-5 halved the divisor
+  // once per search -- which changes nothing where the floor is the larger term: on inputs with many multi-domain regions (paralog
+  // families, low-complexity proteins: bench.py's hard_workload) the 256-entry region queues overflowed in EVERY search, and every search
+  // paid the host-driven cascade (profiles/r06q_hard_workload_overflows.txt).
+  // (the divisor still halves at most once per search, and only where it was the larger term: a small group's share says nothing about
+  //  the large ones -- regions follow the domains present, not the pairs scanned)
+  uint32_t halved = 0;
+  auto learn = [&](int kind, uint32_t &div, uint32_t &floor_, uint64_t pairs, uint64_t want) {
+    const uint64_t w = want + want / 4 + 16;
+    if ((pairs / std::max<uint64_t>(1, (uint64_t)div * shrink) >= floor_ || shrink > 1) && !((halved >> kind) & 1u)) { div = std::max<uint32_t>(1, div / 2); halved |= 1u << kind; }
+    if (shrink == 1) floor_ = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(floor_, w), 1u << 14);
+  };
   uint64_t n_cand = 0, n_nores = 0;
-  bool o_cand = false, o_nores = false, o_f = false, o_e = false, o_r = false;   // (a divisor halves once per search, however many groups overflowed)
   for (size_t g = 0; g < NG; ++g) {
     const uint32_t *c = h_cnt + (1 + g) * CC_SIZE; const Sub &sb = subs[g];
     n_cand += c[CC_CAND]; n_nores += c[CC_NORES];
-    if (c[CC_CAND] > sb.cap_cand) { over("cand", (int)g, -1, c[CC_CAND], sb.cap_cand); o_cand = true; }
-    if (c[CC_NORES] > sb.cap_nores) { over("nores", (int)g, -1, c[CC_NORES], sb.cap_nores); if (sb.Q != kSsvNone) o_nores = true; }
+    if (c[CC_CAND] > sb.cap_cand) { over("cand", (int)g, -1, c[CC_CAND], sb.cap_cand); learn(0, cp.div_cand, cp.fl_cand, sb.pairs, c[CC_CAND]); }
+    if (c[CC_NORES] > sb.cap_nores) { over("nores", (int)g, -1, c[CC_NORES], sb.cap_nores); if (sb.Q != kSsvNone) learn(1, cp.div_nores, cp.fl_nores, sb.pairs, c[CC_NORES]); }
     for (int k = 0; k < NVC; ++k) {
       st.pairs_vit += c[CC_VQ + k]; st.pairs_vit_exact += c[CC_VXQ + k];
-      if (c[CC_VQ + k] > sb.cap_cand || c[CC_VXQ + k] > sb.cap_cand) { over("vq", (int)g, k, std::max(c[CC_VQ + k], c[CC_VXQ + k]), sb.cap_cand); o_cand = true; }
+      const uint32_t v = std::max(c[CC_VQ + k], c[CC_VXQ + k]);
+      if (v > sb.cap_cand) { over("vq", (int)g, k, v, sb.cap_cand); learn(0, cp.div_cand, cp.fl_cand, sb.pairs, v); }
     }
     for (int k = 0; k < NFC; ++k) {
-      if (c[CC_FQ + k] > sb.cap_f || c[CC_BQ + k] > sb.cap_f) { over("fq", (int)g, k, std::max(c[CC_FQ + k], c[CC_BQ + k]), sb.cap_f); o_f = true; }
-      if (c[CC_EQ + k] > sb.cap_e) { over("eq", (int)g, k, c[CC_EQ + k], sb.cap_e); o_e = true; }
-      if (c[CC_RQ + k] > sb.cap_r) { over("rq", (int)g, k, c[CC_RQ + k], sb.cap_r); o_r = true; }
+      const uint32_t f = std::max(c[CC_FQ + k], c[CC_BQ + k]);
+      if (f > sb.cap_f) { over("fq", (int)g, k, f, sb.cap_f); learn(2, cp.div_fwork, cp.fl_fwork, sb.pairs, f); }
+      if (c[CC_EQ + k] > sb.cap_e) { over("eq", (int)g, k, c[CC_EQ + k], sb.cap_e); learn(3, cp.div_ework, cp.fl_ework, sb.pairs, c[CC_EQ + k]); }
+      if (c[CC_RQ + k] > sb.cap_r) { over("rq", (int)g, k, c[CC_RQ + k], sb.cap_r); learn(4, cp.div_rwork, cp.fl_rwork, sb.pairs, c[CC_RQ + k]); }
     }
   }
-  if (o_cand) halve(cp.div_cand);
-  if (o_nores) halve(cp.div_nores);
-  if (o_f) halve(cp.div_fwork);
-  if (o_e) halve(cp.div_ework);
-  if (o_r) halve(cp.div_rwork);
   if (status & CS_RWORK) cp.hens *= 2;
   // zone 2 ran out (regions were deferred to the host): size the workspace from what this search asked for, for the next calls
   st.ws_cap_bytes = ctx->ws.cap; st.ws_used_bytes = (std::min<uint64_t>(h_tops[0], cd0.ws_cap) + h_tops[2]) * 4;
