@@ -395,6 +395,12 @@ GFN unsigned long long upstream_window(const GSeq &s, int strand, int start) {
 GFN int upw_mer(unsigned long long w, int start, int len, int j) { return (int)((w >> (2 * (j - (start - 21)))) & ((1ull << (2 * len)) - 1)); }
 GFN int spacer_ndx(int j, int start, int i) { if (j <= start - 16 - i) return 3; if (j <= start - 14 - i) return 2; if (j >= start - 7 - i) return 1; return 0; }
 
+// the words the first training round counts for a start (update_motif_counts, stage 0): f(length - 3, word) for lengths 6 .. 3 at the
+// positions of the upstream window
+template <class F> GFN void motif_words_stage0(unsigned long long upw, int start, F f) {
+  for (int i = 3; i >= 0; --i) for (int j = start - 18 - i; j <= start - 6 - i; ++j) { if (j < 0) continue; f(i, upw_mer(upw, start, i + 3, j)); }
+}
+
 // find_best_upstream_motif: mot_wt = the bin's [4][4][4096] table.  Returns the packed motif and its score.
 GFN uint32_t best_upstream_motif(const double *mot_wt, double no_mot, unsigned long long upw, int start, int stage, double &mot_score) {
   int max_spacer = 0, max_spacendx = 0, max_len = 0, max_ndx = 0; double max_sc = -100.0;

@@ -284,6 +284,32 @@ void x_rbs(GExec &e, const uint8_t *code, const uint64_t *seq_off, const int32_t
   if (n) hipLaunchKernelGGL(rbs_kernel, dim3((n + 255) / 256), dim3(256), 0, e.st, code, seq_off, seq_len, nd, rbs_wt, n);
 }
 
+// ---- background words of the upstream-motif training's first round ----
+// 5440 counters (64 + 256 + 1024 + 4096 words of 3 .. 6 bases) in LDS per workgroup, a workgroup per eighth of a bin's nodes: 52 LDS
+// increments per start node and one flush, where the thread-per-node kernel sent 52 atomics per start to a 64 KB table in memory (42 M
+// per 48-bin call: 7.7 ms of its own, and the wavefronts stayed until the atomics had drained)
+__global__ void __launch_bounds__(256) motif_bg0_kernel(Nodes nd, const int32_t *__restrict__ seq_len, const MotifPart *__restrict__ parts, uint32_t *__restrict__ bg0) {
+  __shared__ uint32_t h[5440];
+  const MotifPart pt = parts[blockIdx.x];
+  for (int k = threadIdx.x; k < 5440; k += 256) h[k] = 0;
+  __syncthreads();
+  for (uint32_t x = pt.lo + threadIdx.x; x < pt.hi; x += 256) {
+    if (nd.type[x] >= G_STOP || nd.edge[x] == 1) continue;
+    const int sl = seq_len[nd.seq[x]], strand = nd.strand[x], start = strand == 1 ? nd.ndx[x] : sl - 1 - nd.ndx[x];
+    motif_words_stage0(nd.upw[x], start, [&](int i, int w) { atomicAdd(&h[((64 << (2 * i)) - 64) / 3 + w], 1u); });      // (tables of 64, 256, 1024, 4096 words one behind the other)
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 5440; k += 256) {
+    const uint32_t v = h[k];
+    if (!v) continue;
+    const int i = k < 64 ? 0 : k < 320 ? 1 : k < 1344 ? 2 : 3, w = k - ((64 << (2 * i)) - 64) / 3;
+    atomicAdd(&bg0[((size_t)pt.slot * 4 + i) * 4096 + w], v);
+  }
+}
+void x_motif_bg0(GExec &e, const Nodes &nd, const int32_t *seq_len, const MotifPart *parts, uint32_t nparts, uint32_t *bg0) {
+  if (nparts) hipLaunchKernelGGL(motif_bg0_kernel, dim3(nparts), dim3(256), 0, e.st, nd, seq_len, parts, bg0);
+}
+
 // ---- hexamer background ----
 constexpr int HEX_SLICE = 65536;
 __global__ void __launch_bounds__(256) hexbg_kernel(const uint8_t *__restrict__ code, const uint64_t *__restrict__ seq_off, const int32_t *__restrict__ seq_len, uint32_t *__restrict__ hist) {

@@ -178,6 +178,14 @@ void x_path_ends(GExec &, const Nodes &nd, const uint32_t *seq_lo, const uint32_
   }
 }
 
+void x_motif_bg0(GExec &, const Nodes &nd, const int32_t *seq_len, const MotifPart *parts, uint32_t nparts, uint32_t *bg0) {
+  for (uint32_t p = 0; p < nparts; ++p) for (uint32_t x = parts[p].lo; x < parts[p].hi; ++x) {
+    if (nd.type[x] >= G_STOP || nd.edge[x] == 1) continue;
+    const int sl = seq_len[nd.seq[x]], strand = nd.strand[x], start = strand == 1 ? nd.ndx[x] : sl - 1 - nd.ndx[x];
+    motif_words_stage0(nd.upw[x], start, [&](int i, int w) { bg0[((size_t)parts[p].slot * 4 + i) * 4096 + w]++; });
+  }
+}
+
 void x_hexamer_background(GExec &, const uint8_t *code, const uint64_t *seq_off, const int32_t *seq_len, uint32_t nbins, int, uint32_t *hist) {
   memset(hist, 0, (size_t)nbins * 4096 * 4);
   for (uint32_t b = 0; b < nbins; ++b) {
