@@ -401,6 +401,16 @@ template <class F> GFN void motif_words_stage0(unsigned long long upw, int start
   for (int i = 3; i >= 0; --i) for (int j = start - 18 - i; j <= start - 6 - i; ++j) { if (j < 0) continue; f(i, upw_mer(upw, start, i + 3, j)); }
 }
 
+// the words the later rounds count for a start whose current motif is m (update_motif_counts, stages 1 and 2): f(length - 3, spacer class, word)
+template <class F> GFN void motif_words_stage12(uint32_t m, unsigned long long upw, int start, int stage, F f) {
+  const int ml = mot_len(m);
+  if (ml == 0) return;
+  f(ml - 3, mot_spacendx(m), mot_ndx(m));
+  if (stage != 1) return;
+  const int sp = mot_spacer(m);
+  for (int i = 0; i < ml - 3; ++i) for (int j = start - sp - ml; j <= start - sp - (i + 3); ++j) { if (j < 0) continue; f(i, spacer_ndx(j, start, i), upw_mer(upw, start, i + 3, j)); }
+}
+
 // find_best_upstream_motif: mot_wt = the bin's [4][4][4096] table.  Returns the packed motif and its score.
 GFN uint32_t best_upstream_motif(const double *mot_wt, double no_mot, unsigned long long upw, int start, int stage, double &mot_score) {
   int max_spacer = 0, max_spacendx = 0, max_len = 0, max_ndx = 0; double max_sc = -100.0;

@@ -169,11 +169,12 @@ void x_path_ends(GExec &e, const Nodes &nd, const uint32_t *seq_lo, const uint32
 // hexamer counts of both strands of every bin's training sequence: hist[b][f] = number of positions whose forward hexamer is f
 void x_hexamer_background(GExec &e, const uint8_t *code, const uint64_t *seq_off, const int32_t *seq_len, uint32_t nbins, int max_len, uint32_t *hist /* [nbins][4096] */);
 
-// the background of the upstream-motif training's first round (node.c: train_starts_nonsd, stage 0): for every start node of the parts'
-// node ranges that is not an edge, every word of 3-6 bases at the 13 positions of its upstream window, counted into
-// bg0[slot][length - 3][word] -- 52 increments per start; on the device a workgroup per part with the 5440 counters in LDS
+// the background word counts of a round of the upstream-motif training (node.c: update_motif_counts over every start node that is not an
+// edge).  Stage 0: every word of 3-6 bases at the 13 positions of the upstream window, into tab[slot][length - 3][word] (52 increments
+// per start); stages 1 and 2: the start's current motif (nd.mot) and, in stage 1, the shorter words inside it, into
+// tab[slot][length - 3][spacer class][word].  On the device a workgroup per part with the counters in LDS.
 struct MotifPart { uint32_t lo, hi, slot, pad; };
-void x_motif_bg0(GExec &e, const Nodes &nd, const int32_t *seq_len, const MotifPart *parts, uint32_t nparts, uint32_t *bg0 /* [slots][4][4096] */);
+void x_motif_bg(GExec &e, int stage, const Nodes &nd, const int32_t *seq_len, const MotifPart *parts, uint32_t nparts, uint32_t *tab);
 
 // hexamer sums (bin tables staged in LDS on the device) and Shine-Dalgarno bins of every start node
 void x_cscore(GExec &e, const uint8_t *code, const uint64_t *seq_off, const int32_t *seq_len, const Nodes &nd, const double *gene_dc, uint32_t n);

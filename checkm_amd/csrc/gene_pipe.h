@@ -885,11 +885,12 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
       GBuf d_blk; d_blk.ensure(std::max<size_t>(1, h_blk.size()) * 4);
       g_h2d(e, d_blk.p, h_blk.data(), h_blk.size() * 4);
       const uint32_t *blk = d_blk.as<uint32_t>(); const size_t n_ns = h_blk.size() * 256;
-      // the first round's background words: every bin's nodes in eight parts, a workgroup each (x_motif_bg0)
+      // the rounds' background words: every bin's nodes in eight parts, a workgroup each (x_motif_bg)
       std::vector<MotifPart> h_bgp;
       for (size_t k = 0; k < nsl; ++k) {
-        const uint32_t b = ns_bins[k], lo = seq_lo[b], n = seq_n[b], per = ((n + 7) / 8 + 255) & ~255u;
-        for (uint32_t a = 0; a < n; a += std::max<uint32_t>(per, 256)) h_bgp.push_back(MotifPart{lo + a, std::min(n, a + std::max<uint32_t>(per, 256)) + lo, (uint32_t)k, 0});
+        // (a part holds fewer than 65536 nodes: the later rounds count in 16-bit halves)
+        const uint32_t b = ns_bins[k], lo = seq_lo[b], n = seq_n[b], per = std::min<uint32_t>(65280u, std::max<uint32_t>(256u, ((n + 7) / 8 + 255) & ~255u));
+        for (uint32_t a = 0; a < n; a += per) h_bgp.push_back(MotifPart{lo + a, std::min(n, a + per) + lo, (uint32_t)k, 0});
       }
       GBuf d_bgp; d_bgp.ensure(std::max<size_t>(1, h_bgp.size()) * sizeof(MotifPart));
       g_h2d(e, d_bgp.p, h_bgp.data(), h_bgp.size() * sizeof(MotifPart));
@@ -917,17 +918,10 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
           uint32_t *cb = cnt + (size_t)b * TC_SIZE;
           if (stage == 0 && !count_bg0) return;
           if (mot_len(m) == 0) { g_count(&cb[TC_ZBG]); return; }
-          if (stage == 0) return;               // (the words of the first round's background are counted by x_motif_bg0 below: they depend on the windows only)
-          if (stage == 1) {
-            uint32_t *tab = mbg + (size_t)k * MOT_N; const int ml = mot_len(m), sp = mot_spacer(m);
-            g_atomic_add(&tab[((size_t)(ml - 3) * 4 + mot_spacendx(m)) * 4096 + mot_ndx(m)], 1u);
-            for (int i = 0; i < ml - 3; ++i) for (int j = start - sp - ml; j <= start - sp - (i + 3); ++j) {
-              if (j < 0) continue;
-              g_atomic_add(&tab[((size_t)i * 4 + spacer_ndx(j, start, i)) * 4096 + upw_mer(upw, start, i + 3, j)], 1u);
-            }
-          } else g_atomic_add(&mbg[(size_t)k * MOT_N + ((size_t)(mot_len(m) - 3) * 4 + mot_spacendx(m)) * 4096 + mot_ndx(m)], 1u);
+          // (the background WORDS of every stage are counted by x_motif_bg below, workgroup by workgroup in LDS: the first round's depend on
+          //  the windows only, the later rounds' on the motif just stored)
         });
-        if (count_bg0) x_motif_bg0(e, tn, slen_d, d_bgp.as<MotifPart>(), (uint32_t)h_bgp.size(), bg0);
+        if (count_bg0 || stage > 0) x_motif_bg(e, stage, tn, slen_d, d_bgp.as<MotifPart>(), (uint32_t)h_bgp.size(), stage == 0 ? bg0 : mbg);
         // the best start of every open reading frame, and the counts of the ones above the threshold
         g_map(e, n_ns, [=] GLAM(size_t xi) {
           const size_t x = (size_t)blk[xi >> 8] + (xi & 255);

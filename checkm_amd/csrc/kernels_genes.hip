@@ -284,30 +284,62 @@ void x_rbs(GExec &e, const uint8_t *code, const uint64_t *seq_off, const int32_t
   if (n) hipLaunchKernelGGL(rbs_kernel, dim3((n + 255) / 256), dim3(256), 0, e.st, code, seq_off, seq_len, nd, rbs_wt, n);
 }
 
-// ---- background words of the upstream-motif training's first round ----
-// 5440 counters (64 + 256 + 1024 + 4096 words of 3 .. 6 bases) in LDS per workgroup, a workgroup per eighth of a bin's nodes: 52 LDS
-// increments per start node and one flush, where the thread-per-node kernel sent 52 atomics per start to a 64 KB table in memory (42 M
-// per 48-bin call: 7.7 ms of its own, and the wavefronts stayed until the atomics had drained)
+// ---- background words of the upstream-motif training's rounds ----
+// A workgroup per eighth of a bin's nodes, the counters in LDS, one flush: the thread-per-node kernel sent 52 atomics per start (first
+// round) or up to seven (stage 1) to tables in memory -- 42 M + 45 M per 48-bin call, and its wavefronts stayed resident until they had
+// drained (27 % of a call's wavefront-cycles: profiles/r06o).  Stage 0: 5440 counters (64 + 256 + 1024 + 4096 words of 3 .. 6 bases).
+// Stages 1 / 2: four spacer classes of those, 21760 counters held as 16-bit halves of 10880 words (a part has fewer than 65536 starts).
+constexpr int MOT_WORDS = 5440;
+__device__ __forceinline__ int mot_off(int i) { return ((64 << (2 * i)) - 64) / 3; }
 __global__ void __launch_bounds__(256) motif_bg0_kernel(Nodes nd, const int32_t *__restrict__ seq_len, const MotifPart *__restrict__ parts, uint32_t *__restrict__ bg0) {
-  __shared__ uint32_t h[5440];
+  __shared__ uint32_t h[MOT_WORDS];
   const MotifPart pt = parts[blockIdx.x];
-  for (int k = threadIdx.x; k < 5440; k += 256) h[k] = 0;
+  for (int k = threadIdx.x; k < MOT_WORDS; k += 256) h[k] = 0;
   __syncthreads();
   for (uint32_t x = pt.lo + threadIdx.x; x < pt.hi; x += 256) {
     if (nd.type[x] >= G_STOP || nd.edge[x] == 1) continue;
     const int sl = seq_len[nd.seq[x]], strand = nd.strand[x], start = strand == 1 ? nd.ndx[x] : sl - 1 - nd.ndx[x];
-    motif_words_stage0(nd.upw[x], start, [&](int i, int w) { atomicAdd(&h[((64 << (2 * i)) - 64) / 3 + w], 1u); });      // (tables of 64, 256, 1024, 4096 words one behind the other)
+    motif_words_stage0(nd.upw[x], start, [&](int i, int w) { atomicAdd(&h[mot_off(i) + w], 1u); });
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < 5440; k += 256) {
+  for (int k = threadIdx.x; k < MOT_WORDS; k += 256) {
     const uint32_t v = h[k];
     if (!v) continue;
-    const int i = k < 64 ? 0 : k < 320 ? 1 : k < 1344 ? 2 : 3, w = k - ((64 << (2 * i)) - 64) / 3;
-    atomicAdd(&bg0[((size_t)pt.slot * 4 + i) * 4096 + w], v);
+    const int i = k < 64 ? 0 : k < 320 ? 1 : k < 1344 ? 2 : 3;
+    atomicAdd(&bg0[((size_t)pt.slot * 4 + i) * 4096 + (k - mot_off(i))], v);
   }
 }
-void x_motif_bg0(GExec &e, const Nodes &nd, const int32_t *seq_len, const MotifPart *parts, uint32_t nparts, uint32_t *bg0) {
-  if (nparts) hipLaunchKernelGGL(motif_bg0_kernel, dim3(nparts), dim3(256), 0, e.st, nd, seq_len, parts, bg0);
+__global__ void __launch_bounds__(256) motif_bg12_kernel(int stage, Nodes nd, const int32_t *__restrict__ seq_len, const MotifPart *__restrict__ parts, uint32_t *__restrict__ tab) {
+  __shared__ uint32_t h[2 * MOT_WORDS];                            // entry e = 4 * mot_off(i) + sp * 4^(i+3) + w lives in half (e & 1) of word e >> 1
+  const MotifPart pt = parts[blockIdx.x];
+  for (int k = threadIdx.x; k < 2 * MOT_WORDS; k += 256) h[k] = 0;
+  __syncthreads();
+  for (uint32_t x = pt.lo + threadIdx.x; x < pt.hi; x += 256) {
+    if (nd.type[x] >= G_STOP || nd.edge[x] == 1) continue;
+    const int sl = seq_len[nd.seq[x]], strand = nd.strand[x], start = strand == 1 ? nd.ndx[x] : sl - 1 - nd.ndx[x];
+    motif_words_stage12(nd.mot[x], nd.upw[x], start, stage, [&](int i, int sp, int w) {
+      const int e = 4 * mot_off(i) + (sp << (2 * (i + 3))) + w;
+      atomicAdd(&h[e >> 1], (e & 1) ? 0x10000u : 1u);
+    });
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 2 * MOT_WORDS; k += 256) {
+    const uint32_t v = h[k];
+    if (!v) continue;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const uint32_t c = half ? v >> 16 : v & 0xffffu;
+      if (!c) continue;
+      const int e = 2 * k + half;
+      const int i = e < 4 * 64 ? 0 : e < 4 * 320 ? 1 : e < 4 * 1344 ? 2 : 3, r = e - 4 * mot_off(i), sp = r >> (2 * (i + 3)), w = r & ((1 << (2 * (i + 3))) - 1);
+      atomicAdd(&tab[(size_t)pt.slot * 65536 + ((size_t)i * 4 + sp) * 4096 + w], c);
+    }
+  }
+}
+void x_motif_bg(GExec &e, int stage, const Nodes &nd, const int32_t *seq_len, const MotifPart *parts, uint32_t nparts, uint32_t *tab) {
+  if (!nparts) return;
+  if (stage == 0) hipLaunchKernelGGL(motif_bg0_kernel, dim3(nparts), dim3(256), 0, e.st, nd, seq_len, parts, tab);
+  else hipLaunchKernelGGL(motif_bg12_kernel, dim3(nparts), dim3(256), 0, e.st, stage, nd, seq_len, parts, tab);
 }
 
 // ---- hexamer background ----

@@ -178,11 +178,12 @@ void x_path_ends(GExec &, const Nodes &nd, const uint32_t *seq_lo, const uint32_
   }
 }
 
-void x_motif_bg0(GExec &, const Nodes &nd, const int32_t *seq_len, const MotifPart *parts, uint32_t nparts, uint32_t *bg0) {
+void x_motif_bg(GExec &, int stage, const Nodes &nd, const int32_t *seq_len, const MotifPart *parts, uint32_t nparts, uint32_t *tab) {
   for (uint32_t p = 0; p < nparts; ++p) for (uint32_t x = parts[p].lo; x < parts[p].hi; ++x) {
     if (nd.type[x] >= G_STOP || nd.edge[x] == 1) continue;
     const int sl = seq_len[nd.seq[x]], strand = nd.strand[x], start = strand == 1 ? nd.ndx[x] : sl - 1 - nd.ndx[x];
-    motif_words_stage0(nd.upw[x], start, [&](int i, int w) { bg0[((size_t)parts[p].slot * 4 + i) * 4096 + w]++; });
+    if (stage == 0) motif_words_stage0(nd.upw[x], start, [&](int i, int w) { tab[((size_t)parts[p].slot * 4 + i) * 4096 + w]++; });
+    else motif_words_stage12(nd.mot[x], nd.upw[x], start, stage, [&](int i, int sp, int w) { tab[(size_t)parts[p].slot * 65536 + ((size_t)i * 4 + sp) * 4096 + w]++; });
   }
 }
 
