@@ -21,7 +21,7 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-C3="--config cfg3 --no-cpu-baseline --no-cfg2 --no-emulation --no-verify --no-genes --workdir /tmp/ckm_work"      # (one synthetic world for all runs of a call)
+C3="--config cfg3 --no-cpu-baseline --no-cfg2 --no-emulation --no-verify --no-genes --hard-bins 0 --workdir /tmp/ckm_work"      # (one synthetic world for all runs of a call)
 PMC_PASSES=("fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY")
 nbench=0
 for item in "$@"; do
