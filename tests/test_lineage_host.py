@@ -117,3 +117,17 @@ def test_lineage_sets_behave_like_the_dict_the_reference_returns(tmp_path):
     for t in ts:
         t.join()
     assert not errs and len(got) == 8 and all(g is got[0] for g in got)
+
+
+def test_hard_world_is_deterministic_and_leaves_the_plain_one_alone(tmp_path):
+    """bench.py's hard_workload leg (synthdata/synth_lineage.py: make_lineage_bin(hard=True)): same ORF count and names as the plain bin,
+    fixed seeds, the planted markers still there; the plain world's bins are what they were before the switch existed."""
+    w = sl.World(str(tmp_path / "data"), n_models=240, seed=77)
+    a, h = w.bin_records(3, orf_lo=400, orf_hi=500), w.bin_records(3, orf_lo=400, orf_hi=500, hard=True)
+    assert a == w.bin_records(3, orf_lo=400, orf_hi=500) and h == w.bin_records(3, orf_lo=400, orf_hi=500, hard=True)
+    assert [r[0] for r in a] == [r[0] for r in h] and a != h
+    def poor(recs):           # proteins over a small alphabet: the low-complexity ORFs (a random 60-mer of the background uses 15 letters or more)
+        return sum(1 for r in recs if len(r[2]) > 60 and len(set(r[2][:-1])) <= 8)
+    assert poor(h) >= 2 and poor(a) == 0
+    block = sl.scrambled(__import__("numpy").random.default_rng(1), __import__("numpy").arange(100))
+    assert sorted(block.tolist()) == list(range(100)) and block.tolist() != list(range(100))

@@ -88,3 +88,26 @@ def test_profile_files_from_counter_passes(tmp_path):
     assert d["all_kernels"]["valu_insts"] == 1800.0 and d["all_kernels"]["FETCH_SIZE_KB"] == 180.0       # + fwd; gene_* / orf_* left out
     text = open(dst / "t1_cfg3_pmc_summary.txt").read()
     assert "ssv_kernel" in text and "gene_dp_kernel" in text                                   # (the per-kernel table itself lists everything)
+
+
+def test_gene_pass_timeline_and_phase_means(tmp_path):
+    """tools/gene_pass_timeline.py (exposed time per kernel family over the last gap-free run of a kernel trace) and tools/gene_phase_means.py
+    (mean phase durations of ckm_genes_call from CKM_TRACE lines) on hand-made inputs."""
+    ms = 1000000
+    rows = [("Kind", "Kernel_Name", "Start_Timestamp", "End_Timestamp"),
+            ("KERNEL_DISPATCH", "ckm::gene::chain_kernel(ckm::gene::ChainArgs)", 0, 5 * ms),                       # an earlier pass: cut off by the 0.3 s gap
+            ("KERNEL_DISPATCH", "void ckm::gene::gene_dp_kernel<0, 1024>(ckm::gene::Nodes)", 1000 * ms, 1100 * ms),
+            ("KERNEL_DISPATCH", "ckm::gene::chain_kernel(ckm::gene::ChainArgs)", 1050 * ms, 1060 * ms),
+            ("KERNEL_DISPATCH", "void ckm::gene::g_map_kernel<ckm::gene::gene_pipeline(x)::{lambda(unsigned long)#17}>(unsigned long, {lambda(unsigned long)#17})", 1100 * ms, 1130 * ms)]
+    f = tmp_path / "g_kernel_trace.csv"
+    f.write_text("\n".join(",".join('"%s"' % c for c in r) for r in rows) + "\n")
+    out = _run([os.path.join(ROOT, "tools", "gene_pass_timeline.py"), str(f)])
+    assert out.splitlines()[0].startswith("window 0.130 s, 3 launches; a kernel running 100.0 % of it")
+    exposed = {l[:40].strip(): l.split()[-1] for l in out.splitlines()[4:] if l.strip()}
+    assert exposed == {"gene_dp_kernel<0, 1024>": "90.0", "map #17": "30.0", "chain_kernel": "0.0"}
+    t = tmp_path / "err.txt"
+    t.write_text("\n".join(["ckm-trace genes call 0 table 11      10.0 ms  text, planes, flags", "ckm-trace genes call 0 table 11      30.0 ms  nodes in working order",
+                            "ckm-trace genes call 1 table 4       20.0 ms  text, planes, flags", "ckm-trace genes call 1 table 4       70.0 ms  nodes in working order", "noise"]) + "\n")
+    out = _run([os.path.join(ROOT, "tools", "gene_phase_means.py"), str(t)]).splitlines()
+    assert out[0].split("mean")[1].split()[0] == "15.0" and out[1].split("mean")[1].split()[0] == "35.0" and out[-1] == "sum of means 50.0 ms"
+    assert _run([os.path.join(ROOT, "tools", "gene_phase_means.py"), str(t), "1"]).splitlines()[-1] == "sum of means 70.0 ms"
