@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg5", "genes", "fasta"], default="cfg3")
+    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg5", "genes", "fasta", "emulate8"], default="cfg3")
     ap.add_argument("--budget-seconds", type=float, default=float(os.environ.get("CKM_BENCH_BUDGET_S", "240")),
                     help="cfg3: wall-clock budget of the timed region; the steps actually run are min(--steps, budget / estimated step)")
     ap.add_argument("--emulate-rank", default=None, help="cfg3: R/W -- run as rank R of W on this one GPU (no collectives)")
@@ -345,6 +345,9 @@ def main():
             w = sl.World(data)
             DefaultValues.set_data_root(data)
             out = {"from_fasta": from_fasta(w, env.workdir, args.from_fasta_bins)}
+    elif args.config == "emulate8":         # the emulated_ranks_of_8 leg of the cfg3 line alone (bench_cfg3 runs it as a child process)
+        w, binIds, files, lin = lineage_setup(env.workdir, args.bins_total, env.rank, env.world, env.sync)
+        out = emulate_8_ranks(w, binIds, files, lin, env.workdir, env.rank, env)
     elif args.config == "cfg5":
         out = bench_cfg5(args, env)
     else:
@@ -1058,6 +1061,45 @@ def hard_workload(w, workdir, nbins, base_pairs, base_bins, verify_bins):
     return res
 
 
+def emulate_8_ranks(w, binIds, files, lin, workdir, rank, env):
+    """EVERY rank of 8 on this GPU, one after the other: what configs[3] costs each rank (its LPT shard on the device + the host work a rank
+    does), so that the projection is the SLOWEST rank's wall, not rank 0's."""
+    from checkm_amd import markerGeneFinder as mgf
+    walls, parts8, ssv8, searches8 = [], [], [], []
+    try:
+        os.environ["CKM_EMULATE_RANK"] = "0/8"
+        lineage_pass(w, binIds, files, lin, os.path.join(workdir, "cfg3_emu"), rank)       # (warm: tables and workspace at a rank's size)
+        for r in range(8):
+            os.environ["CKM_EMULATE_RANK"] = "%d/8" % r
+            mgf._join_releasers()
+            env.sync()
+            t0 = time.perf_counter()
+            eparts, etot = lineage_pass(w, binIds, files, lin, os.path.join(workdir, "cfg3_emu"), rank)
+            mgf._join_releasers()
+            env.sync()
+            walls.append(time.perf_counter() - t0); parts8.append(eparts); ssv8.append(etot.get("ms_ssv", 0.0) / 1e3); searches8.append(int(etot.get("searches", 0)))
+    finally:
+        del os.environ["CKM_EMULATE_RANK"]
+    mx, mn, mean = max(walls), min(walls), sum(walls) / len(walls)
+    return {"per_rank_wall_s": walls, "max_wall_s": mx, "min_wall_s": mn, "mean_wall_s": mean, "imbalance_max_over_mean": mx / mean,
+            "per_rank_ssv_kernels_s": ssv8, "per_rank_searches": searches8, "slowest_rank": int(walls.index(mx)), "parts_s_slowest_rank": parts8[walls.index(mx)]}
+
+
+def child_leg(argv, timeout_s=900):
+    """A side leg in a process of its own (the same device; this process keeps what it holds): a rank of configs[3] IS a fresh process, and
+    so is a user's cfg2-sized run -- inside this long-lived one the legs that ran before cost the later ones 6-10 % of host-side speed
+    (profiles/r06_not_adopted.txt).  Returns the child's JSON line, or {"error": ...}."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, capture_output=True, text=True, timeout=timeout_s)
+        lines = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "child leg %s: rc %d: %s" % (" ".join(argv[:2]), r.returncode, r.stderr[-400:])}
+        return json.loads(lines[-1])
+    except Exception as e:          # noqa: BLE001  (a side leg must not take the line down)
+        return {"error": "child leg %s: %r" % (" ".join(argv[:2]), e)}
+
+
 def bench_cfg3(args, env):
     """configs[2] (N = 1) / configs[3] (N > 1, strong scaling): the lineage_wf marker path over --bins-total bins from files; the
     product shards the bins over the ranks."""
@@ -1197,31 +1239,16 @@ def bench_cfg3(args, env):
         out["verify"] = None
     if world == 1:
         if not args.no_emulation:
-            # EVERY rank of 8 on this GPU, one after the other: what configs[3] costs each rank (its LPT shard on the device + the host work a
-            # rank does), so that the projection is the SLOWEST rank's wall, not rank 0's
             from checkm_amd import markerGeneFinder as mgf
-            walls, parts8, ssv8, searches8 = [], [], [], []
-            try:
-                os.environ["CKM_EMULATE_RANK"] = "0/8"
-                lineage_pass(w, binIds, files, lin, os.path.join(workdir, "cfg3_emu"), rank)       # (warm: tables and workspace at a rank's size)
-                for r in range(8):
-                    os.environ["CKM_EMULATE_RANK"] = "%d/8" % r
-                    mgf._join_releasers()
-                    env.sync()
-                    t0 = time.perf_counter()
-                    eparts, etot = lineage_pass(w, binIds, files, lin, os.path.join(workdir, "cfg3_emu"), rank)
-                    mgf._join_releasers()
-                    env.sync()
-                    walls.append(time.perf_counter() - t0); parts8.append(eparts); ssv8.append(etot.get("ms_ssv", 0.0) / 1e3); searches8.append(int(etot.get("searches", 0)))
-            finally:
-                del os.environ["CKM_EMULATE_RANK"]
-            mx, mn, mean = max(walls), min(walls), sum(walls) / len(walls)
-            out["emulated_ranks_of_8"] = {"per_rank_wall_s": walls, "max_wall_s": mx, "min_wall_s": mn, "mean_wall_s": mean, "imbalance_max_over_mean": mx / mean,
-                                          "per_rank_ssv_kernels_s": ssv8, "per_rank_searches": searches8, "slowest_rank": int(walls.index(mx)), "parts_s_slowest_rank": parts8[walls.index(mx)],
-                                          "projected_bins_per_hour_8gpu": nbins / mx * 3600.0, "projected_speedup_over_1gpu": per_step / mx,
-                                          "note": "this ONE GPU as rank r of 8 for r = 0..7 in turn: LPT shard of the %d bins (dist.shard_bins: file size x models), the host work a rank "
-                                                  "does, no collective (the one all_gather of QA rows) and no contention for the shared output directory -- a projection from the "
-                                                  "slowest emulated rank, not a measurement of configs[3]; no N > 1 run has ever happened on hardware" % nbins}
+            mgf.release_scan()
+            em = child_leg(["--config", "emulate8", "--bins-total", str(nbins), "--workdir", workdir])
+            if "error" not in em:
+                em["projected_bins_per_hour_8gpu"] = nbins / em["max_wall_s"] * 3600.0
+                em["projected_speedup_over_1gpu"] = per_step / em["max_wall_s"]
+                em["note"] = ("this ONE GPU as rank r of 8 for r = 0..7 in turn, in a process of their own (a rank is one): LPT shard of the %d bins (dist.shard_bins: file size x models), "
+                              "the host work a rank does, no collective (the one all_gather of QA rows) and no contention for the shared output directory -- a projection from "
+                              "the slowest emulated rank, not a measurement of configs[3]; no N > 1 run has ever happened on hardware" % nbins)
+            out["emulated_ranks_of_8"] = em
         if not args.no_genes:
             out["gene_front_end"] = gene_front_end()
             out["gene_calling"] = gene_calling(workdir)
@@ -1236,12 +1263,9 @@ def bench_cfg3(args, env):
         if not args.no_cfg2:
             from checkm_amd import markerGeneFinder as mgf
             mgf.release_scan()
-            import copy
-            a2 = copy.copy(args)
-            a2.steps, a2.warmup, a2.lineage_bins, a2.no_cpu_baseline, a2.scaling, a2.pipeline, a2.bins, a2.orfs = 5, 2, 0, True, "weak", 1, 100, 2000
-            c2 = bench_cfg2(a2, env)
-            out["cfg2"] = {k: c2[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "steady_state", "value_from_host", "gcups_ssv", "roofline",
-                                              "roofline_valu", "step_utilisation", "stages_ms", "step_parts_ms", "stage_pairs", "rows", "device_state_timed_region")}
+            c2 = child_leg(["--config", "cfg2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-verify", "--bins", "100", "--orfs", "2000"])
+            out["cfg2"] = c2 if "error" in c2 else {k: c2[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "steady_state", "value_from_host", "gcups_ssv", "roofline",
+                                                                       "roofline_valu", "step_utilisation", "stages_ms", "step_parts_ms", "stage_pairs", "rows", "device_state_timed_region") if k in c2}
     else:
         out["cpu_baseline"] = None
     g, ff, em, ver = out.get("gene_calling") or {}, out.get("from_fasta") or {}, out.get("emulated_ranks_of_8") or {}, out.get("verify") or {}
