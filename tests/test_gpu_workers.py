@@ -75,6 +75,11 @@ def test_find_with_eight_workers_equals_the_single_process_run(gpu_ctx, tmp_path
     assert mode[0] == "workers 8"
     owners = dict(kv.split(":") for kv in mode[1].split()[1:])
     assert len(owners) == nb and set(owners.values()) == {str(r) for r in range(8)}        # every worker owns bins; every bin has one owner
+    # ... and the bins a worker owns are its shard of dist.shard_bins (longest first, file size x models), the partition SURVEY 8(e) names
+    from checkm_amd import dist as cdist
+    files = sorted(f for f in os.listdir(work) if f.endswith(".faa"))
+    shards = cdist.shard_bins([os.path.getsize(os.path.join(work, f)) * len(profs) for f in files], 8)
+    assert owners == {files[i][:-len(".faa")]: str(r) for r, sh in enumerate(shards) for i in sh}
     for fmt in (1, 2):
         one = open(os.path.join(work, "table_one_fmt%d.tsv" % fmt)).read()
         assert one == open(os.path.join(work, "table_eight_fmt%d.tsv" % fmt)).read() and len(one.strip().split("\n")) == nb + 1
