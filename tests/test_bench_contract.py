@@ -1,5 +1,5 @@
 """The bench line's contract, checked without a GPU: the flags the driver passes parse, and the line recorded by the round's driver-shaped
-run (profiles/r05z_bench_driver_shaped_line.json = `python bench.py --gpus 1 --steps 20 --warmup 5` on one MI355X) carries every field the contract
+run (profiles/r06x_bench_driver_shaped_line.json = `python bench.py --gpus 1 --steps 20 --warmup 5` on one MI355X) carries every field the contract
 names, with figures that agree with each other."""
 import json
 import os
@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINE = os.path.join(ROOT, "profiles", "r05z_bench_driver_shaped_line.json")
+LINE = os.path.join(ROOT, "profiles", "r06x_bench_driver_shaped_line.json")
 
 
 def test_driver_flags_parse():
@@ -41,8 +41,14 @@ def test_recorded_line_meets_the_contract():
     assert r["ms_per_step_kernel"] < d["ms_per_step"]                        # the dominant kernel's time lies inside the step
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "port-simd", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and "scalar" in c["sample"].lower()
+    if c["kind"] == "port-simd":          # (round 6: the integer filters striped on AVX2, the scalar port timed beside it on the same sampled bins)
+        assert 1.0 < c["msv_gcups_per_core"] < 60.0 and c["scalar_port"]["value"] < c["value"] and "NOT HMMER" in c["sample"]
     v = d["verify"]
     assert v["identical"] is True and v["qa_rows_identical"] is True and v["same_tables_when_scanned_alone"] is True and v["mismatches"] == []
+    assert v["oracle_pinned"] is False and sorted(v["known_deviations"]) == ["D1", "D2", "D4", "D5"]      # what "identical" is measured against
+    h = d["hard_workload"]
+    assert h["verify"]["identical"] is True and h["cascade_fallback_lanes"] == 0 and abs(h["seconds_per_1000_bins"] - h["seconds"] / h["bins"] * 1000) < 1e-6
+    assert h["per_bin_vs_plain_world"]["regions_multi"] > 2 and h["slowdown_vs_plain_world_same_bins"] > 1.0
     assert d["cascade_fallback_lanes_rank0"] == 0
     e = d["emulated_ranks_of_8"]
     assert len(e["per_rank_wall_s"]) == 8 and e["max_wall_s"] == max(e["per_rank_wall_s"])
