@@ -8,7 +8,7 @@
 //   scan kernels        exclusive prefix sums of 32-bit counts (ranks of the bit planes, chain offsets, gene and protein offsets)
 //   gc_bias_kernel      one wavefront per bin: the ORDERED sum of the start nodes' GC-frame terms (node.c: record_gc_bias), 64 nodes loaded
 //                       at a time, added one after the other in node order
-//   gene_dp_kernel      the dynamic program (dprog.c: dprog, node.c: score_connection): one workgroup per sequence, the last 2048 nodes in LDS
+//   gene_dp_kernel      the dynamic program (dprog.c: dprog, node.c: score_connection): one workgroup per sequence, 64 nodes per step, the last 1216 nodes in LDS
 //   hexbg_kernel        hexamer histogram of a bin's training sequence in LDS (4096 counters), flushed by atomics
 //   cscore / rbs        per start node: hexamer log-odds sum with the bin's table in LDS; Shine-Dalgarno bins against the bin's 28 weights
 #include <mutex>
@@ -376,32 +376,43 @@ void x_hexamer_background(GExec &e, const uint8_t *code, const uint64_t *seq_off
 // and -- for four of the ten class pairs -- whether j has a predecessor and where it lies (gene_dev.h: dp_connection_s); everything else
 // is fixed before the sweep starts.  Rounds 4-5 took the nodes one at a time, a barrier per node (3.6-4.8 us per node, 58 % of the
 // wavefronts' cycles waiting: profiles/r05t).  Round 6 takes them 64 at a time:
-//   (A) all wavefronts, no barrier: a wavefront takes a node i of the block (heaviest classes first, dealt by an LDS counter) and scores
-//       its candidates class by class out of four LDS rings of node indices -- a wavefront's 64 candidates share one class, so the
-//       connection function folds to that class's cases, and the six class pairs that cannot connect are never touched.  A candidate
-//       BEFORE the block is final: connection + score, into the wavefront's running best (one DPP reduction per node).  A candidate INSIDE
-//       the block is not: its connection WITHOUT its score goes into a 64 x 64 table in LDS (the pairs that read the candidate's
-//       predecessor -- dp_pair_dynamic -- are left out).  A forward stop's / reverse start's candidates begin at the first node its open
-//       reading frame can reach (dp_pos_floor: a binary search over the ring when the node enters), not 1000 nodes back;
+//   (A) a wavefront takes a node i of the block (heaviest classes first, dealt by an LDS counter) and scores its candidates class by class
+//       out of four LDS rings of node indices -- a wavefront's 64 candidates share one class, so the connection function folds to that
+//       class's cases, and the six class pairs that cannot connect are never touched.  A candidate BEFORE the block is final: connection +
+//       score, into the wavefront's running best (one DPP reduction per node).  A candidate INSIDE the block is not: its connection WITHOUT
+//       its score goes into a 64 x 64 table in LDS (the pairs that read the candidate's predecessor -- dp_pair_dynamic -- are left out).
+//       A forward stop's / reverse start's candidates begin at the first node its open reading frame can reach (dp_pos_floor: a binary
+//       search over the ring when the node enters), not 1000 nodes back;
 //   (B) one wavefront, lane per node of the block: for t = 0 .. 63 node t is final (every candidate before it has been offered), its score
 //       and predecessor are broadcast by v_readlane, and every lane behind t takes `score(t) + table[t][lane]` -- one LDS read, one add, one
-//       compare; only a forward stop t meeting reverse nodes runs the connection function here.  Meanwhile another wavefront enters the
-//       NEXT 64 nodes into the rings (their global-memory reads hide behind (B)); the block's results leave for global memory during the
-//       next block's (A).
-// Two barriers per 64 nodes.  The last 1152 nodes live in an LDS ring of 40-byte records read with wide loads: {position, stop position,
-// flags + packed overlapping-start offsets, trace-back and window start as 16-bit distances}, {score, connection value}, {class counts}.
-// What does not fit the rings (a window that starts behind a giant open reading frame, more than 512 nodes of one class in a window) goes
-// through the generic loop with global-memory fall-backs.
+//       compare; only a forward stop t meeting reverse nodes runs the connection function here.
+// (B) is a chain of 64 dependent steps on one wavefront; with (A) and (B) in turn (the first form of this round, 83 ms on 48 bins) the other
+// fifteen wait for it.  So (A) is cut in two and the blocks are pipelined -- per block k, two phases and two barriers:
+//   P(k)  wavefront 0: (B) of block k | wavefront 1: block k + 2 enters the rings (its global-memory reads hide here), then joins | the
+//         others: (A1) of block k + 1 -- its candidates BEFORE block k, nine tenths of them, all final already;
+//   Q(k)  all wavefronts: (A2) of block k + 1 -- its candidates inside block k (final now) and its table; block k leaves for global memory.
+// The last 1216 nodes live in an LDS ring of 40-byte records read with wide loads: {position, stop position, flags + packed
+// overlapping-start offsets, trace-back and window start as 16-bit distances}, {score, connection value}, {class counts}.  What does not
+// fit the rings (a window that starts behind a giant open reading frame, more than 896 nodes of one class in a window) goes through the
+// generic loop with global-memory fall-backs.
+// One rule the first pipelined form broke (98.6k genes of 99,984, and not the same ones twice): what ONE lane stores to LDS and the other
+// lanes of the same wavefront load back later in program order -- the class totals of dp_enter -- needs a barrier (or the loads made
+// volatile) between the two: to the compiler that is one thread storing under `lane == 0` and loading again, and it forwards the value it
+// already holds.  Two dp_enter calls in a row by one wavefront (the prologue) are therefore separated by __syncthreads.
 constexpr int DPB = 64;                                       // nodes per block
-constexpr int DPW = 1152, DPC = 512, DP_FAR = 0xffff;        // 1152 = the 1000-node window + this block + the block entered ahead (+ slack)
+// (the class totals: written by the entering wavefront's lane 0, read by its other lanes and by the scoring wavefronts -- never plain accesses)
+#define DP_LDS_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define DP_LDS_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+constexpr int DPW = 1216, DPC = 1024, DP_FAR = 0xffff;        // 1216 = the 1000-node window + the block being resolved + the two entered ahead (+ slack)
 struct DpRec { int ndx, sv, pk; uint32_t tbl; };            // pk: bit 0 stop, 1 reverse, 3 stars-in-global, 4-5 (overlap mark + 1), 8.. three signed byte offsets; tbl: trace-back distance | window distance << 16
 struct DpRing { DpRec rec[DPW]; double2 sv2[DPW]; ushort4 cnt[DPW]; unsigned short cls[4][DPC]; };
 struct DpBlock {
   double table[DPB * DPB];                                   // [t][(l + t) & 63]: connection t -> l without t's score; -inf: none
-  double pbest[DPB]; int pkey[DPB];                          // (A)'s result per node of the block
-  int lo_eff[DPB];                                           // where the node's candidates begin (window start, or the position floor)
-  unsigned char order[DPB];                                  // the block's nodes, heaviest class first
-  uint32_t next;                                             // (A)'s dealer
+  double best1[2][DPB]; int key1[2][DPB];                    // (A1)'s result per node of a block, by the block's parity
+  double best2[DPB]; int key2[DPB];                          // (A2)'s
+  int lo_eff[2][DPB];                                        // where a node's candidates begin (window start, or the position floor), by the block's parity
+  unsigned char order[2][DPB];                               // a block's nodes, heaviest class first
+  uint32_t next1, next2;                                     // the dealers of (A1) and (A2)
 };
 __device__ __forceinline__ int dp_slot(int rel) { return rel % DPW; }
 __device__ __forceinline__ int dp_tab(int t, int l) { return t * DPB + ((l + t) & (DPB - 1)); }      // (the rotation spreads a column over the banks)
@@ -495,9 +506,10 @@ __device__ __forceinline__ void dp_wave_best(double &best, int &key) {
     best = b0; key = k0; dp_merge(best, key, b1, k1); dp_merge(best, key, b2, k2); dp_merge(best, key, b3, k3);
   }
 }
-__device__ __forceinline__ int dp_ring_lo(int i0) { const int v = i0 + 2 * DPB - DPW; return v > 0 ? v : 0; }     // (the oldest node no entering block overwrites)
+// the oldest node no block entered while block i0 is resolved overwrites (that block and the two behind it are in the ring by then)
+__device__ __forceinline__ int dp_ring_lo(int i0) { const int v = i0 + 3 * DPB - DPW; return v > 0 ? v : 0; }
 
-// the 64 nodes from e0 on enter the rings (one wavefront; the slots they take over are 1152 nodes / 512 class members back)
+// the 64 nodes from e0 on enter the rings (one wavefront; the slots they take over are 1216 nodes / 1024 class members back)
 template <int FLAG>
 __device__ __forceinline__ void dp_enter(const Nodes &nd, DpRing &ring, DpBlock &blk, uint32_t *ring_tot, uint32_t first, int nn, int e0, int lane) {
   const int rel = e0 + lane; const bool in = rel < nn;
@@ -507,7 +519,7 @@ __device__ __forceinline__ void dp_enter(const Nodes &nd, DpRing &ring, DpBlock 
   uint32_t before[4], tot[4];
   unsigned long long m[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) { m[c] = __ballot(cls == c); tot[c] = ring_tot[c]; before[c] = tot[c] + (uint32_t)__popcll(m[c] & below); tot[c] += (uint32_t)__popcll(m[c]); }
+  for (int c = 0; c < 4; ++c) { m[c] = __ballot(cls == c); tot[c] = DP_LDS_LD(&ring_tot[c]); before[c] = tot[c] + (uint32_t)__popcll(m[c] & below); tot[c] += (uint32_t)__popcll(m[c]); }
   int lo = 0, sv = 0;
   if (in) {
     const int k = dp_slot(rel);
@@ -524,32 +536,171 @@ __device__ __forceinline__ void dp_enter(const Nodes &nd, DpRing &ring, DpBlock 
     ring.cnt[k] = make_ushort4((unsigned short)before[0], (unsigned short)before[1], (unsigned short)before[2], (unsigned short)before[3]);
     ring.cls[cls][before[cls] & (DPC - 1)] = (unsigned short)rel;
   }
-  if (lane == 0) { for (int c = 0; c < 4; ++c) ring_tot[c] = tot[c]; }
+  if (lane == 0) { for (int c = 0; c < 4; ++c) DP_LDS_ST(&ring_tot[c], tot[c]); }
   // where the node's candidates begin: a forward stop / reverse start reaches back to dp_pos_floor only (the records of this block are in
   // the ring by now -- LDS operations of one wavefront complete in order)
   if (in) {
     int le = lo;
-    if (dp_class_pos_bounded(cls) && lo >= dp_ring_lo(e0)) {
+    if (dp_class_pos_bounded(cls) && lo >= dp_ring_lo(e0 - 2 * DPB)) {      // (the nodes are entered two blocks before they are scored: what is in the ring now is still there then)
       const int fl = dp_pos_floor(sv);
       int a = lo, b = rel;                                     // smallest j in [lo, rel] with j == rel or ndx(j) >= fl
       while (a < b) { const int mid = (a + b) >> 1; if (ring.rec[dp_slot(mid)].ndx >= fl) b = mid; else a = mid + 1; }
       le = a;
     }
-    blk.lo_eff[lane] = le;
+    blk.lo_eff[(e0 / DPB) & 1][lane] = le;
   }
   // heaviest first: reverse stops (three classes of candidates, the overlapping-start loop), forward starts (two), the position-bounded rest
   const unsigned long long h0 = m[3], h1 = m[0], h2 = m[1] | m[2];
   if (in) {
     const int pos = cls == 3 ? __popcll(h0 & below) : cls == 0 ? __popcll(h0) + __popcll(h1 & below) : __popcll(h0) + __popcll(h1) + __popcll(h2 & below);
-    blk.order[pos] = (unsigned char)lane;
+    blk.order[(e0 / DPB) & 1][pos] = (unsigned char)lane;
   }
 }
 
+// Candidates of the nodes of block i0 .. i1: PART 1 -- those before block i0 - 64 (final when block i0 - 64 is being resolved); PART 2 -- those
+// in block i0 - 64 (final once it is resolved) and, without their score, those inside the block itself (into the table).  A wavefront takes a
+// node at a time from the dealer; its best goes to (pb, pk).
+template <int FLAG, int PART>
+__device__ __forceinline__ void dp_candidates(const Nodes &nd, DpRing &ring, DpBlock &blk, const uint32_t *ring_tot, uint32_t first, double st_wt,
+                                              int i0, int cnt, int lane) {
+  const int par = (i0 / DPB) & 1, i1 = i0 + cnt;
+  const int j_split = i0 - DPB;                                  // PART 1: j < j_split; PART 2: j >= j_split
+  const int ring_lo = dp_ring_lo(PART == 1 ? i0 - DPB : i0);     // (PART 1 runs while block i0 - 64 is resolved and block i0 + 64 enters)
+  const DpSrc<FLAG> S{nd, ring, first, ring_lo, i1, i0};
+  for (;;) {
+    uint32_t u = 0;
+    if (lane == 0) u = atomicAdd(PART == 1 ? &blk.next1 : &blk.next2, 1u);        // (named LDS objects, not pointers handed in: the address space stays known)
+    u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
+    if (u >= (uint32_t)cnt) break;
+    const int l = blk.order[par][u], i = i0 + l;
+    const DpRec qi = ring.rec[dp_slot(i)];
+    DpNode n2; n2.ndx = qi.ndx; n2.sv = qi.sv; n2.strand = (qi.pk & 2) ? -1 : 1; n2.stop = qi.pk & 1;
+    const uint32_t lod = qi.tbl >> 16;
+    const int lo = lod == (uint32_t)DP_FAR ? (int)nd.dp_min[first + (uint32_t)i] : i - (int)lod;
+    const int le = blk.lo_eff[par][l];
+    const int c2 = dp_class(n2.strand, n2.stop);
+    if (PART == 2 && lane < l) blk.table[dp_tab(lane, l)] = -__builtin_inf();
+    double best = -1.0; int bj = -1, bmark = -1;
+    // class ranges: the first candidate must be in the node ring, every class's members behind it in the class rings (which grow by up
+    // to two blocks while this runs: 128 entries of slack)
+    bool by_class = le >= ring_lo;
+    int a[4], n_lo[4], n_hi[4];
+    if (by_class) {
+      const ushort4 ca = ring.cnt[dp_slot(le)], cb = ring.cnt[dp_slot(i)];
+      const int sp = j_split > le ? j_split : le;               // the first candidate of PART 2
+      const ushort4 cs = ring.cnt[dp_slot(sp < i ? sp : i)];
+      const unsigned short ua[4] = {ca.x, ca.y, ca.z, ca.w}, ub[4] = {cb.x, cb.y, cb.z, cb.w}, us[4] = {cs.x, cs.y, cs.z, cs.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        a[c] = ua[c];
+        const int n_all = (unsigned short)(ub[c] - ua[c]), n_one = (unsigned short)(us[c] - ua[c]);
+        n_lo[c] = PART == 1 ? 0 : n_one; n_hi[c] = PART == 1 ? n_one : n_all;
+        if ((unsigned short)((unsigned short)DP_LDS_LD(&ring_tot[c]) - ua[c]) > DPC - 2 * DPB) by_class = false;
+      }
+    }
+    if (by_class) {
+      const DpRingSrc<FLAG> R{S, -1, DpRec{0, 0, 0, 0}};
+#pragma unroll
+      for (int c1 = 0; c1 < 4; ++c1) {
+        if (!dp_pair_possible(c1, c2)) continue;
+        const bool dyn = dp_pair_dynamic(c1, c2);
+        for (int t = n_lo[c1] + lane; t < n_hi[c1]; t += 64) {
+          const int jl = ring.cls[c1][(a[c1] + t) & (DPC - 1)];                           // low 16 bits of the index
+          const int j = i - ((i - jl) & 0xffff);
+          const bool inblk = j >= i0;
+          if (inblk && dyn) continue;
+          double sc; int mark; bool ok;
+          if (c1 == 0) ok = dp_connection_s<DpRingSrc<FLAG>, true, 1, false>(R, st_wt, j, i, n2, sc, mark);
+          else if (c1 == 1) ok = dp_connection_s<DpRingSrc<FLAG>, true, 1, true>(R, st_wt, j, i, n2, sc, mark);
+          else if (c1 == 2) ok = dp_connection_s<DpRingSrc<FLAG>, true, -1, false>(R, st_wt, j, i, n2, sc, mark);
+          else ok = dp_connection_s<DpRingSrc<FLAG>, true, -1, true>(R, st_wt, j, i, n2, sc, mark);
+          if (ok) {
+            if (inblk) blk.table[dp_tab(j - i0, l)] = sc;
+            else dp_take(R.score(j) + sc, j, mark, best, bj, bmark);
+          }
+        }
+      }
+    } else {
+      const int ja = PART == 1 ? lo : (j_split > lo ? j_split : lo), jb = PART == 1 ? (j_split < i ? j_split : i) : i;
+      for (int j = ja + lane; j < jb; j += 64) {
+        const bool inblk = j >= i0;
+        const DpNode n1 = S.node(j);
+        if (inblk && dp_pair_dynamic(dp_class(n1.strand, n1.stop), c2)) continue;
+        double sc; int mark;
+        if (dp_connection_s<DpSrc<FLAG>, false, 0, false>(S, st_wt, j, i, n2, sc, mark)) {
+          if (inblk) blk.table[dp_tab(j - i0, l)] = sc;
+          else dp_take(S.score(j) + sc, j, mark, best, bj, bmark);
+        }
+      }
+    }
+    int key = bj < 0 ? -1 : bj * 4 + (bmark + 1);                 // candidate index and overlap mark travel together
+    dp_wave_best(best, key);
+    if (lane == 0) {
+      if (PART == 1) { blk.best1[par][l] = best; blk.key1[par][l] = key; }
+      else { blk.best2[l] = best; blk.key2[l] = key; }
+    }
+  }
+}
+
+// (B): the nodes of block i0 .. i0 + cnt are resolved one after the other by ONE wavefront, a lane per node
+template <int FLAG>
+__device__ __forceinline__ void dp_resolve(const Nodes &nd, DpRing &ring, DpBlock &blk, uint32_t first, double st_wt, int i0, int cnt, int lane) {
+  const int par = (i0 / DPB) & 1;
+  const DpSrc<FLAG> S{nd, ring, first, dp_ring_lo(i0), i0 + cnt, 0x7fffffff};
+  const DpRingSrc<FLAG> R{S, -1, DpRec{0, 0, 0, 0}};
+  const bool in = lane < cnt;
+  const int i = i0 + (in ? lane : 0);
+  const int k = dp_slot(i);
+  const DpRec qi = ring.rec[k];
+  DpNode n2; n2.ndx = qi.ndx; n2.sv = qi.sv; n2.strand = (qi.pk & 2) ? -1 : 1; n2.stop = qi.pk & 1;
+  const int c2 = dp_class(n2.strand, n2.stop);
+  double best = in ? blk.best1[par][lane] : -1.0; int key0 = in ? blk.key1[par][lane] : -1;
+  if (in) dp_merge(best, key0, blk.best2[lane], blk.key2[lane]);
+  int bj = key0 < 0 ? -1 : key0 >> 2, bmark = key0 < 0 ? -1 : (key0 & 3) - 1;
+  for (int t = 0; t < cnt; ++t) {
+    // node i0 + t is final: every lane learns it, its own lane publishes it to the ring
+    const double bt = dp_mk64(__builtin_amdgcn_readlane(dp_lo32(best), t), __builtin_amdgcn_readlane(dp_hi32(best), t));
+    const int jt = __builtin_amdgcn_readlane(bj, t), c1 = __builtin_amdgcn_readlane(c2, t);
+    if (lane == t && bj >= 0) {
+      ring.sv2[k].x = best;
+      const uint32_t d = i - bj < DP_FAR ? (uint32_t)(i - bj) : (uint32_t)DP_FAR;
+      ring.rec[k].tbl = (qi.tbl & 0xffff0000u) | d;
+      ring.rec[k].pk = qi.pk | ((bmark + 1) << 4);
+      if (d == (uint32_t)DP_FAR) GST(&nd.traceb[first + (uint32_t)i], bj);                  // (a trace-back the 16-bit distance cannot hold is read from global memory)
+    }
+    if (dp_class_needs_tb(c1) && jt < 0) continue;
+    const double sc_t = jt >= 0 ? bt : 0.0;
+    if (in && lane > t) {
+      dp_take(sc_t + blk.table[dp_tab(t, lane)], i0 + t, -1, best, bj, bmark);
+      if (dp_pair_dynamic(c1, c2)) {
+        double tot; int mark;
+        if (dp_connection_x<DpRingSrc<FLAG>, true, 1, true>(R, st_wt, i0 + t, i, n2, tot, mark)) dp_take(tot, i0 + t, mark, best, bj, bmark);
+      }
+    }
+  }
+}
+
+// a block's results leave the ring for global memory (one wavefront)
+__device__ __forceinline__ void dp_flush(const Nodes &nd, DpRing &ring, uint32_t first, int nn, int i0, int lane) {
+  const int rel = i0 + lane;
+  if (rel >= nn) return;
+  const int k = dp_slot(rel); const DpRec q = ring.rec[k]; const uint32_t d = q.tbl & 0xffffu;
+  if (d != 0) {
+    GST(&nd.score[first + (uint32_t)rel], ring.sv2[k].x); GST(&nd.ov_mark[first + (uint32_t)rel], ((q.pk >> 4) & 3) - 1);
+    if (d != (uint32_t)DP_FAR) GST(&nd.traceb[first + (uint32_t)rel], rel - (int)d);
+  }
+}
+
+// Per block k of 64 nodes, two phases and two barriers:
+//   P(k)  wavefront 0 resolves block k (B) | wavefront 1 enters block k + 2 into the rings | the others score the candidates of block
+//         k + 1 that lie before block k (A1: nine tenths of a node's candidates -- all final)
+//   Q(k)  all wavefronts: block k leaves for global memory; the candidates of block k + 1 inside block k (final now) and the table of
+//         block k + 1 (A2)
 template <int FLAG, int DP_NT>
 __global__ void __launch_bounds__(DP_NT) gene_dp_kernel(Nodes nd, const uint32_t *__restrict__ seq_lo, const uint32_t *__restrict__ seq_n, const uint32_t *__restrict__ seq_bin,
                                                         const double *__restrict__ st_wt_of_bin, uint32_t nseq) {
   constexpr int DP_NW = DP_NT / 64;
-  constexpr int W_ENTER = 1 % DP_NW, W_FLUSH = 2 % DP_NW;
+  static_assert(DP_NW >= 4, "gene_dp_kernel: a resolver, an enterer and two scorers at least");
   __shared__ DpRing ring;
   __shared__ DpBlock blk;
   __shared__ uint32_t ring_tot[4];
@@ -560,141 +711,36 @@ __global__ void __launch_bounds__(DP_NT) gene_dp_kernel(Nodes nd, const uint32_t
     const double st_wt = st_wt_of_bin[seq_bin[s]];
     __syncthreads();
     if (tid < 4) ring_tot[tid] = 0;
-    if (tid == 0) blk.next = 0;
+    if (tid == 0) { blk.next1 = 0; blk.next2 = 0; }
     __syncthreads();
-    if (wv == W_ENTER && nn > 0) dp_enter<FLAG>(nd, ring, blk, ring_tot, first, nn, 0, lane);
+    if (nn == 0) continue;
+    // prologue: blocks 0 and 1 enter; block 0 has no candidates before it (A1 empty), its table is (A2)
+    if (wv == 1) dp_enter<FLAG>(nd, ring, blk, ring_tot, first, nn, 0, lane);
+    if (wv == 0) { blk.best1[0][lane] = -1.0; blk.key1[0][lane] = -1; }
+    __syncthreads();                   // (the class totals lane 0 stored are read by every lane of the next entering: a barrier between the two, not program order alone)
+    if (wv == 1 && nn > DPB) dp_enter<FLAG>(nd, ring, blk, ring_tot, first, nn, DPB, lane);
+    __syncthreads();
+    dp_candidates<FLAG, 2>(nd, ring, blk, ring_tot, first, st_wt, 0, min(DPB, nn), lane);
     __syncthreads();
     for (int i0 = 0; i0 < nn; i0 += DPB) {
       const int cnt = min(DPB, nn - i0), i1 = i0 + cnt;
-      const int ring_lo = dp_ring_lo(i0);
-      // ---- the previous block's results go to global memory (its ring entries are final) ----
-      if (wv == W_FLUSH && i0 > 0) {
-        const int rel = i0 - DPB + lane;
-        const int k = dp_slot(rel); const DpRec q = ring.rec[k]; const uint32_t d = q.tbl & 0xffffu;
-        if (d != 0) {
-          GST(&nd.score[first + (uint32_t)rel], ring.sv2[k].x); GST(&nd.ov_mark[first + (uint32_t)rel], ((q.pk >> 4) & 3) - 1);
-          if (d != (uint32_t)DP_FAR) GST(&nd.traceb[first + (uint32_t)rel], rel - (int)d);
-        }
-      }
-      // ---- (A) ----
-      {
-        const DpSrc<FLAG> S{nd, ring, first, ring_lo, i1, i0};
-        const ushort4 c0 = ring.cnt[dp_slot(i0)];                                    // class counts at the block's first node
-        (void)c0;
-        for (;;) {
-          uint32_t u = 0;
-          if (lane == 0) u = atomicAdd(&blk.next, 1u);
-          u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
-          if (u >= (uint32_t)cnt) break;
-          const int l = blk.order[u], i = i0 + l;
-          const DpRec qi = ring.rec[dp_slot(i)];
-          DpNode n2; n2.ndx = qi.ndx; n2.sv = qi.sv; n2.strand = (qi.pk & 2) ? -1 : 1; n2.stop = qi.pk & 1;
-          const uint32_t lod = qi.tbl >> 16;
-          const int lo = lod == (uint32_t)DP_FAR ? (int)nd.dp_min[first + (uint32_t)i] : i - (int)lod;
-          const int le = blk.lo_eff[l];
-          const int c2 = dp_class(n2.strand, n2.stop);
-          if (lane < l) blk.table[dp_tab(lane, l)] = -__builtin_inf();
-          double best = -1.0; int bj = -1, bmark = -1;
-          // class ranges: the first candidate must be in the node ring, every class's members behind it in the class rings
-          bool by_class = le >= ring_lo;
-          unsigned short a[4], n[4];
-          if (by_class) {
-            const ushort4 ca = ring.cnt[dp_slot(le)], cb = ring.cnt[dp_slot(i)];
-            a[0] = ca.x; a[1] = ca.y; a[2] = ca.z; a[3] = ca.w;
-            n[0] = (unsigned short)(cb.x - ca.x); n[1] = (unsigned short)(cb.y - ca.y); n[2] = (unsigned short)(cb.z - ca.z); n[3] = (unsigned short)(cb.w - ca.w);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) if ((unsigned short)((unsigned short)ring_tot[c] - a[c]) > DPC) by_class = false;
-          }
-          if (by_class) {
-            const DpRingSrc<FLAG> R{S, -1, DpRec{0, 0, 0, 0}};
-#pragma unroll
-            for (int c1 = 0; c1 < 4; ++c1) {
-              if (!dp_pair_possible(c1, c2)) continue;
-              const bool dyn = dp_pair_dynamic(c1, c2);
-              for (int t = lane; t < (int)n[c1]; t += 64) {
-                const int jl = ring.cls[c1][(a[c1] + t) & (DPC - 1)];                           // low 16 bits of the index
-                const int j = i - ((i - jl) & 0xffff);
-                const bool inblk = j >= i0;
-                if (inblk && dyn) continue;
-                double sc; int mark; bool ok;
-                if (c1 == 0) ok = dp_connection_s<DpRingSrc<FLAG>, true, 1, false>(R, st_wt, j, i, n2, sc, mark);
-                else if (c1 == 1) ok = dp_connection_s<DpRingSrc<FLAG>, true, 1, true>(R, st_wt, j, i, n2, sc, mark);
-                else if (c1 == 2) ok = dp_connection_s<DpRingSrc<FLAG>, true, -1, false>(R, st_wt, j, i, n2, sc, mark);
-                else ok = dp_connection_s<DpRingSrc<FLAG>, true, -1, true>(R, st_wt, j, i, n2, sc, mark);
-                if (ok) {
-                  if (inblk) blk.table[dp_tab(j - i0, l)] = sc;
-                  else dp_take(R.score(j) + sc, j, mark, best, bj, bmark);
-                }
-              }
-            }
-          } else {
-            for (int j = lo + lane; j < i; j += 64) {
-              const bool inblk = j >= i0;
-              const DpNode n1 = S.node(j);
-              if (inblk && dp_pair_dynamic(dp_class(n1.strand, n1.stop), c2)) continue;
-              double sc; int mark;
-              if (dp_connection_s<DpSrc<FLAG>, false, 0, false>(S, st_wt, j, i, n2, sc, mark)) {
-                if (inblk) blk.table[dp_tab(j - i0, l)] = sc;
-                else dp_take(S.score(j) + sc, j, mark, best, bj, bmark);
-              }
-            }
-          }
-          int key = bj < 0 ? -1 : bj * 4 + (bmark + 1);                 // candidate index and overlap mark travel together
-          dp_wave_best(best, key);
-          if (lane == 0) { blk.pbest[l] = best; blk.pkey[l] = key; }
-        }
-      }
-      __syncthreads();
-      // ---- (B) ----
+      const int cnt1 = i1 < nn ? min(DPB, nn - i1) : 0;                           // nodes of the next block
+      // ---- P ----
       if (wv == 0) {
-        const DpSrc<FLAG> S{nd, ring, first, ring_lo, i1, 0x7fffffff};
-        const DpRingSrc<FLAG> R{S, -1, DpRec{0, 0, 0, 0}};
-        const bool in = lane < cnt;
-        const int i = i0 + (in ? lane : 0);
-        const int k = dp_slot(i);
-        const DpRec qi = ring.rec[k];
-        DpNode n2; n2.ndx = qi.ndx; n2.sv = qi.sv; n2.strand = (qi.pk & 2) ? -1 : 1; n2.stop = qi.pk & 1;
-        const int c2 = dp_class(n2.strand, n2.stop);
-        double best = in ? blk.pbest[lane] : -1.0; const int key0 = in ? blk.pkey[lane] : -1;
-        int bj = key0 < 0 ? -1 : key0 >> 2, bmark = key0 < 0 ? -1 : (key0 & 3) - 1;
-        if (lane == 0) blk.next = 0;
-        for (int t = 0; t < cnt; ++t) {
-          // node i0 + t is final: every lane learns it, its own lane publishes it to the ring
-          const double bt = dp_mk64(__builtin_amdgcn_readlane(dp_lo32(best), t), __builtin_amdgcn_readlane(dp_hi32(best), t));
-          const int jt = __builtin_amdgcn_readlane(bj, t), c1 = __builtin_amdgcn_readlane(c2, t);
-          if (lane == t && bj >= 0) {
-            ring.sv2[k].x = best;
-            const uint32_t d = i - bj < DP_FAR ? (uint32_t)(i - bj) : (uint32_t)DP_FAR;
-            ring.rec[k].tbl = (qi.tbl & 0xffff0000u) | d;
-            ring.rec[k].pk = qi.pk | ((bmark + 1) << 4);
-            if (d == (uint32_t)DP_FAR) GST(&nd.traceb[first + (uint32_t)i], bj);                  // (a trace-back the 16-bit distance cannot hold is read from global memory)
-          }
-          if (dp_class_needs_tb(c1) && jt < 0) continue;
-          const double sc_t = jt >= 0 ? bt : 0.0;
-          if (in && lane > t) {
-            dp_take(sc_t + blk.table[dp_tab(t, lane)], i0 + t, -1, best, bj, bmark);
-            if (dp_pair_dynamic(c1, c2)) {
-              double tot; int mark;
-              if (dp_connection_x<DpRingSrc<FLAG>, true, 1, true>(R, st_wt, i0 + t, i, n2, tot, mark)) dp_take(tot, i0 + t, mark, best, bj, bmark);
-            }
-          }
-        }
-      } else if (wv == W_ENTER && i1 < nn) {
-        dp_enter<FLAG>(nd, ring, blk, ring_tot, first, nn, i1, lane);
+        if (lane == 0) blk.next2 = 0;
+        dp_resolve<FLAG>(nd, ring, blk, first, st_wt, i0, cnt, lane);
+      } else if (wv == 1) {
+        if (i1 + DPB < nn) dp_enter<FLAG>(nd, ring, blk, ring_tot, first, nn, i1 + DPB, lane);
       }
-      if (DP_NW == 1 && i1 < nn) dp_enter<FLAG>(nd, ring, blk, ring_tot, first, nn, i1, lane);
+      if (wv >= 1) {          // (the enterer joins the scorers when it is done; the resolver does not: it is the longer of the two)
+        if (cnt1) dp_candidates<FLAG, 1>(nd, ring, blk, ring_tot, first, st_wt, i1, cnt1, lane);
+      }
       __syncthreads();
-    }
-    // the last block's results
-    if (wv == W_FLUSH && nn > 0) {
-      const int i0 = ((nn - 1) / DPB) * DPB, rel = i0 + lane;
-      if (rel < nn) {
-        const int k = dp_slot(rel); const DpRec q = ring.rec[k]; const uint32_t d = q.tbl & 0xffffu;
-        if (d != 0) {
-          GST(&nd.score[first + (uint32_t)rel], ring.sv2[k].x); GST(&nd.ov_mark[first + (uint32_t)rel], ((q.pk >> 4) & 3) - 1);
-          if (d != (uint32_t)DP_FAR) GST(&nd.traceb[first + (uint32_t)rel], rel - (int)d);
-        }
-      }
+      // ---- Q ----
+      if (wv == 2) dp_flush(nd, ring, first, nn, i0, lane);
+      if (tid == 0) blk.next1 = 0;
+      if (cnt1) dp_candidates<FLAG, 2>(nd, ring, blk, ring_tot, first, st_wt, i1, cnt1, lane);
+      __syncthreads();
     }
   }
 }
