@@ -139,3 +139,29 @@ def edge_genomes():
             [base[0] + "N" * 49 + base[1], base[2][:100] + "N" * 50 + base[2][100:]],
             ["ATG" + "GCA" * 400 + "TAA"],
             [("ATG" + "GCT" * 300 + "TAA" + "CCGGTTAACC") * 30]]
+
+
+def dp_stress_genomes():
+    """Bins (lists of contig strings) that push the gene finder's dynamic program off its common path: an open reading frame of 36 kb (the
+    window of the nodes behind it starts further back than any ring of recent nodes holds -- dprog.c looks 500 nodes back and 500 more behind
+    the node it finds there, further when a giant frame sits there); two thousand in-frame ATG codons in ONE frame, forward and reverse, and three thousand with nothing between them (one
+    class of nodes fills the whole window; a stop's overlapping start is thousands of nodes away); ATG / TAA alternating through all three
+    frames (windows of nothing but nodes, stops every few bases); and two hundred short contigs of 200 - 3000 bases (final-sweep sequences
+    of 0 .. 200 nodes: every remainder of the 64-node blocks the device takes them in)."""
+    from synthdata import synth_genome as sg
+    rng = np.random.default_rng(9)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+    def rc(s):
+        return "".join(comp[c] for c in reversed(s))
+    base = [s for _c, s in sg.make_genome(710, n_contigs=3, contig_len=(25000, 35000))]
+    sense = [a + b + c for a in "ACGT" for b in "ACGT" for c in "ACGT" if a + b + c not in ("TAA", "TAG", "TGA")]
+    giant = "ATG" + "".join(rng.choice(sense, 12000)) + "TAA"
+    many = "ATG" + "".join(("ATG" if k % 2 == 0 else str(rng.choice(sense))) for k in range(4000)) + "TAA"
+    pure = "ATG" * 3000 + "TAA"                                                    # (nothing but forward starts of one frame for 3000 nodes)
+    dense = "".join(rng.choice(["ATGA", "TAAC", "ATGC", "TAGG", "GTGA", "TGAC"], 3000))
+    shorts = ["".join(rng.choice(list("ACGT"), int(n))) for n in rng.integers(200, 3000, 200)]
+    return [[base[0][:12000] + giant + base[0][12000:], base[1]],
+            [base[0], base[1][:8000] + many + base[1][8000:], base[2][:5000] + rc(many) + base[2][5000:]],
+            [base[2], dense + base[0][:20000] + rc(dense), base[1][:3000] + pure + base[1][3000:6000] + rc(pure) + base[1][6000:9000]],
+            shorts + base[:1]]

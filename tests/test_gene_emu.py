@@ -61,6 +61,33 @@ def test_emulated_pipeline_equals_the_oracle(table):
     assert ngenes > 200 and kinds == {0, 1}, (ngenes, kinds)          # both start-site models were trained
 
 
+def _same_as_oracle(genomes, table):
+    cols, per_bin = emu.call_genes(genomes, table)
+    by_bin = {}
+    for k in range(len(cols["begin"])):
+        by_bin.setdefault(int(cols["bin"][k]), []).append(k)
+    ngenes = 0
+    for b, g in enumerate(genomes):
+        t, ogenes, oprots = og.find_genes(g, table)
+        ks = by_bin.get(b, [])
+        assert t is not None and per_bin["trained"][b], b
+        assert [_key(cols, k) for k in ks] == [_okey(x) for x in ogenes], b
+        for f in ("gc_cont", "conf", "score", "cscore", "sscore", "rscore", "uscore", "tscore"):
+            got = np.asarray([cols[f][k] for k in ks], dtype=np.float64).view(np.uint64)
+            want = np.asarray([getattr(x, f) for x in ogenes], dtype=np.float64).view(np.uint64)
+            assert (got == want).all(), (b, f, np.nonzero(got != want)[0][:3])
+        assert [cols["proteins"][k] for k in ks] == oprots, b
+        ngenes += len(ks)
+    return ngenes
+
+
+def test_emulated_pipeline_on_the_dynamic_programs_hard_cases():
+    """A giant open reading frame, thousands of starts in one frame, node-dense repeats, hundreds of short contigs (tests/common.py:
+    dp_stress_genomes) -- the inputs on which the device's dynamic program leaves its rings (tests/test_gpu_genes.py runs the same bins)."""
+    from tests import common
+    assert _same_as_oracle(common.dp_stress_genomes(), 11) > 100
+
+
 def test_product_does_not_load_the_emulation():
     import os
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "checkm_amd")

@@ -65,6 +65,30 @@ def test_genes_identical_to_the_oracle(gpu_ctx, table):
     assert stats["ms_dp_train"] > 0 and stats["ms_dp_find"] > 0
 
 
+@pytest.mark.parametrize("table", [11, 4])
+def test_dynamic_program_off_its_rings(gpu_ctx, table):
+    """tests/common.py: dp_stress_genomes -- a 36 kb open reading frame (windows that start behind the LDS ring: global-memory fall-backs,
+    16-bit distances that do not fit), two thousand starts of one frame (one class of nodes beyond its class ring: the generic candidate
+    loop; overlapping starts further than a packed offset holds), node-dense repeats, two hundred short contigs (every block remainder)."""
+    from tests import common
+    genomes = common.dp_stress_genomes()
+    cols, per_bin, stats = _lib.call_genes(gpu_ctx, genomes, table)
+    by_bin = {}
+    for k in range(len(cols["begin"])):
+        by_bin.setdefault(int(cols["bin"][k]), []).append(k)
+    for b, g in enumerate(genomes):
+        t, ogenes, oprots = og.find_genes(g, table)
+        ks = by_bin.get(b, [])
+        assert t is not None and per_bin["trained"][b], b
+        assert [_key(cols, k) for k in ks] == [_okey(x) for x in ogenes], b
+        for f in ("gc_cont", "conf", "score", "cscore", "sscore", "rscore", "uscore", "tscore"):
+            got = np.asarray([cols[f][k] for k in ks], dtype=np.float64).view(np.uint64)
+            want = np.asarray([getattr(x, f) for x in ogenes], dtype=np.float64).view(np.uint64)
+            assert (got == want).all(), (b, f, np.nonzero(got != want)[0][:3])
+        assert [cols["proteins"][k] for k in ks] == oprots, b
+    assert len(cols["begin"]) > 100
+
+
 def test_find_from_nucleotide_bins_writes_prodigal_files(gpu_ctx, tmp_path, monkeypatch):
     """MarkerGeneFinder.find on nucleotide bins with no prodigal on PATH: genes.faa / genes.gff come from the device caller, the table
     choice follows checkm/prodigal.py:117-133, ProdigalGeneFeatureParser reads the GFF, and the scan runs on the written proteins."""
