@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcheckm_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class CkmError(RuntimeError):
@@ -96,6 +96,11 @@ class OrfColumns(C.Structure):
                 ("ms_flags", C.c_double), ("ms_chain", C.c_double), ("bases", C.c_uint64), ("padded_bytes", C.c_uint64)]
 
 
+class NucBatchView(C.Structure):
+    _fields_ = [("text", C.c_void_p), ("contig_off", C.POINTER(C.c_uint64)), ("bin_first", C.POINTER(C.c_uint32)), ("contig_ids", C.c_void_p),
+                ("bin_bases", C.POINTER(C.c_uint64)), ("ncontigs", C.c_uint32), ("nbins", C.c_uint32)]
+
+
 class GeneColumns(C.Structure):
     _fields_ = [("n", C.c_uint64), ("bin", C.POINTER(C.c_uint32)), ("contig", C.POINTER(C.c_uint32)), ("begin", C.POINTER(C.c_int32)), ("end", C.POINTER(C.c_int32)),
                 ("strand", C.POINTER(C.c_int8)), ("start_type", C.POINTER(C.c_uint8)), ("partial_left", C.POINTER(C.c_uint8)), ("partial_right", C.POINTER(C.c_uint8)),
@@ -122,6 +127,7 @@ EXPORTS = ["ckm_last_error", "ckm_abi_version", "ckm_device_count", "ckm_ctx_cre
            "ckm_hits_write_domtblout", "ckm_hits_write_alignments", "ckm_last_search_stats", "ckm_reduce", "ckm_qa_columns_get", "ckm_qa_free", "ckm_count_sets",
            "ckm_align", "ckm_tables_read", "ckm_tables_assign_models", "ckm_tables_get", "ckm_tables_free",
            "ckm_orf_scan", "ckm_orf_columns_get", "ckm_orf_free", "ckm_debug_orf_flags", "ckm_genes_call", "ckm_genes_columns_get", "ckm_genes_free", "ckm_genes_coding_union", "ckm_genes_write_bin",
+           "ckm_nuc_batch_read", "ckm_nuc_batch_view_get", "ckm_nuc_batch_free",
            "ckm_debug_stages", "ckm_debug_envelopes", "ckm_debug_region"]
 
 _lib = None
@@ -180,12 +186,16 @@ def load():
     L.ckm_orf_columns_get.argtypes = [C.c_void_p, C.POINTER(OrfColumns)]
     L.ckm_orf_free.argtypes = [C.c_void_p]
     L.ckm_orf_free.restype = None
-    L.ckm_genes_call.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.ckm_genes_call.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.ckm_genes_columns_get.argtypes = [C.c_void_p, C.POINTER(GeneColumns)]
     L.ckm_genes_free.argtypes = [C.c_void_p]
     L.ckm_genes_free.restype = None
     L.ckm_genes_coding_union.argtypes = [C.c_void_p, C.c_void_p]
-    L.ckm_genes_write_bin.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]
+    L.ckm_genes_write_bin.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]
+    L.ckm_nuc_batch_read.argtypes = [C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_void_p)]
+    L.ckm_nuc_batch_view_get.argtypes = [C.c_void_p, C.POINTER(NucBatchView)]
+    L.ckm_nuc_batch_free.argtypes = [C.c_void_p]
+    L.ckm_nuc_batch_free.restype = None
     L.ckm_debug_orf_flags.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
     L.ckm_debug_stages.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.ckm_debug_envelopes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -520,6 +530,55 @@ class GeneBatch(object):
         self.text = b"".join(parts)
         self.ids = (C.c_char_p * max(1, len(ids)))(*ids)
         self.bases = [int(self.off[bin_first[b + 1]] - self.off[bin_first[b]]) for b in range(self.nbins)]
+        self._h = None
+
+    @classmethod
+    def from_files(cls, paths):
+        """The batch of the plain nucleotide FASTA files `paths`, a bin each, read and laid out by the library's host threads
+        (ckm_nuc_batch_read: the record rules of geneFinder.read_contigs_bytes) -- no Python object per contig, no interpreter lock held."""
+        self = cls.__new__(cls)
+        arr = (C.c_char_p * max(1, len(paths)))(*[p.encode() for p in paths])
+        h = C.c_void_p()
+        _chk(load().ckm_nuc_batch_read(arr, len(paths), C.byref(h)))
+        self._h = h
+        v = NucBatchView()
+        _chk(load().ckm_nuc_batch_view_get(h, C.byref(v)))
+        self.nbins, self.ncontigs = int(v.nbins), int(v.ncontigs)
+        self.off = np.ctypeslib.as_array(v.contig_off, shape=(self.ncontigs + 1,))
+        total = int(self.off[-1])
+        # views of the library's batch (alive until close): the text as bytes-like uint8, the ids as an address
+        self.text = np.ctypeslib.as_array((C.c_uint8 * total).from_address(v.text)) if total else np.zeros(0, dtype=np.uint8)
+        self.ids = v.contig_ids
+        self.bin_first = np.ctypeslib.as_array(v.bin_first, shape=(self.nbins + 1,))
+        self.bases = [int(x) for x in np.ctypeslib.as_array(v.bin_bases, shape=(self.nbins,))] if self.nbins else []
+        return self
+
+    def text_arg(self):
+        """The text as ckm_genes_call / ckm_genes_write_bin take it."""
+        return self.text if isinstance(self.text, bytes) else self.text.ctypes.data
+
+    def contigs(self, b):
+        """[(id bytes, sequence bytes)] of bin b (tests, diagnostics)."""
+        out = []
+        for c in range(int(self.bin_first[b]), int(self.bin_first[b + 1])):
+            a, z = int(self.off[c]), int(self.off[c + 1])
+            if self._h is None:
+                out.append((self.ids[c], self.text[a:z]))
+            else:
+                out.append((C.cast(self.ids + c * C.sizeof(C.c_void_p), C.POINTER(C.c_char_p))[0], self.text[a:z].tobytes()))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.off = self.bin_first = self.text = None
+            load().ckm_nuc_batch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class GeneCall(object):
@@ -528,7 +587,7 @@ class GeneCall(object):
     def __init__(self, ctx, batch, trans_table=11, closed=False, mask=True):
         self.batch, self.table = batch, int(trans_table)
         self.h = C.c_void_p()
-        _chk(load().ckm_genes_call(ctx.h, batch.text, batch.off.ctypes.data, batch.ncontigs, batch.bin_first.ctypes.data, batch.nbins, self.table, 1 if closed else 0, 1 if mask else 0, C.byref(self.h)))
+        _chk(load().ckm_genes_call(ctx.h, batch.text_arg(), batch.off.ctypes.data, batch.ncontigs, batch.bin_first.ctypes.data, batch.nbins, self.table, 1 if closed else 0, 1 if mask else 0, C.byref(self.h)))
         cols = GeneColumns()
         _chk(load().ckm_genes_columns_get(self.h, C.byref(cols)))
         self._cols = cols
@@ -565,7 +624,7 @@ class GeneCall(object):
 
     def write_bin(self, b, aaFile, gffFile, ntFile=None):
         bt = self.batch
-        _chk(load().ckm_genes_write_bin(self.h, int(b), self.table, bt.ids, bt.text, bt.off.ctypes.data, bt.bin_first.ctypes.data,
+        _chk(load().ckm_genes_write_bin(self.h, int(b), self.table, bt.ids, bt.text_arg(), bt.off.ctypes.data, bt.bin_first.ctypes.data,
                                         aaFile.encode(), gffFile.encode(), ntFile.encode() if ntFile else None))
 
     def close(self):

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <memory>
 #include <mutex>
 #include <system_error>
 #include <thread>
@@ -154,3 +155,100 @@ void build_seq_order(int nthreads, const SeqColumns &o) {
 }
 
 }  // namespace ckm
+
+// ---- nucleotide bins for ckm_genes_call: the files CheckM hands to prodigal by path (checkm/prodigal.py:86-93, `-i <bin>`) ----
+// Record rules as checkm_amd/geneFinder.py: read_contigs_bytes states them (CheckM's own readFasta, checkm/util/seqUtils.py:180-211): a
+// record begins with '>' at the start of a line, what precedes the first one is skipped, the id is the header's first blank-delimited word,
+// the sequence is everything up to the next record with '\n', '\r', ' ' and '\t' removed.  A file per thread, then every bin moved into
+// the batch's one text by its own thread.
+namespace ckm {
+namespace {
+struct NucBin { std::unique_ptr<char[]> text; size_t len = 0; std::vector<uint64_t> off; std::vector<std::string> ids; std::string err; };
+
+inline bool py_space(unsigned char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }          // bytes.split(None): space, \t \n \v \f \r
+
+void parse_nuc_file(const char *path, NucBin &o) {
+  FILE *f = fopen(path, "rb");
+  if (!f) { o.err = std::string("cannot open FASTA file ") + path; return; }
+  fseek(f, 0, SEEK_END); const long sz = ftell(f); fseek(f, 0, SEEK_SET);
+  std::unique_ptr<char[]> buf(new char[(size_t)std::max<long>(sz, 1)]);             // (not zero-filled: 2 MB a bin)
+  const size_t n = sz > 0 ? fread(buf.get(), 1, (size_t)sz, f) : 0;
+  fclose(f);
+  if ((long)n != sz) { o.err = std::string("short read on ") + path; return; }
+  const char *d = buf.get();
+  static const struct Keep { uint8_t t[256]; Keep() { for (int c = 0; c < 256; ++c) t[c] = !(c == '\n' || c == '\r' || c == ' ' || c == '\t'); } } keep;
+  auto next_record = [&](size_t from) -> size_t {                 // index of the '\n' of the next "\n>" at or after `from`, or n
+    for (size_t p = from; p + 1 < n;) {
+      const void *q = memchr(d + p, '\n', n - 1 - p);
+      if (!q) return n;
+      p = (size_t)((const char *)q - d);
+      if (d[p + 1] == '>') return p;
+      ++p;
+    }
+    return n;
+  };
+  size_t pos;                                                      // first byte after the '>' of the current record
+  if (n && d[0] == '>') pos = 1;
+  else { const size_t p = next_record(0); if (p >= n) return; pos = p + 2; }
+  o.text.reset(new char[n + 1]);
+  char *w = o.text.get();
+  for (;;) {
+    const size_t end = next_record(pos);                           // the record is d[pos .. end)
+    const void *nl = pos < end ? memchr(d + pos, '\n', end - pos) : nullptr;
+    const size_t he = nl ? (size_t)((const char *)nl - d) : end;   // header d[pos .. he), body after the '\n'
+    size_t a = pos; while (a < he && py_space((unsigned char)d[a])) ++a;
+    size_t z = a; while (z < he && !py_space((unsigned char)d[z])) ++z;
+    o.ids.emplace_back(d + a, z - a);
+    o.off.push_back((uint64_t)(w - o.text.get()));
+    if (nl) for (size_t i = he + 1; i < end; ++i) { const unsigned char c = (unsigned char)d[i]; *w = (char)c; w += keep.t[c]; }      // (branch-free: a byte per cycle)
+    if (end >= n) break;
+    pos = end + 2;
+  }
+  o.len = (size_t)(w - o.text.get());
+}
+}  // namespace
+}  // namespace ckm
+
+struct ckm_nuc_batch {
+  std::string text; std::vector<uint64_t> contig_off, bin_bases; std::vector<uint32_t> bin_first;
+  std::vector<std::string> ids; std::vector<const char *> id_ptr;
+};
+
+extern "C" int ckm_nuc_batch_read(const char *const *paths, uint32_t nbins, ckm_nuc_batch **out) {
+  using namespace ckm;
+  if (!out || (nbins && !paths)) { set_last_error("NULL argument"); return CKM_EINVAL; }
+  *out = nullptr;
+  try {
+    std::vector<NucBin> bins(nbins);
+    for_each_bin(nbins, ingest_threads(), [&](uint32_t b) { parse_nuc_file(paths[b], bins[b]); });
+    for (auto &nb : bins) if (!nb.err.empty()) { set_last_error(nb.err); return CKM_EIO; }
+    std::unique_ptr<ckm_nuc_batch> B(new ckm_nuc_batch);
+    std::vector<uint64_t> text_at((size_t)nbins + 1, 0), rec_at((size_t)nbins + 1, 0);
+    for (uint32_t b = 0; b < nbins; ++b) { text_at[b + 1] = text_at[b] + bins[b].len; rec_at[b + 1] = rec_at[b] + bins[b].ids.size(); }
+    if (rec_at[nbins] > 0xfffffff0ull) { set_last_error("more than 2^32 contigs in one batch"); return CKM_ERANGE; }
+    const size_t nrec = (size_t)rec_at[nbins];
+    B->text.resize((size_t)text_at[nbins]); B->contig_off.assign(nrec + 1, 0); B->ids.assign(nrec, std::string());
+    B->bin_first.assign((size_t)nbins + 1, 0); B->bin_bases.assign(nbins, 0);
+    for (uint32_t b = 0; b <= nbins; ++b) B->bin_first[b] = (uint32_t)rec_at[b];
+    B->contig_off[nrec] = text_at[nbins];
+    for_each_bin(nbins, ingest_threads(), [&](uint32_t b) {
+      NucBin &nb = bins[b];
+      if (nb.len) memcpy(&B->text[0] + text_at[b], nb.text.get(), nb.len);
+      for (size_t r = 0; r < nb.ids.size(); ++r) { B->contig_off[rec_at[b] + r] = text_at[b] + nb.off[r]; B->ids[rec_at[b] + r] = std::move(nb.ids[r]); }
+      B->bin_bases[b] = nb.len;
+      nb.text.reset();
+    });
+    B->id_ptr.resize(std::max<size_t>(nrec, 1), nullptr);
+    for (size_t r = 0; r < nrec; ++r) B->id_ptr[r] = B->ids[r].c_str();
+    *out = B.release();
+    return CKM_OK;
+  } catch (const std::bad_alloc &) { set_last_error("out of host memory"); return CKM_ENOMEM; }
+  catch (const std::exception &e) { set_last_error(e.what()); return CKM_EINVAL; }
+}
+extern "C" int ckm_nuc_batch_view_get(const ckm_nuc_batch *b, ckm_nuc_batch_view *o) {
+  if (!b || !o) { ckm::set_last_error("NULL argument"); return CKM_EINVAL; }
+  o->text = b->text.data(); o->contig_off = b->contig_off.data(); o->bin_first = b->bin_first.data(); o->contig_ids = b->id_ptr.data();
+  o->bin_bases = b->bin_bases.data(); o->ncontigs = (uint32_t)b->ids.size(); o->nbins = (uint32_t)b->bin_bases.size();
+  return CKM_OK;
+}
+extern "C" void ckm_nuc_batch_free(ckm_nuc_batch *b) { delete b; }

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CKM_ABI_VERSION 6
+#define CKM_ABI_VERSION 7
 
 enum {
   CKM_OK      =  0,
@@ -337,6 +337,25 @@ void ckm_genes_free(ckm_genes *g);
 int  ckm_genes_coding_union(const ckm_genes *g, uint64_t *bases /* [nbins] */);
 int  ckm_genes_write_bin(const ckm_genes *g, uint32_t bin, int trans_table, const char *const *contig_ids, const char *text, const uint64_t *contig_off,
                          const uint32_t *bin_first, const char *aa_path, const char *gff_path, const char *nt_path);
+
+/* ---- the nucleotide files of a batch of bins, laid out for ckm_genes_call / ckm_genes_write_bin (ABI 7) --------------------------------
+ * What checkm/prodigal.py:86-93 hands to prodigal by path (`-i <bin>`): plain (uncompressed) nucleotide FASTA files, one per bin, read by
+ * host threads (a file per thread) with the record rules of CheckM's own reader (checkm/util/seqUtils.py:180-211): a record begins with
+ * '>' at the start of a line, text before the first one is skipped, the contig id is the header's first blank-delimited word, the
+ * sequence is what follows up to the next record without '\n', '\r', ' ', '\t'.  The view's arrays are the arguments of ckm_genes_call
+ * (text, contig_off, ncontigs, bin_first, nbins) and ckm_genes_write_bin (contig_ids) and live until ckm_nuc_batch_free. */
+typedef struct ckm_nuc_batch ckm_nuc_batch;
+typedef struct {
+  const char        *text;          /* all contigs' nucleotides end to end */
+  const uint64_t    *contig_off;    /* [ncontigs + 1] */
+  const uint32_t    *bin_first;     /* [nbins + 1] */
+  const char *const *contig_ids;    /* [ncontigs] */
+  const uint64_t    *bin_bases;     /* [nbins]: nucleotides of each bin */
+  uint32_t           ncontigs, nbins;
+} ckm_nuc_batch_view;
+int  ckm_nuc_batch_read(const char *const *paths, uint32_t nbins, ckm_nuc_batch **out);
+int  ckm_nuc_batch_view_get(const ckm_nuc_batch *b, ckm_nuc_batch_view *out);
+void ckm_nuc_batch_free(ckm_nuc_batch *b);
 
 /* ---- diagnostics used by the parity tests: every stage of one (model, sequence) pair, no filtering */
 typedef struct {

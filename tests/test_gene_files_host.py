@@ -165,3 +165,32 @@ def test_bin_without_genes_is_an_error_after_the_others_are_written(tmp_path, fa
         geneFinder.call_bin_files(jobs)
     assert "bin001.fna" in str(e.value) and "no genes" in str(e.value)
     assert all(os.path.exists(os.path.join(d, "genes.faa")) for _f, d in jobs) and fake_device.live == 0
+
+
+def test_library_reader_equals_the_python_reader(tmp_path):
+    """ckm_nuc_batch_read (the sub-batches' files read by the library's host threads) against geneFinder.read_contigs_bytes, the statement
+    of CheckM's record rules (checkm/util/seqUtils.py:180-211): hand-made edge files and random ones over the bytes that matter."""
+    cases = [b">c1 desc here\nACGT\nAC GT\r\n\n>c2\tx\nTT>TT\n>\n>  spaced id  more\nAAAA", b"junk before\nmore junk\n>x1\nACGTN\n", b"no records at all\n", b">", b"",
+             b">only header", b"\n>lead\nAC\n\n\n>z\n", b">h1\r\nACGT\r\nTTTT\r\n>h2 d\r\nGG\r\n", b"x>notarecord\n>r\nAA\x0bBB\x0cCC\n", b"\n", b"\n>", b">\n>\n>"]
+    rng = np.random.default_rng(3)
+    alphabet = np.frombuffer(b">>\n\n\n\r \tACGTNacgt-*\x0b", dtype=np.uint8)
+    for _ in range(200):
+        cases.append(rng.choice(alphabet, int(rng.integers(0, 200))).tobytes())
+    paths = []
+    for k, data in enumerate(cases):
+        p = tmp_path / ("f%03d.fna" % k)
+        p.write_bytes(data)
+        paths.append(str(p))
+    nb = _lib.GeneBatch.from_files(paths)
+    want = [geneFinder.read_contigs_bytes(p) for p in paths]
+    assert nb.nbins == len(paths)
+    for k in range(len(paths)):
+        assert nb.contigs(k) == want[k], (k, cases[k])
+        assert nb.bases[k] == sum(len(s) for _c, s in want[k])
+    pb = _lib.GeneBatch(want)                                                # the same layout as the Python path builds
+    assert pb.text == nb.text.tobytes() and pb.off.tolist() == nb.off.tolist() and pb.bin_first.tolist() == nb.bin_first.tolist()
+    assert [pb.ids[c] for c in range(pb.ncontigs)] == [c for k in range(len(paths)) for c, _s in nb.contigs(k)]
+    nb.close()
+    with pytest.raises(_lib.CkmError):
+        _lib.GeneBatch.from_files([str(tmp_path / "missing.fna")])
+    assert _lib.GeneBatch.from_files([]).nbins == 0
