@@ -180,8 +180,8 @@ META_RANGE = 100000            # below this CheckM runs `prodigal -p meta` (chec
 
 def _lanes():
     import os
-    # 12: with the files read and written by the library the pass is the device's, and beyond the 16 hardware queues HIP runs with here a
-    # call's stream waits behind another call's dynamic programs (768 bins: 2.0 s with 8 - 16 lanes, 3.1 s with 24: profiles/r06z_gene_calls_in_flight.txt)
+    # 12: with the files read and written by the library the pass is the device's, and past a dozen busy hardware queues (HIP runs with 16
+    # here; more are worse) calls wait on each other (768 bins: 2.0 s with 8 - 16 lanes, 3.1 s with 24: profiles/r06z_gene_calls_in_flight.txt)
     return max(1, min(32, int(os.environ.get("CKM_GENE_LANES", "12"))))
 
 
