@@ -79,43 +79,73 @@ struct NodeSet {
 
 // ---- ordered walks over one sequence's nodes (relative indices; dprog.c / gene.c), a thread per sequence ----
 // max_ndx: where the path ends (x_path_ends: the scan over all of the sequence's nodes is a kernel of its own)
-GFN int walk_dprog_finish(const NView &V, int max_ndx) {
+// Every hop of these walks is a load that depends on the last one (0.7 - 2 us on the device): a step therefore asks for everything it
+// needs of the next node -- its link included -- at once, carries it into the next step in registers, and reads memory again only after the
+// rare step that rewires the path.  (Written as dprog.c has it, `while (traceb[path] != -1) { nxt = traceb[path]; ...; path = traceb[path]; }`,
+// a step was three round trips: the stores of the rare branch keep the compiler from holding a link across them.)
+struct WalkNode { int tb, strand, ndx, sv, mark; bool stop; };
+GFN WalkNode walk_node(const NView &V, int i) {
+  const Nodes &n = V.n; const uint32_t g = V.lo + (uint32_t)i;
+  WalkNode w; w.tb = n.traceb[g]; w.strand = n.strand[g]; w.stop = n.type[g] == G_STOP; w.ndx = n.ndx[g]; w.sv = n.sv[g]; w.mark = n.ov_mark[g];
+  return w;
+}
+// visit(i, node): every node of the finished path, from its end to its beginning (what a walk along traceb from the returned index meets)
+template <class F>
+GFN int walk_dprog_finish(const NView &V, int max_ndx, F visit) {
   const Nodes &n = V.n; const uint32_t lo = V.lo; const int nn = V.nn;
   if (nn == 0) return -1;
   if (max_ndx < 0) return -1;
+  if (n.traceb[lo + max_ndx] == -1) return -1;                     // (a path of one node: nothing to untangle, no gene)
+  // first pass: the triple overlaps
   int path = max_ndx;
-  while (n.traceb[lo + path] != -1) {
-    const int nxt = n.traceb[lo + path];
-    if (V.strand(path) == -1 && V.stop(path) && V.strand(nxt) == 1 && V.stop(nxt) && n.ov_mark[lo + path] != -1 && V.ndx(path) > V.ndx(nxt)) {
-      const int tmp = n.star[(size_t)(lo + path) * 3 + n.ov_mark[lo + path]];
+  WalkNode a = walk_node(V, path);
+  while (a.tb != -1) {
+    const int nxt = a.tb;
+    const WalkNode b = walk_node(V, nxt);
+    if (a.strand == -1 && a.stop && b.strand == 1 && b.stop && a.mark != -1 && a.ndx > b.ndx) {
+      const int tmp = n.star[(size_t)(lo + path) * 3 + a.mark];
       int i;
       for (i = tmp; V.ndx(i) != V.sv(tmp); --i);
       n.traceb[lo + path] = tmp; n.traceb[lo + tmp] = i; n.ov_mark[lo + i] = -1; n.traceb[lo + i] = nxt;
+      path = tmp; a = walk_node(V, path);
+      continue;
     }
-    path = n.traceb[lo + path];
+    path = nxt; a = b;
   }
+  // second pass: the double overlaps; a node's link is final when the pass leaves it, so the forward pointers (dprog.c's third pass) and
+  // the caller's visit ride along
   path = max_ndx;
-  while (n.traceb[lo + path] != -1) {
-    const int nxt = n.traceb[lo + path];
-    if (V.strand(path) == -1 && !V.stop(path) && V.strand(nxt) == 1 && V.stop(nxt)) {
+  a = walk_node(V, path);
+  while (a.tb != -1) {
+    const int nxt = a.tb;
+    const WalkNode b = walk_node(V, nxt);
+    bool rewired = false;
+    if (a.strand == -1 && !a.stop && b.strand == 1 && b.stop) {
       int i;
-      for (i = path; V.ndx(i) != V.sv(path); --i);
+      for (i = path; V.ndx(i) != a.sv; --i);
       n.traceb[lo + path] = i; n.traceb[lo + i] = nxt;
+      rewired = true;
     }
-    if (V.strand(path) == 1 && V.stop(path) && V.strand(nxt) == 1 && V.stop(nxt)) {
-      n.traceb[lo + path] = n.star[(size_t)(lo + nxt) * 3 + V.ndx(path) % 3];
+    if (a.strand == 1 && a.stop && b.strand == 1 && b.stop) {
+      n.traceb[lo + path] = n.star[(size_t)(lo + nxt) * 3 + a.ndx % 3];
       n.traceb[lo + n.traceb[lo + path]] = nxt;
+      rewired = true;
     }
-    if (V.strand(path) == -1 && V.stop(path) && V.strand(nxt) == -1 && V.stop(nxt)) {
-      n.traceb[lo + path] = n.star[(size_t)(lo + path) * 3 + V.ndx(nxt) % 3];
+    if (a.strand == -1 && a.stop && b.strand == -1 && b.stop) {
+      n.traceb[lo + path] = n.star[(size_t)(lo + path) * 3 + b.ndx % 3];
       n.traceb[lo + n.traceb[lo + path]] = nxt;
+      rewired = true;
     }
-    path = n.traceb[lo + path];
+    visit(path, a);
+    const int from = path;
+    if (rewired) { path = n.traceb[lo + path]; a = walk_node(V, path); }
+    else { path = nxt; a = b; }
+    n.tracef[lo + path] = from;
   }
-  path = max_ndx;
-  while (n.traceb[lo + path] != -1) { n.tracef[lo + n.traceb[lo + path]] = path; path = n.traceb[lo + path]; }
-  return n.traceb[lo + max_ndx] == -1 ? -1 : max_ndx;
+  visit(path, a);
+  return max_ndx;
 }
+GFN int walk_dprog_finish(const NView &V, int max_ndx) { return walk_dprog_finish(V, max_ndx, [](int, const WalkNode &) {}); }
 
 struct GeneSlot { int32_t begin, end, start_ndx, stop_ndx; };
 
@@ -728,23 +758,22 @@ inline void gene_pipeline(GExec &e, const PipeInput &in, GeneResult &out) {
       gcnt[b] = 0;
       if (sn[b] == 0) { ipath[b] = -1; return; }
       const NView V{tn, slo[b], (int)sn[b]}; const int sl = slen_d[b];
-      const int dbeg = walk_dprog_finish(V, ipath[b]);
-      ipath[b] = dbeg;
       int left = -1, right = -1, in_gene = 0; uint32_t ng = 0;
-      for (int path = dbeg; path != -1; path = tn.traceb[V.lo + path]) {
-        if (V.strand(path) == -1 && !V.stop(path)) { in_gene = -1; left = sl - V.ndx(path) - 1; }
-        if (V.strand(path) == 1 && V.stop(path)) { in_gene = 1; right = V.ndx(path) + 2; }
-        if (in_gene == -1 && V.strand(path) == -1 && V.stop(path)) {
-          right = sl - V.ndx(path) + 1;
+      const int dbeg = walk_dprog_finish(V, ipath[b], [&](int, const WalkNode &w) {          // (the first gene set is read off the path while it is finished)
+        if (w.strand == -1 && !w.stop) { in_gene = -1; left = sl - w.ndx - 1; }
+        if (w.strand == 1 && w.stop) { in_gene = 1; right = w.ndx + 2; }
+        if (in_gene == -1 && w.strand == -1 && w.stop) {
+          right = sl - w.ndx + 1;
           int32_t *g = gi + (size_t)(V.lo + ng) * 3; g[0] = -1; g[1] = left; g[2] = right; ng++;
           in_gene = 0;
         }
-        if (in_gene == 1 && V.strand(path) == 1 && !V.stop(path)) {
-          left = V.ndx(path);
+        if (in_gene == 1 && w.strand == 1 && !w.stop) {
+          left = w.ndx;
           int32_t *g = gi + (size_t)(V.lo + ng) * 3; g[0] = 1; g[1] = left; g[2] = right; ng++;
           in_gene = 0;
         }
-      }
+      });
+      ipath[b] = dbeg;
       gcnt[b] = ng;
     });
     uint32_t *hcnt = d_hcnt.as<uint32_t>();
