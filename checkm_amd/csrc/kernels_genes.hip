@@ -199,22 +199,39 @@ __global__ void __launch_bounds__(64) gc_bias_kernel(Nodes nd, const uint32_t *_
   if (b >= nbins) return;
   const uint32_t lo = seq_lo[b], nn = seq_n[b];
   const int lane = threadIdx.x;
-  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+  double acc = 0.0;                                                 // lane k: the sum of class k (k = 0, 1, 2)
   if (nn == 0) { if (lane < 3) bias[(size_t)b * 3 + lane] = 0.0; return; }
+  // The next 64 nodes are asked for before the current 64 are added (the loads of a chunk were two round trips that nothing else hid: the type, then -- under
+  // its test -- class and term), and the adds are branch-free: a term goes to its class's sum, +0.0 to the other two -- which leaves them
+  // as they are (the sums start at +0.0 and every term is a non-negative product, so no sum is ever -0.0).
+  auto fetch = [&](uint32_t i0, int &cls, double &term) {
+    const uint32_t i = i0 + (uint32_t)lane;
+    const uint32_t g = lo + (i < nn ? i : nn - 1);                  // (all three loads at once: class and term are zero-filled where no start node wrote them)
+    const int t = nd.type[g]; const int c = nd.gcb_cls[g]; const double v = nd.gcb_term[g];
+    const bool start = i < nn && t < G_STOP;
+    cls = start ? c : 3; term = start ? v : 0.0;                    // class 3: not a start node
+  };
+  int cls, ncls = 3; double term, nterm = 0.0;
+  fetch(0, cls, term);
   for (uint32_t i0 = 0; i0 < nn; i0 += 64) {
-    const uint32_t i = i0 + lane;
-    int cls = 3; double term = 0.0;                                 // class 3: not a start node
-    if (i < nn && nd.type[lo + i] < G_STOP) { cls = nd.gcb_cls[lo + i]; term = nd.gcb_term[lo + i]; }
-    // one after the other, in node order: lane l's class and term through v_readlane (uniform), a scalar branch, one add -- a __shfl per
-    // element (ds_bpermute: an LDS round trip) made this kernel 16 ms of a 48-bin call's critical path
+    if (i0 + 64 < nn) fetch(i0 + 64, ncls, nterm);
+    // one after the other, in node order: lane l's class and term through v_readlane (uniform) -- a __shfl per element (ds_bpermute: an
+    // LDS round trip) made this kernel 16 ms of a 48-bin call's critical path
     const int tlo = (int)(__builtin_bit_cast(unsigned long long, term) & 0xffffffffull), thi = (int)(__builtin_bit_cast(unsigned long long, term) >> 32);
 #pragma unroll
     for (int l = 0; l < 64; ++l) {
+      // lane k keeps class k's sum: every lane adds node l's term if its number is node l's class, +0.0 otherwise.  Vector instructions
+      // only -- three v_readlane, a compare, two selects, one add: with the selects on the scalar unit (s_cmp / s_cselect between the
+      // v_readlane and the v_add_f64) a node cost 200 cycles, the two units waiting on each other's registers
       const int c = __builtin_amdgcn_readlane(cls, l);
       const double v = __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(thi, l) << 32) | (unsigned)__builtin_amdgcn_readlane(tlo, l));
-      if (c == 0) acc0 += v; else if (c == 1) acc1 += v; else if (c == 2) acc2 += v;
+      acc += lane == c ? v : 0.0;
     }
+    cls = ncls; term = nterm;
   }
+  const int alo = (int)(__builtin_bit_cast(unsigned long long, acc) & 0xffffffffull), ahi = (int)(__builtin_bit_cast(unsigned long long, acc) >> 32);
+  auto sum_of = [&](int k) { return __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ahi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(alo, k)); };
+  double acc0 = sum_of(0), acc1 = sum_of(1), acc2 = sum_of(2);
   if (lane == 0) {
     const double tot = acc0 + acc1 + acc2;
     acc0 *= (3.0 / tot); acc1 *= (3.0 / tot); acc2 *= (3.0 / tot);
