@@ -664,20 +664,53 @@ template <int FLAG>
 __device__ __forceinline__ void dp_resolve(const Nodes &nd, DpRing &ring, DpBlock &blk, uint32_t first, double st_wt, int i0, int cnt, int lane) {
   const int par = (i0 / DPB) & 1;
   const DpSrc<FLAG> S{nd, ring, first, dp_ring_lo(i0), i0 + cnt, 0x7fffffff};
-  const DpRingSrc<FLAG> R{S, -1, DpRec{0, 0, 0, 0}};
   const bool in = lane < cnt;
   const int i = i0 + (in ? lane : 0);
   const int k = dp_slot(i);
   const DpRec qi = ring.rec[k];
   DpNode n2; n2.ndx = qi.ndx; n2.sv = qi.sv; n2.strand = (qi.pk & 2) ? -1 : 1; n2.stop = qi.pk & 1;
   const int c2 = dp_class(n2.strand, n2.stop);
+  // The pairs left to this loop are forward stop t -> reverse node behind it (dp_pair_dynamic: they read WHERE t's predecessor lies).
+  // score_connection's two cases for them, with everything that does not depend on t read BEFORE the chain of 64 dependent steps begins
+  // -- the node's own value; a reverse stop's three overlapping starts with their positions and their value (+ intergenic term in the
+  // final sweep) -- so that a step is registers and integer compares: through the general connection function a forward stop's step was
+  // a dozen dependent LDS reads.  Same integer expressions and the same floating-point operations in the same order.
+  // Measured with the cycle counter around the phases (48 bins): this wavefront's 64 steps ARE phase P (99 % of it; the scoring
+  // wavefronts are busy for 75 % of P), a thousand cycles per step -- and neither the reads taken out of the chain here (62.3 -> 60 ms) nor
+  // a raised wave priority (no change) moves that much: a step is 50 - 290 instructions of masked double-precision compares and selects,
+  // issued one dependent instruction at a time.
+  const double my_val = ring.sv2[k].y;
+  int s_ok[3] = {0, 0, 0}, s_ndx[3] = {0, 0, 0}, s_sv[3] = {0, 0, 0}; double s_w[3] = {0.0, 0.0, 0.0};
+  if (in && c2 == 3) {
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+      const int p3 = S.star(i, f);
+      if (p3 == -1) continue;
+      const DpNode n3 = S.node(p3);
+      s_ok[f] = 1; s_ndx[f] = n3.ndx; s_sv[f] = n3.sv;
+      s_w[f] = FLAG == 1 ? S.val(p3) + dp_igm(S, st_wt, p3, n3, i, n2) : S.val(p3);
+    }
+  }
   double best = in ? blk.best1[par][lane] : -1.0; int key0 = in ? blk.key1[par][lane] : -1;
   if (in) dp_merge(best, key0, blk.best2[lane], blk.key2[lane]);
   int bj = key0 < 0 ? -1 : key0 >> 2, bmark = key0 < 0 ? -1 : (key0 & 3) - 1;
-  for (int t = 0; t < cnt; ++t) {
+  // Nothing a step needs may be a memory round trip away (under fifteen scoring wavefronts an LDS read comes back after hundreds of
+  // cycles, and the steps are a chain): the position of every lane's current predecessor rides in a register beside its index, and the
+  // table column of this lane is read eight rows ahead.
+  int bjx = in && bj >= 0 ? S.ndx(bj) : 0;
+  for (int t0 = 0; t0 < cnt; t0 += 8) {
+   double tabv[8];
+#pragma unroll
+   for (int u = 0; u < 8; ++u) tabv[u] = blk.table[dp_tab(t0 + u, lane)];                // (rows of this block's table: written in the phase before)
+#pragma unroll
+   for (int u = 0; u < 8; ++u) {
+    const int t = t0 + u;
+    if (t >= cnt) break;
     // node i0 + t is final: every lane learns it, its own lane publishes it to the ring
     const double bt = dp_mk64(__builtin_amdgcn_readlane(dp_lo32(best), t), __builtin_amdgcn_readlane(dp_hi32(best), t));
     const int jt = __builtin_amdgcn_readlane(bj, t), c1 = __builtin_amdgcn_readlane(c2, t);
+    const int t_ndx = __builtin_amdgcn_readlane(n2.ndx, t);
+    const int t_tbx = __builtin_amdgcn_readlane(bjx, t);                 // position of t's predecessor (meaningful when jt >= 0)
     if (lane == t && bj >= 0) {
       ring.sv2[k].x = best;
       const uint32_t d = i - bj < DP_FAR ? (uint32_t)(i - bj) : (uint32_t)DP_FAR;
@@ -688,12 +721,45 @@ __device__ __forceinline__ void dp_resolve(const Nodes &nd, DpRing &ring, DpBloc
     if (dp_class_needs_tb(c1) && jt < 0) continue;
     const double sc_t = jt >= 0 ? bt : 0.0;
     if (in && lane > t) {
-      dp_take(sc_t + blk.table[dp_tab(t, lane)], i0 + t, -1, best, bj, bmark);
-      if (dp_pair_dynamic(c1, c2)) {
-        double tot; int mark;
-        if (dp_connection_x<DpRingSrc<FLAG>, true, 1, true>(R, st_wt, i0 + t, i, n2, tot, mark)) dp_take(tot, i0 + t, mark, best, bj, bmark);
+      dp_take(sc_t + tabv[u], i0 + t, -1, best, bj, bmark);
+      if (c1 == 1 && c2 >= 2) {                                     // dp_pair_dynamic; jt >= 0 here (a forward stop without a predecessor was skipped above)
+        const int n1x = t_ndx, tbx = t_tbx;                          // position of t, position of t's predecessor (uniform)
+        if (c2 == 2) {                                               // forward stop -> reverse start: the genes may overlap by less than 200 bases
+          bool ok = !(n2.sv - 2 >= n1x + 2);
+          const int ovlp = (n1x + 2) - (n2.sv - 2) + 1;
+          if (ovlp >= 200) ok = false;
+          if ((n1x + 2 - n2.sv - 2 + 1) >= (n2.ndx - n1x + 3 + 1)) ok = false;
+          if ((n1x + 2 - n2.sv - 2 + 1) >= (n2.sv - 3 - tbx + 1)) ok = false;
+          if (ok) {
+            const int left = n2.sv - 2, right = n2.ndx;
+            double score;
+            if (FLAG == 0) score = ((double)(right - left + 1 - (ovlp * 2))) * my_val; else score = my_val - 0.15 * st_wt;
+            dp_take(sc_t + score, i0 + t, -1, best, bj, bmark);
+          }
+        } else {                                                     // forward stop -> reverse stop: through the best overlapping start, if one fits
+          const int left = n1x + 2, right = n2.ndx - 2;
+          if (left < right) {
+            double maxval = 0.0; int best_ov = 0, maxfr = -1;
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+              if (!s_ok[f]) continue;
+              const int ov = left - s_sv[f] + 1;
+              if (ov <= 0 || ov >= 200) continue;
+              if (ov >= s_ndx[f] - left) continue;
+              if (ov >= s_sv[f] - tbx - 2) continue;
+              if (s_w[f] > maxval) { maxfr = f; maxval = s_w[f]; best_ov = ov; }
+            }
+            double score = 0.0, scr_mod = 0.0; int ovlp = 0;
+            if (maxfr != -1) { ovlp = best_ov; if (FLAG == 0) scr_mod = maxval; else score = maxval; }
+            else if (FLAG == 1) { double rval = 0.0; rval -= 0.15 * st_wt; score = rval; }        // (dp_igm of two strands: that alone)
+            if (FLAG == 0) score = ((double)(right - left + 1 - (ovlp * 2))) * scr_mod;
+            dp_take(sc_t + score, i0 + t, maxfr, best, bj, bmark);
+          }
+        }
       }
+      if (bj == i0 + t) bjx = t_ndx;                                 // (t became this lane's predecessor in this step)
     }
+   }
   }
 }
 
