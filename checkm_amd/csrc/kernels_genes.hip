@@ -720,44 +720,41 @@ __device__ __forceinline__ void dp_resolve(const Nodes &nd, DpRing &ring, DpBloc
     }
     if (dp_class_needs_tb(c1) && jt < 0) continue;
     const double sc_t = jt >= 0 ? bt : 0.0;
-    if (in && lane > t) {
-      dp_take(sc_t + tabv[u], i0 + t, -1, best, bj, bmark);
-      if (c1 == 1 && c2 >= 2) {                                     // dp_pair_dynamic; jt >= 0 here (a forward stop without a predecessor was skipped above)
-        const int n1x = t_ndx, tbx = t_tbx;                          // position of t, position of t's predecessor (uniform)
-        if (c2 == 2) {                                               // forward stop -> reverse start: the genes may overlap by less than 200 bases
-          bool ok = !(n2.sv - 2 >= n1x + 2);
-          const int ovlp = (n1x + 2) - (n2.sv - 2) + 1;
-          if (ovlp >= 200) ok = false;
-          if ((n1x + 2 - n2.sv - 2 + 1) >= (n2.ndx - n1x + 3 + 1)) ok = false;
-          if ((n1x + 2 - n2.sv - 2 + 1) >= (n2.sv - 3 - tbx + 1)) ok = false;
-          if (ok) {
-            const int left = n2.sv - 2, right = n2.ndx;
-            double score;
-            if (FLAG == 0) score = ((double)(right - left + 1 - (ovlp * 2))) * my_val; else score = my_val - 0.15 * st_wt;
-            dp_take(sc_t + score, i0 + t, -1, best, bj, bmark);
-          }
-        } else {                                                     // forward stop -> reverse stop: through the best overlapping start, if one fits
-          const int left = n1x + 2, right = n2.ndx - 2;
-          if (left < right) {
-            double maxval = 0.0; int best_ov = 0, maxfr = -1;
+    // One offer per step and lane, without a divergent branch (a masked `if` is a compare, a save of the execution mask, a branch and a
+    // restore, each waiting for the one before): the table's connection -- or, where t is a forward stop and this lane a reverse node
+    // (dp_pair_dynamic; the table holds -inf there, which no offer takes), the connection worked out here.  jt >= 0 in that case (a forward
+    // stop without a predecessor was skipped above).
+    double offer = sc_t + tabv[u]; int omark = -1; bool ok = in & (lane > t);
+    if (c1 == 1) {                                                   // (uniform)
+      const int n1x = t_ndx, tbx = t_tbx;                            // position of t, position of t's predecessor
+      // forward stop -> reverse start: the genes may overlap by less than 200 bases
+      const int ovlp2 = (n1x + 2) - (n2.sv - 2) + 1;
+      const bool ok2 = !(n2.sv - 2 >= n1x + 2) & !(ovlp2 >= 200) & !((n1x + 2 - n2.sv - 2 + 1) >= (n2.ndx - n1x + 3 + 1)) & !((n1x + 2 - n2.sv - 2 + 1) >= (n2.sv - 3 - tbx + 1));
+      const int left2 = n2.sv - 2, right2 = n2.ndx;
+      const double score2 = FLAG == 0 ? ((double)(right2 - left2 + 1 - (ovlp2 * 2))) * my_val : my_val - 0.15 * st_wt;
+      // forward stop -> reverse stop: through the best overlapping start, if one fits
+      const int left = n1x + 2, right = n2.ndx - 2;
+      double maxval = 0.0; int best_ov = 0, maxfr = -1;
 #pragma unroll
-            for (int f = 0; f < 3; ++f) {
-              if (!s_ok[f]) continue;
-              const int ov = left - s_sv[f] + 1;
-              if (ov <= 0 || ov >= 200) continue;
-              if (ov >= s_ndx[f] - left) continue;
-              if (ov >= s_sv[f] - tbx - 2) continue;
-              if (s_w[f] > maxval) { maxfr = f; maxval = s_w[f]; best_ov = ov; }
-            }
-            double score = 0.0, scr_mod = 0.0; int ovlp = 0;
-            if (maxfr != -1) { ovlp = best_ov; if (FLAG == 0) scr_mod = maxval; else score = maxval; }
-            else if (FLAG == 1) { double rval = 0.0; rval -= 0.15 * st_wt; score = rval; }        // (dp_igm of two strands: that alone)
-            if (FLAG == 0) score = ((double)(right - left + 1 - (ovlp * 2))) * scr_mod;
-            dp_take(sc_t + score, i0 + t, maxfr, best, bj, bmark);
-          }
-        }
+      for (int f = 0; f < 3; ++f) {
+        const int ov = left - s_sv[f] + 1;
+        const bool fits = (s_ok[f] != 0) & !(ov <= 0 || ov >= 200) & !(ov >= s_ndx[f] - left) & !(ov >= s_sv[f] - tbx - 2) & (s_w[f] > maxval);
+        maxfr = fits ? f : maxfr; maxval = fits ? s_w[f] : maxval; best_ov = fits ? ov : best_ov;
       }
-      if (bj == i0 + t) bjx = t_ndx;                                 // (t became this lane's predecessor in this step)
+      double score3, scr_mod = 0.0; int ovlp3 = 0;
+      { double rval = 0.0; rval -= 0.15 * st_wt; score3 = FLAG == 1 ? rval : 0.0; }        // (no start fits: dp_igm of two strands -- that alone -- in the final sweep)
+      if (FLAG == 0) scr_mod = maxfr != -1 ? maxval : 0.0; else score3 = maxfr != -1 ? maxval : score3;
+      ovlp3 = maxfr != -1 ? best_ov : 0;
+      if (FLAG == 0) score3 = ((double)(right - left + 1 - (ovlp3 * 2))) * scr_mod;
+      const bool dyn = c2 >= 2;
+      offer = dyn ? sc_t + (c2 == 2 ? score2 : score3) : offer;
+      omark = (dyn & (c2 == 3)) ? maxfr : -1;
+      ok = ok & (!dyn | (c2 == 2 ? ok2 : left < right));
+    }
+    {
+      const int j = i0 + t;
+      const bool take = ok & (offer >= 0.0) & ((bj < 0) | (offer > best) | ((offer == best) & (j > bj)));        // dp_take, every term evaluated
+      best = take ? offer : best; bj = take ? j : bj; bmark = take ? omark : bmark; bjx = take ? t_ndx : bjx;
     }
    }
   }
