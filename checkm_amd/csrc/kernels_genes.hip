@@ -696,16 +696,14 @@ __device__ __forceinline__ void dp_resolve(const Nodes &nd, DpRing &ring, DpBloc
   int bj = key0 < 0 ? -1 : key0 >> 2, bmark = key0 < 0 ? -1 : (key0 & 3) - 1;
   // Nothing a step needs may be a memory round trip away (under fifteen scoring wavefronts an LDS read comes back after hundreds of
   // cycles, and the steps are a chain): the position of every lane's current predecessor rides in a register beside its index, and the
-  // table column of this lane is read eight rows ahead.
+  // table column of this lane is read three rows ahead.
   int bjx = in && bj >= 0 ? S.ndx(bj) : 0;
-  for (int t0 = 0; t0 < cnt; t0 += 8) {
-   double tabv[8];
-#pragma unroll
-   for (int u = 0; u < 8; ++u) tabv[u] = blk.table[dp_tab(t0 + u, lane)];                // (rows of this block's table: written in the phase before)
-#pragma unroll
-   for (int u = 0; u < 8; ++u) {
-    const int t = t0 + u;
-    if (t >= cnt) break;
+  double tab0 = blk.table[dp_tab(0, lane)], tab1 = blk.table[dp_tab(1, lane)], tab2 = blk.table[dp_tab(2, lane)];       // (rows of this block's table: written in the phase before)
+#pragma unroll 1
+  for (int t = 0; t < cnt; ++t) {
+   {
+    const double tab_t = tab0;
+    tab0 = tab1; tab1 = tab2; tab2 = blk.table[dp_tab((t + 3) & (DPB - 1), lane)];       // three rows ahead (a rolled loop: unrolled eight times the 64 steps were 14 KB of code)
     // node i0 + t is final: every lane learns it, its own lane publishes it to the ring
     const double bt = dp_mk64(__builtin_amdgcn_readlane(dp_lo32(best), t), __builtin_amdgcn_readlane(dp_hi32(best), t));
     const int jt = __builtin_amdgcn_readlane(bj, t), c1 = __builtin_amdgcn_readlane(c2, t);
@@ -724,7 +722,7 @@ __device__ __forceinline__ void dp_resolve(const Nodes &nd, DpRing &ring, DpBloc
     // restore, each waiting for the one before): the table's connection -- or, where t is a forward stop and this lane a reverse node
     // (dp_pair_dynamic; the table holds -inf there, which no offer takes), the connection worked out here.  jt >= 0 in that case (a forward
     // stop without a predecessor was skipped above).
-    double offer = sc_t + tabv[u]; int omark = -1; bool ok = in & (lane > t);
+    double offer = sc_t + tab_t; int omark = -1; bool ok = in & (lane > t);
     if (c1 == 1) {                                                   // (uniform)
       const int n1x = t_ndx, tbx = t_tbx;                            // position of t, position of t's predecessor
       // forward stop -> reverse start: the genes may overlap by less than 200 bases
