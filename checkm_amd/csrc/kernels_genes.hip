@@ -810,7 +810,7 @@ __global__ void __launch_bounds__(DP_NT) gene_dp_kernel(Nodes nd, const uint32_t
       } else if (wv == 1) {
         if (i1 + DPB < nn) dp_enter<FLAG>(nd, ring, blk, ring_tot, first, nn, i1 + DPB, lane);
       }
-      if (wv >= 1) {          // (the enterer joins the scorers when it is done; the resolver does not: it is the longer of the two)
+      {          // (the resolver and the enterer join the scorers when they are done)
         if (cnt1) dp_candidates<FLAG, 1>(nd, ring, blk, ring_tot, first, st_wt, i1, cnt1, lane);
       }
       __syncthreads();
