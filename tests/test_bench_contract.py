@@ -1,5 +1,5 @@
 """The bench line's contract, checked without a GPU: the flags the driver passes parse, and the line recorded by the round's driver-shaped
-run (profiles/r06z_bench_driver_shaped_line.json = `python bench.py --gpus 1 --steps 20 --warmup 5` on one MI355X) carries every field the contract
+run (profiles/r06A_bench_driver_shaped_line.json = `python bench.py --gpus 1 --steps 20 --warmup 5` on one MI355X) carries every field the contract
 names, with figures that agree with each other."""
 import json
 import os
@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINE = os.path.join(ROOT, "profiles", "r06z_bench_driver_shaped_line.json")
+LINE = os.path.join(ROOT, "profiles", "r06A_bench_driver_shaped_line.json")
 
 
 def test_driver_flags_parse():
